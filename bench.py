@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: train iterations/sec (forward + backward of one view per GPU per step)
+of the differentiable Gaussian-splat rasterizer + fused multi-scale bilateral-grid colour transform.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric): 2 M Gaussians, 6-camera ring at 1920x1080, SH degree 3, 3-level
+bilateral grid; synthetic scene of SURVEY.md 8(d); one step = SH -> projection -> tile intersection +
+ordering -> alpha compositing (RGB + expected depth) -> clamp + sky blend + bilateral slice + affine ->
+L1 + TV loss -> full backward (-> one all-reduce of the flat per-Gaussian gradients when N > 1).
+At N ranks, rank r renders view (step*N + r) mod 6 ("weak" scaling: one view per GPU per step);
+value = views processed by all ranks per second.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the launch stream inside the timed region) and `cpu_baseline` (the oracle/ port of
+the same pipeline on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=2_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-gaussians", type=int, default=100000)
+    ap.add_argument("--cpu-sample-width", type=int, default=960)
+    ap.add_argument("--cpu-sample-height", type=int, default=540)
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """oracle/ (pure-PyTorch port of the same pipeline) on the host cores, bounded sample."""
+    from bilateral_driving_amd import harness as Hn
+    from oracle import bilagrid_oracle as BO
+    from oracle import gs_oracle as G
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    N, W, H = args.cpu_sample_gaussians, args.cpu_sample_width, args.cpu_sample_height
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,))[0]
+    p = Hn.synthetic_scene(N, seed=0)
+    grids = Hn.make_grids(1)
+    gen = torch.Generator().manual_seed(3)
+    sky = torch.rand(H, W, 3, generator=gen)
+    target = torch.rand(H, W, 3, generator=gen)
+
+    def one():
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        g = [x.clone().requires_grad_(True) for x in grids]
+        dirs = q["means"].detach() - torch.linalg.inv(cam.viewmat)[:3, 3]
+        col = torch.clamp(G.spherical_harmonics(3, dirs, q["sh"]) + 0.5, 0.0, 1.0)
+        r, a, _ = G.rasterization(q["means"], q["quats"] / q["quats"].norm(dim=-1, keepdim=True), torch.exp(q["log_scales"]),
+                                  torch.sigmoid(q["opacity_logits"]), col, cam.viewmat[None], cam.K[None], W, H,
+                                  near_plane=0.1, render_mode="RGB+ED")
+        rgb = BO.multiscale_transform([x[0] for x in g], BO.sky_blend(r[0, ..., :3], a[0], sky), list(Hn.FACTORS_3))
+        loss = (rgb - target).abs().mean() + 0.01 * BO.multiscale_tv(g)
+        loss.backward()
+
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    reps = 1
+    if dt < 8.0:  # aim at ~10-30 s of CPU work in total
+        reps = max(1, min(5, int(16.0 / max(dt, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one()
+        dt = (time.perf_counter() - t0) / reps
+    return {
+        "value": 1.0 / dt, "unit": "iters/sec", "cores": cores, "kind": "port",
+        "sample": f"{N} Gaussians, one {W}x{H} view, SH3 + 3-level bilateral grid, fwd+bwd, fp32 torch CPU oracle, "
+                  f"{reps} rep(s); NOT the GPU workload size",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path in the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
+
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients, view_for_rank
+
+    L.lib()  # fail loudly if libbds.so is missing
+    N, W, H = args.gaussians, args.width, args.height
+    cams = Hn.ring_cameras(W, H, device=dev)
+    params = Hn.synthetic_scene(N, seed=0, device=dev)
+    for v in params.values():
+        v.requires_grad_(True)
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), device=dev)]
+    gen = torch.Generator().manual_seed(7)
+    skies = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    flat = FlatGradients(list(params.values()) + grids)
+
+    stats = {}
+
+    def step(s):
+        v = view_for_rank(s, rank, world, len(cams))
+        flat.zero()
+        out = Hn.render_view(params, cams[v], grids, v, skies[v])
+        loss = Hn.training_loss(out, targets[v], grids)
+        loss.backward()
+        flat.all_reduce()
+        info = out["info"]
+        stats["M"] = info["flatten_ids"].numel()
+        stats["n_visible"] = info["radii"]
+        stats["last_ids"] = None
+        return loss
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.enable_timers(True)
+    t0 = time.perf_counter()
+    Ms = []
+    for s in range(args.warmup, args.warmup + args.steps):
+        step(s)
+        Ms.append(stats["M"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tsum = L.timer_summary()
+    L.enable_timers(False)
+    n_vis = int((stats["n_visible"] > 0).sum())
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    # roofline of the dominant kernel: composite backward (K8).  Algorithmic bytes per launch
+    # (SURVEY.md 8d): 44 B/isect read + 28 B/pixel read + 48 B/isect gradient write.
+    M_mean = sum(Ms) / len(Ms)
+    dom = "rasterize_bwd"
+    calls, mean_ms = tsum.get(dom, (0, float("nan")))
+    alg_bytes = 92.0 * M_mean + 28.0 * W * H
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if calls else float("nan")
+    roofline = {"bound": "hbm", "kernel": "rasterize_bwd_kernel<4,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": mean_ms,
+                "note": "K7/K8 are VALU-bound on algorithmic bytes (SURVEY.md 7, hard part 2); see per_kernel_ms"}
+
+    result = {
+        "metric": "train iters/sec (fwd+bwd) at 2M Gaussians, 6x1920x1080; HBM roofline %",
+        "value": value, "unit": "iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{N} Gaussians, 6-cam ring {W}x{H}, SH deg 3, RGB+ED, 3-level bilateral grid "
+                               f"[[2,2,1],[4,4,2],[8,8,4]] factors [4,4,2], L1+TV loss, one view per GPU per step",
+                   "gaussians": N, "width": W, "height": H, "views": len(cams), "n_visible_last": n_vis,
+                   "isects_mean": M_mean, "parallelism": f"view-dp{world}",
+                   "allreduce_bytes": flat.nbytes if world > 1 else 0},
+        "roofline": roofline,
+        "per_kernel_ms": {k: round(v[1], 4) for k, v in sorted(tsum.items())},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+"""ctypes binding of libbds.so (include/bds.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbds.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+_f = C.c_void_p  # every device pointer is passed as an integer address
+_i, _i64, _sz, _fl = C.c_int, C.c_int64, C.c_size_t, C.c_float
+
+
+class BdsLevel(C.Structure):
+    """bds_bilagrid_level_t"""
+
+    _fields_ = [("grid", C.c_void_p), ("v_grid", C.c_void_p), ("gx", C.c_int32), ("gy", C.c_int32), ("gl", C.c_int32),
+                ("factor", C.c_int32), ("n_avg", C.c_int32)]
+
+
+_SIGS = {
+    "bds_abi_version": (C.c_int, []),
+    "bds_strerror": (C.c_char_p, [_i]),
+    "bds_sh_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f]),
+    "bds_sh_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_project_fwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f]),
+    "bds_project_bwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_isect_prepare_workspace_bytes": (_sz, [_i, _i64]),
+    "bds_isect_build_workspace_bytes": (_sz, [_i, _i64, _i64]),
+    "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), _f]),
+    "bds_isect_build": (_i, [_i, _i64, _i64, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f]),
+    "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
+                               _f, _f, _f, _f]),
+    "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
+    "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
+    "bds_bilagrid_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, C.POINTER(C.c_void_p), _f]),
+    "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
+    "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),
+    "bds_bilagrid_tv_bwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f, _f]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class BdsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libbds.so once.  Raises (never falls back) when it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise BdsError(
+                f"{LIB_PATH} is missing: build it with `python -m bilateral_driving_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.bds_abi_version() != ABI_VERSION:
+            raise BdsError(f"libbds.so ABI {handle.bds_abi_version()} != expected {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise BdsError(f"{what} failed: {lib().bds_strerror(code).decode()} (code {code})")
+
+
+def ptr(t):
+    """Device address of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libbds.so takes contiguous tensors"
+    return t.data_ptr()
+
+
+def stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise BdsError(
+                "bilateral_driving_amd runs on MI355X only (tensor on %s); there is no CPU path "
+                "in the product -- the CPU restatement lives in oracle/ and is test infrastructure" % t.device
+            )
+
+
+# ----------------------------------------------------------------------------------------------
+# optional per-call device timing (bench.py): HIP events on the stream the kernels are launched on
+# ----------------------------------------------------------------------------------------------
+import contextlib
+
+TIMERS = None  # dict name -> list[(start_event, end_event)] when enabled
+
+
+def enable_timers(on: bool = True) -> None:
+    global TIMERS
+    TIMERS = {} if on else None
+
+
+@contextlib.contextmanager
+def timed(name: str):
+    if TIMERS is None:
+        yield
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(torch.cuda.current_stream())
+    try:
+        yield
+    finally:
+        e.record(torch.cuda.current_stream())
+        TIMERS.setdefault(name, []).append((s, e))
+
+
+def timer_summary() -> dict:
+    """name -> (calls, mean ms); call after torch.cuda.synchronize()."""
+    out = {}
+    for k, evs in (TIMERS or {}).items():
+        ms = [s.elapsed_time(e) for s, e in evs]
+        out[k] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out

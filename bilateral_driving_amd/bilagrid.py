@@ -1,0 +1,273 @@
+"""Bilateral-grid half of the hot path, bound to libbds.so.
+
+Mirrors the reference's ``bilateral.lib_bilagrid`` surface (same class / function names, argument
+meaning, parameter name ``grids`` and layout [num, 12, L, H, W], error behaviour) so that
+/root/reference/project/models/modules.py:13 resolves unmodified against
+``bilateral_driving_amd/dropin``:
+
+    BilateralGrid, slice, total_variation_loss, color_affine_transform
+    (/root/reference/project/bilateral/lib_bilagrid.py:131-145,152-168,171-230,256-368)
+
+plus the fused image transform the reference spreads over ~30 torch launches per level
+(models/modules.py:494-522,409-420 + trainers/scene_graph.py:112-117):
+
+    bilagrid_transform(rgb, grids, factors, ...) -> rgb_out [, per-level affine maps]
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def color_affine_transform(affine_mats: Tensor, rgb: Tensor) -> Tensor:
+    """affine_mats [..., 3, 4], rgb [..., 3] -> [..., 3]."""
+    return torch.matmul(affine_mats[..., :3], rgb.unsqueeze(-1)).squeeze(-1) + affine_mats[..., 3]
+
+
+# --------------------------------------------------------------------------------------------
+# TV regulariser
+# --------------------------------------------------------------------------------------------
+class _TotalVariation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: float):
+        L.require_gpu(x)
+        x = _f32c(x)
+        n, c, gl, gy, gx = x.shape
+        assert c == 12
+        out = torch.zeros(1, device=x.device, dtype=torch.float32)
+        L.check(L.lib().bds_bilagrid_tv_fwd(n, gx, gy, gl, L.ptr(x), weight, L.ptr(out), L.stream()), "bds_bilagrid_tv_fwd")
+        ctx.save_for_backward(x)
+        ctx.weight = weight
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, v_out):
+        (x,) = ctx.saved_tensors
+        n, _, gl, gy, gx = x.shape
+        v = _f32c(v_out.reshape(1))
+        v_x = torch.zeros_like(x)
+        L.check(L.lib().bds_bilagrid_tv_bwd(n, gx, gy, gl, L.ptr(x), ctx.weight, L.ptr(v), L.ptr(v_x), L.stream()),
+                "bds_bilagrid_tv_bwd")
+        return v_x, None
+
+
+def total_variation_loss(x: Tensor, weight: float = 1.0) -> Tensor:
+    """Total variation of bilateral grids x [B, 12, L, H, W] (lib_bilagrid.py:152-168), times ``weight``."""
+    if x.dim() != 5 or x.shape[1] != 12:
+        raise ValueError("total_variation_loss expects bilateral grids of shape (B, 12, L, H, W)")
+    return _TotalVariation.apply(x, float(weight))
+
+
+# --------------------------------------------------------------------------------------------
+# point slice (BilateralGrid.forward)
+# --------------------------------------------------------------------------------------------
+class _SlicePoints(torch.autograd.Function):
+    """grid [12,L,gy,gx], xy [P,2], rgb [P,3] -> affine [P,12]"""
+
+    @staticmethod
+    def forward(ctx, grid: Tensor, xy: Tensor, rgb: Tensor):
+        L.require_gpu(grid, xy, rgb)
+        grid, xy, rgb = _f32c(grid), _f32c(xy), _f32c(rgb)
+        P = xy.shape[0]
+        _, gl, gy, gx = grid.shape
+        aff = torch.empty(P, 12, device=grid.device, dtype=torch.float32)
+        L.check(L.lib().bds_bilagrid_slice_fwd(P, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(aff), L.stream()),
+                "bds_bilagrid_slice_fwd")
+        ctx.save_for_backward(grid, xy, rgb)
+        return aff
+
+    @staticmethod
+    def backward(ctx, v_aff):
+        grid, xy, rgb = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradient w.r.t. the slice xy coordinates is not on the reference's path "
+                                      "(they come from linspace / pixel indices)")
+        P = xy.shape[0]
+        _, gl, gy, gx = grid.shape
+        v_aff = _f32c(v_aff)
+        v_grid = torch.zeros_like(grid) if ctx.needs_input_grad[0] else None
+        v_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[2] else None
+        L.check(L.lib().bds_bilagrid_slice_bwd(P, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(v_aff), L.ptr(v_grid),
+                                               L.ptr(v_rgb), L.stream()), "bds_bilagrid_slice_bwd")
+        return v_grid, None, v_rgb
+
+
+class BilateralGrid(nn.Module):
+    """Holds ``num`` bilateral grids [num, 12, L, H, W], identity-initialised (lib_bilagrid.py:256-311)."""
+
+    def __init__(self, num, grid_X=16, grid_Y=16, grid_W=8, mode="bilinear"):
+        super().__init__()
+        if mode != "bilinear":
+            raise NotImplementedError("only mode='bilinear' (the reference's only value, modules.py:434-444)")
+        self.grid_width = grid_X
+        self.grid_height = grid_Y
+        self.grid_guidance = grid_W
+        self.mode = mode
+        ident = torch.tensor([1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0], dtype=torch.float32)
+        grid = ident.reshape(1, 12, 1, 1, 1).repeat(num, 1, grid_W, grid_Y, grid_X)
+        self.grids = nn.Parameter(grid.contiguous())
+        self.register_buffer("rgb2gray_weight", torch.tensor([[0.299, 0.587, 0.114]], dtype=torch.float32))
+
+    def tv_loss(self):
+        return total_variation_loss(self.grids)
+
+    def forward(self, grid_xy: Tensor, rgb: Tensor, idx: Optional[Tensor] = None) -> Tensor:
+        """grid_xy [..., 2] in [0,1], rgb [..., 3]; 2-D..4-D inputs need ``idx`` ([B] grid indices, one per
+        leading-batch entry); 5-D inputs use one grid per leading entry.  Returns [..., 3, 4]."""
+        nd = grid_xy.dim()
+        assert rgb.dim() == nd
+        if not (1 < nd <= 5):
+            raise ValueError("Bilateral grid slicing only takes either 2D, 3D, 4D and 5D inputs")
+        if nd < 5:
+            assert idx is not None
+        B = grid_xy.shape[0]
+        if idx is None:
+            assert self.grids.shape[0] == B
+            sel = range(B)
+        else:
+            idx = idx.reshape(-1)
+            assert idx.numel() == B, (idx.shape, B)
+            sel = idx.tolist()
+        per = grid_xy[0].numel() // 2
+        flat_xy = grid_xy.reshape(B, per, 2)
+        flat_rgb = rgb.reshape(B, per, 3)
+        # one launch per distinct grid: batch entries using the same grid are sliced together
+        groups = {}
+        for b, g in enumerate(sel):
+            groups.setdefault(int(g), []).append(b)
+        if len(groups) == 1:
+            (g, _), = groups.items()
+            out = _SlicePoints.apply(self.grids[g], flat_xy.reshape(-1, 2), flat_rgb.reshape(-1, 3))
+        else:
+            out = torch.zeros(B, per, 12, device=rgb.device, dtype=torch.float32)
+            for g, bs in groups.items():
+                bsel = torch.tensor(bs, device=rgb.device)
+                a = _SlicePoints.apply(self.grids[g], flat_xy[bsel].reshape(-1, 2), flat_rgb[bsel].reshape(-1, 3))
+                out = out.index_add(0, bsel, a.reshape(len(bs), per, 12))
+        return out.reshape(*grid_xy.shape[:-1], 3, 4)
+
+
+def slice(bil_grids: BilateralGrid, xy: Tensor, rgb: Tensor, grid_idx: Tensor):
+    """lib_bilagrid.py:171-230: returns {"rgb", "rgb_affine_mats"}."""
+    sh_ = rgb.shape
+    grid_idx_unique = torch.unique(grid_idx)
+    if len(grid_idx_unique) == 1:
+        grid_idx = grid_idx_unique
+        xy = xy.unsqueeze(0)
+        rgb = rgb.unsqueeze(0)
+    else:
+        if grid_idx.dim() == 4:
+            grid_idx = grid_idx[:, 0, 0, 0]
+        elif grid_idx.dim() == 3:
+            grid_idx = grid_idx[:, 0, 0]
+        elif grid_idx.dim() == 2:
+            grid_idx = grid_idx[:, 0]
+        else:
+            raise ValueError("The input to bilateral grid slicing is not supported yet.")
+    affine_mats = bil_grids(xy, rgb, grid_idx)
+    out = color_affine_transform(affine_mats, rgb)
+    return {
+        "rgb": out.reshape(*sh_),
+        "rgb_affine_mats": affine_mats.reshape(*sh_[:-1], affine_mats.shape[-2], affine_mats.shape[-1]),
+    }
+
+
+# --------------------------------------------------------------------------------------------
+# fused image transform
+# --------------------------------------------------------------------------------------------
+def _levels_struct(grids: Sequence[Tensor], v_grids, factors: Sequence[int]):
+    n = len(grids)
+    arr = (L.BdsLevel * n)()
+    for i, (g, f) in enumerate(zip(grids, factors)):
+        n_avg, c, gl, gy, gx = g.shape
+        assert c == 12
+        arr[i].grid = g.data_ptr()
+        arr[i].v_grid = v_grids[i].data_ptr() if v_grids is not None and v_grids[i] is not None else None
+        arr[i].gx, arr[i].gy, arr[i].gl, arr[i].factor, arr[i].n_avg = gx, gy, gl, int(f), n_avg
+    return arr
+
+
+class _BilagridTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, alpha, sky, factors, want_maps, *grids):
+        L.require_gpu(rgb, alpha, sky, *grids)
+        rgb, alpha, sky = _f32c(rgb), _f32c(alpha), _f32c(sky)
+        grids = [_f32c(g) for g in grids]
+        H, W, _ = rgb.shape
+        n = len(grids)
+        lib = L.lib()
+        lv = _levels_struct(grids, None, factors)
+        ws_bytes = lib.bds_bilagrid_ms_workspace_bytes(n, lv, H, W)
+        if ws_bytes == 0:
+            raise L.BdsError("bds_bilagrid_ms_workspace_bytes rejected the level configuration")
+        ws = torch.empty(ws_bytes, device=rgb.device, dtype=torch.uint8)
+        out = torch.empty(H, W, 3, device=rgb.device, dtype=torch.float32)
+        maps = [torch.empty(H, W, 12, device=rgb.device, dtype=torch.float32) for _ in range(n)] if want_maps else []
+        maps_arr = (C.c_void_p * n)(*[m.data_ptr() for m in maps]) if want_maps else None
+        with L.timed("bilagrid_fwd"):
+            L.check(lib.bds_bilagrid_ms_fwd(n, lv, H, W, L.ptr(rgb), L.ptr(alpha), L.ptr(sky), L.ptr(ws), ws_bytes, L.ptr(out),
+                                            maps_arr, L.stream()), "bds_bilagrid_ms_fwd")
+        ctx.save_for_backward(rgb, alpha, sky, ws, *grids)
+        ctx.factors = tuple(int(f) for f in factors)
+        ctx.n = n
+        ctx.mark_non_differentiable(*maps)
+        return (out, *maps)
+
+    @staticmethod
+    def backward(ctx, v_out, *v_maps):
+        rgb, alpha, sky, ws, *grids = ctx.saved_tensors
+        H, W, _ = rgb.shape
+        n = ctx.n
+        lib = L.lib()
+        need_g = ctx.needs_input_grad[5:]
+        v_grids = [torch.zeros_like(g) if need_g[i] else None for i, g in enumerate(grids)]
+        lv = _levels_struct(grids, v_grids, ctx.factors)
+        v_out = _f32c(v_out)
+        v_rgb = torch.empty_like(rgb)
+        v_alpha = torch.empty_like(alpha) if sky is not None else None
+        v_sky = torch.empty_like(sky) if sky is not None else None
+        with L.timed("bilagrid_bwd"):
+            L.check(lib.bds_bilagrid_ms_bwd(n, lv, H, W, L.ptr(rgb), L.ptr(alpha), L.ptr(sky), L.ptr(ws), ws.numel(),
+                                            L.ptr(v_out), L.ptr(v_rgb), L.ptr(v_alpha), L.ptr(v_sky), L.stream()),
+                    "bds_bilagrid_ms_bwd")
+        return (v_rgb, v_alpha, v_sky, None, None, *v_grids)
+
+
+def bilagrid_transform(rgb: Tensor, grids: Sequence[Tensor], factors: Sequence[int], alpha: Optional[Tensor] = None,
+                       sky: Optional[Tensor] = None, return_maps: bool = False):
+    """Fused multi-scale bilateral slice + 3x4 affine on an image.
+
+    rgb [H,W,3]; grids: per level [12,L,gy,gx] (one image's grid) or [K,12,L,gy,gx] (K grids whose
+    low-res slices are averaged: the test branch, modules.py:523-535); factors: per-level guidance
+    down-sampling factor (modules.py:505 default [4,4,2]; 1 = single-scale transform, :317-335).
+    If ``sky`` is given the input colour is clamp(rgb, max=1) + sky*(1-alpha)
+    (trainers/base.py:417 + scene_graph.py:292-294) with alpha [H,W] or [H,W,1].
+
+    Returns rgb_out [H,W,3], or (rgb_out, [per-level affine maps [H,W,3,4]]) with ``return_maps``."""
+    assert rgb.dim() == 3 and rgb.shape[-1] == 3, rgb.shape
+    assert len(grids) == len(factors) and len(grids) >= 1
+    gs = [g if g.dim() == 5 else g[None] for g in grids]
+    if sky is not None:
+        assert alpha is not None
+        alpha = alpha.reshape(rgb.shape[0], rgb.shape[1])
+    else:
+        alpha = None
+    res = _BilagridTransform.apply(rgb, alpha, sky, tuple(factors), bool(return_maps), *gs)
+    if return_maps:
+        H, W, _ = rgb.shape
+        return res[0], [m.reshape(H, W, 3, 4) for m in res[1:]]
+    return res[0]

@@ -1,0 +1,581 @@
+// K9-K13: sky blend + multi-scale bilateral-grid slice + 3x4 affine colour transform, TV.
+// Restates (file:line under /root/reference/project):
+//   bilateral/lib_bilagrid.py:171-230,317-368   slice(), BilateralGrid.forward
+//   models/modules.py:317-335,494-522,409-420   Bilateral / MultiScaleBilateral AffineTransform.forward
+//   models/trainers/scene_graph.py:95-98,112-117,292-294   application, composition, sky blend
+//   bilateral/lib_bilagrid.py:152-168           total_variation_loss
+//
+// HBM-bound pixel work.  The reference materialises one [H,W,3,4] affine map per level
+// (>= 96 B/pixel/level); here only the LOW-resolution maps exist in memory (0.375 x 48 B per
+// full-res pixel for the shipped 3-level config) and the full-resolution kernel re-derives each
+// level's 3x4 matrix from four cached taps while the pixel stays in registers: 24-40 B/pixel of
+// HBM traffic forward.  Backward is gather-based (deterministic, no atomics on image-sized arrays);
+// grid gradients are accumulated per workgroup in LDS and flushed once.
+#include "bds_common.h"
+#include "bilagrid_math.h"
+
+namespace bds {
+
+constexpr int kBgBlock = 256;
+
+struct LevelDev {
+  const float *grid;   // [n_avg,12,gl,gy,gx]
+  float *v_grid;
+  float *lo;           // [Hd*Wd,12] low-res affine maps
+  float *P;            // [H*W,3] input colour of this level   (bwd scratch)
+  float *Q;            // [H*W,3] gradient w.r.t. this level's output (bwd scratch)
+  float *aff_out;      // optional [H*W,12]
+  int gx, gy, gl, factor, n_avg, Hd, Wd;
+};
+struct MsParams {
+  int nlevels, H, W;
+  const float *rgb, *alpha, *sky;
+  LevelDev lv[BDS_MAX_LEVELS];
+};
+
+// input colour of the transform at pixel (y,x): clamp + sky blend fused when sky != null
+__device__ __forceinline__ void load_input(const MsParams &p, int y, int x, float &r, float &g, float &b) {
+  const int64_t o = (int64_t)y * p.W + x;
+  r = p.rgb[o * 3]; g = p.rgb[o * 3 + 1]; b = p.rgb[o * 3 + 2];
+  if (p.sky) {
+    const float k = 1.f - p.alpha[o];
+    r = fminf(r, 1.f) + p.sky[o * 3] * k;
+    g = fminf(g, 1.f) + p.sky[o * 3 + 1] * k;
+    b = fminf(b, 1.f) + p.sky[o * 3 + 2] * k;
+  }
+}
+
+__device__ __forceinline__ void lowres_colour(const MsParams &p, const Tap &ty, const Tap &tx, float &r, float &g, float &b) {
+  float r00, g00, b00, r01, g01, b01, r10, g10, b10, r11, g11, b11;
+  load_input(p, ty.i0, tx.i0, r00, g00, b00);
+  load_input(p, ty.i0, tx.i1, r01, g01, b01);
+  load_input(p, ty.i1, tx.i0, r10, g10, b10);
+  load_input(p, ty.i1, tx.i1, r11, g11, b11);
+  const float wx = tx.w1, wy = ty.w1;
+  r = (r00 * (1.f - wx) + r01 * wx) * (1.f - wy) + (r10 * (1.f - wx) + r11 * wx) * wy;
+  g = (g00 * (1.f - wx) + g01 * wx) * (1.f - wy) + (g10 * (1.f - wx) + g11 * wx) * wy;
+  b = (b00 * (1.f - wx) + b01 * wx) * (1.f - wy) + (b10 * (1.f - wx) + b11 * wx) * wy;
+}
+
+// ---- A: per-level low-resolution slice -------------------------------------------------------
+__global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, int l) {
+  const LevelDev &L = p.lv[l];
+  const int64_t idx = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (idx >= (int64_t)L.Hd * L.Wd) return;
+  const int i = (int)(idx / L.Wd), j = (int)(idx - (int64_t)i * L.Wd);
+  const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
+  float r, g, b;
+  lowres_colour(p, ty, tx, r, g, b);
+  const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.f;
+  const int gsz = 12 * L.gl * L.gy * L.gx;
+  for (int n = 0; n < L.n_avg; n++) {
+    float a[12];
+    slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a, nullptr);
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] += a[k];
+  }
+  float4 *dst = reinterpret_cast<float4 *>(L.lo + idx * 12);
+  if (L.n_avg > 1) {
+    const float inv = (float)L.n_avg;
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] = acc[k] / inv;
+  }
+  dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+}
+
+// bilinear up-sample of one level's low-res map at full-res pixel (i,j)
+__device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W, int i, int j, float *A) {
+  if (L.Hd == H && L.Wd == W) {
+    const float4 *s = reinterpret_cast<const float4 *>(L.lo + ((int64_t)i * W + j) * 12);
+    const float4 a = s[0], b = s[1], c = s[2];
+    A[0] = a.x; A[1] = a.y; A[2] = a.z; A[3] = a.w; A[4] = b.x; A[5] = b.y; A[6] = b.z; A[7] = b.w;
+    A[8] = c.x; A[9] = c.y; A[10] = c.z; A[11] = c.w;
+    return;
+  }
+  const Tap ty = resample_tap(i, H, L.Hd), tx = resample_tap(j, W, L.Wd);
+  const float4 *s00 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + tx.i0) * 12);
+  const float4 *s01 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + tx.i1) * 12);
+  const float4 *s10 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + tx.i0) * 12);
+  const float4 *s11 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + tx.i1) * 12);
+  const float wx = tx.w1, wy = ty.w1;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float4 a = s00[q], b = s01[q], c = s10[q], d = s11[q];
+    A[q * 4 + 0] = (a.x * (1.f - wx) + b.x * wx) * (1.f - wy) + (c.x * (1.f - wx) + d.x * wx) * wy;
+    A[q * 4 + 1] = (a.y * (1.f - wx) + b.y * wx) * (1.f - wy) + (c.y * (1.f - wx) + d.y * wx) * wy;
+    A[q * 4 + 2] = (a.z * (1.f - wx) + b.z * wx) * (1.f - wy) + (c.z * (1.f - wx) + d.z * wx) * wy;
+    A[q * 4 + 3] = (a.w * (1.f - wx) + b.w * wx) * (1.f - wy) + (c.w * (1.f - wx) + d.w * wx) * wy;
+  }
+}
+
+// ---- B: full-resolution compose --------------------------------------------------------------
+__global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out) {
+  const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (pix >= (int64_t)p.H * p.W) return;
+  const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
+  float r, g, b;
+  load_input(p, i, j, r, g, b);
+#pragma unroll
+  for (int l = 0; l < BDS_MAX_LEVELS; l++) {
+    if (l < p.nlevels) {
+      float A[12];
+      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+      if (p.lv[l].aff_out) {
+        float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out + pix * 12);
+        d[0] = make_float4(A[0], A[1], A[2], A[3]);
+        d[1] = make_float4(A[4], A[5], A[6], A[7]);
+        d[2] = make_float4(A[8], A[9], A[10], A[11]);
+      }
+      apply_affine(A, r, g, b);
+    }
+  }
+  out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
+}
+
+// ---- C: full-resolution backward: direct route + per-level (P, Q) for the gather ---------------
+__global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, const float *__restrict__ v_out,
+                                                               float *__restrict__ v_in) {
+  const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (pix >= (int64_t)p.H * p.W) return;
+  const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
+  float r, g, b;
+  load_input(p, i, j, r, g, b);
+#pragma unroll
+  for (int l = 0; l < BDS_MAX_LEVELS; l++) {
+    if (l < p.nlevels) {
+      float *P = p.lv[l].P + pix * 3;
+      P[0] = r; P[1] = g; P[2] = b;
+      float A[12];
+      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+      apply_affine(A, r, g, b);
+    }
+  }
+  float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
+#pragma unroll
+  for (int l = BDS_MAX_LEVELS - 1; l >= 0; l--) {
+    if (l < p.nlevels) {
+      float *Q = p.lv[l].Q + pix * 3;
+      Q[0] = v0; Q[1] = v1; Q[2] = v2;
+      float A[12];
+      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+      const float n0 = A[0] * v0 + A[4] * v1 + A[8] * v2;
+      const float n1 = A[1] * v0 + A[5] * v1 + A[9] * v2;
+      const float n2 = A[2] * v0 + A[6] * v1 + A[10] * v2;
+      v0 = n0; v1 = n1; v2 = n2;
+    }
+  }
+  v_in[pix * 3] = v0; v_in[pix * 3 + 1] = v1; v_in[pix * 3 + 2] = v2;
+}
+
+// wave64 sum leaving the result in every lane (used only on wave-uniform-address grid updates)
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// accumulate val into acc[addr] (LDS or global), combining across the wave when every active lane
+// targets the same address (coarse grids: the whole wave sits in one cell)
+__device__ __forceinline__ void grid_accumulate(float *acc, int addr, float val, bool active) {
+  const int a0 = __builtin_amdgcn_readfirstlane(active ? addr : -1);
+  const bool uniform = __all(!active || addr == a0) && __any(active) && a0 >= 0;
+  if (uniform) {
+    const float s = wave_sum_all(active ? val : 0.f);
+    if ((threadIdx.x & (kWave - 1)) == 0 && s != 0.f) atomicAdd(acc + a0, s);
+  } else if (active && val != 0.f) {
+    atomicAdd(acc + addr, val);
+  }
+}
+
+// ---- D: per-level low-resolution backward (gather of the up-sample, slice vjp, guidance) --------
+// kLds: the level's grid gradient (n_avg * 12*gl*gy*gx floats) fits the workgroup's LDS accumulator.
+template <bool kLds>
+__global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int l, float *__restrict__ v_in) {
+  extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+  const LevelDev &L = p.lv[l];
+  const int gsz = 12 * L.gl * L.gy * L.gx;
+  const int gtot = gsz * L.n_avg;
+  if (kLds) {
+    for (int e = threadIdx.x; e < gtot; e += kBgBlock) lds_acc[e] = 0.f;
+    __syncthreads();
+  }
+  float *acc = kLds ? lds_acc : L.v_grid;
+  const int64_t idx = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  const bool active = idx < (int64_t)L.Hd * L.Wd;
+  const int i = active ? (int)(idx / L.Wd) : 0, j = active ? (int)(idx - (int64_t)i * L.Wd) : 0;
+  float va[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) va[k] = 0.f;
+  if (active) {
+    if (L.Hd == p.H && L.Wd == p.W) {
+      const float *P = L.P + idx * 3, *Q = L.Q + idx * 3;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        va[r * 4 + 0] = Q[r] * P[0]; va[r * 4 + 1] = Q[r] * P[1]; va[r * 4 + 2] = Q[r] * P[2]; va[r * 4 + 3] = Q[r];
+      }
+    } else {
+      // full-res pixels whose up-sample taps include this low-res cell
+      const float sy = (float)p.H / (float)L.Hd, sx = (float)p.W / (float)L.Wd;
+      int ylo = (int)floorf(((float)i - 0.5f) * sy - 0.5f) - 1, yhi = (int)ceilf(((float)i + 1.5f) * sy - 0.5f) + 1;
+      int xlo = (int)floorf(((float)j - 0.5f) * sx - 0.5f) - 1, xhi = (int)ceilf(((float)j + 1.5f) * sx - 0.5f) + 1;
+      ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, p.H - 1); xhi = min(xhi, p.W - 1);
+      for (int y = ylo; y <= yhi; y++) {
+        const Tap ty = resample_tap(y, p.H, L.Hd);
+        const float wy = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int x = xlo; x <= xhi; x++) {
+          const Tap tx = resample_tap(x, p.W, L.Wd);
+          const float wx = (tx.i0 == j ? 1.f - tx.w1 : 0.f) + (tx.i1 == j ? tx.w1 : 0.f);
+          if (wx == 0.f) continue;
+          const float w = wy * wx;
+          const int64_t o = ((int64_t)y * p.W + x) * 3;
+          const float p0 = L.P[o], p1 = L.P[o + 1], p2 = L.P[o + 2];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            const float q = L.Q[o + r] * w;
+            va[r * 4 + 0] += q * p0; va[r * 4 + 1] += q * p1; va[r * 4 + 2] += q * p2; va[r * 4 + 3] += q;
+          }
+        }
+      }
+    }
+  }
+  // slice backward
+  const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (active) lowres_colour(p, ty, tx, r, g, b);
+  const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
+  const float inv_n = 1.f / (float)L.n_avg;
+  const int plane = L.gy * L.gx, vol = L.gl * plane;
+  float v_iz = 0.f;
+  const int zs[2] = {c.z0, c.z1};
+  const float wz[2] = {1.f - c.fz, c.fz};
+  const int ys[2] = {c.y0, c.y1};
+  const float wyv[2] = {1.f - c.fy, c.fy};
+  const int xs[2] = {c.x0, c.x1};
+  const float wxv[2] = {1.f - c.fx, c.fx};
+  for (int n = 0; n < L.n_avg; n++) {
+    if (L.v_grid) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+          for (int cc = 0; cc < 2; cc++) {
+            const float w = wz[a] * wyv[bb] * wxv[cc] * inv_n;
+            const int base = n * gsz + zs[a] * plane + ys[bb] * L.gx + xs[cc];
+#pragma unroll
+            for (int ch = 0; ch < 12; ch++) grid_accumulate(acc, base + ch * vol, w * va[ch], active);
+          }
+    }
+    if (active && c.z_interior) {
+      float a12[12], dz[12];
+      slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a12, dz);
+#pragma unroll
+      for (int ch = 0; ch < 12; ch++) v_iz += va[ch] * dz[ch] * inv_n;
+    }
+  }
+  if (active && c.z_interior && v_iz != 0.f) {
+    const float v_gray = v_iz * (float)(L.gl - 1);
+    const float vr = v_gray * kGrayR, vg = v_gray * kGrayG, vb = v_gray * kGrayB;
+    const int yy[2] = {ty.i0, ty.i1}, xx[2] = {tx.i0, tx.i1};
+    const float wy2[2] = {1.f - ty.w1, ty.w1}, wx2[2] = {1.f - tx.w1, tx.w1};
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int bb = 0; bb < 2; bb++) {
+        const float w = wy2[a] * wx2[bb];
+        if (w != 0.f) {
+          float *d = v_in + ((int64_t)yy[a] * p.W + xx[bb]) * 3;
+          atomicAdd(d, vr * w); atomicAdd(d + 1, vg * w); atomicAdd(d + 2, vb * w);
+        }
+      }
+  }
+  if (kLds && L.v_grid) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < gtot; e += kBgBlock) {
+      const float v = lds_acc[e];
+      if (v != 0.f) atomicAdd(L.v_grid + e, v);
+    }
+  }
+}
+
+// ---- E: clamp + sky blend backward (in place on v_in) ------------------------------------------
+__global__ __launch_bounds__(kBgBlock) void blend_bwd_kernel(int64_t HW, const float *__restrict__ rgb,
+                                                            const float *__restrict__ alpha, const float *__restrict__ sky,
+                                                            float *__restrict__ v_rgb, float *__restrict__ v_alpha,
+                                                            float *__restrict__ v_sky) {
+  const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const float k = 1.f - alpha[pix];
+  float va = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float v = v_rgb[pix * 3 + c];
+    va -= v * sky[pix * 3 + c];
+    if (v_sky) v_sky[pix * 3 + c] = v * k;
+    v_rgb[pix * 3 + c] = rgb[pix * 3 + c] <= 1.f ? v : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
+  }
+  if (v_alpha) v_alpha[pix] = va;
+}
+
+// ---- generic point slice (BilateralGrid.forward on arbitrary points) ------------------------------
+__global__ __launch_bounds__(kBgBlock) void slice_fwd_kernel(int64_t P, const float *__restrict__ grid, int gx, int gy, int gl,
+                                                            const float *__restrict__ xy, const float *__restrict__ rgb,
+                                                            float *__restrict__ affine) {
+  const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (i >= P) return;
+  const Cell c = slice_cell(xy[i * 2], xy[i * 2 + 1], rgb2gray(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]), gx, gy, gl);
+  float a[12];
+  slice_sample(grid, gx, gy, gl, c, a, nullptr);
+#pragma unroll
+  for (int k = 0; k < 12; k++) affine[i * 12 + k] = a[k];
+}
+
+__global__ __launch_bounds__(kBgBlock) void slice_bwd_kernel(int64_t P, const float *__restrict__ grid, int gx, int gy, int gl,
+                                                            const float *__restrict__ xy, const float *__restrict__ rgb,
+                                                            const float *__restrict__ v_affine, float *__restrict__ v_grid,
+                                                            float *__restrict__ v_rgb) {
+  const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  const bool active = i < P;
+  const int64_t ii = active ? i : 0;
+  const Cell c = slice_cell(xy[ii * 2], xy[ii * 2 + 1], rgb2gray(rgb[ii * 3], rgb[ii * 3 + 1], rgb[ii * 3 + 2]), gx, gy, gl);
+  float va[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) va[k] = active ? v_affine[ii * 12 + k] : 0.f;
+  const int plane = gy * gx, vol = gl * plane;
+  const int zs[2] = {c.z0, c.z1}, ys[2] = {c.y0, c.y1}, xs[2] = {c.x0, c.x1};
+  const float wz[2] = {1.f - c.fz, c.fz}, wyv[2] = {1.f - c.fy, c.fy}, wxv[2] = {1.f - c.fx, c.fx};
+  if (v_grid) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+          const float w = wz[a] * wyv[b] * wxv[cc];
+          const int base = zs[a] * plane + ys[b] * gx + xs[cc];
+#pragma unroll
+          for (int ch = 0; ch < 12; ch++) grid_accumulate(v_grid, base + ch * vol, w * va[ch], active);
+        }
+  }
+  if (active && v_rgb) {
+    float vg = 0.f;
+    if (c.z_interior) {
+      float a12[12], dz[12];
+      slice_sample(grid, gx, gy, gl, c, a12, dz);
+      float v_iz = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 12; ch++) v_iz += va[ch] * dz[ch];
+      vg = v_iz * (float)(gl - 1);
+    }
+    v_rgb[i * 3] = vg * kGrayR; v_rgb[i * 3 + 1] = vg * kGrayG; v_rgb[i * 3 + 2] = vg * kGrayB;
+  }
+}
+
+// ---- TV regulariser ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kBgBlock) void tv_fwd_kernel(int64_t total, int gx, int gy, int gl, const float *__restrict__ x,
+                                                         float scale_l, float scale_y, float scale_x,
+                                                         float *__restrict__ tv_out) {
+  __shared__ float red[kBgBlock / kWave];
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * kBgBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBgBlock) {
+    const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
+    const float v = x[e];
+    if (ix > 0) { const float d = v - x[e - 1]; acc += d * d * scale_x; }
+    if (iy > 0) { const float d = v - x[e - gx]; acc += d * d * scale_y; }
+    if (il > 0) { const float d = v - x[e - (int64_t)gx * gy]; acc += d * d * scale_l; }
+  }
+  acc = wave_sum_all(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kBgBlock / kWave; w++) s += red[w];
+    atomicAdd(tv_out, s);
+  }
+}
+
+__global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx, int gy, int gl, const float *__restrict__ x,
+                                                         float scale_l, float scale_y, float scale_x,
+                                                         const float *__restrict__ v_tv, float *__restrict__ v_x) {
+  const int64_t e = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (e >= total) return;
+  const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
+  const int64_t sl = (int64_t)gx * gy;
+  const float v = x[e];
+  float g = 0.f;
+  if (ix > 0) g += 2.f * (v - x[e - 1]) * scale_x;
+  if (ix < gx - 1) g -= 2.f * (x[e + 1] - v) * scale_x;
+  if (iy > 0) g += 2.f * (v - x[e - gx]) * scale_y;
+  if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * scale_y;
+  if (il > 0) g += 2.f * (v - x[e - sl]) * scale_l;
+  if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * scale_l;
+  v_x[e] += g * v_tv[0];
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct MsLayout {
+  size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS];
+  size_t bytes;
+};
+static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, int W) {
+  MsLayout L;
+  size_t off = 0;
+  for (int l = 0; l < nlevels; l++) {
+    const int Hd = H / lv[l].factor, Wd = W / lv[l].factor;
+    L.lo_off[l] = off;
+    off += align_up((size_t)Hd * Wd * 12 * sizeof(float), 256);
+  }
+  for (int l = 0; l < nlevels; l++) {
+    L.p_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
+    L.q_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
+  }
+  L.bytes = off;
+  return L;
+}
+
+static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int H, int W, const float *rgb,
+                   const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *const *affine_out) {
+  BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && lv && H > 0 && W > 0 && rgb && ws);
+  BDS_REQUIRE((sky == nullptr) || (alpha != nullptr));
+  const MsLayout L = ms_layout(nlevels, lv, H, W);
+  if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
+  BDS_REQUIRE(aligned16(ws));
+  p.nlevels = nlevels; p.H = H; p.W = W; p.rgb = rgb; p.alpha = alpha; p.sky = sky;
+  char *base = static_cast<char *>(ws);
+  for (int l = 0; l < nlevels; l++) {
+    BDS_REQUIRE(lv[l].grid && lv[l].gx >= 1 && lv[l].gy >= 1 && lv[l].gl >= 1 && lv[l].factor >= 1 && lv[l].n_avg >= 1);
+    BDS_REQUIRE(H / lv[l].factor >= 1 && W / lv[l].factor >= 1);
+    LevelDev &d = p.lv[l];
+    d.grid = lv[l].grid; d.v_grid = lv[l].v_grid;
+    d.lo = reinterpret_cast<float *>(base + L.lo_off[l]);
+    d.P = reinterpret_cast<float *>(base + L.p_off[l]);
+    d.Q = reinterpret_cast<float *>(base + L.q_off[l]);
+    d.aff_out = affine_out ? affine_out[l] : nullptr;
+    BDS_REQUIRE(d.aff_out == nullptr || aligned16(d.aff_out));
+    d.gx = lv[l].gx; d.gy = lv[l].gy; d.gl = lv[l].gl; d.factor = lv[l].factor; d.n_avg = lv[l].n_avg;
+    d.Hd = H / lv[l].factor; d.Wd = W / lv[l].factor;
+  }
+  return BDS_OK;
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+extern "C" size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagrid_level_t *levels, int H, int W) {
+  if (nlevels < 1 || nlevels > BDS_MAX_LEVELS || !levels || H <= 0 || W <= 0) return 0;
+  for (int l = 0; l < nlevels; l++)
+    if (levels[l].factor < 1) return 0;
+  return ms_layout(nlevels, levels, H, W).bytes;
+}
+
+extern "C" int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
+                                   const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
+                                   float *const *affine_out, bds_stream_t stream) {
+  MsParams p;
+  int rc = ms_fill(p, nlevels, levels, H, W, rgb, alpha, sky, ws, ws_bytes, affine_out);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(rgb_out);
+  hipStream_t st = as_stream(stream);
+  for (int l = 0; l < nlevels; l++) {
+    const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;
+    hipLaunchKernelGGL(ms_lowres_fwd_kernel, dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l);
+    BDS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(ms_apply_fwd_kernel, dim3((unsigned)cdiv((int64_t)H * W, kBgBlock)), dim3(kBgBlock), 0, st, p, rgb_out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
+                                   const float *alpha, const float *sky, void *ws, size_t ws_bytes,
+                                   const float *v_rgb_out, float *v_rgb, float *v_alpha, float *v_sky,
+                                   bds_stream_t stream) {
+  MsParams p;
+  int rc = ms_fill(p, nlevels, levels, H, W, rgb, alpha, sky, ws, ws_bytes, nullptr);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(v_rgb_out && v_rgb);
+  hipStream_t st = as_stream(stream);
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(ms_apply_bwd_kernel, dim3((unsigned)cdiv(HW, kBgBlock)), dim3(kBgBlock), 0, st, p, v_rgb_out, v_rgb);
+  BDS_LAUNCH_CHECK();
+  for (int l = 0; l < nlevels; l++) {
+    const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;
+    const size_t gbytes = sizeof(float) * 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
+    if (gbytes <= 60 * 1024) {
+      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), gbytes, st, p, l, v_rgb);
+    } else {
+      hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l, v_rgb);
+    }
+    BDS_LAUNCH_CHECK();
+  }
+  if (sky) {
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)cdiv(HW, kBgBlock)), dim3(kBgBlock), 0, st, HW, rgb, alpha, sky, v_rgb,
+                       v_alpha, v_sky);
+    BDS_LAUNCH_CHECK();
+  }
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_slice_fwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy,
+                                      const float *rgb, float *affine, bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0 && gx >= 1 && gy >= 1 && gl >= 1);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(grid && xy && rgb && affine);
+  hipLaunchKernelGGL(slice_fwd_kernel, dim3((unsigned)cdiv(P, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), P, grid, gx, gy,
+                     gl, xy, rgb, affine);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_slice_bwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy,
+                                      const float *rgb, const float *v_affine, float *v_grid, float *v_rgb,
+                                      bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0 && gx >= 1 && gy >= 1 && gl >= 1);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(grid && xy && rgb && v_affine);
+  hipLaunchKernelGGL(slice_bwd_kernel, dim3((unsigned)cdiv(P, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), P, grid, gx, gy,
+                     gl, xy, rgb, v_affine, v_grid, v_rgb);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+static void tv_scales(int64_t n, int gx, int gy, int gl, float weight, float &sl, float &sy, float &sx) {
+  // lib_bilagrid.py:147-168: each axis' squared differences are divided by the element count of
+  // the differenced tensor (per batch item, floor 1); the sum is divided by the batch size.
+  auto cnt = [](int64_t a, int64_t b, int64_t c) { double v = 12.0 * a * b * c; return v < 1.0 ? 1.0 : v; };
+  sl = (float)(weight / (cnt(gl - 1, gy, gx) * (double)n));
+  sy = (float)(weight / (cnt(gl, gy - 1, gx) * (double)n));
+  sx = (float)(weight / (cnt(gl, gy, gx - 1) * (double)n));
+}
+
+extern "C" int bds_bilagrid_tv_fwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, float *tv_out,
+                                   bds_stream_t stream) {
+  BDS_REQUIRE(n >= 1 && gx >= 1 && gy >= 1 && gl >= 1 && grids && tv_out);
+  float sl, sy, sx;
+  tv_scales(n, gx, gy, gl, weight, sl, sy, sx);
+  const int64_t total = n * 12 * gl * gy * gx;
+  const int64_t blocks = cdiv(total, kBgBlock);
+  hipLaunchKernelGGL(tv_fwd_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(kBgBlock), 0, as_stream(stream), total,
+                     gx, gy, gl, grids, sl, sy, sx, tv_out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
+                                   float *v_grids, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 1 && gx >= 1 && gy >= 1 && gl >= 1 && grids && v_tv && v_grids);
+  float sl, sy, sx;
+  tv_scales(n, gx, gy, gl, weight, sl, sy, sx);
+  const int64_t total = n * 12 * gl * gy * gx;
+  hipLaunchKernelGGL(tv_bwd_kernel, dim3((unsigned)cdiv(total, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), total, gx, gy,
+                     gl, grids, sl, sy, sx, v_tv, v_grids);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}

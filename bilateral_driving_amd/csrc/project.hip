@@ -1,0 +1,132 @@
+// K2/K3: per-Gaussian 3D->2D projection, forward and backward.
+// First stage of gsplat.rendering.rasterization as called at
+// /root/reference/project/models/trainers/base.py:393-408.  HBM-bound streaming kernels
+// (68 B/Gaussian forward, 108 B/Gaussian backward).  One thread per Gaussian; the camera loop
+// runs inside the thread so that parameter gradients are summed in registers (no atomics,
+// deterministic); only the 12-float camera-pose gradient is block-reduced.
+#include "bds_common.h"
+#include "gs_math.h"
+
+namespace bds {
+
+constexpr int kProjBlock = 256;
+
+__global__ __launch_bounds__(kProjBlock) void project_fwd_kernel(
+    int C, int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane,
+    float far_plane, float radius_clip, int32_t *__restrict__ radii, float *__restrict__ means2d,
+    float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps) {
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  if (g >= N) return;
+  float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
+  float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+  float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
+  for (int c = 0; c < C; c++) {
+    Camera cam = load_camera(viewmats + c * 16, Ks + c * 9);  // wave-uniform -> scalar loads
+    Proj p = project_one(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
+    const int64_t o = (int64_t)c * N + g;
+    radii[o] = p.radius;
+    means2d[o * 2] = p.mx; means2d[o * 2 + 1] = p.my;
+    depths[o] = p.depth;
+    conics[o * 3] = p.ca; conics[o * 3 + 1] = p.cb; conics[o * 3 + 2] = p.cc;
+    if (comps) comps[o] = p.comp;
+  }
+}
+
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(kProjBlock) void project_bwd_kernel(
+    int C, int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks, int W, int H, float eps2d,
+    const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    const float *__restrict__ v_conics, float *__restrict__ v_means, float *__restrict__ v_quats,
+    float *__restrict__ v_scales, float *__restrict__ v_viewmats) {
+  __shared__ float red[kProjBlock / kWave][12];
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  const bool live = g < N;
+  float m[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, s[3] = {1, 1, 1};
+  if (live) {
+    m[0] = means[g * 3]; m[1] = means[g * 3 + 1]; m[2] = means[g * 3 + 2];
+    q[0] = quats[g * 4]; q[1] = quats[g * 4 + 1]; q[2] = quats[g * 4 + 2]; q[3] = quats[g * 4 + 3];
+    s[0] = scales[g * 3]; s[1] = scales[g * 3 + 1]; s[2] = scales[g * 3 + 2];
+  }
+  float am[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, as[3] = {0, 0, 0};
+  for (int c = 0; c < C; c++) {
+    Camera cam = load_camera(viewmats + c * 16, Ks + c * 9);
+    ProjGrad pg;
+    for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
+    for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
+    const int64_t o = (int64_t)c * N + g;
+    if (live && radii[o] > 0) {
+      project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[o * 2], v_means2d[o * 2 + 1], v_depths[o], v_conics[o * 3],
+                      v_conics[o * 3 + 1], v_conics[o * 3 + 2], pg);
+      for (int i = 0; i < 3; i++) { am[i] += pg.v_mean[i]; as[i] += pg.v_scale[i]; }
+      for (int i = 0; i < 4; i++) aq[i] += pg.v_quat[i];
+    }
+    if (v_viewmats != nullptr) {  // block reduction of the pose gradient, one atomic set per block
+      const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+      float r[12];
+      for (int i = 0; i < 9; i++) r[i] = wave_sum_shfl(pg.v_R[i]);
+      for (int i = 0; i < 3; i++) r[9 + i] = wave_sum_shfl(pg.v_t[i]);
+      __syncthreads();
+      if (lane == 0)
+        for (int i = 0; i < 12; i++) red[wv][i] = r[i];
+      __syncthreads();
+      if (threadIdx.x < 12) {
+        float t = 0.f;
+        for (int w = 0; w < kProjBlock / kWave; w++) t += red[w][threadIdx.x];
+        const int i = threadIdx.x;
+        float *dst = v_viewmats + c * 16 + (i < 9 ? (i / 3) * 4 + (i % 3) : (i - 9) * 4 + 3);
+        if (t != 0.f) atomicAdd(dst, t);
+      }
+    }
+  }
+  if (live) {
+    for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = am[i]; v_scales[g * 3 + i] = as[i]; }
+    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = aq[i];
+  }
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+extern "C" int bds_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                               const float *viewmats, const float *Ks, int W, int H, float eps2d, float near_plane,
+                               float far_plane, float radius_clip, int32_t *radii, float *means2d, float *depths,
+                               float *conics, float *compensations, bds_stream_t stream) {
+  BDS_REQUIRE(C >= 1 && N >= 0 && W > 0 && H > 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && quats && scales && viewmats && Ks && radii && means2d && depths && conics);
+  hipLaunchKernelGGL(project_fwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), C, N,
+                     means, quats, scales, viewmats, Ks, W, H, eps2d, near_plane, far_plane, radius_clip, radii,
+                     means2d, depths, conics, compensations);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_project_bwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                               const float *viewmats, const float *Ks, int W, int H, float eps2d, const int32_t *radii,
+                               const float *conics, const float *compensations, const float *v_means2d,
+                               const float *v_depths, const float *v_conics, const float *v_compensations,
+                               float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
+                               bds_stream_t stream) {
+  (void)conics; (void)compensations;
+  BDS_REQUIRE(C >= 1 && N >= 0 && W > 0 && H > 0);
+  BDS_REQUIRE(v_compensations == nullptr);  // "antialiased" backward is not on the reference's path
+  if (v_viewmats) {
+    if (hipMemsetAsync(v_viewmats, 0, sizeof(float) * 16 * C, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
+  }
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && quats && scales && viewmats && Ks && radii && v_means2d && v_depths && v_conics && v_means &&
+              v_quats && v_scales);
+  hipLaunchKernelGGL(project_bwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), C, N,
+                     means, quats, scales, viewmats, Ks, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_means,
+                     v_quats, v_scales, v_viewmats);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}

@@ -1,0 +1,192 @@
+// K1: spherical-harmonics colour evaluation, forward and backward.
+// Serves gsplat.cuda._wrapper.spherical_harmonics (/root/reference/project/models/gaussians/
+// basics.py:15, vanilla.py:388).  HBM-bound streaming kernel: 216 B/Gaussian at degree 3.
+//
+// Layout: coeffs [n, K, 3] AoS (192 B/Gaussian at K=16).  A workgroup of 256 threads owns 256
+// consecutive Gaussians; their coefficient rows are one contiguous span that is moved HBM<->LDS with
+// fully coalesced 16-byte accesses, and each thread then reads / writes its own row in LDS
+// (row stride padded by one dword so that the per-thread walk is bank-conflict free).
+#include "bds_common.h"
+#include "gs_math.h"
+
+namespace bds {
+
+constexpr int kShBlock = 256;
+
+// kFull: nb == K (every coefficient is used) -> 16-byte coalesced path.  DEG is a template
+// parameter so that the basis array is indexed statically and stays in registers.
+template <int DEG, bool kFull>
+__global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, const float *__restrict__ dirs,
+                                                         const float *__restrict__ coeffs,
+                                                         const uint8_t *__restrict__ masks, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int deg = DEG, nb = (DEG + 1) * (DEG + 1);
+  const int row = nb * 3;       // floats used per Gaussian
+  const int ldr = row + 1;      // padded LDS row
+  const int64_t g0 = (int64_t)blockIdx.x * kShBlock;
+  const int cnt = (int)min((int64_t)kShBlock, n - g0);
+  const int tid = threadIdx.x;
+  if (kFull) {
+    // span of cnt*row floats starting at coeffs + g0*row (16-byte aligned: row*4*256 % 16 == 0)
+    const float4 *src = reinterpret_cast<const float4 *>(coeffs + g0 * row);
+    const int n4 = cnt * row / 4;  // row = 48, 27.. ; kFull only used when row % 4 == 0
+    for (int i = tid; i < n4; i += kShBlock) {
+      float4 v = src[i];
+      int e = i * 4;
+      int r = e / row, c = e - r * row;  // row % 4 == 0 -> the 4 floats stay in one row
+      float *d = lds + r * ldr + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    const int tot = cnt * row;
+    for (int e = tid; e < tot; e += kShBlock) {
+      int r = e / row, c = e - r * row;
+      lds[r * ldr + c] = coeffs[(g0 + r) * (int64_t)K * 3 + c];
+    }
+  }
+  __syncthreads();
+  if (tid >= cnt) return;
+  const int64_t g = g0 + tid;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  if (masks == nullptr || masks[g]) {
+    float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+    float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+    float B[16];
+    sh_bases(deg, x * inorm, y * inorm, z * inorm, B);
+    const float *c = lds + tid * ldr;
+#pragma unroll
+    for (int k = 0; k < nb; k++) {
+      o0 += B[k] * c[k * 3];
+      o1 += B[k] * c[k * 3 + 1];
+      o2 += B[k] * c[k * 3 + 2];
+    }
+  }
+  out[g * 3] = o0; out[g * 3 + 1] = o1; out[g * 3 + 2] = o2;
+}
+
+template <int DEG, bool kFull>
+__global__ __launch_bounds__(kShBlock) void sh_bwd_kernel(int64_t n, int K, const float *__restrict__ dirs,
+                                                         const float *__restrict__ coeffs,
+                                                         const uint8_t *__restrict__ masks,
+                                                         const float *__restrict__ v_out, float *__restrict__ v_coeffs,
+                                                         float *__restrict__ v_dirs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int deg = DEG, nb = (DEG + 1) * (DEG + 1);
+  const int row = K * 3;   // the whole output row is written (bases >= nb get zero)
+  const int ldr = row + 1;
+  const int64_t g0 = (int64_t)blockIdx.x * kShBlock;
+  const int cnt = (int)min((int64_t)kShBlock, n - g0);
+  const int tid = threadIdx.x;
+  if (tid < cnt) {
+    const int64_t g = g0 + tid;
+    float *c = lds + tid * ldr;
+    bool on = (masks == nullptr || masks[g]);
+    float vo0 = v_out[g * 3], vo1 = v_out[g * 3 + 1], vo2 = v_out[g * 3 + 2];
+    float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+    float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+    float ux = x * inorm, uy = y * inorm, uz = z * inorm;
+    float B[16];
+    sh_bases(deg, ux, uy, uz, B);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < K) {
+        float b = (on && k < nb) ? B[k < nb ? k : 0] : 0.f;
+        c[k * 3] = b * vo0; c[k * 3 + 1] = b * vo1; c[k * 3 + 2] = b * vo2;
+      }
+    }
+    if (v_dirs != nullptr) {
+      float vx = 0.f, vy = 0.f, vz = 0.f;
+      if (on) {
+        float gk[16];
+        const float *cf = coeffs + g * (int64_t)K * 3;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          gk[k] = k < nb ? cf[k * 3] * vo0 + cf[k * 3 + 1] * vo1 + cf[k * 3 + 2] * vo2 : 0.f;
+        float ax, ay, az;
+        sh_bases_vjp(deg, ux, uy, uz, gk, ax, ay, az);
+        // through the normalisation: v = (a - (a.u) u) / |d|
+        float dot = ax * ux + ay * uy + az * uz;
+        vx = (ax - dot * ux) * inorm; vy = (ay - dot * uy) * inorm; vz = (az - dot * uz) * inorm;
+      }
+      v_dirs[g * 3] = vx; v_dirs[g * 3 + 1] = vy; v_dirs[g * 3 + 2] = vz;
+    }
+  }
+  __syncthreads();
+  if (kFull) {
+    float4 *dst = reinterpret_cast<float4 *>(v_coeffs + g0 * row);
+    const int n4 = cnt * row / 4;
+    for (int i = tid; i < n4; i += kShBlock) {
+      int e = i * 4;
+      int r = e / row, c = e - r * row;
+      const float *s = lds + r * ldr + c;
+      dst[i] = make_float4(s[0], s[1], s[2], s[3]);
+    }
+  } else {
+    const int tot = cnt * row;
+    for (int e = tid; e < tot; e += kShBlock) {
+      int r = e / row, c = e - r * row;
+      v_coeffs[g0 * row + e] = lds[r * ldr + c];
+    }
+  }
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+template <int DEG>
+static void launch_fwd(bool full, int grid, size_t lds, hipStream_t st, int64_t n, int K, const float *dirs,
+                       const float *coeffs, const uint8_t *masks, float *out) {
+  if (full)
+    hipLaunchKernelGGL((sh_fwd_kernel<DEG, true>), dim3(grid), dim3(kShBlock), lds, st, n, K, dirs, coeffs, masks, out);
+  else
+    hipLaunchKernelGGL((sh_fwd_kernel<DEG, false>), dim3(grid), dim3(kShBlock), lds, st, n, K, dirs, coeffs, masks, out);
+}
+
+template <int DEG>
+static void launch_bwd(bool full, int grid, size_t lds, hipStream_t st, int64_t n, int K, const float *dirs,
+                       const float *coeffs, const uint8_t *masks, const float *v_out, float *v_coeffs, float *v_dirs) {
+  if (full)
+    hipLaunchKernelGGL((sh_bwd_kernel<DEG, true>), dim3(grid), dim3(kShBlock), lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs);
+  else
+    hipLaunchKernelGGL((sh_bwd_kernel<DEG, false>), dim3(grid), dim3(kShBlock), lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs);
+}
+
+extern "C" int bds_sh_fwd(int64_t n, int K, int deg, const float *dirs, const float *coeffs, const uint8_t *masks,
+                          float *out, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(dirs && coeffs && out);
+  const int nb = (deg + 1) * (deg + 1);
+  const int grid = (int)cdiv(n, kShBlock);
+  const size_t lds = (size_t)kShBlock * (nb * 3 + 1) * sizeof(float);
+  const bool full = (nb == K) && ((nb * 3) % 4 == 0) && aligned16(coeffs);
+  hipStream_t st = as_stream(stream);
+  switch (deg) {
+    case 0: launch_fwd<0>(full, grid, lds, st, n, K, dirs, coeffs, masks, out); break;
+    case 1: launch_fwd<1>(full, grid, lds, st, n, K, dirs, coeffs, masks, out); break;
+    case 2: launch_fwd<2>(full, grid, lds, st, n, K, dirs, coeffs, masks, out); break;
+    default: launch_fwd<3>(full, grid, lds, st, n, K, dirs, coeffs, masks, out); break;
+  }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_sh_bwd(int64_t n, int K, int deg, const float *dirs, const float *coeffs, const uint8_t *masks,
+                          const float *v_out, float *v_coeffs, float *v_dirs, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(dirs && coeffs && v_out && v_coeffs);
+  const int grid = (int)cdiv(n, kShBlock);
+  const size_t lds = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+  const bool full = ((K * 3) % 4 == 0) && aligned16(v_coeffs);
+  hipStream_t st = as_stream(stream);
+  switch (deg) {
+    case 0: launch_bwd<0>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
+    case 1: launch_bwd<1>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
+    case 2: launch_bwd<2>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
+    default: launch_bwd<3>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
+  }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}

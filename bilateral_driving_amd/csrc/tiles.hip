@@ -1,0 +1,475 @@
+// K4-K6: tile intersection, (tile|depth) ordering, per-tile offsets.
+// isect_tiles / radix sort / isect_offset_encode stages of gsplat.rendering.rasterization
+// (/root/reference/project/models/trainers/base.py:393-408).  Integer work; the outputs
+// (flatten_ids, isect_ids, isect_offsets) are bit-identical to a stable sort of the 64-bit
+// keys  camera|tile << 32 | fp32-depth-bits  emitted in Gaussian order.
+//
+// MI355X-first restructuring (HBM-bound integer work; no 64-bit key sort of M duplicated keys):
+//   1. depth-order the C*N Gaussians ONCE (32-bit keys, 4 radix passes over C*N, not over M);
+//   2. emit (camera*tiles + tile, id) pairs in that order (M pairs, 32-bit keys);
+//   3. stable-sort the pairs by the tile key only: ceil(log2(C*tiles)) bits -> 2 passes at 1080p
+//      instead of 6 passes over 12-byte records.
+// A stable sort by tile of a depth-ordered sequence is exactly the (tile, depth, emission) order.
+#include "bds_common.h"
+#include "gs_math.h"
+
+namespace bds {
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of uint32 (three-phase, recursive over block sums)
+// ------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanBlock * kScanItems;  // 2048
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    uint32_t t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// returns the exclusive prefix of `v` within the block and the block total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t &total, uint32_t *lds_w /*>= waves+1*/) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int nw = blockDim.x / kWave;
+  uint32_t inc = wave_incl_scan(v);
+  if (lane == kWave - 1) lds_w[wv] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < nw; w++) {
+    uint32_t s = lds_w[w];
+    if (w < wv) base += s;
+    tot += s;
+  }
+  total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(const uint32_t *__restrict__ in, int64_t n,
+                                                                uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++)
+    if (base + i < n) s += in[base + i];
+  uint32_t tot;
+  block_excl_scan(s, tot, lw);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single-block in-place exclusive scan of a short array (n <= kScanTile)
+__global__ __launch_bounds__(kScanBlock) void scan_small_kernel(uint32_t *__restrict__ data, int64_t n,
+                                                               uint64_t *__restrict__ total_out) {
+  __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  const int64_t base = (int64_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    v[i] = base + i < n ? data[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(s, tot, lw);
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < n) data[base + i] = ex;
+    ex += v[i];
+  }
+  if (total_out && threadIdx.x == 0) *total_out = tot;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const uint32_t *__restrict__ in, int64_t n,
+                                                               const uint32_t *__restrict__ block_offsets,
+                                                               uint32_t *__restrict__ out) {
+  __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    v[i] = base + i < n ? in[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(s, tot, lw) + block_offsets[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+// uint32 elements of temp needed to scan n elements
+static size_t scan_temp_elems(int64_t n) {
+  size_t tot = 0;
+  while (n > kScanTile) {
+    n = cdiv(n, kScanTile);
+    tot += align_up((size_t)n, 4);
+  }
+  return tot + 4;
+}
+
+// out may alias in.  total_out (device uint64, may be null) receives the grand total
+// (valid as long as it fits 32 bits, which the callers guarantee).
+static int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *temp, uint64_t *total_out,
+                              hipStream_t st) {
+  if (n <= kScanTile) {
+    if (in != out) {
+      if (hipMemcpyAsync(out, in, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st) != hipSuccess) return BDS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kScanBlock), 0, st, out, n, total_out);
+    BDS_LAUNCH_CHECK();
+    return BDS_OK;
+  }
+  const int64_t nb = cdiv(n, kScanTile);
+  uint32_t *sums = temp;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, st, in, n, sums);
+  BDS_LAUNCH_CHECK();
+  int rc = exclusive_scan_u32(sums, sums, nb, temp + align_up((size_t)nb, 4), total_out, st);
+  if (rc != BDS_OK) return rc;
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, st, in, n, sums, out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stable LSD radix pass on (uint32 key, uint32 value), digit of <= 8 bits
+// ------------------------------------------------------------------------------------------
+constexpr int kSortBlock = 256;
+constexpr int kSortRounds = 16;
+constexpr int kSortChunk = kSortBlock * kSortRounds;  // 4096 pairs per workgroup
+constexpr int kSortWaves = kSortBlock / kWave;
+
+__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift,
+                                                               uint32_t mask, int nblocks,
+                                                               uint32_t *__restrict__ hist /*[256][nblocks]*/) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; r++) {
+    int64_t i = base + r * kSortBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x <= mask) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift, uint32_t mask,
+    int bits, int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out) {
+  __shared__ uint32_t run[256];               // global position of the next element of each digit
+  __shared__ uint32_t wcnt[kSortWaves][256];  // per-wave digit counts of the current round
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  run[tid] = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; w++) wcnt[w][tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = base + r * kSortBlock + tid;
+    if (base + r * kSortBlock >= n) break;  // uniform
+    const bool on = i < n;
+    uint32_t k = 0, v = 0, d = 0;
+    if (on) { k = keys_in[i]; v = vals_in[i]; d = (k >> shift) & mask; }
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(on);
+    for (int b = 0; b < bits; b++) {
+      unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt);
+    if (on && rank == 0) wcnt[wv][d] = __popcll(peers);
+    __syncthreads();
+    if (on) {
+      uint32_t off = run[d] + rank;
+      for (int w = 0; w < kSortWaves; w++)
+        if (w < wv) off += wcnt[w][d];
+      keys_out[off] = k;
+      vals_out[off] = v;
+    }
+    __syncthreads();
+    {
+      uint32_t s = 0;
+#pragma unroll
+      for (int w = 0; w < kSortWaves; w++) { s += wcnt[w][tid]; wcnt[w][tid] = 0; }
+      run[tid] += s;
+    }
+    __syncthreads();
+  }
+}
+
+static size_t radix_temp_elems(int64_t n) {
+  const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
+  const size_t h = align_up((size_t)256 * nblocks, 4);
+  return h + scan_temp_elems((int64_t)256 * nblocks);
+}
+
+static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift,
+                      int bits, uint32_t *temp, hipStream_t st) {
+  if (n == 0) return BDS_OK;
+  const int nblocks = (int)cdiv(n, kSortChunk);
+  const uint32_t mask = (1u << bits) - 1u;
+  const int64_t hn = (int64_t)(mask + 1) * nblocks;
+  uint32_t *hist = temp;
+  uint32_t *stemp = temp + align_up((size_t)256 * nblocks, 4);
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, nblocks, hist);
+  BDS_LAUNCH_CHECK();
+  int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
+  if (rc != BDS_OK) return rc;
+  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, shift, mask, bits, nblocks,
+                     hist, kout, vout);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// intersection kernels
+// ------------------------------------------------------------------------------------------
+constexpr int kIsectBlock = 256;
+
+// per (camera, Gaussian): number of tiles touched + depth key for the depth ordering
+__global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(int64_t CN, const float *__restrict__ means2d,
+                                                                 const int32_t *__restrict__ radii,
+                                                                 const float *__restrict__ depths, int tile_size,
+                                                                 int tile_w, int tile_h,
+                                                                 int32_t *__restrict__ tiles_per_gauss,
+                                                                 uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (o >= CN) return;
+  const int r = radii[o];
+  int cnt = 0;
+  if (r > 0) {
+    int x0, y0, x1, y1;
+    tile_rect(means2d[o * 2], means2d[o * 2 + 1], r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+    cnt = (x1 - x0) * (y1 - y0);
+  }
+  tiles_per_gauss[o] = cnt;
+  keys[o] = __float_as_uint(depths[o]);  // depth > 0 for every visible Gaussian: bits are monotone
+  vals[o] = (uint32_t)o;
+}
+
+__global__ __launch_bounds__(kIsectBlock) void gather_counts_kernel(int64_t CN, const uint32_t *__restrict__ sorted_idx,
+                                                                   const int32_t *__restrict__ tiles_per_gauss,
+                                                                   uint32_t *__restrict__ cnt_sorted) {
+  const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (j >= CN) return;
+  cnt_sorted[j] = (uint32_t)tiles_per_gauss[sorted_idx[j]];
+}
+
+// emit (camera*tiles + tile, cam*N+gaussian) pairs in depth order
+__global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(int64_t CN, int64_t N, const uint32_t *__restrict__ sorted_idx,
+                                                                const uint32_t *__restrict__ cum_sorted,
+                                                                const float *__restrict__ means2d,
+                                                                const int32_t *__restrict__ radii, int tile_size,
+                                                                int tile_w, int tile_h, uint32_t *__restrict__ keys,
+                                                                uint32_t *__restrict__ vals) {
+  const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (j >= CN) return;
+  const uint32_t o = sorted_idx[j];
+  const int r = radii[o];
+  if (r <= 0) return;
+  int x0, y0, x1, y1;
+  tile_rect(means2d[(int64_t)o * 2], means2d[(int64_t)o * 2 + 1], r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+  const uint32_t cam_base = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
+  uint32_t off = cum_sorted[j];
+  for (int ty = y0; ty < y1; ty++)
+    for (int tx = x0; tx < x1; tx++) {
+      keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
+      vals[off] = o;
+      off++;
+    }
+}
+
+// offsets[t] = first index whose key >= t  (lower bound; empty tiles point at the next run)
+__global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M, const uint32_t *__restrict__ keys,
+                                                                   int n_tiles_total, int32_t *__restrict__ offsets) {
+  const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (i > M) return;
+  // thread i < M closes the gap (key[i-1], key[i]]; thread M closes (key[M-1], n_tiles)
+  const int64_t lo = i == 0 ? 0 : (int64_t)keys[i - 1] + 1;
+  const int64_t hi = i == M ? (int64_t)n_tiles_total - 1 : (int64_t)keys[i];
+  for (int64_t t = lo; t <= hi; t++) offsets[t] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(kIsectBlock) void isect_ids_kernel(int64_t M, const uint32_t *__restrict__ keys,
+                                                               const int32_t *__restrict__ flatten_ids,
+                                                               const float *__restrict__ depths,
+                                                               int64_t *__restrict__ isect_ids) {
+  const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (i >= M) return;
+  const uint32_t d = __float_as_uint(depths[flatten_ids[i]]);
+  isect_ids[i] = (int64_t)(((uint64_t)keys[i] << 32) | (uint64_t)d);
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace layouts
+// ------------------------------------------------------------------------------------------
+struct PrepWs {
+  uint64_t *total;      // [2]
+  uint32_t *ka, *va, *kb, *vb;  // [CN] each; after prepare: sorted ids live in `sorted`
+  uint32_t *cum;        // [CN] exclusive scan of counts in depth order
+  uint32_t *temp;       // radix / scan temp
+  size_t bytes;
+};
+
+static PrepWs prep_layout(void *ws, int64_t CN) {
+  PrepWs L;
+  char *p = static_cast<char *>(ws);
+  size_t off = 0;
+  auto take = [&](size_t elems, size_t esz) {
+    char *q = p ? p + off : nullptr;
+    off += align_up(elems * esz, 256);
+    return q;
+  };
+  L.total = reinterpret_cast<uint64_t *>(take(2, 8));
+  L.ka = reinterpret_cast<uint32_t *>(take(CN, 4));
+  L.va = reinterpret_cast<uint32_t *>(take(CN, 4));
+  L.kb = reinterpret_cast<uint32_t *>(take(CN, 4));
+  L.vb = reinterpret_cast<uint32_t *>(take(CN, 4));
+  L.cum = reinterpret_cast<uint32_t *>(take(CN, 4));
+  size_t t = radix_temp_elems(CN);
+  size_t t2 = scan_temp_elems(CN);
+  L.temp = reinterpret_cast<uint32_t *>(take(t > t2 ? t : t2, 4));
+  L.bytes = off;
+  return L;
+}
+
+struct BuildWs {
+  uint32_t *ka, *va, *kb;  // [M] each (the 4th buffer is flatten_ids itself)
+  uint32_t *temp;
+  size_t bytes;
+};
+
+static BuildWs build_layout(void *ws, int64_t M) {
+  BuildWs L;
+  char *p = static_cast<char *>(ws);
+  size_t off = 0;
+  auto take = [&](size_t elems, size_t esz) {
+    char *q = p ? p + off : nullptr;
+    off += align_up(elems * esz, 256);
+    return q;
+  };
+  L.ka = reinterpret_cast<uint32_t *>(take(M, 4));
+  L.va = reinterpret_cast<uint32_t *>(take(M, 4));
+  L.kb = reinterpret_cast<uint32_t *>(take(M, 4));
+  L.temp = reinterpret_cast<uint32_t *>(take(radix_temp_elems(M), 4));
+  L.bytes = off + 256;
+  return L;
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+extern "C" size_t bds_isect_prepare_workspace_bytes(int C, int64_t N) {
+  if (C < 1 || N < 0) return 0;
+  return prep_layout(nullptr, (int64_t)C * N).bytes;
+}
+
+extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
+  (void)C; (void)N;
+  if (M < 0) return 0;
+  return build_layout(nullptr, M).bytes;
+}
+
+extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                                 int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws,
+                                 size_t ws_bytes, int64_t *n_isects, bds_stream_t stream) {
+  BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && n_isects);
+  const int64_t CN = (int64_t)C * N;
+  BDS_REQUIRE(CN < (int64_t)1 << 31);
+  BDS_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)1 << 31);
+  *n_isects = 0;
+  if (CN == 0) return BDS_OK;
+  BDS_REQUIRE(means2d && radii && depths && tiles_per_gauss && ws);
+  PrepWs L = prep_layout(ws, CN);
+  if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = (unsigned)cdiv(CN, kIsectBlock);
+  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, means2d, radii, depths, tile_size, tile_w,
+                     tile_h, tiles_per_gauss, L.ka, L.va);
+  BDS_LAUNCH_CHECK();
+  // depth order: 4 stable passes of 8 bits; ends in (ka, va)
+  uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
+  for (int p = 0; p < 4; p++) {
+    int rc = radix_pass(kin, vin, kout, vout, CN, 8 * p, 8, L.temp, st);
+    if (rc != BDS_OK) return rc;
+    uint32_t *t;
+    t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  // kin/vin == (ka, va) again after 4 swaps: va = Gaussian ids in depth order
+  hipLaunchKernelGGL(gather_counts_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, L.va, tiles_per_gauss, L.kb);
+  BDS_LAUNCH_CHECK();
+  int rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
+  if (rc != BDS_OK) return rc;
+  uint64_t total = 0;
+  if (hipMemcpyAsync(&total, L.total, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return BDS_ELAUNCH;
+  *n_isects = (int64_t)total;
+  return BDS_OK;
+}
+
+extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int32_t *radii,
+                               const float *depths, int tile_size, int tile_w, int tile_h, const void *ws,
+                               size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
+                               int32_t *isect_offsets, bds_stream_t stream) {
+  BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && isect_offsets);
+  BDS_REQUIRE(M < (int64_t)1 << 31);
+  const int64_t CN = (int64_t)C * N;
+  const int n_tiles_total = C * tile_w * tile_h;
+  hipStream_t st = as_stream(stream);
+  if (M == 0) {
+    if (hipMemsetAsync(isect_offsets, 0, sizeof(int32_t) * n_tiles_total, st) != hipSuccess) return BDS_ELAUNCH;
+    return BDS_OK;
+  }
+  BDS_REQUIRE(means2d && radii && depths && ws && ws2 && flatten_ids);
+  PrepWs P = prep_layout(const_cast<void *>(ws), CN);
+  if (ws_bytes < P.bytes) return BDS_EWORKSPACE;
+  BuildWs B = build_layout(ws2, M);
+  if (ws2_bytes < B.bytes) return BDS_EWORKSPACE;
+  // number of radix passes over the tile key
+  int nbits = 1;
+  while (((int64_t)1 << nbits) < n_tiles_total) nbits++;
+  const int npass = (nbits + 7) / 8;
+  const int bits_per = (nbits + npass - 1) / npass;
+  // buffers: pass outputs alternate so that the LAST pass writes values into flatten_ids
+  uint32_t *fl = reinterpret_cast<uint32_t *>(flatten_ids);
+  uint32_t *k_emit, *v_emit;
+  if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
+  else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
+  hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, CN, N, P.va, P.cum,
+                     means2d, radii, tile_size, tile_w, tile_h, k_emit, v_emit);
+  BDS_LAUNCH_CHECK();
+  uint32_t *kin = k_emit, *vin = v_emit;
+  for (int p = 0; p < npass; p++) {
+    uint32_t *kout = (kin == B.ka) ? B.kb : B.ka;
+    uint32_t *vout = (vin == B.va) ? fl : B.va;
+    int bits = bits_per;
+    if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
+    int rc = radix_pass(kin, vin, kout, vout, M, bits_per * p, bits, B.temp, st);
+    if (rc != BDS_OK) return rc;
+    kin = kout; vin = vout;
+  }
+  // now kin == B.kb (sorted tile keys), vin == flatten_ids
+  hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin,
+                     n_tiles_total, isect_offsets);
+  BDS_LAUNCH_CHECK();
+  if (isect_ids) {
+    hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)cdiv(M, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, flatten_ids,
+                       depths, isect_ids);
+    BDS_LAUNCH_CHECK();
+  }
+  return BDS_OK;
+}

@@ -1,0 +1,126 @@
+"""Trainer-side harness for the hot path: the call sequence of the reference's training step,
+restated around the MI355X operators, plus the synthetic scenes the benchmark and tests use.
+
+Reference call sequence being mirrored (file:line under /root/reference/project):
+  models/gaussians/vanilla.py:378-414       get_gaussians: SH colours (+0.5, clamp), activations
+  models/trainers/base.py:385-432           render_gaussians -> rasterization(...), split, clamp(max=1)
+  models/trainers/scene_graph.py:286-294    sky blend + affine_transformation
+  models/trainers/scene_graph.py:86-120     affine_transformation (bilateral maps applied per pixel)
+  models/trainers/base.py:502-516           backward
+  models/trainers/base.py:279-297           consumers of info["means2d"].absgrad / info["radii"]
+
+Scene generator: SURVEY.md 8(d) (ring rig, log-uniform ranges, anisotropic scales).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from .bilagrid import bilagrid_transform, total_variation_loss
+from .gs_ops import spherical_harmonics
+from .rendering import rasterization
+
+SIX_CAM_YAWS = (0.0, 55.0, -55.0, 110.0, -110.0, 180.0)
+FIVE_CAM_YAWS = (0.0, 45.0, -45.0, 90.0, -90.0)
+LEVELS_3 = ((2, 2, 1), (4, 4, 2), (8, 8, 4))   # configs/omnire_ms_bilateral*.yaml model.Affine.params.grid
+FACTORS_3 = (4, 4, 2)                          # modules.py:505 default guidance_factor
+LEVELS_SINGLE = ((16, 16, 8),)
+FACTORS_SINGLE = (1,)
+
+
+@dataclass
+class Camera:
+    viewmat: Tensor  # [4,4] world -> camera (OpenCV: x right, y down, z forward)
+    K: Tensor        # [3,3]
+    width: int
+    height: int
+
+
+def ring_cameras(W: int, H: int, yaws_deg: Sequence[float] = SIX_CAM_YAWS, device="cpu") -> List[Camera]:
+    """Ring rig at the origin; world frame: x forward, y left, z up (driving convention)."""
+    fx = 0.5 * W / math.tan(math.radians(35.0))
+    K = torch.tensor([[fx, 0, W / 2], [0, fx, H / 2], [0, 0, 1]], dtype=torch.float32, device=device)
+    cams = []
+    for yaw in yaws_deg:
+        a = math.radians(yaw)
+        fwd = torch.tensor([math.cos(a), math.sin(a), 0.0])
+        right = torch.tensor([math.sin(a), -math.cos(a), 0.0])
+        down = torch.tensor([0.0, 0.0, -1.0])
+        R = torch.stack([right, down, fwd])  # rows = camera axes in world coordinates
+        vm = torch.eye(4)
+        vm[:3, :3] = R
+        # rig at the origin
+        cams.append(Camera(vm.to(device), K, W, H))
+    return cams
+
+
+def synthetic_scene(N: int, seed: int = 0, device="cpu") -> Dict[str, Tensor]:
+    """Raw (pre-activation) Gaussian parameters, as the reference's VanillaGaussians holds them."""
+    g = torch.Generator().manual_seed(seed)
+    az = torch.rand(N, generator=g) * 2 * math.pi
+    rng = torch.exp(torch.rand(N, generator=g) * math.log(80.0 / 2.0) + math.log(2.0))
+    hgt = torch.rand(N, generator=g) * 8.0 - 2.0
+    means = torch.stack([rng * torch.cos(az), rng * torch.sin(az), hgt], -1)
+    log_scales = (torch.rand(N, 3, generator=g) * math.log(0.3 / 0.01) + math.log(0.01)) + torch.log(rng / 10.0)[:, None]
+    quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=-1)
+    opac_logit = torch.randn(N, generator=g) * 1.5
+    sh = torch.empty(N, 16, 3)
+    sh[:, 0] = (torch.rand(N, 3, generator=g) - 0.5) / 0.28209479177387814
+    sh[:, 1:] = torch.randn(N, 15, 3, generator=g) * 0.05
+    out = dict(means=means, log_scales=log_scales, quats=quats, opacity_logits=opac_logit, sh=sh)
+    return {k: v.to(device).contiguous() for k, v in out.items()}
+
+
+def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> List[Tensor]:
+    g = torch.Generator().manual_seed(1000 + seed)
+    out = []
+    for (gx, gy, gl) in levels:
+        ident = torch.tensor([1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]).reshape(1, 12, 1, 1, 1).repeat(n_images, 1, gl, gy, gx)
+        out.append((ident + 0.05 * torch.randn(n_images, 12, gl, gy, gx, generator=g)).to(device).contiguous())
+    return out
+
+
+def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
+                factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
+                radius_clip: float = 0.0):
+    """One view's forward: returns dict(rgb, depth, opacity, rgb_gaussians, info)."""
+    means = params["means"]
+    c2w_t = torch.linalg.inv(cam.viewmat)[:3, 3]
+    viewdirs = means.detach() - c2w_t                                       # vanilla.py:385
+    rgbs = spherical_harmonics(sh_degree, viewdirs, params["sh"])           # vanilla.py:388 (normalises inside)
+    rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)                                # vanilla.py:389
+    opac = torch.sigmoid(params["opacity_logits"])                         # vanilla.py:393
+    scales = torch.exp(params["log_scales"])
+    quats = params["quats"] / params["quats"].norm(dim=-1, keepdim=True)
+    renders, alphas, info = rasterization(                                   # trainers/base.py:393-408
+        means=means, quats=quats, scales=scales, opacities=opac, colors=rgbs, viewmats=cam.viewmat[None], Ks=cam.K[None],
+        width=cam.width, height=cam.height, packed=False, absgrad=True, sparse_grad=False, rasterize_mode="classic",
+        near_plane=near_plane, far_plane=far_plane, render_mode="RGB+ED", radius_clip=radius_clip)
+    renders = renders[0]
+    rgb_g, depth = renders[..., :3], renders[..., 3:4]                      # base.py:414 (clamp is fused below)
+    opacity = alphas[0]                                                      # [H,W,1]
+    grids_k = [g[img_idx:img_idx + 1] for g in grids]
+    rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)  # clamp + sky blend + slice + affine
+    return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
+
+
+def training_loss(out: Dict[str, Tensor], target: Tensor, grids: Sequence[Tensor], tv_weight: float = 0.01) -> Tensor:
+    """L1 photometric + TV(grids) (trainers/base.py:518-565,590-594: losses.affine.w = 0.01 for the
+    multi-scale config); every gradient path of the hot path is live."""
+    loss = (out["rgb"] - target).abs().mean()
+    for g in grids:
+        _, _, gl, gy, gx = g.shape
+        loss = loss + tv_weight * total_variation_loss(g, 0.5 * math.sqrt(gx * gy * gl))  # modules.py:445
+    return loss
+
+
+def densify_stats(info, width: int, height: int):
+    """What trainers/base.py:279-297 reads after backward."""
+    grads = info["means2d"].absgrad.clone()
+    grads[..., 0] *= width / 2.0
+    grads[..., 1] *= height / 2.0
+    return grads, info["radii"]

@@ -1,0 +1,159 @@
+/*
+ * bds.h -- C ABI of libbds.so: the MI355X (gfx950) hot path of bilateral-driving.
+ *
+ * The reference (BigCiLeng/bilateral-driving) is pure Python; its hot path is reached through
+ * two Python import surfaces, not an FFI.  The functions declared here are the device entry
+ * points those surfaces bind to (through ctypes, see bilateral_driving_amd/_lib.py and
+ * INTEGRATION.md).  Each declaration cites the reference interface it serves
+ * (paths relative to /root/reference/project).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major memory (fp32 unless noted),
+ *     owned by the caller (the torch caching allocator); nothing is allocated inside;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), except
+ *     bds_isect_prepare which must hand the intersection count back to the host;
+ *   - return value: BDS_OK or a negative BDS_E* code; never throws, never exits;
+ *   - C = cameras, N = Gaussians, M = tile intersections, H/W = image size, tile = 16.
+ */
+#ifndef BDS_H
+#define BDS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDS_ABI_VERSION 1
+
+#define BDS_OK 0
+#define BDS_EINVAL (-1)      /* null / misaligned pointer, bad shape or unsupported parameter */
+#define BDS_EWORKSPACE (-2)  /* workspace too small */
+#define BDS_ELAUNCH (-3)     /* hipGetLastError() != hipSuccess after a launch / memcpy */
+
+typedef void *bds_stream_t;
+
+int bds_abi_version(void);
+const char *bds_strerror(int code);
+
+/* ---- spherical harmonics ----------------------------------------------------------------
+ * gsplat.cuda._wrapper.spherical_harmonics(degrees_to_use, dirs, coeffs, masks=None)
+ * imported at models/gaussians/basics.py:15, called at models/gaussians/vanilla.py:388
+ * (and pvg.py:403, deformgs.py:142, nodes/rigid.py:462, deformable.py:83, smpl.py:364).
+ * dirs [n,3] (normalised inside), coeffs [n,K,3], masks [n] uint8 or NULL, out [n,3].
+ * Only the first (deg+1)^2 of the K bases are read.  v_dirs may be NULL. */
+int bds_sh_fwd(int64_t n, int K, int deg, const float *dirs, const float *coeffs, const uint8_t *masks, float *out,
+               bds_stream_t stream);
+int bds_sh_bwd(int64_t n, int K, int deg, const float *dirs, const float *coeffs, const uint8_t *masks,
+               const float *v_out, float *v_coeffs, float *v_dirs, bds_stream_t stream);
+
+/* ---- projection -------------------------------------------------------------------------
+ * first stage of gsplat.rendering.rasterization (called at models/trainers/base.py:393-408,
+ * 811-826): quat+scale -> 3D covariance, world->camera, perspective Jacobian, eps2d blur,
+ * conic, 3-sigma radius, near/far/screen culling.
+ * means [N,3] quats [N,4] (wxyz, normalised inside) scales [N,3] viewmats [C,4,4] Ks [C,3,3]
+ * -> radii [C,N] i32 (0 = culled), means2d [C,N,2], depths [C,N], conics [C,N,3],
+ *    compensations [C,N] or NULL ("antialiased" mode only).  Culled entries are zero-filled. */
+int bds_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                    const float *viewmats, const float *Ks, int W, int H, float eps2d, float near_plane,
+                    float far_plane, float radius_clip, int32_t *radii, float *means2d, float *depths, float *conics,
+                    float *compensations, bds_stream_t stream);
+/* v_means [N,3] v_quats [N,4] v_scales [N,3] are written (summed over cameras);
+ * v_viewmats [C,4,4] (NULL = not needed) is zeroed and accumulated inside
+ * (learnable camera poses: models/trainers/base.py:328-329,399).
+ * v_compensations / compensations may be NULL. */
+int bds_project_bwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                    const float *viewmats, const float *Ks, int W, int H, float eps2d, const int32_t *radii,
+                    const float *conics, const float *compensations, const float *v_means2d, const float *v_depths,
+                    const float *v_conics, const float *v_compensations, float *v_means, float *v_quats,
+                    float *v_scales, float *v_viewmats, bds_stream_t stream);
+
+/* ---- tile intersection + (tile|depth) ordering -------------------------------------------
+ * isect_tiles + radix sort + isect_offset_encode stages of gsplat.rendering.rasterization.
+ * Two calls because the host must size the [M] outputs:
+ *   bds_isect_prepare : counts tiles per Gaussian, depth-orders the Gaussians, scans the
+ *                       counts; synchronises `stream` and returns M in *n_isects.
+ *   bds_isect_build   : emits (camera*tiles+tile, id) pairs in depth order, stable-sorts them
+ *                       by tile, writes flatten_ids [M] i32 (= cam*N+gaussian), isect_offsets
+ *                       [C,th,tw] i32 and, if not NULL, isect_ids [M] i64
+ *                       (cam|tile id << 32 | fp32 depth bits), identical to sorting the 64-bit
+ *                       keys directly.
+ * `ws` (bds_isect_prepare_workspace_bytes) must stay alive and untouched between the two calls;
+ * `ws2` (bds_isect_build_workspace_bytes) is scratch for build.  M must be < 2^31. */
+size_t bds_isect_prepare_workspace_bytes(int C, int64_t N);
+size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M);
+int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                      int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws, size_t ws_bytes,
+                      int64_t *n_isects, bds_stream_t stream);
+int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int32_t *radii, const float *depths,
+                    int tile_size, int tile_w, int tile_h, const void *ws, size_t ws_bytes, void *ws2,
+                    size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
+                    bds_stream_t stream);
+
+/* ---- alpha compositing -------------------------------------------------------------------
+ * rasterize_to_pixels stage of gsplat.rendering.rasterization; outputs consumed at
+ * models/trainers/base.py:409-419 (render, alphas) and :280-297 (means2d.absgrad).
+ * CH in {1,3,4}.  means2d [C,N,2] conics [C,N,3] colors [C,N,CH] opacities [C,N]
+ * backgrounds [C,CH] or NULL -> render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] i32. */
+int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
+                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                      float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
+/* Gradient outputs must be zero-filled by the caller (they are accumulated with atomics).
+ * v_means2d_abs may be NULL (absgrad=False). */
+int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
+                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                      const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
+                      float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors, float *v_opacities,
+                      bds_stream_t stream);
+
+/* ---- bilateral grid ----------------------------------------------------------------------
+ * Point slice: bilateral/lib_bilagrid.py:317-368 BilateralGrid.forward (F.grid_sample,
+ * trilinear, align_corners=True, padding_mode="border") used by slice() :171-230.
+ * grid [12,L,gy,gx]; xy [P,2] in [0,1]; rgb [P,3] (guidance = BT.601 gray) -> affine [P,12].
+ * bwd accumulates into v_grid (caller zero-fills) and writes v_rgb [P,3] (guidance route only). */
+int bds_bilagrid_slice_fwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy, const float *rgb,
+                           float *affine, bds_stream_t stream);
+int bds_bilagrid_slice_bwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy, const float *rgb,
+                           const float *v_affine, float *v_grid, float *v_rgb, bds_stream_t stream);
+
+/* Fused image transform: models/modules.py:505-522 MultiScaleBilateralAffineTransform.forward
+ * (train branch: get_sample_grid :494-504, slice, fill_matrix_res :409-420), the single-scale
+ * BilateralAffineTransform.forward :317-335 (factor 1), the sequential application at
+ * models/trainers/scene_graph.py:95-98,112-117, and optionally the clamp + sky blend in front of
+ * it (trainers/base.py:417, scene_graph.py:292-294).
+ *
+ * Level l: grid [n_avg, 12, L, gy, gx] (n_avg = 1 for training; > 1 averages the low-res
+ * slices of neighbouring frames' grids = the test branch, modules.py:523-535).
+ * If sky != NULL the input colour is clamp(rgb, max=1) + sky * (1 - alpha). */
+#define BDS_MAX_LEVELS 8
+typedef struct {
+  const float *grid; /* [n_avg,12,gl,gy,gx] */
+  float *v_grid;     /* same shape, accumulated (caller zero-fills); may be NULL in fwd */
+  int32_t gx, gy, gl, factor, n_avg;
+} bds_bilagrid_level_t;
+
+size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagrid_level_t *levels, int H, int W);
+/* ws keeps the low-resolution affine maps (fwd -> bwd). affine_out (NULL or nlevels x [H,W,12]
+ * pointers) receives the full-resolution per-level maps the reference module returns. */
+int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
+                        const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
+                        float *const *affine_out, bds_stream_t stream);
+/* v_rgb [H,W,3] written; v_alpha [H,W], v_sky [H,W,3] written when sky != NULL. */
+int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
+                        const float *alpha, const float *sky, void *ws, size_t ws_bytes, const float *v_rgb_out,
+                        float *v_rgb, float *v_alpha, float *v_sky, bds_stream_t stream);
+
+/* TV regulariser: bilateral/lib_bilagrid.py:152-168 total_variation_loss on [n,12,L,gy,gx].
+ * tv_out [1] is accumulated (caller zero-fills) with weight*tv; v_grids += weight*v_tv*dtv/dgrid. */
+int bds_bilagrid_tv_fwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, float *tv_out,
+                        bds_stream_t stream);
+int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
+                        float *v_grids, bds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDS_H */

@@ -83,7 +83,10 @@ def slice_grid(grid: torch.Tensor, x: torch.Tensor, y: torch.Tensor, gray: torch
     C, L, gy, gx = grid.shape
     ix = _unnormalize(x, gx)
     iy = _unnormalize(y, gy)
-    iz = torch.clamp((((gray * 2 - 1) + 1) / 2) * (L - 1), 0, L - 1)
+    vz = (((gray * 2 - 1) + 1) / 2) * (L - 1)
+    # grid_sample's border clip passes NO gradient on the closed boundary (v <= 0 or v >= L-1),
+    # unlike torch.clamp; x/y carry no gradient in this path.
+    iz = torch.where((vz > 0) & (vz < L - 1), vz, vz.detach().clamp(0, L - 1))
     x0f, y0f, z0f = ix.floor(), iy.floor(), iz.floor()
     fx, fy, fz = ix - x0f, iy - y0f, iz - z0f
     x0, y0, z0 = x0f.long(), y0f.long(), z0f.long()

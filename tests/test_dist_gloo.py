@@ -1,0 +1,92 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU exchange step: flat gradient buffer + one
+sum-all-reduce == sequential accumulation over the same views on one process."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy_loss(params, view):
+    # any differentiable function of the shared parameters that depends on the view
+    w = torch.linspace(0.5, 1.5, params[0].numel()).reshape(params[0].shape) * (view + 1)
+    return (params[0] * w).sum() + (params[1] ** 2).sum() * (view + 2) + (params[2].sin() * (view + 1)).sum()
+
+
+def _make_params():
+    g = torch.Generator().manual_seed(0)
+    return [torch.randn(7, 3, generator=g).requires_grad_(True), torch.randn(7, 16, 3, generator=g).requires_grad_(True),
+            torch.randn(5, generator=g).requires_grad_(True)]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd.dist import FlatGradients, reduce_densify_stats, view_for_rank
+    params = _make_params()
+    flat = FlatGradients(params)
+    outs = []
+    for step in range(3):
+        flat.zero()
+        v = view_for_rank(step, rank, world, 6)
+        _toy_loss(params, v).backward()
+        flat.check_views()  # autograd accumulated in place into the communication buffer
+        flat.all_reduce()
+        outs.append(flat.flat.clone())
+    a, b, c = torch.full((4,), float(rank + 1)), torch.full((4,), float(rank + 1)), torch.tensor([1.0, 5.0, 2.0, 0.0]) * (rank + 1)
+    reduce_densify_stats(a, b, c)
+    q.put((rank, [o.numpy() for o in outs], a.numpy(), c.numpy()))
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_equals_sequential_sum():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    from bilateral_driving_amd.dist import view_for_rank
+    for step in range(3):
+        params = _make_params()
+        for r in range(world):
+            _toy_loss(params, view_for_rank(step, r, world, 6)).backward()  # sequential accumulation on one process
+        ref = torch.cat([p.grad.reshape(-1) for p in params]).numpy()
+        for r in range(world):
+            assert abs(res[r][1][step] - ref).max() < 1e-5
+    assert res[0][2].tolist() == [3.0] * 4           # sum of (1, 2)
+    assert res[0][3].tolist() == [2.0, 10.0, 4.0, 0.0]  # max
+
+
+def test_flat_gradients_single_process():
+    from bilateral_driving_amd.dist import FlatGradients
+    params = _make_params()
+    flat = FlatGradients(params)
+    assert flat.nbytes == 4 * sum(p.numel() for p in params)
+    _toy_loss(params, 0).backward()
+    g0 = flat.flat.clone()
+    assert float(g0.abs().sum()) > 0
+    assert flat.all_reduce() is None  # no process group: no-op
+    flat.zero()
+    assert float(flat.flat.abs().sum()) == 0 and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, flat.views))
+    params[0].grad = None  # e.g. optimizer.zero_grad(set_to_none=True)
+    flat.zero()
+    _toy_loss(params, 0).backward()
+    assert torch.equal(flat.flat, g0)

@@ -1,0 +1,149 @@
+"""Pins of oracle/gs_oracle.py that do not need gsplat (PARITY UNPINNED, see its header):
+known answers, independent scalar loop, finite differences, invariances.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle as G
+from tests.util import make_scene
+
+F64 = torch.float64
+
+
+def test_sh_bases_match_closed_form():
+    d = torch.randn(500, 3, dtype=F64)
+    assert (G.sh_bases(3, d) - G.sh_bases_closed_form(d)).abs().max() < 1e-14
+    # C0 is the one constant the reference itself pins (models/gaussians/basics.py:76-89)
+    assert abs(float(G.sh_bases(0, d)[0, 0]) - 0.28209479177387814) < 1e-15
+    # degree truncation uses a prefix of the same bases
+    assert torch.equal(G.sh_bases(2, d), G.sh_bases(3, d)[:, :9])
+
+
+def test_sh_orthonormal_on_sphere():
+    # Monte-Carlo check that the 16 bases are orthonormal: pins signs/constants up to permutation
+    g = torch.Generator().manual_seed(0)
+    d = torch.randn(400000, 3, generator=g, dtype=F64)
+    B = G.sh_bases(3, d)
+    gram = (B.T @ B) / d.shape[0] * 4 * math.pi
+    assert (gram - torch.eye(16, dtype=F64)).abs().max() < 2e-2
+
+
+def test_projection_known_answer():
+    # isotropic Gaussian on the optical axis: covariance (s*fx/z)^2 + eps2d, mean at principal point
+    s, z, fx = 0.2, 4.0, 100.0
+    means = torch.tensor([[0.0, 0.0, z]], dtype=F64)
+    quats = torch.tensor([[0.3, -0.5, 0.1, 0.8]], dtype=F64)
+    scales = torch.full((1, 3), s, dtype=F64)
+    K = torch.tensor([[fx, 0, 32.0], [0, fx, 24.0], [0, 0, 1]], dtype=F64)
+    radii, m2, dep, con, comp = G.project(means, quats, scales, torch.eye(4, dtype=F64), K, 64, 48, calc_compensations=True)
+    var = (s * fx / z) ** 2 + 0.3
+    assert torch.allclose(m2, torch.tensor([[32.0, 24.0]], dtype=F64))
+    assert abs(float(dep) - z) < 1e-12
+    assert torch.allclose(con, torch.tensor([[1 / var, 0.0, 1 / var]], dtype=F64), atol=1e-12)
+    assert int(radii) == math.ceil(3 * math.sqrt(var))
+    assert abs(float(comp) - ((s * fx / z) ** 2) / var) < 1e-12
+    # behind the near plane / off screen -> culled, outputs zero
+    r2, m22, _, _, _ = G.project(torch.tensor([[0.0, 0.0, 0.005], [50.0, 0, 4.0]], dtype=F64), quats.repeat(2, 1),
+                                 scales.repeat(2, 1), torch.eye(4, dtype=F64), K, 64, 48)
+    assert r2.tolist() == [0, 0] and float(m22.abs().max()) == 0.0
+
+
+def test_single_gaussian_image_known_answer():
+    # one isotropic Gaussian: alpha(p) = o * exp(-|p-mu|^2 / (2 var)) inside the 3-sigma tile box
+    s, z, fx, o = 0.3, 5.0, 80.0, 0.8
+    W, H = 48, 32
+    means = torch.tensor([[0.0, 0.0, z]], dtype=F64)  # on the optical axis: the 2D footprint is exactly isotropic
+    K = torch.tensor([[fx, 0, W / 2 + 1.3], [0, fx, H / 2 - 0.7], [0, 0, 1]], dtype=F64)
+    col = torch.tensor([[0.2, 0.5, 0.9]], dtype=F64)
+    r, a, meta = G.rasterization(means, torch.tensor([[1.0, 0, 0, 0]], dtype=F64), torch.full((1, 3), s, dtype=F64),
+                                 torch.tensor([o], dtype=F64), col, torch.eye(4, dtype=F64)[None], K[None], W, H,
+                                 render_mode="RGB+ED")
+    var = (s * fx / z) ** 2 + 0.3
+    mu = torch.tensor([W / 2 + 1.3, H / 2 - 0.7], dtype=F64)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=F64) + 0.5, torch.arange(W, dtype=F64) + 0.5, indexing="ij")
+    alpha = o * torch.exp(-((xs - mu[0]) ** 2 + (ys - mu[1]) ** 2) / (2 * var))
+    alpha = torch.where(alpha >= 1 / 255, alpha.clamp(max=0.999), torch.zeros_like(alpha))
+    # tiles touched by the bounding square
+    rad = float(meta["radii"][0, 0])
+    tmask = torch.zeros(H, W, dtype=torch.bool)
+    x0, x1 = int(math.floor((mu[0] - rad) / 16)), int(math.ceil((mu[0] + rad) / 16))
+    y0, y1 = int(math.floor((mu[1] - rad) / 16)), int(math.ceil((mu[1] + rad) / 16))
+    tmask[max(y0, 0) * 16:y1 * 16, max(x0, 0) * 16:x1 * 16] = True
+    alpha = alpha * tmask
+    assert (a[0, ..., 0] - alpha).abs().max() < 1e-12
+    assert (r[0, ..., :3] - alpha[..., None] * col[0]).abs().max() < 1e-12
+    assert (r[0, ..., 3][alpha > 0] - z).abs().max() < 1e-9  # expected depth of a single Gaussian is its depth
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_vectorised_blend_matches_scalar_loop(seed):
+    sc = make_scene(150, 48, 40, seed=seed, dtype=F64)
+    r, a, meta = G.rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], sc["viewmats"],
+                                 sc["Ks"], 48, 40, render_mode="RGB+D")
+    col = torch.cat([sc["colors"], meta["depths"][0][:, None]], -1)
+    r2, a2, l2 = G.rasterize_pixel_loop(meta["means2d"][0], meta["conics"][0], col, sc["opacities"], 48, 40, 16,
+                                        meta["isect_offsets"][0], meta["flatten_ids"][0])
+    assert (r[0] - r2.double()).abs().max() < 1e-5  # the loop stores float32
+    assert (a[0] - a2.double()).abs().max() < 1e-6
+    assert torch.equal(meta["last_ids"][0], l2)
+    assert float(a.mean()) > 0.2  # the scene is not trivial
+
+
+def test_isect_sorted_and_offsets():
+    sc = make_scene(300, 64, 48, seed=3, dtype=torch.float32)
+    _, _, meta = G.rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], sc["viewmats"],
+                                 sc["Ks"], 64, 48)
+    ids = meta["isect_ids"][0]
+    assert torch.all(ids[1:] >= ids[:-1])
+    assert ids.numel() == int(meta["tiles_per_gauss"].sum())
+    tid = ids >> 32
+    offs = meta["isect_offsets"][0].reshape(-1).long()
+    for t in range(offs.numel()):
+        e = offs[t + 1] if t + 1 < offs.numel() else ids.numel()
+        assert torch.all(tid[offs[t]:e] == t)
+    # depth bits in the low word
+    dep = meta["depths"][0][meta["flatten_ids"][0].long()]
+    assert torch.equal((ids & 0xFFFFFFFF).to(torch.int32), dep.view(torch.int32))
+
+
+def test_permutation_invariance():
+    sc = make_scene(120, 48, 32, seed=5, dtype=F64)
+    r, a, _ = G.rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], sc["viewmats"], sc["Ks"], 48, 32)
+    p = torch.randperm(120, generator=torch.Generator().manual_seed(1))
+    r2, a2, _ = G.rasterization(sc["means"][p], sc["quats"][p], sc["scales"][p], sc["opacities"][p], sc["colors"][p],
+                                sc["viewmats"], sc["Ks"], 48, 32)
+    assert (r - r2).abs().max() < 1e-12 and (a - a2).abs().max() < 1e-12
+
+
+def test_gradients_match_finite_differences():
+    sc = make_scene(12, 32, 32, seed=7, dtype=F64, spread=0.5)
+    params = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    vm = sc["viewmats"].clone().requires_grad_(True)
+    wt = torch.randn(1, 32, 32, 4, generator=torch.Generator().manual_seed(0), dtype=F64)
+    wa = torch.randn(1, 32, 32, 1, generator=torch.Generator().manual_seed(1), dtype=F64)
+
+    def loss_fn(means, quats, scales, opacities, colors, vmx):
+        r, a, _ = G.rasterization(means, quats, scales, opacities, colors, vmx, sc["Ks"], 32, 32, render_mode="RGB+ED")
+        return (r * wt).sum() + (a * wa).sum()
+
+    loss = loss_fn(*params.values(), vm)
+    loss.backward()
+    eps = 1e-6
+    rng = np.random.RandomState(0)
+    for name, p in list(params.items()) + [("viewmats", vm)]:
+        flat = p.detach().reshape(-1)
+        for idx in rng.choice(flat.numel(), size=min(6, flat.numel()), replace=False):
+            if name == "viewmats" and idx >= 12:
+                continue  # bottom row is not used
+            vals = []
+            for sgn in (+1, -1):
+                q = flat.clone()
+                q[idx] += sgn * eps
+                args = [q.reshape(p.shape) if n == name else v.detach() for n, v in params.items()]
+                vmx = q.reshape(vm.shape) if name == "viewmats" else vm.detach()
+                vals.append(float(loss_fn(*args, vmx)))
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            an = float(p.grad.reshape(-1)[idx])
+            assert abs(fd - an) <= 1e-4 * max(1.0, abs(fd)), (name, idx, fd, an)
