@@ -172,6 +172,9 @@ def test_rasterization_end_to_end(ops, seed, N, W, H, mode):
     ((r_ref * wt.double()).sum() + (a_ref * wa.double()).sum()).backward()
     ((r * wt.cuda()).sum() + (a * wa.cuda()).sum()).backward()
     for k in ref_in:
+        if ref_in[k].grad is None:  # e.g. colours in depth-only modes
+            assert gpu_in[k].grad is None or float(gpu_in[k].grad.abs().max()) == 0.0
+            continue
         got, ref = gpu_in[k].grad.cpu().double(), ref_in[k].grad
         rel = float((got - ref).norm() / ref.norm())
         assert rel < 1e-3, (k, rel)
