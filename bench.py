@@ -46,19 +46,19 @@ def parse():
     ap.add_argument("--cpu-sample-gaussians", type=int, default=100000)
     ap.add_argument("--cpu-sample-width", type=int, default=960)
     ap.add_argument("--cpu-sample-height", type=int, default=540)
+    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--cpu-timeout", type=float, default=150.0)
+    ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """oracle/ (pure-PyTorch port of the same pipeline) on the host cores, bounded sample."""
+def _cpu_iter_fn(N, W, H):
+    """One fwd+bwd of the oracle/ port (the checker; here only as the timed CPU baseline)."""
     from bilateral_driving_amd import harness as Hn
     from oracle import bilagrid_oracle as BO
     from oracle import gs_oracle as G
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    N, W, H = args.cpu_sample_gaussians, args.cpu_sample_width, args.cpu_sample_height
     cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,))[0]
     p = Hn.synthetic_scene(N, seed=0)
     grids = Hn.make_grids(1)
@@ -78,25 +78,59 @@ def cpu_baseline(args):
         loss = (rgb - target).abs().mean() + 0.01 * BO.multiscale_tv(g)
         loss.backward()
 
+    return one
+
+
+def cpu_baseline_worker(args):
+    """Runs in a child process (so that a pathological host cannot hang the benchmark): times the
+    oracle/ port on a bounded sample and prints one JSON object."""
+    threads = args.cpu_threads
+    torch.set_num_threads(threads)
+    small = (20000, 480, 270)
+    big = (args.cpu_sample_gaussians, args.cpu_sample_width, args.cpu_sample_height)
+    one = _cpu_iter_fn(*small)
+    one()  # warm-up (allocator, thread pool)
     t0 = time.perf_counter()
     one()
-    dt = time.perf_counter() - t0
-    reps = 1
-    if dt < 8.0:  # aim at ~10-30 s of CPU work in total
-        reps = max(1, min(5, int(16.0 / max(dt, 1e-3))))
+    t_small = time.perf_counter() - t0
+    sample, dt, reps = small, t_small, 1
+    # the big sample costs ~15x the small one (measured); only run it if it fits the 10-30 s budget
+    if t_small * 15.0 < 35.0:
+        one = _cpu_iter_fn(*big)
         t0 = time.perf_counter()
-        for _ in range(reps):
-            one()
-        dt = (time.perf_counter() - t0) / reps
-    return {
-        "value": 1.0 / dt, "unit": "iters/sec", "cores": cores, "kind": "port",
-        "sample": f"{N} Gaussians, one {W}x{H} view, SH3 + 3-level bilateral grid, fwd+bwd, fp32 torch CPU oracle, "
-                  f"{reps} rep(s); NOT the GPU workload size",
-    }
+        one()
+        dt = time.perf_counter() - t0
+        sample = big
+    print(json.dumps({
+        "value": 1.0 / dt, "unit": "iters/sec", "cores": threads, "kind": "port",
+        "sample": f"{sample[0]} Gaussians, one {sample[1]}x{sample[2]} view, SH3 + 3-level bilateral grid, fwd+bwd, fp32 "
+                  f"pure-PyTorch CPU port (oracle/), {reps} rep; NOT the GPU workload size "
+                  f"(host has {os.cpu_count()} logical CPUs, {threads} torch threads used)",
+    }))
+
+
+def cpu_baseline(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", str(args.cpu_threads),
+           "--cpu-sample-gaussians", str(args.cpu_sample_gaussians), "--cpu-sample-width", str(args.cpu_sample_width),
+           "--cpu-sample-height", str(args.cpu_sample_height)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(args.cpu_threads), MKL_NUM_THREADS=str(args.cpu_threads))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # timeout or failure: report it, never hang the benchmark
+        return {"value": None, "unit": "iters/sec", "cores": args.cpu_threads, "kind": "port",
+                "sample": f"not measured: {type(e).__name__} (limit {args.cpu_timeout}s)"}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        cpu_baseline_worker(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

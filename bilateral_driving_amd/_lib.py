@@ -31,6 +31,8 @@ class BdsLevel(C.Structure):
 _SIGS = {
     "bds_abi_version": (C.c_int, []),
     "bds_strerror": (C.c_char_p, [_i]),
+    "bds_set_option": (_i, [_i, _i]),
+    "bds_get_option": (_i, [_i]),
     "bds_sh_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f]),
     "bds_sh_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_project_fwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f]),
@@ -80,6 +82,13 @@ def lib():
             raise BdsError(f"libbds.so ABI {handle.bds_abi_version()} != expected {ABI_VERSION}")
         _lib = handle
     return _lib
+
+
+OPT_RASTER_BWD, OPT_RADIX = 0, 1
+
+
+def set_option(which: int, value: int) -> None:
+    check(lib().bds_set_option(which, value), "bds_set_option")
 
 
 def check(code: int, what: str) -> None:

@@ -12,3 +12,16 @@ extern "C" const char *bds_strerror(int code) {
     default: return "unknown bds error";
   }
 }
+
+namespace bds {
+// defaults: the fastest verified variants
+static int g_options[kOptCount] = {/*raster_bwd*/ 2, /*radix*/ 1, 0, 0, 0, 0, 0, 0};
+int option_get(int which) { return (which >= 0 && which < kOptCount) ? g_options[which] : 0; }
+}  // namespace bds
+
+extern "C" int bds_set_option(int which, int value) {
+  if (which < 0 || which >= bds::kOptCount) return BDS_EINVAL;
+  bds::g_options[which] = value;
+  return BDS_OK;
+}
+extern "C" int bds_get_option(int which) { return bds::option_get(which); }

@@ -37,4 +37,24 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int total) {
   return bid;
 }
 
+
+// ---- wave64 sum that leaves the total in lane 63 (VALU-only: DPP row shifts + row broadcasts) --
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_f<0x111, 0xf, true>(v);   // row_shr:1
+  v += dpp_f<0x112, 0xf, true>(v);   // row_shr:2
+  v += dpp_f<0x114, 0xf, true>(v);   // row_shr:4
+  v += dpp_f<0x118, 0xf, true>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_f<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1,3
+  v += dpp_f<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+  return v;
+}
+
+// run-time selectable kernel variants (bds_set_option): A/B measurement and bisecting
+enum Option { kOptRasterBwd = 0, kOptRadix = 1, kOptCount = 8 };
+int option_get(int which);
+
 }  // namespace bds

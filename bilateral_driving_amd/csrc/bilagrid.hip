@@ -185,8 +185,8 @@ __device__ __forceinline__ void grid_accumulate(float *acc, int addr, float val,
   const int a0 = __builtin_amdgcn_readfirstlane(active ? addr : -1);
   const bool uniform = __all(!active || addr == a0) && __any(active) && a0 >= 0;
   if (uniform) {
-    const float s = wave_sum_all(active ? val : 0.f);
-    if ((threadIdx.x & (kWave - 1)) == 0 && s != 0.f) atomicAdd(acc + a0, s);
+    const float s = wave_sum_to_lane63(active ? val : 0.f);  // VALU-only (DPP); total lands in lane 63
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1 && s != 0.f) atomicAdd(acc + a0, s);
   } else if (active && val != 0.f) {
     atomicAdd(acc + addr, val);
   }

@@ -19,32 +19,69 @@ namespace bds {
 constexpr int kTile = 16;
 constexpr int kRastBlock = kTile * kTile;  // 256
 
-// ---- wave64 sum that leaves the total in lane 63 (VALU-only: DPP row shifts + row broadcasts) --
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, BOUND));
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v += dpp_f<0x111, 0xf, true>(v);   // row_shr:1
-  v += dpp_f<0x112, 0xf, true>(v);   // row_shr:2
-  v += dpp_f<0x114, 0xf, true>(v);   // row_shr:4
-  v += dpp_f<0x118, 0xf, true>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
-  v += dpp_f<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1,3
-  v += dpp_f<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
-  return v;
-}
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
 }
 
-template <int CH>
-struct Staged {
-  float4 a;  // x, y, conic.a, conic.b
-  float4 b;  // conic.c, opacity, col0, col1
-  float4 c;  // col2, col3, -, -
+// ---- 16-value wave64 transpose-reduce ----------------------------------------------------------
+// Sums 16 per-lane values over the 64 lanes in 35 VALU instructions (vs 16 x 6 for one-at-a-time
+// DPP reductions): every step halves the number of live registers while it halves the lane distance
+// -- v_permlane32_swap / v_permlane16_swap (gfx950) across rows, DPP row_ror / half_mirror / quad_perm
+// inside a row.  On return lane l holds the wave total of value  k(l) = b2 + 2*b3 + 4*(l >> 4)
+// (b2, b3 = bits 2, 3 of l), identical in the four lanes of each quad.
+__device__ __forceinline__ int butterfly_slot(int lane) { return ((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + 4 * (lane >> 4); }
+
+__device__ __forceinline__ float swap_add32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float butterfly_sum16(const float *v, int lane) {
+  float s[8], t[4];
+#pragma unroll
+  for (int i = 0; i < 8; i++) s[i] = swap_add32(v[i], v[i + 8]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t[i] = swap_add16(s[i], s[i + 4]);
+  const bool b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+  float u[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const float sa = t[j] + dpp_f<0x128, 0xf, false>(t[j]);          // row_ror:8
+    const float sb = t[j + 2] + dpp_f<0x128, 0xf, false>(t[j + 2]);
+    u[j] = b3 ? sb : sa;
+  }
+  const float sa = u[0] + dpp_f<0x141, 0xf, false>(u[0]);            // row_half_mirror
+  const float sb = u[1] + dpp_f<0x141, 0xf, false>(u[1]);
+  float w = b2 ? sb : sa;
+  w += dpp_f<0xB1, 0xf, false>(w);                                   // quad_perm [1,0,3,2]
+  w += dpp_f<0x4E, 0xf, false>(w);                                   // quad_perm [2,3,0,1]
+  return w;
+}
+
+// value slots of the per-Gaussian gradient record that is reduced over a tile's pixels
+//   0-3 colour, 4-6 conic, 7-8 mean2d, 9-10 |mean2d| (absgrad), 11 opacity
+struct GradTarget {
+  float *ptr;   // nullptr: this lane does not commit anything
+  int stride;
 };
+template <int CH, bool ABS>
+__device__ __forceinline__ GradTarget grad_target(int lane, float *v_means2d, float *v_means2d_abs, float *v_conics,
+                                                  float *v_colors, float *v_opacities) {
+  GradTarget g{nullptr, 0};
+  if (lane & 3) return g;  // one committing lane per quad
+  const int k = butterfly_slot(lane);
+  if (k < 4) { if (k < CH) { g.ptr = v_colors + k; g.stride = CH; } }
+  else if (k < 7) { g.ptr = v_conics + (k - 4); g.stride = 3; }
+  else if (k < 9) { g.ptr = v_means2d + (k - 7); g.stride = 2; }
+  else if (k < 11) { if (ABS) { g.ptr = v_means2d_abs + (k - 9); g.stride = 2; } }
+  else if (k == 11) { g.ptr = v_opacities; g.stride = 1; }
+  return g;
+}
 
 template <int CH>
 __device__ __forceinline__ void stage_gaussian(int32_t g, const float *__restrict__ means2d,
@@ -122,7 +159,9 @@ __global__ __launch_bounds__(kRastBlock) void rasterize_fwd_kernel(
   }
 }
 
-template <int CH, bool ABS>
+// REDUCE = 0: one DPP wave-reduction per gradient value, 13 single-lane atomics per (Gaussian, wave)
+// REDUCE = 1: 16-value transpose-reduce (butterfly_sum16), one 12-lane atomic instruction
+template <int CH, bool ABS, int REDUCE>
 __global__ __launch_bounds__(kRastBlock) void rasterize_bwd_kernel(
     int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
@@ -162,6 +201,7 @@ __global__ __launch_bounds__(kRastBlock) void rasterize_bwd_kernel(
     for (int k = 0; k < CH; k++) bgdot += backgrounds[cam * CH + k] * vr[k];
   }
   const int wave_bin_final = wave_max_i32(bin_final);
+  const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
   for (int b = 0; b < nbatch; b++) {
     __syncthreads();
     const int batch_end = end - 1 - kRastBlock * b;
@@ -216,6 +256,13 @@ __global__ __launch_bounds__(kRastBlock) void rasterize_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < CH; k++) buffer[k] += col[k] * fac;
       }
+      if (REDUCE == 1) {
+        float v[16] = {g_col[0], g_col[1], g_col[2], g_col[3], g_conic[0], g_conic[1], g_conic[2], g_xy[0], g_xy[1],
+                       g_xy_abs[0], g_xy_abs[1], g_opac, 0.f, 0.f, 0.f, 0.f};
+        const float tot = butterfly_sum16(v, lane);
+        if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
+        continue;
+      }
       // wave64 reduction (DPP), then one atomic per value per wave
 #pragma unroll
       for (int k = 0; k < CH; k++) g_col[k] = wave_sum_to_lane63(g_col[k]);
@@ -241,6 +288,133 @@ __global__ __launch_bounds__(kRastBlock) void rasterize_bwd_kernel(
         }
         atomicAdd(v_opacities + g, g_opac);
       }
+    }
+  }
+}
+
+// ---- backward, one wave64 per 16x16 tile, four pixels per lane ------------------------------------
+// Lane l owns column l % 16 and rows (l / 16) + 4q, q = 0..3: the four pixels share dx, and their
+// partial gradients are summed in registers before the single 16-value transpose-reduce, so the
+// cross-lane work and the atomics are paid once per (Gaussian, tile) instead of once per wave.
+// Strip q (rows 4q..4q+3) is skipped as a whole when none of its 64 pixels needs the Gaussian.
+template <int CH, bool ABS>
+__global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
+    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
+    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
+    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  __shared__ int32_t sId[kWave];
+  const int n_tiles = tile_w * tile_h;
+  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int cam = item / n_tiles, tile = item - cam * n_tiles;
+  const int ty = tile / tile_w, tx = tile - ty * tile_w;
+  const int lane = threadIdx.x;
+  const int start = offsets[item];
+  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
+  if (end <= start) return;
+  const int j = tx * kTile + (lane & 15);
+  const float px = (float)j + 0.5f;
+  const int i0 = ty * kTile + (lane >> 4);
+  bool inside[4];
+  float T[4], T_final[4], vra[4], buffer[4][4], vr[4][4], bgdot[4];
+  int bin_final[4];
+  int max_bin = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = i0 + 4 * q;
+    inside[q] = i < H && j < W;
+    const int64_t pix = ((int64_t)cam * H + (inside[q] ? i : 0)) * W + (inside[q] ? j : 0);
+    T_final[q] = inside[q] ? 1.f - alphas[pix] : 1.f;
+    T[q] = T_final[q];
+    bin_final[q] = inside[q] ? last_ids[pix] : 0;
+    max_bin = max(max_bin, bin_final[q]);
+    vra[q] = inside[q] ? v_alphas[pix] : 0.f;
+    bgdot[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      buffer[q][k] = 0.f;
+      vr[q][k] = (k < CH && inside[q]) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
+      if (backgrounds && k < CH) bgdot[q] += backgrounds[cam * CH + k] * vr[q][k];
+    }
+  }
+  const int tile_bin_final = wave_max_i32(max_bin);
+  const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
+  const int py0 = i0;
+  const int nbatch = (end - start + kWave - 1) / kWave;
+  for (int b = 0; b < nbatch; b++) {
+    const int batch_end = end - 1 - kWave * b;
+    if (batch_end - (kWave - 1) > tile_bin_final) continue;  // whole batch lies behind every pixel's last Gaussian
+    __syncthreads();
+    const int bs = min(kWave, batch_end + 1 - start);
+    const int idx = batch_end - lane;
+    if (idx >= start) {
+      const int32_t g = flatten_ids[idx];
+      float4 A, B, Cc;
+      stage_gaussian<CH>(g, means2d, conics, colors, opacities, A, B, Cc);
+      sId[lane] = g; sA[lane] = A; sB[lane] = B;
+      if (CH > 2) sC[lane] = Cc;
+    }
+    __syncthreads();
+    for (int t = max(0, batch_end - tile_bin_final); t < bs; t++) {
+      const float4 A = sA[t], B = sB[t];
+      const float dx = A.x - px;
+      const float opac = B.y;
+      const float hax2 = 0.5f * A.z * dx * dx, bdx = A.w * dx;
+      float dy[4], vis[4], alpha[4];
+      bool valid[4];
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        dy[q] = A.y - ((float)(py0 + 4 * q) + 0.5f);
+        const float sigma = hax2 + (0.5f * B.x * dy[q] + bdx) * dy[q];
+        vis[q] = __expf(-sigma);
+        alpha[q] = fminf(kAlphaMax, opac * vis[q]);
+        valid[q] = inside[q] && (batch_end - t <= bin_final[q]) && !(sigma < 0.f || alpha[q] < kAlphaMin);
+        any |= valid[q];
+      }
+      if (!__any(any)) continue;
+      float col[4] = {B.z, B.w, 0.f, 0.f};
+      if (CH > 2) { const float4 Cc = sC[t]; col[2] = Cc.x; col[3] = Cc.y; }
+      float acc[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc[k] = 0.f;
+      float s_vs = 0.f;  // sum of v_sigma * ... terms that share dx are folded after the strip loop
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!__any(valid[q])) continue;  // strip-uniform skip
+        if (valid[q]) {
+          const float ra = 1.f / (1.f - alpha[q]);
+          T[q] *= ra;
+          const float fac = alpha[q] * T[q];
+          float v_alpha = 0.f;
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            acc[k] += fac * vr[q][k];
+            v_alpha += (col[k] * T[q] - buffer[q][k] * ra) * vr[q][k];
+          }
+          v_alpha += T_final[q] * ra * vra[q];
+          if (backgrounds) v_alpha += -T_final[q] * ra * bgdot[q];
+          if (opac * vis[q] <= kAlphaMax) {
+            const float v_sigma = -opac * vis[q] * v_alpha;
+            acc[4] += 0.5f * v_sigma * dx * dx;
+            acc[5] += v_sigma * dx * dy[q];
+            acc[6] += 0.5f * v_sigma * dy[q] * dy[q];
+            const float gx = v_sigma * (A.z * dx + A.w * dy[q]);
+            const float gy = v_sigma * (A.w * dx + B.x * dy[q]);
+            acc[7] += gx; acc[8] += gy;
+            if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
+            acc[11] += vis[q] * v_alpha;
+          }
+#pragma unroll
+          for (int k = 0; k < CH; k++) buffer[q][k] += col[k] * fac;
+        }
+      }
+      (void)s_vs;
+      const float tot = butterfly_sum16(acc, lane);
+      if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
     }
   }
 }
@@ -290,10 +464,19 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
   const dim3 grid((unsigned)(C * tile_w * tile_h)), block(kRastBlock);
   hipStream_t st = as_stream(stream);
+  const int variant = bds::option_get(bds::kOptRasterBwd);
+#define BDS_BWD_ARGS                                                                                                   \
+  C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, alphas,  \
+      last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities
 #define BDS_BWD(ch, ab)                                                                                                \
-  hipLaunchKernelGGL((rasterize_bwd_kernel<ch, ab>), grid, block, 0, st, C, N, M, means2d, conics, colors, opacities,  \
-                     backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, alphas, last_ids, v_render,        \
-                     v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities)
+  do {                                                                                                                 \
+    if (variant == 2)                                                                                                  \
+      hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS);                 \
+    else if (variant == 1)                                                                                             \
+      hipLaunchKernelGGL((rasterize_bwd_kernel<ch, ab, 1>), grid, block, 0, st, BDS_BWD_ARGS);                         \
+    else                                                                                                               \
+      hipLaunchKernelGGL((rasterize_bwd_kernel<ch, ab, 0>), grid, block, 0, st, BDS_BWD_ARGS);                         \
+  } while (0)
   if (v_means2d_abs) {
     if (CH == 1) BDS_BWD(1, true);
     else if (CH == 3) BDS_BWD(3, true);
@@ -304,6 +487,7 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
     else BDS_BWD(4, false);
   }
 #undef BDS_BWD
+#undef BDS_BWD_ARGS
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -209,6 +209,68 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
   }
 }
 
+// Variant 1: wave-private ranking.  Each wave owns a contiguous quarter of the workgroup's chunk and
+// ranks it without any cross-wave traffic: after one LDS histogram + prefix over (wave, digit) the
+// four waves run their 16 rounds back to back with NO barriers (the block-synchronous variant needs
+// three per round).  Stable: global position = scanned block base + elements of earlier waves
+// + elements of earlier rounds of this wave + rank among the lanes of this round.
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift, uint32_t mask,
+    int bits, int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out) {
+  __shared__ uint32_t wrun[kSortWaves][256];  // next output position per (wave, digit)
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
+  __syncthreads();
+  constexpr int kPerWave = kSortChunk / kSortWaves;  // 1024 consecutive elements per wave
+  const int64_t wbase = (int64_t)blockIdx.x * kSortChunk + (int64_t)wv * kPerWave;
+  uint32_t k[kSortRounds], v[kSortRounds];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    k[r] = 0xFFFFFFFFu; v[r] = 0;
+    if (i < n) {
+      k[r] = keys_in[i]; v[r] = vals_in[i];
+      atomicAdd(&wrun[wv][(k[r] >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  {  // digit `tid`: exclusive prefix over the waves, on top of the block's scanned base
+    uint32_t base = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+      const uint32_t c = wrun[w][tid];
+      wrun[w][tid] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    const bool on = i < n;
+    const uint32_t d = (k[r] >> shift) & mask;
+    unsigned long long peers = __ballot(on);
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt);
+    uint32_t pos = 0;
+    if (on) pos = wrun[wv][d];                                  // every peer reads the same slot ...
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): reads landed before the update
+    __builtin_amdgcn_wave_barrier();
+    if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);   // ... then the group's first lane bumps it
+    __builtin_amdgcn_wave_barrier();
+    if (on) {
+      keys_out[pos + rank] = k[r];
+      vals_out[pos + rank] = v[r];
+    }
+  }
+}
+
 static size_t radix_temp_elems(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
   const size_t h = align_up((size_t)256 * nblocks, 4);
@@ -227,8 +289,12 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
-  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, shift, mask, bits, nblocks,
-                     hist, kout, vout);
+  if (option_get(kOptRadix) == 1)
+    hipLaunchKernelGGL(radix_scatter_wave_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, shift, mask, bits,
+                       nblocks, hist, kout, vout);
+  else
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, shift, mask, bits, nblocks,
+                       hist, kout, vout);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -16,6 +16,25 @@ from torch import Tensor
 from .gs_ops import (TILE_SIZE, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
 
 
+class _Meta(dict):
+    """The ``meta`` dict of gsplat's rasterization().  ``isect_ids`` (the sorted 64-bit keys, which nothing on
+    the reference's path reads) is materialised on first access instead of on every step."""
+
+    def __getitem__(self, key):
+        if key == "isect_ids" and dict.__getitem__(self, key) is None:
+            self["isect_ids"] = _isect_ids_from(self["isect_offsets"], self["flatten_ids"], self["depths"])
+        return dict.__getitem__(self, key)
+
+
+@torch.no_grad()
+def _isect_ids_from(isect_offsets: Tensor, flatten_ids: Tensor, depths: Tensor) -> Tensor:
+    M = flatten_ids.numel()
+    idx = torch.arange(M, device=flatten_ids.device)
+    tile = torch.bucketize(idx, isect_offsets.reshape(-1).long(), right=True) - 1  # camera*tiles + tile
+    bits = depths.detach().reshape(-1)[flatten_ids.long()].contiguous().view(torch.int32).long()
+    return (tile << 32) | bits
+
+
 def _as_int(v) -> int:
     # the reference passes 0-d (GPU) int64 tensors for width/height
     # (/root/reference/project/datasets/base/pixel_source.py:653-654, tools/train.py:262-264)
@@ -110,7 +129,7 @@ def rasterization(
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(means2d, radii, depths, tile_size, tile_width,
-                                                                         tile_height)
+                                                                         tile_height, want_isect_ids=False)
     render_colors, render_alphas = rasterize_to_pixels(means2d, conics, col.contiguous(), opac.contiguous(), width, height,
                                                        tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds,
                                                        absgrad=absgrad)
@@ -118,7 +137,7 @@ def rasterization(
         render_colors = torch.cat(
             [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
 
-    meta = {
+    meta = _Meta({
         "camera_ids": None,
         "gaussian_ids": None,
         "radii": radii,
@@ -136,5 +155,5 @@ def rasterization(
         "height": height,
         "tile_size": tile_size,
         "n_cameras": C,
-    }
+    })
     return render_colors, render_alphas, meta

@@ -37,6 +37,13 @@ typedef void *bds_stream_t;
 int bds_abi_version(void);
 const char *bds_strerror(int code);
 
+/* Kernel-variant switches for A/B measurement and bisecting (results are identical up to fp32
+ * summation order).  which: 0 = composite backward (0: per-value DPP reduce, 4 waves/tile;
+ * 1: 16-value transpose-reduce, 4 waves/tile; 2: one wave/tile, 4 pixels/lane [default]);
+ * 1 = radix pass (0: block-synchronous ranking; 1: wave-private ranking [default]). */
+int bds_set_option(int which, int value);
+int bds_get_option(int which);
+
 /* ---- spherical harmonics ----------------------------------------------------------------
  * gsplat.cuda._wrapper.spherical_harmonics(degrees_to_use, dirs, coeffs, masks=None)
  * imported at models/gaussians/basics.py:15, called at models/gaussians/vanilla.py:388

@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_kernel_variants():
+    """Tests may switch kernel variants (bds_set_option); restore the defaults afterwards."""
+    yield
+    try:
+        from bilateral_driving_amd import _lib
+        if _lib._lib is not None:
+            _lib.set_option(_lib.OPT_RASTER_BWD, 2)
+            _lib.set_option(_lib.OPT_RADIX, 1)
+    except Exception:
+        pass

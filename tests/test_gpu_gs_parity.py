@@ -105,8 +105,12 @@ def test_projection_multi_camera(ops):
         assert float(tot[k].abs().max()) < 1e-3 * float(leaves[k].grad.abs().max())
 
 
-@pytest.mark.parametrize("seed,N,W,H,C", [(0, 2000, 256, 256, 1), (1, 20000, 640, 368, 1), (2, 3000, 200, 120, 3), (3, 10, 64, 64, 1)])
-def test_isect_bit_exact(ops, seed, N, W, H, C):
+@pytest.mark.parametrize("radix", [1, 0], ids=["radix_wave", "radix_block"])
+@pytest.mark.parametrize("seed,N,W,H,C", [(0, 2000, 256, 256, 1), (1, 20000, 640, 368, 1), (2, 3000, 200, 120, 3), (3, 10, 64, 64, 1),
+                                          (4, 150000, 1920, 1080, 1)])
+def test_isect_bit_exact(ops, seed, N, W, H, C, radix):
+    from bilateral_driving_amd import _lib
+    _lib.set_option(_lib.OPT_RADIX, radix)
     sc = make_scene(N, W, H, seed=seed, spread=1.3)
     vms = sc["viewmats"].repeat(C, 1, 1)
     for c in range(C):
@@ -131,6 +135,17 @@ def test_isect_bit_exact(ops, seed, N, W, H, C):
     assert torch.equal(offs.cpu(), ref_off)
 
 
+def test_meta_isect_ids_lazy_equals_kernel(ops):
+    import bilateral_driving_amd.rendering as R
+    sc = make_scene(3000, 200, 120, seed=9)
+    args = [sc[k].cuda() for k in ("means", "quats", "scales", "opacities", "colors")]
+    _, _, meta = R.rasterization(*args, sc["viewmats"].cuda(), sc["Ks"].cuda(), 200, 120)
+    assert dict.__getitem__(meta, "isect_ids") is None
+    lazy = meta["isect_ids"]
+    _, iids, fids, offs = ops.isect_tiles(meta["means2d"], meta["radii"], meta["depths"], 16, meta["tile_width"], meta["tile_height"])
+    assert torch.equal(lazy, iids) and torch.equal(fids, meta["flatten_ids"]) and torch.equal(offs, meta["isect_offsets"])
+
+
 def test_isect_empty(ops):
     z = torch.zeros(1, 50, device="cuda")
     tpg, iids, fids, offs = ops.isect_tiles(torch.zeros(1, 50, 2, device="cuda"), torch.zeros(1, 50, dtype=torch.int32, device="cuda"), z, 16, 4, 3)
@@ -150,9 +165,12 @@ def _render_both(ops, sc, W, H, mode, bg=None, seed=0):
     return ref_in, r_ref, a_ref, m_ref, gpu_in, r, a, meta
 
 
+@pytest.mark.parametrize("variant", [2, 1, 0], ids=["bwd_wave4px", "bwd_butterfly", "bwd_dpp"])
 @pytest.mark.parametrize("seed,N,W,H,mode", [(0, 1000, 256, 256, "RGB+ED"), (1, 4000, 320, 200, "RGB"), (2, 600, 75, 50, "RGB+ED"),
                                               (3, 3000, 128, 128, "ED"), (4, 300, 64, 64, "RGB+D")])
-def test_rasterization_end_to_end(ops, seed, N, W, H, mode):
+def test_rasterization_end_to_end(ops, seed, N, W, H, mode, variant):
+    from bilateral_driving_amd import _lib
+    _lib.set_option(_lib.OPT_RASTER_BWD, variant)
     sc = make_scene(N, W, H, seed=seed)
     bg = torch.rand(1, 3) if mode == "RGB" else None
     ref_in, r_ref, a_ref, m_ref, gpu_in, r, a, meta = _render_both(ops, sc, W, H, mode, bg)
