@@ -22,8 +22,8 @@ struct LevelDev {
   const float *grid;   // [n_avg,12,gl,gy,gx]
   float *v_grid;
   float *lo;           // [Hd*Wd,12] low-res affine maps
-  float *P;            // [H*W,3] input colour of this level   (bwd scratch)
-  float *Q;            // [H*W,3] gradient w.r.t. this level's output (bwd scratch)
+  float *va;           // [Hd*Wd,12] gradient w.r.t. the low-res affine maps (bwd scratch)
+  int lds_off, cw, ch; // backward tile accumulator: offset (floats) and cell-window size in LDS
   float *aff_out;      // optional [H*W,12]
   int gx, gy, gl, factor, n_avg, Hd, Wd;
 };
@@ -114,6 +114,7 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
 }
 
 // ---- B: full-resolution compose --------------------------------------------------------------
+template <int NL>  // NL >= p.nlevels: bounds the static unrolling (registers) of the level loop
 __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
   float r, g, b;
   load_input(p, i, j, r, g, b);
 #pragma unroll
-  for (int l = 0; l < BDS_MAX_LEVELS; l++) {
+  for (int l = 0; l < NL; l++) {
     if (l < p.nlevels) {
       float A[12];
       upsample_affine(p.lv[l], p.H, p.W, i, j, A);
@@ -137,39 +138,103 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
   out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
 }
 
-// ---- C: full-resolution backward: direct route + per-level (P, Q) for the gather ---------------
-__global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, const float *__restrict__ v_out,
+// ---- C: full-resolution backward ---------------------------------------------------------------
+// One workgroup = a 16 x 64 pixel tile, four pixels per thread.  Per pixel the level chain is replayed,
+// the direct-route gradient is written, and each level's d(loss)/d(A_l) = v (x) [p;1] is pushed through
+// the adjoint of the bilinear up-sampler into a per-tile LDS window of low-res cells (ds_add_f32);
+// the window is flushed to the level's [Hd*Wd,12] buffer once per workgroup.  Nothing image-sized and
+// level-specific ever goes to HBM (the reference's autograd keeps three [H,W,3,4] maps + their grads).
+constexpr int kBwdTileH = 16, kBwdTileW = 64;
+
+template <int NL>
+__global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, int lds_floats, const float *__restrict__ v_out,
                                                                float *__restrict__ v_in) {
-  const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
-  if (pix >= (int64_t)p.H * p.W) return;
-  const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
-  float r, g, b;
-  load_input(p, i, j, r, g, b);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int e = threadIdx.x; e < lds_floats; e += kBgBlock) lds[e] = 0.f;
+  const int tiles_x = (p.W + kBwdTileW - 1) / kBwdTileW;
+  const int r0 = (blockIdx.x / tiles_x) * kBwdTileH, c0 = (blockIdx.x % tiles_x) * kBwdTileW;
+  int cy0[NL], cx0[NL];
 #pragma unroll
-  for (int l = 0; l < BDS_MAX_LEVELS; l++) {
-    if (l < p.nlevels) {
-      float *P = p.lv[l].P + pix * 3;
-      P[0] = r; P[1] = g; P[2] = b;
-      float A[12];
-      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
-      apply_affine(A, r, g, b);
+  for (int l = 0; l < NL; l++) {
+    cy0[l] = cx0[l] = 0;
+    if (l < p.nlevels && p.lv[l].cw > 0) {
+      cy0[l] = resample_tap(r0, p.H, p.lv[l].Hd).i0;
+      cx0[l] = resample_tap(c0, p.W, p.lv[l].Wd).i0;
     }
   }
-  float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
+  __syncthreads();
+  const int j = c0 + (threadIdx.x & (kBwdTileW - 1));
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    const int i = r0 + (threadIdx.x / kBwdTileW) + 4 * q;
+    if (i >= p.H || j >= p.W) continue;
+    const int64_t pix = (int64_t)i * p.W + j;
+    float pr[NL], pg[NL], pb[NL];
+    float r, g, b;
+    load_input(p, i, j, r, g, b);
 #pragma unroll
-  for (int l = BDS_MAX_LEVELS - 1; l >= 0; l--) {
-    if (l < p.nlevels) {
-      float *Q = p.lv[l].Q + pix * 3;
-      Q[0] = v0; Q[1] = v1; Q[2] = v2;
-      float A[12];
-      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
-      const float n0 = A[0] * v0 + A[4] * v1 + A[8] * v2;
-      const float n1 = A[1] * v0 + A[5] * v1 + A[9] * v2;
-      const float n2 = A[2] * v0 + A[6] * v1 + A[10] * v2;
-      v0 = n0; v1 = n1; v2 = n2;
+    for (int l = 0; l < NL; l++) {
+      pr[l] = r; pg[l] = g; pb[l] = b;
+      if (l < p.nlevels) {
+        float A[12];
+        upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+        apply_affine(A, r, g, b);
+      }
+    }
+    float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
+#pragma unroll
+    for (int l = NL - 1; l >= 0; l--) {
+      if (l < p.nlevels) {
+        const LevelDev &L = p.lv[l];
+        const float o[12] = {v0 * pr[l], v0 * pg[l], v0 * pb[l], v0, v1 * pr[l], v1 * pg[l], v1 * pb[l], v1,
+                             v2 * pr[l], v2 * pg[l], v2 * pb[l], v2};
+        if (L.cw == 0) {  // level sliced at full resolution: the map IS the low-res map
+          float4 *d = reinterpret_cast<float4 *>(L.va + pix * 12);
+          d[0] = make_float4(o[0], o[1], o[2], o[3]);
+          d[1] = make_float4(o[4], o[5], o[6], o[7]);
+          d[2] = make_float4(o[8], o[9], o[10], o[11]);
+        } else {
+          const Tap ty = resample_tap(i, p.H, L.Hd), tx = resample_tap(j, p.W, L.Wd);
+          const int ys[2] = {ty.i0 - cy0[l], ty.i1 - cy0[l]}, xs[2] = {tx.i0 - cx0[l], tx.i1 - cx0[l]};
+          const float wy[2] = {1.f - ty.w1, ty.w1}, wx[2] = {1.f - tx.w1, tx.w1};
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int bb = 0; bb < 2; bb++) {
+              const float w = wy[a] * wx[bb];
+              if (w != 0.f) {
+                float *cell = lds + L.lds_off + (ys[a] * L.cw + xs[bb]) * 12;
+#pragma unroll
+                for (int k = 0; k < 12; k++) atomicAdd(cell + k, w * o[k]);
+              }
+            }
+        }
+        float A[12];
+        upsample_affine(L, p.H, p.W, i, j, A);
+        const float n0 = A[0] * v0 + A[4] * v1 + A[8] * v2;
+        const float n1 = A[1] * v0 + A[5] * v1 + A[9] * v2;
+        const float n2 = A[2] * v0 + A[6] * v1 + A[10] * v2;
+        v0 = n0; v1 = n1; v2 = n2;
+      }
+    }
+    v_in[pix * 3] = v0; v_in[pix * 3 + 1] = v1; v_in[pix * 3 + 2] = v2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l >= p.nlevels) break;
+    const LevelDev &L = p.lv[l];
+    if (L.cw == 0) continue;
+    const int n = L.cw * L.ch * 12;
+    for (int e = threadIdx.x; e < n; e += kBgBlock) {
+      const float v = lds[L.lds_off + e];
+      if (v != 0.f) {
+        const int cell = e / 12, k = e - cell * 12;
+        const int cy = cy0[l] + cell / L.cw, cx = cx0[l] + cell % L.cw;
+        if (cy < L.Hd && cx < L.Wd) atomicAdd(L.va + ((int64_t)cy * L.Wd + cx) * 12 + k, v);
+      }
     }
   }
-  v_in[pix * 3] = v0; v_in[pix * 3 + 1] = v1; v_in[pix * 3 + 2] = v2;
 }
 
 // wave64 sum leaving the result in every lane (used only on wave-uniform-address grid updates)
@@ -179,20 +244,29 @@ __device__ __forceinline__ float wave_sum_all(float v) {
   return v;
 }
 
-// accumulate val into acc[addr] (LDS or global), combining across the wave when every active lane
-// targets the same address (coarse grids: the whole wave sits in one cell)
-__device__ __forceinline__ void grid_accumulate(float *acc, int addr, float val, bool active) {
-  const int a0 = __builtin_amdgcn_readfirstlane(active ? addr : -1);
-  const bool uniform = __all(!active || addr == a0) && __any(active) && a0 >= 0;
+// Scatter one trilinear corner's 12 channel contributions into the grid-gradient accumulator (LDS or
+// global).  Coarse grids put a whole wave into one cell: when every active lane targets the same
+// corner the 12 values are wave-reduced on the VALU (DPP) and committed by one lane, instead of 64
+// serialised same-address atomics.
+__device__ __forceinline__ void corner_accumulate(float *acc, int base, int vol, float w, const float *va, bool active) {
+  const int a0 = __builtin_amdgcn_readfirstlane(active ? base : -1);
+  const bool uniform = a0 >= 0 && __all(!active || base == a0);
   if (uniform) {
-    const float s = wave_sum_to_lane63(active ? val : 0.f);  // VALU-only (DPP); total lands in lane 63
-    if ((threadIdx.x & (kWave - 1)) == kWave - 1 && s != 0.f) atomicAdd(acc + a0, s);
-  } else if (active && val != 0.f) {
-    atomicAdd(acc + addr, val);
+#pragma unroll
+    for (int ch = 0; ch < 12; ch++) {
+      const float s = wave_sum_to_lane63(active ? w * va[ch] : 0.f);
+      if ((threadIdx.x & (kWave - 1)) == kWave - 1 && s != 0.f) atomicAdd(acc + a0 + ch * vol, s);
+    }
+  } else if (active) {
+#pragma unroll
+    for (int ch = 0; ch < 12; ch++) {
+      const float v = w * va[ch];
+      if (v != 0.f) atomicAdd(acc + base + ch * vol, v);
+    }
   }
 }
 
-// ---- D: per-level low-resolution backward (gather of the up-sample, slice vjp, guidance) --------
+// ---- D: per-level low-resolution backward (slice vjp into the grid, guidance route) ---------------
 // kLds: the level's grid gradient (n_avg * 12*gl*gy*gx floats) fits the workgroup's LDS accumulator.
 template <bool kLds>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int l, float *__restrict__ v_in) {
@@ -212,37 +286,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
 #pragma unroll
   for (int k = 0; k < 12; k++) va[k] = 0.f;
   if (active) {
-    if (L.Hd == p.H && L.Wd == p.W) {
-      const float *P = L.P + idx * 3, *Q = L.Q + idx * 3;
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        va[r * 4 + 0] = Q[r] * P[0]; va[r * 4 + 1] = Q[r] * P[1]; va[r * 4 + 2] = Q[r] * P[2]; va[r * 4 + 3] = Q[r];
-      }
-    } else {
-      // full-res pixels whose up-sample taps include this low-res cell
-      const float sy = (float)p.H / (float)L.Hd, sx = (float)p.W / (float)L.Wd;
-      int ylo = (int)floorf(((float)i - 0.5f) * sy - 0.5f) - 1, yhi = (int)ceilf(((float)i + 1.5f) * sy - 0.5f) + 1;
-      int xlo = (int)floorf(((float)j - 0.5f) * sx - 0.5f) - 1, xhi = (int)ceilf(((float)j + 1.5f) * sx - 0.5f) + 1;
-      ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, p.H - 1); xhi = min(xhi, p.W - 1);
-      for (int y = ylo; y <= yhi; y++) {
-        const Tap ty = resample_tap(y, p.H, L.Hd);
-        const float wy = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
-        if (wy == 0.f) continue;
-        for (int x = xlo; x <= xhi; x++) {
-          const Tap tx = resample_tap(x, p.W, L.Wd);
-          const float wx = (tx.i0 == j ? 1.f - tx.w1 : 0.f) + (tx.i1 == j ? tx.w1 : 0.f);
-          if (wx == 0.f) continue;
-          const float w = wy * wx;
-          const int64_t o = ((int64_t)y * p.W + x) * 3;
-          const float p0 = L.P[o], p1 = L.P[o + 1], p2 = L.P[o + 2];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            const float q = L.Q[o + r] * w;
-            va[r * 4 + 0] += q * p0; va[r * 4 + 1] += q * p1; va[r * 4 + 2] += q * p2; va[r * 4 + 3] += q;
-          }
-        }
-      }
-    }
+    const float4 *sv = reinterpret_cast<const float4 *>(L.va + idx * 12);
+    const float4 a = sv[0], b = sv[1], c = sv[2];
+    va[0] = a.x; va[1] = a.y; va[2] = a.z; va[3] = a.w; va[4] = b.x; va[5] = b.y; va[6] = b.z; va[7] = b.w;
+    va[8] = c.x; va[9] = c.y; va[10] = c.z; va[11] = c.w;
   }
   // slice backward
   const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
@@ -252,25 +299,14 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
   const float inv_n = 1.f / (float)L.n_avg;
   const int plane = L.gy * L.gx, vol = L.gl * plane;
   float v_iz = 0.f;
-  const int zs[2] = {c.z0, c.z1};
-  const float wz[2] = {1.f - c.fz, c.fz};
-  const int ys[2] = {c.y0, c.y1};
-  const float wyv[2] = {1.f - c.fy, c.fy};
-  const int xs[2] = {c.x0, c.x1};
-  const float wxv[2] = {1.f - c.fx, c.fx};
   for (int n = 0; n < L.n_avg; n++) {
     if (L.v_grid) {
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int bb = 0; bb < 2; bb++)
-#pragma unroll
-          for (int cc = 0; cc < 2; cc++) {
-            const float w = wz[a] * wyv[bb] * wxv[cc] * inv_n;
-            const int base = n * gsz + zs[a] * plane + ys[bb] * L.gx + xs[cc];
-#pragma unroll
-            for (int ch = 0; ch < 12; ch++) grid_accumulate(acc, base + ch * vol, w * va[ch], active);
-          }
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) {
+        const int zz = (k & 4) ? c.z1 : c.z0, yy = (k & 2) ? c.y1 : c.y0, xx = (k & 1) ? c.x1 : c.x0;
+        const float w = ((k & 4) ? c.fz : 1.f - c.fz) * ((k & 2) ? c.fy : 1.f - c.fy) * ((k & 1) ? c.fx : 1.f - c.fx) * inv_n;
+        corner_accumulate(acc, n * gsz + zz * plane + yy * L.gx + xx, vol, w, va, active);
+      }
     }
     if (active && c.z_interior) {
       float a12[12], dz[12];
@@ -348,20 +384,13 @@ __global__ __launch_bounds__(kBgBlock) void slice_bwd_kernel(int64_t P, const fl
 #pragma unroll
   for (int k = 0; k < 12; k++) va[k] = active ? v_affine[ii * 12 + k] : 0.f;
   const int plane = gy * gx, vol = gl * plane;
-  const int zs[2] = {c.z0, c.z1}, ys[2] = {c.y0, c.y1}, xs[2] = {c.x0, c.x1};
-  const float wz[2] = {1.f - c.fz, c.fz}, wyv[2] = {1.f - c.fy, c.fy}, wxv[2] = {1.f - c.fx, c.fx};
   if (v_grid) {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int cc = 0; cc < 2; cc++) {
-          const float w = wz[a] * wyv[b] * wxv[cc];
-          const int base = zs[a] * plane + ys[b] * gx + xs[cc];
-#pragma unroll
-          for (int ch = 0; ch < 12; ch++) grid_accumulate(v_grid, base + ch * vol, w * va[ch], active);
-        }
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+      const int zz = (k & 4) ? c.z1 : c.z0, yy = (k & 2) ? c.y1 : c.y0, xx = (k & 1) ? c.x1 : c.x0;
+      const float w = ((k & 4) ? c.fz : 1.f - c.fz) * ((k & 2) ? c.fy : 1.f - c.fy) * ((k & 1) ? c.fx : 1.f - c.fx);
+      corner_accumulate(v_grid, zz * plane + yy * gx + xx, vol, w, va, active);
+    }
   }
   if (active && v_rgb) {
     float vg = 0.f;
@@ -420,7 +449,8 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
 
 // ---- host side ---------------------------------------------------------------------------------
 struct MsLayout {
-  size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS];
+  size_t lo_off[BDS_MAX_LEVELS], va_off[BDS_MAX_LEVELS];
+  size_t va_begin, va_end;  // the va buffers of the up-sampled levels are contiguous: one memset
   size_t bytes;
 };
 static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, int W) {
@@ -431,10 +461,13 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     L.lo_off[l] = off;
     off += align_up((size_t)Hd * Wd * 12 * sizeof(float), 256);
   }
+  L.va_begin = off;
   for (int l = 0; l < nlevels; l++) {
-    L.p_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
-    L.q_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
+    const int Hd = H / lv[l].factor, Wd = W / lv[l].factor;
+    L.va_off[l] = off;
+    off += align_up((size_t)Hd * Wd * 12 * sizeof(float), 256);
   }
+  L.va_end = off;
   L.bytes = off;
   return L;
 }
@@ -454,8 +487,8 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
     LevelDev &d = p.lv[l];
     d.grid = lv[l].grid; d.v_grid = lv[l].v_grid;
     d.lo = reinterpret_cast<float *>(base + L.lo_off[l]);
-    d.P = reinterpret_cast<float *>(base + L.p_off[l]);
-    d.Q = reinterpret_cast<float *>(base + L.q_off[l]);
+    d.va = reinterpret_cast<float *>(base + L.va_off[l]);
+    d.lds_off = d.cw = d.ch = 0;
     d.aff_out = affine_out ? affine_out[l] : nullptr;
     BDS_REQUIRE(d.aff_out == nullptr || aligned16(d.aff_out));
     d.gx = lv[l].gx; d.gy = lv[l].gy; d.gl = lv[l].gl; d.factor = lv[l].factor; d.n_avg = lv[l].n_avg;
@@ -488,7 +521,16 @@ extern "C" int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *leve
     hipLaunchKernelGGL(ms_lowres_fwd_kernel, dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l);
     BDS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(ms_apply_fwd_kernel, dim3((unsigned)cdiv((int64_t)H * W, kBgBlock)), dim3(kBgBlock), 0, st, p, rgb_out);
+  {
+    const dim3 grid((unsigned)cdiv((int64_t)H * W, kBgBlock)), block(kBgBlock);
+    switch (nlevels) {
+      case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1>), grid, block, 0, st, p, rgb_out); break;
+      case 2: hipLaunchKernelGGL((ms_apply_fwd_kernel<2>), grid, block, 0, st, p, rgb_out); break;
+      case 3: hipLaunchKernelGGL((ms_apply_fwd_kernel<3>), grid, block, 0, st, p, rgb_out); break;
+      case 4: hipLaunchKernelGGL((ms_apply_fwd_kernel<4>), grid, block, 0, st, p, rgb_out); break;
+      default: hipLaunchKernelGGL((ms_apply_fwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, rgb_out); break;
+    }
+  }
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -503,7 +545,33 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
   BDS_REQUIRE(v_rgb_out && v_rgb);
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
-  hipLaunchKernelGGL(ms_apply_bwd_kernel, dim3((unsigned)cdiv(HW, kBgBlock)), dim3(kBgBlock), 0, st, p, v_rgb_out, v_rgb);
+  // per-tile LDS windows of low-res cells for the levels that are up-sampled
+  int lds_floats = 0;
+  for (int l = 0; l < nlevels; l++) {
+    LevelDev &d = p.lv[l];
+    if (d.Hd == H && d.Wd == W) continue;
+    d.ch = kBwdTileH / d.factor + 3;
+    d.cw = kBwdTileW / d.factor + 3;
+    d.lds_off = lds_floats;
+    lds_floats += d.ch * d.cw * 12;
+  }
+  BDS_REQUIRE((size_t)lds_floats * sizeof(float) <= 64 * 1024);
+  {
+    const MsLayout ML = ms_layout(nlevels, levels, H, W);
+    if (hipMemsetAsync(static_cast<char *>(ws) + ML.va_begin, 0, ML.va_end - ML.va_begin, st) != hipSuccess) return BDS_ELAUNCH;
+  }
+  const unsigned tiles = (unsigned)(cdiv(H, kBwdTileH) * cdiv(W, kBwdTileW));
+  {
+    const size_t lb = (size_t)lds_floats * sizeof(float);
+    const dim3 grid(tiles), block(kBgBlock);
+    switch (nlevels) {
+      case 1: hipLaunchKernelGGL((ms_apply_bwd_kernel<1>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
+      case 2: hipLaunchKernelGGL((ms_apply_bwd_kernel<2>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
+      case 3: hipLaunchKernelGGL((ms_apply_bwd_kernel<3>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_kernel<4>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_kernel<BDS_MAX_LEVELS>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
+    }
+  }
   BDS_LAUNCH_CHECK();
   for (int l = 0; l < nlevels; l++) {
     const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;

@@ -351,4 +351,66 @@ BDS_HD void tile_rect(float mx, float my, int radius, int tile_size, int tile_w,
   y1 = (int)fminf(fmaxf(fy1, 0.f), (float)tile_h);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// exact (conservative) tile culling
+// ------------------------------------------------------------------------------------------
+// A pixel blends a Gaussian only if alpha = opacity * exp(-sigma) >= 1/255, i.e.
+// sigma <= tau = ln(255 * opacity), sigma = 0.5*(a dx^2 + c dy^2) + b dx dy.  A (tile, Gaussian)
+// pair none of whose 256 pixel centres can reach that is dropped from the intersection list: the
+// rendered image and every gradient are unchanged (such a pair is skipped pixel by pixel anyway),
+// only the lists the sort / compositing kernels walk get shorter.  kCullMargin keeps pairs whose best
+// pixel is within rounding distance of the threshold.
+constexpr float kCullMargin = 1e-3f;
+
+BDS_HD float cull_tau(float opacity) { return logf(255.0f * opacity) + kCullMargin; }
+
+// pixel-centre rectangle [x0,x1] x [y0,y1] (inclusive) vs the ellipse {q(d) <= q_max},
+// q(d) = a dx^2 + 2 b dx dy + c dy^2 (a, c > 0), d = p - mean
+BDS_HD bool rect_hits_ellipse(float mx, float my, float a, float b, float c, float q_max, float x0, float y0, float x1,
+                              float y1) {
+  const float dx0 = x0 - mx, dx1 = x1 - mx, dy0 = y0 - my, dy1 = y1 - my;
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;  // mean inside the rectangle
+  float qmin = 3.4e38f;
+  // vertical edges: dx fixed, dy in [dy0, dy1]; unconstrained minimiser dy* = -b dx / c
+  for (int e = 0; e < 2; e++) {
+    const float dx = e ? dx1 : dx0;
+    float dy = -b * dx / c;
+    dy = fminf(fmaxf(dy, dy0), dy1);
+    qmin = fminf(qmin, a * dx * dx + 2.f * b * dx * dy + c * dy * dy);
+  }
+  for (int e = 0; e < 2; e++) {
+    const float dy = e ? dy1 : dy0;
+    float dx = -b * dy / a;
+    dx = fminf(fmaxf(dx, dx0), dx1);
+    qmin = fminf(qmin, a * dx * dx + 2.f * b * dx * dy + c * dy * dy);
+  }
+  return qmin <= q_max;
+}
+
+// Tile rectangle after culling: gsplat's bounding square (tile_rect) intersected with the axis-aligned
+// bounding box of the tau-ellipse (pixel-centre convention).  Returns false if nothing is left.
+BDS_HD bool tile_rect_tight(float mx, float my, int radius, float a, float b, float c, float opacity, int tile_size,
+                            int tile_w, int tile_h, int &x0, int &y0, int &x1, int &y1, float &q_max) {
+  tile_rect(mx, my, radius, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+  const float tau = cull_tau(opacity);
+  const float det = a * c - b * b;
+  if (!(tau > 0.f) || !(det > 0.f) || !(a > 0.f) || !(c > 0.f)) { x1 = x0; y1 = y0; q_max = 0.f; return false; }
+  q_max = 2.f * tau;
+  const float hx = sqrtf(q_max * c / det) * 1.0001f + 0.01f, hy = sqrtf(q_max * a / det) * 1.0001f + 0.01f;
+  const float ts = (float)tile_size;
+  // tile t holds pixel centres t*ts + 0.5 ... t*ts + ts - 0.5
+  const int tx0 = (int)ceilf((mx - hx - (ts - 0.5f)) / ts), tx1 = (int)floorf((mx + hx - 0.5f) / ts) + 1;
+  const int ty0 = (int)ceilf((my - hy - (ts - 0.5f)) / ts), ty1 = (int)floorf((my + hy - 0.5f) / ts) + 1;
+  x0 = x0 > tx0 ? x0 : tx0; x1 = x1 < tx1 ? x1 : tx1;
+  y0 = y0 > ty0 ? y0 : ty0; y1 = y1 < ty1 ? y1 : ty1;
+  if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; return false; }
+  return true;
+}
+
+BDS_HD bool tile_hit(float mx, float my, float a, float b, float c, float q_max, int tx, int ty, int tile_size) {
+  const float ts = (float)tile_size;
+  return rect_hits_ellipse(mx, my, a, b, c, q_max, tx * ts + 0.5f, ty * ts + 0.5f, tx * ts + ts - 0.5f, ty * ts + ts - 0.5f);
+}
+
 }  // namespace bds

@@ -31,9 +31,10 @@ __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, cons
     const float4 *src = reinterpret_cast<const float4 *>(coeffs + g0 * row);
     const int n4 = cnt * row / 4;  // row = 48, 27.. ; kFull only used when row % 4 == 0
     for (int i = tid; i < n4; i += kShBlock) {
-      float4 v = src[i];
       int e = i * 4;
       int r = e / row, c = e - r * row;  // row % 4 == 0 -> the 4 floats stay in one row
+      if (masks != nullptr && !masks[g0 + r]) continue;  // culled Gaussian: its 192-byte row is never fetched
+      float4 v = src[i];
       float *d = lds + r * ldr + c;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, cons
     const int tot = cnt * row;
     for (int e = tid; e < tot; e += kShBlock) {
       int r = e / row, c = e - r * row;
+      if (masks != nullptr && !masks[g0 + r]) continue;
       lds[r * ldr + c] = coeffs[(g0 + r) * (int64_t)K * 3 + c];
     }
   }

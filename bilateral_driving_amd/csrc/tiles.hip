@@ -307,7 +307,9 @@ constexpr int kIsectBlock = 256;
 // per (camera, Gaussian): number of tiles touched + depth key for the depth ordering
 __global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(int64_t CN, const float *__restrict__ means2d,
                                                                  const int32_t *__restrict__ radii,
-                                                                 const float *__restrict__ depths, int tile_size,
+                                                                 const float *__restrict__ depths,
+                                                                 const float *__restrict__ conics,
+                                                                 const float *__restrict__ opacities, int tile_size,
                                                                  int tile_w, int tile_h,
                                                                  int32_t *__restrict__ tiles_per_gauss,
                                                                  uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
@@ -317,8 +319,18 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(int64_t CN, co
   int cnt = 0;
   if (r > 0) {
     int x0, y0, x1, y1;
-    tile_rect(means2d[o * 2], means2d[o * 2 + 1], r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
-    cnt = (x1 - x0) * (y1 - y0);
+    const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
+    if (conics == nullptr) {
+      tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+      cnt = (x1 - x0) * (y1 - y0);
+    } else {
+      const float a = conics[o * 3], b = conics[o * 3 + 1], c = conics[o * 3 + 2];
+      float q_max;
+      if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
+        for (int ty = y0; ty < y1; ty++)
+          for (int tx = x0; tx < x1; tx++) cnt += tile_hit(mx, my, a, b, c, q_max, tx, ty, tile_size) ? 1 : 0;
+      }
+    }
   }
   tiles_per_gauss[o] = cnt;
   keys[o] = __float_as_uint(depths[o]);  // depth > 0 for every visible Gaussian: bits are monotone
@@ -337,7 +349,9 @@ __global__ __launch_bounds__(kIsectBlock) void gather_counts_kernel(int64_t CN, 
 __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(int64_t CN, int64_t N, const uint32_t *__restrict__ sorted_idx,
                                                                 const uint32_t *__restrict__ cum_sorted,
                                                                 const float *__restrict__ means2d,
-                                                                const int32_t *__restrict__ radii, int tile_size,
+                                                                const int32_t *__restrict__ radii,
+                                                                const float *__restrict__ conics,
+                                                                const float *__restrict__ opacities, int tile_size,
                                                                 int tile_w, int tile_h, uint32_t *__restrict__ keys,
                                                                 uint32_t *__restrict__ vals) {
   const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
@@ -346,15 +360,29 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(int64_t CN, int
   const int r = radii[o];
   if (r <= 0) return;
   int x0, y0, x1, y1;
-  tile_rect(means2d[(int64_t)o * 2], means2d[(int64_t)o * 2 + 1], r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+  const float mx = means2d[(int64_t)o * 2], my = means2d[(int64_t)o * 2 + 1];
   const uint32_t cam_base = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
   uint32_t off = cum_sorted[j];
-  for (int ty = y0; ty < y1; ty++)
-    for (int tx = x0; tx < x1; tx++) {
-      keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
-      vals[off] = o;
-      off++;
-    }
+  if (conics == nullptr) {
+    tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+    for (int ty = y0; ty < y1; ty++)
+      for (int tx = x0; tx < x1; tx++) {
+        keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
+        vals[off] = o;
+        off++;
+      }
+  } else {
+    const float a = conics[(int64_t)o * 3], b = conics[(int64_t)o * 3 + 1], c = conics[(int64_t)o * 3 + 2];
+    float q_max;
+    if (!tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) return;
+    for (int ty = y0; ty < y1; ty++)
+      for (int tx = x0; tx < x1; tx++)
+        if (tile_hit(mx, my, a, b, c, q_max, tx, ty, tile_size)) {
+          keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
+          vals[off] = o;
+          off++;
+        }
+  }
 }
 
 // offsets[t] = first index whose key >= t  (lower bound; empty tiles point at the next run)
@@ -450,7 +478,8 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
 }
 
 extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
-                                 int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws,
+                                 const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                                 int32_t *tiles_per_gauss, void *ws,
                                  size_t ws_bytes, int64_t *n_isects, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && n_isects);
   const int64_t CN = (int64_t)C * N;
@@ -459,12 +488,13 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   *n_isects = 0;
   if (CN == 0) return BDS_OK;
   BDS_REQUIRE(means2d && radii && depths && tiles_per_gauss && ws);
+  BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
   PrepWs L = prep_layout(ws, CN);
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const unsigned grid = (unsigned)cdiv(CN, kIsectBlock);
-  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, means2d, radii, depths, tile_size, tile_w,
-                     tile_h, tiles_per_gauss, L.ka, L.va);
+  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, means2d, radii, depths, conics, opacities,
+                     tile_size, tile_w, tile_h, tiles_per_gauss, L.ka, L.va);
   BDS_LAUNCH_CHECK();
   // depth order: 4 stable passes of 8 bits; ends in (ka, va)
   uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
@@ -488,7 +518,8 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
 }
 
 extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int32_t *radii,
-                               const float *depths, int tile_size, int tile_w, int tile_h, const void *ws,
+                               const float *depths, const float *conics, const float *opacities, int tile_size,
+                               int tile_w, int tile_h, const void *ws,
                                size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
                                int32_t *isect_offsets, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && isect_offsets);
@@ -515,8 +546,9 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d
   uint32_t *k_emit, *v_emit;
   if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
   else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
+  BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
   hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, CN, N, P.va, P.cum,
-                     means2d, radii, tile_size, tile_w, tile_h, k_emit, v_emit);
+                     means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
   BDS_LAUNCH_CHECK();
   uint32_t *kin = k_emit, *vin = v_emit;
   for (int p = 0; p < npass; p++) {

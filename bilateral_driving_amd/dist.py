@@ -5,8 +5,7 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm
 tests).  Every rank holds a full replica of the Gaussian parameters and renders its own view; the only
 exchange step of an iteration is ONE sum-all-reduce of the flat per-Gaussian gradient buffer
 (59 floats/Gaussian at SH degree 3: 3 means + 4 quats + 3 scales + 1 opacity + 48 SH) plus the small
-bilateral-grid / pose tail.  Parameter gradients live as views into that flat buffer, so there is no
-pack/unpack pass: autograd accumulates straight into the communication buffer.
+bilateral-grid / pose tail.
 """
 from __future__ import annotations
 
@@ -18,42 +17,57 @@ from torch import Tensor
 
 
 class FlatGradients:
-    """Owns one contiguous fp32 buffer; ``param.grad`` of every registered parameter is a view into it."""
+    """One contiguous fp32 communication buffer for the gradients of a fixed parameter list.
+
+    Single GPU: nothing is copied -- ``zero()`` drops the old gradients and autograd adopts the kernels'
+    gradient outputs as ``param.grad`` without an accumulation pass.  Multi GPU: ``all_reduce()`` packs the
+    gradients into the flat buffer (one read + one write of the payload), runs ONE sum-all-reduce, and
+    re-points every ``param.grad`` at its slice of the reduced buffer."""
 
     def __init__(self, params: Iterable[Tensor]):
         self.params: List[Tensor] = [p for p in params]
         assert self.params, "no parameters"
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
-        self.views: List[Tensor] = []
         for p in self.params:
             assert p.dtype == torch.float32 and p.device == dev and p.requires_grad
-            v = self.flat[off:off + p.numel()].view_as(p)
-            p.grad = v
-            self.views.append(v)
-            off += p.numel()
+        self.total = sum(p.numel() for p in self.params)
+        self._flat: Optional[Tensor] = None
+        self._views: List[Tensor] = []
         self._work = None
 
-    def zero(self) -> None:
-        self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            if p.grad is not v:  # someone replaced .grad (e.g. optimizer.zero_grad(set_to_none=True))
-                p.grad = v
+    @property
+    def flat(self) -> Tensor:
+        if self._flat is None:
+            self._flat = torch.zeros(self.total, device=self.params[0].device, dtype=torch.float32)
+            off = 0
+            for p in self.params:
+                self._views.append(self._flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return self._flat
 
-    def check_views(self) -> None:
-        for p, v in zip(self.params, self.views):
-            assert p.grad is not None and p.grad.data_ptr() == v.data_ptr(), "param.grad no longer aliases the flat buffer"
+    def zero(self) -> None:
+        for p in self.params:
+            p.grad = None
+
+    def pack(self) -> Tensor:
+        flat = self.flat
+        for p, v in zip(self.params, self._views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+        return flat
 
     def all_reduce(self, average: bool = False, async_op: bool = False):
         """Sum (or average) the gradients over all ranks.  No-op for world size 1."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
-        self.check_views()
-        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        flat = self.pack()
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+        self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if not async_op and average:
-            self.flat.div_(dist.get_world_size())
+            flat.div_(dist.get_world_size())
         return self._work
 
     def wait(self, average: bool = False) -> None:
@@ -65,7 +79,7 @@ class FlatGradients:
 
     @property
     def nbytes(self) -> int:
-        return self.flat.numel() * 4
+        return self.total * 4
 
 
 def reduce_densify_stats(grad_norm_accum: Tensor, vis_counts: Tensor, max_2d_size: Tensor) -> None:

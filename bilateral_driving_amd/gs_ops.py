@@ -144,23 +144,33 @@ def fully_fused_projection(means: Tensor, quats: Tensor, scales: Tensor, viewmat
 # --------------------------------------------------------------------------------------------
 @torch.no_grad()
 def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
-                want_isect_ids: bool = True) -> Tuple[Tensor, Optional[Tensor], Tensor, Tensor]:
+                want_isect_ids: bool = True, conics: Optional[Tensor] = None,
+                opacities: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Tensor, Tensor]:
     """means2d [C,N,2], radii [C,N] i32, depths [C,N] ->
     tiles_per_gauss [C,N] i32, isect_ids [M] i64 | None, flatten_ids [M] i32, isect_offsets [C,th,tw] i32.
 
-    (gsplat's isect_tiles + isect_offset_encode in one call: the offsets fall out of the ordering.)"""
+    (gsplat's isect_tiles + isect_offset_encode in one call: the offsets fall out of the ordering.)
+
+    With ``conics`` [C,N,3] and ``opacities`` [C,N], (tile, Gaussian) pairs in which no pixel can reach
+    alpha >= 1/255 are dropped (exact, conservative tile culling): the rendered image and all gradients
+    are unchanged, only the lists get shorter.  Without them the lists are gsplat's bounding-square lists."""
     L.require_gpu(means2d, radii, depths)
     Cn, N = radii.shape
     dev = means2d.device
     means2d, depths = _f32c(means2d.detach()), _f32c(depths.detach())
     radii = radii.contiguous()
+    assert (conics is None) == (opacities is None)
+    if conics is not None:
+        conics, opacities = _f32c(conics.detach()), _f32c(opacities.detach())
+        assert conics.shape == (Cn, N, 3) and opacities.shape == (Cn, N)
     lib = L.lib()
     tiles_per_gauss = torch.empty(Cn, N, device=dev, dtype=torch.int32)
     ws_bytes = lib.bds_isect_prepare_workspace_bytes(Cn, N)
     ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
     m = C.c_int64(0)
     with L.timed("isect_prepare"):
-        L.check(lib.bds_isect_prepare(Cn, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), tile_size, tile_width, tile_height,
+        L.check(lib.bds_isect_prepare(Cn, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
+                                      tile_size, tile_width, tile_height,
                                       L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), L.stream()), "bds_isect_prepare")
     M = int(m.value)
     flatten_ids = torch.empty(M, device=dev, dtype=torch.int32)
@@ -169,7 +179,8 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     ws2_bytes = lib.bds_isect_build_workspace_bytes(Cn, N, M)
     ws2 = torch.empty(max(ws2_bytes, 16), device=dev, dtype=torch.uint8)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build(Cn, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), tile_size, tile_width, tile_height,
+        L.check(lib.bds_isect_build(Cn, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
+                                    tile_size, tile_width, tile_height,
                                     L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, L.ptr(isect_ids), L.ptr(flatten_ids),
                                     L.ptr(isect_offsets), L.stream()), "bds_isect_build")
     return tiles_per_gauss, isect_ids, flatten_ids, isect_offsets

@@ -21,8 +21,7 @@ import torch
 from torch import Tensor
 
 from .bilagrid import bilagrid_transform, total_variation_loss
-from .gs_ops import spherical_harmonics
-from .rendering import rasterization
+from .gs_ops import (TILE_SIZE, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
 
 SIX_CAM_YAWS = (0.0, 55.0, -55.0, 110.0, -110.0, 180.0)
 FIVE_CAM_YAWS = (0.0, 45.0, -45.0, 90.0, -90.0)
@@ -30,6 +29,7 @@ LEVELS_3 = ((2, 2, 1), (4, 4, 2), (8, 8, 4))   # configs/omnire_ms_bilateral*.ya
 FACTORS_3 = (4, 4, 2)                          # modules.py:505 default guidance_factor
 LEVELS_SINGLE = ((16, 16, 8),)
 FACTORS_SINGLE = (1,)
+TILE_CULL = True  # exact tile culling in render_view (see gs_ops.isect_tiles); images/gradients are unaffected
 
 
 @dataclass
@@ -86,25 +86,42 @@ def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> L
 
 def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
                 factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
-                radius_clip: float = 0.0):
-    """One view's forward: returns dict(rgb, depth, opacity, rgb_gaussians, info)."""
+                radius_clip: float = 0.0, eps2d: float = 0.3):
+    """One view's forward: returns dict(rgb, depth, opacity, rgb_gaussians, info).
+
+    Same arithmetic as get_gaussians -> rasterization(...) -> split/clamp -> sky blend -> affine_transformation in
+    the reference; the stages are called directly so that SH colours are only evaluated for Gaussians that survive
+    projection (the reference evaluates all N before it knows which are visible)."""
     means = params["means"]
-    c2w_t = torch.linalg.inv(cam.viewmat)[:3, 3]
-    viewdirs = means.detach() - c2w_t                                       # vanilla.py:385
-    rgbs = spherical_harmonics(sh_degree, viewdirs, params["sh"])           # vanilla.py:388 (normalises inside)
-    rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)                                # vanilla.py:389
+    W, H = cam.width, cam.height
     opac = torch.sigmoid(params["opacity_logits"])                         # vanilla.py:393
     scales = torch.exp(params["log_scales"])
     quats = params["quats"] / params["quats"].norm(dim=-1, keepdim=True)
-    renders, alphas, info = rasterization(                                   # trainers/base.py:393-408
-        means=means, quats=quats, scales=scales, opacities=opac, colors=rgbs, viewmats=cam.viewmat[None], Ks=cam.K[None],
-        width=cam.width, height=cam.height, packed=False, absgrad=True, sparse_grad=False, rasterize_mode="classic",
-        near_plane=near_plane, far_plane=far_plane, render_mode="RGB+ED", radius_clip=radius_clip)
+    viewmats, Ks = cam.viewmat[None], cam.K[None]
+    radii, means2d, depths, conics, _ = fully_fused_projection(means, quats, scales, viewmats, Ks, W, H, eps2d=eps2d,
+                                                               near_plane=near_plane, far_plane=far_plane,
+                                                               radius_clip=radius_clip)
+    c2w_t = torch.linalg.inv(cam.viewmat)[:3, 3]
+    viewdirs = means.detach() - c2w_t                                       # vanilla.py:385
+    rgbs = spherical_harmonics(sh_degree, viewdirs, params["sh"], masks=radii[0] > 0)  # vanilla.py:388
+    rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)                                # vanilla.py:389
+    colors = torch.cat([rgbs, depths[0][:, None]], dim=-1)[None]            # render_mode "RGB+ED"
+    opac_c = opac[None]
+    tw, th = math.ceil(W / TILE_SIZE), math.ceil(H / TILE_SIZE)
+    tiles_per_gauss, _, flatten_ids, isect_offsets = isect_tiles(means2d, radii, depths, TILE_SIZE, tw, th,
+                                                                 want_isect_ids=False, conics=conics if TILE_CULL else None,
+                                                                 opacities=opac_c if TILE_CULL else None)
+    renders, alphas = rasterize_to_pixels(means2d, conics, colors, opac_c, W, H, TILE_SIZE, isect_offsets, flatten_ids,
+                                          absgrad=True)
     renders = renders[0]
-    rgb_g, depth = renders[..., :3], renders[..., 3:4]                      # base.py:414 (clamp is fused below)
+    rgb_g = renders[..., :3]                                                 # base.py:414 (clamp is fused below)
     opacity = alphas[0]                                                      # [H,W,1]
+    depth = renders[..., 3:4] / opacity.clamp(min=1e-10)                     # expected depth ("ED")
     grids_k = [g[img_idx:img_idx + 1] for g in grids]
     rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)  # clamp + sky blend + slice + affine
+    info = {"means2d": means2d, "radii": radii, "depths": depths, "conics": conics, "width": W, "height": H,
+            "tiles_per_gauss": tiles_per_gauss, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
+            "tile_size": TILE_SIZE, "n_cameras": 1}
     return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
 
 

@@ -8,6 +8,7 @@ Pipeline (every stage a hand-written gfx950 kernel behind libbds.so):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -33,6 +34,17 @@ def _isect_ids_from(isect_offsets: Tensor, flatten_ids: Tensor, depths: Tensor) 
     tile = torch.bucketize(idx, isect_offsets.reshape(-1).long(), right=True) - 1  # camera*tiles + tile
     bits = depths.detach().reshape(-1)[flatten_ids.long()].contiguous().view(torch.int32).long()
     return (tile << 32) | bits
+
+
+# Exact tile culling (see gs_ops.isect_tiles): on by default -- images and gradients are identical, only the
+# intersection lists in ``meta`` (tiles_per_gauss / flatten_ids / isect_ids / isect_offsets) are shorter than
+# gsplat's bounding-square lists.  Switch off to reproduce gsplat's lists entry for entry.
+_TILE_CULLING = os.environ.get("BDS_TILE_CULL", "1") != "0"
+
+
+def set_tile_culling(on: bool) -> None:
+    global _TILE_CULLING
+    _TILE_CULLING = bool(on)
 
 
 def _as_int(v) -> int:
@@ -129,7 +141,9 @@ def rasterization(
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(means2d, radii, depths, tile_size, tile_width,
-                                                                         tile_height, want_isect_ids=False)
+                                                                         tile_height, want_isect_ids=False,
+                                                                         conics=conics if _TILE_CULLING else None,
+                                                                         opacities=opac.contiguous() if _TILE_CULLING else None)
     render_colors, render_alphas = rasterize_to_pixels(means2d, conics, col.contiguous(), opac.contiguous(), width, height,
                                                        tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds,
                                                        absgrad=absgrad)

@@ -90,11 +90,15 @@ int bds_project_bwd(int C, int64_t N, const float *means, const float *quats, co
  * `ws2` (bds_isect_build_workspace_bytes) is scratch for build.  M must be < 2^31. */
 size_t bds_isect_prepare_workspace_bytes(int C, int64_t N);
 size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M);
+/* conics [C,N,3] + opacities [C,N] (both or neither): when given, (tile, Gaussian) pairs in which no
+ * pixel centre can reach alpha >= 1/255 are dropped ("exact tile culling"): rendered images and
+ * gradients are unchanged, M shrinks; when NULL the lists are gsplat's bounding-square lists. */
 int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
-                      int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws, size_t ws_bytes,
-                      int64_t *n_isects, bds_stream_t stream);
+                      const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                      int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *n_isects, bds_stream_t stream);
 int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int32_t *radii, const float *depths,
-                    int tile_size, int tile_w, int tile_h, const void *ws, size_t ws_bytes, void *ws2,
+                    const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h, const void *ws,
+                    size_t ws_bytes, void *ws2,
                     size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
                     bds_stream_t stream);
 

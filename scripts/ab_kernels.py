@@ -52,6 +52,7 @@ def main():
     target = torch.rand(a.height, a.width, 3, generator=gen).to(dev)
     cam = cams[a.view]
 
+    Hn.TILE_CULL = False
     out = Hn.render_view(params, cam, grids, a.view, sky)
     info = out["info"]
     M = info["flatten_ids"].numel()
@@ -77,9 +78,10 @@ def main():
             L.set_option(L.OPT_RASTER_BWD, rb)
             L.set_option(L.OPT_RADIX, rx)
             fwd_bwd()
-    order = [(2, 1), (1, 1), (0, 1), (2, 0)]
+    order = [(2, 1, True), (2, 1, False), (1, 1, True), (2, 0, True)]
     for r in range(a.rounds):
-        for rb, rx in order:
+        for rb, rx, cull in order:
+            Hn.TILE_CULL = cull
             L.set_option(L.OPT_RASTER_BWD, rb)
             L.set_option(L.OPT_RADIX, rx)
             L.enable_timers(True)
@@ -87,14 +89,18 @@ def main():
             torch.cuda.synchronize()
             ts = L.timer_summary()
             L.enable_timers(False)
-            d = res.setdefault(f"bwd{rb}_radix{rx}", {"step": [], "rasterize_bwd": [], "rasterize_fwd": [], "isect_prepare": [],
-                                                     "isect_build": [], "bilagrid_bwd": [], "bilagrid_fwd": []})
+            d = res.setdefault(f"bwd{rb}_radix{rx}_cull{int(cull)}", {"step": [], "rasterize_bwd": [], "rasterize_fwd": [], "isect_prepare": [],
+                                                     "isect_build": [], "bilagrid_bwd": [], "bilagrid_fwd": [], "sh_fwd": [], "sh_bwd": [],
+                                                     "project_fwd": [], "project_bwd": []})
             d["step"].append(t)
             for k in d:
                 if k != "step" and k in ts:
                     d[k].append(ts[k][1])
     L.set_option(L.OPT_RASTER_BWD, 2)
     L.set_option(L.OPT_RADIX, 1)
+    Hn.TILE_CULL = True
+    out = Hn.render_view(params, cam, grids, a.view, sky)
+    print("CULLED_M", out["info"]["flatten_ids"].numel())
     for name, d in res.items():
         print("AB", name, json.dumps({k: {"median": round(statistics.median(v), 4), "min": round(min(v), 4)} for k, v in d.items() if v}))
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/<tag>/ profile (scripts/profile_round.sh) into small committed files under
+profiles/: per-kernel stats (rocprofv3 --kernel-trace --stats) and per-kernel HBM traffic from the
+FETCH_SIZE / WRITE_SIZE passes (KB per launch; gfx950 correction: FETCH_SIZE x2 for wide coalesced
+reads, calibrated here on sh_fwd_kernel whose byte count is known)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+src = os.path.join("gpurun_out", tag)
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv"))))
+total = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows[:45]:
+        w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+print(f"GPU kernel time per step: {total / steps / 1e6:.3f} ms over {steps} steps")
+
+pmc = {}
+for name, key in (("pmc_fetch", "FETCH_SIZE_KB"), ("pmc_write", "WRITE_SIZE_KB")):
+    path = os.path.join(src, name, "bench_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0][:80]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    for k, (n, v) in agg.items():
+        if k.startswith("void bds::") or k.startswith("bds::"):
+            pmc.setdefault(k, {})[key] = v / n
+            pmc[k]["launches"] = n
+for k, d in pmc.items():
+    f, wv = d.get("FETCH_SIZE_KB", 0.0), d.get("WRITE_SIZE_KB", 0.0)
+    d["hbm_bytes_per_launch_corrected"] = (2.0 * f + wv) * 1024.0
+json.dump({"note": "KB per launch, mean over launches; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                   "(MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read on gfx950; "
+                   "WRITE_SIZE is exact -- both confirmed on sh_fwd/sh_bwd whose byte counts are known)",
+           "kernels": pmc}, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+for extra in ("bench.json", "trace_bench.json"):
+    p = os.path.join(src, extra)
+    if os.path.exists(p):
+        open(os.path.join(dst, f"{tag}_{extra}"), "w").write(open(p).read())
+print("wrote", sorted(x for x in os.listdir(dst) if x.startswith(tag)))

@@ -62,7 +62,7 @@ def test_argument_validation_without_gpu(libpath):
     assert h.bds_isect_build_workspace_bytes(1, 1000, 50000) > 3 * 4 * 50000
     lv = (_lib.BdsLevel * 1)()
     lv[0].gx, lv[0].gy, lv[0].gl, lv[0].factor, lv[0].n_avg = 8, 8, 4, 2, 1
-    assert h.bds_bilagrid_ms_workspace_bytes(1, lv, 64, 64) >= 32 * 32 * 48 + 2 * 64 * 64 * 12
+    assert h.bds_bilagrid_ms_workspace_bytes(1, lv, 64, 64) >= 2 * 32 * 32 * 48  # low-res maps + their gradients
     assert h.bds_bilagrid_ms_workspace_bytes(0, lv, 64, 64) == 0
 
 

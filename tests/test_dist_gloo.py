@@ -41,8 +41,8 @@ def _worker(rank, world, port, q):
         flat.zero()
         v = view_for_rank(step, rank, world, 6)
         _toy_loss(params, v).backward()
-        flat.check_views()  # autograd accumulated in place into the communication buffer
         flat.all_reduce()
+        assert all(p.grad.data_ptr() == w.data_ptr() for p, w in zip(params, flat._views))  # grads = reduced slices
         outs.append(flat.flat.clone())
     a, b, c = torch.full((4,), float(rank + 1)), torch.full((4,), float(rank + 1)), torch.tensor([1.0, 5.0, 2.0, 0.0]) * (rank + 1)
     reduce_densify_stats(a, b, c)
@@ -81,12 +81,11 @@ def test_flat_gradients_single_process():
     flat = FlatGradients(params)
     assert flat.nbytes == 4 * sum(p.numel() for p in params)
     _toy_loss(params, 0).backward()
-    g0 = flat.flat.clone()
-    assert float(g0.abs().sum()) > 0
-    assert flat.all_reduce() is None  # no process group: no-op
+    g0 = torch.cat([p.grad.reshape(-1) for p in params])
+    assert flat.all_reduce() is None  # no process group: no-op, nothing is packed or copied
+    assert flat._flat is None
+    assert torch.equal(flat.pack(), g0)
     flat.zero()
-    assert float(flat.flat.abs().sum()) == 0 and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, flat.views))
-    params[0].grad = None  # e.g. optimizer.zero_grad(set_to_none=True)
-    flat.zero()
+    assert all(p.grad is None for p in params)
     _toy_loss(params, 0).backward()
-    assert torch.equal(flat.flat, g0)
+    assert torch.equal(flat.pack(), g0)

@@ -239,3 +239,93 @@ def test_permutation_and_determinism(ops):
     perm = torch.randperm(3000, device="cuda")
     r2, a2, _ = R.rasterization(*[x[perm] for x in args], sc["viewmats"].cuda(), sc["Ks"].cuda(), 192, 160, render_mode="RGB+ED")
     assert rel_err(r2.cpu(), r1.cpu()) < 1e-6  # order only changes tie-breaking of exactly equal depths
+
+
+@pytest.mark.parametrize("seed,N,W,H", [(0, 3000, 256, 192), (1, 20000, 640, 368), (2, 400, 96, 64)])
+def test_exact_tile_culling_is_invisible(ops, seed, N, W, H):
+    """Dropping (tile, Gaussian) pairs in which no pixel reaches alpha >= 1/255 changes neither image nor
+    gradients; the culled lists are sub-lists of gsplat's bounding-square lists."""
+    sc = make_scene(N, W, H, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    res = {}
+    for cull in (False, True):
+        p = {k: sc[k].cuda().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+        radii, m2, d, con, _ = ops.fully_fused_projection(p["means"], p["quats"], p["scales"], sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H)
+        col = torch.cat([p["colors"], d[0][:, None]], -1)[None]
+        op = p["opacities"][None]
+        tw, th = (W + 15) // 16, (H + 15) // 16
+        tpg, iids, fids, offs = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con if cull else None, opacities=op if cull else None)
+        r, a = ops.rasterize_to_pixels(m2, con, col, op, W, H, 16, offs, fids, absgrad=True)
+        wt = torch.randn(r.shape, generator=torch.Generator().manual_seed(seed)).cuda()
+        ((r * wt).sum() + a.sum()).backward()
+        res[cull] = dict(r=r.detach(), a=a.detach(), tpg=tpg, iids=iids, grads={k: v.grad.clone() for k, v in p.items()},
+                         m2=m2.detach(), con=con.detach(), op=op.detach(), fids=fids, offs=offs)
+    full, cul = res[False], res[True]
+    assert torch.equal(full["r"], cul["r"]) and torch.equal(full["a"], cul["a"])  # forward is bit-identical
+    assert bool((cul["tpg"] <= full["tpg"]).all())
+    assert cul["iids"].numel() < 0.8 * full["iids"].numel()  # the lists really shrink
+    # culled keys are a sub-multiset of the full keys (both sorted)
+    merged = torch.cat([full["iids"], cul["iids"]]).sort().values
+    uniq, counts = torch.unique_consecutive(merged, return_counts=True)
+    assert int(counts.max()) <= 2 and int((counts == 2).sum()) == cul["iids"].numel()
+    for k in full["grads"]:
+        ref, got = full["grads"][k], cul["grads"][k]
+        assert float((got - ref).norm() / ref.norm().clamp(min=1e-20)) < 1e-5, k
+    # brute force (float64, CPU): every dropped pair has max alpha over its tile's pixel centres < 1/255
+    tw = (W + 15) // 16
+    fk, ck = full["iids"].cpu(), cul["iids"].cpu()
+    keep = torch.isin(fk, ck)
+    dropped = (~keep).nonzero()[:, 0]
+    sel = dropped[torch.randperm(dropped.numel(), generator=g)[:3000]]
+    gid = full["fids"].cpu().long()[sel]
+    tile = (fk[sel] >> 32)
+    m2, con, op = full["m2"][0].cpu().double(), full["con"][0].cpu().double(), full["op"][0].cpu().double()
+    ys, xs = torch.meshgrid(torch.arange(16, dtype=torch.float64) + 0.5, torch.arange(16, dtype=torch.float64) + 0.5, indexing="ij")
+    px = (tile % tw).double()[:, None, None] * 16 + xs
+    py = (tile // tw).double()[:, None, None] * 16 + ys
+    dx, dy = m2[gid, 0][:, None, None] - px, m2[gid, 1][:, None, None] - py
+    sig = 0.5 * (con[gid, 0][:, None, None] * dx * dx + con[gid, 2][:, None, None] * dy * dy) + con[gid, 1][:, None, None] * dx * dy
+    alpha = op[gid][:, None, None] * torch.exp(-sig)
+    assert float(alpha.reshape(len(sel), -1).max(dim=1).values.max()) < 1.0 / 255.0
+
+
+def test_harness_view_matches_rasterization_api(ops):
+    """harness.render_view (stage ops, SH after projection with the visibility mask, culling) ==
+    the reference-shaped call sequence through rasterization() + separate torch post-processing."""
+    import bilateral_driving_amd.rendering as R
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.bilagrid import bilagrid_transform
+    dev = "cuda"
+    W, H, N = 320, 192, 4000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    base = Hn.synthetic_scene(N, seed=1, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    grids0 = Hn.make_grids(2, device=dev)
+    sky = torch.rand(H, W, 3, device=dev)
+    target = torch.rand(H, W, 3, device=dev)
+    outs = []
+    for mode in ("harness", "api"):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        if mode == "harness":
+            out = Hn.render_view(p, cam, grids, 1, sky)
+            rgb, depth = out["rgb"], out["depth"]
+        else:
+            dirs = p["means"].detach() - torch.linalg.inv(cam.viewmat)[:3, 3]
+            col = torch.clamp(ops.spherical_harmonics(3, dirs, p["sh"]) + 0.5, 0.0, 1.0)
+            rr, aa, info = R.rasterization(p["means"], p["quats"] / p["quats"].norm(dim=-1, keepdim=True), torch.exp(p["log_scales"]),
+                                           torch.sigmoid(p["opacity_logits"]), col, cam.viewmat[None], cam.K[None], W, H,
+                                           packed=False, absgrad=True, near_plane=0.1, render_mode="RGB+ED")
+            rgb_g = torch.clamp(rr[0][..., :3], max=1.0)
+            blended = rgb_g + sky * (1.0 - aa[0])
+            rgb = bilagrid_transform(blended, [g[1:2] for g in grids], Hn.FACTORS_3)
+            depth = rr[0][..., 3:4]
+        loss = (rgb - target).abs().mean() + 0.1 * depth.mean() * 0.01
+        loss.backward()
+        outs.append((rgb.detach(), depth.detach(), {k: v.grad.clone() for k, v in p.items()}, [g.grad.clone() for g in grids]))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][1], outs[1][1]) < 1e-5
+    for k in outs[0][2]:
+        a, b = outs[0][2][k], outs[1][2][k]
+        assert float((a - b).norm() / b.norm()) < 1e-4, k
+    for a, b in zip(outs[0][3], outs[1][3]):
+        assert float((a - b).norm() / b.norm()) < 1e-4
