@@ -22,8 +22,9 @@ struct LevelDev {
   const float *grid;   // [n_avg,12,gl,gy,gx]
   float *v_grid;
   float *lo;           // [Hd*Wd,12] low-res affine maps
-  float *va;           // [Hd*Wd,12] gradient w.r.t. the low-res affine maps (bwd scratch)
-  int lds_off, cw, ch; // backward tile accumulator: offset (floats) and cell-window size in LDS
+  float *P;            // [H*W,3] input colour of this level                  (bwd scratch)
+  float *Q;            // [H*W,3] gradient w.r.t. this level's output          (bwd scratch)
+  float *R;            // [H*Wd,12] x-reduced adjoint of the up-sampler        (bwd scratch)
   float *aff_out;      // optional [H*W,12]
   int gx, gy, gl, factor, n_avg, Hd, Wd;
 };
@@ -138,103 +139,84 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
   out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
 }
 
-// ---- C: full-resolution backward ---------------------------------------------------------------
-// One workgroup = a 16 x 64 pixel tile, four pixels per thread.  Per pixel the level chain is replayed,
-// the direct-route gradient is written, and each level's d(loss)/d(A_l) = v (x) [p;1] is pushed through
-// the adjoint of the bilinear up-sampler into a per-tile LDS window of low-res cells (ds_add_f32);
-// the window is flushed to the level's [Hd*Wd,12] buffer once per workgroup.  Nothing image-sized and
-// level-specific ever goes to HBM (the reference's autograd keeps three [H,W,3,4] maps + their grads).
-constexpr int kBwdTileH = 16, kBwdTileW = 64;
-
+// ---- C: full-resolution backward: direct route + per-level (P, Q) ------------------------------------
+// d(loss)/d(A_l) at a pixel is the outer product Q (x) [P;1] of the gradient arriving at level l's output
+// and the colour entering it; only those 6 floats per level are stored.  The adjoint of the bilinear
+// up-sampler is then applied SEPARABLY and gather-style (deterministic, no atomics): an x pass
+// (kernel D1) reduces each image row onto the low-res columns, a y pass (fused in kernel D2) reduces
+// those onto the low-res rows -- 2(2f+2) taps per output instead of (2f+2)^2.
 template <int NL>
-__global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, int lds_floats, const float *__restrict__ v_out,
+__global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, const float *__restrict__ v_out,
                                                                float *__restrict__ v_in) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int e = threadIdx.x; e < lds_floats; e += kBgBlock) lds[e] = 0.f;
-  const int tiles_x = (p.W + kBwdTileW - 1) / kBwdTileW;
-  const int r0 = (blockIdx.x / tiles_x) * kBwdTileH, c0 = (blockIdx.x % tiles_x) * kBwdTileW;
-  int cy0[NL], cx0[NL];
+  const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (pix >= (int64_t)p.H * p.W) return;
+  const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
+  float r, g, b;
+  load_input(p, i, j, r, g, b);
 #pragma unroll
   for (int l = 0; l < NL; l++) {
-    cy0[l] = cx0[l] = 0;
-    if (l < p.nlevels && p.lv[l].cw > 0) {
-      cy0[l] = resample_tap(r0, p.H, p.lv[l].Hd).i0;
-      cx0[l] = resample_tap(c0, p.W, p.lv[l].Wd).i0;
+    if (l < p.nlevels) {
+      float *P = p.lv[l].P + pix * 3;
+      P[0] = r; P[1] = g; P[2] = b;
+      float A[12];
+      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+      apply_affine(A, r, g, b);
     }
   }
-  __syncthreads();
-  const int j = c0 + (threadIdx.x & (kBwdTileW - 1));
-#pragma unroll 1
-  for (int q = 0; q < 4; q++) {
-    const int i = r0 + (threadIdx.x / kBwdTileW) + 4 * q;
-    if (i >= p.H || j >= p.W) continue;
-    const int64_t pix = (int64_t)i * p.W + j;
-    float pr[NL], pg[NL], pb[NL];
-    float r, g, b;
-    load_input(p, i, j, r, g, b);
+  float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
 #pragma unroll
-    for (int l = 0; l < NL; l++) {
-      pr[l] = r; pg[l] = g; pb[l] = b;
-      if (l < p.nlevels) {
-        float A[12];
-        upsample_affine(p.lv[l], p.H, p.W, i, j, A);
-        apply_affine(A, r, g, b);
-      }
-    }
-    float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
-#pragma unroll
-    for (int l = NL - 1; l >= 0; l--) {
-      if (l < p.nlevels) {
-        const LevelDev &L = p.lv[l];
-        const float o[12] = {v0 * pr[l], v0 * pg[l], v0 * pb[l], v0, v1 * pr[l], v1 * pg[l], v1 * pb[l], v1,
-                             v2 * pr[l], v2 * pg[l], v2 * pb[l], v2};
-        if (L.cw == 0) {  // level sliced at full resolution: the map IS the low-res map
-          float4 *d = reinterpret_cast<float4 *>(L.va + pix * 12);
-          d[0] = make_float4(o[0], o[1], o[2], o[3]);
-          d[1] = make_float4(o[4], o[5], o[6], o[7]);
-          d[2] = make_float4(o[8], o[9], o[10], o[11]);
-        } else {
-          const Tap ty = resample_tap(i, p.H, L.Hd), tx = resample_tap(j, p.W, L.Wd);
-          const int ys[2] = {ty.i0 - cy0[l], ty.i1 - cy0[l]}, xs[2] = {tx.i0 - cx0[l], tx.i1 - cx0[l]};
-          const float wy[2] = {1.f - ty.w1, ty.w1}, wx[2] = {1.f - tx.w1, tx.w1};
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int bb = 0; bb < 2; bb++) {
-              const float w = wy[a] * wx[bb];
-              if (w != 0.f) {
-                float *cell = lds + L.lds_off + (ys[a] * L.cw + xs[bb]) * 12;
-#pragma unroll
-                for (int k = 0; k < 12; k++) atomicAdd(cell + k, w * o[k]);
-              }
-            }
-        }
-        float A[12];
-        upsample_affine(L, p.H, p.W, i, j, A);
-        const float n0 = A[0] * v0 + A[4] * v1 + A[8] * v2;
-        const float n1 = A[1] * v0 + A[5] * v1 + A[9] * v2;
-        const float n2 = A[2] * v0 + A[6] * v1 + A[10] * v2;
-        v0 = n0; v1 = n1; v2 = n2;
-      }
-    }
-    v_in[pix * 3] = v0; v_in[pix * 3 + 1] = v1; v_in[pix * 3 + 2] = v2;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l >= p.nlevels) break;
-    const LevelDev &L = p.lv[l];
-    if (L.cw == 0) continue;
-    const int n = L.cw * L.ch * 12;
-    for (int e = threadIdx.x; e < n; e += kBgBlock) {
-      const float v = lds[L.lds_off + e];
-      if (v != 0.f) {
-        const int cell = e / 12, k = e - cell * 12;
-        const int cy = cy0[l] + cell / L.cw, cx = cx0[l] + cell % L.cw;
-        if (cy < L.Hd && cx < L.Wd) atomicAdd(L.va + ((int64_t)cy * L.Wd + cx) * 12 + k, v);
-      }
+  for (int l = NL - 1; l >= 0; l--) {
+    if (l < p.nlevels) {
+      float *Q = p.lv[l].Q + pix * 3;
+      Q[0] = v0; Q[1] = v1; Q[2] = v2;
+      float A[12];
+      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+      const float n0 = A[0] * v0 + A[4] * v1 + A[8] * v2;
+      const float n1 = A[1] * v0 + A[5] * v1 + A[9] * v2;
+      const float n2 = A[2] * v0 + A[6] * v1 + A[10] * v2;
+      v0 = n0; v1 = n1; v2 = n2;
     }
   }
+  v_in[pix * 3] = v0; v_in[pix * 3 + 1] = v1; v_in[pix * 3 + 2] = v2;
+}
+
+// destination indices of a bilinear up-sample (size `full` from `low`) whose taps touch source cell c:
+// conservative [lo, hi] (every candidate is re-checked with resample_tap)
+__device__ __forceinline__ void adjoint_range(int c, int full, int low, int &lo, int &hi) {
+  const float s = (float)full / (float)low;
+  lo = (int)floorf(((float)c - 0.5f) * s - 0.5f) - 1;
+  hi = (int)ceilf(((float)c + 1.5f) * s - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > full - 1 ? full - 1 : hi;
+}
+
+// ---- D1: x pass of the up-sampler adjoint: R[y, cx, :] = sum_x wx(x -> cx) * Q[y,x] (x) [P[y,x]; 1] -------
+__global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, int l) {
+  const LevelDev &L = p.lv[l];
+  const int64_t idx = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (idx >= (int64_t)p.H * L.Wd) return;
+  const int y = (int)(idx / L.Wd), cx = (int)(idx - (int64_t)y * L.Wd);
+  int xlo, xhi;
+  adjoint_range(cx, p.W, L.Wd, xlo, xhi);
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.f;
+  for (int x = xlo; x <= xhi; x++) {
+    const Tap tx = resample_tap(x, p.W, L.Wd);
+    const float w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
+    if (w == 0.f) continue;
+    const int64_t o = ((int64_t)y * p.W + x) * 3;
+    const float p0 = L.P[o], p1 = L.P[o + 1], p2 = L.P[o + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float q = L.Q[o + r] * w;
+      acc[r * 4 + 0] += q * p0; acc[r * 4 + 1] += q * p1; acc[r * 4 + 2] += q * p2; acc[r * 4 + 3] += q;
+    }
+  }
+  float4 *d = reinterpret_cast<float4 *>(L.R + idx * 12);
+  d[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  d[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  d[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
 }
 
 // wave64 sum leaving the result in every lane (used only on wave-uniform-address grid updates)
@@ -266,7 +248,7 @@ __device__ __forceinline__ void corner_accumulate(float *acc, int base, int vol,
   }
 }
 
-// ---- D: per-level low-resolution backward (slice vjp into the grid, guidance route) ---------------
+// ---- D2: per-level low-resolution backward (y pass, slice vjp into the grid, guidance route) -----------
 // kLds: the level's grid gradient (n_avg * 12*gl*gy*gx floats) fits the workgroup's LDS accumulator.
 template <bool kLds>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int l, float *__restrict__ v_in) {
@@ -286,10 +268,26 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
 #pragma unroll
   for (int k = 0; k < 12; k++) va[k] = 0.f;
   if (active) {
-    const float4 *sv = reinterpret_cast<const float4 *>(L.va + idx * 12);
-    const float4 a = sv[0], b = sv[1], c = sv[2];
-    va[0] = a.x; va[1] = a.y; va[2] = a.z; va[3] = a.w; va[4] = b.x; va[5] = b.y; va[6] = b.z; va[7] = b.w;
-    va[8] = c.x; va[9] = c.y; va[10] = c.z; va[11] = c.w;
+    if (L.Hd == p.H && L.Wd == p.W) {
+      const float *P = L.P + idx * 3, *Q = L.Q + idx * 3;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        va[r * 4 + 0] = Q[r] * P[0]; va[r * 4 + 1] = Q[r] * P[1]; va[r * 4 + 2] = Q[r] * P[2]; va[r * 4 + 3] = Q[r];
+      }
+    } else {  // y pass of the up-sampler adjoint over the x-reduced rows
+      int ylo, yhi;
+      adjoint_range(i, p.H, L.Hd, ylo, yhi);
+      for (int y = ylo; y <= yhi; y++) {
+        const Tap ty = resample_tap(y, p.H, L.Hd);
+        const float w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
+        if (w == 0.f) continue;
+        const float4 *sv = reinterpret_cast<const float4 *>(L.R + ((int64_t)y * L.Wd + j) * 12);
+        const float4 a = sv[0], b = sv[1], c = sv[2];
+        va[0] += w * a.x; va[1] += w * a.y; va[2] += w * a.z; va[3] += w * a.w;
+        va[4] += w * b.x; va[5] += w * b.y; va[6] += w * b.z; va[7] += w * b.w;
+        va[8] += w * c.x; va[9] += w * c.y; va[10] += w * c.z; va[11] += w * c.w;
+      }
+    }
   }
   // slice backward
   const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
@@ -449,8 +447,7 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
 
 // ---- host side ---------------------------------------------------------------------------------
 struct MsLayout {
-  size_t lo_off[BDS_MAX_LEVELS], va_off[BDS_MAX_LEVELS];
-  size_t va_begin, va_end;  // the va buffers of the up-sampled levels are contiguous: one memset
+  size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS];
   size_t bytes;
 };
 static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, int W) {
@@ -461,13 +458,13 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     L.lo_off[l] = off;
     off += align_up((size_t)Hd * Wd * 12 * sizeof(float), 256);
   }
-  L.va_begin = off;
   for (int l = 0; l < nlevels; l++) {
     const int Hd = H / lv[l].factor, Wd = W / lv[l].factor;
-    L.va_off[l] = off;
-    off += align_up((size_t)Hd * Wd * 12 * sizeof(float), 256);
+    L.p_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
+    L.q_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
+    L.r_off[l] = off;
+    if (!(Hd == H && Wd == W)) off += align_up((size_t)H * Wd * 12 * sizeof(float), 256);
   }
-  L.va_end = off;
   L.bytes = off;
   return L;
 }
@@ -487,8 +484,9 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
     LevelDev &d = p.lv[l];
     d.grid = lv[l].grid; d.v_grid = lv[l].v_grid;
     d.lo = reinterpret_cast<float *>(base + L.lo_off[l]);
-    d.va = reinterpret_cast<float *>(base + L.va_off[l]);
-    d.lds_off = d.cw = d.ch = 0;
+    d.P = reinterpret_cast<float *>(base + L.p_off[l]);
+    d.Q = reinterpret_cast<float *>(base + L.q_off[l]);
+    d.R = reinterpret_cast<float *>(base + L.r_off[l]);
     d.aff_out = affine_out ? affine_out[l] : nullptr;
     BDS_REQUIRE(d.aff_out == nullptr || aligned16(d.aff_out));
     d.gx = lv[l].gx; d.gy = lv[l].gy; d.gl = lv[l].gl; d.factor = lv[l].factor; d.n_avg = lv[l].n_avg;
@@ -545,34 +543,23 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
   BDS_REQUIRE(v_rgb_out && v_rgb);
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
-  // per-tile LDS windows of low-res cells for the levels that are up-sampled
-  int lds_floats = 0;
-  for (int l = 0; l < nlevels; l++) {
-    LevelDev &d = p.lv[l];
-    if (d.Hd == H && d.Wd == W) continue;
-    d.ch = kBwdTileH / d.factor + 3;
-    d.cw = kBwdTileW / d.factor + 3;
-    d.lds_off = lds_floats;
-    lds_floats += d.ch * d.cw * 12;
-  }
-  BDS_REQUIRE((size_t)lds_floats * sizeof(float) <= 64 * 1024);
   {
-    const MsLayout ML = ms_layout(nlevels, levels, H, W);
-    if (hipMemsetAsync(static_cast<char *>(ws) + ML.va_begin, 0, ML.va_end - ML.va_begin, st) != hipSuccess) return BDS_ELAUNCH;
-  }
-  const unsigned tiles = (unsigned)(cdiv(H, kBwdTileH) * cdiv(W, kBwdTileW));
-  {
-    const size_t lb = (size_t)lds_floats * sizeof(float);
-    const dim3 grid(tiles), block(kBgBlock);
+    const dim3 grid((unsigned)cdiv(HW, kBgBlock)), block(kBgBlock);
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_bwd_kernel<1>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
-      case 2: hipLaunchKernelGGL((ms_apply_bwd_kernel<2>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
-      case 3: hipLaunchKernelGGL((ms_apply_bwd_kernel<3>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
-      case 4: hipLaunchKernelGGL((ms_apply_bwd_kernel<4>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_kernel<BDS_MAX_LEVELS>), grid, block, lb, st, p, lds_floats, v_rgb_out, v_rgb); break;
+      case 1: hipLaunchKernelGGL((ms_apply_bwd_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+      case 2: hipLaunchKernelGGL((ms_apply_bwd_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+      case 3: hipLaunchKernelGGL((ms_apply_bwd_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
     }
   }
   BDS_LAUNCH_CHECK();
+  for (int l = 0; l < nlevels; l++) {
+    if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
+    const int64_t n = (int64_t)H * p.lv[l].Wd;
+    hipLaunchKernelGGL(ms_adjoint_x_kernel, dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l);
+    BDS_LAUNCH_CHECK();
+  }
   for (int l = 0; l < nlevels; l++) {
     const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;
     const size_t gbytes = sizeof(float) * 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;

@@ -408,9 +408,35 @@ BDS_HD bool tile_rect_tight(float mx, float my, int radius, float a, float b, fl
   return true;
 }
 
-BDS_HD bool tile_hit(float mx, float my, float a, float b, float c, float q_max, int tx, int ty, int tile_size) {
+// Tiles of tile-row `ty` (inside [x0, x1)) that contain a pixel centre of the tau-ellipse: the ellipse
+// cut by the row's band of pixel centres is convex, so the answer is ONE interval [tx_lo, tx_hi)
+// obtained in O(1) from the x-extent of that cut (no per-tile test).  Conservative by kSpanSlack px.
+constexpr float kSpanSlack = 0.02f;
+BDS_HD void row_tile_span(float mx, float my, float a, float b, float c, float q_max, int ty, int tile_size, int x0,
+                          int x1, int &tx_lo, int &tx_hi) {
+  tx_lo = tx_hi = x0;
   const float ts = (float)tile_size;
-  return rect_hits_ellipse(mx, my, a, b, c, q_max, tx * ts + 0.5f, ty * ts + 0.5f, tx * ts + ts - 0.5f, ty * ts + ts - 0.5f);
+  const float det = a * c - b * b;
+  const float hx = sqrtf(q_max * c / det), hy = sqrtf(q_max * a / det);
+  // band of pixel-centre rows of this tile row, relative to the mean, clipped to the ellipse's y-extent
+  float e0 = (ty * ts + 0.5f) - my, e1 = (ty * ts + ts - 0.5f) - my;
+  if (e0 > hy + kSpanSlack || e1 < -hy - kSpanSlack) return;
+  e0 = fminf(fmaxf(e0, -hy), hy);
+  e1 = fminf(fmaxf(e1, -hy), hy);
+  // x-extent of the ellipse at height dy: (-b dy -+ sqrt(a q - det dy^2)) / a
+  const float r0 = sqrtf(fmaxf(a * q_max - det * e0 * e0, 0.f)), r1 = sqrtf(fmaxf(a * q_max - det * e1 * e1, 0.f));
+  float xr = fmaxf((-b * e0 + r0) / a, (-b * e1 + r1) / a);
+  float xl = fminf((-b * e0 - r0) / a, (-b * e1 - r1) / a);
+  const float dyR = -b * hx / c;  // height of the right-most / left-most (-dyR) point of the ellipse
+  if (dyR >= e0 && dyR <= e1) xr = hx;
+  if (-dyR >= e0 && -dyR <= e1) xl = -hx;
+  xl += mx - kSpanSlack;
+  xr += mx + kSpanSlack;
+  // tile t holds pixel centres t*ts + 0.5 ... t*ts + ts - 0.5
+  int lo = (int)ceilf((xl - (ts - 0.5f)) / ts), hi = (int)floorf((xr - 0.5f) / ts) + 1;
+  lo = lo > x0 ? lo : x0;
+  hi = hi < x1 ? hi : x1;
+  if (hi > lo) { tx_lo = lo; tx_hi = hi; }
 }
 
 }  // namespace bds

@@ -66,6 +66,47 @@ __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, cons
   out[g * 3] = o0; out[g * 3 + 1] = o1; out[g * 3 + 2] = o2;
 }
 
+// Masked forward (the hot path evaluates SH after projection, only for the ~15 % of Gaussians that are
+// on screen): no LDS staging -- a visible Gaussian reads its own row with 16-byte loads, a culled one
+// touches nothing but its mask byte, so HBM traffic scales with the visible count.
+template <int DEG, bool kVec>
+__global__ __launch_bounds__(kShBlock) void sh_fwd_masked_kernel(int64_t n, int K, const float *__restrict__ dirs,
+                                                                const float *__restrict__ coeffs,
+                                                                const uint8_t *__restrict__ masks, float *__restrict__ out) {
+  constexpr int nb = (DEG + 1) * (DEG + 1);
+  const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
+  if (g >= n) return;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  if (masks[g]) {
+    float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+    float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+    float B[16];
+    sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+    const float *c = coeffs + g * (int64_t)K * 3;
+    float cf[nb * 3 + 3];
+    if (kVec) {
+      constexpr int n4 = (nb * 3 + 3) / 4;
+#pragma unroll
+      for (int i = 0; i < n4; i++) {
+        if (i * 4 < K * 3) {  // stay inside the row
+          const float4 v = reinterpret_cast<const float4 *>(c)[i];
+          cf[i * 4] = v.x; cf[i * 4 + 1] = v.y; cf[i * 4 + 2] = v.z; cf[i * 4 + 3] = v.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < nb * 3; i++) cf[i] = c[i];
+    }
+#pragma unroll
+    for (int k = 0; k < nb; k++) {
+      o0 += B[k] * cf[k * 3];
+      o1 += B[k] * cf[k * 3 + 1];
+      o2 += B[k] * cf[k * 3 + 2];
+    }
+  }
+  out[g * 3] = o0; out[g * 3 + 1] = o1; out[g * 3 + 2] = o2;
+}
+
 template <int DEG, bool kFull>
 __global__ __launch_bounds__(kShBlock) void sh_bwd_kernel(int64_t n, int K, const float *__restrict__ dirs,
                                                          const float *__restrict__ coeffs,
@@ -139,6 +180,14 @@ using namespace bds;
 template <int DEG>
 static void launch_fwd(bool full, int grid, size_t lds, hipStream_t st, int64_t n, int K, const float *dirs,
                        const float *coeffs, const uint8_t *masks, float *out) {
+  if (masks != nullptr) {
+    const bool vec = ((K * 3) % 4 == 0) && aligned16(coeffs);  // every row starts on a 16-byte boundary
+    if (vec)
+      hipLaunchKernelGGL((sh_fwd_masked_kernel<DEG, true>), dim3(grid), dim3(kShBlock), 0, st, n, K, dirs, coeffs, masks, out);
+    else
+      hipLaunchKernelGGL((sh_fwd_masked_kernel<DEG, false>), dim3(grid), dim3(kShBlock), 0, st, n, K, dirs, coeffs, masks, out);
+    return;
+  }
   if (full)
     hipLaunchKernelGGL((sh_fwd_kernel<DEG, true>), dim3(grid), dim3(kShBlock), lds, st, n, K, dirs, coeffs, masks, out);
   else

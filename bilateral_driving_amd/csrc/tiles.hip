@@ -327,8 +327,11 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(int64_t CN, co
       const float a = conics[o * 3], b = conics[o * 3 + 1], c = conics[o * 3 + 2];
       float q_max;
       if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
-        for (int ty = y0; ty < y1; ty++)
-          for (int tx = x0; tx < x1; tx++) cnt += tile_hit(mx, my, a, b, c, q_max, tx, ty, tile_size) ? 1 : 0;
+        for (int ty = y0; ty < y1; ty++) {
+          int lo, hi;
+          row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
+          cnt += hi - lo;
+        }
       }
     }
   }
@@ -375,13 +378,15 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(int64_t CN, int
     const float a = conics[(int64_t)o * 3], b = conics[(int64_t)o * 3 + 1], c = conics[(int64_t)o * 3 + 2];
     float q_max;
     if (!tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) return;
-    for (int ty = y0; ty < y1; ty++)
-      for (int tx = x0; tx < x1; tx++)
-        if (tile_hit(mx, my, a, b, c, q_max, tx, ty, tile_size)) {
-          keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
-          vals[off] = o;
-          off++;
-        }
+    for (int ty = y0; ty < y1; ty++) {
+      int lo, hi;
+      row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
+      for (int tx = lo; tx < hi; tx++) {
+        keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
+        vals[off] = o;
+        off++;
+      }
+    }
   }
 }
 

@@ -85,3 +85,18 @@ extern "C" void hm_slice(int P, const float *grid, int gx, int gy, int gl, const
     for (int k = 0; k < 12; k++) dgray12[i * 12 + k] = c.z_interior ? dz[k] * (float)(gl - 1) : 0.f;
   }
 }
+
+// culled tile set of one Gaussian as a tile_h x tile_w 0/1 mask (row-span method used by the kernels)
+extern "C" int hm_culled_tiles(float mx, float my, int radius, float a, float b, float c, float opacity, int tile_size, int tw,
+                               int th, unsigned char *mask) {
+  for (int i = 0; i < tw * th; i++) mask[i] = 0;
+  int x0, y0, x1, y1, n = 0;
+  float q_max;
+  if (!tile_rect_tight(mx, my, radius, a, b, c, opacity, tile_size, tw, th, x0, y0, x1, y1, q_max)) return 0;
+  for (int ty = y0; ty < y1; ty++) {
+    int lo, hi;
+    row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
+    for (int tx = lo; tx < hi; tx++) { mask[ty * tw + tx] = 1; n++; }
+  }
+  return n;
+}

@@ -142,7 +142,8 @@ def test_meta_isect_ids_lazy_equals_kernel(ops):
     _, _, meta = R.rasterization(*args, sc["viewmats"].cuda(), sc["Ks"].cuda(), 200, 120)
     assert dict.__getitem__(meta, "isect_ids") is None
     lazy = meta["isect_ids"]
-    _, iids, fids, offs = ops.isect_tiles(meta["means2d"], meta["radii"], meta["depths"], 16, meta["tile_width"], meta["tile_height"])
+    _, iids, fids, offs = ops.isect_tiles(meta["means2d"], meta["radii"], meta["depths"], 16, meta["tile_width"], meta["tile_height"],
+                                          conics=meta["conics"], opacities=meta["opacities"])  # rasterization() culls by default
     assert torch.equal(lazy, iids) and torch.equal(fids, meta["flatten_ids"]) and torch.equal(offs, meta["isect_offsets"])
 
 

@@ -146,3 +146,37 @@ def test_slice_matches_oracle(hm, gs):
         gr, = torch.autograd.grad(aff[:, ch].sum(), rgb_r, retain_graph=True)
         dgray = gr[:, 0] / 0.299
         assert np.abs(dg[:, ch] - dgray.numpy()).max() < 2e-4 * max(1.0, float(dgray.abs().max()))
+
+
+def test_tile_culling_is_conservative_and_tight(hm):
+    """Brute force over pixel centres (float64): every tile of gsplat's bounding square that holds a pixel
+    with alpha >= 1/255 is kept by the row-span culling; few kept tiles are useless."""
+    W, H, ts = 320, 208, 16
+    tw, th = W // ts, H // ts
+    sc = make_scene(600, W, H, seed=12, dtype=torch.float32, spread=1.2)
+    radii, m2, dep, con, _ = G.project(sc["means"], sc["quats"], sc["scales"], sc["viewmats"][0], sc["Ks"][0], W, H)
+    op = sc["opacities"].clone()
+    op[:20] = 0.003  # below 1/255: never visible
+    op[20:40] = 1.0
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=F64) + 0.5, torch.arange(W, dtype=F64) + 0.5, indexing="ij")
+    x0, y0, x1, y1 = G.tile_rect(m2, radii, ts, tw, th)
+    kept_tot = needed_tot = box_tot = 0
+    for g in torch.nonzero(radii > 0)[:, 0].tolist():
+        a, b, c = [float(v) for v in con[g]]
+        dx, dy = float(m2[g, 0]) - xs, float(m2[g, 1]) - ys
+        alpha = float(op[g]) * torch.exp(-(0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy))
+        hit = (alpha >= 1.0 / 255.0).reshape(th, ts, tw, ts).any(3).any(1)
+        box = torch.zeros(th, tw, dtype=torch.bool)
+        box[y0[g]:y1[g], x0[g]:x1[g]] = True
+        needed = hit & box
+        mask = np.zeros(tw * th, np.uint8)
+        n = hm.hm_culled_tiles(C.c_float(float(m2[g, 0])), C.c_float(float(m2[g, 1])), int(radii[g]), C.c_float(a), C.c_float(b),
+                               C.c_float(c), C.c_float(float(op[g])), ts, tw, th, fptr(mask))
+        kept = torch.from_numpy(mask.reshape(th, tw).astype(bool))
+        assert n == int(kept.sum())
+        assert bool((kept | ~needed).all()), f"gaussian {g}: a needed tile was culled"
+        assert bool((box | ~kept).all()), "kept tiles must lie inside gsplat's bounding square"
+        kept_tot += int(kept.sum()); needed_tot += int(needed.sum()); box_tot += int(box.sum())
+    assert needed_tot > 500
+    assert kept_tot <= 1.25 * needed_tot + 50, (kept_tot, needed_tot)  # tight
+    assert kept_tot < 0.7 * box_tot, (kept_tot, box_tot)               # and a real reduction vs the bounding squares
