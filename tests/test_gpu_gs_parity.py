@@ -265,17 +265,19 @@ def test_exact_tile_culling_is_invisible(ops, seed, N, W, H):
     assert torch.equal(full["r"], cul["r"]) and torch.equal(full["a"], cul["a"])  # forward is bit-identical
     assert bool((cul["tpg"] <= full["tpg"]).all())
     assert cul["iids"].numel() < 0.8 * full["iids"].numel()  # the lists really shrink
-    # culled keys are a sub-multiset of the full keys (both sorted)
-    merged = torch.cat([full["iids"], cul["iids"]]).sort().values
-    uniq, counts = torch.unique_consecutive(merged, return_counts=True)
-    assert int(counts.max()) <= 2 and int((counts == 2).sum()) == cul["iids"].numel()
+    # culled (key, Gaussian) pairs are a subset of the full pairs
+    pf = torch.stack([full["iids"], full["fids"].long()], 1)
+    pc = torch.stack([cul["iids"], cul["fids"].long()], 1)
+    _, counts = torch.unique(torch.cat([pf, pc]), dim=0, return_counts=True)
+    assert int(counts.max()) == 2 and int((counts == 2).sum()) == pc.shape[0]
     for k in full["grads"]:
         ref, got = full["grads"][k], cul["grads"][k]
         assert float((got - ref).norm() / ref.norm().clamp(min=1e-20)) < 1e-5, k
     # brute force (float64, CPU): every dropped pair has max alpha over its tile's pixel centres < 1/255
     tw = (W + 15) // 16
-    fk, ck = full["iids"].cpu(), cul["iids"].cpu()
-    keep = torch.isin(fk, ck)
+    fk = full["iids"].cpu()
+    enc = lambda d: d["iids"].cpu() * (1 << 20) % (1 << 62) + d["fids"].cpu().long()  # (key, id) -> one int64 (collision-free enough)
+    keep = torch.isin(enc(full), enc(cul))
     dropped = (~keep).nonzero()[:, 0]
     sel = dropped[torch.randperm(dropped.numel(), generator=g)[:3000]]
     gid = full["fids"].cpu().long()[sel]
