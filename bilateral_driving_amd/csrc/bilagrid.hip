@@ -250,8 +250,13 @@ __device__ __forceinline__ void corner_accumulate(float *acc, int base, int vol,
 
 // ---- D2: per-level low-resolution backward (y pass, slice vjp into the grid, guidance route) -----------
 // kLds: the level's grid gradient (n_avg * 12*gl*gy*gx floats) fits the workgroup's LDS accumulator.
+// Persistent workgroups (grid-stride over the low-res pixels): each accumulates the whole level's grid
+// gradient in LDS and writes ONE partial grid; a tiny second kernel sums the partials.  (Flushing
+// with atomics from thousands of short workgroups serialises on the few-thousand grid addresses in L2:
+// that was 3x the cost of everything else in this kernel.)  Deterministic for the LDS path.
 template <bool kLds>
-__global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int l, float *__restrict__ v_in) {
+__global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int l, float *__restrict__ v_in,
+                                                                float *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float lds_acc[];
   const LevelDev &L = p.lv[l];
   const int gsz = 12 * L.gl * L.gy * L.gx;
@@ -261,8 +266,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
     __syncthreads();
   }
   float *acc = kLds ? lds_acc : L.v_grid;
-  const int64_t idx = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
-  const bool active = idx < (int64_t)L.Hd * L.Wd;
+  const int64_t n_low = (int64_t)L.Hd * L.Wd;
+  for (int64_t base = (int64_t)blockIdx.x * kBgBlock; base < n_low; base += (int64_t)gridDim.x * kBgBlock) {
+  const int64_t idx = base + threadIdx.x;
+  const bool active = idx < n_low;
   const int i = active ? (int)(idx / L.Wd) : 0, j = active ? (int)(idx - (int64_t)i * L.Wd) : 0;
   float va[12];
 #pragma unroll
@@ -329,13 +336,22 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
         }
       }
   }
+  }  // grid-stride loop
   if (kLds && L.v_grid) {
     __syncthreads();
-    for (int e = threadIdx.x; e < gtot; e += kBgBlock) {
-      const float v = lds_acc[e];
-      if (v != 0.f) atomicAdd(L.v_grid + e, v);
-    }
+    float *dst = partials + (int64_t)blockIdx.x * gtot;
+    for (int e = threadIdx.x; e < gtot; e += kBgBlock) dst[e] = lds_acc[e];
   }
+}
+
+// v_grid[e] += sum_b partials[b][e]
+__global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(int gtot, int nparts, const float *__restrict__ partials,
+                                                                       float *__restrict__ v_grid) {
+  const int e = blockIdx.x * kBgBlock + threadIdx.x;
+  if (e >= gtot) return;
+  float s = 0.f;
+  for (int b = 0; b < nparts; b++) s += partials[(int64_t)b * gtot + e];
+  v_grid[e] += s;
 }
 
 // ---- E: clamp + sky blend backward (in place on v_in) ------------------------------------------
@@ -448,8 +464,11 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
 // ---- host side ---------------------------------------------------------------------------------
 struct MsLayout {
   size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS];
+  size_t part_off;  // per-workgroup partial grid gradients (shared by the levels, which run one after the other)
   size_t bytes;
 };
+constexpr int kPartBlocks = 512;               // persistent workgroups of the low-res backward (2 per CU)
+constexpr size_t kMaxGridLds = 150 * 1024;     // a level's grid gradient must fit the 160 KiB LDS to use the LDS path
 static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, int W) {
   MsLayout L;
   size_t off = 0;
@@ -465,6 +484,13 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     L.r_off[l] = off;
     if (!(Hd == H && Wd == W)) off += align_up((size_t)H * Wd * 12 * sizeof(float), 256);
   }
+  L.part_off = off;
+  size_t gmax = 0;
+  for (int l = 0; l < nlevels; l++) {
+    const size_t g = sizeof(float) * 12 * lv[l].gl * lv[l].gy * lv[l].gx * lv[l].n_avg;
+    if (g <= kMaxGridLds && g > gmax) gmax = g;
+  }
+  off += align_up(gmax * kPartBlocks, 256);
   L.bytes = off;
   return L;
 }
@@ -560,15 +586,31 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
     hipLaunchKernelGGL(ms_adjoint_x_kernel, dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l);
     BDS_LAUNCH_CHECK();
   }
+  const MsLayout ML = ms_layout(nlevels, levels, H, W);
+  float *partials = reinterpret_cast<float *>(static_cast<char *>(ws) + ML.part_off);
   for (int l = 0; l < nlevels; l++) {
     const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;
-    const size_t gbytes = sizeof(float) * 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
-    if (gbytes <= 60 * 1024) {
-      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), gbytes, st, p, l, v_rgb);
+    const int gtot = 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
+    const size_t gbytes = sizeof(float) * gtot;
+    const int64_t need = cdiv(n, kBgBlock);
+    if (gbytes <= kMaxGridLds) {
+      const int nblk = (int)(need < kPartBlocks ? need : kPartBlocks);
+      if (gbytes > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ms_lowres_bwd_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbytes) != hipSuccess)
+          return BDS_ELAUNCH;
+      }
+      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)nblk), dim3(kBgBlock), gbytes, st, p, l, v_rgb, partials);
+      BDS_LAUNCH_CHECK();
+      if (p.lv[l].v_grid) {
+        hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)cdiv(gtot, kBgBlock)), dim3(kBgBlock), 0, st, gtot, nblk,
+                           partials, p.lv[l].v_grid);
+        BDS_LAUNCH_CHECK();
+      }
     } else {
-      hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l, v_rgb);
+      hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)need), dim3(kBgBlock), 0, st, p, l, v_rgb, partials);
+      BDS_LAUNCH_CHECK();
     }
-    BDS_LAUNCH_CHECK();
   }
   if (sky) {
     hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)cdiv(HW, kBgBlock)), dim3(kBgBlock), 0, st, HW, rgb, alpha, sky, v_rgb,

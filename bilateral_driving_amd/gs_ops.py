@@ -222,11 +222,16 @@ class _RasterizeToPixels(torch.autograd.Function):
         th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
         M = flatten_ids.shape[0]
         v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
-        v_means2d = torch.zeros_like(means2d_c)
-        v_abs = torch.zeros_like(means2d_c) if absgrad else None
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opac = torch.zeros_like(opacities)
+        # the atomically accumulated outputs live in ONE zero-filled buffer (one fill instead of five)
+        CN = Cn * N
+        sizes = [2 * CN, 2 * CN if absgrad else 0, 3 * CN, CH * CN, CN]
+        buf = torch.zeros(sum(sizes), device=means2d_c.device, dtype=torch.float32)
+        chunks = torch.split(buf, sizes)
+        v_means2d = chunks[0].view(Cn, N, 2)
+        v_abs = chunks[1].view(Cn, N, 2) if absgrad else None
+        v_conics = chunks[2].view(Cn, N, 3)
+        v_colors = chunks[3].view(Cn, N, CH)
+        v_opac = chunks[4].view(Cn, N)
         with L.timed("rasterize_bwd"):
             L.check(L.lib().bds_rasterize_bwd(Cn, N, M, CH, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities),
                                               L.ptr(backgrounds), width, height, tile_size, tw, th, L.ptr(isect_offsets),

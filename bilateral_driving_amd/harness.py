@@ -96,7 +96,9 @@ def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor],
     W, H = cam.width, cam.height
     opac = torch.sigmoid(params["opacity_logits"])                         # vanilla.py:393
     scales = torch.exp(params["log_scales"])
-    quats = params["quats"] / params["quats"].norm(dim=-1, keepdim=True)
+    # get_quats normalises (vanilla.py:395) and so does the projection kernel internally; normalising twice is
+    # the identity, so the raw quaternions go straight in and the normalisation's backward is part of the kernel
+    quats = params["quats"]
     viewmats, Ks = cam.viewmat[None], cam.K[None]
     radii, means2d, depths, conics, _ = fully_fused_projection(means, quats, scales, viewmats, Ks, W, H, eps2d=eps2d,
                                                                near_plane=near_plane, far_plane=far_plane,
