@@ -226,24 +226,39 @@ __device__ __forceinline__ float wave_sum_all(float v) {
   return v;
 }
 
-// Scatter one trilinear corner's 12 channel contributions into the grid-gradient accumulator (LDS or
-// global).  Coarse grids put a whole wave into one cell: when every active lane targets the same
-// corner the 12 values are wave-reduced on the VALU (DPP) and committed by one lane, instead of 64
-// serialised same-address atomics.
-__device__ __forceinline__ void corner_accumulate(float *acc, int base, int vol, float w, const float *va, bool active) {
-  const int a0 = __builtin_amdgcn_readfirstlane(active ? base : -1);
-  const bool uniform = a0 >= 0 && __all(!active || base == a0);
-  if (uniform) {
+// Scatter the slice gradient of a wave's 64 samples into the grid-gradient accumulator (LDS or global).
+// Neighbouring samples fall into the same grid cell (coarse grids: the whole wave), so per-lane atomics
+// would serialise 20-64 ways on one address.  Instead the wave walks its DISTINCT cells (typically 1-6):
+// for each cell and each of its 8 trilinear corners the 12 channel contributions of the member lanes are
+// summed with the 16-value transpose-reduce (35 VALU ops) and committed by 12 lanes to 12 different
+// addresses -- conflict-free by construction.
+__device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, int gx, int gy, int gl, float scale,
+                                                   const float *va, bool active) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int plane = gy * gx, vol = gl * plane;
+  const int key = active ? (c.z0 * gy + c.y0) * gx + c.x0 : -1;
+  const int slot = butterfly_slot(lane);
+  const bool committer = ((lane & 3) == 0) && slot < 12;
+  unsigned long long remaining = __ballot(active);
+  while (remaining) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int k = __builtin_amdgcn_readlane(key, leader);
+    const bool member = active && key == k;
+    remaining &= ~__ballot(member);
+    // the cell's corner indices are the same for every member: take the leader's
+    const int z0 = __builtin_amdgcn_readlane(c.z0, leader), z1 = __builtin_amdgcn_readlane(c.z1, leader);
+    const int y0 = __builtin_amdgcn_readlane(c.y0, leader), y1 = __builtin_amdgcn_readlane(c.y1, leader);
+    const int x0 = __builtin_amdgcn_readlane(c.x0, leader), x1 = __builtin_amdgcn_readlane(c.x1, leader);
+#pragma unroll 1
+    for (int q = 0; q < 8; q++) {
+      const int base = ((q & 4) ? z1 : z0) * plane + ((q & 2) ? y1 : y0) * gx + ((q & 1) ? x1 : x0);
+      const float w = member ? ((q & 4) ? c.fz : 1.f - c.fz) * ((q & 2) ? c.fy : 1.f - c.fy) * ((q & 1) ? c.fx : 1.f - c.fx) * scale : 0.f;
+      float v[16];
 #pragma unroll
-    for (int ch = 0; ch < 12; ch++) {
-      const float s = wave_sum_to_lane63(active ? w * va[ch] : 0.f);
-      if ((threadIdx.x & (kWave - 1)) == kWave - 1 && s != 0.f) atomicAdd(acc + a0 + ch * vol, s);
-    }
-  } else if (active) {
-#pragma unroll
-    for (int ch = 0; ch < 12; ch++) {
-      const float v = w * va[ch];
-      if (v != 0.f) atomicAdd(acc + base + ch * vol, v);
+      for (int ch = 0; ch < 12; ch++) v[ch] = w * va[ch];
+      v[12] = v[13] = v[14] = v[15] = 0.f;
+      const float tot = butterfly_sum16(v, lane);
+      if (committer && tot != 0.f) atomicAdd(acc + base + slot * vol, tot);
     }
   }
 }
@@ -302,17 +317,9 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
   if (active) lowres_colour(p, ty, tx, r, g, b);
   const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
   const float inv_n = 1.f / (float)L.n_avg;
-  const int plane = L.gy * L.gx, vol = L.gl * plane;
   float v_iz = 0.f;
   for (int n = 0; n < L.n_avg; n++) {
-    if (L.v_grid) {
-#pragma unroll 1
-      for (int k = 0; k < 8; k++) {
-        const int zz = (k & 4) ? c.z1 : c.z0, yy = (k & 2) ? c.y1 : c.y0, xx = (k & 1) ? c.x1 : c.x0;
-        const float w = ((k & 4) ? c.fz : 1.f - c.fz) * ((k & 2) ? c.fy : 1.f - c.fy) * ((k & 1) ? c.fx : 1.f - c.fx) * inv_n;
-        corner_accumulate(acc, n * gsz + zz * plane + yy * L.gx + xx, vol, w, va, active);
-      }
-    }
+    if (L.v_grid) slice_grid_scatter(acc + n * gsz, c, L.gx, L.gy, L.gl, inv_n, va, active);
     if (active && c.z_interior) {
       float a12[12], dz[12];
       slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a12, dz);
@@ -397,15 +404,7 @@ __global__ __launch_bounds__(kBgBlock) void slice_bwd_kernel(int64_t P, const fl
   float va[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) va[k] = active ? v_affine[ii * 12 + k] : 0.f;
-  const int plane = gy * gx, vol = gl * plane;
-  if (v_grid) {
-#pragma unroll 1
-    for (int k = 0; k < 8; k++) {
-      const int zz = (k & 4) ? c.z1 : c.z0, yy = (k & 2) ? c.y1 : c.y0, xx = (k & 1) ? c.x1 : c.x0;
-      const float w = ((k & 4) ? c.fz : 1.f - c.fz) * ((k & 2) ? c.fy : 1.f - c.fy) * ((k & 1) ? c.fx : 1.f - c.fx);
-      corner_accumulate(v_grid, zz * plane + yy * gx + xx, vol, w, va, active);
-    }
-  }
+  if (v_grid) slice_grid_scatter(v_grid, c, gx, gy, gl, 1.f, va, active);
   if (active && v_rgb) {
     float vg = 0.f;
     if (c.z_interior) {
@@ -467,7 +466,14 @@ struct MsLayout {
   size_t part_off;  // per-workgroup partial grid gradients (shared by the levels, which run one after the other)
   size_t bytes;
 };
-constexpr int kPartBlocks = 512;               // persistent workgroups of the low-res backward (2 per CU)
+constexpr int kPartBlocks = 2048;              // upper bound of persistent workgroups of the low-res backward (8 per CU)
+constexpr size_t kPartBytes = 64u << 20;       // bound of the partial-grid buffer
+static int part_blocks(size_t gbytes) {
+  size_t n = gbytes ? kPartBytes / gbytes : kPartBlocks;
+  if (n > (size_t)kPartBlocks) n = kPartBlocks;
+  if (n < 256) n = 256;
+  return (int)n;
+}
 constexpr size_t kMaxGridLds = 150 * 1024;     // a level's grid gradient must fit the 160 KiB LDS to use the LDS path
 static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, int W) {
   MsLayout L;
@@ -490,7 +496,13 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     const size_t g = sizeof(float) * 12 * lv[l].gl * lv[l].gy * lv[l].gx * lv[l].n_avg;
     if (g <= kMaxGridLds && g > gmax) gmax = g;
   }
-  off += align_up(gmax * kPartBlocks, 256);
+  size_t pmax = 0;
+  for (int l = 0; l < nlevels; l++) {
+    const size_t g = sizeof(float) * 12 * lv[l].gl * lv[l].gy * lv[l].gx * lv[l].n_avg;
+    if (g <= kMaxGridLds && g * part_blocks(g) > pmax) pmax = g * part_blocks(g);
+  }
+  (void)gmax;
+  off += align_up(pmax, 256);
   L.bytes = off;
   return L;
 }
@@ -594,7 +606,8 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
     const size_t gbytes = sizeof(float) * gtot;
     const int64_t need = cdiv(n, kBgBlock);
     if (gbytes <= kMaxGridLds) {
-      const int nblk = (int)(need < kPartBlocks ? need : kPartBlocks);
+      const int cap = part_blocks(gbytes);
+      const int nblk = (int)(need < cap ? need : cap);
       if (gbytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ms_lowres_bwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbytes) != hipSuccess)

@@ -25,44 +25,6 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
-// ---- 16-value wave64 transpose-reduce ----------------------------------------------------------
-// Sums 16 per-lane values over the 64 lanes in 35 VALU instructions (vs 16 x 6 for one-at-a-time
-// DPP reductions): every step halves the number of live registers while it halves the lane distance
-// -- v_permlane32_swap / v_permlane16_swap (gfx950) across rows, DPP row_ror / half_mirror / quad_perm
-// inside a row.  On return lane l holds the wave total of value  k(l) = b2 + 2*b3 + 4*(l >> 4)
-// (b2, b3 = bits 2, 3 of l), identical in the four lanes of each quad.
-__device__ __forceinline__ int butterfly_slot(int lane) { return ((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + 4 * (lane >> 4); }
-
-__device__ __forceinline__ float swap_add32(float a, float b) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float swap_add16(float a, float b) {
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float butterfly_sum16(const float *v, int lane) {
-  float s[8], t[4];
-#pragma unroll
-  for (int i = 0; i < 8; i++) s[i] = swap_add32(v[i], v[i + 8]);
-#pragma unroll
-  for (int i = 0; i < 4; i++) t[i] = swap_add16(s[i], s[i + 4]);
-  const bool b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
-  float u[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const float sa = t[j] + dpp_f<0x128, 0xf, false>(t[j]);          // row_ror:8
-    const float sb = t[j + 2] + dpp_f<0x128, 0xf, false>(t[j + 2]);
-    u[j] = b3 ? sb : sa;
-  }
-  const float sa = u[0] + dpp_f<0x141, 0xf, false>(u[0]);            // row_half_mirror
-  const float sb = u[1] + dpp_f<0x141, 0xf, false>(u[1]);
-  float w = b2 ? sb : sa;
-  w += dpp_f<0xB1, 0xf, false>(w);                                   // quad_perm [1,0,3,2]
-  w += dpp_f<0x4E, 0xf, false>(w);                                   // quad_perm [2,3,0,1]
-  return w;
-}
-
 // value slots of the per-Gaussian gradient record that is reduced over a tile's pixels
 //   0-3 colour, 4-6 conic, 7-8 mean2d, 9-10 |mean2d| (absgrad), 11 opacity
 struct GradTarget {
