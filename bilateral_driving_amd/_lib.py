@@ -84,7 +84,7 @@ def lib():
     return _lib
 
 
-OPT_RASTER_BWD, OPT_RADIX = 0, 1
+OPT_RASTER_BWD, OPT_RADIX, OPT_RASTER_FWD = 0, 1, 2
 
 
 def set_option(which: int, value: int) -> None:

@@ -351,14 +351,33 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
   }
 }
 
-// v_grid[e] += sum_b partials[b][e]
+// v_grid[e] += sum_b partials[b][e].  Workgroup = 32 grid entries x 8 partial-lanes: coalesced 128-byte
+// rows, 8 independent loads in flight per thread, fixed summation order (deterministic).
 __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(int gtot, int nparts, const float *__restrict__ partials,
                                                                        float *__restrict__ v_grid) {
-  const int e = blockIdx.x * kBgBlock + threadIdx.x;
-  if (e >= gtot) return;
+  __shared__ float red[8][33];
+  const int ex = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + ex;
   float s = 0.f;
-  for (int b = 0; b < nparts; b++) s += partials[(int64_t)b * gtot + e];
-  v_grid[e] += s;
+  if (e < gtot) {
+    int b = py;
+    for (; b + 56 < nparts; b += 64) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = partials[(int64_t)(b + 8 * u) * gtot + e];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += t[u];
+    }
+    for (; b < nparts; b += 8) s += partials[(int64_t)b * gtot + e];
+  }
+  red[py][ex] = s;
+  __syncthreads();
+  if (py == 0 && e < gtot) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += red[k][ex];
+    v_grid[e] += t;
+  }
 }
 
 // ---- E: clamp + sky blend backward (in place on v_in) ------------------------------------------
@@ -466,7 +485,7 @@ struct MsLayout {
   size_t part_off;  // per-workgroup partial grid gradients (shared by the levels, which run one after the other)
   size_t bytes;
 };
-constexpr int kPartBlocks = 2048;              // upper bound of persistent workgroups of the low-res backward (8 per CU)
+constexpr int kPartBlocks = 1024;              // upper bound of persistent workgroups of the low-res backward (4 per CU)
 constexpr size_t kPartBytes = 64u << 20;       // bound of the partial-grid buffer
 static int part_blocks(size_t gbytes) {
   size_t n = gbytes ? kPartBytes / gbytes : kPartBlocks;
@@ -616,7 +635,7 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
       hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)nblk), dim3(kBgBlock), gbytes, st, p, l, v_rgb, partials);
       BDS_LAUNCH_CHECK();
       if (p.lv[l].v_grid) {
-        hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)cdiv(gtot, kBgBlock)), dim3(kBgBlock), 0, st, gtot, nblk,
+        hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)cdiv(gtot, 32)), dim3(kBgBlock), 0, st, gtot, nblk,
                            partials, p.lv[l].v_grid);
         BDS_LAUNCH_CHECK();
       }

@@ -121,6 +121,90 @@ __global__ __launch_bounds__(kRastBlock) void rasterize_fwd_kernel(
   }
 }
 
+// ---- forward, one wave64 per 16x16 tile, four pixels per lane ------------------------------------
+// Same pixel ownership as the backward wave kernel (lane l: column l % 16, rows (l / 16) + 4q): the
+// Gaussian record is read from LDS once per four pixels and dx / a*dx^2 / b*dx are shared.
+template <int CH>
+__global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
+    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
+    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  const int n_tiles = tile_w * tile_h;
+  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int cam = item / n_tiles, tile = item - cam * n_tiles;
+  const int ty = tile / tile_w, tx = tile - ty * tile_w;
+  const int lane = threadIdx.x;
+  const int j = tx * kTile + (lane & 15);
+  const int i0 = ty * kTile + (lane >> 4);
+  const float px = (float)j + 0.5f;
+  const int start = offsets[item];
+  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
+  bool done[4];
+  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  int cur[4] = {0, 0, 0, 0};
+  float out[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    done[q] = !((i0 + 4 * q) < H && j < W);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[q][k] = 0.f;
+  }
+  const int nbatch = (end - start + kWave - 1) / kWave;
+  for (int b = 0; b < nbatch; b++) {
+    if (__all(done[0] && done[1] && done[2] && done[3])) break;
+    __syncthreads();
+    const int bstart = start + b * kWave;
+    if (bstart + lane < end) {
+      float4 A, B, Cc;
+      stage_gaussian<CH>(flatten_ids[bstart + lane], means2d, conics, colors, opacities, A, B, Cc);
+      sA[lane] = A; sB[lane] = B;
+      if (CH > 2) sC[lane] = Cc;
+    }
+    __syncthreads();
+    const int bs = min(kWave, end - bstart);
+    for (int t = 0; t < bs; t++) {
+      if (__all(done[0] && done[1] && done[2] && done[3])) break;
+      const float4 A = sA[t], B = sB[t];
+      const float dx = A.x - px;
+      const float hax2 = 0.5f * A.z * dx * dx, bdx = A.w * dx;
+      float4 Cc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (CH > 2) Cc = sC[t];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float dy = A.y - ((float)(i0 + 4 * q) + 0.5f);
+        const float sigma = hax2 + (0.5f * B.x * dy + bdx) * dy;
+        const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
+        const bool hit = !done[q] && !(sigma < 0.f || alpha < kAlphaMin);
+        const float nT = T[q] * (1.f - alpha);
+        if (hit && nT <= kTStop) done[q] = true;
+        else if (hit) {
+          const float vis = alpha * T[q];
+          out[q][0] += B.z * vis;
+          if (CH > 1) out[q][1] += B.w * vis;
+          if (CH > 2) out[q][2] += Cc.x * vis;
+          if (CH > 3) out[q][3] += Cc.y * vis;
+          cur[q] = bstart + t;
+          T[q] = nT;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = i0 + 4 * q;
+    if (i < H && j < W) {
+      const int64_t pix = ((int64_t)cam * H + i) * W + j;
+      alphas[pix] = 1.f - T[q];
+      last_ids[pix] = cur[q];
+      float *r = render + pix * CH;
+#pragma unroll
+      for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + T[q] * backgrounds[cam * CH + k] : out[q][k];
+    }
+  }
+}
+
 // REDUCE = 0: one DPP wave-reduction per gradient value, 13 single-lane atomics per (Gaussian, wave)
 // REDUCE = 1: 16-value transpose-reduce (butterfly_sum16), one 12-lane atomic instruction
 template <int CH, bool ABS, int REDUCE>
@@ -399,13 +483,21 @@ extern "C" int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const floa
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
   const dim3 grid((unsigned)(C * tile_w * tile_h)), block(kRastBlock);
   hipStream_t st = as_stream(stream);
+#define BDS_FWD_ARGS                                                                                                   \
+  C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, render,  \
+      alphas, last_ids
 #define BDS_FWD(ch)                                                                                                    \
-  hipLaunchKernelGGL((rasterize_fwd_kernel<ch>), grid, block, 0, st, C, N, M, means2d, conics, colors, opacities,      \
-                     backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, render, alphas, last_ids)
+  do {                                                                                                                 \
+    if (bds::option_get(bds::kOptRasterFwd) == 1)                                                                      \
+      hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS);                     \
+    else                                                                                                               \
+      hipLaunchKernelGGL((rasterize_fwd_kernel<ch>), grid, block, 0, st, BDS_FWD_ARGS);                                \
+  } while (0)
   if (CH == 1) BDS_FWD(1);
   else if (CH == 3) BDS_FWD(3);
   else BDS_FWD(4);
 #undef BDS_FWD
+#undef BDS_FWD_ARGS
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -78,10 +78,11 @@ def main():
             L.set_option(L.OPT_RASTER_BWD, rb)
             L.set_option(L.OPT_RADIX, rx)
             fwd_bwd()
-    order = [(2, 1, True), (2, 1, False), (1, 1, True), (2, 0, True)]
+    order = [(2, 1, True, 1), (2, 1, True, 0), (2, 1, False, 1)]
     for r in range(a.rounds):
-        for rb, rx, cull in order:
+        for rb, rx, cull, fw in order:
             Hn.TILE_CULL = cull
+            L.set_option(L.OPT_RASTER_FWD, fw)
             L.set_option(L.OPT_RASTER_BWD, rb)
             L.set_option(L.OPT_RADIX, rx)
             L.enable_timers(True)
@@ -89,7 +90,7 @@ def main():
             torch.cuda.synchronize()
             ts = L.timer_summary()
             L.enable_timers(False)
-            d = res.setdefault(f"bwd{rb}_radix{rx}_cull{int(cull)}", {"step": [], "rasterize_bwd": [], "rasterize_fwd": [], "isect_prepare": [],
+            d = res.setdefault(f"bwd{rb}_radix{rx}_cull{int(cull)}_fwd{fw}", {"step": [], "rasterize_bwd": [], "rasterize_fwd": [], "isect_prepare": [],
                                                      "isect_build": [], "bilagrid_bwd": [], "bilagrid_fwd": [], "sh_fwd": [], "sh_bwd": [],
                                                      "project_fwd": [], "project_bwd": []})
             d["step"].append(t)
@@ -98,6 +99,7 @@ def main():
                     d[k].append(ts[k][1])
     L.set_option(L.OPT_RASTER_BWD, 2)
     L.set_option(L.OPT_RADIX, 1)
+    L.set_option(L.OPT_RASTER_FWD, 1)
     Hn.TILE_CULL = True
     out = Hn.render_view(params, cam, grids, a.view, sky)
     print("CULLED_M", out["info"]["flatten_ids"].numel())

@@ -28,5 +28,6 @@ def _reset_kernel_variants():
         if _lib._lib is not None:
             _lib.set_option(_lib.OPT_RASTER_BWD, 2)
             _lib.set_option(_lib.OPT_RADIX, 1)
+            _lib.set_option(_lib.OPT_RASTER_FWD, 1)
     except Exception:
         pass

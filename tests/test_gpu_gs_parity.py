@@ -172,6 +172,7 @@ def _render_both(ops, sc, W, H, mode, bg=None, seed=0):
 def test_rasterization_end_to_end(ops, seed, N, W, H, mode, variant):
     from bilateral_driving_amd import _lib
     _lib.set_option(_lib.OPT_RASTER_BWD, variant)
+    _lib.set_option(_lib.OPT_RASTER_FWD, 1 if variant == 2 else 0)  # wave kernels together, 4-wave kernels together
     sc = make_scene(N, W, H, seed=seed)
     bg = torch.rand(1, 3) if mode == "RGB" else None
     ref_in, r_ref, a_ref, m_ref, gpu_in, r, a, meta = _render_both(ops, sc, W, H, mode, bg)
