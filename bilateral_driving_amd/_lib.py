@@ -51,6 +51,12 @@ _SIGS = {
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
     "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),
     "bds_bilagrid_tv_bwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f, _f]),
+    "bds_activate_fwd": (_i, [_i64, _f, _f, _f, _f, _f]),
+    "bds_activate_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_colors_pack_fwd": (_i, [_i64, _f, _f, _f, _f]),
+    "bds_colors_pack_bwd": (_i, [_i64, _f, _f, _f, _f, _f]),
+    "bds_render_unpack_fwd": (_i, [_i64, _f, _f, _f, _f, _f]),
+    "bds_render_unpack_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
 }
 
 EXPORTS = tuple(_SIGS)

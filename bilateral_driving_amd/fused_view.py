@@ -1,0 +1,185 @@
+"""One autograd node for a whole view: activations -> projection -> SH (visible only) -> tile ordering ->
+alpha compositing -> expected depth -> clamp + sky blend + multi-scale bilateral transform.
+
+Same arithmetic, in the same order, as the reference's training forward
+(/root/reference/project/models/gaussians/vanilla.py:378-414 -> models/trainers/base.py:385-432 ->
+models/trainers/scene_graph.py:286-294,86-120) and as ``harness.render_view_staged`` (which strings the
+individual autograd operators together and is tested equal to this node).  What changes is only the
+host side: the ~60 framework nodes / ~100 launches of the staged formulation become one node that
+issues ~25 launches of libbds.so kernels back to back, so the step is bound by the GPU, not by Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import weakref
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from .bilagrid import _levels_struct
+
+TILE = 16
+
+
+def _empty(shape, dev, dtype=torch.float32):
+    return torch.empty(shape, device=dev, dtype=dtype)
+
+
+class _FusedView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, *grids):
+        L.require_gpu(means, quats, log_scales, logits, sh, sky, *grids)
+        lib, st = L.lib(), L.stream()
+        dev = means.device
+        W, H = cfg["width"], cfg["height"]
+        N, K = means.shape[0], sh.shape[1]
+        P = H * W
+        means, quats, log_scales, logits, sh, sky = (t.contiguous() for t in (means, quats, log_scales, logits, sh, sky))
+        viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
+        # activations (vanilla.py:393-394)
+        scales, opac = _empty((N, 3), dev), _empty((N,), dev)
+        L.check(lib.bds_activate_fwd(N, L.ptr(log_scales), L.ptr(logits), L.ptr(scales), L.ptr(opac), st), "bds_activate_fwd")
+        # projection (C = 1)
+        radii = _empty((1, N), dev, torch.int32)
+        means2d, depths, conics = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev)
+        with L.timed("project_fwd"):
+            L.check(lib.bds_project_fwd(1, N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(viewmat), L.ptr(Kmat), W, H,
+                                        cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], L.ptr(radii),
+                                        L.ptr(means2d), L.ptr(depths), L.ptr(conics), None, st), "bds_project_fwd")
+        # SH colours of the visible Gaussians (vanilla.py:385-389)
+        dirs = means - cfg["cam_pos"]
+        mask8 = (radii[0] > 0).to(torch.uint8)
+        sh_rgb = _empty((N, 3), dev)
+        with L.timed("sh_fwd"):
+            L.check(lib.bds_sh_fwd(N, K, cfg["sh_degree"], L.ptr(dirs), L.ptr(sh), L.ptr(mask8), L.ptr(sh_rgb), st), "bds_sh_fwd")
+        colors = _empty((1, N, 4), dev)
+        L.check(lib.bds_colors_pack_fwd(N, L.ptr(sh_rgb), L.ptr(depths), L.ptr(colors), st), "bds_colors_pack_fwd")
+        # tile ordering
+        tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
+        cull = cfg["tile_cull"]
+        opac_c = opac.view(1, N)
+        tiles_per_gauss = _empty((1, N), dev, torch.int32)
+        ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
+        ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
+        m = C.c_int64(0)
+        with L.timed("isect_prepare"):
+            L.check(lib.bds_isect_prepare(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics) if cull else None,
+                                          L.ptr(opac_c) if cull else None, TILE, tw, th, L.ptr(tiles_per_gauss), L.ptr(ws),
+                                          ws_bytes, C.byref(m), st), "bds_isect_prepare")
+        M = int(m.value)
+        flatten_ids = _empty((M,), dev, torch.int32)
+        isect_offsets = _empty((1, th, tw), dev, torch.int32)
+        ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
+        ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
+        with L.timed("isect_build"):
+            L.check(lib.bds_isect_build(1, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics) if cull else None,
+                                        L.ptr(opac_c) if cull else None, TILE, tw, th, L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes,
+                                        None, L.ptr(flatten_ids), L.ptr(isect_offsets), st), "bds_isect_build")
+        del ws, ws2
+        # compositing (RGB + depth)
+        render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
+        last_ids = _empty((1, H, W), dev, torch.int32)
+        with L.timed("rasterize_fwd"):
+            L.check(lib.bds_rasterize_fwd(1, N, M, 4, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), None, W, H,
+                                          TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas),
+                                          L.ptr(last_ids), st), "bds_rasterize_fwd")
+        rgb_g, depth = _empty((H, W, 3), dev), _empty((H, W, 1), dev)
+        L.check(lib.bds_render_unpack_fwd(P, L.ptr(render), L.ptr(alphas), L.ptr(rgb_g), L.ptr(depth), st), "bds_render_unpack_fwd")
+        # clamp + sky blend + bilateral transform
+        grids = [g.contiguous() for g in grids]
+        factors = cfg["factors"]
+        lv = _levels_struct(grids, None, factors)
+        bws_bytes = lib.bds_bilagrid_ms_workspace_bytes(len(grids), lv, H, W)
+        bws = _empty((bws_bytes,), dev, torch.uint8)
+        rgb = _empty((H, W, 3), dev)
+        with L.timed("bilagrid_fwd"):
+            L.check(lib.bds_bilagrid_ms_fwd(len(grids), lv, H, W, L.ptr(rgb_g), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
+                                            L.ptr(rgb), None, st), "bds_bilagrid_ms_fwd")
+        ctx.cfg = cfg
+        ctx.M = M
+        ctx.n_grids = len(grids)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, dirs, mask8, sh_rgb,
+                              colors, flatten_ids, isect_offsets, render, alphas, last_ids, rgb_g, bws, *grids)
+        opacity = alphas[0]
+        # rgb_g / means2d are returned for inspection and as the carrier of .absgrad; no gradient flows into them
+        ctx.mark_non_differentiable(rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets)
+        return rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth, v_opacity, *_):
+        (means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, dirs, mask8, sh_rgb, colors, flatten_ids,
+         isect_offsets, render, alphas, last_ids, rgb_g, bws, *grids) = ctx.saved_tensors
+        cfg = ctx.cfg
+        lib, st = L.lib(), L.stream()
+        dev = means.device
+        W, H = cfg["width"], cfg["height"]
+        N, K = means.shape[0], sh.shape[1]
+        P, M = H * W, ctx.M
+        tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
+        # colour transform
+        need_g = ctx.needs_input_grad[7:]
+        v_grids = [torch.zeros_like(g) if need_g[i] else None for i, g in enumerate(grids)]
+        lv = _levels_struct(list(grids), v_grids, cfg["factors"])
+        v_rgb = torch.zeros(H, W, 3, device=dev) if v_rgb is None else v_rgb.contiguous()
+        v_depth = None if v_depth is None else v_depth.contiguous()
+        v_opacity = None if v_opacity is None else v_opacity.contiguous()
+        v_rgb_t, v_alpha_t, v_sky = _empty((H, W, 3), dev), _empty((H, W), dev), _empty((H, W, 3), dev)
+        with L.timed("bilagrid_bwd"):
+            L.check(lib.bds_bilagrid_ms_bwd(len(grids), lv, H, W, L.ptr(rgb_g), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
+                                            L.ptr(v_rgb), L.ptr(v_rgb_t), L.ptr(v_alpha_t), L.ptr(v_sky), st), "bds_bilagrid_ms_bwd")
+        # expected depth + channel split
+        v_render, v_alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
+        L.check(lib.bds_render_unpack_bwd(P, L.ptr(render), L.ptr(alphas), L.ptr(v_rgb_t), L.ptr(v_depth), L.ptr(v_alpha_t),
+                                          L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas), st),
+                "bds_render_unpack_bwd")
+        # compositing
+        buf = torch.zeros(12 * N, device=dev, dtype=torch.float32)
+        v_col, v_m2, v_abs, v_con, v_op = torch.split(buf, [4 * N, 2 * N, 2 * N, 3 * N, N])  # v_col first: 16-byte aligned
+        opac_c = opac.view(1, N)
+        with L.timed("rasterize_bwd"):
+            L.check(lib.bds_rasterize_bwd(1, N, M, 4, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), None, W, H, TILE,
+                                          tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids),
+                                          L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_m2), L.ptr(v_abs), L.ptr(v_con), L.ptr(v_col),
+                                          L.ptr(v_op), st), "bds_rasterize_bwd")
+        carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
+        if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282 reads .absgrad)
+            carrier.absgrad = v_abs.view(1, N, 2)
+            carrier.grad_means2d = v_m2.view(1, N, 2)
+        v_sh_rgb, v_depths = _empty((N, 3), dev), _empty((1, N), dev)
+        L.check(lib.bds_colors_pack_bwd(N, L.ptr(sh_rgb), L.ptr(v_col), L.ptr(v_sh_rgb), L.ptr(v_depths), st), "bds_colors_pack_bwd")
+        v_sh = torch.empty_like(sh)
+        with L.timed("sh_bwd"):
+            L.check(lib.bds_sh_bwd(N, K, cfg["sh_degree"], L.ptr(dirs), L.ptr(sh), L.ptr(mask8), L.ptr(v_sh_rgb), L.ptr(v_sh), None,
+                                   st), "bds_sh_bwd")
+        v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+        viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
+        with L.timed("project_bwd"):
+            L.check(lib.bds_project_bwd(1, N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(viewmat), L.ptr(Kmat), W, H,
+                                        cfg["eps2d"], L.ptr(radii), L.ptr(conics), None, L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con),
+                                        None, L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), None, st), "bds_project_bwd")
+        v_ls, v_logits = torch.empty_like(log_scales), _empty((N,), dev)
+        L.check(lib.bds_activate_bwd(N, L.ptr(scales), L.ptr(opac), L.ptr(v_scales), L.ptr(v_op), L.ptr(v_ls), L.ptr(v_logits), st),
+                "bds_activate_bwd")
+        return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, *v_grids)
+
+
+def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor],
+               sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
+               radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True):
+    """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
+    grids: per level [1,12,L,gy,gx] (the current image's grids).  Returns dict(rgb, depth, opacity, rgb_gaussians, info)."""
+    cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
+    cfg = dict(width=int(width), height=int(height), viewmat=viewmat, K=K, cam_pos=cam_pos, factors=tuple(int(f) for f in factors),
+               sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
+               eps2d=float(eps2d), tile_cull=bool(tile_cull))
+    gs = [g if g.dim() == 5 else g[None] for g in grids]
+    out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky, *gs)
+    rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets = out
+    cfg["_means2d_ref"] = weakref.ref(means2d)  # backward attaches .absgrad to THIS tensor object
+    info = {"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
+            "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "tile_size": TILE, "n_cameras": 1}
+    return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)

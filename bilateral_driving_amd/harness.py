@@ -21,6 +21,7 @@ import torch
 from torch import Tensor
 
 from .bilagrid import bilagrid_transform, total_variation_loss
+from .fused_view import fused_view
 from .gs_ops import (TILE_SIZE, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
 
 SIX_CAM_YAWS = (0.0, 55.0, -55.0, 110.0, -110.0, 180.0)
@@ -30,6 +31,7 @@ FACTORS_3 = (4, 4, 2)                          # modules.py:505 default guidance
 LEVELS_SINGLE = ((16, 16, 8),)
 FACTORS_SINGLE = (1,)
 TILE_CULL = True  # exact tile culling in render_view (see gs_ops.isect_tiles); images/gradients are unaffected
+FUSED = True      # render_view = one fused autograd node (fused_view.py); False = chain of individual operators
 
 
 @dataclass
@@ -87,6 +89,18 @@ def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> L
 def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
                 factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                 radius_clip: float = 0.0, eps2d: float = 0.3):
+    """One view's forward (dict(rgb, depth, opacity, rgb_gaussians, info)): a single fused autograd node
+    (fused_view.py) by default, or the chain of individual operators (render_view_staged) when FUSED is off."""
+    if not FUSED:
+        return render_view_staged(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
+    grids_k = [g[img_idx:img_idx + 1] for g in grids]
+    return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids_k, sky, factors, sh_degree=sh_degree,
+                      near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL)
+
+
+def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
+                       factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
+                       radius_clip: float = 0.0, eps2d: float = 0.3):
     """One view's forward: returns dict(rgb, depth, opacity, rgb_gaussians, info).
 
     Same arithmetic as get_gaussians -> rasterization(...) -> split/clamp -> sky blend -> affine_transformation in

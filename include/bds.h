@@ -165,6 +165,25 @@ int bds_bilagrid_tv_fwd(int64_t n, int gx, int gy, int gl, const float *grids, f
 int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
                         float *v_grids, bds_stream_t stream);
 
+/* ---- element-wise glue of the training step, one launch each -----------------------------------
+ * models/gaussians/vanilla.py:389,393-394 (clamp(sh+0.5,0,1), sigmoid, exp); the RGB+ED colour
+ * concat / expected-depth normalise inside gsplat's rasterization(); models/trainers/base.py:414-419. */
+int bds_activate_fwd(int64_t N, const float *log_scales, const float *logits, float *scales, float *opacities,
+                     bds_stream_t stream);
+int bds_activate_bwd(int64_t N, const float *scales, const float *opacities, const float *v_scales,
+                     const float *v_opacities, float *v_log_scales, float *v_logits, bds_stream_t stream);
+/* colors [N,4] = (clamp(sh_rgb + 0.5, 0, 1), depth) */
+int bds_colors_pack_fwd(int64_t N, const float *sh_rgb, const float *depths, float *colors, bds_stream_t stream);
+int bds_colors_pack_bwd(int64_t N, const float *sh_rgb, const float *v_colors, float *v_sh_rgb, float *v_depths,
+                        bds_stream_t stream);
+/* render [P,4], alphas [P] -> rgb [P,3], depth [P] = render.w / max(alpha, 1e-10); bwd sums two optional
+ * extra alpha gradients (from the colour transform and from the caller) into v_alphas. */
+int bds_render_unpack_fwd(int64_t P, const float *render, const float *alphas, float *rgb, float *depth,
+                          bds_stream_t stream);
+int bds_render_unpack_bwd(int64_t P, const float *render, const float *alphas, const float *v_rgb, const float *v_depth,
+                          const float *v_alpha_a, const float *v_alpha_b, float *v_render, float *v_alphas,
+                          bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

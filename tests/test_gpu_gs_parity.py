@@ -308,12 +308,17 @@ def test_harness_view_matches_rasterization_api(ops):
     sky = torch.rand(H, W, 3, device=dev)
     target = torch.rand(H, W, 3, device=dev)
     outs = []
-    for mode in ("harness", "api"):
+    for mode in ("fused", "staged", "api"):
         p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         grids = [g.clone().requires_grad_(True) for g in grids0]
-        if mode == "harness":
-            out = Hn.render_view(p, cam, grids, 1, sky)
+        if mode in ("fused", "staged"):
+            Hn.FUSED = mode == "fused"
+            try:
+                out = Hn.render_view(p, cam, grids, 1, sky)
+            finally:
+                Hn.FUSED = True
             rgb, depth = out["rgb"], out["depth"]
+            absg_holder = out["info"]["means2d"]
         else:
             dirs = p["means"].detach() - torch.linalg.inv(cam.viewmat)[:3, 3]
             col = torch.clamp(ops.spherical_harmonics(3, dirs, p["sh"]) + 0.5, 0.0, 1.0)
@@ -326,10 +331,13 @@ def test_harness_view_matches_rasterization_api(ops):
             depth = rr[0][..., 3:4]
         loss = (rgb - target).abs().mean() + 0.1 * depth.mean() * 0.01
         loss.backward()
+        if mode != "api":
+            assert absg_holder.absgrad.shape == (1, N, 2) and float(absg_holder.absgrad.sum()) > 0
         outs.append((rgb.detach(), depth.detach(), {k: v.grad.clone() for k, v in p.items()}, [g.grad.clone() for g in grids]))
-    assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][1], outs[1][1]) < 1e-5
-    for k in outs[0][2]:
-        a, b = outs[0][2][k], outs[1][2][k]
-        assert float((a - b).norm() / b.norm()) < 1e-4, k
-    for a, b in zip(outs[0][3], outs[1][3]):
-        assert float((a - b).norm() / b.norm()) < 1e-4
+    for o in outs[:2]:
+        assert rel_err(o[0], outs[2][0]) < 1e-5 and rel_err(o[1], outs[2][1]) < 1e-5
+        for k in o[2]:
+            a, b = o[2][k], outs[2][2][k]
+            assert float((a - b).norm() / b.norm()) < 1e-4, k
+        for a, b in zip(o[3], outs[2][3]):
+            assert float((a - b).norm() / b.norm()) < 1e-4
