@@ -126,6 +126,23 @@ def cpu_baseline(args):
                 "sample": f"not measured: {type(e).__name__} (limit {args.cpu_timeout}s)"}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950-corrected).
+    bench.py cannot collect counters itself; null when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for k, v in d.items():
+            if kernel_substr in k:
+                return v.get("hbm_bytes_per_launch_corrected"), os.path.basename(f)
+    return None, None
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -207,10 +224,12 @@ def main():
     calls, mean_ms = tsum.get(dom, (0, float("nan")))
     alg_bytes = 92.0 * M_mean + 28.0 * W * H
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if calls else float("nan")
-    roofline = {"bound": "hbm", "kernel": "rasterize_bwd_kernel<4,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic, traffic_src = pmc_traffic("rasterize_bwd_wave_kernel<4, true>")
+    roofline = {"bound": "hbm", "kernel": "bds::rasterize_bwd_wave_kernel<4, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": mean_ms,
-                "note": "K7/K8 are VALU-bound on algorithmic bytes (SURVEY.md 7, hard part 2); see per_kernel_ms"}
+                "note": "achieved = algorithmic bytes (92 B/isect + 28 B/pixel, SURVEY.md 8d) / HIP-event launch time; the composite "
+                        "kernels are VALU-bound (SURVEY.md 7, hard part 2) and L2 serves most re-reads, so HBM traffic << algorithmic bytes"}
 
     result = {
         "metric": "train iters/sec (fwd+bwd) at 2M Gaussians, 6x1920x1080; HBM roofline %",
