@@ -174,13 +174,15 @@ def main():
     skies = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
     targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
     flat = FlatGradients(list(params.values()) + grids)
+    # multi-GPU: the backward kernels write the per-Gaussian gradients straight into the all-reduce buffer
+    arena = flat.arena(list(params.keys())) if world > 1 else None
 
     stats = {}
 
     def step(s):
         v = view_for_rank(s, rank, world, len(cams))
         flat.zero()
-        out = Hn.render_view(params, cams[v], grids, v, skies[v])
+        out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena)
         loss = Hn.training_loss(out, targets[v], grids)
         loss.backward()
         flat.all_reduce()

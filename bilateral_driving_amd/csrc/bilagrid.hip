@@ -34,6 +34,22 @@ struct MsParams {
   LevelDev lv[BDS_MAX_LEVELS];
 };
 
+// Several levels in ONE launch: workgroup ranges per level (the levels are independent, each alone
+// under-fills the chip, and a launch boundary costs ~1.5-2 us).
+struct LevelSched {
+  int n;                               // entries
+  int level[BDS_MAX_LEVELS];           // level index of entry k
+  int blk_off[BDS_MAX_LEVELS + 1];     // workgroups [blk_off[k], blk_off[k+1]) belong to entry k
+  int nblk[BDS_MAX_LEVELS];            // = blk_off[k+1] - blk_off[k]
+  long long part_off[BDS_MAX_LEVELS];  // float offset of the entry's partial-grid region
+};
+__device__ __forceinline__ int sched_find(const LevelSched &s, int bid, int &local) {
+  int k = 0;
+  while (k + 1 < s.n && bid >= s.blk_off[k + 1]) k++;
+  local = bid - s.blk_off[k];
+  return k;
+}
+
 // input colour of the transform at pixel (y,x): clamp + sky blend fused when sky != null
 __device__ __forceinline__ void load_input(const MsParams &p, int y, int x, float &r, float &g, float &b) {
   const int64_t o = (int64_t)y * p.W + x;
@@ -59,9 +75,11 @@ __device__ __forceinline__ void lowres_colour(const MsParams &p, const Tap &ty, 
 }
 
 // ---- A: per-level low-resolution slice -------------------------------------------------------
-__global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, int l) {
+__global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, LevelSched sc) {
+  int local;
+  const int l = sc.level[sched_find(sc, blockIdx.x, local)];
   const LevelDev &L = p.lv[l];
-  const int64_t idx = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  const int64_t idx = (int64_t)local * kBgBlock + threadIdx.x;
   if (idx >= (int64_t)L.Hd * L.Wd) return;
   const int i = (int)(idx / L.Wd), j = (int)(idx - (int64_t)i * L.Wd);
   const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
@@ -191,9 +209,11 @@ __device__ __forceinline__ void adjoint_range(int c, int full, int low, int &lo,
 }
 
 // ---- D1: x pass of the up-sampler adjoint: R[y, cx, :] = sum_x wx(x -> cx) * Q[y,x] (x) [P[y,x]; 1] -------
-__global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, int l) {
+__global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, LevelSched sc) {
+  int local;
+  const int l = sc.level[sched_find(sc, blockIdx.x, local)];
   const LevelDev &L = p.lv[l];
-  const int64_t idx = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  const int64_t idx = (int64_t)local * kBgBlock + threadIdx.x;
   if (idx >= (int64_t)p.H * L.Wd) return;
   const int y = (int)(idx / L.Wd), cx = (int)(idx - (int64_t)y * L.Wd);
   int xlo, xhi;
@@ -270,9 +290,12 @@ __device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, in
 // with atomics from thousands of short workgroups serialises on the few-thousand grid addresses in L2:
 // that was 3x the cost of everything else in this kernel.)  Deterministic for the LDS path.
 template <bool kLds>
-__global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int l, float *__restrict__ v_in,
+__global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, LevelSched sc, float *__restrict__ v_in,
                                                                 float *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+  int local;
+  const int k_entry = sched_find(sc, blockIdx.x, local);
+  const int l = sc.level[k_entry];
   const LevelDev &L = p.lv[l];
   const int gsz = 12 * L.gl * L.gy * L.gx;
   const int gtot = gsz * L.n_avg;
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
   }
   float *acc = kLds ? lds_acc : L.v_grid;
   const int64_t n_low = (int64_t)L.Hd * L.Wd;
-  for (int64_t base = (int64_t)blockIdx.x * kBgBlock; base < n_low; base += (int64_t)gridDim.x * kBgBlock) {
+  for (int64_t base = (int64_t)local * kBgBlock; base < n_low; base += (int64_t)sc.nblk[k_entry] * kBgBlock) {
   const int64_t idx = base + threadIdx.x;
   const bool active = idx < n_low;
   const int i = active ? (int)(idx / L.Wd) : 0, j = active ? (int)(idx - (int64_t)i * L.Wd) : 0;
@@ -346,18 +369,23 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, int
   }  // grid-stride loop
   if (kLds && L.v_grid) {
     __syncthreads();
-    float *dst = partials + (int64_t)blockIdx.x * gtot;
+    float *dst = partials + sc.part_off[k_entry] + (int64_t)local * gtot;
     for (int e = threadIdx.x; e < gtot; e += kBgBlock) dst[e] = lds_acc[e];
   }
 }
 
 // v_grid[e] += sum_b partials[b][e].  Workgroup = 32 grid entries x 8 partial-lanes: coalesced 128-byte
 // rows, 8 independent loads in flight per thread, fixed summation order (deterministic).
-__global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(int gtot, int nparts, const float *__restrict__ partials,
-                                                                       float *__restrict__ v_grid) {
-  __shared__ float red[8][33];
+__global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams p, LevelSched sc, LevelSched red,
+                                                                       const float *__restrict__ partials_all) {
+  __shared__ float sred[8][33];
+  int local;
+  const int k = sched_find(red, blockIdx.x, local);  // `red` mirrors `sc` entry by entry, with its own block ranges
+  const LevelDev &L = p.lv[sc.level[k]];
+  const int gtot = 12 * L.gl * L.gy * L.gx * L.n_avg, nparts = sc.nblk[k];
+  const float *partials = partials_all + sc.part_off[k];
   const int ex = threadIdx.x & 31, py = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + ex;
+  const int e = local * 32 + ex;
   float s = 0.f;
   if (e < gtot) {
     int b = py;
@@ -370,13 +398,13 @@ __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(int gtot
     }
     for (; b < nparts; b += 8) s += partials[(int64_t)b * gtot + e];
   }
-  red[py][ex] = s;
+  sred[py][ex] = s;
   __syncthreads();
   if (py == 0 && e < gtot) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) t += red[k][ex];
-    v_grid[e] += t;
+    for (int q = 0; q < 8; q++) t += sred[q][ex];
+    L.v_grid[e] += t;
   }
 }
 
@@ -515,13 +543,13 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     const size_t g = sizeof(float) * 12 * lv[l].gl * lv[l].gy * lv[l].gx * lv[l].n_avg;
     if (g <= kMaxGridLds && g > gmax) gmax = g;
   }
-  size_t pmax = 0;
+  size_t psum = 0;  // the levels run concurrently: every level has its own partial region
   for (int l = 0; l < nlevels; l++) {
     const size_t g = sizeof(float) * 12 * lv[l].gl * lv[l].gy * lv[l].gx * lv[l].n_avg;
-    if (g <= kMaxGridLds && g * part_blocks(g) > pmax) pmax = g * part_blocks(g);
+    if (g <= kMaxGridLds) psum += align_up(g * part_blocks(g), 256);
   }
   (void)gmax;
-  off += align_up(pmax, 256);
+  off += psum;
   L.bytes = off;
   return L;
 }
@@ -571,9 +599,15 @@ extern "C" int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *leve
   if (rc != BDS_OK) return rc;
   BDS_REQUIRE(rgb_out);
   hipStream_t st = as_stream(stream);
-  for (int l = 0; l < nlevels; l++) {
-    const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;
-    hipLaunchKernelGGL(ms_lowres_fwd_kernel, dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l);
+  {
+    LevelSched sc{};
+    sc.n = nlevels;
+    for (int l = 0; l < nlevels; l++) {
+      sc.level[l] = l;
+      sc.nblk[l] = (int)cdiv((int64_t)p.lv[l].Hd * p.lv[l].Wd, kBgBlock);
+      sc.blk_off[l + 1] = sc.blk_off[l] + sc.nblk[l];
+    }
+    hipLaunchKernelGGL(ms_lowres_fwd_kernel, dim3((unsigned)sc.blk_off[nlevels]), dim3(kBgBlock), 0, st, p, sc);
     BDS_LAUNCH_CHECK();
   }
   {
@@ -611,37 +645,64 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
     }
   }
   BDS_LAUNCH_CHECK();
-  for (int l = 0; l < nlevels; l++) {
-    if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
-    const int64_t n = (int64_t)H * p.lv[l].Wd;
-    hipLaunchKernelGGL(ms_adjoint_x_kernel, dim3((unsigned)cdiv(n, kBgBlock)), dim3(kBgBlock), 0, st, p, l);
-    BDS_LAUNCH_CHECK();
+  {  // x pass of the up-sampler adjoint, all up-sampled levels in one launch
+    LevelSched sc{};
+    for (int l = 0; l < nlevels; l++) {
+      if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
+      const int k = sc.n++;
+      sc.level[k] = l;
+      sc.nblk[k] = (int)cdiv((int64_t)H * p.lv[l].Wd, kBgBlock);
+      sc.blk_off[k + 1] = sc.blk_off[k] + sc.nblk[k];
+    }
+    if (sc.n > 0) {
+      hipLaunchKernelGGL(ms_adjoint_x_kernel, dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), 0, st, p, sc);
+      BDS_LAUNCH_CHECK();
+    }
   }
   const MsLayout ML = ms_layout(nlevels, levels, H, W);
   float *partials = reinterpret_cast<float *>(static_cast<char *>(ws) + ML.part_off);
-  for (int l = 0; l < nlevels; l++) {
-    const int64_t n = (int64_t)p.lv[l].Hd * p.lv[l].Wd;
-    const int gtot = 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
-    const size_t gbytes = sizeof(float) * gtot;
-    const int64_t need = cdiv(n, kBgBlock);
-    if (gbytes <= kMaxGridLds) {
+  {  // low-res backward: LDS-path levels together in one persistent launch, then one reduce launch
+    LevelSched sc{}, red{};
+    size_t lds_max = 0;
+    long long poff = 0;
+    for (int l = 0; l < nlevels; l++) {
+      const int gtot = 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
+      const size_t gbytes = sizeof(float) * gtot;
+      const int64_t need = cdiv((int64_t)p.lv[l].Hd * p.lv[l].Wd, kBgBlock);
+      if (gbytes > kMaxGridLds) {  // grid gradient too large for LDS: direct global atomics, own launch
+        LevelSched one{};
+        one.n = 1; one.level[0] = l; one.nblk[0] = (int)need; one.blk_off[1] = (int)need;
+        hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)need), dim3(kBgBlock), 0, st, p, one, v_rgb, partials);
+        BDS_LAUNCH_CHECK();
+        continue;
+      }
       const int cap = part_blocks(gbytes);
-      const int nblk = (int)(need < cap ? need : cap);
-      if (gbytes > 48 * 1024) {
+      const int k = sc.n++;
+      sc.level[k] = l;
+      sc.nblk[k] = (int)(need < cap ? need : cap);
+      sc.blk_off[k + 1] = sc.blk_off[k] + sc.nblk[k];
+      sc.part_off[k] = poff;
+      poff += (long long)(align_up(gbytes * part_blocks(gbytes), 256) / sizeof(float));
+      if (gbytes > lds_max) lds_max = gbytes;
+      red.level[k] = l;
+      red.nblk[k] = p.lv[l].v_grid ? (int)cdiv(gtot, 32) : 0;
+      red.blk_off[k + 1] = red.blk_off[k] + red.nblk[k];
+      red.n = sc.n;
+    }
+    if (sc.n > 0) {
+      if (lds_max > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ms_lowres_bwd_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbytes) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
           return BDS_ELAUNCH;
       }
-      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)nblk), dim3(kBgBlock), gbytes, st, p, l, v_rgb, partials);
+      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_max, st, p, sc, v_rgb,
+                         partials);
       BDS_LAUNCH_CHECK();
-      if (p.lv[l].v_grid) {
-        hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)cdiv(gtot, 32)), dim3(kBgBlock), 0, st, gtot, nblk,
-                           partials, p.lv[l].v_grid);
+      if (red.blk_off[red.n] > 0) {
+        hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)red.blk_off[red.n]), dim3(kBgBlock), 0, st, p, sc, red,
+                           partials);
         BDS_LAUNCH_CHECK();
       }
-    } else {
-      hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)need), dim3(kBgBlock), 0, st, p, l, v_rgb, partials);
-      BDS_LAUNCH_CHECK();
     }
   }
   if (sky) {

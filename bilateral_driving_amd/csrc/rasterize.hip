@@ -152,17 +152,21 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     for (int k = 0; k < 4; k++) out[q][k] = 0.f;
   }
   const int nbatch = (end - start + kWave - 1) / kWave;
+  // the next chunk's records are fetched into registers while the current chunk is blended, so the
+  // two dependent gather latencies (id -> attributes) are off the critical path of this single-wave workgroup
+  float4 pA = make_float4(0.f, 0.f, 0.f, 0.f), pB = pA, pC = pA;
+  if (start + lane < end) stage_gaussian<CH>(flatten_ids[start + lane], means2d, conics, colors, opacities, pA, pB, pC);
   for (int b = 0; b < nbatch; b++) {
     if (__all(done[0] && done[1] && done[2] && done[3])) break;
     __syncthreads();
     const int bstart = start + b * kWave;
     if (bstart + lane < end) {
-      float4 A, B, Cc;
-      stage_gaussian<CH>(flatten_ids[bstart + lane], means2d, conics, colors, opacities, A, B, Cc);
-      sA[lane] = A; sB[lane] = B;
-      if (CH > 2) sC[lane] = Cc;
+      sA[lane] = pA; sB[lane] = pB;
+      if (CH > 2) sC[lane] = pC;
     }
     __syncthreads();
+    if (bstart + kWave + lane < end)
+      stage_gaussian<CH>(flatten_ids[bstart + kWave + lane], means2d, conics, colors, opacities, pA, pB, pC);
     const int bs = min(kWave, end - bstart);
     for (int t = 0; t < bs; t++) {
       if (__all(done[0] && done[1] && done[2] && done[3])) break;
@@ -390,20 +394,33 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
   const int py0 = i0;
   const int nbatch = (end - start + kWave - 1) / kWave;
-  for (int b = 0; b < nbatch; b++) {
+  const int b0 = (end - 1 - tile_bin_final) / kWave;  // chunks in front of it lie behind every pixel's last Gaussian
+  // register prefetch of the next chunk (see the forward wave kernel)
+  int32_t pg = 0;
+  float4 pA = make_float4(0.f, 0.f, 0.f, 0.f), pB = pA, pC = pA;
+  {
+    const int idx = end - 1 - kWave * b0 - lane;
+    if (idx >= start) {
+      pg = flatten_ids[idx];
+      stage_gaussian<CH>(pg, means2d, conics, colors, opacities, pA, pB, pC);
+    }
+  }
+  for (int b = b0; b < nbatch; b++) {
     const int batch_end = end - 1 - kWave * b;
-    if (batch_end - (kWave - 1) > tile_bin_final) continue;  // whole batch lies behind every pixel's last Gaussian
     __syncthreads();
     const int bs = min(kWave, batch_end + 1 - start);
-    const int idx = batch_end - lane;
-    if (idx >= start) {
-      const int32_t g = flatten_ids[idx];
-      float4 A, B, Cc;
-      stage_gaussian<CH>(g, means2d, conics, colors, opacities, A, B, Cc);
-      sId[lane] = g; sA[lane] = A; sB[lane] = B;
-      if (CH > 2) sC[lane] = Cc;
+    if (batch_end - lane >= start) {
+      sId[lane] = pg; sA[lane] = pA; sB[lane] = pB;
+      if (CH > 2) sC[lane] = pC;
     }
     __syncthreads();
+    {
+      const int idx = batch_end - kWave - lane;
+      if (idx >= start) {
+        pg = flatten_ids[idx];
+        stage_gaussian<CH>(pg, means2d, conics, colors, opacities, pA, pB, pC);
+      }
+    }
     for (int t = max(0, batch_end - tile_bin_final); t < bs; t++) {
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;

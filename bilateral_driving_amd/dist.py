@@ -49,6 +49,12 @@ class FlatGradients:
         for p in self.params:
             p.grad = None
 
+    def arena(self, names: Iterable[str]) -> Dict[str, Tensor]:
+        """name -> slice of the flat buffer, for producers that can write a parameter's gradient in place
+        (fused_view(grad_arena=...)); ``pack()`` then finds the gradient already where it belongs."""
+        _ = self.flat
+        return {n: v for n, v in zip(names, self._views)}
+
     def pack(self) -> Tensor:
         flat = self.flat
         for p, v in zip(self.params, self._views):

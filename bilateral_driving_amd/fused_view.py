@@ -151,17 +151,26 @@ class _FusedView(torch.autograd.Function):
             carrier.grad_means2d = v_m2.view(1, N, 2)
         v_sh_rgb, v_depths = _empty((N, 3), dev), _empty((1, N), dev)
         L.check(lib.bds_colors_pack_bwd(N, L.ptr(sh_rgb), L.ptr(v_col), L.ptr(v_sh_rgb), L.ptr(v_depths), st), "bds_colors_pack_bwd")
-        v_sh = torch.empty_like(sh)
+        arena = cfg.get("grad_arena") or {}
+
+        def out_like(name, ref):  # gradient output: the caller's slice of a flat communication buffer, or a fresh tensor
+            t = arena.get(name)
+            if t is None:
+                return torch.empty_like(ref)
+            assert t.shape == ref.shape and t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device, name
+            return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
+
+        v_sh = out_like("sh", sh)
         with L.timed("sh_bwd"):
             L.check(lib.bds_sh_bwd(N, K, cfg["sh_degree"], L.ptr(dirs), L.ptr(sh), L.ptr(mask8), L.ptr(v_sh_rgb), L.ptr(v_sh), None,
                                    st), "bds_sh_bwd")
-        v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+        v_means, v_quats, v_scales = out_like("means", means), out_like("quats", quats), torch.empty_like(scales)
         viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
         with L.timed("project_bwd"):
             L.check(lib.bds_project_bwd(1, N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(viewmat), L.ptr(Kmat), W, H,
                                         cfg["eps2d"], L.ptr(radii), L.ptr(conics), None, L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con),
                                         None, L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), None, st), "bds_project_bwd")
-        v_ls, v_logits = torch.empty_like(log_scales), _empty((N,), dev)
+        v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         L.check(lib.bds_activate_bwd(N, L.ptr(scales), L.ptr(opac), L.ptr(v_scales), L.ptr(v_op), L.ptr(v_ls), L.ptr(v_logits), st),
                 "bds_activate_bwd")
         return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, *v_grids)
@@ -169,13 +178,19 @@ class _FusedView(torch.autograd.Function):
 
 def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor],
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
-               radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True):
+               radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
+               grad_arena: Optional[Dict[str, Tensor]] = None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
-    grids: per level [1,12,L,gy,gx] (the current image's grids).  Returns dict(rgb, depth, opacity, rgb_gaussians, info)."""
+    grids: per level [1,12,L,gy,gx] (the current image's grids).  Returns dict(rgb, depth, opacity, rgb_gaussians, info).
+
+    ``grad_arena`` (optional): name -> preallocated tensor; the backward kernels write the parameter gradients
+    straight into these (e.g. slices of the flat all-reduce buffer of ``dist.FlatGradients``) instead of fresh
+    tensors, so that multi-GPU runs need no pack pass.  Valid when each parameter receives its gradient from
+    this node only (the reference's step: one view per iteration)."""
     cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), viewmat=viewmat, K=K, cam_pos=cam_pos, factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
-               eps2d=float(eps2d), tile_cull=bool(tile_cull))
+               eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky, *gs)
     rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets = out

@@ -341,3 +341,32 @@ def test_harness_view_matches_rasterization_api(ops):
             assert float((a - b).norm() / b.norm()) < 1e-4, k
         for a, b in zip(o[3], outs[2][3]):
             assert float((a - b).norm() / b.norm()) < 1e-4
+
+
+def test_fused_view_writes_gradients_into_flat_buffer(ops):
+    """Multi-GPU plumbing on one GPU: with grad_arena the backward kernels write the per-Gaussian gradients into
+    the flat all-reduce buffer and autograd adopts those slices as .grad (no pack copy)."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients
+    dev = "cuda"
+    W, H, N = 256, 160, 3000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    base = Hn.synthetic_scene(N, seed=2, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    grids0 = Hn.make_grids(1, device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    res = []
+    for use_arena in (False, True):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        flat = FlatGradients(list(p.values()) + grids)
+        arena = flat.arena(list(p.keys())) if use_arena else None
+        flat.zero()
+        out = Hn.render_view(p, cam, grids, 0, sky, grad_arena=arena)
+        Hn.training_loss(out, target, grids).backward()
+        if use_arena:
+            for k, v in p.items():
+                assert v.grad.data_ptr() == arena[k].data_ptr(), k  # adopted in place
+        res.append(flat.pack().clone())
+    assert float((res[0] - res[1]).norm() / res[0].norm()) < 1e-4
+    assert float(res[0].abs().sum()) > 0
