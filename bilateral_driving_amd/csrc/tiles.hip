@@ -147,10 +147,14 @@ constexpr int kSortRounds = 16;
 constexpr int kSortChunk = kSortBlock * kSortRounds;  // 4096 pairs per workgroup
 constexpr int kSortWaves = kSortBlock / kWave;
 
-__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift,
+// n_dev (optional): the element count lives in device memory (a compaction result the host never
+// reads); the launch is sized for the host-side upper bound n_host and surplus workgroups see no elements.
+__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *__restrict__ keys, int64_t n_host,
+                                                               const uint64_t *__restrict__ n_dev, int shift,
                                                                uint32_t mask, int nblocks,
                                                                uint32_t *__restrict__ hist /*[256][nblocks]*/) {
   __shared__ uint32_t h[256];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortChunk;
@@ -164,9 +168,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *
 }
 
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift, uint32_t mask,
-    int bits, int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
+    const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   __shared__ uint32_t run[256];               // global position of the next element of each digit
   __shared__ uint32_t wcnt[kSortWaves][256];  // per-wave digit counts of the current round
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
@@ -215,9 +220,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
 // three per round).  Stable: global position = scanned block base + elements of earlier waves
 // + elements of earlier rounds of this wave + rank among the lanes of this round.
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift, uint32_t mask,
-    int bits, int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
+    const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   __shared__ uint32_t wrun[kSortWaves][256];  // next output position per (wave, digit)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 #pragma unroll
@@ -278,23 +284,23 @@ static size_t radix_temp_elems(int64_t n) {
 }
 
 static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift,
-                      int bits, uint32_t *temp, hipStream_t st) {
+                      int bits, uint32_t *temp, hipStream_t st, const uint64_t *n_dev = nullptr) {
   if (n == 0) return BDS_OK;
   const int nblocks = (int)cdiv(n, kSortChunk);
   const uint32_t mask = (1u << bits) - 1u;
   const int64_t hn = (int64_t)(mask + 1) * nblocks;
   uint32_t *hist = temp;
   uint32_t *stemp = temp + align_up((size_t)256 * nblocks, 4);
-  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, nblocks, hist);
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
   if (option_get(kOptRadix) == 1)
-    hipLaunchKernelGGL(radix_scatter_wave_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, shift, mask, bits,
+    hipLaunchKernelGGL(radix_scatter_wave_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
                        nblocks, hist, kout, vout);
   else
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, shift, mask, bits, nblocks,
-                       hist, kout, vout);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
+                       nblocks, hist, kout, vout);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -304,52 +310,73 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
 // ------------------------------------------------------------------------------------------
 constexpr int kIsectBlock = 256;
 
-// per (camera, Gaussian): number of tiles touched + depth key for the depth ordering
-__global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(int64_t CN, const float *__restrict__ means2d,
+// Visible (camera, Gaussian) entries are compacted first (typically ~15 % of C*N): the row loops of
+// the counting / emission kernels then run with dense lanes (they were 2-9 % lane-utilised on the
+// un-compacted list) and the depth sort shrinks with them.  The visible count stays on the device.
+__global__ __launch_bounds__(kIsectBlock) void isect_flag_kernel(int64_t CN, const int32_t *__restrict__ radii,
+                                                                uint32_t *__restrict__ flags) {
+  const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (o < CN) flags[o] = radii[o] > 0 ? 1u : 0u;
+}
+
+// keys = fp32 depth bits (depth > 0 for every visible Gaussian: the bits are monotone), vals = cam*N+g
+__global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, const int32_t *__restrict__ radii,
+                                                                   const uint32_t *__restrict__ pos,
+                                                                   const float *__restrict__ depths,
+                                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (o >= CN || radii[o] <= 0) return;
+  const uint32_t j = pos[o];
+  keys[j] = __float_as_uint(depths[o]);
+  vals[j] = (uint32_t)o;
+}
+
+// number of tiles touched by each visible entry (tiles_per_gauss was zero-filled)
+__global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(const uint64_t *__restrict__ n_vis_dev,
+                                                                 const uint32_t *__restrict__ vis_idx,
+                                                                 const float *__restrict__ means2d,
                                                                  const int32_t *__restrict__ radii,
-                                                                 const float *__restrict__ depths,
                                                                  const float *__restrict__ conics,
                                                                  const float *__restrict__ opacities, int tile_size,
                                                                  int tile_w, int tile_h,
-                                                                 int32_t *__restrict__ tiles_per_gauss,
-                                                                 uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-  const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  if (o >= CN) return;
+                                                                 int32_t *__restrict__ tiles_per_gauss) {
+  const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
+  if (j >= (int64_t)*n_vis_dev) return;
+  const int64_t o = vis_idx[j];
   const int r = radii[o];
   int cnt = 0;
-  if (r > 0) {
-    int x0, y0, x1, y1;
-    const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
-    if (conics == nullptr) {
-      tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
-      cnt = (x1 - x0) * (y1 - y0);
-    } else {
-      const float a = conics[o * 3], b = conics[o * 3 + 1], c = conics[o * 3 + 2];
-      float q_max;
-      if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
-        for (int ty = y0; ty < y1; ty++) {
-          int lo, hi;
-          row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
-          cnt += hi - lo;
-        }
+  int x0, y0, x1, y1;
+  const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
+  if (conics == nullptr) {
+    tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+    cnt = (x1 - x0) * (y1 - y0);
+  } else {
+    const float a = conics[o * 3], b = conics[o * 3 + 1], c = conics[o * 3 + 2];
+    float q_max;
+    if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
+      for (int ty = y0; ty < y1; ty++) {
+        int lo, hi;
+        row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
+        cnt += hi - lo;
       }
     }
   }
   tiles_per_gauss[o] = cnt;
-  keys[o] = __float_as_uint(depths[o]);  // depth > 0 for every visible Gaussian: bits are monotone
-  vals[o] = (uint32_t)o;
 }
 
-__global__ __launch_bounds__(kIsectBlock) void gather_counts_kernel(int64_t CN, const uint32_t *__restrict__ sorted_idx,
+// counts in depth order (zero beyond the visible count, so that the scan can run over the upper bound)
+__global__ __launch_bounds__(kIsectBlock) void gather_counts_kernel(int64_t CN, const uint64_t *__restrict__ n_vis_dev,
+                                                                   const uint32_t *__restrict__ sorted_idx,
                                                                    const int32_t *__restrict__ tiles_per_gauss,
                                                                    uint32_t *__restrict__ cnt_sorted) {
   const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (j >= CN) return;
-  cnt_sorted[j] = (uint32_t)tiles_per_gauss[sorted_idx[j]];
+  cnt_sorted[j] = j < (int64_t)*n_vis_dev ? (uint32_t)tiles_per_gauss[sorted_idx[j]] : 0u;
 }
 
 // emit (camera*tiles + tile, cam*N+gaussian) pairs in depth order
-__global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(int64_t CN, int64_t N, const uint32_t *__restrict__ sorted_idx,
+__global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(const uint64_t *__restrict__ n_vis_dev, int64_t N,
+                                                                const uint32_t *__restrict__ sorted_idx,
                                                                 const uint32_t *__restrict__ cum_sorted,
                                                                 const float *__restrict__ means2d,
                                                                 const int32_t *__restrict__ radii,
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(int64_t CN, int
                                                                 int tile_w, int tile_h, uint32_t *__restrict__ keys,
                                                                 uint32_t *__restrict__ vals) {
   const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  if (j >= CN) return;
+  if (j >= (int64_t)*n_vis_dev) return;
   const uint32_t o = sorted_idx[j];
   const int r = radii[o];
   if (r <= 0) return;
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_ids_kernel(int64_t M, const
 // workspace layouts
 // ------------------------------------------------------------------------------------------
 struct PrepWs {
-  uint64_t *total;      // [2]
+  uint64_t *total;      // [0] = M (intersections), [1] = visible (camera, Gaussian) entries
   uint32_t *ka, *va, *kb, *vb;  // [CN] each; after prepare: sorted ids live in `sorted`
   uint32_t *cum;        // [CN] exclusive scan of counts in depth order
   uint32_t *temp;       // radix / scan temp
@@ -498,22 +525,32 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const unsigned grid = (unsigned)cdiv(CN, kIsectBlock);
-  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, means2d, radii, depths, conics, opacities,
-                     tile_size, tile_w, tile_h, tiles_per_gauss, L.ka, L.va);
+  // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
+  uint64_t *n_vis = L.total + 1;
+  hipLaunchKernelGGL(isect_flag_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.kb);
   BDS_LAUNCH_CHECK();
-  // depth order: 4 stable passes of 8 bits; ends in (ka, va)
+  int rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, n_vis, st);
+  if (rc != BDS_OK) return rc;
+  hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va);
+  BDS_LAUNCH_CHECK();
+  // 2. tiles per visible entry
+  if (hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
+  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(kIsectBlock), 0, st, n_vis, L.va, means2d, radii, conics, opacities,
+                     tile_size, tile_w, tile_h, tiles_per_gauss);
+  BDS_LAUNCH_CHECK();
+  // 3. depth order: 4 stable passes of 8 bits over the visible entries; ends in (ka, va)
   uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
   for (int p = 0; p < 4; p++) {
-    int rc = radix_pass(kin, vin, kout, vout, CN, 8 * p, 8, L.temp, st);
+    rc = radix_pass(kin, vin, kout, vout, CN, 8 * p, 8, L.temp, st, n_vis);
     if (rc != BDS_OK) return rc;
     uint32_t *t;
     t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
   }
-  // kin/vin == (ka, va) again after 4 swaps: va = Gaussian ids in depth order
-  hipLaunchKernelGGL(gather_counts_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, L.va, tiles_per_gauss, L.kb);
+  // 4. counts in depth order -> exclusive scan (offsets of every entry's run) and the total M
+  hipLaunchKernelGGL(gather_counts_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, tiles_per_gauss, L.kb);
   BDS_LAUNCH_CHECK();
-  int rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
+  rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
   if (rc != BDS_OK) return rc;
   uint64_t total = 0;
   if (hipMemcpyAsync(&total, L.total, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
@@ -552,8 +589,8 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d
   if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
   else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
-  hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, CN, N, P.va, P.cum,
-                     means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
+  hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
+                     P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
   BDS_LAUNCH_CHECK();
   uint32_t *kin = k_emit, *vin = v_emit;
   for (int p = 0; p < npass; p++) {
