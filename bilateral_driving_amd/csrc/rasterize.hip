@@ -209,6 +209,113 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   }
 }
 
+// ---- quadrant-masked wave kernels ---------------------------------------------------------------------
+// One wave64 per 16x16 tile; lane l owns pixel (l % 8, l / 8) of EACH of the tile's four 8x8 quadrants.
+// When a Gaussian is staged, its lane also computes which quadrants the alpha >= 1/255 ellipse can reach
+// (64 Gaussians tested in parallel, the same conservative test as the tile culling); the blend loop then
+// touches only those quadrants.  After tile culling most (tile, Gaussian) pairs clip one or two quadrants,
+// so the per-pair VALU work roughly halves and the lanes that do run are denser (8x8 blocks, not 16x4 strips).
+__device__ __forceinline__ int quadrant_mask(const float4 &A, const float4 &B, int x0, int y0) {
+  const float tau = cull_tau(B.y);
+  const float a = A.z, b = A.w, c = B.x;
+  if (!(tau > 0.f)) return 0;                                           // opacity < 1/255: alpha < 1/255 everywhere
+  if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return 0xF;   // degenerate conic: no pruning
+  const float q_max = 2.f * tau;
+  int m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float fx = (float)(x0 + 8 * (q & 1)), fy = (float)(y0 + 8 * (q >> 1));
+    if (rect_hits_ellipse(A.x, A.y, a, b, c, q_max, fx + 0.5f, fy + 0.5f, fx + 7.5f, fy + 7.5f)) m |= 1 << q;
+  }
+  return m;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kWave) void rasterize_fwd_quad_kernel(
+    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
+    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  __shared__ int sM[kWave];
+  const int n_tiles = tile_w * tile_h;
+  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int cam = item / n_tiles, tile = item - cam * n_tiles;
+  const int ty = tile / tile_w, tx = tile - ty * tile_w;
+  const int lane = threadIdx.x;
+  const int x0 = tx * kTile, y0 = ty * kTile;
+  const int start = offsets[item];
+  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
+  float pxq[4], pyq[4];
+  bool done[4];
+  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  int cur[4] = {0, 0, 0, 0};
+  float out[4][4];
+  int live = 0;  // quadrants that still have an unfinished pixel (wave-uniform)
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int j = x0 + 8 * (q & 1) + (lane & 7), i = y0 + 8 * (q >> 1) + (lane >> 3);
+    pxq[q] = (float)j + 0.5f; pyq[q] = (float)i + 0.5f;
+    done[q] = !(i < H && j < W);
+    if (!__all(done[q])) live |= 1 << q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[q][k] = 0.f;
+  }
+  const int nbatch = (end - start + kWave - 1) / kWave;
+  for (int b = 0; b < nbatch && live; b++) {
+    __syncthreads();
+    const int bstart = start + b * kWave;
+    if (bstart + lane < end) {
+      float4 A, B, Cc;
+      stage_gaussian<CH>(flatten_ids[bstart + lane], means2d, conics, colors, opacities, A, B, Cc);
+      sA[lane] = A; sB[lane] = B;
+      if (CH > 2) sC[lane] = Cc;
+      sM[lane] = quadrant_mask(A, B, x0, y0);
+    }
+    __syncthreads();
+    const int bs = min(kWave, end - bstart);
+    for (int t = 0; t < bs && live; t++) {
+      const int mask = __builtin_amdgcn_readfirstlane(sM[t]) & live;
+      if (mask == 0) continue;
+      const float4 A = sA[t], B = sB[t];
+      float4 Cc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (CH > 2) Cc = sC[t];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!(mask & (1 << q))) continue;  // wave-uniform
+        const float dx = A.x - pxq[q], dy = A.y - pyq[q];
+        const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
+        const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
+        const bool hit = !done[q] && !(sigma < 0.f || alpha < kAlphaMin);
+        const float nT = T[q] * (1.f - alpha);
+        if (hit && nT <= kTStop) done[q] = true;
+        else if (hit) {
+          const float vis = alpha * T[q];
+          out[q][0] += B.z * vis;
+          if (CH > 1) out[q][1] += B.w * vis;
+          if (CH > 2) out[q][2] += Cc.x * vis;
+          if (CH > 3) out[q][3] += Cc.y * vis;
+          cur[q] = bstart + t;
+          T[q] = nT;
+        }
+        if (__all(done[q])) live &= ~(1 << q);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int j = x0 + 8 * (q & 1) + (lane & 7), i = y0 + 8 * (q >> 1) + (lane >> 3);
+    if (i < H && j < W) {
+      const int64_t pix = ((int64_t)cam * H + i) * W + j;
+      alphas[pix] = 1.f - T[q];
+      last_ids[pix] = cur[q];
+      float *r = render + pix * CH;
+#pragma unroll
+      for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + T[q] * backgrounds[cam * CH + k] : out[q][k];
+    }
+  }
+}
+
 // REDUCE = 0: one DPP wave-reduction per gradient value, 13 single-lane atomics per (Gaussian, wave)
 // REDUCE = 1: 16-value transpose-reduce (butterfly_sum16), one 12-lane atomic instruction
 template <int CH, bool ABS, int REDUCE>
@@ -482,6 +589,128 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   }
 }
 
+
+// ---- backward, quadrant-masked (see rasterize_fwd_quad_kernel) -----------------------------------------
+template <int CH, bool ABS>
+__global__ __launch_bounds__(kWave) void rasterize_bwd_quad_kernel(
+    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
+    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
+    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  __shared__ int32_t sId[kWave];
+  __shared__ int sM[kWave];
+  const int n_tiles = tile_w * tile_h;
+  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int cam = item / n_tiles, tile = item - cam * n_tiles;
+  const int ty = tile / tile_w, tx = tile - ty * tile_w;
+  const int lane = threadIdx.x;
+  const int start = offsets[item];
+  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
+  if (end <= start) return;
+  const int x0 = tx * kTile, y0 = ty * kTile;
+  bool inside[4];
+  float pxq[4], pyq[4], T[4], T_final[4], vra[4], buffer[4][4], vr[4][4], bgdot[4];
+  int bin_final[4], qmax[4];
+  int tile_bin_final = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int j = x0 + 8 * (q & 1) + (lane & 7), i = y0 + 8 * (q >> 1) + (lane >> 3);
+    pxq[q] = (float)j + 0.5f; pyq[q] = (float)i + 0.5f;
+    inside[q] = i < H && j < W;
+    const int64_t pix = ((int64_t)cam * H + (inside[q] ? i : 0)) * W + (inside[q] ? j : 0);
+    T_final[q] = inside[q] ? 1.f - alphas[pix] : 1.f;
+    T[q] = T_final[q];
+    bin_final[q] = inside[q] ? last_ids[pix] : 0;
+    qmax[q] = wave_max_i32(bin_final[q]);   // deepest Gaussian any pixel of this quadrant blended
+    tile_bin_final = max(tile_bin_final, qmax[q]);
+    vra[q] = inside[q] ? v_alphas[pix] : 0.f;
+    bgdot[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      buffer[q][k] = 0.f;
+      vr[q][k] = (k < CH && inside[q]) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
+      if (backgrounds && k < CH) bgdot[q] += backgrounds[cam * CH + k] * vr[q][k];
+    }
+  }
+  const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
+  const int nbatch = (end - start + kWave - 1) / kWave;
+  const int b0 = (end - 1 - tile_bin_final) / kWave;
+  for (int b = b0; b < nbatch; b++) {
+    const int batch_end = end - 1 - kWave * b;
+    __syncthreads();
+    const int bs = min(kWave, batch_end + 1 - start);
+    const int idx = batch_end - lane;
+    if (idx >= start) {
+      const int32_t g = flatten_ids[idx];
+      float4 A, B, Cc;
+      stage_gaussian<CH>(g, means2d, conics, colors, opacities, A, B, Cc);
+      sId[lane] = g; sA[lane] = A; sB[lane] = B;
+      if (CH > 2) sC[lane] = Cc;
+      sM[lane] = quadrant_mask(A, B, x0, y0);
+    }
+    __syncthreads();
+    for (int t = max(0, batch_end - tile_bin_final); t < bs; t++) {
+      const int gidx = batch_end - t;  // position of this Gaussian in the tile's list
+      int mask = __builtin_amdgcn_readfirstlane(sM[t]);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (gidx > qmax[q]) mask &= ~(1 << q);
+      if (mask == 0) continue;
+      const float4 A = sA[t], B = sB[t];
+      const float opac = B.y;
+      float col[4] = {B.z, B.w, 0.f, 0.f};
+      if (CH > 2) { const float4 Cc = sC[t]; col[2] = Cc.x; col[3] = Cc.y; }
+      float acc[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc[k] = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!(mask & (1 << q))) continue;  // wave-uniform
+        const float dx = A.x - pxq[q], dy = A.y - pyq[q];
+        const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
+        const float vis = __expf(-sigma);
+        const float alpha = fminf(kAlphaMax, opac * vis);
+        const bool valid = inside[q] && (gidx <= bin_final[q]) && !(sigma < 0.f || alpha < kAlphaMin);
+        if (!__any(valid)) continue;
+        any = true;
+        if (valid) {
+          const float ra = 1.f / (1.f - alpha);
+          T[q] *= ra;
+          const float fac = alpha * T[q];
+          float v_alpha = 0.f;
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            acc[k] += fac * vr[q][k];
+            v_alpha += (col[k] * T[q] - buffer[q][k] * ra) * vr[q][k];
+          }
+          v_alpha += T_final[q] * ra * vra[q];
+          if (backgrounds) v_alpha += -T_final[q] * ra * bgdot[q];
+          if (opac * vis <= kAlphaMax) {
+            const float v_sigma = -opac * vis * v_alpha;
+            acc[4] += 0.5f * v_sigma * dx * dx;
+            acc[5] += v_sigma * dx * dy;
+            acc[6] += 0.5f * v_sigma * dy * dy;
+            const float gx = v_sigma * (A.z * dx + A.w * dy);
+            const float gy = v_sigma * (A.w * dx + B.x * dy);
+            acc[7] += gx; acc[8] += gy;
+            if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
+            acc[11] += vis * v_alpha;
+          }
+#pragma unroll
+          for (int k = 0; k < CH; k++) buffer[q][k] += col[k] * fac;
+        }
+      }
+      if (!any) continue;
+      const float tot = butterfly_sum16(acc, lane);
+      if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
+    }
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -505,7 +734,9 @@ extern "C" int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const floa
       alphas, last_ids
 #define BDS_FWD(ch)                                                                                                    \
   do {                                                                                                                 \
-    if (bds::option_get(bds::kOptRasterFwd) == 1)                                                                      \
+    if (bds::option_get(bds::kOptRasterFwd) == 2)                                                                      \
+      hipLaunchKernelGGL((rasterize_fwd_quad_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS);                     \
+    else if (bds::option_get(bds::kOptRasterFwd) == 1)                                                                 \
       hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS);                     \
     else                                                                                                               \
       hipLaunchKernelGGL((rasterize_fwd_kernel<ch>), grid, block, 0, st, BDS_FWD_ARGS);                                \
@@ -541,7 +772,9 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
       last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities
 #define BDS_BWD(ch, ab)                                                                                                \
   do {                                                                                                                 \
-    if (variant == 2)                                                                                                  \
+    if (variant == 3)                                                                                                  \
+      hipLaunchKernelGGL((rasterize_bwd_quad_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS);                 \
+    else if (variant == 2)                                                                                             \
       hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS);                 \
     else if (variant == 1)                                                                                             \
       hipLaunchKernelGGL((rasterize_bwd_kernel<ch, ab, 1>), grid, block, 0, st, BDS_BWD_ARGS);                         \

@@ -39,9 +39,11 @@ const char *bds_strerror(int code);
 
 /* Kernel-variant switches for A/B measurement and bisecting (results are identical up to fp32
  * summation order).  which: 0 = composite backward (0: per-value DPP reduce, 4 waves/tile;
- * 1: 16-value transpose-reduce, 4 waves/tile; 2: one wave/tile, 4 pixels/lane [default]);
+ * 1: 16-value transpose-reduce, 4 waves/tile; 2: one wave/tile, 4 pixels/lane (row strips);
+ * 3: one wave/tile, 4 pixels/lane (8x8 quadrants, per-Gaussian quadrant masks));
  * 1 = radix pass (0: block-synchronous ranking; 1: wave-private ranking [default]);
- * 2 = composite forward (0: 4 waves/tile, 1 pixel/lane; 1: one wave/tile, 4 pixels/lane [default]). */
+ * 2 = composite forward (0: 4 waves/tile, 1 pixel/lane; 1: one wave/tile, 4 pixels/lane (row strips);
+ *     2: one wave/tile, quadrant-masked).  Defaults: see csrc/api.hip. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 

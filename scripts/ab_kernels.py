@@ -73,12 +73,12 @@ def main():
         Hn.training_loss(o, target, grids).backward()
 
     # whole step, per backward variant x radix variant
-    for rb in (2, 1, 0):
-        for rx in (1, 0):
+    for rb in (3, 2):
+        for rx in (1,):
             L.set_option(L.OPT_RASTER_BWD, rb)
             L.set_option(L.OPT_RADIX, rx)
             fwd_bwd()
-    order = [(2, 1, True, 1), (2, 1, True, 0), (2, 1, False, 1)]
+    order = [(2, 1, True, 1), (3, 1, True, 2), (2, 1, True, 2), (3, 1, False, 2)]
     for r in range(a.rounds):
         for rb, rx, cull, fw in order:
             Hn.TILE_CULL = cull

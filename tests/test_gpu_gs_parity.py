@@ -166,13 +166,13 @@ def _render_both(ops, sc, W, H, mode, bg=None, seed=0):
     return ref_in, r_ref, a_ref, m_ref, gpu_in, r, a, meta
 
 
-@pytest.mark.parametrize("variant", [2, 1, 0], ids=["bwd_wave4px", "bwd_butterfly", "bwd_dpp"])
+@pytest.mark.parametrize("variant", [3, 2, 1, 0], ids=["quad", "bwd_wave4px", "bwd_butterfly", "bwd_dpp"])
 @pytest.mark.parametrize("seed,N,W,H,mode", [(0, 1000, 256, 256, "RGB+ED"), (1, 4000, 320, 200, "RGB"), (2, 600, 75, 50, "RGB+ED"),
                                               (3, 3000, 128, 128, "ED"), (4, 300, 64, 64, "RGB+D")])
 def test_rasterization_end_to_end(ops, seed, N, W, H, mode, variant):
     from bilateral_driving_amd import _lib
     _lib.set_option(_lib.OPT_RASTER_BWD, variant)
-    _lib.set_option(_lib.OPT_RASTER_FWD, 1 if variant == 2 else 0)  # wave kernels together, 4-wave kernels together
+    _lib.set_option(_lib.OPT_RASTER_FWD, {3: 2, 2: 1}.get(variant, 0))  # matching forward kernel for each backward kernel
     sc = make_scene(N, W, H, seed=seed)
     bg = torch.rand(1, 3) if mode == "RGB" else None
     ref_in, r_ref, a_ref, m_ref, gpu_in, r, a, meta = _render_both(ops, sc, W, H, mode, bg)
