@@ -1,0 +1,156 @@
+"""-m gpu: size-independent properties at the BENCHMARK's full size (2 M Gaussians, 1920x1080), where the CPU
+oracle cannot run, plus edge cases (empty / fully culled inputs, multi-camera batches)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    assert torch.cuda.is_available()
+    from bilateral_driving_amd import harness as Hn
+    import bilateral_driving_amd.gs_ops as ops
+    dev = "cuda"
+    N, W, H = 2_000_000, 1920, 1080
+    cam = Hn.ring_cameras(W, H, device=dev)[0]
+    p = Hn.synthetic_scene(N, seed=0, device=dev)
+    opac = torch.sigmoid(p["opacity_logits"])
+    scales = torch.exp(p["log_scales"])
+    radii, m2, d, con, _ = ops.fully_fused_projection(p["means"], p["quats"], scales, cam.viewmat[None], cam.K[None], W, H, near_plane=0.1)
+    return dict(Hn=Hn, ops=ops, N=N, W=W, H=H, cam=cam, p=p, opac=opac, radii=radii, m2=m2, d=d, con=con)
+
+
+def test_fullsize_lists_are_ordered_and_consistent(full):
+    ops, W, H = full["ops"], full["W"], full["H"]
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    for cull in (False, True):
+        tpg, iids, fids, offs = ops.isect_tiles(full["m2"], full["radii"], full["d"], 16, tw, th,
+                                                conics=full["con"] if cull else None, opacities=full["opac"][None] if cull else None)
+        M = iids.numel()
+        assert M == int(tpg.sum()) and M > 1_000_000
+        assert bool((iids[1:] >= iids[:-1]).all())                      # (tile | depth) sorted
+        tile = iids >> 32
+        o = offs.reshape(-1).long()
+        assert bool((o[1:] >= o[:-1]).all()) and int(o[0]) == 0
+        cnt = torch.bincount(tile, minlength=tw * th)
+        assert torch.equal(torch.cumsum(cnt, 0)[:-1], o[1:])            # offsets = lower bounds of every tile
+        bits = full["d"].reshape(-1)[fids.long()].view(torch.int32).long()
+        assert torch.equal(iids & 0xFFFFFFFF, bits)                     # low word = fp32 depth bits of the listed Gaussian
+        assert bool((full["radii"].reshape(-1)[fids.long()] > 0).all())  # only visible Gaussians are listed
+        assert int(torch.unique(fids).numel()) <= int((full["radii"] > 0).sum())
+
+
+def test_fullsize_render_properties(full):
+    ops, W, H, N = full["ops"], full["W"], full["H"], full["N"]
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    g = torch.Generator().manual_seed(0)
+    c1 = torch.rand(1, N, 3, generator=g).cuda()
+    c2 = torch.rand(1, N, 3, generator=g).cuda()
+    op = full["opac"][None]
+    _, _, fids_f, offs_f = ops.isect_tiles(full["m2"], full["radii"], full["d"], 16, tw, th, want_isect_ids=False)
+    _, _, fids_c, offs_c = ops.isect_tiles(full["m2"], full["radii"], full["d"], 16, tw, th, want_isect_ids=False,
+                                           conics=full["con"], opacities=op)
+    assert fids_c.numel() < 0.6 * fids_f.numel()
+    r1f, a1f = ops.rasterize_to_pixels(full["m2"], full["con"], c1, op, W, H, 16, offs_f, fids_f)
+    r1, a1 = ops.rasterize_to_pixels(full["m2"], full["con"], c1, op, W, H, 16, offs_c, fids_c)
+    assert torch.equal(r1, r1f) and torch.equal(a1, a1f)                 # exact tile culling is invisible, bit for bit
+    r1b, _ = ops.rasterize_to_pixels(full["m2"], full["con"], c1, op, W, H, 16, offs_c, fids_c)
+    assert torch.equal(r1, r1b)                                          # forward is deterministic
+    r2, _ = ops.rasterize_to_pixels(full["m2"], full["con"], c2, op, W, H, 16, offs_c, fids_c)
+    r12, a12 = ops.rasterize_to_pixels(full["m2"], full["con"], c1 + 2.0 * c2, op, W, H, 16, offs_c, fids_c)
+    assert float((r12 - (r1 + 2.0 * r2)).abs().max()) < 2e-5             # linear in the colours
+    assert torch.equal(a12, a1)                                          # alpha does not depend on colour
+    assert float(a1.min()) >= 0.0 and float(a1.max()) <= 1.0
+    ones = torch.ones(1, N, 1, device="cuda")
+    r_one, a_one = ops.rasterize_to_pixels(full["m2"], full["con"], ones, op, W, H, 16, offs_c, fids_c)
+    assert float((r_one[..., 0] - a_one[..., 0]).abs().max()) < 2e-5     # colour 1 everywhere -> rendered colour == alpha
+    # backgrounds: out = colour + (1 - alpha) * bg
+    bg = torch.tensor([[0.25, 0.5, 0.75]], device="cuda")
+    rb, _ = ops.rasterize_to_pixels(full["m2"], full["con"], c1, op, W, H, 16, offs_c, fids_c, backgrounds=bg)
+    assert float((rb - (r1 + (1 - a1) * bg[0])).abs().max()) < 1e-5
+
+
+def test_fullsize_bilagrid_identity_and_training_step(full):
+    Hn, W, H = full["Hn"], full["W"], full["H"]
+    from bilateral_driving_amd.bilagrid import bilagrid_transform, total_variation_loss
+    rgb = torch.rand(H, W, 3, device="cuda") * 1.2
+    ident = [torch.tensor([1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0], device="cuda").reshape(1, 12, 1, 1, 1).repeat(1, 1, gl, gy, gx)
+             for (gx, gy, gl) in Hn.LEVELS_3]
+    out = bilagrid_transform(rgb, ident, Hn.FACTORS_3)
+    assert float((out - rgb).abs().max()) < 1e-5                          # identity grids leave the image unchanged
+    assert float(sum(total_variation_loss(g) for g in ident)) == 0.0
+    # one full-size training step through the fused node: finite, every gradient path live
+    p = {k: v.clone().requires_grad_(True) for k, v in full["p"].items()}
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(6, device="cuda")]
+    sky, target = torch.rand(H, W, 3, device="cuda"), torch.rand(H, W, 3, device="cuda")
+    o = Hn.render_view(p, full["cam"], grids, 0, sky)
+    loss = Hn.training_loss(o, target, grids)
+    loss.backward()
+    assert math.isfinite(float(loss))
+    for k, v in p.items():
+        assert v.grad is not None and bool(torch.isfinite(v.grad).all()) and float(v.grad.abs().sum()) > 0, k
+    vis = o["info"]["radii"][0] > 0
+    assert float(p["sh"].grad[~vis].abs().max()) == 0.0                   # culled Gaussians get exactly zero gradient
+    assert float(grids[0].grad[0].abs().sum()) > 0 and float(grids[2].grad[1:].abs().sum()) > 0  # slice + TV routes
+    ag = o["info"]["means2d"].absgrad
+    assert ag.shape == (1, full["N"], 2) and float(ag[0][~vis].abs().max()) == 0.0 and float(ag.sum()) > 0
+
+
+def test_empty_and_fully_culled_inputs():
+    import bilateral_driving_amd.rendering as R
+    dev = "cuda"
+    vm, K = torch.eye(4, device=dev)[None], torch.tensor([[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]], device=dev)[None]
+    # all Gaussians behind the camera
+    means = torch.randn(100, 3, device=dev) - torch.tensor([0.0, 0.0, 10.0], device=dev)
+    means.requires_grad_(True)
+    args = (torch.randn(100, 4, device=dev), torch.rand(100, 3, device=dev) * 0.1 + 0.01, torch.rand(100, device=dev),
+            torch.rand(100, 3, device=dev))
+    r, a, meta = R.rasterization(means, *args, vm, K, 64, 48, render_mode="RGB+ED", absgrad=True)
+    assert int(meta["radii"].abs().sum()) == 0 and meta["flatten_ids"].numel() == 0
+    assert float(r.abs().max()) == 0.0 and float(a.abs().max()) == 0.0
+    (r.sum() + a.sum()).backward()
+    assert float(means.grad.abs().max()) == 0.0
+    # zero opacity Gaussians (invalid instance points, nodes/rigid.py:469) render nothing
+    means2 = torch.randn(50, 3, device=dev) * 0.5 + torch.tensor([0.0, 0.0, 5.0], device=dev)
+    r2, a2, _ = R.rasterization(means2, torch.randn(50, 4, device=dev), torch.rand(50, 3, device=dev) * 0.3 + 0.05,
+                                torch.zeros(50, device=dev), torch.rand(50, 3, device=dev), vm, K, 64, 48)
+    assert float(a2.abs().max()) == 0.0
+    # 2-D Gaussians (one zero scale, gaussians/vanilla.py:132-135) are finite
+    sc = torch.rand(50, 3, device=dev) * 0.3 + 0.05
+    sc[:, 2] = 0.0
+    r3, a3, _ = R.rasterization(means2, torch.randn(50, 4, device=dev), sc, torch.rand(50, device=dev), torch.rand(50, 3, device=dev),
+                                vm, K, 64, 48)
+    assert bool(torch.isfinite(r3).all()) and float(a3.max()) > 0
+
+
+def test_multi_camera_batch_equals_loop():
+    import bilateral_driving_amd.rendering as R
+    from bilateral_driving_amd import harness as Hn
+    dev = "cuda"
+    W, H, N = 208, 120, 5000
+    cams = Hn.ring_cameras(W, H, yaws_deg=(0.0, 40.0, -40.0), device=dev)
+    p = Hn.synthetic_scene(N, seed=3, device=dev)
+    p["means"] = p["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    base = dict(means=p["means"], quats=p["quats"], scales=torch.exp(p["log_scales"]), opacities=torch.sigmoid(p["opacity_logits"]),
+                colors=torch.rand(N, 3, device=dev))
+    vms, Ks = torch.stack([c.viewmat for c in cams]), torch.stack([c.K for c in cams])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    r, a, meta = R.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"], vms, Ks,
+                                 W, H, packed=False, absgrad=True, render_mode="RGB+ED")
+    assert r.shape == (3, H, W, 4) and meta["radii"].shape == (3, N)
+    wt = torch.randn(r.shape, device=dev)
+    (r * wt).sum().backward()
+    tot = {k: torch.zeros_like(v) for k, v in base.items()}
+    for c in range(3):
+        l2 = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        rc, ac, _ = R.rasterization(l2["means"], l2["quats"], l2["scales"], l2["opacities"], l2["colors"], vms[c:c + 1], Ks[c:c + 1],
+                                    W, H, packed=False, render_mode="RGB+ED")
+        assert torch.equal(rc[0], r[c]) and torch.equal(ac[0], a[c])
+        (rc * wt[c:c + 1]).sum().backward()
+        for k in tot:
+            tot[k] += l2[k].grad
+    for k in tot:
+        assert float((leaves[k].grad - tot[k]).norm() / tot[k].norm()) < 1e-4, k
