@@ -167,44 +167,15 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *
   if (threadIdx.x <= mask) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// Row scan of the [bin][block] histogram: workgroup `bin` turns its row into exclusive prefixes over the
-// blocks and records the row total.  The scatter kernels add the (256-entry) prefix over the bins
-// themselves, so a radix pass is 3 launches (histogram, row scan, scatter) instead of 5.
-__global__ __launch_bounds__(kSortBlock) void radix_rowscan_kernel(uint32_t *__restrict__ hist, int nblocks,
-                                                                  uint32_t *__restrict__ totals) {
-  __shared__ uint32_t lw[kSortBlock / kWave + 1];
-  uint32_t *row = hist + (int64_t)blockIdx.x * nblocks;
-  uint32_t carry = 0;
-  for (int base = 0; base < nblocks; base += kSortBlock) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = i < nblocks ? row[i] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(v, tot, lw);
-    if (i < nblocks) row[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
-}
-
-// exclusive prefix over the digit totals, computed redundantly by every scatter workgroup (256 values)
-__device__ __forceinline__ uint32_t digit_base(const uint32_t *__restrict__ totals, uint32_t mask, uint32_t *lw) {
-  const uint32_t v = threadIdx.x <= mask ? totals[threadIdx.x] : 0u;
-  uint32_t tot;
-  return block_excl_scan(v, tot, lw);
-}
-
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
-    const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
-  __shared__ uint32_t lw_[kSortBlock / kWave + 1];
-  const uint32_t dbase = digit_base(totals, mask, lw_);
   __shared__ uint32_t run[256];               // global position of the next element of each digit
   __shared__ uint32_t wcnt[kSortWaves][256];  // per-wave digit counts of the current round
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-  run[tid] = tid <= (int)mask ? dbase + hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
+  run[tid] = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
 #pragma unroll
   for (int w = 0; w < kSortWaves; w++) wcnt[w][tid] = 0;
   __syncthreads();
@@ -251,11 +222,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
-    const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
-  __shared__ uint32_t lw_[kSortBlock / kWave + 1];
-  const uint32_t dbase = digit_base(totals, mask, lw_);
   __shared__ uint32_t wrun[kSortWaves][256];  // next output position per (wave, digit)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 #pragma unroll
@@ -275,7 +243,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
   }
   __syncthreads();
   {  // digit `tid`: exclusive prefix over the waves, on top of the block's scanned base
-    uint32_t base = tid <= (int)mask ? dbase + hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
+    uint32_t base = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
 #pragma unroll
     for (int w = 0; w < kSortWaves; w++) {
       const uint32_t c = wrun[w][tid];
@@ -312,7 +280,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
 static size_t radix_temp_elems(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
   const size_t h = align_up((size_t)256 * nblocks, 4);
-  return h + 256 + scan_temp_elems((int64_t)256 * nblocks);
+  return h + scan_temp_elems((int64_t)256 * nblocks);
 }
 
 static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift,
@@ -322,18 +290,17 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
   const uint32_t mask = (1u << bits) - 1u;
   const int64_t hn = (int64_t)(mask + 1) * nblocks;
   uint32_t *hist = temp;
-  uint32_t *totals = temp + align_up((size_t)256 * nblocks, 4);
-  (void)hn;
+  uint32_t *stemp = temp + align_up((size_t)256 * nblocks, 4);
   hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
   BDS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(mask + 1), dim3(kSortBlock), 0, st, hist, nblocks, totals);
-  BDS_LAUNCH_CHECK();
+  int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
+  if (rc != BDS_OK) return rc;
   if (option_get(kOptRadix) == 1)
     hipLaunchKernelGGL(radix_scatter_wave_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, totals, kout, vout);
+                       nblocks, hist, kout, vout);
   else
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, totals, kout, vout);
+                       nblocks, hist, kout, vout);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
