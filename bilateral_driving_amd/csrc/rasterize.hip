@@ -476,7 +476,9 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   const float px = (float)j + 0.5f;
   const int i0 = ty * kTile + (lane >> 4);
   bool inside[4];
-  float T[4], T_final[4], vra[4], buffer[4][4], vr[4][4], bgdot[4];
+  // Bd[q] = sum_k buffer_k * v_render_k - T_final * (v_alpha - bg . v_render): the only combination of the accumulated
+  // colour `buffer` that the gradient needs, kept as ONE scalar per pixel (saves 16 VGPRs and 5 VALU ops per pixel-pair)
+  float T[4], Bd[4], vr[4][4];
   int bin_final[4];
   int max_bin = 0;
 #pragma unroll
@@ -484,18 +486,18 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     const int i = i0 + 4 * q;
     inside[q] = i < H && j < W;
     const int64_t pix = ((int64_t)cam * H + (inside[q] ? i : 0)) * W + (inside[q] ? j : 0);
-    T_final[q] = inside[q] ? 1.f - alphas[pix] : 1.f;
-    T[q] = T_final[q];
+    const float T_final = inside[q] ? 1.f - alphas[pix] : 1.f;
+    T[q] = T_final;
     bin_final[q] = inside[q] ? last_ids[pix] : 0;
     max_bin = max(max_bin, bin_final[q]);
-    vra[q] = inside[q] ? v_alphas[pix] : 0.f;
-    bgdot[q] = 0.f;
+    const float vra = inside[q] ? v_alphas[pix] : 0.f;
+    float bgdot = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      buffer[q][k] = 0.f;
       vr[q][k] = (k < CH && inside[q]) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
-      if (backgrounds && k < CH) bgdot[q] += backgrounds[cam * CH + k] * vr[q][k];
+      if (backgrounds && k < CH) bgdot += backgrounds[cam * CH + k] * vr[q][k];
     }
+    Bd[q] = -T_final * (vra - bgdot);
   }
   const int tile_bin_final = wave_max_i32(max_bin);
   const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
@@ -551,38 +553,36 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
       float acc[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) acc[k] = 0.f;
-      float s_vs = 0.f;  // sum of v_sigma * ... terms that share dx are folded after the strip loop
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if (!__any(valid[q])) continue;  // strip-uniform skip
         if (valid[q]) {
-          const float ra = 1.f / (1.f - alpha[q]);
+          const float ra = __builtin_amdgcn_rcpf(1.f - alpha[q]);
           T[q] *= ra;
           const float fac = alpha[q] * T[q];
-          float v_alpha = 0.f;
+          float cdot = 0.f;  // colour . v_render
 #pragma unroll
           for (int k = 0; k < CH; k++) {
             acc[k] += fac * vr[q][k];
-            v_alpha += (col[k] * T[q] - buffer[q][k] * ra) * vr[q][k];
+            cdot += col[k] * vr[q][k];
           }
-          v_alpha += T_final[q] * ra * vra[q];
-          if (backgrounds) v_alpha += -T_final[q] * ra * bgdot[q];
+          const float v_alpha = T[q] * cdot - ra * Bd[q];
+          Bd[q] += fac * cdot;
           if (opac * vis[q] <= kAlphaMax) {
             const float v_sigma = -opac * vis[q] * v_alpha;
-            acc[4] += 0.5f * v_sigma * dx * dx;
-            acc[5] += v_sigma * dx * dy[q];
-            acc[6] += 0.5f * v_sigma * dy[q] * dy[q];
-            const float gx = v_sigma * (A.z * dx + A.w * dy[q]);
-            const float gy = v_sigma * (A.w * dx + B.x * dy[q]);
+            const float t1 = v_sigma * dx, t2 = v_sigma * dy[q];
+            acc[4] += t1 * dx;      // x 0.5 after the strip loop
+            acc[5] += t1 * dy[q];
+            acc[6] += t2 * dy[q];   // x 0.5 after the strip loop
+            const float gx = A.z * t1 + A.w * t2;
+            const float gy = A.w * t1 + B.x * t2;
             acc[7] += gx; acc[8] += gy;
             if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
             acc[11] += vis[q] * v_alpha;
           }
-#pragma unroll
-          for (int k = 0; k < CH; k++) buffer[q][k] += col[k] * fac;
         }
       }
-      (void)s_vs;
+      acc[4] *= 0.5f; acc[6] *= 0.5f;
       const float tot = butterfly_sum16(acc, lane);
       if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
     }
