@@ -182,16 +182,16 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
         const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
         const bool hit = !done[q] && !(sigma < 0.f || alpha < kAlphaMin);
         const float nT = T[q] * (1.f - alpha);
-        const bool stop = hit && nT <= kTStop;
-        const bool blend = hit && !stop;          // predicated, no divergent branches in the pair loop
-        done[q] = done[q] || stop;
-        const float vis = blend ? alpha * T[q] : 0.f;
-        out[q][0] += B.z * vis;
-        if (CH > 1) out[q][1] += B.w * vis;
-        if (CH > 2) out[q][2] += Cc.x * vis;
-        if (CH > 3) out[q][3] += Cc.y * vis;
-        cur[q] = blend ? bstart + t : cur[q];
-        T[q] = blend ? nT : T[q];
+        if (hit && nT <= kTStop) done[q] = true;
+        else if (hit) {
+          const float vis = alpha * T[q];
+          out[q][0] += B.z * vis;
+          if (CH > 1) out[q][1] += B.w * vis;
+          if (CH > 2) out[q][2] += Cc.x * vis;
+          if (CH > 3) out[q][3] += Cc.y * vis;
+          cur[q] = bstart + t;
+          T[q] = nT;
+        }
       }
     }
   }
@@ -568,19 +568,18 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
           }
           const float v_alpha = T[q] * cdot - ra * Bd[q];
           Bd[q] += fac * cdot;
-          // alpha clamped at 0.999 -> no gradient through sigma / opacity (predicated, not branched)
-          const float live = (opac * vis[q] <= kAlphaMax) ? 1.f : 0.f;
-          const float va_l = v_alpha * live;
-          const float v_sigma = -opac * vis[q] * va_l;
-          const float t1 = v_sigma * dx, t2 = v_sigma * dy[q];
-          acc[4] += t1 * dx;      // x 0.5 after the strip loop
-          acc[5] += t1 * dy[q];
-          acc[6] += t2 * dy[q];   // x 0.5 after the strip loop
-          const float gx = A.z * t1 + A.w * t2;
-          const float gy = A.w * t1 + B.x * t2;
-          acc[7] += gx; acc[8] += gy;
-          if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
-          acc[11] += vis[q] * va_l;
+          if (opac * vis[q] <= kAlphaMax) {
+            const float v_sigma = -opac * vis[q] * v_alpha;
+            const float t1 = v_sigma * dx, t2 = v_sigma * dy[q];
+            acc[4] += t1 * dx;      // x 0.5 after the strip loop
+            acc[5] += t1 * dy[q];
+            acc[6] += t2 * dy[q];   // x 0.5 after the strip loop
+            const float gx = A.z * t1 + A.w * t2;
+            const float gy = A.w * t1 + B.x * t2;
+            acc[7] += gx; acc[8] += gy;
+            if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
+            acc[11] += vis[q] * v_alpha;
+          }
         }
       }
       acc[4] *= 0.5f; acc[6] *= 0.5f;
