@@ -202,8 +202,8 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, cons
 // conservative [lo, hi] (every candidate is re-checked with resample_tap)
 __device__ __forceinline__ void adjoint_range(int c, int full, int low, int &lo, int &hi) {
   const float s = (float)full / (float)low;
-  lo = (int)floorf(((float)c - 0.5f) * s - 0.5f) - 1;
-  hi = (int)ceilf(((float)c + 1.5f) * s - 0.5f) + 1;
+  lo = (int)floorf(((float)c - 0.5f) * s - 0.5f);
+  hi = (int)ceilf(((float)c + 1.5f) * s - 0.5f);
   lo = lo < 0 ? 0 : lo;
   hi = hi > full - 1 ? full - 1 : hi;
 }
@@ -221,10 +221,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.f;
+#pragma unroll 4
   for (int x = xlo; x <= xhi; x++) {
     const Tap tx = resample_tap(x, p.W, L.Wd);
     const float w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
-    if (w == 0.f) continue;
     const int64_t o = ((int64_t)y * p.W + x) * 3;
     const float p0 = L.P[o], p1 = L.P[o + 1], p2 = L.P[o + 2];
 #pragma unroll
@@ -322,10 +322,12 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
     } else {  // y pass of the up-sampler adjoint over the x-reduced rows
       int ylo, yhi;
       adjoint_range(i, p.H, L.Hd, ylo, yhi);
+      // no early-out on zero weights: the few extra rows of the conservative window cost less than the
+      // serialised load -> test -> load chain they would otherwise create (the loop is latency-bound)
+#pragma unroll 4
       for (int y = ylo; y <= yhi; y++) {
         const Tap ty = resample_tap(y, p.H, L.Hd);
         const float w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
-        if (w == 0.f) continue;
         const float4 *sv = reinterpret_cast<const float4 *>(L.R + ((int64_t)y * L.Wd + j) * 12);
         const float4 a = sv[0], b = sv[1], c = sv[2];
         va[0] += w * a.x; va[1] += w * a.y; va[2] += w * a.z; va[3] += w * a.w;
