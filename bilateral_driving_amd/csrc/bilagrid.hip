@@ -25,6 +25,7 @@ struct LevelDev {
   float *P;            // [H*W,3] input colour of this level                  (bwd scratch)
   float *Q;            // [H*W,3] gradient w.r.t. this level's output          (bwd scratch)
   float *R;            // [H*Wd,12] x-reduced adjoint of the up-sampler        (bwd scratch)
+  float *vg;           // [Hd*Wd] gradient w.r.t. the low-res guidance (gray)  (bwd scratch)
   float *aff_out;      // optional [H*W,12]
   int gx, gy, gl, factor, n_avg, Hd, Wd;
 };
@@ -291,7 +292,7 @@ __device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, in
 // that was 3x the cost of everything else in this kernel.)  Deterministic for the LDS path.
 template <bool kLds>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, LevelSched sc, float *__restrict__ v_in,
-                                                                float *__restrict__ partials) {
+                                                                float *__restrict__ partials, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds_acc[];
   int local;
   const int k_entry = sched_find(sc, blockIdx.x, local);
@@ -319,6 +320,8 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
       for (int r = 0; r < 3; r++) {
         va[r * 4 + 0] = Q[r] * P[0]; va[r * 4 + 1] = Q[r] * P[1]; va[r * 4 + 2] = Q[r] * P[2]; va[r * 4 + 3] = Q[r];
       }
+    } else if (dbg & 1) {
+      for (int k = 0; k < 12; k++) va[k] = 1.f;
     } else {  // y pass of the up-sampler adjoint over the x-reduced rows
       int ylo, yhi;
       adjoint_range(i, p.H, L.Hd, ylo, yhi);
@@ -344,30 +347,17 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
   const float inv_n = 1.f / (float)L.n_avg;
   float v_iz = 0.f;
   for (int n = 0; n < L.n_avg; n++) {
-    if (L.v_grid) slice_grid_scatter(acc + n * gsz, c, L.gx, L.gy, L.gl, inv_n, va, active);
-    if (active && c.z_interior) {
+    if (L.v_grid && !(dbg & 2)) slice_grid_scatter(acc + n * gsz, c, L.gx, L.gy, L.gl, inv_n, va, active);
+    if (active && c.z_interior && !(dbg & 4)) {
       float a12[12], dz[12];
       slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a12, dz);
 #pragma unroll
       for (int ch = 0; ch < 12; ch++) v_iz += va[ch] * dz[ch] * inv_n;
     }
   }
-  if (active && c.z_interior && v_iz != 0.f) {
-    const float v_gray = v_iz * (float)(L.gl - 1);
-    const float vr = v_gray * kGrayR, vg = v_gray * kGrayG, vb = v_gray * kGrayB;
-    const int yy[2] = {ty.i0, ty.i1}, xx[2] = {tx.i0, tx.i1};
-    const float wy2[2] = {1.f - ty.w1, ty.w1}, wx2[2] = {1.f - tx.w1, tx.w1};
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int bb = 0; bb < 2; bb++) {
-        const float w = wy2[a] * wx2[bb];
-        if (w != 0.f) {
-          float *d = v_in + ((int64_t)yy[a] * p.W + xx[bb]) * 3;
-          atomicAdd(d, vr * w); atomicAdd(d + 1, vg * w); atomicAdd(d + 2, vb * w);
-        }
-      }
-  }
+  // guidance route: d(loss)/d(gray) of this low-res pixel; the full-resolution kernel E gathers it through the
+  // adjoint of the bilinear down-sampler (no atomics on the image)
+  if (active) L.vg[idx] = c.z_interior ? v_iz * (float)(L.gl - 1) : 0.f;
   }  // grid-stride loop
   if (kLds && L.v_grid) {
     __syncthreads();
@@ -410,23 +400,49 @@ __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams
   }
 }
 
-// ---- E: clamp + sky blend backward (in place on v_in) ------------------------------------------
-__global__ __launch_bounds__(kBgBlock) void blend_bwd_kernel(int64_t HW, const float *__restrict__ rgb,
-                                                            const float *__restrict__ alpha, const float *__restrict__ sky,
-                                                            float *__restrict__ v_rgb, float *__restrict__ v_alpha,
-                                                            float *__restrict__ v_sky) {
+// ---- E: guidance route gather + clamp / sky blend backward (in place on v_in) -----------------------
+// v_in already holds the direct-route gradient.  Every level adds  gray_weights * sum_{low-res pixels whose
+// down-sample taps include this pixel} w * v_gray  (adjoint of the bilinear down-sampler, gather form), then the
+// clamp(max=1) + sky blend in front of the transform is back-propagated.
+template <int NL>
+__global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParams p, float *__restrict__ v_in,
+                                                                        float *__restrict__ v_alpha, float *__restrict__ v_sky) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
-  if (pix >= HW) return;
-  const float k = 1.f - alpha[pix];
-  float va = 0.f;
+  if (pix >= (int64_t)p.H * p.W) return;
+  const int y = (int)(pix / p.W), x = (int)(pix - (int64_t)y * p.W);
+  float vg = 0.f;
 #pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float v = v_rgb[pix * 3 + c];
-    va -= v * sky[pix * 3 + c];
-    if (v_sky) v_sky[pix * 3 + c] = v * k;
-    v_rgb[pix * 3 + c] = rgb[pix * 3 + c] <= 1.f ? v : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
+  for (int l = 0; l < NL; l++) {
+    if (l >= p.nlevels) break;
+    const LevelDev &L = p.lv[l];
+    if (L.Hd == p.H && L.Wd == p.W) { vg += L.vg[pix]; continue; }
+    int ilo, ihi, jlo, jhi;
+    adjoint_range(y, L.Hd, p.H, ilo, ihi);
+    adjoint_range(x, L.Wd, p.W, jlo, jhi);
+    for (int i = ilo; i <= ihi; i++) {
+      const Tap ty = resample_tap(i, L.Hd, p.H);
+      const float wy = (ty.i0 == y ? 1.f - ty.w1 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int j = jlo; j <= jhi; j++) {
+        const Tap tx = resample_tap(j, L.Wd, p.W);
+        const float wx = (tx.i0 == x ? 1.f - tx.w1 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
+        if (wx != 0.f) vg += wy * wx * L.vg[(int64_t)i * L.Wd + j];
+      }
+    }
   }
-  if (v_alpha) v_alpha[pix] = va;
+  float v[3] = {v_in[pix * 3] + vg * kGrayR, v_in[pix * 3 + 1] + vg * kGrayG, v_in[pix * 3 + 2] + vg * kGrayB};
+  if (p.sky) {
+    const float k = 1.f - p.alpha[pix];
+    float va = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      va -= v[c] * p.sky[pix * 3 + c];
+      if (v_sky) v_sky[pix * 3 + c] = v[c] * k;
+      v[c] = p.rgb[pix * 3 + c] <= 1.f ? v[c] : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
+    }
+    if (v_alpha) v_alpha[pix] = va;
+  }
+  v_in[pix * 3] = v[0]; v_in[pix * 3 + 1] = v[1]; v_in[pix * 3 + 2] = v[2];
 }
 
 // ---- generic point slice (BilateralGrid.forward on arbitrary points) ------------------------------
@@ -511,7 +527,7 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
 
 // ---- host side ---------------------------------------------------------------------------------
 struct MsLayout {
-  size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS];
+  size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS], vg_off[BDS_MAX_LEVELS];
   size_t part_off;  // per-workgroup partial grid gradients (shared by the levels, which run one after the other)
   size_t bytes;
 };
@@ -538,6 +554,7 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     L.q_off[l] = off; off += align_up((size_t)H * W * 3 * sizeof(float), 256);
     L.r_off[l] = off;
     if (!(Hd == H && Wd == W)) off += align_up((size_t)H * Wd * 12 * sizeof(float), 256);
+    L.vg_off[l] = off; off += align_up((size_t)Hd * Wd * sizeof(float), 256);
   }
   L.part_off = off;
   size_t gmax = 0;
@@ -574,6 +591,7 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
     d.P = reinterpret_cast<float *>(base + L.p_off[l]);
     d.Q = reinterpret_cast<float *>(base + L.q_off[l]);
     d.R = reinterpret_cast<float *>(base + L.r_off[l]);
+    d.vg = reinterpret_cast<float *>(base + L.vg_off[l]);
     d.aff_out = affine_out ? affine_out[l] : nullptr;
     BDS_REQUIRE(d.aff_out == nullptr || aligned16(d.aff_out));
     d.gx = lv[l].gx; d.gy = lv[l].gy; d.gl = lv[l].gl; d.factor = lv[l].factor; d.n_avg = lv[l].n_avg;
@@ -674,7 +692,8 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
       if (gbytes > kMaxGridLds) {  // grid gradient too large for LDS: direct global atomics, own launch
         LevelSched one{};
         one.n = 1; one.level[0] = l; one.nblk[0] = (int)need; one.blk_off[1] = (int)need;
-        hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)need), dim3(kBgBlock), 0, st, p, one, v_rgb, partials);
+        hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)need), dim3(kBgBlock), 0, st, p, one, v_rgb, partials,
+                           option_get(kOptDebug));
         BDS_LAUNCH_CHECK();
         continue;
       }
@@ -698,7 +717,7 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
           return BDS_ELAUNCH;
       }
       hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_max, st, p, sc, v_rgb,
-                         partials);
+                         partials, option_get(kOptDebug));
       BDS_LAUNCH_CHECK();
       if (red.blk_off[red.n] > 0) {
         hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)red.blk_off[red.n]), dim3(kBgBlock), 0, st, p, sc, red,
@@ -707,9 +726,15 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
       }
     }
   }
-  if (sky) {
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)cdiv(HW, kBgBlock)), dim3(kBgBlock), 0, st, HW, rgb, alpha, sky, v_rgb,
-                       v_alpha, v_sky);
+  {
+    const dim3 grid((unsigned)cdiv(HW, kBgBlock)), block(kBgBlock);
+    switch (nlevels) {
+      case 1: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<1>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
+      case 2: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<2>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
+      case 3: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<3>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
+      case 4: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<4>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
+      default: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
+    }
     BDS_LAUNCH_CHECK();
   }
   return BDS_OK;
