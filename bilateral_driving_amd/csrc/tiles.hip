@@ -85,10 +85,23 @@ __global__ __launch_bounds__(kScanBlock) void scan_small_kernel(uint32_t *__rest
   if (total_out && threadIdx.x == 0) *total_out = tot;
 }
 
+// kSelfOffset: block_offsets holds the raw tile TOTALS and every workgroup sums the ones in front of it itself
+// (at most a few hundred values) -- saves the separate scan-of-totals launch for all but huge inputs.
+template <bool kSelfOffset>
 __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const uint32_t *__restrict__ in, int64_t n,
                                                                const uint32_t *__restrict__ block_offsets,
-                                                               uint32_t *__restrict__ out) {
+                                                               uint32_t *__restrict__ out, uint64_t *__restrict__ total_out) {
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  uint32_t my_offset;
+  if (kSelfOffset) {
+    uint32_t part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kScanBlock) part += block_offsets[b];
+    uint32_t tot;
+    block_excl_scan(part, tot, lw);
+    my_offset = tot;
+  } else {
+    my_offset = block_offsets[blockIdx.x];
+  }
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   uint32_t v[kScanItems];
   uint32_t s = 0;
@@ -98,12 +111,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const uint32_t *
     s += v[i];
   }
   uint32_t tot;
-  uint32_t ex = block_excl_scan(s, tot, lw) + block_offsets[blockIdx.x];
+  uint32_t ex = block_excl_scan(s, tot, lw) + my_offset;
 #pragma unroll
   for (int i = 0; i < kScanItems; i++) {
     if (base + i < n) out[base + i] = ex;
     ex += v[i];
   }
+  if (kSelfOffset && total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = (uint64_t)my_offset + tot;
 }
 
 // uint32 elements of temp needed to scan n elements
@@ -132,9 +146,14 @@ static int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint
   uint32_t *sums = temp;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, st, in, n, sums);
   BDS_LAUNCH_CHECK();
+  if (nb <= 4096) {  // two launches: every workgroup derives its own offset from the tile totals
+    hipLaunchKernelGGL((scan_apply_kernel<true>), dim3((unsigned)nb), dim3(kScanBlock), 0, st, in, n, sums, out, total_out);
+    BDS_LAUNCH_CHECK();
+    return BDS_OK;
+  }
   int rc = exclusive_scan_u32(sums, sums, nb, temp + align_up((size_t)nb, 4), total_out, st);
   if (rc != BDS_OK) return rc;
-  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, st, in, n, sums, out);
+  hipLaunchKernelGGL((scan_apply_kernel<false>), dim3((unsigned)nb), dim3(kScanBlock), 0, st, in, n, sums, out, nullptr);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -172,6 +191,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
     const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+  if ((int64_t)blockIdx.x * kSortChunk >= n) return;  // launch is sized for the host-side bound
   __shared__ uint32_t run[256];               // global position of the next element of each digit
   __shared__ uint32_t wcnt[kSortWaves][256];  // per-wave digit counts of the current round
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
@@ -224,6 +244,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
     const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+  if ((int64_t)blockIdx.x * kSortChunk >= n) return;  // launch is sized for the host-side bound
   __shared__ uint32_t wrun[kSortWaves][256];  // next output position per (wave, digit)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 #pragma unroll
