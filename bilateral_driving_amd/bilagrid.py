@@ -162,28 +162,24 @@ class BilateralGrid(nn.Module):
 
 
 def slice(bil_grids: BilateralGrid, xy: Tensor, rgb: Tensor, grid_idx: Tensor):
-    """lib_bilagrid.py:171-230: returns {"rgb", "rgb_affine_mats"}."""
-    sh_ = rgb.shape
-    grid_idx_unique = torch.unique(grid_idx)
-    if len(grid_idx_unique) == 1:
-        grid_idx = grid_idx_unique
-        xy = xy.unsqueeze(0)
-        rgb = rgb.unsqueeze(0)
+    """Slice bilateral grids at pixel coordinates ``xy`` (in [0,1]) guided by the gray value of ``rgb`` and apply the
+    sliced 3x4 affine maps: returns ``{"rgb": transformed colours, "rgb_affine_mats": [..., 3, 4]}``
+    (same contract as the reference's lib_bilagrid.slice, /root/reference/project/bilateral/lib_bilagrid.py:171-230).
+
+    Batched inputs (2-D .. 4-D, leading dim = batch) carry one grid index per batch entry in ``grid_idx[:, 0, ...]``;
+    when every sample uses the same grid (the training path: one image per step) the whole input is one batch entry."""
+    shape = rgb.shape
+    distinct = torch.unique(grid_idx)
+    if distinct.numel() == 1:
+        per_entry_idx = distinct
+        xy, rgb = xy[None], rgb[None]
     else:
-        if grid_idx.dim() == 4:
-            grid_idx = grid_idx[:, 0, 0, 0]
-        elif grid_idx.dim() == 3:
-            grid_idx = grid_idx[:, 0, 0]
-        elif grid_idx.dim() == 2:
-            grid_idx = grid_idx[:, 0]
-        else:
+        if not 2 <= grid_idx.dim() <= 4:
             raise ValueError("The input to bilateral grid slicing is not supported yet.")
-    affine_mats = bil_grids(xy, rgb, grid_idx)
-    out = color_affine_transform(affine_mats, rgb)
-    return {
-        "rgb": out.reshape(*sh_),
-        "rgb_affine_mats": affine_mats.reshape(*sh_[:-1], affine_mats.shape[-2], affine_mats.shape[-1]),
-    }
+        per_entry_idx = grid_idx.reshape(grid_idx.shape[0], -1)[:, 0]
+    mats = bil_grids(xy, rgb, per_entry_idx)
+    out = color_affine_transform(mats, rgb)
+    return {"rgb": out.reshape(shape), "rgb_affine_mats": mats.reshape(*shape[:-1], 3, 4)}
 
 
 # --------------------------------------------------------------------------------------------

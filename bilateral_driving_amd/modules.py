@@ -67,12 +67,11 @@ class BilateralAffineTransform(nn.Module):
         return self.bil_grids.grids[torch.as_tensor(near, device=self.bil_grids.grids.device)]
 
     def forward(self, rgb: Tensor, image_infos) -> Tensor:
+        """Reference API: the per-pixel 3x4 maps [1,H,W,3,4] (differentiable when grad mode is on)."""
         assert "img_idx" in image_infos
-        _, maps = bilagrid_transform(rgb, [self._grids_for(image_infos)], [1], return_maps=True) if not torch.is_grad_enabled() \
-            else (None, None)
-        if maps is not None:
+        if not torch.is_grad_enabled():  # evaluation: the fused kernels also emit the maps
+            _, maps = bilagrid_transform(rgb, [self._grids_for(image_infos)], [1], return_maps=True)
             return maps[0][None]
-        # differentiable maps (reference API): point slice at full resolution
         H, W, _ = rgb.shape
         gy, gx = torch.meshgrid(torch.linspace(0, 1.0, H, device=rgb.device), torch.linspace(0, 1.0, W, device=rgb.device),
                                 indexing="ij")
