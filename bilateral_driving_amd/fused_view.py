@@ -179,7 +179,7 @@ class _FusedView(torch.autograd.Function):
 def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor],
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
-               grad_arena: Optional[Dict[str, Tensor]] = None):
+               grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids).  Returns dict(rgb, depth, opacity, rgb_gaussians, info).
 
@@ -187,7 +187,8 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     straight into these (e.g. slices of the flat all-reduce buffer of ``dist.FlatGradients``) instead of fresh
     tensors, so that multi-GPU runs need no pack pass.  Valid when each parameter receives its gradient from
     this node only (the reference's step: one view per iteration)."""
-    cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
+    if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds[..., :3, 3]); callers with fixed cameras cache it
+        cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), viewmat=viewmat, K=K, cam_pos=cam_pos, factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena)

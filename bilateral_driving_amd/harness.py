@@ -40,6 +40,7 @@ class Camera:
     K: Tensor        # [3,3]
     width: int
     height: int
+    cam_pos: Optional[Tensor] = None  # [3] camera centre in world space (= inv(viewmat)[:3, 3]), cached per camera
 
 
 def ring_cameras(W: int, H: int, yaws_deg: Sequence[float] = SIX_CAM_YAWS, device="cpu") -> List[Camera]:
@@ -56,7 +57,7 @@ def ring_cameras(W: int, H: int, yaws_deg: Sequence[float] = SIX_CAM_YAWS, devic
         vm = torch.eye(4)
         vm[:3, :3] = R
         # rig at the origin
-        cams.append(Camera(vm.to(device), K, W, H))
+        cams.append(Camera(vm.to(device), K, W, H, torch.linalg.inv(vm)[:3, 3].contiguous().to(device)))
     return cams
 
 
@@ -94,7 +95,7 @@ def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor],
     if not FUSED:
         return render_view_staged(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
     grids_k = [g[img_idx:img_idx + 1] for g in grids]
-    return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids_k, sky, factors, sh_degree=sh_degree,
+    return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids_k, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL,
                       grad_arena=grad_arena)
 
