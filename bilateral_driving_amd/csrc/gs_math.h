@@ -104,7 +104,6 @@ BDS_HD void sh_bases_vjp(int deg, float x, float y, float z, const float *g, flo
 // tiny fixed-size linear algebra (row-major)
 // ------------------------------------------------------------------------------------------
 struct M3 { float m[9]; };
-struct M2 { float m[4]; };
 
 BDS_HD M3 mul33(const M3 &a, const M3 &b) {
   M3 r;
