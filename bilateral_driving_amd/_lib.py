@@ -43,7 +43,8 @@ _SIGS = {
     "bds_isect_build": (_i, [_i, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f]),
     "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
-                               _f, _f, _f, _f]),
+                               _f, _f, _f, _f, _f]),
+    "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),

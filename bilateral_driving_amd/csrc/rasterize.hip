@@ -25,6 +25,13 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
+// Work item of a workgroup: the XCD-contiguous position, optionally redirected through a schedule
+// (bds_rasterize_bwd_schedule: each XCD's range re-ordered longest tile first, see below).
+__device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int bid, int total) {
+  const int p = xcd_contiguous(bid, total);
+  return order ? order[p] : p;
+}
+
 // value slots of the per-Gaussian gradient record that is reduced over a tile's pixels
 //   0-3 colour, 4-6 conic, 7-8 mean2d, 9-10 |mean2d| (absgrad), 11 opacity
 struct GradTarget {
@@ -141,13 +148,14 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   const float px = (float)j + 0.5f;
   const int start = offsets[item];
   const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
-  bool done[4];
-  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  // T[q] > 0: running transmittance; T[q] < 0: the pixel is finished and |T[q]| is its final transmittance
+  // (pixels outside the image start finished).  One register instead of a flag + a value per pixel.
+  float T[4];
   int cur[4] = {0, 0, 0, 0};
   float out[4][4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    done[q] = !((i0 + 4 * q) < H && j < W);
+    T[q] = ((i0 + 4 * q) < H && j < W) ? 1.f : -1.f;
 #pragma unroll
     for (int k = 0; k < 4; k++) out[q][k] = 0.f;
   }
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   float4 pA = make_float4(0.f, 0.f, 0.f, 0.f), pB = pA, pC = pA;
   if (start + lane < end) stage_gaussian<CH>(flatten_ids[start + lane], means2d, conics, colors, opacities, pA, pB, pC);
   for (int b = 0; b < nbatch; b++) {
-    if (__all(done[0] && done[1] && done[2] && done[3])) break;
+    if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
     __syncthreads();
     const int bstart = start + b * kWave;
     if (bstart + lane < end) {
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       stage_gaussian<CH>(flatten_ids[bstart + kWave + lane], means2d, conics, colors, opacities, pA, pB, pC);
     const int bs = min(kWave, end - bstart);
     for (int t = 0; t < bs; t++) {
-      if (__all(done[0] && done[1] && done[2] && done[3])) break;
+      if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;
       const float hax2 = 0.5f * A.z * dx * dx, bdx = A.w * dx;
@@ -180,9 +188,9 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
         const float dy = A.y - ((float)(i0 + 4 * q) + 0.5f);
         const float sigma = hax2 + (0.5f * B.x * dy + bdx) * dy;
         const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
-        const bool hit = !done[q] && !(sigma < 0.f || alpha < kAlphaMin);
+        const bool hit = T[q] > 0.f && !(sigma < 0.f || alpha < kAlphaMin);
         const float nT = T[q] * (1.f - alpha);
-        if (hit && nT <= kTStop) done[q] = true;
+        if (hit && nT <= kTStop) T[q] = -T[q];
         else if (hit) {
           const float vis = alpha * T[q];
           out[q][0] += B.z * vis;
@@ -200,11 +208,12 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     const int i = i0 + 4 * q;
     if (i < H && j < W) {
       const int64_t pix = ((int64_t)cam * H + i) * W + j;
-      alphas[pix] = 1.f - T[q];
+      const float Tf = fabsf(T[q]);
+      alphas[pix] = 1.f - Tf;
       last_ids[pix] = cur[q];
       float *r = render + pix * CH;
 #pragma unroll
-      for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + T[q] * backgrounds[cam * CH + k] : out[q][k];
+      for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + Tf * backgrounds[cam * CH + k] : out[q][k];
     }
   }
 }
@@ -325,11 +334,12 @@ __global__ __launch_bounds__(kRastBlock) void rasterize_bwd_kernel(
     int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
-    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
+    const int32_t *__restrict__ tile_order) {
   __shared__ float4 sA[kRastBlock], sB[kRastBlock], sC[kRastBlock];
   __shared__ int32_t sId[kRastBlock];
   const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -461,11 +471,12 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
-    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
+    const int32_t *__restrict__ tile_order) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     const int64_t pix = ((int64_t)cam * H + (inside[q] ? i : 0)) * W + (inside[q] ? j : 0);
     const float T_final = inside[q] ? 1.f - alphas[pix] : 1.f;
     T[q] = T_final;
-    bin_final[q] = inside[q] ? last_ids[pix] : 0;
+    bin_final[q] = inside[q] ? last_ids[pix] : -1;   // -1: never valid (pixel outside the image)
     max_bin = max(max_bin, bin_final[q]);
     const float vra = inside[q] ? v_alphas[pix] : 0.f;
     float bgdot = 0.f;
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
         const float sigma = hax2 + (0.5f * B.x * dy[q] + bdx) * dy[q];
         vis[q] = __expf(-sigma);
         alpha[q] = fminf(kAlphaMax, opac * vis[q]);
-        valid[q] = inside[q] && (batch_end - t <= bin_final[q]) && !(sigma < 0.f || alpha[q] < kAlphaMin);
+        valid[q] = (batch_end - t <= bin_final[q]) && !(sigma < 0.f || alpha[q] < kAlphaMin);
         any |= valid[q];
       }
       if (!__any(any)) continue;
@@ -598,12 +609,13 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_quad_kernel(
     int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
-    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
+    const int32_t *__restrict__ tile_order) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   __shared__ int sM[kWave];
   const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -711,6 +723,74 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_quad_kernel(
   }
 }
 
+// ---- backward schedule: longest tile first inside each XCD's range ------------------------------------
+// One wave per tile finishes when its LAST pixel does, and the chip holds only ~2 rounds of tiles
+// (8160 tiles at 1080p over 1024 SIMDs x 4 resident waves), so tiles dispatched late that happen to be long
+// leave most SIMDs idle at the end of the launch.  The visited length of every tile is known exactly after the
+// forward pass (max last_id - list start); dispatching each XCD's contiguous range longest-first (LPT rule)
+// removes that tail while keeping the range -> XCD assignment (L2 locality) unchanged.
+__global__ __launch_bounds__(kRastBlock) void tile_work_kernel(int C, int W, int H, int tile_w, int tile_h,
+                                                               const int32_t *__restrict__ offsets,
+                                                               const int32_t *__restrict__ last_ids,
+                                                               int32_t *__restrict__ work) {
+  const int n_tiles = tile_w * tile_h, total = C * n_tiles;
+  const int item = blockIdx.x * (kRastBlock / kWave) + (threadIdx.x >> 6);
+  if (item >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int cam = item / n_tiles, tile = item - cam * n_tiles;
+  const int ty = tile / tile_w, tx = tile - ty * tile_w;
+  const int j = tx * kTile + (lane & 15);
+  int m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = ty * kTile + (lane >> 4) + 4 * q;
+    if (i < H && j < W) m = max(m, last_ids[((int64_t)cam * H + i) * W + j]);
+  }
+  m = wave_max_i32(m);
+  // (an empty list leaves last_ids at 0: the estimate is then 0, or 1 for the very first tile)
+  if (lane == 0) work[item] = max(0, m - offsets[item] + 1);
+}
+
+constexpr int kSchedThreads = 1024, kSchedBins = 1024;
+__global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, const int32_t *__restrict__ work,
+                                                                   int32_t *__restrict__ order) {
+  __shared__ int hist[kSchedBins];
+  __shared__ int s_max;
+  constexpr int kXcd = 8;
+  const int per = total / kXcd, rem = total % kXcd, x = blockIdx.x;
+  const int cnt = per + (x < rem ? 1 : 0), first = x * per + (x < rem ? x : rem);
+  const int tid = threadIdx.x;
+  if (tid == 0) s_max = 0;
+  for (int b = tid; b < kSchedBins; b += kSchedThreads) hist[b] = 0;
+  __syncthreads();
+  int lmax = 0;
+  for (int i = tid; i < cnt; i += kSchedThreads) lmax = max(lmax, work[first + i]);
+  lmax = wave_max_i32(lmax);
+  if ((tid & 63) == 0) atomicMax(&s_max, lmax);
+  __syncthreads();
+  int shift = 0;
+  while ((s_max >> shift) >= kSchedBins) shift++;
+  // bin 0 = longest
+  for (int i = tid; i < cnt; i += kSchedThreads) atomicAdd(&hist[kSchedBins - 1 - (work[first + i] >> shift)], 1);
+  __syncthreads();
+  // exclusive scan of the 1024 bins (one bin per thread, Hillis-Steele in LDS)
+  const int mine = hist[tid];
+  int incl = mine;
+  for (int o = 1; o < kSchedBins; o <<= 1) {
+    __syncthreads();
+    hist[tid] = incl;
+    __syncthreads();
+    if (tid >= o) incl += hist[tid - o];
+  }
+  __syncthreads();
+  hist[tid] = incl - mine;   // becomes the bin's running cursor
+  __syncthreads();
+  for (int i = tid; i < cnt; i += kSchedThreads) {
+    const int pos = atomicAdd(&hist[kSchedBins - 1 - (work[first + i] >> shift)], 1);
+    order[first + pos] = first + i;
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -755,7 +835,8 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
                                  int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
                                  const int32_t *flatten_ids, const float *alphas, const int32_t *last_ids,
                                  const float *v_render, const float *v_alphas, float *v_means2d, float *v_means2d_abs,
-                                 float *v_conics, float *v_colors, float *v_opacities, bds_stream_t stream) {
+                                 float *v_conics, float *v_colors, float *v_opacities, const int32_t *tile_order,
+                                 bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
@@ -769,7 +850,7 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
   const int variant = bds::option_get(bds::kOptRasterBwd);
 #define BDS_BWD_ARGS                                                                                                   \
   C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, alphas,  \
-      last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities
+      last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, tile_order
 #define BDS_BWD(ch, ab)                                                                                                \
   do {                                                                                                                 \
     if (variant == 3)                                                                                                  \
@@ -792,6 +873,24 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
   }
 #undef BDS_BWD
 #undef BDS_BWD_ARGS
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int tile_w, int tile_h,
+                                          const int32_t *isect_offsets, const int32_t *last_ids, int32_t *tile_order,
+                                          bds_stream_t stream) {
+  BDS_REQUIRE(C >= 1 && W > 0 && H > 0);
+  BDS_REQUIRE(tile_size == kTile);
+  BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
+  BDS_REQUIRE(isect_offsets && last_ids && tile_order);
+  const int total = C * tile_w * tile_h;
+  hipStream_t st = as_stream(stream);
+  int32_t *work = tile_order + total;   // second half of the caller's buffer
+  constexpr int per_block = kRastBlock / kWave;
+  hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(kRastBlock), 0, st, C, W,
+                     H, tile_w, tile_h, isect_offsets, last_ids, work);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, st, total, work, tile_order);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -19,6 +19,7 @@ import torch
 from torch import Tensor
 
 from . import _lib as L
+from . import gs_ops as ops
 from .bilagrid import _levels_struct
 
 TILE = 16
@@ -140,11 +141,12 @@ class _FusedView(torch.autograd.Function):
         buf = torch.zeros(12 * N, device=dev, dtype=torch.float32)
         v_col, v_m2, v_abs, v_con, v_op = torch.split(buf, [4 * N, 2 * N, 2 * N, 3 * N, N])  # v_col first: 16-byte aligned
         opac_c = opac.view(1, N)
+        order = ops.bwd_schedule(1, W, H, TILE, tw, th, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
             L.check(lib.bds_rasterize_bwd(1, N, M, 4, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), None, W, H, TILE,
                                           tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids),
                                           L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_m2), L.ptr(v_abs), L.ptr(v_con), L.ptr(v_col),
-                                          L.ptr(v_op), st), "bds_rasterize_bwd")
+                                          L.ptr(v_op), L.ptr(order), st), "bds_rasterize_bwd")
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282 reads .absgrad)
             carrier.absgrad = v_abs.view(1, N, 2)

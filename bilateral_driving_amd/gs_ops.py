@@ -13,6 +13,7 @@ shapes) so that ``rendering.rasterization`` below them reads like the reference'
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -189,6 +190,26 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # --------------------------------------------------------------------------------------------
 # compositing
 # --------------------------------------------------------------------------------------------
+_BWD_SCHEDULE = os.environ.get("BDS_BWD_SCHEDULE", "1") != "0"
+
+
+def set_bwd_schedule(on: bool) -> None:
+    """Longest-tile-first launch order for the composite backward (include/bds.h: bds_rasterize_bwd_schedule).
+    Affects timing only.  Default on; BDS_BWD_SCHEDULE=0 turns it off."""
+    global _BWD_SCHEDULE
+    _BWD_SCHEDULE = bool(on)
+
+
+def bwd_schedule(C_: int, width: int, height: int, tile_size: int, tw: int, th: int, isect_offsets: Tensor,
+                 last_ids: Tensor) -> Optional[Tensor]:
+    if not _BWD_SCHEDULE:
+        return None
+    order = torch.empty(2 * C_ * tw * th, device=last_ids.device, dtype=torch.int32)
+    L.check(L.lib().bds_rasterize_bwd_schedule(C_, width, height, tile_size, tw, th, L.ptr(isect_offsets), L.ptr(last_ids),
+                                               L.ptr(order), L.stream()), "bds_rasterize_bwd_schedule")
+    return order
+
+
 class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect_offsets, flatten_ids,
@@ -232,12 +253,13 @@ class _RasterizeToPixels(torch.autograd.Function):
         v_conics = chunks[2].view(Cn, N, 3)
         v_colors = chunks[3].view(Cn, N, CH)
         v_opac = chunks[4].view(Cn, N)
+        order = bwd_schedule(Cn, width, height, tile_size, tw, th, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
             L.check(L.lib().bds_rasterize_bwd(Cn, N, M, CH, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities),
                                               L.ptr(backgrounds), width, height, tile_size, tw, th, L.ptr(isect_offsets),
                                               L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
                                               L.ptr(v_means2d), L.ptr(v_abs), L.ptr(v_conics), L.ptr(v_colors), L.ptr(v_opac),
-                                              L.stream()), "bds_rasterize_bwd")
+                                              L.ptr(order), L.stream()), "bds_rasterize_bwd")
         if absgrad:
             # same contract as gsplat: the tensor the caller holds in meta["means2d"] grows `.absgrad`
             # (read at /root/reference/project/models/trainers/base.py:282)

@@ -115,13 +115,21 @@ int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const float *means2d,
                       int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
                       float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
 /* Gradient outputs must be zero-filled by the caller (they are accumulated with atomics).
- * v_means2d_abs may be NULL (absgrad=False). */
+ * v_means2d_abs may be NULL (absgrad=False).  tile_order may be NULL (tiles are taken in image order, one
+ * contiguous band per XCD) or the schedule written by bds_rasterize_bwd_schedule. */
 int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
                       const float *colors, const float *opacities, const float *backgrounds, int W, int H,
                       int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
                       const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
                       float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors, float *v_opacities,
-                      bds_stream_t stream);
+                      const int32_t *tile_order, bds_stream_t stream);
+/* Launch schedule for bds_rasterize_bwd (no reference counterpart; results do not depend on it).  One wave owns a
+ * tile and the chip holds only about two rounds of tiles, so the launch ends with a tail of long tiles that started
+ * late.  After the forward pass each tile's visited length is known exactly (max last_id - list start); this call
+ * orders every XCD's contiguous range of tiles longest-first.  tile_order: int32[2 * C*tile_w*tile_h] — the first
+ * half receives the schedule, the second half is scratch. */
+int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                               const int32_t *last_ids, int32_t *tile_order, bds_stream_t stream);
 
 /* ---- bilateral grid ----------------------------------------------------------------------
  * Point slice: bilateral/lib_bilagrid.py:317-368 BilateralGrid.forward (F.grid_sample,

@@ -304,6 +304,64 @@ def test_exact_tile_culling_is_invisible(ops, seed, N, W, H):
     assert float(alpha.reshape(len(sel), -1).max(dim=1).values.max()) < 1.0 / 255.0
 
 
+@pytest.mark.parametrize("variant", [2, 3, 1], ids=["bwd_wave4px", "quad", "bwd_butterfly"])
+@pytest.mark.parametrize("seed,N,W,H,C", [(0, 4000, 320, 200, 1), (1, 20000, 640, 368, 1), (2, 1500, 100, 52, 3), (3, 30, 40, 24, 1)])
+def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C, variant):
+    """bds_rasterize_bwd_schedule: every XCD range of tiles is permuted longest-first; gradients do not depend on it."""
+    from bilateral_driving_amd import _lib as L
+    L.set_option(L.OPT_RASTER_BWD, variant)
+    sc = make_scene(N, W, H, seed=seed)
+    if C > 1:  # extra cameras: the same pose shifted sideways
+        vms = sc["viewmats"].repeat(C, 1, 1)
+        vms[:, 0, 3] += torch.arange(C, dtype=vms.dtype) * 0.3
+        sc["viewmats"], sc["Ks"] = vms, sc["Ks"].repeat(C, 1, 1)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    res = {}
+    for sched in (False, True):
+        ops.set_bwd_schedule(sched)
+        p = {k: sc[k].cuda().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+        radii, m2, d, con, _ = ops.fully_fused_projection(p["means"], p["quats"], p["scales"], sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H)
+        Cn = m2.shape[0]
+        col = p["colors"][None].expand(Cn, -1, -1).contiguous()
+        op = p["opacities"][None].expand(Cn, -1).contiguous()
+        _, _, fids, offs = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con, opacities=op)
+        r, a = ops.rasterize_to_pixels(m2, con, col, op, W, H, 16, offs, fids, absgrad=True)
+        wt = torch.randn(r.shape, generator=torch.Generator().manual_seed(seed)).cuda()
+        ((r * wt).sum() + a.sum()).backward()
+        res[sched] = {k: v.grad.clone() for k, v in p.items()}
+    ops.set_bwd_schedule(True)
+    for k in res[False]:
+        ref, got = res[False][k], res[True][k]
+        assert float((got - ref).norm() / ref.norm().clamp(min=1e-20)) < 2e-4, k  # atomics summation order differs
+    # the schedule itself
+    last = torch.zeros(Cn, H, W, dtype=torch.int32, device="cuda")
+    rr, aa = torch.empty(Cn, H, W, 3, device="cuda"), torch.empty(Cn, H, W, 1, device="cuda")
+    M = fids.numel()
+    L.check(L.lib().bds_rasterize_fwd(Cn, N, M, 3, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), None,
+                                      W, H, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa), L.ptr(last), L.stream()), "fwd")
+    order = ops.bwd_schedule(Cn, W, H, 16, tw, th, offs, last)
+    total = Cn * tw * th
+    o = order[:total].cpu().long()
+    work = order[total:].cpu().long()
+    assert torch.equal(o.sort().values, torch.arange(total))
+    Hp, Wp = th * 16, tw * 16
+    lid = torch.zeros(Cn, Hp, Wp, dtype=torch.long); lid[:, :H, :W] = last.cpu().long()
+    tmax = lid.reshape(Cn, th, 16, tw, 16).permute(0, 1, 3, 2, 4).reshape(total, 256).max(dim=1).values
+    assert torch.equal(work, (tmax - offs.reshape(-1).cpu().long() + 1).clamp(min=0))
+    per, rem = divmod(total, 8)
+    first = 0
+    for x in range(8):
+        cnt = per + (1 if x < rem else 0)
+        seg = o[first:first + cnt]
+        assert bool(((seg >= first) & (seg < first + cnt)).all())          # tiles stay inside their XCD range
+        w = work[seg]
+        shift = 0
+        while cnt and (int(work[first:first + cnt].max()) >> shift) >= 1024:
+            shift += 1
+        assert bool(((w >> shift)[:-1] >= (w >> shift)[1:]).all())           # longest first (bucket granularity)
+        first += cnt
+
+
 def test_harness_view_matches_rasterization_api(ops):
     """harness.render_view (stage ops, SH after projection with the visibility mask, culling) ==
     the reference-shaped call sequence through rasterization() + separate torch post-processing."""
