@@ -9,13 +9,14 @@ extern "C" const char *bds_strerror(int code) {
     case BDS_EINVAL: return "invalid argument (null/misaligned pointer, bad shape or unsupported parameter)";
     case BDS_EWORKSPACE: return "workspace too small";
     case BDS_ELAUNCH: return "HIP launch or copy failed";
+    case BDS_ECAPACITY: return "more intersections than the caller's buffers hold";
     default: return "unknown bds error";
   }
 }
 
 namespace bds {
 // defaults: the fastest verified variants
-static int g_options[kOptCount] = {/*raster_bwd*/ 2, /*radix*/ 1, /*raster_fwd*/ 1, 0, 0, 0, 0, 0};
+static int g_options[kOptCount] = {/*raster_bwd*/ 2, /*radix*/ 1, /*raster_fwd*/ 1, /*debug*/ 0, /*short_sort*/ 1, 0, 0, 0};
 int option_get(int which) { return (which >= 0 && which < kOptCount) ? g_options[which] : 0; }
 }  // namespace bds
 

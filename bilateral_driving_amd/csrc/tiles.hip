@@ -326,6 +326,119 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
   return BDS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// short sort: the same stable LSD pass in TWO launches, for inputs whose length lives on the device
+// ------------------------------------------------------------------------------------------
+// The depth sort of the visible entries is latency-bound (a few hundred thousand keys: every launch costs more
+// than the bytes it moves), so the scan of the [digit][workgroup] histogram is folded away: histograms are stored
+// workgroup-major, every 32 workgroups also add theirs to a group row (256 atomics per workgroup), and a scatter
+// workgroup derives its own bases from <= ng group rows + <= 31 workgroup rows (all L2-resident).
+constexpr int kGroupShift = 5;                      // 32 workgroups per group row
+constexpr int kChunkShift = 12;                     // kSortChunk == 1 << 12
+static_assert(kSortChunk == (1 << kChunkShift), "chunk shift");
+constexpr int64_t kShortSortMax = (int64_t)kSortChunk * 4096;   // <= 128 group rows
+
+__global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *__restrict__ keys,
+                                                               const uint64_t *__restrict__ n_dev, int shift,
+                                                               uint32_t *__restrict__ hist /*[nblocks][256]*/,
+                                                               uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
+  __shared__ uint32_t h[256];
+  const int64_t n = (int64_t)*n_dev;
+  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+  if (base >= n) return;  // the launch is sized for the host-side bound
+  h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = base + r * kSortBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = h[threadIdx.x];
+  hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
+  if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kGroupShift) * 256 + threadIdx.x], c);
+}
+
+// wave-private ranking as in radix_scatter_wave_kernel; bases from the group / workgroup rows
+__global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int shift,
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out) {
+  const int64_t n = (int64_t)*n_dev;
+  if ((int64_t)blockIdx.x * kSortChunk >= n) return;
+  __shared__ uint32_t wrun[kSortWaves][256];
+  __shared__ uint32_t lw[kSortBlock / kWave + 1];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
+  // digit `tid`: elements of this digit in front of this workgroup, and in the whole input
+  const int nb = (int)((n + kSortChunk - 1) >> kChunkShift), ng = (nb + (1 << kGroupShift) - 1) >> kGroupShift;
+  const int gb = (int)blockIdx.x >> kGroupShift;
+  uint32_t below = 0, total = 0;
+  for (int g = 0; g < ng; g++) {
+    const uint32_t c = ghist[(int64_t)g * 256 + tid];
+    total += c;
+    if (g < gb) below += c;
+  }
+  for (int b = gb << kGroupShift; b < (int)blockIdx.x; b++) below += hist[(int64_t)b * 256 + tid];
+  uint32_t all;
+  const uint32_t digit_base = block_excl_scan(total, all, lw);   // (contains the barrier that publishes wrun = 0)
+  constexpr int kPerWave = kSortChunk / kSortWaves;
+  const int64_t wbase = (int64_t)blockIdx.x * kSortChunk + (int64_t)wv * kPerWave;
+  uint32_t k[kSortRounds], v[kSortRounds];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    k[r] = 0xFFFFFFFFu; v[r] = 0;
+    if (i < n) {
+      k[r] = keys_in[i]; v[r] = vals_in[i];
+      atomicAdd(&wrun[wv][(k[r] >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t base = digit_base + below;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+      const uint32_t c = wrun[w][tid];
+      wrun[w][tid] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    const bool on = i < n;
+    const uint32_t d = (k[r] >> shift) & 255u;
+    unsigned long long peers = __ballot(on);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt);
+    uint32_t pos = 0;
+    if (on) pos = wrun[wv][d];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (on) {
+      keys_out[pos + rank] = k[r];
+      vals_out[pos + rank] = v[r];
+    }
+  }
+}
+
+// uint32 elements: one workgroup-major histogram + four zero-initialised group tables
+static size_t short_sort_elems(int64_t n_bound) {
+  const int64_t nb = cdiv(n_bound > 0 ? n_bound : 1, kSortChunk), ng = cdiv(nb, 1 << kGroupShift);
+  return (size_t)(nb + 4 * ng) * 256;
+}
+
 // ------------------------------------------------------------------------------------------
 // intersection kernels
 // ------------------------------------------------------------------------------------------
@@ -352,18 +465,83 @@ __global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, 
   vals[j] = (uint32_t)o;
 }
 
-// number of tiles touched by each visible entry (tiles_per_gauss was zero-filled)
-__global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(const uint64_t *__restrict__ n_vis_dev,
-                                                                 const uint32_t *__restrict__ vis_idx,
-                                                                 const float *__restrict__ means2d,
-                                                                 const int32_t *__restrict__ radii,
-                                                                 const float *__restrict__ conics,
-                                                                 const float *__restrict__ opacities, int tile_size,
-                                                                 int tile_w, int tile_h,
-                                                                 int32_t *__restrict__ tiles_per_gauss) {
+// ---- short path (C*N <= kShortSortMax): compaction fused with its scan and with the first histogram --------
+// visible_reduce: visible entries per 2048-entry tile; also clears the tables the later launches add into.
+__global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, const int32_t *__restrict__ radii,
+                                                                   uint32_t *__restrict__ tile_sums,
+                                                                   uint32_t *__restrict__ zero_me, int64_t zero_elems) {
+  __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < zero_elems; i += (int64_t)gridDim.x * kScanBlock)
+    zero_me[i] = 0u;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++)
+    if (base + i < CN) s += radii[base + i] > 0 ? 1u : 0u;
+  uint32_t tot;
+  block_excl_scan(s, tot, lw);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// visible_compact: (depth bits, cam*N+g) of the visible entries in index order; the histogram of the first
+// sort digit is accumulated on the way (a tile's outputs fall into at most two sort chunks).
+__global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN, const int32_t *__restrict__ radii,
+                                                                    const float *__restrict__ depths,
+                                                                    const uint32_t *__restrict__ tile_sums,
+                                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                                    uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
+                                                                    uint64_t *__restrict__ n_vis_out) {
+  static_assert(kScanTile <= kSortChunk, "a tile may straddle at most two sort chunks");
+  __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  __shared__ uint32_t h[2][256];
+  h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+  uint32_t part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kScanBlock) part += tile_sums[b];
+  uint32_t my_offset;
+  block_excl_scan(part, my_offset, lw);   // total of the partial sums = this tile's offset
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  bool vis[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    vis[i] = base + i < CN && radii[base + i] > 0;
+    s += vis[i] ? 1u : 0u;
+  }
+  uint32_t tot;
+  uint32_t j = block_excl_scan(s, tot, lw) + my_offset;
+  const uint32_t chunk0 = my_offset >> kChunkShift;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (vis[i]) {
+      const uint32_t key = __float_as_uint(depths[base + i]);
+      keys[j] = key;
+      vals[j] = (uint32_t)(base + i);
+      atomicAdd(&h[(j >> kChunkShift) - chunk0][key & 255u], 1u);
+      j++;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const uint32_t c = h[t][threadIdx.x];
+    if (c) {
+      atomicAdd(&hist[(int64_t)(chunk0 + t) * 256 + threadIdx.x], c);
+      atomicAdd(&ghist[(int64_t)((chunk0 + t) >> kGroupShift) * 256 + threadIdx.x], c);
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_vis_out = (uint64_t)my_offset + tot;
+}
+
+// tiles touched by each visible entry, visited in depth order: cnt_sorted[j] feeds the scan that places every
+// entry's run of intersections (zero beyond the visible count), tiles_per_gauss[o] (optional, pre-zeroed) is the API output.
+__global__ __launch_bounds__(kIsectBlock) void isect_count_sorted_kernel(
+    int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
+    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted) {
   const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  if (j >= (int64_t)*n_vis_dev) return;
-  const int64_t o = vis_idx[j];
+  if (j >= CN) return;
+  if (j >= (int64_t)*n_vis_dev) { cnt_sorted[j] = 0u; return; }
+  const int64_t o = sorted_idx[j];
   const int r = radii[o];
   int cnt = 0;
   int x0, y0, x1, y1;
@@ -382,17 +560,8 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_kernel(const uint64_t
       }
     }
   }
-  tiles_per_gauss[o] = cnt;
-}
-
-// counts in depth order (zero beyond the visible count, so that the scan can run over the upper bound)
-__global__ __launch_bounds__(kIsectBlock) void gather_counts_kernel(int64_t CN, const uint64_t *__restrict__ n_vis_dev,
-                                                                   const uint32_t *__restrict__ sorted_idx,
-                                                                   const int32_t *__restrict__ tiles_per_gauss,
-                                                                   uint32_t *__restrict__ cnt_sorted) {
-  const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  if (j >= CN) return;
-  cnt_sorted[j] = j < (int64_t)*n_vis_dev ? (uint32_t)tiles_per_gauss[sorted_idx[j]] : 0u;
+  cnt_sorted[j] = (uint32_t)cnt;
+  if (tiles_per_gauss) tiles_per_gauss[o] = cnt;
 }
 
 // emit (camera*tiles + tile, cam*N+gaussian) pairs in depth order
@@ -467,6 +636,7 @@ struct PrepWs {
   uint32_t *ka, *va, *kb, *vb;  // [CN] each; after prepare: sorted ids live in `sorted`
   uint32_t *cum;        // [CN] exclusive scan of counts in depth order
   uint32_t *temp;       // radix / scan temp
+  uint32_t *tables;     // short path: workgroup-major histogram + 4 group tables
   size_t bytes;
 };
 
@@ -488,6 +658,7 @@ static PrepWs prep_layout(void *ws, int64_t CN) {
   size_t t = radix_temp_elems(CN);
   size_t t2 = scan_temp_elems(CN);
   L.temp = reinterpret_cast<uint32_t *>(take(t > t2 ? t : t2, 4));
+  L.tables = reinterpret_cast<uint32_t *>(take(CN <= kShortSortMax ? short_sort_elems(CN) : 0, 4));
   L.bytes = off;
   return L;
 }
@@ -540,37 +711,66 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   BDS_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)1 << 31);
   *n_isects = 0;
   if (CN == 0) return BDS_OK;
-  BDS_REQUIRE(means2d && radii && depths && tiles_per_gauss && ws);
+  BDS_REQUIRE(means2d && radii && depths && ws);
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
   PrepWs L = prep_layout(ws, CN);
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const unsigned grid = (unsigned)cdiv(CN, kIsectBlock);
-  // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
   uint64_t *n_vis = L.total + 1;
-  hipLaunchKernelGGL(isect_flag_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.kb);
-  BDS_LAUNCH_CHECK();
-  int rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, n_vis, st);
-  if (rc != BDS_OK) return rc;
-  hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va);
-  BDS_LAUNCH_CHECK();
-  // 2. tiles per visible entry
-  if (hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
-  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(kIsectBlock), 0, st, n_vis, L.va, means2d, radii, conics, opacities,
-                     tile_size, tile_w, tile_h, tiles_per_gauss);
-  BDS_LAUNCH_CHECK();
-  // 3. depth order: 4 stable passes of 8 bits over the visible entries; ends in (ka, va)
-  uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
-  for (int p = 0; p < 4; p++) {
-    rc = radix_pass(kin, vin, kout, vout, CN, 8 * p, 8, L.temp, st, n_vis);
+  int rc;
+  if (CN <= kShortSortMax && option_get(kOptShortSort)) {
+    // 12 launches instead of 27: the whole stage is launch-latency bound at this size
+    const int64_t nb = cdiv(CN, kSortChunk), ng = cdiv(nb, 1 << kGroupShift);
+    uint32_t *hist = L.tables, *ghist = L.tables + nb * 256;   // ghist[p] = ghist + p * ng * 256
+    const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
+    // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
+    hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
+                       (int64_t)short_sort_elems(CN));
+    hipLaunchKernelGGL(visible_compact_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, depths, L.temp, L.ka, L.va, hist,
+                       ghist, n_vis);
+    BDS_LAUNCH_CHECK();
+    // 2. depth order: 4 stable passes of 8 bits; ends in (ka, va)
+    uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
+    for (int p = 0; p < 4; p++) {
+      uint32_t *gh = ghist + (int64_t)p * ng * 256;
+      if (p > 0) hipLaunchKernelGGL(short_hist_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, n_vis, 8 * p, hist, gh);
+      hipLaunchKernelGGL(short_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, vin, n_vis, 8 * p, hist, gh, kout,
+                         vout);
+      uint32_t *t;
+      t = kin; kin = kout; kout = t;
+      t = vin; vin = vout; vout = t;
+    }
+    BDS_LAUNCH_CHECK();
+    // 3. tiles per entry, in depth order
+    if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
+    hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+    BDS_LAUNCH_CHECK();
+  } else {
+    // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
+    hipLaunchKernelGGL(isect_flag_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.kb);
+    BDS_LAUNCH_CHECK();
+    rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, n_vis, st);
     if (rc != BDS_OK) return rc;
-    uint32_t *t;
-    t = kin; kin = kout; kout = t;
-    t = vin; vin = vout; vout = t;
+    hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va);
+    BDS_LAUNCH_CHECK();
+    // 2. depth order: 4 stable passes of 8 bits over the visible entries; ends in (ka, va)
+    uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
+    for (int p = 0; p < 4; p++) {
+      rc = radix_pass(kin, vin, kout, vout, CN, 8 * p, 8, L.temp, st, n_vis);
+      if (rc != BDS_OK) return rc;
+      uint32_t *t;
+      t = kin; kin = kout; kout = t;
+      t = vin; vin = vout; vout = t;
+    }
+    // 3. tiles per entry, in depth order
+    if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
+    hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+    BDS_LAUNCH_CHECK();
   }
-  // 4. counts in depth order -> exclusive scan (offsets of every entry's run) and the total M
-  hipLaunchKernelGGL(gather_counts_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, tiles_per_gauss, L.kb);
-  BDS_LAUNCH_CHECK();
+  // 4. exclusive scan of the counts (offset of every entry's run) and the total M
   rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
   if (rc != BDS_OK) return rc;
   uint64_t total = 0;
@@ -633,4 +833,19 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d
     BDS_LAUNCH_CHECK();
   }
   return BDS_OK;
+}
+
+extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                               const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                               int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, void *ws2, size_t ws2_bytes,
+                               int64_t flatten_capacity, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
+                               int64_t *n_isects, bds_stream_t stream) {
+  BDS_REQUIRE(flatten_capacity >= 0 && n_isects);
+  int rc = bds_isect_prepare(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws,
+                             ws_bytes, n_isects, stream);
+  if (rc != BDS_OK) return rc;
+  const int64_t M = *n_isects;
+  if (M > flatten_capacity || (M > 0 && ws2_bytes < build_layout(nullptr, M).bytes)) return BDS_ECAPACITY;
+  return bds_isect_build(C, N, M, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws, ws_bytes, ws2,
+                         ws2_bytes, isect_ids, flatten_ids, isect_offsets, stream);
 }

@@ -29,6 +29,9 @@ def _empty(shape, dev, dtype=torch.float32):
     return torch.empty(shape, device=dev, dtype=dtype)
 
 
+_LIST_CAPACITY: Dict[tuple, int] = {}   # (N, W, H, culling) -> entries to provision for the intersection lists
+
+
 class _FusedView(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, *grids):
@@ -66,19 +69,40 @@ class _FusedView(torch.autograd.Function):
         ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
         ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
         m = C.c_int64(0)
-        with L.timed("isect_prepare"):
-            L.check(lib.bds_isect_prepare(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics) if cull else None,
-                                          L.ptr(opac_c) if cull else None, TILE, tw, th, L.ptr(tiles_per_gauss), L.ptr(ws),
-                                          ws_bytes, C.byref(m), st), "bds_isect_prepare")
-        M = int(m.value)
-        flatten_ids = _empty((M,), dev, torch.int32)
         isect_offsets = _empty((1, th, tw), dev, torch.int32)
-        ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
-        ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-        with L.timed("isect_build"):
-            L.check(lib.bds_isect_build(1, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics) if cull else None,
-                                        L.ptr(opac_c) if cull else None, TILE, tw, th, L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes,
-                                        None, L.ptr(flatten_ids), L.ptr(isect_offsets), st), "bds_isect_build")
+        cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
+        # Buffers for the lists are sized from the largest count this configuration has produced so far, so that the
+        # library can go from counting to building without handing control back (the GPU idles during that hand-over).
+        key = (N, W, H, bool(cull))
+        cap = _LIST_CAPACITY.get(key, 0)
+        flatten_ids = None
+        if cap:
+            buf = _empty((cap,), dev, torch.int32)
+            ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
+            ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
+            with L.timed("isect_tiles"):
+                rc = lib.bds_isect_tiles(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
+                                         L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, cap, None, L.ptr(buf),
+                                         L.ptr(isect_offsets), C.byref(m), st)
+            if rc != L.ECAPACITY:
+                L.check(rc, "bds_isect_tiles")
+                flatten_ids = buf[:int(m.value)]
+            del buf
+        else:
+            with L.timed("isect_prepare"):
+                L.check(lib.bds_isect_prepare(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
+                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), st), "bds_isect_prepare")
+        M = int(m.value)
+        if flatten_ids is None:  # first call of this configuration, or the lists outgrew the expectation
+            flatten_ids = _empty((M,), dev, torch.int32)
+            ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
+            ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
+            with L.timed("isect_build"):
+                L.check(lib.bds_isect_build(1, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
+                                            ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten_ids), L.ptr(isect_offsets), st),
+                        "bds_isect_build")
+        if M + M // 16 > cap:
+            _LIST_CAPACITY[key] = M + M // 6 + 4096
         del ws, ws2
         # compositing (RGB + depth)
         render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)

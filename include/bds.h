@@ -31,6 +31,7 @@ extern "C" {
 #define BDS_EINVAL (-1)      /* null / misaligned pointer, bad shape or unsupported parameter */
 #define BDS_EWORKSPACE (-2)  /* workspace too small */
 #define BDS_ELAUNCH (-3)     /* hipGetLastError() != hipSuccess after a launch / memcpy */
+#define BDS_ECAPACITY (-4)   /* bds_isect_tiles: more intersections than the caller's buffers hold (see there) */
 
 typedef void *bds_stream_t;
 
@@ -43,7 +44,9 @@ const char *bds_strerror(int code);
  * 3: one wave/tile, 4 pixels/lane (8x8 quadrants, per-Gaussian quadrant masks));
  * 1 = radix pass (0: block-synchronous ranking; 1: wave-private ranking [default]);
  * 2 = composite forward (0: 4 waves/tile, 1 pixel/lane; 1: one wave/tile, 4 pixels/lane (row strips);
- *     2: one wave/tile, quadrant-masked).  Defaults: see csrc/api.hip. */
+ *     2: one wave/tile, quadrant-masked);
+ * 4 = depth ordering of the visible entries (1: two-launch radix passes with workgroup-derived bases, compaction
+ *     fused with its scan [default]; 0: generic histogram / scan / scatter passes).  Defaults: see csrc/api.hip. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 
@@ -95,7 +98,8 @@ size_t bds_isect_prepare_workspace_bytes(int C, int64_t N);
 size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M);
 /* conics [C,N,3] + opacities [C,N] (both or neither): when given, (tile, Gaussian) pairs in which no
  * pixel centre can reach alpha >= 1/255 are dropped ("exact tile culling"): rendered images and
- * gradients are unchanged, M shrinks; when NULL the lists are gsplat's bounding-square lists. */
+ * gradients are unchanged, M shrinks; when NULL the lists are gsplat's bounding-square lists.
+ * tiles_per_gauss [C,N] i32 may be NULL (the per-Gaussian counts are then not written). */
 int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                       const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                       int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *n_isects, bds_stream_t stream);
@@ -104,6 +108,17 @@ int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int
                     size_t ws_bytes, void *ws2,
                     size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
                     bds_stream_t stream);
+/* One-call form: bds_isect_prepare and then, without returning to the caller in between, bds_isect_build into
+ * buffers sized for an EXPECTED count (flatten_ids / isect_ids hold flatten_capacity entries, ws2 is
+ * bds_isect_build_workspace_bytes(C, N, flatten_capacity)).  M <= flatten_capacity: BDS_OK, *n_isects = M, lists
+ * written (entries [M, capacity) untouched).  Otherwise BDS_ECAPACITY, *n_isects = M, nothing built: allocate for M
+ * and call bds_isect_build (ws is intact).  Saves the host's allocation work between the two stages, during which
+ * the GPU idles. */
+int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                    const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                    int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, void *ws2, size_t ws2_bytes,
+                    int64_t flatten_capacity, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
+                    int64_t *n_isects, bds_stream_t stream);
 
 /* ---- alpha compositing -------------------------------------------------------------------
  * rasterize_to_pixels stage of gsplat.rendering.rasterization; outputs consumed at

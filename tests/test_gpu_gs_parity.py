@@ -135,6 +135,68 @@ def test_isect_bit_exact(ops, seed, N, W, H, C, radix):
     assert torch.equal(offs.cpu(), ref_off)
 
 
+def test_isect_tiles_one_call_and_capacity(ops):
+    """bds_isect_tiles == prepare + build when the caller's buffers are large enough; BDS_ECAPACITY (and M) otherwise."""
+    import ctypes as C
+    from bilateral_driving_amd import _lib as L
+    N, W, H = 6000, 400, 240
+    sc = make_scene(N, W, H, seed=5)
+    radii, m2, d, con, _ = ops.fully_fused_projection(sc["means"].cuda(), sc["quats"].cuda(), sc["scales"].cuda(), sc["viewmats"].cuda(),
+                                                      sc["Ks"].cuda(), W, H)
+    op = sc["opacities"].cuda()[None].contiguous()
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    tpg_ref, iids_ref, fids_ref, offs_ref = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con, opacities=op)
+    M = fids_ref.numel()
+    lib = L.lib()
+    ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
+    for cap, expect_ok in ((M, True), (M + 1000, True), (M - 1, False), (0, False)):
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
+        ws2 = torch.empty(max(ws2_bytes, 16), dtype=torch.uint8, device="cuda")
+        fids = torch.full((max(cap, 1),), -7, dtype=torch.int32, device="cuda")
+        iids = torch.full((max(cap, 1),), -7, dtype=torch.int64, device="cuda")
+        offs = torch.full((1, th, tw), -7, dtype=torch.int32, device="cuda")
+        tpg = torch.empty(1, N, dtype=torch.int32, device="cuda")
+        m = C.c_int64(-1)
+        rc = lib.bds_isect_tiles(1, N, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th, L.ptr(tpg),
+                                 L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, cap, L.ptr(iids), L.ptr(fids), L.ptr(offs), C.byref(m),
+                                 L.stream())
+        torch.cuda.synchronize()
+        assert m.value == M
+        assert torch.equal(tpg, tpg_ref)
+        if expect_ok:
+            assert rc == 0
+            assert torch.equal(fids[:M], fids_ref) and torch.equal(iids[:M], iids_ref) and torch.equal(offs, offs_ref)
+            assert bool((fids[M:] == -7).all())
+        else:
+            assert rc == L.ECAPACITY
+            assert bool((fids == -7).all()) and bool((offs == -7).all())   # nothing built
+            # the prepared workspace is intact: the two-call continuation gives the reference lists
+            ws2b = torch.empty(max(lib.bds_isect_build_workspace_bytes(1, N, M), 16), dtype=torch.uint8, device="cuda")
+            fids2 = torch.empty(M, dtype=torch.int32, device="cuda")
+            L.check(lib.bds_isect_build(1, N, M, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
+                                        L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(fids2), L.ptr(offs), L.stream()), "build")
+            assert torch.equal(fids2, fids_ref) and torch.equal(offs, offs_ref)
+
+
+@pytest.mark.parametrize("short", [1, 0], ids=["short_sort", "generic_sort"])
+def test_isect_short_sort_option(ops, short):
+    """Both depth-ordering paths give the oracle's lists (the default path is covered by test_isect_bit_exact)."""
+    from bilateral_driving_amd import _lib as L
+    L.set_option(L.OPT_SHORT_SORT, short)
+    try:
+        for seed, N, W, H in ((0, 9000, 320, 200), (1, 70000, 640, 368)):
+            sc = make_scene(N, W, H, seed=seed)
+            radii, m2, d, con, _ = ops.fully_fused_projection(sc["means"].cuda(), sc["quats"].cuda(), sc["scales"].cuda(),
+                                                              sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H)
+            tw, th = (W + 15) // 16, (H + 15) // 16
+            tpg, iids, fids, offs = ops.isect_tiles(m2, radii, d, 16, tw, th)
+            tpg_o, iids_o, fids_o = G.isect_tiles(m2[0].cpu(), radii[0].cpu(), d[0].cpu(), 16, tw, th)
+            assert torch.equal(tpg[0].cpu(), tpg_o) and torch.equal(iids.cpu(), iids_o) and torch.equal(fids.cpu(), fids_o)
+    finally:
+        L.set_option(L.OPT_SHORT_SORT, 1)
+
+
 def test_meta_isect_ids_lazy_equals_kernel(ops):
     import bilateral_driving_amd.rendering as R
     sc = make_scene(3000, 200, 120, seed=9)
