@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbds.so")
 SOURCES = ["api.hip", "sh.hip", "project.hip", "tiles.hip", "rasterize.hip", "bilagrid.hip", "glue.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast-honor-pragmas", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -340,6 +340,7 @@ BDS_HD void project_one_vjp(const float *mean, const float *quat, const float *s
 // ------------------------------------------------------------------------------------------
 BDS_HD void tile_rect(float mx, float my, int radius, int tile_size, int tile_w, int tile_h, int &x0, int &y0, int &x1,
                       int &y1) {
+#pragma clang fp contract(off)  // the counting and the emitting kernel must take IDENTICAL integer decisions: no context-dependent fusing
   float ts = (float)tile_size;
   float tr = (float)radius / ts;
   float txf = mx / ts, tyf = my / ts;
@@ -391,6 +392,7 @@ BDS_HD bool rect_hits_ellipse(float mx, float my, float a, float b, float c, flo
 // bounding box of the tau-ellipse (pixel-centre convention).  Returns false if nothing is left.
 BDS_HD bool tile_rect_tight(float mx, float my, int radius, float a, float b, float c, float opacity, int tile_size,
                             int tile_w, int tile_h, int &x0, int &y0, int &x1, int &y1, float &q_max) {
+#pragma clang fp contract(off)  // the counting and the emitting kernel must take IDENTICAL integer decisions: no context-dependent fusing
   tile_rect(mx, my, radius, tile_size, tile_w, tile_h, x0, y0, x1, y1);
   const float tau = cull_tau(opacity);
   const float det = a * c - b * b;
@@ -413,6 +415,7 @@ BDS_HD bool tile_rect_tight(float mx, float my, int radius, float a, float b, fl
 constexpr float kSpanSlack = 0.02f;
 BDS_HD void row_tile_span(float mx, float my, float a, float b, float c, float q_max, int ty, int tile_size, int x0,
                           int x1, int &tx_lo, int &tx_hi) {
+#pragma clang fp contract(off)  // the counting and the emitting kernel must take IDENTICAL integer decisions: no context-dependent fusing
   tx_lo = tx_hi = x0;
   const float ts = (float)tile_size;
   const float det = a * c - b * b;

@@ -298,6 +298,85 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
   }
 }
 
+
+// Variant 2: wave-private ranking as above, but the workgroup's 4096 pairs are first ordered by digit in LDS and then
+// written out by consecutive threads: a digit's run leaves as whole cache lines (4096 / 2^bits pairs at a time)
+// instead of the 8-pair fragments of one wave round.  Pays on the long tile passes, where the scatter is write-bound.
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
+    const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+  const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
+  if (bbase >= n) return;
+  __shared__ uint32_t wrun[kSortWaves][256];  // next LOCAL position per (wave, digit)
+  __shared__ uint32_t dstart[256], gbase[256];
+  __shared__ uint32_t lw[kSortBlock / kWave + 1];
+  __shared__ uint32_t lk[kSortChunk], lv[kSortChunk];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
+  __syncthreads();
+  constexpr int kPerWave = kSortChunk / kSortWaves;
+  const int64_t wbase = bbase + (int64_t)wv * kPerWave;
+  uint32_t k[kSortRounds], v[kSortRounds];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    k[r] = 0xFFFFFFFFu; v[r] = 0;
+    if (i < n) {
+      k[r] = keys_in[i]; v[r] = vals_in[i];
+      atomicAdd(&wrun[wv][(k[r] >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) tot += wrun[w][tid];
+    uint32_t all;
+    uint32_t base = block_excl_scan(tot, all, lw);
+    dstart[tid] = base;
+    gbase[tid] = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+      const uint32_t c = wrun[w][tid];
+      wrun[w][tid] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    const bool on = i < n;
+    const uint32_t d = (k[r] >> shift) & mask;
+    unsigned long long peers = __ballot(on);
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt);
+    uint32_t pos = 0;
+    if (on) pos = wrun[wv][d];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (on) { lk[pos + rank] = k[r]; lv[pos + rank] = v[r]; }
+  }
+  __syncthreads();
+  const int cnt = (int)((n - bbase) < (int64_t)kSortChunk ? (n - bbase) : (int64_t)kSortChunk);
+  for (int i = tid; i < cnt; i += kSortBlock) {
+    const uint32_t kk = lk[i];
+    const uint32_t d = (kk >> shift) & mask;
+    const uint32_t g = gbase[d] + ((uint32_t)i - dstart[d]);
+    keys_out[g] = kk;
+    vals_out[g] = lv[i];
+  }
+}
+
 static size_t radix_temp_elems(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
   const size_t h = align_up((size_t)256 * nblocks, 4);
@@ -316,7 +395,10 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
-  if (option_get(kOptRadix) == 1)
+  if (option_get(kOptRadix) == 2)
+    hipLaunchKernelGGL(radix_scatter_lds_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
+                       nblocks, hist, kout, vout);
+  else if (option_get(kOptRadix) == 1)
     hipLaunchKernelGGL(radix_scatter_wave_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
                        nblocks, hist, kout, vout);
   else
@@ -606,6 +688,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(const uint64_t 
     }
   }
 }
+
 
 // offsets[t] = first index whose key >= t  (lower bound; empty tiles point at the next run)
 __global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M, const uint32_t *__restrict__ keys,

@@ -42,7 +42,8 @@ const char *bds_strerror(int code);
  * summation order).  which: 0 = composite backward (0: per-value DPP reduce, 4 waves/tile;
  * 1: 16-value transpose-reduce, 4 waves/tile; 2: one wave/tile, 4 pixels/lane (row strips);
  * 3: one wave/tile, 4 pixels/lane (8x8 quadrants, per-Gaussian quadrant masks));
- * 1 = radix pass (0: block-synchronous ranking; 1: wave-private ranking [default]);
+ * 1 = radix pass (0: block-synchronous ranking; 1: wave-private ranking; 2: wave-private ranking + digit-ordered
+ *     write-out through LDS [default]);
  * 2 = composite forward (0: 4 waves/tile, 1 pixel/lane; 1: one wave/tile, 4 pixels/lane (row strips);
  *     2: one wave/tile, quadrant-masked);
  * 4 = depth ordering of the visible entries (1: two-launch radix passes with workgroup-derived bases, compaction

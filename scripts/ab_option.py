@@ -1,7 +1,11 @@
-import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+#!/usr/bin/env python3
+"""Interleaved A/B of one bds_set_option switch on the benchmark step:  ab_option.py <which> <value_a> <value_b> [timer]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bilateral_driving_amd import _lib as L, harness as Hn
+which, va, vb = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+tname = sys.argv[4] if len(sys.argv) > 4 else "isect_tiles"
 dev = torch.device("cuda", 0)
 W, H, N = 1920, 1080, 2_000_000
 cams = Hn.ring_cameras(W, H, device=dev)
@@ -14,17 +18,16 @@ def step(i):
     v = i % len(cams)
     o = Hn.render_view(params, cams[v], grids, v, sky)
     Hn.training_loss(o, target, grids).backward()
-    return o
 for i in range(6): step(i)
-res = {0: [], 1: []}
+res = {va: [], vb: []}
 for rnd in range(4):
-    for on in (0, 1):
-        L.set_option(4, on)
+    for val in (va, vb):
+        L.set_option(which, val)
         L.enable_timers(True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(12): step(i)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 12 * 1e3
         ts = L.timer_summary(); L.enable_timers(False)
-        res[on].append((dt, ts["isect_prepare"][1]))
-for on in (0, 1):
-    print("short_sort", on, " step ms:", " ".join(f"{a:.3f}" for a, _ in res[on]), "  isect_prepare ms:", " ".join(f"{b:.4f}" for _, b in res[on]))
+        res[val].append((dt, ts[tname][1]))
+for val in (va, vb):
+    print(f"option {which} = {val}  step ms:", " ".join(f"{a:.3f}" for a, _ in res[val]), f"  {tname} ms:", " ".join(f"{b:.4f}" for _, b in res[val]))

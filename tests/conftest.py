@@ -27,7 +27,7 @@ def _reset_kernel_variants():
         from bilateral_driving_amd import _lib
         if _lib._lib is not None:
             _lib.set_option(_lib.OPT_RASTER_BWD, 2)
-            _lib.set_option(_lib.OPT_RADIX, 1)
+            _lib.set_option(_lib.OPT_RADIX, 2)
             _lib.set_option(_lib.OPT_RASTER_FWD, 1)
     except Exception:
         pass

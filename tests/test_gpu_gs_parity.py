@@ -105,7 +105,7 @@ def test_projection_multi_camera(ops):
         assert float(tot[k].abs().max()) < 1e-3 * float(leaves[k].grad.abs().max())
 
 
-@pytest.mark.parametrize("radix", [1, 0], ids=["radix_wave", "radix_block"])
+@pytest.mark.parametrize("radix", [2, 1, 0], ids=["radix_lds", "radix_wave", "radix_block"])
 @pytest.mark.parametrize("seed,N,W,H,C", [(0, 2000, 256, 256, 1), (1, 20000, 640, 368, 1), (2, 3000, 200, 120, 3), (3, 10, 64, 64, 1),
                                           (4, 150000, 1920, 1080, 1)])
 def test_isect_bit_exact(ops, seed, N, W, H, C, radix):
