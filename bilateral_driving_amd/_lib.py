@@ -46,6 +46,10 @@ _SIGS = {
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
                                _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_project_view_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_sh_view_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
@@ -53,10 +57,6 @@ _SIGS = {
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
     "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),
     "bds_bilagrid_tv_bwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f, _f]),
-    "bds_activate_fwd": (_i, [_i64, _f, _f, _f, _f, _f]),
-    "bds_activate_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_colors_pack_fwd": (_i, [_i64, _f, _f, _f, _f]),
-    "bds_colors_pack_bwd": (_i, [_i64, _f, _f, _f, _f, _f]),
     "bds_render_unpack_fwd": (_i, [_i64, _f, _f, _f, _f, _f]),
     "bds_render_unpack_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
 }

@@ -172,14 +172,14 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, cons
   const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
   float r, g, b;
   load_input(p, i, j, r, g, b);
+  float A[NL][12];   // each level's up-sampled 3x4 map, kept for the way back (one gather of the low-res taps, not two)
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     if (l < p.nlevels) {
       float *P = p.lv[l].P + pix * 3;
       P[0] = r; P[1] = g; P[2] = b;
-      float A[12];
-      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
-      apply_affine(A, r, g, b);
+      upsample_affine(p.lv[l], p.H, p.W, i, j, A[l]);
+      apply_affine(A[l], r, g, b);
     }
   }
   float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
@@ -188,11 +188,9 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, cons
     if (l < p.nlevels) {
       float *Q = p.lv[l].Q + pix * 3;
       Q[0] = v0; Q[1] = v1; Q[2] = v2;
-      float A[12];
-      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
-      const float n0 = A[0] * v0 + A[4] * v1 + A[8] * v2;
-      const float n1 = A[1] * v0 + A[5] * v1 + A[9] * v2;
-      const float n2 = A[2] * v0 + A[6] * v1 + A[10] * v2;
+      const float n0 = A[l][0] * v0 + A[l][4] * v1 + A[l][8] * v2;
+      const float n1 = A[l][1] * v0 + A[l][5] * v1 + A[l][9] * v2;
+      const float n2 = A[l][2] * v0 + A[l][6] * v1 + A[l][10] * v2;
       v0 = n0; v1 = n1; v2 = n2;
     }
   }

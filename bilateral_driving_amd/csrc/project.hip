@@ -91,6 +91,64 @@ __global__ __launch_bounds__(kProjBlock) void project_bwd_kernel(
   }
 }
 
+// ---- one-view variants for the fused training step: activations folded in --------------------------------
+// scales = exp(log_scales), opacities = sigmoid(logits) (models/gaussians/vanilla.py:393-394) are produced by the
+// projection itself (they are also outputs: the compositor and the backward need them), and the backward returns
+// the gradients of the RAW parameters.  A culled Gaussian reads only its radius and writes zeros.
+__global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
+    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ log_scales,
+    const float *__restrict__ logits, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
+    float eps2d, float near_plane, float far_plane, float radius_clip, float *__restrict__ scales,
+    float *__restrict__ opacities, int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
+    float *__restrict__ conics) {
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  if (g >= N) return;
+  float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
+  float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+  float s[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    s[k] = expf(log_scales[g * 3 + k]);
+    scales[g * 3 + k] = s[k];
+  }
+  opacities[g] = 1.f / (1.f + expf(-logits[g]));
+  Camera cam = load_camera(viewmat, K);
+  Proj p = project_one(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
+  radii[g] = p.radius;
+  means2d[g * 2] = p.mx; means2d[g * 2 + 1] = p.my;
+  depths[g] = p.depth;
+  conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
+}
+
+__global__ __launch_bounds__(kProjBlock) void project_view_bwd_kernel(
+    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
+    float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
+    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits) {
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  if (g >= N) return;
+  float am[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, as[3] = {0, 0, 0}, al = 0.f;
+  if (radii[g] > 0) {
+    const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
+    const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+    const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
+    Camera cam = load_camera(viewmat, K);
+    ProjGrad pg;
+    for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
+    for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
+    project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[g * 2], v_means2d[g * 2 + 1], v_depths[g], v_conics[g * 3],
+                    v_conics[g * 3 + 1], v_conics[g * 3 + 2], pg);
+    for (int i = 0; i < 3; i++) { am[i] = pg.v_mean[i]; as[i] = pg.v_scale[i] * s[i]; }
+    for (int i = 0; i < 4; i++) aq[i] = pg.v_quat[i];
+    const float o = opacities[g];
+    al = v_opacities[g] * o * (1.f - o);
+  }
+  for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = am[i]; v_log_scales[g * 3 + i] = as[i]; }
+  for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = aq[i];
+  v_logits[g] = al;
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -127,6 +185,37 @@ extern "C" int bds_project_bwd(int C, int64_t N, const float *means, const float
   hipLaunchKernelGGL(project_bwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), C, N,
                      means, quats, scales, viewmats, Ks, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_means,
                      v_quats, v_scales, v_viewmats);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                    const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                    float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                    int32_t *radii, float *means2d, float *depths, float *conics, bds_stream_t stream) {
+  BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && quats && log_scales && logits && viewmat && K && scales && opacities && radii && means2d && depths &&
+              conics);
+  hipLaunchKernelGGL(project_view_fwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
+                     means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
+                     opacities, radii, means2d, depths, conics);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_project_view_bwd(int64_t N, const float *means, const float *quats, const float *scales,
+                                    const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                    const int32_t *radii, const float *v_means2d, const float *v_depths, const float *v_conics,
+                                    const float *v_opacities, float *v_means, float *v_quats, float *v_log_scales,
+                                    float *v_logits, bds_stream_t stream) {
+  BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && quats && scales && opacities && viewmat && K && radii && v_means2d && v_depths && v_conics &&
+              v_opacities && v_means && v_quats && v_log_scales && v_logits);
+  hipLaunchKernelGGL(project_view_bwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
+                     means, quats, scales, opacities, viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics,
+                     v_opacities, v_means, v_quats, v_log_scales, v_logits);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

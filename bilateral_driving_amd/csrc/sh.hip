@@ -173,6 +173,115 @@ __global__ __launch_bounds__(kShBlock) void sh_bwd_kernel(int64_t n, int K, cons
   }
 }
 
+// ---- one-view variants for the fused training step -----------------------------------------------------
+// Same arithmetic as above with the glue folded in: the view direction is means - cam_pos (vanilla.py:384,
+// detached), visibility is radii > 0, and the result leaves already packed for the compositor as
+// (clamp(rgb + 0.5, 0, 1), depth)  (vanilla.py:389 + the RGB+ED channel layout of base.py:393-408).
+// sh_rgb keeps the un-clamped value: the backward needs to know where the clamp was active.
+template <int DEG, bool kVec>
+__global__ __launch_bounds__(kShBlock) void sh_view_fwd_kernel(int64_t n, int K, const float *__restrict__ means,
+                                                              const float *__restrict__ cam_pos,
+                                                              const float *__restrict__ coeffs,
+                                                              const int32_t *__restrict__ radii,
+                                                              const float *__restrict__ depths, float *__restrict__ sh_rgb,
+                                                              float4 *__restrict__ colors) {
+  constexpr int nb = (DEG + 1) * (DEG + 1);
+  const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
+  if (g >= n) return;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  if (radii[g] > 0) {
+    const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
+    const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+    float B[16];
+    sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+    const float *c = coeffs + g * (int64_t)K * 3;
+    float cf[nb * 3 + 3];
+    if (kVec) {
+      constexpr int n4 = (nb * 3 + 3) / 4;
+#pragma unroll
+      for (int i = 0; i < n4; i++) {
+        if (i * 4 < K * 3) {
+          const float4 v = reinterpret_cast<const float4 *>(c)[i];
+          cf[i * 4] = v.x; cf[i * 4 + 1] = v.y; cf[i * 4 + 2] = v.z; cf[i * 4 + 3] = v.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < nb * 3; i++) cf[i] = c[i];
+    }
+#pragma unroll
+    for (int k = 0; k < nb; k++) {
+      o0 += B[k] * cf[k * 3];
+      o1 += B[k] * cf[k * 3 + 1];
+      o2 += B[k] * cf[k * 3 + 2];
+    }
+  }
+  sh_rgb[g * 3] = o0; sh_rgb[g * 3 + 1] = o1; sh_rgb[g * 3 + 2] = o2;
+  colors[g] = make_float4(fminf(fmaxf(o0 + 0.5f, 0.f), 1.f), fminf(fmaxf(o1 + 0.5f, 0.f), 1.f),
+                          fminf(fmaxf(o2 + 0.5f, 0.f), 1.f), depths[g]);
+}
+
+template <int DEG, bool kFull>
+__global__ __launch_bounds__(kShBlock) void sh_view_bwd_kernel(int64_t n, int K, const float *__restrict__ means,
+                                                              const float *__restrict__ cam_pos,
+                                                              const int32_t *__restrict__ radii,
+                                                              const float *__restrict__ sh_rgb,
+                                                              const float4 *__restrict__ v_colors,
+                                                              float *__restrict__ v_coeffs, float *__restrict__ v_depths) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int nb = (DEG + 1) * (DEG + 1);
+  const int row = K * 3;
+  const int ldr = row + 1;
+  const int64_t g0 = (int64_t)blockIdx.x * kShBlock;
+  const int cnt = (int)min((int64_t)kShBlock, n - g0);
+  const int tid = threadIdx.x;
+  if (tid < cnt) {
+    const int64_t g = g0 + tid;
+    float *c = lds + tid * ldr;
+    const bool on = radii[g] > 0;
+    const float4 v = v_colors[g];
+    v_depths[g] = v.w;
+    float vo[3] = {v.x, v.y, v.z};
+    float B[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) B[k] = 0.f;
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float x = sh_rgb[g * 3 + k] + 0.5f;
+        if (!(x >= 0.f && x <= 1.f)) vo[k] = 0.f;   // torch.clamp passes the gradient on the closed interval
+      }
+      const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
+      const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+      sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < K) {
+        const float b = (on && k < nb) ? B[k < nb ? k : 0] : 0.f;
+        c[k * 3] = b * vo[0]; c[k * 3 + 1] = b * vo[1]; c[k * 3 + 2] = b * vo[2];
+      }
+    }
+  }
+  __syncthreads();
+  if (kFull) {
+    float4 *dst = reinterpret_cast<float4 *>(v_coeffs + g0 * row);
+    const int n4 = cnt * row / 4;
+    for (int i = tid; i < n4; i += kShBlock) {
+      const int e = i * 4;
+      const int r = e / row, cc = e - r * row;
+      const float *sp = lds + r * ldr + cc;
+      dst[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+    }
+  } else {
+    const int tot = cnt * row;
+    for (int e = tid; e < tot; e += kShBlock) {
+      const int r = e / row, cc = e - r * row;
+      v_coeffs[g0 * row + e] = lds[r * ldr + cc];
+    }
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -237,6 +346,69 @@ extern "C" int bds_sh_bwd(int64_t n, int K, int deg, const float *dirs, const fl
     case 1: launch_bwd<1>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
     case 2: launch_bwd<2>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
     default: launch_bwd<3>(full, grid, lds, st, n, K, dirs, coeffs, masks, v_out, v_coeffs, v_dirs); break;
+  }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+template <int DEG>
+static void launch_view_fwd(bool vec, int grid, hipStream_t st, int64_t n, int K, const float *means, const float *cam_pos,
+                            const float *coeffs, const int32_t *radii, const float *depths, float *sh_rgb, float4 *colors) {
+  if (vec)
+    hipLaunchKernelGGL((sh_view_fwd_kernel<DEG, true>), dim3(grid), dim3(kShBlock), 0, st, n, K, means, cam_pos, coeffs, radii,
+                       depths, sh_rgb, colors);
+  else
+    hipLaunchKernelGGL((sh_view_fwd_kernel<DEG, false>), dim3(grid), dim3(kShBlock), 0, st, n, K, means, cam_pos, coeffs, radii,
+                       depths, sh_rgb, colors);
+}
+
+template <int DEG>
+static void launch_view_bwd(bool full, int grid, size_t lds, hipStream_t st, int64_t n, int K, const float *means,
+                            const float *cam_pos, const int32_t *radii, const float *sh_rgb, const float4 *v_colors,
+                            float *v_coeffs, float *v_depths) {
+  if (full)
+    hipLaunchKernelGGL((sh_view_bwd_kernel<DEG, true>), dim3(grid), dim3(kShBlock), lds, st, n, K, means, cam_pos, radii, sh_rgb,
+                       v_colors, v_coeffs, v_depths);
+  else
+    hipLaunchKernelGGL((sh_view_bwd_kernel<DEG, false>), dim3(grid), dim3(kShBlock), lds, st, n, K, means, cam_pos, radii, sh_rgb,
+                       v_colors, v_coeffs, v_depths);
+}
+
+extern "C" int bds_sh_view_fwd(int64_t n, int K, int deg, const float *means, const float *cam_pos, const float *coeffs,
+                               const int32_t *radii, const float *depths, float *sh_rgb, float *colors, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(means && cam_pos && coeffs && radii && depths && sh_rgb && colors && aligned16(colors));
+  const int grid = (int)cdiv(n, kShBlock);
+  const bool vec = ((K * 3) % 4 == 0) && aligned16(coeffs);
+  hipStream_t st = as_stream(stream);
+  float4 *c4 = reinterpret_cast<float4 *>(colors);
+  switch (deg) {
+    case 0: launch_view_fwd<0>(vec, grid, st, n, K, means, cam_pos, coeffs, radii, depths, sh_rgb, c4); break;
+    case 1: launch_view_fwd<1>(vec, grid, st, n, K, means, cam_pos, coeffs, radii, depths, sh_rgb, c4); break;
+    case 2: launch_view_fwd<2>(vec, grid, st, n, K, means, cam_pos, coeffs, radii, depths, sh_rgb, c4); break;
+    default: launch_view_fwd<3>(vec, grid, st, n, K, means, cam_pos, coeffs, radii, depths, sh_rgb, c4); break;
+  }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_sh_view_bwd(int64_t n, int K, int deg, const float *means, const float *cam_pos, const int32_t *radii,
+                               const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths,
+                               bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(means && cam_pos && radii && sh_rgb && v_colors && v_coeffs && v_depths && aligned16(v_colors));
+  const int grid = (int)cdiv(n, kShBlock);
+  const size_t lds = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+  const bool full = ((K * 3) % 4 == 0) && aligned16(v_coeffs);
+  hipStream_t st = as_stream(stream);
+  const float4 *v4 = reinterpret_cast<const float4 *>(v_colors);
+  switch (deg) {
+    case 0: launch_view_bwd<0>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    case 1: launch_view_bwd<1>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    case 2: launch_view_bwd<2>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    default: launch_view_bwd<3>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
   }
   BDS_LAUNCH_CHECK();
   return BDS_OK;

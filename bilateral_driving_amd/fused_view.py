@@ -43,24 +43,21 @@ class _FusedView(torch.autograd.Function):
         P = H * W
         means, quats, log_scales, logits, sh, sky = (t.contiguous() for t in (means, quats, log_scales, logits, sh, sky))
         viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
-        # activations (vanilla.py:393-394)
+        # activations (vanilla.py:393-394) + projection (C = 1)
         scales, opac = _empty((N, 3), dev), _empty((N,), dev)
-        L.check(lib.bds_activate_fwd(N, L.ptr(log_scales), L.ptr(logits), L.ptr(scales), L.ptr(opac), st), "bds_activate_fwd")
-        # projection (C = 1)
         radii = _empty((1, N), dev, torch.int32)
         means2d, depths, conics = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev)
         with L.timed("project_fwd"):
-            L.check(lib.bds_project_fwd(1, N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(viewmat), L.ptr(Kmat), W, H,
-                                        cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], L.ptr(radii),
-                                        L.ptr(means2d), L.ptr(depths), L.ptr(conics), None, st), "bds_project_fwd")
-        # SH colours of the visible Gaussians (vanilla.py:385-389)
-        dirs = means - cfg["cam_pos"]
-        mask8 = (radii[0] > 0).to(torch.uint8)
-        sh_rgb = _empty((N, 3), dev)
+            L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
+                                             L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
+                                             L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
+                    "bds_project_view_fwd")
+        # SH colours of the visible Gaussians, packed with the depth channel (vanilla.py:384-389)
+        cam_pos = cfg["cam_pos"].contiguous()
+        sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
         with L.timed("sh_fwd"):
-            L.check(lib.bds_sh_fwd(N, K, cfg["sh_degree"], L.ptr(dirs), L.ptr(sh), L.ptr(mask8), L.ptr(sh_rgb), st), "bds_sh_fwd")
-        colors = _empty((1, N, 4), dev)
-        L.check(lib.bds_colors_pack_fwd(N, L.ptr(sh_rgb), L.ptr(depths), L.ptr(colors), st), "bds_colors_pack_fwd")
+            L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
+                                        L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
         # tile ordering
         tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
         cull = cfg["tile_cull"]
@@ -127,7 +124,7 @@ class _FusedView(torch.autograd.Function):
         ctx.M = M
         ctx.n_grids = len(grids)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, dirs, mask8, sh_rgb,
+        ctx.save_for_backward(means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
                               colors, flatten_ids, isect_offsets, render, alphas, last_ids, rgb_g, bws, *grids)
         opacity = alphas[0]
         # rgb_g / means2d are returned for inspection and as the carrier of .absgrad; no gradient flows into them
@@ -136,7 +133,7 @@ class _FusedView(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_opacity, *_):
-        (means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, dirs, mask8, sh_rgb, colors, flatten_ids,
+        (means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, flatten_ids,
          isect_offsets, render, alphas, last_ids, rgb_g, bws, *grids) = ctx.saved_tensors
         cfg = ctx.cfg
         lib, st = L.lib(), L.stream()
@@ -175,8 +172,6 @@ class _FusedView(torch.autograd.Function):
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282 reads .absgrad)
             carrier.absgrad = v_abs.view(1, N, 2)
             carrier.grad_means2d = v_m2.view(1, N, 2)
-        v_sh_rgb, v_depths = _empty((N, 3), dev), _empty((1, N), dev)
-        L.check(lib.bds_colors_pack_bwd(N, L.ptr(sh_rgb), L.ptr(v_col), L.ptr(v_sh_rgb), L.ptr(v_depths), st), "bds_colors_pack_bwd")
         arena = cfg.get("grad_arena") or {}
 
         def out_like(name, ref):  # gradient output: the caller's slice of a flat communication buffer, or a fresh tensor
@@ -186,19 +181,17 @@ class _FusedView(torch.autograd.Function):
             assert t.shape == ref.shape and t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device, name
             return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
 
-        v_sh = out_like("sh", sh)
+        v_sh, v_depths = out_like("sh", sh), _empty((1, N), dev)
         with L.timed("sh_bwd"):
-            L.check(lib.bds_sh_bwd(N, K, cfg["sh_degree"], L.ptr(dirs), L.ptr(sh), L.ptr(mask8), L.ptr(v_sh_rgb), L.ptr(v_sh), None,
-                                   st), "bds_sh_bwd")
-        v_means, v_quats, v_scales = out_like("means", means), out_like("quats", quats), torch.empty_like(scales)
+            L.check(lib.bds_sh_view_bwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col),
+                                        L.ptr(v_sh), L.ptr(v_depths), st), "bds_sh_view_bwd")
+        v_means, v_quats = out_like("means", means), out_like("quats", quats)
+        v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
         with L.timed("project_bwd"):
-            L.check(lib.bds_project_bwd(1, N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(viewmat), L.ptr(Kmat), W, H,
-                                        cfg["eps2d"], L.ptr(radii), L.ptr(conics), None, L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con),
-                                        None, L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), None, st), "bds_project_bwd")
-        v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
-        L.check(lib.bds_activate_bwd(N, L.ptr(scales), L.ptr(opac), L.ptr(v_scales), L.ptr(v_op), L.ptr(v_ls), L.ptr(v_logits), st),
-                "bds_activate_bwd")
+            L.check(lib.bds_project_view_bwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat), W, H,
+                                             cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
+                                             L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), st), "bds_project_view_bwd")
         return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, *v_grids)
 
 

@@ -191,17 +191,30 @@ int bds_bilagrid_tv_fwd(int64_t n, int gx, int gy, int gl, const float *grids, f
 int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
                         float *v_grids, bds_stream_t stream);
 
-/* ---- element-wise glue of the training step, one launch each -----------------------------------
- * models/gaussians/vanilla.py:389,393-394 (clamp(sh+0.5,0,1), sigmoid, exp); the RGB+ED colour
- * concat / expected-depth normalise inside gsplat's rasterization(); models/trainers/base.py:414-419. */
-int bds_activate_fwd(int64_t N, const float *log_scales, const float *logits, float *scales, float *opacities,
-                     bds_stream_t stream);
-int bds_activate_bwd(int64_t N, const float *scales, const float *opacities, const float *v_scales,
-                     const float *v_opacities, float *v_log_scales, float *v_logits, bds_stream_t stream);
-/* colors [N,4] = (clamp(sh_rgb + 0.5, 0, 1), depth) */
-int bds_colors_pack_fwd(int64_t N, const float *sh_rgb, const float *depths, float *colors, bds_stream_t stream);
-int bds_colors_pack_bwd(int64_t N, const float *sh_rgb, const float *v_colors, float *v_sh_rgb, float *v_depths,
-                        bds_stream_t stream);
+/* ---- one-view forms for the fused training step ------------------------------------------------------
+ * The per-Gaussian glue of one reference iteration folded into the two streaming kernels that sit next to it
+ * (C = 1; same arithmetic as the general forms above):
+ *   project_view: scales = exp(log_scales), opacities = sigmoid(logits) (models/gaussians/vanilla.py:393-394) are
+ *     computed by the projection (and returned: the compositor and the backward read them); the backward returns the
+ *     gradients of the raw parameters and reads only the radius of a culled Gaussian.
+ *   sh_view: view direction = means - cam_pos (vanilla.py:384, detached), visibility = radii > 0, output packed for
+ *     the RGB+ED compositor as colors [N,4] = (clamp(sh + 0.5, 0, 1), depth) (vanilla.py:389); sh_rgb [N,3] keeps the
+ *     un-clamped value for the backward; the backward also splits off v_depths [N] = v_colors[:,3]. */
+int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales, const float *logits,
+                         const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane,
+                         float far_plane, float radius_clip, float *scales, float *opacities, int32_t *radii,
+                         float *means2d, float *depths, float *conics, bds_stream_t stream);
+int bds_project_view_bwd(int64_t N, const float *means, const float *quats, const float *scales, const float *opacities,
+                         const float *viewmat, const float *K, int W, int H, float eps2d, const int32_t *radii,
+                         const float *v_means2d, const float *v_depths, const float *v_conics, const float *v_opacities,
+                         float *v_means, float *v_quats, float *v_log_scales, float *v_logits, bds_stream_t stream);
+int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const float *coeffs,
+                    const int32_t *radii, const float *depths, float *sh_rgb, float *colors, bds_stream_t stream);
+int bds_sh_view_bwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const int32_t *radii,
+                    const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, bds_stream_t stream);
+
+/* ---- image-side glue: the expected-depth normalise inside gsplat's rasterization() (RGB+ED) and the channel
+ * split of models/trainers/base.py:414-419. */
 /* render [P,4], alphas [P] -> rgb [P,3], depth [P] = render.w / max(alpha, 1e-10); bwd sums two optional
  * extra alpha gradients (from the colour transform and from the caller) into v_alphas. */
 int bds_render_unpack_fwd(int64_t P, const float *render, const float *alphas, float *rgb, float *depth,
