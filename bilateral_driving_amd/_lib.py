@@ -55,10 +55,12 @@ _SIGS = {
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
     "bds_bilagrid_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, C.POINTER(C.c_void_p), _f]),
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
+    "bds_bilagrid_ms_ed_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
+    "bds_bilagrid_ms_ed_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_l1_mean_fwd": (_i, [_i64, _f, _f, _f, _f]),
+    "bds_l1_mean_bwd": (_i, [_i64, _f, _f, _f, _f, _f]),
     "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),
     "bds_bilagrid_tv_bwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f, _f]),
-    "bds_render_unpack_fwd": (_i, [_i64, _f, _f, _f, _f, _f]),
-    "bds_render_unpack_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -31,7 +31,11 @@ struct LevelDev {
 };
 struct MsParams {
   int nlevels, H, W;
+  int cs;                  // floats per pixel of `rgb` and of the returned colour gradient: 3, or 4 in the RGB+ED form
   const float *rgb, *alpha, *sky;
+  float *depth_out;        // RGB+ED form: [H*W] expected depth = rgb[.,3] / max(alpha, 1e-10)
+  const float *v_depth;    // RGB+ED form, backward: gradient of that depth (may be null)
+  const float *v_alpha_in; // RGB+ED form, backward: gradient arriving at alpha from the caller (may be null)
   LevelDev lv[BDS_MAX_LEVELS];
 };
 
@@ -54,7 +58,7 @@ __device__ __forceinline__ int sched_find(const LevelSched &s, int bid, int &loc
 // input colour of the transform at pixel (y,x): clamp + sky blend fused when sky != null
 __device__ __forceinline__ void load_input(const MsParams &p, int y, int x, float &r, float &g, float &b) {
   const int64_t o = (int64_t)y * p.W + x;
-  r = p.rgb[o * 3]; g = p.rgb[o * 3 + 1]; b = p.rgb[o * 3 + 2];
+  r = p.rgb[o * p.cs]; g = p.rgb[o * p.cs + 1]; b = p.rgb[o * p.cs + 2];
   if (p.sky) {
     const float k = 1.f - p.alpha[o];
     r = fminf(r, 1.f) + p.sky[o * 3] * k;
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
     }
   }
   out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
+  if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
 }
 
 // ---- C: full-resolution backward: direct route + per-level (P, Q) ------------------------------------
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, cons
       v0 = n0; v1 = n1; v2 = n2;
     }
   }
-  v_in[pix * 3] = v0; v_in[pix * 3 + 1] = v1; v_in[pix * 3 + 2] = v2;
+  v_in[pix * p.cs] = v0; v_in[pix * p.cs + 1] = v1; v_in[pix * p.cs + 2] = v2;
 }
 
 // destination indices of a bilinear up-sample (size `full` from `low`) whose taps touch source cell c:
@@ -428,19 +433,29 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
       }
     }
   }
-  float v[3] = {v_in[pix * 3] + vg * kGrayR, v_in[pix * 3 + 1] + vg * kGrayG, v_in[pix * 3 + 2] + vg * kGrayB};
+  const int cs = p.cs;
+  float v[3] = {v_in[pix * cs] + vg * kGrayR, v_in[pix * cs + 1] + vg * kGrayG, v_in[pix * cs + 2] + vg * kGrayB};
+  float va = 0.f;
   if (p.sky) {
     const float k = 1.f - p.alpha[pix];
-    float va = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       va -= v[c] * p.sky[pix * 3 + c];
       if (v_sky) v_sky[pix * 3 + c] = v[c] * k;
-      v[c] = p.rgb[pix * 3 + c] <= 1.f ? v[c] : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
+      v[c] = p.rgb[pix * cs + c] <= 1.f ? v[c] : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
     }
-    if (v_alpha) v_alpha[pix] = va;
   }
-  v_in[pix * 3] = v[0]; v_in[pix * 3 + 1] = v[1]; v_in[pix * 3 + 2] = v[2];
+  v_in[pix * cs] = v[0]; v_in[pix * cs + 1] = v[1]; v_in[pix * cs + 2] = v[2];
+  if (cs == 4) {  // RGB+ED form: depth = D / clamp(alpha, min=1e-10); plus the caller's own alpha gradient
+    const float a = p.alpha[pix], ac = fmaxf(a, 1e-10f);
+    const float vd = p.v_depth ? p.v_depth[pix] : 0.f;
+    v_in[pix * 4 + 3] = vd / ac;
+    if (p.v_alpha_in) va += p.v_alpha_in[pix];
+    if (a >= 1e-10f) va -= p.rgb[pix * 4 + 3] * vd / (ac * ac);  // clamp(min) passes the gradient where alpha >= 1e-10
+    if (v_alpha) v_alpha[pix] = va;
+  } else if (p.sky && v_alpha) {
+    v_alpha[pix] = va;
+  }
 }
 
 // ---- generic point slice (BilateralGrid.forward on arbitrary points) ------------------------------
@@ -579,6 +594,7 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   BDS_REQUIRE(aligned16(ws));
   p.nlevels = nlevels; p.H = H; p.W = W; p.rgb = rgb; p.alpha = alpha; p.sky = sky;
+  p.cs = 3; p.depth_out = nullptr; p.v_depth = nullptr; p.v_alpha_in = nullptr;
   char *base = static_cast<char *>(ws);
   for (int l = 0; l < nlevels; l++) {
     BDS_REQUIRE(lv[l].grid && lv[l].gx >= 1 && lv[l].gy >= 1 && lv[l].gl >= 1 && lv[l].factor >= 1 && lv[l].n_avg >= 1);
@@ -609,13 +625,14 @@ extern "C" size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagri
   return ms_layout(nlevels, levels, H, W).bytes;
 }
 
-extern "C" int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
-                                   const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
-                                   float *const *affine_out, bds_stream_t stream) {
+static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb, int cs,
+                       const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out, float *depth_out,
+                       float *const *affine_out, bds_stream_t stream) {
   MsParams p;
   int rc = ms_fill(p, nlevels, levels, H, W, rgb, alpha, sky, ws, ws_bytes, affine_out);
   if (rc != BDS_OK) return rc;
   BDS_REQUIRE(rgb_out);
+  p.cs = cs; p.depth_out = depth_out;
   hipStream_t st = as_stream(stream);
   {
     LevelSched sc{};
@@ -642,14 +659,28 @@ extern "C" int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *leve
   return BDS_OK;
 }
 
-extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
-                                   const float *alpha, const float *sky, void *ws, size_t ws_bytes,
-                                   const float *v_rgb_out, float *v_rgb, float *v_alpha, float *v_sky,
-                                   bds_stream_t stream) {
+extern "C" int bds_bilagrid_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
+                                   const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
+                                   float *const *affine_out, bds_stream_t stream) {
+  return ms_fwd_impl(nlevels, levels, H, W, rgb, 3, alpha, sky, ws, ws_bytes, rgb_out, nullptr, affine_out, stream);
+}
+
+extern "C" int bds_bilagrid_ms_ed_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                                      const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
+                                      float *depth_out, bds_stream_t stream) {
+  BDS_REQUIRE(alpha && depth_out);
+  return ms_fwd_impl(nlevels, levels, H, W, render, 4, alpha, sky, ws, ws_bytes, rgb_out, depth_out, nullptr, stream);
+}
+
+static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb, int cs,
+                       const float *alpha, const float *sky, void *ws, size_t ws_bytes, const float *v_rgb_out,
+                       const float *v_depth, const float *v_alpha_in, float *v_rgb, float *v_alpha, float *v_sky,
+                       bds_stream_t stream) {
   MsParams p;
   int rc = ms_fill(p, nlevels, levels, H, W, rgb, alpha, sky, ws, ws_bytes, nullptr);
   if (rc != BDS_OK) return rc;
   BDS_REQUIRE(v_rgb_out && v_rgb);
+  p.cs = cs; p.v_depth = v_depth; p.v_alpha_in = v_alpha_in;
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
   {
@@ -736,6 +767,23 @@ extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *leve
     BDS_LAUNCH_CHECK();
   }
   return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb,
+                                   const float *alpha, const float *sky, void *ws, size_t ws_bytes,
+                                   const float *v_rgb_out, float *v_rgb, float *v_alpha, float *v_sky,
+                                   bds_stream_t stream) {
+  return ms_bwd_impl(nlevels, levels, H, W, rgb, 3, alpha, sky, ws, ws_bytes, v_rgb_out, nullptr, nullptr, v_rgb, v_alpha, v_sky,
+                     stream);
+}
+
+extern "C" int bds_bilagrid_ms_ed_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                                      const float *alpha, const float *sky, void *ws, size_t ws_bytes,
+                                      const float *v_rgb_out, const float *v_depth, const float *v_opacity, float *v_render,
+                                      float *v_alpha, float *v_sky, bds_stream_t stream) {
+  BDS_REQUIRE(alpha && v_alpha);
+  return ms_bwd_impl(nlevels, levels, H, W, render, 4, alpha, sky, ws, ws_bytes, v_rgb_out, v_depth, v_opacity, v_render, v_alpha,
+                     v_sky, stream);
 }
 
 extern "C" int bds_bilagrid_slice_fwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy,

@@ -108,24 +108,23 @@ class _FusedView(torch.autograd.Function):
             L.check(lib.bds_rasterize_fwd(1, N, M, 4, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), None, W, H,
                                           TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas),
                                           L.ptr(last_ids), st), "bds_rasterize_fwd")
-        rgb_g, depth = _empty((H, W, 3), dev), _empty((H, W, 1), dev)
-        L.check(lib.bds_render_unpack_fwd(P, L.ptr(render), L.ptr(alphas), L.ptr(rgb_g), L.ptr(depth), st), "bds_render_unpack_fwd")
-        # clamp + sky blend + bilateral transform
+        # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         grids = [g.contiguous() for g in grids]
         factors = cfg["factors"]
         lv = _levels_struct(grids, None, factors)
         bws_bytes = lib.bds_bilagrid_ms_workspace_bytes(len(grids), lv, H, W)
         bws = _empty((bws_bytes,), dev, torch.uint8)
-        rgb = _empty((H, W, 3), dev)
+        rgb, depth = _empty((H, W, 3), dev), _empty((H, W, 1), dev)
         with L.timed("bilagrid_fwd"):
-            L.check(lib.bds_bilagrid_ms_fwd(len(grids), lv, H, W, L.ptr(rgb_g), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
-                                            L.ptr(rgb), None, st), "bds_bilagrid_ms_fwd")
+            L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
+                                               L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")
+        rgb_g = render[0, :, :, :3]   # view: the Gaussians' colour before clamp / sky / transform (base.py:414)
         ctx.cfg = cfg
         ctx.M = M
         ctx.n_grids = len(grids)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
-                              colors, flatten_ids, isect_offsets, render, alphas, last_ids, rgb_g, bws, *grids)
+                              colors, flatten_ids, isect_offsets, render, alphas, last_ids, bws, *grids)
         opacity = alphas[0]
         # rgb_g / means2d are returned for inspection and as the carrier of .absgrad; no gradient flows into them
         ctx.mark_non_differentiable(rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets)
@@ -134,7 +133,7 @@ class _FusedView(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_opacity, *_):
         (means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, flatten_ids,
-         isect_offsets, render, alphas, last_ids, rgb_g, bws, *grids) = ctx.saved_tensors
+         isect_offsets, render, alphas, last_ids, bws, *grids) = ctx.saved_tensors
         cfg = ctx.cfg
         lib, st = L.lib(), L.stream()
         dev = means.device
@@ -149,15 +148,11 @@ class _FusedView(torch.autograd.Function):
         v_rgb = torch.zeros(H, W, 3, device=dev) if v_rgb is None else v_rgb.contiguous()
         v_depth = None if v_depth is None else v_depth.contiguous()
         v_opacity = None if v_opacity is None else v_opacity.contiguous()
-        v_rgb_t, v_alpha_t, v_sky = _empty((H, W, 3), dev), _empty((H, W), dev), _empty((H, W, 3), dev)
+        v_render, v_alphas, v_sky = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((H, W, 3), dev)
         with L.timed("bilagrid_bwd"):
-            L.check(lib.bds_bilagrid_ms_bwd(len(grids), lv, H, W, L.ptr(rgb_g), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
-                                            L.ptr(v_rgb), L.ptr(v_rgb_t), L.ptr(v_alpha_t), L.ptr(v_sky), st), "bds_bilagrid_ms_bwd")
-        # expected depth + channel split
-        v_render, v_alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
-        L.check(lib.bds_render_unpack_bwd(P, L.ptr(render), L.ptr(alphas), L.ptr(v_rgb_t), L.ptr(v_depth), L.ptr(v_alpha_t),
-                                          L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas), st),
-                "bds_render_unpack_bwd")
+            L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
+                                               L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
+                                               L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
         # compositing
         buf = torch.zeros(12 * N, device=dev, dtype=torch.float32)
         v_col, v_m2, v_abs, v_con, v_op = torch.split(buf, [4 * N, 2 * N, 2 * N, 3 * N, N])  # v_col first: 16-byte aligned

@@ -213,15 +213,26 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
 int bds_sh_view_bwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const int32_t *radii,
                     const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, bds_stream_t stream);
 
-/* ---- image-side glue: the expected-depth normalise inside gsplat's rasterization() (RGB+ED) and the channel
- * split of models/trainers/base.py:414-419. */
-/* render [P,4], alphas [P] -> rgb [P,3], depth [P] = render.w / max(alpha, 1e-10); bwd sums two optional
- * extra alpha gradients (from the colour transform and from the caller) into v_alphas. */
-int bds_render_unpack_fwd(int64_t P, const float *render, const float *alphas, float *rgb, float *depth,
-                          bds_stream_t stream);
-int bds_render_unpack_bwd(int64_t P, const float *render, const float *alphas, const float *v_rgb, const float *v_depth,
-                          const float *v_alpha_a, const float *v_alpha_b, float *v_render, float *v_alphas,
-                          bds_stream_t stream);
+/* RGB+ED form of the fused image transform: the input is the compositor's 4-channel render [H*W,4] (RGB +
+ * accumulated depth, gsplat render_mode "RGB+ED") and its alpha.  Forward additionally writes the expected depth
+ * depth [H*W] = render[.,3] / max(alpha, 1e-10) (the normalise inside gsplat's rasterization(); split as in
+ * models/trainers/base.py:414-419).  Backward returns v_render [H*W,4] and the TOTAL alpha gradient: colour
+ * transform (sky blend) + expected depth + the caller's own v_opacity; v_depth / v_opacity / v_sky may be NULL.
+ * Same workspace as bds_bilagrid_ms_fwd/bwd. */
+int bds_bilagrid_ms_ed_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                           const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
+                           float *depth_out, bds_stream_t stream);
+int bds_bilagrid_ms_ed_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                           const float *alpha, const float *sky, void *ws, size_t ws_bytes, const float *v_rgb_out,
+                           const float *v_depth, const float *v_opacity, float *v_render, float *v_alpha, float *v_sky,
+                           bds_stream_t stream);
+
+/* ---- photometric L1 (the step right after the path) ---------------------------------
+ * models/trainers/base.py:518-529: mean |a - b| over n floats.  out [1] is ACCUMULATED (caller zero-fills, so that
+ * the TV terms of bds_bilagrid_tv_fwd can land in the same scalar); a, b 16-byte aligned.
+ * bwd: v_a = sign(a - b) * v_out / n with v_out a device scalar. */
+int bds_l1_mean_fwd(int64_t n, const float *a, const float *b, float *out, bds_stream_t stream);
+int bds_l1_mean_bwd(int64_t n, const float *a, const float *b, const float *v_out, float *v_a, bds_stream_t stream);
 
 #ifdef __cplusplus
 }
