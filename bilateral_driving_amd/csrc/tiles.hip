@@ -416,10 +416,13 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
 // than the bytes it moves), so the scan of the [digit][workgroup] histogram is folded away: histograms are stored
 // workgroup-major, every 32 workgroups also add theirs to a group row (256 atomics per workgroup), and a scatter
 // workgroup derives its own bases from <= ng group rows + <= 31 workgroup rows (all L2-resident).
-constexpr int kGroupShift = 5;                      // 32 workgroups per group row
-constexpr int kChunkShift = 12;                     // kSortChunk == 1 << 12
-static_assert(kSortChunk == (1 << kChunkShift), "chunk shift");
-constexpr int64_t kShortSortMax = (int64_t)kSortChunk * 4096;   // <= 128 group rows
+// Chunks of 1024 pairs (4 rounds per wave): a few hundred thousand keys then spread over > 256 workgroups.
+constexpr int kGroupShift = 6;                      // 64 workgroups per group row
+constexpr int kShortRounds = 4;
+constexpr int kShortChunk = kSortBlock * kShortRounds;   // 1024
+constexpr int kChunkShift = 10;
+static_assert(kShortChunk == (1 << kChunkShift), "chunk shift");
+constexpr int64_t kShortSortMax = (int64_t)kShortChunk * 8192;   // <= 128 group rows
 
 __global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *__restrict__ keys,
                                                                const uint64_t *__restrict__ n_dev, int shift,
@@ -427,12 +430,12 @@ __global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *
                                                                uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
   __shared__ uint32_t h[256];
   const int64_t n = (int64_t)*n_dev;
-  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+  const int64_t base = (int64_t)blockIdx.x * kShortChunk;
   if (base >= n) return;  // the launch is sized for the host-side bound
   h[threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll 4
-  for (int r = 0; r < kSortRounds; r++) {
+  for (int r = 0; r < kShortRounds; r++) {
     const int64_t i = base + r * kSortBlock + threadIdx.x;
     if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
   }
@@ -448,14 +451,14 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out) {
   const int64_t n = (int64_t)*n_dev;
-  if ((int64_t)blockIdx.x * kSortChunk >= n) return;
+  if ((int64_t)blockIdx.x * kShortChunk >= n) return;
   __shared__ uint32_t wrun[kSortWaves][256];
   __shared__ uint32_t lw[kSortBlock / kWave + 1];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 #pragma unroll
   for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
   // digit `tid`: elements of this digit in front of this workgroup, and in the whole input
-  const int nb = (int)((n + kSortChunk - 1) >> kChunkShift), ng = (nb + (1 << kGroupShift) - 1) >> kGroupShift;
+  const int nb = (int)((n + kShortChunk - 1) >> kChunkShift), ng = (nb + (1 << kGroupShift) - 1) >> kGroupShift;
   const int gb = (int)blockIdx.x >> kGroupShift;
   uint32_t below = 0, total = 0;
   for (int g = 0; g < ng; g++) {
@@ -466,11 +469,11 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
   for (int b = gb << kGroupShift; b < (int)blockIdx.x; b++) below += hist[(int64_t)b * 256 + tid];
   uint32_t all;
   const uint32_t digit_base = block_excl_scan(total, all, lw);   // (contains the barrier that publishes wrun = 0)
-  constexpr int kPerWave = kSortChunk / kSortWaves;
-  const int64_t wbase = (int64_t)blockIdx.x * kSortChunk + (int64_t)wv * kPerWave;
-  uint32_t k[kSortRounds], v[kSortRounds];
+  constexpr int kPerWave = kShortChunk / kSortWaves;
+  const int64_t wbase = (int64_t)blockIdx.x * kShortChunk + (int64_t)wv * kPerWave;
+  uint32_t k[kShortRounds], v[kShortRounds];
 #pragma unroll
-  for (int r = 0; r < kSortRounds; r++) {
+  for (int r = 0; r < kShortRounds; r++) {
     const int64_t i = wbase + r * kWave + lane;
     k[r] = 0xFFFFFFFFu; v[r] = 0;
     if (i < n) {
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
   __syncthreads();
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-  for (int r = 0; r < kSortRounds; r++) {
+  for (int r = 0; r < kShortRounds; r++) {
     const int64_t i = wbase + r * kWave + lane;
     const bool on = i < n;
     const uint32_t d = (k[r] >> shift) & 255u;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
 
 // uint32 elements: one workgroup-major histogram + four zero-initialised group tables
 static size_t short_sort_elems(int64_t n_bound) {
-  const int64_t nb = cdiv(n_bound > 0 ? n_bound : 1, kSortChunk), ng = cdiv(nb, 1 << kGroupShift);
+  const int64_t nb = cdiv(n_bound > 0 ? n_bound : 1, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
   return (size_t)(nb + 4 * ng) * 256;
 }
 
@@ -566,17 +569,18 @@ __global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, 
 }
 
 // visible_compact: (depth bits, cam*N+g) of the visible entries in index order; the histogram of the first
-// sort digit is accumulated on the way (a tile's outputs fall into at most two sort chunks).
+// sort digit is accumulated on the way (a tile's outputs fall into at most kSpan sort chunks).
 __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN, const int32_t *__restrict__ radii,
                                                                     const float *__restrict__ depths,
                                                                     const uint32_t *__restrict__ tile_sums,
                                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                     uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
                                                                     uint64_t *__restrict__ n_vis_out) {
-  static_assert(kScanTile <= kSortChunk, "a tile may straddle at most two sort chunks");
+  constexpr int kSpan = kScanTile / kShortChunk + 1;   // sort chunks a tile's outputs can straddle
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
-  __shared__ uint32_t h[2][256];
-  h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+  __shared__ uint32_t h[kSpan][256];
+#pragma unroll
+  for (int t = 0; t < kSpan; t++) h[t][threadIdx.x] = 0;
   uint32_t part = 0;
   for (int b = threadIdx.x; b < (int)blockIdx.x; b += kScanBlock) part += tile_sums[b];
   uint32_t my_offset;
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
+  for (int t = 0; t < kSpan; t++) {
     const uint32_t c = h[t][threadIdx.x];
     if (c) {
       atomicAdd(&hist[(int64_t)(chunk0 + t) * 256 + threadIdx.x], c);
@@ -804,7 +808,7 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   int rc;
   if (CN <= kShortSortMax && option_get(kOptShortSort)) {
     // 12 launches instead of 27: the whole stage is launch-latency bound at this size
-    const int64_t nb = cdiv(CN, kSortChunk), ng = cdiv(nb, 1 << kGroupShift);
+    const int64_t nb = cdiv(CN, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
     uint32_t *hist = L.tables, *ghist = L.tables + nb * 256;   // ghist[p] = ghist + p * ng * 256
     const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
     // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
