@@ -94,7 +94,7 @@ def lib():
     return _lib
 
 
-OPT_RASTER_BWD, OPT_RADIX, OPT_RASTER_FWD, OPT_SHORT_SORT = 0, 1, 2, 4
+OPT_RASTER_BWD, OPT_RADIX, OPT_RASTER_FWD, OPT_SHORT_SORT, OPT_ROW_ITEMS = 0, 1, 2, 4, 5
 ECAPACITY = -4
 
 

@@ -650,7 +650,140 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_sorted_kernel(
   if (tiles_per_gauss) tiles_per_gauss[o] = cnt;
 }
 
-// emit (camera*tiles + tile, cam*N+gaussian) pairs in depth order
+
+// ---- row-parallel counting / emission ---------------------------------------------------------------------
+// One thread per Gaussian leaves most lanes idle: the tile rectangles of 64 depth-neighbours differ by an order of
+// magnitude in size and the wave runs as long as its largest member (rows x tiles, serially).  Here a workgroup still
+// owns 256 consecutive (depth-ordered) Gaussians -- so its output range is contiguous and starts at the scanned
+// offset of its first member -- but the unit of work is one tile ROW of one Gaussian: the members' records are parked
+// in LDS, a prefix over their row counts maps a row item back to its owner (8-step search in LDS), and for the
+// emission a workgroup-wide running prefix over the rows' tile counts gives every row its output offset.
+struct RowStage {
+  float mx[kIsectBlock], my[kIsectBlock], a[kIsectBlock], b[kIsectBlock], c[kIsectBlock], qmax[kIsectBlock];
+  int x0[kIsectBlock], x1[kIsectBlock], y0[kIsectBlock];
+  uint32_t id[kIsectBlock];          // cam*N + gaussian
+  uint32_t cam_base[kIsectBlock];    // camera * tiles-per-camera
+  uint32_t rowoff[kIsectBlock + 1];  // exclusive prefix of the members' row counts
+  uint32_t lw[kIsectBlock / kWave + 1];
+};
+
+// fills the stage for members j0 .. j0+255 of the depth order; returns the workgroup's number of row items
+__device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t n_vis, int64_t N, const uint32_t *__restrict__ sorted_idx,
+                                               const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                                               const float *__restrict__ conics, const float *__restrict__ opacities,
+                                               int tile_size, int tile_w, int tile_h) {
+  const int t = threadIdx.x;
+  const int64_t j = j0 + t;
+  uint32_t nrows = 0;
+  if (j < n_vis) {
+    const uint32_t o = sorted_idx[j];
+    const int r = radii[o];
+    if (r > 0) {
+      const float mx = means2d[(int64_t)o * 2], my = means2d[(int64_t)o * 2 + 1];
+      int x0, y0, x1, y1;
+      float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
+      bool ok;
+      if (conics == nullptr) {
+        tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+        ok = x1 > x0 && y1 > y0;
+      } else {
+        a = conics[(int64_t)o * 3]; b = conics[(int64_t)o * 3 + 1]; c = conics[(int64_t)o * 3 + 2];
+        ok = tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max);
+      }
+      if (ok) {
+        nrows = (uint32_t)(y1 - y0);
+        S.mx[t] = mx; S.my[t] = my; S.a[t] = a; S.b[t] = b; S.c[t] = c; S.qmax[t] = q_max;
+        S.x0[t] = x0; S.x1[t] = x1; S.y0[t] = y0; S.id[t] = o;
+        S.cam_base[t] = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
+      }
+    }
+  }
+  uint32_t total;
+  const uint32_t ex = block_excl_scan(nrows, total, S.lw);
+  S.rowoff[t] = ex;
+  if (t == 0) S.rowoff[kIsectBlock] = total;
+  __syncthreads();
+  return total;
+}
+
+// owner of row item r (largest g with rowoff[g] <= r; members without rows are skipped by construction)
+__device__ __forceinline__ int row_owner(const RowStage &S, uint32_t r) {
+  int lo = 0, hi = kIsectBlock;   // invariant: rowoff[lo] <= r < rowoff[hi]
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const int mid = (lo + hi) >> 1;
+    if (S.rowoff[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void row_span_of(const RowStage &S, int g, int ty, bool cull, int tile_size, int &lo, int &hi) {
+  lo = S.x0[g]; hi = S.x1[g];
+  if (cull) row_tile_span(S.mx[g], S.my[g], S.a[g], S.b[g], S.c[g], S.qmax[g], ty, tile_size, S.x0[g], S.x1[g], lo, hi);
+}
+
+__global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
+    int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
+    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted) {
+  __shared__ RowStage S;
+  __shared__ uint32_t cnt[kIsectBlock];
+  const int64_t n_vis = (int64_t)*n_vis_dev;
+  const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock, j = j0 + threadIdx.x;
+  if (j0 >= n_vis) {  // the scan runs over the host-side bound: zeros beyond the visible count
+    if (j < CN) cnt_sorted[j] = 0u;
+    return;
+  }
+  cnt[threadIdx.x] = 0u;
+  const uint32_t R = stage_rows(S, j0, n_vis, CN, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h);
+  const bool cull = conics != nullptr;
+  for (uint32_t r = threadIdx.x; r < R; r += kIsectBlock) {
+    const int g = row_owner(S, r);
+    int lo, hi;
+    row_span_of(S, g, S.y0[g] + (int)(r - S.rowoff[g]), cull, tile_size, lo, hi);
+    if (hi > lo) atomicAdd(&cnt[g], (uint32_t)(hi - lo));
+  }
+  __syncthreads();
+  if (j < CN) cnt_sorted[j] = cnt[threadIdx.x];
+  if (tiles_per_gauss && j < n_vis) tiles_per_gauss[sorted_idx[j]] = (int32_t)cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
+    const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ cum_sorted,
+    const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ vals) {
+  __shared__ RowStage S;
+  const int64_t n_vis = (int64_t)*n_vis_dev;
+  const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
+  if (j0 >= n_vis) return;
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h);
+  const bool cull = conics != nullptr;
+  uint32_t carry = cum_sorted[j0];   // output offset of the workgroup's first row
+  for (uint32_t base = 0; base < R; base += kIsectBlock) {   // uniform trip count: the scan below has barriers
+    const uint32_t r = base + threadIdx.x;
+    int lo = 0, hi = 0;
+    uint32_t id = 0, key0 = 0;
+    if (r < R) {
+      const int g = row_owner(S, r);
+      const int ty = S.y0[g] + (int)(r - S.rowoff[g]);
+      row_span_of(S, g, ty, cull, tile_size, lo, hi);
+      id = S.id[g];
+      key0 = S.cam_base[g] + (uint32_t)(ty * tile_w);
+    }
+    const uint32_t c = hi > lo ? (uint32_t)(hi - lo) : 0u;
+    uint32_t total;
+    uint32_t off = carry + block_excl_scan(c, total, S.lw);
+    carry += total;
+    for (int tx = lo; tx < hi; tx++) {
+      keys[off] = key0 + (uint32_t)tx;
+      vals[off] = id;
+      off++;
+    }
+  }
+}
+
+// emit (camera*tiles + tile, cam*N+gaussian) pairs in depth order (one thread per Gaussian; option 5 = 0)
 __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(const uint64_t *__restrict__ n_vis_dev, int64_t N,
                                                                 const uint32_t *__restrict__ sorted_idx,
                                                                 const uint32_t *__restrict__ cum_sorted,
@@ -831,8 +964,12 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
     BDS_LAUNCH_CHECK();
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
-    hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+    if (option_get(kOptRowItems))
+      hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
+                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+    else
+      hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
+                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
     BDS_LAUNCH_CHECK();
   } else {
     // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
@@ -897,8 +1034,12 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d
   if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
   else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
-  hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                     P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
+  if (option_get(kOptRowItems))
+    hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
+                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
+  else
+    hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
+                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
   BDS_LAUNCH_CHECK();
   uint32_t *kin = k_emit, *vin = v_emit;
   for (int p = 0; p < npass; p++) {

@@ -47,7 +47,9 @@ const char *bds_strerror(int code);
  * 2 = composite forward (0: 4 waves/tile, 1 pixel/lane; 1: one wave/tile, 4 pixels/lane (row strips);
  *     2: one wave/tile, quadrant-masked);
  * 4 = depth ordering of the visible entries (1: two-launch radix passes with workgroup-derived bases, compaction
- *     fused with its scan [default]; 0: generic histogram / scan / scatter passes).  Defaults: see csrc/api.hip. */
+ *     fused with its scan [default]; 0: generic histogram / scan / scatter passes);
+ * 5 = counting / emission of the (tile, id) pairs (1: one work item per tile ROW of a Gaussian [default];
+ *     0: one thread per Gaussian).  Defaults: see csrc/api.hip. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 

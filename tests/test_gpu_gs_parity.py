@@ -179,11 +179,13 @@ def test_isect_tiles_one_call_and_capacity(ops):
             assert torch.equal(fids2, fids_ref) and torch.equal(offs, offs_ref)
 
 
-@pytest.mark.parametrize("short", [1, 0], ids=["short_sort", "generic_sort"])
-def test_isect_short_sort_option(ops, short):
-    """Both depth-ordering paths give the oracle's lists (the default path is covered by test_isect_bit_exact)."""
+@pytest.mark.parametrize("short,rows", [(1, 1), (0, 1), (1, 0)], ids=["short_sort", "generic_sort", "thread_per_gaussian"])
+def test_isect_short_sort_option(ops, short, rows):
+    """Both depth-ordering paths and both work decompositions of counting / emission give the oracle's lists, with and
+    without exact tile culling (the default combination is also covered by test_isect_bit_exact)."""
     from bilateral_driving_amd import _lib as L
     L.set_option(L.OPT_SHORT_SORT, short)
+    L.set_option(L.OPT_ROW_ITEMS, rows)
     try:
         for seed, N, W, H in ((0, 9000, 320, 200), (1, 70000, 640, 368)):
             sc = make_scene(N, W, H, seed=seed)
@@ -193,8 +195,17 @@ def test_isect_short_sort_option(ops, short):
             tpg, iids, fids, offs = ops.isect_tiles(m2, radii, d, 16, tw, th)
             tpg_o, iids_o, fids_o = G.isect_tiles(m2[0].cpu(), radii[0].cpu(), d[0].cpu(), 16, tw, th)
             assert torch.equal(tpg[0].cpu(), tpg_o) and torch.equal(iids.cpu(), iids_o) and torch.equal(fids.cpu(), fids_o)
+            # culled lists: identical between the variants (reference = the default variant)
+            op = sc["opacities"].cuda()[None].contiguous()
+            got = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con, opacities=op)
+            L.set_option(L.OPT_SHORT_SORT, 1); L.set_option(L.OPT_ROW_ITEMS, 1)
+            ref = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con, opacities=op)
+            L.set_option(L.OPT_SHORT_SORT, short); L.set_option(L.OPT_ROW_ITEMS, rows)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
     finally:
         L.set_option(L.OPT_SHORT_SORT, 1)
+        L.set_option(L.OPT_ROW_ITEMS, 1)
 
 
 def test_meta_isect_ids_lazy_equals_kernel(ops):
