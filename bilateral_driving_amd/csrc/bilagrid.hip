@@ -243,6 +243,96 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
   d[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
 }
 
+
+// ---- C+D1 fused: full-resolution backward with the x pass of the up-sampler adjoint done in LDS -------------
+// A workgroup owns `stride` = 256 - 2*halo consecutive pixels of ONE image row and also evaluates `halo` pixels on
+// either side, so that every low-res column anchored in its range finds all of its taps (a column's support is its
+// anchor +- (scale + 2)) among the workgroup's own pixels: P and Q (6 floats per pixel and level) never travel
+// through global memory, and the x reduction reads them from LDS.  Arithmetic and summation order are those of
+// ms_apply_bwd_kernel + ms_adjoint_x_kernel (the halo pixels are recomputed, ~7 % extra work at factor 4).
+template <int NL>
+__global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
+                                                                 float *__restrict__ v_in, int halo, int nbx) {
+  __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
+  const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
+  const int stride = kBgBlock - 2 * halo;
+  const int own0 = bx * stride, own1 = min(p.W, own0 + stride);
+  const int xs = own0 - halo;
+  const int x = xs + (int)threadIdx.x;
+  if (x >= 0 && x < p.W) {
+    const int64_t pix = (int64_t)y * p.W + x;
+    const bool owner = x >= own0 && x < own1;
+    float r, g, b;
+    load_input(p, y, x, r, g, b);
+    float A[NL][12];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (l < p.nlevels) {
+        sP[l][0][threadIdx.x] = r; sP[l][1][threadIdx.x] = g; sP[l][2][threadIdx.x] = b;
+        if (owner && p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {  // level without up-sampling: the low-res kernel reads P, Q
+          float *P = p.lv[l].P + pix * 3;
+          P[0] = r; P[1] = g; P[2] = b;
+        }
+        upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
+        apply_affine(A[l], r, g, b);
+      }
+    }
+    float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
+#pragma unroll
+    for (int l = NL - 1; l >= 0; l--) {
+      if (l < p.nlevels) {
+        sQ[l][0][threadIdx.x] = v0; sQ[l][1][threadIdx.x] = v1; sQ[l][2][threadIdx.x] = v2;
+        if (owner && p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {
+          float *Q = p.lv[l].Q + pix * 3;
+          Q[0] = v0; Q[1] = v1; Q[2] = v2;
+        }
+        const float n0 = A[l][0] * v0 + A[l][4] * v1 + A[l][8] * v2;
+        const float n1 = A[l][1] * v0 + A[l][5] * v1 + A[l][9] * v2;
+        const float n2 = A[l][2] * v0 + A[l][6] * v1 + A[l][10] * v2;
+        v0 = n0; v1 = n1; v2 = n2;
+      }
+    }
+    if (owner) { v_in[pix * p.cs] = v0; v_in[pix * p.cs + 1] = v1; v_in[pix * p.cs + 2] = v2; }
+  }
+  __syncthreads();
+  // x pass: candidate columns of every up-sampled level, one item per thread
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l >= p.nlevels) break;
+    const LevelDev &L = p.lv[l];
+    if (L.Wd == p.W && L.Hd == p.H) continue;
+    const float sc = (float)p.W / (float)L.Wd;
+    const int cx0 = max(0, (int)((float)own0 / sc) - 2);
+    const int ncand = (int)((float)stride / sc) + 5;
+    for (int t = threadIdx.x; t < ncand; t += kBgBlock) {
+      const int cx = cx0 + t;
+      if (cx >= L.Wd) continue;
+      const int anchor = min(p.W - 1, (int)(((float)cx + 0.5f) * sc));
+      if (anchor < own0 || anchor >= own0 + stride) continue;   // owned by a neighbour
+      int xlo, xhi;
+      adjoint_range(cx, p.W, L.Wd, xlo, xhi);
+      float acc[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = 0.f;
+      for (int xx = xlo; xx <= xhi; xx++) {
+        const Tap tx = resample_tap(xx, p.W, L.Wd);
+        const float w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
+        const int k = xx - xs;   // inside the window by construction (halo >= scale + 2)
+        const float p0 = sP[l][0][k], p1 = sP[l][1][k], p2 = sP[l][2][k];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const float q = sQ[l][r][k] * w;
+          acc[r * 4 + 0] += q * p0; acc[r * 4 + 1] += q * p1; acc[r * 4 + 2] += q * p2; acc[r * 4 + 3] += q;
+        }
+      }
+      float4 *d = reinterpret_cast<float4 *>(L.R + ((int64_t)y * L.Wd + cx) * 12);
+      d[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      d[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      d[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    }
+  }
+}
+
 // wave64 sum leaving the result in every lane (used only on wave-uniform-address grid updates)
 __device__ __forceinline__ float wave_sum_all(float v) {
 #pragma unroll
@@ -683,29 +773,53 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   p.cs = cs; p.v_depth = v_depth; p.v_alpha_in = v_alpha_in;
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
-  {
-    const dim3 grid((unsigned)cdiv(HW, kBgBlock)), block(kBgBlock);
-    switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_bwd_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
-      case 2: hipLaunchKernelGGL((ms_apply_bwd_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
-      case 3: hipLaunchKernelGGL((ms_apply_bwd_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
-      case 4: hipLaunchKernelGGL((ms_apply_bwd_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
-    }
+  // fused x pass when some level is up-sampled and the widest support fits the workgroup's halo
+  float smax = 1.f;
+  bool any_up = false;
+  for (int l = 0; l < nlevels; l++) {
+    if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
+    any_up = true;
+    const float sc = (float)W / (float)p.lv[l].Wd;
+    if (sc > smax) smax = sc;
   }
-  BDS_LAUNCH_CHECK();
-  {  // x pass of the up-sampler adjoint, all up-sampled levels in one launch
-    LevelSched sc{};
-    for (int l = 0; l < nlevels; l++) {
-      if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
-      const int k = sc.n++;
-      sc.level[k] = l;
-      sc.nblk[k] = (int)cdiv((int64_t)H * p.lv[l].Wd, kBgBlock);
-      sc.blk_off[k + 1] = sc.blk_off[k] + sc.nblk[k];
+  const int halo = (int)ceilf(smax) + 2;
+  if (any_up && halo <= 48 && !(option_get(kOptDebug) & 8)) {
+    const int stride = kBgBlock - 2 * halo;
+    const int nbx = (int)cdiv(W, stride);
+    const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
+    switch (nlevels) {
+      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
     }
-    if (sc.n > 0) {
-      hipLaunchKernelGGL(ms_adjoint_x_kernel, dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), 0, st, p, sc);
-      BDS_LAUNCH_CHECK();
+    BDS_LAUNCH_CHECK();
+  } else {
+    {
+      const dim3 grid((unsigned)cdiv(HW, kBgBlock)), block(kBgBlock);
+      switch (nlevels) {
+        case 1: hipLaunchKernelGGL((ms_apply_bwd_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+        case 2: hipLaunchKernelGGL((ms_apply_bwd_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+        case 3: hipLaunchKernelGGL((ms_apply_bwd_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+        case 4: hipLaunchKernelGGL((ms_apply_bwd_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+        default: hipLaunchKernelGGL((ms_apply_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb); break;
+      }
+    }
+    BDS_LAUNCH_CHECK();
+    {  // x pass of the up-sampler adjoint, all up-sampled levels in one launch
+      LevelSched sc{};
+      for (int l = 0; l < nlevels; l++) {
+        if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
+        const int k = sc.n++;
+        sc.level[k] = l;
+        sc.nblk[k] = (int)cdiv((int64_t)H * p.lv[l].Wd, kBgBlock);
+        sc.blk_off[k + 1] = sc.blk_off[k] + sc.nblk[k];
+      }
+      if (sc.n > 0) {
+        hipLaunchKernelGGL(ms_adjoint_x_kernel, dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), 0, st, p, sc);
+        BDS_LAUNCH_CHECK();
+      }
     }
   }
   const MsLayout ML = ms_layout(nlevels, levels, H, W);
