@@ -110,8 +110,10 @@ class _FusedView(torch.autograd.Function):
                                           L.ptr(last_ids), st), "bds_rasterize_fwd")
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         grids = [g.contiguous() for g in grids]
+        idx = cfg.get("img_idx")
+        sel = grids if idx is None else [g[idx:idx + 1] for g in grids]   # views: the level struct takes their addresses
         factors = cfg["factors"]
-        lv = _levels_struct(grids, None, factors)
+        lv = _levels_struct(sel, None, factors)
         bws_bytes = lib.bds_bilagrid_ms_workspace_bytes(len(grids), lv, H, W)
         bws = _empty((bws_bytes,), dev, torch.uint8)
         rgb, depth = _empty((H, W, 3), dev), _empty((H, W, 1), dev)
@@ -143,8 +145,18 @@ class _FusedView(torch.autograd.Function):
         tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
         # colour transform
         need_g = ctx.needs_input_grad[7:]
-        v_grids = [torch.zeros_like(g) if need_g[i] else None for i, g in enumerate(grids)]
-        lv = _levels_struct(list(grids), v_grids, cfg["factors"])
+        # grid gradients: one zero fill for all levels; with img_idx the full [n_img, ...] gradient is returned with only that
+        # image's slice written (no slice-backward / scatter in the autograd graph)
+        sizes = [(g.numel() + 3) // 4 * 4 if need_g[i] else 0 for i, g in enumerate(grids)]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32) if sum(sizes) else None
+        v_grids, off = [], 0
+        for i, g in enumerate(grids):
+            v_grids.append(flat[off:off + g.numel()].view(g.shape) if need_g[i] else None)
+            off += sizes[i]
+        idx = cfg.get("img_idx")
+        sel = list(grids) if idx is None else [g[idx:idx + 1] for g in grids]
+        v_sel = v_grids if idx is None else [None if v is None else v[idx:idx + 1] for v in v_grids]
+        lv = _levels_struct(sel, v_sel, cfg["factors"])
         v_rgb = torch.zeros(H, W, 3, device=dev) if v_rgb is None else v_rgb.contiguous()
         v_depth = None if v_depth is None else v_depth.contiguous()
         v_opacity = None if v_opacity is None else v_opacity.contiguous()
@@ -193,9 +205,12 @@ class _FusedView(torch.autograd.Function):
 def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor],
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
-               grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None):
+               grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
+               img_idx: Optional[int] = None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
-    grids: per level [1,12,L,gy,gx] (the current image's grids).  Returns dict(rgb, depth, opacity, rgb_gaussians, info).
+    grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
+    [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
+    parameter's shape.  Returns dict(rgb, depth, opacity, rgb_gaussians, info).
 
     ``grad_arena`` (optional): name -> preallocated tensor; the backward kernels write the parameter gradients
     straight into these (e.g. slices of the flat all-reduce buffer of ``dist.FlatGradients``) instead of fresh
@@ -205,7 +220,8 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), viewmat=viewmat, K=K, cam_pos=cam_pos, factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
-               eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena)
+               eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena,
+               img_idx=None if img_idx is None else int(img_idx))
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky, *gs)
     rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets = out

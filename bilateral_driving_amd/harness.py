@@ -94,10 +94,9 @@ def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor],
     (fused_view.py) by default, or the chain of individual operators (render_view_staged) when FUSED is off."""
     if not FUSED:
         return render_view_staged(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
-    grids_k = [g[img_idx:img_idx + 1] for g in grids]
-    return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids_k, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
+    return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL,
-                      grad_arena=grad_arena)
+                      grad_arena=grad_arena, img_idx=img_idx)
 
 
 def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
