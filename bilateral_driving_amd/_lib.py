@@ -39,9 +39,10 @@ _SIGS = {
     "bds_project_bwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_isect_prepare_workspace_bytes": (_sz, [_i, _i64]),
     "bds_isect_build_workspace_bytes": (_sz, [_i, _i64, _i64]),
-    "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), _f]),
-    "bds_isect_build": (_i, [_i, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f]),
-    "bds_isect_tiles": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _sz, _i64, _f, _f, _f, C.POINTER(C.c_int64), _f]),
+    "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _f]),
+    "bds_isect_build": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f]),
+    "bds_isect_tiles": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _sz, _i64, _f, _f, _f, C.POINTER(C.c_int64),
+                             C.POINTER(C.c_int64), _f]),
     "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
                                _f, _f, _f, _f, _f]),
@@ -94,7 +95,7 @@ def lib():
     return _lib
 
 
-OPT_RASTER_BWD, OPT_RADIX, OPT_RASTER_FWD, OPT_SHORT_SORT, OPT_ROW_ITEMS = 0, 1, 2, 4, 5
+OPT_RASTER_BWD, OPT_RADIX, OPT_RASTER_FWD, OPT_SHORT_SORT, OPT_ROW_ITEMS, OPT_PACKED = 0, 1, 2, 4, 5, 6
 ECAPACITY = -4
 
 

@@ -92,7 +92,7 @@ __device__ __forceinline__ float butterfly_sum16(const float *v, int lane) {
 }
 
 // run-time selectable kernel variants (bds_set_option): A/B measurement and bisecting
-enum Option { kOptRasterBwd = 0, kOptRadix = 1, kOptRasterFwd = 2, kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptRowItems = 5, kOptCount = 8 };
+enum Option { kOptRasterBwd = 0, kOptRadix = 1, kOptRasterFwd = 2, kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptRowItems = 5, kOptPacked = 6, kOptCount = 8 };
 int option_get(int which);
 
 }  // namespace bds

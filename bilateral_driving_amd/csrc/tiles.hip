@@ -377,6 +377,84 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
   }
 }
 
+// Keys-only form of the digit-ordered scatter, for the PACKED tile lists: an entry is one 32-bit word
+// (tile << rank_bits | depth rank of the Gaussian among the visible ones), so a pass moves 4 bytes per entry instead
+// of 8.  On the last pass (`unpack` != null) the Gaussian id of every entry is looked up from its rank and written
+// to vals_out next to the packed word.
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
+    const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
+    uint32_t rank_mask, uint32_t *__restrict__ vals_out) {
+  const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
+  if (bbase >= n) return;
+  __shared__ uint32_t wrun[kSortWaves][256];
+  __shared__ uint32_t dstart[256], gbase[256];
+  __shared__ uint32_t lw[kSortBlock / kWave + 1];
+  __shared__ uint32_t lk[kSortChunk];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
+  __syncthreads();
+  constexpr int kPerWave = kSortChunk / kSortWaves;
+  const int64_t wbase = bbase + (int64_t)wv * kPerWave;
+  uint32_t k[kSortRounds];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    k[r] = 0xFFFFFFFFu;
+    if (i < n) {
+      k[r] = keys_in[i];
+      atomicAdd(&wrun[wv][(k[r] >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) tot += wrun[w][tid];
+    uint32_t all;
+    uint32_t base = block_excl_scan(tot, all, lw);
+    dstart[tid] = base;
+    gbase[tid] = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+      const uint32_t c = wrun[w][tid];
+      wrun[w][tid] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    const bool on = i < n;
+    const uint32_t d = (k[r] >> shift) & mask;
+    unsigned long long peers = __ballot(on);
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt);
+    uint32_t pos = 0;
+    if (on) pos = wrun[wv][d];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (on) lk[pos + rank] = k[r];
+  }
+  __syncthreads();
+  const int cnt = (int)((n - bbase) < (int64_t)kSortChunk ? (n - bbase) : (int64_t)kSortChunk);
+  for (int i = tid; i < cnt; i += kSortBlock) {
+    const uint32_t kk = lk[i];
+    const uint32_t d = (kk >> shift) & mask;
+    const uint32_t g = gbase[d] + ((uint32_t)i - dstart[d]);
+    keys_out[g] = kk;
+    if (unpack) vals_out[g] = unpack[kk & rank_mask];
+  }
+}
+
 static size_t radix_temp_elems(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
   const size_t h = align_up((size_t)256 * nblocks, 4);
@@ -408,6 +486,25 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
   return BDS_OK;
 }
 
+
+static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int shift, int bits, uint32_t *temp, hipStream_t st,
+                           const uint32_t *unpack, uint32_t rank_mask, uint32_t *vout) {
+  if (n == 0) return BDS_OK;
+  const int nblocks = (int)cdiv(n, kSortChunk);
+  const uint32_t mask = (1u << bits) - 1u;
+  const int64_t hn = (int64_t)(mask + 1) * nblocks;
+  uint32_t *hist = temp;
+  uint32_t *stemp = temp + align_up((size_t)256 * nblocks, 4);
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, (const uint64_t *)nullptr, shift, mask,
+                     nblocks, hist);
+  BDS_LAUNCH_CHECK();
+  int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
+  if (rc != BDS_OK) return rc;
+  hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks, hist,
+                     kout, unpack, rank_mask, vout);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // short sort: the same stable LSD pass in TWO launches, for inputs whose length lives on the device
@@ -752,7 +849,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
     const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ cum_sorted,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ vals) {
+    uint32_t *__restrict__ vals, int pack_shift) {
   __shared__ RowStage S;
   const int64_t n_vis = (int64_t)*n_vis_dev;
   const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
@@ -770,15 +867,20 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
       row_span_of(S, g, ty, cull, tile_size, lo, hi);
       id = S.id[g];
       key0 = S.cam_base[g] + (uint32_t)(ty * tile_w);
+      if (pack_shift) id = (uint32_t)(j0 + g);   // packed lists carry the depth rank, not the Gaussian id
     }
     const uint32_t c = hi > lo ? (uint32_t)(hi - lo) : 0u;
     uint32_t total;
     uint32_t off = carry + block_excl_scan(c, total, S.lw);
     carry += total;
-    for (int tx = lo; tx < hi; tx++) {
-      keys[off] = key0 + (uint32_t)tx;
-      vals[off] = id;
-      off++;
+    if (pack_shift) {
+      for (int tx = lo; tx < hi; tx++) keys[off++] = ((key0 + (uint32_t)tx) << pack_shift) | id;
+    } else {
+      for (int tx = lo; tx < hi; tx++) {
+        keys[off] = key0 + (uint32_t)tx;
+        vals[off] = id;
+        off++;
+      }
     }
   }
 }
@@ -828,24 +930,25 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(const uint64_t 
 
 
 // offsets[t] = first index whose key >= t  (lower bound; empty tiles point at the next run)
-__global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M, const uint32_t *__restrict__ keys,
+// (key_shift: the tile key sits above the rank bits of a packed entry)
+__global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M, const uint32_t *__restrict__ keys, int key_shift,
                                                                    int n_tiles_total, int32_t *__restrict__ offsets) {
   const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (i > M) return;
   // thread i < M closes the gap (key[i-1], key[i]]; thread M closes (key[M-1], n_tiles)
-  const int64_t lo = i == 0 ? 0 : (int64_t)keys[i - 1] + 1;
-  const int64_t hi = i == M ? (int64_t)n_tiles_total - 1 : (int64_t)keys[i];
+  const int64_t lo = i == 0 ? 0 : (int64_t)(keys[i - 1] >> key_shift) + 1;
+  const int64_t hi = i == M ? (int64_t)n_tiles_total - 1 : (int64_t)(keys[i] >> key_shift);
   for (int64_t t = lo; t <= hi; t++) offsets[t] = (int32_t)i;
 }
 
-__global__ __launch_bounds__(kIsectBlock) void isect_ids_kernel(int64_t M, const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(kIsectBlock) void isect_ids_kernel(int64_t M, const uint32_t *__restrict__ keys, int key_shift,
                                                                const int32_t *__restrict__ flatten_ids,
                                                                const float *__restrict__ depths,
                                                                int64_t *__restrict__ isect_ids) {
   const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (i >= M) return;
   const uint32_t d = __float_as_uint(depths[flatten_ids[i]]);
-  isect_ids[i] = (int64_t)(((uint64_t)keys[i] << 32) | (uint64_t)d);
+  isect_ids[i] = (int64_t)(((uint64_t)(keys[i] >> key_shift) << 32) | (uint64_t)d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -924,8 +1027,9 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
 extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                                  const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                                  int32_t *tiles_per_gauss, void *ws,
-                                 size_t ws_bytes, int64_t *n_isects, bds_stream_t stream) {
+                                 size_t ws_bytes, int64_t *n_isects, int64_t *n_visible, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && n_isects);
+  if (n_visible) *n_visible = 0;
   const int64_t CN = (int64_t)C * N;
   BDS_REQUIRE(CN < (int64_t)1 << 31);
   BDS_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)1 << 31);
@@ -997,14 +1101,15 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   // 4. exclusive scan of the counts (offset of every entry's run) and the total M
   rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
   if (rc != BDS_OK) return rc;
-  uint64_t total = 0;
-  if (hipMemcpyAsync(&total, L.total, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
+  uint64_t total[2] = {0, 0};   // M, visible entries
+  if (hipMemcpyAsync(total, L.total, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return BDS_ELAUNCH;
-  *n_isects = (int64_t)total;
+  *n_isects = (int64_t)total[0];
+  if (n_visible) *n_visible = (int64_t)total[1];
   return BDS_OK;
 }
 
-extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int32_t *radii,
+extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float *means2d, const int32_t *radii,
                                const float *depths, const float *conics, const float *opacities, int tile_size,
                                int tile_w, int tile_h, const void *ws,
                                size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
@@ -1028,36 +1133,65 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d
   while (((int64_t)1 << nbits) < n_tiles_total) nbits++;
   const int npass = (nbits + 7) / 8;
   const int bits_per = (nbits + npass - 1) / npass;
-  // buffers: pass outputs alternate so that the LAST pass writes values into flatten_ids
-  uint32_t *fl = reinterpret_cast<uint32_t *>(flatten_ids);
-  uint32_t *k_emit, *v_emit;
-  if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
-  else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
-  if (option_get(kOptRowItems))
+  uint32_t *fl = reinterpret_cast<uint32_t *>(flatten_ids);
+  // Packed lists: when the depth rank of every visible entry fits next to the tile key in ONE 32-bit word
+  // (tile << rank_bits | rank), the sort moves 4 bytes per entry instead of 8 and the Gaussian ids are looked up from
+  // the ranks while the last pass writes out.  Same order: entries are emitted by increasing rank and the passes are stable.
+  const int rank_bits = 32 - nbits;
+  const bool packed = n_visible >= 0 && rank_bits >= 1 && n_visible <= ((int64_t)1 << rank_bits) && option_get(kOptRadix) == 2 &&
+                      option_get(kOptRowItems) && option_get(kOptPacked);
+  int key_shift = 0;
+  uint32_t *kin;
+  if (packed) {
+    key_shift = rank_bits;
+    uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
-  else
-    hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
-  BDS_LAUNCH_CHECK();
-  uint32_t *kin = k_emit, *vin = v_emit;
-  for (int p = 0; p < npass; p++) {
-    uint32_t *kout = (kin == B.ka) ? B.kb : B.ka;
-    uint32_t *vout = (vin == B.va) ? fl : B.va;
-    int bits = bits_per;
-    if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
-    int rc = radix_pass(kin, vin, kout, vout, M, bits_per * p, bits, B.temp, st);
-    if (rc != BDS_OK) return rc;
-    kin = kout; vin = vout;
+                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits);
+    BDS_LAUNCH_CHECK();
+    kin = k_emit;
+    const uint32_t rank_mask = (1u << rank_bits) - 1u;
+    for (int p = 0; p < npass; p++) {
+      uint32_t *kout = (kin == B.ka) ? B.kb : B.ka;
+      int bits = bits_per;
+      if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
+      const bool last = p == npass - 1;
+      int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, last ? P.va : nullptr, rank_mask,
+                               last ? fl : nullptr);
+      if (rc != BDS_OK) return rc;
+      kin = kout;
+    }
+  } else {
+    // buffers: pass outputs alternate so that the LAST pass writes values into flatten_ids
+    uint32_t *k_emit, *v_emit;
+    if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
+    else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
+    if (option_get(kOptRowItems))
+      hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
+                         P.va, P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0);
+    else
+      hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
+                         P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
+    BDS_LAUNCH_CHECK();
+    kin = k_emit;
+    uint32_t *vin = v_emit;
+    for (int p = 0; p < npass; p++) {
+      uint32_t *kout = (kin == B.ka) ? B.kb : B.ka;
+      uint32_t *vout = (vin == B.va) ? fl : B.va;
+      int bits = bits_per;
+      if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
+      int rc = radix_pass(kin, vin, kout, vout, M, bits_per * p, bits, B.temp, st);
+      if (rc != BDS_OK) return rc;
+      kin = kout; vin = vout;
+    }
   }
-  // now kin == B.kb (sorted tile keys), vin == flatten_ids
-  hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin,
+  // now kin == B.kb (sorted tile keys, or packed words), flatten_ids holds the Gaussian ids
+  hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
                      n_tiles_total, isect_offsets);
   BDS_LAUNCH_CHECK();
   if (isect_ids) {
-    hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)cdiv(M, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, flatten_ids,
-                       depths, isect_ids);
+    hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)cdiv(M, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
+                       flatten_ids, depths, isect_ids);
     BDS_LAUNCH_CHECK();
   }
   return BDS_OK;
@@ -1067,13 +1201,15 @@ extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int
                                const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                                int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, void *ws2, size_t ws2_bytes,
                                int64_t flatten_capacity, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
-                               int64_t *n_isects, bds_stream_t stream) {
+                               int64_t *n_isects, int64_t *n_visible, bds_stream_t stream) {
   BDS_REQUIRE(flatten_capacity >= 0 && n_isects);
+  int64_t nvis_local = 0;
+  if (!n_visible) n_visible = &nvis_local;
   int rc = bds_isect_prepare(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws,
-                             ws_bytes, n_isects, stream);
+                             ws_bytes, n_isects, n_visible, stream);
   if (rc != BDS_OK) return rc;
   const int64_t M = *n_isects;
   if (M > flatten_capacity || (M > 0 && ws2_bytes < build_layout(nullptr, M).bytes)) return BDS_ECAPACITY;
-  return bds_isect_build(C, N, M, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws, ws_bytes, ws2,
+  return bds_isect_build(C, N, M, *n_visible, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws, ws_bytes, ws2,
                          ws2_bytes, isect_ids, flatten_ids, isect_offsets, stream);
 }

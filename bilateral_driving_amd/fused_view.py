@@ -65,7 +65,7 @@ class _FusedView(torch.autograd.Function):
         tiles_per_gauss = _empty((1, N), dev, torch.int32)
         ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
         ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
-        m = C.c_int64(0)
+        m, nv = C.c_int64(0), C.c_int64(0)
         isect_offsets = _empty((1, th, tw), dev, torch.int32)
         cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
         # Buffers for the lists are sized from the largest count this configuration has produced so far, so that the
@@ -80,7 +80,7 @@ class _FusedView(torch.autograd.Function):
             with L.timed("isect_tiles"):
                 rc = lib.bds_isect_tiles(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
                                          L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, cap, None, L.ptr(buf),
-                                         L.ptr(isect_offsets), C.byref(m), st)
+                                         L.ptr(isect_offsets), C.byref(m), C.byref(nv), st)
             if rc != L.ECAPACITY:
                 L.check(rc, "bds_isect_tiles")
                 flatten_ids = buf[:int(m.value)]
@@ -88,14 +88,14 @@ class _FusedView(torch.autograd.Function):
         else:
             with L.timed("isect_prepare"):
                 L.check(lib.bds_isect_prepare(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
-                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), st), "bds_isect_prepare")
+                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), C.byref(nv), st), "bds_isect_prepare")
         M = int(m.value)
         if flatten_ids is None:  # first call of this configuration, or the lists outgrew the expectation
             flatten_ids = _empty((M,), dev, torch.int32)
             ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
             ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
             with L.timed("isect_build"):
-                L.check(lib.bds_isect_build(1, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
+                L.check(lib.bds_isect_build(1, N, M, int(nv.value), L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
                                             ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten_ids), L.ptr(isect_offsets), st),
                         "bds_isect_build")
         if M + M // 16 > cap:

@@ -168,11 +168,12 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     tiles_per_gauss = torch.empty(Cn, N, device=dev, dtype=torch.int32)
     ws_bytes = lib.bds_isect_prepare_workspace_bytes(Cn, N)
     ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-    m = C.c_int64(0)
+    m, nv = C.c_int64(0), C.c_int64(0)
     with L.timed("isect_prepare"):
         L.check(lib.bds_isect_prepare(Cn, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
                                       tile_size, tile_width, tile_height,
-                                      L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), L.stream()), "bds_isect_prepare")
+                                      L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), C.byref(nv), L.stream()),
+                "bds_isect_prepare")
     M = int(m.value)
     flatten_ids = torch.empty(M, device=dev, dtype=torch.int32)
     isect_ids = torch.empty(M, device=dev, dtype=torch.int64) if want_isect_ids else None
@@ -180,7 +181,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     ws2_bytes = lib.bds_isect_build_workspace_bytes(Cn, N, M)
     ws2 = torch.empty(max(ws2_bytes, 16), device=dev, dtype=torch.uint8)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build(Cn, N, M, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
+        L.check(lib.bds_isect_build(Cn, N, M, int(nv.value), L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
                                     tile_size, tile_width, tile_height,
                                     L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, L.ptr(isect_ids), L.ptr(flatten_ids),
                                     L.ptr(isect_offsets), L.stream()), "bds_isect_build")

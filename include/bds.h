@@ -49,7 +49,9 @@ const char *bds_strerror(int code);
  * 4 = depth ordering of the visible entries (1: two-launch radix passes with workgroup-derived bases, compaction
  *     fused with its scan [default]; 0: generic histogram / scan / scatter passes);
  * 5 = counting / emission of the (tile, id) pairs (1: one work item per tile ROW of a Gaussian [default];
- *     0: one thread per Gaussian).  Defaults: see csrc/api.hip. */
+ *     0: one thread per Gaussian);
+ * 6 = packed 32-bit tile lists when the visible count allows (1 [default]; 0: always (key, id) pairs).
+ * Defaults: see csrc/api.hip. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 
@@ -103,10 +105,15 @@ size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M);
  * pixel centre can reach alpha >= 1/255 are dropped ("exact tile culling"): rendered images and
  * gradients are unchanged, M shrinks; when NULL the lists are gsplat's bounding-square lists.
  * tiles_per_gauss [C,N] i32 may be NULL (the per-Gaussian counts are then not written). */
+/* n_visible (may be NULL): number of (camera, Gaussian) entries with radii > 0.  Handing it to bds_isect_build
+ * (or -1 when unknown) lets the build use PACKED lists when every entry's depth rank fits next to the tile key in one
+ * 32-bit word (rank < 2^(32 - bits(C*tiles))): the tile sort then moves 4 bytes per entry instead of 8.  Same outputs. */
 int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                       const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
-                      int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *n_isects, bds_stream_t stream);
-int bds_isect_build(int C, int64_t N, int64_t M, const float *means2d, const int32_t *radii, const float *depths,
+                      int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *n_isects, int64_t *n_visible,
+                      bds_stream_t stream);
+int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float *means2d, const int32_t *radii,
+                    const float *depths,
                     const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h, const void *ws,
                     size_t ws_bytes, void *ws2,
                     size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
@@ -121,7 +128,7 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
                     const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                     int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, void *ws2, size_t ws2_bytes,
                     int64_t flatten_capacity, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
-                    int64_t *n_isects, bds_stream_t stream);
+                    int64_t *n_isects, int64_t *n_visible, bds_stream_t stream);
 
 /* ---- alpha compositing -------------------------------------------------------------------
  * rasterize_to_pixels stage of gsplat.rendering.rasterization; outputs consumed at

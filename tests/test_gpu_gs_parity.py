@@ -157,12 +157,12 @@ def test_isect_tiles_one_call_and_capacity(ops):
         iids = torch.full((max(cap, 1),), -7, dtype=torch.int64, device="cuda")
         offs = torch.full((1, th, tw), -7, dtype=torch.int32, device="cuda")
         tpg = torch.empty(1, N, dtype=torch.int32, device="cuda")
-        m = C.c_int64(-1)
+        m, nv = C.c_int64(-1), C.c_int64(-1)
         rc = lib.bds_isect_tiles(1, N, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th, L.ptr(tpg),
                                  L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, cap, L.ptr(iids), L.ptr(fids), L.ptr(offs), C.byref(m),
-                                 L.stream())
+                                 C.byref(nv), L.stream())
         torch.cuda.synchronize()
-        assert m.value == M
+        assert m.value == M and nv.value == int((radii > 0).sum())
         assert torch.equal(tpg, tpg_ref)
         if expect_ok:
             assert rc == 0
@@ -174,18 +174,20 @@ def test_isect_tiles_one_call_and_capacity(ops):
             # the prepared workspace is intact: the two-call continuation gives the reference lists
             ws2b = torch.empty(max(lib.bds_isect_build_workspace_bytes(1, N, M), 16), dtype=torch.uint8, device="cuda")
             fids2 = torch.empty(M, dtype=torch.int32, device="cuda")
-            L.check(lib.bds_isect_build(1, N, M, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
+            L.check(lib.bds_isect_build(1, N, M, -1 if cap == 0 else nv.value, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
                                         L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(fids2), L.ptr(offs), L.stream()), "build")
             assert torch.equal(fids2, fids_ref) and torch.equal(offs, offs_ref)
 
 
-@pytest.mark.parametrize("short,rows", [(1, 1), (0, 1), (1, 0)], ids=["short_sort", "generic_sort", "thread_per_gaussian"])
-def test_isect_short_sort_option(ops, short, rows):
+@pytest.mark.parametrize("short,rows,packed", [(1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)],
+                         ids=["short_sort", "generic_sort", "thread_per_gaussian", "pair_lists"])
+def test_isect_short_sort_option(ops, short, rows, packed):
     """Both depth-ordering paths and both work decompositions of counting / emission give the oracle's lists, with and
     without exact tile culling (the default combination is also covered by test_isect_bit_exact)."""
     from bilateral_driving_amd import _lib as L
     L.set_option(L.OPT_SHORT_SORT, short)
     L.set_option(L.OPT_ROW_ITEMS, rows)
+    L.set_option(L.OPT_PACKED, packed)
     try:
         for seed, N, W, H in ((0, 9000, 320, 200), (1, 70000, 640, 368)):
             sc = make_scene(N, W, H, seed=seed)
@@ -198,14 +200,15 @@ def test_isect_short_sort_option(ops, short, rows):
             # culled lists: identical between the variants (reference = the default variant)
             op = sc["opacities"].cuda()[None].contiguous()
             got = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con, opacities=op)
-            L.set_option(L.OPT_SHORT_SORT, 1); L.set_option(L.OPT_ROW_ITEMS, 1)
+            L.set_option(L.OPT_SHORT_SORT, 1); L.set_option(L.OPT_ROW_ITEMS, 1); L.set_option(L.OPT_PACKED, 1)
             ref = ops.isect_tiles(m2, radii, d, 16, tw, th, conics=con, opacities=op)
-            L.set_option(L.OPT_SHORT_SORT, short); L.set_option(L.OPT_ROW_ITEMS, rows)
+            L.set_option(L.OPT_SHORT_SORT, short); L.set_option(L.OPT_ROW_ITEMS, rows); L.set_option(L.OPT_PACKED, packed)
             for a, b in zip(got, ref):
                 assert torch.equal(a, b)
     finally:
         L.set_option(L.OPT_SHORT_SORT, 1)
         L.set_option(L.OPT_ROW_ITEMS, 1)
+        L.set_option(L.OPT_PACKED, 1)
 
 
 def test_meta_isect_ids_lazy_equals_kernel(ops):
