@@ -1024,16 +1024,15 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
   return build_layout(nullptr, M).bytes;
 }
 
-extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
-                                 const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
-                                 int32_t *tiles_per_gauss, void *ws,
-                                 size_t ws_bytes, int64_t *n_isects, int64_t *n_visible, bds_stream_t stream) {
-  BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && n_isects);
-  if (n_visible) *n_visible = 0;
+// enqueues the whole prepare stage; the counts (M, visible entries) end up in L.total on the device
+static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                           const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                           int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, bds_stream_t stream, uint64_t **counts_dev) {
+  BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0);
   const int64_t CN = (int64_t)C * N;
   BDS_REQUIRE(CN < (int64_t)1 << 31);
   BDS_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)1 << 31);
-  *n_isects = 0;
+  *counts_dev = nullptr;
   if (CN == 0) return BDS_OK;
   BDS_REQUIRE(means2d && radii && depths && ws);
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
@@ -1101,11 +1100,46 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   // 4. exclusive scan of the counts (offset of every entry's run) and the total M
   rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
   if (rc != BDS_OK) return rc;
+  *counts_dev = L.total;
+  return BDS_OK;
+}
+
+extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                                 const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                                 int32_t *tiles_per_gauss, void *ws,
+                                 size_t ws_bytes, int64_t *n_isects, int64_t *n_visible, bds_stream_t stream) {
+  BDS_REQUIRE(n_isects);
+  *n_isects = 0;
+  if (n_visible) *n_visible = 0;
+  uint64_t *counts_dev = nullptr;
+  int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
+                           stream, &counts_dev);
+  if (rc != BDS_OK || counts_dev == nullptr) return rc;
+  hipStream_t st = as_stream(stream);
   uint64_t total[2] = {0, 0};   // M, visible entries
-  if (hipMemcpyAsync(total, L.total, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
+  if (hipMemcpyAsync(total, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return BDS_ELAUNCH;
   *n_isects = (int64_t)total[0];
   if (n_visible) *n_visible = (int64_t)total[1];
+  return BDS_OK;
+}
+
+extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                                       const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                                       int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *counts_pinned,
+                                       void *event, bds_stream_t stream) {
+  BDS_REQUIRE(counts_pinned && event);
+  uint64_t *counts_dev = nullptr;
+  int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
+                           stream, &counts_dev);
+  if (rc != BDS_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  if (counts_dev == nullptr) {
+    counts_pinned[0] = 0; counts_pinned[1] = 0;
+  } else if (hipMemcpyAsync(counts_pinned, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) {
+    return BDS_ELAUNCH;
+  }
+  if (hipEventRecord(static_cast<hipEvent_t>(event), st) != hipSuccess) return BDS_ELAUNCH;
   return BDS_OK;
 }
 

@@ -29,6 +29,20 @@ def _empty(shape, dev, dtype=torch.float32):
     return torch.empty(shape, device=dev, dtype=dtype)
 
 
+_SYNC: Dict[torch.device, tuple] = {}
+
+
+def _host_sync_objects(dev):
+    """(page-locked int64[2], event) used to read the two list counts back without draining the stream."""
+    o = _SYNC.get(dev)
+    if o is None:
+        counts = torch.zeros(2, dtype=torch.int64).pin_memory()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))   # materialises the underlying hipEvent_t
+        o = _SYNC[dev] = (counts, ev)
+    return o
+
+
 _LIST_CAPACITY: Dict[tuple, int] = {}   # (N, W, H, culling) -> entries to provision for the intersection lists
 
 
@@ -52,12 +66,6 @@ class _FusedView(torch.autograd.Function):
                                              L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
                                              L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
                     "bds_project_view_fwd")
-        # SH colours of the visible Gaussians, packed with the depth channel (vanilla.py:384-389)
-        cam_pos = cfg["cam_pos"].contiguous()
-        sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
-        with L.timed("sh_fwd"):
-            L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
-                                        L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
         # tile ordering
         tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
         cull = cfg["tile_cull"]
@@ -65,42 +73,41 @@ class _FusedView(torch.autograd.Function):
         tiles_per_gauss = _empty((1, N), dev, torch.int32)
         ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
         ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
-        m, nv = C.c_int64(0), C.c_int64(0)
         isect_offsets = _empty((1, th, tw), dev, torch.int32)
         cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
-        # Buffers for the lists are sized from the largest count this configuration has produced so far, so that the
-        # library can go from counting to building without handing control back (the GPU idles during that hand-over).
+        counts, ev = _host_sync_objects(dev)
+        with L.timed("isect_prepare"):
+            L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
+                                                L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, st),
+                    "bds_isect_prepare_async")
+        # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
+        # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
+        cam_pos = cfg["cam_pos"].contiguous()
+        sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
+        with L.timed("sh_fwd"):
+            L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
+                                        L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
         key = (N, W, H, bool(cull))
         cap = _LIST_CAPACITY.get(key, 0)
-        flatten_ids = None
+        buf, ws2, ws2_bytes = None, None, 0
         if cap:
             buf = _empty((cap,), dev, torch.int32)
             ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
             ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-            with L.timed("isect_tiles"):
-                rc = lib.bds_isect_tiles(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
-                                         L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, cap, None, L.ptr(buf),
-                                         L.ptr(isect_offsets), C.byref(m), C.byref(nv), st)
-            if rc != L.ECAPACITY:
-                L.check(rc, "bds_isect_tiles")
-                flatten_ids = buf[:int(m.value)]
-            del buf
-        else:
-            with L.timed("isect_prepare"):
-                L.check(lib.bds_isect_prepare(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
-                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), C.byref(nv), st), "bds_isect_prepare")
-        M = int(m.value)
-        if flatten_ids is None:  # first call of this configuration, or the lists outgrew the expectation
-            flatten_ids = _empty((M,), dev, torch.int32)
+        ev.synchronize()
+        M, n_vis = int(counts[0]), int(counts[1])
+        if M > cap or buf is None:   # first call of this configuration, or the lists outgrew the expectation
+            buf = _empty((M,), dev, torch.int32)
             ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
             ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-            with L.timed("isect_build"):
-                L.check(lib.bds_isect_build(1, N, M, int(nv.value), L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
-                                            ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten_ids), L.ptr(isect_offsets), st),
-                        "bds_isect_build")
+        flatten_ids = buf[:M]
+        with L.timed("isect_build"):
+            L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
+                                        ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten_ids), L.ptr(isect_offsets), st),
+                    "bds_isect_build")
         if M + M // 16 > cap:
             _LIST_CAPACITY[key] = M + M // 6 + 4096
-        del ws, ws2
+        del ws, ws2, buf
         # compositing (RGB + depth)
         render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
         last_ids = _empty((1, H, W), dev, torch.int32)

@@ -118,6 +118,14 @@ int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float 
                     size_t ws_bytes, void *ws2,
                     size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
                     bds_stream_t stream);
+/* Asynchronous prepare: same work, but instead of synchronising it copies {M, n_visible} into `counts_pinned`
+ * (int64[2], page-locked host memory) and records `event` (a hipEvent_t) on the stream.  The caller may enqueue
+ * independent work, then waits for the event, reads the counts and calls bds_isect_build: the GPU keeps running that
+ * work while the host sizes the lists. */
+int bds_isect_prepare_async(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                            const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                            int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *counts_pinned, void *event,
+                            bds_stream_t stream);
 /* One-call form: bds_isect_prepare and then, without returning to the caller in between, bds_isect_build into
  * buffers sized for an EXPECTED count (flatten_ids / isect_ids hold flatten_capacity entries, ws2 is
  * bds_isect_build_workspace_bytes(C, N, flatten_capacity)).  M <= flatten_capacity: BDS_OK, *n_isects = M, lists
