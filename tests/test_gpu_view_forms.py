@@ -1,0 +1,176 @@
+"""-m gpu: the one-view / RGB+ED / asynchronous entry points of the fused step against the general forms they fold
+together (which are themselves checked against the oracle in test_gpu_gs_parity.py / test_gpu_bilagrid_parity.py)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from tests.util import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import bilateral_driving_amd.gs_ops as ops
+    from bilateral_driving_amd import _lib as L
+    L.lib()
+    return ops, L
+
+
+def _scene(N, W, H, seed):
+    sc = make_scene(N, W, H, seed=seed)
+    d = {k: v.cuda() for k, v in sc.items()}
+    d["log_scales"] = d["scales"].log()
+    d["logits"] = torch.logit(d["opacities"].clamp(1e-4, 1 - 1e-4))
+    return d
+
+
+@pytest.mark.parametrize("seed,N,W,H", [(0, 3000, 320, 200), (1, 257, 96, 64)])
+def test_project_view_equals_general_form_with_activations(env, seed, N, W, H):
+    ops, L = env
+    lib, st = L.lib(), L.stream()
+    s = _scene(N, W, H, seed)
+    vm, K = s["viewmats"][0].contiguous(), s["Ks"][0].contiguous()
+    scales, opac = torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda")
+    radii = torch.empty(1, N, dtype=torch.int32, device="cuda")
+    m2, dep, con = torch.empty(1, N, 2, device="cuda"), torch.empty(1, N, device="cuda"), torch.empty(1, N, 3, device="cuda")
+    L.check(lib.bds_project_view_fwd(N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(s["log_scales"]), L.ptr(s["logits"]), L.ptr(vm), L.ptr(K),
+                                     W, H, 0.3, 0.01, 1e10, 0.0, L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(m2), L.ptr(dep), L.ptr(con), st), "fwd")
+    ref_scales, ref_opac = torch.exp(s["log_scales"]), torch.sigmoid(s["logits"])
+    assert torch.allclose(scales, ref_scales, rtol=2e-6, atol=0) and torch.allclose(opac, ref_opac, rtol=2e-6, atol=1e-7)
+    r2, rm2, rdep, rcon, _ = ops.fully_fused_projection(s["means"], s["quats"], scales, vm[None], K[None], W, H)
+    assert torch.equal(radii, r2) and torch.equal(m2, rm2) and torch.equal(dep, rdep) and torch.equal(con, rcon)
+    # backward: raw-parameter gradients == general backward chained with the activation derivatives
+    g = torch.Generator().manual_seed(seed)
+    vis = (radii[0] > 0)
+    v_m2 = torch.randn(1, N, 2, generator=g).cuda() * vis[None, :, None]
+    v_dep = torch.randn(1, N, generator=g).cuda() * vis[None]
+    v_con = torch.randn(1, N, 3, generator=g).cuda() * vis[None, :, None]
+    v_op = torch.randn(N, generator=g).cuda() * vis
+    out = [torch.full((N, k), 7.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 7.0, device="cuda")]
+    L.check(lib.bds_project_view_bwd(N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K), W, H, 0.3,
+                                     L.ptr(radii), L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), L.ptr(v_op), L.ptr(out[0]), L.ptr(out[1]),
+                                     L.ptr(out[2]), L.ptr(out[3]), st), "bwd")
+    ref = [torch.empty(N, k, device="cuda") for k in (3, 4, 3)]
+    L.check(lib.bds_project_bwd(1, N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(vm), L.ptr(K), W, H, 0.3, L.ptr(radii),
+                                L.ptr(con), None, L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), None, L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]),
+                                None, st), "ref bwd")
+    # (two separately compiled kernels: fused multiply-adds differ in the last bits, and the projection vjp cancels)
+    for a, b in ((out[0], ref[0]), (out[1], ref[1]), (out[2], ref[2] * scales)):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm())
+    assert torch.allclose(out[3], v_op * opac * (1 - opac), rtol=1e-6, atol=0)
+    assert float(out[0][~vis].abs().max()) == 0.0 and float(out[3][~vis].abs().max()) == 0.0   # culled: exact zeros
+
+
+@pytest.mark.parametrize("deg", [0, 3])
+def test_sh_view_equals_general_form_with_glue(env, deg):
+    ops, L = env
+    lib, st = L.lib(), L.stream()
+    N, W, H = 5000, 320, 200
+    s = _scene(N, W, H, 2)
+    radii, _, dep, _, _ = ops.fully_fused_projection(s["means"], s["quats"], s["scales"], s["viewmats"], s["Ks"], W, H)
+    g = torch.Generator().manual_seed(3)
+    sh = (torch.randn(N, 16, 3, generator=g) * 0.6).cuda()
+    cam_pos = torch.linalg.inv(s["viewmats"][0])[:3, 3].contiguous()
+    sh_rgb, colors = torch.empty(N, 3, device="cuda"), torch.empty(N, 4, device="cuda")
+    L.check(lib.bds_sh_view_fwd(N, 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(dep), L.ptr(sh_rgb),
+                                L.ptr(colors), st), "fwd")
+    vis = radii[0] > 0
+    dirs = s["means"] - cam_pos
+    ref = ops.spherical_harmonics(deg, dirs, sh, masks=vis)
+    assert torch.allclose(sh_rgb, ref, rtol=1e-5, atol=2e-6)   # separately compiled kernels: last-bit fma differences
+    assert torch.equal(colors[:, :3], (sh_rgb + 0.5).clamp(0, 1)) and torch.equal(colors[:, 3], dep[0])
+    assert bool(((ref[vis] + 0.5 < 0) | (ref[vis] + 0.5 > 1)).any())   # the clamp is exercised
+    v_col = torch.randn(N, 4, generator=g).cuda()
+    v_sh, v_dep = torch.full((N, 16, 3), 7.0, device="cuda"), torch.empty(N, device="cuda")
+    L.check(lib.bds_sh_view_bwd(N, 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col), L.ptr(v_sh),
+                                L.ptr(v_dep), st), "bwd")
+    x = sh_rgb + 0.5
+    v_rgb = (v_col[:, :3] * ((x >= 0) & (x <= 1))).contiguous()
+    ref_v = torch.empty(N, 16, 3, device="cuda")
+    mask8 = vis.to(torch.uint8)
+    L.check(lib.bds_sh_bwd(N, 16, deg, L.ptr(dirs.contiguous()), L.ptr(sh), L.ptr(mask8), L.ptr(v_rgb), L.ptr(ref_v), None, st), "ref bwd")
+    assert torch.allclose(v_sh, ref_v, rtol=1e-5, atol=2e-6) and torch.equal(v_dep, v_col[:, 3])
+    assert float(v_sh[~vis].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("H,W,use_sky", [(57, 91, True), (120, 200, False)])
+def test_bilagrid_ed_form_equals_rgb_form_plus_depth_normalise(env, H, W, use_sky):
+    ops, L = env
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.bilagrid import _levels_struct
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator().manual_seed(5)
+    render = (torch.rand(H, W, 4, generator=g) * 1.3).cuda()
+    alpha = torch.rand(H, W, generator=g).cuda()
+    alpha[0, :5] = 0.0   # alpha below the 1e-10 clamp
+    sky = torch.rand(H, W, 3, generator=g).cuda() if use_sky else None
+    grids = [x[1:2].contiguous().cuda() for x in Hn.make_grids(3, seed=4)]
+    factors = Hn.FACTORS_3
+    lv = _levels_struct(grids, None, factors)
+    wsb = lib.bds_bilagrid_ms_workspace_bytes(3, lv, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    rgb, depth = torch.empty(H, W, 3, device="cuda"), torch.empty(H, W, device="cuda")
+    L.check(lib.bds_bilagrid_ms_ed_fwd(3, lv, H, W, L.ptr(render), L.ptr(alpha), L.ptr(sky), L.ptr(ws), wsb, L.ptr(rgb), L.ptr(depth), st), "ed fwd")
+    rgb3 = render[..., :3].contiguous()
+    ws2 = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    ref = torch.empty(H, W, 3, device="cuda")
+    L.check(lib.bds_bilagrid_ms_fwd(3, lv, H, W, L.ptr(rgb3), L.ptr(alpha), L.ptr(sky), L.ptr(ws2), wsb, L.ptr(ref), None, st), "fwd")
+    assert torch.equal(rgb, ref)
+    assert torch.equal(depth, render[..., 3] / alpha.clamp(min=1e-10))
+    # backward
+    v_out = torch.randn(H, W, 3, generator=g).cuda()
+    v_depth, v_opac = torch.randn(H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    vg = [torch.zeros_like(x) for x in grids]
+    lvb = _levels_struct(grids, vg, factors)
+    v_render, v_alpha = torch.empty(H, W, 4, device="cuda"), torch.empty(H, W, device="cuda")
+    v_sky = torch.empty(H, W, 3, device="cuda") if use_sky else None
+    L.check(lib.bds_bilagrid_ms_ed_bwd(3, lvb, H, W, L.ptr(render), L.ptr(alpha), L.ptr(sky), L.ptr(ws), wsb, L.ptr(v_out), L.ptr(v_depth),
+                                       L.ptr(v_opac), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_sky), st), "ed bwd")
+    vg2 = [torch.zeros_like(x) for x in grids]
+    lvb2 = _levels_struct(grids, vg2, factors)
+    r_rgb, r_alpha = torch.empty(H, W, 3, device="cuda"), torch.zeros(H, W, device="cuda")
+    r_sky = torch.empty(H, W, 3, device="cuda") if use_sky else None
+    L.check(lib.bds_bilagrid_ms_bwd(3, lvb2, H, W, L.ptr(rgb3), L.ptr(alpha), L.ptr(sky), L.ptr(ws2), wsb, L.ptr(v_out), L.ptr(r_rgb),
+                                    L.ptr(r_alpha) if use_sky else None, L.ptr(r_sky), st), "bwd")
+    ac = alpha.clamp(min=1e-10)
+    assert torch.equal(v_render[..., :3], r_rgb)
+    assert torch.equal(v_render[..., 3], v_depth / ac)
+    exp_alpha = (r_alpha if use_sky else 0.0) + v_opac - torch.where(alpha >= 1e-10, render[..., 3] * v_depth / (ac * ac), torch.zeros_like(ac))
+    assert torch.allclose(v_alpha, exp_alpha, rtol=1e-5, atol=1e-6)
+    if use_sky:
+        assert torch.equal(v_sky, r_sky)
+    for a, b in zip(vg, vg2):   # LDS float atomics inside a workgroup: summation order is not fixed
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
+def test_isect_prepare_async_reports_the_same_counts(env):
+    ops, L = env
+    lib, st = L.lib(), L.stream()
+    N, W, H = 8000, 400, 240
+    s = _scene(N, W, H, 6)
+    radii, m2, d, con, _ = ops.fully_fused_projection(s["means"], s["quats"], s["scales"], s["viewmats"], s["Ks"], W, H)
+    op = s["opacities"][None].contiguous()
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg_ref, _, fids_ref, offs_ref = ops.isect_tiles(m2, radii, d, 16, tw, th, want_isect_ids=False, conics=con, opacities=op)
+    wsb = lib.bds_isect_prepare_workspace_bytes(1, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    counts = torch.full((2,), -1, dtype=torch.int64).pin_memory()
+    ev = torch.cuda.Event()
+    ev.record()
+    tpg = torch.empty(1, N, dtype=torch.int32, device="cuda")
+    L.check(lib.bds_isect_prepare_async(1, N, L.ptr(m2), L.ptr(radii), L.ptr(d), L.ptr(con), L.ptr(op), 16, tw, th, L.ptr(tpg), L.ptr(ws), wsb,
+                                        counts.data_ptr(), ev.cuda_event, st), "prepare_async")
+    ev.synchronize()
+    M, nv = int(counts[0]), int(counts[1])
+    assert M == fids_ref.numel() and nv == int((radii > 0).sum()) and torch.equal(tpg, tpg_ref)
+    ws2b = lib.bds_isect_build_workspace_bytes(1, N, M)
+    ws2 = torch.empty(max(ws2b, 16), dtype=torch.uint8, device="cuda")
+    fids, offs = torch.empty(M, dtype=torch.int32, device="cuda"), torch.empty(1, th, tw, dtype=torch.int32, device="cuda")
+    L.check(lib.bds_isect_build(1, N, M, nv, L.ptr(m2), L.ptr(radii), L.ptr(d), L.ptr(con), L.ptr(op), 16, tw, th, L.ptr(ws), wsb, L.ptr(ws2),
+                                ws2b, None, L.ptr(fids), L.ptr(offs), st), "build")
+    assert torch.equal(fids, fids_ref) and torch.equal(offs, offs_ref)
