@@ -717,25 +717,30 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
 
 // tiles touched by each visible entry, visited in depth order: cnt_sorted[j] feeds the scan that places every
 // entry's run of intersections (zero beyond the visible count), tiles_per_gauss[o] (optional, pre-zeroed) is the API output.
+// (also leaves the per-member record the row-item emission reads: see stage_rows)
 __global__ __launch_bounds__(kIsectBlock) void isect_count_sorted_kernel(
     int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
-    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted) {
+    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
+    float4 *__restrict__ rec) {
   const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (j >= CN) return;
   if (j >= (int64_t)*n_vis_dev) { cnt_sorted[j] = 0u; return; }
   const int64_t o = sorted_idx[j];
   const int r = radii[o];
   int cnt = 0;
-  int x0, y0, x1, y1;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  uint32_t nrows = 0;
+  float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
   const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
   if (conics == nullptr) {
     tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
     cnt = (x1 - x0) * (y1 - y0);
+    if (x1 > x0 && y1 > y0) nrows = (uint32_t)(y1 - y0);
   } else {
-    const float a = conics[o * 3], b = conics[o * 3 + 1], c = conics[o * 3 + 2];
-    float q_max;
+    a = conics[o * 3]; b = conics[o * 3 + 1]; c = conics[o * 3 + 2];
     if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
+      nrows = (uint32_t)(y1 - y0);
       for (int ty = y0; ty < y1; ty++) {
         int lo, hi;
         row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
@@ -745,8 +750,11 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_sorted_kernel(
   }
   cnt_sorted[j] = (uint32_t)cnt;
   if (tiles_per_gauss) tiles_per_gauss[o] = cnt;
+  const uint32_t cam_base = (uint32_t)(o / N) * (uint32_t)(tile_w * tile_h);
+  rec[j * 3] = make_float4(mx, my, a, b);
+  rec[j * 3 + 1] = make_float4(c, q_max, __int_as_float(x0), __int_as_float(x1));
+  rec[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float((uint32_t)o), __uint_as_float(cam_base));
 }
-
 
 // ---- row-parallel counting / emission ---------------------------------------------------------------------
 // One thread per Gaussian leaves most lanes idle: the tile rectangles of 64 depth-neighbours differ by an order of
@@ -764,34 +772,52 @@ struct RowStage {
   uint32_t lw[kIsectBlock / kWave + 1];
 };
 
+// Per-member record in depth order (12 words): the counting kernel gathers a member's attributes from the four
+// per-Gaussian arrays ONCE (4 scattered cache lines per member) and leaves the derived rectangle here; the emission
+// reads it back coalesced instead of gathering again, and is guaranteed to take the same decisions.
+constexpr int kRecWords = 12;
+
 // fills the stage for members j0 .. j0+255 of the depth order; returns the workgroup's number of row items
+// rec_out != null: compute from the attribute arrays and store the records; rec_in != null: load the records.
 __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t n_vis, int64_t N, const uint32_t *__restrict__ sorted_idx,
                                                const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                const float *__restrict__ conics, const float *__restrict__ opacities,
-                                               int tile_size, int tile_w, int tile_h) {
+                                               int tile_size, int tile_w, int tile_h, float4 *__restrict__ rec_out,
+                                               const float4 *__restrict__ rec_in) {
   const int t = threadIdx.x;
   const int64_t j = j0 + t;
   uint32_t nrows = 0;
   if (j < n_vis) {
-    const uint32_t o = sorted_idx[j];
-    const int r = radii[o];
-    if (r > 0) {
-      const float mx = means2d[(int64_t)o * 2], my = means2d[(int64_t)o * 2 + 1];
-      int x0, y0, x1, y1;
-      float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
-      bool ok;
-      if (conics == nullptr) {
-        tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
-        ok = x1 > x0 && y1 > y0;
-      } else {
-        a = conics[(int64_t)o * 3]; b = conics[(int64_t)o * 3 + 1]; c = conics[(int64_t)o * 3 + 2];
-        ok = tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max);
+    if (rec_in != nullptr) {
+      const float4 r0 = rec_in[j * 3], r1 = rec_in[j * 3 + 1], r2 = rec_in[j * 3 + 2];
+      nrows = __float_as_uint(r2.y);
+      S.mx[t] = r0.x; S.my[t] = r0.y; S.a[t] = r0.z; S.b[t] = r0.w;
+      S.c[t] = r1.x; S.qmax[t] = r1.y; S.x0[t] = __float_as_int(r1.z); S.x1[t] = __float_as_int(r1.w);
+      S.y0[t] = __float_as_int(r2.x); S.id[t] = __float_as_uint(r2.z); S.cam_base[t] = __float_as_uint(r2.w);
+    } else {
+      const uint32_t o = sorted_idx[j];
+      const int r = radii[o];
+      float mx = 0.f, my = 0.f, a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
+      int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+      if (r > 0) {
+        mx = means2d[(int64_t)o * 2]; my = means2d[(int64_t)o * 2 + 1];
+        bool ok;
+        if (conics == nullptr) {
+          tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+          ok = x1 > x0 && y1 > y0;
+        } else {
+          a = conics[(int64_t)o * 3]; b = conics[(int64_t)o * 3 + 1]; c = conics[(int64_t)o * 3 + 2];
+          ok = tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max);
+        }
+        if (ok) nrows = (uint32_t)(y1 - y0);
       }
-      if (ok) {
-        nrows = (uint32_t)(y1 - y0);
-        S.mx[t] = mx; S.my[t] = my; S.a[t] = a; S.b[t] = b; S.c[t] = c; S.qmax[t] = q_max;
-        S.x0[t] = x0; S.x1[t] = x1; S.y0[t] = y0; S.id[t] = o;
-        S.cam_base[t] = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
+      const uint32_t cam_base = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
+      S.mx[t] = mx; S.my[t] = my; S.a[t] = a; S.b[t] = b; S.c[t] = c; S.qmax[t] = q_max;
+      S.x0[t] = x0; S.x1[t] = x1; S.y0[t] = y0; S.id[t] = o; S.cam_base[t] = cam_base;
+      if (rec_out != nullptr) {
+        rec_out[j * 3] = make_float4(mx, my, a, b);
+        rec_out[j * 3 + 1] = make_float4(c, q_max, __int_as_float(x0), __int_as_float(x1));
+        rec_out[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float(o), __uint_as_float(cam_base));
       }
     }
   }
@@ -822,7 +848,8 @@ __device__ __forceinline__ void row_span_of(const RowStage &S, int g, int ty, bo
 __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
-    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted) {
+    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
+    float4 *__restrict__ rec) {
   __shared__ RowStage S;
   __shared__ uint32_t cnt[kIsectBlock];
   const int64_t n_vis = (int64_t)*n_vis_dev;
@@ -832,7 +859,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     return;
   }
   cnt[threadIdx.x] = 0u;
-  const uint32_t R = stage_rows(S, j0, n_vis, CN, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h);
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, rec, nullptr);
   const bool cull = conics != nullptr;
   for (uint32_t r = threadIdx.x; r < R; r += kIsectBlock) {
     const int g = row_owner(S, r);
@@ -849,12 +876,12 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
     const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ cum_sorted,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ vals, int pack_shift) {
+    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec) {
   __shared__ RowStage S;
   const int64_t n_vis = (int64_t)*n_vis_dev;
   const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
   if (j0 >= n_vis) return;
-  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h);
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec);
   const bool cull = conics != nullptr;
   uint32_t carry = cum_sorted[j0];   // output offset of the workgroup's first row
   for (uint32_t base = 0; base < R; base += kIsectBlock) {   // uniform trip count: the scan below has barriers
@@ -960,6 +987,7 @@ struct PrepWs {
   uint32_t *cum;        // [CN] exclusive scan of counts in depth order
   uint32_t *temp;       // radix / scan temp
   uint32_t *tables;     // short path: workgroup-major histogram + 4 group tables
+  float4 *rec;          // [CN][3] per-member records in depth order, written by EVERY counting kernel, read by the row emission
   size_t bytes;
 };
 
@@ -982,6 +1010,7 @@ static PrepWs prep_layout(void *ws, int64_t CN) {
   size_t t2 = scan_temp_elems(CN);
   L.temp = reinterpret_cast<uint32_t *>(take(t > t2 ? t : t2, 4));
   L.tables = reinterpret_cast<uint32_t *>(take(CN <= kShortSortMax ? short_sort_elems(CN) : 0, 4));
+  L.rec = reinterpret_cast<float4 *>(take((size_t)CN * kRecWords, 4));
   L.bytes = off;
   return L;
 }
@@ -1069,10 +1098,10 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     if (option_get(kOptRowItems))
       hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec);
     else
       hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec);
     BDS_LAUNCH_CHECK();
   } else {
     // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
@@ -1094,7 +1123,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb);
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec);
     BDS_LAUNCH_CHECK();
   }
   // 4. exclusive scan of the counts (offset of every entry's run) and the total M
@@ -1181,7 +1210,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     key_shift = rank_bits;
     uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits);
+                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     const uint32_t rank_mask = (1u << rank_bits) - 1u;
@@ -1202,7 +1231,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
     if (option_get(kOptRowItems))
       hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
-                         P.va, P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0);
+                         P.va, P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
     else
       hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
                          P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
