@@ -171,7 +171,8 @@ def main():
         v.requires_grad_(True)
     grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), device=dev)]
     gen = torch.Generator().manual_seed(7)
-    skies = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    # the sky colour comes from a trainable sky model in the reference: its gradient path stays live
+    skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
     targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
     flat = FlatGradients(list(params.values()) + grids)
     # multi-GPU: the backward kernels write the per-Gaussian gradients straight into the all-reduce buffer
@@ -182,6 +183,7 @@ def main():
     def step(s):
         v = view_for_rank(s, rank, world, len(cams))
         flat.zero()
+        skies[v].grad = None
         out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena)
         loss = Hn.training_loss(out, targets[v], grids)
         loss.backward()

@@ -167,7 +167,8 @@ class _FusedView(torch.autograd.Function):
         v_rgb = torch.zeros(H, W, 3, device=dev) if v_rgb is None else v_rgb.contiguous()
         v_depth = None if v_depth is None else v_depth.contiguous()
         v_opacity = None if v_opacity is None else v_opacity.contiguous()
-        v_render, v_alphas, v_sky = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((H, W, 3), dev)
+        v_render, v_alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
+        v_sky = _empty((H, W, 3), dev) if ctx.needs_input_grad[6] else None   # the sky colour is often a constant input
         with L.timed("bilagrid_bwd"):
             L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
                                                L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
