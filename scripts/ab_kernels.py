@@ -74,11 +74,11 @@ def main():
 
     # whole step, per backward variant x radix variant
     for rb in (3, 2):
-        for rx in (1,):
+        for rx in (2,):
             L.set_option(L.OPT_RASTER_BWD, rb)
             L.set_option(L.OPT_RADIX, rx)
             fwd_bwd()
-    order = [(2, 1, True, 1), (3, 1, True, 2), (2, 1, True, 2), (3, 1, False, 2)]
+    order = [(2, 2, True, 1), (3, 2, True, 2), (2, 1, True, 1), (2, 2, False, 1)]
     for r in range(a.rounds):
         for rb, rx, cull, fw in order:
             Hn.TILE_CULL = cull
@@ -98,7 +98,7 @@ def main():
                 if k != "step" and k in ts:
                     d[k].append(ts[k][1])
     L.set_option(L.OPT_RASTER_BWD, 2)
-    L.set_option(L.OPT_RADIX, 1)
+    L.set_option(L.OPT_RADIX, 2)
     L.set_option(L.OPT_RASTER_FWD, 1)
     Hn.TILE_CULL = True
     out = Hn.render_view(params, cam, grids, a.view, sky)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bilateral_driving_amd import _lib as L, harness as Hn
 which, va, vb = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-tname = sys.argv[4] if len(sys.argv) > 4 else "isect_tiles"
+tname = sys.argv[4] if len(sys.argv) > 4 else "isect_build"
 dev = torch.device("cuda", 0)
 W, H, N = 1920, 1080, 2_000_000
 cams = Hn.ring_cameras(W, H, device=dev)
