@@ -61,6 +61,9 @@ _SIGS = {
     "bds_bilagrid_ms_ed_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f, _f, _f]),
     "bds_l1_mean_fwd": (_i, [_i64, _f, _f, _f, _f]),
     "bds_l1_mean_bwd": (_i, [_i64, _f, _f, _f, _f, _f]),
+    "bds_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
+    "bds_ssim_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _sz, _f]),
+    "bds_ssim_bwd": (_i, [_i, _i, _i, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),
     "bds_bilagrid_tv_bwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f, _f]),
 }

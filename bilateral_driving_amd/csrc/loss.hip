@@ -52,6 +52,120 @@ __global__ __launch_bounds__(kLossBlock) void l1_mean_bwd_kernel(int64_t n, cons
   }
 }
 
+// ---- SSIM (11x11 Gaussian window, sigma 1.5, VALID region, K = (0.01, 0.03), data range 1) -----------------------
+// pytorch_msssim 1.0.0 `SSIM(data_range=1.0, size_average=True, channel=3)` as used at models/trainers/base.py:114,541
+// (external package, parity unpinned: oracle/loss_oracle.py).  Images are [H,W,CH] as the path produces them (the
+// reference permutes to [1,CH,H,W] first).  One workgroup = one 16x16 tile of OUTPUT pixels of one channel: the
+// 26x26 input patch is staged in LDS, the five windowed moments are taken separably (row pass into LDS, column pass in
+// registers), and next to the SSIM value the three partial derivatives with respect to the moments of `pred` that the
+// backward needs are written out, so that the backward is ONE more separable pass (the adjoint of the valid filter).
+constexpr int kSsimWin = 11, kSsimTile = 16, kSsimIn = kSsimTile + kSsimWin - 1;  // 26
+struct SsimWindow { float w[kSsimWin]; };
+
+__global__ __launch_bounds__(kSsimTile * kSsimTile) void ssim_fwd_kernel(int H, int W, int CH, const float *__restrict__ x,
+                                                                        const float *__restrict__ y, SsimWindow win, float C1,
+                                                                        float C2, float scale, float *__restrict__ out,
+                                                                        float *__restrict__ dmaps) {
+  __shared__ float sx[kSsimIn][kSsimIn + 1], sy[kSsimIn][kSsimIn + 1];
+  __shared__ float hb[5][kSsimIn][kSsimTile + 1];
+  __shared__ float red[kSsimTile * kSsimTile / kWave];
+  const int Ho = H - (kSsimWin - 1), Wo = W - (kSsimWin - 1);
+  const int c = blockIdx.z, oi0 = blockIdx.y * kSsimTile, oj0 = blockIdx.x * kSsimTile, tid = threadIdx.x;
+  for (int e = tid; e < kSsimIn * kSsimIn; e += kSsimTile * kSsimTile) {
+    const int r = e / kSsimIn, q = e - r * kSsimIn, i = oi0 + r, j = oj0 + q;
+    const bool in = i < H && j < W;
+    const int64_t o = ((int64_t)i * W + j) * CH + c;
+    sx[r][q] = in ? x[o] : 0.f;
+    sy[r][q] = in ? y[o] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSsimIn * kSsimTile; e += kSsimTile * kSsimTile) {   // row pass
+    const int r = e / kSsimTile, j = e - r * kSsimTile;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int b = 0; b < kSsimWin; b++) {
+      const float xv = sx[r][j + b], yv = sy[r][j + b], w = win.w[b];
+      a0 += w * xv; a1 += w * yv; a2 += w * xv * xv; a3 += w * yv * yv; a4 += w * xv * yv;
+    }
+    hb[0][r][j] = a0; hb[1][r][j] = a1; hb[2][r][j] = a2; hb[3][r][j] = a3; hb[4][r][j] = a4;
+  }
+  __syncthreads();
+  const int ti = tid / kSsimTile, tj = tid - ti * kSsimTile;
+  float m1 = 0.f, m2 = 0.f, e1 = 0.f, e2 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int a = 0; a < kSsimWin; a++) {   // column pass
+    const float w = win.w[a];
+    m1 += w * hb[0][ti + a][tj]; m2 += w * hb[1][ti + a][tj];
+    e1 += w * hb[2][ti + a][tj]; e2 += w * hb[3][ti + a][tj]; e12 += w * hb[4][ti + a][tj];
+  }
+  const int oi = oi0 + ti, oj = oj0 + tj;
+  const bool valid = oi < Ho && oj < Wo;
+  const float s1 = e1 - m1 * m1, s2 = e2 - m2 * m2, s12 = e12 - m1 * m2;
+  const float A = 2.f * m1 * m2 + C1, B = m1 * m1 + m2 * m2 + C1, Cn = 2.f * s12 + C2, D = s1 + s2 + C2;
+  const float lum = A / B, cs = Cn / D;
+  float S = valid ? lum * cs : 0.f;
+  if (valid && dmaps != nullptr) {
+    // S as a function of (m2, e2, e12) with s2 = e2 - m2^2, s12 = e12 - m1 m2
+    const float d_lum = (2.f * m1 * B - A * 2.f * m2) / (B * B);
+    const float d_cs = (-2.f * m1 * D + 2.f * m2 * Cn) / (D * D);
+    const int64_t plane = (int64_t)Ho * Wo, o = ((int64_t)c * Ho + oi) * Wo + oj;
+    dmaps[o] = d_lum * cs + lum * d_cs;                       // dS / d mu_pred
+    dmaps[(int64_t)CH * plane + o] = -lum * Cn / (D * D);     // dS / d E[pred^2]
+    dmaps[2 * (int64_t)CH * plane + o] = lum * 2.f / D;       // dS / d E[gt * pred]
+  }
+  S = wave_sum_to_lane63(S);
+  if ((tid & (kWave - 1)) == kWave - 1) red[tid / kWave] = S;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kSsimTile * kSsimTile / kWave; w++) t += red[w];
+    atomicAdd(out, t * scale);
+  }
+}
+
+__global__ __launch_bounds__(kSsimTile * kSsimTile) void ssim_bwd_kernel(int H, int W, int CH, const float *__restrict__ x,
+                                                                        const float *__restrict__ y, SsimWindow win, float scale,
+                                                                        const float *__restrict__ v_out,
+                                                                        const float *__restrict__ dmaps, float *__restrict__ v_y) {
+  __shared__ float sd[3][kSsimIn][kSsimIn + 1];
+  __shared__ float hb[3][kSsimIn][kSsimTile + 1];
+  const int Ho = H - (kSsimWin - 1), Wo = W - (kSsimWin - 1);
+  const int c = blockIdx.z, i0 = blockIdx.y * kSsimTile, j0 = blockIdx.x * kSsimTile, tid = threadIdx.x;
+  const int64_t plane = (int64_t)Ho * Wo;
+  // output pixels whose window covers input pixel (i,j): (i-a, j-b), a, b = 0..10
+  for (int e = tid; e < kSsimIn * kSsimIn; e += kSsimTile * kSsimTile) {
+    const int r = e / kSsimIn, q = e - r * kSsimIn, oi = i0 - (kSsimWin - 1) + r, oj = j0 - (kSsimWin - 1) + q;
+    const bool in = oi >= 0 && oi < Ho && oj >= 0 && oj < Wo;
+    const int64_t o = ((int64_t)c * Ho + (in ? oi : 0)) * Wo + (in ? oj : 0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) sd[k][r][q] = in ? dmaps[(int64_t)k * CH * plane + o] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSsimIn * kSsimTile; e += kSsimTile * kSsimTile) {
+    const int r = e / kSsimTile, j = e - r * kSsimTile;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < kSsimWin; b++) {
+      const float w = win.w[b];
+      const int q = j + (kSsimWin - 1) - b;
+      a0 += w * sd[0][r][q]; a1 += w * sd[1][r][q]; a2 += w * sd[2][r][q];
+    }
+    hb[0][r][j] = a0; hb[1][r][j] = a1; hb[2][r][j] = a2;
+  }
+  __syncthreads();
+  const int ti = tid / kSsimTile, tj = tid - ti * kSsimTile, i = i0 + ti, j = j0 + tj;
+  if (i >= H || j >= W) return;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int a = 0; a < kSsimWin; a++) {
+    const float w = win.w[a];
+    const int r = ti + (kSsimWin - 1) - a;
+    c0 += w * hb[0][r][tj]; c1 += w * hb[1][r][tj]; c2 += w * hb[2][r][tj];
+  }
+  const int64_t o = ((int64_t)i * W + j) * CH + c;
+  v_y[o] = v_out[0] * scale * (c0 + 2.f * y[o] * c1 + x[o] * c2);
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -80,6 +194,49 @@ extern "C" int bds_l1_mean_bwd(int64_t n, const float *a, const float *b, const 
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3((unsigned)blocks), dim3(kLossBlock), 0, as_stream(stream), n, a, b,
                      1.0f / (float)n, v_out, v_a);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+static SsimWindow ssim_window() {   // _fspecial_gauss_1d(11, 1.5) in float arithmetic
+  SsimWindow w;
+  float sum = 0.f;
+  for (int i = 0; i < kSsimWin; i++) {
+    const float cidx = (float)(i - kSsimWin / 2);
+    w.w[i] = expf(-(cidx * cidx) / (2.f * 1.5f * 1.5f));
+    sum += w.w[i];
+  }
+  for (int i = 0; i < kSsimWin; i++) w.w[i] /= sum;
+  return w;
+}
+
+extern "C" size_t bds_ssim_workspace_bytes(int H, int W, int CH) {
+  if (H < kSsimWin || W < kSsimWin || CH < 1) return 0;
+  return sizeof(float) * 3 * (size_t)CH * (size_t)(H - kSsimWin + 1) * (size_t)(W - kSsimWin + 1);
+}
+
+extern "C" int bds_ssim_fwd(int H, int W, int CH, const float *target, const float *pred, float *ssim_out, void *ws,
+                            size_t ws_bytes, bds_stream_t stream) {
+  BDS_REQUIRE(H >= kSsimWin && W >= kSsimWin && CH >= 1 && CH <= 65535 && target && pred && ssim_out);
+  if (ws != nullptr && ws_bytes < bds_ssim_workspace_bytes(H, W, CH)) return BDS_EWORKSPACE;
+  const int Ho = H - kSsimWin + 1, Wo = W - kSsimWin + 1;
+  const dim3 grid((unsigned)cdiv(Wo, kSsimTile), (unsigned)cdiv(Ho, kSsimTile), (unsigned)CH);
+  const float scale = 1.0f / ((float)Ho * (float)Wo * (float)CH);
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(kSsimTile * kSsimTile), 0, as_stream(stream), H, W, CH, target, pred,
+                     ssim_window(), 0.01f * 0.01f, 0.03f * 0.03f, scale, ssim_out, static_cast<float *>(ws));
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_ssim_bwd(int H, int W, int CH, const float *target, const float *pred, const void *ws, size_t ws_bytes,
+                            const float *v_ssim, float *v_pred, bds_stream_t stream) {
+  BDS_REQUIRE(H >= kSsimWin && W >= kSsimWin && CH >= 1 && CH <= 65535 && target && pred && ws && v_ssim && v_pred);
+  if (ws_bytes < bds_ssim_workspace_bytes(H, W, CH)) return BDS_EWORKSPACE;
+  const int Ho = H - kSsimWin + 1, Wo = W - kSsimWin + 1;
+  const dim3 grid((unsigned)cdiv(W, kSsimTile), (unsigned)cdiv(H, kSsimTile), (unsigned)CH);
+  const float scale = 1.0f / ((float)Ho * (float)Wo * (float)CH);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kSsimTile * kSsimTile), 0, as_stream(stream), H, W, CH, target, pred,
+                     ssim_window(), scale, v_ssim, static_cast<const float *>(ws), v_pred);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

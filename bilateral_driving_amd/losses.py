@@ -60,3 +60,48 @@ def photometric_tv_loss(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv
     """mean|rgb - target| + sum_l tv_weights[l] * total_variation(grids[l])  (grids [n_img,12,L,gy,gx])."""
     assert len(grids) == len(tv_weights)
     return _PhotometricTV.apply(rgb, target, tuple(tv_weights), *grids)
+
+
+class _SSIM(torch.autograd.Function):
+    """mean SSIM(target, pred) of [H,W,C] images: pytorch_msssim.SSIM(data_range=1, size_average=True) as the reference
+    trainer calls it (models/trainers/base.py:114,541); gradient w.r.t. pred only (the ground truth is data)."""
+
+    @staticmethod
+    def forward(ctx, pred: Tensor, target: Tensor):
+        L.require_gpu(pred, target)
+        lib, st = L.lib(), L.stream()
+        pred, target = pred.contiguous(), target.contiguous()
+        assert pred.shape == target.shape and pred.dim() == 3 and pred.dtype == torch.float32 and target.dtype == torch.float32
+        H, W, CH = pred.shape
+        if H < 11 or W < 11:
+            raise ValueError("SSIM needs images of at least 11x11 pixels (window 11, valid region)")
+        out = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        ws = None
+        if ctx.needs_input_grad[0]:
+            ws = torch.empty(lib.bds_ssim_workspace_bytes(H, W, CH), device=pred.device, dtype=torch.uint8)
+        L.check(lib.bds_ssim_fwd(H, W, CH, L.ptr(target), L.ptr(pred), L.ptr(out), L.ptr(ws), 0 if ws is None else ws.numel(), st),
+                "bds_ssim_fwd")
+        ctx.save_for_backward(pred, target, ws)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, v_out):
+        pred, target, ws = ctx.saved_tensors
+        if ws is None:
+            return None, None
+        H, W, CH = pred.shape
+        v = v_out.reshape(1).to(torch.float32).contiguous()
+        v_pred = torch.empty_like(pred)
+        L.check(L.lib().bds_ssim_bwd(H, W, CH, L.ptr(target), L.ptr(pred), L.ptr(ws), ws.numel(), L.ptr(v), L.ptr(v_pred), L.stream()),
+                "bds_ssim_bwd")
+        return v_pred, None
+
+
+def ssim(pred: Tensor, target: Tensor) -> Tensor:
+    """Mean structural similarity of two [H,W,C] images in [0,1] (11x11 Gaussian window, valid region)."""
+    return _SSIM.apply(pred, target)
+
+
+def ssim_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """1 - ssim: the reference's `ssim_loss` before its weight (models/trainers/base.py:541-544)."""
+    return 1.0 - ssim(pred, target)

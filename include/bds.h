@@ -251,6 +251,17 @@ int bds_bilagrid_ms_ed_bwd(int nlevels, const bds_bilagrid_level_t *levels, int 
 int bds_l1_mean_fwd(int64_t n, const float *a, const float *b, float *out, bds_stream_t stream);
 int bds_l1_mean_bwd(int64_t n, const float *a, const float *b, const float *v_out, float *v_a, bds_stream_t stream);
 
+/* SSIM term of the image loss (models/trainers/base.py:114,541: pytorch_msssim.SSIM(data_range=1, size_average=True,
+ * channel=3), loss = 1 - ssim(gt, pred)): 11x11 Gaussian window (sigma 1.5), valid region, K = (0.01, 0.03).
+ * target / pred [H,W,CH] (H, W >= 11).  fwd ACCUMULATES the mean SSIM into ssim_out [1] (caller zero-fills) and, when
+ * ws != NULL (bds_ssim_workspace_bytes), stores the per-pixel derivatives the backward needs; bwd writes
+ * v_pred = v_ssim * d(mean SSIM)/d pred with v_ssim a device scalar (pass -upstream for the 1 - ssim loss). */
+size_t bds_ssim_workspace_bytes(int H, int W, int CH);
+int bds_ssim_fwd(int H, int W, int CH, const float *target, const float *pred, float *ssim_out, void *ws, size_t ws_bytes,
+                 bds_stream_t stream);
+int bds_ssim_bwd(int H, int W, int CH, const float *target, const float *pred, const void *ws, size_t ws_bytes,
+                 const float *v_ssim, float *v_pred, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

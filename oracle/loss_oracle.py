@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): CPU restatement of the image-loss terms that follow the hot
+path.  Not imported by the product.
+
+SSIM -- **parity unpinned**: the reference calls the external package pytorch_msssim, pinned at 1.0.0 in
+/root/reference/requirements.txt:2 and used at /root/reference/project/models/trainers/base.py:15,114,541
+(`SSIM(data_range=1.0, size_average=True, channel=3)`, loss = 1 - ssim(gt, pred) on [1,3,H,W]).  The package is neither
+vendored in the reference tree nor installed here, so this file restates its published algorithm (pytorch_msssim/ssim.py,
+v1.0.0: `_fspecial_gauss_1d`, `gaussian_filter`, `_ssim`, `ssim`) and is pinned only by this repo's own tests
+(brute-force window sums, identities, autograd).  Equality with the package itself could not be checked.
+L1 is torch's own `(a - b).abs().mean()` (models/trainers/base.py:540)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+WIN_SIZE, WIN_SIGMA, K1, K2 = 11, 1.5, 0.01, 0.03
+
+
+def gauss_window(size: int = WIN_SIZE, sigma: float = WIN_SIGMA, dtype=torch.float32) -> torch.Tensor:
+    """_fspecial_gauss_1d: float arithmetic in the order the package uses."""
+    coords = torch.arange(size, dtype=dtype)
+    coords -= size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    g /= g.sum()
+    return g
+
+
+def _filter(x: torch.Tensor, win: torch.Tensor) -> torch.Tensor:
+    """gaussian_filter: separable VALID correlation over H then W, one group per channel.  x [1,C,H,W]."""
+    C = x.shape[1]
+    w = win.to(x.dtype).reshape(1, 1, -1).repeat(C, 1, 1)
+    out = F.conv2d(x, w.unsqueeze(-1), groups=C)      # along H  (weight [C,1,11,1])
+    out = F.conv2d(out, w.unsqueeze(-2), groups=C)    # along W  (weight [C,1,1,11])
+    return out
+
+
+def ssim_map(X: torch.Tensor, Y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """_ssim: X, Y [1,C,H,W] -> per-pixel SSIM over the valid region [1,C,H-10,W-10]."""
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    win = gauss_window(dtype=X.dtype)
+    mu1, mu2 = _filter(X, win), _filter(Y, win)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = _filter(X * X, win) - mu1_sq
+    sigma2_sq = _filter(Y * Y, win) - mu2_sq
+    sigma12 = _filter(X * Y, win) - mu1_mu2
+    cs_map = (2 * sigma12 + C2) / (sigma1_sq + sigma2_sq + C2)
+    return ((2 * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+
+
+def ssim(gt_hwc: torch.Tensor, pred_hwc: torch.Tensor) -> torch.Tensor:
+    """The trainer's call: images [H,W,3] -> scalar mean SSIM (size_average=True: mean over channels of the
+    per-channel spatial means = mean over everything)."""
+    X = gt_hwc.permute(2, 0, 1)[None]
+    Y = pred_hwc.permute(2, 0, 1)[None]
+    m = ssim_map(X, Y)
+    return torch.flatten(m, 2).mean(-1).mean()
+
+
+def ssim_loss(gt_hwc: torch.Tensor, pred_hwc: torch.Tensor) -> torch.Tensor:
+    return 1 - ssim(gt_hwc, pred_hwc)
+
+
+def ssim_map_bruteforce(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """Independent check of ssim_map on small inputs: explicit 11x11 window sums in float64, no convolution calls."""
+    X, Y = X.double(), Y.double()
+    _, C, H, W = X.shape
+    w1 = gauss_window(dtype=torch.float64)
+    w2 = w1[:, None] * w1[None, :]
+    C1, C2 = K1 ** 2, K2 ** 2
+    out = torch.zeros(1, C, H - 10, W - 10, dtype=torch.float64)
+    for c in range(C):
+        for i in range(H - 10):
+            for j in range(W - 10):
+                px, py = X[0, c, i:i + 11, j:j + 11], Y[0, c, i:i + 11, j:j + 11]
+                m1, m2 = (w2 * px).sum(), (w2 * py).sum()
+                s1, s2, s12 = (w2 * px * px).sum() - m1 * m1, (w2 * py * py).sum() - m2 * m2, (w2 * px * py).sum() - m1 * m2
+                out[0, c, i, j] = ((2 * m1 * m2 + C1) / (m1 * m1 + m2 * m2 + C1)) * ((2 * s12 + C2) / (s1 + s2 + C2))
+    return out

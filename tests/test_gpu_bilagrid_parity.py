@@ -208,3 +208,26 @@ def test_fused_training_loss_matches_framework_expression(H, W):
     assert float(got[1][0, 0].abs().max()) == 0.0
     for a, b in zip(got[2], ref[2]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("H,W", [(11, 11), (37, 53), (270, 480)])
+def test_ssim_matches_oracle(H, W):
+    """losses.ssim (HIP, [H,W,3]) vs the pytorch_msssim restatement (oracle/loss_oracle.py; parity unpinned), value and
+    gradient w.r.t. the prediction."""
+    from oracle import loss_oracle as LO
+    from bilateral_driving_amd.losses import ssim, ssim_loss
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    gt = torch.rand(H, W, 3, generator=g)
+    pred = (gt + 0.15 * torch.randn(H, W, 3, generator=g)).clamp(0, 1)     # a correlated prediction
+    p_ref = pred.clone().double().requires_grad_(True)
+    s_ref = LO.ssim(gt.double(), p_ref)
+    (1.7 * (1 - s_ref)).backward()
+    p = pred.cuda().requires_grad_(True)
+    s = ssim(p, gt.cuda())
+    (1.7 * ssim_loss(p, gt.cuda())).backward()
+    assert abs(float(s) - float(s_ref)) < 2e-5
+    gref = p_ref.grad.float()
+    assert float((p.grad.cpu() - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-9
+    # no gradient requested: no workspace, same value
+    with torch.no_grad():
+        assert abs(float(ssim(pred.cuda(), gt.cuda())) - float(s)) < 1e-6

@@ -1,0 +1,43 @@
+"""Oracle of the SSIM term (parity unpinned: pytorch_msssim 1.0.0 is absent, see oracle/loss_oracle.py): pinned by
+independent restatements and identities only."""
+import torch
+
+from oracle import loss_oracle as LO
+
+
+def test_window_is_normalised_and_symmetric():
+    g = LO.gauss_window()
+    assert g.shape == (11,) and abs(float(g.sum()) - 1.0) < 1e-6
+    assert torch.allclose(g, g.flip(0)) and float(g[5]) == float(g.max())
+    # closed form
+    ref = torch.exp(-(torch.arange(-5, 6, dtype=torch.float64) ** 2) / 4.5)
+    assert torch.allclose(g.double(), ref / ref.sum(), atol=1e-7)
+
+
+def test_ssim_map_against_explicit_window_sums():
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.rand(1, 3, 17, 14, generator=g, dtype=torch.float64), torch.rand(1, 3, 17, 14, generator=g, dtype=torch.float64)
+    assert torch.allclose(LO.ssim_map(X, Y), LO.ssim_map_bruteforce(X, Y), rtol=1e-10, atol=1e-12)
+
+
+def test_ssim_identities():
+    g = torch.Generator().manual_seed(1)
+    X = torch.rand(23, 31, 3, generator=g)
+    assert abs(float(LO.ssim(X, X)) - 1.0) < 1e-5
+    Y = torch.rand(23, 31, 3, generator=g)
+    assert abs(float(LO.ssim(X, Y)) - float(LO.ssim(Y, X))) < 1e-6     # symmetric
+    assert float(LO.ssim(X, Y)) < 0.2                                   # independent noise is dissimilar
+    assert abs(float(LO.ssim_loss(X, Y)) - (1 - float(LO.ssim(X, Y)))) < 1e-7
+
+
+def test_ssim_gradient_by_finite_differences():
+    g = torch.Generator().manual_seed(2)
+    X = torch.rand(13, 15, 3, generator=g, dtype=torch.float64)
+    Y = torch.rand(13, 15, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    LO.ssim(X, Y).backward()
+    eps = 1e-6
+    for (i, j, c) in [(0, 0, 0), (6, 7, 1), (12, 14, 2), (3, 10, 0)]:
+        Yp, Ym = Y.detach().clone(), Y.detach().clone()
+        Yp[i, j, c] += eps; Ym[i, j, c] -= eps
+        fd = (float(LO.ssim(X, Yp)) - float(LO.ssim(X, Ym))) / (2 * eps)
+        assert abs(fd - float(Y.grad[i, j, c])) < 1e-7 + 1e-5 * abs(fd)
