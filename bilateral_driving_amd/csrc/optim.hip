@@ -1,0 +1,73 @@
+// Adam step on one parameter tensor: the optimiser of the reference trainer
+// (torch.optim.Adam(groups, lr=0.0, eps=1e-15), /root/reference/project/models/trainers/base.py:222; per-group lr / eps /
+// weight_decay :201-207; betas (0.9, 0.999), amsgrad off) as ONE streaming pass -- SURVEY.md 8f rank 2, first slice.
+// The arithmetic follows torch/optim/adam.py `_single_tensor_adam` (non-capturable branch) operation by operation:
+//   g = grad + weight_decay * p;  m = m + (g - m) * (1 - b1)  [lerp];  v = v * b2 + (1 - b2) * g * g  [mul, addcmul]
+//   denom = sqrt(v) / sqrt(1 - b2^t) + eps;  p = p - (lr / (1 - b1^t)) * m / denom  [addcdiv]
+// HBM-bound: 28 B per element (read p, g, m, v; write p, m, v).  59 floats per Gaussian -> 1.65 KB per Gaussian per step.
+#include "bds_common.h"
+
+namespace bds {
+
+constexpr int kOptBlock = 256;
+
+template <bool kVec>
+__global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *__restrict__ p, const float *__restrict__ g,
+                                                             float *__restrict__ m, float *__restrict__ v, float step_size,
+                                                             float one_minus_b1, float b2, float one_minus_b2,
+                                                             float bc2_sqrt, float eps, float weight_decay) {
+#pragma clang fp contract(off)  // torch evaluates these as separate element-wise operations
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {
+    if (weight_decay != 0.f) gg = gg + weight_decay * pp;
+    mm = mm + (gg - mm) * one_minus_b1;
+    vv = vv * b2 + (one_minus_b2 * gg) * gg;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp = pp + (-step_size) * (mm / denom);
+  };
+  const int64_t stride = (int64_t)gridDim.x * kOptBlock;
+  if (kVec) {
+    const int64_t n4 = n / 4;
+    float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4; i += stride) {
+      float4 pp = p4[i], mm = m4[i], vv = v4[i];
+      const float4 gg = g4[i];
+      upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+      p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
+      const int64_t i = n4 * 4 + threadIdx.x;
+      upd(p[i], g[i], m[i], v[i]);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
+  }
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+extern "C" int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && step >= 1);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(param && grad && exp_avg && exp_avg_sq);
+  // scalars in double like Python's float arithmetic in torch/optim/adam.py (1 - beta, bias corrections), each rounded
+  // to fp32 once where torch hands it to an fp32 element-wise kernel
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const bool vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+  int64_t blocks = cdiv(vec ? cdiv(n, 4) : n, kOptBlock * 2);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = as_stream(stream);
+  if (vec)
+    hipLaunchKernelGGL((adam_step_kernel<true>), dim3((unsigned)blocks), dim3(kOptBlock), 0, st, n, param, grad, exp_avg, exp_avg_sq,
+                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, (float)weight_decay);
+  else
+    hipLaunchKernelGGL((adam_step_kernel<false>), dim3((unsigned)blocks), dim3(kOptBlock), 0, st, n, param, grad, exp_avg, exp_avg_sq,
+                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, (float)weight_decay);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}

@@ -1,0 +1,49 @@
+"""Drop-in for the optimiser of the reference trainer: ``torch.optim.Adam(groups, lr=0.0, eps=1e-15)``
+(/root/reference/project/models/trainers/base.py:222) with the parameter update done by ONE HIP pass per tensor
+(``bds_adam_step``) instead of torch's multi-kernel foreach implementation.  Same constructor arguments, same
+``param_groups`` (the reference's LR schedulers write ``group["lr"]``, base.py:240-246) and the same ``state`` layout
+(``step``, ``exp_avg``, ``exp_avg_sq``) that the reference's densification code edits in place
+(models/gaussians/basics.py:162-206), so it can replace the optimiser without touching the trainer."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib, st = L.lib(), L.stream()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                L.require_gpu(p)
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam expects contiguous float32 parameters")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0)   # host scalar, as torch's default (capturable=False) layout
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                g = p.grad.contiguous()
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous() and m.shape == p.shape and v.shape == p.shape):
+                    raise RuntimeError("optimizer state does not match its parameter (after densification, re-create both)")
+                L.check(lib.bds_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), float(group["lr"]), float(b1), float(b2),
+                                          float(group["eps"]), float(group["weight_decay"]), int(state["step"]), st), "bds_adam_step")
+        return loss

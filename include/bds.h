@@ -262,6 +262,14 @@ int bds_ssim_fwd(int H, int W, int CH, const float *target, const float *pred, f
 int bds_ssim_bwd(int H, int W, int CH, const float *target, const float *pred, const void *ws, size_t ws_bytes,
                  const float *v_ssim, float *v_pred, bds_stream_t stream);
 
+/* ---- Adam step on one parameter tensor (first slice) --------------------------------------
+ * torch.optim.Adam as the reference trainer configures it (models/trainers/base.py:201-222: per-group lr / eps /
+ * weight_decay, betas (0.9, 0.999), amsgrad off), one streaming pass, in place on param / exp_avg / exp_avg_sq.
+ * `step` is the 1-based step count AFTER the increment (torch's state["step"]); the hyper-parameters are doubles (Python
+ * floats): 1 - beta and the bias corrections are formed in double and rounded to fp32 once, as torch does. */
+int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,57 @@
+"""-m gpu: FusedAdam (one HIP pass per tensor) against torch.optim.Adam itself -- the optimiser the reference trainer
+builds (models/trainers/base.py:222) -- on the same parameters, gradients and per-group settings."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(wd):
+    assert torch.cuda.is_available()
+    from bilateral_driving_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000, 3), (1000, 4), (1000,), (1000, 16, 3), (7,), (3, 12, 2, 4, 4)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    lrs = [1.6e-4, 1e-3, 5e-2, 1.25e-4, 1e-2, 2e-3]
+
+    def make(opt_cls):
+        ps = [b.clone().cuda().requires_grad_(True) for b in base]
+        groups = [{"params": [p], "name": f"g{i}", "lr": lrs[i], "eps": 1e-15, "weight_decay": wd if i % 2 == 0 else 0.0} for i, p in enumerate(ps)]
+        return ps, opt_cls(groups, lr=0.0, eps=1e-15)
+
+    pa, oa = make(torch.optim.Adam)
+    pb, ob = make(FusedAdam)
+    for it in range(25):
+        gg = torch.Generator().manual_seed(100 + it)
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            gr = torch.randn(x.shape, generator=gg) * (10.0 ** ((i % 3) - 2))
+            if it % 7 == 3 and i == 2:
+                gr.zero_()                       # an all-zero gradient (culled Gaussians): m decays, eps dominates
+            x.grad = gr.cuda(); y.grad = gr.cuda()
+        if it == 10:                              # the reference's schedulers rewrite group["lr"] every step
+            for grp_a, grp_b in zip(oa.param_groups, ob.param_groups):
+                grp_a["lr"] *= 0.5; grp_b["lr"] *= 0.5
+        oa.step(); ob.step()
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        sa, sb = oa.state[x], ob.state[y]
+        assert float(sa["step"]) == float(sb["step"]) == 25
+        for a, b, what in ((x, y, "param"), (sa["exp_avg"], sb["exp_avg"], "exp_avg"), (sa["exp_avg_sq"], sb["exp_avg_sq"], "exp_avg_sq")):
+            err = float((a.detach() - b.detach()).abs().max()) / max(float(a.detach().abs().max()), 1e-30)
+            assert err < 2e-6, (i, what, err)
+
+
+def test_fused_adam_state_layout_allows_the_reference_surgery():
+    """models/gaussians/basics.py:162-206 style: replace a parameter and its state tensors by concatenated ones."""
+    from bilateral_driving_amd.optim import FusedAdam
+    p = torch.randn(10, 3, device="cuda").requires_grad_(True)
+    opt = FusedAdam([{"params": [p], "name": "x", "lr": 1e-2, "eps": 1e-15, "weight_decay": 0}], lr=0.0, eps=1e-15)
+    p.grad = torch.randn_like(p); opt.step()
+    st = opt.state.pop(p)
+    new_p = torch.nn.Parameter(torch.cat([p.detach(), torch.zeros(5, 3, device="cuda")]))
+    st["exp_avg"] = torch.cat([st["exp_avg"], torch.zeros(5, 3, device="cuda")])
+    st["exp_avg_sq"] = torch.cat([st["exp_avg_sq"], torch.zeros(5, 3, device="cuda")])
+    opt.param_groups[0]["params"] = [new_p]
+    opt.state[new_p] = st
+    new_p.grad = torch.randn_like(new_p); opt.step()
+    assert float(opt.state[new_p]["step"]) == 2 and torch.isfinite(new_p).all()
