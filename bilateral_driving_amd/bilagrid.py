@@ -16,7 +16,7 @@ plus the fused image transform the reference spreads over ~30 torch launches per
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn

@@ -10,10 +10,9 @@ issues ~25 launches of libbds.so kernels back to back, so the step is bound by t
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 import weakref
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 from torch import Tensor
