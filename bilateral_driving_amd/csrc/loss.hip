@@ -166,6 +166,100 @@ __global__ __launch_bounds__(kSsimTile * kSsimTile) void ssim_bwd_kernel(int H, 
   v_y[o] = v_out[0] * scale * (c0 + 2.f * y[o] * c1 + x[o] * c2);
 }
 
+// ---- per-pixel terms of the reference's image loss ---------------------------------------------------------------
+// BasicTrainer.compute_losses, models/trainers/base.py:518-565 with the loss functions of :230-250 (models/losses.py:82-84
+// binary_cross_entropy, :92-178 DepthLoss(normalize=False, use_inverse_depth=False, reduction="mean_on_hit")):
+//   valid = 1 - egocar (or 1);  rgb: |pixels*valid - rgb*valid|.mean();  mask: BCE(opacity*valid, (1-sky)*valid).mean()
+//   depth: hit = (lidar > 0)*valid, pred = depth*hit, gt = lidar*hit, over {gt > 0.01, gt < max_depth, pred > 1e-4}: L1 or L2 mean
+// One pass computes the four sums (three numerators + the depth count); the backward is one more pass.  PINNED by
+// tests/golden/pixel_loss_*.npz (generated with the reference's own functions).
+struct PixelLossArgs {
+  const float *rgb, *pixels, *opacity, *sky, *depth, *lidar, *egocar;
+  int depth_l2;
+  float max_depth;
+};
+
+__device__ __forceinline__ float bce_log(float v) { return fmaxf(logf(v), -100.f); }   // torch clamps the logs at -100
+
+__global__ __launch_bounds__(kLossBlock) void pixel_loss_fwd_kernel(int64_t P, PixelLossArgs a, float *__restrict__ sums) {
+  __shared__ float red[4][kLossBlock / kWave];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < P; i += (int64_t)gridDim.x * kLossBlock) {
+    const float valid = a.egocar ? 1.f - a.egocar[i] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) s[0] += fabsf(a.pixels[i * 3 + c] * valid - a.rgb[i * 3 + c] * valid);
+    if (a.opacity) {
+      const float x = a.opacity[i] * valid, t = (1.f - a.sky[i]) * valid;
+      s[1] += (t - 1.f) * bce_log(1.f - x) - t * bce_log(x);
+    }
+    if (a.depth) {
+      const float l = a.lidar[i], hit = (l > 0.f ? 1.f : 0.f) * valid;
+      const float pred = a.depth[i] * hit, gt = l * hit;
+      if (gt > 0.01f && gt < a.max_depth && pred > 0.0001f) {
+        const float e = pred - gt;
+        s[2] += a.depth_l2 ? e * e : fabsf(e);
+        s[3] += 1.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float t = wave_sum_to_lane63(s[k]);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) red[k][threadIdx.x / kWave] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float t = 0.f;
+    for (int w = 0; w < kLossBlock / kWave; w++) t += red[threadIdx.x][w];
+    if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
+  }
+}
+
+// terms[0..2] = weighted rgb / mask / depth losses (depth: 0/0 = NaN when no lidar return is valid, as torch's empty mean)
+__global__ void pixel_loss_finalize_kernel(int64_t P, const float *__restrict__ sums, float w_rgb, float w_mask, float w_depth,
+                                           int has_mask, int has_depth, float *__restrict__ terms) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  terms[0] = w_rgb * (sums[0] / (3.f * (float)P));
+  terms[1] = has_mask ? w_mask * (sums[1] / (float)P) : 0.f;
+  terms[2] = has_depth ? w_depth * (sums[2] / sums[3]) : 0.f;
+}
+
+__global__ __launch_bounds__(kLossBlock) void pixel_loss_bwd_kernel(int64_t P, PixelLossArgs a, const float *__restrict__ sums,
+                                                                   const float *__restrict__ v_terms, float w_rgb, float w_mask,
+                                                                   float w_depth, float *__restrict__ v_rgb,
+                                                                   float *__restrict__ v_opacity, float *__restrict__ v_depth) {
+  const float g_rgb = v_terms[0] * w_rgb / (3.f * (float)P), g_mask = v_terms[1] * w_mask / (float)P;
+  const float g_depth = a.depth ? v_terms[2] * w_depth / sums[3] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < P; i += (int64_t)gridDim.x * kLossBlock) {
+    const float valid = a.egocar ? 1.f - a.egocar[i] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float d = a.rgb[i * 3 + c] * valid - a.pixels[i * 3 + c] * valid;
+      v_rgb[i * 3 + c] = (d > 0.f ? g_rgb : (d < 0.f ? -g_rgb : 0.f)) * valid;
+    }
+    if (v_opacity) {
+      float v = 0.f;
+      if (a.opacity) {
+        const float x = a.opacity[i] * valid, t = (1.f - a.sky[i]) * valid;
+        v = g_mask * (x - t) / fmaxf((1.f - x) * x, 1e-12f) * valid;   // torch's binary_cross_entropy backward
+      }
+      v_opacity[i] = v;
+    }
+    if (v_depth) {
+      float v = 0.f;
+      if (a.depth) {
+        const float l = a.lidar[i], hit = (l > 0.f ? 1.f : 0.f) * valid;
+        const float pred = a.depth[i] * hit, gt = l * hit;
+        if (gt > 0.01f && gt < a.max_depth && pred > 0.0001f) {
+          const float e = pred - gt;
+          v = g_depth * (a.depth_l2 ? 2.f * e : (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f))) * hit;
+        }
+      }
+      v_depth[i] = v;
+    }
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -237,6 +331,51 @@ extern "C" int bds_ssim_bwd(int H, int W, int CH, const float *target, const flo
   const float scale = 1.0f / ((float)Ho * (float)Wo * (float)CH);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(kSsimTile * kSsimTile), 0, as_stream(stream), H, W, CH, target, pred,
                      ssim_window(), scale, v_ssim, static_cast<const float *>(ws), v_pred);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+static int pixel_loss_args(PixelLossArgs &a, int64_t P, const float *rgb, const float *pixels, const float *opacity,
+                           const float *sky_masks, const float *depth, const float *lidar, const float *egocar, int depth_l2,
+                           float max_depth) {
+  BDS_REQUIRE(P >= 1 && rgb && pixels);
+  BDS_REQUIRE((opacity == nullptr) == (sky_masks == nullptr));
+  BDS_REQUIRE((depth == nullptr) == (lidar == nullptr));
+  a.rgb = rgb; a.pixels = pixels; a.opacity = opacity; a.sky = sky_masks; a.depth = depth; a.lidar = lidar; a.egocar = egocar;
+  a.depth_l2 = depth_l2 ? 1 : 0; a.max_depth = max_depth;
+  return BDS_OK;
+}
+
+extern "C" int bds_pixel_loss_fwd(int64_t P, const float *rgb, const float *pixels, const float *opacity, const float *sky_masks,
+                                  const float *depth, const float *lidar, const float *egocar, float w_rgb, float w_mask,
+                                  float w_depth, int depth_l2, float max_depth, float *sums, float *terms, bds_stream_t stream) {
+  PixelLossArgs a;
+  int rc = pixel_loss_args(a, P, rgb, pixels, opacity, sky_masks, depth, lidar, egocar, depth_l2, max_depth);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(sums && terms);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(sums, 0, 4 * sizeof(float), st) != hipSuccess) return BDS_ELAUNCH;
+  int64_t blocks = cdiv(P, kLossBlock * 4);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(pixel_loss_fwd_kernel, dim3((unsigned)blocks), dim3(kLossBlock), 0, st, P, a, sums);
+  hipLaunchKernelGGL(pixel_loss_finalize_kernel, dim3(1), dim3(kWave), 0, st, P, sums, w_rgb, w_mask, w_depth, opacity != nullptr,
+                     depth != nullptr, terms);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_pixel_loss_bwd(int64_t P, const float *rgb, const float *pixels, const float *opacity, const float *sky_masks,
+                                  const float *depth, const float *lidar, const float *egocar, float w_rgb, float w_mask,
+                                  float w_depth, int depth_l2, float max_depth, const float *sums, const float *v_terms,
+                                  float *v_rgb, float *v_opacity, float *v_depth, bds_stream_t stream) {
+  PixelLossArgs a;
+  int rc = pixel_loss_args(a, P, rgb, pixels, opacity, sky_masks, depth, lidar, egocar, depth_l2, max_depth);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(sums && v_terms && v_rgb);
+  int64_t blocks = cdiv(P, kLossBlock * 2);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((unsigned)blocks), dim3(kLossBlock), 0, as_stream(stream), P, a, sums, v_terms,
+                     w_rgb, w_mask, w_depth, v_rgb, v_opacity, v_depth);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -105,3 +105,56 @@ def ssim(pred: Tensor, target: Tensor) -> Tensor:
 def ssim_loss(pred: Tensor, target: Tensor) -> Tensor:
     """1 - ssim: the reference's `ssim_loss` before its weight (models/trainers/base.py:541-544)."""
     return 1.0 - ssim(pred, target)
+
+
+class _PixelLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, opacity, depth, pixels, sky_masks, lidar, egocar, w, depth_l2, max_depth):
+        L.require_gpu(rgb, pixels)
+        lib, st = L.lib(), L.stream()
+        f = lambda t: None if t is None else t.contiguous().to(torch.float32)
+        rgb, opacity, depth, pixels, sky_masks, lidar, egocar = (f(t) for t in (rgb, opacity, depth, pixels, sky_masks, lidar, egocar))
+        P = rgb.numel() // 3
+        assert rgb.shape[-1] == 3 and pixels.shape == rgb.shape
+        for t in (opacity, depth, sky_masks, lidar, egocar):
+            assert t is None or t.numel() == P, "per-pixel inputs must have H*W elements"
+        use_mask = opacity is not None and sky_masks is not None and w[1] != 0.0
+        use_depth = depth is not None and lidar is not None and w[2] != 0.0
+        sums = torch.empty(4, device=rgb.device, dtype=torch.float32)
+        terms = torch.empty(3, device=rgb.device, dtype=torch.float32)
+        L.check(lib.bds_pixel_loss_fwd(P, L.ptr(rgb), L.ptr(pixels), L.ptr(opacity) if use_mask else None,
+                                       L.ptr(sky_masks) if use_mask else None, L.ptr(depth) if use_depth else None,
+                                       L.ptr(lidar) if use_depth else None, L.ptr(egocar), w[0], w[1], w[2], int(depth_l2), max_depth,
+                                       L.ptr(sums), L.ptr(terms), st), "bds_pixel_loss_fwd")
+        ctx.save_for_backward(rgb, opacity, depth, pixels, sky_masks, lidar, egocar, sums)
+        ctx.cfg = (tuple(w), int(depth_l2), float(max_depth), use_mask, use_depth)
+        return terms
+
+    @staticmethod
+    def backward(ctx, v_terms):
+        rgb, opacity, depth, pixels, sky_masks, lidar, egocar, sums = ctx.saved_tensors
+        w, depth_l2, max_depth, use_mask, use_depth = ctx.cfg
+        P = rgb.numel() // 3
+        v_terms = v_terms.contiguous().to(torch.float32)
+        v_rgb = torch.empty_like(rgb)
+        v_op = torch.empty_like(opacity) if (opacity is not None and ctx.needs_input_grad[1]) else None
+        v_dp = torch.empty_like(depth) if (depth is not None and ctx.needs_input_grad[2]) else None
+        L.check(L.lib().bds_pixel_loss_bwd(P, L.ptr(rgb), L.ptr(pixels), L.ptr(opacity) if use_mask else None,
+                                           L.ptr(sky_masks) if use_mask else None, L.ptr(depth) if use_depth else None,
+                                           L.ptr(lidar) if use_depth else None, L.ptr(egocar), w[0], w[1], w[2], depth_l2, max_depth,
+                                           L.ptr(sums), L.ptr(v_terms), L.ptr(v_rgb), L.ptr(v_op), L.ptr(v_dp), L.stream()),
+                "bds_pixel_loss_bwd")
+        return v_rgb, v_op, v_dp, None, None, None, None, None, None, None
+
+
+def pixel_loss(rgb: Tensor, opacity: Tensor, depth: Tensor, pixels: Tensor, sky_masks: Tensor, lidar_depth: Tensor,
+               egocar_masks: Tensor = None, w_rgb: float = 0.8, w_mask: float = 0.05, w_depth: float = 0.01,
+               depth_loss_type: str = "l1", max_depth: float = 80.0) -> Tensor:
+    """The per-pixel terms of ``BasicTrainer.compute_losses`` (models/trainers/base.py:518-565) in one pass each way:
+    returns the three WEIGHTED terms ``[rgb_loss, sky_loss_opacity, depth_loss]`` (sum them for the total; they are what
+    the trainer logs).  rgb / pixels [H,W,3]; opacity, depth [H,W,1] or [H,W]; sky_masks, lidar_depth, egocar_masks [H,W].
+    Pass ``opacity=None`` / ``depth=None`` to drop a term."""
+    if depth_loss_type not in ("l1", "l2"):
+        raise NotImplementedError(f"Unknown loss type: {depth_loss_type}")   # DepthLoss (models/losses.py:150) also has smooth_l1
+    return _PixelLoss.apply(rgb, opacity, depth, pixels, sky_masks, lidar_depth, egocar_masks,
+                            (float(w_rgb), float(w_mask), float(w_depth)), depth_loss_type == "l2", float(max_depth))

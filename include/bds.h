@@ -262,6 +262,22 @@ int bds_ssim_fwd(int H, int W, int CH, const float *target, const float *pred, f
 int bds_ssim_bwd(int H, int W, int CH, const float *target, const float *pred, const void *ws, size_t ws_bytes,
                  const float *v_ssim, float *v_pred, bds_stream_t stream);
 
+/* Per-pixel terms of the reference's image loss in one pass each way (models/trainers/base.py:518-565; loss functions
+ * :230-250 = models/losses.py binary_cross_entropy and DepthLoss(normalize=False, use_inverse_depth=False)):
+ *   terms[0] = w_rgb   * mean |pixels*valid - rgb*valid|                          rgb, pixels [P,3]
+ *   terms[1] = w_mask  * mean BCE(opacity*valid, (1 - sky_masks)*valid)           opacity, sky_masks [P] (both or neither)
+ *   terms[2] = w_depth * mean over valid lidar returns of |.| (or (.)^2 if depth_l2) of depth*hit - lidar*hit,
+ *              hit = (lidar > 0)*valid, valid returns: 0.01 < gt < max_depth, pred > 1e-4   depth, lidar [P] (both or neither)
+ * valid = 1 - egocar [P] (NULL: 1).  sums [4] is scratch that the backward reads (three numerators + the depth count);
+ * v_terms [3] are the upstream gradients of the three terms (device); v_opacity / v_depth may be NULL. */
+int bds_pixel_loss_fwd(int64_t P, const float *rgb, const float *pixels, const float *opacity, const float *sky_masks,
+                       const float *depth, const float *lidar, const float *egocar, float w_rgb, float w_mask, float w_depth,
+                       int depth_l2, float max_depth, float *sums, float *terms, bds_stream_t stream);
+int bds_pixel_loss_bwd(int64_t P, const float *rgb, const float *pixels, const float *opacity, const float *sky_masks,
+                       const float *depth, const float *lidar, const float *egocar, float w_rgb, float w_mask, float w_depth,
+                       int depth_l2, float max_depth, const float *sums, const float *v_terms, float *v_rgb, float *v_opacity,
+                       float *v_depth, bds_stream_t stream);
+
 /* ---- Adam step on one parameter tensor (first slice) --------------------------------------
  * torch.optim.Adam as the reference trainer configures it (models/trainers/base.py:201-222: per-group lr / eps /
  * weight_decay, betas (0.9, 0.999), amsgrad off), one streaming pass, in place on param / exp_avg / exp_avg_sq.

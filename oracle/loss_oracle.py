@@ -28,7 +28,7 @@ def gauss_window(size: int = WIN_SIZE, sigma: float = WIN_SIGMA, dtype=torch.flo
 def _filter(x: torch.Tensor, win: torch.Tensor) -> torch.Tensor:
     """gaussian_filter: separable VALID correlation over H then W, one group per channel.  x [1,C,H,W]."""
     C = x.shape[1]
-    w = win.to(x.dtype).reshape(1, 1, -1).repeat(C, 1, 1)
+    w = win.to(device=x.device, dtype=x.dtype).reshape(1, 1, -1).repeat(C, 1, 1)
     out = F.conv2d(x, w.unsqueeze(-1), groups=C)      # along H  (weight [C,1,11,1])
     out = F.conv2d(out, w.unsqueeze(-2), groups=C)    # along W  (weight [C,1,1,11])
     return out
@@ -76,3 +76,38 @@ def ssim_map_bruteforce(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
                 s1, s2, s12 = (w2 * px * px).sum() - m1 * m1, (w2 * py * py).sum() - m2 * m2, (w2 * px * py).sum() - m1 * m2
                 out[0, c, i, j] = ((2 * m1 * m2 + C1) / (m1 * m1 + m2 * m2 + C1)) * ((2 * s12 + C2) / (s1 + s2 + C2))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-pixel terms of BasicTrainer.compute_losses (/root/reference/project/models/trainers/base.py:518-565) -- PINNED:
+# tests/golden/pixel_loss_*.npz are produced by the reference's own models/losses.py (oracle/gen_golden_losses.py).
+#   rgb   : |pixels*valid - rgb*valid|.mean()                                             (base.py:533-540)
+#   mask  : F.binary_cross_entropy(opacity*valid, (1-sky)*valid).mean()                   (losses.py:82-84, base.py:536-549)
+#   depth : DepthLoss(loss_type, normalize=False, use_inverse_depth=False)                (losses.py:92-178, base.py:553-557)
+# Values AND gradients are written out in closed form (torch's BCE backward divides by max((1-x)x, float(1e-12)) and its
+# forward clamps the logs at -100; autograd through a re-implementation would not reproduce the first).
+# ------------------------------------------------------------------------------------------------------------------
+def pixel_loss(rgb, pixels, opacity, sky_masks, depth, lidar, egocar=None, w=(0.8, 0.05, 0.01), depth_l2=False,
+               max_depth=80.0):
+    """rgb/pixels [H,W,3], opacity/depth [H,W,1], sky_masks/lidar/egocar [H,W].
+    Returns dict(rgb_loss, sky_loss, depth_loss, total, v_rgb, v_opacity, v_depth) for upstream gradient 1."""
+    dt = rgb.dtype
+    valid = (1.0 - egocar) if egocar is not None else torch.ones_like(sky_masks)
+    P = sky_masks.numel()
+    diff = (rgb - pixels) * valid[..., None]
+    rgb_loss = w[0] * diff.abs().sum() / (3 * P)
+    v_rgb = w[0] / (3 * P) * torch.sign(diff) * valid[..., None]
+    x, t = opacity.squeeze(-1) * valid, (1.0 - sky_masks) * valid
+    bce = -(t * torch.log(x).clamp(min=-100.0) + (1.0 - t) * torch.log(1.0 - x).clamp(min=-100.0))
+    sky_loss = w[1] * bce.sum() / P
+    eps = 9.999999960041972e-13   # torch's BCE backward clamps with a FLOAT constant 1e-12, also for float64 inputs
+    v_opacity = (w[1] / P * valid * (x - t) / ((1.0 - x) * x).clamp(min=eps))[..., None]
+    hit = (lidar > 0).to(dt) * valid
+    pred, gt = depth.squeeze(-1) * hit, lidar * hit
+    m = (gt > 0.01) & (gt < max_depth) & (pred > 0.0001)
+    cnt = m.sum().to(dt)
+    e = (pred - gt) * m
+    depth_loss = w[2] * ((e * e).sum() if depth_l2 else e.abs().sum()) / cnt
+    v_depth = (w[2] / cnt * hit * m * (2.0 * e if depth_l2 else torch.sign(e)))[..., None]
+    return dict(rgb_loss=rgb_loss, sky_loss=sky_loss, depth_loss=depth_loss, total=rgb_loss + sky_loss + depth_loss,
+                v_rgb=v_rgb, v_opacity=v_opacity, v_depth=v_depth)

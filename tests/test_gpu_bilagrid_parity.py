@@ -231,3 +231,26 @@ def test_ssim_matches_oracle(H, W):
     # no gradient requested: no workspace, same value
     with torch.no_grad():
         assert abs(float(ssim(pred.cuda(), gt.cuda())) - float(s)) < 1e-6
+
+
+def test_pixel_loss_matches_reference_goldens(golden_dir):
+    """losses.pixel_loss (HIP, one pass each way) vs tests/golden/pixel_loss_*.npz, which the reference's own
+    models/losses.py produced (oracle/gen_golden_losses.py): the three weighted terms and d/d(rgb, opacity, depth)."""
+    from bilateral_driving_amd.losses import pixel_loss
+    files = sorted(glob.glob(os.path.join(golden_dir, "pixel_loss_*f32.npz")))
+    assert len(files) >= 3
+    for f in files:
+        z = np.load(f)
+        c = lambda k: torch.from_numpy(z[k]).cuda()
+        rgb, opacity, depth = c("rgb").requires_grad_(True), c("opacity").requires_grad_(True), c("depth").requires_grad_(True)
+        ego = c("egocar") if z["egocar"].size else None
+        w = [float(v) for v in z["w"]]
+        terms = pixel_loss(rgb, opacity, depth, c("pixels"), c("sky_masks"), c("lidar"), ego, w[0], w[1], w[2],
+                           "l2" if int(z["depth_l2"]) else "l1")
+        terms.sum().backward()
+        for i, k in enumerate(("rgb_loss", "sky_loss", "depth_loss")):
+            assert abs(float(terms[i]) - float(z[k])) <= 3e-6 * max(1.0, abs(float(z[k]))), (f, k, float(terms[i]), float(z[k]))
+        for t, k in ((rgb, "v_rgb"), (opacity, "v_opacity"), (depth, "v_depth")):
+            ref = torch.from_numpy(z[k]).cuda()
+            err = float((t.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+            assert err <= 3e-6, (f, k, err)

@@ -41,3 +41,29 @@ def test_ssim_gradient_by_finite_differences():
         Yp[i, j, c] += eps; Ym[i, j, c] -= eps
         fd = (float(LO.ssim(X, Yp)) - float(LO.ssim(X, Ym))) / (2 * eps)
         assert abs(fd - float(Y.grad[i, j, c])) < 1e-7 + 1e-5 * abs(fd)
+
+
+def _load_pixel_case(path, dtype=None):
+    import numpy as np
+    z = np.load(path)
+    t = lambda k: torch.from_numpy(z[k]) if dtype is None else torch.from_numpy(z[k]).to(dtype)
+    ego = t("egocar") if z["egocar"].size else None
+    return z, dict(rgb=t("rgb"), pixels=t("pixels"), opacity=t("opacity"), sky_masks=t("sky_masks"), depth=t("depth"), lidar=t("lidar"),
+                   egocar=ego, w=tuple(float(v) for v in z["w"]), depth_l2=bool(int(z["depth_l2"])))
+
+
+def test_pixel_loss_oracle_against_reference_goldens(golden_dir):
+    """values and gradients of the rgb / sky-mask / depth terms == what the reference's own models/losses.py gave."""
+    import glob, os
+    files = sorted(glob.glob(os.path.join(golden_dir, "pixel_loss_*.npz")))
+    assert len(files) >= 5
+    for f in files:
+        z, kw = _load_pixel_case(f)
+        out = LO.pixel_loss(**kw)
+        tol = 1e-12 if "f64" in f else 2e-6
+        for k in ("rgb_loss", "sky_loss", "depth_loss", "total"):
+            assert abs(float(out[k]) - float(z[k])) <= tol * max(1.0, abs(float(z[k]))), (f, k)
+        for k in ("v_rgb", "v_opacity", "v_depth"):
+            ref = torch.from_numpy(z[k])
+            err = float((out[k] - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+            assert err <= (1e-12 if "f64" in f else 2e-6), (f, k, err)
