@@ -66,6 +66,7 @@ _SIGS = {
     "bds_ssim_bwd": (_i, [_i, _i, _i, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_pixel_loss_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f]),
     "bds_pixel_loss_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f, _f, _f, _f]),
+    "bds_densify_stats": (_i, [_i64, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_adam_step": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),
     "bds_bilagrid_tv_bwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f, _f]),

@@ -71,3 +71,53 @@ extern "C" int bds_adam_step(int64_t n, float *param, const float *grad, float *
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
+
+// ---- per-step densification statistics --------------------------------------------------------------------------------
+// BasicTrainer.postprocess_per_train_step (models/trainers/base.py:279-297) + VanillaGaussians.after_train
+// (models/gaussians/vanilla.py:163-191) for one set of Gaussians, in one launch and without the boolean-mask indexing of the
+// reference (each `x[mask] = ...` there is a nonzero() with a host sync):
+//   g = |absgrad| scaled by (width/2, height/2) * batch_size;  n = ||g||_2
+//   first call : xys_grad_norm = n for EVERY Gaussian, vis_counts = 1 for EVERY Gaussian (the reference's initialisation)
+//   later calls: visible (radii > 0): xys_grad_norm += n, vis_counts += 1
+//   always     : visible: max_2Dsize = max(max_2Dsize, radii / last_size)   (max_2Dsize starts at 0)
+// PINNED by tests/golden/densify_stats.npz (the reference's own method, oracle/gen_golden_densify.py).
+namespace bds {
+__global__ __launch_bounds__(kOptBlock) void densify_stats_kernel(int64_t N, const float *__restrict__ grad2d,
+                                                                 const int32_t *__restrict__ radii, float sx, float sy,
+                                                                 float last_size, int first, float *__restrict__ xys_grad_norm,
+                                                                 float *__restrict__ vis_counts, float *__restrict__ max_2Dsize) {
+#pragma clang fp contract(off)  // torch: separate multiply, square, add, sqrt
+  const int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x;
+  if (i >= N) return;
+  const int r = radii[i];
+  const bool vis = r > 0;
+  float n = 0.f;
+  if (first || vis) {
+    const float gx = grad2d[i * 2] * sx, gy = grad2d[i * 2 + 1] * sy;
+    n = sqrtf(gx * gx + gy * gy);
+  }
+  if (first) {
+    xys_grad_norm[i] = n;
+    vis_counts[i] = 1.f;
+    max_2Dsize[i] = vis ? fmaxf(0.f, (float)r / last_size) : 0.f;
+  } else if (vis) {
+    xys_grad_norm[i] = n + xys_grad_norm[i];
+    vis_counts[i] = vis_counts[i] + 1.f;
+    max_2Dsize[i] = fmaxf(max_2Dsize[i], (float)r / last_size);
+  }
+}
+}  // namespace bds
+
+extern "C" int bds_densify_stats(int64_t N, const float *grad2d, const int32_t *radii, int width, int height, int batch_size,
+                                 int last_size, int first, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
+                                 bds_stream_t stream) {
+  BDS_REQUIRE(N >= 0 && width > 0 && height > 0 && batch_size >= 1 && last_size > 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(grad2d && radii && xys_grad_norm && vis_counts && max_2Dsize);
+  // the reference multiplies by the Python float (width / 2.0 * batch_size): formed in double, rounded once
+  const float sx = (float)((double)width / 2.0 * (double)batch_size), sy = (float)((double)height / 2.0 * (double)batch_size);
+  hipLaunchKernelGGL(bds::densify_stats_kernel, dim3((unsigned)cdiv(N, bds::kOptBlock)), dim3(bds::kOptBlock), 0, as_stream(stream),
+                     N, grad2d, radii, sx, sy, (float)last_size, first, xys_grad_norm, vis_counts, max_2Dsize);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}

@@ -286,6 +286,14 @@ int bds_pixel_loss_bwd(int64_t P, const float *rgb, const float *pixels, const f
 int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream);
 
+/* Per-step densification statistics of one set of Gaussians in one launch (models/trainers/base.py:279-297 +
+ * models/gaussians/vanilla.py:163-191): grad2d [N,2] is info["means2d"].absgrad (or .grad) BEFORE the trainer's
+ * width/2, height/2, batch_size scaling; radii [N] i32.  first != 0 reproduces the reference's initialising call
+ * (xys_grad_norm = norm for every Gaussian, vis_counts = 1 for every Gaussian, max_2Dsize from zero). */
+int bds_densify_stats(int64_t N, const float *grad2d, const int32_t *radii, int width, int height, int batch_size,
+                      int last_size, int first, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
+                      bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

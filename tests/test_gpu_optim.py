@@ -55,3 +55,23 @@ def test_fused_adam_state_layout_allows_the_reference_surgery():
     opt.state[new_p] = st
     new_p.grad = torch.randn_like(new_p); opt.step()
     assert float(opt.state[new_p]["step"]) == 2 and torch.isfinite(new_p).all()
+
+
+def test_densify_stats_match_the_reference_method(golden_dir):
+    """optim.DensifyStats vs tests/golden/densify_stats.npz = three consecutive calls of the reference's own
+    VanillaGaussians.after_train fed as BasicTrainer.postprocess_per_train_step feeds it."""
+    import os
+    import numpy as np
+    from bilateral_driving_amd.optim import DensifyStats
+    z = np.load(os.path.join(golden_dir, "densify_stats.npz"))
+    N, W, H = int(z["N"]), int(z["W"]), int(z["H"])
+    st = DensifyStats(N, "cuda", batch_size=int(z["batch"]))
+    for call in range(3):
+        m2 = torch.zeros(1, N, 2, device="cuda")
+        m2.absgrad = torch.from_numpy(z[f"absgrad{call}"]).cuda()
+        info = {"means2d": m2, "radii": torch.from_numpy(z[f"radii{call}"]).cuda()[None], "width": W, "height": H}
+        st.update(info)
+        for name in ("xys_grad_norm", "vis_counts", "max_2Dsize"):
+            ref = torch.from_numpy(z[f"{name}{call}"]).cuda()
+            got = getattr(st, name)
+            assert torch.allclose(got, ref, rtol=2e-7, atol=0), (call, name, float((got - ref).abs().max()))
