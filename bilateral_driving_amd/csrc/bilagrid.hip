@@ -628,6 +628,63 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
   v_x[e] += g * v_tv[0];
 }
 
+
+// ---- TV of several grid pyramids' levels in ONE launch each way (the levels are tiny: a launch costs more than a level) ----
+struct TvLevels {
+  int n;
+  const float *x[BDS_MAX_LEVELS];
+  float *v_x[BDS_MAX_LEVELS];
+  long long total[BDS_MAX_LEVELS];
+  int gx[BDS_MAX_LEVELS], gy[BDS_MAX_LEVELS], gl[BDS_MAX_LEVELS];
+  float sl[BDS_MAX_LEVELS], sy[BDS_MAX_LEVELS], sx[BDS_MAX_LEVELS];
+  int blk_off[BDS_MAX_LEVELS + 1];
+};
+
+__global__ __launch_bounds__(kBgBlock) void tv_ms_fwd_kernel(TvLevels L, float *__restrict__ tv_out) {
+  __shared__ float red[kBgBlock / kWave];
+  int k = 0;
+  while (k + 1 < L.n && (int)blockIdx.x >= L.blk_off[k + 1]) k++;
+  const int nb = L.blk_off[k + 1] - L.blk_off[k], local = (int)blockIdx.x - L.blk_off[k];
+  const int gx = L.gx[k], gy = L.gy[k], gl = L.gl[k];
+  const float *x = L.x[k];
+  float acc = 0.f;
+  for (int64_t e = (int64_t)local * kBgBlock + threadIdx.x; e < L.total[k]; e += (int64_t)nb * kBgBlock) {
+    const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
+    const float v = x[e];
+    if (ix > 0) { const float d = v - x[e - 1]; acc += d * d * L.sx[k]; }
+    if (iy > 0) { const float d = v - x[e - gx]; acc += d * d * L.sy[k]; }
+    if (il > 0) { const float d = v - x[e - (int64_t)gx * gy]; acc += d * d * L.sl[k]; }
+  }
+  acc = wave_sum_all(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBgBlock / kWave; w++) t += red[w];
+    atomicAdd(tv_out, t);
+  }
+}
+
+__global__ __launch_bounds__(kBgBlock) void tv_ms_bwd_kernel(TvLevels L, const float *__restrict__ v_tv) {
+  int k = 0;
+  while (k + 1 < L.n && (int)blockIdx.x >= L.blk_off[k + 1]) k++;
+  const int64_t e = (int64_t)((int)blockIdx.x - L.blk_off[k]) * kBgBlock + threadIdx.x;
+  if (e >= L.total[k]) return;
+  const int gx = L.gx[k], gy = L.gy[k], gl = L.gl[k];
+  const float *x = L.x[k];
+  const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
+  const int64_t sl = (int64_t)gx * gy;
+  const float v = x[e];
+  float g = 0.f;
+  if (ix > 0) g += 2.f * (v - x[e - 1]) * L.sx[k];
+  if (ix < gx - 1) g -= 2.f * (x[e + 1] - v) * L.sx[k];
+  if (iy > 0) g += 2.f * (v - x[e - gx]) * L.sy[k];
+  if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * L.sy[k];
+  if (il > 0) g += 2.f * (v - x[e - sl]) * L.sl[k];
+  if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * L.sl[k];
+  L.v_x[k][e] += g * v_tv[0];
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct MsLayout {
   size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS], vg_off[BDS_MAX_LEVELS];
@@ -953,6 +1010,46 @@ extern "C" int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const floa
   const int64_t total = n * 12 * gl * gy * gx;
   hipLaunchKernelGGL(tv_bwd_kernel, dim3((unsigned)cdiv(total, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), total, gx, gy,
                      gl, grids, sl, sy, sx, v_tv, v_grids);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+static int tv_levels_fill(TvLevels &T, int nlevels, const bds_bilagrid_level_t *lv, const float *weights, bool bwd, int cap) {
+  BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && lv && weights);
+  T.n = nlevels;
+  T.blk_off[0] = 0;
+  for (int l = 0; l < nlevels; l++) {
+    BDS_REQUIRE(lv[l].grid && lv[l].gx >= 1 && lv[l].gy >= 1 && lv[l].gl >= 1 && lv[l].n_avg >= 1);
+    BDS_REQUIRE(!bwd || lv[l].v_grid);
+    T.x[l] = lv[l].grid; T.v_x[l] = lv[l].v_grid;
+    T.gx[l] = lv[l].gx; T.gy[l] = lv[l].gy; T.gl[l] = lv[l].gl;
+    T.total[l] = (long long)lv[l].n_avg * 12 * lv[l].gl * lv[l].gy * lv[l].gx;
+    tv_scales(lv[l].n_avg, lv[l].gx, lv[l].gy, lv[l].gl, weights[l], T.sl[l], T.sy[l], T.sx[l]);
+    int64_t nb = cdiv(T.total[l], kBgBlock);
+    if (cap > 0 && nb > cap) nb = cap;
+    T.blk_off[l + 1] = T.blk_off[l] + (int)nb;
+  }
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_tv_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, float *tv_out,
+                                      bds_stream_t stream) {
+  TvLevels T;
+  int rc = tv_levels_fill(T, nlevels, levels, weights, false, 256);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(tv_out);
+  hipLaunchKernelGGL(tv_ms_fwd_kernel, dim3((unsigned)T.blk_off[nlevels]), dim3(kBgBlock), 0, as_stream(stream), T, tv_out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, const float *v_tv,
+                                      bds_stream_t stream) {
+  TvLevels T;
+  int rc = tv_levels_fill(T, nlevels, levels, weights, true, 0);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(v_tv);
+  hipLaunchKernelGGL(tv_ms_bwd_kernel, dim3((unsigned)T.blk_off[nlevels]), dim3(kBgBlock), 0, as_stream(stream), T, v_tv);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -1,14 +1,17 @@
-"""Training-step loss on the path's outputs: photometric L1 + TV regulariser of the bilateral grids, as ONE autograd
-node whose terms accumulate into one device scalar (reference: models/trainers/base.py:518-529 rgb L1,
-:590-594 + models/modules.py:445,466-472 affine TV with per-level weights).  SURVEY.md 8f rank 1 (first slice: L1)."""
+"""Image loss of the training step on the path's outputs (reference:
+models/trainers/base.py:518-565 + models/losses.py, affine TV :590-594 + models/modules.py:445,466-472):
+``photometric_tv_loss`` (L1 + per-level TV as ONE node accumulating into one device scalar -- the benchmark's loss),
+``pixel_loss`` (rgb L1 + sky-mask BCE + lidar depth in one pass each way), ``ssim`` / ``ssim_loss``."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import Sequence
 
 import torch
 from torch import Tensor
 
 from . import _lib as L
+from .bilagrid import _levels_struct
 
 
 class _PhotometricTV(torch.autograd.Function):
@@ -21,10 +24,10 @@ class _PhotometricTV(torch.autograd.Function):
         grids = [g.contiguous() for g in grids]
         out = torch.zeros(1, device=rgb.device, dtype=torch.float32)
         L.check(lib.bds_l1_mean_fwd(rgb.numel(), L.ptr(rgb), L.ptr(target), L.ptr(out), st), "bds_l1_mean_fwd")
-        for g, w in zip(grids, tv_weights):
-            n, c, gl, gy, gx = g.shape
-            assert c == 12
-            L.check(lib.bds_bilagrid_tv_fwd(n, gx, gy, gl, L.ptr(g), float(w), L.ptr(out), st), "bds_bilagrid_tv_fwd")
+        if grids:
+            lv = _levels_struct(grids, None, [1] * len(grids))
+            wts = (C.c_float * len(grids))(*[float(w) for w in tv_weights])
+            L.check(lib.bds_bilagrid_tv_ms_fwd(len(grids), lv, wts, L.ptr(out), st), "bds_bilagrid_tv_ms_fwd")
         ctx.save_for_backward(rgb, target, *grids)
         ctx.tv_weights = tuple(float(w) for w in tv_weights)
         return out.reshape(())
@@ -43,16 +46,17 @@ class _PhotometricTV(torch.autograd.Function):
         if any(need):
             sizes = [(g.numel() + 3) // 4 * 4 if need[i] else 0 for i, g in enumerate(grids)]   # 16-byte aligned slices
             flat = torch.zeros(sum(sizes), device=rgb.device, dtype=torch.float32)               # one fill for all levels
-            off = 0
+            off, sel, sel_v, sel_w = 0, [], [], []
             for i, g in enumerate(grids):
                 if not need[i]:
                     continue
                 vg = flat[off:off + g.numel()].view(g.shape)
                 off += sizes[i]
-                n, _, gl, gy, gx = g.shape
-                L.check(lib.bds_bilagrid_tv_bwd(n, gx, gy, gl, L.ptr(g), ctx.tv_weights[i], L.ptr(v), L.ptr(vg), st),
-                        "bds_bilagrid_tv_bwd")
                 v_grids[i] = vg
+                sel.append(g); sel_v.append(vg); sel_w.append(ctx.tv_weights[i])
+            lv = _levels_struct(sel, sel_v, [1] * len(sel))
+            wts = (C.c_float * len(sel))(*sel_w)
+            L.check(lib.bds_bilagrid_tv_ms_bwd(len(sel), lv, wts, L.ptr(v), st), "bds_bilagrid_tv_ms_bwd")
         return (v_rgb, None, None, *v_grids)
 
 

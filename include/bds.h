@@ -207,6 +207,12 @@ int bds_bilagrid_tv_fwd(int64_t n, int gx, int gy, int gl, const float *grids, f
                         bds_stream_t stream);
 int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
                         float *v_grids, bds_stream_t stream);
+/* The same for all levels of a multi-scale transform in ONE launch each way: levels[l].grid / v_grid [n_avg,12,gl,gy,gx]
+ * (n_avg = number of images, factor unused), weights[l] as above; tv_out accumulates sum_l weights[l] * tv_l. */
+int bds_bilagrid_tv_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, float *tv_out,
+                           bds_stream_t stream);
+int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, const float *v_tv,
+                           bds_stream_t stream);
 
 /* ---- one-view forms for the fused training step ------------------------------------------------------
  * The per-Gaussian glue of one reference iteration folded into the two streaming kernels that sit next to it
