@@ -155,3 +155,27 @@ def test_scene_generator_shapes():
     assert torch.allclose(pc, torch.tensor([0.0, 0.0, 10.0]), atol=1e-6)
     g = Hn.make_grids(4)
     assert [tuple(x.shape) for x in g] == [(4, 12, 1, 2, 2), (4, 12, 2, 4, 4), (4, 12, 4, 8, 8)]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/project/models"), reason="the reference tree is only mounted in the build container")
+def test_reference_modules_import_against_the_dropin_packages():
+    """The UNMODIFIED reference modules that sit on the hot path import with this repo's `gsplat` / `bilateral` packages in
+    front (third-party packages the path never touches are stubbed): the import surface of SURVEY.md 8b resolves here."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "bilateral_driving_amd", "dropin"), ROOT, "/root/reference/project"]))
+    code = ("import sys, types\n"
+            "def stub(n, **a):\n"
+            "    m = types.ModuleType(n); m.__dict__.update(a); sys.modules[n] = m\n"
+            "stub('tensorly', set_backend=lambda *_: None)\n"
+            "stub('pytorch3d'); stub('pytorch3d.ops', knn_points=None)\n"
+            "stub('pytorch3d.transforms', matrix_to_quaternion=None, quaternion_to_matrix=None)\n"
+            "stub('nvdiffrast'); stub('nvdiffrast.torch')\n"
+            "stub('omegaconf', OmegaConf=type('OmegaConf', (), {}))\n"
+            "import models.gaussians.basics as B, models.gaussians.vanilla as V, models.modules as M\n"
+            "import bilateral_driving_amd.rendering as R, bilateral_driving_amd.gs_ops as O, bilateral_driving_amd.bilagrid as G\n"
+            "assert B.rasterization is R.rasterization and B.spherical_harmonics is O.spherical_harmonics\n"
+            "assert M.BilateralGrid is G.BilateralGrid and M.slice is G.slice and M.total_variation_loss is G.total_variation_loss\n"
+            "m = M.MultiScaleBilateralAffineTransform.__init__\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
