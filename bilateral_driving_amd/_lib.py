@@ -68,6 +68,10 @@ _SIGS = {
     "bds_pixel_loss_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f, _f, _f, _f]),
     "bds_densify_stats": (_i, [_i64, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_adam_step": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
+    "bds_bilagrid_slice_feat_fwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f]),
+    "bds_bilagrid_slice_feat_bwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_grid_tv_fwd": (_i, [_i64, _i, _i, _i, _i, _f, _fl, _f, _f]),
+    "bds_grid_tv_bwd": (_i, [_i64, _i, _i, _i, _i, _f, _fl, _f, _f, _f]),
     "bds_bilagrid_tv_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _f, _f]),
     "bds_bilagrid_tv_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _f, _f]),
     "bds_bilagrid_tv_fwd": (_i, [_i64, _i, _i, _i, _f, _fl, _f, _f]),

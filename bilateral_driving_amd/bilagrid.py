@@ -47,9 +47,8 @@ class _TotalVariation(torch.autograd.Function):
         L.require_gpu(x)
         x = _f32c(x)
         n, c, gl, gy, gx = x.shape
-        assert c == 12
         out = torch.zeros(1, device=x.device, dtype=torch.float32)
-        L.check(L.lib().bds_bilagrid_tv_fwd(n, gx, gy, gl, L.ptr(x), weight, L.ptr(out), L.stream()), "bds_bilagrid_tv_fwd")
+        L.check(L.lib().bds_grid_tv_fwd(n, c, gx, gy, gl, L.ptr(x), weight, L.ptr(out), L.stream()), "bds_grid_tv_fwd")
         ctx.save_for_backward(x)
         ctx.weight = weight
         return out.reshape(())
@@ -57,18 +56,19 @@ class _TotalVariation(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_out):
         (x,) = ctx.saved_tensors
-        n, _, gl, gy, gx = x.shape
+        n, c, gl, gy, gx = x.shape
         v = _f32c(v_out.reshape(1))
         v_x = torch.zeros_like(x)
-        L.check(L.lib().bds_bilagrid_tv_bwd(n, gx, gy, gl, L.ptr(x), ctx.weight, L.ptr(v), L.ptr(v_x), L.stream()),
-                "bds_bilagrid_tv_bwd")
+        L.check(L.lib().bds_grid_tv_bwd(n, c, gx, gy, gl, L.ptr(x), ctx.weight, L.ptr(v), L.ptr(v_x), L.stream()),
+                "bds_grid_tv_bwd")
         return v_x, None
 
 
 def total_variation_loss(x: Tensor, weight: float = 1.0) -> Tensor:
-    """Total variation of bilateral grids x [B, 12, L, H, W] (lib_bilagrid.py:152-168), times ``weight``."""
-    if x.dim() != 5 or x.shape[1] != 12:
-        raise ValueError("total_variation_loss expects bilateral grids of shape (B, 12, L, H, W)")
+    """Total variation of bilateral grids x [B, C, L, H, W] (lib_bilagrid.py:152-168; C = 12 affine or any feature
+    width), times ``weight``."""
+    if x.dim() != 5:
+        raise ValueError("total_variation_loss expects bilateral grids of shape (B, C, L, H, W)")
     return _TotalVariation.apply(x, float(weight))
 
 
@@ -76,17 +76,21 @@ def total_variation_loss(x: Tensor, weight: float = 1.0) -> Tensor:
 # point slice (BilateralGrid.forward)
 # --------------------------------------------------------------------------------------------
 class _SlicePoints(torch.autograd.Function):
-    """grid [12,L,gy,gx], xy [P,2], rgb [P,3] -> affine [P,12]"""
+    """grid [C,L,gy,gx], xy [P,2], rgb [P,3] -> [P,C]  (C = 12: affine maps; any other C: feature grids)"""
 
     @staticmethod
     def forward(ctx, grid: Tensor, xy: Tensor, rgb: Tensor):
         L.require_gpu(grid, xy, rgb)
         grid, xy, rgb = _f32c(grid), _f32c(xy), _f32c(rgb)
         P = xy.shape[0]
-        _, gl, gy, gx = grid.shape
-        aff = torch.empty(P, 12, device=grid.device, dtype=torch.float32)
-        L.check(L.lib().bds_bilagrid_slice_fwd(P, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(aff), L.stream()),
-                "bds_bilagrid_slice_fwd")
+        nc, gl, gy, gx = grid.shape
+        aff = torch.empty(P, nc, device=grid.device, dtype=torch.float32)
+        if nc == 12:
+            L.check(L.lib().bds_bilagrid_slice_fwd(P, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(aff), L.stream()),
+                    "bds_bilagrid_slice_fwd")
+        else:
+            L.check(L.lib().bds_bilagrid_slice_feat_fwd(P, nc, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(aff), L.stream()),
+                    "bds_bilagrid_slice_feat_fwd")
         ctx.save_for_backward(grid, xy, rgb)
         return aff
 
@@ -97,12 +101,16 @@ class _SlicePoints(torch.autograd.Function):
             raise NotImplementedError("gradient w.r.t. the slice xy coordinates is not on the reference's path "
                                       "(they come from linspace / pixel indices)")
         P = xy.shape[0]
-        _, gl, gy, gx = grid.shape
+        nc, gl, gy, gx = grid.shape
         v_aff = _f32c(v_aff)
         v_grid = torch.zeros_like(grid) if ctx.needs_input_grad[0] else None
         v_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[2] else None
-        L.check(L.lib().bds_bilagrid_slice_bwd(P, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(v_aff), L.ptr(v_grid),
-                                               L.ptr(v_rgb), L.stream()), "bds_bilagrid_slice_bwd")
+        if nc == 12:
+            L.check(L.lib().bds_bilagrid_slice_bwd(P, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(v_aff), L.ptr(v_grid),
+                                                   L.ptr(v_rgb), L.stream()), "bds_bilagrid_slice_bwd")
+        else:
+            L.check(L.lib().bds_bilagrid_slice_feat_bwd(P, nc, L.ptr(grid), gx, gy, gl, L.ptr(xy), L.ptr(rgb), L.ptr(v_aff),
+                                                        L.ptr(v_grid), L.ptr(v_rgb), L.stream()), "bds_bilagrid_slice_feat_bwd")
         return v_grid, None, v_rgb
 
 
@@ -128,37 +136,81 @@ class BilateralGrid(nn.Module):
     def forward(self, grid_xy: Tensor, rgb: Tensor, idx: Optional[Tensor] = None) -> Tensor:
         """grid_xy [..., 2] in [0,1], rgb [..., 3]; 2-D..4-D inputs need ``idx`` ([B] grid indices, one per
         leading-batch entry); 5-D inputs use one grid per leading entry.  Returns [..., 3, 4]."""
-        nd = grid_xy.dim()
-        assert rgb.dim() == nd
-        if not (1 < nd <= 5):
-            raise ValueError("Bilateral grid slicing only takes either 2D, 3D, 4D and 5D inputs")
-        if nd < 5:
-            assert idx is not None
-        B = grid_xy.shape[0]
-        if idx is None:
-            assert self.grids.shape[0] == B
-            sel = range(B)
-        else:
-            idx = idx.reshape(-1)
-            assert idx.numel() == B, (idx.shape, B)
-            sel = idx.tolist()
-        per = grid_xy[0].numel() // 2
-        flat_xy = grid_xy.reshape(B, per, 2)
-        flat_rgb = rgb.reshape(B, per, 3)
-        # one launch per distinct grid: batch entries using the same grid are sliced together
-        groups = {}
-        for b, g in enumerate(sel):
-            groups.setdefault(int(g), []).append(b)
-        if len(groups) == 1:
-            (g, _), = groups.items()
-            out = _SlicePoints.apply(self.grids[g], flat_xy.reshape(-1, 2), flat_rgb.reshape(-1, 3))
-        else:
-            out = torch.zeros(B, per, 12, device=rgb.device, dtype=torch.float32)
-            for g, bs in groups.items():
-                bsel = torch.tensor(bs, device=rgb.device)
-                a = _SlicePoints.apply(self.grids[g], flat_xy[bsel].reshape(-1, 2), flat_rgb[bsel].reshape(-1, 3))
-                out = out.index_add(0, bsel, a.reshape(len(bs), per, 12))
+        out = _slice_grids(self.grids, grid_xy, rgb, idx)
         return out.reshape(*grid_xy.shape[:-1], 3, 4)
+
+
+def _slice_grids(grids: Tensor, grid_xy: Tensor, rgb: Tensor, idx: Optional[Tensor]) -> Tensor:
+    """Shared body of BilateralGrid.forward / NeuralBilateralGrid.forward: [B, per, C] sliced values."""
+    nd = grid_xy.dim()
+    assert rgb.dim() == nd
+    if not (1 < nd <= 5):
+        raise ValueError("Bilateral grid slicing only takes either 2D, 3D, 4D and 5D inputs")
+    if nd < 5:
+        assert idx is not None
+    B, nc = grid_xy.shape[0], grids.shape[1]
+    if idx is None:
+        assert grids.shape[0] == B
+        sel = range(B)
+    else:
+        idx = idx.reshape(-1)
+        assert idx.numel() == B, (idx.shape, B)
+        sel = idx.tolist()
+    per = grid_xy[0].numel() // 2
+    flat_xy = grid_xy.reshape(B, per, 2)
+    flat_rgb = rgb.reshape(B, per, 3)
+    # one launch per distinct grid: batch entries using the same grid are sliced together
+    groups = {}
+    for b, g in enumerate(sel):
+        groups.setdefault(int(g), []).append(b)
+    if len(groups) == 1:
+        (g, _), = groups.items()
+        return _SlicePoints.apply(grids[g], flat_xy.reshape(-1, 2), flat_rgb.reshape(-1, 3)).reshape(B, per, nc)
+    out = torch.zeros(B, per, nc, device=rgb.device, dtype=torch.float32)
+    for g, bs in groups.items():
+        bsel = torch.tensor(bs, device=rgb.device)
+        a = _SlicePoints.apply(grids[g], flat_xy[bsel].reshape(-1, 2), flat_rgb[bsel].reshape(-1, 3))
+        out = out.index_add(0, bsel, a.reshape(len(bs), per, nc))
+    return out
+
+
+class NeuralBilateralGrid(nn.Module):
+    """``num`` FEATURE grids [num, feature_dim, L, H, W], zero-initialised (lib_bilagrid.py:370-414); ``forward`` slices
+    them like ``BilateralGrid`` and returns the features [..., feature_dim] (lib_bilagrid.py:420-461)."""
+
+    def __init__(self, num, grid_X=16, grid_Y=16, grid_W=8, feature_dim=8, mode="bilinear"):
+        super().__init__()
+        if mode != "bilinear":
+            raise NotImplementedError("only mode='bilinear'")
+        self.grid_width, self.grid_height, self.grid_guidance, self.mode = grid_X, grid_Y, grid_W, mode
+        self.grids = nn.Parameter(torch.zeros(num, feature_dim, grid_W, grid_Y, grid_X, dtype=torch.float32))
+        self.register_buffer("rgb2gray_weight", torch.tensor([[0.299, 0.587, 0.114]], dtype=torch.float32))
+
+    def tv_loss(self):
+        return total_variation_loss(self.grids)
+
+    def forward(self, grid_xy: Tensor, rgb: Tensor, idx: Optional[Tensor] = None) -> Tensor:
+        out = _slice_grids(self.grids, grid_xy, rgb, idx)     # [B, per, f]
+        nd = grid_xy.dim()
+        # the reference pads the input to 5-D and squeezes dim 1 of the result (lib_bilagrid.py:437-459)
+        shape5 = list(grid_xy.shape[:1]) + [1] * (5 - nd) + list(grid_xy.shape[1:-1]) + [out.shape[-1]]
+        out = out.reshape(shape5)
+        return out.squeeze(1)
+
+
+def slice_feature(bil_grids: NeuralBilateralGrid, xy: Tensor, rgb: Tensor, grid_idx: Tensor):
+    """lib_bilagrid.slice_feature (:232-253): as ``slice`` but returns ``{"affine_features": [..., feature_dim]}``."""
+    shape = rgb.shape
+    distinct = torch.unique(grid_idx)
+    if distinct.numel() == 1:
+        per_entry_idx = distinct
+        xy, rgb = xy[None], rgb[None]
+    else:
+        if not 2 <= grid_idx.dim() <= 4:
+            raise ValueError("The input to bilateral grid slicing is not supported yet.")
+        per_entry_idx = grid_idx.reshape(grid_idx.shape[0], -1)[:, 0]
+    feats = bil_grids(xy, rgb, per_entry_idx)
+    return {"affine_features": feats.reshape(*shape[:-1], feats.shape[-1])}
 
 
 def slice(bil_grids: BilateralGrid, xy: Tensor, rgb: Tensor, grid_idx: Tensor):

@@ -347,12 +347,12 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 // summed with the 16-value transpose-reduce (35 VALU ops) and committed by 12 lanes to 12 different
 // addresses -- conflict-free by construction.
 __device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, int gx, int gy, int gl, float scale,
-                                                   const float *va, bool active) {
+                                                   const float *va, bool active, int nch = 12) {
   const int lane = threadIdx.x & (kWave - 1);
   const int plane = gy * gx, vol = gl * plane;
   const int key = active ? (c.z0 * gy + c.y0) * gx + c.x0 : -1;
   const int slot = butterfly_slot(lane);
-  const bool committer = ((lane & 3) == 0) && slot < 12;
+  const bool committer = ((lane & 3) == 0) && slot < nch;
   unsigned long long remaining = __ballot(active);
   while (remaining) {
     const int leader = __ffsll((long long)remaining) - 1;
@@ -583,6 +583,50 @@ __global__ __launch_bounds__(kBgBlock) void slice_bwd_kernel(int64_t P, const fl
       for (int ch = 0; ch < 12; ch++) v_iz += va[ch] * dz[ch];
       vg = v_iz * (float)(gl - 1);
     }
+    v_rgb[i * 3] = vg * kGrayR; v_rgb[i * 3 + 1] = vg * kGrayG; v_rgb[i * 3 + 2] = vg * kGrayB;
+  }
+}
+
+// ---- point slice of a FEATURE grid with any channel count (NeuralBilateralGrid.forward, lib_bilagrid.py:370-461) ---------
+__global__ __launch_bounds__(kBgBlock) void slice_feat_fwd_kernel(int64_t P, int NC, const float *__restrict__ grid, int gx, int gy,
+                                                                 int gl, const float *__restrict__ xy, const float *__restrict__ rgb,
+                                                                 float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  if (i >= P) return;
+  const Cell c = slice_cell(xy[i * 2], xy[i * 2 + 1], rgb2gray(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]), gx, gy, gl);
+  const int vol = gl * gy * gx;
+  for (int c0 = 0; c0 < NC; c0 += 12) {
+    const int nch = NC - c0 < 12 ? NC - c0 : 12;
+    float a[12];
+    slice_sample_n(grid + (int64_t)c0 * vol, gx, gy, gl, c, nch, a, nullptr);
+    for (int k = 0; k < nch; k++) out[i * NC + c0 + k] = a[k];
+  }
+}
+
+__global__ __launch_bounds__(kBgBlock) void slice_feat_bwd_kernel(int64_t P, int NC, const float *__restrict__ grid, int gx, int gy,
+                                                                 int gl, const float *__restrict__ xy, const float *__restrict__ rgb,
+                                                                 const float *__restrict__ v_out, float *__restrict__ v_grid,
+                                                                 float *__restrict__ v_rgb) {
+  const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
+  const bool active = i < P;
+  const int64_t ii = active ? i : 0;
+  const Cell c = slice_cell(xy[ii * 2], xy[ii * 2 + 1], rgb2gray(rgb[ii * 3], rgb[ii * 3 + 1], rgb[ii * 3 + 2]), gx, gy, gl);
+  const int vol = gl * gy * gx;
+  float v_iz = 0.f;
+  for (int c0 = 0; c0 < NC; c0 += 12) {   // uniform trip count: the scatter is a wave-collective
+    const int nch = NC - c0 < 12 ? NC - c0 : 12;
+    float va[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) va[k] = (active && k < nch) ? v_out[ii * NC + c0 + k] : 0.f;
+    if (v_grid) slice_grid_scatter(v_grid + (int64_t)c0 * vol, c, gx, gy, gl, 1.f, va, active, nch);
+    if (active && v_rgb && c.z_interior) {
+      float a12[12], dz[12];
+      slice_sample_n(grid + (int64_t)c0 * vol, gx, gy, gl, c, nch, a12, dz);
+      for (int k = 0; k < nch; k++) v_iz += va[k] * dz[k];
+    }
+  }
+  if (active && v_rgb) {
+    const float vg = c.z_interior ? v_iz * (float)(gl - 1) : 0.f;
     v_rgb[i * 3] = vg * kGrayR; v_rgb[i * 3 + 1] = vg * kGrayG; v_rgb[i * 3 + 2] = vg * kGrayB;
   }
 }
@@ -980,10 +1024,10 @@ extern "C" int bds_bilagrid_slice_bwd(int64_t P, const float *grid, int gx, int 
   return BDS_OK;
 }
 
-static void tv_scales(int64_t n, int gx, int gy, int gl, float weight, float &sl, float &sy, float &sx) {
+static void tv_scales(int64_t n, int gx, int gy, int gl, float weight, float &sl, float &sy, float &sx, int channels = 12) {
   // lib_bilagrid.py:147-168: each axis' squared differences are divided by the element count of
   // the differenced tensor (per batch item, floor 1); the sum is divided by the batch size.
-  auto cnt = [](int64_t a, int64_t b, int64_t c) { double v = 12.0 * a * b * c; return v < 1.0 ? 1.0 : v; };
+  auto cnt = [channels](int64_t a, int64_t b, int64_t c) { double v = (double)channels * a * b * c; return v < 1.0 ? 1.0 : v; };
   sl = (float)(weight / (cnt(gl - 1, gy, gx) * (double)n));
   sy = (float)(weight / (cnt(gl, gy - 1, gx) * (double)n));
   sx = (float)(weight / (cnt(gl, gy, gx - 1) * (double)n));
@@ -1050,6 +1094,55 @@ extern "C" int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *l
   if (rc != BDS_OK) return rc;
   BDS_REQUIRE(v_tv);
   hipLaunchKernelGGL(tv_ms_bwd_kernel, dim3((unsigned)T.blk_off[nlevels]), dim3(kBgBlock), 0, as_stream(stream), T, v_tv);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_slice_feat_fwd(int64_t P, int NC, const float *grid, int gx, int gy, int gl, const float *xy,
+                                           const float *rgb, float *out, bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0 && NC >= 1 && gx >= 1 && gy >= 1 && gl >= 1);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(grid && xy && rgb && out);
+  hipLaunchKernelGGL(slice_feat_fwd_kernel, dim3((unsigned)cdiv(P, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), P, NC, grid, gx,
+                     gy, gl, xy, rgb, out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_slice_feat_bwd(int64_t P, int NC, const float *grid, int gx, int gy, int gl, const float *xy,
+                                           const float *rgb, const float *v_out, float *v_grid, float *v_rgb,
+                                           bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0 && NC >= 1 && gx >= 1 && gy >= 1 && gl >= 1);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(grid && xy && rgb && v_out);
+  hipLaunchKernelGGL(slice_feat_bwd_kernel, dim3((unsigned)cdiv(P, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), P, NC, grid, gx,
+                     gy, gl, xy, rgb, v_out, v_grid, v_rgb);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+// TV of grids with any channel count: x [n, channels, gl, gy, gx]
+extern "C" int bds_grid_tv_fwd(int64_t n, int channels, int gx, int gy, int gl, const float *grids, float weight, float *tv_out,
+                               bds_stream_t stream) {
+  BDS_REQUIRE(n >= 1 && channels >= 1 && gx >= 1 && gy >= 1 && gl >= 1 && grids && tv_out);
+  float sl, sy, sx;
+  tv_scales(n, gx, gy, gl, weight, sl, sy, sx, channels);
+  const int64_t total = n * channels * gl * gy * gx;
+  const int64_t blocks = cdiv(total, kBgBlock);
+  hipLaunchKernelGGL(tv_fwd_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(kBgBlock), 0, as_stream(stream), total,
+                     gx, gy, gl, grids, sl, sy, sx, tv_out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_grid_tv_bwd(int64_t n, int channels, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
+                               float *v_grids, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 1 && channels >= 1 && gx >= 1 && gy >= 1 && gl >= 1 && grids && v_tv && v_grids);
+  float sl, sy, sx;
+  tv_scales(n, gx, gy, gl, weight, sl, sy, sx, channels);
+  const int64_t total = n * channels * gl * gy * gx;
+  hipLaunchKernelGGL(tv_bwd_kernel, dim3((unsigned)cdiv(total, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), total, gx, gy,
+                     gl, grids, sl, sy, sx, v_tv, v_grids);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

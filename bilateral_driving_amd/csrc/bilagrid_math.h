@@ -98,6 +98,22 @@ BDS_HD void slice_sample(const float *grid, int gx, int gy, int gl, const Cell &
   }
 }
 
+// the same for a run of `nch` <= 12 channels starting at `grid` (feature grids: any channel count, 12 at a time)
+BDS_HD void slice_sample_n(const float *grid, int gx, int gy, int gl, const Cell &c, int nch, float *out, float *dz) {
+  const int plane = gy * gx, vol = gl * plane;
+  const int o00 = c.y0 * gx + c.x0, o01 = c.y0 * gx + c.x1, o10 = c.y1 * gx + c.x0, o11 = c.y1 * gx + c.x1;
+  const float w00 = (1.f - c.fy) * (1.f - c.fx), w01 = (1.f - c.fy) * c.fx, w10 = c.fy * (1.f - c.fx), w11 = c.fy * c.fx;
+  for (int ch = 0; ch < 12; ch++) {
+    if (ch >= nch) { out[ch] = 0.f; if (dz) dz[ch] = 0.f; continue; }
+    const float *g0 = grid + ch * vol + c.z0 * plane;
+    const float *g1 = grid + ch * vol + c.z1 * plane;
+    const float a = g0[o00] * w00 + g0[o01] * w01 + g0[o10] * w10 + g0[o11] * w11;
+    const float b = g1[o00] * w00 + g1[o01] * w01 + g1[o10] * w10 + g1[o11] * w11;
+    out[ch] = a * (1.f - c.fz) + b * c.fz;
+    if (dz) dz[ch] = b - a;
+  }
+}
+
 // p <- A[:, :3] p + A[:, 3]   (A row-major 3x4 in a12)
 BDS_HD void apply_affine(const float *a12, float &r, float &g, float &b) {
   const float nr = a12[0] * r + a12[1] * g + a12[2] * b + a12[3];

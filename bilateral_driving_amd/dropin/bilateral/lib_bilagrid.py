@@ -1,26 +1,20 @@
 """Import surface of the reference's bilateral.lib_bilagrid (models/modules.py:13), served by
-bilateral_driving_amd.bilagrid.  The names outside the hot path are present
+bilateral_driving_amd.bilagrid.  The names not built here (CP-4D grids, colour-correct post-process) are present
 so that the import line resolves, and raise when used."""
 from bilateral_driving_amd.bilagrid import (  # noqa: F401
-    BilateralGrid, bilagrid_transform, color_affine_transform, slice, total_variation_loss)
+    BilateralGrid, NeuralBilateralGrid, bilagrid_transform, color_affine_transform, slice, slice_feature, total_variation_loss)
 
 
 def _not_on_hot_path(name):
     def f(*a, **k):
         raise NotImplementedError(f"bilateral.lib_bilagrid.{name} is outside the MI355X hot path built here "
-                                  "(neural / CP-4D bilateral variants, colour-correct post-process)")
+                                  "(CP-4D bilateral grids, colour-correct post-process)")
     f.__name__ = name
     return f
 
 
 color_correct = _not_on_hot_path("color_correct")
-slice_feature = _not_on_hot_path("slice_feature")
 slice4d = _not_on_hot_path("slice4d")
-
-
-class NeuralBilateralGrid:  # noqa: D101
-    def __init__(self, *a, **k):
-        _not_on_hot_path("NeuralBilateralGrid")()
 
 
 class BilateralGridCP4D:  # noqa: D101

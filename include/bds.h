@@ -174,6 +174,13 @@ int bds_bilagrid_slice_fwd(int64_t P, const float *grid, int gx, int gy, int gl,
 int bds_bilagrid_slice_bwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy, const float *rgb,
                            const float *v_affine, float *v_grid, float *v_rgb, bds_stream_t stream);
 
+/* The same slice for FEATURE grids of any channel count NC (bilateral/lib_bilagrid.py:370-461 NeuralBilateralGrid.forward,
+ * used by slice_feature :232-253): grid [NC,L,gy,gx] -> out [P,NC]; v_grid accumulated, v_rgb written (guidance route). */
+int bds_bilagrid_slice_feat_fwd(int64_t P, int NC, const float *grid, int gx, int gy, int gl, const float *xy,
+                                const float *rgb, float *out, bds_stream_t stream);
+int bds_bilagrid_slice_feat_bwd(int64_t P, int NC, const float *grid, int gx, int gy, int gl, const float *xy,
+                                const float *rgb, const float *v_out, float *v_grid, float *v_rgb, bds_stream_t stream);
+
 /* Fused image transform: models/modules.py:505-522 MultiScaleBilateralAffineTransform.forward
  * (train branch: get_sample_grid :494-504, slice, fill_matrix_res :409-420), the single-scale
  * BilateralAffineTransform.forward :317-335 (factor 1), the sequential application at
@@ -207,6 +214,11 @@ int bds_bilagrid_tv_fwd(int64_t n, int gx, int gy, int gl, const float *grids, f
                         bds_stream_t stream);
 int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
                         float *v_grids, bds_stream_t stream);
+/* ... and for grids with `channels` != 12 (NeuralBilateralGrid.tv_loss): grids [n, channels, gl, gy, gx] */
+int bds_grid_tv_fwd(int64_t n, int channels, int gx, int gy, int gl, const float *grids, float weight, float *tv_out,
+                    bds_stream_t stream);
+int bds_grid_tv_bwd(int64_t n, int channels, int gx, int gy, int gl, const float *grids, float weight, const float *v_tv,
+                    float *v_grids, bds_stream_t stream);
 /* The same for all levels of a multi-scale transform in ONE launch each way: levels[l].grid / v_grid [n_avg,12,gl,gy,gx]
  * (n_avg = number of images, factor unused), weights[l] as above; tv_out accumulates sum_l weights[l] * tv_l. */
 int bds_bilagrid_tv_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, float *tv_out,

@@ -254,3 +254,29 @@ def test_pixel_loss_matches_reference_goldens(golden_dir):
             ref = torch.from_numpy(z[k]).cuda()
             err = float((t.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
             assert err <= 3e-6, (f, k, err)
+
+
+def test_feature_grid_slice_matches_reference_goldens(golden_dir):
+    """NeuralBilateralGrid + slice_feature + tv_loss on the HIP kernels (any channel count) vs the reference's own
+    classes (tests/golden/neural_slice_*.npz): features, TV, d/d(grids), d/d(rgb)."""
+    from bilateral_driving_amd.bilagrid import NeuralBilateralGrid, slice_feature
+    files = sorted(glob.glob(os.path.join(golden_dir, "neural_slice_*f32.npz")))
+    assert len(files) >= 4
+    for f in files:
+        z = np.load(f)
+        num, fdim, gl, gy, gx = z["grids"].shape
+        net = NeuralBilateralGrid(num, gx, gy, gl, feature_dim=fdim).cuda()
+        assert net.grids.shape == z["grids"].shape and float(net.grids.abs().max()) == 0.0     # zero-initialised
+        with torch.no_grad():
+            net.grids.copy_(torch.from_numpy(z["grids"]))
+        xy = torch.from_numpy(z["xy"]).cuda()
+        rgb = torch.from_numpy(z["rgb"]).cuda().requires_grad_(True)
+        idx, w = torch.from_numpy(z["idx"]).cuda(), torch.from_numpy(z["w"]).cuda()
+        feats = slice_feature(net, xy, rgb, idx)["affine_features"]
+        tv = net.tv_loss()
+        ((feats * w).sum() + 0.3 * tv).backward()
+        assert feats.shape == z["feats"].shape
+        assert rel_err(feats.cpu(), torch.from_numpy(z["feats"])) < 2e-5, f
+        assert abs(float(tv) - float(z["tv"])) < 2e-5 * max(1.0, float(z["tv"])), f
+        assert rel_err(net.grids.grad.cpu(), torch.from_numpy(z["v_grids"])) < 5e-5, f
+        assert rel_err(rgb.grad.cpu(), torch.from_numpy(z["v_rgb"])) < 5e-5, f

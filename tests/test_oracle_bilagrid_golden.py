@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import bilagrid_oracle as O
+from tests.util import rel_err
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -114,3 +115,29 @@ def test_tv_matches_reference(path):
             np.testing.assert_allclose(x.grad.numpy(), z[f"v_x{i}"], rtol=tol["rtol"] * 5, atol=tol["atol"])
         i += 1
     assert i == 4
+
+
+def test_feature_grid_slice_and_tv_against_reference_goldens(golden_dir):
+    """The channel-generic slice / TV of the oracle vs NeuralBilateralGrid + slice_feature + tv_loss of the reference
+    (tests/golden/neural_slice_*.npz, oracle/gen_golden_neural.py): features, TV, d/d(grids), d/d(rgb)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(golden_dir, "neural_slice_*.npz")))
+    assert len(files) >= 5
+    for f in files:
+        z = np.load(f)
+        grids = torch.from_numpy(z["grids"]).requires_grad_(True)
+        xy, rgb = torch.from_numpy(z["xy"]), torch.from_numpy(z["rgb"]).requires_grad_(True)
+        idx, w = torch.from_numpy(z["idx"]), torch.from_numpy(z["w"])
+        if xy.dim() == 3:    # one view
+            feats = O.slice_grid(grids[int(idx.reshape(-1)[0])], xy[..., 0], xy[..., 1], O.rgb2gray(rgb))
+        else:                # one grid per leading entry
+            feats = torch.stack([O.slice_grid(grids[int(idx[b].reshape(-1)[0])], xy[b, ..., 0], xy[b, ..., 1], O.rgb2gray(rgb[b]))
+                                 for b in range(xy.shape[0])])
+        tv = O.total_variation_loss(grids)
+        ((feats * w).sum() + 0.3 * tv).backward()
+        # (the reference keeps its BT.601 weights as float32 constants also when run in float64: 5e-8 relative on the guidance)
+        tol = 1e-6 if "f64" in f else 3e-5
+        assert rel_err(feats, torch.from_numpy(z["feats"])) < tol, f
+        assert abs(float(tv) - float(z["tv"])) < tol * max(1.0, float(z["tv"])), f
+        assert rel_err(grids.grad, torch.from_numpy(z["v_grids"])) < tol, f
+        assert rel_err(rgb.grad, torch.from_numpy(z["v_rgb"])) < tol, f
