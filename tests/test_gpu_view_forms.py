@@ -174,3 +174,34 @@ def test_isect_prepare_async_reports_the_same_counts(env):
     L.check(lib.bds_isect_build(1, N, M, nv, L.ptr(m2), L.ptr(radii), L.ptr(d), L.ptr(con), L.ptr(op), 16, tw, th, L.ptr(ws), wsb, L.ptr(ws2),
                                 ws2b, None, L.ptr(fids), L.ptr(offs), st), "build")
     assert torch.equal(fids, fids_ref) and torch.equal(offs, offs_ref)
+
+
+def test_fused_view_with_nothing_on_screen(env):
+    """Every Gaussian behind the camera: M = 0 through the whole fused step (image = sky through the transform, all
+    parameter gradients exactly zero, grid gradients live through the sky)."""
+    ops, L = env
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.fused_view import fused_view
+    W, H, N = 96, 64, 500
+    cam = Hn.ring_cameras(W, H, device="cuda")[0]
+    p = Hn.synthetic_scene(N, seed=1, device="cuda")
+    with torch.no_grad():
+        # move everything behind the first camera (it looks along +z of its own frame)
+        R, t = cam.viewmat[:3, :3], cam.viewmat[:3, 3]
+        pc = p["means"] @ R.T + t
+        pc[:, 2] = -pc[:, 2].abs() - 1.0
+        p["means"].copy_((pc - t) @ R)
+    for v in p.values():
+        v.requires_grad_(True)
+    grids = [g.cuda().requires_grad_(True) for g in Hn.make_grids(6, seed=2)]
+    sky = torch.rand(H, W, 3, device="cuda")
+    for rep in range(2):   # the second call goes through the provisioned-capacity path
+        out = fused_view(p, cam.viewmat, cam.K, W, H, grids, sky, Hn.FACTORS_3, img_idx=0, cam_pos=cam.cam_pos)
+        assert out["info"]["flatten_ids"].numel() == 0 and int((out["info"]["radii"] > 0).sum()) == 0
+        assert float(out["opacity"].abs().max()) == 0.0 and float(out["depth"].abs().max()) == 0.0
+        (out["rgb"] * torch.rand_like(out["rgb"])).sum().backward()
+        for k, v in p.items():
+            assert v.grad is not None and float(v.grad.abs().max()) == 0.0, k
+        assert any(float(g.grad.abs().max()) > 0 for g in grids)
+        for t_ in list(p.values()) + grids:
+            t_.grad = None
