@@ -184,6 +184,8 @@ def main():
         flat.zero()
         skies[v].grad = None
         out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena)
+        if world > 1:   # rows that can receive a gradient on this rank; the OR over the ranks runs behind the backward pass
+            flat.begin_rows_union(out["info"]["radii"][0] > 0)
         loss = Hn.training_loss(out, targets[v], grids)
         loss.backward()
         flat.all_reduce()
@@ -243,7 +245,7 @@ def main():
                                f"[[2,2,1],[4,4,2],[8,8,4]] factors [4,4,2], L1+TV loss, one view per GPU per step",
                    "gaussians": N, "width": W, "height": H, "views": len(cams), "n_visible_last": n_vis,
                    "isects_mean": M_mean, "parallelism": f"view-dp{world}",
-                   "allreduce_bytes": flat.nbytes if world > 1 else 0},
+                   "allreduce_bytes": flat.last_payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0},
         "roofline": roofline,
         "per_kernel_ms": {k: round(v[1], 4) for k, v in sorted(tsum.items())},
     }

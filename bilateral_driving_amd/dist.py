@@ -34,6 +34,9 @@ class FlatGradients:
         self._flat: Optional[Tensor] = None
         self._views: List[Tensor] = []
         self._work = None
+        self._union: Optional[Tensor] = None     # rows (first-dim entries) touched on ANY rank this step
+        self._union_work = None
+        self.last_payload_bytes = 0
 
     @property
     def flat(self) -> Tensor:
@@ -64,6 +67,44 @@ class FlatGradients:
                 v.copy_(p.grad)
         return flat
 
+    def begin_rows_union(self, touched: Tensor) -> None:
+        """Optional, call right after the forward pass: ``touched`` [N] marks the rows (Gaussians) that can receive a
+        non-zero gradient on this rank (radii > 0 -- every backward kernel writes exact zeros for culled Gaussians).
+        The element-wise OR over the ranks is started asynchronously; the next ``all_reduce()`` then exchanges only the
+        rows touched on at least one rank (a view sees ~15 % of the Gaussians, so with few ranks most of the 59 floats per
+        Gaussian that a dense all-reduce would move are zeros on every rank).  The result is identical to the dense sum."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        self._union = touched.reshape(-1).to(torch.uint8).clone()
+        self._union_work = dist.all_reduce(self._union, op=dist.ReduceOp.MAX, async_op=True)
+
+    def _all_reduce_rows(self, flat: Tensor) -> bool:
+        """Exchange only the rows of the union.  Returns False (nothing done) when that would not pay."""
+        self._union_work.wait()
+        union, self._union, self._union_work = self._union, None, None
+        n_rows = union.numel()
+        idx = union.nonzero().squeeze(1)            # same on every rank (host sync: the exchange waits for backward anyway)
+        if idx.numel() > 0.85 * n_rows:
+            return False
+        row_views = [v for v in self._views if v.dim() >= 1 and v.shape[0] == n_rows]
+        other_views = [v for v in self._views if not (v.dim() >= 1 and v.shape[0] == n_rows)]
+        if not row_views:
+            return False
+        k = idx.numel()
+        parts = [v.reshape(n_rows, -1).index_select(0, idx).reshape(-1) for v in row_views] + [v.reshape(-1) for v in other_views]
+        comm = torch.cat(parts)
+        dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+        off = 0
+        for v in row_views:
+            w = v.reshape(n_rows, -1)
+            w.index_copy_(0, idx, comm[off:off + k * w.shape[1]].view(k, w.shape[1]))
+            off += k * w.shape[1]
+        for v in other_views:
+            v.copy_(comm[off:off + v.numel()].view_as(v))
+            off += v.numel()
+        self.last_payload_bytes = comm.numel() * 4
+        return True
+
     def all_reduce(self, average: bool = False, async_op: bool = False):
         """Sum (or average) the gradients over all ranks.  No-op for world size 1."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -71,6 +112,11 @@ class FlatGradients:
         flat = self.pack()
         for p, v in zip(self.params, self._views):
             p.grad = v
+        if self._union_work is not None and self._all_reduce_rows(flat):
+            if average:
+                flat.div_(dist.get_world_size())
+            return None
+        self.last_payload_bytes = flat.numel() * 4
         self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if not async_op and average:
             flat.div_(dist.get_world_size())

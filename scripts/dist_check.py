@@ -32,8 +32,10 @@ def main():
     skies = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
     targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
 
-    def run_view(v, params, grids, arena):
+    def run_view(v, params, grids, arena, flat=None):
         out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena)
+        if flat is not None:   # as bench.py: only rows visible on some rank travel
+            flat.begin_rows_union(out["info"]["radii"][0] > 0)
         Hn.training_loss(out, targets[v], grids).backward()
 
     params = {k: t.clone().requires_grad_(True) for k, t in base.items()}
@@ -41,9 +43,9 @@ def main():
     flat = FlatGradients(list(params.values()) + grids)
     arena = flat.arena(list(params.keys()))
     ok = True
-    for step in range(2):
+    for step in range(4):   # even steps: rows-union exchange, odd steps: dense all-reduce
         flat.zero()
-        run_view(view_for_rank(step, rank, world, len(cams)), params, grids, arena)
+        run_view(view_for_rank(step, rank, world, len(cams)), params, grids, arena, flat if step % 2 == 0 else None)
         flat.all_reduce()
         torch.cuda.synchronize()
         if rank == 0:
@@ -54,7 +56,7 @@ def main():
             ref = torch.cat([t.grad.reshape(-1) for t in list(p2.values()) + g2])
             rel = float((flat.flat - ref).norm() / ref.norm())
             aliased = all(t.grad.data_ptr() == v.data_ptr() for t, v in zip(flat.params, flat._views))
-            print(f"[dist_check] step {step}: rel err {rel:.2e}, grads alias the reduced buffer: {aliased}, payload {flat.nbytes / 1e6:.1f} MB")
+            print(f"[dist_check] step {step}: rel err {rel:.2e}, grads alias the reduced buffer: {aliased}, payload {flat.last_payload_bytes / 1e6:.1f} of {flat.nbytes / 1e6:.1f} MB")
             ok = ok and rel < 1e-3 and aliased
     if rank == 0:
         print("[dist_check]", "PASS" if ok else "FAIL")

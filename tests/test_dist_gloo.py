@@ -89,3 +89,62 @@ def test_flat_gradients_single_process():
     assert all(p.grad is None for p in params)
     _toy_loss(params, 0).backward()
     assert torch.equal(flat.pack(), g0)
+
+
+def _rows_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd.dist import FlatGradients
+    N = 200
+    g = torch.Generator().manual_seed(1)
+    params = [torch.randn(N, 3, generator=g).requires_grad_(True), torch.randn(N, 16, 3, generator=g).requires_grad_(True),
+              torch.randn(N, generator=g).requires_grad_(True), torch.randn(6, 12, 2, 2, 2, generator=g).requires_grad_(True)]
+    flat = FlatGradients(params)
+    outs, payloads = [], []
+    for step in range(3):
+        flat.zero()
+        vis = torch.zeros(N, dtype=torch.bool)
+        lo = (37 * step + 60 * rank) % N
+        vis[lo:lo + 30] = True                                     # each rank touches its own 15 % of the rows
+        w = vis.float()
+        loss = (params[0] * w[:, None] * (rank + 1)).sum() + (params[1] ** 2 * w[:, None, None]).sum() + (params[2].sin() * w).sum() \
+            + (params[3] ** 2).sum() * (rank + 2)                  # the last one is dense on every rank (grids / TV)
+        flat.begin_rows_union(vis)
+        loss.backward()
+        flat.all_reduce()
+        outs.append(flat.flat.clone())
+        payloads.append(flat.last_payload_bytes)
+    q.put((rank, [o.numpy() for o in outs], payloads, flat.nbytes))
+    dist.destroy_process_group()
+
+
+def test_rows_union_exchange_equals_dense_sum():
+    """begin_rows_union + all_reduce (only rows touched on some rank travel) == dense all-reduce, with a smaller payload."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    N = 200
+    g = torch.Generator().manual_seed(1)
+    base = [torch.randn(N, 3, generator=g), torch.randn(N, 16, 3, generator=g), torch.randn(N, generator=g), torch.randn(6, 12, 2, 2, 2, generator=g)]
+    for step in range(3):
+        params = [b.clone().requires_grad_(True) for b in base]
+        for rank in range(world):
+            vis = torch.zeros(N)
+            lo = (37 * step + 60 * rank) % N
+            vis[lo:lo + 30] = 1.0
+            ((params[0] * vis[:, None] * (rank + 1)).sum() + (params[1] ** 2 * vis[:, None, None]).sum() + (params[2].sin() * vis).sum()
+             + (params[3] ** 2).sum() * (rank + 2)).backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in params]).numpy()
+        for r in range(world):
+            assert abs(res[r][1][step] - ref).max() < 1e-5
+            assert res[r][2][step] < 0.5 * res[r][3]               # the payload really shrank (<= 60 of 200 rows + the dense tail)
