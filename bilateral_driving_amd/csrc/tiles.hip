@@ -651,8 +651,10 @@ __global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, 
 // visible_reduce: visible entries per 2048-entry tile; also clears the tables the later launches add into.
 __global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, const int32_t *__restrict__ radii,
                                                                    uint32_t *__restrict__ tile_sums,
-                                                                   uint32_t *__restrict__ zero_me, int64_t zero_elems) {
+                                                                   uint32_t *__restrict__ zero_me, int64_t zero_elems,
+                                                                   uint64_t *__restrict__ m_total) {
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *m_total = 0;   // M is accumulated by the counting kernels
   for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < zero_elems; i += (int64_t)gridDim.x * kScanBlock)
     zero_me[i] = 0u;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -722,38 +724,45 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_sorted_kernel(
     int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
     int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
-    float4 *__restrict__ rec) {
+    float4 *__restrict__ rec, uint32_t *__restrict__ btot, uint64_t *__restrict__ m_total) {
+  __shared__ uint32_t lw[kIsectBlock / kWave + 1];
   const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  if (j >= CN) return;
-  if (j >= (int64_t)*n_vis_dev) { cnt_sorted[j] = 0u; return; }
-  const int64_t o = sorted_idx[j];
-  const int r = radii[o];
   int cnt = 0;
-  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  uint32_t nrows = 0;
-  float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
-  const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
-  if (conics == nullptr) {
-    tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
-    cnt = (x1 - x0) * (y1 - y0);
-    if (x1 > x0 && y1 > y0) nrows = (uint32_t)(y1 - y0);
-  } else {
-    a = conics[o * 3]; b = conics[o * 3 + 1]; c = conics[o * 3 + 2];
-    if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
-      nrows = (uint32_t)(y1 - y0);
-      for (int ty = y0; ty < y1; ty++) {
-        int lo, hi;
-        row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
-        cnt += hi - lo;
+  if (j < CN && j < (int64_t)*n_vis_dev) {
+    const int64_t o = sorted_idx[j];
+    const int r = radii[o];
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint32_t nrows = 0;
+    float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
+    const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
+    if (conics == nullptr) {
+      tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+      cnt = (x1 - x0) * (y1 - y0);
+      if (x1 > x0 && y1 > y0) nrows = (uint32_t)(y1 - y0);
+    } else {
+      a = conics[o * 3]; b = conics[o * 3 + 1]; c = conics[o * 3 + 2];
+      if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
+        nrows = (uint32_t)(y1 - y0);
+        for (int ty = y0; ty < y1; ty++) {
+          int lo, hi;
+          row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
+          cnt += hi - lo;
+        }
       }
     }
+    if (tiles_per_gauss) tiles_per_gauss[o] = cnt;
+    const uint32_t cam_base = (uint32_t)(o / N) * (uint32_t)(tile_w * tile_h);
+    rec[j * 3] = make_float4(mx, my, a, b);
+    rec[j * 3 + 1] = make_float4(c, q_max, __int_as_float(x0), __int_as_float(x1));
+    rec[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float((uint32_t)o), __uint_as_float(cam_base));
   }
-  cnt_sorted[j] = (uint32_t)cnt;
-  if (tiles_per_gauss) tiles_per_gauss[o] = cnt;
-  const uint32_t cam_base = (uint32_t)(o / N) * (uint32_t)(tile_w * tile_h);
-  rec[j * 3] = make_float4(mx, my, a, b);
-  rec[j * 3 + 1] = make_float4(c, q_max, __int_as_float(x0), __int_as_float(x1));
-  rec[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float((uint32_t)o), __uint_as_float(cam_base));
+  if (j < CN) cnt_sorted[j] = (uint32_t)cnt;
+  uint32_t total;
+  block_excl_scan((uint32_t)cnt, total, lw);
+  if (threadIdx.x == 0) {
+    btot[blockIdx.x] = total;
+    if (total) atomicAdd(reinterpret_cast<unsigned long long *>(m_total), (unsigned long long)total);
+  }
 }
 
 // ---- row-parallel counting / emission ---------------------------------------------------------------------
@@ -849,13 +858,14 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
     int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
-    float4 *__restrict__ rec) {
+    float4 *__restrict__ rec, uint32_t *__restrict__ btot, uint64_t *__restrict__ m_total) {
   __shared__ RowStage S;
   __shared__ uint32_t cnt[kIsectBlock];
   const int64_t n_vis = (int64_t)*n_vis_dev;
   const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock, j = j0 + threadIdx.x;
-  if (j0 >= n_vis) {  // the scan runs over the host-side bound: zeros beyond the visible count
+  if (j0 >= n_vis) {  // zeros beyond the visible count (a later scan may run over the host-side bound)
     if (j < CN) cnt_sorted[j] = 0u;
+    if (threadIdx.x == 0) btot[blockIdx.x] = 0u;
     return;
   }
   cnt[threadIdx.x] = 0u;
@@ -870,10 +880,16 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
   __syncthreads();
   if (j < CN) cnt_sorted[j] = cnt[threadIdx.x];
   if (tiles_per_gauss && j < n_vis) tiles_per_gauss[sorted_idx[j]] = (int32_t)cnt[threadIdx.x];
+  uint32_t total;
+  block_excl_scan(cnt[threadIdx.x], total, S.lw);
+  if (threadIdx.x == 0) {
+    btot[blockIdx.x] = total;
+    if (total) atomicAdd(reinterpret_cast<unsigned long long *>(m_total), (unsigned long long)total);
+  }
 }
 
 __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
-    const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ cum_sorted,
+    const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ btot,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec) {
@@ -883,7 +899,14 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
   if (j0 >= n_vis) return;
   const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec);
   const bool cull = conics != nullptr;
-  uint32_t carry = cum_sorted[j0];   // output offset of the workgroup's first row
+  // output offset of the workgroup's first row = intersections of all groups in front of it (no scan launch: <= a few
+  // thousand L2-resident totals are summed here)
+  uint32_t carry;
+  {
+    uint32_t part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kIsectBlock) part += btot[b];
+    block_excl_scan(part, carry, S.lw);
+  }
   for (uint32_t base = 0; base < R; base += kIsectBlock) {   // uniform trip count: the scan below has barriers
     const uint32_t r = base + threadIdx.x;
     int lo = 0, hi = 0;
@@ -988,6 +1011,7 @@ struct PrepWs {
   uint32_t *temp;       // radix / scan temp
   uint32_t *tables;     // short path: workgroup-major histogram + 4 group tables
   float4 *rec;          // [CN][3] per-member records in depth order, written by EVERY counting kernel, read by the row emission
+  uint32_t *btot;       // [cdiv(CN,256)] intersections of each 256-member group of the depth order (every counting kernel)
   size_t bytes;
 };
 
@@ -1011,6 +1035,7 @@ static PrepWs prep_layout(void *ws, int64_t CN) {
   L.temp = reinterpret_cast<uint32_t *>(take(t > t2 ? t : t2, 4));
   L.tables = reinterpret_cast<uint32_t *>(take(CN <= kShortSortMax ? short_sort_elems(CN) : 0, 4));
   L.rec = reinterpret_cast<float4 *>(take((size_t)CN * kRecWords, 4));
+  L.btot = reinterpret_cast<uint32_t *>(take((size_t)cdiv(CN > 0 ? CN : 1, kIsectBlock) + 1, 4));
   L.bytes = off;
   return L;
 }
@@ -1078,7 +1103,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
     // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
     hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
-                       (int64_t)short_sort_elems(CN));
+                       (int64_t)short_sort_elems(CN), L.total);
     hipLaunchKernelGGL(visible_compact_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, depths, L.temp, L.ka, L.va, hist,
                        ghist, n_vis);
     BDS_LAUNCH_CHECK();
@@ -1098,12 +1123,13 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     if (option_get(kOptRowItems))
       hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec);
+                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
     else
       hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec);
+                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
     BDS_LAUNCH_CHECK();
   } else {
+    if (hipMemsetAsync(L.total, 0, sizeof(uint64_t), st) != hipSuccess) return BDS_ELAUNCH;   // M is accumulated by the counting kernel
     // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
     hipLaunchKernelGGL(isect_flag_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.kb);
     BDS_LAUNCH_CHECK();
@@ -1123,12 +1149,11 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec);
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
     BDS_LAUNCH_CHECK();
   }
-  // 4. exclusive scan of the counts (offset of every entry's run) and the total M
-  rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, L.total, st);
-  if (rc != BDS_OK) return rc;
+  // 4. (no scan: every counting kernel leaves the per-256-member totals and adds them to M; the emission derives its offsets)
+  (void)rc;
   *counts_dev = L.total;
   return BDS_OK;
 }
@@ -1210,7 +1235,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     key_shift = rank_bits;
     uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                       P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
+                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     const uint32_t rank_mask = (1u << rank_bits) - 1u;
@@ -1231,10 +1256,14 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
     if (option_get(kOptRowItems))
       hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
-                         P.va, P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
-    else
+                         P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
+    else {
+      // one thread per Gaussian needs every member's own offset: scan the counts now (prepare leaves only group totals)
+      int rc = exclusive_scan_u32(P.kb, P.cum, CN, P.temp, nullptr, st);
+      if (rc != BDS_OK) return rc;
       hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
                          P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
+    }
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     uint32_t *vin = v_emit;

@@ -90,8 +90,9 @@ int bds_project_bwd(int C, int64_t N, const float *means, const float *quats, co
 /* ---- tile intersection + (tile|depth) ordering -------------------------------------------
  * isect_tiles + radix sort + isect_offset_encode stages of gsplat.rendering.rasterization.
  * Two calls because the host must size the [M] outputs:
- *   bds_isect_prepare : counts tiles per Gaussian, depth-orders the Gaussians, scans the
- *                       counts; synchronises `stream` and returns M in *n_isects.
+ *   bds_isect_prepare : depth-orders the visible Gaussians, counts their tiles in that order (per-member
+ *                       records and per-256-member totals stay in `ws`); synchronises `stream` and
+ *                       returns M in *n_isects.
  *   bds_isect_build   : emits (camera*tiles+tile, id) pairs in depth order, stable-sorts them
  *                       by tile, writes flatten_ids [M] i32 (= cam*N+gaussian), isect_offsets
  *                       [C,th,tw] i32 and, if not NULL, isect_ids [M] i64
