@@ -151,14 +151,20 @@ import contextlib
 TIMERS = None  # dict name -> list[(start_event, end_event)] when enabled
 
 
-def enable_timers(on: bool = True) -> None:
-    global TIMERS
+def enable_timers(on: bool = True, only=None) -> None:
+    """HIP-event timing of the operators wrapped in ``timed(name)``.  ``only``: an iterable of names to time (every event
+    pair is two more packets on the stream; a timed benchmark region keeps them to the one kernel it reports)."""
+    global TIMERS, TIMERS_ONLY
     TIMERS = {} if on else None
+    TIMERS_ONLY = None if only is None else frozenset(only)
+
+
+TIMERS_ONLY = None
 
 
 @contextlib.contextmanager
 def timed(name: str):
-    if TIMERS is None:
+    if TIMERS is None or (TIMERS_ONLY is not None and name not in TIMERS_ONLY):
         yield
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
