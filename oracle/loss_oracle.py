@@ -111,3 +111,25 @@ def pixel_loss(rgb, pixels, opacity, sky_masks, depth, lidar, egocar=None, w=(0.
     v_depth = (w[2] / cnt * hit * m * (2.0 * e if depth_l2 else torch.sign(e)))[..., None]
     return dict(rgb_loss=rgb_loss, sky_loss=sky_loss, depth_loss=depth_loss, total=rgb_loss + sky_loss + depth_loss,
                 v_rgb=v_rgb, v_opacity=v_opacity, v_depth=v_depth)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-step densification statistics -- PINNED by tests/golden/densify_stats.npz (the reference's own
+# VanillaGaussians.after_train, /root/reference/project/models/gaussians/vanilla.py:163-191, fed as
+# BasicTrainer.postprocess_per_train_step does, models/trainers/base.py:279-297; oracle/gen_golden_densify.py)
+# ------------------------------------------------------------------------------------------------------------------
+def densify_stats_update(state, absgrad, radii, width, height, batch_size=1):
+    """state: dict(xys_grad_norm, vis_counts, max_2Dsize) or None on the first call; absgrad [N,2], radii [N] int.
+    Returns the new state (closed form of the reference's masked-index updates)."""
+    g = absgrad.clone()
+    g[..., 0] *= width / 2.0 * batch_size
+    g[..., 1] *= height / 2.0 * batch_size
+    n = g.norm(dim=-1)
+    vis = radii > 0
+    size = radii.to(torch.float32) / float(max(width, height))
+    if state is None:   # first call: norm for EVERY Gaussian, vis_counts = 1 for EVERY Gaussian
+        return dict(xys_grad_norm=n.clone(), vis_counts=torch.ones_like(n),
+                    max_2Dsize=torch.where(vis, size, torch.zeros_like(size)))
+    return dict(xys_grad_norm=torch.where(vis, n + state["xys_grad_norm"], state["xys_grad_norm"]),
+                vis_counts=torch.where(vis, state["vis_counts"] + 1, state["vis_counts"]),
+                max_2Dsize=torch.where(vis, torch.maximum(state["max_2Dsize"], size), state["max_2Dsize"]))

@@ -67,3 +67,16 @@ def test_pixel_loss_oracle_against_reference_goldens(golden_dir):
             ref = torch.from_numpy(z[k])
             err = float((out[k] - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
             assert err <= (1e-12 if "f64" in f else 2e-6), (f, k, err)
+
+
+def test_densify_stats_oracle_against_the_reference_method(golden_dir):
+    import os
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "densify_stats.npz"))
+    W, H, b = int(z["W"]), int(z["H"]), int(z["batch"])
+    st = None
+    for call in range(3):
+        st = LO.densify_stats_update(st, torch.from_numpy(z[f"absgrad{call}"])[0], torch.from_numpy(z[f"radii{call}"]), W, H, b)
+        for name in ("xys_grad_norm", "vis_counts", "max_2Dsize"):
+            assert torch.allclose(st[name], torch.from_numpy(z[f"{name}{call}"]), rtol=1e-6, atol=0), (call, name)
+    assert float(st["vis_counts"].min()) >= 1.0   # the reference's first call counts every Gaussian as seen once
