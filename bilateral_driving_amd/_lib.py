@@ -67,6 +67,11 @@ _SIGS = {
     "bds_pixel_loss_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f]),
     "bds_pixel_loss_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f, _f, _f, _f]),
     "bds_densify_stats": (_i, [_i64, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "bds_refine_plan_temp_bytes": (_sz, [_i64]),
+    "bds_refine_plan": (_i, [_i64, _f, _f, _f, _f, _f, _i, _fl, _fl, _i, _fl, _i, _fl, _i, _fl, _i, _fl, _f, _f, _f, _f, _sz, _f]),
+    "bds_refine_geometry": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_refine_rows": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_opacity_reset": (_i, [_i64, _f, _fl, _f, _f, _f]),
     "bds_adam_step": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_bilagrid_slice_feat_fwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_feat_bwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),

@@ -1,0 +1,152 @@
+"""Adaptive density control of one class of Gaussians on the device: drop-in for
+``VanillaGaussians.refinement_after`` (/root/reference/project/models/gaussians/vanilla.py:205-304) including the optimiser
+surgery of models/gaussians/basics.py:162-206.
+
+    from bilateral_driving_amd.densify import refinement_after
+    VanillaGaussians.refinement_after = refinement_after          # or: refinement_after(model, step, optimizer)
+
+``model`` is anything with the reference's attributes: ``_means [N,3] _features_dc [N,3] _features_rest [N,K-1,3]
+_opacities [N,1] _scales [N,3] _quats [N,4]`` (``nn.Parameter``), ``ctrl_cfg`` (attribute access to the ``ctrl`` keys),
+``scene_scale``, ``num_train_images``, ``step``, ``class_prefix`` and the statistics ``xys_grad_norm / vis_counts / max_2Dsize``
+(``optim.DensifyStats`` keeps them on the device).  ``optimizer`` is the trainer's Adam (torch.optim.Adam or
+``optim.FusedAdam``) with one named group per parameter (models/trainers/base.py:201-222).
+
+Where the reference runs three rounds of boolean-mask indexing + ``torch.cat`` over 18 tensors and then masks all of them again
+for the cull (a few hundred launches and a host sync per mask), this plans the topology change once (``bds_refine_plan``: 3
+launches, ONE host read-back of five counts -- the size of the noise tensor has to be known, as in the reference) and writes
+each of the 18 arrays exactly once into its final layout.  The result -- order of the rows included -- is the reference's.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+from torch.nn import Parameter
+
+from . import _lib as L
+
+_ATTRS = ("_means", "_features_dc", "_features_rest", "_opacities", "_scales", "_quats")
+_GROUPS = ("xyz", "sh_dc", "sh_rest", "opacity", "scaling", "rotation")       # vanilla.py:193-201
+
+
+def _group_of(optimizer, name: str):
+    for g in optimizer.param_groups:
+        if g.get("name") == name:
+            return g
+    return None
+
+
+def plan(log_scales: Tensor, logits: Tensor, xys_grad_norm: Optional[Tensor], vis_counts: Optional[Tensor],
+         max_2Dsize: Optional[Tensor], *, do_densify: bool, grad_thresh: float, size_thresh: float, split_by_screen: bool,
+         split_screen_size: float, do_cull: bool, cull_alpha_thresh: float, cull_by_scale: bool, cull_scale_thresh: float,
+         cull_by_screen: bool, cull_screen_size: float):
+    """bds_refine_plan: (flags [N] u8, ranks [N,4] i32, totals [5] i64 on the device)."""
+    L.require_gpu(log_scales)
+    N, dev = log_scales.shape[0], log_scales.device
+    flags = torch.empty(N, dtype=torch.uint8, device=dev)
+    ranks = torch.empty(N, 4, dtype=torch.int32, device=dev)
+    totals = torch.empty(5, dtype=torch.int64, device=dev)
+    nb = int(L.lib().bds_refine_plan_temp_bytes(N))
+    temp = torch.empty(nb, dtype=torch.uint8, device=dev)
+    f32 = lambda t: None if t is None else t.detach().reshape(-1).contiguous().float()
+    xs, vc, m2 = f32(xys_grad_norm), f32(vis_counts), f32(max_2Dsize)
+    ls, lg = log_scales.detach().contiguous(), logits.detach().reshape(-1).contiguous()
+    L.check(L.lib().bds_refine_plan(N, L.ptr(xs), L.ptr(vc), L.ptr(m2), L.ptr(ls), L.ptr(lg), int(do_densify), float(grad_thresh),
+                                    float(size_thresh), int(split_by_screen), float(split_screen_size), int(do_cull),
+                                    float(cull_alpha_thresh), int(cull_by_scale), float(cull_scale_thresh), int(cull_by_screen),
+                                    float(cull_screen_size), L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(temp), nb, L.stream()),
+            "bds_refine_plan")
+    return flags, ranks, totals
+
+
+def _rows(src: Tensor, n_new: int, samps: int, flags, ranks, totals, zero_children: bool) -> Tensor:
+    src = src.detach().contiguous()
+    N = src.shape[0]
+    width = src.numel() // max(N, 1)
+    dst = torch.empty((n_new,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    L.check(L.lib().bds_refine_rows(N, width, samps, L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(src), L.ptr(dst),
+                                    int(zero_children), L.stream()), "bds_refine_rows")
+    return dst
+
+
+@torch.no_grad()
+def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples: Optional[Tensor] = None, verbose: bool = True) -> None:
+    """Same contract as VanillaGaussians.refinement_after(step, optimizer).  ``samples`` (optional, [n_split_samples * n_split, 3])
+    replaces the ``torch.randn`` draw of split_gaussians (vanilla.py:343) -- the tests feed the reference's recorded noise."""
+    assert step == self.step
+    ctrl = self.ctrl_cfg
+    if self.step <= ctrl.warmup_steps:
+        return
+    if getattr(self, "ball_gaussians", False) or getattr(self, "gaussian_2d", False):
+        raise NotImplementedError("ball / 2-D Gaussians are not covered by the fused refinement")
+    reset_interval = ctrl.reset_alpha_interval
+    past = self.step % reset_interval > max(self.num_train_images, ctrl.refine_interval)
+    do_densify = bool(self.step < ctrl.stop_split_at and past)
+    do_cull = bool(past)
+    if verbose:
+        print(f"Class {self.class_prefix} current points: {self._means.shape[0]} @ step {self.step}")
+    if do_densify or do_cull:
+        if do_densify:
+            assert self.xys_grad_norm is not None and self.vis_counts is not None and self.max_2Dsize is not None
+        for a in _ATTRS:
+            L.require_gpu(getattr(self, a))
+        N = self._means.shape[0]
+        samps = int(ctrl.n_split_samples) if do_densify else 0
+        by_scale = bool(self.step > reset_interval)
+        flags, ranks, totals = plan(
+            self._scales, self._opacities, self.xys_grad_norm, self.vis_counts, self.max_2Dsize,
+            do_densify=do_densify, grad_thresh=ctrl.densify_grad_thresh, size_thresh=ctrl.densify_size_thresh * self.scene_scale,
+            split_by_screen=self.step < ctrl.stop_screen_size_at, split_screen_size=ctrl.split_screen_size, do_cull=do_cull,
+            cull_alpha_thresh=ctrl.cull_alpha_thresh, cull_by_scale=by_scale, cull_scale_thresh=ctrl.cull_scale_thresh * self.scene_scale,
+            cull_by_screen=by_scale and self.step < ctrl.stop_screen_size_at, cull_screen_size=ctrl.cull_screen_size)
+        n_split, n_dup, KO, KS, KD = (int(v) for v in totals.tolist())       # the one host sync (the reference: one per mask)
+        n_new = KO + samps * KS + KD
+        dev = self._means.device
+        if do_densify:
+            if samples is None:
+                samples = torch.randn((samps * n_split, 3), device=dev)       # vanilla.py:343, same draw from the same stream
+            samples = samples.to(device=dev, dtype=torch.float32).contiguous()
+            assert samples.shape == (samps * n_split, 3)
+        old = {a: getattr(self, a) for a in _ATTRS}
+        new: Dict[str, Tensor] = {}
+        means, quats, ls = old["_means"].detach().contiguous(), old["_quats"].detach().contiguous(), old["_scales"].detach().contiguous()
+        new["_means"] = torch.empty(n_new, 3, device=dev)
+        new["_scales"] = torch.empty(n_new, 3, device=dev)
+        L.check(L.lib().bds_refine_geometry(N, samps, L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(samples) if do_densify else None,
+                                            L.ptr(means), L.ptr(quats), L.ptr(ls), L.ptr(new["_means"]), L.ptr(new["_scales"]),
+                                            L.stream()), "bds_refine_geometry")
+        for a in ("_features_dc", "_features_rest", "_opacities", "_quats"):
+            new[a] = _rows(old[a], n_new, samps, flags, ranks, totals, zero_children=False)
+        for a, gname in zip(_ATTRS, _GROUPS):
+            prm = Parameter(new[a])
+            setattr(self, a, prm)
+            group = _group_of(optimizer, self.class_prefix + gname)
+            if group is None:
+                continue
+            old_p = group["params"][0]
+            state = optimizer.state.pop(old_p, None)                          # basics.py:162-206
+            if state:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    state[k] = _rows(state[k], n_new, samps, flags, ranks, totals, zero_children=True)
+                optimizer.state[prm] = state
+            group["params"] = [prm]
+        if verbose:
+            if do_densify:
+                print(f"    Split: {n_split}")
+                print(f"      Dup: {n_dup}")
+            print(f"     Cull: {N + samps * n_split + n_dup - n_new}")
+    if verbose:
+        print(f"Class {self.class_prefix} left points: {self._means.shape[0]}")
+    if self.step % reset_interval == ctrl.refine_interval:                    # vanilla.py:286-299
+        prm = self._opacities
+        L.require_gpu(prm)
+        group = _group_of(optimizer, self.class_prefix + "opacity")
+        state = optimizer.state.get(group["params"][0]) if group is not None else None
+        m = state["exp_avg"] if state else None
+        v = state["exp_avg_sq"] if state else None
+        L.check(L.lib().bds_opacity_reset(prm.numel(), L.ptr(prm.data), float(ctrl.reset_alpha_value), L.ptr(m), L.ptr(v), L.stream()),
+                "bds_opacity_reset")
+    self.xys_grad_norm = None
+    self.vis_counts = None
+    self.max_2Dsize = None

@@ -313,6 +313,46 @@ int bds_densify_stats(int64_t N, const float *grad2d, const int32_t *radii, int 
                       int last_size, int first, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
                       bds_stream_t stream);
 
+/* ---- Adaptive density control: split / duplicate / cull + Adam-state surgery (second slice) -----
+ * VanillaGaussians.refinement_after (models/gaussians/vanilla.py:205-304) with split_gaussians (:336-363), dup_gaussians
+ * (:365-376), cull_gaussians (:306-334) and dup_in_optim / remove_from_optim (models/gaussians/basics.py:162-206), done as
+ * ONE plan over the Gaussians followed by one write of every array straight into its final (culled) layout
+ *   [ kept originals | kept split children, sample-major | kept dup children ]      (the order the reference's cat + cull gives).
+ *
+ * bds_refine_plan: flags [N] u8 (bit 0 split, 1 dup, 2 keep original, 3 keep its split children, 4 keep its dup child),
+ * ranks [N,4] u32 (16-byte aligned; exclusive ranks among: split parents, kept originals, kept split parents, kept dup
+ * parents) and totals [5] i64 on the device = {n_split, n_dup, kept originals KO, kept split parents KS, kept dup KD};
+ * the new size is KO + samps*KS + KD and the host needs n_split for the noise tensor ([samps*n_split, 3], the reference's
+ * torch.randn at vanilla.py:343).  The host decides the step-dependent switches exactly as the reference does:
+ *   do_densify      step < stop_split_at and step % reset_interval > max(num_train_images, refine_interval)   (:212-215)
+ *   size_thresh     densify_size_thresh * scene_scale;   split_by_screen: step < stop_screen_size_at            (:224-230)
+ *   do_cull         step % reset_interval > max(num_train_images, refine_interval)                               (:279)
+ *   cull_by_scale   step > reset_alpha_interval, cull_scale_thresh = cull_scale_thresh * scene_scale             (:314-320)
+ *   cull_by_screen  additionally step < stop_screen_size_at                                                      (:321-324)
+ * xys_grad_norm / vis_counts may be NULL when do_densify == 0; max_2Dsize may be NULL (treated as zeros).
+ * temp: bds_refine_plan_temp_bytes(N) bytes of scratch.  N < 2^31. */
+size_t bds_refine_plan_temp_bytes(int64_t N);
+int bds_refine_plan(int64_t N, const float *xys_grad_norm, const float *vis_counts, const float *max_2Dsize,
+                    const float *log_scales, const float *logits, int do_densify, float grad_thresh, float size_thresh,
+                    int split_by_screen, float split_screen_size, int do_cull, float cull_alpha_thresh, int cull_by_scale,
+                    float cull_scale_thresh, int cull_by_screen, float cull_screen_size, uint8_t *flags, uint32_t *ranks,
+                    int64_t *totals, void *temp, size_t temp_bytes, bds_stream_t stream);
+
+/* New means [N',3] and log-scales [N',3]: split children are mean + R(q/|q|) (exp(log_scale) * noise) (vanilla.py:343-348);
+ * a split parent and its children get log(exp(log_scale) / 1.6) (:356-359); dup children copy the (possibly shrunk) parent. */
+int bds_refine_geometry(int64_t N, int samps, const uint8_t *flags, const uint32_t *ranks, const int64_t *totals,
+                        const float *samples, const float *means, const float *quats, const float *log_scales,
+                        float *new_means, float *new_log_scales, bds_stream_t stream);
+
+/* Any other per-Gaussian array src [N,width] -> dst [N',width]: children receive the parent's row (zero_children = 0:
+ * features, opacities, quaternions) or zeros (zero_children = 1: exp_avg / exp_avg_sq, basics.py:191-201). */
+int bds_refine_rows(int64_t N, int width, int samps, const uint8_t *flags, const uint32_t *ranks, const int64_t *totals,
+                    const float *src, float *dst, int zero_children, bds_stream_t stream);
+
+/* Opacity reset (vanilla.py:286-299): logit = logit(min(sigmoid(logit), reset_value)) in place; the opacity group's
+ * exp_avg / exp_avg_sq (either may be NULL) are zeroed. */
+int bds_opacity_reset(int64_t N, float *logits, float reset_value, float *exp_avg, float *exp_avg_sq, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

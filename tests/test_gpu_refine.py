@@ -1,0 +1,144 @@
+"""Adaptive density control on the device (bilateral_driving_amd.densify.refinement_after -> csrc/refine.hip through the C ABI)
+against (1) the golden vectors of the reference's own VanillaGaussians.refinement_after and (2) the pinned CPU oracle at a size
+where the plan spans thousands of workgroups."""
+import glob
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refine_oracle as RO
+
+pytestmark = pytest.mark.gpu
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "refine_step*.npz")))
+GROUPS = ("xyz", "sh_dc", "sh_rest", "opacity", "scaling", "rotation")
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def build_model(P, M, V, stats, ctrl, scene_scale, num_train_images, step, opt_cls, dev="cuda"):
+    model = types.SimpleNamespace(ctrl_cfg=Cfg(ctrl), scene_scale=scene_scale, num_train_images=num_train_images, step=step,
+                                  class_prefix="Background#")
+    groups = []
+    for a, n in zip(RO.PARAMS, GROUPS):
+        prm = torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(P[a])).to(dev))
+        setattr(model, a, prm)
+        groups.append({"params": [prm], "lr": 1e-3, "eps": 1e-15, "weight_decay": 0, "name": model.class_prefix + n})
+    opt = opt_cls(groups, lr=0.0, eps=1e-15)
+    for a in RO.PARAMS:
+        opt.state[getattr(model, a)] = {"step": torch.tensor(1.0), "exp_avg": torch.from_numpy(np.ascontiguousarray(M[a])).to(dev),
+                                        "exp_avg_sq": torch.from_numpy(np.ascontiguousarray(V[a])).to(dev)}
+    for k, v in stats.items():
+        setattr(model, k, None if v is None else torch.from_numpy(v).to(dev))
+    return model, opt
+
+
+def check(model, opt, exp_P, exp_M, exp_V, means_atol=3e-6):
+    for a, n in zip(RO.PARAMS, GROUPS):
+        prm = getattr(model, a)
+        assert isinstance(prm, torch.nn.Parameter) and prm.is_cuda
+        got = prm.detach().cpu().numpy()
+        assert got.shape == exp_P[a].shape, a
+        if a in ("_means", "_scales", "_opacities"):     # exp / log / rotation: last bits
+            np.testing.assert_allclose(got, exp_P[a], rtol=3e-6, atol=means_atol if a == "_means" else 3e-6, err_msg=a)
+        else:
+            np.testing.assert_array_equal(got, exp_P[a], err_msg=a)
+        grp = [g for g in opt.param_groups if g["name"] == model.class_prefix + n][0]
+        assert grp["params"][0] is prm and len(grp["params"]) == 1
+        st = opt.state[prm]
+        np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), exp_M[a], err_msg="exp_avg" + a)
+        np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), exp_V[a], err_msg="exp_avg_sq" + a)
+    assert len(opt.state) == len(RO.PARAMS)                     # the old parameters' entries are gone
+    assert model.xys_grad_norm is None and model.vis_counts is None and model.max_2Dsize is None
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_adam", "fused_adam"])
+def test_refinement_equals_reference_golden(path, fused, capsys):
+    from bilateral_driving_amd.densify import refinement_after
+    from bilateral_driving_amd.optim import FusedAdam
+    z = np.load(path)
+    ctrl = {k[5:]: z[k].item() for k in z.files if k.startswith("ctrl_")}
+    P = {a: z["in" + a] for a in RO.PARAMS}; M = {a: z["in_m" + a] for a in RO.PARAMS}; V = {a: z["in_v" + a] for a in RO.PARAMS}
+    stats = {k: z["in_" + k] for k in ("xys_grad_norm", "vis_counts", "max_2Dsize")}
+    step = int(z["step"])
+    model, opt = build_model(P, M, V, stats, ctrl, float(z["scene_scale"]), int(z["num_train_images"]), step,
+                             FusedAdam if fused else torch.optim.Adam)
+    refinement_after(model, step, opt, samples=torch.from_numpy(z["samples"]))
+    check(model, opt, {a: z["out" + a] for a in RO.PARAMS}, {a: z["out_m" + a] for a in RO.PARAMS},
+          {a: z["out_v" + a] for a in RO.PARAMS})
+    out = capsys.readouterr().out
+    assert f"left points: {z['out_means'].shape[0]}" in out
+    # the optimiser keeps working on the new set
+    for a in RO.PARAMS:
+        getattr(model, a).grad = torch.full_like(getattr(model, a), 1e-3)
+    opt.step()
+
+
+def synthetic(N, seed):
+    g = np.random.default_rng(seed)
+    r = lambda *s: g.random(s, dtype=np.float32)
+    ls = r(N, 3) * 7.5 - 4.5
+    small = r(N) < 0.3
+    ls[small] = r(int(small.sum()), 3) * 1.6 - 4.5
+    lg = r(N, 1) * 9 - 6.5
+    # keep every decision away from its threshold (libm and the device differ in the last bit of exp / log)
+    for t in (math.log(0.06), math.log(15.0)):
+        for tt in (t, t + math.log(1.6)):
+            ls = np.where(np.abs(ls - tt) < 2e-3, ls + 5e-3, ls).astype(np.float32)
+    lg = np.where(np.abs(lg - math.log(0.005 / 0.995)) < 2e-3, lg + 5e-3, lg).astype(np.float32)
+    P = {"_means": (r(N, 3) - 0.5) * 40, "_features_dc": r(N, 3), "_features_rest": (r(N, 15, 3) - 0.5) * 0.2, "_opacities": lg,
+         "_scales": ls, "_quats": g.standard_normal((N, 4)).astype(np.float32)}
+    M = {a: (g.standard_normal(v.shape) * 1e-2).astype(np.float32) for a, v in P.items()}
+    V = {a: (g.random(v.shape) * 1e-4).astype(np.float32) for a, v in P.items()}
+    stats = {"xys_grad_norm": r(N) * 0.004, "vis_counts": np.floor(r(N) * 6).astype(np.float32) + 1, "max_2Dsize": r(N) * 0.2}
+    return P, M, V, stats
+
+
+CTRL = dict(warmup_steps=500, reset_alpha_interval=3000, refine_interval=100, n_split_samples=2, reset_alpha_value=0.01,
+            densify_grad_thresh=0.0003, densify_size_thresh=0.002, cull_alpha_thresh=0.005, cull_scale_thresh=0.5, cull_screen_size=0.15,
+            split_screen_size=0.05, stop_screen_size_at=4000, stop_split_at=15000, sh_degree=3)
+
+
+@pytest.mark.parametrize("N,step", [(600_001, 3300), (300_000, 1300), (262_145, 16300), (1000, 3100), (255, 3300), (1, 3300)])
+def test_refinement_equals_oracle_at_scale(N, step):
+    """Sizes on both sides of the 1024-segment boundary of the count scan (N / 256 workgroups); SH degree 3 rows (45 floats)."""
+    from bilateral_driving_amd.densify import refinement_after, plan
+    P, M, V, stats = synthetic(N, seed=N + step)
+    model, opt = build_model(P, M, V, stats, CTRL, 30.0, 150, step, torch.optim.Adam)
+    sch = RO.schedule(step, CTRL, 30.0, 150)
+    n_split = 0
+    if sch["do_densify"]:
+        n_split = int(RO.plan(sch, CTRL, P["_scales"], P["_opacities"], stats["xys_grad_norm"], stats["vis_counts"], stats["max_2Dsize"])[0].sum())
+    samples = np.random.default_rng(1).standard_normal((2 * n_split, 3)).astype(np.float32)
+    eP, eM, eV, ns = RO.refine(step, CTRL, 30.0, 150, P, M, V, stats["xys_grad_norm"], stats["vis_counts"], stats["max_2Dsize"], samples)
+    assert ns == n_split
+    refinement_after(model, step, opt, samples=torch.from_numpy(samples), verbose=False)
+    # a split child is mean + R (scale * noise) with scale up to e^3 and |noise| up to ~5: the sum cancels, so the last-bit
+    # differences of exp() between libm and the device are relative to the offset (up to ~100), not to the result
+    check(model, opt, eP, eM, eV, means_atol=5e-5)
+    if N > 1000 and sch["do_densify"]:
+        assert n_split > N // 10 and eP["_means"].shape[0] != N
+
+
+def test_plan_counts_and_ranks_are_exclusive_scans():
+    from bilateral_driving_amd.densify import plan
+    N = 300_123
+    P, M, V, stats = synthetic(N, seed=5)
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(a).to(dev)
+    flags, ranks, totals = plan(t(P["_scales"]), t(P["_opacities"]), t(stats["xys_grad_norm"]), t(stats["vis_counts"]), t(stats["max_2Dsize"]),
+                                do_densify=True, grad_thresh=0.0003, size_thresh=0.06, split_by_screen=True, split_screen_size=0.05,
+                                do_cull=True, cull_alpha_thresh=0.005, cull_by_scale=True, cull_scale_thresh=15.0, cull_by_screen=True,
+                                cull_screen_size=0.15)
+    f = flags.cpu().numpy(); r = ranks.cpu().numpy().astype(np.int64); tot = totals.cpu().numpy()
+    for k, bit in enumerate((0, 2, 3, 4)):
+        m = (f >> bit) & 1
+        np.testing.assert_array_equal(r[:, k], np.cumsum(m) - m)
+    np.testing.assert_array_equal(tot, [int(((f >> b) & 1).sum()) for b in range(5)])
+    assert not np.any((f & 8) & ~((f & 1) << 3)) and not np.any((f & 16) & ~((f & 2) << 3))   # kept children imply the parent flag

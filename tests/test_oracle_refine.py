@@ -1,0 +1,75 @@
+"""The CPU restatement of adaptive density control (oracle/refine_oracle.py) against the golden vectors produced by the
+reference's own VanillaGaussians.refinement_after (oracle/gen_golden_refine.py): this is what PINS that oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refine_oracle as RO
+
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "refine_step*.npz")))
+
+
+def load(path):
+    z = np.load(path)
+    ctrl = {k[5:]: z[k].item() for k in z.files if k.startswith("ctrl_")}
+    P = {a: z["in" + a] for a in RO.PARAMS}
+    M = {a: z["in_m" + a] for a in RO.PARAMS}
+    V = {a: z["in_v" + a] for a in RO.PARAMS}
+    return z, ctrl, P, M, V
+
+
+def test_four_regimes_present():
+    assert len(FILES) == 4
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_refine_oracle_equals_reference(path):
+    z, ctrl, P, M, V = load(path)
+    oP, oM, oV, n_split = RO.refine(int(z["step"]), ctrl, float(z["scene_scale"]), int(z["num_train_images"]), P, M, V,
+                                    z["in_xys_grad_norm"], z["in_vis_counts"], z["in_max_2Dsize"], z["samples"])
+    assert n_split * ctrl["n_split_samples"] == z["samples"].shape[0]
+    for a in RO.PARAMS:
+        ref = z["out" + a]
+        assert oP[a].shape == ref.shape, a                       # same topology decision for every Gaussian
+        if a in ("_means", "_scales", "_opacities"):              # exp / log / 3x3 product: libm vs torch, last bits
+            np.testing.assert_allclose(oP[a], ref, rtol=2e-6, atol=2e-6, err_msg=a)
+        else:
+            np.testing.assert_array_equal(oP[a], ref, err_msg=a)  # pure row movement
+        np.testing.assert_array_equal(oM[a], z["out_m" + a], err_msg="exp_avg" + a)
+        np.testing.assert_array_equal(oV[a], z["out_v" + a], err_msg="exp_avg_sq" + a)
+
+
+def test_schedule_regimes():
+    z, ctrl, *_ = load(FILES[0])
+    sc, n = float(z["scene_scale"]), int(z["num_train_images"])
+    s = RO.schedule(3300, ctrl, sc, n)
+    assert s["do_densify"] and s["do_cull"] and s["cull_by_scale"] and s["cull_by_screen"] and s["split_by_screen"] and not s["reset_opacity"]
+    s = RO.schedule(1300, ctrl, sc, n)
+    assert s["do_densify"] and s["do_cull"] and not s["cull_by_scale"] and not s["cull_by_screen"]
+    s = RO.schedule(16300, ctrl, sc, n)
+    assert not s["do_densify"] and s["do_cull"] and s["cull_by_scale"] and not s["cull_by_screen"]
+    s = RO.schedule(3100, ctrl, sc, n)
+    assert not s["do_densify"] and not s["do_cull"] and s["reset_opacity"]
+    assert not RO.schedule(400, ctrl, sc, n)["active"]
+
+
+def test_product_refinement_has_no_cpu_path():
+    """The product (bilateral_driving_amd.densify) must refuse CPU tensors instead of falling back to anything."""
+    import types
+    import torch
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd.densify import refinement_after
+    z, ctrl, P, M, V = load(FILES[0])
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    model = types.SimpleNamespace(ctrl_cfg=Cfg(ctrl), scene_scale=30.0, num_train_images=150, step=3300, class_prefix="Background#",
+                                  xys_grad_norm=torch.from_numpy(z["in_xys_grad_norm"]), vis_counts=torch.from_numpy(z["in_vis_counts"]),
+                                  max_2Dsize=torch.from_numpy(z["in_max_2Dsize"]))
+    for a in RO.PARAMS:
+        setattr(model, a, torch.nn.Parameter(torch.from_numpy(P[a])))
+    opt = torch.optim.Adam([{"params": [getattr(model, a)], "name": "Background#" + a} for a in RO.PARAMS], lr=0.0)
+    with pytest.raises(L.BdsError):
+        refinement_after(model, 3300, opt, verbose=False)
