@@ -1,0 +1,183 @@
+// Cube-map sky: EnvLight.forward (/root/reference/project/models/modules.py:176-211) looks the sky colour of every pixel up in a
+// learnable cube texture base [6, res, res, 3] with nvdiffrast -- dr.texture(base[None], l, filter_mode='linear',
+// boundary_mode='cube') (:202), l = viewdirs @ to_opengl^T (:196) -- a CUDA-only package.  This is the MI355X replacement
+// ("a ROCm cube-map sky sampler to replace nvdiffrast"); its output is the `sky` input of the hot path's
+// blend (trainers/scene_graph.py:292-294), its backward scatters the blend's v_sky into the texture gradient.
+//
+// PARITY UNPINNED: nvdiffrast is neither vendored in /root/reference nor installed here and the reference pins no version
+// (README.md:83).  Restated from the public convention it implements (the OpenGL cube map):
+//   major axis = largest |component| (z wins over x, y only if strictly larger than both; y wins over x only if strictly
+//   larger), face order +x -x +y -y +z -z,
+//   (sc, tc) = +x: (-z,-y)  -x: (+z,-y)  +y: (+x,+z)  -y: (+x,-z)  +z: (+x,-y)  -z: (-x,-y),   u = sc/(2|ma|) + 1/2, v likewise,
+//   bilinear over texel centres (i + 1/2)/res, u -> column, v -> row, zero output for a non-finite direction.
+// A tap that falls off the face is taken from the neighbouring face: the texel centre is extended on the face plane, pushed back
+// onto the cube and the nearest texel of the face it lands on is used -- on an edge that is exactly the adjacent face's border
+// texel with the same index along the edge; at the 8 corners (where no fourth texel exists) the tap is first clamped in v, i.e. it
+// duplicates the u-neighbour's corner texel.  HBM-bound gather: 12 B direction in, 12 B out and 4 texels (mostly L2 hits: neighbouring pixels share them) per pixel.
+#include "bds_common.h"
+
+namespace bds {
+
+constexpr int kEnvBlock = 256;
+
+// direction -> face index (or -1) and (u, v) in [0, 1]
+__device__ __forceinline__ int cube_face(float x, float y, float z, float &u, float &v) {
+#pragma clang fp contract(off)
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  int idx;
+  float c, sc, tc;
+  if (az > fmaxf(ax, ay)) { idx = 4; c = z; sc = x; tc = y; }
+  else if (ay > ax)       { idx = 2; c = y; sc = x; tc = z; }
+  else                    { idx = 0; c = x; sc = z; tc = y; }
+  if (c < 0.f) idx += 1;
+  const float m = 0.5f / fabsf(c);
+  const float m0 = (idx == 0 || idx == 5) ? -m : m;   // +x: sc = -z,  -z: sc = -x
+  const float m1 = (idx == 2) ? m : -m;               // +y: tc = +z, every other face flips its t source
+  u = sc * m0 + 0.5f;
+  v = tc * m1 + 0.5f;
+  if (!isfinite(u) || !isfinite(v)) return -1;
+  u = fminf(fmaxf(u, 0.f), 1.f);
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  return idx;
+}
+
+// face + (sc, tc) in face-plane units (|.| may exceed 1) -> direction
+__device__ __forceinline__ void cube_dir(int idx, float sc, float tc, float &x, float &y, float &z) {
+  switch (idx) {
+    case 0: x = 1.f;  y = -tc; z = -sc; break;
+    case 1: x = -1.f; y = -tc; z = sc;  break;
+    case 2: x = sc;   y = 1.f;  z = tc;  break;
+    case 3: x = sc;   y = -1.f; z = -tc; break;
+    case 4: x = sc;   y = -tc; z = 1.f;  break;
+    default: x = -sc; y = -tc; z = -1.f; break;
+  }
+}
+
+// linear index of texel (iu, iv) of face idx, wrapped onto the neighbouring face when it lies outside
+__device__ __forceinline__ int64_t cube_texel(int idx, int iu, int iv, int res) {
+  const bool out_u = iu < 0 || iu >= res, out_v = iv < 0 || iv >= res;
+  if (out_u && out_v) iv = min(max(iv, 0), res - 1);  // cube corner: no fourth texel exists; take the u-neighbour's corner texel
+  if (out_u || out_v) {
+    const float sc = (2.f * (float)iu + 1.f) / (float)res - 1.f, tc = (2.f * (float)iv + 1.f) / (float)res - 1.f;
+    float x, y, z, u, v;
+    cube_dir(idx, sc, tc, x, y, z);
+    idx = cube_face(x, y, z, u, v);  // finite by construction
+    iu = min(max((int)floorf(u * (float)res), 0), res - 1);
+    iv = min(max((int)floorf(v * (float)res), 0), res - 1);
+  }
+  return ((int64_t)idx * res + iv) * res + iu;
+}
+
+struct CubeTaps {
+  int64_t t[4];
+  float w[4];
+  bool valid;
+};
+
+__device__ __forceinline__ CubeTaps cube_taps(float x, float y, float z, int res) {
+#pragma clang fp contract(off)
+  CubeTaps o;
+  float u, v;
+  const int idx = cube_face(x, y, z, u, v);
+  o.valid = idx >= 0;
+  if (!o.valid) return o;
+  const float ut = u * (float)res - 0.5f, vt = v * (float)res - 0.5f;
+  const float fu0 = floorf(ut), fv0 = floorf(vt);
+  const int iu0 = (int)fu0, iv0 = (int)fv0;
+  const float fu = ut - fu0, fv = vt - fv0;
+  o.t[0] = cube_texel(idx, iu0, iv0, res);         o.w[0] = (1.f - fu) * (1.f - fv);
+  o.t[1] = cube_texel(idx, iu0 + 1, iv0, res);     o.w[1] = fu * (1.f - fv);
+  o.t[2] = cube_texel(idx, iu0, iv0 + 1, res);     o.w[2] = (1.f - fu) * fv;
+  o.t[3] = cube_texel(idx, iu0 + 1, iv0 + 1, res); o.w[3] = fu * fv;
+  return o;
+}
+
+__device__ __forceinline__ void load_dir(const float *__restrict__ dirs, const float *__restrict__ rot, int64_t i, float &x, float &y,
+                                         float &z) {
+#pragma clang fp contract(off)
+  const float a = dirs[i * 3], b = dirs[i * 3 + 1], c = dirs[i * 3 + 2];
+  if (rot) {  // l @ rot^T  (modules.py:196)
+    x = (a * rot[0] + b * rot[1]) + c * rot[2];
+    y = (a * rot[3] + b * rot[4]) + c * rot[5];
+    z = (a * rot[6] + b * rot[7]) + c * rot[8];
+  } else {
+    x = a; y = b; z = c;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kEnvBlock) void cubemap_fwd_kernel(int64_t n, int res, const float *__restrict__ dirs,
+                                                               const float *__restrict__ rot, const float *__restrict__ tex,
+                                                               float *__restrict__ out, int nch) {
+  const int64_t i = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+  if (i >= n) return;
+  float x, y, z;
+  load_dir(dirs, rot, i, x, y, z);
+  const CubeTaps tp = cube_taps(x, y, z, res);
+  const int ch = C > 0 ? C : nch;
+  for (int c = 0; c < ch; c++) {
+    float acc = 0.f;
+    if (tp.valid)
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc += tp.w[k] * tex[tp.t[k] * ch + c];
+    out[i * ch + c] = acc;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kEnvBlock) void cubemap_bwd_kernel(int64_t n, int res, const float *__restrict__ dirs,
+                                                               const float *__restrict__ rot, const float *__restrict__ v_out,
+                                                               float *__restrict__ v_tex, int nch) {
+  const int64_t i = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+  if (i >= n) return;
+  const int ch = C > 0 ? C : nch;
+  float g[C > 0 ? C : 1];
+  bool any = false;
+  if (C > 0) {
+#pragma unroll
+    for (int c = 0; c < C; c++) { g[c] = v_out[i * C + c]; any = any || (g[c] != 0.f); }
+    if (!any) return;  // pixels the blend gives no sky weight (alpha = 1) touch nothing
+  }
+  float x, y, z;
+  load_dir(dirs, rot, i, x, y, z);
+  const CubeTaps tp = cube_taps(x, y, z, res);
+  if (!tp.valid) return;
+  for (int c = 0; c < ch; c++) {
+    const float gv = C > 0 ? g[C > 0 ? c : 0] : v_out[i * ch + c];
+    if (gv == 0.f) continue;
+#pragma unroll
+    for (int k = 0; k < 4; k++) atomicAdd(v_tex + tp.t[k] * ch + c, tp.w[k] * gv);
+  }
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+extern "C" int bds_cubemap_fwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *tex, float *out,
+                               bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && res >= 1 && res <= 16384 && channels >= 1);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(dirs && tex && out);
+  const dim3 grid((unsigned)cdiv(n, kEnvBlock)), block(kEnvBlock);
+  if (channels == 3)
+    hipLaunchKernelGGL((cubemap_fwd_kernel<3>), grid, block, 0, as_stream(stream), n, res, dirs, rot, tex, out, channels);
+  else
+    hipLaunchKernelGGL((cubemap_fwd_kernel<0>), grid, block, 0, as_stream(stream), n, res, dirs, rot, tex, out, channels);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_cubemap_bwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *v_out,
+                               float *v_tex, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && res >= 1 && res <= 16384 && channels >= 1);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(dirs && v_out && v_tex);
+  const dim3 grid((unsigned)cdiv(n, kEnvBlock)), block(kEnvBlock);
+  if (channels == 3)
+    hipLaunchKernelGGL((cubemap_bwd_kernel<3>), grid, block, 0, as_stream(stream), n, res, dirs, rot, v_out, v_tex, channels);
+  else
+    hipLaunchKernelGGL((cubemap_bwd_kernel<0>), grid, block, 0, as_stream(stream), n, res, dirs, rot, v_out, v_tex, channels);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}

@@ -353,6 +353,18 @@ int bds_refine_rows(int64_t N, int width, int samps, const uint8_t *flags, const
  * exp_avg / exp_avg_sq (either may be NULL) are zeroed. */
 int bds_opacity_reset(int64_t N, float *logits, float reset_value, float *exp_avg, float *exp_avg_sq, bds_stream_t stream);
 
+/* ---- Cube-map sky (the ROCm replacement of nvdiffrast's cube texture) -----------------------------
+ * EnvLight.forward (models/modules.py:176-211): out[i] = bilinear cube-map lookup of tex [6,res,res,channels] along
+ * dirs[i] @ rot^T (rot: 9 floats on the device, row-major, NULL = identity; the reference's to_opengl, :189,196) --
+ * dr.texture(tex[None], l, filter_mode='linear', boundary_mode='cube') (:202).  OpenGL face order / orientation; taps that
+ * fall off a face come from the neighbouring face; a non-finite direction yields zeros.  PARITY UNPINNED (nvdiffrast is
+ * absent and unpinned, README.md:83): see csrc/envlight.hip.
+ * bwd ACCUMULATES into v_tex (caller zeroes it); directions carry no gradient (the reference's viewdirs are data). */
+int bds_cubemap_fwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *tex, float *out,
+                    bds_stream_t stream);
+int bds_cubemap_bwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *v_out, float *v_tex,
+                    bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,13 +169,14 @@ def test_reference_modules_import_against_the_dropin_packages():
             "stub('tensorly', set_backend=lambda *_: None)\n"
             "stub('pytorch3d'); stub('pytorch3d.ops', knn_points=None)\n"
             "stub('pytorch3d.transforms', matrix_to_quaternion=None, quaternion_to_matrix=None)\n"
-            "stub('nvdiffrast'); stub('nvdiffrast.torch')\n"
             "stub('omegaconf', OmegaConf=type('OmegaConf', (), {}))\n"
             "import models.gaussians.basics as B, models.gaussians.vanilla as V, models.modules as M\n"
             "import bilateral_driving_amd.rendering as R, bilateral_driving_amd.gs_ops as O, bilateral_driving_amd.bilagrid as G\n"
             "assert B.rasterization is R.rasterization and B.spherical_harmonics is O.spherical_harmonics\n"
             "assert M.BilateralGrid is G.BilateralGrid and M.slice is G.slice and M.total_variation_loss is G.total_variation_loss\n"
             "m = M.MultiScaleBilateralAffineTransform.__init__\n"
+            "import bilateral_driving_amd.envlight as E\n"
+            "assert M.dr.texture.__module__ == 'nvdiffrast.torch' and M.dr.cubemap_sample is E.cubemap_sample\n"
             "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
