@@ -11,6 +11,10 @@ Two ways to use them:
   * ``transform(rgb, image_infos, alpha=None, sky=None)`` -- the fused fast path: one call that
     slices, up-samples and applies all levels (optionally with the clamp + sky blend in front)
     without materialising the maps.  Numerically equal to forward + composition.
+
+The neural variants (modules.py:595-820) are mirrored too: the feature-grid slice runs on the HIP
+kernels (``bds_bilagrid_slice_feat_*``), the three bias-free Linear layers of ``affine_network`` stay ``nn.Linear`` --
+[pixels x F] x [F x 64] GEMMs are library (hipBLASLt) work, not something to re-tile by hand.
 """
 from __future__ import annotations
 
@@ -21,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from .bilagrid import BilateralGrid, bilagrid_transform, slice, total_variation_loss
+from .bilagrid import BilateralGrid, NeuralBilateralGrid, bilagrid_transform, slice, slice_feature, total_variation_loss
 
 
 def _img_index(image_infos) -> int:
@@ -172,3 +176,116 @@ class MultiScaleBilateralAffineTransform(nn.Module):
 
     def get_param_groups(self):
         return {f"{self.class_prefix}grid{i}": getattr(self, f"bil_grids{i}").parameters() for i in range(len(self.grid_size))}
+
+
+def _pixel_xy(H: int, W: int, device) -> Tensor:
+    gy, gx = torch.meshgrid(torch.linspace(0, 1.0, H, device=device), torch.linspace(0, 1.0, W, device=device), indexing="ij")
+    return torch.stack([gx, gy], dim=-1).unsqueeze(0)
+
+
+def _affine_network(in_dim: int, hidden_dim: int) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(in_dim, hidden_dim, bias=False), nn.Tanh(), nn.Linear(hidden_dim, hidden_dim, bias=False), nn.Tanh(),
+                         nn.Linear(hidden_dim, 12, bias=False))
+
+
+def _sliced_features(grids: NeuralBilateralGrid, rgb: Tensor, xy: Tensor, idxs: Sequence[int]) -> Tensor:
+    """Feature slice for one image, or the mean over the neighbour images' grids in the test branch (modules.py:651-662)."""
+    acc = None
+    for i in idxs:
+        f = slice_feature(grids, xy, rgb.unsqueeze(0), torch.tensor(i, device=rgb.device, dtype=torch.long))["affine_features"]
+        acc = f if acc is None else acc + f
+    return acc / len(idxs) if len(idxs) > 1 else acc
+
+
+class NeuralBilateralAffineTransform(nn.Module):
+    """modules.py:595-670: one feature grid per image -> per-pixel features -> 3-layer tanh MLP -> 3x4 map; the trainer adds the
+    input back (trainers/scene_graph.py:99-102): ``rgb' = A rgb + b + rgb``."""
+
+    def __init__(self, class_name, n, grid_X, grid_Y, grid_W, feature_dim, hidden_dim, device="cuda"):
+        super().__init__()
+        self.bil_grids = NeuralBilateralGrid(num=n, grid_X=grid_X, grid_Y=grid_Y, grid_W=grid_W, feature_dim=feature_dim)
+        self.register_buffer("rgb2gray_weight", torch.tensor([0.299, 0.587, 0.114], dtype=torch.float32))
+        self.affine_network = _affine_network(feature_dim, hidden_dim)
+        self.feature_dim = feature_dim
+        self.class_prefix = class_name + "#"
+        self.device = device
+        self.in_test_set = False
+        self.training_indices_for_test: Dict[int, List[int]] = {}
+        self.to(device)
+
+    def tv_loss(self):
+        return total_variation_loss(self.bil_grids.grids)
+
+    def forward(self, rgb: Tensor, image_infos) -> Tensor:
+        assert "img_idx" in image_infos
+        k = _img_index(image_infos)
+        H, W, _ = rgb.shape
+        idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
+        feats = _sliced_features(self.bil_grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
+        return self.affine_network(feats).reshape(1, H, W, 3, 4)
+
+    def transform(self, rgb: Tensor, image_infos) -> Tensor:
+        """forward + the trainer's application with the residual (scene_graph.py:99-102)."""
+        A = self.forward(rgb, image_infos)[0]
+        return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
+
+    def get_param_groups(self):
+        return {self.class_prefix + "all": self.parameters()}
+
+
+class MultiScaleNeuralBilateralAffineTransform(nn.Module):
+    """modules.py:672-820: one feature grid per level; the levels' features (sliced at 1/factor resolution and up-sampled, or at
+    full resolution when ``guidance_factor`` is None -- what the trainer passes, scene_graph.py:104) are concatenated in front of
+    the MLP."""
+
+    def __init__(self, class_name, n, grid, feature_dim, hidden_dim, device="cuda"):
+        super().__init__()
+        self.grid_size = grid
+        self.tv_weight = []
+        for i, (gx, gy, gl) in enumerate(grid):
+            setattr(self, f"bil_grids{i}", NeuralBilateralGrid(num=n, grid_X=gx, grid_Y=gy, grid_W=gl, feature_dim=feature_dim))
+            self.tv_weight.append(0.5 * (gx * gy * gl) ** 0.5)
+        self.register_buffer("rgb2gray_weight", torch.tensor([0.299, 0.587, 0.114], dtype=torch.float32))
+        self.feature_dim = feature_dim
+        self.affine_network = _affine_network(len(grid) * feature_dim, hidden_dim)
+        self.class_prefix = class_name + "#"
+        self.device = device
+        self.in_test_set = False
+        self.training_indices_for_test: Dict[int, List[int]] = {}
+        self.save_matrix = None
+        self.to(device)
+
+    def tv_loss(self):
+        loss = 0
+        for i in range(len(self.grid_size)):
+            loss = loss + total_variation_loss(getattr(self, f"bil_grids{i}").grids) * self.tv_weight[i]
+        return loss
+
+    get_sample_grid = MultiScaleBilateralAffineTransform.get_sample_grid
+
+    def forward(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
+        assert "img_idx" in image_infos
+        k = _img_index(image_infos)
+        H, W, _ = rgb.shape
+        idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
+        out_list = []
+        for i in range(len(self.grid_size)):
+            grids = getattr(self, f"bil_grids{i}")
+            if guidance_factor is not None:
+                xy, lo = self.get_sample_grid(guidance_factor[i], H, W, rgb)
+                f = _sliced_features(grids, lo, xy, idxs)
+                B, Hm, Wm, C = f.shape
+                if (Hm, Wm) != (H, W):     # fill_matrix_res on the feature channels (modules.py:748)
+                    f = F.interpolate(f.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+            else:
+                f = _sliced_features(grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
+            out_list.append(f)
+        self.save_matrix = out_list
+        return self.affine_network(torch.cat(out_list, dim=-1)).reshape(1, H, W, 3, 4)
+
+    def transform(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
+        A = self.forward(rgb, image_infos, guidance_factor)[0]
+        return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
+
+    def get_param_groups(self):
+        return {self.class_prefix + "all": self.parameters()}

@@ -180,3 +180,13 @@ def test_reference_modules_import_against_the_dropin_packages():
             "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_neural_modules_refuse_cpu_tensors():
+    """No CPU fallback behind the module mirrors either: the feature slice underneath raises."""
+    import torch
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd.modules import NeuralBilateralAffineTransform
+    mod = NeuralBilateralAffineTransform("Affine", 2, 4, 4, 2, feature_dim=8, hidden_dim=16, device="cpu")
+    with pytest.raises(L.BdsError):
+        mod(torch.rand(5, 6, 3), {"img_idx": 0})
