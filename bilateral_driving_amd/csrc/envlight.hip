@@ -150,6 +150,67 @@ __global__ __launch_bounds__(kEnvBlock) void cubemap_bwd_kernel(int64_t n, int r
   }
 }
 
+// Texture gradient for an IMAGE of directions (the sky model's use): one workgroup owns a 16x16 pixel tile, whose 1024 taps fall
+// on only ~17x17 texels when a texel is about a pixel wide.  The taps are first summed in an LDS hash table (texel -> rgb) and
+// every touched texel is flushed to HBM once per tile: ~3.5x fewer global atomics, and the ones that remain no longer queue up
+// on the same cache line.  Tiles whose pixels carry no gradient leave after reading v_out.
+constexpr int kHashSize = 1024, kMaxProbe = 16;  // a tap that finds no slot in kMaxProbe steps goes to HBM directly
+__global__ __launch_bounds__(kEnvBlock) void cubemap_bwd_tiles_kernel(int height, int width, int res, const float *__restrict__ dirs,
+                                                                     const float *__restrict__ rot, const float *__restrict__ v_out,
+                                                                     float *__restrict__ v_tex) {
+  __shared__ int keys[kHashSize];
+  __shared__ float vals[kHashSize][3];
+  const int tiles_x = (width + 15) / 16;
+  const int px = (blockIdx.x % tiles_x) * 16 + (threadIdx.x & 15), py = (blockIdx.x / tiles_x) * 16 + (threadIdx.x >> 4);
+  const bool inside = px < width && py < height;
+  const int64_t i = (int64_t)py * width + px;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (inside) { g0 = v_out[i * 3]; g1 = v_out[i * 3 + 1]; g2 = v_out[i * 3 + 2]; }
+  const bool live = g0 != 0.f || g1 != 0.f || g2 != 0.f;
+  if (!__syncthreads_or(live)) return;  // tiles without sky weight (most of a street scene) cost one read of v_out
+  for (int e = threadIdx.x; e < kHashSize; e += kEnvBlock) {
+    keys[e] = -1;
+    vals[e][0] = 0.f; vals[e][1] = 0.f; vals[e][2] = 0.f;
+  }
+  __syncthreads();
+  if (live) {
+    float x, y, z;
+    load_dir(dirs, rot, i, x, y, z);
+    const CubeTaps tp = cube_taps(x, y, z, res);
+    if (tp.valid) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (tp.w[k] == 0.f) continue;
+        const int key = (int)tp.t[k];
+        unsigned h = ((unsigned)key * 2654435761u) >> 22;  // 10 bits
+        bool found = false;
+        for (int probe = 0; probe < kMaxProbe; probe++) {
+          const int old = atomicCAS(&keys[h], -1, key);
+          if (old == -1 || old == key) { found = true; break; }
+          h = (h + 1) & (kHashSize - 1);
+        }
+        if (found) {
+          atomicAdd(&vals[h][0], tp.w[k] * g0);
+          atomicAdd(&vals[h][1], tp.w[k] * g1);
+          atomicAdd(&vals[h][2], tp.w[k] * g2);
+        } else {
+          atomicAdd(v_tex + (int64_t)key * 3, tp.w[k] * g0);
+          atomicAdd(v_tex + (int64_t)key * 3 + 1, tp.w[k] * g1);
+          atomicAdd(v_tex + (int64_t)key * 3 + 2, tp.w[k] * g2);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kHashSize; e += kEnvBlock) {
+    const int key = keys[e];
+    if (key < 0) continue;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      if (vals[e][c] != 0.f) atomicAdd(v_tex + (int64_t)key * 3 + c, vals[e][c]);
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -168,12 +229,20 @@ extern "C" int bds_cubemap_fwd(int64_t n, int res, int channels, const float *di
   return BDS_OK;
 }
 
-extern "C" int bds_cubemap_bwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *v_out,
+extern "C" int bds_cubemap_bwd(int64_t n, int res, int channels, int width, const float *dirs, const float *rot, const float *v_out,
                                float *v_tex, bds_stream_t stream) {
-  BDS_REQUIRE(n >= 0 && res >= 1 && res <= 16384 && channels >= 1);
+  BDS_REQUIRE(n >= 0 && res >= 1 && res <= 16384 && channels >= 1 && width >= 0);
   if (n == 0) return BDS_OK;
   BDS_REQUIRE(dirs && v_out && v_tex);
   const dim3 grid((unsigned)cdiv(n, kEnvBlock)), block(kEnvBlock);
+  if (channels == 3 && width > 0 && n % width == 0 && (int64_t)6 * res * res < ((int64_t)1 << 31)) {
+    const int64_t height = n / width;
+    const int64_t tiles = cdiv(width, 16) * cdiv(height, 16);
+    hipLaunchKernelGGL(cubemap_bwd_tiles_kernel, dim3((unsigned)tiles), block, 0, as_stream(stream), (int)height, width, res, dirs, rot,
+                       v_out, v_tex);
+    BDS_LAUNCH_CHECK();
+    return BDS_OK;
+  }
   if (channels == 3)
     hipLaunchKernelGGL((cubemap_bwd_kernel<3>), grid, block, 0, as_stream(stream), n, res, dirs, rot, v_out, v_tex, channels);
   else

@@ -27,6 +27,8 @@ class _CubemapSample(torch.autograd.Function):
             L.check(L.lib().bds_cubemap_fwd(d.shape[0], res, C, L.ptr(d), L.ptr(r), L.ptr(texc), L.ptr(out), L.stream()), "bds_cubemap_fwd")
         ctx.save_for_backward(d, r)
         ctx.tex_shape = tuple(tex.shape)
+        # an image of directions [..., H, W, 3] with at least a few tile rows: the backward pre-sums 16x16 pixel tiles in LDS
+        ctx.width = int(dirs.shape[-2]) if dirs.dim() >= 3 and dirs.shape[-2] >= 16 and d.shape[0] // dirs.shape[-2] >= 16 else 0
         return out.reshape(tuple(dirs.shape[:-1]) + (C,))
 
     @staticmethod
@@ -36,7 +38,7 @@ class _CubemapSample(torch.autograd.Function):
         v_tex = torch.zeros(ctx.tex_shape, device=v_out.device, dtype=torch.float32)
         vo = v_out.reshape(-1, C).contiguous().float()
         with L.timed("cubemap_bwd"):
-            L.check(L.lib().bds_cubemap_bwd(d.shape[0], res, C, L.ptr(d), L.ptr(r), L.ptr(vo), L.ptr(v_tex), L.stream()), "bds_cubemap_bwd")
+            L.check(L.lib().bds_cubemap_bwd(d.shape[0], res, C, ctx.width, L.ptr(d), L.ptr(r), L.ptr(vo), L.ptr(v_tex), L.stream()), "bds_cubemap_bwd")
         return v_tex, None, None
 
 

@@ -359,11 +359,13 @@ int bds_opacity_reset(int64_t N, float *logits, float reset_value, float *exp_av
  * dr.texture(tex[None], l, filter_mode='linear', boundary_mode='cube') (:202).  OpenGL face order / orientation; taps that
  * fall off a face come from the neighbouring face; a non-finite direction yields zeros.  PARITY UNPINNED (nvdiffrast is
  * absent and unpinned, README.md:83): see csrc/envlight.hip.
- * bwd ACCUMULATES into v_tex (caller zeroes it); directions carry no gradient (the reference's viewdirs are data). */
+ * bwd ACCUMULATES into v_tex (caller zeroes it); directions carry no gradient (the reference's viewdirs are data).
+ * width > 0 tells bwd that dirs is a row-major image [n / width, width, 3] (n % width == 0): 16x16 pixel tiles then pre-sum
+ * their taps in LDS before touching v_tex (channels == 3 only); width = 0: one global atomic per tap and channel. */
 int bds_cubemap_fwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *tex, float *out,
                     bds_stream_t stream);
-int bds_cubemap_bwd(int64_t n, int res, int channels, const float *dirs, const float *rot, const float *v_out, float *v_tex,
-                    bds_stream_t stream);
+int bds_cubemap_bwd(int64_t n, int res, int channels, int width, const float *dirs, const float *rot, const float *v_out,
+                    float *v_tex, bds_stream_t stream);
 
 #ifdef __cplusplus
 }

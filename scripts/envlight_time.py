@@ -15,18 +15,24 @@ dirs = torch.nn.functional.normalize(torch.stack([jj, ii, torch.ones_like(jj)], 
 sky = EnvLight("Sky", resolution=1024)
 with torch.no_grad():
     sky.base.copy_(torch.rand_like(sky.base))
-v = torch.rand(H, W, 3, device="cuda") * (torch.rand(H, W, 1, device="cuda") < 0.3)     # ~30 % of the pixels see sky
-for _ in range(3):
-    sky.base.grad = None
-    sky({"viewdirs": dirs}).backward(v)
-L.enable_timers(True)
-for _ in range(20):
-    sky.base.grad = None
-    sky({"viewdirs": dirs}).backward(v)
-torch.cuda.synchronize()
-t = L.timer_summary()
-L.enable_timers(False)
 px = H * W
-for k, b in (("cubemap_fwd", px * 24 + 0), ("cubemap_bwd", px * 24)):
-    ms = t[k][1]
-    print(f"{k}: {ms * 1e3:.1f} us per 1080p view   ({b / ms / 1e6:.0f} GB/s of the {b / 1e6:.0f} MB of directions + colours)")
+rows = torch.arange(H, device="cuda")[:, None, None]
+masks = {"sky = upper 30 % of the image (a street scene)": (rows < 0.3 * H).float().expand(H, W, 1),
+         "sky = random 30 % of the pixels (worst case)": (torch.rand(H, W, 1, device="cuda") < 0.3).float()}
+for name, m in masks.items():
+    v = (torch.rand(H, W, 3, device="cuda") * m).contiguous()
+    for flat in (False, True):
+        d = dirs.reshape(-1, 3) if flat else dirs
+        vv = v.reshape(-1, 3) if flat else v
+        for _ in range(3):
+            sky.base.grad = None
+            sky({"viewdirs": d}).backward(vv)
+        L.enable_timers(True)
+        for _ in range(20):
+            sky.base.grad = None
+            sky({"viewdirs": d}).backward(vv)
+        torch.cuda.synchronize()
+        t = L.timer_summary()
+        L.enable_timers(False)
+        print(f"{name}, {'one atomic per tap' if flat else '16x16 tiles pre-summed in LDS'}: fwd {t['cubemap_fwd'][1] * 1e3:.1f} us  "
+              f"bwd {t['cubemap_bwd'][1] * 1e3:.1f} us per 1080p view  (fwd {px * 24 / t['cubemap_fwd'][1] / 1e6:.0f} GB/s of directions + colours)")

@@ -57,6 +57,32 @@ def test_forward_and_texture_gradient_equal_oracle(res, C, use_rot):
     assert abs(lhs - rhs) < 1e-3 * (abs(lhs) + 1)
 
 
+@pytest.mark.parametrize("H,W,res", [(50, 70, 32), (16, 16, 4), (33, 129, 256), (270, 480, 1024)])
+def test_image_shaped_directions_use_the_tiled_gradient_and_equal_oracle(H, W, res):
+    """dirs [H,W,3] (the sky model's use): the backward pre-sums 16x16 pixel tiles in an LDS hash table; same gradient."""
+    from bilateral_driving_amd.envlight import cubemap_sample
+    rng = np.random.default_rng(H + W)
+    jj, ii = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    f = 0.5 * W / np.tan(np.radians(35.0))
+    d = np.stack([(jj - W / 2) / f, (ii - H / 2) / f, np.ones_like(jj)], -1).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d[0, 0] = np.nan; d[-1, -1] = 0
+    tex = rng.random((6, res, res, 3)).astype(np.float32)
+    v = (rng.standard_normal((H, W, 3)) * (rng.random((H, W, 1)) < 0.4)).astype(np.float32)
+    rot = CO.TO_OPENGL.astype(np.float32)
+    grads = []
+    for shaped in (True, False):
+        t_tex = torch.from_numpy(tex).cuda().requires_grad_(True)
+        dd = torch.from_numpy(d).cuda()
+        out = cubemap_sample(t_tex, dd if shaped else dd.reshape(-1, 3), torch.from_numpy(rot).cuda())
+        out.backward(torch.from_numpy(v).cuda().reshape(out.shape))
+        grads.append(t_tex.grad.cpu().numpy())
+    g_ref = CO.cubemap_bwd(tex.shape, d, v, rot, dtype=np.float32)
+    denom = np.abs(g_ref).max() + 1e-12
+    assert np.abs(grads[0] - g_ref).max() / denom < 1e-4 and np.abs(grads[1] - g_ref).max() / denom < 1e-4
+    assert np.abs(grads[0]).sum() > 0
+
+
 def test_invalid_directions_and_constant_texture():
     from bilateral_driving_amd.envlight import cubemap_sample
     d = torch.tensor([[0.0, 0, 0], [float("nan"), 1, 0], [1.0, float("nan"), 0], [float("inf"), 3, -2], [1.0, 0, 0]], device="cuda")
