@@ -71,9 +71,12 @@ def _rows(src: Tensor, n_new: int, samps: int, flags, ranks, totals, zero_childr
 
 
 @torch.no_grad()
-def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples: Optional[Tensor] = None, verbose: bool = True) -> None:
+def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples: Optional[Tensor] = None, verbose: bool = True,
+                     sample_fn=None) -> None:
     """Same contract as VanillaGaussians.refinement_after(step, optimizer).  ``samples`` (optional, [n_split_samples * n_split, 3])
-    replaces the ``torch.randn`` draw of split_gaussians (vanilla.py:343) -- the tests feed the reference's recorded noise."""
+    replaces the ``torch.randn`` draw of split_gaussians (vanilla.py:343) -- the tests feed the reference's recorded noise;
+    ``sample_fn(shape, device)`` (optional) produces it instead (view-parallel training: ``dist.broadcast_randn`` gives every rank
+    rank 0's draw, so that the replicas stay identical -- SURVEY.md 8e)."""
     assert step == self.step
     ctrl = self.ctrl_cfg
     if self.step <= ctrl.warmup_steps:
@@ -104,6 +107,8 @@ def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples:
         n_new = KO + samps * KS + KD
         dev = self._means.device
         if do_densify:
+            if samples is None and sample_fn is not None:
+                samples = sample_fn((samps * n_split, 3), dev)
             if samples is None:
                 samples = torch.randn((samps * n_split, 3), device=dev)       # vanilla.py:343, same draw from the same stream
             samples = samples.to(device=dev, dtype=torch.float32).contiguous()

@@ -144,6 +144,34 @@ def reduce_densify_stats(grad_norm_accum: Tensor, vis_counts: Tensor, max_2d_siz
     dist.all_reduce(max_2d_size, op=dist.ReduceOp.MAX)
 
 
+def broadcast_randn(shape, device) -> Tensor:
+    """``torch.randn(shape)`` drawn on rank 0 and broadcast: the noise of ``split_gaussians`` (models/gaussians/vanilla.py:343) has to be
+    the same on every replica, or the replicas' Gaussians diverge at the first densification ("extra state")."""
+    t = torch.randn(tuple(shape), device=device) if (not _active() or dist.get_rank() == 0) else torch.empty(tuple(shape), device=device)
+    if _active():
+        dist.broadcast(t, src=0)
+    return t
+
+
+def _active() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def refinement_after_synced(model, step: int, optimizer, stats=None, verbose: bool = False) -> None:
+    """View-parallel densification: sum / max the per-view statistics over the ranks (``reduce_densify_stats``), then let every rank
+    run the same refinement on its replica with rank 0's noise.  Parameters, optimiser state and reduced statistics are identical on
+    all ranks, hence so are the plan and the resulting set.  ``stats``: an ``optim.DensifyStats`` (or None if ``model`` already
+    carries ``xys_grad_norm / vis_counts / max_2Dsize``).  Create the per-rank statistics with
+    ``DensifyStats(..., first_call_initialises=(rank == 0))``: the reference's first ``after_train`` call sets ``vis_counts`` to one
+    for EVERY Gaussian; only one rank may contribute that one, then the sums equal a single process visiting the same views."""
+    from .densify import refinement_after
+    if stats is not None:
+        model.xys_grad_norm, model.vis_counts, model.max_2Dsize = stats.xys_grad_norm, stats.vis_counts, stats.max_2Dsize
+    if model.xys_grad_norm is not None:
+        reduce_densify_stats(model.xys_grad_norm, model.vis_counts, model.max_2Dsize)
+    refinement_after(model, step, optimizer, verbose=verbose, sample_fn=broadcast_randn)
+
+
 def view_for_rank(step: int, rank: int, world: int, n_views: int) -> int:
     """Round-robin view assignment: at step s, rank r renders view (s*world + r) mod n_views."""
     return (step * world + rank) % n_views

@@ -54,12 +54,15 @@ class DensifyStats:
     models/gaussians/vanilla.py:163-191), updated by one launch per step instead of ~10 masked-indexing operations with host
     syncs.  ``update(info)`` takes the ``info`` dict of ``rasterization()`` / ``fused_view`` after ``backward()``."""
 
-    def __init__(self, num_points: int, device, batch_size: int = 1):
+    def __init__(self, num_points: int, device, batch_size: int = 1, first_call_initialises: bool = True):
+        """``first_call_initialises=False`` (view-parallel training, every rank but one): start from zeros and count only visible
+        Gaussians from the first call on, so that the sum over the ranks equals one process visiting all the views
+        (``dist.refinement_after_synced``)."""
         self.xys_grad_norm = torch.zeros(num_points, device=device, dtype=torch.float32)
         self.vis_counts = torch.zeros(num_points, device=device, dtype=torch.float32)
         self.max_2Dsize = torch.zeros(num_points, device=device, dtype=torch.float32)
         self.batch_size = int(batch_size)
-        self._first = True
+        self._first = bool(first_call_initialises)
 
     @torch.no_grad()
     def update(self, info, absgrad: bool = True) -> None:

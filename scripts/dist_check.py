@@ -58,11 +58,65 @@ def main():
             aliased = all(t.grad.data_ptr() == v.data_ptr() for t, v in zip(flat.params, flat._views))
             print(f"[dist_check] step {step}: rel err {rel:.2e}, grads alias the reduced buffer: {aliased}, payload {flat.last_payload_bytes / 1e6:.1f} of {flat.nbytes / 1e6:.1f} MB")
             ok = ok and rel < 1e-3 and aliased
+    ok = refinement_phase(rank, world, dev, base) and ok
     if rank == 0:
         print("[dist_check]", "PASS" if ok else "FAIL")
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
+
+
+def refinement_phase(rank, world, dev, base):
+    """View-parallel densification: per-rank statistics are reduced, rank 0's split noise is broadcast, every replica runs the same
+    refinement -> the replicas must end up bit-identical (and equal to one process that saw both ranks' statistics)."""
+    import types
+    from bilateral_driving_amd.dist import refinement_after_synced
+    from bilateral_driving_amd.densify import refinement_after
+    from bilateral_driving_amd.optim import FusedAdam
+    N = base["means"].shape[0]
+    ctrl = types.SimpleNamespace(warmup_steps=500, reset_alpha_interval=3000, refine_interval=100, n_split_samples=2, reset_alpha_value=0.01,
+                                 densify_grad_thresh=0.0003, densify_size_thresh=0.002, cull_alpha_thresh=0.005, cull_scale_thresh=0.5,
+                                 cull_screen_size=0.15, split_screen_size=0.05, stop_screen_size_at=4000, stop_split_at=15000)
+
+    def make():
+        m = types.SimpleNamespace(ctrl_cfg=ctrl, scene_scale=30.0, num_train_images=6, step=3300, class_prefix="Background#")
+        P = torch.nn.Parameter
+        m._means, m._quats, m._scales = P(base["means"].clone()), P(base["quats"].clone()), P(base["log_scales"].clone())
+        m._opacities = P(base["opacity_logits"].clone()[:, None])
+        m._features_dc, m._features_rest = P(base["sh"][:, 0].clone()), P(base["sh"][:, 1:].clone())
+        names = dict(_means="xyz", _features_dc="sh_dc", _features_rest="sh_rest", _opacities="opacity", _scales="scaling", _quats="rotation")
+        opt = FusedAdam([{"params": [getattr(m, a)], "name": m.class_prefix + n, "lr": 1e-3} for a, n in names.items()], lr=0.0, eps=1e-15)
+        for a in names:
+            getattr(m, a).grad = torch.full_like(getattr(m, a), 1e-3)
+        opt.step()
+        return m, opt, list(names)
+
+    def rank_stats(r):   # what rank r's views would have accumulated (rank 0 carries the reference's initial one in vis_counts)
+        g = torch.Generator().manual_seed(100 + r)
+        return (torch.rand(N, generator=g).to(dev) * 0.004, torch.floor(torch.rand(N, generator=g) * 3).to(dev) + (1.0 if r == 0 else 0.0),
+                torch.rand(N, generator=g).to(dev) * 0.2)
+
+    m, opt, attrs = make()
+    m.xys_grad_norm, m.vis_counts, m.max_2Dsize = rank_stats(rank)
+    torch.manual_seed(1234 + rank)                       # different RNG streams on the ranks: the broadcast has to make them agree
+    refinement_after_synced(m, 3300, opt)
+    sig = torch.stack([getattr(m, a).detach().double().sum() for a in attrs] +
+                      [opt.state[getattr(m, a)]["exp_avg_sq"].double().sum() for a in attrs] + [torch.tensor(float(m._means.shape[0]), device=dev, dtype=torch.float64)])
+    sigs = [torch.empty_like(sig) for _ in range(world)]
+    dist.all_gather(sigs, sig)
+    same = all(torch.equal(sigs[0], s) for s in sigs)
+    ok = same and m._means.shape[0] != N
+    if rank == 0:   # one process with the summed statistics and the same noise stream gives the same set
+        m1, opt1, _ = make()
+        st = [rank_stats(r) for r in range(world)]
+        m1.xys_grad_norm, m1.vis_counts = sum(s[0] for s in st), sum(s[1] for s in st)
+        m1.max_2Dsize = torch.stack([s[2] for s in st]).max(dim=0).values
+        torch.manual_seed(1234)
+        refinement_after(m1, 3300, opt1, verbose=False)
+        seq = m1._means.shape == m._means.shape and torch.equal(m1._means, m._means) and torch.equal(m1._features_rest, m._features_rest)
+        print(f"[dist_check] synced refinement: {N} -> {m._means.shape[0]} Gaussians, replicas identical: {same}, equals one process: {seq}")
+        ok = ok and seq
+    return ok
 
 
 if __name__ == "__main__":

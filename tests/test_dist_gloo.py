@@ -3,6 +3,7 @@ sum-all-reduce == sequential accumulation over the same views on one process."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -148,3 +149,35 @@ def test_rows_union_exchange_equals_dense_sum():
         for r in range(world):
             assert abs(res[r][1][step] - ref).max() < 1e-5
             assert res[r][2][step] < 0.5 * res[r][3]               # the payload really shrank (<= 60 of 200 rows + the dense tail)
+
+
+def _randn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd.dist import broadcast_randn
+    torch.manual_seed(100 + rank)                      # different streams: the broadcast must make the ranks agree
+    t = broadcast_randn((7, 3), "cpu")
+    e = broadcast_randn((0, 3), "cpu")
+    q.put((rank, t.numpy(), tuple(e.shape)))
+    dist.destroy_process_group()
+
+
+def test_split_noise_is_rank0s_draw_on_every_rank():
+    """Densification under view parallelism: every replica has to split with the same noise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_randn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    torch.manual_seed(100)
+    np.testing.assert_array_equal(res[0][1], torch.randn(7, 3).numpy())
+    assert res[0][2] == (0, 3) and res[1][2] == (0, 3)
+    from bilateral_driving_amd.dist import broadcast_randn      # no process group: plain randn
+    assert broadcast_randn((2, 3), "cpu").shape == (2, 3)
