@@ -367,6 +367,18 @@ int bds_cubemap_fwd(int64_t n, int res, int channels, const float *dirs, const f
 int bds_cubemap_bwd(int64_t n, int res, int channels, int width, const float *dirs, const float *rot, const float *v_out,
                     float *v_tex, bds_stream_t stream);
 
+/* ---- Colour-correct post-process of the evaluation path ----------------------------------------
+ * One iteration of lib_bilagrid.color_correct (bilateral/lib_bilagrid.py:56-120; called per frame at
+ * models/video_utils_color_correction.py:201) as one streaming pass:
+ *   cur = warp ? clip(expand(cur_in) @ warp, 0, 1) : cur_in          expand(r,g,b) = [rr, rg, rb, gg, gb, bb, r, g, b, 1] (:98-104)
+ *   mask0 [P] u8: bit c = channel c of the ORIGINAL image is in [eps, 1-eps] -- written when warp == NULL (first pass), read otherwise
+ *   cur_out [P,3] (may be NULL) receives cur
+ *   acc [3,65] doubles (may be NULL; ACCUMULATED into, caller zeroes): per output channel c, over the pixels with mask0 bit c set and
+ *   cur_c, ref_c in [eps, 1-eps] (:110): the 55 upper-triangle entries (row-major) of sum expand expand^T, then the 10 entries of
+ *   sum expand * ref_c.  The caller solves the three 10x10 systems (float64) -> next warp [10,3] row-major float. */
+int bds_color_correct_step(int64_t P, const float *cur_in, const float *ref, const float *warp, float eps, uint8_t *mask0,
+                           float *cur_out, double *acc, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
