@@ -190,3 +190,31 @@ def test_neural_modules_refuse_cpu_tensors():
     mod = NeuralBilateralAffineTransform("Affine", 2, 4, 4, 2, feature_dim=8, hidden_dim=16, device="cpu")
     with pytest.raises(L.BdsError):
         mod(torch.rand(5, 6, 3), {"img_idx": 0})
+
+
+def test_sky_and_colour_correct_refuse_cpu_tensors():
+    import torch
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd.colorcorrect import color_correct
+    from bilateral_driving_amd.envlight import EnvLight, cubemap_sample
+    with pytest.raises(L.BdsError):
+        color_correct(torch.rand(4, 4, 3), torch.rand(4, 4, 3))
+    with pytest.raises(L.BdsError):
+        cubemap_sample(torch.rand(6, 4, 4, 3), torch.rand(5, 3))
+    sky = EnvLight("Sky", resolution=4, device="cpu")
+    assert list(sky.state_dict()) == ["base"] and sky.base.shape == (6, 4, 4, 3)
+    with pytest.raises(L.BdsError):
+        sky({"viewdirs": torch.rand(3, 5, 3)})
+    with pytest.raises(ValueError):
+        color_correct(torch.rand(4, 4, 3), torch.rand(4, 4, 4))
+
+
+def test_dropin_lib_bilagrid_exports_the_product_functions():
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "bilateral_driving_amd", "dropin"), ROOT]))
+    code = ("import bilateral.lib_bilagrid as LB, bilateral_driving_amd.colorcorrect as C, bilateral_driving_amd.bilagrid as G\n"
+            "assert LB.color_correct is C.color_correct and LB.slice_feature is G.slice_feature and LB.NeuralBilateralGrid is G.NeuralBilateralGrid\n"
+            "import nvdiffrast.torch as dr, bilateral_driving_amd.envlight as E\n"
+            "assert dr.cubemap_sample is E.cubemap_sample\n"
+            "try:\n    LB.slice4d()\nexcept NotImplementedError:\n    print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
