@@ -1,0 +1,97 @@
+"""End-to-end regression on the device: sky cube -> fused view -> image loss + TV -> FusedAdam -> densification statistics ->
+refinement_after, a short version of scripts/train_loop_demo.py.  The optimisation has to make progress (PSNR against targets
+rendered from a ground-truth scene rises by several dB) and the densification has to change the set while the optimiser keeps working."""
+import math
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_short_training_run_converges_and_densifies():
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.bilagrid import total_variation_loss
+    from bilateral_driving_amd.densify import refinement_after
+    from bilateral_driving_amd.envlight import EnvLight
+    from bilateral_driving_amd.losses import pixel_loss, ssim_loss
+    from bilateral_driving_amd.optim import DensifyStats, FusedAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    W, H, N_GT = 320, 192, 20_000
+    cams = Hn.ring_cameras(W, H, device=dev)[:3]
+
+    def view_dirs(cam):
+        jj, ii = torch.meshgrid(torch.arange(W, device=dev) + 0.5, torch.arange(H, device=dev) + 0.5, indexing="xy")
+        d = torch.stack([jj, ii, torch.ones_like(jj)], -1) @ torch.linalg.inv(cam.K).T @ torch.linalg.inv(cam.viewmat)[:3, :3].T
+        return torch.nn.functional.normalize(d, dim=-1).contiguous()
+    dirs = [view_dirs(c) for c in cams]
+    gt = Hn.synthetic_scene(N_GT, seed=1, device=dev)
+    gt_sky = EnvLight("Sky", resolution=16)
+    with torch.no_grad():
+        gt_sky.base.copy_(torch.rand_like(gt_sky.base))
+    gt_grids = Hn.make_grids(len(cams), seed=3, device=dev)
+    targets, sky_masks, lidar = [], [], []
+    with torch.no_grad():
+        for v, cam in enumerate(cams):
+            out = Hn.render_view(gt, cam, gt_grids, v, gt_sky({"viewdirs": dirs[v]}))
+            targets.append(out["rgb"].clone())
+            sky_masks.append((out["opacity"].squeeze(-1) < 0.5).float())
+            lidar.append(out["depth"].squeeze(-1) * ((torch.rand(H, W, device=dev) < 0.3) & (out["opacity"].squeeze(-1) > 0.9)))
+    sel = torch.randperm(N_GT, device=dev)[: N_GT // 2]
+    m = types.SimpleNamespace(
+        class_prefix="Background#", scene_scale=30.0, num_train_images=len(cams), step=0, xys_grad_norm=None, vis_counts=None, max_2Dsize=None,
+        ctrl_cfg=types.SimpleNamespace(warmup_steps=10, reset_alpha_interval=3000, refine_interval=50, n_split_samples=2, reset_alpha_value=0.01,
+                                       densify_grad_thresh=0.0002, densify_size_thresh=0.002, cull_alpha_thresh=0.005, cull_scale_thresh=0.5,
+                                       cull_screen_size=0.15, split_screen_size=0.05, stop_screen_size_at=4000, stop_split_at=15000))
+    P = torch.nn.Parameter
+    m._means, m._quats, m._scales = P(gt["means"][sel] + 0.05 * torch.randn(len(sel), 3, device=dev)), P(gt["quats"][sel].clone()), P(gt["log_scales"][sel] + 0.2)
+    m._features_dc, m._features_rest = P(torch.zeros(len(sel), 3, device=dev)), P(torch.zeros(len(sel), 15, 3, device=dev))
+    m._opacities = P(torch.full((len(sel), 1), -1.0, device=dev))
+    sky = EnvLight("Sky", resolution=16)
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), seed=0, device=dev)]
+    names = dict(_means=("xyz", 1.6e-3), _features_dc=("sh_dc", 2.5e-3), _features_rest=("sh_rest", 1.25e-4), _opacities=("opacity", 5e-2),
+                 _scales=("scaling", 5e-3), _quats=("rotation", 1e-3))
+    groups = [{"params": [getattr(m, a)], "name": m.class_prefix + n, "lr": lr, "eps": 1e-15, "weight_decay": 0} for a, (n, lr) in names.items()]
+    groups += [{"params": [g], "name": f"Affine#grid{i}", "lr": 2e-3, "eps": 1e-15, "weight_decay": 0} for i, g in enumerate(grids)]
+    groups += [{"params": [sky.base], "name": "Sky#all", "lr": 1e-2, "eps": 1e-15, "weight_decay": 0}]
+    opt = FusedAdam(groups, lr=0.0, eps=1e-15)
+    tvw = [0.01 * 0.5 * math.sqrt(g.shape[4] * g.shape[3] * g.shape[2]) for g in grids]
+
+    def params():
+        return dict(means=m._means, quats=m._quats, log_scales=m._scales, opacity_logits=m._opacities.squeeze(-1),
+                    sh=torch.cat([m._features_dc[:, None, :], m._features_rest], dim=1))
+
+    def psnr():
+        with torch.no_grad():
+            mse = sum(float(((Hn.render_view(params(), c, grids, v, sky({"viewdirs": dirs[v]}))["rgb"] - targets[v]) ** 2).mean())
+                      for v, c in enumerate(cams))
+        return -10 * math.log10(mse / len(cams))
+
+    p0, n0, stats, sizes = psnr(), m._means.shape[0], None, []
+    for step in range(1, 201):
+        m.step = step
+        v = step % len(cams)
+        opt.zero_grad(set_to_none=True)
+        out = Hn.render_view(params(), cams[v], grids, v, sky({"viewdirs": dirs[v]}))
+        loss = pixel_loss(out["rgb"], out["opacity"], out["depth"], targets[v], sky_masks[v], lidar[v]).sum() + 0.2 * ssim_loss(out["rgb"], targets[v])
+        for g, w in zip(grids, tvw):
+            loss = loss + total_variation_loss(g, w)
+        loss.backward()
+        assert torch.isfinite(loss)
+        opt.step()
+        stats = stats or DensifyStats(m._means.shape[0], dev)
+        stats.update(out["info"])
+        if step % m.ctrl_cfg.refine_interval == 0:
+            m.xys_grad_norm, m.vis_counts, m.max_2Dsize = stats.xys_grad_norm, stats.vis_counts, stats.max_2Dsize
+            refinement_after(m, step, opt, verbose=False)
+            stats = None
+            sizes.append(m._means.shape[0])
+            for a in names:   # optimiser state follows the new set
+                st = opt.state[getattr(m, a)]
+                assert st["exp_avg"].shape == getattr(m, a).shape and st["exp_avg_sq"].shape == getattr(m, a).shape
+    p1 = psnr()
+    assert p1 > p0 + 4.0, (p0, p1)
+    assert len(set(sizes + [n0])) > 1, sizes                     # densification changed the number of Gaussians
+    assert all(torch.isfinite(getattr(m, a)).all() for a in names) and torch.isfinite(sky.base).all()
