@@ -92,6 +92,7 @@ def test_short_training_run_converges_and_densifies():
                 st = opt.state[getattr(m, a)]
                 assert st["exp_avg"].shape == getattr(m, a).shape and st["exp_avg_sq"].shape == getattr(m, a).shape
     p1 = psnr()
+    print(f"[train_loop] PSNR {p0:.2f} -> {p1:.2f} dB, Gaussians {n0} -> {sizes}")
     assert p1 > p0 + 4.0, (p0, p1)
     assert len(set(sizes + [n0])) > 1, sizes                     # densification changed the number of Gaussians
     assert all(torch.isfinite(getattr(m, a)).all() for a in names) and torch.isfinite(sky.base).all()
