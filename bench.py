@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=150.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--sparse-grads", action="store_true",
+                    help="opt-in experiment: persistent gradient buffer, the backward touches only the rows of visible Gaussians")
     return ap.parse_args()
 
 
@@ -181,9 +183,10 @@ def main():
     # the sky colour comes from a trainable sky model in the reference: its gradient path stays live
     skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
     targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
-    flat = FlatGradients(list(params.values()) + grids)
+    sparse = bool(args.sparse_grads)
+    flat = FlatGradients(list(params.values()) + grids, sparse_rows=sparse)
     # multi-GPU: the backward kernels write the per-Gaussian gradients straight into the all-reduce buffer
-    arena = flat.arena(list(params.keys())) if world > 1 else None
+    arena = flat.arena(list(params.keys())) if (world > 1 or sparse) else None
 
     stats = {}
 
@@ -191,9 +194,11 @@ def main():
         v = view_for_rank(s, rank, world, len(cams))
         flat.zero()
         skies[v].grad = None
-        out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena)
+        out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena, arena_rows=1 if flat.rows_clean else 0)
         if world > 1:   # rows that can receive a gradient on this rank; the OR over the ranks runs behind the backward pass
             flat.begin_rows_union(out["info"]["radii"][0] > 0)
+        elif sparse:
+            flat.mark_rows(out["info"]["radii"][0] > 0)
         loss = Hn.training_loss(out, targets[v], grids)
         loss.backward()
         flat.all_reduce()

@@ -52,6 +52,9 @@ _SIGS = {
     "bds_project_view_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_sh_view_bwd_rows": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_project_view_bwd_rows": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_view_grads_clear": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),

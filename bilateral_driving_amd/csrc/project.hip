@@ -149,6 +149,37 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_kernel(
   v_logits[g] = al;
 }
 
+// the same for the VISIBLE Gaussians only: rows of culled Gaussians are not touched (persistent gradient buffers kept zero by the
+// caller, or several views accumulated into one buffer: kAcc adds instead of storing) -- see sh_view_bwd_rows_kernel
+template <bool kAcc>
+__global__ __launch_bounds__(kProjBlock) void project_view_bwd_rows_kernel(
+    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
+    float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
+    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits) {
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  if (g >= N || radii[g] <= 0) return;
+  const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
+  const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+  const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
+  Camera cam = load_camera(viewmat, K);
+  ProjGrad pg;
+  for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
+  for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
+  project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[g * 2], v_means2d[g * 2 + 1], v_depths[g], v_conics[g * 3], v_conics[g * 3 + 1],
+                  v_conics[g * 3 + 2], pg);
+  const float o = opacities[g];
+  const float al = v_opacities[g] * o * (1.f - o);
+  for (int i = 0; i < 3; i++) {
+    const float a = pg.v_mean[i], b = pg.v_scale[i] * s[i];
+    v_means[g * 3 + i] = kAcc ? v_means[g * 3 + i] + a : a;
+    v_log_scales[g * 3 + i] = kAcc ? v_log_scales[g * 3 + i] + b : b;
+  }
+  for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = kAcc ? v_quats[g * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
+  v_logits[g] = kAcc ? v_logits[g] + al : al;
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -216,6 +247,26 @@ extern "C" int bds_project_view_bwd(int64_t N, const float *means, const float *
   hipLaunchKernelGGL(project_view_bwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
                      means, quats, scales, opacities, viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics,
                      v_opacities, v_means, v_quats, v_log_scales, v_logits);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_project_view_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
+                                         const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                         const int32_t *radii, const float *v_means2d, const float *v_depths, const float *v_conics,
+                                         const float *v_opacities, float *v_means, float *v_quats, float *v_log_scales,
+                                         float *v_logits, int accumulate, bds_stream_t stream) {
+  BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && quats && scales && opacities && viewmat && K && radii && v_means2d && v_depths && v_conics &&
+              v_opacities && v_means && v_quats && v_log_scales && v_logits);
+  const dim3 grid((unsigned)cdiv(N, kProjBlock)), block(kProjBlock);
+  if (accumulate)
+    hipLaunchKernelGGL((project_view_bwd_rows_kernel<true>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities,
+                       viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits);
+  else
+    hipLaunchKernelGGL((project_view_bwd_rows_kernel<false>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities,
+                       viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -282,6 +282,77 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_kernel(int64_t n, int K,
   }
 }
 
+// ---- gradient rows of the VISIBLE Gaussians only (persistent / accumulating gradient buffers) -------------------------------
+// The dense backward above streams 192 B of zeros for every Gaussian the view culls (~85 %).  When the caller keeps the gradient
+// buffer zero outside the rows it knows to be dirty (dist.FlatGradients(sparse_rows=True)), or accumulates several views into it,
+// only the visible rows have to be touched: kAcc = false stores them, kAcc = true adds to them.  v_depths stays dense (4 B/Gaussian,
+// it is an input of the projection backward).
+template <int DEG, bool kVec, bool kAcc>
+__global__ __launch_bounds__(kShBlock) void sh_view_bwd_rows_kernel(int64_t n, int K, const float *__restrict__ means,
+                                                                   const float *__restrict__ cam_pos,
+                                                                   const int32_t *__restrict__ radii,
+                                                                   const float *__restrict__ sh_rgb,
+                                                                   const float4 *__restrict__ v_colors,
+                                                                   float *__restrict__ v_coeffs, float *__restrict__ v_depths) {
+  constexpr int nb = (DEG + 1) * (DEG + 1);
+  const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
+  if (g >= n) return;
+  const float4 v = v_colors[g];
+  v_depths[g] = v.w;
+  if (radii[g] <= 0) return;
+  float vo[3] = {v.x, v.y, v.z};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float x = sh_rgb[g * 3 + k] + 0.5f;
+    if (!(x >= 0.f && x <= 1.f)) vo[k] = 0.f;
+  }
+  const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
+  const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+  float B[16];
+  sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+  float row[48];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const float b = k < nb ? B[k < nb ? k : 0] : 0.f;
+    row[k * 3] = b * vo[0]; row[k * 3 + 1] = b * vo[1]; row[k * 3 + 2] = b * vo[2];
+  }
+  float *dst = v_coeffs + g * (int64_t)K * 3;
+  if (kVec) {
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+      if (i * 4 < K * 3) {
+        float4 o = make_float4(row[i * 4], row[i * 4 + 1], row[i * 4 + 2], row[i * 4 + 3]);
+        if (kAcc) {
+          const float4 p = reinterpret_cast<const float4 *>(dst)[i];
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        reinterpret_cast<float4 *>(dst)[i] = o;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 48; i++)
+      if (i < K * 3) dst[i] = kAcc ? dst[i] + row[i] : row[i];
+  }
+}
+
+// zero the rows marked in `dirty` of the five per-Gaussian gradient arrays (sparse clear of a persistent buffer)
+__global__ __launch_bounds__(kShBlock) void view_grads_clear_kernel(int64_t n, int K, const uint8_t *__restrict__ dirty,
+                                                                   float *__restrict__ v_means, float *__restrict__ v_quats,
+                                                                   float *__restrict__ v_log_scales, float *__restrict__ v_logits,
+                                                                   float *__restrict__ v_sh) {
+  const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
+  if (g >= n || !dirty[g]) return;
+  for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
+  for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
+  v_logits[g] = 0.f;
+  float *dst = v_sh + g * (int64_t)K * 3;
+  if (((K * 3) & 3) == 0 && (reinterpret_cast<uintptr_t>(v_sh) & 15u) == 0) {
+    for (int i = 0; i < K * 3 / 4; i++) reinterpret_cast<float4 *>(dst)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int i = 0; i < K * 3; i++) dst[i] = 0.f;
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -410,6 +481,49 @@ extern "C" int bds_sh_view_bwd(int64_t n, int K, int deg, const float *means, co
     case 2: launch_view_bwd<2>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
     default: launch_view_bwd<3>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
   }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+template <int DEG>
+static void launch_view_bwd_rows(bool vec, bool acc, int grid, hipStream_t st, int64_t n, int K, const float *means,
+                                 const float *cam_pos, const int32_t *radii, const float *sh_rgb, const float4 *v_colors,
+                                 float *v_coeffs, float *v_depths) {
+#define BDS_ROWS(V, A)                                                                                                          \
+  hipLaunchKernelGGL((sh_view_bwd_rows_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), 0, st, n, K, means, cam_pos, radii, sh_rgb, \
+                     v_colors, v_coeffs, v_depths)
+  if (vec) { if (acc) BDS_ROWS(true, true); else BDS_ROWS(true, false); }
+  else     { if (acc) BDS_ROWS(false, true); else BDS_ROWS(false, false); }
+#undef BDS_ROWS
+}
+
+extern "C" int bds_sh_view_bwd_rows(int64_t n, int K, int deg, const float *means, const float *cam_pos, const int32_t *radii,
+                                    const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, int accumulate,
+                                    bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(means && cam_pos && radii && sh_rgb && v_colors && v_coeffs && v_depths && aligned16(v_colors));
+  const int grid = (int)cdiv(n, kShBlock);
+  const bool vec = ((K * 3) % 4 == 0) && aligned16(v_coeffs);
+  hipStream_t st = as_stream(stream);
+  const float4 *v4 = reinterpret_cast<const float4 *>(v_colors);
+  switch (deg) {
+    case 0: launch_view_bwd_rows<0>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    case 1: launch_view_bwd_rows<1>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    case 2: launch_view_bwd_rows<2>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    default: launch_view_bwd_rows<3>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+  }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_view_grads_clear(int64_t n, int K, const uint8_t *dirty, float *v_means, float *v_quats, float *v_log_scales,
+                                    float *v_logits, float *v_sh, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && K >= 1 && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(dirty && v_means && v_quats && v_log_scales && v_logits && v_sh);
+  hipLaunchKernelGGL(view_grads_clear_kernel, dim3((unsigned)cdiv(n, kShBlock)), dim3(kShBlock), 0, as_stream(stream), n, K, dirty,
+                     v_means, v_quats, v_log_scales, v_logits, v_sh);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -24,7 +24,14 @@ class FlatGradients:
     gradients into the flat buffer (one read + one write of the payload), runs ONE sum-all-reduce, and
     re-points every ``param.grad`` at its slice of the reduced buffer."""
 
-    def __init__(self, params: Iterable[Tensor]):
+    def __init__(self, params: Iterable[Tensor], sparse_rows: bool = False):
+        """``sparse_rows`` (opt-in): the flat buffer is kept all-zero between steps by clearing only the rows that were written
+        (``mark_rows`` / ``begin_rows_union`` tell which), so that a producer may touch just the rows it needs
+        (``fused_view(grad_arena=..., arena_rows=1 | 2)``).  Whenever the book is incomplete the whole buffer is cleared."""
+        self.sparse_rows = bool(sparse_rows)
+        self._dirty: Optional[Tensor] = None      # uint8 [N]: rows that may be non-zero (None: unknown -> dense clear)
+        self._clean = False                       # the flat buffer is known to be all zeros
+        self._arena_names: List[str] = []
         self.params: List[Tensor] = [p for p in params]
         assert self.params, "no parameters"
         dev = self.params[0].device
@@ -51,11 +58,47 @@ class FlatGradients:
     def zero(self) -> None:
         for p in self.params:
             p.grad = None
+        if self.sparse_rows:
+            self._clear_rows()
+
+    def mark_rows(self, touched: Tensor) -> None:
+        """Rows (first-dim entries) a backward of THIS process may write; call once per view, the marks of a step accumulate
+        (with several ranks ``begin_rows_union`` records the union over the ranks instead)."""
+        if not self.sparse_rows:
+            return
+        if not self._clean and self._dirty is None:
+            return                                   # state unknown (never cleared yet): stays unknown -> dense clear next time
+        t = touched.reshape(-1)
+        t = t.view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8)
+        self._dirty = t if self._dirty is None else torch.maximum(self._dirty, t)
+        self._clean = False
+
+    @property
+    def rows_clean(self) -> bool:
+        """True right after ``zero()`` in sparse_rows mode: every row of the arena is zero."""
+        return self.sparse_rows and self._clean
+
+    def _clear_rows(self) -> None:
+        from . import _lib as L   # the row-wise clear is a libbds kernel
+        flat = self.flat
+        row = dict(zip(self._arena_names, self._views))
+        keys = ("means", "quats", "log_scales", "opacity_logits", "sh")
+        if self._dirty is not None and flat.is_cuda and all(k in row for k in keys) and row["sh"].dim() == 3:
+            n, K = row["sh"].shape[0], row["sh"].shape[1]
+            L.check(L.lib().bds_view_grads_clear(n, K, L.ptr(self._dirty.contiguous()), L.ptr(row["means"]), L.ptr(row["quats"]),
+                                                 L.ptr(row["log_scales"]), L.ptr(row["opacity_logits"]), L.ptr(row["sh"]), L.stream()),
+                    "bds_view_grads_clear")
+            # the other slices are dense: pack() / autograd overwrite (or zero) them before they are read
+        else:
+            flat.zero_()
+        self._dirty = None
+        self._clean = True
 
     def arena(self, names: Iterable[str]) -> Dict[str, Tensor]:
         """name -> slice of the flat buffer, for producers that can write a parameter's gradient in place
         (fused_view(grad_arena=...)); ``pack()`` then finds the gradient already where it belongs."""
         _ = self.flat
+        self._arena_names = list(names)
         return {n: v for n, v in zip(names, self._views)}
 
     def pack(self) -> Tensor:
@@ -77,11 +120,14 @@ class FlatGradients:
             return
         self._union = touched.reshape(-1).to(torch.uint8).clone()
         self._union_work = dist.all_reduce(self._union, op=dist.ReduceOp.MAX, async_op=True)
+        self._clean = False
 
     def _all_reduce_rows(self, flat: Tensor) -> bool:
         """Exchange only the rows of the union.  Returns False (nothing done) when that would not pay."""
         self._union_work.wait()
         union, self._union, self._union_work = self._union, None, None
+        if self.sparse_rows:
+            self._dirty = union      # after the exchange exactly the rows of the union may be non-zero (also on the dense path)
         n_rows = union.numel()
         idx = union.nonzero().squeeze(1)            # same on every rank (host sync: the exchange waits for backward anyway)
         if idx.numel() > 0.85 * n_rows:

@@ -195,17 +195,32 @@ class _FusedView(torch.autograd.Function):
             assert t.shape == ref.shape and t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device, name
             return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
 
+        # opt-in: touch only the rows of the Gaussians this view sees (1: store them into an arena the caller keeps zero elsewhere,
+        # 2: add them to an arena that already is the parameters' .grad -- several views summed before one exchange)
+        rows = int(cfg.get("arena_rows", 0)) if all(k in arena for k in ("means", "quats", "log_scales", "opacity_logits", "sh")) else 0
         v_sh, v_depths = out_like("sh", sh), _empty((1, N), dev)
         with L.timed("sh_bwd"):
-            L.check(lib.bds_sh_view_bwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col),
-                                        L.ptr(v_sh), L.ptr(v_depths), st), "bds_sh_view_bwd")
+            if rows:
+                L.check(lib.bds_sh_view_bwd_rows(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col),
+                                                 L.ptr(v_sh), L.ptr(v_depths), int(rows == 2), st), "bds_sh_view_bwd_rows")
+            else:
+                L.check(lib.bds_sh_view_bwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col),
+                                            L.ptr(v_sh), L.ptr(v_depths), st), "bds_sh_view_bwd")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
         with L.timed("project_bwd"):
-            L.check(lib.bds_project_view_bwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat), W, H,
-                                             cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
-                                             L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), st), "bds_project_view_bwd")
+            if rows:
+                L.check(lib.bds_project_view_bwd_rows(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat),
+                                                      W, H, cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
+                                                      L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), int(rows == 2), st),
+                        "bds_project_view_bwd_rows")
+            else:
+                L.check(lib.bds_project_view_bwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat), W, H,
+                                                 cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
+                                                 L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), st), "bds_project_view_bwd")
+        if rows == 2:   # already added in place to what autograd holds as .grad: nothing to hand back
+            return (None, None, None, None, None, None, v_sky, *v_grids)
         return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, *v_grids)
 
 
@@ -213,7 +228,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
                grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
-               img_idx: Optional[int] = None):
+               img_idx: Optional[int] = None, arena_rows: int = 0):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
     [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
@@ -222,13 +237,17 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     ``grad_arena`` (optional): name -> preallocated tensor; the backward kernels write the parameter gradients
     straight into these (e.g. slices of the flat all-reduce buffer of ``dist.FlatGradients``) instead of fresh
     tensors, so that multi-GPU runs need no pack pass.  Valid when each parameter receives its gradient from
-    this node only (the reference's step: one view per iteration)."""
+    this node only (the reference's step: one view per iteration).
+    ``arena_rows`` (opt-in, needs all five per-Gaussian arena entries): 1 = the backward STORES only the rows of the Gaussians this view
+    sees -- the caller promises that every other row of the arena is zero (``dist.FlatGradients(sparse_rows=True).zero()`` keeps it so);
+    2 = it ADDS them to an arena that autograd already holds as the parameters' ``.grad`` (second and later views of a frame that
+    is exchanged once) and returns no gradient for those parameters."""
     if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds[..., :3, 3]); callers with fixed cameras cache it
         cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), viewmat=viewmat, K=K, cam_pos=cam_pos, factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena,
-               img_idx=None if img_idx is None else int(img_idx))
+               img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows))
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky, *gs)
     rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets = out

@@ -379,6 +379,23 @@ int bds_cubemap_bwd(int64_t n, int res, int channels, int width, const float *di
 int bds_color_correct_step(int64_t P, const float *cur_in, const float *ref, const float *warp, float eps, uint8_t *mask0,
                            float *cur_out, double *acc, bds_stream_t stream);
 
+/* ---- Gradient rows of the visible Gaussians only (opt-in: persistent or accumulating per-Gaussian gradient buffers) ----
+ * bds_sh_view_bwd / bds_project_view_bwd write every row of the dense gradient arrays -- zeros for the ~85 % of Gaussians a view
+ * culls.  The *_rows forms touch only the rows with radii > 0: accumulate = 0 stores them (the caller guarantees the other rows
+ * are already zero, see bds_view_grads_clear), accumulate = 1 adds to them (several views summed into one buffer before one
+ * exchange).  v_depths of bds_sh_view_bwd_rows stays dense.  Same arguments otherwise. */
+int bds_sh_view_bwd_rows(int64_t n, int K, int deg, const float *means, const float *cam_pos, const int32_t *radii,
+                         const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, int accumulate,
+                         bds_stream_t stream);
+int bds_project_view_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales, const float *opacities,
+                              const float *viewmat, const float *K, int W, int H, float eps2d, const int32_t *radii,
+                              const float *v_means2d, const float *v_depths, const float *v_conics, const float *v_opacities,
+                              float *v_means, float *v_quats, float *v_log_scales, float *v_logits, int accumulate,
+                              bds_stream_t stream);
+/* Zero the rows g with dirty[g] != 0 of the five per-Gaussian gradient arrays (v_sh is [n,K,3]). */
+int bds_view_grads_clear(int64_t n, int K, const uint8_t *dirty, float *v_means, float *v_quats, float *v_log_scales,
+                         float *v_logits, float *v_sh, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
