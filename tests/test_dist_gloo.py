@@ -181,3 +181,28 @@ def test_split_noise_is_rank0s_draw_on_every_rank():
     assert res[0][2] == (0, 3) and res[1][2] == (0, 3)
     from bilateral_driving_amd.dist import broadcast_randn      # no process group: plain randn
     assert broadcast_randn((2, 3), "cpu").shape == (2, 3)
+
+
+def test_sparse_rows_bookkeeping_single_process():
+    """FlatGradients(sparse_rows=True) on CPU tensors (the row-wise clear itself is a GPU kernel; here the dense fallback runs):
+    the state machine that decides when a producer may rely on an all-zero buffer."""
+    from bilateral_driving_amd.dist import FlatGradients
+    params = _make_params()
+    flat = FlatGradients(params, sparse_rows=True)
+    assert not flat.rows_clean                        # unknown until the first zero()
+    flat.mark_rows(torch.tensor([True] * 7))          # ignored while the state is unknown
+    assert flat._dirty is None
+    flat.zero()
+    assert flat.rows_clean and float(flat.flat.abs().sum()) == 0.0
+    a = torch.tensor([1, 0, 0, 1, 0, 0, 0], dtype=torch.bool)
+    b = torch.tensor([0, 0, 1, 1, 0, 0, 0], dtype=torch.bool)
+    flat.mark_rows(a)
+    assert not flat.rows_clean
+    flat.mark_rows(b)                                 # the views of a frame: marks accumulate
+    assert flat._dirty.tolist() == [1, 0, 1, 1, 0, 0, 0]
+    flat.flat.fill_(3.0)
+    flat.zero()
+    assert flat.rows_clean and flat._dirty is None and float(flat.flat.abs().sum()) == 0.0
+    dense = FlatGradients(_make_params())
+    dense.zero()
+    assert not dense.rows_clean                       # the default form never promises anything
