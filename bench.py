@@ -149,6 +149,17 @@ def main():
     if args.cpu_baseline_only:
         cpu_baseline_worker(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run on 127.0.0.1)
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,6 +186,8 @@ def main():
     L.lib()  # fail loudly if libbds.so is missing
     N, W, H = args.gaussians, args.width, args.height
     cams = Hn.ring_cameras(W, H, device=dev)
+    for cam in cams:   # the camera pose is learnable in the reference (trainers/base.py:328-329,399): its gradient stays live
+        cam.viewmat.requires_grad_(True)
     params = Hn.synthetic_scene(N, seed=0, device=dev)
     for v in params.values():
         v.requires_grad_(True)
@@ -194,6 +207,7 @@ def main():
         v = view_for_rank(s, rank, world, len(cams))
         flat.zero()
         skies[v].grad = None
+        cams[v].viewmat.grad = None
         out = Hn.render_view(params, cams[v], grids, v, skies[v], grad_arena=arena, arena_rows=1 if flat.rows_clean else 0)
         if world > 1:   # rows that can receive a gradient on this rank; the OR over the ranks runs behind the backward pass
             flat.begin_rows_union(out["info"]["radii"][0] > 0)

@@ -49,11 +49,11 @@ _SIGS = {
                                _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_project_view_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_project_view_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd_rows": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
-    "bds_project_view_bwd_rows": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_project_view_bwd_rows": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
@@ -120,7 +120,7 @@ def lib():
     return _lib
 
 
-OPT_RASTER_BWD, OPT_RADIX, OPT_RASTER_FWD, OPT_SHORT_SORT, OPT_ROW_ITEMS, OPT_PACKED = 0, 1, 2, 4, 5, 6
+OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
 
 
@@ -146,12 +146,24 @@ def stream(device=None):
 
 
 def require_gpu(*tensors):
+    """Every tensor lives on ONE GPU, and it is the current device: the kernels are enqueued on the current device's current
+    stream (``stream()``), so a tensor of another GPU would be touched from the wrong device's queue."""
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise BdsError(
                 "bilateral_driving_amd runs on MI355X only (tensor on %s); there is no CPU path "
                 "in the product -- the CPU restatement lives in oracle/ and is test infrastructure" % t.device
             )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise BdsError(f"tensors on different GPUs in one call ({dev} and {t.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise BdsError(f"tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                       "call torch.cuda.set_device (one process per GPU) before using bilateral_driving_amd")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -91,8 +91,8 @@ __device__ __forceinline__ float butterfly_sum16(const float *v, int lane) {
   return w;
 }
 
-// run-time selectable kernel variants (bds_set_option): A/B measurement and bisecting
-enum Option { kOptRasterBwd = 0, kOptRadix = 1, kOptRasterFwd = 2, kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptRowItems = 5, kOptPacked = 6, kOptCount = 8 };
+// test hooks (bds_set_option): force the large-input fallback paths of the tile stage; see include/bds.h
+enum Option { kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptPacked = 6, kOptCount = 8 };
 int option_get(int which);
 
 }  // namespace bds

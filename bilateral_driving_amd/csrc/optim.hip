@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *
 #pragma clang fp contract(off)  // torch evaluates these as separate element-wise operations
   auto upd = [&](float &pp, float gg, float &mm, float &vv) {
     if (weight_decay != 0.f) gg = gg + weight_decay * pp;
-    mm = mm + (gg - mm) * one_minus_b1;
+    // torch's lerp_(g, w): w < 0.5 ? m + w * (g - m) : g - (g - m) * (1 - w)   (w = 1 - beta1; the second branch is taken for beta1 <= 0.5)
+    mm = one_minus_b1 < 0.5f ? mm + one_minus_b1 * (gg - mm) : gg - (gg - mm) * (1.f - one_minus_b1);
     vv = vv * b2 + (one_minus_b2 * gg) * gg;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     pp = pp + (-step_size) * (mm / denom);

@@ -120,23 +120,49 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
   conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
 }
 
+// Block reduction of the camera-pose gradient (9 rotation + 3 translation partials per Gaussian): one 16-value
+// transpose-reduce per wave, the workgroup's waves summed through LDS, one atomic set per workgroup.
+__device__ __forceinline__ void pose_grad_reduce(const ProjGrad &pg, float (*red)[12], float *__restrict__ v_viewmat) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 9; i++) v[i] = pg.v_R[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) v[9 + i] = pg.v_t[i];
+  v[12] = v[13] = v[14] = v[15] = 0.f;
+  const float tot = butterfly_sum16(v, lane);
+  const int k = butterfly_slot(lane);
+  if ((lane & 3) == 0 && k < 12) red[wv][k] = tot;
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kProjBlock / kWave; w++) t += red[w][threadIdx.x];
+    const int i = threadIdx.x;
+    if (t != 0.f) atomicAdd(v_viewmat + (i < 9 ? (i / 3) * 4 + (i % 3) : (i - 9) * 4 + 3), t);
+  }
+}
+
+// v_viewmat (optional, [4,4], zero-filled by the entry point): gradient of the world->camera matrix -- the camera pose is a
+// learnable input of the reference's step (models/trainers/base.py:328-329 CamPose, :399 viewmats = inv(camtoworlds)).
+template <bool kPose>
 __global__ __launch_bounds__(kProjBlock) void project_view_bwd_kernel(
     int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
     float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
     const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
-    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits) {
+    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat) {
+  __shared__ float red[kProjBlock / kWave][12];
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
-  if (g >= N) return;
   float am[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, as[3] = {0, 0, 0}, al = 0.f;
-  if (radii[g] > 0) {
+  ProjGrad pg;
+  for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
+  for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
+  if (g < N && radii[g] > 0) {
     const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
     const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
     const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
     Camera cam = load_camera(viewmat, K);
-    ProjGrad pg;
-    for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
-    for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
     project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[g * 2], v_means2d[g * 2 + 1], v_depths[g], v_conics[g * 3],
                     v_conics[g * 3 + 1], v_conics[g * 3 + 2], pg);
     for (int i = 0; i < 3; i++) { am[i] = pg.v_mean[i]; as[i] = pg.v_scale[i] * s[i]; }
@@ -144,29 +170,25 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_kernel(
     const float o = opacities[g];
     al = v_opacities[g] * o * (1.f - o);
   }
-  for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = am[i]; v_log_scales[g * 3 + i] = as[i]; }
-  for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = aq[i];
-  v_logits[g] = al;
+  if (g < N) {
+    for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = am[i]; v_log_scales[g * 3 + i] = as[i]; }
+    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = aq[i];
+    v_logits[g] = al;
+  }
+  if (kPose) pose_grad_reduce(pg, red, v_viewmat);
 }
 
-// the same for the VISIBLE Gaussians only: rows of culled Gaussians are not touched (persistent gradient buffers kept zero by the
-// caller, or several views accumulated into one buffer: kAcc adds instead of storing) -- see sh_view_bwd_rows_kernel
 template <bool kAcc>
-__global__ __launch_bounds__(kProjBlock) void project_view_bwd_rows_kernel(
-    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+__device__ __forceinline__ void rows_body(
+    int64_t g, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
-    float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    float eps2d, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
     const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
-    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits) {
-  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
-  if (g >= N || radii[g] <= 0) return;
+    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, ProjGrad &pg) {
   const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
   const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
   const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
   Camera cam = load_camera(viewmat, K);
-  ProjGrad pg;
-  for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
-  for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
   project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[g * 2], v_means2d[g * 2 + 1], v_depths[g], v_conics[g * 3], v_conics[g * 3 + 1],
                   v_conics[g * 3 + 2], pg);
   const float o = opacities[g];
@@ -178,6 +200,25 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_rows_kernel(
   }
   for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = kAcc ? v_quats[g * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
   v_logits[g] = kAcc ? v_logits[g] + al : al;
+}
+
+// the same for the VISIBLE Gaussians only: rows of culled Gaussians are not touched (persistent gradient buffers kept zero by the
+// caller, or several views accumulated into one buffer: kAcc adds instead of storing) -- see sh_view_bwd_rows_kernel
+template <bool kAcc, bool kPose>
+__global__ __launch_bounds__(kProjBlock) void project_view_bwd_rows_kernel(
+    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
+    float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
+    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat) {
+  __shared__ float red[kProjBlock / kWave][12];
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  ProjGrad pg;
+  for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
+  for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
+  if (g < N && radii[g] > 0) rows_body<kAcc>(g, means, quats, scales, opacities, viewmat, K, W, H, eps2d, v_means2d, v_depths, v_conics,
+                                             v_opacities, v_means, v_quats, v_log_scales, v_logits, pg);
+  if (kPose) pose_grad_reduce(pg, red, v_viewmat);
 }
 
 }  // namespace bds
@@ -239,14 +280,19 @@ extern "C" int bds_project_view_bwd(int64_t N, const float *means, const float *
                                     const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
                                     const int32_t *radii, const float *v_means2d, const float *v_depths, const float *v_conics,
                                     const float *v_opacities, float *v_means, float *v_quats, float *v_log_scales,
-                                    float *v_logits, bds_stream_t stream) {
+                                    float *v_logits, float *v_viewmat, bds_stream_t stream) {
   BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
+  if (v_viewmat && hipMemsetAsync(v_viewmat, 0, sizeof(float) * 16, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
   if (N == 0) return BDS_OK;
   BDS_REQUIRE(means && quats && scales && opacities && viewmat && K && radii && v_means2d && v_depths && v_conics &&
               v_opacities && v_means && v_quats && v_log_scales && v_logits);
-  hipLaunchKernelGGL(project_view_bwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
-                     means, quats, scales, opacities, viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics,
-                     v_opacities, v_means, v_quats, v_log_scales, v_logits);
+  const dim3 grid((unsigned)cdiv(N, kProjBlock)), block(kProjBlock);
+  if (v_viewmat)
+    hipLaunchKernelGGL((project_view_bwd_kernel<true>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities, viewmat, K,
+                       W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits, v_viewmat);
+  else
+    hipLaunchKernelGGL((project_view_bwd_kernel<false>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities, viewmat, K,
+                       W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits, v_viewmat);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -255,18 +301,20 @@ extern "C" int bds_project_view_bwd_rows(int64_t N, const float *means, const fl
                                          const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
                                          const int32_t *radii, const float *v_means2d, const float *v_depths, const float *v_conics,
                                          const float *v_opacities, float *v_means, float *v_quats, float *v_log_scales,
-                                         float *v_logits, int accumulate, bds_stream_t stream) {
+                                         float *v_logits, float *v_viewmat, int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
+  if (v_viewmat && hipMemsetAsync(v_viewmat, 0, sizeof(float) * 16, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
   if (N == 0) return BDS_OK;
   BDS_REQUIRE(means && quats && scales && opacities && viewmat && K && radii && v_means2d && v_depths && v_conics &&
               v_opacities && v_means && v_quats && v_log_scales && v_logits);
   const dim3 grid((unsigned)cdiv(N, kProjBlock)), block(kProjBlock);
-  if (accumulate)
-    hipLaunchKernelGGL((project_view_bwd_rows_kernel<true>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities,
-                       viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits);
-  else
-    hipLaunchKernelGGL((project_view_bwd_rows_kernel<false>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities,
-                       viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits);
+#define BDS_ROWS(A, P)                                                                                                               \
+  hipLaunchKernelGGL((project_view_bwd_rows_kernel<A, P>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities,   \
+                     viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales,     \
+                     v_logits, v_viewmat)
+  if (accumulate) { if (v_viewmat) BDS_ROWS(true, true); else BDS_ROWS(true, false); }
+  else            { if (v_viewmat) BDS_ROWS(false, true); else BDS_ROWS(false, false); }
+#undef BDS_ROWS
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

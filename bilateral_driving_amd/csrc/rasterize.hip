@@ -3,13 +3,12 @@
 // /root/reference/project/models/trainers/base.py:393-408 (render_mode "RGB+ED" -> CH = 4,
 // viewer "RGB" -> CH = 3).
 //
-// Mapping (gfx950): one workgroup of 256 threads = four wave64 per 16x16 tile; wave w owns the
-// 16x4 pixel strip of rows 4w..4w+3, so image rows are written as 64-byte coalesced segments.
-// The tile's depth-ordered Gaussians are staged through LDS in chunks of 256 (one gathered
-// Gaussian per thread), then every lane walks the chunk reading LDS at a wave-uniform address
-// (broadcast reads).  Early termination: a lane stops at T*(1-a) <= 1e-4, a wave skips the rest
-// of a chunk once all 64 lanes are done (ballot), the workgroup stops fetching once all four
-// waves are done.  Workgroup ids are remapped so that each XCD rasterises one contiguous band of
+// Mapping (gfx950): ONE wave64 per 16x16 tile, four pixels per lane (lane l: column l % 16, rows
+// l / 16 + 4q): the tile's depth-ordered Gaussians are staged through LDS in chunks of 64 (one gathered
+// Gaussian per lane, next chunk prefetched into registers), then every lane walks the chunk reading LDS
+// at a wave-uniform address (broadcast reads); dx and the x-terms of the quadratic form are shared by the
+// lane's four pixels.  Early termination: a pixel stops at T*(1-a) <= 1e-4, the wave leaves once all its
+// pixels are done (ballot).  Workgroup ids are remapped so that each XCD rasterises one contiguous band of
 // the image (its private L2 then serves the re-reads of Gaussians shared by neighbouring tiles).
 #include "bds_common.h"
 #include "gs_math.h"
@@ -62,70 +61,6 @@ __device__ __forceinline__ void stage_gaussian(int32_t g, const float *__restric
   A = make_float4(xy.x, xy.y, cn[0], cn[1]);
   B = make_float4(cn[2], opacities[g], cl[0], CH > 1 ? cl[CH > 1 ? 1 : 0] : 0.f);
   Cc = make_float4(CH > 2 ? cl[CH > 2 ? 2 : 0] : 0.f, CH > 3 ? cl[CH > 3 ? 3 : 0] : 0.f, 0.f, 0.f);
-}
-
-template <int CH>
-__global__ __launch_bounds__(kRastBlock) void rasterize_fwd_kernel(
-    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
-    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
-  __shared__ float4 sA[kRastBlock], sB[kRastBlock], sC[kRastBlock];
-  const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
-  const int cam = item / n_tiles, tile = item - cam * n_tiles;
-  const int ty = tile / tile_w, tx = tile - ty * tile_w;
-  const int tid = threadIdx.x;
-  const int i = ty * kTile + tid / kTile, j = tx * kTile + tid % kTile;
-  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  const bool inside = i < H && j < W;
-  bool done = !inside;
-  const int start = offsets[item];
-  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
-  const int nbatch = (end - start + kRastBlock - 1) / kRastBlock;
-  float T = 1.f;
-  int cur = 0;
-  float out[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < nbatch; b++) {
-    if (__syncthreads_and(done)) break;
-    const int bstart = start + b * kRastBlock;
-    if (bstart + tid < end) {
-      float4 A, B, Cc;
-      stage_gaussian<CH>(flatten_ids[bstart + tid], means2d, conics, colors, opacities, A, B, Cc);
-      sA[tid] = A; sB[tid] = B;
-      if (CH > 2) sC[tid] = Cc;
-    }
-    __syncthreads();
-    if (__all(done)) continue;  // this wave is finished; it only keeps helping with the staging
-    const int bs = min(kRastBlock, end - bstart);
-    for (int t = 0; t < bs && !done; t++) {
-      const float4 A = sA[t], B = sB[t];
-      const float dx = A.x - px, dy = A.y - py;
-      const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-      const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
-      if (sigma < 0.f || alpha < kAlphaMin) continue;
-      const float nT = T * (1.f - alpha);
-      if (nT <= kTStop) { done = true; break; }
-      const float vis = alpha * T;
-      out[0] += B.z * vis;
-      if (CH > 1) out[1] += B.w * vis;
-      if (CH > 2) {
-        const float4 Cc = sC[t];
-        out[2] += Cc.x * vis;
-        if (CH > 3) out[3] += Cc.y * vis;
-      }
-      cur = bstart + t;
-      T = nT;
-    }
-  }
-  if (inside) {
-    const int64_t pix = ((int64_t)cam * H + i) * W + j;
-    alphas[pix] = 1.f - T;
-    last_ids[pix] = cur;
-    float *r = render + pix * CH;
-#pragma unroll
-    for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[k] + T * backgrounds[cam * CH + k] : out[k];
-  }
 }
 
 // ---- forward, one wave64 per 16x16 tile, four pixels per lane ------------------------------------
@@ -214,247 +149,6 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       float *r = render + pix * CH;
 #pragma unroll
       for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + Tf * backgrounds[cam * CH + k] : out[q][k];
-    }
-  }
-}
-
-// ---- quadrant-masked wave kernels ---------------------------------------------------------------------
-// One wave64 per 16x16 tile; lane l owns pixel (l % 8, l / 8) of EACH of the tile's four 8x8 quadrants.
-// When a Gaussian is staged, its lane also computes which quadrants the alpha >= 1/255 ellipse can reach
-// (64 Gaussians tested in parallel, the same conservative test as the tile culling); the blend loop then
-// touches only those quadrants.  After tile culling most (tile, Gaussian) pairs clip one or two quadrants,
-// so the per-pair VALU work roughly halves and the lanes that do run are denser (8x8 blocks, not 16x4 strips).
-__device__ __forceinline__ int quadrant_mask(const float4 &A, const float4 &B, int x0, int y0) {
-  const float tau = cull_tau(B.y);
-  const float a = A.z, b = A.w, c = B.x;
-  if (!(tau > 0.f)) return 0;                                           // opacity < 1/255: alpha < 1/255 everywhere
-  if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return 0xF;   // degenerate conic: no pruning
-  const float q_max = 2.f * tau;
-  int m = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float fx = (float)(x0 + 8 * (q & 1)), fy = (float)(y0 + 8 * (q >> 1));
-    if (rect_hits_ellipse(A.x, A.y, a, b, c, q_max, fx + 0.5f, fy + 0.5f, fx + 7.5f, fy + 7.5f)) m |= 1 << q;
-  }
-  return m;
-}
-
-template <int CH>
-__global__ __launch_bounds__(kWave) void rasterize_fwd_quad_kernel(
-    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
-    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  __shared__ int sM[kWave];
-  const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
-  const int cam = item / n_tiles, tile = item - cam * n_tiles;
-  const int ty = tile / tile_w, tx = tile - ty * tile_w;
-  const int lane = threadIdx.x;
-  const int x0 = tx * kTile, y0 = ty * kTile;
-  const int start = offsets[item];
-  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
-  float pxq[4], pyq[4];
-  bool done[4];
-  float T[4] = {1.f, 1.f, 1.f, 1.f};
-  int cur[4] = {0, 0, 0, 0};
-  float out[4][4];
-  int live = 0;  // quadrants that still have an unfinished pixel (wave-uniform)
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int j = x0 + 8 * (q & 1) + (lane & 7), i = y0 + 8 * (q >> 1) + (lane >> 3);
-    pxq[q] = (float)j + 0.5f; pyq[q] = (float)i + 0.5f;
-    done[q] = !(i < H && j < W);
-    if (!__all(done[q])) live |= 1 << q;
-#pragma unroll
-    for (int k = 0; k < 4; k++) out[q][k] = 0.f;
-  }
-  const int nbatch = (end - start + kWave - 1) / kWave;
-  for (int b = 0; b < nbatch && live; b++) {
-    __syncthreads();
-    const int bstart = start + b * kWave;
-    if (bstart + lane < end) {
-      float4 A, B, Cc;
-      stage_gaussian<CH>(flatten_ids[bstart + lane], means2d, conics, colors, opacities, A, B, Cc);
-      sA[lane] = A; sB[lane] = B;
-      if (CH > 2) sC[lane] = Cc;
-      sM[lane] = quadrant_mask(A, B, x0, y0);
-    }
-    __syncthreads();
-    const int bs = min(kWave, end - bstart);
-    for (int t = 0; t < bs && live; t++) {
-      const int mask = __builtin_amdgcn_readfirstlane(sM[t]) & live;
-      if (mask == 0) continue;
-      const float4 A = sA[t], B = sB[t];
-      float4 Cc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (CH > 2) Cc = sC[t];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (!(mask & (1 << q))) continue;  // wave-uniform
-        const float dx = A.x - pxq[q], dy = A.y - pyq[q];
-        const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-        const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
-        const bool hit = !done[q] && !(sigma < 0.f || alpha < kAlphaMin);
-        const float nT = T[q] * (1.f - alpha);
-        if (hit && nT <= kTStop) done[q] = true;
-        else if (hit) {
-          const float vis = alpha * T[q];
-          out[q][0] += B.z * vis;
-          if (CH > 1) out[q][1] += B.w * vis;
-          if (CH > 2) out[q][2] += Cc.x * vis;
-          if (CH > 3) out[q][3] += Cc.y * vis;
-          cur[q] = bstart + t;
-          T[q] = nT;
-        }
-        if (__all(done[q])) live &= ~(1 << q);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int j = x0 + 8 * (q & 1) + (lane & 7), i = y0 + 8 * (q >> 1) + (lane >> 3);
-    if (i < H && j < W) {
-      const int64_t pix = ((int64_t)cam * H + i) * W + j;
-      alphas[pix] = 1.f - T[q];
-      last_ids[pix] = cur[q];
-      float *r = render + pix * CH;
-#pragma unroll
-      for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + T[q] * backgrounds[cam * CH + k] : out[q][k];
-    }
-  }
-}
-
-// REDUCE = 0: one DPP wave-reduction per gradient value, 13 single-lane atomics per (Gaussian, wave)
-// REDUCE = 1: 16-value transpose-reduce (butterfly_sum16), one 12-lane atomic instruction
-template <int CH, bool ABS, int REDUCE>
-__global__ __launch_bounds__(kRastBlock) void rasterize_bwd_kernel(
-    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
-    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
-    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
-    const int32_t *__restrict__ tile_order) {
-  __shared__ float4 sA[kRastBlock], sB[kRastBlock], sC[kRastBlock];
-  __shared__ int32_t sId[kRastBlock];
-  const int n_tiles = tile_w * tile_h;
-  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
-  const int cam = item / n_tiles, tile = item - cam * n_tiles;
-  const int ty = tile / tile_w, tx = tile - ty * tile_w;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int i = ty * kTile + tid / kTile, j = tx * kTile + tid % kTile;
-  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  const bool inside = i < H && j < W;
-  const int start = offsets[item];
-  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
-  if (end <= start) return;  // uniform
-  const int nbatch = (end - start + kRastBlock - 1) / kRastBlock;
-  const int64_t pix = ((int64_t)cam * H + (inside ? i : 0)) * W + (inside ? j : 0);
-  const float T_final = inside ? 1.f - alphas[pix] : 1.f;
-  float T = T_final;
-  float buffer[4] = {0.f, 0.f, 0.f, 0.f};
-  const int bin_final = inside ? last_ids[pix] : 0;
-  float vr[4] = {0.f, 0.f, 0.f, 0.f};
-  float vra = 0.f;
-  if (inside) {
-#pragma unroll
-    for (int k = 0; k < CH; k++) vr[k] = v_render[pix * CH + k];
-    vra = v_alphas[pix];
-  }
-  float bgdot = 0.f;  // sum_k bg[k] * v_render[k]
-  if (backgrounds) {
-#pragma unroll
-    for (int k = 0; k < CH; k++) bgdot += backgrounds[cam * CH + k] * vr[k];
-  }
-  const int wave_bin_final = wave_max_i32(bin_final);
-  const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
-  for (int b = 0; b < nbatch; b++) {
-    __syncthreads();
-    const int batch_end = end - 1 - kRastBlock * b;
-    const int bs = min(kRastBlock, batch_end + 1 - start);
-    const int idx = batch_end - tid;
-    if (idx >= start) {
-      const int32_t g = flatten_ids[idx];
-      float4 A, B, Cc;
-      stage_gaussian<CH>(g, means2d, conics, colors, opacities, A, B, Cc);
-      sId[tid] = g; sA[tid] = A; sB[tid] = B;
-      if (CH > 2) sC[tid] = Cc;
-    }
-    __syncthreads();
-    for (int t = max(0, batch_end - wave_bin_final); t < bs; t++) {
-      bool valid = inside && (batch_end - t <= bin_final);
-      const float4 A = sA[t], B = sB[t];
-      const float dx = A.x - px, dy = A.y - py;
-      const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-      const float vis = __expf(-sigma);
-      const float opac = B.y;
-      const float alpha = fminf(kAlphaMax, opac * vis);
-      if (sigma < 0.f || alpha < kAlphaMin) valid = false;
-      if (!__any(valid)) continue;
-      float col[4] = {B.z, B.w, 0.f, 0.f};
-      if (CH > 2) { const float4 Cc = sC[t]; col[2] = Cc.x; col[3] = Cc.y; }
-      float g_col[4] = {0.f, 0.f, 0.f, 0.f};
-      float g_conic[3] = {0.f, 0.f, 0.f};
-      float g_xy[2] = {0.f, 0.f}, g_xy_abs[2] = {0.f, 0.f};
-      float g_opac = 0.f;
-      if (valid) {
-        const float ra = 1.f / (1.f - alpha);
-        T *= ra;
-        const float fac = alpha * T;
-        float v_alpha = 0.f;
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          g_col[k] = fac * vr[k];
-          v_alpha += (col[k] * T - buffer[k] * ra) * vr[k];
-        }
-        v_alpha += T_final * ra * vra;
-        if (backgrounds) v_alpha += -T_final * ra * bgdot;
-        if (opac * vis <= kAlphaMax) {
-          const float v_sigma = -opac * vis * v_alpha;
-          g_conic[0] = 0.5f * v_sigma * dx * dx;
-          g_conic[1] = v_sigma * dx * dy;
-          g_conic[2] = 0.5f * v_sigma * dy * dy;
-          g_xy[0] = v_sigma * (A.z * dx + A.w * dy);
-          g_xy[1] = v_sigma * (A.w * dx + B.x * dy);
-          if (ABS) { g_xy_abs[0] = fabsf(g_xy[0]); g_xy_abs[1] = fabsf(g_xy[1]); }
-          g_opac = vis * v_alpha;
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) buffer[k] += col[k] * fac;
-      }
-      if (REDUCE == 1) {
-        float v[16] = {g_col[0], g_col[1], g_col[2], g_col[3], g_conic[0], g_conic[1], g_conic[2], g_xy[0], g_xy[1],
-                       g_xy_abs[0], g_xy_abs[1], g_opac, 0.f, 0.f, 0.f, 0.f};
-        const float tot = butterfly_sum16(v, lane);
-        if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
-        continue;
-      }
-      // wave64 reduction (DPP), then one atomic per value per wave
-#pragma unroll
-      for (int k = 0; k < CH; k++) g_col[k] = wave_sum_to_lane63(g_col[k]);
-      g_conic[0] = wave_sum_to_lane63(g_conic[0]);
-      g_conic[1] = wave_sum_to_lane63(g_conic[1]);
-      g_conic[2] = wave_sum_to_lane63(g_conic[2]);
-      g_xy[0] = wave_sum_to_lane63(g_xy[0]);
-      g_xy[1] = wave_sum_to_lane63(g_xy[1]);
-      if (ABS) { g_xy_abs[0] = wave_sum_to_lane63(g_xy_abs[0]); g_xy_abs[1] = wave_sum_to_lane63(g_xy_abs[1]); }
-      g_opac = wave_sum_to_lane63(g_opac);
-      if (lane == kWave - 1) {
-        const int64_t g = sId[t];
-#pragma unroll
-        for (int k = 0; k < CH; k++) atomicAdd(v_colors + g * CH + k, g_col[k]);
-        atomicAdd(v_conics + g * 3, g_conic[0]);
-        atomicAdd(v_conics + g * 3 + 1, g_conic[1]);
-        atomicAdd(v_conics + g * 3 + 2, g_conic[2]);
-        atomicAdd(v_means2d + g * 2, g_xy[0]);
-        atomicAdd(v_means2d + g * 2 + 1, g_xy[1]);
-        if (ABS) {
-          atomicAdd(v_means2d_abs + g * 2, g_xy_abs[0]);
-          atomicAdd(v_means2d_abs + g * 2 + 1, g_xy_abs[1]);
-        }
-        atomicAdd(v_opacities + g, g_opac);
-      }
     }
   }
 }
@@ -600,129 +294,6 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   }
 }
 
-
-// ---- backward, quadrant-masked (see rasterize_fwd_quad_kernel) -----------------------------------------
-template <int CH, bool ABS>
-__global__ __launch_bounds__(kWave) void rasterize_bwd_quad_kernel(
-    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
-    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
-    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
-    const int32_t *__restrict__ tile_order) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  __shared__ int32_t sId[kWave];
-  __shared__ int sM[kWave];
-  const int n_tiles = tile_w * tile_h;
-  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
-  const int cam = item / n_tiles, tile = item - cam * n_tiles;
-  const int ty = tile / tile_w, tx = tile - ty * tile_w;
-  const int lane = threadIdx.x;
-  const int start = offsets[item];
-  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
-  if (end <= start) return;
-  const int x0 = tx * kTile, y0 = ty * kTile;
-  bool inside[4];
-  float pxq[4], pyq[4], T[4], T_final[4], vra[4], buffer[4][4], vr[4][4], bgdot[4];
-  int bin_final[4], qmax[4];
-  int tile_bin_final = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int j = x0 + 8 * (q & 1) + (lane & 7), i = y0 + 8 * (q >> 1) + (lane >> 3);
-    pxq[q] = (float)j + 0.5f; pyq[q] = (float)i + 0.5f;
-    inside[q] = i < H && j < W;
-    const int64_t pix = ((int64_t)cam * H + (inside[q] ? i : 0)) * W + (inside[q] ? j : 0);
-    T_final[q] = inside[q] ? 1.f - alphas[pix] : 1.f;
-    T[q] = T_final[q];
-    bin_final[q] = inside[q] ? last_ids[pix] : 0;
-    qmax[q] = wave_max_i32(bin_final[q]);   // deepest Gaussian any pixel of this quadrant blended
-    tile_bin_final = max(tile_bin_final, qmax[q]);
-    vra[q] = inside[q] ? v_alphas[pix] : 0.f;
-    bgdot[q] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      buffer[q][k] = 0.f;
-      vr[q][k] = (k < CH && inside[q]) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
-      if (backgrounds && k < CH) bgdot[q] += backgrounds[cam * CH + k] * vr[q][k];
-    }
-  }
-  const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
-  const int nbatch = (end - start + kWave - 1) / kWave;
-  const int b0 = (end - 1 - tile_bin_final) / kWave;
-  for (int b = b0; b < nbatch; b++) {
-    const int batch_end = end - 1 - kWave * b;
-    __syncthreads();
-    const int bs = min(kWave, batch_end + 1 - start);
-    const int idx = batch_end - lane;
-    if (idx >= start) {
-      const int32_t g = flatten_ids[idx];
-      float4 A, B, Cc;
-      stage_gaussian<CH>(g, means2d, conics, colors, opacities, A, B, Cc);
-      sId[lane] = g; sA[lane] = A; sB[lane] = B;
-      if (CH > 2) sC[lane] = Cc;
-      sM[lane] = quadrant_mask(A, B, x0, y0);
-    }
-    __syncthreads();
-    for (int t = max(0, batch_end - tile_bin_final); t < bs; t++) {
-      const int gidx = batch_end - t;  // position of this Gaussian in the tile's list
-      int mask = __builtin_amdgcn_readfirstlane(sM[t]);
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (gidx > qmax[q]) mask &= ~(1 << q);
-      if (mask == 0) continue;
-      const float4 A = sA[t], B = sB[t];
-      const float opac = B.y;
-      float col[4] = {B.z, B.w, 0.f, 0.f};
-      if (CH > 2) { const float4 Cc = sC[t]; col[2] = Cc.x; col[3] = Cc.y; }
-      float acc[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) acc[k] = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (!(mask & (1 << q))) continue;  // wave-uniform
-        const float dx = A.x - pxq[q], dy = A.y - pyq[q];
-        const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-        const float vis = __expf(-sigma);
-        const float alpha = fminf(kAlphaMax, opac * vis);
-        const bool valid = inside[q] && (gidx <= bin_final[q]) && !(sigma < 0.f || alpha < kAlphaMin);
-        if (!__any(valid)) continue;
-        any = true;
-        if (valid) {
-          const float ra = 1.f / (1.f - alpha);
-          T[q] *= ra;
-          const float fac = alpha * T[q];
-          float v_alpha = 0.f;
-#pragma unroll
-          for (int k = 0; k < CH; k++) {
-            acc[k] += fac * vr[q][k];
-            v_alpha += (col[k] * T[q] - buffer[q][k] * ra) * vr[q][k];
-          }
-          v_alpha += T_final[q] * ra * vra[q];
-          if (backgrounds) v_alpha += -T_final[q] * ra * bgdot[q];
-          if (opac * vis <= kAlphaMax) {
-            const float v_sigma = -opac * vis * v_alpha;
-            acc[4] += 0.5f * v_sigma * dx * dx;
-            acc[5] += v_sigma * dx * dy;
-            acc[6] += 0.5f * v_sigma * dy * dy;
-            const float gx = v_sigma * (A.z * dx + A.w * dy);
-            const float gy = v_sigma * (A.w * dx + B.x * dy);
-            acc[7] += gx; acc[8] += gy;
-            if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
-            acc[11] += vis * v_alpha;
-          }
-#pragma unroll
-          for (int k = 0; k < CH; k++) buffer[q][k] += col[k] * fac;
-        }
-      }
-      if (!any) continue;
-      const float tot = butterfly_sum16(acc, lane);
-      if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
-    }
-  }
-}
-
 // ---- backward schedule: longest tile first inside each XCD's range ------------------------------------
 // One wave per tile finishes when its LAST pixel does, and the chip holds only ~2 rounds of tiles
 // (8160 tiles at 1080p over 1024 SIMDs x 4 resident waves), so tiles dispatched late that happen to be long
@@ -807,20 +378,12 @@ extern "C" int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const floa
   BDS_REQUIRE(isect_offsets && render && alphas && last_ids);
   BDS_REQUIRE(M == 0 || (means2d && conics && colors && opacities && flatten_ids));
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
-  const dim3 grid((unsigned)(C * tile_w * tile_h)), block(kRastBlock);
+  const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
 #define BDS_FWD_ARGS                                                                                                   \
   C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, render,  \
       alphas, last_ids
-#define BDS_FWD(ch)                                                                                                    \
-  do {                                                                                                                 \
-    if (bds::option_get(bds::kOptRasterFwd) == 2)                                                                      \
-      hipLaunchKernelGGL((rasterize_fwd_quad_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS);                     \
-    else if (bds::option_get(bds::kOptRasterFwd) == 1)                                                                 \
-      hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS);                     \
-    else                                                                                                               \
-      hipLaunchKernelGGL((rasterize_fwd_kernel<ch>), grid, block, 0, st, BDS_FWD_ARGS);                                \
-  } while (0)
+#define BDS_FWD(ch) hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS)
   if (CH == 1) BDS_FWD(1);
   else if (CH == 3) BDS_FWD(3);
   else BDS_FWD(4);
@@ -845,23 +408,12 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
   BDS_REQUIRE(means2d && conics && colors && opacities && isect_offsets && flatten_ids && alphas && last_ids &&
               v_render && v_alphas && v_means2d && v_conics && v_colors && v_opacities);
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
-  const dim3 grid((unsigned)(C * tile_w * tile_h)), block(kRastBlock);
+  const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
-  const int variant = bds::option_get(bds::kOptRasterBwd);
 #define BDS_BWD_ARGS                                                                                                   \
   C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, alphas,  \
       last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, tile_order
-#define BDS_BWD(ch, ab)                                                                                                \
-  do {                                                                                                                 \
-    if (variant == 3)                                                                                                  \
-      hipLaunchKernelGGL((rasterize_bwd_quad_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS);                 \
-    else if (variant == 2)                                                                                             \
-      hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS);                 \
-    else if (variant == 1)                                                                                             \
-      hipLaunchKernelGGL((rasterize_bwd_kernel<ch, ab, 1>), grid, block, 0, st, BDS_BWD_ARGS);                         \
-    else                                                                                                               \
-      hipLaunchKernelGGL((rasterize_bwd_kernel<ch, ab, 0>), grid, block, 0, st, BDS_BWD_ARGS);                         \
-  } while (0)
+#define BDS_BWD(ch, ab) hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS)
   if (v_means2d_abs) {
     if (CH == 1) BDS_BWD(1, true);
     else if (CH == 3) BDS_BWD(3, true);

@@ -186,120 +186,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *
   if (threadIdx.x <= mask) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
-    const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
-    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
-  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
-  if ((int64_t)blockIdx.x * kSortChunk >= n) return;  // launch is sized for the host-side bound
-  __shared__ uint32_t run[256];               // global position of the next element of each digit
-  __shared__ uint32_t wcnt[kSortWaves][256];  // per-wave digit counts of the current round
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-  run[tid] = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
-#pragma unroll
-  for (int w = 0; w < kSortWaves; w++) wcnt[w][tid] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
-  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int r = 0; r < kSortRounds; r++) {
-    const int64_t i = base + r * kSortBlock + tid;
-    if (base + r * kSortBlock >= n) break;  // uniform
-    const bool on = i < n;
-    uint32_t k = 0, v = 0, d = 0;
-    if (on) { k = keys_in[i]; v = vals_in[i]; d = (k >> shift) & mask; }
-    // lanes of this wave holding the same digit
-    unsigned long long peers = __ballot(on);
-    for (int b = 0; b < bits; b++) {
-      unsigned long long bal = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? bal : ~bal;
-    }
-    const uint32_t rank = __popcll(peers & lt);
-    if (on && rank == 0) wcnt[wv][d] = __popcll(peers);
-    __syncthreads();
-    if (on) {
-      uint32_t off = run[d] + rank;
-      for (int w = 0; w < kSortWaves; w++)
-        if (w < wv) off += wcnt[w][d];
-      keys_out[off] = k;
-      vals_out[off] = v;
-    }
-    __syncthreads();
-    {
-      uint32_t s = 0;
-#pragma unroll
-      for (int w = 0; w < kSortWaves; w++) { s += wcnt[w][tid]; wcnt[w][tid] = 0; }
-      run[tid] += s;
-    }
-    __syncthreads();
-  }
-}
-
-// Variant 1: wave-private ranking.  Each wave owns a contiguous quarter of the workgroup's chunk and
-// ranks it without any cross-wave traffic: after one LDS histogram + prefix over (wave, digit) the
-// four waves run their 16 rounds back to back with NO barriers (the block-synchronous variant needs
-// three per round).  Stable: global position = scanned block base + elements of earlier waves
-// + elements of earlier rounds of this wave + rank among the lanes of this round.
-__global__ __launch_bounds__(kSortBlock) void radix_scatter_wave_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
-    const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
-    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
-  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
-  if ((int64_t)blockIdx.x * kSortChunk >= n) return;  // launch is sized for the host-side bound
-  __shared__ uint32_t wrun[kSortWaves][256];  // next output position per (wave, digit)
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-#pragma unroll
-  for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
-  __syncthreads();
-  constexpr int kPerWave = kSortChunk / kSortWaves;  // 1024 consecutive elements per wave
-  const int64_t wbase = (int64_t)blockIdx.x * kSortChunk + (int64_t)wv * kPerWave;
-  uint32_t k[kSortRounds], v[kSortRounds];
-#pragma unroll
-  for (int r = 0; r < kSortRounds; r++) {
-    const int64_t i = wbase + r * kWave + lane;
-    k[r] = 0xFFFFFFFFu; v[r] = 0;
-    if (i < n) {
-      k[r] = keys_in[i]; v[r] = vals_in[i];
-      atomicAdd(&wrun[wv][(k[r] >> shift) & mask], 1u);
-    }
-  }
-  __syncthreads();
-  {  // digit `tid`: exclusive prefix over the waves, on top of the block's scanned base
-    uint32_t base = tid <= (int)mask ? hist_scanned[(int64_t)tid * nblocks + blockIdx.x] : 0u;
-#pragma unroll
-    for (int w = 0; w < kSortWaves; w++) {
-      const uint32_t c = wrun[w][tid];
-      wrun[w][tid] = base;
-      base += c;
-    }
-  }
-  __syncthreads();
-  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-  for (int r = 0; r < kSortRounds; r++) {
-    const int64_t i = wbase + r * kWave + lane;
-    const bool on = i < n;
-    const uint32_t d = (k[r] >> shift) & mask;
-    unsigned long long peers = __ballot(on);
-    for (int b = 0; b < bits; b++) {
-      const unsigned long long bal = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? bal : ~bal;
-    }
-    const uint32_t rank = __popcll(peers & lt);
-    uint32_t pos = 0;
-    if (on) pos = wrun[wv][d];                                  // every peer reads the same slot ...
-    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): reads landed before the update
-    __builtin_amdgcn_wave_barrier();
-    if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);   // ... then the group's first lane bumps it
-    __builtin_amdgcn_wave_barrier();
-    if (on) {
-      keys_out[pos + rank] = k[r];
-      vals_out[pos + rank] = v[r];
-    }
-  }
-}
-
-
-// Variant 2: wave-private ranking as above, but the workgroup's 4096 pairs are first ordered by digit in LDS and then
+// Scatter with wave-private ranking: each wave owns a contiguous quarter of the workgroup's chunk and ranks it without
+// cross-wave traffic (one LDS histogram + prefix over (wave, digit), then 16 rounds with NO barriers: ballot match).
+// Stable: position = scanned block base + elements of earlier waves + earlier rounds of this wave + rank in the round.
+// The workgroup's 4096 pairs are first ordered by digit in LDS and then
 // written out by consecutive threads: a digit's run leaves as whole cache lines (4096 / 2^bits pairs at a time)
 // instead of the 8-pair fragments of one wave round.  Pays on the long tile passes, where the scatter is write-bound.
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
@@ -473,15 +363,8 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
-  if (option_get(kOptRadix) == 2)
-    hipLaunchKernelGGL(radix_scatter_lds_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, kout, vout);
-  else if (option_get(kOptRadix) == 1)
-    hipLaunchKernelGGL(radix_scatter_wave_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, kout, vout);
-  else
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, kout, vout);
+  hipLaunchKernelGGL(radix_scatter_lds_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, vin, n, n_dev, shift, mask, bits,
+                     nblocks, hist, kout, vout);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -542,7 +425,7 @@ __global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *
   if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kGroupShift) * 256 + threadIdx.x], c);
 }
 
-// wave-private ranking as in radix_scatter_wave_kernel; bases from the group / workgroup rows
+// wave-private ranking as in radix_scatter_lds_kernel; bases from the group / workgroup rows
 __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
@@ -717,54 +600,6 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_vis_out = (uint64_t)my_offset + tot;
 }
 
-// tiles touched by each visible entry, visited in depth order: cnt_sorted[j] feeds the scan that places every
-// entry's run of intersections (zero beyond the visible count), tiles_per_gauss[o] (optional, pre-zeroed) is the API output.
-// (also leaves the per-member record the row-item emission reads: see stage_rows)
-__global__ __launch_bounds__(kIsectBlock) void isect_count_sorted_kernel(
-    int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
-    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
-    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
-    float4 *__restrict__ rec, uint32_t *__restrict__ btot, uint64_t *__restrict__ m_total) {
-  __shared__ uint32_t lw[kIsectBlock / kWave + 1];
-  const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  int cnt = 0;
-  if (j < CN && j < (int64_t)*n_vis_dev) {
-    const int64_t o = sorted_idx[j];
-    const int r = radii[o];
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    uint32_t nrows = 0;
-    float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
-    const float mx = means2d[o * 2], my = means2d[o * 2 + 1];
-    if (conics == nullptr) {
-      tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
-      cnt = (x1 - x0) * (y1 - y0);
-      if (x1 > x0 && y1 > y0) nrows = (uint32_t)(y1 - y0);
-    } else {
-      a = conics[o * 3]; b = conics[o * 3 + 1]; c = conics[o * 3 + 2];
-      if (tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) {
-        nrows = (uint32_t)(y1 - y0);
-        for (int ty = y0; ty < y1; ty++) {
-          int lo, hi;
-          row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
-          cnt += hi - lo;
-        }
-      }
-    }
-    if (tiles_per_gauss) tiles_per_gauss[o] = cnt;
-    const uint32_t cam_base = (uint32_t)(o / N) * (uint32_t)(tile_w * tile_h);
-    rec[j * 3] = make_float4(mx, my, a, b);
-    rec[j * 3 + 1] = make_float4(c, q_max, __int_as_float(x0), __int_as_float(x1));
-    rec[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float((uint32_t)o), __uint_as_float(cam_base));
-  }
-  if (j < CN) cnt_sorted[j] = (uint32_t)cnt;
-  uint32_t total;
-  block_excl_scan((uint32_t)cnt, total, lw);
-  if (threadIdx.x == 0) {
-    btot[blockIdx.x] = total;
-    if (total) atomicAdd(reinterpret_cast<unsigned long long *>(m_total), (unsigned long long)total);
-  }
-}
-
 // ---- row-parallel counting / emission ---------------------------------------------------------------------
 // One thread per Gaussian leaves most lanes idle: the tile rectangles of 64 depth-neighbours differ by an order of
 // magnitude in size and the wave runs as long as its largest member (rows x tiles, serially).  Here a workgroup still
@@ -935,49 +770,6 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
   }
 }
 
-// emit (camera*tiles + tile, cam*N+gaussian) pairs in depth order (one thread per Gaussian; option 5 = 0)
-__global__ __launch_bounds__(kIsectBlock) void isect_emit_kernel(const uint64_t *__restrict__ n_vis_dev, int64_t N,
-                                                                const uint32_t *__restrict__ sorted_idx,
-                                                                const uint32_t *__restrict__ cum_sorted,
-                                                                const float *__restrict__ means2d,
-                                                                const int32_t *__restrict__ radii,
-                                                                const float *__restrict__ conics,
-                                                                const float *__restrict__ opacities, int tile_size,
-                                                                int tile_w, int tile_h, uint32_t *__restrict__ keys,
-                                                                uint32_t *__restrict__ vals) {
-  const int64_t j = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
-  if (j >= (int64_t)*n_vis_dev) return;
-  const uint32_t o = sorted_idx[j];
-  const int r = radii[o];
-  if (r <= 0) return;
-  int x0, y0, x1, y1;
-  const float mx = means2d[(int64_t)o * 2], my = means2d[(int64_t)o * 2 + 1];
-  const uint32_t cam_base = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
-  uint32_t off = cum_sorted[j];
-  if (conics == nullptr) {
-    tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
-    for (int ty = y0; ty < y1; ty++)
-      for (int tx = x0; tx < x1; tx++) {
-        keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
-        vals[off] = o;
-        off++;
-      }
-  } else {
-    const float a = conics[(int64_t)o * 3], b = conics[(int64_t)o * 3 + 1], c = conics[(int64_t)o * 3 + 2];
-    float q_max;
-    if (!tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max)) return;
-    for (int ty = y0; ty < y1; ty++) {
-      int lo, hi;
-      row_tile_span(mx, my, a, b, c, q_max, ty, tile_size, x0, x1, lo, hi);
-      for (int tx = lo; tx < hi; tx++) {
-        keys[off] = cam_base + (uint32_t)(ty * tile_w + tx);
-        vals[off] = o;
-        off++;
-      }
-    }
-  }
-}
-
 
 // offsets[t] = first index whose key >= t  (lower bound; empty tiles point at the next run)
 // (key_shift: the tile key sits above the rank bits of a packed entry)
@@ -1121,12 +913,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     BDS_LAUNCH_CHECK();
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
-    if (option_get(kOptRowItems))
-      hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
-    else
-      hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                         opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
+    hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
     BDS_LAUNCH_CHECK();
   } else {
     if (hipMemsetAsync(L.total, 0, sizeof(uint64_t), st) != hipSuccess) return BDS_ELAUNCH;   // M is accumulated by the counting kernel
@@ -1148,7 +936,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     }
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
-    hipLaunchKernelGGL(isect_count_sorted_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
+    hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
     BDS_LAUNCH_CHECK();
   }
@@ -1227,8 +1015,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   // (tile << rank_bits | rank), the sort moves 4 bytes per entry instead of 8 and the Gaussian ids are looked up from
   // the ranks while the last pass writes out.  Same order: entries are emitted by increasing rank and the passes are stable.
   const int rank_bits = 32 - nbits;
-  const bool packed = n_visible >= 0 && rank_bits >= 1 && n_visible <= ((int64_t)1 << rank_bits) && option_get(kOptRadix) == 2 &&
-                      option_get(kOptRowItems) && option_get(kOptPacked);
+  const bool packed = n_visible >= 0 && rank_bits >= 1 && n_visible <= ((int64_t)1 << rank_bits) && option_get(kOptPacked);
   int key_shift = 0;
   uint32_t *kin;
   if (packed) {
@@ -1254,16 +1041,8 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     uint32_t *k_emit, *v_emit;
     if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
     else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
-    if (option_get(kOptRowItems))
-      hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
-                         P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
-    else {
-      // one thread per Gaussian needs every member's own offset: scan the counts now (prepare leaves only group totals)
-      int rc = exclusive_scan_u32(P.kb, P.cum, CN, P.temp, nullptr, st);
-      if (rc != BDS_OK) return rc;
-      hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                         P.cum, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit);
-    }
+    hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
+                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     uint32_t *vin = v_emit;

@@ -58,6 +58,10 @@ class FlatGradients:
     def zero(self) -> None:
         for p in self.params:
             p.grad = None
+        if self._union_work is not None:      # a union that no exchange consumed: drop it (and distrust the book)
+            self._union_work.wait()
+            self._union, self._union_work = None, None
+            self._dirty = None
         if self.sparse_rows:
             self._clear_rows()
 
@@ -162,6 +166,11 @@ class FlatGradients:
             if average:
                 flat.div_(dist.get_world_size())
             return None
+        if self.sparse_rows:
+            # dense exchange without a union (the caller only used mark_rows): rows touched on OTHER ranks are non-zero now,
+            # and this rank's book does not know them -> the next zero() has to clear everything
+            self._dirty = None
+            self._clean = False
         self.last_payload_bytes = flat.numel() * 4
         self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if not async_op and average:

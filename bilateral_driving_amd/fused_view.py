@@ -47,15 +47,15 @@ _LIST_CAPACITY: Dict[tuple, int] = {}   # (N, W, H, culling) -> entries to provi
 
 class _FusedView(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, *grids):
-        L.require_gpu(means, quats, log_scales, logits, sh, sky, *grids)
+    def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, viewmat, *grids):
+        L.require_gpu(means, quats, log_scales, logits, sh, sky, viewmat, *grids)
         lib, st = L.lib(), L.stream()
         dev = means.device
         W, H = cfg["width"], cfg["height"]
         N, K = means.shape[0], sh.shape[1]
         P = H * W
         means, quats, log_scales, logits, sh, sky = (t.contiguous() for t in (means, quats, log_scales, logits, sh, sky))
-        viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
+        viewmat, Kmat = viewmat.contiguous(), cfg["K"].contiguous()
         # activations (vanilla.py:393-394) + projection (C = 1)
         scales, opac = _empty((N, 3), dev), _empty((N,), dev)
         radii = _empty((1, N), dev, torch.int32)
@@ -126,21 +126,24 @@ class _FusedView(torch.autograd.Function):
         with L.timed("bilagrid_fwd"):
             L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
                                                L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")
-        rgb_g = render[0, :, :, :3]   # view: the Gaussians' colour before clamp / sky / transform (base.py:414)
+        rgb_g = render[0, :, :, :3].clamp(max=1.0)   # the Gaussians' colour before sky / transform (base.py:414: clamp(max=1.0))
         ctx.cfg = cfg
         ctx.M = M
         ctx.n_grids = len(grids)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
+        ctx.save_for_backward(means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
                               colors, flatten_ids, isect_offsets, render, alphas, last_ids, bws, *grids)
         opacity = alphas[0]
-        # rgb_g / means2d are returned for inspection and as the carrier of .absgrad; no gradient flows into them
-        ctx.mark_non_differentiable(rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets)
-        return rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets
+        # rgb_g is returned for inspection.  means2d_out is a graph tensor (trainers/base.py:429-430 calls retain_grad() on
+        # info["means2d"]): the backward attaches .absgrad / .grad to it, and a gradient a caller sends INTO it is added to the
+        # compositor's before the projection backward.
+        means2d_out = means2d.view(1, N, 2)
+        ctx.mark_non_differentiable(rgb_g, radii, tiles_per_gauss, flatten_ids, isect_offsets)
+        return rgb, depth, opacity, rgb_g, means2d_out, radii, tiles_per_gauss, flatten_ids, isect_offsets
 
     @staticmethod
-    def backward(ctx, v_rgb, v_depth, v_opacity, *_):
-        (means, quats, log_scales, sh, sky, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, flatten_ids,
+    def backward(ctx, v_rgb, v_depth, v_opacity, _v_rgb_g, v_means2d_ext, *_):
+        (means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, flatten_ids,
          isect_offsets, render, alphas, last_ids, bws, *grids) = ctx.saved_tensors
         cfg = ctx.cfg
         lib, st = L.lib(), L.stream()
@@ -150,7 +153,7 @@ class _FusedView(torch.autograd.Function):
         P, M = H * W, ctx.M
         tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
         # colour transform
-        need_g = ctx.needs_input_grad[7:]
+        need_g = ctx.needs_input_grad[8:]
         # grid gradients: one zero fill for all levels; with img_idx the full [n_img, ...] gradient is returned with only that
         # image's slice written (no slice-backward / scatter in the autograd graph)
         sizes = [(g.numel() + 3) // 4 * 4 if need_g[i] else 0 for i, g in enumerate(grids)]
@@ -182,10 +185,12 @@ class _FusedView(torch.autograd.Function):
                                           tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids),
                                           L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_m2), L.ptr(v_abs), L.ptr(v_con), L.ptr(v_col),
                                           L.ptr(v_op), L.ptr(order), st), "bds_rasterize_bwd")
+        if v_means2d_ext is not None:   # a loss term on info["means2d"] itself
+            v_m2.add_(v_means2d_ext.reshape(-1))
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
-        if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282 reads .absgrad)
+        if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.absgrad = v_abs.view(1, N, 2)
-            carrier.grad_means2d = v_m2.view(1, N, 2)
+            carrier.grad = v_m2.view(1, N, 2)
         arena = cfg.get("grad_arena") or {}
 
         def out_like(name, ref):  # gradient output: the caller's slice of a flat communication buffer, or a fresh tensor
@@ -208,20 +213,22 @@ class _FusedView(torch.autograd.Function):
                                             L.ptr(v_sh), L.ptr(v_depths), st), "bds_sh_view_bwd")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
-        viewmat, Kmat = cfg["viewmat"].contiguous(), cfg["K"].contiguous()
+        viewmat, Kmat = viewmat.contiguous(), cfg["K"].contiguous()
+        v_viewmat = _empty((4, 4), dev) if ctx.needs_input_grad[7] else None   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
             if rows:
                 L.check(lib.bds_project_view_bwd_rows(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat),
                                                       W, H, cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
-                                                      L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), int(rows == 2), st),
+                                                      L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_viewmat), int(rows == 2), st),
                         "bds_project_view_bwd_rows")
             else:
                 L.check(lib.bds_project_view_bwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat), W, H,
                                                  cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
-                                                 L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), st), "bds_project_view_bwd")
+                                                 L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_viewmat), st),
+                        "bds_project_view_bwd")
         if rows == 2:   # already added in place to what autograd holds as .grad: nothing to hand back
-            return (None, None, None, None, None, None, v_sky, *v_grids)
-        return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, *v_grids)
+            return (None, None, None, None, None, None, v_sky, v_viewmat, *v_grids)
+        return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, v_viewmat, *v_grids)
 
 
 def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor],
@@ -232,7 +239,10 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
     [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
-    parameter's shape.  Returns dict(rgb, depth, opacity, rgb_gaussians, info).
+    parameter's shape.  ``viewmat`` [4,4] may require grad (learnable camera pose, trainers/base.py:328-329,399): its gradient
+    comes from the projection; the SH view direction uses the detached camera centre as the reference does (vanilla.py:385 ``.data``).
+    Returns dict(rgb, depth, opacity, rgb_gaussians, info); ``info["means2d"]`` [1,N,2] is a graph tensor that supports
+    ``retain_grad()`` and carries ``.absgrad`` / ``.grad`` after ``backward()`` (trainers/base.py:279-297,429-430).
 
     ``grad_arena`` (optional): name -> preallocated tensor; the backward kernels write the parameter gradients
     straight into these (e.g. slices of the flat all-reduce buffer of ``dist.FlatGradients``) instead of fresh
@@ -242,14 +252,15 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     sees -- the caller promises that every other row of the arena is zero (``dist.FlatGradients(sparse_rows=True).zero()`` keeps it so);
     2 = it ADDS them to an arena that autograd already holds as the parameters' ``.grad`` (second and later views of a frame that
     is exchanged once) and returns no gradient for those parameters."""
-    if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds[..., :3, 3]); callers with fixed cameras cache it
-        cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
-    cfg = dict(width=int(width), height=int(height), viewmat=viewmat, K=K, cam_pos=cam_pos, factors=tuple(int(f) for f in factors),
+    if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds.data[..., :3, 3]); callers with fixed cameras cache it
+        cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
+    cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena,
                img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows))
     gs = [g if g.dim() == 5 else g[None] for g in grids]
-    out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky, *gs)
+    out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky,
+                           viewmat, *gs)
     rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets = out
     cfg["_means2d_ref"] = weakref.ref(means2d)  # backward attaches .absgrad to THIS tensor object
     info = {"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,

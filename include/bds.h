@@ -38,20 +38,13 @@ typedef void *bds_stream_t;
 int bds_abi_version(void);
 const char *bds_strerror(int code);
 
-/* Kernel-variant switches for A/B measurement and bisecting (results are identical up to fp32
- * summation order).  which: 0 = composite backward (0: per-value DPP reduce, 4 waves/tile;
- * 1: 16-value transpose-reduce, 4 waves/tile; 2: one wave/tile, 4 pixels/lane (row strips);
- * 3: one wave/tile, 4 pixels/lane (8x8 quadrants, per-Gaussian quadrant masks));
- * 1 = radix pass (0: block-synchronous ranking; 1: wave-private ranking; 2: wave-private ranking + digit-ordered
- *     write-out through LDS [default]);
- * 2 = composite forward (0: 4 waves/tile, 1 pixel/lane; 1: one wave/tile, 4 pixels/lane (row strips);
- *     2: one wave/tile, quadrant-masked);
- * 4 = depth ordering of the visible entries (1: two-launch radix passes with workgroup-derived bases, compaction
- *     fused with its scan [default]; 0: generic histogram / scan / scatter passes);
- * 5 = counting / emission of the (tile, id) pairs (1: one work item per tile ROW of a Gaussian [default];
- *     0: one thread per Gaussian);
- * 6 = packed 32-bit tile lists when the visible count allows (1 [default]; 0: always (key, id) pairs).
- * Defaults: see csrc/api.hip. */
+/* Test hooks that force the large-input fallback paths of the tile stage on small inputs (there is ONE kernel per
+ * operation; these select which size regime a call is treated as).  which:
+ * 4 = depth ordering of the visible entries: 1 [default] = the two-launch radix passes used up to 8.4 M (camera, Gaussian)
+ *     entries; 0 = the generic histogram / scan / scatter passes that larger inputs take;
+ * 6 = tile lists: 1 [default] = packed 32-bit entries (tile << rank_bits | depth rank) whenever the visible count fits the
+ *     rank bits; 0 = the (tile key, id) pair lists that larger visible counts take.
+ * 3 = profiling only: ablation mask of the bilateral backward.  Other indices are unused. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 
@@ -243,7 +236,8 @@ int bds_project_view_fwd(int64_t N, const float *means, const float *quats, cons
 int bds_project_view_bwd(int64_t N, const float *means, const float *quats, const float *scales, const float *opacities,
                          const float *viewmat, const float *K, int W, int H, float eps2d, const int32_t *radii,
                          const float *v_means2d, const float *v_depths, const float *v_conics, const float *v_opacities,
-                         float *v_means, float *v_quats, float *v_log_scales, float *v_logits, bds_stream_t stream);
+                         float *v_means, float *v_quats, float *v_log_scales, float *v_logits, float *v_viewmat /* [4,4] or NULL */,
+                         bds_stream_t stream);
 int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const float *coeffs,
                     const int32_t *radii, const float *depths, float *sh_rgb, float *colors, bds_stream_t stream);
 int bds_sh_view_bwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const int32_t *radii,
@@ -390,8 +384,8 @@ int bds_sh_view_bwd_rows(int64_t n, int K, int deg, const float *means, const fl
 int bds_project_view_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales, const float *opacities,
                               const float *viewmat, const float *K, int W, int H, float eps2d, const int32_t *radii,
                               const float *v_means2d, const float *v_depths, const float *v_conics, const float *v_opacities,
-                              float *v_means, float *v_quats, float *v_log_scales, float *v_logits, int accumulate,
-                              bds_stream_t stream);
+                              float *v_means, float *v_quats, float *v_log_scales, float *v_logits, float *v_viewmat /* [4,4] or NULL */,
+                              int accumulate, bds_stream_t stream);
 /* Zero the rows g with dirty[g] != 0 of the five per-Gaussian gradient arrays (v_sh is [n,K,3]). */
 int bds_view_grads_clear(int64_t n, int K, const uint8_t *dirty, float *v_means, float *v_quats, float *v_log_scales,
                          float *v_logits, float *v_sh, bds_stream_t stream);

@@ -225,13 +225,18 @@ def isect_offset_encode(isect_ids, tile_w, tile_h):
 # compositing
 # --------------------------------------------------------------------------------------
 def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-                        backgrounds=None, return_unstable=False, margin=1e-4):
+                        backgrounds=None, return_unstable=False, margin=1e-4, absgrad_probe=None):
     """means2d [N,2], conics [N,3], colors [N,D], opacities [N]; per-pixel front-to-back blend.
 
     Returns render [H,W,D], alphas [H,W,1], last_ids [H,W] (index into the sorted intersection
     list of the last blended Gaussian; 0 if none).  With ``return_unstable`` also a bool map of
     pixels in which some discrete decision (alpha cut, T stop) sits within ``margin`` (relative)
-    of its threshold, i.e. where an fp32 reimplementation may legitimately differ."""
+    of its threshold, i.e. where an fp32 reimplementation may legitimately differ.
+
+    ``absgrad_probe`` (a list): every tile appends (ids, dx, dy) with the per-(Gaussian, pixel) offsets kept as
+    graph tensors whose gradient is retained; after ``backward()`` ``absgrad_from_probe`` sums their absolute values --
+    the ``means2d.absgrad`` buffer of gsplat (sum over pixels of |dL/dmean2d through that pixel|), which the
+    reference's densification reads at project/models/trainers/base.py:280-297."""
     H, W = int(height), int(width)
     D = colors.shape[-1]
     dt = means2d.dtype
@@ -258,6 +263,10 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, tile_
                 ids = flatten_ids[s:e].long()
                 dx = means2d[ids, 0][:, None] - px[None, :]
                 dy = means2d[ids, 1][:, None] - py[None, :]
+                if absgrad_probe is not None and dx.requires_grad:
+                    dx.retain_grad()
+                    dy.retain_grad()
+                    absgrad_probe.append((ids, dx, dy))
                 cn = conics[ids]
                 sigma = 0.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) + cn[:, 1:2] * dx * dy
                 raw = opacities[ids][:, None] * torch.exp(-sigma)
@@ -305,6 +314,19 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, tile_
     return render, alphas, last
 
 
+def absgrad_from_probe(probe, n):
+    """[n, 2]: sum over tiles and pixels of |d loss / d (mean2d - pixel)| per Gaussian (call after backward())."""
+    out = None
+    for ids, dx, dy in probe:
+        if dx.grad is None:
+            continue
+        if out is None:
+            out = torch.zeros(n, 2, dtype=dx.dtype)
+        out[:, 0].index_add_(0, ids, dx.grad.abs().sum(1))
+        out[:, 1].index_add_(0, ids, dy.grad.abs().sum(1))
+    return out if out is not None else torch.zeros(n, 2)
+
+
 def rasterize_pixel_loop(means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids):
     """Literal per-pixel scalar loop (no autograd) -- the independent check of the vectorised
     ``rasterize_to_pixels`` on tiny cases."""
@@ -349,9 +371,10 @@ def rasterize_pixel_loop(means2d, conics, colors, opacities, width, height, tile
 # --------------------------------------------------------------------------------------
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane=0.01,
                   far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_size=16, backgrounds=None, render_mode="RGB",
-                  return_unstable=False):
+                  return_unstable=False, absgrad_probes=None):
     """Single- or multi-camera (looped).  colors [N,D] or [C,N,D]; opacities [N].
-    Returns render [C,H,W,D(+1)], alphas [C,H,W,1], meta (means2d/radii/depths/conics [C,N,*], ...)."""
+    Returns render [C,H,W,D(+1)], alphas [C,H,W,1], meta (means2d/radii/depths/conics [C,N,*], ...).
+    ``absgrad_probes``: a list that receives one probe list per camera (see rasterize_to_pixels)."""
     assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED")
     W, H = int(width), int(height)
     C = viewmats.shape[0]
@@ -367,7 +390,11 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         tpg, iids, fids = isect_tiles(m2, radii, dep, tile_size, tw, th)
         offs = isect_offset_encode(iids, tw, th)
         bg = None if backgrounds is None else backgrounds[c]
-        res = rasterize_to_pixels(m2, con, col, opacities, W, H, tile_size, offs, fids, bg, return_unstable)
+        probe = None
+        if absgrad_probes is not None:
+            probe = []
+            absgrad_probes.append(probe)
+        res = rasterize_to_pixels(m2, con, col, opacities, W, H, tile_size, offs, fids, bg, return_unstable, absgrad_probe=probe)
         r, a = res[0], res[1]
         if render_mode in ("ED", "RGB+ED"):
             r = torch.cat([r[..., :-1], r[..., -1:] / a.clamp(min=1e-10)], -1)

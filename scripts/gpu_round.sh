@@ -1,0 +1,39 @@
+#!/bin/bash
+# One GPU-box visit (through gpurun): full -m gpu suite (log kept), smoke, bench line, rocprofv3 kernel stats + PMC passes.
+# usage: scripts/gpu_round.sh <tag> [tests|notests] [pmc|nopmc]
+set -u
+TAG=${1:-r02a}
+DO_TESTS=${2:-tests}
+DO_PMC=${3:-pmc}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+cd $REPO
+export PYTHONDONTWRITEBYTECODE=1
+if [ "$DO_TESTS" = "tests" ]; then
+  (timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -150) > $OUT/gpu_tests.log
+  tail -5 $OUT/gpu_tests.log
+  (timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v Warning | tail -5) > $OUT/smoke.log
+  tail -2 $OUT/smoke.log
+fi
+(timeout 600 python bench.py 2>$OUT/bench.stderr | tail -1) > $OUT/bench.json
+cat $OUT/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
+    python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_bench.json 2>$OUT/trace.stderr
+if [ "$DO_PMC" = "pmc" ]; then
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
+      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_fetch.stderr
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
+      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_write.stderr
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
+      --output-format csv -d $OUT/pmc_sq -o bench -- \
+      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_sq.stderr
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+      --output-format csv -d $OUT/pmc_sq2 -o bench -- \
+      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_sq2.stderr
+fi
+# keep what travels back small: drop the raw per-dispatch traces, keep stats + counter CSVs
+find $OUT -name "*kernel_trace.csv" -size +4M -delete
+find $OUT -name "*.csv" | head -20
+du -sh $OUT

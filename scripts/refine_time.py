@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import torch
-from test_gpu_refine import CTRL, Cfg, GROUPS, synthetic, build_model
+from test_gpu_11_refine import CTRL, Cfg, GROUPS, synthetic, build_model
 from oracle import refine_oracle as RO          # names of the parameters only
 from bilateral_driving_amd.densify import refinement_after
 

@@ -21,13 +21,12 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _reset_kernel_variants():
-    """Tests may switch kernel variants (bds_set_option); restore the defaults afterwards."""
+    """Tests may force the tile stage's large-input fallback paths (bds_set_option); restore the defaults afterwards."""
     yield
     try:
         from bilateral_driving_amd import _lib
         if _lib._lib is not None:
-            _lib.set_option(_lib.OPT_RASTER_BWD, 2)
-            _lib.set_option(_lib.OPT_RADIX, 2)
-            _lib.set_option(_lib.OPT_RASTER_FWD, 1)
+            _lib.set_option(_lib.OPT_SHORT_SORT, 1)
+            _lib.set_option(_lib.OPT_PACKED, 1)
     except Exception:
         pass

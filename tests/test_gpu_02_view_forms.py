@@ -51,13 +51,23 @@ def test_project_view_equals_general_form_with_activations(env, seed, N, W, H):
     v_con = torch.randn(1, N, 3, generator=g).cuda() * vis[None, :, None]
     v_op = torch.randn(N, generator=g).cuda() * vis
     out = [torch.full((N, k), 7.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 7.0, device="cuda")]
+    v_vm = torch.full((4, 4), 7.0, device="cuda")          # camera-pose gradient (trainers/base.py:328-329,399)
     L.check(lib.bds_project_view_bwd(N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K), W, H, 0.3,
                                      L.ptr(radii), L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), L.ptr(v_op), L.ptr(out[0]), L.ptr(out[1]),
-                                     L.ptr(out[2]), L.ptr(out[3]), st), "bwd")
+                                     L.ptr(out[2]), L.ptr(out[3]), L.ptr(v_vm), st), "bwd")
     ref = [torch.empty(N, k, device="cuda") for k in (3, 4, 3)]
+    ref_vm = torch.empty(1, 4, 4, device="cuda")
     L.check(lib.bds_project_bwd(1, N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(vm), L.ptr(K), W, H, 0.3, L.ptr(radii),
                                 L.ptr(con), None, L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), None, L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]),
-                                None, st), "ref bwd")
+                                L.ptr(ref_vm), st), "ref bwd")
+    assert float(ref_vm[0, :3].abs().max()) > 0 and float(v_vm[3].abs().max()) == 0.0
+    assert float((v_vm - ref_vm[0]).norm()) <= 1e-4 * float(ref_vm.norm())       # block-reduction order differs
+    # without a pose gradient buffer nothing else changes
+    out2 = [torch.empty_like(o) for o in out]
+    L.check(lib.bds_project_view_bwd(N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K), W, H, 0.3,
+                                     L.ptr(radii), L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), L.ptr(v_op), L.ptr(out2[0]), L.ptr(out2[1]),
+                                     L.ptr(out2[2]), L.ptr(out2[3]), None, st), "bwd (no pose)")
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))
     # (two separately compiled kernels: fused multiply-adds differ in the last bits, and the projection vjp cancels)
     for a, b in ((out[0], ref[0]), (out[1], ref[1]), (out[2], ref[2] * scales)):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())

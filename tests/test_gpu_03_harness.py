@@ -1,0 +1,216 @@
+"""-m gpu: the harness-level forms of the path (one fused autograd node per view, gradient arenas, row-wise buffers)
+against the operator-by-operator form that tests/test_gpu_01_gs_parity.py checks against the oracle."""
+import pytest
+import torch
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import bilateral_driving_amd.gs_ops as ops
+    from bilateral_driving_amd import _lib
+    _lib.lib()  # fails loudly if libbds.so is missing
+    return ops
+
+
+def test_harness_view_matches_rasterization_api(ops):
+    """harness.render_view (stage ops, SH after projection with the visibility mask, culling) ==
+    the reference-shaped call sequence through rasterization() + separate torch post-processing."""
+    import bilateral_driving_amd.rendering as R
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.bilagrid import bilagrid_transform
+    dev = "cuda"
+    W, H, N = 320, 192, 4000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    base = Hn.synthetic_scene(N, seed=1, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    grids0 = Hn.make_grids(2, device=dev)
+    sky = torch.rand(H, W, 3, device=dev)
+    target = torch.rand(H, W, 3, device=dev)
+    outs = []
+    for mode in ("fused", "staged", "api"):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        if mode in ("fused", "staged"):
+            Hn.FUSED = mode == "fused"
+            try:
+                out = Hn.render_view(p, cam, grids, 1, sky)
+            finally:
+                Hn.FUSED = True
+            rgb, depth = out["rgb"], out["depth"]
+            absg_holder = out["info"]["means2d"]
+        else:
+            dirs = p["means"].detach() - torch.linalg.inv(cam.viewmat)[:3, 3]
+            col = torch.clamp(ops.spherical_harmonics(3, dirs, p["sh"]) + 0.5, 0.0, 1.0)
+            rr, aa, info = R.rasterization(p["means"], p["quats"] / p["quats"].norm(dim=-1, keepdim=True), torch.exp(p["log_scales"]),
+                                           torch.sigmoid(p["opacity_logits"]), col, cam.viewmat[None], cam.K[None], W, H,
+                                           packed=False, absgrad=True, near_plane=0.1, render_mode="RGB+ED")
+            rgb_g = torch.clamp(rr[0][..., :3], max=1.0)
+            blended = rgb_g + sky * (1.0 - aa[0])
+            rgb = bilagrid_transform(blended, [g[1:2] for g in grids], Hn.FACTORS_3)
+            depth = rr[0][..., 3:4]
+        loss = (rgb - target).abs().mean() + 0.1 * depth.mean() * 0.01
+        loss.backward()
+        if mode != "api":
+            assert absg_holder.absgrad.shape == (1, N, 2) and float(absg_holder.absgrad.sum()) > 0
+        outs.append((rgb.detach(), depth.detach(), {k: v.grad.clone() for k, v in p.items()}, [g.grad.clone() for g in grids]))
+    for o in outs[:2]:
+        assert rel_err(o[0], outs[2][0]) < 1e-5 and rel_err(o[1], outs[2][1]) < 1e-5
+        for k in o[2]:
+            a, b = o[2][k], outs[2][2][k]
+            assert float((a - b).norm() / b.norm()) < 1e-4, k
+        for a, b in zip(o[3], outs[2][3]):
+            assert float((a - b).norm() / b.norm()) < 1e-4
+
+
+def test_fused_view_writes_gradients_into_flat_buffer(ops):
+    """Multi-GPU plumbing on one GPU: with grad_arena the backward kernels write the per-Gaussian gradients into
+    the flat all-reduce buffer and autograd adopts those slices as .grad (no pack copy)."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients
+    dev = "cuda"
+    W, H, N = 256, 160, 3000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    base = Hn.synthetic_scene(N, seed=2, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    grids0 = Hn.make_grids(1, device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    res = []
+    for use_arena in (False, True):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        flat = FlatGradients(list(p.values()) + grids)
+        arena = flat.arena(list(p.keys())) if use_arena else None
+        flat.zero()
+        out = Hn.render_view(p, cam, grids, 0, sky, grad_arena=arena)
+        Hn.training_loss(out, target, grids).backward()
+        if use_arena:
+            for k, v in p.items():
+                assert v.grad.data_ptr() == arena[k].data_ptr(), k  # adopted in place
+        res.append(flat.pack().clone())
+    assert float((res[0] - res[1]).norm() / res[0].norm()) < 1e-4
+    assert float(res[0].abs().sum()) > 0
+
+
+def test_sparse_row_gradient_buffer_matches_dense_over_rotating_views(ops):
+    """Opt-in FlatGradients(sparse_rows=True) + fused_view(arena_rows=1): the persistent buffer is cleared row-wise (only what the
+    last step wrote) and the backward stores only the rows of the Gaussians the view sees.  Over steps that rotate through views
+    with different visible sets every step's gradients equal the ones the dense form produces."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients
+    dev = "cuda"
+    W, H, N = 256, 160, 6000
+    cams = Hn.ring_cameras(W, H, yaws_deg=(0.0, 120.0, 240.0, 60.0), device=dev)
+    base = Hn.synthetic_scene(N, seed=3, device=dev)
+    grids0 = Hn.make_grids(len(cams), device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    res, seen = {}, []
+    for sparse in (False, True):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        flat = FlatGradients(list(p.values()) + grids, sparse_rows=sparse)
+        arena = flat.arena(list(p.keys()))
+        n_gauss = sum(x.numel() for x in p.values())
+        out_steps = []
+        for step in range(6):
+            v = step % len(cams)
+            flat.zero()
+            assert flat.rows_clean == sparse
+            if sparse:
+                assert float(flat.flat[:n_gauss].abs().sum()) == 0.0          # really all-zero again
+            out = Hn.render_view(p, cams[v], grids, v, sky, grad_arena=arena, arena_rows=1 if flat.rows_clean else 0)
+            vis = out["info"]["radii"][0] > 0
+            flat.mark_rows(vis)
+            if not sparse:
+                seen.append(int(vis.sum()))
+            Hn.training_loss(out, target, grids).backward()
+            for k, t in p.items():
+                assert t.grad.data_ptr() == arena[k].data_ptr(), k
+            assert float(p["sh"].grad[~vis].abs().sum()) == 0.0 and float(p["means"].grad[~vis].abs().sum()) == 0.0
+            out_steps.append(flat.pack().clone())
+        res[sparse] = out_steps
+    assert 0 < min(seen) and max(seen) < N and len(set(seen)) > 1      # the views cull different, proper subsets
+    for a, b in zip(res[False], res[True]):
+        assert float(a.abs().sum()) > 0
+        assert float((a - b).norm() / a.norm()) < 1e-4      # the composite's atomics make two runs differ in the last bits
+
+
+def test_views_of_a_frame_accumulate_into_the_arena(ops):
+    """fused_view(arena_rows=2): the second and later views of a frame ADD their visible rows to the buffer that autograd already holds
+    as .grad (one exchange per frame); the result equals the sum of the views' separately computed gradients."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients
+    dev = "cuda"
+    W, H, N = 256, 160, 6000
+    cams = Hn.ring_cameras(W, H, yaws_deg=(0.0, 100.0, 200.0), device=dev)
+    base = Hn.synthetic_scene(N, seed=4, device=dev)
+    grids0 = Hn.make_grids(len(cams), device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    # reference: dense gradients of every view, summed
+    ref = None
+    for v, cam in enumerate(cams):
+        p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        Hn.training_loss(Hn.render_view(p, cam, grids, v, sky), target, grids).backward()
+        g = torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids])
+        ref = g if ref is None else ref + g
+    p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+    grids = [g.clone().requires_grad_(True) for g in grids0]
+    flat = FlatGradients(list(p.values()) + grids, sparse_rows=True)
+    arena = flat.arena(list(p.keys()))
+    for frame in range(2):          # twice: the second frame starts from the row-wise cleared buffer
+        flat.zero()
+        for v, cam in enumerate(cams):
+            out = Hn.render_view(p, cam, grids, v, sky, grad_arena=arena, arena_rows=1 if v == 0 else 2)
+            flat.mark_rows(out["info"]["radii"][0] > 0)
+            Hn.training_loss(out, target, grids).backward()
+        for k, t in p.items():
+            assert t.grad.data_ptr() == arena[k].data_ptr(), k
+        got = flat.pack()
+        assert float((got - ref).norm() / ref.norm()) < 1e-4, frame
+
+
+@pytest.mark.parametrize("N,W,H,seed,pull", [(1000, 256, 256, 0, 0.25), (3000, 320, 200, 1, 0.3), (400, 75, 50, 2, 0.2)])
+def test_fused_view_against_oracle_incl_pose_gradient_and_absgrad(ops, N, W, H, seed, pull):
+    """The fused view (what bench.py times) against the float64 oracle: image 1e-4 rel, all gradients incl. the camera-pose
+    gradient and the VALUE of info["means2d"].absgrad 1e-3-class; retain_grad() on info["means2d"] as trainers/base.py:429-430 does."""
+    import __graft_entry__ as E
+    E.smoke_check(verbose=True, N=N, W=W, H=H, seed=seed, pull=pull)
+
+
+def test_rasterization_api_pose_gradient_and_fused_equivalence(ops):
+    """rasterization() (the gsplat-shaped API) and the fused view give the same camera-pose gradient."""
+    import bilateral_driving_amd.rendering as R
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.bilagrid import bilagrid_transform
+    dev = "cuda"
+    W, H, N = 256, 160, 3000
+    base = Hn.synthetic_scene(N, seed=5, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    grids0 = Hn.make_grids(1, device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    res = []
+    for mode in ("fused", "api"):
+        cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+        cam.viewmat = cam.viewmat.clone().requires_grad_(True)
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        if mode == "fused":
+            out = Hn.render_view(p, cam, grids, 0, sky)
+            rgb = out["rgb"]
+            assert float((out["rgb_gaussians"].max())) <= 1.0      # base.py:414 clamp(max=1.0)
+        else:
+            dirs = p["means"].detach() - torch.linalg.inv(cam.viewmat.detach())[:3, 3]
+            col = torch.clamp(ops.spherical_harmonics(3, dirs, p["sh"]) + 0.5, 0.0, 1.0)
+            rr, aa, info = R.rasterization(p["means"], p["quats"] / p["quats"].norm(dim=-1, keepdim=True), torch.exp(p["log_scales"]),
+                                           torch.sigmoid(p["opacity_logits"]), col, cam.viewmat[None], cam.K[None], W, H,
+                                           packed=False, absgrad=True, near_plane=0.1, render_mode="RGB+ED")
+            rgb = bilagrid_transform(torch.clamp(rr[0][..., :3], max=1.0) + sky * (1.0 - aa[0]), [g[0:1] for g in grids], Hn.FACTORS_3)
+        (rgb - target).abs().mean().backward()
+        res.append(cam.viewmat.grad.clone())
+    assert float(res[1].abs().max()) > 0
+    assert float((res[0] - res[1]).norm() / res[1].norm()) < 1e-3

@@ -147,3 +147,34 @@ def test_gradients_match_finite_differences():
             fd = (vals[0] - vals[1]) / (2 * eps)
             an = float(p.grad.reshape(-1)[idx])
             assert abs(fd - an) <= 1e-4 * max(1.0, abs(fd)), (name, idx, fd, an)
+
+
+def test_absgrad_probe_equals_brute_force_per_pixel_gradients():
+    """G.absgrad_from_probe (what the GPU tests compare info["means2d"].absgrad with) == sum over pixels of the absolute value of that
+    pixel's own gradient w.r.t. the projected mean, each obtained by a separate autograd pass (the definition the reference's
+    densification relies on, /root/reference/project/models/trainers/base.py:280-297)."""
+    N, W, H = 40, 32, 32
+    sc = make_scene(N, W, H, seed=3, dtype=torch.float64)
+    p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    probes = []
+    r, a, meta = G.rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], sc["viewmats"], sc["Ks"], W, H,
+                                 render_mode="RGB+ED", absgrad_probes=probes)
+    wt = torch.randn(r.shape, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    (r * wt).sum().backward()
+    ab = G.absgrad_from_probe(probes[0], N)
+    radii, m2, dep, con, _ = G.project(sc["means"], sc["quats"], sc["scales"], sc["viewmats"][0], sc["Ks"][0], W, H)
+    col = torch.cat([sc["colors"], dep[:, None]], -1)
+    tpg, iids, fids = G.isect_tiles(m2, radii, dep, 16, 2, 2)
+    offs = G.isect_offset_encode(iids, 2, 2)
+    m2l = m2.clone().requires_grad_(True)
+    rr, aa, _ = G.rasterize_to_pixels(m2l, con, col, sc["opacities"], W, H, 16, offs, fids)
+    rr = torch.cat([rr[..., :-1], rr[..., -1:] / aa.clamp(min=1e-10)], -1)
+    ref = torch.zeros(N, 2, dtype=torch.float64)
+    for i in range(0, H, 1):
+        for j in range(0, W, 1):
+            gr, = torch.autograd.grad((rr[i, j] * wt[0, i, j]).sum(), m2l, retain_graph=True)
+            ref += gr.abs()
+    assert float(ab.abs().max()) > 1.0
+    assert float((ab - ref).abs().max()) < 1e-10 * float(ref.abs().max())
+    # and it dominates the signed gradient, with equality only where every pixel pulls the same way
+    assert bool((ab >= p["means"].grad.new_zeros(()).abs()).all())
