@@ -40,21 +40,19 @@ _SIGS = {
     "bds_isect_prepare_workspace_bytes": (_sz, [_i, _i64]),
     "bds_isect_build_workspace_bytes": (_sz, [_i, _i64, _i64]),
     "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _f]),
-    "bds_isect_build": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f]),
+    "bds_isect_build": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f, _i, _f]),
     "bds_isect_prepare_async": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _f, _f]),
     "bds_isect_tiles": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _sz, _i64, _f, _f, _f, C.POINTER(C.c_int64),
                              C.POINTER(C.c_int64), _f]),
-    "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
-    "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f,
-                               _f, _f, _f, _f, _f]),
+    "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_project_view_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_sh_view_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_sh_view_bwd_rows": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
-    "bds_project_view_bwd_rows": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
-    "bds_view_grads_clear": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
@@ -120,6 +118,7 @@ def lib():
     return _lib
 
 
+SPLAT_RECORD_FLOATS, GRAD_RECORD_FLOATS, POSE_GRAD_SLOTS = 12, 16, 64
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
 

@@ -121,8 +121,11 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
 }
 
 // Block reduction of the camera-pose gradient (9 rotation + 3 translation partials per Gaussian): one 16-value
-// transpose-reduce per wave, the workgroup's waves summed through LDS, one atomic set per workgroup.
-__device__ __forceinline__ void pose_grad_reduce(const ProjGrad &pg, float (*red)[12], float *__restrict__ v_viewmat) {
+// transpose-reduce per wave, the workgroup's waves summed through LDS, one atomic set per workgroup into one of
+// kPoseSlots replicated [4,4] accumulators (every workgroup on the same 12 addresses serialises in L2: measured +58 us
+// at 7800 workgroups); the caller sums the slots.
+constexpr int kPoseSlots = BDS_POSE_GRAD_SLOTS;
+__device__ __forceinline__ void pose_grad_reduce(const ProjGrad &pg, float (*red)[12], float *__restrict__ v_viewmat_slots) {
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   float v[16];
 #pragma unroll
@@ -139,86 +142,51 @@ __device__ __forceinline__ void pose_grad_reduce(const ProjGrad &pg, float (*red
 #pragma unroll
     for (int w = 0; w < kProjBlock / kWave; w++) t += red[w][threadIdx.x];
     const int i = threadIdx.x;
-    if (t != 0.f) atomicAdd(v_viewmat + (i < 9 ? (i / 3) * 4 + (i % 3) : (i - 9) * 4 + 3), t);
+    float *dst = v_viewmat_slots + (blockIdx.x % kPoseSlots) * 16;
+    if (t != 0.f) atomicAdd(dst + (i < 9 ? (i / 3) * 4 + (i % 3) : (i - 9) * 4 + 3), t);
   }
 }
 
-// v_viewmat (optional, [4,4], zero-filled by the entry point): gradient of the world->camera matrix -- the camera pose is a
-// learnable input of the reference's step (models/trainers/base.py:328-329 CamPose, :399 viewmats = inv(camtoworlds)).
-template <bool kPose>
-__global__ __launch_bounds__(kProjBlock) void project_view_bwd_kernel(
-    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
-    const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
-    float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
-    const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
-    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat) {
+// ---- one-view backward over the VISIBLE Gaussians, list-driven ----------------------------------------------------------------
+// Work list = the depth-ordered ids of the visible entries (bds_isect_build: visible_ids); input = the compositor's gradient
+// record of the same rank (conic 4-6, mean2d 7-8, |mean2d| 9-10, opacity 11, depth channel 3), read coalesced.  Returns the
+// gradients of the RAW parameters (log-scales, opacity logits: models/gaussians/vanilla.py:393-394), stored (kAcc = false) or added
+// (kAcc = true) to the rows of the visible Gaussians only -- rows of culled Gaussians are the caller's business.  Optionally
+// scatters the screen-space gradient and its absolute sum to the dense [N,2] arrays the densification statistics read
+// (models/trainers/base.py:280-297), and reduces the camera-pose gradient (models/trainers/base.py:328-329,399).
+template <bool kAcc, bool kPose>
+__global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
+    int64_t n_list, const int32_t *__restrict__ ids, const float *__restrict__ means, const float *__restrict__ quats,
+    const float *__restrict__ scales, const float *__restrict__ opacities, const float *__restrict__ viewmat,
+    const float *__restrict__ K, int W, int H, float eps2d, const float4 *__restrict__ v_rec, float *__restrict__ v_means,
+    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat_slots,
+    float *__restrict__ grad2d, float *__restrict__ absgrad2d) {
   __shared__ float red[kProjBlock / kWave][12];
-  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
-  float am[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, as[3] = {0, 0, 0}, al = 0.f;
+  const int64_t r = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   ProjGrad pg;
   for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
   for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
-  if (g < N && radii[g] > 0) {
+  if (r < n_list) {
+    const int64_t g = ids[r];
+    const float4 r0 = v_rec[r * 4], r1 = v_rec[r * 4 + 1], r2 = v_rec[r * 4 + 2];
     const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
     const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
     const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
     Camera cam = load_camera(viewmat, K);
-    project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[g * 2], v_means2d[g * 2 + 1], v_depths[g], v_conics[g * 3],
-                    v_conics[g * 3 + 1], v_conics[g * 3 + 2], pg);
-    for (int i = 0; i < 3; i++) { am[i] = pg.v_mean[i]; as[i] = pg.v_scale[i] * s[i]; }
-    for (int i = 0; i < 4; i++) aq[i] = pg.v_quat[i];
+    project_one_vjp(m, q, s, cam, W, H, eps2d, r1.w, r2.x, /*v_depth*/ r0.w, r1.x, r1.y, r1.z, pg);
     const float o = opacities[g];
-    al = v_opacities[g] * o * (1.f - o);
+    const float al = r2.w * o * (1.f - o);
+    for (int i = 0; i < 3; i++) {
+      const float a = pg.v_mean[i], b = pg.v_scale[i] * s[i];
+      v_means[g * 3 + i] = kAcc ? v_means[g * 3 + i] + a : a;
+      v_log_scales[g * 3 + i] = kAcc ? v_log_scales[g * 3 + i] + b : b;
+    }
+    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = kAcc ? v_quats[g * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
+    v_logits[g] = kAcc ? v_logits[g] + al : al;
+    if (grad2d) { grad2d[g * 2] = r1.w; grad2d[g * 2 + 1] = r2.x; }
+    if (absgrad2d) { absgrad2d[g * 2] = r2.y; absgrad2d[g * 2 + 1] = r2.z; }
   }
-  if (g < N) {
-    for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = am[i]; v_log_scales[g * 3 + i] = as[i]; }
-    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = aq[i];
-    v_logits[g] = al;
-  }
-  if (kPose) pose_grad_reduce(pg, red, v_viewmat);
-}
-
-template <bool kAcc>
-__device__ __forceinline__ void rows_body(
-    int64_t g, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
-    const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
-    float eps2d, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
-    const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
-    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, ProjGrad &pg) {
-  const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
-  const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
-  const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
-  Camera cam = load_camera(viewmat, K);
-  project_one_vjp(m, q, s, cam, W, H, eps2d, v_means2d[g * 2], v_means2d[g * 2 + 1], v_depths[g], v_conics[g * 3], v_conics[g * 3 + 1],
-                  v_conics[g * 3 + 2], pg);
-  const float o = opacities[g];
-  const float al = v_opacities[g] * o * (1.f - o);
-  for (int i = 0; i < 3; i++) {
-    const float a = pg.v_mean[i], b = pg.v_scale[i] * s[i];
-    v_means[g * 3 + i] = kAcc ? v_means[g * 3 + i] + a : a;
-    v_log_scales[g * 3 + i] = kAcc ? v_log_scales[g * 3 + i] + b : b;
-  }
-  for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = kAcc ? v_quats[g * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
-  v_logits[g] = kAcc ? v_logits[g] + al : al;
-}
-
-// the same for the VISIBLE Gaussians only: rows of culled Gaussians are not touched (persistent gradient buffers kept zero by the
-// caller, or several views accumulated into one buffer: kAcc adds instead of storing) -- see sh_view_bwd_rows_kernel
-template <bool kAcc, bool kPose>
-__global__ __launch_bounds__(kProjBlock) void project_view_bwd_rows_kernel(
-    int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
-    const float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
-    float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
-    const float *__restrict__ v_conics, const float *__restrict__ v_opacities, float *__restrict__ v_means,
-    float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat) {
-  __shared__ float red[kProjBlock / kWave][12];
-  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
-  ProjGrad pg;
-  for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
-  for (int i = 0; i < 3; i++) pg.v_t[i] = 0.f;
-  if (g < N && radii[g] > 0) rows_body<kAcc>(g, means, quats, scales, opacities, viewmat, K, W, H, eps2d, v_means2d, v_depths, v_conics,
-                                             v_opacities, v_means, v_quats, v_log_scales, v_logits, pg);
-  if (kPose) pose_grad_reduce(pg, red, v_viewmat);
+  if (kPose) pose_grad_reduce(pg, red, v_viewmat_slots);
 }
 
 }  // namespace bds
@@ -276,45 +244,27 @@ extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *
   return BDS_OK;
 }
 
-extern "C" int bds_project_view_bwd(int64_t N, const float *means, const float *quats, const float *scales,
-                                    const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
-                                    const int32_t *radii, const float *v_means2d, const float *v_depths, const float *v_conics,
-                                    const float *v_opacities, float *v_means, float *v_quats, float *v_log_scales,
-                                    float *v_logits, float *v_viewmat, bds_stream_t stream) {
-  BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
-  if (v_viewmat && hipMemsetAsync(v_viewmat, 0, sizeof(float) * 16, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
-  if (N == 0) return BDS_OK;
-  BDS_REQUIRE(means && quats && scales && opacities && viewmat && K && radii && v_means2d && v_depths && v_conics &&
-              v_opacities && v_means && v_quats && v_log_scales && v_logits);
-  const dim3 grid((unsigned)cdiv(N, kProjBlock)), block(kProjBlock);
-  if (v_viewmat)
-    hipLaunchKernelGGL((project_view_bwd_kernel<true>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities, viewmat, K,
-                       W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits, v_viewmat);
-  else
-    hipLaunchKernelGGL((project_view_bwd_kernel<false>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities, viewmat, K,
-                       W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales, v_logits, v_viewmat);
-  BDS_LAUNCH_CHECK();
-  return BDS_OK;
-}
-
-extern "C" int bds_project_view_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
-                                         const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
-                                         const int32_t *radii, const float *v_means2d, const float *v_depths, const float *v_conics,
-                                         const float *v_opacities, float *v_means, float *v_quats, float *v_log_scales,
-                                         float *v_logits, float *v_viewmat, int accumulate, bds_stream_t stream) {
-  BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
-  if (v_viewmat && hipMemsetAsync(v_viewmat, 0, sizeof(float) * 16, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
-  if (N == 0) return BDS_OK;
-  BDS_REQUIRE(means && quats && scales && opacities && viewmat && K && radii && v_means2d && v_depths && v_conics &&
-              v_opacities && v_means && v_quats && v_log_scales && v_logits);
-  const dim3 grid((unsigned)cdiv(N, kProjBlock)), block(kProjBlock);
-#define BDS_ROWS(A, P)                                                                                                               \
-  hipLaunchKernelGGL((project_view_bwd_rows_kernel<A, P>), grid, block, 0, as_stream(stream), N, means, quats, scales, opacities,   \
-                     viewmat, K, W, H, eps2d, radii, v_means2d, v_depths, v_conics, v_opacities, v_means, v_quats, v_log_scales,     \
-                     v_logits, v_viewmat)
-  if (accumulate) { if (v_viewmat) BDS_ROWS(true, true); else BDS_ROWS(true, false); }
-  else            { if (v_viewmat) BDS_ROWS(false, true); else BDS_ROWS(false, false); }
-#undef BDS_ROWS
+extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats,
+                                         const float *scales, const float *opacities, const float *viewmat, const float *K, int W,
+                                         int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
+                                         float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
+                                         float *absgrad2d, int accumulate, bds_stream_t stream) {
+  BDS_REQUIRE(n_list >= 0 && W > 0 && H > 0);
+  if (v_viewmat_slots &&
+      hipMemsetAsync(v_viewmat_slots, 0, sizeof(float) * 16 * BDS_POSE_GRAD_SLOTS, as_stream(stream)) != hipSuccess)
+    return BDS_ELAUNCH;
+  if (n_list == 0) return BDS_OK;
+  BDS_REQUIRE(ids && means && quats && scales && opacities && viewmat && K && v_records && aligned16(v_records) && v_means &&
+              v_quats && v_log_scales && v_logits);
+  const dim3 grid((unsigned)cdiv(n_list, kProjBlock)), block(kProjBlock);
+  const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
+#define BDS_LIST(A, P)                                                                                                         \
+  hipLaunchKernelGGL((project_view_bwd_list_kernel<A, P>), grid, block, 0, as_stream(stream), n_list, ids, means, quats, scales, \
+                     opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d,   \
+                     absgrad2d)
+  if (accumulate) { if (v_viewmat_slots) BDS_LIST(true, true); else BDS_LIST(true, false); }
+  else            { if (v_viewmat_slots) BDS_LIST(false, true); else BDS_LIST(false, false); }
+#undef BDS_LIST
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

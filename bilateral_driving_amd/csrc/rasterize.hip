@@ -3,20 +3,36 @@
 // /root/reference/project/models/trainers/base.py:393-408 (render_mode "RGB+ED" -> CH = 4,
 // viewer "RGB" -> CH = 3).
 //
-// Mapping (gfx950): ONE wave64 per 16x16 tile, four pixels per lane (lane l: column l % 16, rows
-// l / 16 + 4q): the tile's depth-ordered Gaussians are staged through LDS in chunks of 64 (one gathered
-// Gaussian per lane, next chunk prefetched into registers), then every lane walks the chunk reading LDS
-// at a wave-uniform address (broadcast reads); dx and the x-terms of the quadratic form are shared by the
-// lane's four pixels.  Early termination: a pixel stops at T*(1-a) <= 1e-4, the wave leaves once all its
-// pixels are done (ballot).  Workgroup ids are remapped so that each XCD rasterises one contiguous band of
-// the image (its private L2 then serves the re-reads of Gaussians shared by neighbouring tiles).
+// Data (gfx950): the compositor reads SPLAT RECORDS -- one 48-byte record per (camera, Gaussian), or per visible
+// Gaussian in depth-rank order -- through the per-tile index lists: one record is one or two cache lines instead of
+// four gathers from four arrays.  A record is 3 x float4:
+//     (mean2d.x, mean2d.y, ea, eb) (ec, opacity, colour0, colour1) (colour2, colour3, -, -)
+// with the conic pre-scaled into the exponent's base-2 units, (ea, eb, ec) = -log2(e) * (a/2, b, c/2), so that
+// alpha = opacity * 2^(ea dx^2 + eb dx dy + ec dy^2): one multiply per (pixel, Gaussian) less than exp(-sigma), in both
+// directions, with the forward and the backward taking bit-identical alpha decisions.
+// The backward accumulates into GRADIENT RECORDS of 16 floats (64-byte aligned: colour 0-3 | conic a,b,c 4-6 | mean2d 7-8 |
+// |mean2d| 9-10 (absgrad) | opacity 11): the 12 lanes that commit a (tile, Gaussian) pair's sums hit ONE 64-byte segment
+// (measured on MI355X, scripts/ubench/valu_rate.hip: 4.1x the atomic throughput of five separate arrays).
+//
+// Mapping: ONE wave64 per 16x16 tile, four pixels per lane (lane l: column l % 16, rows l / 16 + 4q): the tile's
+// depth-ordered list is staged through LDS in chunks of 64 (one record per lane, next chunk prefetched into registers),
+// then every lane walks the chunk reading LDS at a wave-uniform address (broadcast reads); dx and the x-terms of the
+// quadratic form are shared by the lane's four pixels.  Early termination: a pixel stops at T*(1-a) <= 1e-4, the wave
+// leaves once all its pixels are done (ballot).  Both kernels are bound by VALU issue (SQ counters: ~100 % VALU busy), so the
+// inner loops are written branch-free per pixel: a pixel that does not blend a Gaussian runs the same instructions with
+// alpha = 0 (exec-masked branches cost the compiler ~50 register copies per pair for the accumulator phis).
+// Workgroup ids are remapped so that each XCD rasterises one contiguous band of the image (its private L2 then serves
+// the re-reads of records shared by neighbouring tiles).
 #include "bds_common.h"
 #include "gs_math.h"
 
 namespace bds {
 
 constexpr int kTile = 16;
-constexpr int kRastBlock = kTile * kTile;  // 256
+constexpr int kPackBlock = 256;
+constexpr int kGradStride = BDS_GRAD_RECORD_FLOATS;  // 16
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
@@ -31,47 +47,36 @@ __device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int 
   return order ? order[p] : p;
 }
 
-// value slots of the per-Gaussian gradient record that is reduced over a tile's pixels
-//   0-3 colour, 4-6 conic, 7-8 mean2d, 9-10 |mean2d| (absgrad), 11 opacity
-struct GradTarget {
-  float *ptr;   // nullptr: this lane does not commit anything
-  int stride;
-};
-template <int CH, bool ABS>
-__device__ __forceinline__ GradTarget grad_target(int lane, float *v_means2d, float *v_means2d_abs, float *v_conics,
-                                                  float *v_colors, float *v_opacities) {
-  GradTarget g{nullptr, 0};
-  if (lane & 3) return g;  // one committing lane per quad
-  const int k = butterfly_slot(lane);
-  if (k < 4) { if (k < CH) { g.ptr = v_colors + k; g.stride = CH; } }
-  else if (k < 7) { g.ptr = v_conics + (k - 4); g.stride = 3; }
-  else if (k < 9) { g.ptr = v_means2d + (k - 7); g.stride = 2; }
-  else if (k < 11) { if (ABS) { g.ptr = v_means2d_abs + (k - 9); g.stride = 2; } }
-  else if (k == 11) { g.ptr = v_opacities; g.stride = 1; }
-  return g;
-}
-
+// ---- splat records --------------------------------------------------------------------------------------
+// rec[r] = record of entry ids[r] (ids == null: r itself) of the per-(camera, Gaussian) arrays
 template <int CH>
-__device__ __forceinline__ void stage_gaussian(int32_t g, const float *__restrict__ means2d,
-                                               const float *__restrict__ conics, const float *__restrict__ colors,
-                                               const float *__restrict__ opacities, float4 &A, float4 &B, float4 &Cc) {
-  const float2 xy = *reinterpret_cast<const float2 *>(means2d + (int64_t)g * 2);
-  const float *cn = conics + (int64_t)g * 3;
-  const float *cl = colors + (int64_t)g * CH;
-  A = make_float4(xy.x, xy.y, cn[0], cn[1]);
-  B = make_float4(cn[2], opacities[g], cl[0], CH > 1 ? cl[CH > 1 ? 1 : 0] : 0.f);
-  Cc = make_float4(CH > 2 ? cl[CH > 2 ? 2 : 0] : 0.f, CH > 3 ? cl[CH > 3 ? 3 : 0] : 0.f, 0.f, 0.f);
+__global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n, const int32_t *__restrict__ ids,
+                                                               const float *__restrict__ means2d, const float *__restrict__ conics,
+                                                               const float *__restrict__ colors, const float *__restrict__ opacities,
+                                                               float4 *__restrict__ rec) {
+  const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
+  if (r >= n) return;
+  const int64_t g = ids ? (int64_t)ids[r] : r;
+  const float2 xy = *reinterpret_cast<const float2 *>(means2d + g * 2);
+  const float *cn = conics + g * 3;
+  const float *cl = colors + g * CH;
+  rec[r * 3] = make_float4(xy.x, xy.y, (-0.5f * kLog2e) * cn[0], -kLog2e * cn[1]);
+  rec[r * 3 + 1] = make_float4((-0.5f * kLog2e) * cn[2], opacities[g], cl[0], CH > 1 ? cl[CH > 1 ? 1 : 0] : 0.f);
+  rec[r * 3 + 2] = make_float4(CH > 2 ? cl[CH > 2 ? 2 : 0] : 0.f, CH > 3 ? cl[CH > 3 ? 3 : 0] : 0.f, 0.f, 0.f);
 }
 
-// ---- forward, one wave64 per 16x16 tile, four pixels per lane ------------------------------------
-// Same pixel ownership as the backward wave kernel (lane l: column l % 16, rows (l / 16) + 4q): the
-// Gaussian record is read from LDS once per four pixels and dx / a*dx^2 / b*dx are shared.
+// exponent (base 2) of a Gaussian at a pixel of the lane's column: ea dx^2 + (ec dy + eb dx) dy, <= 0 for a valid conic.
+// ONE definition shared by the forward and the backward: their alpha decisions have to agree bit for bit.
+__device__ __forceinline__ float splat_exponent(float eadx2, float ebdx, float ec, float dy) {
+  return __builtin_fmaf(__builtin_fmaf(ec, dy, ebdx), dy, eadx2);
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------
 template <int CH>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
-    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
-    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
+    int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, float *__restrict__ render,
+    float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   const int n_tiles = tile_w * tile_h;
   const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
@@ -85,20 +90,25 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
   // T[q] > 0: running transmittance; T[q] < 0: the pixel is finished and |T[q]| is its final transmittance
   // (pixels outside the image start finished).  One register instead of a flag + a value per pixel.
-  float T[4];
+  float T[4], pyc[4];
   int cur[4] = {0, 0, 0, 0};
   float out[4][4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     T[q] = ((i0 + 4 * q) < H && j < W) ? 1.f : -1.f;
+    pyc[q] = (float)(i0 + 4 * q) + 0.5f;
 #pragma unroll
     for (int k = 0; k < 4; k++) out[q][k] = 0.f;
   }
   const int nbatch = (end - start + kWave - 1) / kWave;
   // the next chunk's records are fetched into registers while the current chunk is blended, so the
-  // two dependent gather latencies (id -> attributes) are off the critical path of this single-wave workgroup
+  // two dependent gather latencies (index -> record) are off the critical path of this single-wave workgroup
   float4 pA = make_float4(0.f, 0.f, 0.f, 0.f), pB = pA, pC = pA;
-  if (start + lane < end) stage_gaussian<CH>(flatten_ids[start + lane], means2d, conics, colors, opacities, pA, pB, pC);
+  if (start + lane < end) {
+    const int64_t r = flatten[start + lane];
+    pA = rec[r * 3]; pB = rec[r * 3 + 1];
+    if (CH > 2) pC = rec[r * 3 + 2];
+  }
   for (int b = 0; b < nbatch; b++) {
     if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
     __syncthreads();
@@ -108,22 +118,25 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       if (CH > 2) sC[lane] = pC;
     }
     __syncthreads();
-    if (bstart + kWave + lane < end)
-      stage_gaussian<CH>(flatten_ids[bstart + kWave + lane], means2d, conics, colors, opacities, pA, pB, pC);
+    if (bstart + kWave + lane < end) {
+      const int64_t r = flatten[bstart + kWave + lane];
+      pA = rec[r * 3]; pB = rec[r * 3 + 1];
+      if (CH > 2) pC = rec[r * 3 + 2];
+    }
     const int bs = min(kWave, end - bstart);
     for (int t = 0; t < bs; t++) {
       if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;
-      const float hax2 = 0.5f * A.z * dx * dx, bdx = A.w * dx;
+      const float ebdx = A.w * dx, eadx2 = A.z * dx * dx;
       float4 Cc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (CH > 2) Cc = sC[t];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const float dy = A.y - ((float)(i0 + 4 * q) + 0.5f);
-        const float sigma = hax2 + (0.5f * B.x * dy + bdx) * dy;
-        const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
-        const bool hit = T[q] > 0.f && !(sigma < 0.f || alpha < kAlphaMin);
+        const float e = splat_exponent(eadx2, ebdx, B.x, A.y - pyc[q]);
+        const float ov = B.y * __builtin_amdgcn_exp2f(e);
+        const float alpha = fminf(kAlphaMax, ov);
+        const bool hit = T[q] > 0.f && !(e > 0.f || ov < kAlphaMin);
         const float nT = T[q] * (1.f - alpha);
         if (hit && nT <= kTStop) T[q] = -T[q];
         else if (hit) {
@@ -153,20 +166,17 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   }
 }
 
-// ---- backward, one wave64 per 16x16 tile, four pixels per lane ------------------------------------
-// Lane l owns column l % 16 and rows (l / 16) + 4q, q = 0..3: the four pixels share dx, and their
-// partial gradients are summed in registers before the single 16-value transpose-reduce, so the
-// cross-lane work and the atomics are paid once per (Gaussian, tile) instead of once per wave.
-// Strip q (rows 4q..4q+3) is skipped as a whole when none of its 64 pixels needs the Gaussian.
+// ---- backward -----------------------------------------------------------------------------------------------
+// Lane l owns column l % 16 and rows (l / 16) + 4q, q = 0..3.  The four pixels share dx, so the conic / mean gradients
+// need only three per-lane moments of d(loss)/d(sigma) (S0 = sum vs, S1 = sum vs dy, S2 = sum vs dy^2) that are expanded
+// once per (lane, Gaussian); 12 per-lane sums then go through ONE 16-value transpose-reduce and 12 lanes commit them to the
+// Gaussian's gradient record.  The list is replayed back to front from the tile's deepest blended entry.
 template <int CH, bool ABS>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
-    int C, int64_t N, int64_t M, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int W,
-    int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs,
-    float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
-    const int32_t *__restrict__ tile_order) {
+    int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas,
+    const int32_t *__restrict__ last_ids, const float *__restrict__ v_render, const float *__restrict__ v_alphas,
+    float *__restrict__ v_rec, const int32_t *__restrict__ tile_order) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   const int n_tiles = tile_w * tile_h;
@@ -180,43 +190,47 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   const int j = tx * kTile + (lane & 15);
   const float px = (float)j + 0.5f;
   const int i0 = ty * kTile + (lane >> 4);
-  bool inside[4];
   // Bd[q] = sum_k buffer_k * v_render_k - T_final * (v_alpha - bg . v_render): the only combination of the accumulated
-  // colour `buffer` that the gradient needs, kept as ONE scalar per pixel (saves 16 VGPRs and 5 VALU ops per pixel-pair)
-  float T[4], Bd[4], vr[4][4];
+  // colour `buffer` that the gradient needs, kept as ONE scalar per pixel
+  float T[4], Bd[4], vr[4][4], pyc[4];
   int bin_final[4];
-  int max_bin = 0;
+  int max_bin = -1;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int i = i0 + 4 * q;
-    inside[q] = i < H && j < W;
-    const int64_t pix = ((int64_t)cam * H + (inside[q] ? i : 0)) * W + (inside[q] ? j : 0);
-    const float T_final = inside[q] ? 1.f - alphas[pix] : 1.f;
+    const bool inside = i < H && j < W;
+    pyc[q] = (float)i + 0.5f;
+    const int64_t pix = ((int64_t)cam * H + (inside ? i : 0)) * W + (inside ? j : 0);
+    const float T_final = inside ? 1.f - alphas[pix] : 1.f;
     T[q] = T_final;
-    bin_final[q] = inside[q] ? last_ids[pix] : -1;   // -1: never valid (pixel outside the image)
+    bin_final[q] = inside ? last_ids[pix] : -1;   // -1: never valid (pixel outside the image)
     max_bin = max(max_bin, bin_final[q]);
-    const float vra = inside[q] ? v_alphas[pix] : 0.f;
+    const float vra = inside ? v_alphas[pix] : 0.f;
     float bgdot = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      vr[q][k] = (k < CH && inside[q]) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
+      vr[q][k] = (k < CH && inside) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
       if (backgrounds && k < CH) bgdot += backgrounds[cam * CH + k] * vr[q][k];
     }
     Bd[q] = -T_final * (vra - bgdot);
   }
   const int tile_bin_final = wave_max_i32(max_bin);
-  const GradTarget tgt = grad_target<CH, ABS>(lane, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
-  const int py0 = i0;
+  if (tile_bin_final < start) return;   // no pixel of this tile blended anything (last_ids stays 0 then)
+  // gradient-record slot this lane commits after the transpose-reduce (one committing lane per quad)
+  const int slot = butterfly_slot(lane);
+  const bool commit = ((lane & 3) == 0) && (slot < 4 ? slot < CH : (slot < 12 && (ABS || (slot != 9 && slot != 10))));
+  float *const tgt = v_rec + slot;
   const int nbatch = (end - start + kWave - 1) / kWave;
   const int b0 = (end - 1 - tile_bin_final) / kWave;  // chunks in front of it lie behind every pixel's last Gaussian
-  // register prefetch of the next chunk (see the forward wave kernel)
+  // register prefetch of the next chunk (see the forward kernel)
   int32_t pg = 0;
   float4 pA = make_float4(0.f, 0.f, 0.f, 0.f), pB = pA, pC = pA;
   {
     const int idx = end - 1 - kWave * b0 - lane;
     if (idx >= start) {
-      pg = flatten_ids[idx];
-      stage_gaussian<CH>(pg, means2d, conics, colors, opacities, pA, pB, pC);
+      pg = flatten[idx];
+      pA = rec[(int64_t)pg * 3]; pB = rec[(int64_t)pg * 3 + 1];
+      if (CH > 2) pC = rec[(int64_t)pg * 3 + 2];
     }
   }
   for (int b = b0; b < nbatch; b++) {
@@ -231,65 +245,74 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     {
       const int idx = batch_end - kWave - lane;
       if (idx >= start) {
-        pg = flatten_ids[idx];
-        stage_gaussian<CH>(pg, means2d, conics, colors, opacities, pA, pB, pC);
+        pg = flatten[idx];
+        pA = rec[(int64_t)pg * 3]; pB = rec[(int64_t)pg * 3 + 1];
+        if (CH > 2) pC = rec[(int64_t)pg * 3 + 2];
       }
     }
     for (int t = max(0, batch_end - tile_bin_final); t < bs; t++) {
+      const int gidx = batch_end - t;   // position of this entry in the list
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;
-      const float opac = B.y;
-      const float hax2 = 0.5f * A.z * dx * dx, bdx = A.w * dx;
-      float dy[4], vis[4], alpha[4];
+      const float opac = B.y, ec = B.x;
+      const float eadx = A.z * dx, ebdx = A.w * dx;
+      const float eadx2 = eadx * dx;
+      float e[4], vis[4], ov[4];
       bool valid[4];
       bool any = false;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        dy[q] = A.y - ((float)(py0 + 4 * q) + 0.5f);
-        const float sigma = hax2 + (0.5f * B.x * dy[q] + bdx) * dy[q];
-        vis[q] = __expf(-sigma);
-        alpha[q] = fminf(kAlphaMax, opac * vis[q]);
-        valid[q] = (batch_end - t <= bin_final[q]) && !(sigma < 0.f || alpha[q] < kAlphaMin);
+        e[q] = splat_exponent(eadx2, ebdx, ec, A.y - pyc[q]);
+        vis[q] = __builtin_amdgcn_exp2f(e[q]);
+        ov[q] = opac * vis[q];
+        valid[q] = (gidx <= bin_final[q]) && !(e[q] > 0.f || ov[q] < kAlphaMin);
         any |= valid[q];
       }
       if (!__any(any)) continue;
       float col[4] = {B.z, B.w, 0.f, 0.f};
       if (CH > 2) { const float4 Cc = sC[t]; col[2] = Cc.x; col[3] = Cc.y; }
-      float acc[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) acc[k] = 0.f;
+      const float two_eadx = eadx + eadx, two_ec = ec + ec;
+      // per-lane sums over the four pixels (branch-free: a pixel that did not blend this Gaussian contributes alpha = 0)
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, ax = 0.f, ay = 0.f, go = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        if (!__any(valid[q])) continue;  // strip-uniform skip
-        if (valid[q]) {
-          const float ra = __builtin_amdgcn_rcpf(1.f - alpha[q]);
-          T[q] *= ra;
-          const float fac = alpha[q] * T[q];
-          float cdot = 0.f;  // colour . v_render
-#pragma unroll
-          for (int k = 0; k < CH; k++) {
-            acc[k] += fac * vr[q][k];
-            cdot += col[k] * vr[q][k];
-          }
-          const float v_alpha = T[q] * cdot - ra * Bd[q];
-          Bd[q] += fac * cdot;
-          if (opac * vis[q] <= kAlphaMax) {
-            const float v_sigma = -opac * vis[q] * v_alpha;
-            const float t1 = v_sigma * dx, t2 = v_sigma * dy[q];
-            acc[4] += t1 * dx;      // x 0.5 after the strip loop
-            acc[5] += t1 * dy[q];
-            acc[6] += t2 * dy[q];   // x 0.5 after the strip loop
-            const float gx = A.z * t1 + A.w * t2;
-            const float gy = A.w * t1 + B.x * t2;
-            acc[7] += gx; acc[8] += gy;
-            if (ABS) { acc[9] += fabsf(gx); acc[10] += fabsf(gy); }
-            acc[11] += vis[q] * v_alpha;
-          }
+        const float dy = A.y - pyc[q];
+        const float am = valid[q] ? fminf(kAlphaMax, ov[q]) : 0.f;
+        const float vm = (valid[q] && ov[q] <= kAlphaMax) ? vis[q] : 0.f;   // the 0.999 clamp passes no gradient
+        const float ra = __builtin_amdgcn_rcpf(1.f - am);                   // exactly 1 for am = 0
+        T[q] *= ra;
+        const float fac = am * T[q];
+        float cdot = col[0] * vr[q][0];   // colour . v_render
+        g0 = __builtin_fmaf(fac, vr[q][0], g0);
+        if (CH > 1) { cdot = __builtin_fmaf(col[1], vr[q][1], cdot); g1 = __builtin_fmaf(fac, vr[q][1], g1); }
+        if (CH > 2) { cdot = __builtin_fmaf(col[2], vr[q][2], cdot); g2 = __builtin_fmaf(fac, vr[q][2], g2); }
+        if (CH > 3) { cdot = __builtin_fmaf(col[3], vr[q][3], cdot); g3 = __builtin_fmaf(fac, vr[q][3], g3); }
+        const float v_alpha = __builtin_fmaf(-ra, Bd[q], T[q] * cdot);
+        Bd[q] = __builtin_fmaf(fac, cdot, Bd[q]);
+        const float vs = -(opac * vm) * v_alpha;   // d(loss)/d(sigma), sigma = -ln2 * e
+        S0 += vs;
+        S1 = __builtin_fmaf(vs, dy, S1);
+        S2 = __builtin_fmaf(vs * dy, dy, S2);
+        if (ABS) {
+          ax = __builtin_fmaf(fabsf(vs), fabsf(__builtin_fmaf(A.w, dy, two_eadx)), ax);
+          ay = __builtin_fmaf(fabsf(vs), fabsf(__builtin_fmaf(two_ec, dy, ebdx)), ay);
         }
+        go = __builtin_fmaf(vm, v_alpha, go);
       }
-      acc[4] *= 0.5f; acc[6] *= 0.5f;
+      // expand the moments: d sigma / d (a, b, c) = (dx^2 / 2, dx dy, dy^2 / 2); d sigma / d mean = -ln2 * d e / d (dx, dy)
+      float acc[16];
+      acc[0] = g0; acc[1] = g1; acc[2] = g2; acc[3] = g3;
+      const float dxS0 = dx * S0;
+      acc[4] = 0.5f * dx * dxS0;
+      acc[5] = dx * S1;
+      acc[6] = 0.5f * S2;
+      acc[7] = -kLn2 * __builtin_fmaf(two_eadx, S0, A.w * S1);
+      acc[8] = -kLn2 * __builtin_fmaf(A.w, dxS0, two_ec * S1);
+      acc[9] = kLn2 * ax; acc[10] = kLn2 * ay;
+      acc[11] = go;
+      acc[12] = acc[13] = acc[14] = acc[15] = 0.f;
       const float tot = butterfly_sum16(acc, lane);
-      if (tgt.ptr != nullptr) atomicAdd(tgt.ptr + (int64_t)sId[t] * tgt.stride, tot);
+      if (commit) atomicAdd(tgt + (int64_t)sId[t] * kGradStride, tot);
     }
   }
 }
@@ -300,12 +323,13 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
 // leave most SIMDs idle at the end of the launch.  The visited length of every tile is known exactly after the
 // forward pass (max last_id - list start); dispatching each XCD's contiguous range longest-first (LPT rule)
 // removes that tail while keeping the range -> XCD assignment (L2 locality) unchanged.
-__global__ __launch_bounds__(kRastBlock) void tile_work_kernel(int C, int W, int H, int tile_w, int tile_h,
+constexpr int kWorkBlock = 256;
+__global__ __launch_bounds__(kWorkBlock) void tile_work_kernel(int C, int W, int H, int tile_w, int tile_h,
                                                                const int32_t *__restrict__ offsets,
                                                                const int32_t *__restrict__ last_ids,
                                                                int32_t *__restrict__ work) {
   const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-  const int item = blockIdx.x * (kRastBlock / kWave) + (threadIdx.x >> 6);
+  const int item = blockIdx.x * (kWorkBlock / kWave) + (threadIdx.x >> 6);
   if (item >= total) return;
   const int lane = threadIdx.x & 63;
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
@@ -366,55 +390,64 @@ __global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, co
 
 using namespace bds;
 
-extern "C" int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
-                                 const float *colors, const float *opacities, const float *backgrounds, int W, int H,
-                                 int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                                 const int32_t *flatten_ids, float *render, float *alphas, int32_t *last_ids,
-                                 bds_stream_t stream) {
-  BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && W > 0 && H > 0);
-  BDS_REQUIRE(tile_size == kTile);
-  BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
-  BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
-  BDS_REQUIRE(isect_offsets && render && alphas && last_ids);
-  BDS_REQUIRE(M == 0 || (means2d && conics && colors && opacities && flatten_ids));
+extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
+                              const float *opacities, float *records, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && (CH == 1 || CH == 3 || CH == 4));
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(means2d && conics && colors && opacities && records && aligned16(records));
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
-  const dim3 grid((unsigned)(C * tile_w * tile_h));
+  const dim3 grid((unsigned)cdiv(n, kPackBlock)), block(kPackBlock);
+  float4 *rec = reinterpret_cast<float4 *>(records);
   hipStream_t st = as_stream(stream);
-#define BDS_FWD_ARGS                                                                                                   \
-  C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, render,  \
-      alphas, last_ids
-#define BDS_FWD(ch) hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, BDS_FWD_ARGS)
-  if (CH == 1) BDS_FWD(1);
-  else if (CH == 3) BDS_FWD(3);
-  else BDS_FWD(4);
-#undef BDS_FWD
-#undef BDS_FWD_ARGS
+  if (CH == 1) hipLaunchKernelGGL((splat_pack_kernel<1>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, rec);
+  else if (CH == 3) hipLaunchKernelGGL((splat_pack_kernel<3>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, rec);
+  else hipLaunchKernelGGL((splat_pack_kernel<4>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, rec);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
 
-extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
-                                 const float *colors, const float *opacities, const float *backgrounds, int W, int H,
-                                 int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                                 const int32_t *flatten_ids, const float *alphas, const int32_t *last_ids,
-                                 const float *v_render, const float *v_alphas, float *v_means2d, float *v_means2d_abs,
-                                 float *v_conics, float *v_colors, float *v_opacities, const int32_t *tile_order,
+extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
+                                 int W, int H, int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                                 const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream) {
+  BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
+  BDS_REQUIRE(tile_size == kTile);
+  BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
+  BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
+  BDS_REQUIRE(isect_offsets && render && alphas && last_ids);
+  BDS_REQUIRE(M == 0 || (records && flatten && aligned16(records)));
+  const dim3 grid((unsigned)(C * tile_w * tile_h));
+  hipStream_t st = as_stream(stream);
+  const float4 *rec = reinterpret_cast<const float4 *>(records);
+#define BDS_FWD(ch)                                                                                                           \
+  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
+                     isect_offsets, flatten, render, alphas, last_ids)
+  if (CH == 1) BDS_FWD(1);
+  else if (CH == 3) BDS_FWD(3);
+  else BDS_FWD(4);
+#undef BDS_FWD
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
+                                 int W, int H, int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                                 const int32_t *flatten, const float *alphas, const int32_t *last_ids, const float *v_render,
+                                 const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order,
                                  bds_stream_t stream) {
-  BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && W > 0 && H > 0);
+  BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
   BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
   if (M == 0) return BDS_OK;
-  BDS_REQUIRE(means2d && conics && colors && opacities && isect_offsets && flatten_ids && alphas && last_ids &&
-              v_render && v_alphas && v_means2d && v_conics && v_colors && v_opacities);
-  BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
+  BDS_REQUIRE(records && isect_offsets && flatten && alphas && last_ids && v_render && v_alphas && v_records);
+  BDS_REQUIRE(aligned16(records) && aligned16(v_records));
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
-#define BDS_BWD_ARGS                                                                                                   \
-  C, N, M, means2d, conics, colors, opacities, backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten_ids, alphas,  \
-      last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, tile_order
-#define BDS_BWD(ch, ab) hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, BDS_BWD_ARGS)
-  if (v_means2d_abs) {
+  const float4 *rec = reinterpret_cast<const float4 *>(records);
+#define BDS_BWD(ch, ab)                                                                                                       \
+  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
+                     isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order)
+  if (absgrad) {
     if (CH == 1) BDS_BWD(1, true);
     else if (CH == 3) BDS_BWD(3, true);
     else BDS_BWD(4, true);
@@ -424,7 +457,6 @@ extern "C" int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const floa
     else BDS_BWD(4, false);
   }
 #undef BDS_BWD
-#undef BDS_BWD_ARGS
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -439,8 +471,8 @@ extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, in
   const int total = C * tile_w * tile_h;
   hipStream_t st = as_stream(stream);
   int32_t *work = tile_order + total;   // second half of the caller's buffer
-  constexpr int per_block = kRastBlock / kWave;
-  hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(kRastBlock), 0, st, C, W,
+  constexpr int per_block = kWorkBlock / kWave;
+  hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(kWorkBlock), 0, st, C, W,
                      H, tile_w, tile_h, isect_offsets, last_ids, work);
   hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, st, total, work, tile_order);
   BDS_LAUNCH_CHECK();

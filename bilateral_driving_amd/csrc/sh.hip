@@ -221,135 +221,101 @@ __global__ __launch_bounds__(kShBlock) void sh_view_fwd_kernel(int64_t n, int K,
                           fminf(fmaxf(o2 + 0.5f, 0.f), 1.f), depths[g]);
 }
 
-template <int DEG, bool kFull>
-__global__ __launch_bounds__(kShBlock) void sh_view_bwd_kernel(int64_t n, int K, const float *__restrict__ means,
-                                                              const float *__restrict__ cam_pos,
-                                                              const int32_t *__restrict__ radii,
-                                                              const float *__restrict__ sh_rgb,
-                                                              const float4 *__restrict__ v_colors,
-                                                              float *__restrict__ v_coeffs, float *__restrict__ v_depths) {
+// ---- backward over the VISIBLE Gaussians, list-driven -----------------------------------------------------------------------
+// A view sees ~15 % of the Gaussians; the dense form streams 192 B of zeros for every culled one.  Here the work list is the
+// depth-ordered id list of the visible entries (bds_isect_build: visible_ids) and the input is the compositor's gradient record of
+// the same rank (colour gradient = floats 0-2 of the 64-byte record, read fully coalesced).  A workgroup stages its 256 rows in LDS
+// and writes each as whole 16-byte pieces, 12 lanes per 192-byte row.  kAcc = false stores the rows (every other row of v_coeffs is
+// the caller's business: zero-filled, or kept zero by bds_view_grads_clear_list), kAcc = true adds to them (several views summed
+// into one buffer before one exchange).
+template <int DEG, bool kVec, bool kAcc>
+__global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_list, const int32_t *__restrict__ ids, int K,
+                                                                   const float *__restrict__ means,
+                                                                   const float *__restrict__ cam_pos,
+                                                                   const float *__restrict__ sh_rgb,
+                                                                   const float4 *__restrict__ v_rec, float *__restrict__ v_coeffs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int32_t s_g[kShBlock];
   constexpr int nb = (DEG + 1) * (DEG + 1);
   const int row = K * 3;
   const int ldr = row + 1;
-  const int64_t g0 = (int64_t)blockIdx.x * kShBlock;
-  const int cnt = (int)min((int64_t)kShBlock, n - g0);
+  const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
+  const int cnt = (int)min((int64_t)kShBlock, n_list - r0);
   const int tid = threadIdx.x;
   if (tid < cnt) {
-    const int64_t g = g0 + tid;
-    float *c = lds + tid * ldr;
-    const bool on = radii[g] > 0;
-    const float4 v = v_colors[g];
-    v_depths[g] = v.w;
+    const int64_t g = ids[r0 + tid];
+    s_g[tid] = (int32_t)g;
+    const float4 v = v_rec[(r0 + tid) * (BDS_GRAD_RECORD_FLOATS / 4)];
     float vo[3] = {v.x, v.y, v.z};
-    float B[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) B[k] = 0.f;
-    if (on) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const float x = sh_rgb[g * 3 + k] + 0.5f;
-        if (!(x >= 0.f && x <= 1.f)) vo[k] = 0.f;   // torch.clamp passes the gradient on the closed interval
-      }
-      const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
-      const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
-      sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+    for (int k = 0; k < 3; k++) {
+      const float x = sh_rgb[g * 3 + k] + 0.5f;
+      if (!(x >= 0.f && x <= 1.f)) vo[k] = 0.f;   // torch.clamp passes the gradient on the closed interval
     }
+    const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
+    const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+    float B[16];
+    sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+    float *c = lds + tid * ldr;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       if (k < K) {
-        const float b = (on && k < nb) ? B[k < nb ? k : 0] : 0.f;
+        const float b = k < nb ? B[k < nb ? k : 0] : 0.f;
         c[k * 3] = b * vo[0]; c[k * 3 + 1] = b * vo[1]; c[k * 3 + 2] = b * vo[2];
       }
     }
   }
   __syncthreads();
-  if (kFull) {
-    float4 *dst = reinterpret_cast<float4 *>(v_coeffs + g0 * row);
-    const int n4 = cnt * row / 4;
-    for (int i = tid; i < n4; i += kShBlock) {
-      const int e = i * 4;
-      const int r = e / row, cc = e - r * row;
-      const float *sp = lds + r * ldr + cc;
-      dst[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
-    }
-  } else {
-    const int tot = cnt * row;
-    for (int e = tid; e < tot; e += kShBlock) {
-      const int r = e / row, cc = e - r * row;
-      v_coeffs[g0 * row + e] = lds[r * ldr + cc];
-    }
-  }
-}
-
-// ---- gradient rows of the VISIBLE Gaussians only (persistent / accumulating gradient buffers) -------------------------------
-// The dense backward above streams 192 B of zeros for every Gaussian the view culls (~85 %).  When the caller keeps the gradient
-// buffer zero outside the rows it knows to be dirty (dist.FlatGradients(sparse_rows=True)), or accumulates several views into it,
-// only the visible rows have to be touched: kAcc = false stores them, kAcc = true adds to them.  v_depths stays dense (4 B/Gaussian,
-// it is an input of the projection backward).
-template <int DEG, bool kVec, bool kAcc>
-__global__ __launch_bounds__(kShBlock) void sh_view_bwd_rows_kernel(int64_t n, int K, const float *__restrict__ means,
-                                                                   const float *__restrict__ cam_pos,
-                                                                   const int32_t *__restrict__ radii,
-                                                                   const float *__restrict__ sh_rgb,
-                                                                   const float4 *__restrict__ v_colors,
-                                                                   float *__restrict__ v_coeffs, float *__restrict__ v_depths) {
-  constexpr int nb = (DEG + 1) * (DEG + 1);
-  const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
-  if (g >= n) return;
-  const float4 v = v_colors[g];
-  v_depths[g] = v.w;
-  if (radii[g] <= 0) return;
-  float vo[3] = {v.x, v.y, v.z};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float x = sh_rgb[g * 3 + k] + 0.5f;
-    if (!(x >= 0.f && x <= 1.f)) vo[k] = 0.f;
-  }
-  const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
-  const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
-  float B[16];
-  sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
-  float row[48];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const float b = k < nb ? B[k < nb ? k : 0] : 0.f;
-    row[k * 3] = b * vo[0]; row[k * 3 + 1] = b * vo[1]; row[k * 3 + 2] = b * vo[2];
-  }
-  float *dst = v_coeffs + g * (int64_t)K * 3;
   if (kVec) {
-#pragma unroll
-    for (int i = 0; i < 12; i++)
-      if (i * 4 < K * 3) {
-        float4 o = make_float4(row[i * 4], row[i * 4 + 1], row[i * 4 + 2], row[i * 4 + 3]);
-        if (kAcc) {
-          const float4 p = reinterpret_cast<const float4 *>(dst)[i];
-          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-        }
-        reinterpret_cast<float4 *>(dst)[i] = o;
-      }
+    const int q4 = row / 4;   // 16-byte pieces per row
+    for (int e = tid; e < cnt * q4; e += kShBlock) {
+      const int r = e / q4, cc = (e - r * q4) * 4;
+      const float *sp = lds + r * ldr + cc;
+      float4 *dst = reinterpret_cast<float4 *>(v_coeffs + (int64_t)s_g[r] * row + cc);
+      float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      if (kAcc) { const float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      *dst = o;
+    }
   } else {
-#pragma unroll
-    for (int i = 0; i < 48; i++)
-      if (i < K * 3) dst[i] = kAcc ? dst[i] + row[i] : row[i];
+    for (int e = tid; e < cnt * row; e += kShBlock) {
+      const int r = e / row, cc = e - r * row;
+      float *dst = v_coeffs + (int64_t)s_g[r] * row + cc;
+      *dst = kAcc ? *dst + lds[r * ldr + cc] : lds[r * ldr + cc];
+    }
   }
 }
 
-// zero the rows marked in `dirty` of the five per-Gaussian gradient arrays (sparse clear of a persistent buffer)
-__global__ __launch_bounds__(kShBlock) void view_grads_clear_kernel(int64_t n, int K, const uint8_t *__restrict__ dirty,
-                                                                   float *__restrict__ v_means, float *__restrict__ v_quats,
-                                                                   float *__restrict__ v_log_scales, float *__restrict__ v_logits,
-                                                                   float *__restrict__ v_sh) {
-  const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
-  if (g >= n || !dirty[g]) return;
-  for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
-  for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
-  v_logits[g] = 0.f;
-  float *dst = v_sh + g * (int64_t)K * 3;
-  if (((K * 3) & 3) == 0 && (reinterpret_cast<uintptr_t>(v_sh) & 15u) == 0) {
-    for (int i = 0; i < K * 3 / 4; i++) reinterpret_cast<float4 *>(dst)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+// zero the rows ids[0..n_list) of the five per-Gaussian gradient arrays (row-wise clear of a persistent buffer: the rows a
+// previous view wrote); v_sh rows leave as whole 16-byte pieces, 12 lanes per 192-byte row
+template <bool kVec>
+__global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t n_list, const int32_t *__restrict__ ids, int K,
+                                                                        float *__restrict__ v_means, float *__restrict__ v_quats,
+                                                                        float *__restrict__ v_log_scales, float *__restrict__ v_logits,
+                                                                        float *__restrict__ v_sh) {
+  __shared__ int32_t s_g[kShBlock];
+  const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
+  const int cnt = (int)min((int64_t)kShBlock, n_list - r0);
+  const int tid = threadIdx.x;
+  if (tid < cnt) {
+    const int64_t g = ids[r0 + tid];
+    s_g[tid] = (int32_t)g;
+    for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
+    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
+    v_logits[g] = 0.f;
+  }
+  __syncthreads();
+  const int row = K * 3;
+  if (kVec) {
+    const int q4 = row / 4;
+    for (int e = tid; e < cnt * q4; e += kShBlock) {
+      const int r = e / q4, cc = (e - r * q4) * 4;
+      *reinterpret_cast<float4 *>(v_sh + (int64_t)s_g[r] * row + cc) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   } else {
-    for (int i = 0; i < K * 3; i++) dst[i] = 0.f;
+    for (int e = tid; e < cnt * row; e += kShBlock) {
+      const int r = e / row;
+      v_sh[(int64_t)s_g[r] * row + (e - r * row)] = 0.f;
+    }
   }
 }
 
@@ -433,18 +399,6 @@ static void launch_view_fwd(bool vec, int grid, hipStream_t st, int64_t n, int K
                        depths, sh_rgb, colors);
 }
 
-template <int DEG>
-static void launch_view_bwd(bool full, int grid, size_t lds, hipStream_t st, int64_t n, int K, const float *means,
-                            const float *cam_pos, const int32_t *radii, const float *sh_rgb, const float4 *v_colors,
-                            float *v_coeffs, float *v_depths) {
-  if (full)
-    hipLaunchKernelGGL((sh_view_bwd_kernel<DEG, true>), dim3(grid), dim3(kShBlock), lds, st, n, K, means, cam_pos, radii, sh_rgb,
-                       v_colors, v_coeffs, v_depths);
-  else
-    hipLaunchKernelGGL((sh_view_bwd_kernel<DEG, false>), dim3(grid), dim3(kShBlock), lds, st, n, K, means, cam_pos, radii, sh_rgb,
-                       v_colors, v_coeffs, v_depths);
-}
-
 extern "C" int bds_sh_view_fwd(int64_t n, int K, int deg, const float *means, const float *cam_pos, const float *coeffs,
                                const int32_t *radii, const float *depths, float *sh_rgb, float *colors, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
@@ -464,66 +418,50 @@ extern "C" int bds_sh_view_fwd(int64_t n, int K, int deg, const float *means, co
   return BDS_OK;
 }
 
-extern "C" int bds_sh_view_bwd(int64_t n, int K, int deg, const float *means, const float *cam_pos, const int32_t *radii,
-                               const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths,
-                               bds_stream_t stream) {
-  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
-  if (n == 0) return BDS_OK;
-  BDS_REQUIRE(means && cam_pos && radii && sh_rgb && v_colors && v_coeffs && v_depths && aligned16(v_colors));
-  const int grid = (int)cdiv(n, kShBlock);
-  const size_t lds = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
-  const bool full = ((K * 3) % 4 == 0) && aligned16(v_coeffs);
-  hipStream_t st = as_stream(stream);
-  const float4 *v4 = reinterpret_cast<const float4 *>(v_colors);
-  switch (deg) {
-    case 0: launch_view_bwd<0>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-    case 1: launch_view_bwd<1>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-    case 2: launch_view_bwd<2>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-    default: launch_view_bwd<3>(full, grid, lds, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-  }
-  BDS_LAUNCH_CHECK();
-  return BDS_OK;
-}
-
 template <int DEG>
-static void launch_view_bwd_rows(bool vec, bool acc, int grid, hipStream_t st, int64_t n, int K, const float *means,
-                                 const float *cam_pos, const int32_t *radii, const float *sh_rgb, const float4 *v_colors,
-                                 float *v_coeffs, float *v_depths) {
-#define BDS_ROWS(V, A)                                                                                                          \
-  hipLaunchKernelGGL((sh_view_bwd_rows_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), 0, st, n, K, means, cam_pos, radii, sh_rgb, \
-                     v_colors, v_coeffs, v_depths)
-  if (vec) { if (acc) BDS_ROWS(true, true); else BDS_ROWS(true, false); }
-  else     { if (acc) BDS_ROWS(false, true); else BDS_ROWS(false, false); }
-#undef BDS_ROWS
+static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipStream_t st, int64_t n_list, const int32_t *ids, int K,
+                                 const float *means, const float *cam_pos, const float *sh_rgb, const float4 *v_rec, float *v_coeffs) {
+#define BDS_LIST(V, A)                                                                                                           \
+  hipLaunchKernelGGL((sh_view_bwd_list_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), lds, st, n_list, ids, K, means, cam_pos, \
+                     sh_rgb, v_rec, v_coeffs)
+  if (vec) { if (acc) BDS_LIST(true, true); else BDS_LIST(true, false); }
+  else     { if (acc) BDS_LIST(false, true); else BDS_LIST(false, false); }
+#undef BDS_LIST
 }
 
-extern "C" int bds_sh_view_bwd_rows(int64_t n, int K, int deg, const float *means, const float *cam_pos, const int32_t *radii,
-                                    const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, int accumulate,
+extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
+                                    const float *sh_rgb, const float *v_records, float *v_coeffs, int accumulate,
                                     bds_stream_t stream) {
-  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
-  if (n == 0) return BDS_OK;
-  BDS_REQUIRE(means && cam_pos && radii && sh_rgb && v_colors && v_coeffs && v_depths && aligned16(v_colors));
-  const int grid = (int)cdiv(n, kShBlock);
+  BDS_REQUIRE(n_list >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n_list == 0) return BDS_OK;
+  BDS_REQUIRE(ids && means && cam_pos && sh_rgb && v_records && v_coeffs && aligned16(v_records));
+  const int grid = (int)cdiv(n_list, kShBlock);
+  const size_t lds = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
   const bool vec = ((K * 3) % 4 == 0) && aligned16(v_coeffs);
   hipStream_t st = as_stream(stream);
-  const float4 *v4 = reinterpret_cast<const float4 *>(v_colors);
+  const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
   switch (deg) {
-    case 0: launch_view_bwd_rows<0>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-    case 1: launch_view_bwd_rows<1>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-    case 2: launch_view_bwd_rows<2>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
-    default: launch_view_bwd_rows<3>(vec, accumulate != 0, grid, st, n, K, means, cam_pos, radii, sh_rgb, v4, v_coeffs, v_depths); break;
+    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
+    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
+    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
+    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
   }
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
 
-extern "C" int bds_view_grads_clear(int64_t n, int K, const uint8_t *dirty, float *v_means, float *v_quats, float *v_log_scales,
-                                    float *v_logits, float *v_sh, bds_stream_t stream) {
-  BDS_REQUIRE(n >= 0 && K >= 1 && K <= 16);
-  if (n == 0) return BDS_OK;
-  BDS_REQUIRE(dirty && v_means && v_quats && v_log_scales && v_logits && v_sh);
-  hipLaunchKernelGGL(view_grads_clear_kernel, dim3((unsigned)cdiv(n, kShBlock)), dim3(kShBlock), 0, as_stream(stream), n, K, dirty,
-                     v_means, v_quats, v_log_scales, v_logits, v_sh);
+extern "C" int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int K, float *v_means, float *v_quats,
+                                         float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
+  BDS_REQUIRE(n_list >= 0 && K >= 1 && K <= 16);
+  if (n_list == 0) return BDS_OK;
+  BDS_REQUIRE(ids && v_means && v_quats && v_log_scales && v_logits && v_sh);
+  const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);
+  if (((K * 3) % 4 == 0) && aligned16(v_sh))
+    hipLaunchKernelGGL((view_grads_clear_list_kernel<true>), grid, block, 0, as_stream(stream), n_list, ids, K, v_means, v_quats,
+                       v_log_scales, v_logits, v_sh);
+  else
+    hipLaunchKernelGGL((view_grads_clear_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, ids, K, v_means, v_quats,
+                       v_log_scales, v_logits, v_sh);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
 
 // Keys-only form of the digit-ordered scatter, for the PACKED tile lists: an entry is one 32-bit word
 // (tile << rank_bits | depth rank of the Gaussian among the visible ones), so a pass moves 4 bytes per entry instead
-// of 8.  On the last pass (`unpack` != null) the Gaussian id of every entry is looked up from its rank and written
-// to vals_out next to the packed word.
+// of 8.  On the last pass (`vals_out` != null) every entry's value is written next to the packed word: the Gaussian id looked
+// up from its rank (`unpack` != null), or the rank itself (lists that address rank-ordered splat records).
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
     const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
     const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
     const uint32_t d = (kk >> shift) & mask;
     const uint32_t g = gbase[d] + ((uint32_t)i - dstart[d]);
     keys_out[g] = kk;
-    if (unpack) vals_out[g] = unpack[kk & rank_mask];
+    if (vals_out) vals_out[g] = unpack ? unpack[kk & rank_mask] : (kk & rank_mask);
   }
 }
 
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
     const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ btot,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec) {
+    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec, int emit_rank) {
   __shared__ RowStage S;
   const int64_t n_vis = (int64_t)*n_vis_dev;
   const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
       row_span_of(S, g, ty, cull, tile_size, lo, hi);
       id = S.id[g];
       key0 = S.cam_base[g] + (uint32_t)(ty * tile_w);
-      if (pack_shift) id = (uint32_t)(j0 + g);   // packed lists carry the depth rank, not the Gaussian id
+      if (pack_shift || emit_rank) id = (uint32_t)(j0 + g);   // packed lists (and rank lists) carry the depth rank, not the Gaussian id
     }
     const uint32_t c = hi > lo ? (uint32_t)(hi - lo) : 0u;
     uint32_t total;
@@ -989,8 +989,17 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
                                const float *depths, const float *conics, const float *opacities, int tile_size,
                                int tile_w, int tile_h, const void *ws,
                                size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
-                               int32_t *isect_offsets, bds_stream_t stream) {
+                               int32_t *isect_offsets, int32_t *visible_ids, int flatten_ranks, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && isect_offsets);
+  BDS_REQUIRE(!(flatten_ranks && isect_ids));          // the 64-bit keys need the Gaussian ids
+  BDS_REQUIRE(!visible_ids || n_visible >= 0);
+  if (visible_ids && n_visible > 0) {   // the depth-ordered ids of the visible entries (rank -> cam*N + g) for the caller
+    BDS_REQUIRE(ws);
+    const PrepWs P0 = prep_layout(const_cast<void *>(ws), (int64_t)C * N);
+    if (ws_bytes < P0.bytes) return BDS_EWORKSPACE;
+    if (hipMemcpyAsync(visible_ids, P0.va, sizeof(int32_t) * n_visible, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+      return BDS_ELAUNCH;
+  }
   BDS_REQUIRE(M < (int64_t)1 << 31);
   const int64_t CN = (int64_t)C * N;
   const int n_tiles_total = C * tile_w * tile_h;
@@ -1022,7 +1031,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     key_shift = rank_bits;
     uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
+                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec, 0);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     const uint32_t rank_mask = (1u << rank_bits) - 1u;
@@ -1031,8 +1040,8 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
       int bits = bits_per;
       if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
       const bool last = p == npass - 1;
-      int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, last ? P.va : nullptr, rank_mask,
-                               last ? fl : nullptr);
+      int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, (last && !flatten_ranks) ? P.va : nullptr,
+                               rank_mask, last ? fl : nullptr);
       if (rc != BDS_OK) return rc;
       kin = kout;
     }
@@ -1042,7 +1051,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
     else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
-                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
+                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec, flatten_ranks);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     uint32_t *vin = v_emit;
@@ -1082,5 +1091,5 @@ extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int
   const int64_t M = *n_isects;
   if (M > flatten_capacity || (M > 0 && ws2_bytes < build_layout(nullptr, M).bytes)) return BDS_ECAPACITY;
   return bds_isect_build(C, N, M, *n_visible, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws, ws_bytes, ws2,
-                         ws2_bytes, isect_ids, flatten_ids, isect_offsets, stream);
+                         ws2_bytes, isect_ids, flatten_ids, isect_offsets, nullptr, 0, stream);
 }

@@ -25,12 +25,13 @@ class FlatGradients:
     re-points every ``param.grad`` at its slice of the reduced buffer."""
 
     def __init__(self, params: Iterable[Tensor], sparse_rows: bool = False):
-        """``sparse_rows`` (opt-in): the flat buffer is kept all-zero between steps by clearing only the rows that were written
-        (``mark_rows`` / ``begin_rows_union`` tell which), so that a producer may touch just the rows it needs
-        (``fused_view(grad_arena=..., arena_rows=1 | 2)``).  Whenever the book is incomplete the whole buffer is cleared."""
+        """``sparse_rows``: the flat buffer is kept all-zero between steps by clearing only the rows that were written
+        (``mark_list`` / ``begin_rows_union`` tell which), so that a producer may touch just the rows it needs
+        (``fused_view(grad_arena=..., arena_rows=1 | 2)``: a view sees ~15 % of the Gaussians).  Whenever the book is incomplete
+        the whole buffer is cleared."""
         self.sparse_rows = bool(sparse_rows)
-        self._dirty: Optional[Tensor] = None      # uint8 [N]: rows that may be non-zero (None: unknown -> dense clear)
-        self._clean = False                       # the flat buffer is known to be all zeros
+        self._dirty: Optional[List[Tensor]] = None   # id lists (int32) of the rows that may be non-zero (None: unknown -> dense clear)
+        self._clean = False                          # the flat buffer is known to be all zeros
         self._arena_names: List[str] = []
         self.params: List[Tensor] = [p for p in params]
         assert self.params, "no parameters"
@@ -65,17 +66,21 @@ class FlatGradients:
         if self.sparse_rows:
             self._clear_rows()
 
-    def mark_rows(self, touched: Tensor) -> None:
-        """Rows (first-dim entries) a backward of THIS process may write; call once per view, the marks of a step accumulate
-        (with several ranks ``begin_rows_union`` records the union over the ranks instead)."""
+    def mark_list(self, ids: Tensor) -> None:
+        """Rows (first-dim entries, as an int32 id list, e.g. ``info["visible_ids"]`` of a fused view) that a backward of THIS
+        process may write; call once per view, the lists of a step accumulate (with several ranks ``begin_rows_union`` records
+        the union over the ranks instead)."""
         if not self.sparse_rows:
             return
         if not self._clean and self._dirty is None:
             return                                   # state unknown (never cleared yet): stays unknown -> dense clear next time
-        t = touched.reshape(-1)
-        t = t.view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8)
-        self._dirty = t if self._dirty is None else torch.maximum(self._dirty, t)
+        self._dirty = (self._dirty or []) + [ids.reshape(-1).to(torch.int32)]
         self._clean = False
+
+    def mark_rows(self, touched: Tensor) -> None:
+        """The same from a boolean / uint8 mask [N] (costs a host sync: prefer ``mark_list``)."""
+        if self.sparse_rows:
+            self.mark_list(touched.reshape(-1).nonzero().squeeze(1))
 
     @property
     def rows_clean(self) -> bool:
@@ -88,14 +93,21 @@ class FlatGradients:
         row = dict(zip(self._arena_names, self._views))
         keys = ("means", "quats", "log_scales", "opacity_logits", "sh")
         if self._dirty is not None and flat.is_cuda and all(k in row for k in keys) and row["sh"].dim() == 3:
-            n, K = row["sh"].shape[0], row["sh"].shape[1]
-            L.check(L.lib().bds_view_grads_clear(n, K, L.ptr(self._dirty.contiguous()), L.ptr(row["means"]), L.ptr(row["quats"]),
-                                                 L.ptr(row["log_scales"]), L.ptr(row["opacity_logits"]), L.ptr(row["sh"]), L.stream()),
-                    "bds_view_grads_clear")
+            K = row["sh"].shape[1]
+            for ids in self._dirty:
+                L.check(L.lib().bds_view_grads_clear_list(ids.numel(), L.ptr(ids.contiguous()), K, L.ptr(row["means"]), L.ptr(row["quats"]),
+                                                          L.ptr(row["log_scales"]), L.ptr(row["opacity_logits"]), L.ptr(row["sh"]),
+                                                          L.stream()), "bds_view_grads_clear_list")
             # the other slices are dense: pack() / autograd overwrite (or zero) them before they are read
+        elif self._dirty is not None and not flat.is_cuda:   # CPU tensors (the gloo tests of the exchange logic): same effect
+            n_rows = max((v.shape[0] for v in self._views if v.dim() >= 1), default=0)
+            for ids in self._dirty:
+                for v in self._views:
+                    if v.dim() >= 1 and v.shape[0] == n_rows:
+                        v.index_fill_(0, ids.long(), 0.0)
         else:
             flat.zero_()
-        self._dirty = None
+        self._dirty = []
         self._clean = True
 
     def arena(self, names: Iterable[str]) -> Dict[str, Tensor]:
@@ -130,10 +142,10 @@ class FlatGradients:
         """Exchange only the rows of the union.  Returns False (nothing done) when that would not pay."""
         self._union_work.wait()
         union, self._union, self._union_work = self._union, None, None
-        if self.sparse_rows:
-            self._dirty = union      # after the exchange exactly the rows of the union may be non-zero (also on the dense path)
         n_rows = union.numel()
         idx = union.nonzero().squeeze(1)            # same on every rank (host sync: the exchange waits for backward anyway)
+        if self.sparse_rows:
+            self._dirty = [idx.to(torch.int32)]     # after the exchange exactly the rows of the union may be non-zero (also on the dense path)
         if idx.numel() > 0.85 * n_rows:
             return False
         row_views = [v for v in self._views if v.dim() >= 1 and v.shape[0] == n_rows]

@@ -45,6 +45,20 @@ def _host_sync_objects(dev):
 _LIST_CAPACITY: Dict[tuple, int] = {}   # (N, W, H, culling) -> entries to provision for the intersection lists
 
 
+class _Info(dict):
+    """info dict of the fused view.  The per-tile lists are kept as depth RANKS of the visible Gaussians (``flatten_ranks``; they
+    address the compact splat / gradient records); gsplat's ``flatten_ids`` (Gaussian ids) is derived on first access:
+    ``visible_ids[flatten_ranks]``."""
+
+    def __getitem__(self, k):
+        if k == "flatten_ids" and not dict.__contains__(self, k):
+            dict.__setitem__(self, k, dict.__getitem__(self, "visible_ids")[dict.__getitem__(self, "flatten_ranks").long()])
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k == "flatten_ids" or dict.__contains__(self, k)
+
+
 class _FusedView(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, viewmat, *grids):
@@ -99,21 +113,24 @@ class _FusedView(torch.autograd.Function):
             buf = _empty((M,), dev, torch.int32)
             ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
             ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-        flatten_ids = buf[:M]
+        flatten = buf[:M]                                  # per-tile lists of depth RANKS (they address the records below)
+        vis_ids = _empty((n_vis,), dev, torch.int32)       # depth rank -> Gaussian id, the work list of everything downstream
         with L.timed("isect_build"):
             L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
-                                        ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten_ids), L.ptr(isect_offsets), st),
+                                        ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), L.ptr(vis_ids), 1, st),
                     "bds_isect_build")
         if M + M // 16 > cap:
             _LIST_CAPACITY[key] = M + M // 6 + 4096
         del ws, ws2, buf
-        # compositing (RGB + depth)
+        # compositing (RGB + depth) from the visible Gaussians' splat records, in depth-rank order
+        rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
         render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
         last_ids = _empty((1, H, W), dev, torch.int32)
         with L.timed("rasterize_fwd"):
-            L.check(lib.bds_rasterize_fwd(1, N, M, 4, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), None, W, H,
-                                          TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas),
-                                          L.ptr(last_ids), st), "bds_rasterize_fwd")
+            L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(vis_ids), L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), L.ptr(rec), st),
+                    "bds_splat_pack")
+            L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
+                                          L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         grids = [g.contiguous() for g in grids]
         idx = cfg.get("img_idx")
@@ -131,26 +148,26 @@ class _FusedView(torch.autograd.Function):
         ctx.M = M
         ctx.n_grids = len(grids)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
-                              colors, flatten_ids, isect_offsets, render, alphas, last_ids, bws, *grids)
+        ctx.save_for_backward(means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, cam_pos, sh_rgb,
+                              rec, vis_ids, flatten, isect_offsets, render, alphas, last_ids, bws, *grids)
         opacity = alphas[0]
         # rgb_g is returned for inspection.  means2d_out is a graph tensor (trainers/base.py:429-430 calls retain_grad() on
         # info["means2d"]): the backward attaches .absgrad / .grad to it, and a gradient a caller sends INTO it is added to the
         # compositor's before the projection backward.
         means2d_out = means2d.view(1, N, 2)
-        ctx.mark_non_differentiable(rgb_g, radii, tiles_per_gauss, flatten_ids, isect_offsets)
-        return rgb, depth, opacity, rgb_g, means2d_out, radii, tiles_per_gauss, flatten_ids, isect_offsets
+        ctx.mark_non_differentiable(rgb_g, radii, tiles_per_gauss, flatten, isect_offsets, vis_ids)
+        return rgb, depth, opacity, rgb_g, means2d_out, radii, tiles_per_gauss, flatten, isect_offsets, vis_ids
 
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_opacity, _v_rgb_g, v_means2d_ext, *_):
-        (means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, flatten_ids,
+        (means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, cam_pos, sh_rgb, rec, vis_ids, flatten,
          isect_offsets, render, alphas, last_ids, bws, *grids) = ctx.saved_tensors
         cfg = ctx.cfg
         lib, st = L.lib(), L.stream()
         dev = means.device
         W, H = cfg["width"], cfg["height"]
         N, K = means.shape[0], sh.shape[1]
-        P, M = H * W, ctx.M
+        M, n_vis = ctx.M, vis_ids.numel()
         tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
         # colour transform
         need_g = ctx.needs_input_grad[8:]
@@ -175,57 +192,49 @@ class _FusedView(torch.autograd.Function):
             L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
                                                L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
                                                L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
-        # compositing
-        buf = torch.zeros(12 * N, device=dev, dtype=torch.float32)
-        v_col, v_m2, v_abs, v_con, v_op = torch.split(buf, [4 * N, 2 * N, 2 * N, 3 * N, N])  # v_col first: 16-byte aligned
-        opac_c = opac.view(1, N)
+        # compositing: gradient records of the visible Gaussians, in depth-rank order (64 bytes each)
+        v_rec = torch.zeros(max(n_vis, 1), L.GRAD_RECORD_FLOATS, device=dev, dtype=torch.float32)
         order = ops.bwd_schedule(1, W, H, TILE, tw, th, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
-            L.check(lib.bds_rasterize_bwd(1, N, M, 4, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), None, W, H, TILE,
-                                          tw, th, L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids),
-                                          L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_m2), L.ptr(v_abs), L.ptr(v_con), L.ptr(v_col),
-                                          L.ptr(v_op), L.ptr(order), st), "bds_rasterize_bwd")
-        if v_means2d_ext is not None:   # a loss term on info["means2d"] itself
-            v_m2.add_(v_means2d_ext.reshape(-1))
-        carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
-        if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
-            carrier.absgrad = v_abs.view(1, N, 2)
-            carrier.grad = v_m2.view(1, N, 2)
+            L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
+                                          L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
+                                          L.ptr(order), st), "bds_rasterize_bwd")
+        if v_means2d_ext is not None and n_vis:   # a loss term on info["means2d"] itself: add its rows to the records
+            v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())
+        # dense screen-space gradient + its absolute sum for the densification statistics (zeros for culled Gaussians, as gsplat)
+        g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         arena = cfg.get("grad_arena") or {}
+        # arena modes (need all five per-Gaussian arena entries): 1 = store the visible rows into an arena the caller keeps zero
+        # elsewhere, 2 = add them to an arena that already is the parameters' .grad (several views summed before one exchange)
+        rows = int(cfg.get("arena_rows", 0)) if all(k in arena for k in ("means", "quats", "log_scales", "opacity_logits", "sh")) else 0
 
-        def out_like(name, ref):  # gradient output: the caller's slice of a flat communication buffer, or a fresh tensor
+        def out_like(name, ref):  # gradient output: the caller's slice of a flat communication buffer, or a fresh zero tensor
             t = arena.get(name)
             if t is None:
-                return torch.empty_like(ref)
+                return torch.zeros_like(ref)
             assert t.shape == ref.shape and t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device, name
+            if not rows:
+                t.zero_()
             return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
 
-        # opt-in: touch only the rows of the Gaussians this view sees (1: store them into an arena the caller keeps zero elsewhere,
-        # 2: add them to an arena that already is the parameters' .grad -- several views summed before one exchange)
-        rows = int(cfg.get("arena_rows", 0)) if all(k in arena for k in ("means", "quats", "log_scales", "opacity_logits", "sh")) else 0
-        v_sh, v_depths = out_like("sh", sh), _empty((1, N), dev)
+        v_sh = out_like("sh", sh)
         with L.timed("sh_bwd"):
-            if rows:
-                L.check(lib.bds_sh_view_bwd_rows(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col),
-                                                 L.ptr(v_sh), L.ptr(v_depths), int(rows == 2), st), "bds_sh_view_bwd_rows")
-            else:
-                L.check(lib.bds_sh_view_bwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col),
-                                            L.ptr(v_sh), L.ptr(v_depths), st), "bds_sh_view_bwd")
+            L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
+                                             L.ptr(v_rec), L.ptr(v_sh), int(rows == 2), st), "bds_sh_view_bwd_list")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
-        viewmat, Kmat = viewmat.contiguous(), cfg["K"].contiguous()
-        v_viewmat = _empty((4, 4), dev) if ctx.needs_input_grad[7] else None   # camera-pose gradient (base.py:328-329,399)
+        Kmat = cfg["K"].contiguous()
+        v_vm_slots = _empty((L.POSE_GRAD_SLOTS, 4, 4), dev) if ctx.needs_input_grad[7] else None   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
-            if rows:
-                L.check(lib.bds_project_view_bwd_rows(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat),
-                                                      W, H, cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
-                                                      L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_viewmat), int(rows == 2), st),
-                        "bds_project_view_bwd_rows")
-            else:
-                L.check(lib.bds_project_view_bwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat), L.ptr(Kmat), W, H,
-                                                 cfg["eps2d"], L.ptr(radii), L.ptr(v_m2), L.ptr(v_depths), L.ptr(v_con), L.ptr(v_op),
-                                                 L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_viewmat), st),
-                        "bds_project_view_bwd")
+            L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
+                                                  L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
+                                                  L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
+                                                  int(rows == 2), st), "bds_project_view_bwd_list")
+        carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
+        if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
+            carrier.grad = g2d[0:1]
+            carrier.absgrad = g2d[1:2]
+        v_viewmat = None if v_vm_slots is None else v_vm_slots.sum(0)
         if rows == 2:   # already added in place to what autograd holds as .grad: nothing to hand back
             return (None, None, None, None, None, None, v_sky, v_viewmat, *v_grids)
         return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, v_viewmat, *v_grids)
@@ -261,8 +270,9 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky,
                            viewmat, *gs)
-    rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ids, isect_offsets = out
+    rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ranks, isect_offsets, vis_ids = out
     cfg["_means2d_ref"] = weakref.ref(means2d)  # backward attaches .absgrad to THIS tensor object
-    info = {"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
-            "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "tile_size": TILE, "n_cameras": 1}
+    info = _Info({"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
+                  "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets, "tile_size": TILE,
+                  "n_cameras": 1, "n_isects": int(flatten_ranks.numel()), "n_visible": int(vis_ids.numel())})
     return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)

@@ -184,7 +184,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         L.check(lib.bds_isect_build(Cn, N, M, int(nv.value), L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
                                     tile_size, tile_width, tile_height,
                                     L.ptr(ws), ws_bytes, L.ptr(ws2), ws2_bytes, L.ptr(isect_ids), L.ptr(flatten_ids),
-                                    L.ptr(isect_offsets), L.stream()), "bds_isect_build")
+                                    L.ptr(isect_offsets), None, 0, L.stream()), "bds_isect_build")
     return tiles_per_gauss, isect_ids, flatten_ids, isect_offsets
 
 
@@ -222,48 +222,44 @@ class _RasterizeToPixels(torch.autograd.Function):
         th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
         M = flatten_ids.shape[0]
         dev = means2d_c.device
+        lib, st = L.lib(), L.stream()
+        # splat records in array order (record index = cam*N + g = what flatten_ids holds)
+        rec = torch.empty(Cn * N, L.SPLAT_RECORD_FLOATS, device=dev, dtype=torch.float32)
         render = torch.empty(Cn, height, width, CH, device=dev, dtype=torch.float32)
         alphas = torch.empty(Cn, height, width, 1, device=dev, dtype=torch.float32)
         last_ids = torch.empty(Cn, height, width, device=dev, dtype=torch.int32)
         with L.timed("rasterize_fwd"):
-            L.check(L.lib().bds_rasterize_fwd(Cn, N, M, CH, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities),
-                                              L.ptr(backgrounds), width, height, tile_size, tw, th, L.ptr(isect_offsets),
-                                              L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), L.stream()),
+            L.check(lib.bds_splat_pack(Cn * N, CH, None, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(rec), st),
+                    "bds_splat_pack")
+            L.check(lib.bds_rasterize_fwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, tile_size, tw, th,
+                                          L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),
                     "bds_rasterize_fwd")
-        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas, last_ids)
-        ctx.cfg = (width, height, tile_size, absgrad)
+        ctx.save_for_backward(means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids)
+        ctx.cfg = (width, height, tile_size, absgrad, CH)
         return render, alphas
 
     @staticmethod
     def backward(ctx, v_render, v_alphas):
-        means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
-        width, height, tile_size, absgrad = ctx.cfg
-        means2d_c = _f32c(means2d)
-        Cn, N = means2d_c.shape[0], means2d_c.shape[1]
-        CH = colors.shape[-1]
+        means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        width, height, tile_size, absgrad, CH = ctx.cfg
+        Cn, N = means2d.shape[0], means2d.shape[1]
         th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
         M = flatten_ids.shape[0]
         v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
-        # the atomically accumulated outputs live in ONE zero-filled buffer (one fill instead of five)
-        CN = Cn * N
-        sizes = [2 * CN, 2 * CN if absgrad else 0, 3 * CN, CH * CN, CN]
-        buf = torch.zeros(sum(sizes), device=means2d_c.device, dtype=torch.float32)
-        chunks = torch.split(buf, sizes)
-        v_means2d = chunks[0].view(Cn, N, 2)
-        v_abs = chunks[1].view(Cn, N, 2) if absgrad else None
-        v_conics = chunks[2].view(Cn, N, 3)
-        v_colors = chunks[3].view(Cn, N, CH)
-        v_opac = chunks[4].view(Cn, N)
+        # gradient records (64 bytes per entry, accumulated with atomics): include/bds.h bds_rasterize_bwd
+        v_rec = torch.zeros(Cn * N, L.GRAD_RECORD_FLOATS, device=rec.device, dtype=torch.float32)
         order = bwd_schedule(Cn, width, height, tile_size, tw, th, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
-            L.check(L.lib().bds_rasterize_bwd(Cn, N, M, CH, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities),
-                                              L.ptr(backgrounds), width, height, tile_size, tw, th, L.ptr(isect_offsets),
-                                              L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
-                                              L.ptr(v_means2d), L.ptr(v_abs), L.ptr(v_conics), L.ptr(v_colors), L.ptr(v_opac),
-                                              L.ptr(order), L.stream()), "bds_rasterize_bwd")
+            L.check(L.lib().bds_rasterize_bwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, tile_size, tw, th,
+                                              L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render),
+                                              L.ptr(v_alphas), L.ptr(v_rec), int(bool(absgrad)), L.ptr(order), L.stream()),
+                    "bds_rasterize_bwd")
+        v = v_rec.view(Cn, N, L.GRAD_RECORD_FLOATS)
+        v_colors, v_conics, v_means2d, v_opac = v[..., 0:CH], v[..., 4:7], v[..., 7:9], v[..., 11]
         if absgrad:
             # same contract as gsplat: the tensor the caller holds in meta["means2d"] grows `.absgrad`
             # (read at /root/reference/project/models/trainers/base.py:282)
+            v_abs = v[..., 9:11].contiguous()
             prev = getattr(means2d, "absgrad", None)  # set by an earlier channel chunk of this backward
             means2d.absgrad = v_abs if prev is None else prev + v_abs
         v_bg = None

@@ -138,7 +138,7 @@ def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[T
     rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)  # clamp + sky blend + slice + affine
     info = {"means2d": means2d, "radii": radii, "depths": depths, "conics": conics, "width": W, "height": H,
             "tiles_per_gauss": tiles_per_gauss, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
-            "tile_size": TILE_SIZE, "n_cameras": 1}
+            "tile_size": TILE_SIZE, "n_cameras": 1, "n_isects": int(flatten_ids.numel())}
     return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
 
 

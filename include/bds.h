@@ -111,8 +111,12 @@ int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float 
                     const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h, const void *ws,
                     size_t ws_bytes, void *ws2,
                     size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
-                    bds_stream_t stream);
-/* Asynchronous prepare: same work, but instead of synchronising it copies {M, n_visible} into `counts_pinned`
+                    int32_t *visible_ids, int flatten_ranks, bds_stream_t stream);
+/* visible_ids (may be NULL; needs n_visible >= 0): receives the depth-ordered ids cam*N+g of the n_visible entries with
+ * radii > 0, i.e. the map depth rank -> entry.  flatten_ranks != 0: flatten_ids receives every intersection's depth RANK
+ * instead of its id (same order; isect_ids must be NULL) -- the lists then address splat records packed through
+ * visible_ids (bds_splat_pack), and gradient records come back in that compact order.
+ * Asynchronous prepare: same work, but instead of synchronising it copies {M, n_visible} into `counts_pinned`
  * (int64[2], page-locked host memory) and records `event` (a hipEvent_t) on the stream.  The caller may enqueue
  * independent work, then waits for the event, reads the counts and calls bds_isect_build: the GPU keeps running that
  * work while the host sizes the lists. */
@@ -135,21 +139,31 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
 /* ---- alpha compositing -------------------------------------------------------------------
  * rasterize_to_pixels stage of gsplat.rendering.rasterization; outputs consumed at
  * models/trainers/base.py:409-419 (render, alphas) and :280-297 (means2d.absgrad).
- * CH in {1,3,4}.  means2d [C,N,2] conics [C,N,3] colors [C,N,CH] opacities [C,N]
- * backgrounds [C,CH] or NULL -> render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] i32. */
-int bds_rasterize_fwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
-                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
-                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+ *
+ * The compositor reads SPLAT RECORDS: 12 floats (48 bytes, 16-byte aligned) per list-addressable entry,
+ *     mean2d.x, mean2d.y, ea, eb | ec, opacity, colour0, colour1 | colour2, colour3, 0, 0
+ * with (ea, eb, ec) = -log2(e) * (a/2, b, c/2) of the conic (a, b, c): alpha = opacity * 2^(ea dx^2 + eb dx dy + ec dy^2).
+ * bds_splat_pack builds them from the per-entry arrays means2d [n,2] conics [n,3] colors [n,CH] opacities [n]: record r is
+ * entry ids[r], or entry r when ids == NULL.  The per-tile lists (`flatten`) hold RECORD indices: cam*N + g for records in
+ * array order (gsplat's flatten_ids), or depth ranks of the visible entries for records packed through a sorted id list.
+ * CH in {1,3,4}; backgrounds [C,CH] or NULL -> render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] i32. */
+#define BDS_SPLAT_RECORD_FLOATS 12
+#define BDS_GRAD_RECORD_FLOATS 16
+int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
+                   const float *opacities, float *records, bds_stream_t stream);
+int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
+                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten,
                       float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
-/* Gradient outputs must be zero-filled by the caller (they are accumulated with atomics).
- * v_means2d_abs may be NULL (absgrad=False).  tile_order may be NULL (tiles are taken in image order, one
- * contiguous band per XCD) or the schedule written by bds_rasterize_bwd_schedule. */
-int bds_rasterize_bwd(int C, int64_t N, int64_t M, int CH, const float *means2d, const float *conics,
-                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
-                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+/* Backward into GRADIENT RECORDS v_records [n_records, 16] (64-byte stride, zero-filled by the caller, accumulated with
+ * atomics), in the units of the un-scaled inputs:
+ *     0-3 d/d colour | 4-6 d/d conic (a, b, c) | 7-8 d/d mean2d | 9-10 sum over pixels of |d/d mean2d| (absgrad != 0) |
+ *     11 d/d opacity | 12-15 unused.
+ * tile_order may be NULL (tiles are taken in image order, one contiguous band per XCD) or the schedule written by
+ * bds_rasterize_bwd_schedule. */
+int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
+                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten,
                       const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
-                      float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors, float *v_opacities,
-                      const int32_t *tile_order, bds_stream_t stream);
+                      float *v_records, int absgrad, const int32_t *tile_order, bds_stream_t stream);
 /* Launch schedule for bds_rasterize_bwd (no reference counterpart; results do not depend on it).  One wave owns a
  * tile and the chip holds only about two rounds of tiles, so the launch ends with a tail of long tiles that started
  * late.  After the forward pass each tile's visited length is known exactly (max last_id - list start); this call
@@ -228,20 +242,34 @@ int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, cons
  *     gradients of the raw parameters and reads only the radius of a culled Gaussian.
  *   sh_view: view direction = means - cam_pos (vanilla.py:384, detached), visibility = radii > 0, output packed for
  *     the RGB+ED compositor as colors [N,4] = (clamp(sh + 0.5, 0, 1), depth) (vanilla.py:389); sh_rgb [N,3] keeps the
- *     un-clamped value for the backward; the backward also splits off v_depths [N] = v_colors[:,3]. */
+ *     un-clamped value for the backward. */
 int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales, const float *logits,
                          const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane,
                          float far_plane, float radius_clip, float *scales, float *opacities, int32_t *radii,
                          float *means2d, float *depths, float *conics, bds_stream_t stream);
-int bds_project_view_bwd(int64_t N, const float *means, const float *quats, const float *scales, const float *opacities,
-                         const float *viewmat, const float *K, int W, int H, float eps2d, const int32_t *radii,
-                         const float *v_means2d, const float *v_depths, const float *v_conics, const float *v_opacities,
-                         float *v_means, float *v_quats, float *v_log_scales, float *v_logits, float *v_viewmat /* [4,4] or NULL */,
-                         bds_stream_t stream);
 int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const float *coeffs,
                     const int32_t *radii, const float *depths, float *sh_rgb, float *colors, bds_stream_t stream);
-int bds_sh_view_bwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const int32_t *radii,
-                    const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, bds_stream_t stream);
+/* Backward of the one-view forms over the VISIBLE entries only, list-driven (no reference counterpart; the reference's dense
+ * backward writes zeros for every culled Gaussian).  ids [n_list] = depth-ordered ids of the visible entries (bds_isect_build:
+ * visible_ids); v_records [n_list,16] = the compositor's gradient records of the same ranks (bds_rasterize_bwd with rank lists).
+ * accumulate = 0 STORES the rows ids[.] of the gradient arrays (all other rows are the caller's business: zero-filled, or kept zero
+ * with bds_view_grads_clear_list), accumulate = 1 ADDS to them (several views summed into one buffer before one exchange).
+ *   sh_view_bwd_list     : v_coeffs [N,K,3] rows (colour clamp of vanilla.py:389 applied through sh_rgb).
+ *   project_view_bwd_list: v_means [N,3] v_quats [N,4] v_log_scales [N,3] v_logits [N] rows; optionally (may be NULL)
+ *       grad2d / absgrad2d [N,2]: the screen-space gradient and the sum over pixels of its absolute value scattered to the
+ *       dense arrays models/trainers/base.py:280-297 reads (rows of culled Gaussians untouched);
+ *       v_viewmat_slots [BDS_POSE_GRAD_SLOTS,4,4]: camera-pose gradient partials (zero-filled inside; the sum over the slots is
+ *       d(loss)/d(viewmat), models/trainers/base.py:328-329,399). */
+#define BDS_POSE_GRAD_SLOTS 64
+int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
+                         const float *sh_rgb, const float *v_records, float *v_coeffs, int accumulate, bds_stream_t stream);
+int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats, const float *scales,
+                              const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
+                              const float *v_records, float *v_means, float *v_quats, float *v_log_scales, float *v_logits,
+                              float *v_viewmat_slots, float *grad2d, float *absgrad2d, int accumulate, bds_stream_t stream);
+/* Zero the rows ids[0..n_list) of the five per-Gaussian gradient arrays (v_sh is [N,K,3]). */
+int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int K, float *v_means, float *v_quats, float *v_log_scales,
+                              float *v_logits, float *v_sh, bds_stream_t stream);
 
 /* RGB+ED form of the fused image transform: the input is the compositor's 4-channel render [H*W,4] (RGB +
  * accumulated depth, gsplat render_mode "RGB+ED") and its alpha.  Forward additionally writes the expected depth
@@ -372,23 +400,6 @@ int bds_cubemap_bwd(int64_t n, int res, int channels, int width, const float *di
  *   sum expand * ref_c.  The caller solves the three 10x10 systems (float64) -> next warp [10,3] row-major float. */
 int bds_color_correct_step(int64_t P, const float *cur_in, const float *ref, const float *warp, float eps, uint8_t *mask0,
                            float *cur_out, double *acc, bds_stream_t stream);
-
-/* ---- Gradient rows of the visible Gaussians only (opt-in: persistent or accumulating per-Gaussian gradient buffers) ----
- * bds_sh_view_bwd / bds_project_view_bwd write every row of the dense gradient arrays -- zeros for the ~85 % of Gaussians a view
- * culls.  The *_rows forms touch only the rows with radii > 0: accumulate = 0 stores them (the caller guarantees the other rows
- * are already zero, see bds_view_grads_clear), accumulate = 1 adds to them (several views summed into one buffer before one
- * exchange).  v_depths of bds_sh_view_bwd_rows stays dense.  Same arguments otherwise. */
-int bds_sh_view_bwd_rows(int64_t n, int K, int deg, const float *means, const float *cam_pos, const int32_t *radii,
-                         const float *sh_rgb, const float *v_colors, float *v_coeffs, float *v_depths, int accumulate,
-                         bds_stream_t stream);
-int bds_project_view_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales, const float *opacities,
-                              const float *viewmat, const float *K, int W, int H, float eps2d, const int32_t *radii,
-                              const float *v_means2d, const float *v_depths, const float *v_conics, const float *v_opacities,
-                              float *v_means, float *v_quats, float *v_log_scales, float *v_logits, float *v_viewmat /* [4,4] or NULL */,
-                              int accumulate, bds_stream_t stream);
-/* Zero the rows g with dirty[g] != 0 of the five per-Gaussian gradient arrays (v_sh is [n,K,3]). */
-int bds_view_grads_clear(int64_t n, int K, const uint8_t *dirty, float *v_means, float *v_quats, float *v_log_scales,
-                         float *v_logits, float *v_sh, bds_stream_t stream);
 
 #ifdef __cplusplus
 }

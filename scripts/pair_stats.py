@@ -41,8 +41,10 @@ def main():
         col = torch.rand(1, N, 3, device=dev)
         render, alphas = torch.empty(1, H, W, 3, device=dev), torch.empty(1, H, W, 1, device=dev)
         last = torch.zeros(1, H, W, dtype=torch.int32, device=dev)
-        L.check(L.lib().bds_rasterize_fwd(1, N, M, 3, L.ptr(m2), L.ptr(con), L.ptr(col), L.ptr(op), None, W, H, 16, tw, th, L.ptr(offs),
-                                          L.ptr(fids), L.ptr(render), L.ptr(alphas), L.ptr(last), L.stream()), "fwd")
+        rec = torch.empty(N, L.SPLAT_RECORD_FLOATS, device=dev)
+        L.check(L.lib().bds_splat_pack(N, 3, None, L.ptr(m2), L.ptr(con), L.ptr(col), L.ptr(op), L.ptr(rec), L.stream()), "pack")
+        L.check(L.lib().bds_rasterize_fwd(1, N, M, 3, L.ptr(rec), None, W, H, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(render),
+                                          L.ptr(alphas), L.ptr(last), L.stream()), "fwd")
         n_tiles = tw * th
         start = offs.reshape(-1).long()
         end = torch.cat([start[1:], torch.tensor([M], device=dev)])

@@ -21,6 +21,7 @@ constexpr int REPS = 2000;
 #define KERNEL_F(NAME, OP)                                                                              \
   __global__ void NAME(float *out, long long *cyc, float s) {                                           \
     float a[8], b = s, c = s * 0.5f;                                                                    \
+    const unsigned long long m64 = s > 0.f ? 0x5555555555555555ull : 0xffffull; (void)m64;              \
     for (int i = 0; i < 8; i++) a[i] = s + threadIdx.x * 1e-3f + i;                                     \
     long long t0 = __builtin_readcyclecounter();                                                        \
     for (int r = 0; r < REPS; r++) { BODY64(OP) }                                                       \
@@ -50,6 +51,11 @@ constexpr int REPS = 2000;
 #define OP_MIN(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 #define OP_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
 #define OP_CMP(i) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+#define OP_CND64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(m64));
+#define OP_MOV(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+#define OP_ADDABS(i) asm volatile("v_add_f32_e64 %0, |%0|, %1" : "+v"(a[i]) : "v"(b));
+#define OP_FMAABS(i) asm volatile("v_fma_f32 %0, |%0|, |%1|, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define OP_AND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 #define OP_DPP(i) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
 #define OP_SWAP(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
 #define OP_PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -66,6 +72,11 @@ KERNEL_F(k_rcp, OP_RCP)
 KERNEL_F(k_min, OP_MIN)
 KERNEL_F(k_cnd, OP_CND)
 KERNEL_F(k_cmp, OP_CMP)
+KERNEL_F(k_cnd64, OP_CND64)
+KERNEL_F(k_mov, OP_MOV)
+KERNEL_F(k_addabs, OP_ADDABS)
+KERNEL_F(k_fmaabs, OP_FMAABS)
+KERNEL_F(k_and, OP_AND)
 KERNEL_F(k_dpp, OP_DPP)
 KERNEL_F(k_swap, OP_SWAP)
 KERNEL_F(k_mixexp, OP_MIX_EXP)
@@ -147,9 +158,24 @@ static void run(const char *name, K kern, int insts_per_rep, double flop_per_ins
   CHECK(hipFree(out)); CHECK(hipFree(cyc));
 }
 
+__global__ void k_rcp_bits(unsigned *out, float x) {
+  float r;
+  asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(x));
+  float e;
+  asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(x - 1.0f));
+  out[0] = __float_as_uint(r); out[1] = __float_as_uint(e);
+}
+
 int main() {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   printf("device %s  CUs %d  clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+  {
+    unsigned *d, h[2];
+    CHECK(hipMalloc(&d, 8));
+    hipLaunchKernelGGL(k_rcp_bits, dim3(1), dim3(64), 0, 0, d, 1.0f);
+    CHECK(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
+    printf("v_rcp_f32(1.0) = 0x%08x (exact: 0x3f800000)   v_exp_f32(0.0) = 0x%08x\n", h[0], h[1]);
+  }
   run("v_fma", k_fma, 64, 2);
   run("v_pk_fma", k_pkfma, 64, 4);
   run("v_mul", k_mul, 64, 1);
@@ -161,6 +187,11 @@ int main() {
   run("v_min", k_min, 64, 1);
   run("v_cndmask", k_cnd, 64, 1);
   run("v_cmp", k_cmp, 64, 1);
+  run("cndmask_s", k_cnd64, 64, 1);
+  run("v_mov", k_mov, 64, 1);
+  run("add_abs_e64", k_addabs, 64, 1);
+  run("fma_abs", k_fmaabs, 64, 2);
+  run("v_and", k_and, 64, 1);
   run("add_dpp", k_dpp, 64, 1);
   run("perm32swap", k_swap, 64, 1);
   run("exp+3fma", k_mixexp, 64 * 4, 1);

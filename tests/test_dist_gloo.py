@@ -184,25 +184,28 @@ def test_split_noise_is_rank0s_draw_on_every_rank():
 
 
 def test_sparse_rows_bookkeeping_single_process():
-    """FlatGradients(sparse_rows=True) on CPU tensors (the row-wise clear itself is a GPU kernel; here the dense fallback runs):
+    """FlatGradients(sparse_rows=True) on CPU tensors (the row-wise clear itself is a GPU kernel; here its torch equivalent runs):
     the state machine that decides when a producer may rely on an all-zero buffer."""
     from bilateral_driving_amd.dist import FlatGradients
     params = _make_params()
     flat = FlatGradients(params, sparse_rows=True)
+    flat.arena(["means", "sh", "tail"])
     assert not flat.rows_clean                        # unknown until the first zero()
     flat.mark_rows(torch.tensor([True] * 7))          # ignored while the state is unknown
     assert flat._dirty is None
     flat.zero()
     assert flat.rows_clean and float(flat.flat.abs().sum()) == 0.0
-    a = torch.tensor([1, 0, 0, 1, 0, 0, 0], dtype=torch.bool)
-    b = torch.tensor([0, 0, 1, 1, 0, 0, 0], dtype=torch.bool)
-    flat.mark_rows(a)
+    flat.mark_list(torch.tensor([0, 3], dtype=torch.int32))
     assert not flat.rows_clean
-    flat.mark_rows(b)                                 # the views of a frame: marks accumulate
-    assert flat._dirty.tolist() == [1, 0, 1, 1, 0, 0, 0]
-    flat.flat.fill_(3.0)
+    flat.mark_rows(torch.tensor([0, 0, 1, 1, 0, 0, 0], dtype=torch.bool))   # the views of a frame: the lists accumulate
+    assert sorted(set(int(i) for ids in flat._dirty for i in ids.tolist())) == [0, 2, 3]
+    n_row_floats = 7 * 3 + 7 * 16 * 3
+    rows = flat.flat[:n_row_floats]
+    flat._views[0][[0, 2, 3]] = 3.0                   # what the backward of those views wrote
+    flat._views[1][[0, 2, 3]] = 3.0
     flat.zero()
-    assert flat.rows_clean and flat._dirty is None and float(flat.flat.abs().sum()) == 0.0
+    assert flat.rows_clean and flat._dirty == [] and float(rows.abs().sum()) == 0.0
+    # an exchange without a union (dense all-reduce) makes the book unknown again: covered in the two-process test below
     dense = FlatGradients(_make_params())
     dense.zero()
     assert not dense.rows_clean                       # the default form never promises anything

@@ -171,9 +171,20 @@ def test_isect_tiles_one_call_and_capacity(ops):
             # the prepared workspace is intact: the two-call continuation gives the reference lists
             ws2b = torch.empty(max(lib.bds_isect_build_workspace_bytes(1, N, M), 16), dtype=torch.uint8, device="cuda")
             fids2 = torch.empty(M, dtype=torch.int32, device="cuda")
+            vis_ids = torch.empty(nv.value, dtype=torch.int32, device="cuda")
             L.check(lib.bds_isect_build(1, N, M, -1 if cap == 0 else nv.value, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
-                                        L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(fids2), L.ptr(offs), L.stream()), "build")
+                                        L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(fids2), L.ptr(offs), None, 0, L.stream()), "build")
             assert torch.equal(fids2, fids_ref) and torch.equal(offs, offs_ref)
+            # rank lists + the rank -> id map (what the fused view composites from): visible_ids[ranks] are the same lists,
+            # and visible_ids is the depth order (ties in Gaussian order) of the visible entries
+            ranks = torch.empty(M, dtype=torch.int32, device="cuda")
+            L.check(lib.bds_isect_build(1, N, M, nv.value, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
+                                        L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(ranks), L.ptr(offs), L.ptr(vis_ids), 1,
+                                        L.stream()), "build ranks")
+            assert torch.equal(vis_ids[ranks.long()], fids_ref) and torch.equal(offs, offs_ref)
+            vis = (radii[0] > 0).nonzero().squeeze(1)
+            order = torch.argsort(d[0][vis], stable=True)
+            assert torch.equal(vis_ids.long(), vis[order])
 
 
 @pytest.mark.parametrize("short,packed", [(0, 1), (1, 0), (0, 0)], ids=["generic_sort", "pair_lists", "generic_sort+pair_lists"])
@@ -429,8 +440,11 @@ def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C)
     last = torch.zeros(Cn, H, W, dtype=torch.int32, device="cuda")
     rr, aa = torch.empty(Cn, H, W, 3, device="cuda"), torch.empty(Cn, H, W, 1, device="cuda")
     M = fids.numel()
-    L.check(L.lib().bds_rasterize_fwd(Cn, N, M, 3, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), None,
-                                      W, H, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa), L.ptr(last), L.stream()), "fwd")
+    rec = torch.empty(Cn * N, L.SPLAT_RECORD_FLOATS, device="cuda")
+    L.check(L.lib().bds_splat_pack(Cn * N, 3, None, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), L.ptr(rec),
+                                   L.stream()), "pack")
+    L.check(L.lib().bds_rasterize_fwd(Cn, Cn * N, M, 3, L.ptr(rec), None, W, H, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa),
+                                      L.ptr(last), L.stream()), "fwd")
     order = ops.bwd_schedule(Cn, W, H, 16, tw, th, offs, last)
     total = Cn * tw * th
     o = order[:total].cpu().long()

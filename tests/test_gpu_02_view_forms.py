@@ -43,37 +43,52 @@ def test_project_view_equals_general_form_with_activations(env, seed, N, W, H):
     assert torch.allclose(scales, ref_scales, rtol=2e-6, atol=0) and torch.allclose(opac, ref_opac, rtol=2e-6, atol=1e-7)
     r2, rm2, rdep, rcon, _ = ops.fully_fused_projection(s["means"], s["quats"], scales, vm[None], K[None], W, H)
     assert torch.equal(radii, r2) and torch.equal(m2, rm2) and torch.equal(dep, rdep) and torch.equal(con, rcon)
-    # backward: raw-parameter gradients == general backward chained with the activation derivatives
+    # backward (list-driven over the visible entries, gradient records as input): raw-parameter gradients == general backward
+    # chained with the activation derivatives; rows of culled Gaussians are not touched
     g = torch.Generator().manual_seed(seed)
     vis = (radii[0] > 0)
-    v_m2 = torch.randn(1, N, 2, generator=g).cuda() * vis[None, :, None]
-    v_dep = torch.randn(1, N, generator=g).cuda() * vis[None]
-    v_con = torch.randn(1, N, 3, generator=g).cuda() * vis[None, :, None]
-    v_op = torch.randn(N, generator=g).cuda() * vis
-    out = [torch.full((N, k), 7.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 7.0, device="cuda")]
-    v_vm = torch.full((4, 4), 7.0, device="cuda")          # camera-pose gradient (trainers/base.py:328-329,399)
-    L.check(lib.bds_project_view_bwd(N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K), W, H, 0.3,
-                                     L.ptr(radii), L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), L.ptr(v_op), L.ptr(out[0]), L.ptr(out[1]),
-                                     L.ptr(out[2]), L.ptr(out[3]), L.ptr(v_vm), st), "bwd")
+    ids = vis.nonzero().squeeze(1).to(torch.int32)
+    ids = ids[torch.randperm(ids.numel(), generator=g).cuda()].contiguous()      # any order (the fused view hands a depth order)
+    n = ids.numel()
+    v_rec = torch.randn(n, 16, generator=g).cuda()
+    il = ids.long()
+    v_m2, v_dep = torch.zeros(1, N, 2, device="cuda"), torch.zeros(1, N, device="cuda")
+    v_con, v_op = torch.zeros(1, N, 3, device="cuda"), torch.zeros(N, device="cuda")
+    v_m2[0, il] = v_rec[:, 7:9]; v_dep[0, il] = v_rec[:, 3]; v_con[0, il] = v_rec[:, 4:7]; v_op[il] = v_rec[:, 11]
     ref = [torch.empty(N, k, device="cuda") for k in (3, 4, 3)]
     ref_vm = torch.empty(1, 4, 4, device="cuda")
     L.check(lib.bds_project_bwd(1, N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(vm), L.ptr(K), W, H, 0.3, L.ptr(radii),
                                 L.ptr(con), None, L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), None, L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]),
                                 L.ptr(ref_vm), st), "ref bwd")
-    assert float(ref_vm[0, :3].abs().max()) > 0 and float(v_vm[3].abs().max()) == 0.0
-    assert float((v_vm - ref_vm[0]).norm()) <= 1e-4 * float(ref_vm.norm())       # block-reduction order differs
+    for acc in (0, 1):
+        out = [torch.full((N, k), 7.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 7.0, device="cuda")]
+        slots = torch.full((L.POSE_GRAD_SLOTS, 4, 4), 7.0, device="cuda")          # camera-pose gradient partials (trainers/base.py:328-329,399)
+        g2d, ag2d = torch.full((N, 2), 7.0, device="cuda"), torch.full((N, 2), 7.0, device="cuda")
+        L.check(lib.bds_project_view_bwd_list(n, L.ptr(ids), L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K),
+                                              W, H, 0.3, L.ptr(v_rec), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), L.ptr(slots),
+                                              L.ptr(g2d), L.ptr(ag2d), acc, st), "bwd list")
+        base = 7.0 * acc
+        # (two separately compiled kernels: fused multiply-adds differ in the last bits, and the projection vjp cancels)
+        for a, b in ((out[0], ref[0]), (out[1], ref[1]), (out[2], ref[2] * scales)):
+            assert float((a[il] - base - b[il]).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-5 * base
+            assert float((a[il] - base - b[il]).norm()) <= 1e-4 * float(b.norm()) + 1e-4 * base
+            assert bool((a[~vis] == 7.0).all())                                   # culled rows untouched
+        assert torch.allclose(out[3][il] - base, (v_op * opac * (1 - opac))[il], rtol=1e-5, atol=1e-6 + 1e-6 * base)
+        assert bool((out[3][~vis] == 7.0).all())
+        assert torch.equal(g2d[il], v_rec[:, 7:9]) and torch.equal(ag2d[il], v_rec[:, 9:11]) and bool((g2d[~vis] == 7.0).all())
+        v_vm = slots.sum(0)
+        assert float(ref_vm[0, :3].abs().max()) > 0 and float(v_vm[3].abs().max()) == 0.0
+        assert float((v_vm - ref_vm[0]).norm()) <= 1e-4 * float(ref_vm.norm())      # reduction order differs
     # without a pose gradient buffer nothing else changes
-    out2 = [torch.empty_like(o) for o in out]
-    L.check(lib.bds_project_view_bwd(N, L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K), W, H, 0.3,
-                                     L.ptr(radii), L.ptr(v_m2), L.ptr(v_dep), L.ptr(v_con), L.ptr(v_op), L.ptr(out2[0]), L.ptr(out2[1]),
-                                     L.ptr(out2[2]), L.ptr(out2[3]), None, st), "bwd (no pose)")
-    assert all(torch.equal(a, b) for a, b in zip(out, out2))
-    # (two separately compiled kernels: fused multiply-adds differ in the last bits, and the projection vjp cancels)
-    for a, b in ((out[0], ref[0]), (out[1], ref[1]), (out[2], ref[2] * scales)):
-        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
-        assert float((a - b).norm()) <= 1e-4 * float(b.norm())
-    assert torch.allclose(out[3], v_op * opac * (1 - opac), rtol=1e-6, atol=0)
-    assert float(out[0][~vis].abs().max()) == 0.0 and float(out[3][~vis].abs().max()) == 0.0   # culled: exact zeros
+    out2 = [torch.zeros(N, k, device="cuda") for k in (3, 4, 3)] + [torch.zeros(N, device="cuda")]
+    out3 = [torch.zeros(N, k, device="cuda") for k in (3, 4, 3)] + [torch.zeros(N, device="cuda")]
+    slots = torch.empty(L.POSE_GRAD_SLOTS, 4, 4, device="cuda")
+    for o, sl in ((out2, None), (out3, slots)):
+        L.check(lib.bds_project_view_bwd_list(n, L.ptr(ids), L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K),
+                                              W, H, 0.3, L.ptr(v_rec), L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.ptr(o[3]), L.ptr(sl), None, None,
+                                              0, st), "bwd list (pose on / off)")
+    for a, b in zip(out2, out3):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize("deg", [0, 3])
@@ -95,17 +110,29 @@ def test_sh_view_equals_general_form_with_glue(env, deg):
     assert torch.allclose(sh_rgb, ref, rtol=1e-5, atol=2e-6)   # separately compiled kernels: last-bit fma differences
     assert torch.equal(colors[:, :3], (sh_rgb + 0.5).clamp(0, 1)) and torch.equal(colors[:, 3], dep[0])
     assert bool(((ref[vis] + 0.5 < 0) | (ref[vis] + 0.5 > 1)).any())   # the clamp is exercised
-    v_col = torch.randn(N, 4, generator=g).cuda()
-    v_sh, v_dep = torch.full((N, 16, 3), 7.0, device="cuda"), torch.empty(N, device="cuda")
-    L.check(lib.bds_sh_view_bwd(N, 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(radii), L.ptr(sh_rgb), L.ptr(v_col), L.ptr(v_sh),
-                                L.ptr(v_dep), st), "bwd")
+    # backward, list-driven: rows of the visible Gaussians from the colour part of their gradient records
+    ids = vis.nonzero().squeeze(1).to(torch.int32)
+    ids = ids[torch.randperm(ids.numel(), generator=g).cuda()].contiguous()
+    n, il = ids.numel(), ids.long()
+    v_rec = torch.randn(n, 16, generator=g).cuda()
+    v_col = torch.zeros(N, 3, device="cuda")
+    v_col[il] = v_rec[:, :3]
     x = sh_rgb + 0.5
-    v_rgb = (v_col[:, :3] * ((x >= 0) & (x <= 1))).contiguous()
+    v_rgb = (v_col * ((x >= 0) & (x <= 1))).contiguous()
     ref_v = torch.empty(N, 16, 3, device="cuda")
     mask8 = vis.to(torch.uint8)
     L.check(lib.bds_sh_bwd(N, 16, deg, L.ptr(dirs.contiguous()), L.ptr(sh), L.ptr(mask8), L.ptr(v_rgb), L.ptr(ref_v), None, st), "ref bwd")
-    assert torch.allclose(v_sh, ref_v, rtol=1e-5, atol=2e-6) and torch.equal(v_dep, v_col[:, 3])
-    assert float(v_sh[~vis].abs().max()) == 0.0
+    for acc in (0, 1):
+        v_sh = torch.full((N, 16, 3), 7.0, device="cuda")
+        L.check(lib.bds_sh_view_bwd_list(n, L.ptr(ids), 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(sh_rgb), L.ptr(v_rec), L.ptr(v_sh),
+                                         acc, st), "bwd list")
+        assert torch.allclose(v_sh[il] - 7.0 * acc, ref_v[il], rtol=1e-5, atol=2e-6 + 1e-5 * acc)
+        assert bool((v_sh[~vis] == 7.0).all())                                    # culled rows untouched
+    # row-wise clear
+    bufs = [torch.full((N, k), 3.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 3.0, device="cuda"), torch.full((N, 16, 3), 3.0, device="cuda")]
+    L.check(lib.bds_view_grads_clear_list(n, L.ptr(ids), 16, *[L.ptr(b) for b in bufs], st), "clear list")
+    for b in bufs:
+        assert float(b[il].abs().max()) == 0.0 and bool((b[~vis] == 3.0).all())
 
 
 @pytest.mark.parametrize("H,W,use_sky", [(57, 91, True), (120, 200, False)])
@@ -182,7 +209,7 @@ def test_isect_prepare_async_reports_the_same_counts(env):
     ws2 = torch.empty(max(ws2b, 16), dtype=torch.uint8, device="cuda")
     fids, offs = torch.empty(M, dtype=torch.int32, device="cuda"), torch.empty(1, th, tw, dtype=torch.int32, device="cuda")
     L.check(lib.bds_isect_build(1, N, M, nv, L.ptr(m2), L.ptr(radii), L.ptr(d), L.ptr(con), L.ptr(op), 16, tw, th, L.ptr(ws), wsb, L.ptr(ws2),
-                                ws2b, None, L.ptr(fids), L.ptr(offs), st), "build")
+                                ws2b, None, L.ptr(fids), L.ptr(offs), None, 0, st), "build")
     assert torch.equal(fids, fids_ref) and torch.equal(offs, offs_ref)
 
 
@@ -207,7 +234,7 @@ def test_fused_view_with_nothing_on_screen(env):
     sky = torch.rand(H, W, 3, device="cuda")
     for rep in range(2):   # the second call goes through the provisioned-capacity path
         out = fused_view(p, cam.viewmat, cam.K, W, H, grids, sky, Hn.FACTORS_3, img_idx=0, cam_pos=cam.cam_pos)
-        assert out["info"]["flatten_ids"].numel() == 0 and int((out["info"]["radii"] > 0).sum()) == 0
+        assert out["info"]["n_isects"] == 0 and out["info"]["flatten_ids"].numel() == 0 and int((out["info"]["radii"] > 0).sum()) == 0
         assert float(out["opacity"].abs().max()) == 0.0 and float(out["depth"].abs().max()) == 0.0
         (out["rgb"] * torch.rand_like(out["rgb"])).sum().backward()
         for k, v in p.items():

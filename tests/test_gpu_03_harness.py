@@ -124,7 +124,7 @@ def test_sparse_row_gradient_buffer_matches_dense_over_rotating_views(ops):
                 assert float(flat.flat[:n_gauss].abs().sum()) == 0.0          # really all-zero again
             out = Hn.render_view(p, cams[v], grids, v, sky, grad_arena=arena, arena_rows=1 if flat.rows_clean else 0)
             vis = out["info"]["radii"][0] > 0
-            flat.mark_rows(vis)
+            flat.mark_list(out["info"]["visible_ids"])
             if not sparse:
                 seen.append(int(vis.sum()))
             Hn.training_loss(out, target, grids).backward()
@@ -166,7 +166,7 @@ def test_views_of_a_frame_accumulate_into_the_arena(ops):
         flat.zero()
         for v, cam in enumerate(cams):
             out = Hn.render_view(p, cam, grids, v, sky, grad_arena=arena, arena_rows=1 if v == 0 else 2)
-            flat.mark_rows(out["info"]["radii"][0] > 0)
+            flat.mark_list(out["info"]["visible_ids"])
             Hn.training_loss(out, target, grids).backward()
         for k, t in p.items():
             assert t.grad.data_ptr() == arena[k].data_ptr(), k
