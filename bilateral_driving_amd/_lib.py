@@ -39,9 +39,9 @@ _SIGS = {
     "bds_project_bwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_isect_prepare_workspace_bytes": (_sz, [_i, _i64]),
     "bds_isect_build_workspace_bytes": (_sz, [_i, _i64, _i64]),
-    "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _f]),
+    "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i, _f]),
     "bds_isect_build": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f, _i, _f]),
-    "bds_isect_prepare_async": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _f, _f]),
+    "bds_isect_prepare_async": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _f, _i, _f]),
     "bds_isect_tiles": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _sz, _i64, _f, _f, _f, C.POINTER(C.c_int64),
                              C.POINTER(C.c_int64), _f]),
     "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f]),
@@ -50,9 +50,10 @@ _SIGS = {
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _i, _f]),
-    "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_view_grads_add_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     const float *__restrict__ scales, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     const float *__restrict__ K, int W, int H, float eps2d, const float4 *__restrict__ v_rec, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat_slots,
-    float *__restrict__ grad2d, float *__restrict__ absgrad2d) {
+    float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map) {
   __shared__ float red[kProjBlock / kWave][12];
   const int64_t r = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   ProjGrad pg;
@@ -176,13 +176,14 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     project_one_vjp(m, q, s, cam, W, H, eps2d, r1.w, r2.x, /*v_depth*/ r0.w, r1.x, r1.y, r1.z, pg);
     const float o = opacities[g];
     const float al = r2.w * o * (1.f - o);
+    const int64_t d = row_map ? (int64_t)row_map[g] : g;   // destination row of the parameter gradients
     for (int i = 0; i < 3; i++) {
       const float a = pg.v_mean[i], b = pg.v_scale[i] * s[i];
-      v_means[g * 3 + i] = kAcc ? v_means[g * 3 + i] + a : a;
-      v_log_scales[g * 3 + i] = kAcc ? v_log_scales[g * 3 + i] + b : b;
+      v_means[d * 3 + i] = kAcc ? v_means[d * 3 + i] + a : a;
+      v_log_scales[d * 3 + i] = kAcc ? v_log_scales[d * 3 + i] + b : b;
     }
-    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = kAcc ? v_quats[g * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
-    v_logits[g] = kAcc ? v_logits[g] + al : al;
+    for (int i = 0; i < 4; i++) v_quats[d * 4 + i] = kAcc ? v_quats[d * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
+    v_logits[d] = kAcc ? v_logits[d] + al : al;
     if (grad2d) { grad2d[g * 2] = r1.w; grad2d[g * 2 + 1] = r2.x; }
     if (absgrad2d) { absgrad2d[g * 2] = r2.y; absgrad2d[g * 2 + 1] = r2.z; }
   }
@@ -248,7 +249,7 @@ extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, con
                                          const float *scales, const float *opacities, const float *viewmat, const float *K, int W,
                                          int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
                                          float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
-                                         float *absgrad2d, int accumulate, bds_stream_t stream) {
+                                         float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(n_list >= 0 && W > 0 && H > 0);
   if (v_viewmat_slots &&
       hipMemsetAsync(v_viewmat_slots, 0, sizeof(float) * 16 * BDS_POSE_GRAD_SLOTS, as_stream(stream)) != hipSuccess)
@@ -261,7 +262,7 @@ extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, con
 #define BDS_LIST(A, P)                                                                                                         \
   hipLaunchKernelGGL((project_view_bwd_list_kernel<A, P>), grid, block, 0, as_stream(stream), n_list, ids, means, quats, scales, \
                      opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d,   \
-                     absgrad2d)
+                     absgrad2d, row_map)
   if (accumulate) { if (v_viewmat_slots) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else            { if (v_viewmat_slots) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST

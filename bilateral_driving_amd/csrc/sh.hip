@@ -233,9 +233,10 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
                                                                    const float *__restrict__ means,
                                                                    const float *__restrict__ cam_pos,
                                                                    const float *__restrict__ sh_rgb,
-                                                                   const float4 *__restrict__ v_rec, float *__restrict__ v_coeffs) {
+                                                                   const float4 *__restrict__ v_rec, float *__restrict__ v_coeffs,
+                                                                   const int32_t *__restrict__ row_map) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int32_t s_g[kShBlock];
+  __shared__ int32_t s_g[kShBlock];   // destination row of each staged entry
   constexpr int nb = (DEG + 1) * (DEG + 1);
   const int row = K * 3;
   const int ldr = row + 1;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
   const int tid = threadIdx.x;
   if (tid < cnt) {
     const int64_t g = ids[r0 + tid];
-    s_g[tid] = (int32_t)g;
+    s_g[tid] = row_map ? row_map[g] : (int32_t)g;
     const float4 v = v_rec[(r0 + tid) * (BDS_GRAD_RECORD_FLOATS / 4)];
     float vo[3] = {v.x, v.y, v.z};
 #pragma unroll
@@ -315,6 +316,50 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
     for (int e = tid; e < cnt * row; e += kShBlock) {
       const int r = e / row;
       v_sh[(int64_t)s_g[r] * row + (e - r * row)] = 0.f;
+    }
+  }
+}
+
+// dst[ids[s]] += src[s] for the five per-Gaussian gradient arrays: compact rows (an exchange buffer in the order of `ids`) added to
+// the dense arrays; negative ids (padding of a fixed-capacity list) are skipped.  v_sh rows move as 16-byte pieces, 12 lanes per row.
+template <bool kVec>
+__global__ __launch_bounds__(kShBlock) void view_grads_add_list_kernel(
+    int64_t n_list, const int32_t *__restrict__ ids, int K, const float *__restrict__ s_means, const float *__restrict__ s_quats,
+    const float *__restrict__ s_log_scales, const float *__restrict__ s_logits, const float *__restrict__ s_sh,
+    float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits,
+    float *__restrict__ v_sh) {
+  __shared__ int32_t s_g[kShBlock];
+  const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
+  const int cnt = (int)min((int64_t)kShBlock, n_list - r0);
+  const int tid = threadIdx.x;
+  if (tid < cnt) {
+    const int64_t r = r0 + tid;
+    const int64_t g = ids[r];
+    s_g[tid] = (int32_t)g;
+    if (g >= 0) {
+      for (int i = 0; i < 3; i++) { v_means[g * 3 + i] += s_means[r * 3 + i]; v_log_scales[g * 3 + i] += s_log_scales[r * 3 + i]; }
+      for (int i = 0; i < 4; i++) v_quats[g * 4 + i] += s_quats[r * 4 + i];
+      v_logits[g] += s_logits[r];
+    }
+  }
+  __syncthreads();
+  const int row = K * 3;
+  if (kVec) {
+    const int q4 = row / 4;
+    for (int e = tid; e < cnt * q4; e += kShBlock) {
+      const int r = e / q4, cc = (e - r * q4) * 4;
+      if (s_g[r] < 0) continue;
+      const float4 a = *reinterpret_cast<const float4 *>(s_sh + (r0 + r) * row + cc);
+      float4 *d = reinterpret_cast<float4 *>(v_sh + (int64_t)s_g[r] * row + cc);
+      float4 o = *d;
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      *d = o;
+    }
+  } else {
+    for (int e = tid; e < cnt * row; e += kShBlock) {
+      const int r = e / row;
+      if (s_g[r] < 0) continue;
+      v_sh[(int64_t)s_g[r] * row + (e - r * row)] += s_sh[(r0 + r) * row + (e - r * row)];
     }
   }
 }
@@ -420,18 +465,19 @@ extern "C" int bds_sh_view_fwd(int64_t n, int K, int deg, const float *means, co
 
 template <int DEG>
 static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipStream_t st, int64_t n_list, const int32_t *ids, int K,
-                                 const float *means, const float *cam_pos, const float *sh_rgb, const float4 *v_rec, float *v_coeffs) {
+                                 const float *means, const float *cam_pos, const float *sh_rgb, const float4 *v_rec, float *v_coeffs,
+                                 const int32_t *row_map) {
 #define BDS_LIST(V, A)                                                                                                           \
   hipLaunchKernelGGL((sh_view_bwd_list_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), lds, st, n_list, ids, K, means, cam_pos, \
-                     sh_rgb, v_rec, v_coeffs)
+                     sh_rgb, v_rec, v_coeffs, row_map)
   if (vec) { if (acc) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else     { if (acc) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST
 }
 
 extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
-                                    const float *sh_rgb, const float *v_records, float *v_coeffs, int accumulate,
-                                    bds_stream_t stream) {
+                                    const float *sh_rgb, const float *v_records, float *v_coeffs, const int32_t *row_map,
+                                    int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(n_list >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
   if (n_list == 0) return BDS_OK;
   BDS_REQUIRE(ids && means && cam_pos && sh_rgb && v_records && v_coeffs && aligned16(v_records));
@@ -441,10 +487,10 @@ extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, i
   hipStream_t st = as_stream(stream);
   const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
   switch (deg) {
-    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
-    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
-    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
-    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs); break;
+    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
+    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
+    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
+    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
   }
   BDS_LAUNCH_CHECK();
   return BDS_OK;
@@ -462,6 +508,23 @@ extern "C" int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int
   else
     hipLaunchKernelGGL((view_grads_clear_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, ids, K, v_means, v_quats,
                        v_log_scales, v_logits, v_sh);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const float *s_means, const float *s_quats,
+                                       const float *s_log_scales, const float *s_logits, const float *s_sh, float *v_means,
+                                       float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
+  BDS_REQUIRE(n_list >= 0 && K >= 1 && K <= 16);
+  if (n_list == 0) return BDS_OK;
+  BDS_REQUIRE(ids && s_means && s_quats && s_log_scales && s_logits && s_sh && v_means && v_quats && v_log_scales && v_logits && v_sh);
+  const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);
+  if (((K * 3) % 4 == 0) && aligned16(v_sh) && aligned16(s_sh))
+    hipLaunchKernelGGL((view_grads_add_list_kernel<true>), grid, block, 0, as_stream(stream), n_list, ids, K, s_means, s_quats,
+                       s_log_scales, s_logits, s_sh, v_means, v_quats, v_log_scales, v_logits, v_sh);
+  else
+    hipLaunchKernelGGL((view_grads_add_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, ids, K, s_means, s_quats,
+                       s_log_scales, s_logits, s_sh, v_means, v_quats, v_log_scales, v_logits, v_sh);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

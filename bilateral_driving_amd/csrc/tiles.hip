@@ -269,8 +269,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
 
 // Keys-only form of the digit-ordered scatter, for the PACKED tile lists: an entry is one 32-bit word
 // (tile << rank_bits | depth rank of the Gaussian among the visible ones), so a pass moves 4 bytes per entry instead
-// of 8.  On the last pass (`vals_out` != null) every entry's value is written next to the packed word: the Gaussian id looked
-// up from its rank (`unpack` != null), or the rank itself (lists that address rank-ordered splat records).
+// of 8.  On the last pass (`unpack` != null) every entry's list value (Gaussian id, or compact position) is looked up from its
+// rank and written to vals_out next to the packed word.
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
     const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
     const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
     const uint32_t d = (kk >> shift) & mask;
     const uint32_t g = gbase[d] + ((uint32_t)i - dstart[d]);
     keys_out[g] = kk;
-    if (vals_out) vals_out[g] = unpack ? unpack[kk & rank_mask] : (kk & rank_mask);
+    if (unpack) vals_out[g] = unpack[kk & rank_mask];
   }
 }
 
@@ -518,16 +518,19 @@ __global__ __launch_bounds__(kIsectBlock) void isect_flag_kernel(int64_t CN, con
   if (o < CN) flags[o] = radii[o] > 0 ? 1u : 0u;
 }
 
-// keys = fp32 depth bits (depth > 0 for every visible Gaussian: the bits are monotone), vals = cam*N+g
+// keys = fp32 depth bits (depth > 0 for every visible Gaussian: the bits are monotone), vals = cam*N+g (or, in compact mode, the
+// position j in the ascending list asc[] of the visible entries, which is written in both modes)
 __global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, const int32_t *__restrict__ radii,
                                                                    const uint32_t *__restrict__ pos,
                                                                    const float *__restrict__ depths,
-                                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                                   uint32_t *__restrict__ asc, int compact) {
   const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (o >= CN || radii[o] <= 0) return;
   const uint32_t j = pos[o];
   keys[j] = __float_as_uint(depths[o]);
-  vals[j] = (uint32_t)o;
+  vals[j] = compact ? j : (uint32_t)o;   // compact mode: the sort carries the entry's position in the ascending visible list
+  asc[j] = (uint32_t)o;
 }
 
 // ---- short path (C*N <= kShortSortMax): compaction fused with its scan and with the first histogram --------
@@ -557,7 +560,8 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
                                                                     const uint32_t *__restrict__ tile_sums,
                                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                     uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
-                                                                    uint64_t *__restrict__ n_vis_out) {
+                                                                    uint64_t *__restrict__ n_vis_out, uint32_t *__restrict__ asc,
+                                                                    int compact) {
   constexpr int kSpan = kScanTile / kShortChunk + 1;   // sort chunks a tile's outputs can straddle
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   __shared__ uint32_t h[kSpan][256];
@@ -583,7 +587,8 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
     if (vis[i]) {
       const uint32_t key = __float_as_uint(depths[base + i]);
       keys[j] = key;
-      vals[j] = (uint32_t)(base + i);
+      vals[j] = compact ? j : (uint32_t)(base + i);
+      asc[j] = (uint32_t)(base + i);
       atomicAdd(&h[(j >> kChunkShift) - chunk0][key & 255u], 1u);
       j++;
     }
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
 struct RowStage {
   float mx[kIsectBlock], my[kIsectBlock], a[kIsectBlock], b[kIsectBlock], c[kIsectBlock], qmax[kIsectBlock];
   int x0[kIsectBlock], x1[kIsectBlock], y0[kIsectBlock];
-  uint32_t id[kIsectBlock];          // cam*N + gaussian
+  uint32_t id[kIsectBlock];          // list value of the member: cam*N + gaussian, or its compact position
   uint32_t cam_base[kIsectBlock];    // camera * tiles-per-camera
   uint32_t rowoff[kIsectBlock + 1];  // exclusive prefix of the members' row counts
   uint32_t lw[kIsectBlock / kWave + 1];
@@ -624,6 +629,7 @@ constexpr int kRecWords = 12;
 // fills the stage for members j0 .. j0+255 of the depth order; returns the workgroup's number of row items
 // rec_out != null: compute from the attribute arrays and store the records; rec_in != null: load the records.
 __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t n_vis, int64_t N, const uint32_t *__restrict__ sorted_idx,
+                                               const uint32_t *__restrict__ asc /* compact mode: sorted_idx holds positions in asc[] */,
                                                const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                const float *__restrict__ conics, const float *__restrict__ opacities,
                                                int tile_size, int tile_w, int tile_h, float4 *__restrict__ rec_out,
@@ -639,7 +645,8 @@ __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t 
       S.c[t] = r1.x; S.qmax[t] = r1.y; S.x0[t] = __float_as_int(r1.z); S.x1[t] = __float_as_int(r1.w);
       S.y0[t] = __float_as_int(r2.x); S.id[t] = __float_as_uint(r2.z); S.cam_base[t] = __float_as_uint(r2.w);
     } else {
-      const uint32_t o = sorted_idx[j];
+      const uint32_t val = sorted_idx[j];            // what the lists will carry for this entry: its id, or its compact position
+      const uint32_t o = asc ? asc[val] : val;
       const int r = radii[o];
       float mx = 0.f, my = 0.f, a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
       int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -657,11 +664,11 @@ __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t 
       }
       const uint32_t cam_base = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
       S.mx[t] = mx; S.my[t] = my; S.a[t] = a; S.b[t] = b; S.c[t] = c; S.qmax[t] = q_max;
-      S.x0[t] = x0; S.x1[t] = x1; S.y0[t] = y0; S.id[t] = o; S.cam_base[t] = cam_base;
+      S.x0[t] = x0; S.x1[t] = x1; S.y0[t] = y0; S.id[t] = val; S.cam_base[t] = cam_base;
       if (rec_out != nullptr) {
         rec_out[j * 3] = make_float4(mx, my, a, b);
         rec_out[j * 3 + 1] = make_float4(c, q_max, __int_as_float(x0), __int_as_float(x1));
-        rec_out[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float(o), __uint_as_float(cam_base));
+        rec_out[j * 3 + 2] = make_float4(__int_as_float(y0), __uint_as_float(nrows), __uint_as_float(val), __uint_as_float(cam_base));
       }
     }
   }
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
     int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
-    float4 *__restrict__ rec, uint32_t *__restrict__ btot, uint64_t *__restrict__ m_total) {
+    float4 *__restrict__ rec, uint32_t *__restrict__ btot, uint64_t *__restrict__ m_total, const uint32_t *__restrict__ asc) {
   __shared__ RowStage S;
   __shared__ uint32_t cnt[kIsectBlock];
   const int64_t n_vis = (int64_t)*n_vis_dev;
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     return;
   }
   cnt[threadIdx.x] = 0u;
-  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, rec, nullptr);
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, asc, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, rec, nullptr);
   const bool cull = conics != nullptr;
   for (uint32_t r = threadIdx.x; r < R; r += kIsectBlock) {
     const int g = row_owner(S, r);
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
   }
   __syncthreads();
   if (j < CN) cnt_sorted[j] = cnt[threadIdx.x];
-  if (tiles_per_gauss && j < n_vis) tiles_per_gauss[sorted_idx[j]] = (int32_t)cnt[threadIdx.x];
+  if (tiles_per_gauss && j < n_vis) tiles_per_gauss[asc ? asc[sorted_idx[j]] : sorted_idx[j]] = (int32_t)cnt[threadIdx.x];
   uint32_t total;
   block_excl_scan(cnt[threadIdx.x], total, S.lw);
   if (threadIdx.x == 0) {
@@ -727,12 +734,12 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
     const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ btot,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec, int emit_rank) {
+    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec) {
   __shared__ RowStage S;
   const int64_t n_vis = (int64_t)*n_vis_dev;
   const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
   if (j0 >= n_vis) return;
-  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec);
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, nullptr, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec);
   const bool cull = conics != nullptr;
   // output offset of the workgroup's first row = intersections of all groups in front of it (no scan launch: <= a few
   // thousand L2-resident totals are summed here)
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
       row_span_of(S, g, ty, cull, tile_size, lo, hi);
       id = S.id[g];
       key0 = S.cam_base[g] + (uint32_t)(ty * tile_w);
-      if (pack_shift || emit_rank) id = (uint32_t)(j0 + g);   // packed lists (and rank lists) carry the depth rank, not the Gaussian id
+      if (pack_shift) id = (uint32_t)(j0 + g);   // packed lists carry the depth rank; the list value is looked up when the last pass writes out
     }
     const uint32_t c = hi > lo ? (uint32_t)(hi - lo) : 0u;
     uint32_t total;
@@ -800,6 +807,7 @@ struct PrepWs {
   uint64_t *total;      // [0] = M (intersections), [1] = visible (camera, Gaussian) entries
   uint32_t *ka, *va, *kb, *vb;  // [CN] each; after prepare: sorted ids live in `sorted`
   uint32_t *cum;        // [CN] exclusive scan of counts in depth order
+  uint32_t *asc;        // [CN] ids cam*N+g of the visible entries in ascending order (compact position -> id)
   uint32_t *temp;       // radix / scan temp
   uint32_t *tables;     // short path: workgroup-major histogram + 4 group tables
   float4 *rec;          // [CN][3] per-member records in depth order, written by EVERY counting kernel, read by the row emission
@@ -822,6 +830,7 @@ static PrepWs prep_layout(void *ws, int64_t CN) {
   L.kb = reinterpret_cast<uint32_t *>(take(CN, 4));
   L.vb = reinterpret_cast<uint32_t *>(take(CN, 4));
   L.cum = reinterpret_cast<uint32_t *>(take(CN, 4));
+  L.asc = reinterpret_cast<uint32_t *>(take(CN, 4));
   size_t t = radix_temp_elems(CN);
   size_t t2 = scan_temp_elems(CN);
   L.temp = reinterpret_cast<uint32_t *>(take(t > t2 ? t : t2, 4));
@@ -873,7 +882,8 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
 // enqueues the whole prepare stage; the counts (M, visible entries) end up in L.total on the device
 static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                            const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
-                           int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, bds_stream_t stream, uint64_t **counts_dev) {
+                           int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int compact, bds_stream_t stream,
+                           uint64_t **counts_dev) {
   BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0);
   const int64_t CN = (int64_t)C * N;
   BDS_REQUIRE(CN < (int64_t)1 << 31);
@@ -897,7 +907,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
                        (int64_t)short_sort_elems(CN), L.total);
     hipLaunchKernelGGL(visible_compact_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, depths, L.temp, L.ka, L.va, hist,
-                       ghist, n_vis);
+                       ghist, n_vis, L.asc, compact);
     BDS_LAUNCH_CHECK();
     // 2. depth order: 4 stable passes of 8 bits; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
@@ -914,7 +924,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
+                       compact ? L.asc : (const uint32_t *)nullptr);
     BDS_LAUNCH_CHECK();
   } else {
     if (hipMemsetAsync(L.total, 0, sizeof(uint64_t), st) != hipSuccess) return BDS_ELAUNCH;   // M is accumulated by the counting kernel
@@ -923,7 +934,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     BDS_LAUNCH_CHECK();
     rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, n_vis, st);
     if (rc != BDS_OK) return rc;
-    hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va);
+    hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va, L.asc, compact);
     BDS_LAUNCH_CHECK();
     // 2. depth order: 4 stable passes of 8 bits over the visible entries; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
@@ -937,7 +948,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total);
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
+                       compact ? L.asc : (const uint32_t *)nullptr);
     BDS_LAUNCH_CHECK();
   }
   // 4. (no scan: every counting kernel leaves the per-256-member totals and adds them to M; the emission derives its offsets)
@@ -949,13 +961,13 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
 extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                                  const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                                  int32_t *tiles_per_gauss, void *ws,
-                                 size_t ws_bytes, int64_t *n_isects, int64_t *n_visible, bds_stream_t stream) {
+                                 size_t ws_bytes, int64_t *n_isects, int64_t *n_visible, int compact, bds_stream_t stream) {
   BDS_REQUIRE(n_isects);
   *n_isects = 0;
   if (n_visible) *n_visible = 0;
   uint64_t *counts_dev = nullptr;
   int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
-                           stream, &counts_dev);
+                           compact, stream, &counts_dev);
   if (rc != BDS_OK || counts_dev == nullptr) return rc;
   hipStream_t st = as_stream(stream);
   uint64_t total[2] = {0, 0};   // M, visible entries
@@ -969,11 +981,11 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
 extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                                        const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                                        int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *counts_pinned,
-                                       void *event, bds_stream_t stream) {
+                                       void *event, int compact, bds_stream_t stream) {
   BDS_REQUIRE(counts_pinned && event);
   uint64_t *counts_dev = nullptr;
   int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
-                           stream, &counts_dev);
+                           compact, stream, &counts_dev);
   if (rc != BDS_OK) return rc;
   hipStream_t st = as_stream(stream);
   if (counts_dev == nullptr) {
@@ -989,15 +1001,15 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
                                const float *depths, const float *conics, const float *opacities, int tile_size,
                                int tile_w, int tile_h, const void *ws,
                                size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
-                               int32_t *isect_offsets, int32_t *visible_ids, int flatten_ranks, bds_stream_t stream) {
+                               int32_t *isect_offsets, int32_t *visible_ids, int compact, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && isect_offsets);
-  BDS_REQUIRE(!(flatten_ranks && isect_ids));          // the 64-bit keys need the Gaussian ids
+  BDS_REQUIRE(!(compact && isect_ids));          // the 64-bit keys need the Gaussian ids
   BDS_REQUIRE(!visible_ids || n_visible >= 0);
-  if (visible_ids && n_visible > 0) {   // the depth-ordered ids of the visible entries (rank -> cam*N + g) for the caller
+  if (visible_ids && n_visible > 0) {   // ascending ids of the visible entries (compact position -> cam*N + g) for the caller
     BDS_REQUIRE(ws);
     const PrepWs P0 = prep_layout(const_cast<void *>(ws), (int64_t)C * N);
     if (ws_bytes < P0.bytes) return BDS_EWORKSPACE;
-    if (hipMemcpyAsync(visible_ids, P0.va, sizeof(int32_t) * n_visible, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+    if (hipMemcpyAsync(visible_ids, P0.asc, sizeof(int32_t) * n_visible, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
       return BDS_ELAUNCH;
   }
   BDS_REQUIRE(M < (int64_t)1 << 31);
@@ -1031,7 +1043,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     key_shift = rank_bits;
     uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
-                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec, 0);
+                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     const uint32_t rank_mask = (1u << rank_bits) - 1u;
@@ -1040,8 +1052,8 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
       int bits = bits_per;
       if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
       const bool last = p == npass - 1;
-      int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, (last && !flatten_ranks) ? P.va : nullptr,
-                               rank_mask, last ? fl : nullptr);
+      int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, last ? P.va : nullptr, rank_mask,
+                               last ? fl : nullptr);
       if (rc != BDS_OK) return rc;
       kin = kout;
     }
@@ -1051,7 +1063,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
     else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
-                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec, flatten_ranks);
+                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     uint32_t *vin = v_emit;
@@ -1086,7 +1098,7 @@ extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int
   int64_t nvis_local = 0;
   if (!n_visible) n_visible = &nvis_local;
   int rc = bds_isect_prepare(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws,
-                             ws_bytes, n_isects, n_visible, stream);
+                             ws_bytes, n_isects, n_visible, 0, stream);
   if (rc != BDS_OK) return rc;
   const int64_t M = *n_isects;
   if (M > flatten_capacity || (M > 0 && ws2_bytes < build_layout(nullptr, M).bytes)) return BDS_ECAPACITY;

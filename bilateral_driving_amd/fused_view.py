@@ -46,9 +46,9 @@ _LIST_CAPACITY: Dict[tuple, int] = {}   # (N, W, H, culling) -> entries to provi
 
 
 class _Info(dict):
-    """info dict of the fused view.  The per-tile lists are kept as depth RANKS of the visible Gaussians (``flatten_ranks``; they
-    address the compact splat / gradient records); gsplat's ``flatten_ids`` (Gaussian ids) is derived on first access:
-    ``visible_ids[flatten_ranks]``."""
+    """info dict of the fused view.  The per-tile lists are kept as positions in ``visible_ids`` (the ascending ids of the visible
+    Gaussians; ``flatten_ranks`` addresses the compact splat / gradient records); gsplat's ``flatten_ids`` (Gaussian ids) is
+    derived on first access: ``visible_ids[flatten_ranks]``."""
 
     def __getitem__(self, k):
         if k == "flatten_ids" and not dict.__contains__(self, k):
@@ -91,7 +91,7 @@ class _FusedView(torch.autograd.Function):
         counts, ev = _host_sync_objects(dev)
         with L.timed("isect_prepare"):
             L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
-                                                L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, st),
+                                                L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
                     "bds_isect_prepare_async")
         # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
         # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
@@ -113,8 +113,9 @@ class _FusedView(torch.autograd.Function):
             buf = _empty((M,), dev, torch.int32)
             ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
             ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-        flatten = buf[:M]                                  # per-tile lists of depth RANKS (they address the records below)
-        vis_ids = _empty((n_vis,), dev, torch.int32)       # depth rank -> Gaussian id, the work list of everything downstream
+        flatten = buf[:M]                                  # per-tile lists of COMPACT positions (they address the records below)
+        vis_ids = _empty((n_vis,), dev, torch.int32)       # ascending ids of the visible Gaussians: compact position -> id, the
+        #                                                    work list of everything downstream (walks memory in order)
         with L.timed("isect_build"):
             L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
                                         ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), L.ptr(vis_ids), 1, st),
@@ -122,7 +123,7 @@ class _FusedView(torch.autograd.Function):
         if M + M // 16 > cap:
             _LIST_CAPACITY[key] = M + M // 6 + 4096
         del ws, ws2, buf
-        # compositing (RGB + depth) from the visible Gaussians' splat records, in depth-rank order
+        # compositing (RGB + depth) from the visible Gaussians' splat records (ascending-id order)
         rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
         render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
         last_ids = _empty((1, H, W), dev, torch.int32)
@@ -192,7 +193,7 @@ class _FusedView(torch.autograd.Function):
             L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
                                                L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
                                                L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
-        # compositing: gradient records of the visible Gaussians, in depth-rank order (64 bytes each)
+        # compositing: gradient records of the visible Gaussians, in the order of vis_ids (64 bytes each)
         v_rec = torch.zeros(max(n_vis, 1), L.GRAD_RECORD_FLOATS, device=dev, dtype=torch.float32)
         order = ops.bwd_schedule(1, W, H, TILE, tw, th, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
@@ -220,7 +221,7 @@ class _FusedView(torch.autograd.Function):
         v_sh = out_like("sh", sh)
         with L.timed("sh_bwd"):
             L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
-                                             L.ptr(v_rec), L.ptr(v_sh), int(rows == 2), st), "bds_sh_view_bwd_list")
+                                             L.ptr(v_rec), L.ptr(v_sh), None, int(rows == 2), st), "bds_sh_view_bwd_list")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
@@ -229,7 +230,7 @@ class _FusedView(torch.autograd.Function):
             L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
                                                   L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
                                                   L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
-                                                  int(rows == 2), st), "bds_project_view_bwd_list")
+                                                  None, int(rows == 2), st), "bds_project_view_bwd_list")
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]

@@ -172,7 +172,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     with L.timed("isect_prepare"):
         L.check(lib.bds_isect_prepare(Cn, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(conics), L.ptr(opacities),
                                       tile_size, tile_width, tile_height,
-                                      L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), C.byref(nv), L.stream()),
+                                      L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, C.byref(m), C.byref(nv), 0, L.stream()),
                 "bds_isect_prepare")
     M = int(m.value)
     flatten_ids = torch.empty(M, device=dev, dtype=torch.int32)

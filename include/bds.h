@@ -104,18 +104,19 @@ size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M);
  * 32-bit word (rank < 2^(32 - bits(C*tiles))): the tile sort then moves 4 bytes per entry instead of 8.  Same outputs. */
 int bds_isect_prepare(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                       const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
-                      int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *n_isects, int64_t *n_visible,
+                      int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *n_isects, int64_t *n_visible, int compact,
                       bds_stream_t stream);
 int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float *means2d, const int32_t *radii,
                     const float *depths,
                     const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h, const void *ws,
                     size_t ws_bytes, void *ws2,
                     size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets,
-                    int32_t *visible_ids, int flatten_ranks, bds_stream_t stream);
-/* visible_ids (may be NULL; needs n_visible >= 0): receives the depth-ordered ids cam*N+g of the n_visible entries with
- * radii > 0, i.e. the map depth rank -> entry.  flatten_ranks != 0: flatten_ids receives every intersection's depth RANK
- * instead of its id (same order; isect_ids must be NULL) -- the lists then address splat records packed through
- * visible_ids (bds_splat_pack), and gradient records come back in that compact order.
+                    int32_t *visible_ids, int compact, bds_stream_t stream);
+/* COMPACT lists (no reference counterpart).  compact != 0 (the same value in prepare and build; isect_ids must be NULL): every
+ * intersection's list value is the entry's POSITION in the ascending list of the visible entries instead of its id cam*N+g
+ * (same list order).  visible_ids (may be NULL; needs n_visible >= 0) receives that ascending list (position -> id) in either
+ * mode.  Compact lists address splat records packed through visible_ids (bds_splat_pack), the compositor's gradient records
+ * come back in that order, and everything downstream walks the visible ~15 % of the scene in memory order.
  * Asynchronous prepare: same work, but instead of synchronising it copies {M, n_visible} into `counts_pinned`
  * (int64[2], page-locked host memory) and records `event` (a hipEvent_t) on the stream.  The caller may enqueue
  * independent work, then waits for the event, reads the counts and calls bds_isect_build: the GPU keeps running that
@@ -123,7 +124,7 @@ int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float 
 int bds_isect_prepare_async(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                             const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                             int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *counts_pinned, void *event,
-                            bds_stream_t stream);
+                            int compact, bds_stream_t stream);
 /* One-call form: bds_isect_prepare and then, without returning to the caller in between, bds_isect_build into
  * buffers sized for an EXPECTED count (flatten_ids / isect_ids hold flatten_capacity entries, ws2 is
  * bds_isect_build_workspace_bytes(C, N, flatten_capacity)).  M <= flatten_capacity: BDS_OK, *n_isects = M, lists
@@ -259,17 +260,26 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
  *       grad2d / absgrad2d [N,2]: the screen-space gradient and the sum over pixels of its absolute value scattered to the
  *       dense arrays models/trainers/base.py:280-297 reads (rows of culled Gaussians untouched);
  *       v_viewmat_slots [BDS_POSE_GRAD_SLOTS,4,4]: camera-pose gradient partials (zero-filled inside; the sum over the slots is
- *       d(loss)/d(viewmat), models/trainers/base.py:328-329,399). */
+ *       d(loss)/d(viewmat), models/trainers/base.py:328-329,399).
+ * row_map (may be NULL) [N] i32: the parameter-gradient row of Gaussian g is row_map[g] instead of g -- the rows then land in a
+ * compact exchange buffer (multi-GPU: the slot of g in the union of the ranks' visible sets) instead of the dense arrays. */
 #define BDS_POSE_GRAD_SLOTS 64
 int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
-                         const float *sh_rgb, const float *v_records, float *v_coeffs, int accumulate, bds_stream_t stream);
+                         const float *sh_rgb, const float *v_records, float *v_coeffs, const int32_t *row_map, int accumulate,
+                         bds_stream_t stream);
 int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats, const float *scales,
                               const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
                               const float *v_records, float *v_means, float *v_quats, float *v_log_scales, float *v_logits,
-                              float *v_viewmat_slots, float *grad2d, float *absgrad2d, int accumulate, bds_stream_t stream);
+                              float *v_viewmat_slots, float *grad2d, float *absgrad2d, const int32_t *row_map, int accumulate,
+                              bds_stream_t stream);
 /* Zero the rows ids[0..n_list) of the five per-Gaussian gradient arrays (v_sh is [N,K,3]). */
 int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int K, float *v_means, float *v_quats, float *v_log_scales,
                               float *v_logits, float *v_sh, bds_stream_t stream);
+/* v_*[ids[s]] += s_*[s]: compact rows (s_means [n_list,3] s_quats [n_list,4] s_log_scales [n_list,3] s_logits [n_list]
+ * s_sh [n_list,K,3], e.g. a reduced exchange buffer) added to the dense arrays; entries with ids[s] < 0 are skipped. */
+int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const float *s_means, const float *s_quats,
+                            const float *s_log_scales, const float *s_logits, const float *s_sh, float *v_means, float *v_quats,
+                            float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
 
 /* RGB+ED form of the fused image transform: the input is the compositor's 4-channel render [H*W,4] (RGB +
  * accumulated depth, gsplat render_mode "RGB+ED") and its alpha.  Forward additionally writes the expected depth

@@ -45,6 +45,35 @@ json.dump({"note": "KB per launch, mean over launches; corrected = (2*FETCH_SIZE
                    "(MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read on gfx950; "
                    "WRITE_SIZE is exact -- both confirmed on sh_fwd/sh_bwd whose byte counts are known)",
            "kernels": pmc}, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+# SQ counters (two passes of 8): per-kernel means + derived VALU figures
+sq = {}
+for name in ("pmc_sq", "pmc_sq2"):
+    path = os.path.join(src, name, "bench_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0][:80]
+        if k.startswith("void bds::") or k.startswith("bds::"):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in agg.items():
+        for c, v in d.items():
+            sq.setdefault(k, {})[c] = sum(v) / len(v)
+for k, d in sq.items():
+    if d.get("SQ_INSTS_VALU") and d.get("SQ_ACTIVE_INST_VALU") and d.get("GRBM_GUI_ACTIVE"):
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+        d["valu_cycles_per_inst"] = 4.0 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_INSTS_VALU"]
+        d["valu_busy_frac"] = 4.0 * d["SQ_ACTIVE_INST_VALU"] / 1024.0 / (d["GRBM_GUI_ACTIVE"] / 8.0)
+        if d.get("SQ_THREAD_CYCLES_VALU"):
+            d["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])
+if sq:
+    json.dump({"note": "rocprofv3 --pmc, two passes of 8 SQ counters + GRBM_GUI_ACTIVE, mean per launch; valu_busy_frac = "
+                       "4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles)",
+               "kernels": sq}, open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1, sort_keys=True)
+for extra in ("valu_rate.txt", "pair_stats.json", "gpu_tests.log", "smoke.log"):
+    p = os.path.join(src, extra)
+    if os.path.exists(p):
+        open(os.path.join(dst, f"{tag}_{extra}"), "w").write(open(p).read())
 for extra in ("bench.json", "trace_bench.json"):
     p = os.path.join(src, extra)
     if os.path.exists(p):

@@ -175,16 +175,29 @@ def test_isect_tiles_one_call_and_capacity(ops):
             L.check(lib.bds_isect_build(1, N, M, -1 if cap == 0 else nv.value, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
                                         L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(fids2), L.ptr(offs), None, 0, L.stream()), "build")
             assert torch.equal(fids2, fids_ref) and torch.equal(offs, offs_ref)
-            # rank lists + the rank -> id map (what the fused view composites from): visible_ids[ranks] are the same lists,
-            # and visible_ids is the depth order (ties in Gaussian order) of the visible entries
-            ranks = torch.empty(M, dtype=torch.int32, device="cuda")
+            # ascending list of the visible entries (available in both modes)
             L.check(lib.bds_isect_build(1, N, M, nv.value, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
-                                        L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(ranks), L.ptr(offs), L.ptr(vis_ids), 1,
-                                        L.stream()), "build ranks")
-            assert torch.equal(vis_ids[ranks.long()], fids_ref) and torch.equal(offs, offs_ref)
-            vis = (radii[0] > 0).nonzero().squeeze(1)
-            order = torch.argsort(d[0][vis], stable=True)
-            assert torch.equal(vis_ids.long(), vis[order])
+                                        L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(fids2), L.ptr(offs), L.ptr(vis_ids), 0,
+                                        L.stream()), "build + visible ids")
+            assert torch.equal(vis_ids.long(), (radii[0] > 0).nonzero().squeeze(1)) and torch.equal(fids2, fids_ref)
+    # COMPACT lists (what the fused view composites from): list values = positions in the ascending visible list; same lists
+    for packed in (1, 0):
+        L.set_option(L.OPT_PACKED, packed)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        m, nv = C.c_int64(-1), C.c_int64(-1)
+        L.check(lib.bds_isect_prepare(1, N, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th, L.ptr(tpg),
+                                      L.ptr(ws), ws_bytes, C.byref(m), C.byref(nv), 1, L.stream()), "prepare compact")
+        assert m.value == M and torch.equal(tpg, tpg_ref)
+        ws2b = torch.empty(max(lib.bds_isect_build_workspace_bytes(1, N, M), 16), dtype=torch.uint8, device="cuda")
+        pos, offs = torch.empty(M, dtype=torch.int32, device="cuda"), torch.empty(1, th, tw, dtype=torch.int32, device="cuda")
+        vis_ids = torch.empty(nv.value, dtype=torch.int32, device="cuda")
+        L.check(lib.bds_isect_build(1, N, M, nv.value, L.ptr(m2.detach()), L.ptr(radii), L.ptr(d.detach()), L.ptr(con.detach()), L.ptr(op), 16, tw, th,
+                                    L.ptr(ws), ws_bytes, L.ptr(ws2b), ws2b.numel(), None, L.ptr(pos), L.ptr(offs), L.ptr(vis_ids), 1, L.stream()),
+                "build compact")
+        assert torch.equal(vis_ids.long(), (radii[0] > 0).nonzero().squeeze(1))
+        assert int(pos.min()) >= 0 and int(pos.max()) < nv.value
+        assert torch.equal(vis_ids[pos.long()], fids_ref) and torch.equal(offs, offs_ref)
+    L.set_option(L.OPT_PACKED, 1)
 
 
 @pytest.mark.parametrize("short,packed", [(0, 1), (1, 0), (0, 0)], ids=["generic_sort", "pair_lists", "generic_sort+pair_lists"])
