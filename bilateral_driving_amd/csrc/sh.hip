@@ -300,9 +300,11 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
   if (tid < cnt) {
     const int64_t g = ids[r0 + tid];
     s_g[tid] = (int32_t)g;
-    for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
-    for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
-    v_logits[g] = 0.f;
+    if (g >= 0) {   // negative ids: padding of a fixed-capacity list
+      for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
+      for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
+      v_logits[g] = 0.f;
+    }
   }
   __syncthreads();
   const int row = K * 3;
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
     const int q4 = row / 4;
     for (int e = tid; e < cnt * q4; e += kShBlock) {
       const int r = e / q4, cc = (e - r * q4) * 4;
-      *reinterpret_cast<float4 *>(v_sh + (int64_t)s_g[r] * row + cc) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s_g[r] >= 0) *reinterpret_cast<float4 *>(v_sh + (int64_t)s_g[r] * row + cc) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   } else {
     for (int e = tid; e < cnt * row; e += kShBlock) {
       const int r = e / row;
-      v_sh[(int64_t)s_g[r] * row + (e - r * row)] = 0.f;
+      if (s_g[r] >= 0) v_sh[(int64_t)s_g[r] * row + (e - r * row)] = 0.f;
     }
   }
 }

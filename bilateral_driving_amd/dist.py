@@ -102,9 +102,10 @@ class FlatGradients:
         elif self._dirty is not None and not flat.is_cuda:   # CPU tensors (the gloo tests of the exchange logic): same effect
             n_rows = max((v.shape[0] for v in self._views if v.dim() >= 1), default=0)
             for ids in self._dirty:
+                il = ids[ids >= 0].long()
                 for v in self._views:
                     if v.dim() >= 1 and v.shape[0] == n_rows:
-                        v.index_fill_(0, ids.long(), 0.0)
+                        v.index_fill_(0, il, 0.0)
         else:
             flat.zero_()
         self._dirty = []
@@ -199,6 +200,194 @@ class FlatGradients:
     @property
     def nbytes(self) -> int:
         return self.total * 4
+
+
+ROW_NAMES = ("means", "quats", "log_scales", "opacity_logits", "sh")   # the per-Gaussian parameters of the fused view
+
+
+class FrameExchange:
+    """One training step of view-parallel data parallelism = one FRAME: every rank renders the V views of its timestep
+    (BASELINE.json: "6 cams x 8 timesteps sharded across 8 GPUs"), their gradients are summed over views and ranks.
+
+    The exchange is made per VIEW and overlapped with the next view's compute.  A view sees ~15 % of the Gaussians and every
+    backward kernel writes only those rows, so instead of ONE dense all-reduce of 59 floats x N at the end of the frame (472 MB
+    at 2 M Gaussians: ~2.6 ms over xGMI behind 7.5 ms of compute, nothing to overlap it with) each view does:
+
+      1. right after its forward pass: an asynchronous MAX-all-reduce of the uint8 visibility mask (N bytes) -> union over the ranks;
+      2. inside its backward, before the list-driven kernels: slot map of the union (prefix sum) -> the kernels store the rows of
+         the visible Gaussians at their union slot of a zeroed COMPACT buffer [capacity, 59] (``fused_view(grad_sink=self)``);
+      3. after its backward: asynchronous SUM-all-reduce of the compact buffer (RCCL runs it on its own stream while the next
+         view's kernels run on the compute stream);
+      4. one view later: the reduced rows are added to the dense gradient buffer (``param.grad``) through the union's id list.
+
+    Only the last view's exchange is exposed.  Capacity = 1.25 x the largest union seen (the first frame sizes it with one host
+    read); a union that outgrows it is detected one frame later (the counts are copied back asynchronously) and raises.
+    World size 1: ``view_kwargs`` selects the in-place arena modes of ``fused_view`` and nothing is exchanged.  ``force=True`` runs the
+    compact path without any collective (single-GPU test of the kernels the exchange depends on)."""
+
+    def __init__(self, flat: FlatGradients, names: Iterable[str], headroom: float = 1.25, n_buffers: int = 3, force: bool = False):
+        self.flat = flat
+        self.names = list(names)
+        assert flat.sparse_rows, "FrameExchange keeps the dense buffer clean row-wise: FlatGradients(sparse_rows=True)"
+        self.arena = flat.arena(self.names)
+        assert sorted(self.names[:len(ROW_NAMES)]) == sorted(ROW_NAMES), "the five per-Gaussian parameters must lead the parameter list"
+        self.N = self.arena["means"].shape[0]
+        self.K = self.arena["sh"].shape[1]
+        self.row_floats = 3 + 4 + 3 + 1 + self.K * 3
+        self.world = dist.get_world_size() if _active() else 1
+        self.active = bool(force) or self.world > 1
+        self.headroom, self.n_buffers = float(headroom), int(n_buffers)
+        self.cap = 0
+        self._bufs: List[Tensor] = []
+        self._free: List[int] = []
+        self._pending: List[tuple] = []     # (work, buffer index, ids) of exchanges in flight, oldest first
+        self._union = None                  # (mask uint8 [N], work) of the current view
+        self._cur = None                    # (buffer index, ids) handed out by targets() for the current view
+        self._counts = []                   # (pinned int64 tensor, event, capacity) for the deferred overflow check
+        self.payload_bytes = 0              # bytes all-reduced during the last frame (per rank)
+        self.n_exchanges = 0
+
+    # ---- per frame -------------------------------------------------------------------------------------------------
+    def begin_frame(self) -> None:
+        self._check_overflow()
+        self.flat.zero()
+        if self.active:   # the reduced rows are added into the dense buffer, which IS the parameters' .grad; the small dense tail
+            #               (grids, ...) is accumulated by autograd as usual and packed in end_frame
+            for p, v in zip(self.flat.params[:len(ROW_NAMES)], self.flat._views[:len(ROW_NAMES)]):
+                p.grad = v
+        self.payload_bytes, self.n_exchanges = 0, 0
+
+    def view_kwargs(self, v: int) -> dict:
+        """Keyword arguments of ``fused_view`` / ``harness.render_view`` for the v-th view of the frame."""
+        if self.active:
+            return dict(grad_sink=self)
+        return dict(grad_arena=self.arena, arena_rows=1 if v == 0 else 2)
+
+    def begin_view(self, info) -> None:
+        """Right after the view's forward pass (``info`` = its info dict)."""
+        if not self.active:
+            self.flat.mark_list(info["visible_ids"])
+            return
+        mask = (info["radii"].reshape(-1) > 0).to(torch.uint8)
+        work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, async_op=True) if self.world > 1 else None
+        self._union = (mask, work)
+
+    def targets(self, visible_ids: Tensor):
+        """Called by the fused view's backward: compact destination buffers + the slot map of the ranks' union."""
+        mask, work = self._union
+        self._union = None
+        if work is not None:
+            work.wait()
+        slot = torch.cumsum(mask, 0, dtype=torch.int32) - 1
+        if self.cap == 0:   # first view ever: size the buffers from the actual union (one host read)
+            self._allocate(int(slot[-1]) + 1)
+        cnt = torch.empty(1, dtype=torch.int64).pin_memory() if mask.is_cuda else torch.empty(1, dtype=torch.int64)
+        cnt.copy_(slot[-1:] + 1, non_blocking=True)
+        ev = None
+        if mask.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._counts.append((cnt, ev, self.cap))
+        row_map = slot.clamp_(max=self.cap - 1)
+        # ids[s] = the Gaussian at union slot s, -1 beyond the union (no host sync: scatter through a dump slot)
+        if getattr(self, "_iota", None) is None or self._iota.numel() != self.N or self._iota.device != mask.device:
+            self._iota = torch.arange(self.N, device=mask.device, dtype=torch.int32)
+        ids = torch.full((self.cap + 1,), -1, device=mask.device, dtype=torch.int32)
+        ids.scatter_(0, torch.where(mask > 0, row_map, self.cap).long(), self._iota)
+        ids = ids[:self.cap]
+        if not self._free:      # every buffer is in flight: retire the oldest exchange first
+            self._retire()
+        b = self._free.pop()
+        buf = self._bufs[b]
+        buf.zero_()
+        self._cur = (b, ids)
+        return self._views_of(buf), row_map
+
+    def end_view(self) -> None:
+        """Right after the view's backward pass."""
+        if not self.active:
+            return
+        b, ids = self._cur
+        self._cur = None
+        buf = self._bufs[b]
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+        self.payload_bytes += buf.numel() * 4
+        self.n_exchanges += 1
+        self._pending.append((work, b, ids))
+        while len(self._pending) > 1:      # the previous view's exchange ran behind this view's compute
+            self._retire()
+
+    def end_frame(self) -> None:
+        """After the last view: drain the exchanges and sum the small dense tail (grids, ...) over the ranks."""
+        if not self.active:
+            return
+        while self._pending:
+            self._retire()
+        n_row = self.N * self.row_floats
+        tail = self.flat.flat[n_row:]
+        if tail.numel():
+            for p, v in zip(self.flat.params[len(ROW_NAMES):], self.flat._views[len(ROW_NAMES):]):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                p.grad = v
+            if self.world > 1:
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+                self.payload_bytes += tail.numel() * 4
+
+    # ---- internals -------------------------------------------------------------------------------------------------
+    def _allocate(self, n_union: int) -> None:
+        cap = int(n_union * self.headroom) + 64
+        self.cap = min((cap + 3) // 4 * 4, (self.N + 3) // 4 * 4)    # multiple of 4: every sub-array starts 16-byte aligned
+        dev = self.arena["means"].device
+        self._bufs = [torch.zeros(self.cap * self.row_floats, device=dev, dtype=torch.float32) for _ in range(self.n_buffers)]
+        self._free = list(range(self.n_buffers))
+
+    def _views_of(self, buf: Tensor) -> Dict[str, Tensor]:
+        c, K = self.cap, self.K
+        o, out = 0, {}
+        for name, shape in (("means", (c, 3)), ("quats", (c, 4)), ("log_scales", (c, 3)), ("opacity_logits", (c,)), ("sh", (c, K, 3))):
+            n = 1
+            for d in shape:
+                n *= d
+            out[name] = buf[o:o + n].view(shape)
+            o += n
+        return out
+
+    def _retire(self) -> None:
+        work, b, ids = self._pending.pop(0)
+        if work is not None:
+            work.wait()
+        src, dst = self._views_of(self._bufs[b]), self.arena
+        if src["means"].is_cuda:
+            from . import _lib as L
+            L.check(L.lib().bds_view_grads_add_list(ids.numel(), L.ptr(ids), self.K, L.ptr(src["means"]), L.ptr(src["quats"]),
+                                                    L.ptr(src["log_scales"]), L.ptr(src["opacity_logits"]), L.ptr(src["sh"]),
+                                                    L.ptr(dst["means"]), L.ptr(dst["quats"]), L.ptr(dst["log_scales"]),
+                                                    L.ptr(dst["opacity_logits"]), L.ptr(dst["sh"]), L.stream()), "bds_view_grads_add_list")
+        else:   # CPU tensors (gloo tests of the exchange logic)
+            ok = ids >= 0
+            il = ids[ok].long()
+            for k in ROW_NAMES:
+                dst[k].index_add_(0, il, src[k][ok])
+        self.flat.mark_list(ids)
+        self._free.append(b)
+
+    def _check_overflow(self) -> None:
+        keep = []
+        for cnt, ev, cap in self._counts:
+            if ev is not None:
+                ev.synchronize()    # recorded during the previous frame: long done; (never query(): every rank must decide alike)
+            n = int(cnt[0])
+            if n > cap:
+                raise RuntimeError(f"FrameExchange: the union of the ranks' visible sets ({n} Gaussians) outgrew the exchange "
+                                   f"capacity ({cap}); the previous frame's gradients are incomplete -- raise `headroom`")
+            if n > 0.92 * cap and cap < self.N:     # growing scene: re-size before it overflows
+                self.cap = 0
+        self._counts = keep
+        if self.cap == 0 and self._bufs and not self._pending:
+            self._bufs, self._free = [], []
 
 
 def reduce_densify_stats(grad_norm_accum: Tensor, vis_counts: Tensor, max_2d_size: Tensor) -> None:

@@ -59,6 +59,19 @@ class _Info(dict):
         return k == "flatten_ids" or dict.__contains__(self, k)
 
 
+class _Out(dict):
+    """Result dict of the fused view; ``rgb_gaussians`` (the reference's ``clamp(rendered_rgb, max=1.0)``, trainers/base.py:414, only
+    used for inspection: the transform consumes the clamp fused) is materialised on first access."""
+
+    def __getitem__(self, k):
+        if k == "rgb_gaussians" and not dict.__contains__(self, k):
+            dict.__setitem__(self, k, dict.__getitem__(self, "_rgb_g_raw").clamp(max=1.0))
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k == "rgb_gaussians" or dict.__contains__(self, k)
+
+
 class _FusedView(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, viewmat, *grids):
@@ -144,7 +157,7 @@ class _FusedView(torch.autograd.Function):
         with L.timed("bilagrid_fwd"):
             L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
                                                L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")
-        rgb_g = render[0, :, :, :3].clamp(max=1.0)   # the Gaussians' colour before sky / transform (base.py:414: clamp(max=1.0))
+        rgb_g = render[0, :, :, :3]   # view: the Gaussians' colour before clamp / sky / transform (clamped on access, see _Out)
         ctx.cfg = cfg
         ctx.M = M
         ctx.n_grids = len(grids)
@@ -208,12 +221,19 @@ class _FusedView(torch.autograd.Function):
         # arena modes (need all five per-Gaussian arena entries): 1 = store the visible rows into an arena the caller keeps zero
         # elsewhere, 2 = add them to an arena that already is the parameters' .grad (several views summed before one exchange)
         rows = int(cfg.get("arena_rows", 0)) if all(k in arena for k in ("means", "quats", "log_scales", "opacity_logits", "sh")) else 0
+        # sink mode (multi-GPU, dist.FrameExchange): the rows go into a compact exchange buffer, row_map[g] = the slot of Gaussian g
+        # in the union of the ranks' visible sets; the sink adds the reduced rows to the parameters' .grad itself
+        sink, row_map = cfg.get("grad_sink"), None
+        if sink is not None:
+            arena, row_map = sink.targets(vis_ids)
+            rows = 1
 
         def out_like(name, ref):  # gradient output: the caller's slice of a flat communication buffer, or a fresh zero tensor
             t = arena.get(name)
             if t is None:
                 return torch.zeros_like(ref)
-            assert t.shape == ref.shape and t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device, name
+            assert t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device and t.shape[1:] == ref.shape[1:], name
+            assert sink is not None or t.shape == ref.shape, name
             if not rows:
                 t.zero_()
             return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
@@ -221,7 +241,7 @@ class _FusedView(torch.autograd.Function):
         v_sh = out_like("sh", sh)
         with L.timed("sh_bwd"):
             L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
-                                             L.ptr(v_rec), L.ptr(v_sh), None, int(rows == 2), st), "bds_sh_view_bwd_list")
+                                             L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map), int(rows == 2), st), "bds_sh_view_bwd_list")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
@@ -230,13 +250,13 @@ class _FusedView(torch.autograd.Function):
             L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
                                                   L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
                                                   L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
-                                                  None, int(rows == 2), st), "bds_project_view_bwd_list")
+                                                  L.ptr(row_map), int(rows == 2), st), "bds_project_view_bwd_list")
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]
             carrier.absgrad = g2d[1:2]
         v_viewmat = None if v_vm_slots is None else v_vm_slots.sum(0)
-        if rows == 2:   # already added in place to what autograd holds as .grad: nothing to hand back
+        if rows == 2 or sink is not None:   # already added in place to what autograd holds as .grad (or handed to the sink)
             return (None, None, None, None, None, None, v_sky, v_viewmat, *v_grids)
         return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, v_viewmat, *v_grids)
 
@@ -245,7 +265,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
                grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
-               img_idx: Optional[int] = None, arena_rows: int = 0):
+               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
     [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
@@ -261,12 +281,15 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     ``arena_rows`` (opt-in, needs all five per-Gaussian arena entries): 1 = the backward STORES only the rows of the Gaussians this view
     sees -- the caller promises that every other row of the arena is zero (``dist.FlatGradients(sparse_rows=True).zero()`` keeps it so);
     2 = it ADDS them to an arena that autograd already holds as the parameters' ``.grad`` (second and later views of a frame that
-    is exchanged once) and returns no gradient for those parameters."""
+    is exchanged once) and returns no gradient for those parameters.
+    ``grad_sink`` (multi-GPU, ``dist.FrameExchange``): an object whose ``targets(visible_ids)`` is called inside the backward and
+    returns (compact buffers by name, row_map [N] i32); the visible rows are stored at ``row_map[g]`` of those buffers and no
+    gradient is returned for the five per-Gaussian parameters (the sink adds the reduced rows to their ``.grad``)."""
     if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds.data[..., :3, 3]); callers with fixed cameras cache it
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
-               eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena,
+               eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena, grad_sink=grad_sink,
                img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows))
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky,
@@ -276,4 +299,4 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     info = _Info({"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
                   "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets, "tile_size": TILE,
                   "n_cameras": 1, "n_isects": int(flatten_ranks.numel()), "n_visible": int(vis_ids.numel())})
-    return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
+    return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)

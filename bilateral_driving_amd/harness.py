@@ -43,8 +43,8 @@ class Camera:
     cam_pos: Optional[Tensor] = None  # [3] camera centre in world space (= inv(viewmat)[:3, 3]), cached per camera
 
 
-def ring_cameras(W: int, H: int, yaws_deg: Sequence[float] = SIX_CAM_YAWS, device="cpu") -> List[Camera]:
-    """Ring rig at the origin; world frame: x forward, y left, z up (driving convention)."""
+def ring_cameras(W: int, H: int, yaws_deg: Sequence[float] = SIX_CAM_YAWS, device="cpu", origin=(0.0, 0.0, 0.0)) -> List[Camera]:
+    """Ring rig at ``origin`` (default: the world origin); world frame: x forward, y left, z up (driving convention)."""
     fx = 0.5 * W / math.tan(math.radians(35.0))
     K = torch.tensor([[fx, 0, W / 2], [0, fx, H / 2], [0, 0, 1]], dtype=torch.float32, device=device)
     cams = []
@@ -56,7 +56,7 @@ def ring_cameras(W: int, H: int, yaws_deg: Sequence[float] = SIX_CAM_YAWS, devic
         R = torch.stack([right, down, fwd])  # rows = camera axes in world coordinates
         vm = torch.eye(4)
         vm[:3, :3] = R
-        # rig at the origin
+        vm[:3, 3] = -R @ torch.tensor([float(o) for o in origin])   # rig at the origin by default
         cams.append(Camera(vm.to(device), K, W, H, torch.linalg.inv(vm)[:3, 3].contiguous().to(device)))
     return cams
 
@@ -89,14 +89,14 @@ def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> L
 
 def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
                 factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
-                radius_clip: float = 0.0, eps2d: float = 0.3, grad_arena=None, arena_rows: int = 0):
+                radius_clip: float = 0.0, eps2d: float = 0.3, grad_arena=None, arena_rows: int = 0, grad_sink=None):
     """One view's forward (dict(rgb, depth, opacity, rgb_gaussians, info)): a single fused autograd node
     (fused_view.py) by default, or the chain of individual operators (render_view_staged) when FUSED is off."""
     if not FUSED:
         return render_view_staged(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
     return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL,
-                      grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows)
+                      grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink)
 
 
 def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,

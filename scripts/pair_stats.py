@@ -20,16 +20,9 @@ from bilateral_driving_amd import gs_ops as ops  # noqa: E402
 from bilateral_driving_amd import harness as Hn  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gaussians", type=int, default=2_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--view", type=int, default=0)
-    a = ap.parse_args()
-    dev = torch.device("cuda", 0)
-    N, W, H = a.gaussians, a.width, a.height
-    cam = Hn.ring_cameras(W, H, device=dev)[a.view]
+def pair_stats(N, W, H, view=0):
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cam = Hn.ring_cameras(W, H, device=dev)[view]
     p = Hn.synthetic_scene(N, seed=0, device=dev)
     with torch.no_grad():
         radii, m2, dep, con, _ = ops.fully_fused_projection(p["means"], p["quats"], torch.exp(p["log_scales"]), cam.viewmat[None], cam.K[None],
@@ -91,11 +84,21 @@ def main():
             vq = valid.reshape(valid.shape[0], valid.shape[1], 4, 4, 16)          # rows r = 4*q + l  -> index [q, l]
             pairs2 += int(vq[:, :, 0:2].any(dim=4).any(dim=3).any(dim=2).sum()) + int(vq[:, :, 2:4].any(dim=4).any(dim=3).any(dim=2).sum())
             quads += int(valid.reshape(valid.shape[0], valid.shape[1], 2, 8, 2, 8).any(dim=5).any(dim=3).sum())
-        out = dict(gaussians=N, width=W, height=H, view=a.view, n_visible=int((radii > 0).sum()), isects_listed=M, pairs_tested=tested,
+        out = dict(gaussians=N, width=W, height=H, view=view, n_visible=int((radii > 0).sum()), isects_listed=M, pairs_tested=tested,
                    pairs_visited=visited, strips_visited=strips, halves_visited=pairs2, quadrants_visited=quads, pixel_blends=pix,
                    mean_strips_per_visited_pair=strips / max(visited, 1), mean_halves_per_visited_pair=pairs2 / max(visited, 1),
                    mean_pixels_per_visited_pair=pix / max(visited, 1))
-        print(json.dumps(out))
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gaussians", type=int, default=2_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--view", type=int, default=0)
+    a = ap.parse_args()
+    print(json.dumps(pair_stats(a.gaussians, a.width, a.height, a.view)))
 
 
 if __name__ == "__main__":

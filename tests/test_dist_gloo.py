@@ -209,3 +209,105 @@ def test_sparse_rows_bookkeeping_single_process():
     dense = FlatGradients(_make_params())
     dense.zero()
     assert not dense.rows_clean                       # the default form never promises anything
+
+
+# ---- frame-wise exchange (dist.FrameExchange): per-view compact all-reduce, logic on CPU tensors over gloo ------------------
+_FX_N, _FX_K, _FX_VIEWS, _FX_FRAMES = 300, 4, 3, 3
+_FX_NAMES = ["means", "log_scales", "quats", "opacity_logits", "sh", "grid0"]
+
+
+def _fx_params():
+    g = torch.Generator().manual_seed(5)
+    shapes = [(_FX_N, 3), (_FX_N, 3), (_FX_N, 4), (_FX_N,), (_FX_N, _FX_K, 3), (2, 12, 1, 2, 2)]
+    return [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+
+
+def _fx_view(rank, frame, v):
+    """What a fused view's backward would produce on `rank`: the visible id list and one gradient row per visible Gaussian."""
+    g = torch.Generator().manual_seed(1000 * rank + 10 * frame + v)
+    lo = (41 * frame + 70 * v + 55 * rank) % _FX_N
+    n = 40 + 5 * v + (30 if frame == 2 else 0)               # the last frame's unions are larger: the capacity has to hold
+    ids = (torch.arange(lo, lo + n) % _FX_N).sort().values.to(torch.int32)
+    rows = {"means": torch.randn(n, 3, generator=g), "log_scales": torch.randn(n, 3, generator=g), "quats": torch.randn(n, 4, generator=g),
+            "opacity_logits": torch.randn(n, generator=g), "sh": torch.randn(n, _FX_K, 3, generator=g)}
+    grid_grad = torch.randn(2, 12, 1, 2, 2, generator=g)
+    return ids, rows, grid_grad
+
+
+def _fx_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    params = _fx_params()
+    flat = FlatGradients(params, sparse_rows=True)
+    fx = FrameExchange(flat, _FX_NAMES, headroom=1.6)
+    outs, payloads = [], []
+    for frame in range(_FX_FRAMES):
+        fx.begin_frame()
+        for v in range(_FX_VIEWS):
+            assert fx.view_kwargs(v) == dict(grad_sink=fx)
+            ids, rows, grid_grad = _fx_view(rank, frame, v)
+            radii = torch.zeros(1, _FX_N, dtype=torch.int32)
+            radii[0, ids.long()] = 3
+            fx.begin_view({"radii": radii, "visible_ids": ids})
+            # ... what fused_view's backward does with the sink: rows of the visible Gaussians at their union slots
+            bufs, row_map = fx.targets(ids)
+            slots = row_map[ids.long()].long()
+            for k, r in rows.items():
+                bufs[k][slots] = r
+            params[5].grad = grid_grad.clone() if params[5].grad is None else params[5].grad + grid_grad   # autograd's accumulation
+            fx.end_view()
+        fx.end_frame()
+        assert all(p.grad is not None and p.grad.data_ptr() == w.data_ptr() for p, w in zip(params, flat._views))
+        outs.append(flat.flat.clone())
+        payloads.append(fx.payload_bytes)
+    q.put((rank, [o.numpy() for o in outs], payloads, flat.nbytes, fx.cap))
+    dist.destroy_process_group()
+
+
+def test_frame_exchange_equals_sequential_sum_over_views_and_ranks():
+    """Every frame: sum over ranks and views of the per-view gradient rows, exchanged per view through compact buffers whose
+    slots are the union of the ranks' visible sets == one process adding up the same rows; every single exchange moves a fraction
+    of the dense buffer (what makes it short enough to hide behind the next view); stale rows of the previous frame are cleared
+    through the union lists."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fx_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [tuple(p.shape) for p in _fx_params()]
+    for frame in range(_FX_FRAMES):
+        ref = [torch.zeros(s) for s in shapes]
+        for rank in range(world):
+            for v in range(_FX_VIEWS):
+                ids, rows, grid_grad = _fx_view(rank, frame, v)
+                for i, k in enumerate(_FX_NAMES[:5]):
+                    ref[i].index_add_(0, ids.long(), rows[k])
+                ref[5] += grid_grad
+        ref = torch.cat([r.reshape(-1) for r in ref]).numpy()
+        for r in range(world):
+            assert abs(res[r][1][frame] - ref).max() < 1e-5, (frame, r)
+            assert res[r][2][frame] / _FX_VIEWS < 0.8 * res[r][3]       # every single exchange moves a fraction of the dense buffer
+    assert res[0][4] == res[1][4] and res[0][4] % 4 == 0               # same capacity on every rank, 16-byte aligned sub-arrays
+
+
+def test_frame_exchange_single_process_uses_the_arena_modes():
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    params = _fx_params()
+    flat = FlatGradients(params, sparse_rows=True)
+    fx = FrameExchange(flat, _FX_NAMES)
+    assert not fx.active
+    fx.begin_frame()
+    kw0, kw1 = fx.view_kwargs(0), fx.view_kwargs(1)
+    assert kw0["arena_rows"] == 1 and kw1["arena_rows"] == 2 and kw0["grad_arena"]["sh"].data_ptr() == flat._views[4].data_ptr()
+    fx.begin_view({"radii": torch.ones(1, _FX_N, dtype=torch.int32), "visible_ids": torch.arange(5, dtype=torch.int32)})
+    fx.end_view()
+    fx.end_frame()
+    assert flat._dirty is not None and len(flat._dirty) == 1
