@@ -68,6 +68,8 @@ _SIGS = {
     "bds_ssim_bwd": (_i, [_i, _i, _i, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_pixel_loss_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f]),
     "bds_pixel_loss_bwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _fl, _f, _f, _f, _f, _f, _f]),
+    "bds_reg_loss_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _fl, _f, _f, _f]),
+    "bds_reg_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _fl, _f, _f, _f, _f, _f, _f]),
     "bds_densify_stats": (_i, [_i64, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_refine_plan_temp_bytes": (_sz, [_i64]),
     "bds_refine_plan": (_i, [_i64, _f, _f, _f, _f, _f, _i, _fl, _fl, _i, _fl, _i, _fl, _i, _fl, _i, _fl, _f, _f, _f, _f, _sz, _f]),

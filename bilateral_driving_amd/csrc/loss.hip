@@ -260,6 +260,127 @@ __global__ __launch_bounds__(kLossBlock) void pixel_loss_bwd_kernel(int64_t P, P
   }
 }
 
+// ---- regularisers of the reference's image loss (models/trainers/base.py:566-585, 638-659) ---------------------------
+//   opacity entropy     p = clamp(opacity, 1e-6, 1 - 1e-6);  (-p log p).mean()                                        (:566-572)
+//   inverse-depth smoothness (kornia.losses.inverse_depth_smoothness_loss -- external package, PARITY UNPINNED, restated from its
+//     published definition):  id = 1 / (depth + 1e-5);  mean |(id[x] - id[x+1]) * exp(-mean_c |img[x] - img[x+1]|)| over (H, W-1)
+//     + the same along y over (H-1, W); the reference repeats id to three equal channels (:575-582), which leaves the mean unchanged
+//   dynamic-region L1   over the pixels with Dynamic_opacity > 0.2 (detached) and valid: |pixels*valid - rgb*valid|.mean()  (:638-651)
+// One pass computes the sums (sums[0] entropy, [1] x-smoothness, [2] y-smoothness, [3] masked L1, [4] masked pixel count);
+// the backward is one more (gather-style: a pixel's depth gradient collects its four neighbour differences).
+struct RegLossArgs {
+  const float *opacity, *depth, *pixels, *rgb, *dyn_opacity, *egocar;
+  int H, W;
+  float dyn_threshold;
+};
+
+__device__ __forceinline__ float inv_depth(const RegLossArgs &a, int y, int x) { return 1.f / (a.depth[(int64_t)y * a.W + x] + 1e-5f); }
+// exp(-mean_c |img[p] - img[q]|)
+__device__ __forceinline__ float edge_weight(const RegLossArgs &a, int64_t p, int64_t q) {
+  const float d = fabsf(a.pixels[p * 3] - a.pixels[q * 3]) + fabsf(a.pixels[p * 3 + 1] - a.pixels[q * 3 + 1]) +
+                  fabsf(a.pixels[p * 3 + 2] - a.pixels[q * 3 + 2]);
+  return expf(-(d / 3.f));
+}
+
+__global__ __launch_bounds__(kLossBlock) void reg_loss_fwd_kernel(RegLossArgs a, float *__restrict__ sums) {
+  __shared__ float red[5][kLossBlock / kWave];
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int64_t P = (int64_t)a.H * a.W;
+  for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < P; i += (int64_t)gridDim.x * kLossBlock) {
+    const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
+    if (a.opacity) {
+      const float p = fminf(fmaxf(a.opacity[i], 1e-6f), 1.f - 1e-6f);
+      s[0] += -p * logf(p);
+    }
+    if (a.depth) {
+      const float id = inv_depth(a, y, x);
+      if (x + 1 < a.W) s[1] += fabsf((id - inv_depth(a, y, x + 1)) * edge_weight(a, i, i + 1));
+      if (y + 1 < a.H) s[2] += fabsf((id - inv_depth(a, y + 1, x)) * edge_weight(a, i, i + a.W));
+    }
+    if (a.dyn_opacity && a.dyn_opacity[i] > a.dyn_threshold) {
+      const float valid = a.egocar ? 1.f - a.egocar[i] : 1.f;
+      if (valid != 0.f) {   // dynamic_pred_mask & valid_loss_mask.bool()
+#pragma unroll
+        for (int c = 0; c < 3; c++) s[3] += fabsf(a.pixels[i * 3 + c] * valid - a.rgb[i * 3 + c] * valid);
+        s[4] += 1.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const float t = wave_sum_to_lane63(s[k]);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) red[k][threadIdx.x / kWave] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    float t = 0.f;
+    for (int w = 0; w < kLossBlock / kWave; w++) t += red[threadIdx.x][w];
+    if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
+  }
+}
+
+// terms[0..2] = entropy, smoothness, dynamic-region L1 (0 when the mask is empty: the reference then adds no term)
+__global__ void reg_loss_finalize_kernel(int H, int W, const float *__restrict__ sums, int has_entropy, int has_smooth, int has_dyn,
+                                         float *__restrict__ terms) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float P = (float)H * (float)W;
+  terms[0] = has_entropy ? sums[0] / P : 0.f;
+  float sm = 0.f;
+  if (has_smooth) {   // a mean over an empty tensor (W = 1 or H = 1) is NaN in the reference, too
+    sm = sums[1] / ((float)H * (float)(W - 1)) + sums[2] / ((float)(H - 1) * (float)W);
+  }
+  terms[1] = sm;
+  terms[2] = (has_dyn && sums[4] > 0.f) ? sums[3] / (3.f * sums[4]) : 0.f;
+}
+
+__global__ __launch_bounds__(kLossBlock) void reg_loss_bwd_kernel(RegLossArgs a, const float *__restrict__ sums,
+                                                                 const float *__restrict__ v_terms, float *__restrict__ v_opacity,
+                                                                 float *__restrict__ v_depth, float *__restrict__ v_rgb) {
+  const int64_t P = (int64_t)a.H * a.W;
+  const float g_ent = v_terms[0] / (float)P;
+  const float gx = v_terms[1] / ((float)a.H * (float)(a.W - 1)), gy = v_terms[1] / ((float)(a.H - 1) * (float)a.W);
+  const float g_dyn = sums[4] > 0.f ? v_terms[2] / (3.f * sums[4]) : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < P; i += (int64_t)gridDim.x * kLossBlock) {
+    const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
+    if (v_opacity) {
+      float v = 0.f;
+      if (a.opacity) {
+        const float o = a.opacity[i];
+        if (o >= 1e-6f && o <= 1.f - 1e-6f) v = -g_ent * (logf(o) + 1.f);   // torch.clamp passes the gradient on the closed interval
+      }
+      v_opacity[i] = v;
+    }
+    if (v_depth) {
+      float v = 0.f;
+      if (a.depth) {
+        const float id = inv_depth(a, y, x);
+        float vid = 0.f;   // d / d id of the four differences this pixel takes part in; |t| has derivative sign(t), sign(0) = 0
+        auto sgn = [](float t) { return t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); };
+        if (x + 1 < a.W) { const float w = edge_weight(a, i, i + 1); vid += gx * sgn((id - inv_depth(a, y, x + 1)) * w) * w; }
+        if (x > 0) { const float w = edge_weight(a, i - 1, i); vid -= gx * sgn((inv_depth(a, y, x - 1) - id) * w) * w; }
+        if (y + 1 < a.H) { const float w = edge_weight(a, i, i + a.W); vid += gy * sgn((id - inv_depth(a, y + 1, x)) * w) * w; }
+        if (y > 0) { const float w = edge_weight(a, i - a.W, i); vid -= gy * sgn((inv_depth(a, y - 1, x) - id) * w) * w; }
+        v = -vid * id * id;
+      }
+      v_depth[i] = v;
+    }
+    if (v_rgb) {
+      float v[3] = {0.f, 0.f, 0.f};
+      if (a.dyn_opacity && a.dyn_opacity[i] > a.dyn_threshold) {
+        const float valid = a.egocar ? 1.f - a.egocar[i] : 1.f;
+        if (valid != 0.f) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float d = a.rgb[i * 3 + c] * valid - a.pixels[i * 3 + c] * valid;
+            v[c] = (d > 0.f ? g_dyn : (d < 0.f ? -g_dyn : 0.f)) * valid;
+          }
+        }
+      }
+      v_rgb[i * 3] = v[0]; v_rgb[i * 3 + 1] = v[1]; v_rgb[i * 3 + 2] = v[2];
+    }
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -376,6 +497,49 @@ extern "C" int bds_pixel_loss_bwd(int64_t P, const float *rgb, const float *pixe
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((unsigned)blocks), dim3(kLossBlock), 0, as_stream(stream), P, a, sums, v_terms,
                      w_rgb, w_mask, w_depth, v_rgb, v_opacity, v_depth);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+static int reg_loss_args(RegLossArgs &a, int H, int W, const float *opacity, const float *depth, const float *pixels, const float *rgb,
+                         const float *dyn_opacity, const float *egocar, float dyn_threshold) {
+  BDS_REQUIRE(H >= 1 && W >= 1);
+  BDS_REQUIRE(depth == nullptr || pixels != nullptr);
+  BDS_REQUIRE(dyn_opacity == nullptr || (pixels != nullptr && rgb != nullptr));
+  a.opacity = opacity; a.depth = depth; a.pixels = pixels; a.rgb = rgb; a.dyn_opacity = dyn_opacity; a.egocar = egocar;
+  a.H = H; a.W = W; a.dyn_threshold = dyn_threshold;
+  return BDS_OK;
+}
+
+extern "C" int bds_reg_loss_fwd(int H, int W, const float *opacity, const float *depth, const float *pixels, const float *rgb,
+                                const float *dyn_opacity, const float *egocar, float dyn_threshold, float *sums, float *terms,
+                                bds_stream_t stream) {
+  RegLossArgs a;
+  int rc = reg_loss_args(a, H, W, opacity, depth, pixels, rgb, dyn_opacity, egocar, dyn_threshold);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(sums && terms);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(sums, 0, 5 * sizeof(float), st) != hipSuccess) return BDS_ELAUNCH;
+  int64_t blocks = cdiv((int64_t)H * W, kLossBlock * 4);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(reg_loss_fwd_kernel, dim3((unsigned)blocks), dim3(kLossBlock), 0, st, a, sums);
+  hipLaunchKernelGGL(reg_loss_finalize_kernel, dim3(1), dim3(kWave), 0, st, H, W, sums, opacity != nullptr, depth != nullptr,
+                     dyn_opacity != nullptr, terms);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_reg_loss_bwd(int H, int W, const float *opacity, const float *depth, const float *pixels, const float *rgb,
+                                const float *dyn_opacity, const float *egocar, float dyn_threshold, const float *sums,
+                                const float *v_terms, float *v_opacity, float *v_depth, float *v_rgb, bds_stream_t stream) {
+  RegLossArgs a;
+  int rc = reg_loss_args(a, H, W, opacity, depth, pixels, rgb, dyn_opacity, egocar, dyn_threshold);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(sums && v_terms);
+  int64_t blocks = cdiv((int64_t)H * W, kLossBlock * 2);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reg_loss_bwd_kernel, dim3((unsigned)blocks), dim3(kLossBlock), 0, as_stream(stream), a, sums, v_terms,
+                     v_opacity, v_depth, v_rgb);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

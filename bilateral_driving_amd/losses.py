@@ -162,3 +162,45 @@ def pixel_loss(rgb: Tensor, opacity: Tensor, depth: Tensor, pixels: Tensor, sky_
         raise NotImplementedError(f"Unknown loss type: {depth_loss_type}")   # DepthLoss (models/losses.py:150) also has smooth_l1
     return _PixelLoss.apply(rgb, opacity, depth, pixels, sky_masks, lidar_depth, egocar_masks,
                             (float(w_rgb), float(w_mask), float(w_depth)), depth_loss_type == "l2", float(max_depth))
+
+
+class _RegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, opacity, depth, rgb, pixels, dyn_opacity, egocar, dyn_threshold):
+        L.require_gpu(pixels, opacity, depth, rgb)
+        f = lambda t: None if t is None else t.contiguous().to(torch.float32)
+        opacity, depth, rgb, pixels, dyn_opacity, egocar = (f(t) for t in (opacity, depth, rgb, pixels, dyn_opacity, egocar))
+        H, W = pixels.shape[0], pixels.shape[1]
+        for t in (opacity, depth, dyn_opacity, egocar):
+            assert t is None or t.numel() == H * W, "per-pixel inputs must have H*W elements"
+        dev = pixels.device
+        sums, terms = torch.empty(5, device=dev, dtype=torch.float32), torch.empty(3, device=dev, dtype=torch.float32)
+        L.check(L.lib().bds_reg_loss_fwd(H, W, L.ptr(opacity), L.ptr(depth), L.ptr(pixels), L.ptr(rgb), L.ptr(dyn_opacity), L.ptr(egocar),
+                                         dyn_threshold, L.ptr(sums), L.ptr(terms), L.stream()), "bds_reg_loss_fwd")
+        ctx.save_for_backward(opacity, depth, rgb, pixels, dyn_opacity, egocar, sums)
+        ctx.dyn_threshold = dyn_threshold
+        return terms
+
+    @staticmethod
+    def backward(ctx, v_terms):
+        opacity, depth, rgb, pixels, dyn_opacity, egocar, sums = ctx.saved_tensors
+        H, W = pixels.shape[0], pixels.shape[1]
+        v_terms = v_terms.contiguous().to(torch.float32)
+        v_op = torch.empty_like(opacity) if (opacity is not None and ctx.needs_input_grad[0]) else None
+        v_dp = torch.empty_like(depth) if (depth is not None and ctx.needs_input_grad[1]) else None
+        v_rgb = torch.empty_like(rgb) if (rgb is not None and dyn_opacity is not None and ctx.needs_input_grad[2]) else None
+        L.check(L.lib().bds_reg_loss_bwd(H, W, L.ptr(opacity), L.ptr(depth), L.ptr(pixels), L.ptr(rgb), L.ptr(dyn_opacity), L.ptr(egocar),
+                                         ctx.dyn_threshold, L.ptr(sums), L.ptr(v_terms), L.ptr(v_op), L.ptr(v_dp), L.ptr(v_rgb), L.stream()),
+                "bds_reg_loss_bwd")
+        return v_op, v_dp, v_rgb, None, None, None, None
+
+
+def reg_losses(pixels: Tensor, opacity: Tensor = None, depth: Tensor = None, rgb: Tensor = None, dyn_opacity: Tensor = None,
+               egocar_masks: Tensor = None, dyn_threshold: float = 0.2) -> Tensor:
+    """The regularisers of ``BasicTrainer.compute_losses`` (models/trainers/base.py:566-585, 638-659) in one pass each way; returns the
+    three UNWEIGHTED terms ``[opacity_entropy, inverse_depth_smoothness, dynamic_region_l1]`` (the trainer multiplies them by
+    ``losses.opacity_entropy.w`` / ``losses.inverse_depth_smoothness.w`` / ``losses.dynamic_region.w``).  pixels / rgb [H,W,3];
+    opacity, depth, dyn_opacity (``outputs["Dynamic_opacity"]``, treated as data like the reference's ``.data``) [H,W,1] or [H,W].
+    Pass ``None`` to drop a term (it is then 0).  The dynamic-region term is 0 when no pixel qualifies (the reference adds none)."""
+    return _RegLoss.apply(opacity, depth, rgb, pixels, None if dyn_opacity is None else dyn_opacity.detach(), egocar_masks,
+                          float(dyn_threshold))

@@ -385,6 +385,21 @@ int bds_refine_rows(int64_t N, int width, int samps, const uint8_t *flags, const
  * exp_avg / exp_avg_sq (either may be NULL) are zeroed. */
 int bds_opacity_reset(int64_t N, float *logits, float reset_value, float *exp_avg, float *exp_avg_sq, bds_stream_t stream);
 
+/* Regularisers of the reference's image loss (models/trainers/base.py:566-585, 638-659), one pass each way:
+ *   terms[0] opacity entropy       (-p log p).mean(), p = clamp(opacity, 1e-6, 1-1e-6)                       (opacity != NULL)
+ *   terms[1] inverse-depth smoothness  kornia.losses.inverse_depth_smoothness_loss(1/(depth+1e-5), pixels)    (depth != NULL;
+ *            kornia is an external package absent here: restated from its published definition, PARITY UNPINNED)
+ *   terms[2] dynamic-region L1     |pixels*valid - rgb*valid| averaged over {dyn_opacity > dyn_threshold and valid} (dyn_opacity != NULL;
+ *            0 when the mask is empty, where the reference adds no term)
+ * opacity / depth / dyn_opacity / egocar [H*W], pixels / rgb [H*W,3]; sums [5] and terms [3] on the device.  The backward writes
+ * (not accumulates) v_opacity / v_depth [H*W], v_rgb [H*W,3] (each may be NULL) for the UNWEIGHTED terms scaled by v_terms [3]. */
+int bds_reg_loss_fwd(int H, int W, const float *opacity, const float *depth, const float *pixels, const float *rgb,
+                     const float *dyn_opacity, const float *egocar, float dyn_threshold, float *sums, float *terms,
+                     bds_stream_t stream);
+int bds_reg_loss_bwd(int H, int W, const float *opacity, const float *depth, const float *pixels, const float *rgb,
+                     const float *dyn_opacity, const float *egocar, float dyn_threshold, const float *sums, const float *v_terms,
+                     float *v_opacity, float *v_depth, float *v_rgb, bds_stream_t stream);
+
 /* ---- Cube-map sky (the ROCm replacement of nvdiffrast's cube texture) -----------------------------
  * EnvLight.forward (models/modules.py:176-211): out[i] = bilinear cube-map lookup of tex [6,res,res,channels] along
  * dirs[i] @ rot^T (rot: 9 floats on the device, row-major, NULL = identity; the reference's to_opengl, :189,196) --

@@ -133,3 +133,41 @@ def densify_stats_update(state, absgrad, radii, width, height, batch_size=1):
     return dict(xys_grad_norm=torch.where(vis, n + state["xys_grad_norm"], state["xys_grad_norm"]),
                 vis_counts=torch.where(vis, state["vis_counts"] + 1, state["vis_counts"]),
                 max_2Dsize=torch.where(vis, torch.maximum(state["max_2Dsize"], size), state["max_2Dsize"]))
+
+
+def reg_losses(pixels, opacity=None, depth=None, rgb=None, dyn_opacity=None, egocar_masks=None, dyn_threshold=0.2):
+    """Regularisers of BasicTrainer.compute_losses, transcribed term by term (differentiable torch ops; autograd = gradient oracle):
+
+      * opacity entropy       /root/reference/project/models/trainers/base.py:566-572
+      * inverse-depth smoothness  :574-585 -> kornia.losses.inverse_depth_smoothness_loss.  kornia is an external package that is not
+        in this image (``import kornia`` fails) and not pinned by the reference: PARITY UNPINNED; restated from kornia's published
+        definition (image-gradient-weighted first differences of the inverse depth, mean over x-differences + mean over y-differences)
+      * dynamic-region L1     :638-651 (the mask is built from ``outputs["Dynamic_opacity"].data``: no gradient through it)
+
+    Returns the three unweighted terms (0 where the reference would add no term)."""
+    terms = []
+    if opacity is not None:
+        p = torch.clamp(opacity.squeeze(), 1e-6, 1 - 1e-6)
+        terms.append((-p * torch.log(p)).mean())
+    else:
+        terms.append(pixels.new_zeros(()))
+    if depth is not None:
+        inverse_depth = 1 / (depth.reshape(pixels.shape[0], pixels.shape[1], 1) + 1e-5)
+        idepth = inverse_depth[None].repeat(1, 1, 1, 3).permute(0, 3, 1, 2)
+        image = pixels[None].permute(0, 3, 1, 2)
+        idx, idy = idepth[:, :, :, :-1] - idepth[:, :, :, 1:], idepth[:, :, :-1, :] - idepth[:, :, 1:, :]
+        imx, imy = image[:, :, :, :-1] - image[:, :, :, 1:], image[:, :, :-1, :] - image[:, :, 1:, :]
+        wx = torch.exp(-torch.mean(torch.abs(imx), dim=1, keepdim=True))
+        wy = torch.exp(-torch.mean(torch.abs(imy), dim=1, keepdim=True))
+        terms.append(torch.abs(idx * wx).mean() + torch.abs(idy * wy).mean())
+    else:
+        terms.append(pixels.new_zeros(()))
+    dyn = pixels.new_zeros(())
+    if dyn_opacity is not None:
+        valid = torch.ones_like(pixels[..., 0]) if egocar_masks is None else (1.0 - egocar_masks).to(pixels.dtype)
+        gt_rgb, predicted_rgb = pixels * valid[..., None], rgb * valid[..., None]
+        mask = (dyn_opacity.detach() > dyn_threshold).reshape(valid.shape) & valid.bool()
+        if mask.sum() > 0:
+            dyn = torch.abs(gt_rgb[mask] - predicted_rgb[mask]).mean()
+    terms.append(dyn)
+    return torch.stack(terms)
