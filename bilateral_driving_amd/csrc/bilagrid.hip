@@ -385,15 +385,42 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
 // anchor +- (scale + 2)) among the workgroup's own pixels: P and Q (6 floats per pixel and level) never travel
 // through global memory, and the x reduction reads them from LDS.  Arithmetic and summation order are those of
 // ms_apply_bwd_kernel + ms_adjoint_x_kernel (the halo pixels are recomputed, ~7 % extra work at factor 4).
+// The two low-resolution rows (x the columns the window reaches) of every up-sampled level are staged in LDS first: a pixel then
+// re-derives its 3x4 maps from LDS taps instead of 12 scattered 16-byte loads per level (576 B/pixel of L2 traffic at 3 levels).
+struct MsRowStage {
+  int lds_off[BDS_MAX_LEVELS];   // float offset of the level's [2][max_lc][12] staging area
+  int max_lc[BDS_MAX_LEVELS];
+};
+
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
-                                                                 float *__restrict__ v_in, int halo, int nbx) {
+                                                                 float *__restrict__ v_in, int halo, int nbx, MsRowStage rs) {
   __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
+  extern __shared__ __attribute__((aligned(16))) float lds_rows[];
   const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
   const int stride = kBgBlock - 2 * halo;
   const int own0 = bx * stride, own1 = min(p.W, own0 + stride);
   const int xs = own0 - halo;
   const int x = xs + (int)threadIdx.x;
+  const int xa = max(xs, 0), xb = min(xs + kBgBlock, p.W) - 1;   // columns the window evaluates
+  int jlo[NL], nlc[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    jlo[l] = 0; nlc[l] = 0;
+    if (l >= p.nlevels) continue;
+    const LevelDev &L = p.lv[l];
+    if (L.Hd == p.H && L.Wd == p.W) continue;
+    const Tap ty = resample_tap(y, p.H, L.Hd);
+    jlo[l] = resample_tap(xa, p.W, L.Wd).i0;
+    nlc[l] = min(resample_tap(xb, p.W, L.Wd).i1 - jlo[l] + 1, rs.max_lc[l]);
+    float4 *dst = reinterpret_cast<float4 *>(lds_rows + rs.lds_off[l]);
+    for (int e = threadIdx.x; e < 2 * nlc[l] * 3; e += kBgBlock) {
+      const int r = e / (nlc[l] * 3), q = e - r * nlc[l] * 3;   // q = column * 3 + float4 index
+      const int row = r ? ty.i1 : ty.i0;
+      dst[r * rs.max_lc[l] * 3 + q] = reinterpret_cast<const float4 *>(L.lo + ((int64_t)row * L.Wd + jlo[l]) * 12)[q];
+    }
+  }
+  __syncthreads();
   if (x >= 0 && x < p.W) {
     const int64_t pix = (int64_t)y * p.W + x;
     const bool owner = x >= own0 && x < own1;
@@ -408,7 +435,25 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
           float *P = p.lv[l].P + pix * 3;
           P[0] = r; P[1] = g; P[2] = b;
         }
-        upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
+        if (p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {
+          upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
+        } else {   // same expression as upsample_affine, taps from the staged rows
+          const LevelDev &L = p.lv[l];
+          const Tap ty = resample_tap(y, p.H, L.Hd), tx = resample_tap(x, p.W, L.Wd);
+          const float4 *row0 = reinterpret_cast<const float4 *>(lds_rows + rs.lds_off[l]);
+          const float4 *row1 = row0 + rs.max_lc[l] * 3;
+          const float4 *s00 = row0 + (tx.i0 - jlo[l]) * 3, *s01 = row0 + (tx.i1 - jlo[l]) * 3;
+          const float4 *s10 = row1 + (tx.i0 - jlo[l]) * 3, *s11 = row1 + (tx.i1 - jlo[l]) * 3;
+          const float wx = tx.w1, wy = ty.w1;
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const float4 a = s00[q], bb = s01[q], c = s10[q], d = s11[q];
+            A[l][q * 4 + 0] = (a.x * (1.f - wx) + bb.x * wx) * (1.f - wy) + (c.x * (1.f - wx) + d.x * wx) * wy;
+            A[l][q * 4 + 1] = (a.y * (1.f - wx) + bb.y * wx) * (1.f - wy) + (c.y * (1.f - wx) + d.y * wx) * wy;
+            A[l][q * 4 + 2] = (a.z * (1.f - wx) + bb.z * wx) * (1.f - wy) + (c.z * (1.f - wx) + d.z * wx) * wy;
+            A[l][q * 4 + 3] = (a.w * (1.f - wx) + bb.w * wx) * (1.f - wy) + (c.w * (1.f - wx) + d.w * wx) * wy;
+          }
+        }
         apply_affine(A[l], r, g, b);
       }
     }
@@ -1047,16 +1092,25 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     if (sc > smax) smax = sc;
   }
   const int halo = (int)ceilf(smax) + 2;
-  if (any_up && halo <= 48 && !(option_get(kOptDebug) & 8)) {
+  MsRowStage rs{};
+  size_t lds_floats = 0;
+  for (int l = 0; l < nlevels; l++) {
+    rs.lds_off[l] = (int)lds_floats;
+    if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
+    rs.max_lc[l] = (int)((double)kBgBlock * p.lv[l].Wd / W) + 4;
+    lds_floats += (size_t)2 * rs.max_lc[l] * 12;
+  }
+  if (any_up && halo <= 48 && lds_floats * sizeof(float) <= 40 * 1024 && !(option_get(kOptDebug) & 8)) {
     const int stride = kBgBlock - 2 * halo;
     const int nbx = (int)cdiv(W, stride);
     const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
+    const size_t lds = lds_floats * sizeof(float);   // staged low-res rows, next to the static P / Q staging
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
+      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
+      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
     }
     BDS_LAUNCH_CHECK();
   } else {

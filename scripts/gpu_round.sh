@@ -20,20 +20,23 @@ fi
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_bench.json 2>$OUT/trace.stderr
+    python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pair-stats > $OUT/trace_bench.json 2>$OUT/trace.stderr
 if [ "$DO_PMC" = "pmc" ]; then
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
-      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_fetch.stderr
+      python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pair-stats > /dev/null 2>$OUT/pmc_fetch.stderr
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
-      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_write.stderr
+      python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pair-stats > /dev/null 2>$OUT/pmc_write.stderr
   timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
       --output-format csv -d $OUT/pmc_sq -o bench -- \
-      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_sq.stderr
+      python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pair-stats > /dev/null 2>$OUT/pmc_sq.stderr
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
       --output-format csv -d $OUT/pmc_sq2 -o bench -- \
-      python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/pmc_sq2.stderr
+      python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pair-stats > /dev/null 2>$OUT/pmc_sq2.stderr
 fi
-# keep what travels back small: drop the raw per-dispatch traces, keep stats + counter CSVs
+# keep what travels back small (gpurun merges <= 64 MiB): stats + counter CSVs only
+find $OUT -type f ! -name "*.csv" ! -name "*.json" ! -name "*.log" ! -name "*.txt" ! -name "*.stderr" -delete
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
+find $OUT -type f -size +20M -delete
+du -sh $OUT/* | sort -h | tail -4
 find $OUT -name "*.csv" | head -20
 du -sh $OUT
