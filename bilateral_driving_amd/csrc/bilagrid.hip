@@ -163,141 +163,6 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
   if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
 }
 
-// ---- A+B fused: one pass over the image, low-resolution maps in LDS ---------------------------------------------------
-// A workgroup owns a kTileW x kTileH tile of the image.  For every up-sampled level it first slices the few low-resolution
-// pixels whose bilinear taps reach the tile (their down-sample taps are read from the image: L1/L2 hits, the tile's own
-// pixels are read again right after) into LDS, and -- for the low-res pixels it OWNS (anchor inside the tile) -- also to the
-// global low-res map that the backward reads.  Then every pixel composes the levels from LDS taps while it stays in registers.
-// The image is read once and written once: 44 B/pixel (RGB+ED form) instead of the two-kernel form's 3 reads of the input
-// plus a round trip of the low-res maps through global memory.  Levels at full resolution (factor 1) are sliced per pixel.
-constexpr int kTileW = 64, kTileH = 16;
-struct MsTile {
-  int lds_off[BDS_MAX_LEVELS];   // float offset of the level's LDS map
-  int max_lr[BDS_MAX_LEVELS], max_lc[BDS_MAX_LEVELS];
-  int tiles_x;
-};
-
-template <int NL>
-__global__ __launch_bounds__(kBgBlock) void ms_fwd_tile_kernel(MsParams p, MsTile tc, float *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds_maps[];
-  __shared__ int s_lo[BDS_MAX_LEVELS][4];   // ilo, jlo, nlr, nlc of each level for this tile
-  const int tby = (int)blockIdx.x / tc.tiles_x, tbx = (int)blockIdx.x - tby * tc.tiles_x;
-  const int x0 = tbx * kTileW, y0 = tby * kTileH;
-  const int x1 = min(p.W, x0 + kTileW), y1 = min(p.H, y0 + kTileH);   // exclusive
-  const int tid = threadIdx.x;
-  // phase A: low-resolution slices the tile's taps reach
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l >= p.nlevels) break;
-    const LevelDev &L = p.lv[l];
-    if (L.Hd == p.H && L.Wd == p.W) continue;
-    const int ilo = resample_tap(y0, p.H, L.Hd).i0, ihi = resample_tap(y1 - 1, p.H, L.Hd).i1;
-    const int jlo = resample_tap(x0, p.W, L.Wd).i0, jhi = resample_tap(x1 - 1, p.W, L.Wd).i1;
-    const int nlr = min(ihi - ilo + 1, tc.max_lr[l]), nlc = min(jhi - jlo + 1, tc.max_lc[l]);
-    if (tid == 0) { s_lo[l][0] = ilo; s_lo[l][1] = jlo; s_lo[l][2] = nlr; s_lo[l][3] = nlc; }
-    const float sy = (float)p.H / (float)L.Hd, sx = (float)p.W / (float)L.Wd;
-    const int gsz = 12 * L.gl * L.gy * L.gx;
-    float *map = lds_maps + tc.lds_off[l];
-    for (int it = tid; it < nlr * nlc; it += kBgBlock) {
-      const int li = it / nlc, lj = it - li * nlc;
-      const int i = ilo + li, j = jlo + lj;
-      const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
-      float r, g, b;
-      lowres_colour(p, ty, tx, r, g, b);
-      const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
-      float acc[12];
-#pragma unroll
-      for (int k = 0; k < 12; k++) acc[k] = 0.f;
-      for (int n = 0; n < L.n_avg; n++) {
-        float a[12];
-        slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a, nullptr);
-#pragma unroll
-        for (int k = 0; k < 12; k++) acc[k] += a[k];
-      }
-      if (L.n_avg > 1) {
-        const float inv = (float)L.n_avg;
-#pragma unroll
-        for (int k = 0; k < 12; k++) acc[k] = acc[k] / inv;
-      }
-      float4 *d = reinterpret_cast<float4 *>(map + it * 12);
-      d[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      d[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-      d[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
-      // the owner of a low-res pixel (its anchor pixel lies in this tile) also keeps it for the backward
-      const int ay = min(p.H - 1, (int)(((float)i + 0.5f) * sy)), ax = min(p.W - 1, (int)(((float)j + 0.5f) * sx));
-      if (ay >= y0 && ay < y1 && ax >= x0 && ax < x1) {
-        float4 *gdst = reinterpret_cast<float4 *>(L.lo + ((int64_t)i * L.Wd + j) * 12);
-        gdst[0] = d[0]; gdst[1] = d[1]; gdst[2] = d[2];
-      }
-    }
-  }
-  __syncthreads();
-  // phase B: compose
-  const int lx = tid & (kTileW - 1), ly0 = tid / kTileW;   // 4 rows of 64 threads
-#pragma unroll
-  for (int k = 0; k < kTileH / (kBgBlock / kTileW); k++) {
-    const int x = x0 + lx, y = y0 + ly0 + k * (kBgBlock / kTileW);
-    if (x >= p.W || y >= p.H) continue;
-    const int64_t pix = (int64_t)y * p.W + x;
-    float r, g, b;
-    load_input(p, y, x, r, g, b);
-    const float gray = rgb2gray(r, g, b);   // guidance of full-resolution levels: the ORIGINAL input colour
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (l >= p.nlevels) break;
-      const LevelDev &L = p.lv[l];
-      float A[12];
-      if (L.Hd == p.H && L.Wd == p.W) {
-        const Cell c = slice_cell(linspace01(x, p.W), linspace01(y, p.H), gray, L.gx, L.gy, L.gl);
-        const int gsz = 12 * L.gl * L.gy * L.gx;
-#pragma unroll
-        for (int q = 0; q < 12; q++) A[q] = 0.f;
-        for (int n = 0; n < L.n_avg; n++) {
-          float a[12];
-          slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a, nullptr);
-#pragma unroll
-          for (int q = 0; q < 12; q++) A[q] += a[q];
-        }
-        if (L.n_avg > 1) {
-          const float inv = (float)L.n_avg;
-#pragma unroll
-          for (int q = 0; q < 12; q++) A[q] = A[q] / inv;
-        }
-        float4 *gdst = reinterpret_cast<float4 *>(L.lo + pix * 12);   // the backward reads the full-resolution map as well
-        gdst[0] = make_float4(A[0], A[1], A[2], A[3]);
-        gdst[1] = make_float4(A[4], A[5], A[6], A[7]);
-        gdst[2] = make_float4(A[8], A[9], A[10], A[11]);
-      } else {
-        const int ilo = s_lo[l][0], jlo = s_lo[l][1], nlc = s_lo[l][3];
-        const Tap ty = resample_tap(y, p.H, L.Hd), tx = resample_tap(x, p.W, L.Wd);
-        const float *map = lds_maps + tc.lds_off[l];
-        const float4 *s00 = reinterpret_cast<const float4 *>(map + ((ty.i0 - ilo) * nlc + (tx.i0 - jlo)) * 12);
-        const float4 *s01 = reinterpret_cast<const float4 *>(map + ((ty.i0 - ilo) * nlc + (tx.i1 - jlo)) * 12);
-        const float4 *s10 = reinterpret_cast<const float4 *>(map + ((ty.i1 - ilo) * nlc + (tx.i0 - jlo)) * 12);
-        const float4 *s11 = reinterpret_cast<const float4 *>(map + ((ty.i1 - ilo) * nlc + (tx.i1 - jlo)) * 12);
-        const float wx = tx.w1, wy = ty.w1;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {   // same expression as upsample_affine (the backward re-derives A from the global map)
-          const float4 a = s00[q], bb = s01[q], c = s10[q], d = s11[q];
-          A[q * 4 + 0] = (a.x * (1.f - wx) + bb.x * wx) * (1.f - wy) + (c.x * (1.f - wx) + d.x * wx) * wy;
-          A[q * 4 + 1] = (a.y * (1.f - wx) + bb.y * wx) * (1.f - wy) + (c.y * (1.f - wx) + d.y * wx) * wy;
-          A[q * 4 + 2] = (a.z * (1.f - wx) + bb.z * wx) * (1.f - wy) + (c.z * (1.f - wx) + d.z * wx) * wy;
-          A[q * 4 + 3] = (a.w * (1.f - wx) + bb.w * wx) * (1.f - wy) + (c.w * (1.f - wx) + d.w * wx) * wy;
-        }
-      }
-      if (L.aff_out) {
-        float4 *d = reinterpret_cast<float4 *>(L.aff_out + pix * 12);
-        d[0] = make_float4(A[0], A[1], A[2], A[3]);
-        d[1] = make_float4(A[4], A[5], A[6], A[7]);
-        d[2] = make_float4(A[8], A[9], A[10], A[11]);
-      }
-      apply_affine(A, r, g, b);
-    }
-    out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
-    if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
-  }
-}
-
 // ---- C: full-resolution backward: direct route + per-level (P, Q) ------------------------------------
 // d(loss)/d(A_l) at a pixel is the outer product Q (x) [P;1] of the gradient arriving at level l's output
 // and the colour entering it; only those 6 floats per level are stored.  The adjoint of the bilinear
@@ -385,42 +250,15 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
 // anchor +- (scale + 2)) among the workgroup's own pixels: P and Q (6 floats per pixel and level) never travel
 // through global memory, and the x reduction reads them from LDS.  Arithmetic and summation order are those of
 // ms_apply_bwd_kernel + ms_adjoint_x_kernel (the halo pixels are recomputed, ~7 % extra work at factor 4).
-// The two low-resolution rows (x the columns the window reaches) of every up-sampled level are staged in LDS first: a pixel then
-// re-derives its 3x4 maps from LDS taps instead of 12 scattered 16-byte loads per level (576 B/pixel of L2 traffic at 3 levels).
-struct MsRowStage {
-  int lds_off[BDS_MAX_LEVELS];   // float offset of the level's [2][max_lc][12] staging area
-  int max_lc[BDS_MAX_LEVELS];
-};
-
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
-                                                                 float *__restrict__ v_in, int halo, int nbx, MsRowStage rs) {
+                                                                 float *__restrict__ v_in, int halo, int nbx) {
   __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
-  extern __shared__ __attribute__((aligned(16))) float lds_rows[];
   const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
   const int stride = kBgBlock - 2 * halo;
   const int own0 = bx * stride, own1 = min(p.W, own0 + stride);
   const int xs = own0 - halo;
   const int x = xs + (int)threadIdx.x;
-  const int xa = max(xs, 0), xb = min(xs + kBgBlock, p.W) - 1;   // columns the window evaluates
-  int jlo[NL], nlc[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    jlo[l] = 0; nlc[l] = 0;
-    if (l >= p.nlevels) continue;
-    const LevelDev &L = p.lv[l];
-    if (L.Hd == p.H && L.Wd == p.W) continue;
-    const Tap ty = resample_tap(y, p.H, L.Hd);
-    jlo[l] = resample_tap(xa, p.W, L.Wd).i0;
-    nlc[l] = min(resample_tap(xb, p.W, L.Wd).i1 - jlo[l] + 1, rs.max_lc[l]);
-    float4 *dst = reinterpret_cast<float4 *>(lds_rows + rs.lds_off[l]);
-    for (int e = threadIdx.x; e < 2 * nlc[l] * 3; e += kBgBlock) {
-      const int r = e / (nlc[l] * 3), q = e - r * nlc[l] * 3;   // q = column * 3 + float4 index
-      const int row = r ? ty.i1 : ty.i0;
-      dst[r * rs.max_lc[l] * 3 + q] = reinterpret_cast<const float4 *>(L.lo + ((int64_t)row * L.Wd + jlo[l]) * 12)[q];
-    }
-  }
-  __syncthreads();
   if (x >= 0 && x < p.W) {
     const int64_t pix = (int64_t)y * p.W + x;
     const bool owner = x >= own0 && x < own1;
@@ -435,25 +273,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
           float *P = p.lv[l].P + pix * 3;
           P[0] = r; P[1] = g; P[2] = b;
         }
-        if (p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {
-          upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
-        } else {   // same expression as upsample_affine, taps from the staged rows
-          const LevelDev &L = p.lv[l];
-          const Tap ty = resample_tap(y, p.H, L.Hd), tx = resample_tap(x, p.W, L.Wd);
-          const float4 *row0 = reinterpret_cast<const float4 *>(lds_rows + rs.lds_off[l]);
-          const float4 *row1 = row0 + rs.max_lc[l] * 3;
-          const float4 *s00 = row0 + (tx.i0 - jlo[l]) * 3, *s01 = row0 + (tx.i1 - jlo[l]) * 3;
-          const float4 *s10 = row1 + (tx.i0 - jlo[l]) * 3, *s11 = row1 + (tx.i1 - jlo[l]) * 3;
-          const float wx = tx.w1, wy = ty.w1;
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            const float4 a = s00[q], bb = s01[q], c = s10[q], d = s11[q];
-            A[l][q * 4 + 0] = (a.x * (1.f - wx) + bb.x * wx) * (1.f - wy) + (c.x * (1.f - wx) + d.x * wx) * wy;
-            A[l][q * 4 + 1] = (a.y * (1.f - wx) + bb.y * wx) * (1.f - wy) + (c.y * (1.f - wx) + d.y * wx) * wy;
-            A[l][q * 4 + 2] = (a.z * (1.f - wx) + bb.z * wx) * (1.f - wy) + (c.z * (1.f - wx) + d.z * wx) * wy;
-            A[l][q * 4 + 3] = (a.w * (1.f - wx) + bb.w * wx) * (1.f - wy) + (c.w * (1.f - wx) + d.w * wx) * wy;
-          }
-        }
+        upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
         apply_affine(A[l], r, g, b);
       }
     }
@@ -1005,34 +825,6 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   BDS_REQUIRE(rgb_out);
   p.cs = cs; p.depth_out = depth_out;
   hipStream_t st = as_stream(stream);
-  {  // fused single pass when every up-sampled level's low-resolution footprint of a tile fits LDS
-    MsTile tc{};
-    size_t lds_floats = 0;
-    bool ok = !(option_get(kOptDebug) & 16);
-    for (int l = 0; l < nlevels && ok; l++) {
-      tc.lds_off[l] = (int)lds_floats;
-      if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
-      const double sy = (double)H / p.lv[l].Hd, sx = (double)W / p.lv[l].Wd;
-      tc.max_lr[l] = (int)(kTileH / sy) + 4;
-      tc.max_lc[l] = (int)(kTileW / sx) + 4;
-      lds_floats += (size_t)tc.max_lr[l] * tc.max_lc[l] * 12;
-      if (lds_floats * sizeof(float) > 60 * 1024) ok = false;
-    }
-    if (ok) {
-      tc.tiles_x = (int)cdiv(W, kTileW);
-      const dim3 grid((unsigned)(tc.tiles_x * cdiv(H, kTileH))), block(kBgBlock);
-      const size_t lds = lds_floats * sizeof(float);
-      switch (nlevels) {
-        case 1: hipLaunchKernelGGL((ms_fwd_tile_kernel<1>), grid, block, lds, st, p, tc, rgb_out); break;
-        case 2: hipLaunchKernelGGL((ms_fwd_tile_kernel<2>), grid, block, lds, st, p, tc, rgb_out); break;
-        case 3: hipLaunchKernelGGL((ms_fwd_tile_kernel<3>), grid, block, lds, st, p, tc, rgb_out); break;
-        case 4: hipLaunchKernelGGL((ms_fwd_tile_kernel<4>), grid, block, lds, st, p, tc, rgb_out); break;
-        default: hipLaunchKernelGGL((ms_fwd_tile_kernel<BDS_MAX_LEVELS>), grid, block, lds, st, p, tc, rgb_out); break;
-      }
-      BDS_LAUNCH_CHECK();
-      return BDS_OK;
-    }
-  }
   {
     LevelSched sc{};
     sc.n = nlevels;
@@ -1092,25 +884,16 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     if (sc > smax) smax = sc;
   }
   const int halo = (int)ceilf(smax) + 2;
-  MsRowStage rs{};
-  size_t lds_floats = 0;
-  for (int l = 0; l < nlevels; l++) {
-    rs.lds_off[l] = (int)lds_floats;
-    if (p.lv[l].Hd == H && p.lv[l].Wd == W) continue;
-    rs.max_lc[l] = (int)((double)kBgBlock * p.lv[l].Wd / W) + 4;
-    lds_floats += (size_t)2 * rs.max_lc[l] * 12;
-  }
-  if (any_up && halo <= 48 && lds_floats * sizeof(float) <= 40 * 1024 && !(option_get(kOptDebug) & 8)) {
+  if (any_up && halo <= 48 && !(option_get(kOptDebug) & 8)) {
     const int stride = kBgBlock - 2 * halo;
     const int nbx = (int)cdiv(W, stride);
     const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
-    const size_t lds = lds_floats * sizeof(float);   // staged low-res rows, next to the static P / Q staging
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
-      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
-      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
-      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, lds, st, p, v_rgb_out, v_rgb, halo, nbx, rs); break;
+      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
     }
     BDS_LAUNCH_CHECK();
   } else {
