@@ -72,6 +72,99 @@ class _Out(dict):
         return k == "rgb_gaussians" or dict.__contains__(self, k)
 
 
+class _Front:
+    """Everything of one view that does not depend on the opacities' values beyond the tile cull: activations, projection, SH
+    colours, per-tile lists (compact positions) and the ascending visible-id list.  Shared by the training forward and by the
+    evaluation re-renders (``render_classes``), which composite several opacity masks over ONE such front."""
+    __slots__ = ("means", "quats", "log_scales", "sh", "viewmat", "scales", "opac", "radii", "means2d", "depths", "conics", "cam_pos",
+                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N")
+
+
+def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Front:
+    L.require_gpu(means, quats, log_scales, logits, sh, viewmat)
+    lib, st = L.lib(), L.stream()
+    dev = means.device
+    W, H = cfg["width"], cfg["height"]
+    N, K = means.shape[0], sh.shape[1]
+    means, quats, log_scales, logits, sh = (t.contiguous() for t in (means, quats, log_scales, logits, sh))
+    viewmat, Kmat = viewmat.contiguous(), cfg["K"].contiguous()
+    # activations (vanilla.py:393-394) + projection (C = 1)
+    scales, opac = _empty((N, 3), dev), _empty((N,), dev)
+    radii = _empty((1, N), dev, torch.int32)
+    means2d, depths, conics = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev)
+    with L.timed("project_fwd"):
+        L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
+                                         L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
+                                         L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
+                "bds_project_view_fwd")
+    # tile ordering
+    tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
+    cull = cfg["tile_cull"]
+    opac_c = opac.view(1, N)
+    tiles_per_gauss = _empty((1, N), dev, torch.int32)
+    ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
+    ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
+    isect_offsets = _empty((1, th, tw), dev, torch.int32)
+    cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
+    counts, ev = _host_sync_objects(dev)
+    with L.timed("isect_prepare"):
+        L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
+                                            L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
+                "bds_isect_prepare_async")
+    # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
+    # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
+    cam_pos = cfg["cam_pos"].contiguous()
+    sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
+    with L.timed("sh_fwd"):
+        L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
+                                    L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
+    key = (N, W, H, bool(cull))
+    cap = _LIST_CAPACITY.get(key, 0)
+    buf, ws2, ws2_bytes = None, None, 0
+    if cap:
+        buf = _empty((cap,), dev, torch.int32)
+        ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
+        ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
+    ev.synchronize()
+    M, n_vis = int(counts[0]), int(counts[1])
+    if M > cap or buf is None:   # first call of this configuration, or the lists outgrew the expectation
+        buf = _empty((M,), dev, torch.int32)
+        ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
+        ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
+    flatten = buf[:M]                                  # per-tile lists of COMPACT positions (they address the records below)
+    vis_ids = _empty((n_vis,), dev, torch.int32)       # ascending ids of the visible Gaussians: compact position -> id, the
+    #                                                    work list of everything downstream (walks memory in order)
+    with L.timed("isect_build"):
+        L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
+                                    ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), L.ptr(vis_ids), 1, st),
+                "bds_isect_build")
+    if M + M // 16 > cap:
+        _LIST_CAPACITY[key] = M + M // 6 + 4096
+    del ws, ws2, buf
+    f = _Front()
+    f.means, f.quats, f.log_scales, f.sh, f.viewmat = means, quats, log_scales, sh, viewmat
+    f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
+    f.cam_pos, f.sh_rgb, f.colors, f.tiles_per_gauss, f.isect_offsets = cam_pos, sh_rgb, colors, tiles_per_gauss, isect_offsets
+    f.flatten, f.vis_ids, f.M, f.n_vis, f.tw, f.th, f.W, f.H, f.N = flatten, vis_ids, M, n_vis, tw, th, W, H, N
+    return f
+
+
+def _composite(f: _Front, opac: Tensor):
+    """Splat records of the visible Gaussians with the given opacities [N] + the forward composite (RGB + depth)."""
+    lib, st = L.lib(), L.stream()
+    dev = opac.device
+    n_vis, M, W, H = f.n_vis, f.M, f.W, f.H
+    rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
+    render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
+    last_ids = _empty((1, H, W), dev, torch.int32)
+    with L.timed("rasterize_fwd"):
+        L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac), L.ptr(rec), st),
+                "bds_splat_pack")
+        L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, f.tw, f.th, L.ptr(f.isect_offsets), L.ptr(f.flatten),
+                                      L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
+    return rec, render, alphas, last_ids
+
+
 class _FusedView(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, viewmat, *grids):
@@ -79,72 +172,14 @@ class _FusedView(torch.autograd.Function):
         lib, st = L.lib(), L.stream()
         dev = means.device
         W, H = cfg["width"], cfg["height"]
-        N, K = means.shape[0], sh.shape[1]
-        P = H * W
-        means, quats, log_scales, logits, sh, sky = (t.contiguous() for t in (means, quats, log_scales, logits, sh, sky))
-        viewmat, Kmat = viewmat.contiguous(), cfg["K"].contiguous()
-        # activations (vanilla.py:393-394) + projection (C = 1)
-        scales, opac = _empty((N, 3), dev), _empty((N,), dev)
-        radii = _empty((1, N), dev, torch.int32)
-        means2d, depths, conics = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev)
-        with L.timed("project_fwd"):
-            L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
-                                             L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
-                                             L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
-                    "bds_project_view_fwd")
-        # tile ordering
-        tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
-        cull = cfg["tile_cull"]
-        opac_c = opac.view(1, N)
-        tiles_per_gauss = _empty((1, N), dev, torch.int32)
-        ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
-        ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
-        isect_offsets = _empty((1, th, tw), dev, torch.int32)
-        cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
-        counts, ev = _host_sync_objects(dev)
-        with L.timed("isect_prepare"):
-            L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
-                                                L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
-                    "bds_isect_prepare_async")
-        # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
-        # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
-        cam_pos = cfg["cam_pos"].contiguous()
-        sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
-        with L.timed("sh_fwd"):
-            L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
-                                        L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
-        key = (N, W, H, bool(cull))
-        cap = _LIST_CAPACITY.get(key, 0)
-        buf, ws2, ws2_bytes = None, None, 0
-        if cap:
-            buf = _empty((cap,), dev, torch.int32)
-            ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
-            ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-        ev.synchronize()
-        M, n_vis = int(counts[0]), int(counts[1])
-        if M > cap or buf is None:   # first call of this configuration, or the lists outgrew the expectation
-            buf = _empty((M,), dev, torch.int32)
-            ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
-            ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-        flatten = buf[:M]                                  # per-tile lists of COMPACT positions (they address the records below)
-        vis_ids = _empty((n_vis,), dev, torch.int32)       # ascending ids of the visible Gaussians: compact position -> id, the
-        #                                                    work list of everything downstream (walks memory in order)
-        with L.timed("isect_build"):
-            L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
-                                        ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), L.ptr(vis_ids), 1, st),
-                    "bds_isect_build")
-        if M + M // 16 > cap:
-            _LIST_CAPACITY[key] = M + M // 6 + 4096
-        del ws, ws2, buf
-        # compositing (RGB + depth) from the visible Gaussians' splat records (ascending-id order)
-        rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
-        render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
-        last_ids = _empty((1, H, W), dev, torch.int32)
-        with L.timed("rasterize_fwd"):
-            L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(vis_ids), L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac_c), L.ptr(rec), st),
-                    "bds_splat_pack")
-            L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
-                                          L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
+        N = means.shape[0]
+        sky = sky.contiguous()
+        f = _view_front(cfg, means, quats, log_scales, logits, sh, viewmat)
+        means, quats, log_scales, sh, viewmat = f.means, f.quats, f.log_scales, f.sh, f.viewmat
+        scales, opac, radii, means2d, cam_pos, sh_rgb = f.scales, f.opac, f.radii, f.means2d, f.cam_pos, f.sh_rgb
+        tiles_per_gauss, isect_offsets, flatten, vis_ids, M = f.tiles_per_gauss, f.isect_offsets, f.flatten, f.vis_ids, f.M
+        rec, render, alphas, last_ids = _composite(f, opac)
+        del f
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         grids = [g.contiguous() for g in grids]
         idx = cfg.get("img_idx")
@@ -300,3 +335,37 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                   "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets, "tile_size": TILE,
                   "n_cameras": 1, "n_isects": int(flatten_ranks.numel()), "n_visible": int(vis_ids.numel())})
     return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)
+
+
+@torch.no_grad()
+def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, masks: Dict[str, Tensor],
+                   sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
+                   tile_cull: bool = True, cam_pos: Optional[Tensor] = None, include_full: bool = True) -> Dict[str, Tensor]:
+    """Evaluation re-renders of Gaussian subsets (per-class and "Dynamic" images, trainers/scene_graph.py:296-313): the reference calls
+    its ``render_fn(gaussian_mask)`` once per class, i.e. the whole ``rasterization`` again with ``opacities * mask``
+    (trainers/base.py:392-416).  Projection, SH colours, the tile lists and their sort do not depend on the mask, so here they are
+    computed ONCE and only the splat-record pack + forward composite run per mask -- a masked-out Gaussian has opacity 0, fails the
+    alpha >= 1/255 test and leaves the transmittance untouched, exactly as in the reference's re-render.
+
+    masks: name -> [N] bool / float.  Returns ``{name+"_rgb": [H,W,3] (clamped at 1), name+"_depth": [H,W,1] expected depth,
+    name+"_opacity": [H,W,1]}`` for every mask, plus ``rgb_gaussians`` / ``depth`` / ``opacity`` of the unmasked scene with
+    ``include_full``."""
+    if cam_pos is None:
+        cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
+    cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos, sh_degree=int(sh_degree), near_plane=float(near_plane),
+               far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d), tile_cull=bool(tile_cull))
+    f = _view_front(cfg, params["means"].detach(), params["quats"].detach(), params["log_scales"].detach(),
+                    params["opacity_logits"].detach(), params["sh"].detach(), viewmat.detach())
+
+    def image(opac):
+        _, render, alphas, _ = _composite(f, opac.contiguous())
+        a = alphas[0]
+        return torch.clamp(render[0, :, :, :3], max=1.0), render[0, :, :, 3:4] / a.clamp(min=1e-10), a
+
+    out: Dict[str, Tensor] = {}
+    if include_full:
+        out["rgb_gaussians"], out["depth"], out["opacity"] = image(f.opac)
+    for name, m in masks.items():
+        assert m.shape == (f.N,), (name, tuple(m.shape), f.N)
+        out[name + "_rgb"], out[name + "_depth"], out[name + "_opacity"] = image(f.opac * m.to(f.opac.dtype))
+    return out

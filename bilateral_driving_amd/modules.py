@@ -178,6 +178,69 @@ class MultiScaleBilateralAffineTransform(nn.Module):
         return {f"{self.class_prefix}grid{i}": getattr(self, f"bil_grids{i}").parameters() for i in range(len(self.grid_size))}
 
 
+class AffineTransform(nn.Module):
+    """The appearance-code baseline the bilateral grids are compared with (/root/reference/project/models/modules.py:213-267;
+    configs/omnire.yaml:245-249): one learnable code per image -> 2-layer ReLU MLP -> one 3x4 colour matrix (+ identity) for the whole
+    image.  Same constructor, parameter names (``embedding.weight``, ``decoder.0/2.weight/bias``: reference checkpoints load) and
+    ``forward(image_infos)`` return value (per-pixel [*, 3, 4] maps) as the reference.
+
+    ``transform(rgb, image_infos, alpha, sky)`` is the fused fast path for ``pixel_affine=False``: the decoder runs ONCE for the
+    image's code (the reference pushes H*W identical rows through it), and the clamp + sky blend + 3x4 application run in the
+    bilateral transform's kernels with the matrix as a 1x1x1 grid -- exactly constant under slicing / up-sampling."""
+
+    def __init__(self, class_name: str, n: int, embedding_dim: int = 4, pixel_affine: bool = False, base_mlp_layer_width: int = 64,
+                 device="cuda"):
+        super().__init__()
+        self.class_prefix = class_name + "#"
+        self.device = device
+        self.embedding_dim = embedding_dim
+        self.pixel_affine = pixel_affine
+        self.embedding = nn.Embedding(n, embedding_dim, dtype=torch.float32)
+        input_dim = (embedding_dim + 2) if self.pixel_affine else embedding_dim
+        self.decoder = nn.Sequential(nn.Linear(input_dim, base_mlp_layer_width), nn.ReLU(), nn.Linear(base_mlp_layer_width, 12))
+        self.in_test_set = False
+        self.zero_init()
+        self.to(device)
+
+    def zero_init(self):
+        torch.nn.init.zeros_(self.embedding.weight)
+        for layer in self.decoder:
+            if isinstance(layer, nn.Linear):
+                torch.nn.init.zeros_(layer.weight)
+                torch.nn.init.zeros_(layer.bias)
+
+    def forward(self, image_infos) -> Tensor:
+        if "img_idx" in image_infos and not self.in_test_set:
+            embedding = self.embedding(image_infos["img_idx"])
+        else:   # mean appearance code (modules.py:247-252)
+            vd = image_infos["viewdirs"]
+            embedding = torch.ones((*vd.shape[:-1], self.embedding_dim), device=vd.device) * self.embedding.weight.mean(dim=0)
+        if self.pixel_affine:
+            embedding = torch.cat([embedding, image_infos["pixel_coords"]], dim=-1)
+        affine = self.decoder(embedding).reshape(*embedding.shape[:-1], 3, 4)
+        return affine + torch.eye(3, 4, device=affine.device)     # adds the identity to the 3x3 part (modules.py:259)
+
+    def image_matrix(self, image_infos) -> Tensor:
+        """[12] the image's colour matrix (row-major 3x4), decoder evaluated once."""
+        assert not self.pixel_affine, "per-pixel inputs: use forward()"
+        if "img_idx" in image_infos and not self.in_test_set:
+            code = self.embedding.weight[_img_index(image_infos)]
+        else:
+            code = self.embedding.weight.mean(dim=0)
+        return self.decoder(code) + torch.eye(3, 4, device=code.device).reshape(12)
+
+    def transform(self, rgb: Tensor, image_infos, alpha: Optional[Tensor] = None, sky: Optional[Tensor] = None) -> Tensor:
+        if self.pixel_affine:
+            A = self.forward(image_infos)
+            blended = rgb if sky is None else torch.clamp(rgb, max=1.0) + sky * (1.0 - alpha)
+            return (A[..., :3, :3] @ blended[..., None] + A[..., :3, 3:])[..., 0]
+        grid = self.image_matrix(image_infos).reshape(1, 12, 1, 1, 1)
+        return bilagrid_transform(rgb, [grid], [1], alpha=alpha, sky=sky)
+
+    def get_param_groups(self):
+        return {self.class_prefix + "all": self.parameters()}
+
+
 def _pixel_xy(H: int, W: int, device) -> Tensor:
     gy, gx = torch.meshgrid(torch.linspace(0, 1.0, H, device=device), torch.linspace(0, 1.0, W, device=device), indexing="ij")
     return torch.stack([gx, gy], dim=-1).unsqueeze(0)
