@@ -242,6 +242,13 @@ def main():
     flat = FlatGradients(list(params.values()) + grids, sparse_rows=True)
     fx = FrameExchange(flat, list(params.keys()) + [f"grid{i}" for i in range(len(grids))])
 
+    # (16-px tile, Gaussian) pairs per view = the intersections of the reference's algorithm (SURVEY.md 8d counts bytes per such pair);
+    # the fused view builds its lists for larger tiles (fused_view.LIST_TILE) and never materialises them, so they are counted once here
+    from bilateral_driving_amd import fused_view as FV
+    with torch.no_grad():
+        M16 = [Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, list_tile=16)["info"]["n_isects"] for v in range(V)]
+    torch.cuda.synchronize()
+
     stats = {}
 
     def step(s):
@@ -301,7 +308,8 @@ def main():
 
     # ---- roofline of the dominant kernel: composite backward (K8).  Algorithmic bytes per launch: 44 B/isect read +
     # 28 B/pixel read + 48 B/isect gradient write.
-    M_mean, nv_mean, P = sum(Ms) / len(Ms), sum(nvs) / len(nvs), W * H
+    list_pairs_mean = sum(Ms) / len(Ms)          # pairs the tile stage emitted and sorted (list tiles of FV.LIST_TILE px)
+    M_mean, nv_mean, P = sum(M16) / len(M16), sum(nvs) / len(nvs), W * H
     dom = "rasterize_bwd"
     calls, mean_ms = tsum.get(dom, (0, float("nan")))
     alg_bytes = 92.0 * M_mean + 28.0 * P
@@ -336,6 +344,7 @@ def main():
         "sh_fwd": 216.0 * nv_mean + 32.0 * N,                      # K1 on the visible rows + 32 B/Gaussian of radii / depth / colour rows
         "isect_prepare": 36.0 * N + 64.0 * nv_mean,                # K4 count + depth sort of the visible entries (4 x 16 B)
         "isect_build": (4.0 + 16.0 + 4.0 + 8.0) * M_mean,          # K4 emit + K5 tile sort (packed: 2 x 8 B) + list values + K6 offsets
+        #                                                            (bytes of the reference's 16-px pairs; the coarse lists move fewer)
         "rasterize_fwd": 44.0 * M_mean + 24.0 * P + 96.0 * nv_mean,  # K7 (+ packing the visible splat records: 48 B gathered + 48 B written)
         "bilagrid_fwd": 44.0 * P,                                  # K9-K11: 40 B/pixel + 4 B/pixel expected depth
         "bilagrid_bwd": 72.0 * P,                                  # K12: 68 B/pixel + 4 B/pixel depth gradient
@@ -361,7 +370,8 @@ def main():
                                f"frame of {V} views per GPU (1 iter = 1 view)",
                    "workload_name": args.workload, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V,
-                   "n_visible_mean": nv_mean, "isects_mean": M_mean, "parallelism": f"view-dp{world}",
+                   "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
+                   "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
                    "exchanges_per_step": fx.n_exchanges if world > 1 else 0},

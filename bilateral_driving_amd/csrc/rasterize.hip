@@ -71,12 +71,46 @@ __device__ __forceinline__ float splat_exponent(float eadx2, float ebdx, float e
   return __builtin_fmaf(__builtin_fmaf(ec, dy, ebdx), dy, eadx2);
 }
 
+// ---- coarse lists -------------------------------------------------------------------------------------------
+// The depth-ordered lists may be built for LIST tiles of list_div x list_div compositing tiles (64 x 64 px for list_div = 4): the
+// tile stage then emits and sorts one pair per (list tile, Gaussian) -- a fraction of the (16-px tile, Gaussian) pairs, most of
+// which the compositor never reaches because its pixels saturate first -- and every compositing wave filters the chunk of its
+// list tile's list it is about to blend: lane l tests candidate l against the wave's own 16 x 16 rectangle of pixel centres
+// (the exact row-span test of the tile stage, gs_math.h row_tile_span, on the record's base-2 quadratic form) and the survivors
+// are compacted into LDS in list order.  A candidate that fails contributes alpha < 1/255 to every pixel of the tile, so the
+// image, the per-pixel last index and the gradients are those of the fine lists.  Forward and backward share ONE definition of
+// the test (their decisions have to agree).
+struct ListGeom {
+  int div, w, h;   // compositing tiles per list tile (per axis); list tiles per row / column
+  int total;       // C * w * h lists
+};
+
+__device__ __forceinline__ bool tile_candidate_hit(const float4 &A, const float4 &B, int tx, int ty) {
+#pragma clang fp contract(off)
+  // alpha >= 1/255  <=>  -e <= log2(255 opacity) =: tau, with -e = a dx^2 + 2 b dx dy + c dy^2 in the record's base-2 units
+  const float tau = __builtin_amdgcn_logf(B.y * 255.f) + 1e-3f;
+  if (!(tau > 0.f)) return false;
+  int lo, hi;
+  row_tile_span(A.x, A.y, -A.z, -0.5f * A.w, -B.x, tau, ty, kTile, tx, tx + 1, lo, hi);
+  return hi > lo;
+}
+
+// list range [start, end) of a compositing tile
+template <bool kCoarse>
+__device__ __forceinline__ void list_range(const int32_t *__restrict__ offsets, int item, int n_items, int cam, int tx, int ty,
+                                           const ListGeom &lg, int64_t M, int &start, int &end) {
+  const int li = kCoarse ? (cam * lg.h + ty / lg.div) * lg.w + tx / lg.div : item;
+  const int total = kCoarse ? lg.total : n_items;
+  start = offsets[li];
+  end = (li == total - 1) ? (int)M : offsets[li + 1];
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------
-template <int CH>
+template <int CH, bool kCoarse>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, float *__restrict__ render,
-    float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
+    float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   const int n_tiles = tile_w * tile_h;
   const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
@@ -86,8 +120,8 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   const int j = tx * kTile + (lane & 15);
   const int i0 = ty * kTile + (lane >> 4);
   const float px = (float)j + 0.5f;
-  const int start = offsets[item];
-  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
+  int start, end;
+  list_range<kCoarse>(offsets, item, C * n_tiles, cam, tx, ty, lg, M, start, end);
   // T[q] > 0: running transmittance; T[q] < 0: the pixel is finished and |T[q]| is its final transmittance
   // (pixels outside the image start finished).  One register instead of a flag + a value per pixel.
   float T[4], pyc[4];
@@ -107,13 +141,24 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
   if (start + lane < end) {
     const int64_t r = flatten[start + lane];
     pA = rec[r * 3]; pB = rec[r * 3 + 1];
-    if (CH > 2) pC = rec[r * 3 + 2];
+    if (CH > 2 || kCoarse) pC = rec[r * 3 + 2];
   }
   for (int b = 0; b < nbatch; b++) {
     if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
-    __syncthreads();
     const int bstart = start + b * kWave;
-    if (bstart + lane < end) {
+    int bs = min(kWave, end - bstart);
+    __syncthreads();
+    if (kCoarse) {
+      // keep the candidates that reach this tile, in list order; their list position rides in the record's spare slot
+      const bool hit = (bstart + lane < end) && tile_candidate_hit(pA, pB, tx, ty);
+      const uint64_t m = __ballot(hit);
+      bs = __popcll(m);
+      if (hit) {
+        const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        pC.z = __int_as_float(bstart + lane);
+        sA[pos] = pA; sB[pos] = pB; sC[pos] = pC;
+      }
+    } else if (bstart + lane < end) {
       sA[lane] = pA; sB[lane] = pB;
       if (CH > 2) sC[lane] = pC;
     }
@@ -121,16 +166,16 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     if (bstart + kWave + lane < end) {
       const int64_t r = flatten[bstart + kWave + lane];
       pA = rec[r * 3]; pB = rec[r * 3 + 1];
-      if (CH > 2) pC = rec[r * 3 + 2];
+      if (CH > 2 || kCoarse) pC = rec[r * 3 + 2];
     }
-    const int bs = min(kWave, end - bstart);
     for (int t = 0; t < bs; t++) {
       if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;
       const float ebdx = A.w * dx, eadx2 = A.z * dx * dx;
       float4 Cc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (CH > 2) Cc = sC[t];
+      if (CH > 2 || kCoarse) Cc = sC[t];
+      const int pos_t = kCoarse ? __float_as_int(Cc.z) : bstart + t;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float e = splat_exponent(eadx2, ebdx, B.x, A.y - pyc[q]);
@@ -145,7 +190,7 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
           if (CH > 1) out[q][1] += B.w * vis;
           if (CH > 2) out[q][2] += Cc.x * vis;
           if (CH > 3) out[q][3] += Cc.y * vis;
-          cur[q] = bstart + t;
+          cur[q] = pos_t;
           T[q] = nT;
         }
       }
@@ -171,12 +216,12 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 // need only three per-lane moments of d(loss)/d(sigma) (S0 = sum vs, S1 = sum vs dy, S2 = sum vs dy^2) that are expanded
 // once per (lane, Gaussian); 12 per-lane sums then go through ONE 16-value transpose-reduce and 12 lanes commit them to the
 // Gaussian's gradient record.  The list is replayed back to front from the tile's deepest blended entry.
-template <int CH, bool ABS>
+template <int CH, bool ABS, bool kCoarse>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas,
     const int32_t *__restrict__ last_ids, const float *__restrict__ v_render, const float *__restrict__ v_alphas,
-    float *__restrict__ v_rec, const int32_t *__restrict__ tile_order) {
+    float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   const int n_tiles = tile_w * tile_h;
@@ -184,8 +229,8 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
-  const int start = offsets[item];
-  const int end = (item == C * n_tiles - 1) ? (int)M : offsets[item + 1];
+  int start, end;
+  list_range<kCoarse>(offsets, item, C * n_tiles, cam, tx, ty, lg, M, start, end);
   if (end <= start) return;
   const int j = tx * kTile + (lane & 15);
   const float px = (float)j + 0.5f;
@@ -230,14 +275,28 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     if (idx >= start) {
       pg = flatten[idx];
       pA = rec[(int64_t)pg * 3]; pB = rec[(int64_t)pg * 3 + 1];
-      if (CH > 2) pC = rec[(int64_t)pg * 3 + 2];
+      if (CH > 2 || kCoarse) pC = rec[(int64_t)pg * 3 + 2];
     }
   }
   for (int b = b0; b < nbatch; b++) {
     const int batch_end = end - 1 - kWave * b;
     __syncthreads();
-    const int bs = min(kWave, batch_end + 1 - start);
-    if (batch_end - lane >= start) {
+    int bs = min(kWave, batch_end + 1 - start);
+    int t0 = max(0, batch_end - tile_bin_final);
+    if (kCoarse) {
+      // survivors of this chunk (same test as the forward), compacted in replay order; entries behind the tile's deepest blended
+      // one are dropped here instead of being skipped through t0
+      const int idx = batch_end - lane;
+      const bool hit = idx >= start && idx <= tile_bin_final && tile_candidate_hit(pA, pB, tx, ty);
+      const uint64_t m = __ballot(hit);
+      bs = __popcll(m);
+      t0 = 0;
+      if (hit) {
+        const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        pC.z = __int_as_float(idx);
+        sId[pos] = pg; sA[pos] = pA; sB[pos] = pB; sC[pos] = pC;
+      }
+    } else if (batch_end - lane >= start) {
       sId[lane] = pg; sA[lane] = pA; sB[lane] = pB;
       if (CH > 2) sC[lane] = pC;
     }
@@ -247,11 +306,13 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
       if (idx >= start) {
         pg = flatten[idx];
         pA = rec[(int64_t)pg * 3]; pB = rec[(int64_t)pg * 3 + 1];
-        if (CH > 2) pC = rec[(int64_t)pg * 3 + 2];
+        if (CH > 2 || kCoarse) pC = rec[(int64_t)pg * 3 + 2];
       }
     }
-    for (int t = max(0, batch_end - tile_bin_final); t < bs; t++) {
-      const int gidx = batch_end - t;   // position of this entry in the list
+    for (int t = t0; t < bs; t++) {
+      float4 Cc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (CH > 2 || kCoarse) Cc = sC[t];
+      const int gidx = kCoarse ? __float_as_int(Cc.z) : batch_end - t;   // position of this entry in the list
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;
       const float opac = B.y, ec = B.x;
@@ -270,7 +331,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
       }
       if (!__any(any)) continue;
       float col[4] = {B.z, B.w, 0.f, 0.f};
-      if (CH > 2) { const float4 Cc = sC[t]; col[2] = Cc.x; col[3] = Cc.y; }
+      if (CH > 2) { col[2] = Cc.x; col[3] = Cc.y; }
       const float two_eadx = eadx + eadx, two_ec = ec + ec;
       // per-lane sums over the four pixels (branch-free: a pixel that did not blend this Gaussian contributes alpha = 0)
       float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, ax = 0.f, ay = 0.f, go = 0.f;
@@ -327,7 +388,7 @@ constexpr int kWorkBlock = 256;
 __global__ __launch_bounds__(kWorkBlock) void tile_work_kernel(int C, int W, int H, int tile_w, int tile_h,
                                                                const int32_t *__restrict__ offsets,
                                                                const int32_t *__restrict__ last_ids,
-                                                               int32_t *__restrict__ work) {
+                                                               int32_t *__restrict__ work, ListGeom lg) {
   const int n_tiles = tile_w * tile_h, total = C * n_tiles;
   const int item = blockIdx.x * (kWorkBlock / kWave) + (threadIdx.x >> 6);
   if (item >= total) return;
@@ -343,7 +404,9 @@ __global__ __launch_bounds__(kWorkBlock) void tile_work_kernel(int C, int W, int
   }
   m = wave_max_i32(m);
   // (an empty list leaves last_ids at 0: the estimate is then 0, or 1 for the very first tile)
-  if (lane == 0) work[item] = max(0, m - offsets[item] + 1);
+  // (coarse lists: the length of the candidate range -- proportional to the blended length within a neighbourhood)
+  const int li = lg.div > 1 ? (cam * lg.h + ty / lg.div) * lg.w + tx / lg.div : item;
+  if (lane == 0) work[item] = max(0, m - offsets[li] + 1);
 }
 
 constexpr int kSchedThreads = 1024, kSchedBins = 1024;
@@ -406,11 +469,24 @@ extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float
   return BDS_OK;
 }
 
+// list geometry of a launch: list tiles of list_tile_size px (a multiple of the 16-px compositing tile)
+static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
+  if (list_tile_size < kTile || list_tile_size % kTile) return false;
+  lg.div = list_tile_size / kTile;
+  lg.w = (W + list_tile_size - 1) / list_tile_size;
+  lg.h = (H + list_tile_size - 1) / list_tile_size;
+  lg.total = C * lg.w * lg.h;
+  return true;
+}
+
 extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
-                                 int W, int H, int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                                 const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream) {
+                                 int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                                 const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
+                                 int32_t *last_ids, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
+  ListGeom lg;
+  BDS_REQUIRE(list_geom(C, W, H, list_tile_size, lg));
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
   BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
   BDS_REQUIRE(isect_offsets && render && alphas && last_ids);
@@ -418,24 +494,32 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-#define BDS_FWD(ch)                                                                                                           \
-  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
-                     isect_offsets, flatten, render, alphas, last_ids)
-  if (CH == 1) BDS_FWD(1);
-  else if (CH == 3) BDS_FWD(3);
-  else BDS_FWD(4);
+#define BDS_FWD(ch, co)                                                                                                           \
+  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
+                     isect_offsets, flatten, render, alphas, last_ids, lg)
+  if (lg.div > 1) {
+    if (CH == 1) BDS_FWD(1, true);
+    else if (CH == 3) BDS_FWD(3, true);
+    else BDS_FWD(4, true);
+  } else {
+    if (CH == 1) BDS_FWD(1, false);
+    else if (CH == 3) BDS_FWD(3, false);
+    else BDS_FWD(4, false);
+  }
 #undef BDS_FWD
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
 
 extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
-                                 int W, int H, int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                                 const int32_t *flatten, const float *alphas, const int32_t *last_ids, const float *v_render,
-                                 const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order,
-                                 bds_stream_t stream) {
+                                 int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                                 const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
+                                 const float *v_render, const float *v_alphas, float *v_records, int absgrad,
+                                 const int32_t *tile_order, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
+  ListGeom lg;
+  BDS_REQUIRE(list_geom(C, W, H, list_tile_size, lg));
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
   BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
   if (M == 0) return BDS_OK;
@@ -444,28 +528,35 @@ extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, co
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-#define BDS_BWD(ch, ab)                                                                                                       \
-  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
-                     isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order)
+#define BDS_BWD(ch, ab, co)                                                                                                          \
+  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
+                     isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg)
+#define BDS_BWD_CH(ab, co)            \
+  do {                                \
+    if (CH == 1) BDS_BWD(1, ab, co);  \
+    else if (CH == 3) BDS_BWD(3, ab, co); \
+    else BDS_BWD(4, ab, co);          \
+  } while (0)
   if (absgrad) {
-    if (CH == 1) BDS_BWD(1, true);
-    else if (CH == 3) BDS_BWD(3, true);
-    else BDS_BWD(4, true);
+    if (lg.div > 1) BDS_BWD_CH(true, true);
+    else BDS_BWD_CH(true, false);
   } else {
-    if (CH == 1) BDS_BWD(1, false);
-    else if (CH == 3) BDS_BWD(3, false);
-    else BDS_BWD(4, false);
+    if (lg.div > 1) BDS_BWD_CH(false, true);
+    else BDS_BWD_CH(false, false);
   }
+#undef BDS_BWD_CH
 #undef BDS_BWD
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
 
-extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int tile_w, int tile_h,
+extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                                           const int32_t *isect_offsets, const int32_t *last_ids, int32_t *tile_order,
                                           bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
+  ListGeom lg;
+  BDS_REQUIRE(list_geom(C, W, H, list_tile_size, lg));
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
   BDS_REQUIRE(isect_offsets && last_ids && tile_order);
   const int total = C * tile_w * tile_h;
@@ -473,7 +564,7 @@ extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, in
   int32_t *work = tile_order + total;   // second half of the caller's buffer
   constexpr int per_block = kWorkBlock / kWave;
   hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(kWorkBlock), 0, st, C, W,
-                     H, tile_w, tile_h, isect_offsets, last_ids, work);
+                     H, tile_w, tile_h, isect_offsets, last_ids, work, lg);
   hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, st, total, work, tile_order);
   BDS_LAUNCH_CHECK();
   return BDS_OK;

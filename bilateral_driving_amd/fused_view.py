@@ -11,6 +11,7 @@ issues ~25 launches of libbds.so kernels back to back, so the step is bound by t
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, Optional, Sequence
 
@@ -21,7 +22,10 @@ from . import _lib as L
 from . import gs_ops as ops
 from .bilagrid import _levels_struct
 
-TILE = 16
+TILE = 16        # compositing tile (one wave64 per tile)
+# Tile the depth-ordered lists are built for (include/bds.h "coarse lists"): 16 = gsplat's lists; 64 = one pair per (64-px tile,
+# Gaussian), filtered per compositing tile as the chunks are staged -- several times fewer pairs to emit and sort.
+LIST_TILE = int(os.environ.get("BDS_LIST_TILE", "64"))
 
 
 def _empty(shape, dev, dtype=torch.float32):
@@ -77,7 +81,7 @@ class _Front:
     colours, per-tile lists (compact positions) and the ascending visible-id list.  Shared by the training forward and by the
     evaluation re-renders (``render_classes``), which composite several opacity masks over ONE such front."""
     __slots__ = ("means", "quats", "log_scales", "sh", "viewmat", "scales", "opac", "radii", "means2d", "depths", "conics", "cam_pos",
-                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N")
+                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N", "list_tile")
 
 
 def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Front:
@@ -98,7 +102,8 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
                                          L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
                 "bds_project_view_fwd")
     # tile ordering
-    tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
+    LT = cfg.get("list_tile", LIST_TILE)
+    tw, th = math.ceil(W / LT), math.ceil(H / LT)      # list tiles
     cull = cfg["tile_cull"]
     opac_c = opac.view(1, N)
     tiles_per_gauss = _empty((1, N), dev, torch.int32)
@@ -108,7 +113,7 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
     cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
     counts, ev = _host_sync_objects(dev)
     with L.timed("isect_prepare"):
-        L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th,
+        L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
                                             L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
                 "bds_isect_prepare_async")
     # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
@@ -118,7 +123,7 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
     with L.timed("sh_fwd"):
         L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
                                     L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
-    key = (N, W, H, bool(cull))
+    key = (N, W, H, bool(cull), LT)
     cap = _LIST_CAPACITY.get(key, 0)
     buf, ws2, ws2_bytes = None, None, 0
     if cap:
@@ -135,7 +140,7 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
     vis_ids = _empty((n_vis,), dev, torch.int32)       # ascending ids of the visible Gaussians: compact position -> id, the
     #                                                    work list of everything downstream (walks memory in order)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, TILE, tw, th, L.ptr(ws),
+        L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th, L.ptr(ws),
                                     ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), L.ptr(vis_ids), 1, st),
                 "bds_isect_build")
     if M + M // 16 > cap:
@@ -145,7 +150,8 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
     f.means, f.quats, f.log_scales, f.sh, f.viewmat = means, quats, log_scales, sh, viewmat
     f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
     f.cam_pos, f.sh_rgb, f.colors, f.tiles_per_gauss, f.isect_offsets = cam_pos, sh_rgb, colors, tiles_per_gauss, isect_offsets
-    f.flatten, f.vis_ids, f.M, f.n_vis, f.tw, f.th, f.W, f.H, f.N = flatten, vis_ids, M, n_vis, tw, th, W, H, N
+    f.flatten, f.vis_ids, f.M, f.n_vis, f.W, f.H, f.N, f.list_tile = flatten, vis_ids, M, n_vis, W, H, N, LT
+    f.tw, f.th = math.ceil(W / TILE), math.ceil(H / TILE)  # compositing tiles
     return f
 
 
@@ -160,7 +166,7 @@ def _composite(f: _Front, opac: Tensor):
     with L.timed("rasterize_fwd"):
         L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac), L.ptr(rec), st),
                 "bds_splat_pack")
-        L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, f.tw, f.th, L.ptr(f.isect_offsets), L.ptr(f.flatten),
+        L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th, L.ptr(f.isect_offsets), L.ptr(f.flatten),
                                       L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
     return rec, render, alphas, last_ids
 
@@ -179,6 +185,7 @@ class _FusedView(torch.autograd.Function):
         scales, opac, radii, means2d, cam_pos, sh_rgb = f.scales, f.opac, f.radii, f.means2d, f.cam_pos, f.sh_rgb
         tiles_per_gauss, isect_offsets, flatten, vis_ids, M = f.tiles_per_gauss, f.isect_offsets, f.flatten, f.vis_ids, f.M
         rec, render, alphas, last_ids = _composite(f, opac)
+        ctx.list_tile = f.list_tile
         del f
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         grids = [g.contiguous() for g in grids]
@@ -243,9 +250,10 @@ class _FusedView(torch.autograd.Function):
                                                L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
         # compositing: gradient records of the visible Gaussians, in the order of vis_ids (64 bytes each)
         v_rec = torch.zeros(max(n_vis, 1), L.GRAD_RECORD_FLOATS, device=dev, dtype=torch.float32)
-        order = ops.bwd_schedule(1, W, H, TILE, tw, th, isect_offsets, last_ids)
+        LT = ctx.list_tile
+        order = ops.bwd_schedule(1, W, H, LT, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
-            L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
+            L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
                                           L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
                                           L.ptr(order), st), "bds_rasterize_bwd")
         if v_means2d_ext is not None and n_vis:   # a loss term on info["means2d"] itself: add its rows to the records
@@ -300,7 +308,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
                grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
-               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None):
+               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
     [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
@@ -325,14 +333,16 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena, grad_sink=grad_sink,
-               img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows))
+               img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows),
+               list_tile=int(LIST_TILE if list_tile is None else list_tile))
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky,
                            viewmat, *gs)
     rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ranks, isect_offsets, vis_ids = out
     cfg["_means2d_ref"] = weakref.ref(means2d)  # backward attaches .absgrad to THIS tensor object
     info = _Info({"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
-                  "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets, "tile_size": TILE,
+                  "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets,
+                  "tile_size": cfg["list_tile"],   # of the lists in this dict (the compositor subdivides into 16 x 16)
                   "n_cameras": 1, "n_isects": int(flatten_ranks.numel()), "n_visible": int(vis_ids.numel())})
     return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)
 
@@ -340,7 +350,8 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
 @torch.no_grad()
 def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, masks: Dict[str, Tensor],
                    sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
-                   tile_cull: bool = True, cam_pos: Optional[Tensor] = None, include_full: bool = True) -> Dict[str, Tensor]:
+                   tile_cull: bool = True, cam_pos: Optional[Tensor] = None, include_full: bool = True,
+                   list_tile: Optional[int] = None) -> Dict[str, Tensor]:
     """Evaluation re-renders of Gaussian subsets (per-class and "Dynamic" images, trainers/scene_graph.py:296-313): the reference calls
     its ``render_fn(gaussian_mask)`` once per class, i.e. the whole ``rasterization`` again with ``opacities * mask``
     (trainers/base.py:392-416).  Projection, SH colours, the tile lists and their sort do not depend on the mask, so here they are
@@ -353,7 +364,8 @@ def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width:
     if cam_pos is None:
         cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos, sh_degree=int(sh_degree), near_plane=float(near_plane),
-               far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d), tile_cull=bool(tile_cull))
+               far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d), tile_cull=bool(tile_cull),
+               list_tile=int(LIST_TILE if list_tile is None else list_tile))
     f = _view_front(cfg, params["means"].detach(), params["quats"].detach(), params["log_scales"].detach(),
                     params["opacity_logits"].detach(), params["sh"].detach(), viewmat.detach())
 

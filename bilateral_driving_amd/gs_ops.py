@@ -13,6 +13,7 @@ shapes) so that ``rendering.rasterization`` below them reads like the reference'
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Optional, Tuple
 
@@ -21,7 +22,7 @@ from torch import Tensor
 
 from . import _lib as L
 
-TILE_SIZE = 16  # the only tile size the gfx950 kernels are written for (gsplat default)
+TILE_SIZE = 16  # the compositing tile of the gfx950 kernels (gsplat default); lists may be built for any multiple of it
 
 
 def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -201,13 +202,14 @@ def set_bwd_schedule(on: bool) -> None:
     _BWD_SCHEDULE = bool(on)
 
 
-def bwd_schedule(C_: int, width: int, height: int, tile_size: int, tw: int, th: int, isect_offsets: Tensor,
-                 last_ids: Tensor) -> Optional[Tensor]:
+def bwd_schedule(C_: int, width: int, height: int, list_tile_size: int, isect_offsets: Tensor, last_ids: Tensor) -> Optional[Tensor]:
+    """isect_offsets: the lists' offsets, built for tiles of ``list_tile_size`` px (a multiple of the 16-px compositing tile)."""
     if not _BWD_SCHEDULE:
         return None
+    tw, th = math.ceil(width / TILE_SIZE), math.ceil(height / TILE_SIZE)
     order = torch.empty(2 * C_ * tw * th, device=last_ids.device, dtype=torch.int32)
-    L.check(L.lib().bds_rasterize_bwd_schedule(C_, width, height, tile_size, tw, th, L.ptr(isect_offsets), L.ptr(last_ids),
-                                               L.ptr(order), L.stream()), "bds_rasterize_bwd_schedule")
+    L.check(L.lib().bds_rasterize_bwd_schedule(C_, width, height, TILE_SIZE, list_tile_size, tw, th, L.ptr(isect_offsets),
+                                               L.ptr(last_ids), L.ptr(order), L.stream()), "bds_rasterize_bwd_schedule")
     return order
 
 
@@ -219,7 +221,8 @@ class _RasterizeToPixels(torch.autograd.Function):
         means2d_c, conics, colors, opacities, backgrounds = map(_f32c, (means2d, conics, colors, opacities, backgrounds))
         Cn, N = means2d_c.shape[0], means2d_c.shape[1]
         CH = colors.shape[-1]
-        th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
+        tw, th = math.ceil(width / TILE_SIZE), math.ceil(height / TILE_SIZE)   # compositing tiles; tile_size = the lists' tile
+        assert isect_offsets.shape == (Cn, math.ceil(height / tile_size), math.ceil(width / tile_size)), (isect_offsets.shape, tile_size)
         M = flatten_ids.shape[0]
         dev = means2d_c.device
         lib, st = L.lib(), L.stream()
@@ -231,7 +234,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         with L.timed("rasterize_fwd"):
             L.check(lib.bds_splat_pack(Cn * N, CH, None, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(rec), st),
                     "bds_splat_pack")
-            L.check(lib.bds_rasterize_fwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, tile_size, tw, th,
+            L.check(lib.bds_rasterize_fwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, TILE_SIZE, tile_size, tw, th,
                                           L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),
                     "bds_rasterize_fwd")
         ctx.save_for_backward(means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids)
@@ -243,14 +246,14 @@ class _RasterizeToPixels(torch.autograd.Function):
         means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
         width, height, tile_size, absgrad, CH = ctx.cfg
         Cn, N = means2d.shape[0], means2d.shape[1]
-        th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
+        tw, th = math.ceil(width / TILE_SIZE), math.ceil(height / TILE_SIZE)
         M = flatten_ids.shape[0]
         v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
         # gradient records (64 bytes per entry, accumulated with atomics): include/bds.h bds_rasterize_bwd
         v_rec = torch.zeros(Cn * N, L.GRAD_RECORD_FLOATS, device=rec.device, dtype=torch.float32)
-        order = bwd_schedule(Cn, width, height, tile_size, tw, th, isect_offsets, last_ids)
+        order = bwd_schedule(Cn, width, height, tile_size, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
-            L.check(L.lib().bds_rasterize_bwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, tile_size, tw, th,
+            L.check(L.lib().bds_rasterize_bwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, TILE_SIZE, tile_size, tw, th,
                                               L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render),
                                               L.ptr(v_alphas), L.ptr(v_rec), int(bool(absgrad)), L.ptr(order), L.stream()),
                     "bds_rasterize_bwd")
@@ -271,12 +274,15 @@ class _RasterizeToPixels(torch.autograd.Function):
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
                         image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
                         backgrounds: Optional[Tensor] = None, absgrad: bool = False) -> Tuple[Tensor, Tensor]:
-    """means2d [C,N,2], conics [C,N,3], colors [C,N,D], opacities [C,N] -> render [C,H,W,D], alphas [C,H,W,1]."""
+    """means2d [C,N,2], conics [C,N,3], colors [C,N,D], opacities [C,N] -> render [C,H,W,D], alphas [C,H,W,1].
+    ``tile_size``: the tile size ``isect_offsets`` / ``flatten_ids`` were built for (gsplat's argument): 16, or a multiple of 16 --
+    the compositor always works on 16 x 16 tiles and filters the candidates of a larger list tile per 16 x 16 tile (include/bds.h,
+    "coarse lists"); the image and the gradients do not depend on it."""
     Cn, N = means2d.shape[0], means2d.shape[1]
     assert means2d.shape == (Cn, N, 2) and conics.shape == (Cn, N, 3) and opacities.shape == (Cn, N), (
         means2d.shape, conics.shape, opacities.shape)
     assert colors.shape[:2] == (Cn, N), colors.shape
-    assert tile_size == TILE_SIZE, f"tile_size {tile_size} unsupported (kernels are written for {TILE_SIZE})"
+    assert tile_size >= TILE_SIZE and tile_size % TILE_SIZE == 0, f"tile_size {tile_size}: a multiple of {TILE_SIZE} is required"
     D = colors.shape[-1]
     if backgrounds is not None:
         assert backgrounds.shape == (Cn, D), backgrounds.shape

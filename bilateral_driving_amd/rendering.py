@@ -94,7 +94,8 @@ def rasterization(
         raise NotImplementedError("covars= is not on the reference's path (quats/scales are passed)")
     assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED"), render_mode
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
-    assert tile_size == TILE_SIZE, f"tile_size={tile_size}: the gfx950 kernels are written for {TILE_SIZE}"
+    assert tile_size >= TILE_SIZE and tile_size % TILE_SIZE == 0, (
+        f"tile_size={tile_size}: a multiple of {TILE_SIZE} is required (lists of larger tiles are filtered per 16-px compositing tile)")
     N = means.shape[0]
     C = viewmats.shape[0]
     assert means.shape == (N, 3), means.shape

@@ -147,14 +147,21 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
  * bds_splat_pack builds them from the per-entry arrays means2d [n,2] conics [n,3] colors [n,CH] opacities [n]: record r is
  * entry ids[r], or entry r when ids == NULL.  The per-tile lists (`flatten`) hold RECORD indices: cam*N + g for records in
  * array order (gsplat's flatten_ids), or depth ranks of the visible entries for records packed through a sorted id list.
- * CH in {1,3,4}; backgrounds [C,CH] or NULL -> render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] i32. */
+ * CH in {1,3,4}; backgrounds [C,CH] or NULL -> render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] i32.
+ *
+ * COARSE LISTS (no reference counterpart): list_tile_size is the tile size the lists were BUILT for (bds_isect_* called with it:
+ * isect_offsets [C, ceil(H/list_tile_size), ceil(W/list_tile_size)]) -- tile_size (16, gsplat's lists) or a multiple of it.  With a
+ * multiple, the tile stage emits and sorts one pair per (list tile, Gaussian) instead of one per (16-px tile, Gaussian), and every
+ * 16 x 16 compositing wave filters the candidates of its list tile against its own rectangle of pixel centres (the tile stage's
+ * exact span test) as it stages them.  A rejected candidate has alpha < 1/255 on every pixel of the tile, so render / alphas and
+ * the gradients equal those of 16-px lists; last_ids then holds positions in the coarse list. */
 #define BDS_SPLAT_RECORD_FLOATS 12
 #define BDS_GRAD_RECORD_FLOATS 16
 int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
                    const float *opacities, float *records, bds_stream_t stream);
 int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
-                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten,
-                      float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
+                      int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                      const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
 /* Backward into GRADIENT RECORDS v_records [n_records, 16] (64-byte stride, zero-filled by the caller, accumulated with
  * atomics), in the units of the un-scaled inputs:
  *     0-3 d/d colour | 4-6 d/d conic (a, b, c) | 7-8 d/d mean2d | 9-10 sum over pixels of |d/d mean2d| (absgrad != 0) |
@@ -162,15 +169,15 @@ int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *
  * tile_order may be NULL (tiles are taken in image order, one contiguous band per XCD) or the schedule written by
  * bds_rasterize_bwd_schedule. */
 int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
-                      int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten,
-                      const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
-                      float *v_records, int absgrad, const int32_t *tile_order, bds_stream_t stream);
+                      int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                      const int32_t *flatten, const float *alphas, const int32_t *last_ids, const float *v_render,
+                      const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order, bds_stream_t stream);
 /* Launch schedule for bds_rasterize_bwd (no reference counterpart; results do not depend on it).  One wave owns a
  * tile and the chip holds only about two rounds of tiles, so the launch ends with a tail of long tiles that started
  * late.  After the forward pass each tile's visited length is known exactly (max last_id - list start); this call
  * orders every XCD's contiguous range of tiles longest-first.  tile_order: int32[2 * C*tile_w*tile_h] — the first
  * half receives the schedule, the second half is scratch. */
-int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
                                const int32_t *last_ids, int32_t *tile_order, bds_stream_t stream);
 
 /* ---- bilateral grid ----------------------------------------------------------------------

@@ -21,6 +21,7 @@ cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
     python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pair-stats > $OUT/trace_bench.json 2>$OUT/trace.stderr
+python $REPO/scripts/step_timeline.py $OUT/trace/bench_kernel_trace.csv 2 > $OUT/step_timeline.txt 2>&1
 if [ "$DO_PMC" = "pmc" ]; then
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
       python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pair-stats > /dev/null 2>$OUT/pmc_fetch.stderr

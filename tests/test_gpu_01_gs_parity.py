@@ -456,9 +456,9 @@ def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C)
     rec = torch.empty(Cn * N, L.SPLAT_RECORD_FLOATS, device="cuda")
     L.check(L.lib().bds_splat_pack(Cn * N, 3, None, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), L.ptr(rec),
                                    L.stream()), "pack")
-    L.check(L.lib().bds_rasterize_fwd(Cn, Cn * N, M, 3, L.ptr(rec), None, W, H, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa),
+    L.check(L.lib().bds_rasterize_fwd(Cn, Cn * N, M, 3, L.ptr(rec), None, W, H, 16, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa),
                                       L.ptr(last), L.stream()), "fwd")
-    order = ops.bwd_schedule(Cn, W, H, 16, tw, th, offs, last)
+    order = ops.bwd_schedule(Cn, W, H, 16, offs, last)
     total = Cn * tw * th
     o = order[:total].cpu().long()
     work = order[total:].cpu().long()

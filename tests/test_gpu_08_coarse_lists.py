@@ -1,0 +1,97 @@
+"""-m gpu: coarse lists (include/bds.h): depth-ordered lists built for 32 / 64 / 128-px tiles and filtered per 16 x 16 compositing
+tile give the image and the gradients of gsplat's 16-px lists -- through the rasterization() API (tile_size argument), through the
+fused view (list_tile) and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import make_scene, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_api(sc, W, H, tile_size, mode="RGB+ED", absgrad=True, backgrounds=None):
+    import bilateral_driving_amd.rendering as R
+    leaves = {k: sc[k].clone().cuda().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    rr, aa, meta = R.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+                                   sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H, packed=False, absgrad=absgrad, render_mode=mode,
+                                   tile_size=tile_size, backgrounds=backgrounds)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    w1, w2 = torch.randn(rr.shape, generator=g).cuda(), torch.randn(aa.shape, generator=g).cuda()
+    ((rr * w1).sum() + (aa * w2).sum()).backward()
+    grads = {k: v.grad.clone() for k, v in leaves.items()}
+    if absgrad:
+        grads["absgrad"] = meta["means2d"].absgrad.clone()
+    return rr.detach(), aa.detach(), grads, meta
+
+
+@pytest.mark.parametrize("seed,N,W,H,C", [(0, 3000, 320, 200, 1), (1, 800, 75, 50, 2), (2, 5000, 448, 256, 1)])
+@pytest.mark.parametrize("tile_size", [32, 64, 128])
+def test_rasterization_with_coarse_lists_equals_16px_lists(seed, N, W, H, C, tile_size):
+    sc = make_scene(N, W, H, seed=seed)
+    if C > 1:   # a second camera, shifted sideways
+        vm2 = sc["viewmats"][0].clone()
+        vm2[0, 3] += 0.4
+        sc["viewmats"] = torch.stack([sc["viewmats"][0], vm2])
+        sc["Ks"] = sc["Ks"].expand(2, 3, 3).contiguous()
+    bg = torch.rand(sc["viewmats"].shape[0], 4).cuda()
+    r16, a16, g16, m16 = _run_api(sc, W, H, 16, backgrounds=bg)
+    rc, ac, gc, mc = _run_api(sc, W, H, tile_size, backgrounds=bg)
+    assert mc["tile_size"] == tile_size and mc["flatten_ids"].numel() < m16["flatten_ids"].numel()
+    assert mc["isect_offsets"].shape[1:] == (-(-H // tile_size), -(-W // tile_size))
+    # same survivors, same order, same arithmetic: the images are bit-equal
+    assert torch.equal(rc, r16) and torch.equal(ac, a16)
+    for k in g16:
+        assert rel_err(gc[k], g16[k]) < 2e-5, (k, rel_err(gc[k], g16[k]))     # atomics: summation order only
+
+
+def test_coarse_lists_against_oracle():
+    from oracle import gs_oracle as O
+    W, H, N = 150, 100, 1200
+    sc = make_scene(N, W, H, seed=4)
+    rc, ac, gc, _ = _run_api(sc, W, H, 64, absgrad=False)
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    rr, aa, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"], sc["viewmats"],
+                                sc["Ks"], W, H, render_mode="RGB+ED")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    w1, w2 = torch.randn(rr.shape, generator=g), torch.randn(aa.shape, generator=g)
+    ((rr * w1).sum() + (aa * w2).sum()).backward()
+    assert rel_err(rc.cpu()[..., :3], rr.detach()[..., :3]) < 1e-5 and rel_err(ac.cpu(), aa.detach()) < 1e-5
+    for k, v in leaves.items():
+        assert rel_err(gc[k].cpu(), v.grad) < 2e-4, (k, rel_err(gc[k].cpu(), v.grad))
+
+
+@pytest.mark.parametrize("W,H,N", [(320, 192, 4000), (200, 130, 1500)])
+def test_fused_view_list_tile_64_equals_16(W, H, N):
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.fused_view import fused_view, render_classes
+    dev = "cuda"
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    base = Hn.synthetic_scene(N, seed=3, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    grids0 = Hn.make_grids(2, device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    res = {}
+    for lt in (16, 64):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        vm = cam.viewmat.clone().requires_grad_(True)
+        out = fused_view(p, vm, cam.K, W, H, grids, sky, Hn.FACTORS_3, img_idx=1, list_tile=lt)
+        assert out["info"]["tile_size"] == lt
+        ((out["rgb"] - target).abs().mean() + 0.01 * out["depth"].mean() + 0.1 * out["opacity"].mean()).backward()
+        res[lt] = (out["rgb"].detach(), out["depth"].detach(), out["opacity"].detach(), {k: v.grad for k, v in p.items()},
+                   [g.grad for g in grids], vm.grad, out["info"]["means2d"].absgrad, out["info"]["n_isects"])
+    a, b = res[16], res[64]
+    assert b[7] < a[7]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert rel_err(b[3][k], a[3][k]) < 2e-5, k
+    for x, y in zip(a[4], b[4]):
+        assert rel_err(y, x) < 2e-5
+    assert rel_err(b[5], a[5]) < 1e-4 and rel_err(b[6], a[6]) < 2e-5
+    # the evaluation re-renders go through the same front
+    m = {"half": torch.arange(N, device=dev) % 2 == 0}
+    o16 = render_classes(base, cam.viewmat, cam.K, W, H, m, list_tile=16)
+    o64 = render_classes(base, cam.viewmat, cam.K, W, H, m, list_tile=64)
+    for k in o16:
+        assert torch.equal(o16[k], o64[k]), k
