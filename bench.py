@@ -264,7 +264,7 @@ def main():
             out = Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, **kw)
             if not dense:
                 fx.begin_view(out["info"])
-            loss = Hn.training_loss(out, targets[v], grids)
+            loss = Hn.training_loss(out, targets[v], grids, grid_grads=None if dense else fx.tail_grads())
             loss.backward()
             if not dense:
                 fx.end_view()

@@ -44,7 +44,7 @@ _SIGS = {
     "bds_isect_prepare_async": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _f, _i, _f]),
     "bds_isect_tiles": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _sz, _i64, _f, _f, _f, C.POINTER(C.c_int64),
                              C.POINTER(C.c_int64), _f]),
-    "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),

@@ -6,7 +6,7 @@
 // Data (gfx950): the compositor reads SPLAT RECORDS -- one 48-byte record per (camera, Gaussian), or per visible
 // Gaussian in depth-rank order -- through the per-tile index lists: one record is one or two cache lines instead of
 // four gathers from four arrays.  A record is 3 x float4:
-//     (mean2d.x, mean2d.y, ea, eb) (ec, opacity, colour0, colour1) (colour2, colour3, -, -)
+//     (mean2d.x, mean2d.y, ea, eb) (ec, opacity, colour0, colour1) (colour2, colour3, -, radius as int bits)
 // with the conic pre-scaled into the exponent's base-2 units, (ea, eb, ec) = -log2(e) * (a/2, b, c/2), so that
 // alpha = opacity * 2^(ea dx^2 + eb dx dy + ec dy^2): one multiply per (pixel, Gaussian) less than exp(-sigma), in both
 // directions, with the forward and the backward taking bit-identical alpha decisions.
@@ -31,6 +31,7 @@ namespace bds {
 constexpr int kTile = 16;
 constexpr int kPackBlock = 256;
 constexpr int kGradStride = BDS_GRAD_RECORD_FLOATS;  // 16
+constexpr int kUnboundedRadius = 1 << 20;   // record radius slot when the caller has no radii: the bounding square covers any image
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -53,7 +54,7 @@ template <int CH>
 __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n, const int32_t *__restrict__ ids,
                                                                const float *__restrict__ means2d, const float *__restrict__ conics,
                                                                const float *__restrict__ colors, const float *__restrict__ opacities,
-                                                               float4 *__restrict__ rec) {
+                                                               const int32_t *__restrict__ radii, float4 *__restrict__ rec) {
   const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
   if (r >= n) return;
   const int64_t g = ids ? (int64_t)ids[r] : r;
@@ -62,7 +63,9 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n, const
   const float *cl = colors + g * CH;
   rec[r * 3] = make_float4(xy.x, xy.y, (-0.5f * kLog2e) * cn[0], -kLog2e * cn[1]);
   rec[r * 3 + 1] = make_float4((-0.5f * kLog2e) * cn[2], opacities[g], cl[0], CH > 1 ? cl[CH > 1 ? 1 : 0] : 0.f);
-  rec[r * 3 + 2] = make_float4(CH > 2 ? cl[CH > 2 ? 2 : 0] : 0.f, CH > 3 ? cl[CH > 3 ? 3 : 0] : 0.f, 0.f, 0.f);
+  // last slot: the projection's pixel radius (gsplat's bounding square; "unbounded" without radii) -- read by the coarse-list filter
+  rec[r * 3 + 2] = make_float4(CH > 2 ? cl[CH > 2 ? 2 : 0] : 0.f, CH > 3 ? cl[CH > 3 ? 3 : 0] : 0.f, 0.f,
+                               __int_as_float(radii ? radii[g] : kUnboundedRadius));
 }
 
 // exponent (base 2) of a Gaussian at a pixel of the lane's column: ea dx^2 + (ec dy + eb dx) dy, <= 0 for a valid conic.
@@ -76,23 +79,48 @@ __device__ __forceinline__ float splat_exponent(float eadx2, float ebdx, float e
 // tile stage then emits and sorts one pair per (list tile, Gaussian) -- a fraction of the (16-px tile, Gaussian) pairs, most of
 // which the compositor never reaches because its pixels saturate first -- and every compositing wave filters the chunk of its
 // list tile's list it is about to blend: lane l tests candidate l against the wave's own 16 x 16 rectangle of pixel centres
-// (the exact row-span test of the tile stage, gs_math.h row_tile_span, on the record's base-2 quadratic form) and the survivors
-// are compacted into LDS in list order.  A candidate that fails contributes alpha < 1/255 to every pixel of the tile, so the
-// image, the per-pixel last index and the gradients are those of the fine lists.  Forward and backward share ONE definition of
-// the test (their decisions have to agree).
+// (the span test of the tile stage, gs_math.h row_tile_span, on the record's base-2 quadratic form) and the survivors
+// are compacted into LDS in list order.  The test has the two parts that define a (16-px tile, Gaussian) pair of the fine lists:
+// the tile lies in gsplat's bounding square of the Gaussian (tile_rect on the record's radius -- the reference CLIPS a splat there,
+// at 3 sigma, even where alpha is still above 1/255), and a pixel centre of the tile reaches alpha >= 1/255 (a candidate that fails
+// this part contributes nothing anyway).  With the radii in the records the image, and the gradients, are those of 16-px lists;
+// records packed without radii carry an unbounded square, which gives gsplat's own semantics for lists of larger tiles
+// (tile_size = 32, 64, ...: clipped at that tile granularity).  Forward and backward share ONE definition of the test.
 struct ListGeom {
   int div, w, h;   // compositing tiles per list tile (per axis); list tiles per row / column
   int total;       // C * w * h lists
 };
 
-__device__ __forceinline__ bool tile_candidate_hit(const float4 &A, const float4 &B, int tx, int ty) {
+__device__ __forceinline__ bool tile_candidate_hit(const float4 &A, const float4 &B, const float4 &Cr, int tx, int ty, int tile_w,
+                                                   int tile_h) {
 #pragma clang fp contract(off)
-  // alpha >= 1/255  <=>  -e <= log2(255 opacity) =: tau, with -e = a dx^2 + 2 b dx dy + c dy^2 in the record's base-2 units
+  int x0, y0, x1, y1;
+  tile_rect(A.x, A.y, __float_as_int(Cr.w), kTile, tile_w, tile_h, x0, y0, x1, y1);
+  if (tx < x0 || tx >= x1 || ty < y0 || ty >= y1) return false;
+  // alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= log2(255 opacity) =: tau in the record's base-2 units.
+  // Same construction as gs_math.h row_tile_span (x-extent of the ellipse cut by the tile's band of pixel-centre rows) with
+  // hardware rcp / sqrt (1 ulp) and a slack that covers them: conservative -- a spurious survivor only costs its blend.
   const float tau = __builtin_amdgcn_logf(B.y * 255.f) + 1e-3f;
   if (!(tau > 0.f)) return false;
-  int lo, hi;
-  row_tile_span(A.x, A.y, -A.z, -0.5f * A.w, -B.x, tau, ty, kTile, tx, tx + 1, lo, hi);
-  return hi > lo;
+  const float a = -A.z, b = -0.5f * A.w, c = -B.x;
+  const float det = a * c - b * b;
+  const float ia = __builtin_amdgcn_rcpf(a), tid = tau * __builtin_amdgcn_rcpf(det);
+  const float hy = __builtin_amdgcn_sqrtf(a * tid), hx = __builtin_amdgcn_sqrtf(c * tid);
+  constexpr float kSlack = 0.03f;
+  float e0 = ((float)(ty * kTile) + 0.5f) - A.y, e1 = e0 + (float)(kTile - 1);
+  if (e0 > hy + kSlack || e1 < -hy - kSlack) return false;
+  e0 = fminf(fmaxf(e0, -hy), hy);
+  e1 = fminf(fmaxf(e1, -hy), hy);
+  const float aq = a * tau;
+  const float r0 = __builtin_amdgcn_sqrtf(fmaxf(aq - det * e0 * e0, 0.f)), r1 = __builtin_amdgcn_sqrtf(fmaxf(aq - det * e1 * e1, 0.f));
+  float xr = fmaxf(r0 - b * e0, r1 - b * e1) * ia;
+  float xl = fminf(-r0 - b * e0, -r1 - b * e1) * ia;
+  const float dyR = -b * hx * __builtin_amdgcn_rcpf(c);   // height of the ellipse's right-most point (left-most: -dyR)
+  if (dyR >= e0 && dyR <= e1) xr = hx;
+  if (-dyR >= e0 && -dyR <= e1) xl = -hx;
+  const float c0 = ((float)(tx * kTile) + 0.5f) - A.x, c1 = c0 + (float)(kTile - 1);   // the tile's pixel-centre columns
+  const float slack = kSlack + 4e-6f * (fabsf(xl) + fabsf(xr));
+  return !(xr + slack < c0 || xl - slack > c1);   // (NaN from a degenerate conic: keep the candidate)
 }
 
 // list range [start, end) of a compositing tile
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     __syncthreads();
     if (kCoarse) {
       // keep the candidates that reach this tile, in list order; their list position rides in the record's spare slot
-      const bool hit = (bstart + lane < end) && tile_candidate_hit(pA, pB, tx, ty);
+      const bool hit = (bstart + lane < end) && tile_candidate_hit(pA, pB, pC, tx, ty, tile_w, tile_h);
       const uint64_t m = __ballot(hit);
       bs = __popcll(m);
       if (hit) {
@@ -287,7 +315,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
       // survivors of this chunk (same test as the forward), compacted in replay order; entries behind the tile's deepest blended
       // one are dropped here instead of being skipped through t0
       const int idx = batch_end - lane;
-      const bool hit = idx >= start && idx <= tile_bin_final && tile_candidate_hit(pA, pB, tx, ty);
+      const bool hit = idx >= start && idx <= tile_bin_final && tile_candidate_hit(pA, pB, pC, tx, ty, tile_w, tile_h);
       const uint64_t m = __ballot(hit);
       bs = __popcll(m);
       t0 = 0;
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, co
 using namespace bds;
 
 extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
-                              const float *opacities, float *records, bds_stream_t stream) {
+                              const float *opacities, const int32_t *radii, float *records, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && (CH == 1 || CH == 3 || CH == 4));
   if (n == 0) return BDS_OK;
   BDS_REQUIRE(means2d && conics && colors && opacities && records && aligned16(records));
@@ -462,9 +490,9 @@ extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float
   const dim3 grid((unsigned)cdiv(n, kPackBlock)), block(kPackBlock);
   float4 *rec = reinterpret_cast<float4 *>(records);
   hipStream_t st = as_stream(stream);
-  if (CH == 1) hipLaunchKernelGGL((splat_pack_kernel<1>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, rec);
-  else if (CH == 3) hipLaunchKernelGGL((splat_pack_kernel<3>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, rec);
-  else hipLaunchKernelGGL((splat_pack_kernel<4>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, rec);
+  if (CH == 1) hipLaunchKernelGGL((splat_pack_kernel<1>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
+  else if (CH == 3) hipLaunchKernelGGL((splat_pack_kernel<3>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
+  else hipLaunchKernelGGL((splat_pack_kernel<4>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -345,10 +345,122 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
   }
 }
 
-static size_t radix_temp_elems(int64_t n) {
+
+// ---- wide-digit form of the two kernels above, for the packed tile pass: digits of up to 10 bits (kBins = 512 / 1024) --------
+// With coarse list tiles the whole tile key is 9-10 bits (1080p, 64-px list tiles: 510 lists): ONE stable pass orders the
+// pairs instead of two (a pass over the list costs a histogram, a scan of [bins][workgroups] and a scatter launch).
+template <int kBins>
+__global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift,
+                                                                    uint32_t mask, int nblocks, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[kBins];
+  for (int d = threadIdx.x; d < kBins; d += kSortBlock) h[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = base + r * kSortBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d <= (int)mask; d += kSortBlock) hist[(int64_t)d * nblocks + blockIdx.x] = h[d];
+}
+
+template <int kBins>
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
+    const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
+    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
+    uint32_t rank_mask, uint32_t *__restrict__ vals_out) {
+  constexpr int kPer = kBins / kSortBlock;   // digits per thread (consecutive: thread t owns [t * kPer, (t + 1) * kPer))
+  const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
+  if (bbase >= n) return;
+  __shared__ uint32_t wrun[kSortWaves][kBins];
+  __shared__ uint32_t dstart[kBins], gbase[kBins];
+  __shared__ uint32_t lw[kSortBlock / kWave + 1];
+  __shared__ uint32_t lk[kSortChunk];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  for (int d = tid; d < kBins; d += kSortBlock) {
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) wrun[w][d] = 0;
+  }
+  __syncthreads();
+  constexpr int kPerWave = kSortChunk / kSortWaves;
+  const int64_t wbase = bbase + (int64_t)wv * kPerWave;
+  uint32_t k[kSortRounds];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    k[r] = 0xFFFFFFFFu;
+    if (i < n) {
+      k[r] = keys_in[i];
+      atomicAdd(&wrun[wv][(k[r] >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t tot[kPer], sum = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; u++) {
+      const int d = tid * kPer + u;
+      tot[u] = 0;
+#pragma unroll
+      for (int w = 0; w < kSortWaves; w++) tot[u] += wrun[w][d];
+      sum += tot[u];
+    }
+    uint32_t all;
+    uint32_t base = block_excl_scan(sum, all, lw);
+#pragma unroll
+    for (int u = 0; u < kPer; u++) {
+      const int d = tid * kPer + u;
+      dstart[d] = base;
+      gbase[d] = d <= (int)mask ? hist_scanned[(int64_t)d * nblocks + blockIdx.x] : 0u;
+      uint32_t b2 = base;
+#pragma unroll
+      for (int w = 0; w < kSortWaves; w++) {
+        const uint32_t c = wrun[w][d];
+        wrun[w][d] = b2;
+        b2 += c;
+      }
+      base += tot[u];
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = wbase + r * kWave + lane;
+    const bool on = i < n;
+    const uint32_t d = (k[r] >> shift) & mask;
+    unsigned long long peers = __ballot(on);
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(peers & lt);
+    uint32_t pos = 0;
+    if (on) pos = wrun[wv][d];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (on) lk[pos + rank] = k[r];
+  }
+  __syncthreads();
+  const int cnt = (int)((n - bbase) < (int64_t)kSortChunk ? (n - bbase) : (int64_t)kSortChunk);
+  for (int i = tid; i < cnt; i += kSortBlock) {
+    const uint32_t kk = lk[i];
+    const uint32_t d = (kk >> shift) & mask;
+    const uint32_t g = gbase[d] + ((uint32_t)i - dstart[d]);
+    keys_out[g] = kk;
+    if (unpack) vals_out[g] = unpack[kk & rank_mask];
+  }
+}
+
+constexpr int kWideBits = 10;   // widest digit of the packed tile pass
+
+static size_t radix_temp_elems(int64_t n, int max_bins = 256) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
-  const size_t h = align_up((size_t)256 * nblocks, 4);
-  return h + scan_temp_elems((int64_t)256 * nblocks);
+  const size_t h = align_up((size_t)max_bins * nblocks, 4);
+  return h + scan_temp_elems((int64_t)max_bins * nblocks);
 }
 
 static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift,
@@ -377,14 +489,27 @@ static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int s
   const uint32_t mask = (1u << bits) - 1u;
   const int64_t hn = (int64_t)(mask + 1) * nblocks;
   uint32_t *hist = temp;
-  uint32_t *stemp = temp + align_up((size_t)256 * nblocks, 4);
-  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, (const uint64_t *)nullptr, shift, mask,
-                     nblocks, hist);
+  uint32_t *stemp = temp + align_up((size_t)(bits > 8 ? (1 << kWideBits) : 256) * nblocks, 4);
+  if (bits > 8) {
+    if (bits == 9) hipLaunchKernelGGL((radix_hist_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, nblocks, hist);
+    else hipLaunchKernelGGL((radix_hist_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, nblocks, hist);
+  } else {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, (const uint64_t *)nullptr, shift, mask,
+                       nblocks, hist);
+  }
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
-  hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks, hist,
-                     kout, unpack, rank_mask, vout);
+  if (bits == 9) {
+    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks,
+                       hist, kout, unpack, rank_mask, vout);
+  } else if (bits > 9) {
+    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks,
+                       hist, kout, unpack, rank_mask, vout);
+  } else {
+    hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks, hist,
+                       kout, unpack, rank_mask, vout);
+  }
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -859,7 +984,7 @@ static BuildWs build_layout(void *ws, int64_t M) {
   L.ka = reinterpret_cast<uint32_t *>(take(M, 4));
   L.va = reinterpret_cast<uint32_t *>(take(M, 4));
   L.kb = reinterpret_cast<uint32_t *>(take(M, 4));
-  L.temp = reinterpret_cast<uint32_t *>(take(radix_temp_elems(M), 4));
+  L.temp = reinterpret_cast<uint32_t *>(take(radix_temp_elems(M, 1 << kWideBits), 4));
   L.bytes = off + 256;
   return L;
 }
@@ -1028,8 +1153,6 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   // number of radix passes over the tile key
   int nbits = 1;
   while (((int64_t)1 << nbits) < n_tiles_total) nbits++;
-  const int npass = (nbits + 7) / 8;
-  const int bits_per = (nbits + npass - 1) / npass;
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
   uint32_t *fl = reinterpret_cast<uint32_t *>(flatten_ids);
   // Packed lists: when the depth rank of every visible entry fits next to the tile key in ONE 32-bit word
@@ -1037,6 +1160,10 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   // the ranks while the last pass writes out.  Same order: entries are emitted by increasing rank and the passes are stable.
   const int rank_bits = 32 - nbits;
   const bool packed = n_visible >= 0 && rank_bits >= 1 && n_visible <= ((int64_t)1 << rank_bits) && option_get(kOptPacked);
+  // digits: 8 bits, or -- packed lists whose whole key fits -- ONE pass of 9-10 bits (radix_scatter_keys_wide_kernel)
+  const int max_digit = (packed && nbits > 8 && nbits <= kWideBits) ? kWideBits : 8;
+  const int npass = (nbits + max_digit - 1) / max_digit;
+  const int bits_per = (nbits + npass - 1) / npass;
   int key_shift = 0;
   uint32_t *kin;
   if (packed) {

@@ -237,6 +237,8 @@ class FrameExchange:
         self.world = dist.get_world_size() if _active() else 1
         self.active = bool(force) or self.world > 1
         self.headroom, self.n_buffers = float(headroom), int(n_buffers)
+        n_row = sum(v.numel() for v in flat._views[:len(ROW_NAMES)])
+        self._tail = flat.flat[n_row:] if (not self.active and flat.total > n_row) else None
         self.cap = 0
         self._bufs: List[Tensor] = []
         self._free: List[int] = []
@@ -255,6 +257,13 @@ class FrameExchange:
             #               (grids, ...) is accumulated by autograd as usual and packed in end_frame
             for p, v in zip(self.flat.params[:len(ROW_NAMES)], self.flat._views[:len(ROW_NAMES)]):
                 p.grad = v
+        elif self._tail is not None:
+            # world size 1: the small dense tail (grids, ...) is accumulated IN PLACE by the producing kernels (fused_view's grid
+            # gradients, the TV term of the loss: ``tail_grads``) -- one fill per frame here instead of an autograd sum + an
+            # accumulation pass per tensor and view
+            self._tail.zero_()
+            for p, v in zip(self.flat.params[len(ROW_NAMES):], self.flat._views[len(ROW_NAMES):]):
+                p.grad = v
         self.payload_bytes, self.n_exchanges = 0, 0
 
     def view_kwargs(self, v: int) -> dict:
@@ -262,6 +271,14 @@ class FrameExchange:
         if self.active:
             return dict(grad_sink=self)
         return dict(grad_arena=self.arena, arena_rows=1 if v == 0 else 2)
+
+    def tail_grads(self, prefix: str = "grid") -> Optional[List[Tensor]]:
+        """World size 1: the ``.grad`` slices of the parameters named ``prefix + i`` (zeroed by ``begin_frame``), for producers
+        that add their gradient in place (``losses.photometric_tv_loss(grid_grads=...)``); None while an exchange is active
+        (autograd accumulates the tail then)."""
+        if self.active or self._tail is None:
+            return None
+        return [self.arena[n] for n in self.names if n.startswith(prefix)]
 
     def begin_view(self, info) -> None:
         """Right after the view's forward pass (``info`` = its info dict)."""

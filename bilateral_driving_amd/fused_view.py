@@ -164,7 +164,8 @@ def _composite(f: _Front, opac: Tensor):
     render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
     last_ids = _empty((1, H, W), dev, torch.int32)
     with L.timed("rasterize_fwd"):
-        L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac), L.ptr(rec), st),
+        L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac), L.ptr(f.radii),
+                                   L.ptr(rec), st),
                 "bds_splat_pack")
         L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th, L.ptr(f.isect_offsets), L.ptr(f.flatten),
                                       L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
@@ -229,12 +230,19 @@ class _FusedView(torch.autograd.Function):
         need_g = ctx.needs_input_grad[8:]
         # grid gradients: one zero fill for all levels; with img_idx the full [n_img, ...] gradient is returned with only that
         # image's slice written (no slice-backward / scatter in the autograd graph)
-        sizes = [(g.numel() + 3) // 4 * 4 if need_g[i] else 0 for i, g in enumerate(grids)]
-        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32) if sum(sizes) else None
-        v_grids, off = [], 0
-        for i, g in enumerate(grids):
-            v_grids.append(flat[off:off + g.numel()].view(g.shape) if need_g[i] else None)
-            off += sizes[i]
+        # ... or, with grad_arena["grid<i>"] and arena_rows >= 1, ADDED in place to the caller's accumulators (their .grad)
+        arena_g = [(cfg.get("grad_arena") or {}).get(f"grid{i}") for i in range(len(grids))]
+        grids_in_place = (cfg.get("grad_sink") is None and int(cfg.get("arena_rows", 0)) >= 1 and any(need_g)
+                          and all(a is not None and a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)))
+        if grids_in_place:
+            v_grids = [a if need_g[i] else None for i, a in enumerate(arena_g)]
+        else:
+            sizes = [(g.numel() + 3) // 4 * 4 if need_g[i] else 0 for i, g in enumerate(grids)]
+            flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32) if sum(sizes) else None
+            v_grids, off = [], 0
+            for i, g in enumerate(grids):
+                v_grids.append(flat[off:off + g.numel()].view(g.shape) if need_g[i] else None)
+                off += sizes[i]
         idx = cfg.get("img_idx")
         sel = list(grids) if idx is None else [g[idx:idx + 1] for g in grids]
         v_sel = v_grids if idx is None else [None if v is None else v[idx:idx + 1] for v in v_grids]
@@ -299,6 +307,8 @@ class _FusedView(torch.autograd.Function):
             carrier.grad = g2d[0:1]
             carrier.absgrad = g2d[1:2]
         v_viewmat = None if v_vm_slots is None else v_vm_slots.sum(0)
+        if grids_in_place:
+            v_grids = [None] * len(grids)
         if rows == 2 or sink is not None:   # already added in place to what autograd holds as .grad (or handed to the sink)
             return (None, None, None, None, None, None, v_sky, v_viewmat, *v_grids)
         return (None, v_means, v_quats, v_ls, v_logits, v_sh, v_sky, v_viewmat, *v_grids)

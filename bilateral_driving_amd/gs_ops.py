@@ -232,7 +232,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         alphas = torch.empty(Cn, height, width, 1, device=dev, dtype=torch.float32)
         last_ids = torch.empty(Cn, height, width, device=dev, dtype=torch.int32)
         with L.timed("rasterize_fwd"):
-            L.check(lib.bds_splat_pack(Cn * N, CH, None, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(rec), st),
+            L.check(lib.bds_splat_pack(Cn * N, CH, None, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities), None, L.ptr(rec), st),
                     "bds_splat_pack")
             L.check(lib.bds_rasterize_fwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, TILE_SIZE, tile_size, tw, th,
                                           L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),

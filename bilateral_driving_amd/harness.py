@@ -145,13 +145,14 @@ def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[T
 FUSED_LOSS = True   # one autograd node (losses.photometric_tv_loss) instead of ~30 framework kernels
 
 
-def training_loss(out: Dict[str, Tensor], target: Tensor, grids: Sequence[Tensor], tv_weight: float = 0.01) -> Tensor:
+def training_loss(out: Dict[str, Tensor], target: Tensor, grids: Sequence[Tensor], tv_weight: float = 0.01, grid_grads=None) -> Tensor:
     """L1 photometric + TV(grids) (trainers/base.py:518-565,590-594: losses.affine.w = 0.01 for the
     multi-scale config); every gradient path of the hot path is live."""
     level_w = [0.5 * math.sqrt(g.shape[4] * g.shape[3] * g.shape[2]) for g in grids]  # modules.py:445
     if FUSED_LOSS:
         from .losses import photometric_tv_loss
-        return photometric_tv_loss(out["rgb"], target, grids, [tv_weight * w for w in level_w])
+        return photometric_tv_loss(out["rgb"], target, grids, [tv_weight * w for w in level_w], grid_grads=grid_grads)
+    assert grid_grads is None, "in-place grid gradients need the fused loss"
     loss = (out["rgb"] - target).abs().mean()
     for g, w in zip(grids, level_w):
         loss = loss + tv_weight * total_variation_loss(g, w)

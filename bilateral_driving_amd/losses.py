@@ -16,7 +16,7 @@ from .bilagrid import _levels_struct
 
 class _PhotometricTV(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb: Tensor, target: Tensor, tv_weights: tuple, *grids: Tensor):
+    def forward(ctx, rgb: Tensor, target: Tensor, tv_weights: tuple, grid_grads, *grids: Tensor):
         L.require_gpu(rgb, target, *grids)
         lib, st = L.lib(), L.stream()
         rgb, target = rgb.contiguous(), target.contiguous()
@@ -30,6 +30,7 @@ class _PhotometricTV(torch.autograd.Function):
             L.check(lib.bds_bilagrid_tv_ms_fwd(len(grids), lv, wts, L.ptr(out), st), "bds_bilagrid_tv_ms_fwd")
         ctx.save_for_backward(rgb, target, *grids)
         ctx.tv_weights = tuple(float(w) for w in tv_weights)
+        ctx.grid_grads = grid_grads
         return out.reshape(())
 
     @staticmethod
@@ -42,8 +43,14 @@ class _PhotometricTV(torch.autograd.Function):
             v_rgb = torch.empty_like(rgb)
             L.check(lib.bds_l1_mean_bwd(rgb.numel(), L.ptr(rgb), L.ptr(target), L.ptr(v), L.ptr(v_rgb), st), "bds_l1_mean_bwd")
         v_grids = [None] * len(grids)
-        need = [ctx.needs_input_grad[3 + i] for i in range(len(grids))]
-        if any(need):
+        need = [ctx.needs_input_grad[4 + i] for i in range(len(grids))]
+        if any(need) and ctx.grid_grads is not None:    # add in place to the caller's accumulators, return nothing
+            sel = [g for i, g in enumerate(grids) if need[i]]
+            sel_v = [a for i, a in enumerate(ctx.grid_grads) if need[i]]
+            lv = _levels_struct(sel, sel_v, [1] * len(sel))
+            wts = (C.c_float * len(sel))(*[ctx.tv_weights[i] for i in range(len(grids)) if need[i]])
+            L.check(lib.bds_bilagrid_tv_ms_bwd(len(sel), lv, wts, L.ptr(v), st), "bds_bilagrid_tv_ms_bwd")
+        elif any(need):
             sizes = [(g.numel() + 3) // 4 * 4 if need[i] else 0 for i, g in enumerate(grids)]   # 16-byte aligned slices
             flat = torch.zeros(sum(sizes), device=rgb.device, dtype=torch.float32)               # one fill for all levels
             off, sel, sel_v, sel_w = 0, [], [], []
@@ -57,13 +64,19 @@ class _PhotometricTV(torch.autograd.Function):
             lv = _levels_struct(sel, sel_v, [1] * len(sel))
             wts = (C.c_float * len(sel))(*sel_w)
             L.check(lib.bds_bilagrid_tv_ms_bwd(len(sel), lv, wts, L.ptr(v), st), "bds_bilagrid_tv_ms_bwd")
-        return (v_rgb, None, None, *v_grids)
+        return (v_rgb, None, None, None, *v_grids)
 
 
-def photometric_tv_loss(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv_weights: Sequence[float]) -> Tensor:
-    """mean|rgb - target| + sum_l tv_weights[l] * total_variation(grids[l])  (grids [n_img,12,L,gy,gx])."""
+def photometric_tv_loss(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv_weights: Sequence[float],
+                        grid_grads: Sequence[Tensor] = None) -> Tensor:
+    """mean|rgb - target| + sum_l tv_weights[l] * total_variation(grids[l])  (grids [n_img,12,L,gy,gx]).
+    ``grid_grads`` (optional, one tensor per grid, same shapes): the TV gradient is ADDED to these in place (accumulators that
+    already are the grids' ``.grad``, ``dist.FrameExchange.tail_grads()``) and autograd receives no gradient for the grids."""
     assert len(grids) == len(tv_weights)
-    return _PhotometricTV.apply(rgb, target, tuple(tv_weights), *grids)
+    if grid_grads is not None:
+        assert len(grid_grads) == len(grids) and all(a.shape == g.shape and a.is_contiguous() for a, g in zip(grid_grads, grids))
+        grid_grads = list(grid_grads)
+    return _PhotometricTV.apply(rgb, target, tuple(tv_weights), grid_grads, *grids)
 
 
 class _SSIM(torch.autograd.Function):

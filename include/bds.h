@@ -142,7 +142,7 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
  * models/trainers/base.py:409-419 (render, alphas) and :280-297 (means2d.absgrad).
  *
  * The compositor reads SPLAT RECORDS: 12 floats (48 bytes, 16-byte aligned) per list-addressable entry,
- *     mean2d.x, mean2d.y, ea, eb | ec, opacity, colour0, colour1 | colour2, colour3, 0, 0
+ *     mean2d.x, mean2d.y, ea, eb | ec, opacity, colour0, colour1 | colour2, colour3, 0, radius (int32 bits)
  * with (ea, eb, ec) = -log2(e) * (a/2, b, c/2) of the conic (a, b, c): alpha = opacity * 2^(ea dx^2 + eb dx dy + ec dy^2).
  * bds_splat_pack builds them from the per-entry arrays means2d [n,2] conics [n,3] colors [n,CH] opacities [n]: record r is
  * entry ids[r], or entry r when ids == NULL.  The per-tile lists (`flatten`) hold RECORD indices: cam*N + g for records in
@@ -152,13 +152,16 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
  * COARSE LISTS (no reference counterpart): list_tile_size is the tile size the lists were BUILT for (bds_isect_* called with it:
  * isect_offsets [C, ceil(H/list_tile_size), ceil(W/list_tile_size)]) -- tile_size (16, gsplat's lists) or a multiple of it.  With a
  * multiple, the tile stage emits and sorts one pair per (list tile, Gaussian) instead of one per (16-px tile, Gaussian), and every
- * 16 x 16 compositing wave filters the candidates of its list tile against its own rectangle of pixel centres (the tile stage's
- * exact span test) as it stages them.  A rejected candidate has alpha < 1/255 on every pixel of the tile, so render / alphas and
- * the gradients equal those of 16-px lists; last_ids then holds positions in the coarse list. */
+ * 16 x 16 compositing wave filters the candidates of its list tile as it stages them, by the two conditions that define a pair of
+ * gsplat's 16-px lists: the tile lies in the Gaussian's bounding square (radius slot of the record) and one of its pixel centres
+ * reaches alpha >= 1/255 (the tile stage's exact span test).  Records packed WITH radii therefore give exactly the render / alphas /
+ * gradients of 16-px lists (the fused view's use); records packed without (radii == NULL: unbounded square) give gsplat's semantics
+ * for tile_size = list_tile_size, where a splat is clipped to its bounding square at that tile granularity (the rasterization()
+ * API's tile_size argument).  last_ids holds positions in the coarse list. */
 #define BDS_SPLAT_RECORD_FLOATS 12
 #define BDS_GRAD_RECORD_FLOATS 16
 int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
-                   const float *opacities, float *records, bds_stream_t stream);
+                   const float *opacities, const int32_t *radii /* [n entries] or NULL */, float *records, bds_stream_t stream);
 int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
                       int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
                       const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);

@@ -35,7 +35,7 @@ def pair_stats(N, W, H, view=0):
         render, alphas = torch.empty(1, H, W, 3, device=dev), torch.empty(1, H, W, 1, device=dev)
         last = torch.zeros(1, H, W, dtype=torch.int32, device=dev)
         rec = torch.empty(N, L.SPLAT_RECORD_FLOATS, device=dev)
-        L.check(L.lib().bds_splat_pack(N, 3, None, L.ptr(m2), L.ptr(con), L.ptr(col), L.ptr(op), L.ptr(rec), L.stream()), "pack")
+        L.check(L.lib().bds_splat_pack(N, 3, None, L.ptr(m2), L.ptr(con), L.ptr(col), L.ptr(op), None, L.ptr(rec), L.stream()), "pack")
         L.check(L.lib().bds_rasterize_fwd(1, N, M, 3, L.ptr(rec), None, W, H, 16, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(render),
                                           L.ptr(alphas), L.ptr(last), L.stream()), "fwd")
         n_tiles = tw * th

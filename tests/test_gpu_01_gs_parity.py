@@ -132,6 +132,30 @@ def test_isect_bit_exact(ops, seed, N, W, H, C):
     assert torch.equal(offs.cpu(), ref_off)
 
 
+@pytest.mark.parametrize("seed,N,W,H,ts", [(0, 30000, 1920, 1080, 64), (1, 5000, 640, 368, 32), (2, 20000, 1920, 1080, 128), (3, 4000, 333, 211, 48)])
+def test_isect_bit_exact_other_tile_sizes(ops, seed, N, W, H, ts):
+    """Lists for tiles of 32 ... 128 px (the coarse lists of the fused view; gsplat's tile_size argument), with and without culling."""
+    sc = make_scene(N, W, H, seed=seed, spread=1.3)
+    radii, m2, d, con, _ = ops.fully_fused_projection(sc["means"].cuda(), sc["quats"].cuda(), sc["scales"].cuda(), sc["viewmats"].cuda(),
+                                                       sc["Ks"].cuda(), W, H)
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    tpg, iids, fids, offs = ops.isect_tiles(m2, radii, d, ts, tw, th)
+    t, k, v = G.isect_tiles(m2[0].cpu(), radii[0].cpu(), d[0].cpu(), ts, tw, th)
+    assert torch.equal(tpg.cpu()[0], t) and torch.equal(iids.cpu(), k) and torch.equal(fids.cpu().long(), v.long())
+    ref_off = torch.searchsorted((k >> 32).contiguous(), torch.arange(tw * th)).to(torch.int32).reshape(1, th, tw)
+    assert torch.equal(offs.cpu(), ref_off)
+    # culled lists: a subset of the pairs, same order
+    op = sc["opacities"].cuda()[None].contiguous()
+    tpg_c, _, fids_c, offs_c = ops.isect_tiles(m2, radii, d, ts, tw, th, want_isect_ids=False, conics=con, opacities=op)
+    assert fids_c.numel() <= fids.numel() and bool((tpg_c <= tpg).all())
+    full, cul = fids.cpu().tolist(), fids_c.cpu().tolist()
+    o_f, o_c = offs.reshape(-1).cpu().tolist() + [len(full)], offs_c.reshape(-1).cpu().tolist() + [len(cul)]
+    for tile in range(0, tw * th, max(1, tw * th // 40)):
+        a, b = full[o_f[tile]:o_f[tile + 1]], cul[o_c[tile]:o_c[tile + 1]]
+        it = iter(a)
+        assert all(x in it for x in b), tile      # b is a subsequence of a
+
+
 def test_isect_tiles_one_call_and_capacity(ops):
     """bds_isect_tiles == prepare + build when the caller's buffers are large enough; BDS_ECAPACITY (and M) otherwise."""
     import ctypes as C
@@ -454,7 +478,7 @@ def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C)
     rr, aa = torch.empty(Cn, H, W, 3, device="cuda"), torch.empty(Cn, H, W, 1, device="cuda")
     M = fids.numel()
     rec = torch.empty(Cn * N, L.SPLAT_RECORD_FLOATS, device="cuda")
-    L.check(L.lib().bds_splat_pack(Cn * N, 3, None, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), L.ptr(rec),
+    L.check(L.lib().bds_splat_pack(Cn * N, 3, None, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), None, L.ptr(rec),
                                    L.stream()), "pack")
     L.check(L.lib().bds_rasterize_fwd(Cn, Cn * N, M, 3, L.ptr(rec), None, W, H, 16, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa),
                                       L.ptr(last), L.stream()), "fwd")

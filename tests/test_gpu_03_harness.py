@@ -214,3 +214,42 @@ def test_rasterization_api_pose_gradient_and_fused_equivalence(ops):
         res.append(cam.viewmat.grad.clone())
     assert float(res[1].abs().max()) > 0
     assert float((res[0] - res[1]).norm() / res[1].norm()) < 1e-3
+
+
+def test_frame_loop_world1_grids_accumulate_in_place(ops):
+    """dist.FrameExchange at world size 1 (the bench's single-GPU loop): per-Gaussian rows through the arena modes, the grids'
+    gradients (transform + TV term) ADDED in place to their .grad slices -- equals the sum of the views' separate gradients."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    dev = "cuda"
+    W, H, N = 256, 160, 5000
+    cams = Hn.ring_cameras(W, H, yaws_deg=(0.0, 120.0, 240.0), device=dev)
+    base = Hn.synthetic_scene(N, seed=6, device=dev)
+    grids0 = Hn.make_grids(len(cams), device=dev)
+    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    ref = None
+    for v, cam in enumerate(cams):
+        p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        Hn.training_loss(Hn.render_view(p, cam, grids, v, sky), target, grids).backward()
+        g = torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids])
+        ref = g if ref is None else ref + g
+    p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+    grids = [g.clone().requires_grad_(True) for g in grids0]
+    flat = FlatGradients(list(p.values()) + grids, sparse_rows=True)
+    fx = FrameExchange(flat, list(p.keys()) + [f"grid{i}" for i in range(len(grids))])
+    assert not fx.active and fx.tail_grads() is not None and len(fx.tail_grads()) == len(grids)
+    for frame in range(2):
+        fx.begin_frame()
+        for v, cam in enumerate(cams):
+            out = Hn.render_view(p, cam, grids, v, sky, **fx.view_kwargs(v))
+            fx.begin_view(out["info"])
+            Hn.training_loss(out, target, grids, grid_grads=fx.tail_grads()).backward()
+            fx.end_view()
+        fx.end_frame()
+        for g, a in zip(grids, fx.tail_grads()):
+            assert g.grad is not None and g.grad.data_ptr() == a.data_ptr()
+        got = torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids])
+        assert float((got - ref).norm() / ref.norm()) < 1e-4, frame
+        gg, rg = got[-sum(g.numel() for g in grids):], ref[-sum(g.numel() for g in grids):]
+        assert float((gg - rg).norm() / rg.norm()) < 1e-4, frame

@@ -25,40 +25,35 @@ def _run_api(sc, W, H, tile_size, mode="RGB+ED", absgrad=True, backgrounds=None)
     return rr.detach(), aa.detach(), grads, meta
 
 
-@pytest.mark.parametrize("seed,N,W,H,C", [(0, 3000, 320, 200, 1), (1, 800, 75, 50, 2), (2, 5000, 448, 256, 1)])
+@pytest.mark.parametrize("seed,N,W,H,C", [(0, 1500, 200, 130, 1), (1, 800, 75, 50, 2)])
 @pytest.mark.parametrize("tile_size", [32, 64, 128])
-def test_rasterization_with_coarse_lists_equals_16px_lists(seed, N, W, H, C, tile_size):
+def test_rasterization_api_tile_size_equals_oracle_with_that_tile_size(seed, N, W, H, C, tile_size):
+    """gsplat semantics of the tile_size argument: a splat is clipped to its bounding square at THAT tile granularity."""
+    from oracle import gs_oracle as O
     sc = make_scene(N, W, H, seed=seed)
     if C > 1:   # a second camera, shifted sideways
         vm2 = sc["viewmats"][0].clone()
         vm2[0, 3] += 0.4
         sc["viewmats"] = torch.stack([sc["viewmats"][0], vm2])
         sc["Ks"] = sc["Ks"].expand(2, 3, 3).contiguous()
-    bg = torch.rand(sc["viewmats"].shape[0], 4).cuda()
-    r16, a16, g16, m16 = _run_api(sc, W, H, 16, backgrounds=bg)
-    rc, ac, gc, mc = _run_api(sc, W, H, tile_size, backgrounds=bg)
+    bg = torch.rand(C, 3)
+    rc, ac, gc, mc = _run_api(sc, W, H, tile_size, backgrounds=bg.cuda(), absgrad=False)
+    r16, a16, _, m16 = _run_api(sc, W, H, 16, backgrounds=bg.cuda(), absgrad=False)
     assert mc["tile_size"] == tile_size and mc["flatten_ids"].numel() < m16["flatten_ids"].numel()
     assert mc["isect_offsets"].shape[1:] == (-(-H // tile_size), -(-W // tile_size))
-    # same survivors, same order, same arithmetic: the images are bit-equal
-    assert torch.equal(rc, r16) and torch.equal(ac, a16)
-    for k in g16:
-        assert rel_err(gc[k], g16[k]) < 2e-5, (k, rel_err(gc[k], g16[k]))     # atomics: summation order only
-
-
-def test_coarse_lists_against_oracle():
-    from oracle import gs_oracle as O
-    W, H, N = 150, 100, 1200
-    sc = make_scene(N, W, H, seed=4)
-    rc, ac, gc, _ = _run_api(sc, W, H, 64, absgrad=False)
     leaves = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
     rr, aa, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"], sc["viewmats"],
-                                sc["Ks"], W, H, render_mode="RGB+ED")
+                                sc["Ks"], W, H, render_mode="RGB+ED", tile_size=tile_size, backgrounds=torch.cat([bg, torch.zeros(C, 1)], -1))
     g = torch.Generator(device="cpu").manual_seed(7)
     w1, w2 = torch.randn(rr.shape, generator=g), torch.randn(aa.shape, generator=g)
     ((rr * w1).sum() + (aa * w2).sum()).backward()
     assert rel_err(rc.cpu()[..., :3], rr.detach()[..., :3]) < 1e-5 and rel_err(ac.cpu(), aa.detach()) < 1e-5
+    cov = (aa.detach() > 1e-3).squeeze(-1)
+    assert rel_err(rc.cpu()[..., 3][cov], rr.detach()[..., 3][cov]) < 1e-4
     for k, v in leaves.items():
         assert rel_err(gc[k].cpu(), v.grad) < 2e-4, (k, rel_err(gc[k].cpu(), v.grad))
+    # larger list tiles clip the splats later: the image moves a little, and only upwards in coverage
+    assert bool((ac >= a16 - 1e-6).all()) and rel_err(rc[..., :3], r16[..., :3]) < 0.05
 
 
 @pytest.mark.parametrize("W,H,N", [(320, 192, 4000), (200, 130, 1500)])
