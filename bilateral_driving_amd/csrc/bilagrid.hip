@@ -80,36 +80,90 @@ __device__ __forceinline__ void lowres_colour(const MsParams &p, const Tap &ty, 
 }
 
 // ---- A: per-level low-resolution slice -------------------------------------------------------
+// trilinear sample of the 12 channels from a CELL-MAJOR copy of the grid ([cell][12] as three float4): the arithmetic (and its
+// order) is slice_sample's, the eight taps are three 16-byte reads each instead of twelve scalar gathers
+__device__ __forceinline__ void slice_sample_cells(const float4 *__restrict__ cells, int gx, int gy, const Cell &c, float *out12) {
+  const int plane = gy * gx;
+  const int o00 = c.y0 * gx + c.x0, o01 = c.y0 * gx + c.x1, o10 = c.y1 * gx + c.x0, o11 = c.y1 * gx + c.x1;
+  const float w00 = (1.f - c.fy) * (1.f - c.fx), w01 = (1.f - c.fy) * c.fx, w10 = c.fy * (1.f - c.fx), w11 = c.fy * c.fx;
+  const float4 *g0 = cells + (int64_t)c.z0 * plane * 3, *g1 = cells + (int64_t)c.z1 * plane * 3;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float4 a00 = g0[o00 * 3 + q], a01 = g0[o01 * 3 + q], a10 = g0[o10 * 3 + q], a11 = g0[o11 * 3 + q];
+    const float4 b00 = g1[o00 * 3 + q], b01 = g1[o01 * 3 + q], b10 = g1[o10 * 3 + q], b11 = g1[o11 * 3 + q];
+    const float ax = a00.x * w00 + a01.x * w01 + a10.x * w10 + a11.x * w11, bx = b00.x * w00 + b01.x * w01 + b10.x * w10 + b11.x * w11;
+    const float ay = a00.y * w00 + a01.y * w01 + a10.y * w10 + a11.y * w11, by = b00.y * w00 + b01.y * w01 + b10.y * w10 + b11.y * w11;
+    const float az = a00.z * w00 + a01.z * w01 + a10.z * w10 + a11.z * w11, bz = b00.z * w00 + b01.z * w01 + b10.z * w10 + b11.z * w11;
+    const float aw = a00.w * w00 + a01.w * w01 + a10.w * w10 + a11.w * w11, bw = b00.w * w00 + b01.w * w01 + b10.w * w10 + b11.w * w11;
+    out12[q * 4 + 0] = ax * (1.f - c.fz) + bx * c.fz;
+    out12[q * 4 + 1] = ay * (1.f - c.fz) + by * c.fz;
+    out12[q * 4 + 2] = az * (1.f - c.fz) + bz * c.fz;
+    out12[q * 4 + 3] = aw * (1.f - c.fz) + bw * c.fz;
+  }
+}
+
+// d(slice)/d(iz) of the 12 channels from the cell-major copy (slice_sample's dz: upper plane minus lower plane)
+__device__ __forceinline__ void slice_dz_cells(const float4 *__restrict__ cells, int gx, int gy, const Cell &c, float *dz12) {
+  const int plane = gy * gx;
+  const int o00 = c.y0 * gx + c.x0, o01 = c.y0 * gx + c.x1, o10 = c.y1 * gx + c.x0, o11 = c.y1 * gx + c.x1;
+  const float w00 = (1.f - c.fy) * (1.f - c.fx), w01 = (1.f - c.fy) * c.fx, w10 = c.fy * (1.f - c.fx), w11 = c.fy * c.fx;
+  const float4 *g0 = cells + (int64_t)c.z0 * plane * 3, *g1 = cells + (int64_t)c.z1 * plane * 3;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float4 a00 = g0[o00 * 3 + q], a01 = g0[o01 * 3 + q], a10 = g0[o10 * 3 + q], a11 = g0[o11 * 3 + q];
+    const float4 b00 = g1[o00 * 3 + q], b01 = g1[o01 * 3 + q], b10 = g1[o10 * 3 + q], b11 = g1[o11 * 3 + q];
+    dz12[q * 4 + 0] = (b00.x * w00 + b01.x * w01 + b10.x * w10 + b11.x * w11) - (a00.x * w00 + a01.x * w01 + a10.x * w10 + a11.x * w11);
+    dz12[q * 4 + 1] = (b00.y * w00 + b01.y * w01 + b10.y * w10 + b11.y * w11) - (a00.y * w00 + a01.y * w01 + a10.y * w10 + a11.y * w11);
+    dz12[q * 4 + 2] = (b00.z * w00 + b01.z * w01 + b10.z * w10 + b11.z * w11) - (a00.z * w00 + a01.z * w01 + a10.z * w10 + a11.z * w11);
+    dz12[q * 4 + 3] = (b00.w * w00 + b01.w * w01 + b10.w * w10 + b11.w * w11) - (a00.w * w00 + a01.w * w01 + a10.w * w10 + a11.w * w11);
+  }
+}
+
+// kLds: the level's grid(s) (n_avg * 12*gl*gy*gx floats) are staged cell-major in the workgroup's LDS once, and the workgroup then
+// walks a grid-stride range of low-res pixels (persistent workgroups: the staging is amortised over several chunks).  The
+// global-memory form gathered 96 scalars per pixel from L1/L2 and was bound by the latency of those chains.
+template <bool kLds>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, LevelSched sc) {
+  extern __shared__ __attribute__((aligned(16))) float lds_grid[];
   int local;
-  const int l = sc.level[sched_find(sc, blockIdx.x, local)];
+  const int k_entry = sched_find(sc, blockIdx.x, local);
+  const int l = sc.level[k_entry];
   const LevelDev &L = p.lv[l];
-  const int64_t idx = (int64_t)local * kBgBlock + threadIdx.x;
-  if (idx >= (int64_t)L.Hd * L.Wd) return;
-  const int i = (int)(idx / L.Wd), j = (int)(idx - (int64_t)i * L.Wd);
-  const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
-  float r, g, b;
-  lowres_colour(p, ty, tx, r, g, b);
-  const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
-  float acc[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) acc[k] = 0.f;
-  const int gsz = 12 * L.gl * L.gy * L.gx;
-  for (int n = 0; n < L.n_avg; n++) {
-    float a[12];
-    slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a, nullptr);
-#pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] += a[k];
+  const int vol = L.gl * L.gy * L.gx, gsz = 12 * vol;
+  if (kLds) {
+    for (int e = threadIdx.x; e < gsz * L.n_avg; e += kBgBlock) {
+      const int n = e / gsz, r = e - n * gsz, ch = r / vol, cell = r - ch * vol;
+      lds_grid[(n * vol + cell) * 12 + ch] = L.grid[e];
+    }
+    __syncthreads();
   }
-  float4 *dst = reinterpret_cast<float4 *>(L.lo + idx * 12);
-  if (L.n_avg > 1) {
-    const float inv = (float)L.n_avg;
+  const int64_t n_low = (int64_t)L.Hd * L.Wd;
+  for (int64_t idx = (int64_t)local * kBgBlock + threadIdx.x; idx < n_low; idx += (int64_t)sc.nblk[k_entry] * kBgBlock) {
+    const int i = (int)(idx / L.Wd), j = (int)(idx - (int64_t)i * L.Wd);
+    const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
+    float r, g, b;
+    lowres_colour(p, ty, tx, r, g, b);
+    const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
+    float acc[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] = acc[k] / inv;
+    for (int k = 0; k < 12; k++) acc[k] = 0.f;
+    for (int n = 0; n < L.n_avg; n++) {
+      float a[12];
+      if (kLds) slice_sample_cells(reinterpret_cast<const float4 *>(lds_grid) + (int64_t)n * vol * 3, L.gx, L.gy, c, a);
+      else slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a, nullptr);
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] += a[k];
+    }
+    float4 *dst = reinterpret_cast<float4 *>(L.lo + idx * 12);
+    if (L.n_avg > 1) {
+      const float inv = (float)L.n_avg;
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = acc[k] / inv;
+    }
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
   }
-  dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-  dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
 }
 
 // bilinear up-sample of one level's low-res map at full-res pixel (i,j)
@@ -138,7 +192,102 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
 }
 
 // ---- B: full-resolution compose --------------------------------------------------------------
+// Row staging of the up-sampler: a workgroup works on a run of pixels of ONE image row, so the y-interpolation of every level's
+// low-res maps is the same for all of them.  It is done once per low-res column the run touches, while the two source rows are
+// copied (coalesced float4 loads) into LDS; a pixel then only interpolates in x between two LDS entries: 6 LDS reads per level
+// instead of 12 dependent float4 gathers from L2 (the kernels were bound by the latency of those gathers).
+constexpr int kStageCols = kBgBlock / 2 + 4;   // columns of a level with factor >= 2 under a 256-pixel run
+
+struct RowStage {
+  int c_lo[BDS_MAX_LEVELS];   // first staged low-res column of each level
+};
+
+template <int NL>
+__device__ __forceinline__ void stage_level_rows(const MsParams &p, int y, int xs, int xe, float4 (*sS)[kStageCols][3], RowStage &rs) {
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l >= p.nlevels) break;
+    const LevelDev &L = p.lv[l];
+    rs.c_lo[l] = 0;
+    if (L.Hd == p.H && L.Wd == p.W) continue;   // not up-sampled: read in place
+    const Tap ty = resample_tap(y, p.H, L.Hd);
+    const int c_lo = resample_tap(xs, p.W, L.Wd).i0, c_hi = resample_tap(xe - 1, p.W, L.Wd).i1;
+    rs.c_lo[l] = c_lo;
+    const int nitems = (c_hi - c_lo + 1) * 3;
+    const float4 *r0 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + c_lo) * 12);
+    const float4 *r1 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + c_lo) * 12);
+    const float wy = ty.w1, uy = 1.f - ty.w1;
+    for (int it = threadIdx.x; it < nitems; it += kBgBlock) {
+      const float4 a = r0[it], b = r1[it];
+      (&sS[l][0][0])[it] = make_float4(a.x * uy + b.x * wy, a.y * uy + b.y * wy, a.z * uy + b.z * wy, a.w * uy + b.w * wy);
+    }
+  }
+}
+
+// a level's 3x4 map at pixel (y, x) of the staged run
+__device__ __forceinline__ void staged_affine(const LevelDev &L, int H, int W, int y, int x, const float4 (*sSl)[3], int c_lo, float *A) {
+  if (L.Hd == H && L.Wd == W) {
+    const float4 *s = reinterpret_cast<const float4 *>(L.lo + ((int64_t)y * W + x) * 12);
+    const float4 a = s[0], b = s[1], c = s[2];
+    A[0] = a.x; A[1] = a.y; A[2] = a.z; A[3] = a.w; A[4] = b.x; A[5] = b.y; A[6] = b.z; A[7] = b.w;
+    A[8] = c.x; A[9] = c.y; A[10] = c.z; A[11] = c.w;
+    return;
+  }
+  const Tap tx = resample_tap(x, W, L.Wd);
+  const float4 *s0 = sSl[tx.i0 - c_lo], *s1 = sSl[tx.i1 - c_lo];
+  const float wx = tx.w1, ux = 1.f - tx.w1;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float4 a = s0[q], b = s1[q];
+    A[q * 4 + 0] = a.x * ux + b.x * wx;
+    A[q * 4 + 1] = a.y * ux + b.y * wx;
+    A[q * 4 + 2] = a.z * ux + b.z * wx;
+    A[q * 4 + 3] = a.w * ux + b.w * wx;
+  }
+}
+
+// Can the row staging hold every up-sampled level of this configuration?  (factor >= 2 always can.)
+static bool rows_stageable(const MsParams &p) {
+  for (int l = 0; l < p.nlevels; l++) {
+    if (p.lv[l].Hd == p.H && p.lv[l].Wd == p.W) continue;
+    if ((int64_t)p.lv[l].Wd * 2 > p.W) return false;
+  }
+  return true;
+}
+
 template <int NL>  // NL >= p.nlevels: bounds the static unrolling (registers) of the level loop
+__global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_rows_kernel(MsParams p, float *__restrict__ out, int nbx) {
+  __shared__ float4 sS[NL][kStageCols][3];
+  const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
+  const int xs = bx * kBgBlock, xe = min(p.W, xs + kBgBlock);
+  RowStage rs;
+  stage_level_rows<NL>(p, y, xs, xe, sS, rs);
+  __syncthreads();
+  const int x = xs + (int)threadIdx.x;
+  if (x >= xe) return;
+  const int64_t pix = (int64_t)y * p.W + x;
+  float r, g, b;
+  load_input(p, y, x, r, g, b);
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l < p.nlevels) {
+      float A[12];
+      staged_affine(p.lv[l], p.H, p.W, y, x, sS[l], rs.c_lo[l], A);
+      if (p.lv[l].aff_out) {
+        float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out + pix * 12);
+        d[0] = make_float4(A[0], A[1], A[2], A[3]);
+        d[1] = make_float4(A[4], A[5], A[6], A[7]);
+        d[2] = make_float4(A[8], A[9], A[10], A[11]);
+      }
+      apply_affine(A, r, g, b);
+    }
+  }
+  out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
+  if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
+}
+
+// the same without staging (levels finer than half resolution that are still up-sampled: not a configuration the reference uses)
+template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
@@ -254,11 +403,15 @@ template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
                                                                  float *__restrict__ v_in, int halo, int nbx) {
   __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
+  __shared__ float4 sS[NL][kStageCols][3];
   const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
   const int stride = kBgBlock - 2 * halo;
   const int own0 = bx * stride, own1 = min(p.W, own0 + stride);
   const int xs = own0 - halo;
   const int x = xs + (int)threadIdx.x;
+  RowStage rs;
+  stage_level_rows<NL>(p, y, max(xs, 0), min(p.W, xs + kBgBlock), sS, rs);
+  __syncthreads();
   if (x >= 0 && x < p.W) {
     const int64_t pix = (int64_t)y * p.W + x;
     const bool owner = x >= own0 && x < own1;
@@ -273,7 +426,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
           float *P = p.lv[l].P + pix * 3;
           P[0] = r; P[1] = g; P[2] = b;
         }
-        upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
+        staged_affine(p.lv[l], p.H, p.W, y, x, sS[l], rs.c_lo[l], A[l]);
         apply_affine(A[l], r, g, b);
       }
     }
@@ -385,16 +538,25 @@ __device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, in
 // that was 3x the cost of everything else in this kernel.)  Deterministic for the LDS path.
 template <bool kLds>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, LevelSched sc, float *__restrict__ v_in,
-                                                                float *__restrict__ partials, int dbg) {
+                                                                float *__restrict__ partials, int dbg, int lds_floats) {
   extern __shared__ __attribute__((aligned(16))) float lds_acc[];
   int local;
   const int k_entry = sched_find(sc, blockIdx.x, local);
   const int l = sc.level[k_entry];
   const LevelDev &L = p.lv[l];
-  const int gsz = 12 * L.gl * L.gy * L.gx;
+  const int vol = L.gl * L.gy * L.gx, gsz = 12 * vol;
   const int gtot = gsz * L.n_avg;
+  // small grids: a cell-major copy of the grid itself sits behind the accumulator (the guidance route samples it per pixel)
+  const bool cells = kLds && 2 * gtot <= lds_floats;
+  float *lds_cells = lds_acc + gtot;
   if (kLds) {
     for (int e = threadIdx.x; e < gtot; e += kBgBlock) lds_acc[e] = 0.f;
+    if (cells) {
+      for (int e = threadIdx.x; e < gtot; e += kBgBlock) {
+        const int n = e / gsz, r = e - n * gsz, ch = r / vol, cell = r - ch * vol;
+        lds_cells[(n * vol + cell) * 12 + ch] = L.grid[e];
+      }
+    }
     __syncthreads();
   }
   float *acc = kLds ? lds_acc : L.v_grid;
@@ -443,7 +605,8 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
     if (L.v_grid && !(dbg & 2)) slice_grid_scatter(acc + n * gsz, c, L.gx, L.gy, L.gl, inv_n, va, active);
     if (active && c.z_interior && !(dbg & 4)) {
       float a12[12], dz[12];
-      slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a12, dz);
+      if (cells) slice_dz_cells(reinterpret_cast<const float4 *>(lds_cells) + (int64_t)n * vol * 3, L.gx, L.gy, c, dz);
+      else slice_sample(L.grid + (int64_t)n * gsz, L.gx, L.gy, L.gl, c, a12, dz);
 #pragma unroll
       for (int ch = 0; ch < 12; ch++) v_iz += va[ch] * dz[ch] * inv_n;
     }
@@ -826,17 +989,41 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   p.cs = cs; p.depth_out = depth_out;
   hipStream_t st = as_stream(stream);
   {
-    LevelSched sc{};
-    sc.n = nlevels;
+    // levels whose grid fits the staging budget share one persistent launch (a workgroup stages the grid once and walks >= 4
+    // chunks of low-res pixels); larger grids (e.g. 16x16x8) keep the gather form, one workgroup per chunk
+    constexpr size_t kStageGridBytes = 32 * 1024;
+    LevelSched sl{}, sg{};
+    size_t lds_max = 0;
     for (int l = 0; l < nlevels; l++) {
-      sc.level[l] = l;
-      sc.nblk[l] = (int)cdiv((int64_t)p.lv[l].Hd * p.lv[l].Wd, kBgBlock);
-      sc.blk_off[l + 1] = sc.blk_off[l] + sc.nblk[l];
+      const size_t gbytes = sizeof(float) * 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
+      const int64_t chunks = cdiv((int64_t)p.lv[l].Hd * p.lv[l].Wd, kBgBlock);
+      LevelSched &s = gbytes <= kStageGridBytes ? sl : sg;
+      const int k = s.n++;
+      s.level[k] = l;
+      s.nblk[k] = (int)(gbytes <= kStageGridBytes ? (chunks + 3) / 4 : chunks);
+      if (s.nblk[k] < 1) s.nblk[k] = 1;
+      s.blk_off[k + 1] = s.blk_off[k] + s.nblk[k];
+      if (gbytes <= kStageGridBytes && gbytes > lds_max) lds_max = gbytes;
     }
-    hipLaunchKernelGGL(ms_lowres_fwd_kernel, dim3((unsigned)sc.blk_off[nlevels]), dim3(kBgBlock), 0, st, p, sc);
-    BDS_LAUNCH_CHECK();
+    if (sl.n > 0) {
+      hipLaunchKernelGGL((ms_lowres_fwd_kernel<true>), dim3((unsigned)sl.blk_off[sl.n]), dim3(kBgBlock), lds_max, st, p, sl);
+      BDS_LAUNCH_CHECK();
+    }
+    if (sg.n > 0) {
+      hipLaunchKernelGGL((ms_lowres_fwd_kernel<false>), dim3((unsigned)sg.blk_off[sg.n]), dim3(kBgBlock), 0, st, p, sg);
+      BDS_LAUNCH_CHECK();
+    }
   }
-  {
+  if (rows_stageable(p) && nlevels <= 4) {   // (more levels: the staging would not fit the static LDS budget)
+    const int nbx = (int)cdiv(W, kBgBlock);
+    const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
+    switch (nlevels) {
+      case 1: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<1>), grid, block, 0, st, p, rgb_out, nbx); break;
+      case 2: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<2>), grid, block, 0, st, p, rgb_out, nbx); break;
+      case 3: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<3>), grid, block, 0, st, p, rgb_out, nbx); break;
+      default: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<4>), grid, block, 0, st, p, rgb_out, nbx); break;
+    }
+  } else {
     const dim3 grid((unsigned)cdiv((int64_t)H * W, kBgBlock)), block(kBgBlock);
     switch (nlevels) {
       case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1>), grid, block, 0, st, p, rgb_out); break;
@@ -884,7 +1071,7 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     if (sc > smax) smax = sc;
   }
   const int halo = (int)ceilf(smax) + 2;
-  if (any_up && halo <= 48 && !(option_get(kOptDebug) & 8)) {
+  if (any_up && halo <= 48 && rows_stageable(p) && nlevels <= 4 && !(option_get(kOptDebug) & 8)) {
     const int stride = kBgBlock - 2 * halo;
     const int nbx = (int)cdiv(W, stride);
     const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
@@ -892,8 +1079,7 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
       case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
       case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
     }
     BDS_LAUNCH_CHECK();
   } else {
@@ -937,7 +1123,7 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
         LevelSched one{};
         one.n = 1; one.level[0] = l; one.nblk[0] = (int)need; one.blk_off[1] = (int)need;
         hipLaunchKernelGGL((ms_lowres_bwd_kernel<false>), dim3((unsigned)need), dim3(kBgBlock), 0, st, p, one, v_rgb, partials,
-                           option_get(kOptDebug));
+                           option_get(kOptDebug), 0);
         BDS_LAUNCH_CHECK();
         continue;
       }
@@ -955,13 +1141,20 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       red.n = sc.n;
     }
     if (sc.n > 0) {
-      if (lds_max > 48 * 1024) {
+      // room for the cell-major grid copies of the small levels (accumulator + copy <= 48 KiB) next to the largest accumulator
+      size_t lds_bytes = lds_max;
+      for (int k = 0; k < sc.n; k++) {
+        const LevelDev &Lk = p.lv[sc.level[k]];
+        const size_t gb = sizeof(float) * 12 * Lk.gl * Lk.gy * Lk.gx * Lk.n_avg;
+        if (2 * gb <= 48 * 1024 && 2 * gb > lds_bytes) lds_bytes = 2 * gb;
+      }
+      if (lds_bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ms_lowres_bwd_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
           return BDS_ELAUNCH;
       }
-      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_max, st, p, sc, v_rgb,
-                         partials, option_get(kOptDebug));
+      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_bytes, st, p, sc, v_rgb,
+                         partials, option_get(kOptDebug), (int)(lds_bytes / sizeof(float)));
       BDS_LAUNCH_CHECK();
       if (red.blk_off[red.n] > 0) {
         hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)red.blk_off[red.n]), dim3(kBgBlock), 0, st, p, sc, red,

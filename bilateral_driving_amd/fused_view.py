@@ -232,7 +232,7 @@ class _FusedView(torch.autograd.Function):
         # image's slice written (no slice-backward / scatter in the autograd graph)
         # ... or, with grad_arena["grid<i>"] and arena_rows >= 1, ADDED in place to the caller's accumulators (their .grad)
         arena_g = [(cfg.get("grad_arena") or {}).get(f"grid{i}") for i in range(len(grids))]
-        grids_in_place = (cfg.get("grad_sink") is None and int(cfg.get("arena_rows", 0)) >= 1 and any(need_g)
+        grids_in_place = (bool(cfg.get("grids_in_place")) and cfg.get("grad_sink") is None and any(need_g)
                           and all(a is not None and a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)))
         if grids_in_place:
             v_grids = [a if need_g[i] else None for i, a in enumerate(arena_g)]
@@ -346,6 +346,10 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows),
                list_tile=int(LIST_TILE if list_tile is None else list_tile))
     gs = [g if g.dim() == 5 else g[None] for g in grids]
+    # in-place grid gradients only when the arena entries ARE the grids' .grad right now (dist.FrameExchange.begin_frame sets that up)
+    if grad_arena is not None and int(arena_rows) >= 1 and grad_sink is None:
+        cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
+                                    and g.grad.data_ptr() == grad_arena[f"grid{i}"].data_ptr() for i, g in enumerate(gs))
     out = _FusedView.apply(cfg, params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], sky,
                            viewmat, *gs)
     rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ranks, isect_offsets, vis_ids = out

@@ -216,7 +216,8 @@ def test_rasterization_api_pose_gradient_and_fused_equivalence(ops):
     assert float((res[0] - res[1]).norm() / res[1].norm()) < 1e-3
 
 
-def test_frame_loop_world1_grids_accumulate_in_place(ops):
+@pytest.mark.parametrize("drop_grid_grads", [False, True], ids=["in_place", "caller_dropped_the_grid_grads"])
+def test_frame_loop_world1_grids_accumulate_in_place(ops, drop_grid_grads):
     """dist.FrameExchange at world size 1 (the bench's single-GPU loop): per-Gaussian rows through the arena modes, the grids'
     gradients (transform + TV term) ADDED in place to their .grad slices -- equals the sum of the views' separate gradients."""
     from bilateral_driving_amd import harness as Hn
@@ -241,14 +242,17 @@ def test_frame_loop_world1_grids_accumulate_in_place(ops):
     assert not fx.active and fx.tail_grads() is not None and len(fx.tail_grads()) == len(grids)
     for frame in range(2):
         fx.begin_frame()
+        if drop_grid_grads:          # e.g. an optimizer.zero_grad(set_to_none=True) after begin_frame: the in-place route must notice
+            for g in grids:
+                g.grad = None
         for v, cam in enumerate(cams):
             out = Hn.render_view(p, cam, grids, v, sky, **fx.view_kwargs(v))
             fx.begin_view(out["info"])
-            Hn.training_loss(out, target, grids, grid_grads=fx.tail_grads()).backward()
+            Hn.training_loss(out, target, grids, grid_grads=None if drop_grid_grads else fx.tail_grads()).backward()
             fx.end_view()
         fx.end_frame()
         for g, a in zip(grids, fx.tail_grads()):
-            assert g.grad is not None and g.grad.data_ptr() == a.data_ptr()
+            assert g.grad is not None and (drop_grid_grads or g.grad.data_ptr() == a.data_ptr())
         got = torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids])
         assert float((got - ref).norm() / ref.norm()) < 1e-4, frame
         gg, rg = got[-sum(g.numel() for g in grids):], ref[-sum(g.numel() for g in grids):]

@@ -48,8 +48,6 @@ def _run_frames(Hn, cams, base, grids0, sky, target, force, frames=2):
     outs = []
     for frame in range(frames):     # the second frame starts from the row-wise cleared buffer
         fx.begin_frame()
-        for g in grids:
-            g.grad = None
         for v, cam in enumerate(cams):
             out = Hn.render_view(p, cam, grids, v, sky, **fx.view_kwargs(v))
             fx.begin_view(out["info"])

@@ -52,8 +52,8 @@ def test_rasterization_api_tile_size_equals_oracle_with_that_tile_size(seed, N, 
     assert rel_err(rc.cpu()[..., 3][cov], rr.detach()[..., 3][cov]) < 1e-4
     for k, v in leaves.items():
         assert rel_err(gc[k].cpu(), v.grad) < 2e-4, (k, rel_err(gc[k].cpu(), v.grad))
-    # larger list tiles clip the splats later: the image moves a little, and only upwards in coverage
-    assert bool((ac >= a16 - 1e-6).all()) and rel_err(rc[..., :3], r16[..., :3]) < 0.05
+    # larger list tiles clip the splats later (at their own tile granularity): the image moves a little
+    assert rel_err(rc[..., :3], r16[..., :3]) < 0.05 and rel_err(ac, a16) < 0.05
 
 
 @pytest.mark.parametrize("W,H,N", [(320, 192, 4000), (200, 130, 1500)])
