@@ -218,6 +218,8 @@ def main():
     from bilateral_driving_amd.dist import FlatGradients, FrameExchange
 
     L.lib()  # fail loudly if libbds.so is missing
+    if os.environ.get("BDS_DEBUG_OPTION"):   # kernel A/B hooks (include/bds.h: option 3), measurement sessions only
+        L.set_option(3, int(os.environ["BDS_DEBUG_OPTION"]))
     wl = dict(WORKLOADS[args.workload])
     N = args.gaussians or wl["gaussians"]
     W, H = args.width or wl["width"], args.height or wl["height"]

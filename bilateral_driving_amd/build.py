@@ -18,6 +18,10 @@ LIB = os.path.join(HERE, "libbds.so")
 SOURCES = ["api.hip", "sh.hip", "project.hip", "tiles.hip", "rasterize.hip", "bilagrid.hip", "loss.hip", "optim.hip", "refine.hip", "envlight.hip", "colorcorrect.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast-honor-pragmas", "-Wall", "-Wno-unused-function"]
+# per-file additions.  bilagrid.hip: the SLP vectoriser pairs fp32 operations into v_pk_* instructions, which issue at half rate on
+# gfx950 (scripts/ubench/valu_rate.hip) and need register shuffles (v_mov) to line their operands up: net loss in kernels that
+# are bound by instruction issue (static counts: DESIGN.md section 4)
+EXTRA_FLAGS = {"bilagrid.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -45,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -28,9 +28,14 @@ struct LevelDev {
   float *vg;           // [Hd*Wd] gradient w.r.t. the low-res guidance (gray)  (bwd scratch)
   float *aff_out;      // optional [H*W,12]
   int gx, gy, gl, factor, n_avg, Hd, Wd;
+  // resampling scales as torch forms them, divided ONCE on the host: up = low / full (taps of the up-sampler), dn = full / low
+  float up_x, up_y, dn_x, dn_y;
+  float lin_x, lin_y;  // 1 / (Wd - 1), 1 / (Hd - 1): step of torch.linspace(0, 1, n) over the low-res columns / rows
+  uint32_t magic_wd;   // ceil(2^32 / Wd): row / column of a low-res index without an integer division (fast_divmod)
 };
 struct MsParams {
   int nlevels, H, W;
+  uint32_t magic_w;        // ceil(2^32 / W)
   int cs;                  // floats per pixel of `rgb` and of the returned colour gradient: 3, or 4 in the RGB+ED form
   const float *rgb, *alpha, *sky;
   float *depth_out;        // RGB+ED form: [H*W] expected depth = rgb[.,3] / max(alpha, 1e-10)
@@ -38,6 +43,16 @@ struct MsParams {
   const float *v_alpha_in; // RGB+ED form, backward: gradient arriving at alpha from the caller (may be null)
   LevelDev lv[BDS_MAX_LEVELS];
 };
+
+// n / d and n % d for n < 2^31, d < 2^31 from magic = ceil(2^32 / d): the estimate is exact or one too large (a 64-bit division
+// by a launch constant costs ~60 vector instructions per pixel in kernels that are bound by instruction issue)
+__device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t magic, int &q, int &r) {
+  uint32_t qq = d == 1u ? n : __umulhi(n, magic);
+  int rr = (int)(n - qq * d);
+  if (rr < 0) { qq--; rr += (int)d; }
+  q = (int)qq; r = rr;
+}
+static uint32_t divmod_magic(int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 // Several levels in ONE launch: workgroup ranges per level (the levels are independent, each alone
 // under-fills the chip, and a launch boundary costs ~1.5-2 us).
@@ -139,11 +154,12 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, Lev
   }
   const int64_t n_low = (int64_t)L.Hd * L.Wd;
   for (int64_t idx = (int64_t)local * kBgBlock + threadIdx.x; idx < n_low; idx += (int64_t)sc.nblk[k_entry] * kBgBlock) {
-    const int i = (int)(idx / L.Wd), j = (int)(idx - (int64_t)i * L.Wd);
-    const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
+    int i, j;
+    fast_divmod((uint32_t)idx, (uint32_t)L.Wd, L.magic_wd, i, j);
+    const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y), tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
     float r, g, b;
     lowres_colour(p, ty, tx, r, g, b);
-    const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
+    const Cell c = slice_cell(linspace01_s(j, L.Wd, L.lin_x), linspace01_s(i, L.Hd, L.lin_y), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] = 0.f;
@@ -175,7 +191,7 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
     A[8] = c.x; A[9] = c.y; A[10] = c.z; A[11] = c.w;
     return;
   }
-  const Tap ty = resample_tap(i, H, L.Hd), tx = resample_tap(j, W, L.Wd);
+  const Tap ty = resample_tap_s(i, H, L.Hd, L.up_y), tx = resample_tap_s(j, W, L.Wd, L.up_x);
   const float4 *s00 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + tx.i0) * 12);
   const float4 *s01 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + tx.i1) * 12);
   const float4 *s10 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + tx.i0) * 12);
@@ -192,106 +208,15 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
 }
 
 // ---- B: full-resolution compose --------------------------------------------------------------
-// Row staging of the up-sampler: a workgroup works on a run of pixels of ONE image row, so the y-interpolation of every level's
-// low-res maps is the same for all of them.  It is done once per low-res column the run touches, while the two source rows are
-// copied (coalesced float4 loads) into LDS; a pixel then only interpolates in x between two LDS entries: 6 LDS reads per level
-// instead of 12 dependent float4 gathers from L2 (the kernels were bound by the latency of those gathers).
-constexpr int kStageCols = kBgBlock / 2 + 4;   // columns of a level with factor >= 2 under a 256-pixel run
-
-struct RowStage {
-  int c_lo[BDS_MAX_LEVELS];   // first staged low-res column of each level
-};
-
-template <int NL>
-__device__ __forceinline__ void stage_level_rows(const MsParams &p, int y, int xs, int xe, float4 (*sS)[kStageCols][3], RowStage &rs) {
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l >= p.nlevels) break;
-    const LevelDev &L = p.lv[l];
-    rs.c_lo[l] = 0;
-    if (L.Hd == p.H && L.Wd == p.W) continue;   // not up-sampled: read in place
-    const Tap ty = resample_tap(y, p.H, L.Hd);
-    const int c_lo = resample_tap(xs, p.W, L.Wd).i0, c_hi = resample_tap(xe - 1, p.W, L.Wd).i1;
-    rs.c_lo[l] = c_lo;
-    const int nitems = (c_hi - c_lo + 1) * 3;
-    const float4 *r0 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + c_lo) * 12);
-    const float4 *r1 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + c_lo) * 12);
-    const float wy = ty.w1, uy = 1.f - ty.w1;
-    for (int it = threadIdx.x; it < nitems; it += kBgBlock) {
-      const float4 a = r0[it], b = r1[it];
-      (&sS[l][0][0])[it] = make_float4(a.x * uy + b.x * wy, a.y * uy + b.y * wy, a.z * uy + b.z * wy, a.w * uy + b.w * wy);
-    }
-  }
-}
-
-// a level's 3x4 map at pixel (y, x) of the staged run
-__device__ __forceinline__ void staged_affine(const LevelDev &L, int H, int W, int y, int x, const float4 (*sSl)[3], int c_lo, float *A) {
-  if (L.Hd == H && L.Wd == W) {
-    const float4 *s = reinterpret_cast<const float4 *>(L.lo + ((int64_t)y * W + x) * 12);
-    const float4 a = s[0], b = s[1], c = s[2];
-    A[0] = a.x; A[1] = a.y; A[2] = a.z; A[3] = a.w; A[4] = b.x; A[5] = b.y; A[6] = b.z; A[7] = b.w;
-    A[8] = c.x; A[9] = c.y; A[10] = c.z; A[11] = c.w;
-    return;
-  }
-  const Tap tx = resample_tap(x, W, L.Wd);
-  const float4 *s0 = sSl[tx.i0 - c_lo], *s1 = sSl[tx.i1 - c_lo];
-  const float wx = tx.w1, ux = 1.f - tx.w1;
-#pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const float4 a = s0[q], b = s1[q];
-    A[q * 4 + 0] = a.x * ux + b.x * wx;
-    A[q * 4 + 1] = a.y * ux + b.y * wx;
-    A[q * 4 + 2] = a.z * ux + b.z * wx;
-    A[q * 4 + 3] = a.w * ux + b.w * wx;
-  }
-}
-
-// Can the row staging hold every up-sampled level of this configuration?  (factor >= 2 always can.)
-static bool rows_stageable(const MsParams &p) {
-  for (int l = 0; l < p.nlevels; l++) {
-    if (p.lv[l].Hd == p.H && p.lv[l].Wd == p.W) continue;
-    if ((int64_t)p.lv[l].Wd * 2 > p.W) return false;
-  }
-  return true;
-}
-
+// (Measured and dropped, round 2: staging the y-interpolated low-res rows of a 256-pixel run in LDS so that a pixel reads 6 LDS
+// entries per level instead of 12 float4 gathers -- the staging prologue + barrier cost more than the gathers it removed:
+// forward 44 -> 48 us, backward x kernel 88 -> 111 us at 1080p.  The gathers overlap across waves; a per-workgroup prologue does not.)
 template <int NL>  // NL >= p.nlevels: bounds the static unrolling (registers) of the level loop
-__global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_rows_kernel(MsParams p, float *__restrict__ out, int nbx) {
-  __shared__ float4 sS[NL][kStageCols][3];
-  const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
-  const int xs = bx * kBgBlock, xe = min(p.W, xs + kBgBlock);
-  RowStage rs;
-  stage_level_rows<NL>(p, y, xs, xe, sS, rs);
-  __syncthreads();
-  const int x = xs + (int)threadIdx.x;
-  if (x >= xe) return;
-  const int64_t pix = (int64_t)y * p.W + x;
-  float r, g, b;
-  load_input(p, y, x, r, g, b);
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l < p.nlevels) {
-      float A[12];
-      staged_affine(p.lv[l], p.H, p.W, y, x, sS[l], rs.c_lo[l], A);
-      if (p.lv[l].aff_out) {
-        float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out + pix * 12);
-        d[0] = make_float4(A[0], A[1], A[2], A[3]);
-        d[1] = make_float4(A[4], A[5], A[6], A[7]);
-        d[2] = make_float4(A[8], A[9], A[10], A[11]);
-      }
-      apply_affine(A, r, g, b);
-    }
-  }
-  out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
-  if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
-}
-
-// the same without staging (levels finer than half resolution that are still up-sampled: not a configuration the reference uses)
-template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
-  const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
+  int i, j;
+  fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, i, j);
   float r, g, b;
   load_input(p, i, j, r, g, b);
 #pragma unroll
@@ -323,7 +248,8 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, cons
                                                                float *__restrict__ v_in) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
-  const int i = (int)(pix / p.W), j = (int)(pix - (int64_t)i * p.W);
+  int i, j;
+  fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, i, j);
   float r, g, b;
   load_input(p, i, j, r, g, b);
   float A[NL][12];   // each level's up-sampled 3x4 map, kept for the way back (one gather of the low-res taps, not two)
@@ -353,8 +279,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, cons
 
 // destination indices of a bilinear up-sample (size `full` from `low`) whose taps touch source cell c:
 // conservative [lo, hi] (every candidate is re-checked with resample_tap)
-__device__ __forceinline__ void adjoint_range(int c, int full, int low, int &lo, int &hi) {
-  const float s = (float)full / (float)low;
+__device__ __forceinline__ void adjoint_range(int c, int full, float s /* = (float)full / (float)low */, int &lo, int &hi) {
   lo = (int)floorf(((float)c - 0.5f) * s - 0.5f);
   hi = (int)ceilf(((float)c + 1.5f) * s - 0.5f);
   lo = lo < 0 ? 0 : lo;
@@ -368,15 +293,16 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
   const LevelDev &L = p.lv[l];
   const int64_t idx = (int64_t)local * kBgBlock + threadIdx.x;
   if (idx >= (int64_t)p.H * L.Wd) return;
-  const int y = (int)(idx / L.Wd), cx = (int)(idx - (int64_t)y * L.Wd);
+  int y, cx;
+  fast_divmod((uint32_t)idx, (uint32_t)L.Wd, L.magic_wd, y, cx);
   int xlo, xhi;
-  adjoint_range(cx, p.W, L.Wd, xlo, xhi);
+  adjoint_range(cx, p.W, L.dn_x, xlo, xhi);
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.f;
 #pragma unroll 4
   for (int x = xlo; x <= xhi; x++) {
-    const Tap tx = resample_tap(x, p.W, L.Wd);
+    const Tap tx = resample_tap_s(x, p.W, L.Wd, L.up_x);
     const float w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
     const int64_t o = ((int64_t)y * p.W + x) * 3;
     const float p0 = L.P[o], p1 = L.P[o + 1], p2 = L.P[o + 2];
@@ -403,15 +329,11 @@ template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
                                                                  float *__restrict__ v_in, int halo, int nbx) {
   __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
-  __shared__ float4 sS[NL][kStageCols][3];
   const int y = (int)blockIdx.x / nbx, bx = (int)blockIdx.x - y * nbx;
   const int stride = kBgBlock - 2 * halo;
   const int own0 = bx * stride, own1 = min(p.W, own0 + stride);
   const int xs = own0 - halo;
   const int x = xs + (int)threadIdx.x;
-  RowStage rs;
-  stage_level_rows<NL>(p, y, max(xs, 0), min(p.W, xs + kBgBlock), sS, rs);
-  __syncthreads();
   if (x >= 0 && x < p.W) {
     const int64_t pix = (int64_t)y * p.W + x;
     const bool owner = x >= own0 && x < own1;
@@ -426,7 +348,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
           float *P = p.lv[l].P + pix * 3;
           P[0] = r; P[1] = g; P[2] = b;
         }
-        staged_affine(p.lv[l], p.H, p.W, y, x, sS[l], rs.c_lo[l], A[l]);
+        upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
         apply_affine(A[l], r, g, b);
       }
     }
@@ -454,21 +376,21 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
     if (l >= p.nlevels) break;
     const LevelDev &L = p.lv[l];
     if (L.Wd == p.W && L.Hd == p.H) continue;
-    const float sc = (float)p.W / (float)L.Wd;
-    const int cx0 = max(0, (int)((float)own0 / sc) - 2);
-    const int ncand = (int)((float)stride / sc) + 5;
+    const float sc = L.dn_x;
+    const int cx0 = max(0, (int)((float)own0 * L.up_x) - 2);      // conservative window: every candidate's anchor is re-checked
+    const int ncand = (int)((float)stride * L.up_x) + 6;
     for (int t = threadIdx.x; t < ncand; t += kBgBlock) {
       const int cx = cx0 + t;
       if (cx >= L.Wd) continue;
       const int anchor = min(p.W - 1, (int)(((float)cx + 0.5f) * sc));
       if (anchor < own0 || anchor >= own0 + stride) continue;   // owned by a neighbour
       int xlo, xhi;
-      adjoint_range(cx, p.W, L.Wd, xlo, xhi);
+      adjoint_range(cx, p.W, L.dn_x, xlo, xhi);
       float acc[12];
 #pragma unroll
       for (int k = 0; k < 12; k++) acc[k] = 0.f;
       for (int xx = xlo; xx <= xhi; xx++) {
-        const Tap tx = resample_tap(xx, p.W, L.Wd);
+        const Tap tx = resample_tap_s(xx, p.W, L.Wd, L.up_x);
         const float w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
         const int k = xx - xs;   // inside the window by construction (halo >= scale + 2)
         const float p0 = sP[l][0][k], p1 = sP[l][1][k], p2 = sP[l][2][k];
@@ -564,7 +486,8 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
   for (int64_t base = (int64_t)local * kBgBlock; base < n_low; base += (int64_t)sc.nblk[k_entry] * kBgBlock) {
   const int64_t idx = base + threadIdx.x;
   const bool active = idx < n_low;
-  const int i = active ? (int)(idx / L.Wd) : 0, j = active ? (int)(idx - (int64_t)i * L.Wd) : 0;
+  int i = 0, j = 0;
+  if (active) fast_divmod((uint32_t)idx, (uint32_t)L.Wd, L.magic_wd, i, j);
   float va[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) va[k] = 0.f;
@@ -579,12 +502,12 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
       for (int k = 0; k < 12; k++) va[k] = 1.f;
     } else {  // y pass of the up-sampler adjoint over the x-reduced rows
       int ylo, yhi;
-      adjoint_range(i, p.H, L.Hd, ylo, yhi);
+      adjoint_range(i, p.H, L.dn_y, ylo, yhi);
       // no early-out on zero weights: the few extra rows of the conservative window cost less than the
       // serialised load -> test -> load chain they would otherwise create (the loop is latency-bound)
 #pragma unroll 4
       for (int y = ylo; y <= yhi; y++) {
-        const Tap ty = resample_tap(y, p.H, L.Hd);
+        const Tap ty = resample_tap_s(y, p.H, L.Hd, L.up_y);
         const float w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
         const float4 *sv = reinterpret_cast<const float4 *>(L.R + ((int64_t)y * L.Wd + j) * 12);
         const float4 a = sv[0], b = sv[1], c = sv[2];
@@ -595,10 +518,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
     }
   }
   // slice backward
-  const Tap ty = resample_tap(i, L.Hd, p.H), tx = resample_tap(j, L.Wd, p.W);
+  const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y), tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
   float r = 0.f, g = 0.f, b = 0.f;
   if (active) lowres_colour(p, ty, tx, r, g, b);
-  const Cell c = slice_cell(linspace01(j, L.Wd), linspace01(i, L.Hd), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
+  const Cell c = slice_cell(linspace01_s(j, L.Wd, L.lin_x), linspace01_s(i, L.Hd, L.lin_y), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
   const float inv_n = 1.f / (float)L.n_avg;
   float v_iz = 0.f;
   for (int n = 0; n < L.n_avg; n++) {
@@ -665,7 +588,8 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
                                                                         float *__restrict__ v_alpha, float *__restrict__ v_sky) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
-  const int y = (int)(pix / p.W), x = (int)(pix - (int64_t)y * p.W);
+  int y, x;
+  fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, y, x);
   float vg = 0.f;
 #pragma unroll
   for (int l = 0; l < NL; l++) {
@@ -673,14 +597,14 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
     const LevelDev &L = p.lv[l];
     if (L.Hd == p.H && L.Wd == p.W) { vg += L.vg[pix]; continue; }
     int ilo, ihi, jlo, jhi;
-    adjoint_range(y, L.Hd, p.H, ilo, ihi);
-    adjoint_range(x, L.Wd, p.W, jlo, jhi);
+    adjoint_range(y, L.Hd, L.up_y, ilo, ihi);
+    adjoint_range(x, L.Wd, L.up_x, jlo, jhi);
     for (int i = ilo; i <= ihi; i++) {
-      const Tap ty = resample_tap(i, L.Hd, p.H);
+      const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y);
       const float wy = (ty.i0 == y ? 1.f - ty.w1 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
       if (wy == 0.f) continue;
       for (int j = jlo; j <= jhi; j++) {
-        const Tap tx = resample_tap(j, L.Wd, p.W);
+        const Tap tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
         const float wx = (tx.i0 == x ? 1.f - tx.w1 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
         if (wx != 0.f) vg += wy * wx * L.vg[(int64_t)i * L.Wd + j];
       }
@@ -944,6 +868,7 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
                    const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *const *affine_out) {
   BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && lv && H > 0 && W > 0 && rgb && ws);
   BDS_REQUIRE((sky == nullptr) || (alpha != nullptr));
+  BDS_REQUIRE((int64_t)H * W < ((int64_t)1 << 31));   // pixel indices are split with 32-bit arithmetic (fast_divmod)
   const MsLayout L = ms_layout(nlevels, lv, H, W);
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   BDS_REQUIRE(aligned16(ws));
@@ -964,7 +889,12 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
     BDS_REQUIRE(d.aff_out == nullptr || aligned16(d.aff_out));
     d.gx = lv[l].gx; d.gy = lv[l].gy; d.gl = lv[l].gl; d.factor = lv[l].factor; d.n_avg = lv[l].n_avg;
     d.Hd = H / lv[l].factor; d.Wd = W / lv[l].factor;
+    d.up_x = (float)d.Wd / (float)W; d.up_y = (float)d.Hd / (float)H;
+    d.dn_x = (float)W / (float)d.Wd; d.dn_y = (float)H / (float)d.Hd;
+    d.lin_x = d.Wd > 1 ? 1.0f / (float)(d.Wd - 1) : 0.f; d.lin_y = d.Hd > 1 ? 1.0f / (float)(d.Hd - 1) : 0.f;
+    d.magic_wd = divmod_magic(d.Wd);
   }
+  p.magic_w = divmod_magic(W);
   return BDS_OK;
 }
 
@@ -1014,16 +944,7 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       BDS_LAUNCH_CHECK();
     }
   }
-  if (rows_stageable(p) && nlevels <= 4) {   // (more levels: the staging would not fit the static LDS budget)
-    const int nbx = (int)cdiv(W, kBgBlock);
-    const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
-    switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<1>), grid, block, 0, st, p, rgb_out, nbx); break;
-      case 2: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<2>), grid, block, 0, st, p, rgb_out, nbx); break;
-      case 3: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<3>), grid, block, 0, st, p, rgb_out, nbx); break;
-      default: hipLaunchKernelGGL((ms_apply_fwd_rows_kernel<4>), grid, block, 0, st, p, rgb_out, nbx); break;
-    }
-  } else {
+  {
     const dim3 grid((unsigned)cdiv((int64_t)H * W, kBgBlock)), block(kBgBlock);
     switch (nlevels) {
       case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1>), grid, block, 0, st, p, rgb_out); break;
@@ -1071,7 +992,7 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     if (sc > smax) smax = sc;
   }
   const int halo = (int)ceilf(smax) + 2;
-  if (any_up && halo <= 48 && rows_stageable(p) && nlevels <= 4 && !(option_get(kOptDebug) & 8)) {
+  if (any_up && halo <= 48 && !(option_get(kOptDebug) & 8)) {
     const int stride = kBgBlock - 2 * halo;
     const int nbx = (int)cdiv(W, stride);
     const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
@@ -1079,7 +1000,8 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
       case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
       case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
     }
     BDS_LAUNCH_CHECK();
   } else {

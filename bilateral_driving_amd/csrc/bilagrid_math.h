@@ -24,11 +24,12 @@ struct Tap {
   int i0, i1;
   float w1;
 };
-BDS_HD Tap resample_tap(int dst, int out_size, int in_size) {
+// `scale` = (float)in_size / (float)out_size, evaluated once by the caller (the host, for the kernels: an IEEE division costs a dozen
+// vector instructions per call and the sizes are launch constants; same value, same taps)
+BDS_HD Tap resample_tap_s(int dst, int out_size, int in_size, float scale) {
 #pragma clang fp contract(off)  // keep torch's (unfused) source-index arithmetic: floor() decisions depend on it
   Tap t;
   if (out_size == in_size) { t.i0 = t.i1 = dst; t.w1 = 0.f; return t; }
-  const float scale = (float)in_size / (float)out_size;
   float src = scale * ((float)dst + 0.5f) - 0.5f;
   src = src < 0.f ? 0.f : src;
   t.i0 = (int)src;
@@ -37,6 +38,9 @@ BDS_HD Tap resample_tap(int dst, int out_size, int in_size) {
   t.w1 = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
   return t;
 }
+BDS_HD Tap resample_tap(int dst, int out_size, int in_size) {
+  return resample_tap_s(dst, out_size, in_size, (float)in_size / (float)out_size);
+}
 
 // torch.linspace(0, 1, n)[i] in float32 (symmetric evaluation around the midpoint)
 BDS_HD float linspace01(int i, int n) {
@@ -44,6 +48,11 @@ BDS_HD float linspace01(int i, int n) {
   // (torch's scalar loop tail rounds twice: <= 1 ulp apart, only in the non-differentiated x/y).
   if (n <= 1) return 0.f;
   const float step = 1.0f / (float)(n - 1);
+  return i < n / 2 ? step * (float)i : fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+// the same with step = 1.0f / (float)(n - 1) divided once by the caller (0 for n <= 1)
+BDS_HD float linspace01_s(int i, int n, float step) {
+  if (n <= 1) return 0.f;
   return i < n / 2 ? step * (float)i : fmaf(-step, (float)(n - 1 - i), 1.0f);
 }
 

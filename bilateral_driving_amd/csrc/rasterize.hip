@@ -133,8 +133,11 @@ __device__ __forceinline__ void list_range(const int32_t *__restrict__ offsets, 
   end = (li == total - 1) ? (int)M : offsets[li + 1];
 }
 
+// min(0.999, ov) for ov >= 0 as ONE v_med3_f32 (fminf costs a canonicalising v_max in front of the v_min)
+__device__ __forceinline__ float clamp_alpha(float ov) { return __builtin_amdgcn_fmed3f(ov, kAlphaMax, -1.f); }
+
 // ---- forward ----------------------------------------------------------------------------------------------
-template <int CH, bool kCoarse>
+template <int CH, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, float *__restrict__ render,
@@ -206,21 +209,23 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       const int pos_t = kCoarse ? __float_as_int(Cc.z) : bstart + t;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
+        // branch-free per pixel (as the backward): a pixel that does not blend this Gaussian adds vis = 0 and keeps T, cur.
+        // (Exec-masked branches cost ~16 scalar instructions per pixel row here: the kernel was issuing 0.7 scalar per vector op.)
         const float e = splat_exponent(eadx2, ebdx, B.x, A.y - pyc[q]);
         const float ov = B.y * __builtin_amdgcn_exp2f(e);
-        const float alpha = fminf(kAlphaMax, ov);
-        const bool hit = T[q] > 0.f && !(e > 0.f || ov < kAlphaMin);
+        const float alpha = clamp_alpha(ov);
+        const bool hit = (T[q] > 0.f) & !((e > 0.f) | (ov < kAlphaMin));   // (bitwise: no short-circuit exec masking)
+        if (kStrip && !__any(hit)) continue;   // no pixel of this 16 x 4 strip blends the Gaussian
         const float nT = T[q] * (1.f - alpha);
-        if (hit && nT <= kTStop) T[q] = -T[q];
-        else if (hit) {
-          const float vis = alpha * T[q];
-          out[q][0] += B.z * vis;
-          if (CH > 1) out[q][1] += B.w * vis;
-          if (CH > 2) out[q][2] += Cc.x * vis;
-          if (CH > 3) out[q][3] += Cc.y * vis;
-          cur[q] = pos_t;
-          T[q] = nT;
-        }
+        const bool stop = hit & (nT <= kTStop);   // this Gaussian would take the pixel below the transmittance floor: finished, not blended
+        const bool blend = hit & !stop;
+        const float vis = blend ? alpha * T[q] : 0.f;
+        out[q][0] = __builtin_fmaf(B.z, vis, out[q][0]);
+        if (CH > 1) out[q][1] = __builtin_fmaf(B.w, vis, out[q][1]);
+        if (CH > 2) out[q][2] = __builtin_fmaf(Cc.x, vis, out[q][2]);
+        if (CH > 3) out[q][3] = __builtin_fmaf(Cc.y, vis, out[q][3]);
+        cur[q] = blend ? pos_t : cur[q];
+        T[q] = stop ? -T[q] : (blend ? nT : T[q]);
       }
     }
   }
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 // need only three per-lane moments of d(loss)/d(sigma) (S0 = sum vs, S1 = sum vs dy, S2 = sum vs dy^2) that are expanded
 // once per (lane, Gaussian); 12 per-lane sums then go through ONE 16-value transpose-reduce and 12 lanes commit them to the
 // Gaussian's gradient record.  The list is replayed back to front from the tile's deepest blended entry.
-template <int CH, bool ABS, bool kCoarse>
+template <int CH, bool ABS, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas,
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
         e[q] = splat_exponent(eadx2, ebdx, ec, A.y - pyc[q]);
         vis[q] = __builtin_amdgcn_exp2f(e[q]);
         ov[q] = opac * vis[q];
-        valid[q] = (gidx <= bin_final[q]) && !(e[q] > 0.f || ov[q] < kAlphaMin);
+        valid[q] = (gidx <= bin_final[q]) & !((e[q] > 0.f) | (ov[q] < kAlphaMin));
         any |= valid[q];
       }
       if (!__any(any)) continue;
@@ -365,9 +370,11 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
       float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, ax = 0.f, ay = 0.f, go = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
+        // q = one 16 x 4 strip of the tile: a strip none of whose pixels blends this Gaussian adds exact zeros (and T *= 1)
+        if (kStrip && !__any(valid[q])) continue;
         const float dy = A.y - pyc[q];
-        const float am = valid[q] ? fminf(kAlphaMax, ov[q]) : 0.f;
-        const float vm = (valid[q] && ov[q] <= kAlphaMax) ? vis[q] : 0.f;   // the 0.999 clamp passes no gradient
+        const float am = valid[q] ? clamp_alpha(ov[q]) : 0.f;
+        const float vm = (valid[q] & (ov[q] <= kAlphaMax)) ? vis[q] : 0.f;   // the 0.999 clamp passes no gradient
         const float ra = __builtin_amdgcn_rcpf(1.f - am);                   // exactly 1 for am = 0
         T[q] *= ra;
         const float fac = am * T[q];
@@ -522,9 +529,17 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-#define BDS_FWD(ch, co)                                                                                                           \
-  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
-                     isect_offsets, flatten, render, alphas, last_ids, lg)
+  const bool strip = (option_get(kOptDebug) & 16) != 0;
+  const size_t pad = (size_t)((option_get(kOptDebug) >> 8) & 0x3f) * 1024;   // measurement hook: LDS padding = occupancy throttle
+#define BDS_FWD(ch, co)                                                                                                               \
+  do {                                                                                                                                \
+    if (strip)                                                                                                                        \
+      hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), pad, st, C, M, rec, backgrounds, W, H, tile_w, \
+                         tile_h, isect_offsets, flatten, render, alphas, last_ids, lg);                                               \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, false>), grid, dim3(kWave), pad, st, C, M, rec, backgrounds, W, H, tile_w, \
+                         tile_h, isect_offsets, flatten, render, alphas, last_ids, lg);                                               \
+  } while (0)
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
@@ -556,9 +571,16 @@ extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, co
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
+  const bool strip = (option_get(kOptDebug) & 16) != 0;
 #define BDS_BWD(ch, ab, co)                                                                                                          \
-  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
-                     isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg)
+  do {                                                                                                                               \
+    if (strip)                                                                                                                       \
+      hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, true>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, \
+                         tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg);           \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, \
+                         tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg);           \
+  } while (0)
 #define BDS_BWD_CH(ab, co)            \
   do {                                \
     if (CH == 1) BDS_BWD(1, ab, co);  \
