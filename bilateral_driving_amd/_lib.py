@@ -38,6 +38,7 @@ _SIGS = {
     "bds_project_fwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f]),
     "bds_project_bwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_isect_prepare_workspace_bytes": (_sz, [_i, _i64]),
+    "bds_isect_visible_ids_offset": (_sz, [_i, _i64]),
     "bds_isect_build_workspace_bytes": (_sz, [_i, _i64, _i64]),
     "bds_isect_prepare": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i, _f]),
     "bds_isect_build": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _f, _f, _i, _f]),

@@ -251,9 +251,7 @@ extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, con
                                          float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
                                          float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(n_list >= 0 && W > 0 && H > 0);
-  if (v_viewmat_slots &&
-      hipMemsetAsync(v_viewmat_slots, 0, sizeof(float) * 16 * BDS_POSE_GRAD_SLOTS, as_stream(stream)) != hipSuccess)
-    return BDS_ELAUNCH;
+  // (v_viewmat_slots is ADDED to: the caller zero-fills it -- a memset node of 4 KB between two kernels costs ~15 us of idle GPU)
   if (n_list == 0) return BDS_OK;
   BDS_REQUIRE(ids && means && quats && scales && opacities && viewmat && K && v_records && aligned16(v_records) && v_means &&
               v_quats && v_log_scales && v_logits);

@@ -993,6 +993,13 @@ static BuildWs build_layout(void *ws, int64_t M) {
 
 using namespace bds;
 
+extern "C" size_t bds_isect_visible_ids_offset(int C, int64_t N) {
+  if (C < 1 || N < 0) return 0;
+  char *const base = reinterpret_cast<char *>(static_cast<uintptr_t>(4096));   // layout arithmetic only, never dereferenced
+  const PrepWs L = prep_layout(base, (int64_t)C * N);
+  return static_cast<size_t>(reinterpret_cast<char *>(L.asc) - base);
+}
+
 extern "C" size_t bds_isect_prepare_workspace_bytes(int C, int64_t N) {
   if (C < 1 || N < 0) return 0;
   return prep_layout(nullptr, (int64_t)C * N).bytes;

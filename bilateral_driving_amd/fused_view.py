@@ -137,15 +137,17 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
         ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
         ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
     flatten = buf[:M]                                  # per-tile lists of COMPACT positions (they address the records below)
-    vis_ids = _empty((n_vis,), dev, torch.int32)       # ascending ids of the visible Gaussians: compact position -> id, the
-    #                                                    work list of everything downstream (walks memory in order)
+    # ascending ids of the visible Gaussians: compact position -> id, the work list of everything downstream (walks memory in
+    # order).  Read in place from the prepare workspace (which this view keeps alive): no copy node between the kernels.
+    off = lib.bds_isect_visible_ids_offset(1, N)
+    vis_ids = ws[off:off + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
         L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th, L.ptr(ws),
-                                    ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), L.ptr(vis_ids), 1, st),
+                                    ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), None, 1, st),
                 "bds_isect_build")
     if M + M // 16 > cap:
         _LIST_CAPACITY[key] = M + M // 6 + 4096
-    del ws, ws2, buf
+    del ws2, buf
     f = _Front()
     f.means, f.quats, f.log_scales, f.sh, f.viewmat = means, quats, log_scales, sh, viewmat
     f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
@@ -257,7 +259,10 @@ class _FusedView(torch.autograd.Function):
                                                L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
                                                L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
         # compositing: gradient records of the visible Gaussians, in the order of vis_ids (64 bytes each)
-        v_rec = torch.zeros(max(n_vis, 1), L.GRAD_RECORD_FLOATS, device=dev, dtype=torch.float32)
+        # (+ the camera-pose gradient slots of the projection backward behind them: one zero fill for both)
+        want_pose = bool(ctx.needs_input_grad[7])
+        v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev, dtype=torch.float32)
+        v_rec = v_rec_all[:max(n_vis, 1)]
         LT = ctx.list_tile
         order = ops.bwd_schedule(1, W, H, LT, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
@@ -296,7 +301,7 @@ class _FusedView(torch.autograd.Function):
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
-        v_vm_slots = _empty((L.POSE_GRAD_SLOTS, 4, 4), dev) if ctx.needs_input_grad[7] else None   # camera-pose gradient (base.py:328-329,399)
+        v_vm_slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS, 4, 4) if want_pose else None   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
             L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
                                                   L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
@@ -395,3 +400,98 @@ def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width:
         assert m.shape == (f.N,), (name, tuple(m.shape), f.N)
         out[name + "_rgb"], out[name + "_depth"], out[name + "_opacity"] = image(f.opac * m.to(f.opac.dtype))
     return out
+
+
+class _DirectCtx:
+    """Stands in for the autograd context when the forward / backward bodies of a Function are called directly (train_view)."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+_ONES: Dict[torch.device, Tensor] = {}
+
+
+def _accumulate(p: Tensor, g: Optional[Tensor]) -> None:
+    """What autograd's AccumulateGrad does for a leaf: adopt, or add unless the producer already wrote into ``p.grad`` itself."""
+    if g is None or not p.requires_grad:
+        return
+    if p.grad is None:
+        p.grad = g
+    elif p.grad.data_ptr() != g.data_ptr():
+        p.grad.add_(g)
+
+
+def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor], sky: Tensor,
+               factors: Sequence[int], target: Tensor, tv_weights: Sequence[float], img_idx: Optional[int] = None,
+               grid_grads: Optional[Sequence[Tensor]] = None, after_forward=None, **kwargs):
+    """One training view WITHOUT an autograd graph: the forward of ``fused_view``, the L1 + per-level TV loss of
+    ``losses.photometric_tv_loss`` and both backward passes run back to back on the calling thread -- the same kernels in the same
+    order as ``loss = photometric_tv_loss(fused_view(...)["rgb"], target, grids, tv_weights); loss.backward()``, minus the hand-over
+    to autograd's device thread (~50 us of idle GPU per view at 1080p) and its bookkeeping.  Gradients land where autograd would put
+    them: per-Gaussian rows in ``grad_arena`` (``arena_rows``) or in ``param.grad``; the grids' in ``grid_grads`` / ``.grad``;
+    ``sky.grad``, ``viewmat.grad`` accumulated.  Accepts the keyword arguments of ``fused_view``; ``after_forward(info)`` is called
+    between the forward and the backward pass (``dist.FrameExchange.begin_view`` starts its visibility exchange there).
+    Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
+    from .losses import _PhotometricTV
+    cam_pos = kwargs.pop("cam_pos", None)
+    if cam_pos is None:
+        cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
+    grad_arena, arena_rows = kwargs.pop("grad_arena", None), int(kwargs.pop("arena_rows", 0))
+    grad_sink = kwargs.pop("grad_sink", None)
+    list_tile = kwargs.pop("list_tile", None)
+    opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
+    opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
+    assert not kwargs, f"unknown arguments {sorted(kwargs)}"
+    cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), factors=tuple(int(f) for f in factors),
+               sh_degree=int(opts["sh_degree"]), near_plane=float(opts["near_plane"]), far_plane=float(opts["far_plane"]),
+               radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
+               grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
+               list_tile=int(LIST_TILE if list_tile is None else list_tile))
+    gs = [g if g.dim() == 5 else g[None] for g in grids]
+    if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
+        cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
+                                    and g.grad.data_ptr() == grad_arena[f"grid{i}"].data_ptr() for i, g in enumerate(gs))
+    names = ("means", "quats", "log_scales", "opacity_logits", "sh")
+    leaves = [params[k] for k in names]
+    with torch.no_grad():
+        needs = (False, *[bool(t.requires_grad) for t in leaves], bool(sky.requires_grad), bool(viewmat.requires_grad),
+                 *[bool(g.requires_grad) for g in gs])
+        ctx = _DirectCtx(needs)
+        (rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ranks, isect_offsets,
+         vis_ids) = _FusedView.forward(ctx, cfg, *leaves, sky, viewmat, *gs)
+        cfg["_means2d_ref"] = weakref.ref(means2d)
+        info = _Info({"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
+                      "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets,
+                      "tile_size": cfg["list_tile"], "n_cameras": 1, "n_isects": int(flatten_ranks.numel()),
+                      "n_visible": int(vis_ids.numel())})
+        if after_forward is not None:
+            after_forward(info)
+        # loss: forward, then its backward with d(loss) = 1
+        lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
+        gg = None if grid_grads is None else list(grid_grads)
+        loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
+        one = _ONES.get(rgb.device)
+        if one is None:
+            one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
+        lg = _PhotometricTV.backward(lctx, one)
+        v_rgb, v_tv_grids = lg[0], lg[4:]
+        grads = _FusedView.backward(ctx, v_rgb, None, None, None, None)
+        for p, g in zip(leaves, grads[1:6]):
+            _accumulate(p, g)
+        _accumulate(sky, grads[6])
+        _accumulate(viewmat, grads[7])
+        for g, a, b in zip(gs, v_tv_grids, grads[8:]):
+            _accumulate(g, a)
+            _accumulate(g, b)
+    return _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)

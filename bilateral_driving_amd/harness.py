@@ -99,6 +99,16 @@ def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor],
                       grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink, list_tile=list_tile)
 
 
+def train_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor, target: Tensor,
+               factors: Sequence[int] = FACTORS_3, tv_weight: float = 0.01, grid_grads=None, after_forward=None, **kw):
+    """render_view + training_loss + backward of one view without an autograd graph (fused_view.train_view): same kernels, same
+    gradients in the same places; returns dict(loss, rgb, depth, opacity, info)."""
+    from .fused_view import train_view as _tv
+    level_w = [0.5 * math.sqrt(g.shape[4] * g.shape[3] * g.shape[2]) for g in grids]  # modules.py:445
+    return _tv(params, cam.viewmat, cam.K, cam.width, cam.height, grids, sky, factors, target, [tv_weight * w for w in level_w],
+               img_idx=img_idx, grid_grads=grid_grads, after_forward=after_forward, cam_pos=cam.cam_pos, tile_cull=TILE_CULL, **kw)
+
+
 def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
                        factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                        radius_clip: float = 0.0, eps2d: float = 0.3):

@@ -94,6 +94,9 @@ int bds_project_bwd(int C, int64_t N, const float *means, const float *quats, co
  * `ws` (bds_isect_prepare_workspace_bytes) must stay alive and untouched between the two calls;
  * `ws2` (bds_isect_build_workspace_bytes) is scratch for build.  M must be < 2^31. */
 size_t bds_isect_prepare_workspace_bytes(int C, int64_t N);
+/* Byte offset, inside the prepare workspace, of the ascending id list of the visible entries (int32 [n_visible], compact mode):
+ * a caller that keeps `ws` alive reads the list in place and passes visible_ids = NULL to bds_isect_build (no copy). */
+size_t bds_isect_visible_ids_offset(int C, int64_t N);
 size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M);
 /* conics [C,N,3] + opacities [C,N] (both or neither): when given, (tile, Gaussian) pairs in which no
  * pixel centre can reach alpha >= 1/255 are dropped ("exact tile culling"): rendered images and
@@ -269,8 +272,8 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
  *   project_view_bwd_list: v_means [N,3] v_quats [N,4] v_log_scales [N,3] v_logits [N] rows; optionally (may be NULL)
  *       grad2d / absgrad2d [N,2]: the screen-space gradient and the sum over pixels of its absolute value scattered to the
  *       dense arrays models/trainers/base.py:280-297 reads (rows of culled Gaussians untouched);
- *       v_viewmat_slots [BDS_POSE_GRAD_SLOTS,4,4]: camera-pose gradient partials (zero-filled inside; the sum over the slots is
- *       d(loss)/d(viewmat), models/trainers/base.py:328-329,399).
+ *       v_viewmat_slots [BDS_POSE_GRAD_SLOTS,4,4]: camera-pose gradient partials, ADDED to (the caller zero-fills them, e.g. as the
+ *       tail of the gradient-record allocation); the sum over the slots is d(loss)/d(viewmat), models/trainers/base.py:328-329,399.
  * row_map (may be NULL) [N] i32: the parameter-gradient row of Gaussian g is row_map[g] instead of g -- the rows then land in a
  * compact exchange buffer (multi-GPU: the slot of g in the union of the ranks' visible sets) instead of the dense arrays. */
 #define BDS_POSE_GRAD_SLOTS 64

@@ -257,3 +257,62 @@ def test_frame_loop_world1_grids_accumulate_in_place(ops, drop_grid_grads):
         assert float((got - ref).norm() / ref.norm()) < 1e-4, frame
         gg, rg = got[-sum(g.numel() for g in grids):], ref[-sum(g.numel() for g in grids):]
         assert float((gg - rg).norm() / rg.norm()) < 1e-4, frame
+
+
+def test_train_view_direct_path_equals_autograd_path(ops):
+    """harness.train_view (forward + loss + both backward passes without an autograd graph) leaves the same loss, images and
+    gradients, in the same places, as render_view -> training_loss -> backward()."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    dev = "cuda"
+    W, H, N = 256, 160, 5000
+    cams = Hn.ring_cameras(W, H, yaws_deg=(0.0, 120.0), device=dev)
+    base = Hn.synthetic_scene(N, seed=8, device=dev)
+    grids0 = Hn.make_grids(len(cams), device=dev)
+    sky0, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
+    res = {}
+    for mode in ("autograd", "direct", "direct_plain"):
+        p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        sky = sky0.clone().requires_grad_(True)
+        for cam in cams:
+            cam.viewmat.grad = None
+            cam.viewmat.requires_grad_(True)
+        losses, absg = [], []
+        if mode == "direct_plain":            # no arena at all: gradients are adopted / added as autograd would
+            for v, cam in enumerate(cams):
+                out = Hn.train_view(p, cam, grids, v, sky, target)
+                losses.append(float(out["loss"]))
+                absg.append(out["info"]["means2d"].absgrad.clone())
+        else:
+            flat = FlatGradients(list(p.values()) + grids, sparse_rows=True)
+            fx = FrameExchange(flat, list(p.keys()) + [f"grid{i}" for i in range(len(grids))])
+            fx.begin_frame()
+            for v, cam in enumerate(cams):
+                if mode == "autograd":
+                    out = Hn.render_view(p, cam, grids, v, sky, **fx.view_kwargs(v))
+                    fx.begin_view(out["info"])
+                    loss = Hn.training_loss(out, target, grids, grid_grads=fx.tail_grads())
+                    loss.backward()
+                else:
+                    out = Hn.train_view(p, cam, grids, v, sky, target, grid_grads=fx.tail_grads(), after_forward=fx.begin_view,
+                                        **fx.view_kwargs(v))
+                    loss = out["loss"]
+                    assert not out["rgb"].requires_grad and out["rgb"].grad_fn is None
+                fx.end_view()
+                losses.append(float(loss))
+                absg.append(out["info"]["means2d"].absgrad.clone())
+            fx.end_frame()
+        res[mode] = (losses, torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids]).clone(), sky.grad.clone(),
+                     [c.viewmat.grad.clone() for c in cams], absg, out["rgb"].detach().clone())
+    a = res["autograd"]
+    for mode in ("direct", "direct_plain"):
+        b = res[mode]
+        assert a[0] == b[0], (a[0], b[0])                                   # same kernels, same order: the losses are bit-equal
+        assert torch.equal(a[5], b[5])
+        assert float((a[1] - b[1]).norm() / a[1].norm()) < 2e-5             # atomics: summation order only
+        assert float((a[2] - b[2]).norm() / a[2].norm()) < 1e-6
+        for x, y in zip(a[3], b[3]):
+            assert float((x - y).norm() / x.norm()) < 1e-4
+        for x, y in zip(a[4], b[4]):
+            assert float((x - y).norm() / x.norm()) < 2e-5
