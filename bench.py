@@ -67,9 +67,10 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=170.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--autograd", action="store_true",
-                    help="run each view as forward / loss / loss.backward() through torch autograd (the reference-shaped step) instead of "
-                         "harness.train_view, which calls the same kernels back to back without an autograd graph")
+    ap.add_argument("--direct", action="store_true",
+                    help="drive each view through harness.train_view (the same kernels called back to back without an autograd graph) "
+                         "instead of forward / loss / loss.backward() through torch autograd, the reference-shaped step (default); "
+                         "measured equal on MI355X: the host runs ahead of the GPU either way")
     ap.add_argument("--dense-grads", action="store_true",
                     help="N = 1 only: fresh dense gradient tensors per view (zero fill of all N rows, autograd accumulation) instead of "
                          "the flat gradient buffer whose rows are cleared / written through the visible-id lists")
@@ -266,7 +267,7 @@ def main():
             skies[v].grad = None
             cams[v].viewmat.grad = None
             kw = {} if dense else fx.view_kwargs(v)
-            if args.autograd:   # the reference-shaped step: forward, loss, loss.backward() through autograd
+            if not args.direct:   # the reference-shaped step: forward, loss, loss.backward() through autograd
                 out = Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, **kw)
                 if not dense:
                     fx.begin_view(out["info"])
@@ -381,7 +382,7 @@ def main():
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
-                   "step_driver": "autograd (forward, loss, loss.backward())" if args.autograd else "direct (harness.train_view: same kernels, no autograd graph)",
+                   "step_driver": "direct (harness.train_view: same kernels, no autograd graph)" if args.direct else "autograd (forward, loss, loss.backward())",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
                    "exchanges_per_step": fx.n_exchanges if world > 1 else 0},
