@@ -458,7 +458,7 @@ __device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, in
 // gradient in LDS and writes ONE partial grid; a tiny second kernel sums the partials.  (Flushing
 // with atomics from thousands of short workgroups serialises on the few-thousand grid addresses in L2:
 // that was 3x the cost of everything else in this kernel.)  Deterministic for the LDS path.
-template <bool kLds>
+template <bool kLds, int kUnroll = 4>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, LevelSched sc, float *__restrict__ v_in,
                                                                 float *__restrict__ partials, int dbg, int lds_floats) {
   extern __shared__ __attribute__((aligned(16))) float lds_acc[];
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
       adjoint_range(i, p.H, L.dn_y, ylo, yhi);
       // no early-out on zero weights: the few extra rows of the conservative window cost less than the
       // serialised load -> test -> load chain they would otherwise create (the loop is latency-bound)
-#pragma unroll 4
+#pragma unroll kUnroll
       for (int y = ylo; y <= yhi; y++) {
         const Tap ty = resample_tap_s(y, p.H, L.Hd, L.up_y);
         const float w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
@@ -1075,8 +1075,12 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
           return BDS_ELAUNCH;
       }
-      hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_bytes, st, p, sc, v_rgb,
-                         partials, option_get(kOptDebug), (int)(lds_bytes / sizeof(float)));
+      if (option_get(kOptDebug) & 32)
+        hipLaunchKernelGGL((ms_lowres_bwd_kernel<true, 2>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_bytes, st, p, sc, v_rgb,
+                           partials, option_get(kOptDebug), (int)(lds_bytes / sizeof(float)));
+      else
+        hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_bytes, st, p, sc, v_rgb,
+                           partials, option_get(kOptDebug), (int)(lds_bytes / sizeof(float)));
       BDS_LAUNCH_CHECK();
       if (red.blk_off[red.n] > 0) {
         hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)red.blk_off[red.n]), dim3(kBgBlock), 0, st, p, sc, red,

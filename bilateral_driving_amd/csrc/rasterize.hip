@@ -199,8 +199,8 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       pA = rec[r * 3]; pB = rec[r * 3 + 1];
       if (CH > 2 || kCoarse) pC = rec[r * 3 + 2];
     }
-    for (int t = 0; t < bs; t++) {
-      if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
+    // one staged entry against the lane's four pixels
+    auto blend_entry = [&](int t) {
       const float4 A = sA[t], B = sB[t];
       const float dx = A.x - px;
       const float ebdx = A.w * dx, eadx2 = A.z * dx * dx;
@@ -227,6 +227,12 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
         cur[q] = blend ? pos_t : cur[q];
         T[q] = stop ? -T[q] : (blend ? nT : T[q]);
       }
+    };
+    // the all-pixels-finished test runs every second entry: an entry blended against a finished tile changes nothing
+    for (int t = 0; t < bs; t += 2) {
+      if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
+      blend_entry(t);
+      if (t + 1 < bs) blend_entry(t + 1);
     }
   }
 #pragma unroll

@@ -787,7 +787,8 @@ __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t 
         }
         if (ok) nrows = (uint32_t)(y1 - y0);
       }
-      const uint32_t cam_base = (uint32_t)((int64_t)o / N) * (uint32_t)(tile_w * tile_h);
+      // camera of entry o = o / N: entries of the first camera (the only one on the per-view path) need no division
+      const uint32_t cam_base = (int64_t)o < N ? 0u : (uint32_t)((uint32_t)o / (uint32_t)N) * (uint32_t)(tile_w * tile_h);
       S.mx[t] = mx; S.my[t] = my; S.a[t] = a; S.b[t] = b; S.c[t] = c; S.qmax[t] = q_max;
       S.x0[t] = x0; S.x1[t] = x1; S.y0[t] = y0; S.id[t] = val; S.cam_base[t] = cam_base;
       if (rec_out != nullptr) {
