@@ -515,12 +515,13 @@ static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int s
 }
 
 // ------------------------------------------------------------------------------------------
-// short sort: the same stable LSD pass in TWO launches, for inputs whose length lives on the device
+// short sort: the same stable LSD pass in ONE launch, for inputs whose length lives on the device
 // ------------------------------------------------------------------------------------------
 // The depth sort of the visible entries is latency-bound (a few hundred thousand keys: every launch costs more
 // than the bytes it moves), so the scan of the [digit][workgroup] histogram is folded away: histograms are stored
-// workgroup-major, every 32 workgroups also add theirs to a group row (256 atomics per workgroup), and a scatter
-// workgroup derives its own bases from <= ng group rows + <= 31 workgroup rows (all L2-resident).
+// workgroup-major next to one group row per 64 workgroups, a scatter workgroup derives its own bases from <= ng group rows +
+// <= 63 workgroup rows (all L2-resident), and the histogram of the NEXT digit is accumulated per output chunk while the pairs
+// are placed (the first one by the compaction kernel): 4 launches for the 4 passes.
 // Chunks of 1024 pairs (4 rounds per wave): a few hundred thousand keys then spread over > 256 workgroups.
 constexpr int kGroupShift = 6;                      // 64 workgroups per group row
 constexpr int kShortRounds = 4;
@@ -529,32 +530,13 @@ constexpr int kChunkShift = 10;
 static_assert(kShortChunk == (1 << kChunkShift), "chunk shift");
 constexpr int64_t kShortSortMax = (int64_t)kShortChunk * 8192;   // <= 128 group rows
 
-__global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *__restrict__ keys,
-                                                               const uint64_t *__restrict__ n_dev, int shift,
-                                                               uint32_t *__restrict__ hist /*[nblocks][256]*/,
-                                                               uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
-  __shared__ uint32_t h[256];
-  const int64_t n = (int64_t)*n_dev;
-  const int64_t base = (int64_t)blockIdx.x * kShortChunk;
-  if (base >= n) return;  // the launch is sized for the host-side bound
-  h[threadIdx.x] = 0;
-  __syncthreads();
-#pragma unroll 4
-  for (int r = 0; r < kShortRounds; r++) {
-    const int64_t i = base + r * kSortBlock + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  const uint32_t c = h[threadIdx.x];
-  hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
-  if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kGroupShift) * 256 + threadIdx.x], c);
-}
-
 // wave-private ranking as in radix_scatter_lds_kernel; bases from the group / workgroup rows
+// hist_next / ghist_next (null on the last pass): the histogram of the NEXT digit per OUTPUT chunk, accumulated while the pairs are
+// placed (one launch per pass instead of two; the tables are zeroed up front by visible_reduce_kernel)
 __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
+    uint32_t *__restrict__ vals_out, uint32_t *__restrict__ hist_next, uint32_t *__restrict__ ghist_next) {
   const int64_t n = (int64_t)*n_dev;
   if ((int64_t)blockIdx.x * kShortChunk >= n) return;
   __shared__ uint32_t wrun[kSortWaves][256];
@@ -617,16 +599,22 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);
     __builtin_amdgcn_wave_barrier();
     if (on) {
-      keys_out[pos + rank] = k[r];
-      vals_out[pos + rank] = v[r];
+      const uint32_t dst = pos + rank;
+      keys_out[dst] = k[r];
+      vals_out[dst] = v[r];
+      if (hist_next) {
+        const uint32_t nd = (k[r] >> (shift + 8)) & 255u, chunk = dst >> kChunkShift;
+        atomicAdd(&hist_next[(int64_t)chunk * 256 + nd], 1u);
+        atomicAdd(&ghist_next[(int64_t)(chunk >> kGroupShift) * 256 + nd], 1u);
+      }
     }
   }
 }
 
-// uint32 elements: one workgroup-major histogram + four zero-initialised group tables
+// uint32 elements: per pass one workgroup-major histogram + one group table, all zero-initialised
 static size_t short_sort_elems(int64_t n_bound) {
   const int64_t nb = cdiv(n_bound > 0 ? n_bound : 1, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
-  return (size_t)(nb + 4 * ng) * 256;
+  return (size_t)(4 * nb + 4 * ng) * 256;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -663,7 +651,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, 
 __global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, const int32_t *__restrict__ radii,
                                                                    uint32_t *__restrict__ tile_sums,
                                                                    uint32_t *__restrict__ zero_me, int64_t zero_elems,
-                                                                   uint64_t *__restrict__ m_total) {
+                                                                   uint64_t *__restrict__ m_total, int32_t *__restrict__ zero_cn) {
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   if (blockIdx.x == 0 && threadIdx.x == 0) *m_total = 0;   // M is accumulated by the counting kernels
   for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < zero_elems; i += (int64_t)gridDim.x * kScanBlock)
@@ -671,8 +659,12 @@ __global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, 
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   uint32_t s = 0;
 #pragma unroll
-  for (int i = 0; i < kScanItems; i++)
-    if (base + i < CN) s += radii[base + i] > 0 ? 1u : 0u;
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < CN) {
+      s += radii[base + i] > 0 ? 1u : 0u;
+      if (zero_cn) zero_cn[base + i] = 0;   // tiles_per_gauss: the counting kernel writes the visible entries only
+    }
+  }
   uint32_t tot;
   block_excl_scan(s, tot, lw);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
@@ -1034,28 +1026,27 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
   if (CN <= kShortSortMax && option_get(kOptShortSort)) {
     // 12 launches instead of 27: the whole stage is launch-latency bound at this size
     const int64_t nb = cdiv(CN, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
-    uint32_t *hist = L.tables, *ghist = L.tables + nb * 256;   // ghist[p] = ghist + p * ng * 256
+    uint32_t *hist = L.tables, *ghist = L.tables + 4 * nb * 256;   // hist[p] = hist + p * nb * 256, ghist[p] = ghist + p * ng * 256
     const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
     // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
     hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
-                       (int64_t)short_sort_elems(CN), L.total);
+                       (int64_t)short_sort_elems(CN), L.total, tiles_per_gauss);
     hipLaunchKernelGGL(visible_compact_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, depths, L.temp, L.ka, L.va, hist,
                        ghist, n_vis, L.asc, compact);
     BDS_LAUNCH_CHECK();
     // 2. depth order: 4 stable passes of 8 bits; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
     for (int p = 0; p < 4; p++) {
-      uint32_t *gh = ghist + (int64_t)p * ng * 256;
-      if (p > 0) hipLaunchKernelGGL(short_hist_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, n_vis, 8 * p, hist, gh);
-      hipLaunchKernelGGL(short_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, vin, n_vis, 8 * p, hist, gh, kout,
-                         vout);
+      uint32_t *hp = hist + (int64_t)p * nb * 256, *gh = ghist + (int64_t)p * ng * 256;
+      uint32_t *hn = p < 3 ? hist + (int64_t)(p + 1) * nb * 256 : nullptr, *gn = p < 3 ? ghist + (int64_t)(p + 1) * ng * 256 : nullptr;
+      hipLaunchKernelGGL(short_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, vin, n_vis, 8 * p, hp, gh, kout,
+                         vout, hn, gn);
       uint32_t *t;
       t = kin; kin = kout; kout = t;
       t = vin; vin = vout; vout = t;
     }
     BDS_LAUNCH_CHECK();
-    // 3. tiles per entry, in depth order
-    if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
+    // 3. tiles per entry, in depth order (tiles_per_gauss was zeroed by visible_reduce_kernel)
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
                        compact ? L.asc : (const uint32_t *)nullptr);
@@ -1078,8 +1069,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
       t = kin; kin = kout; kout = t;
       t = vin; vin = vout; vout = t;
     }
-    // 3. tiles per entry, in depth order
-    if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
+    // 3. tiles per entry, in depth order (tiles_per_gauss was zeroed by visible_reduce_kernel)
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
                        compact ? L.asc : (const uint32_t *)nullptr);

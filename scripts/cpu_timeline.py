@@ -24,13 +24,20 @@ class EvProxy:
         marks["before_wait"] = time.perf_counter(); orig_sync(); marks["after_wait"] = time.perf_counter()
 FV._SYNC[dev] = (counts, EvProxy())
 
-def step(i):
+from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+flat = FlatGradients(list(params.values()) + grids, sparse_rows=True)
+fx = FrameExchange(flat, list(params.keys()) + [f"grid{i}" for i in range(len(grids))])
+
+def step(i):   # the bench's loop: one view of a frame through the arena modes
     v = i % len(cams)
-    for p in list(params.values()) + grids: p.grad = None
+    if v == 0:
+        fx.begin_frame()
     marks["start"] = time.perf_counter()
-    o = Hn.render_view(params, cams[v], grids, v, sky)
+    o = Hn.render_view(params, cams[v], grids, v, sky, **fx.view_kwargs(v))
+    fx.begin_view(o["info"])
     marks["fwd_done"] = time.perf_counter()
-    Hn.training_loss(o, target, grids).backward()
+    Hn.training_loss(o, target, grids, grid_grads=fx.tail_grads()).backward()
+    fx.end_view()
     marks["end"] = time.perf_counter()
 
 for i in range(6): step(i)
