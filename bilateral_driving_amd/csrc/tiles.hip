@@ -515,14 +515,15 @@ static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int s
 }
 
 // ------------------------------------------------------------------------------------------
-// short sort: the same stable LSD pass in ONE launch, for inputs whose length lives on the device
+// short sort: the same stable LSD pass in TWO launches, for inputs whose length lives on the device
 // ------------------------------------------------------------------------------------------
 // The depth sort of the visible entries is latency-bound (a few hundred thousand keys: every launch costs more
 // than the bytes it moves), so the scan of the [digit][workgroup] histogram is folded away: histograms are stored
-// workgroup-major next to one group row per 64 workgroups, a scatter workgroup derives its own bases from <= ng group rows +
-// <= 63 workgroup rows (all L2-resident), and the histogram of the NEXT digit is accumulated per output chunk while the pairs
-// are placed (the first one by the compaction kernel): 4 launches for the 4 passes.
+// workgroup-major, every 32 workgroups also add theirs to a group row (256 atomics per workgroup), and a scatter
+// workgroup derives its own bases from <= ng group rows + <= 31 workgroup rows (all L2-resident).
 // Chunks of 1024 pairs (4 rounds per wave): a few hundred thousand keys then spread over > 256 workgroups.
+// (Measured and dropped: accumulating the NEXT digit's histogram inside the scatter, per output chunk, with global atomics -- the
+// upper bytes of fp32 depths take a handful of values, so a whole chunk hits ONE counter: 14 -> 500 us for the third pass.)
 constexpr int kGroupShift = 6;                      // 64 workgroups per group row
 constexpr int kShortRounds = 4;
 constexpr int kShortChunk = kSortBlock * kShortRounds;   // 1024
@@ -530,13 +531,32 @@ constexpr int kChunkShift = 10;
 static_assert(kShortChunk == (1 << kChunkShift), "chunk shift");
 constexpr int64_t kShortSortMax = (int64_t)kShortChunk * 8192;   // <= 128 group rows
 
+__global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *__restrict__ keys,
+                                                               const uint64_t *__restrict__ n_dev, int shift,
+                                                               uint32_t *__restrict__ hist /*[nblocks][256]*/,
+                                                               uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
+  __shared__ uint32_t h[256];
+  const int64_t n = (int64_t)*n_dev;
+  const int64_t base = (int64_t)blockIdx.x * kShortChunk;
+  if (base >= n) return;  // the launch is sized for the host-side bound
+  h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll 4
+  for (int r = 0; r < kShortRounds; r++) {
+    const int64_t i = base + r * kSortBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = h[threadIdx.x];
+  hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
+  if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kGroupShift) * 256 + threadIdx.x], c);
+}
+
 // wave-private ranking as in radix_scatter_lds_kernel; bases from the group / workgroup rows
-// hist_next / ghist_next (null on the last pass): the histogram of the NEXT digit per OUTPUT chunk, accumulated while the pairs are
-// placed (one launch per pass instead of two; the tables are zeroed up front by visible_reduce_kernel)
 __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, uint32_t *__restrict__ hist_next, uint32_t *__restrict__ ghist_next) {
+    uint32_t *__restrict__ vals_out) {
   const int64_t n = (int64_t)*n_dev;
   if ((int64_t)blockIdx.x * kShortChunk >= n) return;
   __shared__ uint32_t wrun[kSortWaves][256];
@@ -599,22 +619,16 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     if (on && rank == 0) wrun[wv][d] = pos + __popcll(peers);
     __builtin_amdgcn_wave_barrier();
     if (on) {
-      const uint32_t dst = pos + rank;
-      keys_out[dst] = k[r];
-      vals_out[dst] = v[r];
-      if (hist_next) {
-        const uint32_t nd = (k[r] >> (shift + 8)) & 255u, chunk = dst >> kChunkShift;
-        atomicAdd(&hist_next[(int64_t)chunk * 256 + nd], 1u);
-        atomicAdd(&ghist_next[(int64_t)(chunk >> kGroupShift) * 256 + nd], 1u);
-      }
+      keys_out[pos + rank] = k[r];
+      vals_out[pos + rank] = v[r];
     }
   }
 }
 
-// uint32 elements: per pass one workgroup-major histogram + one group table, all zero-initialised
+// uint32 elements: one workgroup-major histogram + four zero-initialised group tables
 static size_t short_sort_elems(int64_t n_bound) {
   const int64_t nb = cdiv(n_bound > 0 ? n_bound : 1, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
-  return (size_t)(4 * nb + 4 * ng) * 256;
+  return (size_t)(nb + 4 * ng) * 256;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1026,7 +1040,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
   if (CN <= kShortSortMax && option_get(kOptShortSort)) {
     // 12 launches instead of 27: the whole stage is launch-latency bound at this size
     const int64_t nb = cdiv(CN, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
-    uint32_t *hist = L.tables, *ghist = L.tables + 4 * nb * 256;   // hist[p] = hist + p * nb * 256, ghist[p] = ghist + p * ng * 256
+    uint32_t *hist = L.tables, *ghist = L.tables + nb * 256;   // ghist[p] = ghist + p * ng * 256
     const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
     // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
     hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
@@ -1037,10 +1051,10 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 2. depth order: 4 stable passes of 8 bits; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
     for (int p = 0; p < 4; p++) {
-      uint32_t *hp = hist + (int64_t)p * nb * 256, *gh = ghist + (int64_t)p * ng * 256;
-      uint32_t *hn = p < 3 ? hist + (int64_t)(p + 1) * nb * 256 : nullptr, *gn = p < 3 ? ghist + (int64_t)(p + 1) * ng * 256 : nullptr;
-      hipLaunchKernelGGL(short_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, vin, n_vis, 8 * p, hp, gh, kout,
-                         vout, hn, gn);
+      uint32_t *gh = ghist + (int64_t)p * ng * 256;
+      if (p > 0) hipLaunchKernelGGL(short_hist_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, n_vis, 8 * p, hist, gh);
+      hipLaunchKernelGGL(short_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, vin, n_vis, 8 * p, hist, gh, kout,
+                         vout);
       uint32_t *t;
       t = kin; kin = kout; kout = t;
       t = vin; vin = vout; vout = t;
@@ -1069,7 +1083,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
       t = kin; kin = kout; kout = t;
       t = vin; vin = vout; vout = t;
     }
-    // 3. tiles per entry, in depth order (tiles_per_gauss was zeroed by visible_reduce_kernel)
+    // 3. tiles per entry, in depth order
+    if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
                        compact ? L.asc : (const uint32_t *)nullptr);
@@ -1101,6 +1116,13 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   return BDS_OK;
 }
 
+// counts -> page-locked host memory, written by the GPU itself: a copy node between two kernels costs ~15 us of idle GPU
+// (engine switch + barriers), a one-wave kernel ~4.5 us
+__global__ void publish_counts_kernel(const uint64_t *__restrict__ counts_dev, volatile int64_t *__restrict__ counts_host) {
+  if (threadIdx.x < 2) counts_host[threadIdx.x] = (int64_t)counts_dev[threadIdx.x];
+  __threadfence_system();
+}
+
 extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                                        const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                                        int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *counts_pinned,
@@ -1113,8 +1135,15 @@ extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, c
   hipStream_t st = as_stream(stream);
   if (counts_dev == nullptr) {
     counts_pinned[0] = 0; counts_pinned[1] = 0;
-  } else if (hipMemcpyAsync(counts_pinned, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) {
-    return BDS_ELAUNCH;
+  } else {
+    void *mapped = nullptr;   // device view of the caller's page-locked buffer (the same address under unified addressing)
+    if (hipHostGetDevicePointer(&mapped, counts_pinned, 0) == hipSuccess && mapped != nullptr) {
+      hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(64), 0, st, counts_dev, static_cast<volatile int64_t *>(mapped));
+      BDS_LAUNCH_CHECK();
+    } else {
+      (void)hipGetLastError();   // not mapped: fall back to the copy engine
+      if (hipMemcpyAsync(counts_pinned, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
+    }
   }
   if (hipEventRecord(static_cast<hipEvent_t>(event), st) != hipSuccess) return BDS_ELAUNCH;
   return BDS_OK;

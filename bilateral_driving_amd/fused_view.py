@@ -81,10 +81,15 @@ class _Front:
     colours, per-tile lists (compact positions) and the ascending visible-id list.  Shared by the training forward and by the
     evaluation re-renders (``render_classes``), which composite several opacity masks over ONE such front."""
     __slots__ = ("means", "quats", "log_scales", "sh", "viewmat", "scales", "opac", "radii", "means2d", "depths", "conics", "cam_pos",
-                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N", "list_tile")
+                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N", "list_tile", "rec_buf", "pre")
 
 
-def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Front:
+_VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
+
+
+def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before_wait=None) -> _Front:
+    """``before_wait`` (optional callable): host work of the caller that does not depend on the list counts (allocations, level
+    structs); it runs while the GPU is still producing them, so that after the one host wait of a view only launches remain."""
     L.require_gpu(means, quats, log_scales, logits, sh, viewmat)
     lib, st = L.lib(), L.stream()
     dev = means.device
@@ -130,8 +135,16 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
         buf = _empty((cap,), dev, torch.int32)
         ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
         ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
+    vcap = _VIS_CAPACITY.get(key, 0)
+    rec_buf = _empty((vcap, L.SPLAT_RECORD_FLOATS), dev) if vcap else None
+    off = lib.bds_isect_visible_ids_offset(1, N)
+    pre = before_wait() if before_wait is not None else None
     ev.synchronize()
     M, n_vis = int(counts[0]), int(counts[1])
+    if rec_buf is None or n_vis > vcap:
+        rec_buf = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
+    if n_vis + n_vis // 16 > vcap:
+        _VIS_CAPACITY[key] = n_vis + n_vis // 6 + 1024
     if M > cap or buf is None:   # first call of this configuration, or the lists outgrew the expectation
         buf = _empty((M,), dev, torch.int32)
         ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
@@ -139,7 +152,6 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
     flatten = buf[:M]                                  # per-tile lists of COMPACT positions (they address the records below)
     # ascending ids of the visible Gaussians: compact position -> id, the work list of everything downstream (walks memory in
     # order).  Read in place from the prepare workspace (which this view keeps alive): no copy node between the kernels.
-    off = lib.bds_isect_visible_ids_offset(1, N)
     vis_ids = ws[off:off + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
         L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th, L.ptr(ws),
@@ -154,17 +166,25 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Fr
     f.cam_pos, f.sh_rgb, f.colors, f.tiles_per_gauss, f.isect_offsets = cam_pos, sh_rgb, colors, tiles_per_gauss, isect_offsets
     f.flatten, f.vis_ids, f.M, f.n_vis, f.W, f.H, f.N, f.list_tile = flatten, vis_ids, M, n_vis, W, H, N, LT
     f.tw, f.th = math.ceil(W / TILE), math.ceil(H / TILE)  # compositing tiles
+    f.rec_buf, f.pre = rec_buf, pre
     return f
 
 
-def _composite(f: _Front, opac: Tensor):
-    """Splat records of the visible Gaussians with the given opacities [N] + the forward composite (RGB + depth)."""
+def _image_buffers(W: int, H: int, dev):
+    return _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((1, H, W), dev, torch.int32)
+
+
+def _composite(f: _Front, opac: Tensor, images=None):
+    """Splat records of the visible Gaussians with the given opacities [N] + the forward composite (RGB + depth).
+    ``images``: (render, alphas, last_ids) allocated by the caller (before the host wait), else allocated here."""
     lib, st = L.lib(), L.stream()
     dev = opac.device
     n_vis, M, W, H = f.n_vis, f.M, f.W, f.H
-    rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
-    render, alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
-    last_ids = _empty((1, H, W), dev, torch.int32)
+    if f.rec_buf is not None:      # provisioned before the wait (first composite over this front only)
+        rec, f.rec_buf = f.rec_buf[:n_vis], None
+    else:
+        rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
+    render, alphas, last_ids = images if images is not None else _image_buffers(W, H, dev)
     with L.timed("rasterize_fwd"):
         L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac), L.ptr(f.radii),
                                    L.ptr(rec), st),
@@ -183,22 +203,25 @@ class _FusedView(torch.autograd.Function):
         W, H = cfg["width"], cfg["height"]
         N = means.shape[0]
         sky = sky.contiguous()
-        f = _view_front(cfg, means, quats, log_scales, logits, sh, viewmat)
+        grids = [g.contiguous() for g in grids]
+
+        def before_wait():   # everything of the rest of the forward that does not depend on the list counts
+            idx = cfg.get("img_idx")
+            sel = grids if idx is None else [g[idx:idx + 1] for g in grids]   # views: the level struct takes their addresses
+            lv = _levels_struct(sel, None, cfg["factors"])
+            bws_bytes = lib.bds_bilagrid_ms_workspace_bytes(len(grids), lv, H, W)
+            return (_image_buffers(W, H, dev), sel, lv, bws_bytes, _empty((bws_bytes,), dev, torch.uint8), _empty((H, W, 3), dev),
+                    _empty((H, W, 1), dev))
+
+        f = _view_front(cfg, means, quats, log_scales, logits, sh, viewmat, before_wait)
         means, quats, log_scales, sh, viewmat = f.means, f.quats, f.log_scales, f.sh, f.viewmat
         scales, opac, radii, means2d, cam_pos, sh_rgb = f.scales, f.opac, f.radii, f.means2d, f.cam_pos, f.sh_rgb
         tiles_per_gauss, isect_offsets, flatten, vis_ids, M = f.tiles_per_gauss, f.isect_offsets, f.flatten, f.vis_ids, f.M
-        rec, render, alphas, last_ids = _composite(f, opac)
+        images, sel, lv, bws_bytes, bws, rgb, depth = f.pre
+        rec, render, alphas, last_ids = _composite(f, opac, images)
         ctx.list_tile = f.list_tile
         del f
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
-        grids = [g.contiguous() for g in grids]
-        idx = cfg.get("img_idx")
-        sel = grids if idx is None else [g[idx:idx + 1] for g in grids]   # views: the level struct takes their addresses
-        factors = cfg["factors"]
-        lv = _levels_struct(sel, None, factors)
-        bws_bytes = lib.bds_bilagrid_ms_workspace_bytes(len(grids), lv, H, W)
-        bws = _empty((bws_bytes,), dev, torch.uint8)
-        rgb, depth = _empty((H, W, 3), dev), _empty((H, W, 1), dev)
         with L.timed("bilagrid_fwd"):
             L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
                                                L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")

@@ -308,7 +308,7 @@ def test_train_view_direct_path_equals_autograd_path(ops):
     a = res["autograd"]
     for mode in ("direct", "direct_plain"):
         b = res[mode]
-        assert a[0] == b[0], (a[0], b[0])                                   # same kernels, same order: the losses are bit-equal
+        assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(a[0], b[0])), (a[0], b[0])   # same kernels; the L1 sum uses float atomics
         assert torch.equal(a[5], b[5])
         assert float((a[1] - b[1]).norm() / a[1].norm()) < 2e-5             # atomics: summation order only
         assert float((a[2] - b[2]).norm() / a[2].norm()) < 1e-6
