@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=170.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not enqueue the next view's projection / tile counting ahead of the current view's backward "
+                         "(harness.render_view_begin): every view then pays its host wait for the list counts with an idle GPU")
     ap.add_argument("--direct", action="store_true",
                     help="drive each view through harness.train_view (the same kernels called back to back without an autograd graph) "
                          "instead of forward / loss / loss.backward() through torch autograd, the reference-shaped step (default); "
@@ -263,19 +266,25 @@ def main():
                 p.grad = None
         else:
             fx.begin_frame()
+        pipeline = not args.no_pipeline
+        front = Hn.render_view_begin(params, cams[0]) if pipeline else None   # (a real loop begins it right after the optimizer step)
         for v in range(V):
             skies[v].grad = None
             cams[v].viewmat.grad = None
             kw = {} if dense else fx.view_kwargs(v)
             if not args.direct:   # the reference-shaped step: forward, loss, loss.backward() through autograd
-                out = Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, **kw)
+                out = Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, front=front, **kw)
                 if not dense:
                     fx.begin_view(out["info"])
                 loss = Hn.training_loss(out, targets[v], grids, grid_grads=None if dense else fx.tail_grads())
+                # the next view's projection / sort / tile counts go in FRONT of this view's backward: its list counts reach the host
+                # while the GPU is busy with the backward, so its one host wait never leaves the GPU idle
+                front = Hn.render_view_begin(params, cams[v + 1]) if pipeline and v + 1 < V else None
                 loss.backward()
             else:               # the same kernels in the same order, called back to back without an autograd graph
-                out = Hn.train_view(params, cams[v], grids, v, skies[v], targets[v], factors=factors,
+                out = Hn.train_view(params, cams[v], grids, v, skies[v], targets[v], factors=factors, front=front,
                                     grid_grads=None if dense else fx.tail_grads(), after_forward=None if dense else fx.begin_view, **kw)
+                front = None   # (train_view runs forward and backward in one call: nothing to slide in between)
             if not dense:
                 fx.end_view()
             stats.setdefault("M", []).append(out["info"]["n_isects"])
@@ -382,6 +391,7 @@ def main():
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
+                   "pipelined_fronts": not args.no_pipeline and not args.direct,
                    "step_driver": "direct (harness.train_view: same kernels, no autograd graph)" if args.direct else "autograd (forward, loss, loss.backward())",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,

@@ -36,13 +36,18 @@ _SYNC: Dict[torch.device, tuple] = {}
 
 
 def _host_sync_objects(dev):
-    """(page-locked int64[2], event) used to read the two list counts back without draining the stream."""
-    o = _SYNC.get(dev)
-    if o is None:
-        counts = torch.zeros(2, dtype=torch.int64).pin_memory()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))   # materialises the underlying hipEvent_t
-        o = _SYNC[dev] = (counts, ev)
+    """(page-locked int64[2], event) used to read the two list counts back without draining the stream.  A small rotating pool:
+    the front of the next view may be in flight while the current one is still being finished (``fused_view_begin``)."""
+    pool = _SYNC.get(dev)
+    if pool is None:
+        pool = _SYNC[dev] = {"next": 0, "items": []}
+        for _ in range(4):
+            counts = torch.zeros(2, dtype=torch.int64).pin_memory()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))   # materialises the underlying hipEvent_t
+            pool["items"].append((counts, ev))
+    o = pool["items"][pool["next"]]
+    pool["next"] = (pool["next"] + 1) % len(pool["items"])
     return o
 
 
@@ -87,9 +92,36 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
+class _FrontState:
+    """A view's front between its two halves: everything enqueued up to the list counts (see ``_front_begin``)."""
+    pass
+
+
+def _front_signature(cfg: dict, means, quats, log_scales, logits, sh, viewmat):
+    t = (means, quats, log_scales, logits, sh, viewmat, cfg["K"], cfg["cam_pos"])
+    return (tuple((x.data_ptr(), x._version, tuple(x.shape)) for x in t), cfg["width"], cfg["height"], cfg["sh_degree"], cfg["near_plane"],
+            cfg["far_plane"], cfg["radius_clip"], cfg["eps2d"], cfg["tile_cull"], cfg.get("list_tile", LIST_TILE))
+
+
 def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before_wait=None) -> _Front:
     """``before_wait`` (optional callable): host work of the caller that does not depend on the list counts (allocations, level
-    structs); it runs while the GPU is still producing them, so that after the one host wait of a view only launches remain."""
+    structs); it runs while the GPU is still producing them, so that after the one host wait of a view only launches remain.
+    ``cfg["front"]``: a state returned by ``fused_view_begin`` for exactly these inputs (its kernels are already enqueued)."""
+    state = cfg.get("front")
+    if state is not None:
+        assert state.signature == _front_signature(cfg, means, quats, log_scales, logits, sh, viewmat), (
+            "fused_view(front=...): the front was begun for other inputs, or a parameter changed since")
+        assert not state.used, "a front can be finished once"
+    else:
+        state = _front_begin(cfg, means, quats, log_scales, logits, sh, viewmat)
+    state.used = True
+    return _front_finish(state, before_wait)
+
+
+def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _FrontState:
+    """First half of a view's forward: activations + projection, visibility compaction, depth order, tile counts (whose totals travel
+    to the host asynchronously) and the SH colours.  Nothing here depends on the host."""
+    signature = _front_signature(cfg, means, quats, log_scales, logits, sh, viewmat)
     L.require_gpu(means, quats, log_scales, logits, sh, viewmat)
     lib, st = L.lib(), L.stream()
     dev = means.device
@@ -138,6 +170,28 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before
     vcap = _VIS_CAPACITY.get(key, 0)
     rec_buf = _empty((vcap, L.SPLAT_RECORD_FLOATS), dev) if vcap else None
     off = lib.bds_isect_visible_ids_offset(1, N)
+    s_ = _FrontState()
+    (s_.signature, s_.used, s_.cfg, s_.means, s_.quats, s_.log_scales, s_.sh, s_.viewmat, s_.scales, s_.opac, s_.radii, s_.means2d,
+     s_.depths, s_.conics, s_.cam_pos, s_.sh_rgb, s_.colors, s_.tiles_per_gauss, s_.isect_offsets, s_.ws, s_.ws_bytes, s_.cull,
+     s_.counts, s_.ev, s_.key, s_.cap, s_.vcap, s_.buf, s_.ws2, s_.ws2_bytes, s_.rec_buf, s_.off, s_.LT, s_.tw, s_.th) = (
+        signature, False, cfg, means, quats, log_scales, sh, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
+        colors, tiles_per_gauss, isect_offsets, ws, ws_bytes, cull, counts, ev, key, cap, vcap, buf, ws2, ws2_bytes, rec_buf, off, LT,
+        tw, th)
+    return s_
+
+
+def _front_finish(s_: _FrontState, before_wait=None) -> _Front:
+    """Second half: the one host wait of a view (list counts), then the per-tile lists."""
+    lib, st = L.lib(), L.stream()
+    cfg = s_.cfg
+    (means, quats, log_scales, sh, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, tiles_per_gauss,
+     isect_offsets, ws, ws_bytes, cull, counts, ev, key, cap, vcap, buf, ws2, ws2_bytes, rec_buf, off, LT, tw, th) = (
+        s_.means, s_.quats, s_.log_scales, s_.sh, s_.viewmat, s_.scales, s_.opac, s_.radii, s_.means2d, s_.depths, s_.conics, s_.cam_pos,
+        s_.sh_rgb, s_.colors, s_.tiles_per_gauss, s_.isect_offsets, s_.ws, s_.ws_bytes, s_.cull, s_.counts, s_.ev, s_.key, s_.cap,
+        s_.vcap, s_.buf, s_.ws2, s_.ws2_bytes, s_.rec_buf, s_.off, s_.LT, s_.tw, s_.th)
+    dev = means.device
+    W, H, N = cfg["width"], cfg["height"], means.shape[0]
+    cptr, optr = (L.ptr(conics), L.ptr(opac.view(1, N))) if cull else (None, None)
     pre = before_wait() if before_wait is not None else None
     ev.synchronize()
     M, n_vis = int(counts[0]), int(counts[1])
@@ -346,7 +400,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
                grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
-               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None):
+               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None, front=None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
     [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
@@ -365,14 +419,16 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     is exchanged once) and returns no gradient for those parameters.
     ``grad_sink`` (multi-GPU, ``dist.FrameExchange``): an object whose ``targets(visible_ids)`` is called inside the backward and
     returns (compact buffers by name, row_map [N] i32); the visible rows are stored at ``row_map[g]`` of those buffers and no
-    gradient is returned for the five per-Gaussian parameters (the sink adds the reduced rows to their ``.grad``)."""
+    gradient is returned for the five per-Gaussian parameters (the sink adds the reduced rows to their ``.grad``).
+    ``front``: the object ``fused_view_begin`` returned for the same parameters / camera: that half of the forward is already
+    enqueued (software pipelining of the one host wait per view, see there)."""
     if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds.data[..., :3, 3]); callers with fixed cameras cache it
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena, grad_sink=grad_sink,
                img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows),
-               list_tile=int(LIST_TILE if list_tile is None else list_tile))
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     # in-place grid gradients only when the arena entries ARE the grids' .grad right now (dist.FrameExchange.begin_frame sets that up)
     if grad_arena is not None and int(arena_rows) >= 1 and grad_sink is None:
@@ -387,6 +443,35 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                   "tile_size": cfg["list_tile"],   # of the lists in this dict (the compositor subdivides into 16 x 16)
                   "n_cameras": 1, "n_isects": int(flatten_ranks.numel()), "n_visible": int(vis_ids.numel())})
     return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)
+
+
+@torch.no_grad()
+def fused_view_begin(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, sh_degree: int = 3,
+                     near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
+                     tile_cull: bool = True, cam_pos: Optional[Tensor] = None, list_tile: Optional[int] = None):
+    """Enqueue the first half of a view's forward (projection, visibility compaction, depth order, tile counts, SH colours) and return
+    a handle for ``fused_view(..., front=handle)`` / ``train_view(..., front=handle)``.
+
+    A view has ONE host wait (the two list counts, as in gsplat).  Called for view v+1 BEFORE ``loss.backward()`` of view v is
+    enqueued, these kernels run ahead of that backward, the counts are on the host long before they are asked for, and the GPU never
+    idles behind the wait or behind the launches that follow it:
+
+        front = fused_view_begin(params, cams[0].viewmat, ...)
+        for v, cam in enumerate(cams):
+            out = fused_view(params, cam.viewmat, ..., front=front)
+            loss = ...
+            front = fused_view_begin(params, cams[v + 1].viewmat, ...) if v + 1 < len(cams) else None
+            loss.backward()
+
+    The parameters must not change between the two calls (checked through the tensors' version counters): begin the first view of a
+    frame after the optimizer step.  Same keyword arguments, same values as the ``fused_view`` call that consumes the handle."""
+    if cam_pos is None:
+        cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
+    cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), sh_degree=int(sh_degree), near_plane=float(near_plane),
+               far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d), tile_cull=bool(tile_cull),
+               list_tile=int(LIST_TILE if list_tile is None else list_tile))
+    return _front_begin(cfg, params["means"].detach(), params["quats"].detach(), params["log_scales"].detach(),
+                        params["opacity_logits"].detach(), params["sh"].detach(), viewmat.detach())
 
 
 @torch.no_grad()
@@ -472,7 +557,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
     grad_arena, arena_rows = kwargs.pop("grad_arena", None), int(kwargs.pop("arena_rows", 0))
     grad_sink = kwargs.pop("grad_sink", None)
-    list_tile = kwargs.pop("list_tile", None)
+    list_tile, front = kwargs.pop("list_tile", None), kwargs.pop("front", None)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
     assert not kwargs, f"unknown arguments {sorted(kwargs)}"
@@ -480,7 +565,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sh_degree=int(opts["sh_degree"]), near_plane=float(opts["near_plane"]), far_plane=float(opts["far_plane"]),
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
-               list_tile=int(LIST_TILE if list_tile is None else list_tile))
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
