@@ -187,7 +187,24 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     if (grad2d) { grad2d[g * 2] = r1.w; grad2d[g * 2 + 1] = r2.x; }
     if (absgrad2d) { absgrad2d[g * 2] = r2.y; absgrad2d[g * 2 + 1] = r2.z; }
   }
-  if (kPose) pose_grad_reduce(pg, red, v_viewmat_slots);
+  if (kPose) {
+    pose_grad_reduce(pg, red, v_viewmat_slots);
+    // the LAST workgroup to get here sums the slots into row kPoseSlots (one launch less than a separate reduction)
+    __shared__ bool s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned int *counter = reinterpret_cast<unsigned int *>(v_viewmat_slots + (kPoseSlots + 1) * 16);
+      s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 16) {
+      float t = 0.f;
+      for (int k = 0; k < kPoseSlots; k++)
+        t += __hip_atomic_load(v_viewmat_slots + k * 16 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v_viewmat_slots[kPoseSlots * 16 + threadIdx.x] = t;
+    }
+  }
 }
 
 }  // namespace bds
