@@ -67,9 +67,10 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=170.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="do not enqueue the next view's projection / tile counting ahead of the current view's backward "
-                         "(harness.render_view_begin): every view then pays its host wait for the list counts with an idle GPU")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="enqueue the next view's projection / tile counting ahead of the current view's backward "
+                         "(harness.render_view_begin).  Off by default: measured equal to the plain loop on MI355X (772 it/s either way "
+                         "in scripts/host_profile.py: the one host wait per view is already hidden behind the SH kernel)")
     ap.add_argument("--direct", action="store_true",
                     help="drive each view through harness.train_view (the same kernels called back to back without an autograd graph) "
                          "instead of forward / loss / loss.backward() through torch autograd, the reference-shaped step (default); "
@@ -266,7 +267,7 @@ def main():
                 p.grad = None
         else:
             fx.begin_frame()
-        pipeline = not args.no_pipeline
+        pipeline = bool(args.pipeline)
         front = Hn.render_view_begin(params, cams[0]) if pipeline else None   # (a real loop begins it right after the optimizer step)
         for v in range(V):
             skies[v].grad = None
@@ -391,7 +392,7 @@ def main():
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
-                   "pipelined_fronts": not args.no_pipeline and not args.direct,
+                   "pipelined_fronts": bool(args.pipeline) and not args.direct,
                    "step_driver": "direct (harness.train_view: same kernels, no autograd graph)" if args.direct else "autograd (forward, loss, loss.backward())",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
