@@ -198,11 +198,19 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
       s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (s_last && threadIdx.x < 16) {
+    if (s_last) {   // (block-uniform) 16 groups of 16 lanes: group g sums slots g, g + 16, ...: four independent loads per thread
+      __shared__ float s_part[kProjBlock];
       float t = 0.f;
-      for (int k = 0; k < kPoseSlots; k++)
-        t += __hip_atomic_load(v_viewmat_slots + k * 16 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v_viewmat_slots[kPoseSlots * 16 + threadIdx.x] = t;
+      for (int k = threadIdx.x >> 4; k < kPoseSlots; k += kProjBlock >> 4)
+        t += __hip_atomic_load(v_viewmat_slots + k * 16 + (threadIdx.x & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_part[threadIdx.x] = t;
+      __syncthreads();
+      if (threadIdx.x < 16) {
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < kProjBlock / 16; g++) tot += s_part[g * 16 + threadIdx.x];
+        v_viewmat_slots[kPoseSlots * 16 + threadIdx.x] = tot;
+      }
     }
   }
 }

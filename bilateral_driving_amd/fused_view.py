@@ -45,6 +45,7 @@ def _host_sync_objects(dev):
             counts = torch.zeros(2, dtype=torch.int64).pin_memory()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))   # materialises the underlying hipEvent_t
+            counts.np = counts.numpy()                  # (reading two host integers through tensor indexing costs ~10 us)
             pool["items"].append((counts, ev))
     o = pool["items"][pool["next"]]
     pool["next"] = (pool["next"] + 1) % len(pool["items"])
@@ -194,7 +195,7 @@ def _front_finish(s_: _FrontState, before_wait=None) -> _Front:
     cptr, optr = (L.ptr(conics), L.ptr(opac.view(1, N))) if cull else (None, None)
     pre = before_wait() if before_wait is not None else None
     ev.synchronize()
-    M, n_vis = int(counts[0]), int(counts[1])
+    M, n_vis = int(counts.np[0]), int(counts.np[1])
     if rec_buf is None or n_vis > vcap:
         rec_buf = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
     if n_vis + n_vis // 16 > vcap:
@@ -280,6 +281,18 @@ class _FusedView(torch.autograd.Function):
             L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
                                                L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")
         rgb_g = render[0, :, :, :3]   # view: the Gaussians' colour before clamp / sky / transform (clamped on access, see _Out)
+        # The backward's first launch (bilateral transform) is prepared HERE when its gradient targets are already known (in-place
+        # grid gradients): at that point of a step the host is only tens of microseconds ahead of the GPU, and every allocation
+        # or struct fill in front of that launch is GPU idle time.
+        ctx.bwd_pre = None
+        if cfg.get("grids_in_place") and cfg.get("grad_sink") is None and any(ctx.needs_input_grad[8:]):
+            arena_g = [cfg["grad_arena"][f"grid{i}"] for i in range(len(grids))]
+            if all(a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)):
+                v_g = [a if ctx.needs_input_grad[8 + i] else None for i, a in enumerate(arena_g)]
+                idx = cfg.get("img_idx")
+                v_sel = v_g if idx is None else [None if v is None else v[idx:idx + 1] for v in v_g]
+                ctx.bwd_pre = (v_g, _levels_struct(sel, v_sel, cfg["factors"]), sel, _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev),
+                               _empty((H, W, 3), dev) if ctx.needs_input_grad[6] else None)
         ctx.cfg = cfg
         ctx.M = M
         ctx.n_grids = len(grids)
@@ -307,13 +320,16 @@ class _FusedView(torch.autograd.Function):
         tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
         # colour transform
         need_g = ctx.needs_input_grad[8:]
+        pre = getattr(ctx, "bwd_pre", None)
         # grid gradients: one zero fill for all levels; with img_idx the full [n_img, ...] gradient is returned with only that
         # image's slice written (no slice-backward / scatter in the autograd graph)
         # ... or, with grad_arena["grid<i>"] and arena_rows >= 1, ADDED in place to the caller's accumulators (their .grad)
         arena_g = [(cfg.get("grad_arena") or {}).get(f"grid{i}") for i in range(len(grids))]
-        grids_in_place = (bool(cfg.get("grids_in_place")) and cfg.get("grad_sink") is None and any(need_g)
-                          and all(a is not None and a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)))
-        if grids_in_place:
+        grids_in_place = pre is not None or (bool(cfg.get("grids_in_place")) and cfg.get("grad_sink") is None and any(need_g)
+                                            and all(a is not None and a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)))
+        if pre is not None:
+            v_grids = pre[0]
+        elif grids_in_place:
             v_grids = [a if need_g[i] else None for i, a in enumerate(arena_g)]
         else:
             sizes = [(g.numel() + 3) // 4 * 4 if need_g[i] else 0 for i, g in enumerate(grids)]
@@ -322,15 +338,18 @@ class _FusedView(torch.autograd.Function):
             for i, g in enumerate(grids):
                 v_grids.append(flat[off:off + g.numel()].view(g.shape) if need_g[i] else None)
                 off += sizes[i]
-        idx = cfg.get("img_idx")
-        sel = list(grids) if idx is None else [g[idx:idx + 1] for g in grids]
-        v_sel = v_grids if idx is None else [None if v is None else v[idx:idx + 1] for v in v_grids]
-        lv = _levels_struct(sel, v_sel, cfg["factors"])
+        if pre is not None:
+            _, lv, _sel_keepalive, v_render, v_alphas, v_sky = pre
+        else:
+            idx = cfg.get("img_idx")
+            sel = list(grids) if idx is None else [g[idx:idx + 1] for g in grids]
+            v_sel = v_grids if idx is None else [None if v is None else v[idx:idx + 1] for v in v_grids]
+            lv = _levels_struct(sel, v_sel, cfg["factors"])
+            v_render, v_alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
+            v_sky = _empty((H, W, 3), dev) if ctx.needs_input_grad[6] else None   # the sky colour is often a constant input
         v_rgb = torch.zeros(H, W, 3, device=dev) if v_rgb is None else v_rgb.contiguous()
         v_depth = None if v_depth is None else v_depth.contiguous()
         v_opacity = None if v_opacity is None else v_opacity.contiguous()
-        v_render, v_alphas = _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev)
-        v_sky = _empty((H, W, 3), dev) if ctx.needs_input_grad[6] else None   # the sky colour is often a constant input
         with L.timed("bilagrid_bwd"):
             L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
                                                L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),

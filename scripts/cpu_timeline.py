@@ -16,13 +16,14 @@ gen = torch.Generator().manual_seed(7)
 sky = torch.rand(H, W, 3, generator=gen).to(dev); target = torch.rand(H, W, 3, generator=gen).to(dev)
 
 marks = {}
-counts, ev = FV._host_sync_objects(dev)
-orig_sync = ev.synchronize
+FV._host_sync_objects(dev)   # creates the pool
 class EvProxy:
-    def __getattr__(self, k): return getattr(ev, k)
+    def __init__(self, ev): self._ev = ev
+    def __getattr__(self, k): return getattr(self._ev, k)
     def synchronize(self):
-        marks["before_wait"] = time.perf_counter(); orig_sync(); marks["after_wait"] = time.perf_counter()
-FV._SYNC[dev] = (counts, EvProxy())
+        marks["before_wait"] = time.perf_counter(); self._ev.synchronize(); marks["after_wait"] = time.perf_counter()
+pool = FV._SYNC[dev]
+pool["items"] = [(c, EvProxy(e)) for c, e in pool["items"]]
 
 from bilateral_driving_amd.dist import FlatGradients, FrameExchange
 flat = FlatGradients(list(params.values()) + grids, sparse_rows=True)
