@@ -357,7 +357,7 @@ class _FusedView(torch.autograd.Function):
         # compositing: gradient records of the visible Gaussians, in the order of vis_ids (64 bytes each)
         # (+ the camera-pose gradient slots of the projection backward behind them: one zero fill for both)
         want_pose = bool(ctx.needs_input_grad[7])
-        v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS + 2 if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev,
+        v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev,
                                 dtype=torch.float32)
         v_rec = v_rec_all[:max(n_vis, 1)]
         LT = ctx.list_tile
@@ -398,7 +398,7 @@ class _FusedView(torch.autograd.Function):
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
-        v_vm_slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS + 2, 4, 4) if want_pose else None   # camera-pose gradient (base.py:328-329,399)
+        v_vm_slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS, 4, 4) if want_pose else None   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
             L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
                                                   L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
@@ -408,7 +408,7 @@ class _FusedView(torch.autograd.Function):
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]
             carrier.absgrad = g2d[1:2]
-        v_viewmat = None if v_vm_slots is None else v_vm_slots[L.POSE_GRAD_SLOTS]   # summed by the kernel's last workgroup
+        v_viewmat = None if v_vm_slots is None else v_vm_slots.sum(0)
         if grids_in_place:
             v_grids = [None] * len(grids)
         if rows == 2 or sink is not None:   # already added in place to what autograd holds as .grad (or handed to the sink)

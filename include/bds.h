@@ -272,10 +272,9 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
  *   project_view_bwd_list: v_means [N,3] v_quats [N,4] v_log_scales [N,3] v_logits [N] rows; optionally (may be NULL)
  *       grad2d / absgrad2d [N,2]: the screen-space gradient and the sum over pixels of its absolute value scattered to the
  *       dense arrays models/trainers/base.py:280-297 reads (rows of culled Gaussians untouched);
- *       v_viewmat_slots [BDS_POSE_GRAD_SLOTS + 2,4,4], zero-filled by the caller (e.g. as the tail of the gradient-record
- *       allocation): rows 0..SLOTS-1 receive camera-pose gradient partials (replicated accumulators: one address would serialise in
- *       L2), row SLOTS receives their sum = d(loss)/d(viewmat) (models/trainers/base.py:328-329,399), written by the last workgroup
- *       to finish; row SLOTS+1 is its arrival counter.
+ *       v_viewmat_slots [BDS_POSE_GRAD_SLOTS,4,4]: camera-pose gradient partials, ADDED to (the caller zero-fills them, e.g. as the
+ *       tail of the gradient-record allocation; replicated accumulators: one address would serialise in L2); the sum over the slots
+ *       is d(loss)/d(viewmat), models/trainers/base.py:328-329,399.
  * row_map (may be NULL) [N] i32: the parameter-gradient row of Gaussian g is row_map[g] instead of g -- the rows then land in a
  * compact exchange buffer (multi-GPU: the slot of g in the union of the ranks' visible sets) instead of the dense arrays. */
 #define BDS_POSE_GRAD_SLOTS 64

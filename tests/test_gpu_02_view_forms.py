@@ -62,7 +62,7 @@ def test_project_view_equals_general_form_with_activations(env, seed, N, W, H):
                                 L.ptr(ref_vm), st), "ref bwd")
     for acc in (0, 1):
         out = [torch.full((N, k), 7.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 7.0, device="cuda")]
-        slots = torch.zeros(L.POSE_GRAD_SLOTS + 2, 4, 4, device="cuda")            # camera-pose gradient partials + their sum (trainers/base.py:328-329,399)
+        slots = torch.zeros(L.POSE_GRAD_SLOTS, 4, 4, device="cuda")                # camera-pose gradient partials (trainers/base.py:328-329,399)
         g2d, ag2d = torch.full((N, 2), 7.0, device="cuda"), torch.full((N, 2), 7.0, device="cuda")
         L.check(lib.bds_project_view_bwd_list(n, L.ptr(ids), L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K),
                                               W, H, 0.3, L.ptr(v_rec), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), L.ptr(slots),
@@ -76,14 +76,13 @@ def test_project_view_equals_general_form_with_activations(env, seed, N, W, H):
         assert torch.allclose(out[3][il] - base, (v_op * opac * (1 - opac))[il], rtol=1e-5, atol=1e-6 + 1e-6 * base)
         assert bool((out[3][~vis] == 7.0).all())
         assert torch.equal(g2d[il], v_rec[:, 7:9]) and torch.equal(ag2d[il], v_rec[:, 9:11]) and bool((g2d[~vis] == 7.0).all())
-        v_vm = slots[L.POSE_GRAD_SLOTS]
-        assert float((v_vm - slots[:L.POSE_GRAD_SLOTS].sum(0)).abs().max()) <= 1e-6 * float(v_vm.abs().max())
+        v_vm = slots.sum(0)
         assert float(ref_vm[0, :3].abs().max()) > 0 and float(v_vm[3].abs().max()) == 0.0
         assert float((v_vm - ref_vm[0]).norm()) <= 1e-4 * float(ref_vm.norm())      # reduction order differs
     # without a pose gradient buffer nothing else changes
     out2 = [torch.zeros(N, k, device="cuda") for k in (3, 4, 3)] + [torch.zeros(N, device="cuda")]
     out3 = [torch.zeros(N, k, device="cuda") for k in (3, 4, 3)] + [torch.zeros(N, device="cuda")]
-    slots = torch.zeros(L.POSE_GRAD_SLOTS + 2, 4, 4, device="cuda")
+    slots = torch.zeros(L.POSE_GRAD_SLOTS, 4, 4, device="cuda")
     for o, sl in ((out2, None), (out3, slots)):
         L.check(lib.bds_project_view_bwd_list(n, L.ptr(ids), L.ptr(s["means"]), L.ptr(s["quats"]), L.ptr(scales), L.ptr(opac), L.ptr(vm), L.ptr(K),
                                               W, H, 0.3, L.ptr(v_rec), L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.ptr(o[3]), L.ptr(sl), None, None,
