@@ -334,7 +334,7 @@ def main():
     calls, mean_ms = tsum.get(dom, (0, float("nan")))
     alg_bytes = 92.0 * M_mean + 28.0 * P
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if calls else float("nan")
-    kname = "rasterize_bwd_wave_kernel<4, true>"
+    kname = "rasterize_bwd_wave_kernel<4, true, true, false>"   # <CH, absgrad, coarse lists, strip skip> of the fused view
     traffic, traffic_src = _newest_profile("_pmc.json", kname, "hbm_bytes_per_launch_corrected")
     roofline = {"bound": "hbm", "kernel": "bds::" + kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -340,6 +340,7 @@ class _FusedView(torch.autograd.Function):
                 off += sizes[i]
         if pre is not None:
             _, lv, _sel_keepalive, v_render, v_alphas, v_sky = pre
+            ctx.bwd_pre = pre = None   # (a second owner of v_sky would make autograd copy it instead of adopting it as sky.grad)
         else:
             idx = cfg.get("img_idx")
             sel = list(grids) if idx is None else [g[idx:idx + 1] for g in grids]
