@@ -369,7 +369,7 @@ template <int kBins>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
     const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
     const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
-    uint32_t rank_mask, uint32_t *__restrict__ vals_out) {
+    uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out, int n_offsets) {
   constexpr int kPer = kBins / kSortBlock;   // digits per thread (consecutive: thread t owns [t * kPer, (t + 1) * kPer))
   const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
   if (bbase >= n) return;
@@ -413,6 +413,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
       const int d = tid * kPer + u;
       dstart[d] = base;
       gbase[d] = d <= (int)mask ? hist_scanned[(int64_t)d * nblocks + blockIdx.x] : 0u;
+      // when this pass covers the whole tile key, the first workgroup's bases ARE the per-tile offsets (entries with a smaller key)
+      if (offsets_out && blockIdx.x == 0 && d < n_offsets) offsets_out[d] = (int32_t)gbase[d];
       uint32_t b2 = base;
 #pragma unroll
       for (int w = 0; w < kSortWaves; w++) {
@@ -483,7 +485,8 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
 
 
 static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int shift, int bits, uint32_t *temp, hipStream_t st,
-                           const uint32_t *unpack, uint32_t rank_mask, uint32_t *vout) {
+                           const uint32_t *unpack, uint32_t rank_mask, uint32_t *vout, int32_t *offsets_out = nullptr,
+                           int n_offsets = 0) {
   if (n == 0) return BDS_OK;
   const int nblocks = (int)cdiv(n, kSortChunk);
   const uint32_t mask = (1u << bits) - 1u;
@@ -502,10 +505,10 @@ static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int s
   if (rc != BDS_OK) return rc;
   if (bits == 9) {
     hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks,
-                       hist, kout, unpack, rank_mask, vout);
+                       hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
   } else if (bits > 9) {
     hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks,
-                       hist, kout, unpack, rank_mask, vout);
+                       hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
   } else {
     hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks, hist,
                        kout, unpack, rank_mask, vout);
@@ -1192,6 +1195,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   const int npass = (nbits + max_digit - 1) / max_digit;
   const int bits_per = (nbits + npass - 1) / npass;
   int key_shift = 0;
+  bool offsets_fused = false;
   uint32_t *kin;
   if (packed) {
     key_shift = rank_bits;
@@ -1206,8 +1210,10 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
       int bits = bits_per;
       if (bits_per * (p + 1) > nbits) bits = nbits - bits_per * p;
       const bool last = p == npass - 1;
+      // a single wide pass over the whole tile key also yields the per-tile offsets (no separate launch)
+      offsets_fused = npass == 1 && bits > 8 && !isect_ids;
       int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, last ? P.va : nullptr, rank_mask,
-                               last ? fl : nullptr);
+                               last ? fl : nullptr, offsets_fused ? isect_offsets : nullptr, n_tiles_total);
       if (rc != BDS_OK) return rc;
       kin = kout;
     }
@@ -1232,9 +1238,11 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     }
   }
   // now kin == B.kb (sorted tile keys, or packed words), flatten_ids holds the Gaussian ids
-  hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
-                     n_tiles_total, isect_offsets);
-  BDS_LAUNCH_CHECK();
+  if (!offsets_fused) {
+    hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
+                       n_tiles_total, isect_offsets);
+    BDS_LAUNCH_CHECK();
+  }
   if (isect_ids) {
     hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)cdiv(M, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
                        flatten_ids, depths, isect_ids);

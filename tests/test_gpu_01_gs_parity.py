@@ -144,6 +144,9 @@ def test_isect_bit_exact_other_tile_sizes(ops, seed, N, W, H, ts):
     assert torch.equal(tpg.cpu()[0], t) and torch.equal(iids.cpu(), k) and torch.equal(fids.cpu().long(), v.long())
     ref_off = torch.searchsorted((k >> 32).contiguous(), torch.arange(tw * th)).to(torch.int32).reshape(1, th, tw)
     assert torch.equal(offs.cpu(), ref_off)
+    # without the 64-bit keys the offsets come out of the (single, wide) tile pass itself
+    tpg2, _, fids2, offs2 = ops.isect_tiles(m2, radii, d, ts, tw, th, want_isect_ids=False)
+    assert torch.equal(tpg2, tpg) and torch.equal(fids2, fids) and torch.equal(offs2.cpu(), ref_off)
     # culled lists: a subset of the pairs, same order
     op = sc["opacities"].cuda()[None].contiguous()
     tpg_c, _, fids_c, offs_c = ops.isect_tiles(m2, radii, d, ts, tw, th, want_isect_ids=False, conics=con, opacities=op)
