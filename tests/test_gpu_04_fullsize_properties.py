@@ -231,3 +231,30 @@ def test_other_baseline_configs_fullsize_properties(name):
     fx.end_frame()
     got = torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids])
     assert float((got - ref).norm() / ref.norm()) < 1e-4
+
+
+def test_fullsize_coarse_lists_equal_16px_lists(full):
+    """Benchmark size: the fused view through 64-px list tiles (its default) gives bit for bit the image of gsplat's 16-px lists and
+    the same gradients; the 64-px lists are a fraction of the 16-px ones."""
+    Hn, p0, cam, W, H = full["Hn"], full["p"], full["cam"], full["W"], full["H"]
+    from bilateral_driving_amd.fused_view import fused_view
+    grids0 = Hn.make_grids(1, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    sky, target = torch.rand(H, W, 3, generator=g).cuda(), torch.rand(H, W, 3, generator=g).cuda()
+    res = {}
+    for lt in (16, 64):
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in p0.items()}
+        grids = [x.clone().requires_grad_(True) for x in grids0]
+        out = fused_view(p, cam.viewmat, cam.K, W, H, grids, sky, Hn.FACTORS_3, img_idx=0, cam_pos=cam.cam_pos, list_tile=lt)
+        ((out["rgb"] - target).abs().mean() + 0.01 * out["depth"].mean()).backward()
+        res[lt] = (out["rgb"].detach(), out["depth"].detach(), out["opacity"].detach(), {k: v.grad for k, v in p.items()},
+                   [x.grad for x in grids], out["info"]["means2d"].absgrad, out["info"]["n_isects"])
+        del out
+    a, b = res[16], res[64]
+    assert b[6] * 4 < a[6]                                              # several times fewer pairs to emit and sort
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert float((a[3][k] - b[3][k]).norm()) <= 2e-5 * float(a[3][k].norm()), k          # atomics: summation order only
+    for x, y in zip(a[4], b[4]):
+        assert float((x - y).norm()) <= 2e-5 * float(x.norm())
+    assert float((a[5] - b[5]).norm()) <= 2e-5 * float(a[5].norm())
