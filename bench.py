@@ -235,7 +235,7 @@ def main():
     cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev, origin=(1.5 * rank, 0.0, 0.0))   # this rank's timestep of the drive
     V = min(args.views_per_step or len(cams), len(cams))
     for cam in cams:   # the camera pose is learnable in the reference (trainers/base.py:328-329,399): its gradient stays live
-        cam.viewmat.requires_grad_(True)
+        cam.viewmat.requires_grad_(os.environ.get("BDS_BENCH_NO_POSE") != "1")   # (diagnostic switch)
     params = Hn.synthetic_scene(N, seed=0, device=dev)
     for v in params.values():
         v.requires_grad_(True)
@@ -302,7 +302,7 @@ def main():
     stats.clear()
     # inside the timed region only the dominant kernel is bracketed by HIP events (every pair is two more packets on the stream);
     # the per-operator table is taken from a few extra, untimed steps afterwards
-    L.enable_timers(True, only=("rasterize_bwd",))
+    L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))   # (diagnostic switch)
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
         step(s)

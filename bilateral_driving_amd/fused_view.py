@@ -70,16 +70,22 @@ class _Info(dict):
 
 
 class _Out(dict):
-    """Result dict of the fused view; ``rgb_gaussians`` (the reference's ``clamp(rendered_rgb, max=1.0)``, trainers/base.py:414, only
-    used for inspection: the transform consumes the clamp fused) is materialised on first access."""
+    """Result dict of the fused view.  Two of the reference trainer's outputs are only used for inspection / the (zero-weighted)
+    cycle term and are materialised on first access, detached: ``rgb_gaussians`` = ``clamp(rendered_rgb, max=1.0)``
+    (trainers/base.py:414; the transform consumes the clamp fused) and ``original_rgb`` = the colour entering the transform,
+    ``rgb_gaussians + rgb_sky * (1 - opacity)`` (trainers/base.py:496-498)."""
+    _LAZY = ("rgb_gaussians", "original_rgb")
 
     def __getitem__(self, k):
-        if k == "rgb_gaussians" and not dict.__contains__(self, k):
-            dict.__setitem__(self, k, dict.__getitem__(self, "_rgb_g_raw").clamp(max=1.0))
+        if k in self._LAZY and not dict.__contains__(self, k):
+            g = dict.__getitem__(self, "_rgb_g_raw").detach().clamp(max=1.0)
+            if k == "original_rgb":
+                g = g + dict.__getitem__(self, "_sky").detach() * (1.0 - dict.__getitem__(self, "opacity").detach())
+            dict.__setitem__(self, k, g)
         return dict.__getitem__(self, k)
 
     def __contains__(self, k):
-        return k == "rgb_gaussians" or dict.__contains__(self, k)
+        return k in self._LAZY or dict.__contains__(self, k)
 
 
 class _Front:
@@ -463,7 +469,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                   "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets,
                   "tile_size": cfg["list_tile"],   # of the lists in this dict (the compositor subdivides into 16 x 16)
                   "n_cameras": 1, "n_isects": int(flatten_ranks.numel()), "n_visible": int(vis_ids.numel())})
-    return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)
+    return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
 
 
 @torch.no_grad()
@@ -623,4 +629,4 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         for g, a, b in zip(gs, v_tv_grids, grads[8:]):
             _accumulate(g, a)
             _accumulate(g, b)
-    return _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, info=info)
+    return _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)

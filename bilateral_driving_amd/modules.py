@@ -166,6 +166,33 @@ class MultiScaleBilateralAffineTransform(nn.Module):
         self.save_matrix = out_list
         return out_list
 
+    def inverse_loss(self, gt: Tensor, render: Tensor) -> Tensor:
+        """modules.py:474-492 (weighted by ``losses.affine.w1`` at trainers/base.py:630-632): mean |T^-1(gt) - render| with T the
+        composition of the per-pixel 3x4 maps of the LAST ``forward()`` call (``save_matrix``).  The reference inverts one 4x4
+        homogeneous matrix per pixel with ``torch.inverse``; the same inverse is formed here in closed form (3x3 adjugate of the
+        composed linear part, shift = -inv . shift): identical mathematics, no batched LU over H*W matrices."""
+        assert self.save_matrix is not None, "inverse_loss uses the maps of the preceding forward() call"
+        lin, shift = None, None
+        for arr in self.save_matrix:                       # T <- A_l o T   (hom_arr @ mat, modules.py:479-481)
+            A, t = arr[..., :3, :3], arr[..., :3, 3]
+            if lin is None:
+                lin, shift = A, t
+            else:
+                lin, shift = A @ lin, (A @ shift[..., None])[..., 0] + t
+        a, b, c = lin[..., 0, 0], lin[..., 0, 1], lin[..., 0, 2]
+        d, e, f = lin[..., 1, 0], lin[..., 1, 1], lin[..., 1, 2]
+        g, h, i = lin[..., 2, 0], lin[..., 2, 1], lin[..., 2, 2]
+        c00, c01, c02 = e * i - f * h, c * h - b * i, b * f - c * e
+        c10, c11, c12 = f * g - d * i, a * i - c * g, c * d - a * f
+        c20, c21, c22 = d * h - e * g, b * g - a * h, a * e - b * d
+        det = a * c00 + b * c10 + c * c20
+        inv = torch.stack([torch.stack([c00, c01, c02], -1), torch.stack([c10, c11, c12], -1), torch.stack([c20, c21, c22], -1)], -2) \
+            / det[..., None, None]
+        inv = inv.reshape(gt.shape[0], gt.shape[1], 3, 3)
+        inv_shift = -(inv @ shift.reshape(gt.shape[0], gt.shape[1], 3, 1))[..., 0]
+        gt_transformed = (inv @ gt[..., None])[..., 0] + inv_shift
+        return torch.abs(gt_transformed - render).mean()
+
     def transform(self, rgb: Tensor, image_infos, guidance_factor: Sequence[int] = (4, 4, 2), alpha: Optional[Tensor] = None,
                   sky: Optional[Tensor] = None) -> Tensor:
         """Fused fast path: equals the trainer's composition of forward()'s maps (scene_graph.py:112-117)."""

@@ -45,3 +45,22 @@ def test_checkpoint_container_round_trip(tmp_path):
     assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
     with pytest.raises(RuntimeError):      # strict: a shape the file does not have
         load_checkpoint(p, {"AffineCode": AffineTransform("AffineCode", n=4, device="cpu")})
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_inverse_loss_equals_reference_golden(name):
+    """MultiScaleBilateralAffineTransform.inverse_loss (modules.py:474-492) in closed form against the reference's per-pixel
+    torch.inverse of the composed homogeneous matrix (golden: oracle/gen_golden_inverse_loss.py)."""
+    from bilateral_driving_amd.modules import MultiScaleBilateralAffineTransform
+    z = np.load(os.path.join(G, f"inverse_loss_{name}.npz"))
+    mod = MultiScaleBilateralAffineTransform("Affine", n=2, grid=[[2, 2, 1], [4, 4, 2], [8, 8, 4]], device="cpu")
+    maps = [torch.from_numpy(z[f"map{i}"]).requires_grad_(True) for i in range(3)]
+    mod.save_matrix = maps
+    render = torch.from_numpy(z["render"]).requires_grad_(True)
+    loss = mod.inverse_loss(torch.from_numpy(z["gt"]), render)
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=2e-6)
+    loss.backward()
+    np.testing.assert_allclose(render.grad.numpy(), z["v_render"], rtol=1e-6, atol=1e-9)
+    for i, m in enumerate(maps):
+        ref = z[f"v_map{i}"]
+        assert np.linalg.norm(m.grad.numpy() - ref) <= 2e-5 * np.linalg.norm(ref), i

@@ -203,6 +203,8 @@ def test_rasterization_api_pose_gradient_and_fused_equivalence(ops):
             out = Hn.render_view(p, cam, grids, 0, sky)
             rgb = out["rgb"]
             assert float((out["rgb_gaussians"].max())) <= 1.0      # base.py:414 clamp(max=1.0)
+            assert "original_rgb" in out                           # base.py:496-498: the colour entering the transform
+            assert torch.equal(out["original_rgb"], out["rgb_gaussians"] + sky * (1.0 - out["opacity"].detach()))
         else:
             dirs = p["means"].detach() - torch.linalg.inv(cam.viewmat.detach())[:3, 3]
             col = torch.clamp(ops.spherical_harmonics(3, dirs, p["sh"]) + 0.5, 0.0, 1.0)
