@@ -353,6 +353,8 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
 
     get_sample_grid = MultiScaleBilateralAffineTransform.get_sample_grid
 
+    get_sample_grid = MultiScaleBilateralAffineTransform.get_sample_grid   # the reference's helper of the same name (low-res colour + xy grid)
+
     def forward(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
         assert "img_idx" in image_infos
         k = _img_index(image_infos)
