@@ -51,7 +51,8 @@ _SIGS = {
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
+    "bds_splat_pack_sh": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),
     "bds_view_grads_add_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),

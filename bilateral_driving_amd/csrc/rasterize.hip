@@ -68,6 +68,51 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n, const
                                __int_as_float(radii ? radii[g] : kUnboundedRadius));
 }
 
+// The same for the fused view, with the colour evaluated on the way (models/gaussians/vanilla.py:383-389: SH of the normalised view
+// direction means - cam_pos, + 0.5, clamp to [0, 1]; channel 3 = depth for the RGB+ED composite): record r is the visible Gaussian
+// ids[r].  Evaluating the SH colours HERE, for the visible Gaussians only and in list order, replaces a pass over all N Gaussians
+// that wrote two dense per-Gaussian arrays nobody reads for the culled 85 %.  sh_rgb_out [n,3] keeps the un-clamped colour of record
+// r: the backward needs to know where the clamp was active.
+template <int DEG>
+__global__ __launch_bounds__(kPackBlock) void splat_pack_sh_kernel(int64_t n, const int32_t *__restrict__ ids, int K,
+                                                                  const float *__restrict__ means, const float *__restrict__ cam_pos,
+                                                                  const float *__restrict__ coeffs, const float *__restrict__ means2d,
+                                                                  const float *__restrict__ conics, const float *__restrict__ depths,
+                                                                  const float *__restrict__ opacities, const int32_t *__restrict__ radii,
+                                                                  float4 *__restrict__ rec, float *__restrict__ sh_rgb_out) {
+  constexpr int nb = (DEG + 1) * (DEG + 1);
+  const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
+  if (r >= n) return;
+  const int64_t g = ids[r];
+  const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
+  const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
+  float B[16];
+  sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
+  const float4 *c4 = reinterpret_cast<const float4 *>(coeffs + g * (int64_t)K * 3);   // K * 3 floats, 16-byte aligned (checked by the caller)
+  float cf[nb * 3 + 3];
+  constexpr int n4 = (nb * 3 + 3) / 4;
+#pragma unroll
+  for (int i = 0; i < n4; i++) {
+    if (i * 4 < K * 3) {
+      const float4 v = c4[i];
+      cf[i * 4] = v.x; cf[i * 4 + 1] = v.y; cf[i * 4 + 2] = v.z; cf[i * 4 + 3] = v.w;
+    }
+  }
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < nb; k++) {
+    o0 += B[k] * cf[k * 3];
+    o1 += B[k] * cf[k * 3 + 1];
+    o2 += B[k] * cf[k * 3 + 2];
+  }
+  sh_rgb_out[r * 3] = o0; sh_rgb_out[r * 3 + 1] = o1; sh_rgb_out[r * 3 + 2] = o2;
+  const float2 xy = *reinterpret_cast<const float2 *>(means2d + g * 2);
+  const float *cn = conics + g * 3;
+  rec[r * 3] = make_float4(xy.x, xy.y, (-0.5f * kLog2e) * cn[0], -kLog2e * cn[1]);
+  rec[r * 3 + 1] = make_float4((-0.5f * kLog2e) * cn[2], opacities[g], fminf(fmaxf(o0 + 0.5f, 0.f), 1.f), fminf(fmaxf(o1 + 0.5f, 0.f), 1.f));
+  rec[r * 3 + 2] = make_float4(fminf(fmaxf(o2 + 0.5f, 0.f), 1.f), depths[g], 0.f, __int_as_float(radii[g]));
+}
+
 // exponent (base 2) of a Gaussian at a pixel of the lane's column: ea dx^2 + (ec dy + eb dx) dy, <= 0 for a valid conic.
 // ONE definition shared by the forward and the backward: their alpha decisions have to agree bit for bit.
 __device__ __forceinline__ float splat_exponent(float eadx2, float ebdx, float ec, float dy) {
@@ -506,6 +551,30 @@ extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float
   if (CH == 1) hipLaunchKernelGGL((splat_pack_kernel<1>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
   else if (CH == 3) hipLaunchKernelGGL((splat_pack_kernel<3>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
   else hipLaunchKernelGGL((splat_pack_kernel<4>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
+                                 const float *coeffs, const float *means2d, const float *conics, const float *depths,
+                                 const float *opacities, const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(ids && means && cam_pos && coeffs && means2d && conics && depths && opacities && radii && records && sh_rgb);
+  BDS_REQUIRE(aligned16(records) && aligned16(coeffs) && (K * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
+  const dim3 grid((unsigned)cdiv(n, kPackBlock)), block(kPackBlock);
+  float4 *rec = reinterpret_cast<float4 *>(records);
+  hipStream_t st = as_stream(stream);
+#define BDS_PACK_SH(d)                                                                                                              \
+  hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, 0, st, n, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
+                     opacities, radii, rec, sh_rgb)
+  switch (deg) {
+    case 0: BDS_PACK_SH(0); break;
+    case 1: BDS_PACK_SH(1); break;
+    case 2: BDS_PACK_SH(2); break;
+    default: BDS_PACK_SH(3); break;
+  }
+#undef BDS_PACK_SH
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

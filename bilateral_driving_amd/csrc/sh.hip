@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
                                                                    const float *__restrict__ cam_pos,
                                                                    const float *__restrict__ sh_rgb,
                                                                    const float4 *__restrict__ v_rec, float *__restrict__ v_coeffs,
-                                                                   const int32_t *__restrict__ row_map) {
+                                                                   const int32_t *__restrict__ row_map, int sh_rgb_by_rank) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int32_t s_g[kShBlock];   // destination row of each staged entry
   constexpr int nb = (DEG + 1) * (DEG + 1);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
     float vo[3] = {v.x, v.y, v.z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const float x = sh_rgb[g * 3 + k] + 0.5f;
+      const float x = sh_rgb[(sh_rgb_by_rank ? r0 + tid : g) * 3 + k] + 0.5f;   // [N,3] by Gaussian, or [n_list,3] in list order
       if (!(x >= 0.f && x <= 1.f)) vo[k] = 0.f;   // torch.clamp passes the gradient on the closed interval
     }
     const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
@@ -468,18 +468,18 @@ extern "C" int bds_sh_view_fwd(int64_t n, int K, int deg, const float *means, co
 template <int DEG>
 static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipStream_t st, int64_t n_list, const int32_t *ids, int K,
                                  const float *means, const float *cam_pos, const float *sh_rgb, const float4 *v_rec, float *v_coeffs,
-                                 const int32_t *row_map) {
+                                 const int32_t *row_map, int by_rank) {
 #define BDS_LIST(V, A)                                                                                                           \
   hipLaunchKernelGGL((sh_view_bwd_list_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), lds, st, n_list, ids, K, means, cam_pos, \
-                     sh_rgb, v_rec, v_coeffs, row_map)
+                     sh_rgb, v_rec, v_coeffs, row_map, by_rank)
   if (vec) { if (acc) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else     { if (acc) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST
 }
 
 extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
-                                    const float *sh_rgb, const float *v_records, float *v_coeffs, const int32_t *row_map,
-                                    int accumulate, bds_stream_t stream) {
+                                    const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs,
+                                    const int32_t *row_map, int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(n_list >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
   if (n_list == 0) return BDS_OK;
   BDS_REQUIRE(ids && means && cam_pos && sh_rgb && v_records && v_coeffs && aligned16(v_records));
@@ -489,10 +489,10 @@ extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, i
   hipStream_t st = as_stream(stream);
   const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
   switch (deg) {
-    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
-    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
-    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
-    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map); break;
+    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
   }
   BDS_LAUNCH_CHECK();
   return BDS_OK;

@@ -26,6 +26,9 @@ TILE = 16        # compositing tile (one wave64 per tile)
 # Tile the depth-ordered lists are built for (include/bds.h "coarse lists"): 16 = gsplat's lists; 64 = one pair per (64-px tile,
 # Gaussian), filtered per compositing tile as the chunks are staged -- several times fewer pairs to emit and sort.
 LIST_TILE = int(os.environ.get("BDS_LIST_TILE", "64"))
+# SH colours evaluated inside the splat-record pack, for the visible Gaussians only and in list order (bds_splat_pack_sh), instead of
+# a pass over all N Gaussians in front of the tile lists (bds_sh_view_fwd).  Needs 16-byte aligned coefficient rows (K * 3 % 4 == 0).
+SH_IN_PACK = os.environ.get("BDS_SH_IN_PACK", "1") == "1"
 
 
 def _empty(shape, dev, dtype=torch.float32):
@@ -93,7 +96,7 @@ class _Front:
     colours, per-tile lists (compact positions) and the ascending visible-id list.  Shared by the training forward and by the
     evaluation re-renders (``render_classes``), which composite several opacity masks over ONE such front."""
     __slots__ = ("means", "quats", "log_scales", "sh", "viewmat", "scales", "opac", "radii", "means2d", "depths", "conics", "cam_pos",
-                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N", "list_tile", "rec_buf", "pre")
+                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N", "list_tile", "rec_buf", "pre", "sh_by_rank", "sh_degree")
 
 
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
@@ -163,10 +166,13 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
     # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
     cam_pos = cfg["cam_pos"].contiguous()
-    sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
-    with L.timed("sh_fwd"):
-        L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
-                                    L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
+    if cfg.get("sh_in_pack", SH_IN_PACK) and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0:
+        sh_rgb, colors = None, None        # evaluated by the record pack, for the visible Gaussians only (_composite)
+    else:
+        sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
+        with L.timed("sh_fwd"):
+            L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
+                                        L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
     key = (N, W, H, bool(cull), LT)
     cap = _LIST_CAPACITY.get(key, 0)
     buf, ws2, ws2_bytes = None, None, 0
@@ -227,7 +233,7 @@ def _front_finish(s_: _FrontState, before_wait=None) -> _Front:
     f.cam_pos, f.sh_rgb, f.colors, f.tiles_per_gauss, f.isect_offsets = cam_pos, sh_rgb, colors, tiles_per_gauss, isect_offsets
     f.flatten, f.vis_ids, f.M, f.n_vis, f.W, f.H, f.N, f.list_tile = flatten, vis_ids, M, n_vis, W, H, N, LT
     f.tw, f.th = math.ceil(W / TILE), math.ceil(H / TILE)  # compositing tiles
-    f.rec_buf, f.pre = rec_buf, pre
+    f.rec_buf, f.pre, f.sh_by_rank, f.sh_degree = rec_buf, pre, False, cfg["sh_degree"]
     return f
 
 
@@ -247,9 +253,14 @@ def _composite(f: _Front, opac: Tensor, images=None):
         rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
     render, alphas, last_ids = images if images is not None else _image_buffers(W, H, dev)
     with L.timed("rasterize_fwd"):
-        L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac), L.ptr(f.radii),
-                                   L.ptr(rec), st),
-                "bds_splat_pack")
+        if f.colors is None:       # SH colours evaluated on the way; their un-clamped values stay in list order for the backward
+            f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
+            L.check(lib.bds_splat_pack_sh(n_vis, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh),
+                                          L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths), L.ptr(opac), L.ptr(f.radii), L.ptr(rec),
+                                          L.ptr(f.sh_rgb), st), "bds_splat_pack_sh")
+        else:
+            L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac),
+                                       L.ptr(f.radii), L.ptr(rec), st), "bds_splat_pack")
         L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th, L.ptr(f.isect_offsets), L.ptr(f.flatten),
                                       L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
     return rec, render, alphas, last_ids
@@ -280,6 +291,7 @@ class _FusedView(torch.autograd.Function):
         tiles_per_gauss, isect_offsets, flatten, vis_ids, M = f.tiles_per_gauss, f.isect_offsets, f.flatten, f.vis_ids, f.M
         images, sel, lv, bws_bytes, bws, rgb, depth = f.pre
         rec, render, alphas, last_ids = _composite(f, opac, images)
+        sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f.list_tile
         del f
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
@@ -401,7 +413,8 @@ class _FusedView(torch.autograd.Function):
         v_sh = out_like("sh", sh)
         with L.timed("sh_bwd"):
             L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
-                                             L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map), int(rows == 2), st), "bds_sh_view_bwd_list")
+                                             int(bool(getattr(ctx, "sh_by_rank", False))), L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map),
+                                             int(rows == 2), st), "bds_sh_view_bwd_list")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
@@ -519,7 +532,8 @@ def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width:
         cam_pos = torch.linalg.inv(viewmat)[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos, sh_degree=int(sh_degree), near_plane=float(near_plane),
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d), tile_cull=bool(tile_cull),
-               list_tile=int(LIST_TILE if list_tile is None else list_tile))
+               list_tile=int(LIST_TILE if list_tile is None else list_tile),
+               sh_in_pack=False)   # the colours are evaluated once and packed with every mask's opacities
     f = _view_front(cfg, params["means"].detach(), params["quats"].detach(), params["log_scales"].detach(),
                     params["opacity_logits"].detach(), params["sh"].detach(), viewmat.detach())
 

@@ -165,6 +165,13 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
 #define BDS_GRAD_RECORD_FLOATS 16
 int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
                    const float *opacities, const int32_t *radii /* [n entries] or NULL */, float *records, bds_stream_t stream);
+/* Splat records of the fused view with the SH colour evaluated on the way (vanilla.py:383-389: SH of normalise(means - cam_pos), + 0.5,
+ * clamp to [0,1]; channel 3 = depth): record r = visible Gaussian ids[r]; coeffs [N,K,3] with K*3 a multiple of 4 and 16-byte aligned
+ * rows; sh_rgb [n,3] receives the un-clamped colours in list order (for bds_sh_view_bwd_list with sh_rgb_by_rank).  Replaces
+ * bds_sh_view_fwd + bds_splat_pack on that path: the colours of the ~85 % culled Gaussians are never evaluated or stored. */
+int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
+                      const float *coeffs, const float *means2d, const float *conics, const float *depths, const float *opacities,
+                      const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream);
 int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
                       int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
                       const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
@@ -278,9 +285,11 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
  * row_map (may be NULL) [N] i32: the parameter-gradient row of Gaussian g is row_map[g] instead of g -- the rows then land in a
  * compact exchange buffer (multi-GPU: the slot of g in the union of the ranks' visible sets) instead of the dense arrays. */
 #define BDS_POSE_GRAD_SLOTS 64
+/* sh_rgb: the un-clamped colours the forward left -- [N,3] indexed by Gaussian (bds_sh_view_fwd), or, with sh_rgb_by_rank != 0,
+ * [n_list,3] in list order (bds_splat_pack_sh). */
 int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
-                         const float *sh_rgb, const float *v_records, float *v_coeffs, const int32_t *row_map, int accumulate,
-                         bds_stream_t stream);
+                         const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs, const int32_t *row_map,
+                         int accumulate, bds_stream_t stream);
 int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats, const float *scales,
                               const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
                               const float *v_records, float *v_means, float *v_quats, float *v_log_scales, float *v_logits,

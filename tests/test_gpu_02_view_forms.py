@@ -124,10 +124,28 @@ def test_sh_view_equals_general_form_with_glue(env, deg):
     L.check(lib.bds_sh_bwd(N, 16, deg, L.ptr(dirs.contiguous()), L.ptr(sh), L.ptr(mask8), L.ptr(v_rgb), L.ptr(ref_v), None, st), "ref bwd")
     for acc in (0, 1):
         v_sh = torch.full((N, 16, 3), 7.0, device="cuda")
-        L.check(lib.bds_sh_view_bwd_list(n, L.ptr(ids), 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(sh_rgb), L.ptr(v_rec), L.ptr(v_sh),
+        L.check(lib.bds_sh_view_bwd_list(n, L.ptr(ids), 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(sh_rgb), 0, L.ptr(v_rec), L.ptr(v_sh),
                                          None, acc, st), "bwd list")
         assert torch.allclose(v_sh[il] - 7.0 * acc, ref_v[il], rtol=1e-5, atol=2e-6 + 1e-5 * acc)
         assert bool((v_sh[~vis] == 7.0).all())                                    # culled rows untouched
+    # the same colours evaluated by the record pack (visible entries only, in list order) + the backward fed from its compact sh_rgb
+    m2 = torch.rand(N, 2, device="cuda") * 100.0
+    con = torch.rand(N, 3, device="cuda") + 0.1
+    opac = torch.rand(N, device="cuda")
+    rec = torch.full((n, L.SPLAT_RECORD_FLOATS), -1.0, device="cuda")
+    sh_rgb_c = torch.empty(n, 3, device="cuda")
+    L.check(lib.bds_splat_pack_sh(n, L.ptr(ids), 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(sh), L.ptr(m2), L.ptr(con), L.ptr(dep),
+                                  L.ptr(opac), L.ptr(radii), L.ptr(rec), L.ptr(sh_rgb_c), st), "pack sh")
+    ref_rec = torch.empty(n, L.SPLAT_RECORD_FLOATS, device="cuda")
+    L.check(lib.bds_splat_pack(n, 4, L.ptr(ids), L.ptr(m2), L.ptr(con), L.ptr(colors), L.ptr(opac), L.ptr(radii), L.ptr(ref_rec), st), "pack")
+    assert torch.equal(rec.view(torch.int32)[:, 11], ref_rec.view(torch.int32)[:, 11])        # radius slot
+    assert torch.equal(rec[:, :6], ref_rec[:, :6]) and torch.equal(rec[:, 9], ref_rec[:, 9])     # geometry, opacity, depth channel
+    assert torch.allclose(rec[:, 6:9], ref_rec[:, 6:9], rtol=1e-6, atol=1e-6)                     # colour (separately compiled SH sums)
+    assert torch.allclose(sh_rgb_c, sh_rgb[il], rtol=1e-6, atol=1e-6)
+    v_sh2 = torch.zeros(N, 16, 3, device="cuda")
+    L.check(lib.bds_sh_view_bwd_list(n, L.ptr(ids), 16, deg, L.ptr(s["means"]), L.ptr(cam_pos), L.ptr(sh_rgb_c), 1, L.ptr(v_rec), L.ptr(v_sh2),
+                                     None, 0, st), "bwd list by rank")
+    assert torch.allclose(v_sh2[il], ref_v[il], rtol=1e-5, atol=2e-6)
     # row-wise clear
     bufs = [torch.full((N, k), 3.0, device="cuda") for k in (3, 4, 3)] + [torch.full((N,), 3.0, device="cuda"), torch.full((N, 16, 3), 3.0, device="cuda")]
     L.check(lib.bds_view_grads_clear_list(n, L.ptr(ids), 16, *[L.ptr(b) for b in bufs], st), "clear list")
