@@ -26,9 +26,11 @@ TILE = 16        # compositing tile (one wave64 per tile)
 # Tile the depth-ordered lists are built for (include/bds.h "coarse lists"): 16 = gsplat's lists; 64 = one pair per (64-px tile,
 # Gaussian), filtered per compositing tile as the chunks are staged -- several times fewer pairs to emit and sort.
 LIST_TILE = int(os.environ.get("BDS_LIST_TILE", "64"))
-# SH colours evaluated inside the splat-record pack, for the visible Gaussians only and in list order (bds_splat_pack_sh), instead of
-# a pass over all N Gaussians in front of the tile lists (bds_sh_view_fwd).  Needs 16-byte aligned coefficient rows (K * 3 % 4 == 0).
-SH_IN_PACK = os.environ.get("BDS_SH_IN_PACK", "1") == "1"
+# Opt-in, measured slower: SH colours evaluated inside the splat-record pack, for the visible Gaussians only and in list order
+# (bds_splat_pack_sh), instead of a pass over all N Gaussians in front of the tile lists (bds_sh_view_fwd).  One thread per record
+# gathering its own 192-byte coefficient row costs more than it saves: pack + forward composite 183 -> 237 us for 48 us of SH pass
+# removed (profiles/r02x).  Needs 16-byte aligned coefficient rows (K * 3 % 4 == 0).
+SH_IN_PACK = os.environ.get("BDS_SH_IN_PACK", "0") == "1"
 
 
 def _empty(shape, dev, dtype=torch.float32):
