@@ -311,3 +311,11 @@ def test_frame_exchange_single_process_uses_the_arena_modes():
     fx.end_view()
     fx.end_frame()
     assert flat._dirty is not None and len(flat._dirty) == 1
+    # the small dense tail (grids) is accumulated in place at world size 1: begin_frame zeroes it and makes it the .grad
+    tail = fx.tail_grads()
+    assert tail is not None and len(tail) == 1 and tail[0].shape == params[5].shape
+    assert params[5].grad is not None and params[5].grad.data_ptr() == tail[0].data_ptr() and float(tail[0].abs().max()) == 0.0
+    tail[0].add_(1.0)
+    fx.begin_frame()
+    assert float(fx.tail_grads()[0].abs().max()) == 0.0 and params[5].grad.data_ptr() == fx.tail_grads()[0].data_ptr()
+    assert fx.tail_grads("nope") == []
