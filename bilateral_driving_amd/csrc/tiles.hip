@@ -571,12 +571,35 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
   const int nb = (int)((n + kShortChunk - 1) >> kChunkShift), ng = (nb + (1 << kGroupShift) - 1) >> kGroupShift;
   const int gb = (int)blockIdx.x >> kGroupShift;
   uint32_t below = 0, total = 0;
-  for (int g = 0; g < ng; g++) {
-    const uint32_t c = ghist[(int64_t)g * 256 + tid];
-    total += c;
-    if (g < gb) below += c;
+  {
+    int g = 0;
+    for (; g + 4 <= ng; g += 4) {   // (independent loads first, then the sums: see the row loop below)
+      const uint32_t *q = ghist + (int64_t)g * 256 + tid;
+      const uint32_t c0 = q[0], c1 = q[256], c2 = q[512], c3 = q[768];
+      total += (c0 + c1) + (c2 + c3);
+      below += (g < gb ? c0 : 0u) + (g + 1 < gb ? c1 : 0u) + (g + 2 < gb ? c2 : 0u) + (g + 3 < gb ? c3 : 0u);
+    }
+    for (; g < ng; g++) {
+      const uint32_t c = ghist[(int64_t)g * 256 + tid];
+      total += c;
+      if (g < gb) below += c;
+    }
   }
-  for (int b = gb << kGroupShift; b < (int)blockIdx.x; b++) below += hist[(int64_t)b * 256 + tid];
+  {
+    // up to 63 rows of the workgroup-major histogram: EIGHT independent partial sums, so that eight loads are in flight at a time
+    // (a single running sum serialises the L2 latency of every row: that chain was most of this kernel's 14 us)
+    const uint32_t *hp = hist + ((int64_t)gb << kGroupShift) * 256 + tid;
+    const int nrows = (int)blockIdx.x - (gb << kGroupShift);
+    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {
+      const uint32_t *q = hp + (int64_t)r * 256;
+      const uint32_t a0 = q[0], a1 = q[256], a2 = q[512], a3 = q[768], a4 = q[1024], a5 = q[1280], a6 = q[1536], a7 = q[1792];
+      p0 += a0; p1 += a1; p2 += a2; p3 += a3; p4 += a4; p5 += a5; p6 += a6; p7 += a7;
+    }
+    for (; r < nrows; r++) p0 += hp[(int64_t)r * 256];
+    below += ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+  }
   uint32_t all;
   const uint32_t digit_base = block_excl_scan(total, all, lw);   // (contains the barrier that publishes wrun = 0)
   constexpr int kPerWave = kShortChunk / kSortWaves;
