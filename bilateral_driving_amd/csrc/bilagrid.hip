@@ -610,14 +610,37 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
     int ilo, ihi, jlo, jhi;
     adjoint_range(y, L.Hd, L.up_y, ilo, ihi);
     adjoint_range(x, L.Wd, L.up_x, jlo, jhi);
-    for (int i = ilo; i <= ihi; i++) {
-      const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y);
-      const float wy = (ty.i0 == y ? 1.f - ty.w1 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
-      if (wy == 0.f) continue;
-      for (int j = jlo; j <= jhi; j++) {
-        const Tap tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
-        const float wx = (tx.i0 == x ? 1.f - tx.w1 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
-        if (wx != 0.f) vg += wy * wx * L.vg[(int64_t)i * L.Wd + j];
+    if (ihi - ilo < 3 && jhi - jlo < 3) {
+      // the usual case (factor >= 2: at most three candidates per axis): weights first, then ALL loads, then the sum in the order
+      // of the general loops below -- those wait out one memory latency per candidate, the dominant cost of this kernel
+      float wy[3], wx[3], val[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const int i = ilo + a, j = jlo + a;
+        const Tap ty = resample_tap_s(i <= ihi ? i : ihi, L.Hd, p.H, L.dn_y), tx = resample_tap_s(j <= jhi ? j : jhi, L.Wd, p.W, L.dn_x);
+        wy[a] = i <= ihi ? (ty.i0 == y ? 1.f - ty.w1 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f) : 0.f;
+        wx[a] = j <= jhi ? (tx.i0 == x ? 1.f - tx.w1 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f) : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+          val[a][b] = (wy[a] != 0.f && wx[b] != 0.f) ? L.vg[(int64_t)(ilo + a) * L.Wd + (jlo + b)] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+          if (wy[a] != 0.f && wx[b] != 0.f) vg += wy[a] * wx[b] * val[a][b];
+    } else {
+      for (int i = ilo; i <= ihi; i++) {
+        const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y);
+        const float wy = (ty.i0 == y ? 1.f - ty.w1 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int j = jlo; j <= jhi; j++) {
+          const Tap tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
+          const float wx = (tx.i0 == x ? 1.f - tx.w1 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
+          if (wx != 0.f) vg += wy * wx * L.vg[(int64_t)i * L.Wd + j];
+        }
       }
     }
   }

@@ -169,21 +169,33 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
   if (r < n_list) {
     const int64_t g = ids[r];
     const float4 r0 = v_rec[r * 4], r1 = v_rec[r * 4 + 1], r2 = v_rec[r * 4 + 2];
+    // every gather that depends on g is issued here, in front of the arithmetic -- including, in accumulate mode, the eleven old
+    // gradient values: read next to the stores that update them, each would wait out a full memory latency behind the previous
+    // store (the compiler may not move a load of an array above a store to it)
     const float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
     const float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
     const float s[3] = {scales[g * 3], scales[g * 3 + 1], scales[g * 3 + 2]};
+    const float o = opacities[g];
+    const int64_t d = row_map ? (int64_t)row_map[g] : g;   // destination row of the parameter gradients
+    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_q[4] = {0.f, 0.f, 0.f, 0.f}, old_l = 0.f;
+    if (kAcc) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { old_m[i] = v_means[d * 3 + i]; old_s[i] = v_log_scales[d * 3 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) old_q[i] = v_quats[d * 4 + i];
+      old_l = v_logits[d];
+    }
     Camera cam = load_camera(viewmat, K);
     project_one_vjp(m, q, s, cam, W, H, eps2d, r1.w, r2.x, /*v_depth*/ r0.w, r1.x, r1.y, r1.z, pg);
-    const float o = opacities[g];
     const float al = r2.w * o * (1.f - o);
-    const int64_t d = row_map ? (int64_t)row_map[g] : g;   // destination row of the parameter gradients
+#pragma unroll
     for (int i = 0; i < 3; i++) {
-      const float a = pg.v_mean[i], b = pg.v_scale[i] * s[i];
-      v_means[d * 3 + i] = kAcc ? v_means[d * 3 + i] + a : a;
-      v_log_scales[d * 3 + i] = kAcc ? v_log_scales[d * 3 + i] + b : b;
+      v_means[d * 3 + i] = old_m[i] + pg.v_mean[i];
+      v_log_scales[d * 3 + i] = old_s[i] + pg.v_scale[i] * s[i];
     }
-    for (int i = 0; i < 4; i++) v_quats[d * 4 + i] = kAcc ? v_quats[d * 4 + i] + pg.v_quat[i] : pg.v_quat[i];
-    v_logits[d] = kAcc ? v_logits[d] + al : al;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v_quats[d * 4 + i] = old_q[i] + pg.v_quat[i];
+    v_logits[d] = old_l + al;
     if (grad2d) { grad2d[g * 2] = r1.w; grad2d[g * 2 + 1] = r2.x; }
     if (absgrad2d) { absgrad2d[g * 2] = r2.y; absgrad2d[g * 2 + 1] = r2.z; }
   }

@@ -269,13 +269,31 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
   __syncthreads();
   if (kVec) {
     const int q4 = row / 4;   // 16-byte pieces per row
-    for (int e = tid; e < cnt * q4; e += kShBlock) {
-      const int r = e / q4, cc = (e - r * q4) * 4;
-      const float *sp = lds + r * ldr + cc;
-      float4 *dst = reinterpret_cast<float4 *>(v_coeffs + (int64_t)s_g[r] * row + cc);
-      float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
-      if (kAcc) { const float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-      *dst = o;
+    const int total = cnt * q4;
+    // four pieces per step: in accumulate mode their old values are loaded together BEFORE the first store (a load of v_coeffs may
+    // not be moved above a store to it, so piece-by-piece every piece would wait out a full memory latency behind the previous one)
+    for (int e0 = tid; e0 < total; e0 += 4 * kShBlock) {
+      float4 *dst[4];
+      float4 o[4], p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kShBlock;
+        dst[u] = nullptr;
+        if (e < total) {
+          const int r = e / q4, cc = (e - r * q4) * 4;
+          const float *sp = lds + r * ldr + cc;
+          dst[u] = reinterpret_cast<float4 *>(v_coeffs + (int64_t)s_g[r] * row + cc);
+          o[u] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+      }
+      if (kAcc) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (dst[u]) p[u] = *dst[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (dst[u]) { o[u].x += p[u].x; o[u].y += p[u].y; o[u].z += p[u].z; o[u].w += p[u].w; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (dst[u]) *dst[u] = o[u];
     }
   } else {
     for (int e = tid; e < cnt * row; e += kShBlock) {
@@ -338,24 +356,43 @@ __global__ __launch_bounds__(kShBlock) void view_grads_add_list_kernel(
     const int64_t r = r0 + tid;
     const int64_t g = ids[r];
     s_g[tid] = (int32_t)g;
-    if (g >= 0) {
-      for (int i = 0; i < 3; i++) { v_means[g * 3 + i] += s_means[r * 3 + i]; v_log_scales[g * 3 + i] += s_log_scales[r * 3 + i]; }
-      for (int i = 0; i < 4; i++) v_quats[g * 4 + i] += s_quats[r * 4 + i];
-      v_logits[g] += s_logits[r];
+    if (g >= 0) {   // all loads first, then the stores (a load of an array may not be moved above a store to it: see sh_view_bwd_list)
+      float om[3], os[3], oq[4], ol = v_logits[g] + s_logits[r];
+#pragma unroll
+      for (int i = 0; i < 3; i++) { om[i] = v_means[g * 3 + i] + s_means[r * 3 + i]; os[i] = v_log_scales[g * 3 + i] + s_log_scales[r * 3 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) oq[i] = v_quats[g * 4 + i] + s_quats[r * 4 + i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = om[i]; v_log_scales[g * 3 + i] = os[i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = oq[i];
+      v_logits[g] = ol;
     }
   }
   __syncthreads();
   const int row = K * 3;
   if (kVec) {
     const int q4 = row / 4;
-    for (int e = tid; e < cnt * q4; e += kShBlock) {
-      const int r = e / q4, cc = (e - r * q4) * 4;
-      if (s_g[r] < 0) continue;
-      const float4 a = *reinterpret_cast<const float4 *>(s_sh + (r0 + r) * row + cc);
-      float4 *d = reinterpret_cast<float4 *>(v_sh + (int64_t)s_g[r] * row + cc);
-      float4 o = *d;
-      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-      *d = o;
+    const int total = cnt * q4;
+    for (int e0 = tid; e0 < total; e0 += 4 * kShBlock) {   // four pieces per step, their loads in front of the first store
+      float4 *d[4];
+      float4 o[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kShBlock;
+        d[u] = nullptr;
+        if (e < total) {
+          const int r = e / q4, cc = (e - r * q4) * 4;
+          if (s_g[r] >= 0) {
+            const float4 a = *reinterpret_cast<const float4 *>(s_sh + (r0 + r) * row + cc);
+            d[u] = reinterpret_cast<float4 *>(v_sh + (int64_t)s_g[r] * row + cc);
+            const float4 p = *d[u];
+            o[u] = make_float4(p.x + a.x, p.y + a.y, p.z + a.z, p.w + a.w);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (d[u]) *d[u] = o[u];
     }
   } else {
     for (int e = tid; e < cnt * row; e += kShBlock) {

@@ -804,20 +804,27 @@ __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t 
     } else {
       const uint32_t val = sorted_idx[j];            // what the lists will carry for this entry: its id, or its compact position
       const uint32_t o = asc ? asc[val] : val;
+      // every gather of this member is issued before the first one is consumed (the entries of the list ARE visible: testing the
+      // radius first would only put one more memory latency in front of the others)
       const int r = radii[o];
-      float mx = 0.f, my = 0.f, a = 0.f, b = 0.f, c = 0.f, q_max = 0.f;
+      float mx = means2d[(int64_t)o * 2], my = means2d[(int64_t)o * 2 + 1];
+      float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f, op = 0.f;
+      if (conics != nullptr) {
+        a = conics[(int64_t)o * 3]; b = conics[(int64_t)o * 3 + 1]; c = conics[(int64_t)o * 3 + 2];
+        op = opacities[o];
+      }
       int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
       if (r > 0) {
-        mx = means2d[(int64_t)o * 2]; my = means2d[(int64_t)o * 2 + 1];
         bool ok;
         if (conics == nullptr) {
           tile_rect(mx, my, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
           ok = x1 > x0 && y1 > y0;
         } else {
-          a = conics[(int64_t)o * 3]; b = conics[(int64_t)o * 3 + 1]; c = conics[(int64_t)o * 3 + 2];
-          ok = tile_rect_tight(mx, my, r, a, b, c, opacities[o], tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max);
+          ok = tile_rect_tight(mx, my, r, a, b, c, op, tile_size, tile_w, tile_h, x0, y0, x1, y1, q_max);
         }
         if (ok) nrows = (uint32_t)(y1 - y0);
+      } else {
+        mx = my = a = b = c = 0.f;
       }
       // camera of entry o = o / N: entries of the first camera (the only one on the per-view path) need no division
       const uint32_t cam_base = (int64_t)o < N ? 0u : (uint32_t)((uint32_t)o / (uint32_t)N) * (uint32_t)(tile_w * tile_h);
