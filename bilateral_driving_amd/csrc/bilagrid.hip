@@ -376,7 +376,9 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
     if (owner) { v_in[pix * p.cs] = v0; v_in[pix * p.cs + 1] = v1; v_in[pix * p.cs + 2] = v2; }
   }
   __syncthreads();
-  // x pass: candidate columns of every up-sampled level, one item per thread
+  // x pass: candidate columns of every up-sampled level, one item per thread and level.  (One flat item list over all levels --
+  // every thread busy once instead of the first 64 threads three times -- was measured slower, 211 -> 232 us for the bilateral
+  // backward: the per-item level lookup and the mixed loop lengths inside a wave cost more than the idle lanes.)
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     if (l >= p.nlevels) break;
