@@ -94,19 +94,17 @@ class _Out(dict):
 
 
 class _Front:
-    """Everything of one view that does not depend on the opacities' values beyond the tile cull: activations, projection, SH
-    colours, per-tile lists (compact positions) and the ascending visible-id list.  Shared by the training forward and by the
-    evaluation re-renders (``render_classes``), which composite several opacity masks over ONE such front."""
-    __slots__ = ("means", "quats", "log_scales", "sh", "viewmat", "scales", "opac", "radii", "means2d", "depths", "conics", "cam_pos",
-                 "sh_rgb", "colors", "tiles_per_gauss", "isect_offsets", "flatten", "vis_ids", "M", "n_vis", "tw", "th", "W", "H", "N", "list_tile", "rec_buf", "pre", "sh_by_rank", "sh_degree")
+    """One view up to its per-tile lists -- everything that does not depend on the opacities' VALUES beyond the tile cull: activations,
+    projection, SH colours, depth order, per-tile lists (compact positions) and the ascending visible-id list.  Shared by the training
+    forward and by the evaluation re-renders (``render_classes``), which composite several opacity masks over ONE front.
+    ``_front_begin`` fills the first half (nothing there depends on the host), ``_front_finish`` waits for the two list counts and
+    adds the lists.  Plain attribute bag: inputs (means, quats, log_scales, sh, viewmat, cam_pos), projection outputs (scales, opac,
+    radii, means2d, depths, conics), colours (sh_rgb, colors / sh_by_rank), tile-stage state (ws, counts, ev, capacities ...) and,
+    after ``_front_finish``: flatten, vis_ids, isect_offsets, M, n_vis."""
+    pass
 
 
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
-
-
-class _FrontState:
-    """A view's front between its two halves: everything enqueued up to the list counts (see ``_front_begin``)."""
-    pass
 
 
 def _front_signature(cfg: dict, means, quats, log_scales, logits, sh, viewmat):
@@ -130,7 +128,7 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before
     return _front_finish(state, before_wait)
 
 
-def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _FrontState:
+def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Front:
     """First half of a view's forward: activations + projection, visibility compaction, depth order, tile counts (whose totals travel
     to the host asynchronously) and the SH colours.  Nothing here depends on the host."""
     signature = _front_signature(cfg, means, quats, log_scales, logits, sh, viewmat)
@@ -185,57 +183,49 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     vcap = _VIS_CAPACITY.get(key, 0)
     rec_buf = _empty((vcap, L.SPLAT_RECORD_FLOATS), dev) if vcap else None
     off = lib.bds_isect_visible_ids_offset(1, N)
-    s_ = _FrontState()
-    (s_.signature, s_.used, s_.cfg, s_.means, s_.quats, s_.log_scales, s_.sh, s_.viewmat, s_.scales, s_.opac, s_.radii, s_.means2d,
-     s_.depths, s_.conics, s_.cam_pos, s_.sh_rgb, s_.colors, s_.tiles_per_gauss, s_.isect_offsets, s_.ws, s_.ws_bytes, s_.cull,
-     s_.counts, s_.ev, s_.key, s_.cap, s_.vcap, s_.buf, s_.ws2, s_.ws2_bytes, s_.rec_buf, s_.off, s_.LT, s_.tw, s_.th) = (
-        signature, False, cfg, means, quats, log_scales, sh, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb,
-        colors, tiles_per_gauss, isect_offsets, ws, ws_bytes, cull, counts, ev, key, cap, vcap, buf, ws2, ws2_bytes, rec_buf, off, LT,
-        tw, th)
-    return s_
+    f = _Front()
+    f.signature, f.used, f.cfg = signature, False, cfg
+    f.means, f.quats, f.log_scales, f.sh, f.viewmat, f.cam_pos = means, quats, log_scales, sh, viewmat, cam_pos
+    f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
+    f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
+    f.tiles_per_gauss, f.isect_offsets, f.ws, f.ws_bytes, f.cull = tiles_per_gauss, isect_offsets, ws, ws_bytes, cull
+    f.counts, f.ev, f.key, f.cap, f.vcap = counts, ev, key, cap, vcap
+    f.buf, f.ws2, f.ws2_bytes, f.rec_buf, f.ids_offset = buf, ws2, ws2_bytes, rec_buf, off
+    f.list_tile, f.list_tw, f.list_th = LT, tw, th
+    f.W, f.H, f.N = W, H, N
+    f.tw, f.th = math.ceil(W / TILE), math.ceil(H / TILE)   # compositing tiles
+    return f
 
 
-def _front_finish(s_: _FrontState, before_wait=None) -> _Front:
+def _front_finish(f: _Front, before_wait=None) -> _Front:
     """Second half: the one host wait of a view (list counts), then the per-tile lists."""
     lib, st = L.lib(), L.stream()
-    cfg = s_.cfg
-    (means, quats, log_scales, sh, viewmat, scales, opac, radii, means2d, depths, conics, cam_pos, sh_rgb, colors, tiles_per_gauss,
-     isect_offsets, ws, ws_bytes, cull, counts, ev, key, cap, vcap, buf, ws2, ws2_bytes, rec_buf, off, LT, tw, th) = (
-        s_.means, s_.quats, s_.log_scales, s_.sh, s_.viewmat, s_.scales, s_.opac, s_.radii, s_.means2d, s_.depths, s_.conics, s_.cam_pos,
-        s_.sh_rgb, s_.colors, s_.tiles_per_gauss, s_.isect_offsets, s_.ws, s_.ws_bytes, s_.cull, s_.counts, s_.ev, s_.key, s_.cap,
-        s_.vcap, s_.buf, s_.ws2, s_.ws2_bytes, s_.rec_buf, s_.off, s_.LT, s_.tw, s_.th)
-    dev = means.device
-    W, H, N = cfg["width"], cfg["height"], means.shape[0]
-    cptr, optr = (L.ptr(conics), L.ptr(opac.view(1, N))) if cull else (None, None)
-    pre = before_wait() if before_wait is not None else None
-    ev.synchronize()
-    M, n_vis = int(counts.np[0]), int(counts.np[1])
-    if rec_buf is None or n_vis > vcap:
-        rec_buf = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
-    if n_vis + n_vis // 16 > vcap:
-        _VIS_CAPACITY[key] = n_vis + n_vis // 6 + 1024
-    if M > cap or buf is None:   # first call of this configuration, or the lists outgrew the expectation
+    dev, N = f.means.device, f.N
+    cptr, optr = (L.ptr(f.conics), L.ptr(f.opac.view(1, N))) if f.cull else (None, None)
+    f.pre = before_wait() if before_wait is not None else None
+    f.ev.synchronize()
+    M, n_vis = int(f.counts.np[0]), int(f.counts.np[1])
+    if f.rec_buf is None or n_vis > f.vcap:
+        f.rec_buf = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
+    if n_vis + n_vis // 16 > f.vcap:
+        _VIS_CAPACITY[f.key] = n_vis + n_vis // 6 + 1024
+    buf, ws2, ws2_bytes = f.buf, f.ws2, f.ws2_bytes
+    if M > f.cap or buf is None:   # first call of this configuration, or the lists outgrew the expectation
         buf = _empty((M,), dev, torch.int32)
         ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
         ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-    flatten = buf[:M]                                  # per-tile lists of COMPACT positions (they address the records below)
+    f.flatten = buf[:M]                                # per-tile lists of COMPACT positions (they address the splat records)
     # ascending ids of the visible Gaussians: compact position -> id, the work list of everything downstream (walks memory in
     # order).  Read in place from the prepare workspace (which this view keeps alive): no copy node between the kernels.
-    vis_ids = ws[off:off + 4 * n_vis].view(torch.int32)
+    f.vis_ids = f.ws[f.ids_offset:f.ids_offset + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th, L.ptr(ws),
-                                    ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), None, 1, st),
-                "bds_isect_build")
-    if M + M // 16 > cap:
-        _LIST_CAPACITY[key] = M + M // 6 + 4096
-    del ws2, buf
-    f = _Front()
-    f.means, f.quats, f.log_scales, f.sh, f.viewmat = means, quats, log_scales, sh, viewmat
-    f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
-    f.cam_pos, f.sh_rgb, f.colors, f.tiles_per_gauss, f.isect_offsets = cam_pos, sh_rgb, colors, tiles_per_gauss, isect_offsets
-    f.flatten, f.vis_ids, f.M, f.n_vis, f.W, f.H, f.N, f.list_tile = flatten, vis_ids, M, n_vis, W, H, N, LT
-    f.tw, f.th = math.ceil(W / TILE), math.ceil(H / TILE)  # compositing tiles
-    f.rec_buf, f.pre, f.sh_by_rank, f.sh_degree = rec_buf, pre, False, cfg["sh_degree"]
+        L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile, f.list_tw,
+                                    f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(f.flatten),
+                                    L.ptr(f.isect_offsets), None, 1, st), "bds_isect_build")
+    if M + M // 16 > f.cap:
+        _LIST_CAPACITY[f.key] = M + M // 6 + 4096
+    f.buf = f.ws2 = None
+    f.M, f.n_vis = M, n_vis
     return f
 
 
