@@ -889,10 +889,10 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
   if (tiles_per_gauss && j < n_vis) tiles_per_gauss[asc ? asc[sorted_idx[j]] : sorted_idx[j]] = (int32_t)cnt[threadIdx.x];
   uint32_t total;
   block_excl_scan(cnt[threadIdx.x], total, S.lw);
-  if (threadIdx.x == 0) {
-    btot[blockIdx.x] = total;
-    if (total) atomicAdd(reinterpret_cast<unsigned long long *>(m_total), (unsigned long long)total);
-  }
+  // (the grand total M is formed from btot[] by finish_counts_kernel: one atomic per workgroup on ONE address serialises in L2,
+  //  ~7 ns each, at the tail of a kernel that runs a single round of workgroups)
+  if (threadIdx.x == 0) btot[blockIdx.x] = total;
+  (void)m_total;
 }
 
 __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
@@ -1051,16 +1051,43 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
   return build_layout(nullptr, M).bytes;
 }
 
+// M = sum of the counting kernel's per-workgroup totals -> counts_dev[0]; then, for the asynchronous form, both counts -> page-locked
+// host memory, written by the GPU itself (a copy node between two kernels costs ~15 us of idle GPU: engine switch + barriers; this
+// one-workgroup kernel ~4.5 us)
+__global__ __launch_bounds__(256) void finish_counts_kernel(const uint32_t *__restrict__ btot, int nblocks, uint64_t *__restrict__ counts_dev,
+                                                           volatile int64_t *__restrict__ counts_host) {
+  __shared__ unsigned long long part[256];
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // (independent partial sums: four loads in flight per thread)
+  int b = threadIdx.x;
+  for (; b + 768 < nblocks; b += 1024) {
+    const uint32_t a0 = btot[b], a1 = btot[b + 256], a2 = btot[b + 512], a3 = btot[b + 768];
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; b < nblocks; b += 256) s0 += btot[b];
+  part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counts_dev[0] = part[0];
+    if (counts_host) { counts_host[0] = (int64_t)part[0]; counts_host[1] = (int64_t)counts_dev[1]; }
+  }
+  if (counts_host) __threadfence_system();
+}
+
 // enqueues the whole prepare stage; the counts (M, visible entries) end up in L.total on the device
 static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                            const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                            int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int compact, bds_stream_t stream,
-                           uint64_t **counts_dev) {
+                           uint64_t **counts_dev, const uint32_t **btot_out, int *nblocks_out) {
   BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0);
   const int64_t CN = (int64_t)C * N;
   BDS_REQUIRE(CN < (int64_t)1 << 31);
   BDS_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)1 << 31);
   *counts_dev = nullptr;
+  *btot_out = nullptr; *nblocks_out = 0;
   if (CN == 0) return BDS_OK;
   BDS_REQUIRE(means2d && radii && depths && ws);
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
@@ -1126,6 +1153,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
   // 4. (no scan: every counting kernel leaves the per-256-member totals and adds them to M; the emission derives its offsets)
   (void)rc;
   *counts_dev = L.total;
+  *btot_out = L.btot; *nblocks_out = (int)grid;
   return BDS_OK;
 }
 
@@ -1137,10 +1165,14 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   *n_isects = 0;
   if (n_visible) *n_visible = 0;
   uint64_t *counts_dev = nullptr;
+  const uint32_t *btot = nullptr;
+  int nblocks = 0;
   int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
-                           compact, stream, &counts_dev);
+                           compact, stream, &counts_dev, &btot, &nblocks);
   if (rc != BDS_OK || counts_dev == nullptr) return rc;
   hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, st, btot, nblocks, counts_dev, static_cast<volatile int64_t *>(nullptr));
+  BDS_LAUNCH_CHECK();
   uint64_t total[2] = {0, 0};   // M, visible entries
   if (hipMemcpyAsync(total, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return BDS_ELAUNCH;
@@ -1149,34 +1181,28 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
   return BDS_OK;
 }
 
-// counts -> page-locked host memory, written by the GPU itself: a copy node between two kernels costs ~15 us of idle GPU
-// (engine switch + barriers), a one-wave kernel ~4.5 us
-__global__ void publish_counts_kernel(const uint64_t *__restrict__ counts_dev, volatile int64_t *__restrict__ counts_host) {
-  if (threadIdx.x < 2) counts_host[threadIdx.x] = (int64_t)counts_dev[threadIdx.x];
-  __threadfence_system();
-}
-
 extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                                        const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                                        int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t *counts_pinned,
                                        void *event, int compact, bds_stream_t stream) {
   BDS_REQUIRE(counts_pinned && event);
   uint64_t *counts_dev = nullptr;
+  const uint32_t *btot = nullptr;
+  int nblocks = 0;
   int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
-                           compact, stream, &counts_dev);
+                           compact, stream, &counts_dev, &btot, &nblocks);
   if (rc != BDS_OK) return rc;
   hipStream_t st = as_stream(stream);
   if (counts_dev == nullptr) {
     counts_pinned[0] = 0; counts_pinned[1] = 0;
   } else {
     void *mapped = nullptr;   // device view of the caller's page-locked buffer (the same address under unified addressing)
-    if (hipHostGetDevicePointer(&mapped, counts_pinned, 0) == hipSuccess && mapped != nullptr) {
-      hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(64), 0, st, counts_dev, static_cast<volatile int64_t *>(mapped));
-      BDS_LAUNCH_CHECK();
-    } else {
-      (void)hipGetLastError();   // not mapped: fall back to the copy engine
-      if (hipMemcpyAsync(counts_pinned, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
-    }
+    if (hipHostGetDevicePointer(&mapped, counts_pinned, 0) != hipSuccess) { (void)hipGetLastError(); mapped = nullptr; }
+    hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, st, btot, nblocks, counts_dev, static_cast<volatile int64_t *>(mapped));
+    BDS_LAUNCH_CHECK();
+    if (mapped == nullptr &&   // not mapped: the copy engine
+        hipMemcpyAsync(counts_pinned, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+      return BDS_ELAUNCH;
   }
   if (hipEventRecord(static_cast<hipEvent_t>(event), st) != hipSuccess) return BDS_ELAUNCH;
   return BDS_OK;
