@@ -74,9 +74,10 @@ _SIGS = {
     "bds_reg_loss_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _fl, _f, _f, _f, _f, _f, _f]),
     "bds_densify_stats": (_i, [_i64, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_refine_plan_temp_bytes": (_sz, [_i64]),
-    "bds_refine_plan": (_i, [_i64, _f, _f, _f, _f, _f, _i, _fl, _fl, _i, _fl, _i, _fl, _i, _fl, _i, _fl, _f, _f, _f, _f, _sz, _f]),
+    "bds_refine_plan": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _fl, _fl, _i, _fl, _i, _fl, _i, _fl, _i, _fl, _f, _f, _f, _f, _sz, _f]),
     "bds_refine_geometry": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_refine_rows": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_refine_out_of_bound": (_i, [_i64, _f, _f, _i64, _f, _f, _f]),
     "bds_opacity_reset": (_i, [_i64, _f, _fl, _f, _f, _f]),
     "bds_cubemap_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f]),
     "bds_cubemap_bwd": (_i, [_i64, _i, _i, _i, _f, _f, _f, _f, _f]),

@@ -47,7 +47,8 @@ __device__ __forceinline__ float shrink_log_scale(float ls) {
 
 __device__ __forceinline__ uint8_t refine_classify(int64_t g, const RefineCfg &c, const float *__restrict__ xys_grad_norm,
                                                    const float *__restrict__ vis_counts, const float *__restrict__ max_2Dsize,
-                                                   const float *__restrict__ log_scales, const float *__restrict__ logits) {
+                                                   const float *__restrict__ log_scales, const float *__restrict__ logits,
+                                                   const uint8_t *__restrict__ extra_cull) {
 #pragma clang fp contract(off)
   const float lmax = fmaxf(fmaxf(log_scales[g * 3], log_scales[g * 3 + 1]), log_scales[g * 3 + 2]);
   const float smax = expf(lmax);  // exp is monotone: max_i exp(s_i) = exp(max_i s_i)
@@ -75,6 +76,9 @@ __device__ __forceinline__ uint8_t refine_classify(int64_t g, const RefineCfg &c
       if (c.cull_by_screen) cull_o = cull_o || (m2d > c.cull_screen);  // children enter with max_2Dsize = 0
     }
   }
+  // a caller-computed mask over the INPUT rows (the node classes' box test, see bds_refine_out_of_bound): the children are judged
+  // by their own rows in a second plan, not by their parent
+  if (c.do_cull && extra_cull && extra_cull[g]) cull_o = true;
   uint8_t f = 0;
   if (split) f |= kSplit;
   if (dup) f |= kDup;
@@ -89,13 +93,14 @@ __global__ __launch_bounds__(kRefBlock) void refine_flags_kernel(int64_t N, Refi
                                                                 const float *__restrict__ vis_counts,
                                                                 const float *__restrict__ max_2Dsize,
                                                                 const float *__restrict__ log_scales,
-                                                                const float *__restrict__ logits, uint8_t *__restrict__ flags,
+                                                                const float *__restrict__ logits,
+                                                                const uint8_t *__restrict__ extra_cull, uint8_t *__restrict__ flags,
                                                                 uint32_t *__restrict__ blk) {
   __shared__ uint32_t wsum[kRefWaves][kChan];
   const int64_t g = (int64_t)blockIdx.x * kRefBlock + threadIdx.x;
   uint8_t f = 0;
   if (g < N) {
-    f = refine_classify(g, c, xys_grad_norm, vis_counts, max_2Dsize, log_scales, logits);
+    f = refine_classify(g, c, xys_grad_norm, vis_counts, max_2Dsize, log_scales, logits, extra_cull);
     flags[g] = f;
   }
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
@@ -251,6 +256,23 @@ __global__ __launch_bounds__(kRefBlock) void refine_rows_kernel(int64_t N, int w
   if (f & kKeepD) dst[(KO + (int64_t)samps * KS + r.w) * width + c] = cv;
 }
 
+// nodes/rigid.py:374-383 (get_out_of_bound_mask): |mean| > instances_size[point_id] / 2 in any axis, means in the object frame
+__global__ __launch_bounds__(kRefBlock) void refine_out_of_bound_kernel(int64_t N, const float *__restrict__ means,
+                                                                       const int64_t *__restrict__ point_ids, int64_t n_instances,
+                                                                       const float *__restrict__ instances_size,
+                                                                       uint8_t *__restrict__ mask) {
+#pragma clang fp contract(off)
+  const int64_t g = (int64_t)blockIdx.x * kRefBlock + threadIdx.x;
+  if (g >= N) return;
+  const int64_t id = point_ids[g];
+  bool out = true;  // an id outside the table cannot be inside any box
+  if (id >= 0 && id < n_instances) {
+    out = false;
+    for (int i = 0; i < 3; i++) out = out || (fabsf(means[g * 3 + i]) > instances_size[id * 3 + i] / 2.f);
+  }
+  mask[g] = out ? 1 : 0;
+}
+
 // vanilla.py:286-299: opacity = logit(min(sigmoid(opacity), reset_value)); the opacity group's Adam moments start again from zero
 __global__ __launch_bounds__(kRefBlock) void opacity_reset_kernel(int64_t N, float *__restrict__ logits, float reset_value,
                                                                  float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq) {
@@ -274,7 +296,8 @@ extern "C" size_t bds_refine_plan_temp_bytes(int64_t N) {
 }
 
 extern "C" int bds_refine_plan(int64_t N, const float *xys_grad_norm, const float *vis_counts, const float *max_2Dsize,
-                               const float *log_scales, const float *logits, int do_densify, float grad_thresh,
+                               const float *log_scales, const float *logits, const uint8_t *extra_cull, int do_densify,
+                               float grad_thresh,
                                float size_thresh, int split_by_screen, float split_screen_size, int do_cull,
                                float cull_alpha_thresh, int cull_by_scale, float cull_scale_thresh, int cull_by_screen,
                                float cull_screen_size, uint8_t *flags, uint32_t *ranks, int64_t *totals, void *temp,
@@ -293,7 +316,7 @@ extern "C" int bds_refine_plan(int64_t N, const float *xys_grad_norm, const floa
   const int64_t nb = cdiv(N, kRefBlock);
   uint32_t *blk = static_cast<uint32_t *>(temp);
   hipLaunchKernelGGL(refine_flags_kernel, dim3((unsigned)nb), dim3(kRefBlock), 0, st, N, c, xys_grad_norm, vis_counts, max_2Dsize,
-                     log_scales, logits, flags, blk);
+                     log_scales, logits, extra_cull, flags, blk);
   hipLaunchKernelGGL(refine_blockscan_kernel, dim3(1), dim3(kScanThreads), 0, st, nb, blk, totals);
   hipLaunchKernelGGL(refine_ranks_kernel, dim3((unsigned)nb), dim3(kRefBlock), 0, st, N, flags, blk, ranks);
   BDS_LAUNCH_CHECK();
@@ -319,6 +342,17 @@ extern "C" int bds_refine_rows(int64_t N, int width, int samps, const uint8_t *f
   BDS_REQUIRE(flags && ranks && totals && src && dst);
   hipLaunchKernelGGL(refine_rows_kernel, dim3((unsigned)cdiv(N * width, kRefBlock)), dim3(kRefBlock), 0, as_stream(stream), N, width,
                      samps, flags, ranks, totals, src, dst, zero_children);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_refine_out_of_bound(int64_t N, const float *means, const int64_t *point_ids, int64_t n_instances,
+                                       const float *instances_size, uint8_t *mask, bds_stream_t stream) {
+  BDS_REQUIRE(N >= 0 && n_instances >= 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && point_ids && instances_size && mask);
+  hipLaunchKernelGGL(refine_out_of_bound_kernel, dim3((unsigned)cdiv(N, kRefBlock)), dim3(kRefBlock), 0, as_stream(stream), N, means,
+                     point_ids, n_instances, instances_size, mask);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

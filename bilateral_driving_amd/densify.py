@@ -40,8 +40,9 @@ def _group_of(optimizer, name: str):
 def plan(log_scales: Tensor, logits: Tensor, xys_grad_norm: Optional[Tensor], vis_counts: Optional[Tensor],
          max_2Dsize: Optional[Tensor], *, do_densify: bool, grad_thresh: float, size_thresh: float, split_by_screen: bool,
          split_screen_size: float, do_cull: bool, cull_alpha_thresh: float, cull_by_scale: bool, cull_scale_thresh: float,
-         cull_by_screen: bool, cull_screen_size: float):
-    """bds_refine_plan: (flags [N] u8, ranks [N,4] i32, totals [5] i64 on the device)."""
+         cull_by_screen: bool, cull_screen_size: float, extra_cull: Optional[Tensor] = None):
+    """bds_refine_plan: (flags [N] u8, ranks [N,4] i32, totals [5] i64 on the device).  ``extra_cull`` [N] u8: a cull mask over the
+    input rows OR-ed into the originals' decision."""
     L.require_gpu(log_scales)
     N, dev = log_scales.shape[0], log_scales.device
     flags = torch.empty(N, dtype=torch.uint8, device=dev)
@@ -52,7 +53,10 @@ def plan(log_scales: Tensor, logits: Tensor, xys_grad_norm: Optional[Tensor], vi
     f32 = lambda t: None if t is None else t.detach().reshape(-1).contiguous().float()
     xs, vc, m2 = f32(xys_grad_norm), f32(vis_counts), f32(max_2Dsize)
     ls, lg = log_scales.detach().contiguous(), logits.detach().reshape(-1).contiguous()
-    L.check(L.lib().bds_refine_plan(N, L.ptr(xs), L.ptr(vc), L.ptr(m2), L.ptr(ls), L.ptr(lg), int(do_densify), float(grad_thresh),
+    if extra_cull is not None:
+        assert extra_cull.dtype == torch.uint8 and extra_cull.shape == (N,) and extra_cull.is_contiguous()
+    L.check(L.lib().bds_refine_plan(N, L.ptr(xs), L.ptr(vc), L.ptr(m2), L.ptr(ls), L.ptr(lg), L.ptr(extra_cull), int(do_densify),
+                                    float(grad_thresh),
                                     float(size_thresh), int(split_by_screen), float(split_screen_size), int(do_cull),
                                     float(cull_alpha_thresh), int(cull_by_scale), float(cull_scale_thresh), int(cull_by_screen),
                                     float(cull_screen_size), L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(temp), nb, L.stream()),
@@ -65,18 +69,78 @@ def _rows(src: Tensor, n_new: int, samps: int, flags, ranks, totals, zero_childr
     N = src.shape[0]
     width = src.numel() // max(N, 1)
     dst = torch.empty((n_new,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n_new == 0 or width == 0:        # everything culled: nothing to write (an empty tensor has no address to hand over)
+        return dst
     L.check(L.lib().bds_refine_rows(N, width, samps, L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(src), L.ptr(dst),
                                     int(zero_children), L.stream()), "bds_refine_rows")
     return dst
 
 
+def _ctrl_get(ctrl, key: str, default):
+    """ctrl keys that only some classes carry (OmegaConf node, dict or attribute bag)."""
+    if hasattr(ctrl, "get"):
+        v = ctrl.get(key, default)
+        return default if v is None else v
+    return getattr(ctrl, key, default)
+
+
+def _move_rows(self, optimizer, flags, ranks, totals, samps: int, n_new: int, geometry: Optional[Dict[str, Tensor]]) -> None:
+    """Writes every per-Gaussian array of the class once into the planned layout: the six parameters (``geometry`` holds the two a
+    split changes, already computed), the Adam moments of their groups (children start from zero, basics.py:191-201) and -- node
+    classes -- the ``point_ids`` column (nodes/rigid.py:253,317: int64, moved as two 32-bit words per row)."""
+    new: Dict[str, Tensor] = dict(geometry or {})
+    for a in _ATTRS:
+        if a not in new:
+            new[a] = _rows(getattr(self, a), n_new, samps, flags, ranks, totals, zero_children=False)
+    ids = getattr(self, "point_ids", None)
+    if ids is not None:
+        assert ids.dtype == torch.int64 and ids.shape[0] == flags.shape[0]
+        L.require_gpu(ids)
+        words = ids.contiguous().view(torch.float32).reshape(ids.shape[0], -1)
+        moved = _rows(words, n_new, samps, flags, ranks, totals, zero_children=False)
+        self.point_ids = moved.view(torch.int64).reshape((n_new,) + tuple(ids.shape[1:]))
+    for a, gname in zip(_ATTRS, _GROUPS):
+        prm = Parameter(new[a])
+        setattr(self, a, prm)
+        group = _group_of(optimizer, self.class_prefix + gname)
+        if group is None:
+            continue
+        old_p = group["params"][0]
+        state = optimizer.state.pop(old_p, None)                          # basics.py:162-206
+        if state:
+            for k in ("exp_avg", "exp_avg_sq"):
+                state[k] = _rows(state[k], n_new, samps, flags, ranks, totals, zero_children=True)
+            optimizer.state[prm] = state
+        group["params"] = [prm]
+
+
+def out_of_bound_mask(means: Tensor, point_ids: Tensor, instances_size: Tensor) -> Tensor:
+    """RigidNodes.get_out_of_bound_mask (nodes/rigid.py:374-383) as a [N] uint8 mask."""
+    L.require_gpu(means, point_ids, instances_size)
+    N = means.shape[0]
+    assert point_ids.dtype == torch.int64 and point_ids.numel() == N
+    m = means.detach().contiguous().float()
+    sz = instances_size.detach().contiguous().float()
+    ids = point_ids.reshape(-1).contiguous()
+    mask = torch.empty(N, dtype=torch.uint8, device=means.device)
+    L.check(L.lib().bds_refine_out_of_bound(N, L.ptr(m), L.ptr(ids), sz.shape[0], L.ptr(sz), L.ptr(mask), L.stream()),
+            "bds_refine_out_of_bound")
+    return mask
+
+
 @torch.no_grad()
 def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples: Optional[Tensor] = None, verbose: bool = True,
                      sample_fn=None) -> None:
-    """Same contract as VanillaGaussians.refinement_after(step, optimizer).  ``samples`` (optional, [n_split_samples * n_split, 3])
-    replaces the ``torch.randn`` draw of split_gaussians (vanilla.py:343) -- the tests feed the reference's recorded noise;
-    ``sample_fn(shape, device)`` (optional) produces it instead (view-parallel training: ``dist.broadcast_randn`` gives every rank
-    rank 0's draw, so that the replicas stay identical -- SURVEY.md 8e)."""
+    """Same contract as VanillaGaussians.refinement_after(step, optimizer) and, for a model that carries ``point_ids``
+    (+ ``instances_size`` when ``ctrl.cull_out_of_bound``), as RigidNodes / DeformableNodes.refinement_after
+    (models/nodes/rigid.py:194-325).  ``samples`` (optional, [n_split_samples * n_split, 3]) replaces the ``torch.randn`` draw of
+    split_gaussians (vanilla.py:343) -- the tests feed the reference's recorded noise; ``sample_fn(shape, device)`` (optional)
+    produces it instead (view-parallel training: ``dist.broadcast_randn`` gives every rank rank 0's draw, so that the replicas stay
+    identical -- SURVEY.md 8e).
+
+    The box test of the node classes is taken on the rows AFTER split / dup (a split child is judged by where its own sample
+    fell), so it runs as a second, cull-only plan over the new set; removing the two masks one after the other leaves the
+    reference's rows in the reference's order."""
     assert step == self.step
     ctrl = self.ctrl_cfg
     if self.step <= ctrl.warmup_steps:
@@ -87,6 +151,10 @@ def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples:
     past = self.step % reset_interval > max(self.num_train_images, ctrl.refine_interval)
     do_densify = bool(self.step < ctrl.stop_split_at and past)
     do_cull = bool(past)
+    box_cull = bool(do_cull and _ctrl_get(ctrl, "cull_out_of_bound", False))
+    if box_cull:
+        assert getattr(self, "point_ids", None) is not None and getattr(self, "instances_size", None) is not None, \
+            "cull_out_of_bound needs point_ids and instances_size (models/nodes/rigid.py:378-380)"
     if verbose:
         print(f"Class {self.class_prefix} current points: {self._means.shape[0]} @ step {self.step}")
     if do_densify or do_cull:
@@ -113,34 +181,29 @@ def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples:
                 samples = torch.randn((samps * n_split, 3), device=dev)       # vanilla.py:343, same draw from the same stream
             samples = samples.to(device=dev, dtype=torch.float32).contiguous()
             assert samples.shape == (samps * n_split, 3)
-        old = {a: getattr(self, a) for a in _ATTRS}
-        new: Dict[str, Tensor] = {}
-        means, quats, ls = old["_means"].detach().contiguous(), old["_quats"].detach().contiguous(), old["_scales"].detach().contiguous()
-        new["_means"] = torch.empty(n_new, 3, device=dev)
-        new["_scales"] = torch.empty(n_new, 3, device=dev)
-        L.check(L.lib().bds_refine_geometry(N, samps, L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(samples) if do_densify else None,
-                                            L.ptr(means), L.ptr(quats), L.ptr(ls), L.ptr(new["_means"]), L.ptr(new["_scales"]),
-                                            L.stream()), "bds_refine_geometry")
-        for a in ("_features_dc", "_features_rest", "_opacities", "_quats"):
-            new[a] = _rows(old[a], n_new, samps, flags, ranks, totals, zero_children=False)
-        for a, gname in zip(_ATTRS, _GROUPS):
-            prm = Parameter(new[a])
-            setattr(self, a, prm)
-            group = _group_of(optimizer, self.class_prefix + gname)
-            if group is None:
-                continue
-            old_p = group["params"][0]
-            state = optimizer.state.pop(old_p, None)                          # basics.py:162-206
-            if state:
-                for k in ("exp_avg", "exp_avg_sq"):
-                    state[k] = _rows(state[k], n_new, samps, flags, ranks, totals, zero_children=True)
-                optimizer.state[prm] = state
-            group["params"] = [prm]
+        means, quats, ls = self._means.detach().contiguous(), self._quats.detach().contiguous(), self._scales.detach().contiguous()
+        geometry = {"_means": torch.empty(n_new, 3, device=dev), "_scales": torch.empty(n_new, 3, device=dev)}
+        if n_new:
+            L.check(L.lib().bds_refine_geometry(N, samps, L.ptr(flags), L.ptr(ranks), L.ptr(totals), L.ptr(samples) if do_densify else None,
+                                                L.ptr(means), L.ptr(quats), L.ptr(ls), L.ptr(geometry["_means"]), L.ptr(geometry["_scales"]),
+                                                L.stream()), "bds_refine_geometry")
+        _move_rows(self, optimizer, flags, ranks, totals, samps, n_new, geometry)
+        n_out = 0
+        if box_cull and n_new:
+            mask = out_of_bound_mask(self._means, self.point_ids, self.instances_size)
+            flags2, ranks2, totals2 = plan(self._scales, self._opacities, None, None, None, do_densify=False, grad_thresh=0.0,
+                                           size_thresh=0.0, split_by_screen=False, split_screen_size=0.0, do_cull=True,
+                                           cull_alpha_thresh=-1.0, cull_by_scale=False, cull_scale_thresh=0.0, cull_by_screen=False,
+                                           cull_screen_size=0.0, extra_cull=mask)
+            kept = int(totals2[2].item())                                    # second (and last) host read-back: the new size
+            n_out = n_new - kept
+            if n_out:
+                _move_rows(self, optimizer, flags2, ranks2, totals2, 0, kept, None)
         if verbose:
             if do_densify:
                 print(f"    Split: {n_split}")
                 print(f"      Dup: {n_dup}")
-            print(f"     Cull: {N + samps * n_split + n_dup - n_new}")
+            print(f"     Cull: {N + samps * n_split + n_dup - n_new + n_out}")
     if verbose:
         print(f"Class {self.class_prefix} left points: {self._means.shape[0]}")
     if self.step % reset_interval == ctrl.refine_interval:                    # vanilla.py:286-299

@@ -385,13 +385,24 @@ int bds_densify_stats(int64_t N, const float *grad2d, const int32_t *radii, int 
  *   cull_by_scale   step > reset_alpha_interval, cull_scale_thresh = cull_scale_thresh * scene_scale             (:314-320)
  *   cull_by_screen  additionally step < stop_screen_size_at                                                      (:321-324)
  * xys_grad_norm / vis_counts may be NULL when do_densify == 0; max_2Dsize may be NULL (treated as zeros).
+ * extra_cull [N] u8 (may be NULL): a caller-computed cull mask over the INPUT rows, OR-ed into the decision for the originals when
+ * do_cull != 0 (children are unaffected).  It serves the node classes' box test (models/nodes/rigid.py:302-303), which the
+ * reference evaluates after the children were appended: the host runs a first plan for split / dup / the common culls, then
+ * bds_refine_out_of_bound on the NEW means and a second, cull-only plan with that mask -- two order-preserving compactions leave
+ * the rows, and their order, of the reference's single `culls` mask.
  * temp: bds_refine_plan_temp_bytes(N) bytes of scratch.  N < 2^31. */
 size_t bds_refine_plan_temp_bytes(int64_t N);
 int bds_refine_plan(int64_t N, const float *xys_grad_norm, const float *vis_counts, const float *max_2Dsize,
-                    const float *log_scales, const float *logits, int do_densify, float grad_thresh, float size_thresh,
-                    int split_by_screen, float split_screen_size, int do_cull, float cull_alpha_thresh, int cull_by_scale,
-                    float cull_scale_thresh, int cull_by_screen, float cull_screen_size, uint8_t *flags, uint32_t *ranks,
-                    int64_t *totals, void *temp, size_t temp_bytes, bds_stream_t stream);
+                    const float *log_scales, const float *logits, const uint8_t *extra_cull, int do_densify, float grad_thresh,
+                    float size_thresh, int split_by_screen, float split_screen_size, int do_cull, float cull_alpha_thresh,
+                    int cull_by_scale, float cull_scale_thresh, int cull_by_screen, float cull_screen_size, uint8_t *flags,
+                    uint32_t *ranks, int64_t *totals, void *temp, size_t temp_bytes, bds_stream_t stream);
+
+/* RigidNodes.get_out_of_bound_mask (models/nodes/rigid.py:374-383; DeformableNodes inherits it): mask[g] = 1 when
+ * |means[g, i]| > instances_size[point_ids[g], i] / 2 for any axis i (means in the object frame, instances_size [n_instances,3],
+ * point_ids [N] i64 -- the reference's [N,1] column).  An id outside [0, n_instances) is reported out of bound. */
+int bds_refine_out_of_bound(int64_t N, const float *means, const int64_t *point_ids, int64_t n_instances,
+                            const float *instances_size, uint8_t *mask, bds_stream_t stream);
 
 /* New means [N',3] and log-scales [N',3]: split children are mean + R(q/|q|) (exp(log_scale) * noise) (vanilla.py:343-348);
  * a split parent and its children get log(exp(log_scale) / 1.6) (:356-359); dup children copy the (possibly shrunk) parent. */

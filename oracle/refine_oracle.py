@@ -90,12 +90,37 @@ def refine(step: int, ctrl: dict, scene_scale: float, num_train_images: int, par
            samples: Optional[np.ndarray]):
     """Returns (new params, new exp_avg, new exp_avg_sq, n_split).  `samples` [n_split_samples * n_split, 3] is the
     reference's torch.randn draw (vanilla.py:343)."""
+    return _refine(step, ctrl, scene_scale, num_train_images, params, exp_avg, exp_avg_sq, xys_grad_norm, vis_counts, max_2Dsize,
+                   samples, None, None)[:4]
+
+
+def out_of_bound(means, point_ids, instances_size):
+    """nodes/rigid.py:374-383: a Gaussian whose (object-frame) mean lies outside its instance's box."""
+    half = (instances_size[point_ids.reshape(-1)] / f32(2)).astype(f32)
+    return (np.abs(means.astype(f32)) > half).any(axis=-1)
+
+
+def refine_nodes(step: int, ctrl: dict, scene_scale: float, num_train_images: int, params, exp_avg, exp_avg_sq, xys_grad_norm,
+                 vis_counts, max_2Dsize, samples, point_ids: np.ndarray, instances_size: Optional[np.ndarray]):
+    """RigidNodes / DeformableNodes.refinement_after (nodes/rigid.py:194-293): the same schedule and masks as the background
+    class, plus `point_ids` [N,1] (the instance every Gaussian belongs to) carried through split / dup / cull (:253, :317,
+    :355-356, :371) and, with ctrl.cull_out_of_bound, the box test of cull_gaussians (:302-303) -- which the reference evaluates
+    AFTER the new Gaussians were appended, so a split child is culled by where ITS sampled mean fell, not by its parent.
+    Returns (params, exp_avg, exp_avg_sq, n_split, point_ids).  PINNED by tests/golden/refine_rigid_*.npz
+    (oracle/gen_golden_refine_rigid.py)."""
+    return _refine(step, ctrl, scene_scale, num_train_images, params, exp_avg, exp_avg_sq, xys_grad_norm, vis_counts, max_2Dsize,
+                   samples, point_ids, instances_size if ctrl.get("cull_out_of_bound", False) else None)
+
+
+def _refine(step, ctrl, scene_scale, num_train_images, params, exp_avg, exp_avg_sq, xys_grad_norm, vis_counts, max_2Dsize, samples,
+            point_ids, box_sizes):
     sch = schedule(step, ctrl, scene_scale, num_train_images)
     P = {k: v.astype(f32).copy() for k, v in params.items()}
     M = {k: v.astype(f32).copy() for k, v in exp_avg.items()}
     V = {k: v.astype(f32).copy() for k, v in exp_avg_sq.items()}
+    ids = None if point_ids is None else point_ids.copy()
     if not sch["active"]:
-        return P, M, V, 0
+        return P, M, V, 0, ids
     n_split = 0
     if sch["do_densify"] or sch["do_cull"]:
         samps = int(ctrl["n_split_samples"])
@@ -112,7 +137,7 @@ def refine(step: int, ctrl: dict, scene_scale: float, num_train_images: int, par
         dst_d = KO + samps * KS + r_d[keep_d]
 
         def rows(src, zero_children):
-            out = np.zeros((n_new,) + src.shape[1:], f32)
+            out = np.zeros((n_new,) + src.shape[1:], src.dtype)
             out[dst_o] = src[keep_o]
             if not zero_children:
                 for s in range(samps):
@@ -133,9 +158,19 @@ def refine(step: int, ctrl: dict, scene_scale: float, num_train_images: int, par
         P = newP
         M = {k: rows(M[k], True) for k in M}
         V = {k: rows(V[k], True) for k in V}
+        if ids is not None:
+            ids = rows(ids, False)
+        if box_sizes is not None and sch["do_cull"]:
+            # second, order-preserving compaction: the union of the two cull masks removed in two rounds leaves the same rows in
+            # the same order as the reference's single `culls` mask (rigid.py:300-317)
+            keep = ~out_of_bound(P["_means"], ids, box_sizes.astype(f32))
+            P = {k: v[keep] for k, v in P.items()}
+            M = {k: v[keep] for k, v in M.items()}
+            V = {k: v[keep] for k, v in V.items()}
+            ids = ids[keep]
     if sch["reset_opacity"]:                                                  # vanilla.py:286-299
         x = np.minimum(sigmoid(P["_opacities"]), f32(ctrl["reset_alpha_value"]))
         P["_opacities"] = np.log(x / (f32(1) - x)).astype(f32)
         M["_opacities"] = np.zeros_like(M["_opacities"])
         V["_opacities"] = np.zeros_like(V["_opacities"])
-    return P, M, V, n_split
+    return P, M, V, n_split, ids

@@ -41,6 +41,53 @@ def test_refine_oracle_equals_reference(path):
         np.testing.assert_array_equal(oV[a], z["out_v" + a], err_msg="exp_avg_sq" + a)
 
 
+RIGID = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "refine_rigid_*.npz")))
+
+
+@pytest.mark.parametrize("path", RIGID, ids=[os.path.basename(f)[:-4] for f in RIGID])
+def test_node_refinement_oracle_equals_reference(path):
+    """RigidNodes.refinement_after (nodes/rigid.py:194-325, inherited by DeformableNodes): point_ids travel with the rows and the
+    out-of-bound cull is decided per appended child (oracle/gen_golden_refine_rigid.py)."""
+    z, ctrl, P, M, V = load(path)
+    oP, oM, oV, n_split, ids = RO.refine_nodes(int(z["step"]), ctrl, float(z["scene_scale"]), int(z["num_train_images"]), P, M, V,
+                                               z["in_xys_grad_norm"], z["in_vis_counts"], z["in_max_2Dsize"], z["samples"],
+                                               z["in_point_ids"], z["instances_size"])
+    assert n_split * ctrl["n_split_samples"] == z["samples"].shape[0]
+    assert ids.dtype == np.int64
+    np.testing.assert_array_equal(ids, z["out_point_ids"])
+    for a in RO.PARAMS:
+        ref = z["out" + a]
+        assert oP[a].shape == ref.shape, a
+        if a in ("_means", "_scales", "_opacities"):
+            np.testing.assert_allclose(oP[a], ref, rtol=2e-6, atol=2e-6, err_msg=a)
+        else:
+            np.testing.assert_array_equal(oP[a], ref, err_msg=a)
+        np.testing.assert_array_equal(oM[a], z["out_m" + a], err_msg="exp_avg" + a)
+        np.testing.assert_array_equal(oV[a], z["out_v" + a], err_msg="exp_avg_sq" + a)
+
+
+def test_node_goldens_exercise_the_per_child_box_test():
+    """At least one split parent inside its box has a sampled child outside it (and the other way round): the decision cannot
+    be taken per parent."""
+    assert len(RIGID) == 3
+    z, ctrl, P, M, V = load([f for f in RIGID if "oob_step3300" in f][0])
+    sch = RO.schedule(int(z["step"]), ctrl, float(z["scene_scale"]), int(z["num_train_images"]))
+    split, dup, keep_o, keep_s, keep_d = RO.plan(sch, ctrl, P["_scales"], P["_opacities"], z["in_xys_grad_norm"], z["in_vis_counts"],
+                                                 z["in_max_2Dsize"])
+    ctrl_no = dict(ctrl, cull_out_of_bound=False)
+    oP, _, _, n_split, ids = RO.refine_nodes(int(z["step"]), ctrl_no, float(z["scene_scale"]), int(z["num_train_images"]), P, M, V,
+                                             z["in_xys_grad_norm"], z["in_vis_counts"], z["in_max_2Dsize"], z["samples"],
+                                             z["in_point_ids"], z["instances_size"])
+    oob_new = RO.out_of_bound(oP["_means"], ids, z["instances_size"])
+    oob_parent = RO.out_of_bound(P["_means"], z["in_point_ids"], z["instances_size"])
+    KO, KS = int(keep_o.sum()), int(keep_s.sum())
+    parents_of_children = np.nonzero(keep_s)[0]
+    child0 = oob_new[KO:KO + KS]
+    assert (child0 & ~oob_parent[parents_of_children]).any()
+    assert (~child0 & oob_parent[parents_of_children]).any()
+    assert oob_new.any() and not oob_new.all()
+
+
 def test_schedule_regimes():
     z, ctrl, *_ = load(FILES[0])
     sc, n = float(z["scene_scale"]), int(z["num_train_images"])
