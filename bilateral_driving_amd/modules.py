@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from . import mlp_head
 from .bilagrid import BilateralGrid, NeuralBilateralGrid, bilagrid_transform, slice, slice_feature, total_variation_loss
 
 
@@ -278,6 +279,24 @@ def _affine_network(in_dim: int, hidden_dim: int) -> nn.Sequential:
                          nn.Linear(hidden_dim, 12, bias=False))
 
 
+def _head_maps(net: nn.Sequential, feats: Tensor, H: int, W: int) -> Tensor:
+    """``affine_network(feats).reshape(1, H, W, 3, 4)``: one fused kernel when the sizes are the kernel's (mlp_head.supported),
+    the framework's Linear / Tanh modules otherwise."""
+    w1, w2, w3 = net[0].weight, net[2].weight, net[4].weight
+    if feats.is_cuda and mlp_head.supported(w1.shape[1], w1.shape[0]):
+        return mlp_head.affine_maps(feats, w1, w2, w3).reshape(1, H, W, 3, 4)
+    return net(feats).reshape(1, H, W, 3, 4)
+
+
+def _head_transform(net: nn.Sequential, feats: Tensor, rgb: Tensor) -> Tensor:
+    """The trainer's application with the residual (scene_graph.py:99-106) fused behind the network."""
+    w1, w2, w3 = net[0].weight, net[2].weight, net[4].weight
+    if feats.is_cuda and mlp_head.supported(w1.shape[1], w1.shape[0]):
+        return mlp_head.transform(feats.reshape(rgb.shape[:-1] + (feats.shape[-1],)), rgb, w1, w2, w3, residual=True)
+    A = net(feats).reshape(*rgb.shape[:-1], 3, 4)
+    return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
+
+
 def _sliced_features(grids: NeuralBilateralGrid, rgb: Tensor, xy: Tensor, idxs: Sequence[int]) -> Tensor:
     """Feature slice for one image, or the mean over the neighbour images' grids in the test branch (modules.py:651-662)."""
     acc = None
@@ -308,16 +327,20 @@ class NeuralBilateralAffineTransform(nn.Module):
 
     def forward(self, rgb: Tensor, image_infos) -> Tensor:
         assert "img_idx" in image_infos
+        H, W, _ = rgb.shape
+        return _head_maps(self.affine_network, self._features(rgb, image_infos), H, W)
+
+    def _features(self, rgb: Tensor, image_infos) -> Tensor:
         k = _img_index(image_infos)
         H, W, _ = rgb.shape
         idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
-        feats = _sliced_features(self.bil_grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
-        return self.affine_network(feats).reshape(1, H, W, 3, 4)
+        return _sliced_features(self.bil_grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
 
     def transform(self, rgb: Tensor, image_infos) -> Tensor:
-        """forward + the trainer's application with the residual (scene_graph.py:99-102)."""
-        A = self.forward(rgb, image_infos)[0]
-        return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
+        """forward + the trainer's application with the residual (scene_graph.py:99-102) in one pass: the [H,W,3,4] maps are not
+        materialised."""
+        assert "img_idx" in image_infos
+        return _head_transform(self.affine_network, self._features(rgb, image_infos), rgb)
 
     def get_param_groups(self):
         return {self.class_prefix + "all": self.parameters()}
@@ -351,12 +374,15 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
             loss = loss + total_variation_loss(getattr(self, f"bil_grids{i}").grids) * self.tv_weight[i]
         return loss
 
-    get_sample_grid = MultiScaleBilateralAffineTransform.get_sample_grid
-
     get_sample_grid = MultiScaleBilateralAffineTransform.get_sample_grid   # the reference's helper of the same name (low-res colour + xy grid)
 
     def forward(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
         assert "img_idx" in image_infos
+        H, W, _ = rgb.shape
+        return _head_maps(self.affine_network, self._features(rgb, image_infos, guidance_factor), H, W)
+
+    def _features(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
+        """The levels' features side by side [1, H, W, levels * feature_dim] (modules.py:728-760)."""
         k = _img_index(image_infos)
         H, W, _ = rgb.shape
         idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
@@ -373,11 +399,12 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
                 f = _sliced_features(grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
             out_list.append(f)
         self.save_matrix = out_list
-        return self.affine_network(torch.cat(out_list, dim=-1)).reshape(1, H, W, 3, 4)
+        return torch.cat(out_list, dim=-1)
 
     def transform(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
-        A = self.forward(rgb, image_infos, guidance_factor)[0]
-        return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
+        """forward + the trainer's application with the residual (scene_graph.py:103-106), the maps not materialised."""
+        assert "img_idx" in image_infos
+        return _head_transform(self.affine_network, self._features(rgb, image_infos, guidance_factor), rgb)
 
     def get_param_groups(self):
         return {self.class_prefix + "all": self.parameters()}

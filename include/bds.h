@@ -460,6 +460,28 @@ int bds_cubemap_bwd(int64_t n, int res, int channels, int width, const float *di
 int bds_color_correct_step(int64_t P, const float *cur_in, const float *ref, const float *warp, float eps, uint8_t *mask0,
                            float *cur_out, double *acc, bds_stream_t stream);
 
+/* ---- Fused head of the neural bilateral variants ---------------------------------------------------
+ * NeuralBilateralAffineTransform / MultiScaleNeuralBilateralAffineTransform (models/modules.py:595-820): per pixel the sliced
+ * features [P,F] go through `affine_network` = Linear(F,hidden) tanh Linear(hidden,hidden) tanh Linear(hidden,12), all without bias
+ * (:621-627, :700-706; weights in torch's [out, in] layout: w1 [hidden,F], w2 [hidden,hidden], w3 [12,hidden]), and the 12 outputs
+ * are the row-major 3x4 map the trainer applies with a residual (models/trainers/scene_graph.py:99-106):
+ *   affine [P,12] (may be NULL)  = the network's output (what the modules' forward returns, reshaped [1,H,W,3,4] by the caller)
+ *   out    [P,3]  (may be NULL)  = A[:, :3] rgb + A[:, 3] (+ rgb when residual != 0)
+ * One kernel each way on the FP32 matrix cores (exact f32 products and sums, csrc/mlp_head.hip); hidden must be 64 (the shipped
+ * configs, configs/omnire_neuralbilateral.yaml:251-252, omnire_ms_neuralbilateral.yaml:249-250) and F one of 8, 16, 24, 32
+ * (feature_dim x number of levels), anything else returns BDS_EINVAL.  feats / affine / v_feats / v_affine 16-byte aligned.
+ * bwd takes the gradient of either output (v_out and / or v_affine, the other NULL) and writes v_feats [P,F] and v_rgb [P,3] (the
+ * direct path through the application only: the path through the features belongs to the slice operator; needs v_out) -- each may be
+ * NULL -- and the weight gradients v_w1 / v_w2 / v_w3 (each may be NULL; stored, or added to when accumulate_w != 0).  The hidden
+ * activations are recomputed, nothing is kept from the forward.  temp: bds_mlp_head_bwd_temp_bytes(P, F) bytes (per-wave partial
+ * weight gradients, summed in a fixed order: the result is deterministic). */
+size_t bds_mlp_head_bwd_temp_bytes(int64_t P, int F);
+int bds_mlp_head_fwd(int64_t P, int F, int hidden, const float *feats, const float *rgb, const float *w1, const float *w2,
+                     const float *w3, int residual, float *out, float *affine, bds_stream_t stream);
+int bds_mlp_head_bwd(int64_t P, int F, int hidden, const float *feats, const float *rgb, const float *w1, const float *w2,
+                     const float *w3, int residual, const float *v_out, const float *v_affine, float *v_feats, float *v_rgb,
+                     float *v_w1, float *v_w2, float *v_w3, int accumulate_w, void *temp, size_t temp_bytes, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,3 +68,88 @@ def test_no_feature_slice_without_gpu_is_loud():
     mod = NeuralBilateralAffineTransform("Affine", 2, 4, 4, 2, feature_dim=8, hidden_dim=16, device="cpu")
     with pytest.raises(L.BdsError):
         mod(torch.rand(5, 6, 3), {"img_idx": 0})
+
+
+# ---- the fused head (csrc/mlp_head.hip) against the framework's Linear / Tanh modules on the same device ----------------------------
+def _torch_head(feats, rgb, w1, w2, w3, residual):
+    A = torch.tanh(torch.tanh(feats @ w1.T) @ w2.T) @ w3.T
+    M = A.reshape(-1, 3, 4)
+    out = (M[..., :3] @ rgb[..., None])[..., 0] + M[..., 3]
+    return (out + rgb if residual else out), A
+
+
+def _head_inputs(P, F, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    mk = lambda t: t.cuda().requires_grad_(True)
+    return (mk(r(P, F) * scale), mk(torch.rand(P, 3, generator=g)), mk(r(64, F) * 0.3), mk(r(64, 64) * 0.2), mk(r(12, 64) * 0.2),
+            r(P, 3).cuda(), r(P, 12).cuda())
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("F", [8, 16, 24, 32])
+@pytest.mark.parametrize("P,residual", [(1, True), (31, False), (32, True), (1000, True), (70_001, False), (300_017, True)])
+def test_fused_head_equals_framework_modules(F, P, residual):
+    """Forward (both outputs) and every gradient; sizes below one tile, not a multiple of the 32-pixel tile, and large enough that
+    every wave of the persistent grid owns several tiles and a partial weight gradient."""
+    from bilateral_driving_amd import mlp_head
+    feats, rgb, w1, w2, w3, v_out, v_aff = _head_inputs(P, F, seed=P + F)
+    out, aff = mlp_head.transform_and_maps(feats, rgb, w1, w2, w3, residual=residual)
+    ((out * v_out).sum() + (aff * v_aff).sum()).backward()
+    got = [t.grad.clone() for t in (feats, rgb, w1, w2, w3)]
+    for t in (feats, rgb, w1, w2, w3):
+        t.grad = None
+    f64 = lambda t: t.detach().double().requires_grad_(True)
+    ref_in = [f64(t) for t in (feats, rgb, w1, w2, w3)]
+    r_out, r_aff = _torch_head(*ref_in, residual)
+    ((r_out * v_out.double()).sum() + (r_aff * v_aff.double()).sum()).backward()
+    assert _rel(out.double(), r_out) < 2e-6 and _rel(aff.double(), r_aff) < 2e-6
+    # element-wise too: the 12 entries land in the right rows and the right channels
+    torch.testing.assert_close(out.double(), r_out.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(aff.double(), r_aff.detach(), rtol=1e-4, atol=2e-5)
+    for name, g, r in zip(("feats", "rgb", "w1", "w2", "w3"), got, ref_in):
+        # fp32 sums over up to 3e5 pixels for the weights: compare with the float64 result at float32 summation accuracy
+        assert _rel(g.double(), r.grad) < (3e-5 if name.startswith("w") else 3e-6), (name, _rel(g.double(), r.grad))
+
+
+def test_fused_head_single_outputs_and_saturation():
+    """Only one of the two outputs requested (what the modules do); tanh saturated both ways; deterministic weight gradients."""
+    from bilateral_driving_amd import mlp_head
+    P, F = 5000, 24
+    feats, rgb, w1, w2, w3, v_out, v_aff = _head_inputs(P, F, seed=3, scale=40.0)      # pre-activations of +-100
+    out = mlp_head.transform(feats, rgb, w1, w2, w3, residual=True)
+    assert torch.isfinite(out).all()
+    (out * v_out).sum().backward()
+    g_a = [t.grad.clone() for t in (feats, rgb, w1, w2, w3)]
+    for t in (feats, rgb, w1, w2, w3):
+        t.grad = None
+    out2 = mlp_head.transform(feats, rgb, w1, w2, w3, residual=True)
+    (out2 * v_out).sum().backward()
+    for a, t in zip(g_a, (feats, rgb, w1, w2, w3)):
+        assert torch.equal(a, t.grad)                                                  # no atomics anywhere
+    r_out, _ = _torch_head(*[t.detach().double() for t in (feats, rgb, w1, w2, w3)], True)
+    torch.testing.assert_close(out.double(), r_out, rtol=1e-4, atol=1e-4)
+    for t in (feats, rgb, w1, w2, w3):
+        t.grad = None
+    aff = mlp_head.affine_maps(feats, w1, w2, w3)
+    (aff * v_aff).sum().backward()
+    assert rgb.grad is None                                                            # the maps alone do not depend on the colour
+    ref_in = [t.detach().double().requires_grad_(True) for t in (feats, rgb, w1, w2, w3)]
+    _, r_aff = _torch_head(*ref_in, True)
+    (r_aff * v_aff.double()).sum().backward()
+    for name, t, r in zip(("feats", "w1", "w2", "w3"), (feats, w1, w2, w3), (ref_in[0], ref_in[2], ref_in[3], ref_in[4])):
+        assert _rel(t.grad.double(), r.grad) < 3e-5, name
+
+
+def test_fused_head_refuses_other_sizes_and_cpu():
+    from bilateral_driving_amd import _lib as L, mlp_head
+    assert not mlp_head.supported(13, 64) and not mlp_head.supported(24, 32) and mlp_head.supported(16, 64)
+    feats, rgb, w1, w2, w3, *_ = _head_inputs(10, 24, seed=1)
+    with pytest.raises(L.BdsError):
+        mlp_head.transform(feats.cpu(), rgb.cpu(), w1.cpu(), w2.cpu(), w3.cpu())
+    rc = L.lib().bds_mlp_head_fwd(10, 13, 64, L.ptr(feats), L.ptr(rgb), L.ptr(w1), L.ptr(w2), L.ptr(w3), 1, L.ptr(torch.empty(10, 3, device="cuda")),
+                                  None, L.stream())
+    assert rc == -1
