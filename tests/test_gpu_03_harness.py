@@ -361,3 +361,63 @@ def test_pipelined_view_fronts_equal_the_plain_loop(ops):
     Hn.render_view(p, cams[0], grids, 0, sky, front=front)
     with pytest.raises(AssertionError):             # consumed
         Hn.render_view(p, cams[0], grids, 0, sky, front=front)
+
+
+def test_marshalled_scene_graph_route_equals_the_view_node():
+    """the reference-named route -- per-class get_gaussians (SH colours at the active degree, activations) ->
+    collect_gaussians (concatenation + class labels) -> render_gaussians (rasterization(), clamp, retain_grad; per-class re-render
+    through render_fn(mask)) -- gives the image, depth, opacity and every parameter gradient of harness.render_view on the same
+    Gaussians held as two classes."""
+    import types
+    from bilateral_driving_amd import harness as Hn, marshalling as M
+    dev = "cuda"
+    W, H, N = 320, 192, 5000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    base = Hn.synthetic_scene(N, seed=4, device=dev)
+    base["means"] = base["means"] * torch.tensor([0.3, 0.3, 1.0], device=dev)
+    cut = 3200
+    target = torch.rand(H, W, 3, device=dev)
+
+    def as_class(sl):
+        m = types.SimpleNamespace(sh_degree=3, step=5000, ctrl_cfg=types.SimpleNamespace(sh_degree_interval=1000))
+        m._means = base["means"][sl].clone().requires_grad_(True)
+        m._features_dc = base["sh"][sl, 0].clone().requires_grad_(True)
+        m._features_rest = base["sh"][sl, 1:].clone().requires_grad_(True)
+        m._opacities = base["opacity_logits"][sl, None].clone().requires_grad_(True)
+        m._scales = base["log_scales"][sl].clone().requires_grad_(True)
+        m._quats = base["quats"][sl].clone().requires_grad_(True)
+        return m
+    models = {"Background": as_class(slice(0, cut)), "RigidNodes": as_class(slice(cut, N))}
+    classes = {"Background": 0, "RigidNodes": 1}
+    c2w = torch.linalg.inv(cam.viewmat)
+    camera = M.process_camera({"camera_to_world": c2w, "intrinsics": cam.K, "height": H, "width": W}, torch.tensor([0]))
+    gs, labels = M.collect_gaussians(models, classes, camera)
+    assert labels.shape == (N,) and int((labels == 1).sum()) == N - cut
+    results, render_fn, info = M.render_gaussians(gs, camera, near_plane=0.1, far_plane=1e10, render_mode="RGB+ED", radius_clip=0.0)
+    loss = (results["rgb_gaussians"] - target).abs().mean() + 0.001 * results["depth"].mean() + 0.01 * results["opacity"].mean()
+    loss.backward()
+    assert info["means2d"].grad is not None and info["means2d"].absgrad.shape == (1, N, 2)
+
+    p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    out = Hn.render_view_staged(p, cam, Hn.make_grids(1, device=dev), 0, torch.zeros(H, W, 3, device=dev))
+    rgb_g = torch.clamp(out["rgb_gaussians"], max=1.0)                       # base.py:414 (the staged chain clamps inside the grid op)
+    loss2 = (rgb_g - target).abs().mean() + 0.001 * out["depth"].mean() + 0.01 * out["opacity"].mean()
+    loss2.backward()
+    torch.testing.assert_close(results["rgb_gaussians"], rgb_g, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(results["depth"], out["depth"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(results["opacity"], out["opacity"], rtol=1e-4, atol=2e-5)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    cat = lambda name: torch.cat([getattr(models["Background"], name).grad, getattr(models["RigidNodes"], name).grad])
+    assert rel(cat("_means"), p["means"].grad) < 1e-3
+    assert rel(cat("_scales"), p["log_scales"].grad) < 1e-3
+    assert rel(cat("_quats"), p["quats"].grad) < 1e-3
+    assert rel(cat("_opacities")[:, 0], p["opacity_logits"].grad) < 1e-3
+    assert rel(torch.cat([cat("_features_dc")[:, None], cat("_features_rest")], 1), p["sh"].grad) < 1e-3
+    # the evaluation path's per-class render: the class mask multiplies the opacities (scene_graph.py:296-313)
+    with torch.no_grad():
+        rgb_bg, _, op_bg = render_fn((labels == 0).float())
+        rgb_dyn, _, op_dyn = render_fn((labels == 1).float())
+    assert float(op_bg.max()) <= 1.0 + 1e-5 and float(op_dyn.sum()) > 0
+    assert float((op_bg + op_dyn - results["opacity"].detach()).min()) > -1e-4     # two partial scenes cover at least the joint one
