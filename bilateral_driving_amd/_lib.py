@@ -78,6 +78,9 @@ _SIGS = {
     "bds_refine_geometry": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_refine_rows": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f]),
     "bds_refine_out_of_bound": (_i, [_i64, _f, _f, _i64, _f, _f, _f]),
+    "bds_bilagrid_slice_feat_image_ok": (_i, [_i, _i, _i, _i]),
+    "bds_bilagrid_slice_feat_image_fwd": (_i, [_i, _i, _i, _f, _i, _i, _i, _f, _f, _f]),
+    "bds_bilagrid_slice_feat_image_bwd": (_i, [_i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f]),
     "bds_mlp_head_bwd_temp_bytes": (_sz, [_i64, _i]),
     "bds_mlp_head_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _f]),
     "bds_mlp_head_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _sz, _f]),

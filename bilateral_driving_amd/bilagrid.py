@@ -114,6 +114,49 @@ class _SlicePoints(torch.autograd.Function):
         return v_grid, None, v_rgb
 
 
+class _SliceImage(torch.autograd.Function):
+    """grid [C,L,gy,gx], rgb [H,W,3] -> [H,W,C]: the feature slice at the pixel grid (xy = linspace x linspace), band-staged in LDS."""
+
+    @staticmethod
+    def forward(ctx, grid: Tensor, rgb: Tensor):
+        L.require_gpu(grid, rgb)
+        grid, rgb = _f32c(grid), _f32c(rgb)
+        H, W, _ = rgb.shape
+        nc, gl, gy, gx = grid.shape
+        out = torch.empty(H, W, nc, device=grid.device, dtype=torch.float32)
+        L.check(L.lib().bds_bilagrid_slice_feat_image_fwd(H, W, nc, L.ptr(grid), gx, gy, gl, L.ptr(rgb), L.ptr(out), L.stream()),
+                "bds_bilagrid_slice_feat_image_fwd")
+        ctx.save_for_backward(grid, rgb)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        grid, rgb = ctx.saved_tensors
+        H, W, _ = rgb.shape
+        nc, gl, gy, gx = grid.shape
+        v_out = _f32c(v_out)
+        v_grid = torch.zeros_like(grid) if ctx.needs_input_grad[0] else None
+        v_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[1] else None
+        L.check(L.lib().bds_bilagrid_slice_feat_image_bwd(H, W, nc, L.ptr(grid), gx, gy, gl, L.ptr(rgb), L.ptr(v_out), L.ptr(v_grid),
+                                                          L.ptr(v_rgb), L.stream()), "bds_bilagrid_slice_feat_image_bwd")
+        return v_grid, v_rgb
+
+
+def slice_feature_image(bil_grids: "NeuralBilateralGrid", rgb: Tensor, idx: int) -> Tensor:
+    """``slice_feature(bil_grids, xy, rgb, idx)["affine_features"]`` for the case every caller in the reference has
+    (models/modules.py:643-650, 728-760): ``xy`` = the pixel grid ``meshgrid(linspace(0,1,H), linspace(0,1,W))`` of the image ``rgb``
+    [H,W,3].  Returns [1,H,W,feature_dim].  The coordinates are implied, so the kernels stage the grid rows of a pixel row in LDS
+    (``bds_bilagrid_slice_feat_image_*``); grids whose row band does not fit go through the point form."""
+    grid = bil_grids.grids[int(idx)]
+    nc, gl, gy, gx = grid.shape
+    H, W, _ = rgb.shape
+    if rgb.is_cuda and L.lib().bds_bilagrid_slice_feat_image_ok(nc, gx, gy, gl):
+        return _SliceImage.apply(grid, rgb).unsqueeze(0)
+    ys, xs = torch.meshgrid(torch.linspace(0, 1.0, H, device=rgb.device), torch.linspace(0, 1.0, W, device=rgb.device), indexing="ij")
+    xy = torch.stack([xs, ys], dim=-1).unsqueeze(0)
+    return slice_feature(bil_grids, xy, rgb.unsqueeze(0), torch.tensor(int(idx), device=rgb.device, dtype=torch.long))["affine_features"]
+
+
 class BilateralGrid(nn.Module):
     """Holds ``num`` bilateral grids [num, 12, L, H, W], identity-initialised (lib_bilagrid.py:256-311)."""
 

@@ -754,6 +754,124 @@ __global__ __launch_bounds__(kBgBlock) void slice_feat_bwd_kernel(int64_t P, int
   }
 }
 
+// ---- feature slice of a whole IMAGE (xy = the pixel grid, linspace(0,1) both ways: what the neural modules slice at,
+// models/modules.py:643-650, 728-760) ------------------------------------------------------------------------------------------
+// A pixel row touches two grid rows (y0, y1) only: that band of the grid -- [NC][gl][2][gx] floats, 24 KB for the shipped
+// 16x16x8 / 24-feature grid whose full 196 KB does not fit the LDS -- is staged per workgroup, the per-pixel gathers and, backward,
+// the scatter (wave-level butterfly pre-reduction + LDS atomics, slice_grid_scatter) run against the LDS band through the SAME
+// sampling / scatter functions with a band-local cell (gy = 2).  A workgroup owns a block of consecutive rows and flushes its
+// band accumulator with one atomic per non-zero entry when the band changes: ~2 M global atomics per image instead of the
+// point kernel's ~25 M same-address ones (1.77 ms -> see profiles/).
+constexpr int kBandMaxFloats = 6 * 1024;   // values (forward) or values + accumulator (backward): <= 48 KB per workgroup
+
+__device__ __forceinline__ void band_load(float *__restrict__ vals, const float *__restrict__ grid, int NC, int gx, int gy, int gl,
+                                          int y0, int y1) {
+  const int n = NC * gl * 2 * gx;
+  for (int e = threadIdx.x; e < n; e += kBgBlock) {
+    const int x = e % gx, yb = (e / gx) & 1, cz = e / (2 * gx);
+    vals[e] = grid[((int64_t)cz * gy + (yb ? y1 : y0)) * gx + x];
+  }
+}
+
+__device__ __forceinline__ Cell band_cell(int x, int W, float lin_x, float y01, float r, float g, float b, int gx, int gy, int gl) {
+  Cell c = slice_cell(linspace01_s(x, W, lin_x), y01, rgb2gray(r, g, b), gx, gy, gl);
+  c.y1 = c.y1 != c.y0 ? 1 : 0;   // band-local rows
+  c.y0 = 0;
+  return c;
+}
+
+__global__ __launch_bounds__(kBgBlock) void slice_feat_image_fwd_kernel(int H, int W, int NC, const float *__restrict__ grid, int gx,
+                                                                       int gy, int gl, float lin_x, float lin_y, int rows_per_wg,
+                                                                       const float *__restrict__ rgb, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float band[];
+  const int volb = gl * 2 * gx;
+  int cur = -1;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < H ? r0 + rows_per_wg : H;
+  for (int y = r0; y < r1; y++) {
+    const float y01 = linspace01_s(y, H, lin_y);
+    const int y0 = (int)floorf(grid_coord(y01, gy)), y1 = y0 + 1 < gy ? y0 + 1 : gy - 1;
+    if (y0 != cur) {
+      __syncthreads();
+      band_load(band, grid, NC, gx, gy, gl, y0, y1);
+      __syncthreads();
+      cur = y0;
+    }
+    for (int x = threadIdx.x; x < W; x += kBgBlock) {
+      const int64_t i = (int64_t)y * W + x;
+      const Cell c = band_cell(x, W, lin_x, y01, rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], gx, gy, gl);
+      for (int c0 = 0; c0 < NC; c0 += 12) {
+        const int nch = NC - c0 < 12 ? NC - c0 : 12;
+        float a[12];
+        slice_sample_n(band + c0 * volb, gx, 2, gl, c, nch, a, nullptr);
+        float *dst = out + i * NC + c0;
+        if ((NC & 3) == 0) {   // rows and chunks are 16-byte aligned
+          for (int k = 0; k + 4 <= nch; k += 4) *reinterpret_cast<float4 *>(dst + k) = make_float4(a[k], a[k + 1], a[k + 2], a[k + 3]);
+        } else {
+          for (int k = 0; k < nch; k++) dst[k] = a[k];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBgBlock) void slice_feat_image_bwd_kernel(int H, int W, int NC, const float *__restrict__ grid, int gx,
+                                                                       int gy, int gl, float lin_x, float lin_y, int rows_per_wg,
+                                                                       const float *__restrict__ rgb, const float *__restrict__ v_out,
+                                                                       float *__restrict__ v_grid, float *__restrict__ v_rgb) {
+  extern __shared__ __attribute__((aligned(16))) float band[];
+  const int volb = gl * 2 * gx, nband = NC * volb;
+  float *vals = band, *acc = band + nband;
+  int cur = -1, cur_y1 = 0;
+  auto flush = [&]() {   // one atomic per touched entry of the band; leaves the accumulator zeroed
+    for (int e = threadIdx.x; e < nband; e += kBgBlock) {
+      const float v = acc[e];
+      if (v != 0.f) {
+        const int x = e % gx, yb = (e / gx) & 1, cz = e / (2 * gx);
+        atomicAdd(v_grid + ((int64_t)cz * gy + (yb ? cur_y1 : cur)) * gx + x, v);
+        acc[e] = 0.f;
+      }
+    }
+  };
+  for (int e = threadIdx.x; e < nband; e += kBgBlock) acc[e] = 0.f;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < H ? r0 + rows_per_wg : H;
+  const int w_pad = (W + kBgBlock - 1) / kBgBlock * kBgBlock;   // the scatter is a wave collective: uniform trip count
+  for (int y = r0; y < r1; y++) {
+    const float y01 = linspace01_s(y, H, lin_y);
+    const int y0 = (int)floorf(grid_coord(y01, gy)), y1 = y0 + 1 < gy ? y0 + 1 : gy - 1;
+    if (y0 != cur) {
+      __syncthreads();
+      if (cur >= 0 && v_grid) flush();
+      band_load(vals, grid, NC, gx, gy, gl, y0, y1);
+      cur = y0; cur_y1 = y1;
+      __syncthreads();
+    }
+    for (int x = threadIdx.x; x < w_pad; x += kBgBlock) {
+      const bool active = x < W;
+      const int64_t i = (int64_t)y * W + (active ? x : 0);
+      const Cell c = band_cell(active ? x : 0, W, lin_x, y01, rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], gx, gy, gl);
+      float v_iz = 0.f;
+      for (int c0 = 0; c0 < NC; c0 += 12) {
+        const int nch = NC - c0 < 12 ? NC - c0 : 12;
+        float va[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) va[k] = (active && k < nch) ? v_out[i * NC + c0 + k] : 0.f;
+        if (v_grid) slice_grid_scatter(acc + c0 * volb, c, gx, 2, gl, 1.f, va, active, nch);
+        if (active && v_rgb && c.z_interior) {
+          float a12[12], dz[12];
+          slice_sample_n(vals + c0 * volb, gx, 2, gl, c, nch, a12, dz);
+          for (int k = 0; k < nch; k++) v_iz += va[k] * dz[k];
+        }
+      }
+      if (active && v_rgb) {
+        const float vg = c.z_interior ? v_iz * (float)(gl - 1) : 0.f;
+        v_rgb[i * 3] = vg * kGrayR; v_rgb[i * 3 + 1] = vg * kGrayG; v_rgb[i * 3 + 2] = vg * kGrayB;
+      }
+    }
+  }
+  __syncthreads();
+  if (cur >= 0 && v_grid) flush();
+}
+
 // ---- TV regulariser ----------------------------------------------------------------------------
 __global__ __launch_bounds__(kBgBlock) void tv_fwd_kernel(int64_t total, int gx, int gy, int gl, const float *__restrict__ x,
                                                          float scale_l, float scale_y, float scale_x,
@@ -1269,6 +1387,38 @@ extern "C" int bds_bilagrid_slice_feat_bwd(int64_t P, int NC, const float *grid,
   BDS_REQUIRE(grid && xy && rgb && v_out);
   hipLaunchKernelGGL(slice_feat_bwd_kernel, dim3((unsigned)cdiv(P, kBgBlock)), dim3(kBgBlock), 0, as_stream(stream), P, NC, grid, gx,
                      gy, gl, xy, rgb, v_out, v_grid, v_rgb);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_slice_feat_image_ok(int NC, int gx, int gy, int gl) {
+  return NC >= 1 && gx >= 1 && gy >= 1 && gl >= 1 && (int64_t)NC * gl * 2 * gx <= kBandMaxFloats;
+}
+
+extern "C" int bds_bilagrid_slice_feat_image_fwd(int H, int W, int NC, const float *grid, int gx, int gy, int gl, const float *rgb,
+                                                 float *out, bds_stream_t stream) {
+  BDS_REQUIRE(H >= 0 && W >= 0 && bds_bilagrid_slice_feat_image_ok(NC, gx, gy, gl));
+  if (H == 0 || W == 0) return BDS_OK;
+  BDS_REQUIRE(grid && rgb && out && ((NC & 3) || aligned16(out)));
+  const float lin_x = W > 1 ? 1.0f / (float)(W - 1) : 0.f, lin_y = H > 1 ? 1.0f / (float)(H - 1) : 0.f;
+  const size_t lds = (size_t)NC * gl * 2 * gx * sizeof(float);
+  hipLaunchKernelGGL(slice_feat_image_fwd_kernel, dim3((unsigned)H), dim3(kBgBlock), lds, as_stream(stream), H, W, NC, grid, gx, gy, gl,
+                     lin_x, lin_y, 1, rgb, out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_bilagrid_slice_feat_image_bwd(int H, int W, int NC, const float *grid, int gx, int gy, int gl, const float *rgb,
+                                                 const float *v_out, float *v_grid, float *v_rgb, bds_stream_t stream) {
+  BDS_REQUIRE(H >= 0 && W >= 0 && bds_bilagrid_slice_feat_image_ok(NC, gx, gy, gl));
+  if (H == 0 || W == 0) return BDS_OK;
+  BDS_REQUIRE(grid && rgb && v_out);
+  const float lin_x = W > 1 ? 1.0f / (float)(W - 1) : 0.f, lin_y = H > 1 ? 1.0f / (float)(H - 1) : 0.f;
+  const size_t lds = 2 * (size_t)NC * gl * 2 * gx * sizeof(float);
+  // consecutive rows per workgroup: fewer band flushes; still >= 256 workgroups on a 1080-row image
+  const int rows = H >= 1024 ? 4 : (H >= 512 ? 2 : 1);
+  hipLaunchKernelGGL(slice_feat_image_bwd_kernel, dim3((unsigned)cdiv(H, rows)), dim3(kBgBlock), lds, as_stream(stream), H, W, NC, grid,
+                     gx, gy, gl, lin_x, lin_y, rows, rgb, v_out, v_grid, v_rgb);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -342,27 +342,37 @@ __global__ __launch_bounds__(kMhBlock) void mlp_head_bwd_kernel(int64_t P, const
       if (d_row(r, half) < kMhAff) part[d_row(r, half) * kMhHid + 32 * vb + col] = g3[vb][r];
 }
 
-// sums the waves' partials in a fixed order; the three matrices are contiguous in a partial: [64, F] | [64, 64] | [12, 64]
+// sums the waves' partials in a fixed order; the three matrices are contiguous in a partial: [64, F] | [64, 64] | [12, 64].
+// Workgroup = 32 entries x 8 partial-lanes: coalesced 128-byte rows, 8 independent loads in flight per thread
 __global__ __launch_bounds__(256) void mlp_head_reduce_kernel(int n_parts, int F, const float *__restrict__ partials,
                                                              float *__restrict__ v_w1, float *__restrict__ v_w2,
                                                              float *__restrict__ v_w3, int accumulate) {
+  __shared__ float sred[8][33];
   const int n1 = kMhHid * F, n2 = kMhHid * kMhHid, n3 = kMhAff * kMhHid, len = n1 + n2 + n3;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= len) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int p = 0;
-  for (; p + 4 <= n_parts; p += 4) {
-    s0 += partials[(int64_t)p * len + e];
-    s1 += partials[(int64_t)(p + 1) * len + e];
-    s2 += partials[(int64_t)(p + 2) * len + e];
-    s3 += partials[(int64_t)(p + 3) * len + e];
+  const int ex = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + ex;
+  float s = 0.f;
+  if (e < len) {
+    int p = py;
+    for (; p + 56 < n_parts; p += 64) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = partials[(int64_t)(p + 8 * u) * len + e];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += t[u];
+    }
+    for (; p < n_parts; p += 8) s += partials[(int64_t)p * len + e];
   }
-  for (; p < n_parts; p++) s0 += partials[(int64_t)p * len + e];
-  const float s = (s0 + s1) + (s2 + s3);
+  sred[py][ex] = s;
+  __syncthreads();
+  if (py != 0 || e >= len) return;
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; q++) t += sred[q][ex];
   float *base = e < n1 ? v_w1 : (e < n1 + n2 ? v_w2 : v_w3);
   if (!base) return;
   float *dst = base + (e < n1 ? e : (e < n1 + n2 ? e - n1 : e - n1 - n2));
-  *dst = accumulate ? *dst + s : s;
+  *dst = accumulate ? *dst + t : t;
 }
 
 inline int mh_grid_fwd(int64_t P) {
@@ -443,7 +453,7 @@ extern "C" int bds_mlp_head_bwd(int64_t P, int F, int hidden, const float *feats
   if (rc != BDS_OK) return rc;
   if (v_w1 || v_w2 || v_w3) {
     const int len = kMhHid * F + kMhHid * kMhHid + kMhAff * kMhHid;
-    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, st, mh_grid_bwd(P) * kMhWaves, F, partials,
+    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3((unsigned)cdiv(len, 32)), dim3(256), 0, st, mh_grid_bwd(P) * kMhWaves, F, partials,
                        v_w1, v_w2, v_w3, accumulate_w);
     BDS_LAUNCH_CHECK();
   }

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import mlp_head
-from .bilagrid import BilateralGrid, NeuralBilateralGrid, bilagrid_transform, slice, slice_feature, total_variation_loss
+from .bilagrid import (BilateralGrid, NeuralBilateralGrid, bilagrid_transform, slice, slice_feature, slice_feature_image,
+                       total_variation_loss)
 
 
 def _img_index(image_infos) -> int:
@@ -269,11 +270,6 @@ class AffineTransform(nn.Module):
         return {self.class_prefix + "all": self.parameters()}
 
 
-def _pixel_xy(H: int, W: int, device) -> Tensor:
-    gy, gx = torch.meshgrid(torch.linspace(0, 1.0, H, device=device), torch.linspace(0, 1.0, W, device=device), indexing="ij")
-    return torch.stack([gx, gy], dim=-1).unsqueeze(0)
-
-
 def _affine_network(in_dim: int, hidden_dim: int) -> nn.Sequential:
     return nn.Sequential(nn.Linear(in_dim, hidden_dim, bias=False), nn.Tanh(), nn.Linear(hidden_dim, hidden_dim, bias=False), nn.Tanh(),
                          nn.Linear(hidden_dim, 12, bias=False))
@@ -297,11 +293,15 @@ def _head_transform(net: nn.Sequential, feats: Tensor, rgb: Tensor) -> Tensor:
     return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
 
 
-def _sliced_features(grids: NeuralBilateralGrid, rgb: Tensor, xy: Tensor, idxs: Sequence[int]) -> Tensor:
-    """Feature slice for one image, or the mean over the neighbour images' grids in the test branch (modules.py:651-662)."""
+def _sliced_features(grids: NeuralBilateralGrid, rgb: Tensor, xy: Optional[Tensor], idxs: Sequence[int]) -> Tensor:
+    """Feature slice for one image, or the mean over the neighbour images' grids in the test branch (modules.py:651-662).
+    ``xy`` None: the pixel grid of ``rgb`` itself (every call site of the reference) -> the image form of the slice."""
     acc = None
     for i in idxs:
-        f = slice_feature(grids, xy, rgb.unsqueeze(0), torch.tensor(i, device=rgb.device, dtype=torch.long))["affine_features"]
+        if xy is None:
+            f = slice_feature_image(grids, rgb, i)
+        else:
+            f = slice_feature(grids, xy, rgb.unsqueeze(0), torch.tensor(i, device=rgb.device, dtype=torch.long))["affine_features"]
         acc = f if acc is None else acc + f
     return acc / len(idxs) if len(idxs) > 1 else acc
 
@@ -334,7 +334,7 @@ class NeuralBilateralAffineTransform(nn.Module):
         k = _img_index(image_infos)
         H, W, _ = rgb.shape
         idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
-        return _sliced_features(self.bil_grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
+        return _sliced_features(self.bil_grids, rgb, None, idxs)
 
     def transform(self, rgb: Tensor, image_infos) -> Tensor:
         """forward + the trainer's application with the residual (scene_graph.py:99-102) in one pass: the [H,W,3,4] maps are not
@@ -390,13 +390,13 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
         for i in range(len(self.grid_size)):
             grids = getattr(self, f"bil_grids{i}")
             if guidance_factor is not None:
-                xy, lo = self.get_sample_grid(guidance_factor[i], H, W, rgb)
-                f = _sliced_features(grids, lo, xy, idxs)
+                _, lo = self.get_sample_grid(guidance_factor[i], H, W, rgb)     # xy = the pixel grid of the low-res image
+                f = _sliced_features(grids, lo, None, idxs)
                 B, Hm, Wm, C = f.shape
                 if (Hm, Wm) != (H, W):     # fill_matrix_res on the feature channels (modules.py:748)
                     f = F.interpolate(f.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
             else:
-                f = _sliced_features(grids, rgb, _pixel_xy(H, W, rgb.device), idxs)
+                f = _sliced_features(grids, rgb, None, idxs)
             out_list.append(f)
         self.save_matrix = out_list
         return torch.cat(out_list, dim=-1)

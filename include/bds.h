@@ -210,6 +210,18 @@ int bds_bilagrid_slice_feat_fwd(int64_t P, int NC, const float *grid, int gx, in
 int bds_bilagrid_slice_feat_bwd(int64_t P, int NC, const float *grid, int gx, int gy, int gl, const float *xy,
                                 const float *rgb, const float *v_out, float *v_grid, float *v_rgb, bds_stream_t stream);
 
+/* The same slice over a whole IMAGE: xy is implied -- pixel (x, y) samples at (linspace(0,1,W)[x], linspace(0,1,H)[y]), which is what
+ * the neural modules slice at (models/modules.py:643-650, 728-760: torch.meshgrid of two linspaces) -- so a workgroup can stage the
+ * two grid rows a pixel row touches in LDS (the band [NC][gl][2][gx]) and scatter the gradient there.  rgb [H,W,3] -> out [H,W,NC]
+ * (16-byte aligned when NC % 4 == 0).  bwd ACCUMULATES into v_grid [NC,gl,gy,gx] (caller zeroes; may be NULL) and writes v_rgb [H,W,3]
+ * (the guidance route; may be NULL).  bds_bilagrid_slice_feat_image_ok(NC, gx, gy, gl) != 0 when the band fits (NC*gl*2*gx <= 6144
+ * floats: the shipped 16x16x8 grid with 24 features exactly); otherwise the calls return BDS_EINVAL and the point form applies. */
+int bds_bilagrid_slice_feat_image_ok(int NC, int gx, int gy, int gl);
+int bds_bilagrid_slice_feat_image_fwd(int H, int W, int NC, const float *grid, int gx, int gy, int gl, const float *rgb, float *out,
+                                      bds_stream_t stream);
+int bds_bilagrid_slice_feat_image_bwd(int H, int W, int NC, const float *grid, int gx, int gy, int gl, const float *rgb,
+                                      const float *v_out, float *v_grid, float *v_rgb, bds_stream_t stream);
+
 /* Fused image transform: models/modules.py:505-522 MultiScaleBilateralAffineTransform.forward
  * (train branch: get_sample_grid :494-504, slice, fill_matrix_res :409-420), the single-scale
  * BilateralAffineTransform.forward :317-335 (factor 1), the sequential application at

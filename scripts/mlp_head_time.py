@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Time of the fused neural head (csrc/mlp_head.hip) against the framework's Linear / Tanh / matmul modules on one 1920x1080 image
 (the reference's form: models/modules.py:621-627 + trainers/scene_graph.py:99-106).  Prints microseconds per call."""
+import os
 import sys
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bilateral_driving_amd import mlp_head  # noqa: E402
 
 

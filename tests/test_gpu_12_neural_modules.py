@@ -153,3 +153,36 @@ def test_fused_head_refuses_other_sizes_and_cpu():
     rc = L.lib().bds_mlp_head_fwd(10, 13, 64, L.ptr(feats), L.ptr(rgb), L.ptr(w1), L.ptr(w2), L.ptr(w3), 1, L.ptr(torch.empty(10, 3, device="cuda")),
                                   None, L.stream())
     assert rc == -1
+
+
+# ---- the image form of the feature slice (band of the grid staged in LDS) against the point form ---------------------------------------
+@pytest.mark.parametrize("H,W,nc,gx,gy,gl", [(11, 14, 24, 6, 5, 4), (1, 300, 8, 16, 16, 8), (75, 130, 24, 16, 16, 8), (40, 700, 13, 7, 9, 3),
+                                            (33, 65, 8, 1, 1, 1), (1080, 1920, 24, 16, 16, 8), (540, 960, 16, 16, 16, 8)])
+def test_image_slice_equals_point_slice(H, W, nc, gx, gy, gl):
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd.bilagrid import _SliceImage, _SlicePoints
+    assert L.lib().bds_bilagrid_slice_feat_image_ok(nc, gx, gy, gl)
+    g = torch.Generator().manual_seed(H * 7 + W)
+    grid = torch.randn(nc, gl, gy, gx, generator=g).cuda().requires_grad_(True)
+    rgb = (torch.rand(H, W, 3, generator=g) * 1.3 - 0.15).cuda().requires_grad_(True)      # guidance beyond [0, 1]: border cells
+    v = torch.randn(H, W, nc, generator=g).cuda()
+    out = _SliceImage.apply(grid, rgb)
+    (out * v).sum().backward()
+    g_img = (grid.grad.clone(), rgb.grad.clone())
+    grid.grad = None; rgb.grad = None
+    ys, xs = torch.meshgrid(torch.linspace(0, 1.0, H, device="cuda"), torch.linspace(0, 1.0, W, device="cuda"), indexing="ij")
+    xy = torch.stack([xs, ys], dim=-1).reshape(-1, 2)
+    ref = _SlicePoints.apply(grid, xy, rgb.reshape(-1, 3)).reshape(H, W, nc)
+    (ref * v).sum().backward()
+    assert torch.equal(out, ref)                                   # same sampling arithmetic on the same values
+    torch.testing.assert_close(g_img[1], rgb.grad, rtol=1e-5, atol=1e-5)
+    scale = float(grid.grad.abs().max())
+    torch.testing.assert_close(g_img[0], grid.grad, rtol=0, atol=2e-5 * scale)      # sums of up to 2e6 terms in another order
+
+
+def test_image_slice_refuses_a_band_that_does_not_fit():
+    from bilateral_driving_amd import _lib as L
+    assert not L.lib().bds_bilagrid_slice_feat_image_ok(48, 16, 16, 8)
+    assert L.lib().bds_bilagrid_slice_feat_image_ok(24, 16, 16, 8)
+    grid = torch.zeros(48, 8, 16, 16, device="cuda"); rgb = torch.rand(8, 8, 3, device="cuda"); out = torch.empty(8, 8, 48, device="cuda")
+    assert L.lib().bds_bilagrid_slice_feat_image_fwd(8, 8, 48, L.ptr(grid), 16, 16, 8, L.ptr(rgb), L.ptr(out), L.stream()) == -1
