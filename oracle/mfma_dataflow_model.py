@@ -233,3 +233,121 @@ def backward(feats, rgb, W1, W2, W3, v_out, residual=True):
     v_feats = tile_to_matrix(d_x)[:F].T.copy()                   # lane (px, h) stores float4 groups f = 8 g + 4 h + 0..3
     return dict(v_rgb=v_rgb, v_feats=v_feats, v_w1=grad_tiles_to_matrix(g1, HID, F), v_w2=grad_tiles_to_matrix(g2, HID, HID),
                 v_w3=grad_tiles_to_matrix(g3, OUTP, HID))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the feature slice folded into the head (DESIGN.md "next"): with tiles cut at the grid's cell boundaries the 32 pixels of a tile share
+# their (x0, y0) cell on every level, so they touch K = sum_l 4 * gl_l grid "slots" (z, y-corner, x-corner) and
+#   features^T [F x 32 px] = G^T [F x K] . Wt [K x 32 px]                 (one more chained D tile in front of layer 1)
+#   d(grid slots) [K x F]  += Wt [K x px] . dF [px x F]                   (one more product over the pixels, via the LDS transposes)
+#   d(gray) [px]            = sum_ch dF^T[ch][px] * (G^T . dWt/dz)[ch][px] (row-wise dot of two D tiles + one exchange with lane ^ 32)
+# Slot order: q = off_l + (z * 2 + yb) * 2 + xb, consumed as k = 2 s + half -> the lane half IS the x corner.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def slot_table(levels):
+    """levels: list of (gl, nch).  Returns [(level, z, yb)] per step s (K/2 steps), channel offsets, K."""
+    steps, choff, c = [], [], 0
+    for l, (gl, nch) in enumerate(levels):
+        choff.append(c); c += nch
+        for z in range(gl):
+            for yb in (0, 1):
+                steps.append((l, z, yb))
+    return steps, choff, 2 * len(steps)
+
+
+def slice_weights(steps, cells, deriv=False, gls=None):
+    """B operands of the slice: per step s the lane (px, half = x corner) value Wt[slot][px] = wz(z) * wy(yb) * wx(half), or its
+    derivative with respect to the guidance coordinate times (gl - 1) and the interior flag (the chain rule down to the gray value).
+    cells: per level dict(fx [32], fy scalar, z0 [32] int, z1 [32] int, fz [32], interior [32] bool)."""
+    out = []
+    for (l, z, yb) in steps:
+        c = cells[l]
+        wx = np.where(HALF == 1, c["fx"][COL], 1 - c["fx"][COL])
+        wy = c["fy"] if yb else 1 - c["fy"]
+        if not deriv:
+            wz = (c["z0"][COL] == z) * (1 - c["fz"][COL]) + (c["z1"][COL] == z) * c["fz"][COL]
+        else:
+            wz = ((c["z1"][COL] == z).astype(f32) - (c["z0"][COL] == z).astype(f32)) * (gls[l] - 1) * c["interior"][COL]
+        out.append((wz * wy * wx).astype(f32))
+    return out
+
+
+def grid_operands(steps, choff, levels, region_grids):
+    """A operands of the slice: lane (i = channel, half = x corner) holds G_l[slot][ch] of the region's 2 x 2 x gl nodes (zero when
+    the channel belongs to another level).  region_grids[l]: [nch, gl, 2, 2] the nodes (z, yb, xb) of this region."""
+    out = []
+    for (l, z, yb) in steps:
+        nch = levels[l][1]
+        ch = COL - choff[l]
+        ok = (ch >= 0) & (ch < nch)
+        out.append(np.where(ok, region_grids[l][np.clip(ch, 0, nch - 1), z, yb, HALF], 0).astype(f32))
+    return out
+
+
+def slice_tile(a_ops, b_ops):
+    acc = zeros_tile()
+    for a, b in zip(a_ops, b_ops):
+        acc = mfma_32x32x2(a, b, acc)
+    return acc                                                    # rows = channels, cols = pixels
+
+
+def layer_first_chained(W1, xt, F):
+    """Layer 1 fed by the slice's D tile: step = register r of the tile (channel rowmap(r, half)), only the registers whose row is
+    a real channel."""
+    out = []
+    for o in range(2):
+        acc = zeros_tile()
+        for r in range(16):
+            if 8 * (r >> 2) >= F:                                 # rows 8 g + 4 h + (r & 3): the whole register group is padding
+                continue
+            k = rowmap(r, HALF)
+            a = np.where(k < F, W1[32 * o + COL, np.minimum(k, F - 1)], 0).astype(f32)
+            acc = mfma_32x32x2(a, xt[r], acc)
+        out.append(acc)
+    return out
+
+
+def fused_forward(levels, region_grids, cells, rgb, W1, W2, W3, residual=True):
+    F = sum(n for _, n in levels)
+    steps, choff, K = slot_table(levels)
+    xt = slice_tile(grid_operands(steps, choff, levels, region_grids), slice_weights(steps, cells))
+    h1 = [np.tanh(t).astype(f32) for t in layer_first_chained(W1, xt, F)]
+    h2 = [np.tanh(t).astype(f32) for t in layer_chained(W2, h1, 2)]
+    aff = layer_chained(W3, h2, 1)[0]
+    return apply_affine(aff, rgb, residual), dict(xt=xt, h1=h1, h2=h2, aff=aff, steps=steps, choff=choff, K=K)
+
+
+def fused_backward(levels, region_grids, cells, rgb, W1, W2, W3, v_out, residual=True):
+    F = sum(n for _, n in levels)
+    gls = [g for g, _ in levels]
+    _, st = fused_forward(levels, region_grids, cells, rgb, W1, W2, W3, residual)
+    xt, h1, h2, aff, steps, choff, K = (st[k] for k in ("xt", "h1", "h2", "aff", "steps", "choff", "K"))
+    v_rgb = rgb_grad(aff, v_out, residual)
+    d_aff = affine_grad_tile(v_out, rgb)
+    g3 = outer_over_pixels(tile_to_lds([d_aff]), tile_to_lds(h2), [[zeros_tile(), zeros_tile()]], 1, 2)
+    d_h2 = chained_transposed(W3, [d_aff], 2, k_regs=8)
+    d_z2 = [(d * (1 - h * h)).astype(f32) for d, h in zip(d_h2, h2)]
+    g2 = outer_over_pixels(tile_to_lds(d_z2), tile_to_lds(h1), [[zeros_tile(), zeros_tile()], [zeros_tile(), zeros_tile()]], 2, 2)
+    d_h1 = chained_transposed(W2, d_z2, 2)
+    d_z1 = [(d * (1 - h * h)).astype(f32) for d, h in zip(d_h1, h1)]
+    g1 = outer_over_pixels(tile_to_lds(d_z1), tile_to_lds([xt]), [[zeros_tile()], [zeros_tile()]], 2, 1)   # the slice tile IS in D layout
+    d_x = chained_transposed(W1, d_z1, 1)[0]                      # rows = channels
+    # guidance: G^T . dWt/dz, dotted with d_x row by row; each half holds half of the rows
+    a_ops = grid_operands(steps, choff, levels, region_grids)
+    dxdz = slice_tile(a_ops, slice_weights(steps, cells, deriv=True, gls=gls))
+    part = (d_x * dxdz).sum(axis=0).astype(f32)                   # over the 16 registers of a lane
+    v_gray = (part + part[LANES ^ 32])[:32]
+    # grid slots: Wt (lane = pixel) -> LDS rows = slot; d_x tile -> LDS rows = channel; product over the pixels
+    wt = slice_weights(steps, cells)
+    nblk = (K + 31) // 32
+    TW = np.full((32 * nblk, LDS_STRIDE), np.nan, f32)
+    for s, w in enumerate(wt):
+        TW[2 * s + HALF, COL] = w
+    TW[K:, :] = 0                                                 # the kernel zeroes the padding rows of the last block once
+    gs = outer_over_pixels(TW, tile_to_lds([d_x]), [[zeros_tile()] for _ in range(nblk)], nblk, 1)
+    G = grad_tiles_to_matrix(gs, K, F)                            # [slot, channel]
+    v_region = []
+    for l, (gl, nch) in enumerate(levels):
+        off = 2 * [i for i, s in enumerate(steps) if s[0] == l][0]
+        v_region.append(G[off:off + 4 * gl, choff[l]:choff[l] + nch].reshape(gl, 2, 2, nch).transpose(3, 0, 1, 2).copy())
+    return dict(v_rgb=v_rgb, v_gray=v_gray, v_w1=grad_tiles_to_matrix(g1, HID, F), v_w2=grad_tiles_to_matrix(g2, HID, HID),
+                v_w3=grad_tiles_to_matrix(g3, OUTP, HID), v_region=v_region)
