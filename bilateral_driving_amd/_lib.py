@@ -28,6 +28,12 @@ class BdsLevel(C.Structure):
                 ("factor", C.c_int32), ("n_avg", C.c_int32)]
 
 
+class BdsFeatLevel(C.Structure):
+    """bds_feat_level"""
+
+    _fields_ = [("grid", C.c_void_p), ("v_grid", C.c_void_p), ("gx", C.c_int32), ("gy", C.c_int32), ("gl", C.c_int32), ("nch", C.c_int32)]
+
+
 _SIGS = {
     "bds_abi_version": (C.c_int, []),
     "bds_strerror": (C.c_char_p, [_i]),
@@ -81,6 +87,10 @@ _SIGS = {
     "bds_bilagrid_slice_feat_image_ok": (_i, [_i, _i, _i, _i]),
     "bds_bilagrid_slice_feat_image_fwd": (_i, [_i, _i, _i, _f, _i, _i, _i, _f, _f, _f]),
     "bds_bilagrid_slice_feat_image_bwd": (_i, [_i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "bds_neural_image_ok": (_i, [_i, _i, _i, C.POINTER(BdsFeatLevel), _i]),
+    "bds_neural_image_bwd_temp_bytes": (_sz, [_i]),
+    "bds_neural_image_fwd": (_i, [_i, _i, _i, C.POINTER(BdsFeatLevel), _i, _f, _f, _f, _f, _i, _f, _f]),
+    "bds_neural_image_bwd": (_i, [_i, _i, _i, C.POINTER(BdsFeatLevel), _i, _f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _i, _f, _sz, _f]),
     "bds_mlp_head_bwd_temp_bytes": (_sz, [_i64, _i]),
     "bds_mlp_head_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _f]),
     "bds_mlp_head_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _sz, _f]),

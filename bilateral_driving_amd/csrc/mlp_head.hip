@@ -24,6 +24,7 @@
 // tests/test_mlp_head_dataflow.py.  Bound: the FP32 MFMA rate (157 TFLOP/s): 2 * (64 F + 4096 + 2048) flop per pixel forward (the
 // 12-row layer is padded to 32), three times that backward (recompute + data path + weight gradients).
 #include "bds_common.h"
+#include "bilagrid_math.h"
 
 namespace bds {
 
@@ -79,10 +80,9 @@ __device__ __forceinline__ void mh_load_features(const float *__restrict__ feats
   }
 }
 
-// features -> hidden 1 -> hidden 2 -> the affine tile, all as D tiles
+// layer 1 from feature registers (k order: feature half * F/2 + s)
 template <int F>
-__device__ __forceinline__ void mh_forward_tile(const float *__restrict__ lds, int col, int half, const float (&x)[F / 2], acc16 (&h1)[2],
-                                                acc16 (&h2)[2], acc16 &aff) {
+__device__ __forceinline__ void mh_layer1_feats(const float *__restrict__ lds, int col, int half, const float (&x)[F / 2], acc16 (&h1)[2]) {
   using Im = MhImage<F>;
   constexpr int KS1 = F / 2;
 #pragma unroll
@@ -95,6 +95,31 @@ __device__ __forceinline__ void mh_forward_tile(const float *__restrict__ lds, i
     for (int r = 0; r < 16; r++) acc[r] = tanh_fast(acc[r]);
     h1[o] = acc;
   }
+}
+
+// layer 1 from a D tile of features (rows = channels d_row(r, half)): the chained k order, only the register groups that hold
+// real channels (F is a multiple of 8 = one group of both halves)
+template <int F>
+__device__ __forceinline__ void mh_layer1_tile(const float *__restrict__ lds, int col, int half, const acc16 &xt, acc16 (&h1)[2]) {
+  using Im = MhImage<F>;
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    acc16 acc = zero16();
+    const float *wr = lds + Im::off1 + (32 * o + col) * Im::S1 + 4 * half;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      if (8 * (r >> 2) < F) acc = mfma(wr[(r & 3) + 8 * (r >> 2)], xt[r], acc);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = tanh_fast(acc[r]);
+    h1[o] = acc;
+  }
+}
+
+// hidden 1 -> hidden 2 -> the affine tile
+template <int F>
+__device__ __forceinline__ void mh_layers23(const float *__restrict__ lds, int col, int half, const acc16 (&h1)[2], acc16 (&h2)[2],
+                                            acc16 &aff) {
+  using Im = MhImage<F>;
 #pragma unroll
   for (int o = 0; o < 2; o++) {
     acc16 acc = zero16();
@@ -116,6 +141,14 @@ __device__ __forceinline__ void mh_forward_tile(const float *__restrict__ lds, i
     for (int s = 0; s < 16; s++) acc = mfma(wr[(s & 3) + 8 * (s >> 2)], h2[b][s], acc);
   }
   aff = acc;
+}
+
+// features -> hidden 1 -> hidden 2 -> the affine tile, all as D tiles
+template <int F>
+__device__ __forceinline__ void mh_forward_tile(const float *__restrict__ lds, int col, int half, const float (&x)[F / 2], acc16 (&h1)[2],
+                                                acc16 (&h2)[2], acc16 &aff) {
+  mh_layer1_feats<F>(lds, col, half, x, h1);
+  mh_layers23<F>(lds, col, half, h1, h2, aff);
 }
 
 template <int F>
@@ -375,6 +408,457 @@ __global__ __launch_bounds__(256) void mlp_head_reduce_kernel(int n_parts, int F
   *dst = accumulate ? *dst + t : t;
 }
 
+// ==================================================================================================================================
+// The slice folded in: the whole `transform` of the neural variants for one image (features never reach HBM).
+//   models/modules.py:643-670 / 728-790 (feature slice at the pixel grid, one grid per level) + the head + scene_graph.py:99-106.
+// With tiles cut at the grids' cell boundaries the 32 pixels of a tile share their (x0, y0) cell on every level and touch
+// K = sum_l 4 gl_l grid "slots" (z, y corner, x corner):
+//   features^T [F x 32] = G^T [F x K] . Wt [K x 32]              one more chained D tile in front of layer 1
+//   d(slots) [K x F]   += Wt [K x px] . dF [px x F]              one more product over the pixels (the LDS transposes of the weight gradients)
+//   d(gray) [px]        = sum_ch dF^T[ch][px] (G^T . dWt/dz)[ch][px]   row-wise dot of two D tiles + one exchange with lane ^ 32
+// Slot q = off_l + (z * 2 + yb) * 2 + xb is consumed as k = 2 s + half: the lane half IS the x corner.  A pixel ON the last grid
+// column / row (x0 = gx - 1, f = 0) is moved to the cell before it with f = 1 -- the same sample, the same scatter -- so that it does
+// not form a cell of its own.  Dataflow modelled lane by lane: oracle/mfma_dataflow_model.py (fused_forward / fused_backward).
+//
+// Work: jobs = (row band, x segment, chunk of rows); a wave takes whole jobs, loads the region's 2 x 2 x gl nodes once (its A
+// operands, [step][lane] in LDS), accumulates the region's slot gradient in registers and flushes it with one atomic per entry.
+// Segment / band boundaries are found ON THE DEVICE with the same coordinate functions the pixels use (a host copy could disagree
+// in the last bit and put a pixel in the wrong cell).
+constexpr int kNiMaxSeg = 64, kNiMaxTile = 192;
+
+struct NiLevel {
+  const float *grid;
+  float *v_grid;
+  int gx, gy, gl;
+};
+struct NiParams {
+  int H, W, rows_per_job;
+  float lin_x, lin_y;
+  NiLevel lv[2];
+};
+struct NiTables {
+  int nseg, nband, cpb, cnt;
+  int seg_start[kNiMaxSeg + 1], band_start[kNiMaxSeg + 1], seg_tile[kNiMaxSeg + 1], tmp[kNiMaxSeg + 1];
+  short tile_x[kNiMaxTile], tile_n[kNiMaxTile];
+};
+
+__device__ __forceinline__ void ni_axis_cell(float c01, int g, int &i0, float &f) {
+  const float v = grid_coord(c01, g);
+  const float fl = floorf(v);
+  i0 = (int)fl;
+  f = v - fl;
+  if (g > 1 && i0 == g - 1) { i0 = g - 2; f = 1.f; }
+}
+
+template <int NL>
+__device__ __forceinline__ bool ni_new_cell(const NiParams &p, int i, int n, float lin, bool x_axis) {
+  if (i == 0) return true;
+  bool nw = false;
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const int g = x_axis ? p.lv[l].gx : p.lv[l].gy;
+    int a, b;
+    float f;
+    ni_axis_cell(linspace01_s(i, n, lin), g, a, f);
+    ni_axis_cell(linspace01_s(i - 1, n, lin), g, b, f);
+    nw = nw || (a != b);
+  }
+  return nw;
+}
+
+// boundaries along one axis: the indices where some level's cell changes, ascending, closed by n
+template <int NL>
+__device__ void ni_boundaries(const NiParams &p, NiTables &T, int n, float lin, bool x_axis, int *out, int &count) {
+  if (threadIdx.x == 0) T.cnt = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += kMhBlock)
+    if (ni_new_cell<NL>(p, i, n, lin, x_axis)) {
+      const int k = atomicAdd(&T.cnt, 1);
+      if (k < kNiMaxSeg) T.tmp[k] = i;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c = T.cnt < kNiMaxSeg ? T.cnt : kNiMaxSeg;
+    for (int a = 1; a < c; a++) {   // insertion sort of <= 64 entries
+      const int v = T.tmp[a];
+      int b = a - 1;
+      for (; b >= 0 && T.tmp[b] > v; b--) T.tmp[b + 1] = T.tmp[b];
+      T.tmp[b + 1] = v;
+    }
+    for (int a = 0; a < c; a++) out[a] = T.tmp[a];
+    out[c] = n;
+    count = c;
+  }
+  __syncthreads();
+}
+
+template <int NL>
+__device__ void ni_build_tables(const NiParams &p, NiTables &T) {
+  ni_boundaries<NL>(p, T, p.W, p.lin_x, true, T.seg_start, T.nseg);
+  ni_boundaries<NL>(p, T, p.H, p.lin_y, false, T.band_start, T.nband);
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < T.nseg; i++) {
+      T.seg_tile[i] = t;
+      for (int x = T.seg_start[i]; x < T.seg_start[i + 1] && t < kNiMaxTile; x += kMhTile, t++) {
+        T.tile_x[t] = (short)x;
+        const int rest = T.seg_start[i + 1] - x;
+        T.tile_n[t] = (short)(rest < kMhTile ? rest : kMhTile);
+      }
+    }
+    T.seg_tile[T.nseg] = t;
+    int tallest = 1;
+    for (int b = 0; b < T.nband; b++) {
+      const int h = T.band_start[b + 1] - T.band_start[b];
+      tallest = h > tallest ? h : tallest;
+    }
+    T.cpb = (tallest + p.rows_per_job - 1) / p.rows_per_job;
+  }
+  __syncthreads();
+}
+
+// per-pixel state of the slice on one level
+struct NiPix {
+  float fx, fz, isc;   // isc = (gl - 1) inside the guidance range, 0 on / outside its border (grid_sample's border clip)
+  int z0, z1;
+};
+
+template <int NCH0, int GL0, int NCH1, int GL1>
+struct NiShape {
+  static constexpr int NL = GL1 > 0 ? 2 : 1;
+  static constexpr int F = NCH0 + NCH1;
+  static constexpr int KS = 2 * (GL0 + GL1);   // steps = slots / 2
+  static constexpr int K = 2 * KS;
+  static constexpr int NU = (K + 31) / 32;
+  __device__ static constexpr int gl(int l) { return l == 0 ? GL0 : GL1; }
+  __device__ static constexpr int nch(int l) { return l == 0 ? NCH0 : NCH1; }
+  __device__ static constexpr int choff(int l) { return l == 0 ? 0 : NCH0; }
+  __device__ static constexpr int stepoff(int l) { return l == 0 ? 0 : 2 * GL0; }
+};
+
+// Wt[slot][px] of this lane's pixel for step (l, z, yb) and x corner = half; deriv: d/d(gray)
+__device__ __forceinline__ float ni_weight(const NiPix &c, float fy, int z, int yb, int half, bool deriv) {
+  const float wx = half ? c.fx : 1.f - c.fx;
+  const float wy = yb ? fy : 1.f - fy;
+  float wz;
+  if (!deriv) wz = (c.z0 == z ? 1.f - c.fz : 0.f) + (c.z1 == z ? c.fz : 0.f);
+  else wz = ((c.z1 == z ? 1.f : 0.f) - (c.z0 == z ? 1.f : 0.f)) * c.isc;
+  return wz * wy * wx;
+}
+
+template <class S>
+__device__ __forceinline__ acc16 ni_slice(const float *__restrict__ gimg, int lane, int half, const NiPix (&c)[2], const float (&fy)[2],
+                                          bool deriv) {
+  acc16 acc = zero16();
+#pragma unroll
+  for (int l = 0; l < S::NL; l++)
+#pragma unroll
+    for (int z = 0; z < S::gl(l); z++)
+#pragma unroll
+      for (int yb = 0; yb < 2; yb++) {
+        const int s = S::stepoff(l) + z * 2 + yb;
+        acc = mfma(gimg[s * kWave + lane], ni_weight(c[l], fy[l], z, yb, half, deriv), acc);
+      }
+  return acc;
+}
+
+// the region's nodes as A operands: lane (channel = col, x corner = half), step (l, z, yb)
+template <class S>
+__device__ __forceinline__ void ni_load_region(const NiParams &p, float *__restrict__ gimg, int lane, int col, int half, const int (&x0)[2],
+                                               const int (&y0)[2]) {
+#pragma unroll
+  for (int l = 0; l < S::NL; l++) {
+    const NiLevel &L = p.lv[l];
+    const int ch = col - S::choff(l);
+    const bool mine = ch >= 0 && ch < S::nch(l);
+    const int x = x0[l] + half < L.gx ? x0[l] + half : L.gx - 1;
+#pragma unroll
+    for (int z = 0; z < S::gl(l); z++)
+#pragma unroll
+      for (int yb = 0; yb < 2; yb++) {
+        const int y = y0[l] + yb < L.gy ? y0[l] + yb : L.gy - 1;
+        const int s = S::stepoff(l) + z * 2 + yb;
+        gimg[s * kWave + lane] = mine ? L.grid[(((int64_t)ch * L.gl + z) * L.gy + y) * L.gx + x] : 0.f;
+      }
+  }
+}
+
+template <class S>
+__device__ __forceinline__ void ni_pixel(const NiParams &p, int x, float r, float g, float b, NiPix (&c)[2]) {
+  const float x01 = linspace01_s(x, p.W, p.lin_x);
+  const float gray = rgb2gray(r, g, b);
+#pragma unroll
+  for (int l = 0; l < S::NL; l++) {
+    int xi;
+    ni_axis_cell(x01, p.lv[l].gx, xi, c[l].fx);
+    bool interior;
+    const float iz = guide_coord(gray, S::gl(l), interior);
+    const float zf = floorf(iz);
+    c[l].z0 = (int)zf;
+    c[l].z1 = c[l].z0 + 1 < S::gl(l) ? c[l].z0 + 1 : S::gl(l) - 1;
+    c[l].fz = iz - zf;
+    c[l].isc = interior ? (float)(S::gl(l) - 1) : 0.f;
+  }
+}
+
+struct NiJob {
+  int r0, r1, t0, t1, xs, ys;
+};
+__device__ __forceinline__ NiJob ni_job(const NiTables &T, int j, int rows_per_job) {
+  const int per_band = T.nseg * T.cpb;
+  const int b = j / per_band, rem = j - b * per_band, i = rem / T.cpb, k = rem - i * T.cpb;
+  NiJob J;
+  J.r0 = T.band_start[b] + k * rows_per_job;
+  const int r1 = J.r0 + rows_per_job;
+  J.r1 = r1 < T.band_start[b + 1] ? r1 : T.band_start[b + 1];
+  J.t0 = T.seg_tile[i]; J.t1 = T.seg_tile[i + 1];
+  J.xs = T.seg_start[i]; J.ys = T.band_start[b];
+  return J;
+}
+
+template <int NCH0, int GL0, int NCH1, int GL1>
+__global__ __launch_bounds__(kMhBlock) void neural_image_fwd_kernel(NiParams p, const float *__restrict__ rgb, const float *__restrict__ w1,
+                                                                   const float *__restrict__ w2, const float *__restrict__ w3,
+                                                                   int residual, float *__restrict__ out) {
+  using S = NiShape<NCH0, GL0, NCH1, GL1>;
+  constexpr int F = S::F;
+  extern __shared__ float lds[];
+  __shared__ NiTables T;
+  mh_load_weights<F>(lds, w1, w2, w3);
+  ni_build_tables<S::NL>(p, T);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, col = lane & 31, half = lane >> 5;
+  float *gimg = lds + MhImage<F>::floats + wave * (S::KS * kWave);
+  const int njobs = T.nband * T.nseg * T.cpb;
+  for (int j = blockIdx.x * kMhWaves + wave; j < njobs; j += gridDim.x * kMhWaves) {
+    const NiJob J = ni_job(T, j, p.rows_per_job);
+    if (J.r0 >= J.r1) continue;
+    int x0[2] = {0, 0}, y0[2] = {0, 0};
+    float ftmp;
+#pragma unroll
+    for (int l = 0; l < S::NL; l++) {
+      ni_axis_cell(linspace01_s(J.xs, p.W, p.lin_x), p.lv[l].gx, x0[l], ftmp);
+      ni_axis_cell(linspace01_s(J.ys, p.H, p.lin_y), p.lv[l].gy, y0[l], ftmp);
+    }
+    ni_load_region<S>(p, gimg, lane, col, half, x0, y0);
+    for (int y = J.r0; y < J.r1; y++) {
+      float fy[2] = {0.f, 0.f};
+      int ytmp;
+#pragma unroll
+      for (int l = 0; l < S::NL; l++) ni_axis_cell(linspace01_s(y, p.H, p.lin_y), p.lv[l].gy, ytmp, fy[l]);
+      for (int t = J.t0; t < J.t1; t++) {
+        const int n = T.tile_n[t];
+        const bool on = col < n;
+        const int x = T.tile_x[t] + (on ? col : n - 1);
+        const int64_t i = (int64_t)y * p.W + x;
+        const float c0 = rgb[i * 3], c1 = rgb[i * 3 + 1], c2 = rgb[i * 3 + 2];
+        NiPix c[2];
+        ni_pixel<S>(p, x, c0, c1, c2, c);
+        const acc16 xt = ni_slice<S>(gimg, lane, half, c, fy, false);
+        acc16 h1[2], h2[2], aff;
+        mh_layer1_tile<F>(lds, col, half, xt, h1);
+        mh_layers23<F>(lds, col, half, h1, h2, aff);
+        if (!on) continue;
+        float lo = aff[0] * c0 + aff[1] * c1 + aff[2] * c2 + aff[3];
+        float hi = aff[4] * c0 + aff[5] * c1 + aff[6] * c2 + aff[7];
+        if (residual) { lo += half ? c1 : c0; hi += c2; }
+        out[i * 3 + half] = lo;
+        if (half == 0) out[i * 3 + 2] = hi;
+      }
+    }
+  }
+}
+
+template <int NCH0, int GL0, int NCH1, int GL1>
+__global__ __launch_bounds__(kMhBlock) void neural_image_bwd_kernel(NiParams p, const float *__restrict__ rgb, const float *__restrict__ w1,
+                                                                   const float *__restrict__ w2, const float *__restrict__ w3,
+                                                                   int residual, const float *__restrict__ v_out,
+                                                                   float *__restrict__ v_rgb, float *__restrict__ partials) {
+  using S = NiShape<NCH0, GL0, NCH1, GL1>;
+  constexpr int F = S::F;
+  using Im = MhImage<F>;
+  extern __shared__ float lds[];
+  __shared__ NiTables T;
+  mh_load_weights<F>(lds, w1, w2, w3);
+  ni_build_tables<S::NL>(p, T);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, col = lane & 31, half = lane >> 5;
+  float *bufA = lds + Im::floats + wave * (2 * kMhBufBig + kMhBufSmall + S::KS * kWave);
+  float *bufB = bufA + kMhBufBig;
+  float *bufS = bufB + kMhBufBig;
+  float *gimg = bufS + kMhBufSmall;
+  acc16 g1[2], g2[4], g3[2], gs[S::NU];
+#pragma unroll
+  for (int i = 0; i < 2; i++) { g1[i] = zero16(); g3[i] = zero16(); }
+#pragma unroll
+  for (int i = 0; i < 4; i++) g2[i] = zero16();
+
+  const int njobs = T.nband * T.nseg * T.cpb;
+  for (int j = blockIdx.x * kMhWaves + wave; j < njobs; j += gridDim.x * kMhWaves) {
+    const NiJob J = ni_job(T, j, p.rows_per_job);
+    if (J.r0 >= J.r1) continue;
+    int x0[2] = {0, 0}, y0[2] = {0, 0};
+    float ftmp;
+#pragma unroll
+    for (int l = 0; l < S::NL; l++) {
+      ni_axis_cell(linspace01_s(J.xs, p.W, p.lin_x), p.lv[l].gx, x0[l], ftmp);
+      ni_axis_cell(linspace01_s(J.ys, p.H, p.lin_y), p.lv[l].gy, y0[l], ftmp);
+    }
+    ni_load_region<S>(p, gimg, lane, col, half, x0, y0);
+#pragma unroll
+    for (int u = 0; u < S::NU; u++) gs[u] = zero16();
+    for (int y = J.r0; y < J.r1; y++) {
+      float fy[2] = {0.f, 0.f};
+      int ytmp;
+#pragma unroll
+      for (int l = 0; l < S::NL; l++) ni_axis_cell(linspace01_s(y, p.H, p.lin_y), p.lv[l].gy, ytmp, fy[l]);
+      for (int t = J.t0; t < J.t1; t++) {
+        const int n = T.tile_n[t];
+        const bool on = col < n;
+        const int x = T.tile_x[t] + (on ? col : n - 1);
+        const int64_t i = (int64_t)y * p.W + x;
+        const float c0 = rgb[i * 3], c1 = rgb[i * 3 + 1], c2 = rgb[i * 3 + 2];
+        NiPix c[2];
+        ni_pixel<S>(p, x, c0, c1, c2, c);
+        const acc16 xt = ni_slice<S>(gimg, lane, half, c, fy, false);
+        acc16 h1[2], h2[2], aff;
+        mh_layer1_tile<F>(lds, col, half, xt, h1);
+        mh_layers23<F>(lds, col, half, h1, h2, aff);
+
+        const float g0 = on ? v_out[i * 3] : 0.f, gg1 = on ? v_out[i * 3 + 1] : 0.f, gg2 = on ? v_out[i * 3 + 2] : 0.f;
+        const float r_lo = half ? gg1 : g0, r_hi = half ? 0.f : gg2;
+        float t8[8];
+        t8[0] = r_lo * c0; t8[1] = r_lo * c1; t8[2] = r_lo * c2; t8[3] = r_lo;
+        t8[4] = r_hi * c0; t8[5] = r_hi * c1; t8[6] = r_hi * c2; t8[7] = r_hi;
+        float p0 = aff[0] * r_lo + aff[4] * r_hi, p1 = aff[1] * r_lo + aff[5] * r_hi, p2 = aff[2] * r_lo + aff[6] * r_hi;
+        p0 += __shfl_xor(p0, 32); p1 += __shfl_xor(p1, 32); p2 += __shfl_xor(p2, 32);
+
+        // ---- layer 3
+#pragma unroll
+        for (int r = 0; r < 8; r++) bufS[d_row(r, half) * kMhTStride + col] = t8[r];
+        mh_store_tiles<2>(bufA, col, half, h2);
+        mh_wave_fence();
+        mh_outer<1, 2>(bufS, bufA, col, half, g3);
+        mh_wave_fence();
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+          acc16 acc = zero16();
+#pragma unroll
+          for (int s = 0; s < 8; s++) acc = mfma(lds[Im::off3 + d_row(s, half) * kMhWStride + 32 * o + col], t8[s], acc);
+#pragma unroll
+          for (int r = 0; r < 16; r++) h2[o][r] = acc[r] * (1.f - h2[o][r] * h2[o][r]);
+        }
+        // ---- layer 2
+        mh_store_tiles<2>(bufA, col, half, h2);
+        mh_store_tiles<2>(bufB, col, half, h1);
+        mh_wave_fence();
+        mh_outer<2, 2>(bufA, bufB, col, half, g2);
+        mh_wave_fence();
+        {
+          acc16 d[2];
+#pragma unroll
+          for (int o = 0; o < 2; o++) {
+            acc16 acc = zero16();
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+              for (int s = 0; s < 16; s++)
+                acc = mfma(lds[Im::off2 + (32 * b + d_row(s, half)) * kMhWStride + 32 * o + col], h2[b][s], acc);
+            d[o] = acc;
+          }
+#pragma unroll
+          for (int o = 0; o < 2; o++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) h1[o][r] = d[o][r] * (1.f - h1[o][r] * h1[o][r]);
+        }
+        // ---- layer 1: the feature tile is already in D layout
+        mh_store_tiles<2>(bufA, col, half, h1);
+        {
+          const acc16 xs[1] = {xt};
+          mh_store_tiles<1>(bufS, col, half, xs);
+        }
+        mh_wave_fence();
+        mh_outer<2, 1>(bufA, bufS, col, half, g1);
+        mh_wave_fence();
+        acc16 dx = zero16();
+        {
+          const bool live = col < F;
+          const int cc = live ? col : 0;
+#pragma unroll
+          for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+              const float w = lds[Im::off1 + (32 * b + d_row(s, half)) * Im::S1 + cc];
+              dx = mfma(live ? w : 0.f, h1[b][s], dx);
+            }
+        }
+        // ---- the slice: guidance gradient and the region's slot gradient
+        const acc16 dz = ni_slice<S>(gimg, lane, half, c, fy, true);
+        float vg = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) vg += dx[r] * dz[r];
+        vg += __shfl_xor(vg, 32);
+        if (v_rgb && on && half == 0) {
+          v_rgb[i * 3] = p0 + (residual ? g0 : 0.f) + vg * kGrayR;
+          v_rgb[i * 3 + 1] = p1 + (residual ? gg1 : 0.f) + vg * kGrayG;
+          v_rgb[i * 3 + 2] = p2 + (residual ? gg2 : 0.f) + vg * kGrayB;
+        }
+#pragma unroll
+        for (int l = 0; l < S::NL; l++)
+#pragma unroll
+          for (int z = 0; z < S::gl(l); z++)
+#pragma unroll
+            for (int yb = 0; yb < 2; yb++) {
+              const int s = S::stepoff(l) + z * 2 + yb;
+              bufB[(2 * s + half) * kMhTStride + col] = ni_weight(c[l], fy[l], z, yb, half, false);
+            }
+        {
+          const acc16 ds[1] = {dx};
+          mh_store_tiles<1>(bufA, col, half, ds);
+        }
+        mh_wave_fence();
+        mh_outer<S::NU, 1>(bufB, bufA, col, half, gs);
+        mh_wave_fence();
+      }
+    }
+    // flush the region: register r of block u is slot q = 32 u + d_row(r, half), column = channel
+#pragma unroll
+    for (int u = 0; u < S::NU; u++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int q = 32 * u + d_row(r, half);
+        if (q >= S::K) continue;
+        const int l = (S::NL == 2 && q >= 4 * GL0) ? 1 : 0;
+        const int ql = q - (l ? 4 * GL0 : 0);
+        const int xb = ql & 1, yb = (ql >> 1) & 1, z = ql >> 2;
+        const NiLevel &L = p.lv[l];
+        const int ch = col - (l ? NCH0 : 0), nch = l ? NCH1 : NCH0;
+        if (!L.v_grid || ch < 0 || ch >= nch) continue;
+        const int xx = x0[l] + xb < L.gx ? x0[l] + xb : L.gx - 1, yy = y0[l] + yb < L.gy ? y0[l] + yb : L.gy - 1;
+        const float v = gs[u][r];
+        if (v != 0.f) atomicAdd(L.v_grid + (((int64_t)ch * L.gl + z) * L.gy + yy) * L.gx + xx, v);
+      }
+  }
+
+  float *part = partials + ((int64_t)blockIdx.x * kMhWaves + wave) * (kMhHid * F + kMhHid * kMhHid + kMhAff * kMhHid);
+#pragma unroll
+  for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      if (col < F) part[(32 * ob + d_row(r, half)) * F + col] = g1[ob][r];
+  part += kMhHid * F;
+#pragma unroll
+  for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+    for (int vb = 0; vb < 2; vb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) part[(32 * ob + d_row(r, half)) * kMhHid + 32 * vb + col] = g2[ob * 2 + vb][r];
+  part += kMhHid * kMhHid;
+#pragma unroll
+  for (int vb = 0; vb < 2; vb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      if (d_row(r, half) < kMhAff) part[d_row(r, half) * kMhHid + 32 * vb + col] = g3[vb][r];
+}
+
 inline int mh_grid_fwd(int64_t P) {
   const int64_t groups = cdiv(cdiv(P, (int64_t)kMhTile), (int64_t)kMhWaves);
   return (int)(groups < 768 ? (groups > 0 ? groups : 1) : 768);   // three resident workgroups per CU
@@ -411,6 +895,138 @@ int mh_launch_bwd(int64_t P, const float *feats, const float *rgb, const float *
 }  // namespace bds
 
 using namespace bds;
+
+// ---- host side of the fused image transform --------------------------------------------------------------------------------------
+namespace bds {
+
+inline int ni_shape_id(int n_levels, const bds_feat_level *lv) {
+  if (n_levels == 1 && lv[0].gl == 8) {
+    switch (lv[0].nch) { case 8: return 0; case 16: return 1; case 24: return 2; case 32: return 3; default: return -1; }
+  }
+  if (n_levels == 2 && lv[0].gl == 1 && lv[0].nch == 8 && lv[1].gl == 8 && lv[1].nch == 8) return 4;
+  return -1;
+}
+
+inline bool ni_fill(NiParams &p, int H, int W, int n_levels, const bds_feat_level *lv, int rows_per_job) {
+  p.H = H; p.W = W; p.rows_per_job = rows_per_job;
+  p.lin_x = W > 1 ? 1.0f / (float)(W - 1) : 0.f;
+  p.lin_y = H > 1 ? 1.0f / (float)(H - 1) : 0.f;
+  int segs = 1, bands = 1;
+  for (int l = 0; l < 2; l++) {
+    if (l < n_levels) {
+      if (!lv[l].grid || lv[l].gx < 1 || lv[l].gy < 1) return false;
+      p.lv[l] = NiLevel{lv[l].grid, lv[l].v_grid, lv[l].gx, lv[l].gy, lv[l].gl};
+      segs += lv[l].gx > 1 ? lv[l].gx - 2 : 0;
+      bands += lv[l].gy > 1 ? lv[l].gy - 2 : 0;
+    } else {
+      p.lv[l] = NiLevel{nullptr, nullptr, 1, 1, 1};
+    }
+  }
+  // table capacities: cell boundaries per axis, 32-pixel tiles per row
+  return segs <= kNiMaxSeg && bands <= kNiMaxSeg && (W + kMhTile - 1) / kMhTile + segs <= kNiMaxTile;
+}
+
+inline int ni_jobs_upper(const NiParams &p, int n_levels, const bds_feat_level *lv) {
+  int segs = 1, bands = 1;
+  for (int l = 0; l < n_levels; l++) { segs += lv[l].gx > 1 ? lv[l].gx - 2 : 0; bands += lv[l].gy > 1 ? lv[l].gy - 2 : 0; }
+  const int tallest = (p.H + bands - 1) / bands + 1;
+  return bands * segs * ((tallest + p.rows_per_job - 1) / p.rows_per_job);
+}
+
+template <int NCH0, int GL0, int NCH1, int GL1>
+int ni_launch_fwd(const NiParams &p, int grid, const float *rgb, const float *w1, const float *w2, const float *w3, int residual, float *out,
+                  hipStream_t st) {
+  using S = NiShape<NCH0, GL0, NCH1, GL1>;
+  const size_t lds_bytes = (MhImage<S::F>::floats + kMhWaves * S::KS * kWave) * sizeof(float);
+  hipLaunchKernelGGL((neural_image_fwd_kernel<NCH0, GL0, NCH1, GL1>), dim3(grid), dim3(kMhBlock), lds_bytes, st, p, rgb, w1, w2, w3, residual,
+                     out);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+template <int NCH0, int GL0, int NCH1, int GL1>
+int ni_launch_bwd(const NiParams &p, int grid, const float *rgb, const float *w1, const float *w2, const float *w3, int residual,
+                  const float *v_out, float *v_rgb, float *partials, hipStream_t st) {
+  using S = NiShape<NCH0, GL0, NCH1, GL1>;
+  const size_t lds_bytes = (MhImage<S::F>::floats + kMhWaves * (2 * kMhBufBig + kMhBufSmall + S::KS * kWave)) * sizeof(float);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&neural_image_bwd_kernel<NCH0, GL0, NCH1, GL1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+    return BDS_ELAUNCH;
+  hipLaunchKernelGGL((neural_image_bwd_kernel<NCH0, GL0, NCH1, GL1>), dim3(grid), dim3(kMhBlock), lds_bytes, st, p, rgb, w1, w2, w3, residual,
+                     v_out, v_rgb, partials);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+constexpr int kNiGridBwd = 256;   // one workgroup per CU (142 KB of LDS each)
+
+}  // namespace bds
+
+extern "C" int bds_neural_image_ok(int H, int W, int n_levels, const bds_feat_level *levels, int hidden) {
+  if (H < 1 || W < 1 || n_levels < 1 || n_levels > 2 || !levels || hidden != kMhHid) return 0;
+  if (ni_shape_id(n_levels, levels) < 0) return 0;
+  NiParams p;
+  bds_feat_level probe[2];
+  for (int l = 0; l < n_levels; l++) { probe[l] = levels[l]; if (!probe[l].grid) probe[l].grid = reinterpret_cast<const float *>(16); }
+  return ni_fill(p, H, W, n_levels, probe, 4) ? 1 : 0;
+}
+
+extern "C" size_t bds_neural_image_bwd_temp_bytes(int F) {
+  if (!mh_supported(F)) return 0;
+  return (size_t)kNiGridBwd * kMhWaves * (size_t)(kMhHid * F + kMhHid * kMhHid + kMhAff * kMhHid) * sizeof(float);
+}
+
+extern "C" int bds_neural_image_fwd(int H, int W, int n_levels, const bds_feat_level *levels, int hidden, const float *rgb, const float *w1,
+                                    const float *w2, const float *w3, int residual, float *out, bds_stream_t stream) {
+  BDS_REQUIRE(H >= 0 && W >= 0 && n_levels >= 1 && n_levels <= 2 && levels && hidden == kMhHid);
+  if (H == 0 || W == 0) return BDS_OK;
+  const int id = ni_shape_id(n_levels, levels);
+  NiParams p;
+  BDS_REQUIRE(id >= 0 && ni_fill(p, H, W, n_levels, levels, 4) && rgb && w1 && w2 && w3 && out);
+  const int jobs = ni_jobs_upper(p, n_levels, levels);
+  int grid = (jobs + kMhWaves - 1) / kMhWaves;
+  grid = grid < 768 ? (grid > 0 ? grid : 1) : 768;
+  hipStream_t st = as_stream(stream);
+  switch (id) {
+    case 0: return ni_launch_fwd<8, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    case 1: return ni_launch_fwd<16, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    case 2: return ni_launch_fwd<24, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    case 3: return ni_launch_fwd<32, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    default: return ni_launch_fwd<8, 1, 8, 8>(p, grid, rgb, w1, w2, w3, residual, out, st);
+  }
+}
+
+extern "C" int bds_neural_image_bwd(int H, int W, int n_levels, const bds_feat_level *levels, int hidden, const float *rgb, const float *w1,
+                                    const float *w2, const float *w3, int residual, const float *v_out, float *v_rgb, float *v_w1,
+                                    float *v_w2, float *v_w3, int accumulate_w, void *temp, size_t temp_bytes, bds_stream_t stream) {
+  BDS_REQUIRE(H >= 0 && W >= 0 && n_levels >= 1 && n_levels <= 2 && levels && hidden == kMhHid);
+  if (H == 0 || W == 0) return BDS_OK;
+  const int id = ni_shape_id(n_levels, levels);
+  NiParams p;
+  BDS_REQUIRE(id >= 0 && ni_fill(p, H, W, n_levels, levels, 8) && rgb && w1 && w2 && w3 && v_out);
+  int F = 0;
+  for (int l = 0; l < n_levels; l++) F += levels[l].nch;
+  BDS_REQUIRE(temp && temp_bytes >= bds_neural_image_bwd_temp_bytes(F));
+  hipStream_t st = as_stream(stream);
+  float *partials = static_cast<float *>(temp);
+  const int grid = kNiGridBwd;
+  int rc;
+  switch (id) {
+    case 0: rc = ni_launch_bwd<8, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    case 1: rc = ni_launch_bwd<16, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    case 2: rc = ni_launch_bwd<24, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    case 3: rc = ni_launch_bwd<32, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    default: rc = ni_launch_bwd<8, 1, 8, 8>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+  }
+  if (rc != BDS_OK) return rc;
+  if (v_w1 || v_w2 || v_w3) {
+    const int len = kMhHid * F + kMhHid * kMhHid + kMhAff * kMhHid;
+    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3((unsigned)cdiv(len, 32)), dim3(256), 0, st, grid * kMhWaves, F, partials, v_w1, v_w2,
+                       v_w3, accumulate_w);
+    BDS_LAUNCH_CHECK();
+  }
+  return BDS_OK;
+}
 
 extern "C" size_t bds_mlp_head_bwd_temp_bytes(int64_t P, int F) {
   if (P <= 0 || !mh_supported(F)) return 0;

@@ -6,7 +6,7 @@ Reference: ``affine_network`` of NeuralBilateralAffineTransform / MultiScaleNeur
 trainer's application ``A[..., :3] @ rgb + A[..., 3] + rgb`` (models/trainers/scene_graph.py:99-106)."""
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -83,3 +83,65 @@ def transform(feats: Tensor, rgb: Tensor, w1: Tensor, w2: Tensor, w3: Tensor, re
 def transform_and_maps(feats: Tensor, rgb: Tensor, w1: Tensor, w2: Tensor, w3: Tensor, residual: bool = True) -> Tuple[Tensor, Tensor]:
     out, aff = _MlpHead.apply(feats.reshape(-1, feats.shape[-1]), rgb.reshape(-1, 3), w1, w2, w3, residual, True, True)
     return out.reshape(rgb.shape), aff.reshape(*rgb.shape[:-1], 12)
+
+
+# ---- the whole transform of one image, the feature slice folded in -----------------------------------------------------------------------
+def _levels_struct(grids: Sequence[Tensor], v_grids=None):
+    arr = (L.BdsFeatLevel * len(grids))()
+    for i, g in enumerate(grids):
+        nch, gl, gy, gx = g.shape
+        arr[i].grid = g.data_ptr()
+        arr[i].v_grid = None if v_grids is None or v_grids[i] is None else v_grids[i].data_ptr()
+        arr[i].gx, arr[i].gy, arr[i].gl, arr[i].nch = gx, gy, gl, nch
+    return arr
+
+
+def image_supported(H: int, W: int, grids: Sequence[Tensor], hidden_dim: int) -> bool:
+    """Shapes ``bds_neural_image_*`` is built for (the shipped configs: one 16x16x8 grid with 24 features, or the grids
+    [[1,1,1],[16,16,8]] with 8 features each; hidden 64)."""
+    if not grids or len(grids) > 2 or not all(g.is_cuda and g.dim() == 4 for g in grids):
+        return False
+    return bool(L.lib().bds_neural_image_ok(H, W, len(grids), _levels_struct(grids), hidden_dim))
+
+
+class _NeuralImage(torch.autograd.Function):
+    """rgb [H,W,3], w1, w2, w3, one grid [nch,gl,gy,gx] per level -> rgb' [H,W,3] (slice + head + application in one kernel)."""
+
+    @staticmethod
+    def forward(ctx, rgb: Tensor, w1: Tensor, w2: Tensor, w3: Tensor, residual: bool, *grids: Tensor):
+        L.require_gpu(rgb, w1, w2, w3, *grids)
+        H, W, _ = rgb.shape
+        rgb_c = rgb.detach().contiguous().float()
+        ws = [w.detach().contiguous().float() for w in (w1, w2, w3)]
+        gs = [g.detach().contiguous().float() for g in grids]
+        out = torch.empty(H, W, 3, device=rgb.device)
+        L.check(L.lib().bds_neural_image_fwd(H, W, len(gs), _levels_struct(gs), HIDDEN, L.ptr(rgb_c), L.ptr(ws[0]), L.ptr(ws[1]), L.ptr(ws[2]),
+                                             int(residual), L.ptr(out), L.stream()), "bds_neural_image_fwd")
+        ctx.save_for_backward(rgb_c, *ws, *gs)
+        ctx.residual = bool(residual)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        rgb, w1, w2, w3, *gs = ctx.saved_tensors
+        H, W, _ = rgb.shape
+        dev = rgb.device
+        need = ctx.needs_input_grad
+        v_out = v_out.contiguous().float()
+        v_rgb = torch.empty_like(rgb) if need[0] else None
+        v_w = [torch.empty_like(w) if need[1 + i] else None for i, w in enumerate((w1, w2, w3))]
+        v_g = [torch.zeros_like(g) if need[5 + i] else None for i, g in enumerate(gs)]
+        F_ = sum(g.shape[0] for g in gs)
+        nb = int(L.lib().bds_neural_image_bwd_temp_bytes(F_))
+        temp = torch.empty(nb, dtype=torch.uint8, device=dev)
+        L.check(L.lib().bds_neural_image_bwd(H, W, len(gs), _levels_struct(gs, v_g), HIDDEN, L.ptr(rgb), L.ptr(w1), L.ptr(w2), L.ptr(w3),
+                                             int(ctx.residual), L.ptr(v_out), L.ptr(v_rgb), L.ptr(v_w[0]), L.ptr(v_w[1]), L.ptr(v_w[2]), 0,
+                                             L.ptr(temp), nb, L.stream()), "bds_neural_image_bwd")
+        return (v_rgb, v_w[0], v_w[1], v_w[2], None, *v_g)
+
+
+def image_transform(rgb: Tensor, grids: Sequence[Tensor], w1: Tensor, w2: Tensor, w3: Tensor, residual: bool = True) -> Tensor:
+    """The neural variants' whole ``transform`` of one image: per level the feature grid of that image [nch,gl,gy,gx] (for the
+    test branch: the mean of the neighbour images' grids -- the slice is linear in the grid), sliced at the pixel grid, through
+    the head and applied.  ``image_supported`` tells whether the shapes are the kernel's."""
+    return _NeuralImage.apply(rgb, w1, w2, w3, residual, *grids)

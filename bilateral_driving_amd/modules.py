@@ -293,6 +293,21 @@ def _head_transform(net: nn.Sequential, feats: Tensor, rgb: Tensor) -> Tensor:
     return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
 
 
+def _image_grids(levels: Sequence[NeuralBilateralGrid], idxs: Sequence[int]) -> List[Tensor]:
+    """One grid per level for this image: the image's own, or the mean over the neighbour images' grids in the test branch
+    (modules.py:651-662 averages the sliced features; the slice is linear in the grid, so the grids can be averaged instead)."""
+    out = []
+    for g in levels:
+        sel = g.grids[list(idxs)]
+        out.append(sel[0] if len(idxs) == 1 else sel.mean(dim=0))
+    return out
+
+
+def _fused_image_ok(net: nn.Sequential, levels: Sequence[NeuralBilateralGrid], rgb: Tensor) -> bool:
+    H, W, _ = rgb.shape
+    return rgb.is_cuda and mlp_head.image_supported(H, W, [g.grids[0] for g in levels], net[0].weight.shape[0])
+
+
 def _sliced_features(grids: NeuralBilateralGrid, rgb: Tensor, xy: Optional[Tensor], idxs: Sequence[int]) -> Tensor:
     """Feature slice for one image, or the mean over the neighbour images' grids in the test branch (modules.py:651-662).
     ``xy`` None: the pixel grid of ``rgb`` itself (every call site of the reference) -> the image form of the slice."""
@@ -340,6 +355,11 @@ class NeuralBilateralAffineTransform(nn.Module):
         """forward + the trainer's application with the residual (scene_graph.py:99-102) in one pass: the [H,W,3,4] maps are not
         materialised."""
         assert "img_idx" in image_infos
+        if _fused_image_ok(self.affine_network, [self.bil_grids], rgb):      # slice + head + application: one kernel each way
+            k = _img_index(image_infos)
+            idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
+            net = self.affine_network
+            return mlp_head.image_transform(rgb, _image_grids([self.bil_grids], idxs), net[0].weight, net[2].weight, net[4].weight)
         return _head_transform(self.affine_network, self._features(rgb, image_infos), rgb)
 
     def get_param_groups(self):
@@ -404,6 +424,12 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
     def transform(self, rgb: Tensor, image_infos, guidance_factor: Optional[Sequence[int]] = None) -> Tensor:
         """forward + the trainer's application with the residual (scene_graph.py:103-106), the maps not materialised."""
         assert "img_idx" in image_infos
+        levels = [getattr(self, f"bil_grids{i}") for i in range(len(self.grid_size))]
+        if guidance_factor is None and _fused_image_ok(self.affine_network, levels, rgb):
+            k = _img_index(image_infos)
+            idxs = [k] if not self.in_test_set else self.training_indices_for_test[k]
+            net = self.affine_network
+            return mlp_head.image_transform(rgb, _image_grids(levels, idxs), net[0].weight, net[2].weight, net[4].weight)
         return _head_transform(self.affine_network, self._features(rgb, image_infos, guidance_factor), rgb)
 
     def get_param_groups(self):

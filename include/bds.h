@@ -494,6 +494,31 @@ int bds_mlp_head_bwd(int64_t P, int F, int hidden, const float *feats, const flo
                      const float *w3, int residual, const float *v_out, const float *v_affine, float *v_feats, float *v_rgb,
                      float *v_w1, float *v_w2, float *v_w3, int accumulate_w, void *temp, size_t temp_bytes, bds_stream_t stream);
 
+/* The whole `transform` of the neural variants for one image, the feature slice folded in (the sliced features never reach
+ * memory): NeuralBilateralAffineTransform.forward / MultiScaleNeuralBilateralAffineTransform.forward with guidance_factor = None
+ * (models/modules.py:643-670, 728-790: one feature grid per level, sliced at the pixel grid linspace x linspace with the image's
+ * gray value as guidance, levels concatenated) -> affine_network -> the trainer's application with the residual
+ * (models/trainers/scene_graph.py:99-106).  levels[l].grid is ONE image's grid [nch, gl, gy, gx] (the test branch's mean over
+ * neighbour grids is linear: the caller averages the grids); rgb / out / v_out / v_rgb [H,W,3].
+ * bwd ACCUMULATES the grid gradients into levels[l].v_grid (same shape; caller zeroes; may be NULL), writes v_rgb (both routes: the
+ * application and the guidance; may be NULL) and the weight gradients as bds_mlp_head_bwd does.
+ * Built for: one level with gl = 8 and 8 / 16 / 24 / 32 features, or the two levels {gl 1, 8 features} + {gl 8, 8 features}
+ * (configs/omnire_neuralbilateral.yaml:246-252, omnire_ms_neuralbilateral.yaml:247-250), any gx, gy with at most 64 cell
+ * boundaries per axis, W <= 4096, hidden 64: bds_neural_image_ok() != 0; otherwise BDS_EINVAL and the two-step form
+ * (bds_bilagrid_slice_feat_image_* + bds_mlp_head_*) applies.  temp: bds_neural_image_bwd_temp_bytes(F) bytes. */
+typedef struct {
+  const float *grid;
+  float *v_grid;
+  int gx, gy, gl, nch;
+} bds_feat_level;
+int bds_neural_image_ok(int H, int W, int n_levels, const bds_feat_level *levels, int hidden);
+size_t bds_neural_image_bwd_temp_bytes(int F);
+int bds_neural_image_fwd(int H, int W, int n_levels, const bds_feat_level *levels, int hidden, const float *rgb, const float *w1,
+                         const float *w2, const float *w3, int residual, float *out, bds_stream_t stream);
+int bds_neural_image_bwd(int H, int W, int n_levels, const bds_feat_level *levels, int hidden, const float *rgb, const float *w1,
+                         const float *w2, const float *w3, int residual, const float *v_out, float *v_rgb, float *v_w1, float *v_w2,
+                         float *v_w3, int accumulate_w, void *temp, size_t temp_bytes, bds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

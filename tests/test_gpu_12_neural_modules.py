@@ -186,3 +186,85 @@ def test_image_slice_refuses_a_band_that_does_not_fit():
     assert L.lib().bds_bilagrid_slice_feat_image_ok(24, 16, 16, 8)
     grid = torch.zeros(48, 8, 16, 16, device="cuda"); rgb = torch.rand(8, 8, 3, device="cuda"); out = torch.empty(8, 8, 48, device="cuda")
     assert L.lib().bds_bilagrid_slice_feat_image_fwd(8, 8, 48, L.ptr(grid), 16, 16, 8, L.ptr(rgb), L.ptr(out), L.stream()) == -1
+
+
+# ---- slice + head + application as one kernel (bds_neural_image_*) against the two-step path the reference goldens pin ------------------
+def _two_step(mod, rgb, infos, **kw):
+    A = mod(rgb, infos, **kw)[0]
+    return (A[..., :3] @ rgb[..., None])[..., 0] + A[..., 3] + rgb
+
+
+def _randomise(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * (0.5 if "grids" in n else 0.25)).cuda())
+
+
+@pytest.mark.parametrize("kind,H,W", [("single24", 72, 128), ("single24", 37, 301), ("single24", 1, 20), ("single24", 5, 7), ("single8", 40, 333),
+                                      ("single16", 33, 64), ("single32", 16, 200), ("ms", 75, 130), ("ms", 64, 1000), ("single24", 540, 960),
+                                      ("ms", 1080, 1920)])
+def test_fused_image_transform_equals_two_step_path(kind, H, W):
+    from bilateral_driving_amd import mlp_head
+    from bilateral_driving_amd.modules import MultiScaleNeuralBilateralAffineTransform, NeuralBilateralAffineTransform
+    if kind == "ms":
+        mod = MultiScaleNeuralBilateralAffineTransform("Affine", 3, [[1, 1, 1], [16, 16, 8]], feature_dim=8, hidden_dim=64)
+        levels = [mod.bil_grids0, mod.bil_grids1]
+    else:
+        gx, gy = (16, 16) if kind == "single24" else (7, 5)
+        mod = NeuralBilateralAffineTransform("Affine", 3, gx, gy, 8, feature_dim=int(kind[6:]), hidden_dim=64)
+        levels = [mod.bil_grids]
+    _randomise(mod, H + W)
+    assert mlp_head.image_supported(H, W, [g.grids[0] for g in levels], 64)
+    g = torch.Generator().manual_seed(W)
+    rgb = (torch.rand(H, W, 3, generator=g) * 1.2 - 0.1).cuda().requires_grad_(True)       # guidance on both sides of its range
+    v = torch.randn(H, W, 3, generator=g).cuda()
+    infos = {"img_idx": 1}
+    out = mod.transform(rgb, infos)
+    (out * v).sum().backward()
+    got = {n: p.grad.clone() for n, p in mod.named_parameters()}
+    got["rgb"] = rgb.grad.clone()
+    rgb.grad = None
+    for p in mod.parameters():
+        p.grad = None
+    ref = _two_step(mod, rgb, infos)
+    (ref * v).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=5e-5)
+    want = {n: p.grad for n, p in mod.named_parameters()}
+    want["rgb"] = rgb.grad
+    for n in want:
+        scale = float(want[n].abs().max())
+        torch.testing.assert_close(got[n], want[n], rtol=0, atol=2e-4 * scale + 1e-7, msg=lambda m, n=n: f"{n}: {m}")
+        if "grids" in n:   # only image 1's grid gets a gradient
+            assert float(got[n][0].abs().max()) == 0.0 and float(got[n][2].abs().max()) == 0.0 and float(got[n][1].abs().max()) > 0
+
+
+def test_fused_image_transform_test_branch_and_fallbacks():
+    """Test branch: the mean over the neighbour images' grids; shapes outside the kernel's set keep the two-step path."""
+    from bilateral_driving_amd import mlp_head
+    from bilateral_driving_amd.modules import MultiScaleNeuralBilateralAffineTransform, NeuralBilateralAffineTransform
+    H, W = 50, 90
+    mod = NeuralBilateralAffineTransform("Affine", 4, 16, 16, 8, feature_dim=24, hidden_dim=64)
+    _randomise(mod, 5)
+    mod.in_test_set = True
+    mod.training_indices_for_test = {2: [1, 3]}
+    rgb = torch.rand(H, W, 3).cuda().requires_grad_(True)
+    infos = {"img_idx": 2}
+    out = mod.transform(rgb, infos)
+    out.sum().backward()
+    g_fused = mod.bil_grids.grids.grad.clone(); mod.bil_grids.grids.grad = None
+    ref = _two_step(mod, rgb, infos)
+    ref.sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=5e-5)
+    scale = float(mod.bil_grids.grids.grad.abs().max())
+    torch.testing.assert_close(g_fused, mod.bil_grids.grids.grad, rtol=0, atol=2e-4 * scale)
+    assert float(g_fused[0].abs().max()) == 0.0 and float(g_fused[2].abs().max()) == 0.0      # only the two neighbours
+    # gl = 4 is not one of the kernel's shapes: transform still works (slice kernel + head kernel)
+    small = NeuralBilateralAffineTransform("Affine", 2, 6, 5, 4, feature_dim=24, hidden_dim=64)
+    assert not mlp_head.image_supported(H, W, [small.bil_grids.grids[0]], 64)
+    _randomise(small, 6)
+    torch.testing.assert_close(small.transform(rgb, {"img_idx": 0}), _two_step(small, rgb, {"img_idx": 0}), rtol=1e-4, atol=5e-5)
+    ms = MultiScaleNeuralBilateralAffineTransform("Affine", 2, [[1, 1, 1], [16, 16, 8]], feature_dim=8, hidden_dim=64)
+    _randomise(ms, 7)
+    a = ms.transform(rgb, {"img_idx": 0}, guidance_factor=[2, 2])       # an explicit guidance factor: two-step path
+    torch.testing.assert_close(a, _two_step(ms, rgb, {"img_idx": 0}, guidance_factor=[2, 2]), rtol=1e-4, atol=5e-5)
