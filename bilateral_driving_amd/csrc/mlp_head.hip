@@ -617,7 +617,7 @@ __device__ __forceinline__ NiJob ni_job(const NiTables &T, int j, int rows_per_j
 }
 
 template <int NCH0, int GL0, int NCH1, int GL1>
-__global__ __launch_bounds__(kMhBlock) void neural_image_fwd_kernel(NiParams p, const float *__restrict__ rgb, const float *__restrict__ w1,
+__global__ __launch_bounds__(kMhBlock, 2) void neural_image_fwd_kernel(NiParams p, const float *__restrict__ rgb, const float *__restrict__ w1,
                                                                    const float *__restrict__ w2, const float *__restrict__ w3,
                                                                    int residual, float *__restrict__ out) {
   using S = NiShape<NCH0, GL0, NCH1, GL1>;

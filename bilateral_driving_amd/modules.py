@@ -296,11 +296,9 @@ def _head_transform(net: nn.Sequential, feats: Tensor, rgb: Tensor) -> Tensor:
 def _image_grids(levels: Sequence[NeuralBilateralGrid], idxs: Sequence[int]) -> List[Tensor]:
     """One grid per level for this image: the image's own, or the mean over the neighbour images' grids in the test branch
     (modules.py:651-662 averages the sliced features; the slice is linear in the grid, so the grids can be averaged instead)."""
-    out = []
-    for g in levels:
-        sel = g.grids[list(idxs)]
-        out.append(sel[0] if len(idxs) == 1 else sel.mean(dim=0))
-    return out
+    if len(idxs) == 1:
+        return [g.grids[int(idxs[0])] for g in levels]          # a view: no copy
+    return [g.grids[list(idxs)].mean(dim=0) for g in levels]
 
 
 def _fused_image_ok(net: nn.Sequential, levels: Sequence[NeuralBilateralGrid], rgb: Tensor) -> bool:
