@@ -64,6 +64,18 @@ BDS_HD float grid_coord(float c01, int size) {
   const float hi = (float)(size - 1);
   return v > hi ? hi : v;
 }
+// One axis of the slice as (first node, fraction towards the next one), with a coordinate ON the last node (i0 = g - 1, f = 0: the
+// last pixel of a linspace) expressed from the cell before it (i0 = g - 2, f = 1): the same sample and the same scatter weights
+// (slice_cell's clamped second node carries weight f = 0), but every coordinate now lies in one of the g - 1 cells -- what the
+// cell-aligned tiles of the fused image transform need (csrc/mlp_head.hip).
+BDS_HD void axis_cell(float c01, int g, int &i0, float &f) {
+  const float v = grid_coord(c01, g);
+  const float fl = floorf(v);
+  i0 = (int)fl;
+  f = v - fl;
+  if (g > 1 && i0 == g - 1) { i0 = g - 2; f = 1.f; }
+}
+
 BDS_HD float guide_coord(float gray, int L, bool &interior) {
   const float z = gray * 2.f - 1.f;
   const float v = ((z + 1.f) / 2.f) * (float)(L - 1);

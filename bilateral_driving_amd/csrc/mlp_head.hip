@@ -442,14 +442,6 @@ struct NiTables {
   short tile_x[kNiMaxTile], tile_n[kNiMaxTile];
 };
 
-__device__ __forceinline__ void ni_axis_cell(float c01, int g, int &i0, float &f) {
-  const float v = grid_coord(c01, g);
-  const float fl = floorf(v);
-  i0 = (int)fl;
-  f = v - fl;
-  if (g > 1 && i0 == g - 1) { i0 = g - 2; f = 1.f; }
-}
-
 template <int NL>
 __device__ __forceinline__ bool ni_new_cell(const NiParams &p, int i, int n, float lin, bool x_axis) {
   if (i == 0) return true;
@@ -459,8 +451,8 @@ __device__ __forceinline__ bool ni_new_cell(const NiParams &p, int i, int n, flo
     const int g = x_axis ? p.lv[l].gx : p.lv[l].gy;
     int a, b;
     float f;
-    ni_axis_cell(linspace01_s(i, n, lin), g, a, f);
-    ni_axis_cell(linspace01_s(i - 1, n, lin), g, b, f);
+    axis_cell(linspace01_s(i, n, lin), g, a, f);
+    axis_cell(linspace01_s(i - 1, n, lin), g, b, f);
     nw = nw || (a != b);
   }
   return nw;
@@ -590,7 +582,7 @@ __device__ __forceinline__ void ni_pixel(const NiParams &p, int x, float r, floa
 #pragma unroll
   for (int l = 0; l < S::NL; l++) {
     int xi;
-    ni_axis_cell(x01, p.lv[l].gx, xi, c[l].fx);
+    axis_cell(x01, p.lv[l].gx, xi, c[l].fx);
     bool interior;
     const float iz = guide_coord(gray, S::gl(l), interior);
     const float zf = floorf(iz);
@@ -636,15 +628,15 @@ __global__ __launch_bounds__(kMhBlock, 2) void neural_image_fwd_kernel(NiParams 
     float ftmp;
 #pragma unroll
     for (int l = 0; l < S::NL; l++) {
-      ni_axis_cell(linspace01_s(J.xs, p.W, p.lin_x), p.lv[l].gx, x0[l], ftmp);
-      ni_axis_cell(linspace01_s(J.ys, p.H, p.lin_y), p.lv[l].gy, y0[l], ftmp);
+      axis_cell(linspace01_s(J.xs, p.W, p.lin_x), p.lv[l].gx, x0[l], ftmp);
+      axis_cell(linspace01_s(J.ys, p.H, p.lin_y), p.lv[l].gy, y0[l], ftmp);
     }
     ni_load_region<S>(p, gimg, lane, col, half, x0, y0);
     for (int y = J.r0; y < J.r1; y++) {
       float fy[2] = {0.f, 0.f};
       int ytmp;
 #pragma unroll
-      for (int l = 0; l < S::NL; l++) ni_axis_cell(linspace01_s(y, p.H, p.lin_y), p.lv[l].gy, ytmp, fy[l]);
+      for (int l = 0; l < S::NL; l++) axis_cell(linspace01_s(y, p.H, p.lin_y), p.lv[l].gy, ytmp, fy[l]);
       for (int t = J.t0; t < J.t1; t++) {
         const int n = T.tile_n[t];
         const bool on = col < n;
@@ -699,8 +691,8 @@ __global__ __launch_bounds__(kMhBlock) void neural_image_bwd_kernel(NiParams p, 
     float ftmp;
 #pragma unroll
     for (int l = 0; l < S::NL; l++) {
-      ni_axis_cell(linspace01_s(J.xs, p.W, p.lin_x), p.lv[l].gx, x0[l], ftmp);
-      ni_axis_cell(linspace01_s(J.ys, p.H, p.lin_y), p.lv[l].gy, y0[l], ftmp);
+      axis_cell(linspace01_s(J.xs, p.W, p.lin_x), p.lv[l].gx, x0[l], ftmp);
+      axis_cell(linspace01_s(J.ys, p.H, p.lin_y), p.lv[l].gy, y0[l], ftmp);
     }
     ni_load_region<S>(p, gimg, lane, col, half, x0, y0);
 #pragma unroll
@@ -709,7 +701,7 @@ __global__ __launch_bounds__(kMhBlock) void neural_image_bwd_kernel(NiParams p, 
       float fy[2] = {0.f, 0.f};
       int ytmp;
 #pragma unroll
-      for (int l = 0; l < S::NL; l++) ni_axis_cell(linspace01_s(y, p.H, p.lin_y), p.lv[l].gy, ytmp, fy[l]);
+      for (int l = 0; l < S::NL; l++) axis_cell(linspace01_s(y, p.H, p.lin_y), p.lv[l].gy, ytmp, fy[l]);
       for (int t = J.t0; t < J.t1; t++) {
         const int n = T.tile_n[t];
         const bool on = col < n;

@@ -100,3 +100,14 @@ extern "C" int hm_culled_tiles(float mx, float my, int radius, float a, float b,
   }
   return n;
 }
+
+// axis_cell (the fused image transform's cell of a linspace coordinate) next to slice_cell's (x0, x1, fx) for every index of an axis
+extern "C" void hm_axis_cells(int n, int g, int *i0, float *f, int *x0, int *x1, float *fx) {
+  const float lin = n > 1 ? 1.0f / (float)(n - 1) : 0.f;
+  for (int i = 0; i < n; i++) {
+    const float c01 = linspace01_s(i, n, lin);
+    axis_cell(c01, g, i0[i], f[i]);
+    const Cell c = slice_cell(c01, 0.f, 0.5f, g, 1, 1);
+    x0[i] = c.x0; x1[i] = c.x1; fx[i] = c.fx;
+  }
+}

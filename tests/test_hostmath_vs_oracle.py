@@ -180,3 +180,24 @@ def test_tile_culling_is_conservative_and_tight(hm):
     assert needed_tot > 500
     assert kept_tot <= 1.25 * needed_tot + 50, (kept_tot, needed_tot)  # tight
     assert kept_tot < 0.7 * box_tot, (kept_tot, box_tot)               # and a real reduction vs the bounding squares
+
+
+@pytest.mark.parametrize("n,g", [(1920, 16), (1080, 16), (1600, 8), (301, 7), (33, 2), (64, 1), (17, 16), (2, 16), (1, 5), (4096, 16)])
+def test_axis_cell_is_slice_cell_with_the_last_node_folded_into_the_last_cell(hm, n, g):
+    """csrc/bilagrid_math.h::axis_cell (the cell-aligned tiles of the fused image transform): every index of a linspace axis lies in one
+    of the g - 1 cells, the cells are contiguous index ranges in ascending order, and the two node weights equal slice_cell's."""
+    i0 = np.zeros(n, np.int32); f = np.zeros(n, np.float32); x0 = np.zeros(n, np.int32); x1 = np.zeros(n, np.int32); fx = np.zeros(n, np.float32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    hm.hm_axis_cells(n, g, ip(i0), fptr(f), ip(x0), ip(x1), fptr(fx))
+    assert i0.min() >= 0 and i0.max() <= max(g - 2, 0)
+    assert np.all(np.diff(i0) >= 0)                                   # cells are contiguous runs
+    if n >= 4 * g and g > 1:
+        assert len(np.unique(i0)) == g - 1                            # ... and all of them occur
+    # node weights: w[node] over the g nodes, per index
+    wa = np.zeros((n, g), np.float64); wb = np.zeros((n, g), np.float64)
+    idx = np.arange(n)
+    np.add.at(wa, (idx, i0), 1.0 - f.astype(np.float64)); np.add.at(wa, (idx, np.minimum(i0 + 1, g - 1)), f.astype(np.float64))
+    np.add.at(wb, (idx, x0), 1.0 - fx.astype(np.float64)); np.add.at(wb, (idx, x1), fx.astype(np.float64))
+    np.testing.assert_array_equal(wa, wb)
+    if g > 1 and n > 1:
+        assert i0[-1] == g - 2 and f[-1] == 1.0 and x0[-1] == g - 1 and fx[-1] == 0.0     # the folded case really occurs: the last index
