@@ -145,10 +145,10 @@ def render_gaussians(gs: dataclass_gs, cam: dataclass_camera, *, packed: bool = 
     per-class renders of the evaluation path, scene_graph.py:296-313); ``info`` is the trainer's ``self.info``, with
     ``info["means2d"].retain_grad()`` already called when ``training``.  ``kwargs`` go to ``rasterization`` as the reference's do
     (``near_plane``, ``far_plane``, ``render_mode="RGB+ED"``, ``radius_clip``)."""
-    def render_fn(opaticy_mask=None, return_info=False):
+    def render_fn(opacity_mask=None, return_info=False):
         op = gs.opacities.squeeze()
         renders, alphas, info = rasterization(
-            means=gs.means, quats=gs.quats, scales=gs.scales, opacities=op * opaticy_mask if opaticy_mask is not None else op,
+            means=gs.means, quats=gs.quats, scales=gs.scales, opacities=op * opacity_mask if opacity_mask is not None else op,
             colors=gs.rgbs, viewmats=torch.linalg.inv(cam.camtoworlds)[None, ...], Ks=cam.Ks[None, ...], width=cam.W, height=cam.H,
             packed=packed, absgrad=absgrad, sparse_grad=sparse_grad, rasterize_mode="antialiased" if antialiased else "classic",
             **kwargs)
