@@ -432,3 +432,51 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
 
     def get_param_groups(self):
         return {self.class_prefix + "all": self.parameters()}
+
+
+def rotation_6d_to_matrix(d6: Tensor) -> Tensor:
+    """The 6-D rotation representation of Zhou et al. (CVPR 2019) as pytorch3d.transforms.rotation_6d_to_matrix evaluates it (the
+    reference imports it from pytorch3d, which is not in this image: the published definition, PARITY UNPINNED): Gram-Schmidt on the
+    two 3-vectors, third row = their cross product; the three vectors are the ROWS of the result."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = F.normalize(a1, dim=-1)
+    b2 = F.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)
+
+
+class CameraOptModule(nn.Module):
+    """Mirror of models/modules.py:822-874 (the trainer's ``CamPose`` / ``CamPosePerturb``, applied in process_camera,
+    trainers/base.py:324-328): one learnable 9-vector per image -- translation delta + 6-D rotation delta around the identity --
+    right-multiplied onto the camera-to-world matrix.  Same parameter / buffer names (``embeds.weight`` [n,9], ``identity``), so
+    reference checkpoints load.  It is the consumer of the path's camera-pose gradient: viewmat = inverse(module(c2w, id)), and the
+    projection backward returns ``v_viewmat`` (``bds_project_view_bwd_list`` / ``bds_project_bwd``)."""
+
+    def __init__(self, class_name: str, n: int, device="cuda"):
+        super().__init__()
+        self.class_prefix = class_name + "#"
+        self.device = device
+        self.embeds = nn.Embedding(n, 9)
+        self.register_buffer("identity", torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]))
+        self.zero_init()
+        self.to(device)
+
+    def zero_init(self):
+        nn.init.zeros_(self.embeds.weight)
+
+    def random_init(self, std: float):
+        nn.init.normal_(self.embeds.weight, std=std)
+
+    def forward(self, camtoworlds: Tensor, embed_ids: Tensor) -> Tensor:
+        assert camtoworlds.shape[:-2] == embed_ids.shape
+        batch_shape = camtoworlds.shape[:-2]
+        pose_deltas = self.embeds(embed_ids)
+        dx, drot = pose_deltas[..., :3], pose_deltas[..., 3:]
+        rot = rotation_6d_to_matrix(drot + self.identity.expand(*batch_shape, -1))
+        transform = torch.eye(4, device=pose_deltas.device, dtype=pose_deltas.dtype).repeat((*batch_shape, 1, 1))
+        transform[..., :3, :3] = rot
+        transform[..., :3, 3] = dx
+        return torch.matmul(camtoworlds, transform)
+
+    def get_param_groups(self):
+        return {self.class_prefix + "all": self.parameters()}

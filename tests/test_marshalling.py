@@ -83,3 +83,55 @@ def test_get_gaussians_raises_like_the_reference_on_nan_and_inf():
         model._scales[0, 0] = 200.0          # exp overflows
     with pytest.raises(ValueError, match="Inf detected in gaussian _scales at step 7"):
         M.get_gaussians(model, cam)
+
+
+# ---- CameraOptModule (the learnable pose the path's v_viewmat gradient feeds) -------------------------------------------------------------
+def test_camera_opt_module_is_identity_at_init_and_a_rigid_transform_otherwise():
+    from bilateral_driving_amd.modules import CameraOptModule, rotation_6d_to_matrix
+    mod = CameraOptModule("CamPose", 5, device="cpu")
+    assert sorted(mod.state_dict()) == ["embeds.weight", "identity"] and mod.state_dict()["embeds.weight"].shape == (5, 9)
+    assert list(mod.get_param_groups()) == ["CamPose#all"]
+    g = torch.Generator().manual_seed(0)
+    c2w = torch.eye(4).repeat(3, 1, 1) + torch.randn(3, 4, 4, generator=g) * 0.1
+    ids = torch.tensor([4, 0, 2])
+    torch.testing.assert_close(mod(c2w, ids), c2w)                        # zero_init: the identity (models/modules.py:840-843)
+    mod.random_init(0.3)
+    out = mod(c2w, ids)
+    T = torch.linalg.solve(c2w, out)                                      # the right factor
+    R = T[:, :3, :3]
+    torch.testing.assert_close(R @ R.transpose(1, 2), torch.eye(3).expand(3, 3, 3), atol=1e-5, rtol=0)
+    torch.testing.assert_close(torch.linalg.det(R), torch.ones(3), atol=1e-5, rtol=0)
+    torch.testing.assert_close(T[:, :3, 3], mod.embeds.weight[ids, :3].detach(), atol=1e-5, rtol=0)
+    torch.testing.assert_close(T[:, 3], torch.tensor([0.0, 0, 0, 1]).expand(3, 4), atol=1e-6, rtol=0)
+    # rows of the 6-D map: first row = the normalised first vector, second orthogonal to it in the span of both
+    d6 = torch.randn(7, 6, generator=g)
+    M = rotation_6d_to_matrix(d6)
+    torch.testing.assert_close(M[:, 0], torch.nn.functional.normalize(d6[:, :3], dim=-1))
+    assert float((M[:, 0] * M[:, 1]).sum(-1).abs().max()) < 1e-5
+    torch.testing.assert_close(M[:, 2], torch.cross(M[:, 0], M[:, 1], dim=-1))
+
+
+def test_camera_opt_module_passes_the_viewmat_gradient_to_its_embedding():
+    """viewmat = inverse(CamPose(c2w, id)): a gradient on the view matrix (what the projection backward returns) reaches exactly the
+    used image's 9 parameters; checked against finite differences in float64."""
+    from bilateral_driving_amd.modules import CameraOptModule
+    mod = CameraOptModule("CamPose", 4, device="cpu").double()
+    mod.random_init(0.05)
+    g = torch.Generator().manual_seed(1)
+    c2w = (torch.eye(4) + torch.randn(4, 4, generator=g) * 0.05).double()
+    c2w[3] = torch.tensor([0.0, 0, 0, 1.0]).double()
+    G = torch.randn(4, 4, generator=g).double()                            # stands for v_viewmat
+    ids = torch.tensor(2)
+    loss = (torch.linalg.inv(mod(c2w, ids)) * G).sum()
+    loss.backward()
+    grad = mod.embeds.weight.grad
+    assert float(grad[[0, 1, 3]].abs().max()) == 0.0 and float(grad[2].abs().max()) > 0
+    eps = 1e-6
+    for k in range(9):
+        with torch.no_grad():
+            mod.embeds.weight[2, k] += eps
+            up = (torch.linalg.inv(mod(c2w, ids)) * G).sum()
+            mod.embeds.weight[2, k] -= 2 * eps
+            dn = (torch.linalg.inv(mod(c2w, ids)) * G).sum()
+            mod.embeds.weight[2, k] += eps
+        assert abs(float((up - dn) / (2 * eps)) - float(grad[2, k])) < 1e-6 * max(1.0, abs(float(grad[2, k])))
