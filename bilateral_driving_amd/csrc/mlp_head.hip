@@ -895,7 +895,11 @@ inline int ni_shape_id(int n_levels, const bds_feat_level *lv) {
   if (n_levels == 1 && lv[0].gl == 8) {
     switch (lv[0].nch) { case 8: return 0; case 16: return 1; case 24: return 2; case 32: return 3; default: return -1; }
   }
-  if (n_levels == 2 && lv[0].gl == 1 && lv[0].nch == 8 && lv[1].gl == 8 && lv[1].nch == 8) return 4;
+  if (n_levels == 1 && lv[0].gl == 4 && lv[0].nch == 24) return 5;
+  if (n_levels == 2 && lv[0].gl == 1 && lv[0].nch == 8 && lv[1].nch == 8) {
+    if (lv[1].gl == 8) return 4;
+    if (lv[1].gl == 4) return 6;
+  }
   return -1;
 }
 
@@ -984,7 +988,9 @@ extern "C" int bds_neural_image_fwd(int H, int W, int n_levels, const bds_feat_l
     case 1: return ni_launch_fwd<16, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
     case 2: return ni_launch_fwd<24, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
     case 3: return ni_launch_fwd<32, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
-    default: return ni_launch_fwd<8, 1, 8, 8>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    case 4: return ni_launch_fwd<8, 1, 8, 8>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    case 5: return ni_launch_fwd<24, 4, 0, 0>(p, grid, rgb, w1, w2, w3, residual, out, st);
+    default: return ni_launch_fwd<8, 1, 8, 4>(p, grid, rgb, w1, w2, w3, residual, out, st);
   }
 }
 
@@ -1008,7 +1014,9 @@ extern "C" int bds_neural_image_bwd(int H, int W, int n_levels, const bds_feat_l
     case 1: rc = ni_launch_bwd<16, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
     case 2: rc = ni_launch_bwd<24, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
     case 3: rc = ni_launch_bwd<32, 8, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
-    default: rc = ni_launch_bwd<8, 1, 8, 8>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    case 4: rc = ni_launch_bwd<8, 1, 8, 8>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    case 5: rc = ni_launch_bwd<24, 4, 0, 0>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
+    default: rc = ni_launch_bwd<8, 1, 8, 4>(p, grid, rgb, w1, w2, w3, residual, v_out, v_rgb, partials, st); break;
   }
   if (rc != BDS_OK) return rc;
   if (v_w1 || v_w2 || v_w3) {

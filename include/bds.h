@@ -503,7 +503,8 @@ int bds_mlp_head_bwd(int64_t P, int F, int hidden, const float *feats, const flo
  * bwd ACCUMULATES the grid gradients into levels[l].v_grid (same shape; caller zeroes; may be NULL), writes v_rgb (both routes: the
  * application and the guidance; may be NULL) and the weight gradients as bds_mlp_head_bwd does.
  * Built for: one level with gl = 8 and 8 / 16 / 24 / 32 features, or the two levels {gl 1, 8 features} + {gl 8, 8 features}
- * (configs/omnire_neuralbilateral.yaml:246-252, omnire_ms_neuralbilateral.yaml:247-250), any gx, gy with at most 64 cell
+ * (configs/omnire_neuralbilateral.yaml:246-252, omnire_ms_neuralbilateral.yaml:247-250), plus gl = 4 with 24 features and
+ * {gl 1, 8} + {gl 4, 8} (the shapes of the reference-generated golden vectors), any gx, gy with at most 64 cell
  * boundaries per axis, W <= 4096, hidden 64: bds_neural_image_ok() != 0; otherwise BDS_EINVAL and the two-step form
  * (bds_bilagrid_slice_feat_image_* + bds_mlp_head_*) applies.  temp: bds_neural_image_bwd_temp_bytes(F) bytes. */
 typedef struct {

@@ -43,6 +43,9 @@ def test_neural_module_equals_reference_golden(path):
     rgb = torch.from_numpy(z["rgb"]).cuda().requires_grad_(True)
     H, W, _ = rgb.shape
     infos = {"img_idx": torch.full((H, W), k, dtype=torch.long, device="cuda")}
+    from bilateral_driving_amd import mlp_head
+    lv = [getattr(mod, f"bil_grids{i}") for i in range(2)] if name.startswith("ms") else [mod.bil_grids]
+    assert mlp_head.image_supported(H, W, [g.grids[0] for g in lv], 64)     # transform below is the ONE-kernel form: pinned by the reference too
     A = mod(rgb, infos)
     assert A.shape == (1, H, W, 3, 4)
     np.testing.assert_allclose(A[0].detach().cpu().numpy(), z["maps"], rtol=2e-4, atol=2e-5)
@@ -259,8 +262,8 @@ def test_fused_image_transform_test_branch_and_fallbacks():
     scale = float(mod.bil_grids.grids.grad.abs().max())
     torch.testing.assert_close(g_fused, mod.bil_grids.grids.grad, rtol=0, atol=2e-4 * scale)
     assert float(g_fused[0].abs().max()) == 0.0 and float(g_fused[2].abs().max()) == 0.0      # only the two neighbours
-    # gl = 4 is not one of the kernel's shapes: transform still works (slice kernel + head kernel)
-    small = NeuralBilateralAffineTransform("Affine", 2, 6, 5, 4, feature_dim=24, hidden_dim=64)
+    # gl = 2 is not one of the kernel's shapes: transform still works (slice kernel + head kernel)
+    small = NeuralBilateralAffineTransform("Affine", 2, 6, 5, 2, feature_dim=24, hidden_dim=64)
     assert not mlp_head.image_supported(H, W, [small.bil_grids.grids[0]], 64)
     _randomise(small, 6)
     torch.testing.assert_close(small.transform(rgb, {"img_idx": 0}), _two_step(small, rgb, {"img_idx": 0}), rtol=1e-4, atol=5e-5)
