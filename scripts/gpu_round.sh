@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit (through gpurun): full -m gpu suite (log kept), smoke, bench line, rocprofv3 kernel stats + PMC passes.
-# usage: scripts/gpu_round.sh <tag> [tests|notests] [pmc|nopmc]
+# usage: scripts/gpu_round.sh <tag> [tests|notests] [pmc|nopmc] [neural]
 set -u
 TAG=${1:-r02a}
 DO_TESTS=${2:-tests}
@@ -33,6 +33,18 @@ if [ "$DO_PMC" = "pmc" ]; then
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
       --output-format csv -d $OUT/pmc_sq2 -o bench -- \
       python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pair-stats > /dev/null 2>$OUT/pmc_sq2.stderr
+fi
+# optional 4th argument "neural": the neural bilateral variants (one-kernel transform) -- timing, kernel stats and, with pmc, the MFMA
+# busy cycles of the head / fused-image kernels (SQ_VALU_MFMA_BUSY_CYCLES counts cycles: 64 per v_mfma_f32_32x32x2_f32)
+if [ "${4:-}" = "neural" ]; then
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/neural_trace -o nm -- \
+      python $REPO/scripts/neural_module_time.py > $OUT/neural_module_time.txt 2>$OUT/neural_trace.stderr
+  grep "transform fwd" $OUT/neural_module_time.txt
+  timeout 120 python $REPO/scripts/mlp_head_time.py > $OUT/mlp_head_time.txt 2>&1
+  if [ "$DO_PMC" = "pmc" ]; then
+    timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+        --output-format csv -d $OUT/neural_pmc -o nm -- python $REPO/scripts/neural_module_time.py > /dev/null 2>$OUT/neural_pmc.stderr
+  fi
 fi
 # keep what travels back small (gpurun merges <= 64 MiB): stats + counter CSVs only
 find $OUT -type f ! -name "*.csv" ! -name "*.json" ! -name "*.log" ! -name "*.txt" ! -name "*.stderr" -delete
