@@ -435,9 +435,9 @@ class MultiScaleNeuralBilateralAffineTransform(nn.Module):
 
 
 def rotation_6d_to_matrix(d6: Tensor) -> Tensor:
-    """The 6-D rotation representation of Zhou et al. (CVPR 2019) as pytorch3d.transforms.rotation_6d_to_matrix evaluates it (the
-    reference imports it from pytorch3d, which is not in this image: the published definition, PARITY UNPINNED): Gram-Schmidt on the
-    two 3-vectors, third row = their cross product; the three vectors are the ROWS of the result."""
+    """The 6-D rotation representation of Zhou et al. (CVPR 2019) as the reference evaluates it
+    (/root/reference/project/utils/geometry.py:83-105): Gram-Schmidt on the two 3-vectors, third row = their cross product; the three
+    vectors are the ROWS of the result.  Pinned with CameraOptModule by tests/golden/camera_opt.npz."""
     a1, a2 = d6[..., :3], d6[..., 3:]
     b1 = F.normalize(a1, dim=-1)
     b2 = F.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
