@@ -6,7 +6,10 @@ autograd of this file is the gradient reference.
 PARITY UNPINNED.  The arithmetic being restated lives in gsplat v1.3.0, a pip git
 dependency of the reference (/root/reference/README.md:81) that is neither vendored in the
 reference tree nor installable in this image (no network, no CUDA).  There are no golden
-vectors for it.  This file follows the published 3DGS / gsplat algorithm
+vectors for it; the only anchors the reference tree itself offers -- its pinhole projection helper
+(utils/geometry.py:7-21,39-57) and SH2RGB (models/gaussians/basics.py:84-89) -- pin the world -> camera
+transform, means2d / depths and the degree-0 colour (tests/golden/ref_geometry.npz,
+oracle/gen_golden_geometry.py), nothing else.  This file follows the published 3DGS / gsplat algorithm
 and the reference's call-site contract:
 
   * project/models/trainers/base.py:393-408     rasterization(...) call + kwargs

@@ -178,3 +178,33 @@ def test_absgrad_probe_equals_brute_force_per_pixel_gradients():
     assert float((ab - ref).abs().max()) < 1e-10 * float(ref.abs().max())
     # and it dominates the signed gradient, with equality only where every pixel pulls the same way
     assert bool((ab >= p["means"].grad.new_zeros(()).abs()).all())
+
+
+def test_projection_and_degree_zero_colour_against_the_reference_trees_helpers():
+    """The only anchors the reference tree itself offers for the rasterizer half (oracle/gen_golden_geometry.py): its pinhole projection
+    (utils/geometry.py:39-57 after transform_points :7-21) fixes the oracle's world -> camera transform, means2d and depths for
+    every point in front of the camera; SH2RGB (models/gaussians/basics.py:84-89) fixes the degree-0 colour the trainer forms
+    (spherical_harmonics(0, .) + 0.5, vanilla.py:388-389).  The rest of gs_oracle stays parity-unpinned."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_geometry.npz"))
+    t = lambda a: torch.from_numpy(z[a])
+    N = z["points"].shape[0]
+    viewmat = torch.linalg.inv(t("c2w"))
+    quats = torch.tensor([1.0, 0, 0, 0], dtype=torch.float64).repeat(N, 1)
+    scales = torch.full((N, 3), 0.05, dtype=torch.float64)
+    W, H = 100000, 100000                                     # no image-bounds culling: compare every point in front of the camera
+    K = t("K").clone(); K[0, 2] += W / 2; K[1, 2] += H / 2     # (principal point moved with it; undone below)
+    radii, m2, depths, _, _ = G.project(t("points"), quats, scales, viewmat, K, W, H, near_plane=0.2)
+    front = z["depth"] > 0.2
+    assert front.sum() > 150 and (~front).sum() >= 0
+    vis = (radii > 0).numpy()
+    np.testing.assert_array_equal(vis, front)
+    np.testing.assert_allclose(depths.numpy()[front], z["depth"][front], rtol=1e-12)
+    np.testing.assert_allclose(depths.numpy()[front], z["cam_points"][front, 2], rtol=1e-12)
+    uv = m2.numpy()[front] - np.array([W / 2, H / 2])
+    exact = z["uv"][front] * ((z["depth"][front] + 1e-6) / z["depth"][front])[:, None]      # the reference divides by (depth + 1e-6)
+    np.testing.assert_allclose(uv, exact, rtol=1e-9, atol=1e-7)
+    dirs = torch.randn(N, 3, dtype=torch.float64)
+    rgb = G.spherical_harmonics(0, dirs, t("sh_dc")[:, None, :]) + 0.5
+    np.testing.assert_allclose(rgb.numpy(), z["rgb_from_sh"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(z["sh_from_rgb"], z["sh_dc"], rtol=1e-12, atol=1e-12)
