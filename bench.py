@@ -75,6 +75,13 @@ def parse():
                     help="drive each view through harness.train_view (the same kernels called back to back without an autograd graph) "
                          "instead of forward / loss / loss.backward() through torch autograd, the reference-shaped step (default); "
                          "measured equal on MI355X: the host runs ahead of the GPU either way")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of --steps steps is run this many times (barrier + synchronize around each); the MEDIAN "
+                         "repeat is reported (a 0.2 s window on a shared host can swing 10-20 %), min / max beside it")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N = 1: drive the frame through the eager host-count loop (one host wait per view, ~40 launches from Python) "
+                         "instead of replaying the captured hipGraphs of graph_view.FrameGraph (default: same kernels, same order, "
+                         "device-side list counts, one launch per view)")
     ap.add_argument("--dense-grads", action="store_true",
                     help="N = 1 only: fresh dense gradient tensors per view (zero fill of all N rows, autograd accumulation) instead of "
                          "the flat gradient buffer whose rows are cleared / written through the visible-id lists")
@@ -260,8 +267,19 @@ def main():
     torch.cuda.synchronize()
 
     stats = {}
+    use_graph = world == 1 and not args.no_graph and not dense and not args.direct and not args.pipeline
+    frame = None
+    if use_graph:
+        # the views are captured with the roofline kernel bracketed by timing marks (event-record nodes: re-recorded by every replay)
+        from bilateral_driving_amd.graph_view import FrameGraph
+        L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
+        frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)))
+        L.enable_timers(False)
 
     def step(s):
+        if frame is not None:
+            frame.step()
+            return
         if dense:
             for p in list(params.values()) + grids:
                 p.grad = None
@@ -296,33 +314,51 @@ def main():
     for s in range(args.warmup):
         step(s)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    stats.clear()
     # inside the timed region only the dominant kernel is bracketed by HIP events (every pair is two more packets on the stream);
     # the per-operator table is taken from a few extra, untimed steps afterwards
-    L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))   # (diagnostic switch)
-    t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
-        step(s)
-    torch.cuda.synchronize()
+    if frame is None:
+        L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))   # (diagnostic switch)
+    # The timed region -- EXACTLY --steps steps between barrier + synchronize on both sides -- is repeated; the median repeat is the
+    # reported one (max over ranks per repeat first)
+    reps, dom_ms = [], []
+    for r in range(max(args.repeats, 1)):
+        stats.clear()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            step(args.warmup + r * args.steps + s)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+        if frame is not None:   # the marks of the repeat's last frame (one pair per view), recorded inside the timed region
+            dom_ms += frame.mark_samples("rasterize_bwd")
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tsum = L.timer_summary()
-    Ms, nvs = list(stats["M"]), list(stats["n_vis"])
+        t = torch.tensor(reps, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reps = [float(x) for x in t.tolist()]
+    elapsed = sorted(reps)[len(reps) // 2] if len(reps) % 2 else sorted(reps)[len(reps) // 2 - 1]   # (lower median for even counts)
+    if frame is not None:
+        assert frame.valid(), "a list outgrew its calibrated capacity during the timed region"
+        cnts = frame.counts()
+        Ms, nvs = [c[0] for c in cnts], [c[1] for c in cnts]
+        tsum = {"rasterize_bwd": (len(dom_ms), sum(dom_ms) / max(len(dom_ms), 1))} if dom_ms else {}
+    else:
+        tsum = L.timer_summary()
+        Ms, nvs = list(stats["M"]), list(stats["n_vis"])
+    # per-operator table: the eager host-count loop with HIP events around every operator (2 untimed frames)
+    frame_graph, frame = frame, None
     L.enable_timers(True)
     for s in range(2):
         step(s)
     torch.cuda.synchronize()
     tall = L.timer_summary()
     L.enable_timers(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    frame = frame_graph
     ms_per_step = elapsed / args.steps * 1e3
     value = world * V * args.steps / elapsed
 
@@ -383,7 +419,9 @@ def main():
     result = {
         "metric": "train iters/sec (fwd+bwd) at 2M Gaussians, 6x1920x1080; HBM roofline %",
         "value": value, "unit": "iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms_per_step, "repeats": len(reps), "ms_per_step_min": min(reps) / args.steps * 1e3,
+        "ms_per_step_max": max(reps) / args.steps * 1e3, "timing": "median of `repeats` timed regions of `steps` steps each",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['text']}; {N} Gaussians, {len(cams)}-cam ring {W}x{H}, RGB+ED, grids "
                                f"{[list(l) for l in wl['levels']]} factors {list(factors)}, L1+TV loss, camera-pose gradient live; one step = one "
@@ -393,7 +431,10 @@ def main():
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
                    "pipelined_fronts": bool(args.pipeline) and not args.direct,
-                   "step_driver": "direct (harness.train_view: same kernels, no autograd graph)" if args.direct else "autograd (forward, loss, loss.backward())",
+                   "step_driver": ("hipGraph replay (graph_view.FrameGraph): per view ONE captured graph = forward + L1/TV loss + backward, "
+                                   "device-side list counts, no host wait") if frame is not None else
+                                  ("direct (harness.train_view: same kernels, no autograd graph)" if args.direct else
+                                   "autograd (forward, loss, loss.backward())"),
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
                    "exchanges_per_step": fx.n_exchanges if world > 1 else 0},

@@ -39,6 +39,11 @@ _SIGS = {
     "bds_strerror": (C.c_char_p, [_i]),
     "bds_set_option": (_i, [_i, _i]),
     "bds_get_option": (_i, [_i]),
+    "bds_timer_create": (C.c_void_p, []),
+    "bds_timer_destroy": (_i, [_f]),
+    "bds_timer_mark": (_i, [_f, _f]),
+    "bds_timer_elapsed_ms": (C.c_float, [_f, _f]),
+    "bds_last_hip_error": (_i, []),
     "bds_sh_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f]),
     "bds_sh_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_project_fwd": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f]),
@@ -62,6 +67,15 @@ _SIGS = {
     "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),
     "bds_view_grads_add_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_isect_counts_offset": (_sz, [_i]),
+    "bds_isect_prepare_dev": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _i64, _i64, _f, _i, _f]),
+    "bds_isect_build_dev": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _i, _f]),
+    "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f]),
+    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
+    "bds_sh_view_bwd_list_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
+    "bds_project_view_bwd_list_dev": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "bds_view_grads_clear_list_dev": (_i, [_i64, _f, _f, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
@@ -211,6 +225,17 @@ def timed(name: str):
     if TIMERS is None or (TIMERS_ONLY is not None and name not in TIMERS_ONLY):
         yield
         return
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture: marks that become event-record nodes (re-recorded by every replay; read with replay_timers)
+        s, e = _Mark(), _Mark()
+        if lib().bds_timer_mark(s.h, stream()) != 0:
+            raise BdsError(f"bds_timer_mark failed under capture (HIP error {lib().bds_last_hip_error()})")
+        try:
+            yield
+        finally:
+            check(lib().bds_timer_mark(e.h, stream()), "bds_timer_mark")
+            GRAPH_MARKS.setdefault(name, []).append((s, e))
+        return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(torch.cuda.current_stream())
     try:
@@ -218,6 +243,37 @@ def timed(name: str):
     finally:
         e.record(torch.cuda.current_stream())
         TIMERS.setdefault(name, []).append((s, e))
+
+
+class _Mark:
+    """One libbds timing mark (a hipEvent that is recorded as a graph node under capture)."""
+
+    def __init__(self):
+        self.h = lib().bds_timer_create()
+        if not self.h:
+            raise BdsError("bds_timer_create failed")
+
+    def __del__(self):
+        try:
+            if self.h and _lib is not None:
+                _lib.bds_timer_destroy(self.h)
+        except Exception:
+            pass
+
+
+GRAPH_MARKS = {}   # name -> [(start mark, stop mark)] captured inside hipGraphs while timers were enabled
+
+
+def graph_mark_samples(name: str, marks=None):
+    """Milliseconds between every captured mark pair of ``name`` as last recorded by a replay (call after a synchronise; pairs of
+    graphs that have not been replayed yet give negative values and are dropped).  ``marks``: the dict a capture collected
+    (``graph_view.FrameGraph.marks``), default: everything captured so far."""
+    out = []
+    for s, e in (GRAPH_MARKS if marks is None else marks).get(name, []):
+        ms = float(lib().bds_timer_elapsed_ms(s.h, e.h))
+        if ms >= 0.0:
+            out.append(ms)
+    return out
 
 
 def timer_summary() -> dict:

@@ -24,6 +24,14 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Length of a work list whose element count may live in DEVICE memory (a compaction result the host never reads: the `_dev` entry
+// points of include/bds.h).  The launch is sized for the host-side capacity n_cap; surplus workgroups see no elements.
+__device__ __forceinline__ int64_t list_length(int64_t n_cap, const uint64_t *__restrict__ n_dev) {
+  if (n_dev == nullptr) return n_cap;
+  const int64_t n = (int64_t)*n_dev;
+  return n < n_cap ? n : n_cap;
+}
+
 // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8 (observed; used for L2 locality only).
 // Map a linear block id to a work item so that each XCD owns one contiguous range of items.
 __device__ __forceinline__ int xcd_contiguous(int bid, int total) {

@@ -156,12 +156,14 @@ __device__ __forceinline__ void pose_grad_reduce(const ProjGrad &pg, float (*red
 // (models/trainers/base.py:280-297), and reduces the camera-pose gradient (models/trainers/base.py:328-329,399).
 template <bool kAcc, bool kPose>
 __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
-    int64_t n_list, const int32_t *__restrict__ ids, const float *__restrict__ means, const float *__restrict__ quats,
-    const float *__restrict__ scales, const float *__restrict__ opacities, const float *__restrict__ viewmat,
+    int64_t n_cap, const uint64_t *__restrict__ n_dev, const int32_t *__restrict__ ids, const float *__restrict__ means,
+    const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     const float *__restrict__ K, int W, int H, float eps2d, const float4 *__restrict__ v_rec, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat_slots,
     float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map) {
   __shared__ float red[kProjBlock / kWave][12];
+  const int64_t n_list = list_length(n_cap, n_dev);
+  if ((int64_t)blockIdx.x * kProjBlock >= n_list) return;   // (whole workgroup: nothing to add to the pose slots either)
   const int64_t r = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   ProjGrad pg;
   for (int i = 0; i < 9; i++) pg.v_R[i] = 0.f;
@@ -259,11 +261,11 @@ extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *
   return BDS_OK;
 }
 
-extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats,
-                                         const float *scales, const float *opacities, const float *viewmat, const float *K, int W,
-                                         int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
-                                         float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
-                                         float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
+static int project_view_bwd_list_impl(int64_t n_list, const uint64_t *n_dev, const int32_t *ids, const float *means, const float *quats,
+                                      const float *scales, const float *opacities, const float *viewmat, const float *K, int W,
+                                      int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
+                                      float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
+                                      float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(n_list >= 0 && W > 0 && H > 0);
   // (v_viewmat_slots is ADDED to: the caller zero-fills it -- a memset node of 4 KB between two kernels costs ~15 us of idle GPU)
   if (n_list == 0) return BDS_OK;
@@ -271,13 +273,33 @@ extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, con
               v_quats && v_log_scales && v_logits);
   const dim3 grid((unsigned)cdiv(n_list, kProjBlock)), block(kProjBlock);
   const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
-#define BDS_LIST(A, P)                                                                                                         \
-  hipLaunchKernelGGL((project_view_bwd_list_kernel<A, P>), grid, block, 0, as_stream(stream), n_list, ids, means, quats, scales, \
-                     opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d,   \
+#define BDS_LIST(A, P)                                                                                                                \
+  hipLaunchKernelGGL((project_view_bwd_list_kernel<A, P>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, means, quats, scales, \
+                     opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d,        \
                      absgrad2d, row_map)
   if (accumulate) { if (v_viewmat_slots) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else            { if (v_viewmat_slots) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST
   BDS_LAUNCH_CHECK();
   return BDS_OK;
+}
+
+extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats,
+                                         const float *scales, const float *opacities, const float *viewmat, const float *K, int W,
+                                         int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
+                                         float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
+                                         float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
+  return project_view_bwd_list_impl(n_list, nullptr, ids, means, quats, scales, opacities, viewmat, K, W, H, eps2d, v_records, v_means,
+                                    v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d, absgrad2d, row_map, accumulate, stream);
+}
+
+extern "C" int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, const float *means,
+                                             const float *quats, const float *scales, const float *opacities, const float *viewmat,
+                                             const float *K, int W, int H, float eps2d, const float *v_records, float *v_means,
+                                             float *v_quats, float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d,
+                                             float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
+  BDS_REQUIRE(n_dev);
+  return project_view_bwd_list_impl(n_capacity, n_dev, ids, means, quats, scales, opacities, viewmat, K, W, H, eps2d, v_records,
+                                    v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d, absgrad2d, row_map, accumulate,
+                                    stream);
 }

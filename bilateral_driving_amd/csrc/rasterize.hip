@@ -51,12 +51,24 @@ __device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int 
 // ---- splat records --------------------------------------------------------------------------------------
 // rec[r] = record of entry ids[r] (ids == null: r itself) of the per-(camera, Gaussian) arrays
 template <int CH>
-__global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n, const int32_t *__restrict__ ids,
+__global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
+                                                               const int32_t *__restrict__ ids,
                                                                const float *__restrict__ means2d, const float *__restrict__ conics,
                                                                const float *__restrict__ colors, const float *__restrict__ opacities,
-                                                               const int32_t *__restrict__ radii, float4 *__restrict__ rec) {
+                                                               const int32_t *__restrict__ radii, float4 *__restrict__ rec,
+                                                               float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
+                                                               int zero_tail_f4) {
+  // (fused view: the gradient record of every packed row -- what the composite backward accumulates into -- and the camera-pose
+  // gradient slots behind them are cleared here instead of by a fill launch of their own)
+  if (zero_tail && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < zero_tail_f4; i += kPackBlock) zero_tail[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t n = list_length(n_cap, n_dev);
   const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
   if (r >= n) return;
+  if (zero_rec) {
+#pragma unroll
+    for (int i = 0; i < kGradStride / 4; i++) zero_rec[r * (kGradStride / 4) + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int64_t g = ids ? (int64_t)ids[r] : r;
   const float2 xy = *reinterpret_cast<const float2 *>(means2d + g * 2);
   const float *cn = conics + g * 3;
@@ -184,10 +196,11 @@ __device__ __forceinline__ float clamp_alpha(float ov) { return __builtin_amdgcn
 // ---- forward ----------------------------------------------------------------------------------------------
 template <int CH, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
-    int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
-    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, float *__restrict__ render,
-    float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg) {
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  const int64_t M = M_dev ? (int64_t)*M_dev : M_host;   // (the list length may live on the device: bds_rasterize_fwd_dev)
   const int n_tiles = tile_w * tile_h;
   const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
@@ -302,12 +315,13 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 // Gaussian's gradient record.  The list is replayed back to front from the tile's deepest blended entry.
 template <int CH, bool ABS, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
-    int C, int64_t M, const float4 *__restrict__ rec, const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h,
-    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas,
-    const int32_t *__restrict__ last_ids, const float *__restrict__ v_render, const float *__restrict__ v_alphas,
-    float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
+  const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
   const int n_tiles = tile_w * tile_h;
   const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
@@ -539,20 +553,47 @@ __global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, co
 
 using namespace bds;
 
-extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
-                              const float *opacities, const int32_t *radii, float *records, bds_stream_t stream) {
+static int splat_pack_impl(int64_t n, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d, const float *conics,
+                           const float *colors, const float *opacities, const int32_t *radii, float *records, float *zero_records,
+                           float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && (CH == 1 || CH == 3 || CH == 4));
-  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(zero_tail_floats >= 0 && zero_tail_floats % 4 == 0 && zero_tail_floats < ((int64_t)1 << 24));
+  BDS_REQUIRE(!zero_records || aligned16(zero_records));
+  BDS_REQUIRE(!zero_tail || aligned16(zero_tail));
+  if (n == 0) {
+    if (zero_tail && zero_tail_floats &&
+        hipMemsetAsync(zero_tail, 0, sizeof(float) * zero_tail_floats, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
+    return BDS_OK;
+  }
   BDS_REQUIRE(means2d && conics && colors && opacities && records && aligned16(records));
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
   const dim3 grid((unsigned)cdiv(n, kPackBlock)), block(kPackBlock);
   float4 *rec = reinterpret_cast<float4 *>(records);
+  float4 *zr = reinterpret_cast<float4 *>(zero_records), *zt = reinterpret_cast<float4 *>(zero_tail);
+  const int zt4 = (int)(zero_tail_floats / 4);
   hipStream_t st = as_stream(stream);
-  if (CH == 1) hipLaunchKernelGGL((splat_pack_kernel<1>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
-  else if (CH == 3) hipLaunchKernelGGL((splat_pack_kernel<3>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
-  else hipLaunchKernelGGL((splat_pack_kernel<4>), grid, block, 0, st, n, ids, means2d, conics, colors, opacities, radii, rec);
+#define BDS_PACK(ch) \
+  hipLaunchKernelGGL((splat_pack_kernel<ch>), grid, block, 0, st, n, n_dev, ids, means2d, conics, colors, opacities, radii, rec, zr, zt, zt4)
+  if (CH == 1) BDS_PACK(1);
+  else if (CH == 3) BDS_PACK(3);
+  else BDS_PACK(4);
+#undef BDS_PACK
   BDS_LAUNCH_CHECK();
   return BDS_OK;
+}
+
+extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
+                              const float *opacities, const int32_t *radii, float *records, bds_stream_t stream) {
+  return splat_pack_impl(n, nullptr, CH, ids, means2d, conics, colors, opacities, radii, records, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d,
+                                  const float *conics, const float *colors, const float *opacities, const int32_t *radii,
+                                  float *records, float *zero_records, float *zero_tail, int64_t zero_tail_floats,
+                                  bds_stream_t stream) {
+  BDS_REQUIRE(n_dev);
+  return splat_pack_impl(n_capacity, n_dev, CH, ids, means2d, conics, colors, opacities, radii, records, zero_records, zero_tail,
+                         zero_tail_floats, stream);
 }
 
 extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
@@ -589,10 +630,10 @@ static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
   return true;
 }
 
-extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
-                                 int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                                 const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                                 int32_t *last_ids, bds_stream_t stream) {
+static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
+                              const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                              const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
+                              int32_t *last_ids, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -604,9 +645,9 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-#define BDS_FWD(ch, co)                                                                                                                 \
-  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w, tile_h, \
-                     isect_offsets, flatten, render, alphas, last_ids, lg)
+#define BDS_FWD(ch, co)                                                                                                              \
+  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
+                     tile_h, isect_offsets, flatten, render, alphas, last_ids, lg)
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
@@ -621,11 +662,28 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
   return BDS_OK;
 }
 
-extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
+extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
                                  int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                                 const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
-                                 const float *v_render, const float *v_alphas, float *v_records, int absgrad,
-                                 const int32_t *tile_order, bds_stream_t stream) {
+                                 const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
+                                 int32_t *last_ids, bds_stream_t stream) {
+  return rasterize_fwd_impl(C, n_records, M, nullptr, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
+                            isect_offsets, flatten, render, alphas, last_ids, stream);
+}
+
+extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
+                                     const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
+                                     int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
+                                     int32_t *last_ids, bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0);
+  return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
+                            isect_offsets, flatten, render, alphas, last_ids, stream);
+}
+
+static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
+                              const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                              const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
+                              const float *v_render, const float *v_alphas, float *v_records, int absgrad,
+                              const int32_t *tile_order, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -640,8 +698,8 @@ extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, co
   const float4 *rec = reinterpret_cast<const float4 *>(records);
   // (kStrip = false: measured on the benchmark scene, skipping untouched 16 x 4 strips costs the backward 3 % -- its per-pixel
   // body is long enough that the extra control flow outweighs the ~19 % of strips it would skip; the forward gains 7 %)
-#define BDS_BWD(ch, ab, co)                                                                                                              \
-  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), 0, st, C, M, rec, backgrounds, W, H, tile_w,     \
+#define BDS_BWD(ch, ab, co)                                                                                                                 \
+  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
                      tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg)
 #define BDS_BWD_CH(ab, co)            \
   do {                                \
@@ -660,6 +718,25 @@ extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, co
 #undef BDS_BWD
   BDS_LAUNCH_CHECK();
   return BDS_OK;
+}
+
+extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
+                                 int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                                 const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
+                                 const float *v_render, const float *v_alphas, float *v_records, int absgrad,
+                                 const int32_t *tile_order, bds_stream_t stream) {
+  return rasterize_bwd_impl(C, n_records, M, nullptr, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
+                            isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream);
+}
+
+extern "C" int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
+                                     const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
+                                     int tile_h, const int32_t *isect_offsets, const int32_t *flatten, const float *alphas,
+                                     const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records,
+                                     int absgrad, const int32_t *tile_order, bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0);
+  return rasterize_bwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
+                            isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream);
 }
 
 extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,

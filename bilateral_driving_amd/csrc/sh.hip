@@ -229,7 +229,8 @@ __global__ __launch_bounds__(kShBlock) void sh_view_fwd_kernel(int64_t n, int K,
 // the caller's business: zero-filled, or kept zero by bds_view_grads_clear_list), kAcc = true adds to them (several views summed
 // into one buffer before one exchange).
 template <int DEG, bool kVec, bool kAcc>
-__global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_list, const int32_t *__restrict__ ids, int K,
+__global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
+                                                                   const int32_t *__restrict__ ids, int K,
                                                                    const float *__restrict__ means,
                                                                    const float *__restrict__ cam_pos,
                                                                    const float *__restrict__ sh_rgb,
@@ -240,7 +241,9 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
   constexpr int nb = (DEG + 1) * (DEG + 1);
   const int row = K * 3;
   const int ldr = row + 1;
+  const int64_t n_list = list_length(n_cap, n_dev);
   const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
+  if (r0 >= n_list) return;
   const int cnt = (int)min((int64_t)kShBlock, n_list - r0);
   const int tid = threadIdx.x;
   if (tid < cnt) {
@@ -307,12 +310,15 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_li
 // zero the rows ids[0..n_list) of the five per-Gaussian gradient arrays (row-wise clear of a persistent buffer: the rows a
 // previous view wrote); v_sh rows leave as whole 16-byte pieces, 12 lanes per 192-byte row
 template <bool kVec>
-__global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t n_list, const int32_t *__restrict__ ids, int K,
+__global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
+                                                                        const int32_t *__restrict__ ids, int K,
                                                                         float *__restrict__ v_means, float *__restrict__ v_quats,
                                                                         float *__restrict__ v_log_scales, float *__restrict__ v_logits,
                                                                         float *__restrict__ v_sh) {
   __shared__ int32_t s_g[kShBlock];
+  const int64_t n_list = list_length(n_cap, n_dev);
   const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
+  if (r0 >= n_list) return;
   const int cnt = (int)min((int64_t)kShBlock, n_list - r0);
   const int tid = threadIdx.x;
   if (tid < cnt) {
@@ -503,20 +509,21 @@ extern "C" int bds_sh_view_fwd(int64_t n, int K, int deg, const float *means, co
 }
 
 template <int DEG>
-static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipStream_t st, int64_t n_list, const int32_t *ids, int K,
+static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipStream_t st, int64_t n_list, const uint64_t *n_dev,
+                                 const int32_t *ids, int K,
                                  const float *means, const float *cam_pos, const float *sh_rgb, const float4 *v_rec, float *v_coeffs,
                                  const int32_t *row_map, int by_rank) {
 #define BDS_LIST(V, A)                                                                                                           \
-  hipLaunchKernelGGL((sh_view_bwd_list_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), lds, st, n_list, ids, K, means, cam_pos, \
+  hipLaunchKernelGGL((sh_view_bwd_list_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), lds, st, n_list, n_dev, ids, K, means, cam_pos, \
                      sh_rgb, v_rec, v_coeffs, row_map, by_rank)
   if (vec) { if (acc) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else     { if (acc) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST
 }
 
-extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
-                                    const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs,
-                                    const int32_t *row_map, int accumulate, bds_stream_t stream) {
+static int sh_view_bwd_list_impl(int64_t n_list, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
+                                 const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs,
+                                 const int32_t *row_map, int accumulate, bds_stream_t stream) {
   BDS_REQUIRE(n_list >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
   if (n_list == 0) return BDS_OK;
   BDS_REQUIRE(ids && means && cam_pos && sh_rgb && v_records && v_coeffs && aligned16(v_records));
@@ -526,29 +533,55 @@ extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, i
   hipStream_t st = as_stream(stream);
   const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
   switch (deg) {
-    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
-    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
-    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
-    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
   }
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
+                                    const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs,
+                                    const int32_t *row_map, int accumulate, bds_stream_t stream) {
+  return sh_view_bwd_list_impl(n_list, nullptr, ids, K, deg, means, cam_pos, sh_rgb, sh_rgb_by_rank, v_records, v_coeffs, row_map,
+                               accumulate, stream);
+}
+
+extern "C" int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
+                                        const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank, const float *v_records,
+                                        float *v_coeffs, const int32_t *row_map, int accumulate, bds_stream_t stream) {
+  BDS_REQUIRE(n_dev);
+  return sh_view_bwd_list_impl(n_capacity, n_dev, ids, K, deg, means, cam_pos, sh_rgb, sh_rgb_by_rank, v_records, v_coeffs, row_map,
+                               accumulate, stream);
+}
+
+static int view_grads_clear_list_impl(int64_t n_list, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means, float *v_quats,
+                                      float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
+  BDS_REQUIRE(n_list >= 0 && K >= 1 && K <= 16);
+  if (n_list == 0) return BDS_OK;
+  BDS_REQUIRE(ids && v_means && v_quats && v_log_scales && v_logits && v_sh);
+  const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);
+  if (((K * 3) % 4 == 0) && aligned16(v_sh))
+    hipLaunchKernelGGL((view_grads_clear_list_kernel<true>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, K, v_means, v_quats,
+                       v_log_scales, v_logits, v_sh);
+  else
+    hipLaunchKernelGGL((view_grads_clear_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, K, v_means, v_quats,
+                       v_log_scales, v_logits, v_sh);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
 
 extern "C" int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int K, float *v_means, float *v_quats,
                                          float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
-  BDS_REQUIRE(n_list >= 0 && K >= 1 && K <= 16);
-  if (n_list == 0) return BDS_OK;
-  BDS_REQUIRE(ids && v_means && v_quats && v_log_scales && v_logits && v_sh);
-  const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);
-  if (((K * 3) % 4 == 0) && aligned16(v_sh))
-    hipLaunchKernelGGL((view_grads_clear_list_kernel<true>), grid, block, 0, as_stream(stream), n_list, ids, K, v_means, v_quats,
-                       v_log_scales, v_logits, v_sh);
-  else
-    hipLaunchKernelGGL((view_grads_clear_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, ids, K, v_means, v_quats,
-                       v_log_scales, v_logits, v_sh);
-  BDS_LAUNCH_CHECK();
-  return BDS_OK;
+  return view_grads_clear_list_impl(n_list, nullptr, ids, K, v_means, v_quats, v_log_scales, v_logits, v_sh, stream);
+}
+
+extern "C" int bds_view_grads_clear_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means,
+                                             float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
+  BDS_REQUIRE(n_dev);
+  return view_grads_clear_list_impl(n_capacity, n_dev, ids, K, v_means, v_quats, v_log_scales, v_logits, v_sh, stream);
 }
 
 extern "C" int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const float *s_means, const float *s_quats,

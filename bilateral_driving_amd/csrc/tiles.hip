@@ -272,9 +272,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
 // of 8.  On the last pass (`unpack` != null) every entry's list value (Gaussian id, or compact position) is looked up from its
 // rank and written to vals_out next to the packed word.
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
-    const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
-    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
+    const uint32_t *__restrict__ keys_in, int64_t n_host, const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits,
+    int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
     uint32_t rank_mask, uint32_t *__restrict__ vals_out) {
+  const int64_t n = list_length(n_host, n_dev);
   const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
   if (bbase >= n) return;
   __shared__ uint32_t wrun[kSortWaves][256];
@@ -350,9 +351,11 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
 // With coarse list tiles the whole tile key is 9-10 bits (1080p, 64-px list tiles: 510 lists): ONE stable pass orders the
 // pairs instead of two (a pass over the list costs a histogram, a scan of [bins][workgroups] and a scatter launch).
 template <int kBins>
-__global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift,
-                                                                    uint32_t mask, int nblocks, uint32_t *__restrict__ hist) {
+__global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint32_t *__restrict__ keys, int64_t n_host,
+                                                                    const uint64_t *__restrict__ n_dev, int shift, uint32_t mask,
+                                                                    int nblocks, uint32_t *__restrict__ hist) {
   __shared__ uint32_t h[kBins];
+  const int64_t n = list_length(n_host, n_dev);
   for (int d = threadIdx.x; d < kBins; d += kSortBlock) h[d] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortChunk;
@@ -367,12 +370,13 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint3
 
 template <int kBins>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
-    const uint32_t *__restrict__ keys_in, int64_t n, int shift, uint32_t mask, int bits, int nblocks,
-    const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
+    const uint32_t *__restrict__ keys_in, int64_t n_host, const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits,
+    int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
     uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out, int n_offsets) {
   constexpr int kPer = kBins / kSortBlock;   // digits per thread (consecutive: thread t owns [t * kPer, (t + 1) * kPer))
+  const int64_t n = list_length(n_host, n_dev);
   const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
-  if (bbase >= n) return;
+  if (bbase >= n && !(offsets_out && blockIdx.x == 0)) return;   // (an empty list still owes its per-tile offsets: all zero)
   __shared__ uint32_t wrun[kSortWaves][kBins];
   __shared__ uint32_t dstart[kBins], gbase[kBins];
   __shared__ uint32_t lw[kSortBlock / kWave + 1];
@@ -486,7 +490,7 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
 
 static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int shift, int bits, uint32_t *temp, hipStream_t st,
                            const uint32_t *unpack, uint32_t rank_mask, uint32_t *vout, int32_t *offsets_out = nullptr,
-                           int n_offsets = 0) {
+                           int n_offsets = 0, const uint64_t *n_dev = nullptr) {
   if (n == 0) return BDS_OK;
   const int nblocks = (int)cdiv(n, kSortChunk);
   const uint32_t mask = (1u << bits) - 1u;
@@ -494,24 +498,23 @@ static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int s
   uint32_t *hist = temp;
   uint32_t *stemp = temp + align_up((size_t)(bits > 8 ? (1 << kWideBits) : 256) * nblocks, 4);
   if (bits > 8) {
-    if (bits == 9) hipLaunchKernelGGL((radix_hist_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, nblocks, hist);
-    else hipLaunchKernelGGL((radix_hist_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, nblocks, hist);
+    if (bits == 9) hipLaunchKernelGGL((radix_hist_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
+    else hipLaunchKernelGGL((radix_hist_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
   } else {
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, (const uint64_t *)nullptr, shift, mask,
-                       nblocks, hist);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
   }
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
   if (bits == 9) {
-    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks,
-                       hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
+    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits,
+                       nblocks, hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
   } else if (bits > 9) {
-    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks,
-                       hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
+    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits,
+                       nblocks, hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
   } else {
-    hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, shift, mask, bits, nblocks, hist,
-                       kout, unpack, rank_mask, vout);
+    hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits, nblocks,
+                       hist, kout, unpack, rank_mask, vout);
   }
   BDS_LAUNCH_CHECK();
   return BDS_OK;
@@ -945,8 +948,10 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
 
 // offsets[t] = first index whose key >= t  (lower bound; empty tiles point at the next run)
 // (key_shift: the tile key sits above the rank bits of a packed entry)
-__global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M, const uint32_t *__restrict__ keys, int key_shift,
+__global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M_host, const uint64_t *__restrict__ M_dev,
+                                                                   const uint32_t *__restrict__ keys, int key_shift,
                                                                    int n_tiles_total, int32_t *__restrict__ offsets) {
+  const int64_t M = list_length(M_host, M_dev);
   const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (i > M) return;
   // thread i < M closes the gap (key[i-1], key[i]]; thread M closes (key[M-1], n_tiles)
@@ -989,7 +994,7 @@ static PrepWs prep_layout(void *ws, int64_t CN) {
     off += align_up(elems * esz, 256);
     return q;
   };
-  L.total = reinterpret_cast<uint64_t *>(take(2, 8));
+  L.total = reinterpret_cast<uint64_t *>(take(8, 8));   // M, visible, and the effective / overflow words of the device-count form
   L.ka = reinterpret_cast<uint32_t *>(take(CN, 4));
   L.va = reinterpret_cast<uint32_t *>(take(CN, 4));
   L.kb = reinterpret_cast<uint32_t *>(take(CN, 4));
@@ -1054,8 +1059,12 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
 // M = sum of the counting kernel's per-workgroup totals -> counts_dev[0]; then, for the asynchronous form, both counts -> page-locked
 // host memory, written by the GPU itself (a copy node between two kernels costs ~15 us of idle GPU: engine switch + barriers; this
 // one-workgroup kernel ~4.5 us)
+// cap_m / cap_vis >= 0 (the `_dev` forms): the "effective" counts downstream kernels size themselves by are published next to the raw
+// ones -- both ZERO when either count outgrew its capacity (the view then renders nothing instead of overrunning a buffer; the host
+// sees the raw counts and the overflow word one read-back later and provisions more).
+constexpr int kCountMEff = 2, kCountVisEff = 3, kCountOverflow = 4;
 __global__ __launch_bounds__(256) void finish_counts_kernel(const uint32_t *__restrict__ btot, int nblocks, uint64_t *__restrict__ counts_dev,
-                                                           volatile int64_t *__restrict__ counts_host) {
+                                                           volatile int64_t *__restrict__ counts_host, int64_t cap_m, int64_t cap_vis) {
   __shared__ unsigned long long part[256];
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // (independent partial sums: four loads in flight per thread)
   int b = threadIdx.x;
@@ -1072,7 +1081,15 @@ __global__ __launch_bounds__(256) void finish_counts_kernel(const uint32_t *__re
   }
   if (threadIdx.x == 0) {
     counts_dev[0] = part[0];
-    if (counts_host) { counts_host[0] = (int64_t)part[0]; counts_host[1] = (int64_t)counts_dev[1]; }
+    const uint64_t nv = counts_dev[1];
+    if (cap_m >= 0) {
+      const bool over = (int64_t)part[0] > cap_m || (int64_t)nv > cap_vis;
+      counts_dev[kCountMEff] = over ? 0ull : part[0];
+      counts_dev[kCountVisEff] = over ? 0ull : nv;
+      counts_dev[kCountOverflow] = over ? 1ull : 0ull;
+      if (counts_host && over) counts_host[2] = 1;   // sticky: the host clears it when it has provisioned more
+    }
+    if (counts_host) { counts_host[0] = (int64_t)part[0]; counts_host[1] = (int64_t)nv; }
   }
   if (counts_host) __threadfence_system();
 }
@@ -1171,7 +1188,8 @@ extern "C" int bds_isect_prepare(int C, int64_t N, const float *means2d, const i
                            compact, stream, &counts_dev, &btot, &nblocks);
   if (rc != BDS_OK || counts_dev == nullptr) return rc;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, st, btot, nblocks, counts_dev, static_cast<volatile int64_t *>(nullptr));
+  hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, st, btot, nblocks, counts_dev, static_cast<volatile int64_t *>(nullptr),
+                     (int64_t)-1, (int64_t)-1);
   BDS_LAUNCH_CHECK();
   uint64_t total[2] = {0, 0};   // M, visible entries
   if (hipMemcpyAsync(total, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
@@ -1198,7 +1216,8 @@ extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, c
   } else {
     void *mapped = nullptr;   // device view of the caller's page-locked buffer (the same address under unified addressing)
     if (hipHostGetDevicePointer(&mapped, counts_pinned, 0) != hipSuccess) { (void)hipGetLastError(); mapped = nullptr; }
-    hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, st, btot, nblocks, counts_dev, static_cast<volatile int64_t *>(mapped));
+    hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, st, btot, nblocks, counts_dev, static_cast<volatile int64_t *>(mapped),
+                       (int64_t)-1, (int64_t)-1);
     BDS_LAUNCH_CHECK();
     if (mapped == nullptr &&   // not mapped: the copy engine
         hipMemcpyAsync(counts_pinned, counts_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess)
@@ -1208,11 +1227,41 @@ extern "C" int bds_isect_prepare_async(int C, int64_t N, const float *means2d, c
   return BDS_OK;
 }
 
-extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float *means2d, const int32_t *radii,
-                               const float *depths, const float *conics, const float *opacities, int tile_size,
-                               int tile_w, int tile_h, const void *ws,
-                               size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
-                               int32_t *isect_offsets, int32_t *visible_ids, int compact, bds_stream_t stream) {
+// Device-count form of the prepare stage: nothing is read back.  The counts stay in the first words of the workspace --
+// {M, visible, M effective, visible effective, overflow} as uint64 -- where the `_dev` entry points of the later stages read them
+// (bds_isect_counts_offset(which)); `counts_pinned` (optional, page-locked int64[3]: M, visible, overflow) is written by the GPU
+// itself for the host to look at whenever it likes (e.g. one frame later).  Capturable in a hipGraph.
+extern "C" int bds_isect_prepare_dev(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                                     const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                                     int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int64_t M_capacity,
+                                     int64_t n_visible_capacity, int64_t *counts_pinned, int compact, bds_stream_t stream) {
+  BDS_REQUIRE(M_capacity >= 0 && n_visible_capacity >= 0 && (int64_t)C * N > 0);
+  uint64_t *counts_dev = nullptr;
+  const uint32_t *btot = nullptr;
+  int nblocks = 0;
+  int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
+                           compact, stream, &counts_dev, &btot, &nblocks);
+  if (rc != BDS_OK) return rc;
+  void *mapped = nullptr;
+  if (counts_pinned && hipHostGetDevicePointer(&mapped, counts_pinned, 0) != hipSuccess) { (void)hipGetLastError(); return BDS_EINVAL; }
+  hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, as_stream(stream), btot, nblocks, counts_dev,
+                     static_cast<volatile int64_t *>(mapped), M_capacity, n_visible_capacity);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" size_t bds_isect_counts_offset(int which) {
+  // byte offset, inside the prepare workspace, of: 0 = M, 1 = visible entries, 2 = M effective, 3 = visible effective, 4 = overflow
+  return (which >= 0 && which <= kCountOverflow) ? (size_t)which * sizeof(uint64_t) : (size_t)0;
+}
+
+// dev = true: M / n_visible are CAPACITIES (launch sizes, buffer sizes); the actual counts are read on the device from the
+// "effective" slots of the prepare workspace (kCountMEff / kCountVisEff: zero when a count outgrew its capacity)
+static int isect_build_impl(int C, int64_t N, int64_t M, int64_t n_visible, const float *means2d, const int32_t *radii,
+                            const float *depths, const float *conics, const float *opacities, int tile_size,
+                            int tile_w, int tile_h, const void *ws,
+                            size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
+                            int32_t *isect_offsets, int32_t *visible_ids, int compact, bds_stream_t stream, bool dev) {
   BDS_REQUIRE(C >= 1 && N >= 0 && M >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0 && isect_offsets);
   BDS_REQUIRE(!(compact && isect_ids));          // the 64-bit keys need the Gaussian ids
   BDS_REQUIRE(!visible_ids || n_visible >= 0);
@@ -1234,6 +1283,8 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   BDS_REQUIRE(means2d && radii && depths && ws && ws2 && flatten_ids);
   PrepWs P = prep_layout(const_cast<void *>(ws), CN);
   if (ws_bytes < P.bytes) return BDS_EWORKSPACE;
+  const uint64_t *const M_dev = dev ? P.total + kCountMEff : nullptr;
+  const uint64_t *const nvis_dev = dev ? P.total + kCountVisEff : P.total + 1;
   BuildWs B = build_layout(ws2, M);
   if (ws2_bytes < B.bytes) return BDS_EWORKSPACE;
   // number of radix passes over the tile key
@@ -1246,6 +1297,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   // the ranks while the last pass writes out.  Same order: entries are emitted by increasing rank and the passes are stable.
   const int rank_bits = 32 - nbits;
   const bool packed = n_visible >= 0 && rank_bits >= 1 && n_visible <= ((int64_t)1 << rank_bits) && option_get(kOptPacked);
+  if (dev && !packed) return BDS_ECAPACITY;   // the device-count form exists for the packed lists only (every fused-view shape)
   // digits: 8 bits, or -- packed lists whose whole key fits -- ONE pass of 9-10 bits (radix_scatter_keys_wide_kernel)
   const int max_digit = (packed && nbits > 8 && nbits <= kWideBits) ? kWideBits : 8;
   const int npass = (nbits + max_digit - 1) / max_digit;
@@ -1256,7 +1308,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   if (packed) {
     key_shift = rank_bits;
     uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
-    hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N, P.va,
+    hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, nvis_dev, N, P.va,
                        P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
@@ -1269,7 +1321,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
       // a single wide pass over the whole tile key also yields the per-tile offsets (no separate launch)
       offsets_fused = npass == 1 && bits > 8 && !isect_ids;
       int rc = radix_pass_keys(kin, kout, M, rank_bits + bits_per * p, bits, B.temp, st, last ? P.va : nullptr, rank_mask,
-                               last ? fl : nullptr, offsets_fused ? isect_offsets : nullptr, n_tiles_total);
+                               last ? fl : nullptr, offsets_fused ? isect_offsets : nullptr, n_tiles_total, M_dev);
       if (rc != BDS_OK) return rc;
       kin = kout;
     }
@@ -1295,7 +1347,7 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
   }
   // now kin == B.kb (sorted tile keys, or packed words), flatten_ids holds the Gaussian ids
   if (!offsets_fused) {
-    hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
+    hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)cdiv(M + 1, kIsectBlock)), dim3(kIsectBlock), 0, st, M, M_dev, kin, key_shift,
                        n_tiles_total, isect_offsets);
     BDS_LAUNCH_CHECK();
   }
@@ -1305,6 +1357,24 @@ extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, c
     BDS_LAUNCH_CHECK();
   }
   return BDS_OK;
+}
+
+extern "C" int bds_isect_build(int C, int64_t N, int64_t M, int64_t n_visible, const float *means2d, const int32_t *radii,
+                               const float *depths, const float *conics, const float *opacities, int tile_size,
+                               int tile_w, int tile_h, const void *ws,
+                               size_t ws_bytes, void *ws2, size_t ws2_bytes, int64_t *isect_ids, int32_t *flatten_ids,
+                               int32_t *isect_offsets, int32_t *visible_ids, int compact, bds_stream_t stream) {
+  return isect_build_impl(C, N, M, n_visible, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws, ws_bytes, ws2,
+                          ws2_bytes, isect_ids, flatten_ids, isect_offsets, visible_ids, compact, stream, false);
+}
+
+extern "C" int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t n_visible_capacity, const float *means2d,
+                                   const int32_t *radii, const float *depths, const float *conics, const float *opacities,
+                                   int tile_size, int tile_w, int tile_h, const void *ws, size_t ws_bytes, void *ws2,
+                                   size_t ws2_bytes, int32_t *flatten_ids, int32_t *isect_offsets, int compact, bds_stream_t stream) {
+  BDS_REQUIRE(M_capacity > 0 && n_visible_capacity > 0);
+  return isect_build_impl(C, N, M_capacity, n_visible_capacity, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws,
+                          ws_bytes, ws2, ws2_bytes, nullptr, flatten_ids, isect_offsets, nullptr, compact, stream, true);
 }
 
 extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,

@@ -37,24 +37,44 @@ def _empty(shape, dev, dtype=torch.float32):
     return torch.empty(shape, device=dev, dtype=dtype)
 
 
-_SYNC: Dict[torch.device, tuple] = {}
+_SYNC: Dict[torch.device, list] = {}
 
 
 def _host_sync_objects(dev):
-    """(page-locked int64[2], event) used to read the two list counts back without draining the stream.  A small rotating pool:
-    the front of the next view may be in flight while the current one is still being finished (``fused_view_begin``)."""
-    pool = _SYNC.get(dev)
-    if pool is None:
-        pool = _SYNC[dev] = {"next": 0, "items": []}
-        for _ in range(4):
-            counts = torch.zeros(2, dtype=torch.int64).pin_memory()
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))   # materialises the underlying hipEvent_t
-            counts.np = counts.numpy()                  # (reading two host integers through tensor indexing costs ~10 us)
-            pool["items"].append((counts, ev))
-    o = pool["items"][pool["next"]]
-    pool["next"] = (pool["next"] + 1) % len(pool["items"])
-    return o
+    """(page-locked int64[3], event) used to read the two list counts back without draining the stream.  A front OWNS its pair from
+    ``_front_begin`` until ``_front_finish`` has read the counts (``_release_sync_objects``): any number of fronts may be in flight
+    (``fused_view_begin`` for every camera of a rig up front, ``render_classes`` interleaved with pipelined fronts)."""
+    free = _SYNC.setdefault(dev, [])
+    if free:
+        return free.pop()
+    counts = torch.zeros(3, dtype=torch.int64).pin_memory()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))   # materialises the underlying hipEvent_t
+    counts.np = counts.numpy()                  # (reading two host integers through tensor indexing costs ~10 us)
+    return counts, ev
+
+
+def _release_sync_objects(dev, pair) -> None:
+    _SYNC.setdefault(dev, []).append(pair)
+
+
+class ListCapacity:
+    """Capacities of one camera's intersection lists for the DEVICE-COUNT form of the view (include/bds.h "device-count forms"):
+    no host read-back between the tile counting and the list build, every launch sized by these bounds, the actual counts read from
+    device memory -- the form a hipGraph can hold (``graph_view.ViewGraph``).  ``counts`` (page-locked int64[3]: M, visible,
+    overflow) is written by the GPU during the view; the host looks at it after the fact (``observed`` / ``overflowed``)."""
+
+    def __init__(self, m_cap: int, nvis_cap: int):
+        self.m_cap, self.nvis_cap = int(m_cap), int(nvis_cap)
+        self.counts = torch.zeros(3, dtype=torch.int64).pin_memory()
+        self.counts.np = self.counts.numpy()
+
+    def observed(self):
+        """(M, visible) of the last completed visit (the caller has synchronised with it)."""
+        return int(self.counts.np[0]), int(self.counts.np[1])
+
+    def overflowed(self) -> bool:
+        return bool(self.counts.np[2])
 
 
 _LIST_CAPACITY: Dict[tuple, int] = {}   # (N, W, H, culling) -> entries to provision for the intersection lists
@@ -155,18 +175,29 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     opac_c = opac.view(1, N)
     tiles_per_gauss = _empty((1, N), dev, torch.int32)
     ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
-    ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
+    ws = cfg.get("prep_ws")   # a caller-owned prepare workspace (graph_view: the lists and their counts outlive the view)
+    if ws is None:
+        ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
+    assert ws.dtype == torch.uint8 and ws.is_contiguous() and ws.numel() >= ws_bytes and ws.device == dev
     isect_offsets = _empty((1, th, tw), dev, torch.int32)
     cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
-    counts, ev = _host_sync_objects(dev)
-    with L.timed("isect_prepare"):
-        L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
-                                            L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
-                "bds_isect_prepare_async")
+    caps = cfg.get("caps")                 # ListCapacity: the device-count form (no host wait in this view)
+    if caps is not None:
+        counts, ev = caps.counts, None
+        with L.timed("isect_prepare"):
+            L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
+                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
+                                              counts.data_ptr(), 1, st), "bds_isect_prepare_dev")
+    else:
+        counts, ev = _host_sync_objects(dev)
+        with L.timed("isect_prepare"):
+            L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
+                                                L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
+                    "bds_isect_prepare_async")
     # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
     # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
     cam_pos = cfg["cam_pos"].contiguous()
-    if cfg.get("sh_in_pack", SH_IN_PACK) and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0:
+    if caps is None and cfg.get("sh_in_pack", SH_IN_PACK) and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0:
         sh_rgb, colors = None, None        # evaluated by the record pack, for the visible Gaussians only (_composite)
     else:
         sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
@@ -174,13 +205,13 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
             L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
                                         L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
     key = (N, W, H, bool(cull), LT)
-    cap = _LIST_CAPACITY.get(key, 0)
+    cap = _LIST_CAPACITY.get(key, 0) if caps is None else caps.m_cap
     buf, ws2, ws2_bytes = None, None, 0
     if cap:
         buf = _empty((cap,), dev, torch.int32)
         ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap)
         ws2 = _empty((max(ws2_bytes, 16),), dev, torch.uint8)
-    vcap = _VIS_CAPACITY.get(key, 0)
+    vcap = _VIS_CAPACITY.get(key, 0) if caps is None else caps.nvis_cap
     rec_buf = _empty((vcap, L.SPLAT_RECORD_FLOATS), dev) if vcap else None
     off = lib.bds_isect_visible_ids_offset(1, N)
     f = _Front()
@@ -189,7 +220,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
     f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
     f.tiles_per_gauss, f.isect_offsets, f.ws, f.ws_bytes, f.cull = tiles_per_gauss, isect_offsets, ws, ws_bytes, cull
-    f.counts, f.ev, f.key, f.cap, f.vcap = counts, ev, key, cap, vcap
+    f.counts, f.ev, f.key, f.cap, f.vcap, f.caps = counts, ev, key, cap, vcap, caps
     f.buf, f.ws2, f.ws2_bytes, f.rec_buf, f.ids_offset = buf, ws2, ws2_bytes, rec_buf, off
     f.list_tile, f.list_tw, f.list_th = LT, tw, th
     f.W, f.H, f.N = W, H, N
@@ -203,8 +234,11 @@ def _front_finish(f: _Front, before_wait=None) -> _Front:
     dev, N = f.means.device, f.N
     cptr, optr = (L.ptr(f.conics), L.ptr(f.opac.view(1, N))) if f.cull else (None, None)
     f.pre = before_wait() if before_wait is not None else None
+    if f.caps is not None:
+        return _front_finish_dev(f)
     f.ev.synchronize()
     M, n_vis = int(f.counts.np[0]), int(f.counts.np[1])
+    _release_sync_objects(dev, (f.counts, f.ev))
     if f.rec_buf is None or n_vis > f.vcap:
         f.rec_buf = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
     if n_vis + n_vis // 16 > f.vcap:
@@ -226,6 +260,27 @@ def _front_finish(f: _Front, before_wait=None) -> _Front:
         _LIST_CAPACITY[f.key] = M + M // 6 + 4096
     f.buf = f.ws2 = None
     f.M, f.n_vis = M, n_vis
+    f.m_dev = f.nvis_dev = None
+    return f
+
+
+def _front_finish_dev(f: _Front) -> _Front:
+    """Device-count form of the second half: no wait.  The lists are built into buffers of the capacities, every kernel downstream
+    reads the two EFFECTIVE counts from the first words of the prepare workspace (f.m_dev / f.nvis_dev: device addresses)."""
+    lib, st = L.lib(), L.stream()
+    N = f.N
+    cptr, optr = (L.ptr(f.conics), L.ptr(f.opac.view(1, N))) if f.cull else (None, None)
+    M, n_vis = f.caps.m_cap, f.caps.nvis_cap
+    f.flatten = f.buf
+    f.vis_ids = f.ws[f.ids_offset:f.ids_offset + 4 * n_vis].view(torch.int32)
+    with L.timed("isect_build"):
+        L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
+                                        f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
+                                        L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
+    f.buf = f.ws2 = None
+    f.M, f.n_vis = M, n_vis
+    base = f.ws.data_ptr()
+    f.m_dev, f.nvis_dev = base + lib.bds_isect_counts_offset(2), base + lib.bds_isect_counts_offset(3)
     return f
 
 
@@ -233,12 +288,30 @@ def _image_buffers(W: int, H: int, dev):
     return _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((1, H, W), dev, torch.int32)
 
 
-def _composite(f: _Front, opac: Tensor, images=None):
+def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional[Tensor] = None):
     """Splat records of the visible Gaussians with the given opacities [N] + the forward composite (RGB + depth).
-    ``images``: (render, alphas, last_ids) allocated by the caller (before the host wait), else allocated here."""
+    ``images``: (render, alphas, last_ids) allocated by the caller (before the host wait), else allocated here.
+    ``zero_grad_records`` (device-count form): [n_vis capacity + pose slots, 16] gradient records the pack clears on its way."""
     lib, st = L.lib(), L.stream()
     dev = opac.device
     n_vis, M, W, H = f.n_vis, f.M, f.W, f.H
+    if f.m_dev is not None:
+        assert f.colors is not None, "device-count form: SH colours are evaluated by the dense pass (sh_in_pack off)"
+        if f.rec_buf is not None:
+            rec, f.rec_buf = f.rec_buf[:n_vis], None
+        else:
+            rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
+        render, alphas, last_ids = images if images is not None else _image_buffers(W, H, dev)
+        zr = zero_grad_records
+        tail = None if zr is None or zr.shape[0] <= n_vis else zr[n_vis:]
+        with L.timed("rasterize_fwd"):
+            L.check(lib.bds_splat_pack_dev(n_vis, f.nvis_dev, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors),
+                                           L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(zr), L.ptr(tail),
+                                           0 if tail is None else tail.numel(), st), "bds_splat_pack_dev")
+            L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
+                                              L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),
+                    "bds_rasterize_fwd_dev")
+        return rec, render, alphas, last_ids
     if f.rec_buf is not None:      # provisioned before the wait (first composite over this front only)
         rec, f.rec_buf = f.rec_buf[:n_vis], None
     else:
@@ -282,7 +355,14 @@ class _FusedView(torch.autograd.Function):
         scales, opac, radii, means2d, cam_pos, sh_rgb = f.scales, f.opac, f.radii, f.means2d, f.cam_pos, f.sh_rgb
         tiles_per_gauss, isect_offsets, flatten, vis_ids, M = f.tiles_per_gauss, f.isect_offsets, f.flatten, f.vis_ids, f.M
         images, sel, lv, bws_bytes, bws, rgb, depth = f.pre
-        rec, render, alphas, last_ids = _composite(f, opac, images)
+        # device-count form: the gradient records (+ pose-gradient slots) exist from here on; the record pack clears them
+        ctx.dev_counts = None if f.m_dev is None else (f.m_dev, f.nvis_dev)
+        want_pose = bool(ctx.needs_input_grad[7])
+        v_rec_all = None
+        if f.m_dev is not None:
+            v_rec_all = _empty((f.n_vis + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS), dev)
+        ctx.v_rec_all = v_rec_all
+        rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f.list_tile
         del f
@@ -368,15 +448,26 @@ class _FusedView(torch.autograd.Function):
         # compositing: gradient records of the visible Gaussians, in the order of vis_ids (64 bytes each)
         # (+ the camera-pose gradient slots of the projection backward behind them: one zero fill for both)
         want_pose = bool(ctx.needs_input_grad[7])
-        v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev,
-                                dtype=torch.float32)
+        dev_counts = getattr(ctx, "dev_counts", None)   # (M effective, visible effective) device addresses: the device-count form
+        if dev_counts is not None:
+            v_rec_all, ctx.v_rec_all = ctx.v_rec_all, None   # cleared by the forward's record pack
+            assert v_rec_all is not None, "the device-count form runs its backward once"
+            assert v_means2d_ext is None, "device-count form: no gradient into info['means2d'] (its visible-id list has no host length)"
+        else:
+            v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev,
+                                    dtype=torch.float32)
         v_rec = v_rec_all[:max(n_vis, 1)]
         LT = ctx.list_tile
         order = ops.bwd_schedule(1, W, H, LT, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
-            L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
-                                          L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
-                                          L.ptr(order), st), "bds_rasterize_bwd")
+            if dev_counts is not None:
+                L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
+                                                  L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
+                                                  L.ptr(v_rec), 1, L.ptr(order), st), "bds_rasterize_bwd_dev")
+            else:
+                L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
+                                              L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
+                                              L.ptr(order), st), "bds_rasterize_bwd")
         if v_means2d_ext is not None and n_vis:   # a loss term on info["means2d"] itself: add its rows to the records
             v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())
         # dense screen-space gradient + its absolute sum for the densification statistics (zeros for culled Gaussians, as gsplat)
@@ -404,18 +495,30 @@ class _FusedView(torch.autograd.Function):
 
         v_sh = out_like("sh", sh)
         with L.timed("sh_bwd"):
-            L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
-                                             int(bool(getattr(ctx, "sh_by_rank", False))), L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map),
-                                             int(rows == 2), st), "bds_sh_view_bwd_list")
+            if dev_counts is not None:
+                L.check(lib.bds_sh_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos),
+                                                     L.ptr(sh_rgb), 0, L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map), int(rows == 2), st),
+                        "bds_sh_view_bwd_list_dev")
+            else:
+                L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
+                                                 int(bool(getattr(ctx, "sh_by_rank", False))), L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map),
+                                                 int(rows == 2), st), "bds_sh_view_bwd_list")
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
         v_vm_slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS, 4, 4) if want_pose else None   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
-            L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
-                                                  L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
-                                                  L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
-                                                  L.ptr(row_map), int(rows == 2), st), "bds_project_view_bwd_list")
+            if dev_counts is not None:
+                L.check(lib.bds_project_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales),
+                                                          L.ptr(opac), L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec),
+                                                          L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots),
+                                                          L.ptr(g2d[0]), L.ptr(g2d[1]), L.ptr(row_map), int(rows == 2), st),
+                        "bds_project_view_bwd_list_dev")
+            else:
+                L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
+                                                      L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
+                                                      L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
+                                                      L.ptr(row_map), int(rows == 2), st), "bds_project_view_bwd_list")
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]
@@ -432,7 +535,8 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
                grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
-               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None, front=None):
+               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None, front=None,
+               caps: Optional[ListCapacity] = None, prep_ws: Optional[Tensor] = None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
     [n_img,12,L,gy,gx] of which image ``img_idx`` is used (models/modules.py:507-512); the gradient then comes back in the
@@ -453,14 +557,18 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     returns (compact buffers by name, row_map [N] i32); the visible rows are stored at ``row_map[g]`` of those buffers and no
     gradient is returned for the five per-Gaussian parameters (the sink adds the reduced rows to their ``.grad``).
     ``front``: the object ``fused_view_begin`` returned for the same parameters / camera: that half of the forward is already
-    enqueued (software pipelining of the one host wait per view, see there)."""
+    enqueued (software pipelining of the one host wait per view, see there).
+    ``caps`` (``ListCapacity``): the device-count form -- no host wait at all; the lists are built into buffers of these capacities
+    and every kernel takes its counts from device memory (what ``graph_view.ViewGraph`` captures in a hipGraph).  ``info["n_isects"]``
+    / ``["n_visible"]`` are then the CAPACITIES (the lists' tensors have those lengths; entries beyond the counts are undefined);
+    the actual counts arrive in ``caps.counts``."""
     if cam_pos is None:  # camera centre (vanilla.py:385 uses camtoworlds.data[..., :3, 3]); callers with fixed cameras cache it
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
     cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), factors=tuple(int(f) for f in factors),
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena, grad_sink=grad_sink,
                img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows),
-               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front)
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     # in-place grid gradients only when the arena entries ARE the grids' .grad right now (dist.FrameExchange.begin_frame sets that up)
     if grad_arena is not None and int(arena_rows) >= 1 and grad_sink is None:
@@ -590,7 +698,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
     grad_arena, arena_rows = kwargs.pop("grad_arena", None), int(kwargs.pop("arena_rows", 0))
     grad_sink = kwargs.pop("grad_sink", None)
-    list_tile, front = kwargs.pop("list_tile", None), kwargs.pop("front", None)
+    list_tile, front, caps = kwargs.pop("list_tile", None), kwargs.pop("front", None), kwargs.pop("caps", None)
+    prep_ws = kwargs.pop("prep_ws", None)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
     assert not kwargs, f"unknown arguments {sorted(kwargs)}"
@@ -598,7 +707,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sh_degree=int(opts["sh_degree"]), near_plane=float(opts["near_plane"]), far_plane=float(opts["far_plane"]),
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
-               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front)
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None

@@ -1,0 +1,232 @@
+"""A training frame as hipGraphs: every view's forward + loss + backward replayed with ONE launch, no host wait anywhere.
+
+The reference's step has one host read-back per view (the intersection count that sizes gsplat's lists,
+/root/reference/project/models/trainers/base.py:393-408) and ~100 framework launches around it.  ``fused_view`` already folds the
+launches into ~40 libbds kernels behind one host wait; on a slow or busy host that wait and the Python between the launches still
+leave the GPU idle for a quarter of the step.  Here the view runs in its DEVICE-COUNT form (include/bds.h: list capacities from the
+host, actual counts read on the device) inside a captured hipGraph:
+
+    frame = FrameGraph(params, cams, grids, skies, targets, factors)     # calibrates capacities, captures V + 1 graphs
+    for it in range(n_iters):
+        frame.step()            # begin graph (row-wise clear of the previous frame's gradient rows) + one graph per view
+        if not frame.valid():   # optional before an optimizer step: waits for the frame, re-captures with larger lists and
+            continue            # returns False if a list outgrew its capacity (the frame's gradients are then to be discarded)
+        optimizer.step()
+
+Gradients land exactly where the eager frame loop (``bench.py`` / ``dist.FrameExchange`` at world size 1) puts them: every
+``param.grad`` is a slice of ONE flat buffer (``dist.FlatGradients``), a view writes only the rows of the Gaussians it sees, the grids'
+gradients (transform + TV) are added in place, ``sky.grad`` / ``viewmat.grad`` are the graph's static outputs.  Same kernels, same
+order, same numbers as ``harness.train_view`` -- tested equal.
+
+A graph holds device addresses: after anything that re-allocates a parameter (densification) or changes a camera call
+``frame.recapture()``.  Overflow protocol: a view whose list counts outgrow their capacities renders NOTHING (effective counts zero,
+see bds_isect_prepare_dev) and raises the sticky overflow word in its page-locked counts; ``valid()`` / ``check()`` see it after the
+fact, grow the capacities (never shrink) and capture again.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from .dist import ROW_NAMES, FlatGradients
+from .fused_view import LIST_TILE, ListCapacity
+from . import harness as Hn
+
+
+class ViewGraph:
+    """One captured view: forward, L1 + TV loss and backward of camera ``cam`` with image index ``img_idx``."""
+
+    def __init__(self, graph, out, caps: ListCapacity, prep_ws: Tensor, sky: Tensor, viewmat: Tensor):
+        self.graph, self.out, self.caps, self.prep_ws = graph, out, caps, prep_ws
+        self.loss = out["loss"]          # static tensors: rewritten by every replay
+        self.rgb, self.depth, self.opacity = out["rgb"], out["depth"], out["opacity"]
+        self.v_sky, self.v_viewmat = sky.grad, viewmat.grad
+        self.done = torch.cuda.Event()
+
+    def replay(self) -> None:
+        self.graph.replay()
+        self.done.record()
+
+
+class FrameGraph:
+    def __init__(self, params: Dict[str, Tensor], cams: Sequence[Hn.Camera], grids: Sequence[Tensor], skies: Sequence[Tensor],
+                 targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
+                 img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
+                 sh_degree: int = 3, extra_params: Sequence[Tensor] = ()):
+        """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
+        targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
+        headroom x the counts of the calibration visit."""
+        assert sorted(params.keys()) == sorted(ROW_NAMES), "params: means, quats, log_scales, opacity_logits, sh"
+        self.params = {k: params[k] for k in ROW_NAMES}
+        self.cams, self.grids, self.skies, self.targets = list(cams), list(grids), list(skies), list(targets)
+        self.V = len(self.cams)
+        assert len(self.skies) == self.V and len(self.targets) == self.V
+        self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
+        self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
+        self.headroom = float(headroom)
+        self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
+        self.dev = self.params["means"].device
+        L.require_gpu(*self.params.values(), *self.grids)
+        self.N, self.K = self.params["means"].shape[0], self.params["sh"].shape[1]
+        self.names = list(ROW_NAMES) + [f"grid{i}" for i in range(len(self.grids))]
+        self.flat = FlatGradients(list(self.params.values()) + self.grids + list(extra_params), sparse_rows=True)
+        self.arena = self.flat.arena(self.names + [f"extra{i}" for i in range(len(extra_params))])
+        n_row = sum(self.arena[k].numel() for k in ROW_NAMES)
+        self._tail = self.flat.flat[n_row:]
+        self.caps: List[Optional[ListCapacity]] = [None] * self.V
+        self.views: List[Optional[ViewGraph]] = [None] * self.V
+        self.begin_graph = None
+        self.pool = None
+        self.n_captures = 0
+        lib = L.lib()
+        self._ws_bytes = int(lib.bds_isect_prepare_workspace_bytes(1, self.N))
+        self._ids_off = int(lib.bds_isect_visible_ids_offset(1, self.N))
+        self._nvis_off = int(lib.bds_isect_counts_offset(3))
+        # caller-owned prepare workspaces: a view's visible-id list and its counts live here from one frame to the next (the next
+        # frame's begin graph clears exactly those gradient rows).  Zero-initialised: "no rows yet".
+        self.prep_ws = [torch.zeros(max(self._ws_bytes, 16), device=self.dev, dtype=torch.uint8) for _ in range(self.V)]
+        self.calibrate()
+        self.capture()
+
+    # ---- capacities --------------------------------------------------------------------------------------------------------------
+    def calibrate(self) -> None:
+        """One forward visit of every camera through the host-count path: the list capacities are sized from what it needed."""
+        with torch.no_grad():
+            for v, cam in enumerate(self.cams):
+                info = Hn.render_view(self.params, cam, self.grids, self.img_indices[v], self.skies[v], factors=self.factors,
+                                      sh_degree=self.sh_degree, list_tile=self.list_tile)["info"]
+                self._grow(v, int(info["n_isects"]), int(info["n_visible"]))
+
+    def _grow(self, v: int, M: int, n_vis: int) -> None:
+        old = self.caps[v]
+        h = self.headroom if old is None else max(self.headroom, 1.25)   # (a re-provision is a re-capture: make it worth it)
+        m_cap = max(int(M * h) + 4096, old.m_cap if old else 0)
+        nv_cap = max(min(int(n_vis * h) + 1024, self.N), old.nvis_cap if old else 0)   # never shrinks
+        self.caps[v] = ListCapacity(m_cap, max(nv_cap, 1))
+
+    # ---- capture -----------------------------------------------------------------------------------------------------------------
+    def _view_kwargs(self, v: int) -> dict:
+        return dict(factors=self.factors, tv_weight=self.tv_weight, grid_grads=[self.arena[f"grid{i}"] for i in range(len(self.grids))],
+                    grad_arena=self.arena, arena_rows=1 if v == 0 else 2, caps=self.caps[v], prep_ws=self.prep_ws[v],
+                    list_tile=self.list_tile, sh_degree=self.sh_degree)
+
+    def _point_grads_at_flat(self) -> None:
+        for p, view in zip(self.flat.params, self.flat._views):
+            p.grad = view
+        # the flat buffer's own row book-keeping is bypassed (the begin graph clears the rows): make a later flat.zero() dense
+        self.flat._dirty, self.flat._clean = None, False
+
+    def _run_view(self, v: int):
+        return Hn.train_view(self.params, self.cams[v], self.grids, self.img_indices[v], self.skies[v], self.targets[v],
+                             **self._view_kwargs(v))
+
+    def _begin_body(self) -> None:
+        lib, st = L.lib(), L.stream()
+        a = self.arena
+        for v in range(self.V):
+            ws = self.prep_ws[v]
+            ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
+            L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K,
+                                                      L.ptr(a["means"]), L.ptr(a["quats"]), L.ptr(a["log_scales"]),
+                                                      L.ptr(a["opacity_logits"]), L.ptr(a["sh"]), st), "bds_view_grads_clear_list_dev")
+        if self._tail.numel():
+            self._tail.zero_()
+
+    def capture(self) -> None:
+        """(Re-)capture the begin graph and the V view graphs against the current parameter / camera tensors and capacities."""
+        self.views = [None] * self.V
+        self.begin_graph = None
+        self.pool = None
+        torch.cuda.synchronize()
+        self._point_grads_at_flat()
+        for v in range(self.V):
+            self.skies[v].grad = None
+            self.cams[v].viewmat.grad = None
+        # One eager frame in the device-count form on a side stream: lazy one-time work (kernel attributes, allocator growth) happens
+        # here and not inside a capture, and it leaves real lists + counts in the prepare workspaces
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._begin_body()
+            for v in range(self.V):
+                self._run_view(v)
+                self.skies[v].grad = None
+                self.cams[v].viewmat.grad = None
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize()
+        self._check_counts(raise_on_overflow=True)
+        self.pool = torch.cuda.graph_pool_handle()
+        outer, L.GRAPH_MARKS = L.GRAPH_MARKS, {}     # timing marks captured into THESE graphs (when _lib timers are enabled)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                self._begin_body()
+            self.begin_graph = g
+            for v in range(self.V):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool):
+                    out = self._run_view(v)
+                self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat)
+        finally:
+            self.marks, L.GRAPH_MARKS = L.GRAPH_MARKS, outer
+        self.n_captures += 1
+        torch.cuda.synchronize()
+
+    recapture = capture
+
+    # ---- replay ------------------------------------------------------------------------------------------------------------------
+    def begin(self) -> None:
+        self.begin_graph.replay()
+
+    def view(self, v: int) -> ViewGraph:
+        vg = self.views[v]
+        vg.replay()
+        return vg
+
+    def step(self) -> None:
+        """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed."""
+        self.begin_graph.replay()
+        for vg in self.views:
+            vg.replay()
+
+    def mark_samples(self, name: str):
+        """Milliseconds of every timing mark pair ``name`` captured into the view graphs (``_lib.enable_timers`` on during the
+        capture), as recorded by the last replay; synchronise first."""
+        return L.graph_mark_samples(name, getattr(self, "marks", {}))
+
+    # ---- after the fact ----------------------------------------------------------------------------------------------------------
+    def counts(self):
+        """[(M, visible)] per view as last written by the GPU (synchronise first for the current frame's values)."""
+        return [c.observed() for c in self.caps]
+
+    def _check_counts(self, raise_on_overflow: bool = False) -> bool:
+        ok = True
+        for v, c in enumerate(self.caps):
+            M, n_vis = c.observed()
+            if c.overflowed() or M > c.m_cap or n_vis > c.nvis_cap:
+                if raise_on_overflow:
+                    raise L.BdsError(f"view {v}: list counts (M = {M}, visible = {n_vis}) exceed the calibrated capacities "
+                                     f"({c.m_cap}, {c.nvis_cap}) right after calibration")
+                ok = False
+                self._grow(v, M, n_vis)
+        return ok
+
+    def valid(self) -> bool:
+        """Wait for the frame in flight; True if every view's lists fitted.  Otherwise the capacities are grown, the graphs captured
+        again and False is returned: the frame's gradients are incomplete (the overflowing view rendered nothing) -- repeat it."""
+        for vg in self.views:
+            vg.done.synchronize()
+        if self._check_counts():
+            # keep ahead of a growing scene: re-provision when a count comes within 8 % of its capacity
+            grow = [v for v, c in enumerate(self.caps) if c.observed()[0] > 0.92 * c.m_cap or (c.observed()[1] > 0.92 * c.nvis_cap and c.nvis_cap < self.N)]
+            if grow:
+                for v in grow:
+                    self._grow(v, *self.caps[v].observed())
+                self.capture()
+            return True
+        self.capture()
+        return False

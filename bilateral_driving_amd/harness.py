@@ -90,14 +90,15 @@ def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> L
 def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
                 factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                 radius_clip: float = 0.0, eps2d: float = 0.3, grad_arena=None, arena_rows: int = 0, grad_sink=None, list_tile=None,
-                front=None):
+                front=None, caps=None, prep_ws=None):
     """One view's forward (dict(rgb, depth, opacity, rgb_gaussians, info)): a single fused autograd node
     (fused_view.py) by default, or the chain of individual operators (render_view_staged) when FUSED is off."""
     if not FUSED:
         return render_view_staged(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
     return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL,
-                      grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink, list_tile=list_tile, front=front)
+                      grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink, list_tile=list_tile, front=front,
+                      caps=caps, prep_ws=prep_ws)
 
 
 def render_view_begin(params: Dict[str, Tensor], cam: Camera, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,

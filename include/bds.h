@@ -48,6 +48,15 @@ const char *bds_strerror(int code);
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 
+/* Timing marks (measurement plumbing, no reference counterpart): HIP events that are recorded as event-record NODES when the
+ * stream is being captured into a hipGraph, so that every replay re-records them and a kernel inside a captured view can be
+ * bracketed (bench.py's roofline kernel).  bds_timer_elapsed_ms waits for `stop`; negative = not available. */
+void *bds_timer_create(void);
+int bds_timer_destroy(void *timer);
+int bds_timer_mark(void *timer, bds_stream_t stream);
+float bds_timer_elapsed_ms(void *start, void *stop);
+int bds_last_hip_error(void);   /* HIP error code of the last failed runtime call of the timing-mark entry points (diagnostics) */
+
 /* ---- spherical harmonics ----------------------------------------------------------------
  * gsplat.cuda._wrapper.spherical_harmonics(degrees_to_use, dirs, coeffs, masks=None)
  * imported at models/gaussians/basics.py:15, called at models/gaussians/vanilla.py:388
@@ -315,6 +324,54 @@ int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int K, float *
 int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const float *s_means, const float *s_quats,
                             const float *s_log_scales, const float *s_logits, const float *s_sh, float *v_means, float *v_quats,
                             float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
+
+/* ---- device-count forms: one view without a host read-back (capturable in a hipGraph) -----------------------------------------
+ * gsplat's rasterization() reads the intersection count back to size its lists (one host wait per view at
+ * models/trainers/base.py:393-408).  These forms take CAPACITIES from the host (what the previous visit of the camera needed, plus
+ * head-room) and the actual counts from device memory: the first words of the prepare workspace hold, as uint64,
+ * {M, visible entries, M effective, visible effective, overflow} (byte offsets: bds_isect_counts_offset(0..4)).  The effective
+ * counts are what every later stage sizes itself by; both are ZERO when a count outgrew its capacity -- the view then renders
+ * nothing instead of overrunning a buffer, and the host, which looks at `counts_pinned` (page-locked int64[3] = M, visible,
+ * overflow; written by the GPU; may be NULL) whenever it likes, provisions more and repeats the view.  Launches are sized by the
+ * capacities; surplus workgroups see no elements.  Packed lists only (n_visible_capacity <= 2^(32 - bits(C*tiles))), else
+ * BDS_ECAPACITY.  Lists, offsets and images are bit-identical to the host-count forms. */
+size_t bds_isect_counts_offset(int which);
+int bds_isect_prepare_dev(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                          const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws,
+                          size_t ws_bytes, int64_t M_capacity, int64_t n_visible_capacity, int64_t *counts_pinned, int compact,
+                          bds_stream_t stream);
+/* ws2: bds_isect_build_workspace_bytes(C, N, M_capacity); flatten_ids [M_capacity] */
+int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t n_visible_capacity, const float *means2d, const int32_t *radii,
+                        const float *depths, const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                        const void *ws, size_t ws_bytes, void *ws2, size_t ws2_bytes, int32_t *flatten_ids, int32_t *isect_offsets,
+                        int compact, bds_stream_t stream);
+/* bds_splat_pack with the record count on the device (n_dev -> visible effective).  Optionally clears, on the way, the gradient
+ * record of every packed row (zero_records [n_capacity, BDS_GRAD_RECORD_FLOATS]: what bds_rasterize_bwd accumulates into) and a
+ * tail of zero_tail_floats (multiple of 4) floats (the camera-pose gradient slots): no fill launches of their own. */
+int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d, const float *conics,
+                       const float *colors, const float *opacities, const int32_t *radii, float *records, float *zero_records,
+                       float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream);
+/* bds_rasterize_fwd / _bwd with the list length on the device (M_dev -> M effective) */
+int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
+                          const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                          const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, int32_t *last_ids,
+                          bds_stream_t stream);
+int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
+                          const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
+                          const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
+                          const float *v_render, const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order,
+                          bds_stream_t stream);
+/* the list-driven backward kernels and the row-wise clear with the list length on the device (n_dev -> visible effective) */
+int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int degrees_to_use,
+                             const float *means, const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank,
+                             const float *v_records, float *v_coeffs, const int32_t *row_map, int accumulate, bds_stream_t stream);
+int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, const float *means,
+                                  const float *quats, const float *scales, const float *opacities, const float *viewmat,
+                                  const float *K, int W, int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
+                                  float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d, float *absgrad2d,
+                                  const int32_t *row_map, int accumulate, bds_stream_t stream);
+int bds_view_grads_clear_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means,
+                                  float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
 
 /* RGB+ED form of the fused image transform: the input is the compositor's 4-channel render [H*W,4] (RGB +
  * accumulated depth, gsplat render_mode "RGB+ED") and its alpha.  Forward additionally writes the expected depth

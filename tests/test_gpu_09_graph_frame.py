@@ -1,0 +1,159 @@
+"""-m gpu: the device-count form of the view (no host read-back: list capacities from the host, counts on the device) and its
+hipGraph replay (graph_view.FrameGraph) against the host-count frame loop that tests/test_gpu_03_harness.py ties to the oracle.
+Same kernels, same order: lists bit-equal, images bit-equal, gradients equal up to the atomics' order."""
+import pytest
+import torch
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from bilateral_driving_amd import _lib
+    _lib.lib()  # fails loudly if libbds.so is missing
+    from bilateral_driving_amd import fused_view as FV
+    from bilateral_driving_amd import graph_view as GV
+    from bilateral_driving_amd import harness as Hn
+    return FV, GV, Hn
+
+
+def _scene(Hn, N, W, H, yaws, seed, dev="cuda"):
+    cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev)
+    for c in cams:
+        c.viewmat.requires_grad_(True)
+    p = Hn.synthetic_scene(N, seed=seed, device=dev)
+    p["means"] = p["means"] * torch.tensor([0.4, 0.4, 1.0], device=dev)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), device=dev)]
+    gen = torch.Generator().manual_seed(11 + seed)
+    skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
+    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    return cams, p, grids, skies, targets
+
+
+def _eager_frame(Hn, cams, p, grids, skies, targets):
+    """The host-count frame loop (what bench.py ran before the graphs): dense per-parameter gradients summed by autograd."""
+    for t in list(p.values()) + grids + skies + [c.viewmat for c in cams]:
+        t.grad = None
+    outs = []
+    for v, cam in enumerate(cams):
+        out = Hn.render_view(p, cam, grids, v, skies[v])
+        loss = Hn.training_loss(out, targets[v], grids)
+        loss.backward()
+        outs.append((out["rgb"].detach().clone(), out["depth"].detach().clone(), float(loss), out["info"]["n_isects"], out["info"]["n_visible"]))
+    grads = {k: t.grad.clone() for k, t in p.items()}
+    grads.update({f"grid{i}": g.grad.clone() for i, g in enumerate(grids)})
+    return outs, grads, [s.grad.clone() for s in skies], [c.viewmat.grad.clone() for c in cams]
+
+
+def test_device_count_view_equals_host_count_view(mods):
+    """fused_view(caps=...) == fused_view(): images bit-equal, lists equal over the counted range, gradients to atomics noise."""
+    FV, GV, Hn = mods
+    W, H, N = 320, 192, 5000
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0,), 1)
+    cam = cams[0]
+    ref = Hn.render_view(p, cam, grids, 0, skies[0])
+    M, nv = ref["info"]["n_isects"], ref["info"]["n_visible"]
+    assert M > 0 and nv > 0
+    Hn.training_loss(ref, targets[0], grids).backward()
+    g_ref = {k: t.grad.clone() for k, t in p.items()}
+    vm_ref, sky_ref = cam.viewmat.grad.clone(), skies[0].grad.clone()
+    absg_ref = ref["info"]["means2d"].absgrad.clone()
+    for t in list(p.values()) + grids + skies + [cam.viewmat]:
+        t.grad = None
+    caps = FV.ListCapacity(int(M * 1.5) + 100, int(nv * 1.5) + 100)
+    out = Hn.render_view(p, cam, grids, 0, skies[0], caps=caps)
+    Hn.training_loss(out, targets[0], grids).backward()
+    torch.cuda.synchronize()
+    assert caps.observed() == (M, nv) and not caps.overflowed()
+    assert torch.equal(out["rgb"], ref["rgb"]) and torch.equal(out["depth"], ref["depth"]) and torch.equal(out["opacity"], ref["opacity"])
+    assert torch.equal(out["info"]["flatten_ranks"][:M], ref["info"]["flatten_ranks"])
+    assert torch.equal(out["info"]["visible_ids"][:nv], ref["info"]["visible_ids"])
+    assert torch.equal(out["info"]["isect_offsets"], ref["info"]["isect_offsets"])
+    for k, t in p.items():
+        assert rel_err(t.grad, g_ref[k]) < 2e-5, k
+    assert rel_err(cam.viewmat.grad, vm_ref) < 1e-4 and rel_err(skies[0].grad, sky_ref) < 1e-6
+    assert rel_err(out["info"]["means2d"].absgrad, absg_ref) < 2e-5
+
+
+def test_device_count_overflow_renders_nothing_and_is_flagged(mods):
+    """A list that outgrows its capacity: effective counts zero (empty image, zero gradients, nothing out of bounds), overflow word set."""
+    FV, GV, Hn = mods
+    W, H, N = 256, 160, 4000
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0,), 2)
+    cam = cams[0]
+    ref = Hn.render_view(p, cam, grids, 0, skies[0])
+    M, nv = ref["info"]["n_isects"], ref["info"]["n_visible"]
+    for m_cap, nv_cap in ((max(M // 2, 1), nv + 10), (M + 10, max(nv // 2, 1))):
+        caps = FV.ListCapacity(m_cap, nv_cap)
+        for t in list(p.values()) + grids:
+            t.grad = None
+        out = Hn.render_view(p, cam, grids, 0, skies[0], caps=caps)
+        Hn.training_loss(out, targets[0], grids).backward()
+        torch.cuda.synchronize()
+        assert caps.overflowed() and caps.observed() == (M, nv)
+        assert float(out["opacity"].abs().max()) == 0.0
+        for k, t in p.items():
+            assert t.grad is None or float(t.grad.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("n_views", [1, 3])
+def test_frame_graph_equals_eager_frame(mods, n_views):
+    """FrameGraph.step() (begin graph + one hipGraph per view) == the eager host-count frame, over several replays, and the flat
+    gradient buffer holds exactly one frame's gradients each time (row-wise clear by the begin graph)."""
+    FV, GV, Hn = mods
+    W, H, N = 320, 192, 6000
+    yaws = (0.0, 120.0, 240.0)[:n_views]
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, yaws, 3)
+    outs, g_ref, sky_ref, vm_ref = _eager_frame(Hn, cams, p, grids, skies, targets)
+    frame = GV.FrameGraph(p, cams, grids, skies, targets)
+    for rep in range(3):
+        frame.step()
+        assert frame.valid()
+        for v, vg in enumerate(frame.views):
+            assert torch.equal(vg.rgb, outs[v][0]) and torch.equal(vg.depth, outs[v][1]), (rep, v)
+            assert abs(float(vg.loss) - outs[v][2]) < 1e-6 * max(1.0, abs(outs[v][2]))
+            assert frame.counts()[v] == (outs[v][3], outs[v][4])
+            assert rel_err(vg.v_sky, sky_ref[v]) < 1e-6 and rel_err(vg.v_viewmat, vm_ref[v]) < 1e-4
+        for k, t in p.items():
+            assert t.grad.data_ptr() == frame.arena[k].data_ptr()
+            assert rel_err(t.grad, g_ref[k]) < 3e-5, (rep, k)
+        for i, g in enumerate(grids):
+            assert rel_err(g.grad, g_ref[f"grid{i}"]) < 3e-5, (rep, i)
+
+
+def test_frame_graph_follows_parameter_updates_and_grows_on_overflow(mods):
+    """The graphs read the parameters in place: after an in-place update the replay equals a fresh eager frame; when the update makes
+    a list outgrow its capacity, valid() returns False, re-captures, and the repeated frame is right."""
+    FV, GV, Hn = mods
+    W, H, N = 256, 160, 5000
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0, 180.0), 4)
+    frame = GV.FrameGraph(p, cams, grids, skies, targets)
+    frame.step()
+    assert frame.valid()
+    # tight capacities (what a scene that grew since the calibration looks like), captured again
+    for v, (M, nv) in enumerate(frame.counts()):
+        frame.caps[v] = FV.ListCapacity(M + 16, nv + 16)
+    frame.capture()
+    frame.step()
+    for vg in frame.views:
+        vg.done.synchronize()
+    assert frame._check_counts()
+    with torch.no_grad():
+        p["log_scales"].add_(0.7)      # every splat 2x larger: more (tile, Gaussian) pairs than the lists hold
+        p["opacity_logits"].add_(0.5)
+    n_cap = frame.n_captures
+    frame.step()
+    assert not frame.valid() and frame.n_captures == n_cap + 1
+    frame.step()
+    assert frame.valid()
+    got = {k: t.grad.clone() for k, t in p.items()}
+    rgb = [vg.rgb.clone() for vg in frame.views]
+    outs, g_ref, _, _ = _eager_frame(Hn, cams, p, grids, skies, targets)
+    for v in range(len(cams)):
+        assert torch.equal(rgb[v], outs[v][0])
+    for k in got:
+        assert rel_err(got[k], g_ref[k]) < 3e-5, k
