@@ -79,6 +79,7 @@ _SIGS = {
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
+    "bds_bilagrid_ms_uses_strips": (_i, [_i, C.POINTER(BdsLevel), _i, _i]),
     "bds_bilagrid_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, C.POINTER(C.c_void_p), _f]),
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_ed_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
@@ -155,6 +156,8 @@ def lib():
 
 
 SPLAT_RECORD_FLOATS, GRAD_RECORD_FLOATS, POSE_GRAD_SLOTS = 12, 16, 64
+OPT_DEBUG, OPT_STRIP_ROWS = 3, 5      # 3: ablation mask (bit 16: general bilateral kernels instead of the column strips); 5: rows per band
+OPT_STRIPS = 7                         # bilateral column-strip kernels: 1 = forward, 2 = backward (opt-in, see csrc/bilagrid.hip)
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
 

@@ -671,6 +671,409 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
   }
 }
 
+// =====================================================================================================================
+// Column-strip form of the full-resolution kernels (levels whose factor is a power of two that divides the image size)
+// =====================================================================================================================
+// The kernels above touch every full-resolution pixel three times in the backward (P / Q and the x pass, the y pass through the
+// [H, Wd, 12] scratch, the guidance epilogue) and gather 12 float4 of the low-res maps per pixel and level; they are bound by those
+// gathers and by the scratch traffic (1.0 GB moved for 0.24 GB of algorithmic bytes at 1080p).  Here ONE wave64 owns a strip of
+// 64 pixel columns (lane = column) and marches down a band of rows with the state a pixel column needs in REGISTERS:
+//   * colA[level][2][12]: the two low-res map rows the current pixel row interpolates between, already interpolated in x for this
+//     lane's column (the x taps of a column never change).  A pixel's 3x4 matrix is ONE lerp of the two with the row's
+//     wave-uniform y weight; a new map row is fetched every `factor` rows (6 float4 per lane).
+//   * colAcc[level][2][12] (backward): d(loss)/d(map) accumulated down the column for the same two map rows (the y pass of the
+//     up-sampler's adjoint, in registers).  When the march leaves a map row, its 64 column sums are reduced in x through a small
+//     wave-private LDS transpose, and the row's cells -- one lane each -- run the slice backward at once: grid gradient into the
+//     workgroup's LDS accumulator, guidance gradient into a ring of the last few rows' colour gradients (also wave-private LDS),
+//     from which a row leaves through the clamp / sky / expected-depth backward F + 1 rows after it was visited.
+// No [H*W,3] P / Q arrays, no [H,Wd,12] scratch, no low-res guidance map, no image-sized atomics, one pass over the image.
+// A strip carries F/2 halo columns and a band F/2 halo rows either side (F = largest factor): a map cell's whole support
+// (2 factor pixels per axis) then lies inside the strip that owns it.  Workgroup = 4 independent waves (adjacent strips of a band)
+// sharing a cell-major copy of the grids and ONE grid-gradient accumulator in LDS, flushed with one atomic per touched entry.
+constexpr int kStripWaves = kBgBlock / kWave;
+constexpr int kStripMaxGridFloats = 6144;   // all levels' grids together: copy + accumulator = 48 KB of the workgroup's LDS
+
+struct StripGeom {
+  int F, own, nstrips, groups, RH, nbands, RD;   // RD: rows of the colour-gradient ring (F + 2)
+  int goff[BDS_MAX_LEVELS];                      // float offset of a level's grid inside the LDS copy / accumulator
+  int gfloats;
+  int dbg;                                       // profiling only (bds_set_option(3, mask)): 32 = no grid scatter, 64 = no guidance route,
+                                                 // 128 = no x reduction, 256 = no completed-row work at all
+};
+
+// Hand-over of wave-private LDS data between the lanes of ONE wave: the wave's LDS operations complete in order, so waiting for
+// its own (lgkmcnt = 0) is enough -- and, unlike a workgroup-scope fence, leaves the row's prefetched global loads in flight
+// (a fence waits for vmcnt = 0 too: one full memory latency per pixel row).
+__device__ __forceinline__ void wave_lds_sync() {
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // vmcnt = 63, expcnt = 7, lgkmcnt = 0
+  __builtin_amdgcn_wave_barrier();
+  __asm__ volatile("" ::: "memory");
+}
+
+// x-interpolated map row `cy` of level L for the lane's column (taps tx): the first half of upsample_affine
+__device__ __forceinline__ void strip_load_col(const LevelDev &L, int cy, const Tap &tx, float *dst) {
+  const float4 *s0 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)cy * L.Wd + tx.i0) * 12);
+  const float4 *s1 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)cy * L.Wd + tx.i1) * 12);
+  const float wx = tx.w1;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float4 a = s0[q], b = s1[q];
+    dst[q * 4 + 0] = a.x * (1.f - wx) + b.x * wx;
+    dst[q * 4 + 1] = a.y * (1.f - wx) + b.y * wx;
+    dst[q * 4 + 2] = a.z * (1.f - wx) + b.z * wx;
+    dst[q * 4 + 3] = a.w * (1.f - wx) + b.w * wx;
+  }
+}
+
+template <int NL>
+__global__ __launch_bounds__(kBgBlock) void ms_strip_fwd_kernel(MsParams p, StripGeom g, float *__restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int band = item / g.groups, strip = (item - band * g.groups) * kStripWaves + wave;
+  if (strip >= g.nstrips) return;
+  const int x = strip * kWave + lane;
+  const bool xin = x < p.W;
+  const int xc = xin ? x : p.W - 1;
+  const int Y0 = band * g.RH, Y1 = min(p.H, Y0 + g.RH);
+  Tap tx[NL];
+  float colA[NL][2][12];
+  int cur0[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l < p.nlevels) {
+      const LevelDev &L = p.lv[l];
+      tx[l] = resample_tap_s(xc, p.W, L.Wd, L.up_x);
+      const Tap ty = resample_tap_s(Y0, p.H, L.Hd, L.up_y);
+      cur0[l] = ty.i0;
+      strip_load_col(L, ty.i0, tx[l], colA[l][0]);
+      strip_load_col(L, ty.i1, tx[l], colA[l][1]);
+    }
+  }
+  // the row's inputs are fetched one row ahead
+  float nr = 0.f, ng = 0.f, nb = 0.f, nd = 0.f;
+  auto fetch = [&](int i) {
+    if (xin && i < Y1) {
+      load_input(p, i, x, nr, ng, nb);
+      if (p.depth_out) nd = p.rgb[((int64_t)i * p.W + x) * 4 + 3];
+    }
+  };
+  fetch(Y0);
+  for (int i = Y0; i < Y1; i++) {
+    float r = nr, gg = ng, b = nb;
+    const float dcur = nd;
+    fetch(i + 1);
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (l < p.nlevels) {
+        const LevelDev &L = p.lv[l];
+        const Tap ty = resample_tap_s(i, p.H, L.Hd, L.up_y);
+        if (ty.i0 != cur0[l]) {   // (wave-uniform) the march enters the next map row
+          cur0[l] = ty.i0;
+#pragma unroll
+          for (int k = 0; k < 12; k++) colA[l][0][k] = colA[l][1][k];
+          strip_load_col(L, ty.i1, tx[l], colA[l][1]);
+        }
+        const float wy = ty.w1;
+        float A[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) A[k] = colA[l][0][k] * (1.f - wy) + colA[l][1][k] * wy;
+        apply_affine(A, r, gg, b);
+      }
+    }
+    if (xin) {
+      const int64_t pix = (int64_t)i * p.W + x;
+      out[pix * 3] = r; out[pix * 3 + 1] = gg; out[pix * 3 + 2] = b;
+      if (p.depth_out) p.depth_out[pix] = dcur / fmaxf(p.alpha[pix], 1e-10f);
+    }
+  }
+}
+
+// One completed map row `cy` of level l: x reduction of the 64 column sums, slice backward of the row's owned cells.
+template <int NL>
+__device__ __forceinline__ void strip_complete_row(const MsParams &p, const StripGeom &g, int l, int cy, const float *colsum, int lane,
+                                                   int x0, int xs, float *__restrict__ T, float *__restrict__ ring,
+                                                   const float *__restrict__ cells, float *__restrict__ acc) {
+  const LevelDev &L = p.lv[l];
+  const int f = L.factor;
+  if (g.dbg & 256) return;
+  float4 *t4 = reinterpret_cast<float4 *>(T + lane * 12);
+  t4[0] = make_float4(colsum[0], colsum[1], colsum[2], colsum[3]);
+  t4[1] = make_float4(colsum[4], colsum[5], colsum[6], colsum[7]);
+  t4[2] = make_float4(colsum[8], colsum[9], colsum[10], colsum[11]);
+  wave_lds_sync();
+  const int cx = x0 / f + lane;
+  const bool active = lane < g.own / f && cx < L.Wd;
+  float va[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) va[k] = 0.f;
+  Cell c;
+  Tap tyd, txd;
+  {
+    const int cxc = active ? cx : 0;
+    int xlo, xhi;
+    adjoint_range(cxc, p.W, L.dn_x, xlo, xhi);
+    if (active && !(g.dbg & 128)) {
+#pragma unroll 1   // (rare, wave-uniform code next to ~150 live registers of the march: keep its own footprint small)
+      for (int xx = xlo; xx <= xhi; xx++) {
+        const int k = xx - xs;
+        if (k < 0 || k >= kWave) continue;   // (the conservative window's zero-weight ends)
+        const Tap t = resample_tap_s(xx, p.W, L.Wd, L.up_x);
+        const float w = (t.i0 == cx ? 1.f - t.w1 : 0.f) + (t.i1 == cx ? t.w1 : 0.f);
+        const float4 *s = reinterpret_cast<const float4 *>(T + k * 12);
+        const float4 a = s[0], b = s[1], d = s[2];
+        va[0] += w * a.x; va[1] += w * a.y; va[2] += w * a.z; va[3] += w * a.w;
+        va[4] += w * b.x; va[5] += w * b.y; va[6] += w * b.z; va[7] += w * b.w;
+        va[8] += w * d.x; va[9] += w * d.y; va[10] += w * d.z; va[11] += w * d.w;
+      }
+    }
+    tyd = resample_tap_s(cy, L.Hd, p.H, L.dn_y);
+    txd = resample_tap_s(cxc, L.Wd, p.W, L.dn_x);
+    // down-sampled input colour of the cell (lowres_colour's arithmetic, one tap at a time: see the note on registers above)
+    float rw[2] = {0.f, 0.f}, gw[2] = {0.f, 0.f}, bw[2] = {0.f, 0.f};
+    if (active) {
+#pragma unroll 1
+      for (int t = 0; t < 4; t++) {
+        float r1, g1, b1;
+        load_input(p, (t & 2) ? tyd.i1 : tyd.i0, (t & 1) ? txd.i1 : txd.i0, r1, g1, b1);
+        const float wq = (t & 1) ? txd.w1 : 1.f - txd.w1;
+        const int row = t >> 1;
+        rw[0] = row == 0 ? rw[0] + r1 * wq : rw[0]; rw[1] = row == 1 ? rw[1] + r1 * wq : rw[1];
+        gw[0] = row == 0 ? gw[0] + g1 * wq : gw[0]; gw[1] = row == 1 ? gw[1] + g1 * wq : gw[1];
+        bw[0] = row == 0 ? bw[0] + b1 * wq : bw[0]; bw[1] = row == 1 ? bw[1] + b1 * wq : bw[1];
+      }
+    }
+    const float r = rw[0] * (1.f - tyd.w1) + rw[1] * tyd.w1, gg = gw[0] * (1.f - tyd.w1) + gw[1] * tyd.w1,
+                b = bw[0] * (1.f - tyd.w1) + bw[1] * tyd.w1;
+    c = slice_cell(linspace01_s(cxc, L.Wd, L.lin_x), linspace01_s(cy, L.Hd, L.lin_y), rgb2gray(r, gg, b), L.gx, L.gy, L.gl);
+  }
+  if (L.v_grid && !(g.dbg & 32)) slice_grid_scatter(acc + g.goff[l], c, L.gx, L.gy, L.gl, 1.f, va, active);
+  if (active && c.z_interior && !(g.dbg & 64)) {
+    // sum_ch va[ch] * d(slice)/d(iz)[ch] (slice_dz_cells, four channels at a time)
+    float v_iz = 0.f;
+    {
+      const float4 *cl = reinterpret_cast<const float4 *>(cells + g.goff[l]);
+      const int plane = L.gy * L.gx;
+      const int o00 = c.y0 * L.gx + c.x0, o01 = c.y0 * L.gx + c.x1, o10 = c.y1 * L.gx + c.x0, o11 = c.y1 * L.gx + c.x1;
+      const float w00 = (1.f - c.fy) * (1.f - c.fx), w01 = (1.f - c.fy) * c.fx, w10 = c.fy * (1.f - c.fx), w11 = c.fy * c.fx;
+      const float4 *g0 = cl + (int64_t)c.z0 * plane * 3, *g1 = cl + (int64_t)c.z1 * plane * 3;
+#pragma unroll 1
+      for (int q = 0; q < 3; q++) {
+        const float4 a00 = g0[o00 * 3 + q], a01 = g0[o01 * 3 + q], a10 = g0[o10 * 3 + q], a11 = g0[o11 * 3 + q];
+        const float4 b00 = g1[o00 * 3 + q], b01 = g1[o01 * 3 + q], b10 = g1[o10 * 3 + q], b11 = g1[o11 * 3 + q];
+        const float dx = (b00.x * w00 + b01.x * w01 + b10.x * w10 + b11.x * w11) - (a00.x * w00 + a01.x * w01 + a10.x * w10 + a11.x * w11);
+        const float dy = (b00.y * w00 + b01.y * w01 + b10.y * w10 + b11.y * w11) - (a00.y * w00 + a01.y * w01 + a10.y * w10 + a11.y * w11);
+        const float dzz = (b00.z * w00 + b01.z * w01 + b10.z * w10 + b11.z * w11) - (a00.z * w00 + a01.z * w01 + a10.z * w10 + a11.z * w11);
+        const float dw = (b00.w * w00 + b01.w * w01 + b10.w * w10 + b11.w * w11) - (a00.w * w00 + a01.w * w01 + a10.w * w10 + a11.w * w11);
+        // (va[q * 4 + k] with q a run-time index would go through scratch: select)
+        const float e0 = q == 0 ? va[0] : (q == 1 ? va[4] : va[8]), e1 = q == 0 ? va[1] : (q == 1 ? va[5] : va[9]);
+        const float e2 = q == 0 ? va[2] : (q == 1 ? va[6] : va[10]), e3 = q == 0 ? va[3] : (q == 1 ? va[7] : va[11]);
+        v_iz += e0 * dx + e1 * dy + e2 * dzz + e3 * dw;
+      }
+    }
+    const float vg = v_iz * (float)(L.gl - 1);
+    // adjoint of the bilinear down-sampler: the cell's gray gradient goes to the (up to) 2 x 2 pixels it was formed from, which
+    // still sit in the ring (blocks of different cells are disjoint: plain read-modify-write)
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+      for (int bq = 0; bq < 2; bq++) {
+        const float w = (a ? tyd.w1 : 1.f - tyd.w1) * (bq ? txd.w1 : 1.f - txd.w1);
+        if (w == 0.f) continue;
+        const int row = a ? tyd.i1 : tyd.i0, col = bq ? txd.i1 : txd.i0;
+        float *dst = ring + ((row % g.RD) * kWave + (col - xs)) * 3;
+        const float t = vg * w;
+        dst[0] += t * kGrayR; dst[1] += t * kGrayG; dst[2] += t * kGrayB;
+      }
+    }
+  }
+  wave_lds_sync();
+}
+
+template <int NL>
+__global__ __launch_bounds__(kBgBlock, 2) void ms_strip_bwd_kernel(MsParams p, StripGeom g, const float *__restrict__ v_out,
+                                                                  float *__restrict__ v_in, float *__restrict__ v_alpha,
+                                                                  float *__restrict__ v_sky) {
+  extern __shared__ __attribute__((aligned(16))) float lds_strip[];
+  float *cells = lds_strip, *acc = lds_strip + g.gfloats;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  const int wave_floats = kWave * 12 + g.RD * kWave * 3;
+  float *T = lds_strip + 2 * g.gfloats + wave * wave_floats;
+  float *ring = T + kWave * 12;
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l < p.nlevels) {
+      const LevelDev &L = p.lv[l];
+      const int vol = L.gl * L.gy * L.gx;
+      for (int e = threadIdx.x; e < 12 * vol; e += kBgBlock) {
+        const int ch = e / vol, cell = e - ch * vol;
+        cells[g.goff[l] + cell * 12 + ch] = L.grid[e];
+        acc[g.goff[l] + e] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int band = item / g.groups, strip = (item - band * g.groups) * kStripWaves + wave;
+  if (strip < g.nstrips) {
+    const int F = g.F, x0 = strip * g.own, xs = x0 - F / 2, x = xs + lane;
+    const bool xin = x >= 0 && x < p.W;
+    const bool xown = xin && x >= x0 && x < x0 + g.own;
+    const int xc = min(max(x, 0), p.W - 1);
+    const int Y0 = band * g.RH, Y1 = min(p.H, Y0 + g.RH);
+    const int ya = max(0, Y0 - F / 2), yb = min(p.H, Y1 + F / 2);
+    const int cs = p.cs;
+    float colA[NL][2][12], colAcc[NL][2][12];
+    int cur0[NL], cur1[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (l < p.nlevels) {
+        const LevelDev &L = p.lv[l];
+        const Tap tx = resample_tap_s(xc, p.W, L.Wd, L.up_x);   // (formed again at every new map row: rare, and 3 registers per level)
+        const Tap ty = resample_tap_s(ya, p.H, L.Hd, L.up_y);
+        cur0[l] = ty.i0; cur1[l] = ty.i1;
+        strip_load_col(L, ty.i0, tx, colA[l][0]);
+        strip_load_col(L, ty.i1, tx, colA[l][1]);
+#pragma unroll
+        for (int k = 0; k < 12; k++) { colAcc[l][0][k] = 0.f; colAcc[l][1][k] = 0.f; }
+      }
+    }
+    // clamp / sky / expected-depth backward of an owned row whose colour gradient is final (ms_guidance_blend_bwd_kernel's tail)
+    auto epilogue = [&](int j) {
+      if (!xown) return;
+      const int64_t pix = (int64_t)j * p.W + x;
+      const float *src = ring + ((j % g.RD) * kWave + lane) * 3;
+      float v[3] = {src[0], src[1], src[2]};
+      float va = 0.f;
+      if (p.sky) {
+        const float k = 1.f - p.alpha[pix];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          va -= v[c] * p.sky[pix * 3 + c];
+          if (v_sky) v_sky[pix * 3 + c] = v[c] * k;
+          v[c] = p.rgb[pix * cs + c] <= 1.f ? v[c] : 0.f;
+        }
+      }
+      v_in[pix * cs] = v[0]; v_in[pix * cs + 1] = v[1]; v_in[pix * cs + 2] = v[2];
+      if (cs == 4) {
+        const float a = p.alpha[pix], ac = fmaxf(a, 1e-10f);
+        const float vd = p.v_depth ? p.v_depth[pix] : 0.f;
+        v_in[pix * 4 + 3] = vd / ac;
+        if (p.v_alpha_in) va += p.v_alpha_in[pix];
+        if (a >= 1e-10f) va -= p.rgb[pix * 4 + 3] * vd / (ac * ac);
+        if (v_alpha) v_alpha[pix] = va;
+      } else if (p.sky && v_alpha) {
+        v_alpha[pix] = va;
+      }
+    };
+    // the row's inputs are fetched one row ahead (a wave has one or two neighbours on its SIMD: nothing else hides the latency)
+    float nr = 0.f, ng = 0.f, nb = 0.f, nv0 = 0.f, nv1 = 0.f, nv2 = 0.f;
+    auto fetch = [&](int i) {
+      nr = ng = nb = nv0 = nv1 = nv2 = 0.f;
+      if (xin && i < yb) {
+        load_input(p, i, x, nr, ng, nb);
+        const int64_t pix = (int64_t)i * p.W + x;
+        nv0 = v_out[pix * 3]; nv1 = v_out[pix * 3 + 1]; nv2 = v_out[pix * 3 + 2];
+      }
+    };
+    fetch(ya);
+    for (int i = ya; i < yb; i++) {
+      float wy[NL];
+      // ---- map rows: the march leaves row cur0 when the y tap moves on
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        if (l < p.nlevels) {
+          const LevelDev &L = p.lv[l];
+          const Tap ty = resample_tap_s(i, p.H, L.Hd, L.up_y);
+          wy[l] = ty.w1;
+          if (ty.i0 != cur0[l]) {   // wave-uniform
+            const int done = cur0[l];
+            if (done * L.factor >= Y0 && done * L.factor < Y1)
+              strip_complete_row<NL>(p, g, l, done, colAcc[l][0], lane, x0, xs, T, ring, cells, acc);
+            cur0[l] = ty.i0; cur1[l] = ty.i1;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+              colA[l][0][k] = colA[l][1][k];
+              colAcc[l][0][k] = colAcc[l][1][k];
+              colAcc[l][1][k] = 0.f;
+            }
+            strip_load_col(L, ty.i1, resample_tap_s(xc, p.W, L.Wd, L.up_x), colA[l][1]);
+          }
+        }
+      }
+      // ---- this row's pixel: forward chain, then the way back (the 3x4 of a level is one lerp: formed again on the way back
+      // instead of being kept)
+      float r = nr, gg = ng, b = nb, v0 = nv0, v1 = nv1, v2 = nv2;
+      fetch(i + 1);
+      float P[NL][3];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        if (l < p.nlevels) {
+          float A[12];
+#pragma unroll
+          for (int k = 0; k < 12; k++) A[k] = colA[l][0][k] * (1.f - wy[l]) + colA[l][1][k] * wy[l];
+          P[l][0] = r; P[l][1] = gg; P[l][2] = b;
+          apply_affine(A, r, gg, b);
+        }
+      }
+#pragma unroll
+      for (int l = NL - 1; l >= 0; l--) {
+        if (l < p.nlevels) {
+          const float q[3] = {v0, v1, v2};
+          const float w1 = wy[l], w0 = 1.f - wy[l];
+          float n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) {
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+              const int k = rr * 4 + cc;
+              const float d = cc < 3 ? q[rr] * P[l][cc] : q[rr];
+              colAcc[l][0][k] += w0 * d;
+              colAcc[l][1][k] += w1 * d;
+              if (cc < 3) n[cc] += (colA[l][0][k] * w0 + colA[l][1][k] * w1) * q[rr];
+            }
+          }
+          v0 = n[0]; v1 = n[1]; v2 = n[2];
+        }
+      }
+      if (i >= Y0 && i < Y1) {   // direct-route colour gradient of an owned row waits in the ring for its guidance terms
+        float *dst = ring + ((i % g.RD) * kWave + lane) * 3;
+        dst[0] = v0; dst[1] = v1; dst[2] = v2;
+      }
+      wave_lds_sync();
+      const int j = i - (F + 1);
+      if (j >= Y0) epilogue(j);
+    }
+    // ---- the map rows still open at the end of the band
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (l < p.nlevels) {
+        const LevelDev &L = p.lv[l];
+        if (cur1[l] == cur0[l]) {   // bottom border: both taps on the last map row
+#pragma unroll
+          for (int k = 0; k < 12; k++) colAcc[l][0][k] += colAcc[l][1][k];
+        }
+        if (cur0[l] * L.factor >= Y0 && cur0[l] * L.factor < Y1)
+          strip_complete_row<NL>(p, g, l, cur0[l], colAcc[l][0], lane, x0, xs, T, ring, cells, acc);
+        if (cur1[l] != cur0[l] && cur1[l] * L.factor >= Y0 && cur1[l] * L.factor < Y1)
+          strip_complete_row<NL>(p, g, l, cur1[l], colAcc[l][1], lane, x0, xs, T, ring, cells, acc);
+      }
+    }
+    for (int j = max(Y0, yb - (F + 1)); j < Y1; j++) epilogue(j);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    if (l < p.nlevels && p.lv[l].v_grid) {
+      const int gsz = 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx;
+      for (int e = threadIdx.x; e < gsz; e += kBgBlock) {
+        const float v = acc[g.goff[l] + e];
+        if (v != 0.f) atomicAdd(p.lv[l].v_grid + e, v);
+      }
+    }
+  }
+}
+
 // ---- generic point slice (BilateralGrid.forward on arbitrary points) ------------------------------
 __global__ __launch_bounds__(kBgBlock) void slice_fwd_kernel(int64_t P, const float *__restrict__ grid, int gx, int gy, int gl,
                                                             const float *__restrict__ xy, const float *__restrict__ rgb,
@@ -1052,6 +1455,47 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
   return BDS_OK;
 }
 
+// Column-strip kernels: every level's factor is a power of two (2, 4, 8) that divides the image size, one grid per level, all grids
+// together small enough for the workgroup's LDS.  `rows_per_band` <= 0: default.
+static bool strip_geom(const MsParams &p, bool backward, int rows_per_band, StripGeom &g) {
+  // Opt-in (bds_set_option(7, 1 | 2): 1 = forward, 2 = backward).  Measured on MI355X at 1080p / 3 levels: the forward strips equal the
+  // general kernel; the backward strips are SLOWER than the four general kernels (340 vs 250 us on a noisy image): at two waves per
+  // SIMD (the ~150 registers of per-column state) every row's dependent loads -- inputs of the delayed epilogue, the next map row --
+  // stall the march, and the completed-row work runs at 15-30 active lanes.  Kept for the configurations / follow-up it was sized
+  // for; results equal the general kernels' (tests/test_gpu_16_bilagrid_strips.py).
+  if (!(option_get(kOptStrips) & (backward ? 2 : 1))) return false;
+  if (p.nlevels > 4 || (option_get(kOptDebug) & 16)) return false;
+  int F = 1, gf = 0;
+  for (int l = 0; l < p.nlevels; l++) {
+    const LevelDev &L = p.lv[l];
+    const int f = L.factor;
+    if (!(f == 2 || f == 4 || f == 8) || p.H % f || p.W % f || L.n_avg != 1 || L.Hd < 2 || L.Wd < 2 || L.aff_out) return false;
+    if (f > F) F = f;
+    g.goff[l] = gf;
+    gf += 12 * L.gl * L.gy * L.gx;
+  }
+  if (gf > kStripMaxGridFloats) return false;
+  g.F = F; g.gfloats = gf; g.RD = F + 2;
+  g.dbg = option_get(kOptDebug);
+  g.own = backward ? kWave - F : kWave;
+  g.nstrips = (int)cdiv(p.W, g.own);
+  g.groups = (int)cdiv(g.nstrips, kStripWaves);
+  // rows per band: enough bands to give every SIMD two waves (1024 SIMDs), not so few rows that the halo rows dominate
+  int RH = rows_per_band;
+  if (RH <= 0) {
+    const int want = (2 * 1024 + g.nstrips - 1) / g.nstrips;
+    RH = (p.H + want - 1) / want;
+    if (RH < (backward ? 16 : 8)) RH = backward ? 16 : 8;
+  }
+  RH = (RH + F - 1) / F * F;
+  g.RH = RH;
+  g.nbands = (int)cdiv(p.H, RH);
+  return true;
+}
+static size_t strip_lds_bytes(const StripGeom &g) {
+  return sizeof(float) * ((size_t)2 * g.gfloats + (size_t)kStripWaves * (kWave * 12 + g.RD * kWave * 3));
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -1061,6 +1505,22 @@ extern "C" size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagri
   for (int l = 0; l < nlevels; l++)
     if (levels[l].factor < 1) return 0;
   return ms_layout(nlevels, levels, H, W).bytes;
+}
+
+// 1 when the full-resolution stage of this configuration runs as column strips (see "column-strip form"), else 0
+extern "C" int bds_bilagrid_ms_uses_strips(int nlevels, const bds_bilagrid_level_t *levels, int H, int W) {
+  if (nlevels < 1 || nlevels > BDS_MAX_LEVELS || !levels || H <= 0 || W <= 0) return 0;
+  MsParams p;
+  p.nlevels = nlevels; p.H = H; p.W = W;
+  for (int l = 0; l < nlevels; l++) {
+    if (levels[l].factor < 1) return 0;
+    LevelDev &d = p.lv[l];
+    d.gx = levels[l].gx; d.gy = levels[l].gy; d.gl = levels[l].gl; d.factor = levels[l].factor; d.n_avg = levels[l].n_avg;
+    d.Hd = H / levels[l].factor; d.Wd = W / levels[l].factor;
+    d.aff_out = nullptr;
+  }
+  StripGeom g;
+  return strip_geom(p, true, 0, g) ? 1 : 0;
 }
 
 static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb, int cs,
@@ -1098,7 +1558,16 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       BDS_LAUNCH_CHECK();
     }
   }
-  {
+  StripGeom sg;
+  if (strip_geom(p, false, option_get(kOptStripRows), sg)) {
+    const dim3 grid((unsigned)(sg.nbands * sg.groups)), block(kBgBlock);
+    switch (nlevels) {
+      case 1: hipLaunchKernelGGL((ms_strip_fwd_kernel<1>), grid, block, 0, st, p, sg, rgb_out); break;
+      case 2: hipLaunchKernelGGL((ms_strip_fwd_kernel<2>), grid, block, 0, st, p, sg, rgb_out); break;
+      case 3: hipLaunchKernelGGL((ms_strip_fwd_kernel<3>), grid, block, 0, st, p, sg, rgb_out); break;
+      default: hipLaunchKernelGGL((ms_strip_fwd_kernel<4>), grid, block, 0, st, p, sg, rgb_out); break;
+    }
+  } else {
     const dim3 grid((unsigned)cdiv((int64_t)H * W, kBgBlock)), block(kBgBlock);
     switch (nlevels) {
       case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1>), grid, block, 0, st, p, rgb_out); break;
@@ -1136,6 +1605,29 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   p.cs = cs; p.v_depth = v_depth; p.v_alpha_in = v_alpha_in;
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
+  {
+    StripGeom sg;
+    if (strip_geom(p, true, option_get(kOptStripRows), sg)) {   // one pass over the image (see "column-strip form")
+      const size_t lds = strip_lds_bytes(sg);
+      const dim3 grid((unsigned)(sg.nbands * sg.groups)), block(kBgBlock);
+#define BDS_STRIP_BWD(n)                                                                                                              \
+  do {                                                                                                                                \
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&ms_strip_bwd_kernel<n>),                              \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                 \
+      return BDS_ELAUNCH;                                                                                                             \
+    hipLaunchKernelGGL((ms_strip_bwd_kernel<n>), grid, block, lds, st, p, sg, v_rgb_out, v_rgb, v_alpha, v_sky);                      \
+  } while (0)
+      switch (nlevels) {
+        case 1: BDS_STRIP_BWD(1); break;
+        case 2: BDS_STRIP_BWD(2); break;
+        case 3: BDS_STRIP_BWD(3); break;
+        default: BDS_STRIP_BWD(4); break;
+      }
+#undef BDS_STRIP_BWD
+      BDS_LAUNCH_CHECK();
+      return BDS_OK;
+    }
+  }
   // fused x pass when some level is up-sampled and the widest support fits the workgroup's halo
   float smax = 1.f;
   bool any_up = false;

@@ -44,7 +44,10 @@ const char *bds_strerror(int code);
  *     entries; 0 = the generic histogram / scan / scatter passes that larger inputs take;
  * 6 = tile lists: 1 [default] = packed 32-bit entries (tile << rank_bits | depth rank) whenever the visible count fits the
  *     rank bits; 0 = the (tile key, id) pair lists that larger visible counts take.
- * 3 = profiling only: ablation mask of the bilateral backward.  Other indices are unused. */
+ * 3 = profiling only: ablation mask of the bilateral backward;
+ * 7 = column-strip form of the bilateral transform's full-resolution stage (bds_bilagrid_ms_uses_strips): bit 0 = forward, bit 1 =
+ *     backward; default 0 (measured slower than the general kernels on MI355X, kept opt-in); 5 = its rows per band (0 = default).
+ * Other indices are unused. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
 
@@ -247,6 +250,10 @@ typedef struct {
   int32_t gx, gy, gl, factor, n_avg;
 } bds_bilagrid_level_t;
 
+/* 1 when the full-resolution stage of this configuration runs as column strips -- one wave64 per strip of 64 pixel columns marching
+ * down the image with the up-sampler's state in registers: opted in through bds_set_option(7, ..), every factor 2, 4 or 8 and
+ * dividing H and W, one grid per level, all grids together <= 6144 floats -- else 0 (the general kernels).  Same results either way. */
+int bds_bilagrid_ms_uses_strips(int nlevels, const bds_bilagrid_level_t *levels, int H, int W);
 size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagrid_level_t *levels, int H, int W);
 /* ws keeps the low-resolution affine maps (fwd -> bwd). affine_out (NULL or nlevels x [H,W,12]
  * pointers) receives the full-resolution per-level maps the reference module returns. */
