@@ -82,6 +82,9 @@ def parse():
                     help="N = 1: drive the frame through the eager host-count loop (one host wait per view, ~40 launches from Python) "
                          "instead of replaying the captured hipGraphs of graph_view.FrameGraph (default: same kernels, same order, "
                          "device-side list counts, one launch per view)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="graph replay: one graph per view on one stream instead of forward / backward graphs on two streams (view v + 1's "
+                         "forward next to view v's backward)")
     ap.add_argument("--dense-grads", action="store_true",
                     help="N = 1 only: fresh dense gradient tensors per view (zero fill of all N rows, autograd accumulation) instead of "
                          "the flat gradient buffer whose rows are cleared / written through the visible-id lists")
@@ -273,7 +276,8 @@ def main():
         # the views are captured with the roofline kernel bracketed by timing marks (event-record nodes: re-recorded by every replay)
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
-        frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)))
+        frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
+                           overlap=not args.no_overlap)
         L.enable_timers(False)
 
     def step(s):
@@ -431,8 +435,10 @@ def main():
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
                    "pipelined_fronts": bool(args.pipeline) and not args.direct,
-                   "step_driver": ("hipGraph replay (graph_view.FrameGraph): per view ONE captured graph = forward + L1/TV loss + backward, "
-                                   "device-side list counts, no host wait") if frame is not None else
+                   "step_driver": ("hipGraph replay (graph_view.FrameGraph): per view " +
+                                   ("two captured graphs (forward + L1/TV loss value | backward), the forwards on a second stream next to "
+                                    "the previous view's backward" if not args.no_overlap else "ONE captured graph = forward + L1/TV loss + backward") +
+                                   ", device-side list counts, no host wait") if frame is not None else
                                   ("direct (harness.train_view: same kernels, no autograd graph)" if args.direct else
                                    "autograd (forward, loss, loss.backward())"),
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",

@@ -691,7 +691,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     them: per-Gaussian rows in ``grad_arena`` (``arena_rows``) or in ``param.grad``; the grids' in ``grid_grads`` / ``.grad``;
     ``sky.grad``, ``viewmat.grad`` accumulated.  Accepts the keyword arguments of ``fused_view``; ``after_forward(info)`` is called
     between the forward and the backward pass (``dist.FrameExchange.begin_view`` starts its visibility exchange there).
-    Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
+    ``two_phase=True``: only the forward + loss value are enqueued; the returned dict carries ``backward``, a callable that enqueues
+    the rest (once).  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
     from .losses import _PhotometricTV
     cam_pos = kwargs.pop("cam_pos", None)
     if cam_pos is None:
@@ -699,7 +700,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     grad_arena, arena_rows = kwargs.pop("grad_arena", None), int(kwargs.pop("arena_rows", 0))
     grad_sink = kwargs.pop("grad_sink", None)
     list_tile, front, caps = kwargs.pop("list_tile", None), kwargs.pop("front", None), kwargs.pop("caps", None)
-    prep_ws = kwargs.pop("prep_ws", None)
+    prep_ws, two_phase = kwargs.pop("prep_ws", None), bool(kwargs.pop("two_phase", False))
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
     assert not kwargs, f"unknown arguments {sorted(kwargs)}"
@@ -727,21 +728,30 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                       "n_visible": int(vis_ids.numel())})
         if after_forward is not None:
             after_forward(info)
-        # loss: forward, then its backward with d(loss) = 1
+        # loss: forward (its backward, with d(loss) = 1, opens the second half)
         lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
         gg = None if grid_grads is None else list(grid_grads)
         loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
-        one = _ONES.get(rgb.device)
-        if one is None:
-            one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
-        lg = _PhotometricTV.backward(lctx, one)
-        v_rgb, v_tv_grids = lg[0], lg[4:]
-        grads = _FusedView.backward(ctx, v_rgb, None, None, None, None)
-        for p, g in zip(leaves, grads[1:6]):
-            _accumulate(p, g)
-        _accumulate(sky, grads[6])
-        _accumulate(viewmat, grads[7])
-        for g, a, b in zip(gs, v_tv_grids, grads[8:]):
-            _accumulate(g, a)
-            _accumulate(g, b)
-    return _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
+    out = _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
+
+    def backward():
+        with torch.no_grad():
+            one = _ONES.get(rgb.device)
+            if one is None:
+                one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
+            lg = _PhotometricTV.backward(lctx, one)
+            v_rgb, v_tv_grids = lg[0], lg[4:]
+            grads = _FusedView.backward(ctx, v_rgb, None, None, None, None)
+            for p, g in zip(leaves, grads[1:6]):
+                _accumulate(p, g)
+            _accumulate(sky, grads[6])
+            _accumulate(viewmat, grads[7])
+            for g, a, b in zip(gs, v_tv_grids, grads[8:]):
+                _accumulate(g, a)
+                _accumulate(g, b)
+
+    if two_phase:     # the caller runs the second half itself (graph_view: forward and backward as two hipGraphs on two streams)
+        out["backward"] = backward
+        return out
+    backward()
+    return out

@@ -38,17 +38,22 @@ from . import harness as Hn
 
 
 class ViewGraph:
-    """One captured view: forward, L1 + TV loss and backward of camera ``cam`` with image index ``img_idx``."""
+    """One captured view: forward, L1 + TV loss and backward of camera ``cam`` with image index ``img_idx`` -- ONE graph, or two
+    (``graph`` = forward + loss value, ``graph_bwd`` = the rest) when the frame overlaps a view's forward with the previous view's
+    backward."""
 
-    def __init__(self, graph, out, caps: ListCapacity, prep_ws: Tensor, sky: Tensor, viewmat: Tensor):
-        self.graph, self.out, self.caps, self.prep_ws = graph, out, caps, prep_ws
+    def __init__(self, graph, out, caps: ListCapacity, prep_ws: Tensor, sky: Tensor, viewmat: Tensor, graph_bwd=None):
+        self.graph, self.graph_bwd, self.out, self.caps, self.prep_ws = graph, graph_bwd, out, caps, prep_ws
         self.loss = out["loss"]          # static tensors: rewritten by every replay
         self.rgb, self.depth, self.opacity = out["rgb"], out["depth"], out["opacity"]
         self.v_sky, self.v_viewmat = sky.grad, viewmat.grad
         self.done = torch.cuda.Event()
+        self.fwd_done = torch.cuda.Event()
 
     def replay(self) -> None:
         self.graph.replay()
+        if self.graph_bwd is not None:
+            self.graph_bwd.replay()
         self.done.record()
 
 
@@ -56,10 +61,15 @@ class FrameGraph:
     def __init__(self, params: Dict[str, Tensor], cams: Sequence[Hn.Camera], grids: Sequence[Tensor], skies: Sequence[Tensor],
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
-                 sh_degree: int = 3, extra_params: Sequence[Tensor] = ()):
+                 sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
-        headroom x the counts of the calibration visit."""
+        headroom x the counts of the calibration visit.
+        ``overlap``: every view is captured as TWO graphs (forward + loss value | backward) and ``step()`` replays the forwards on a
+        second stream: view v + 1's forward -- projection, the launch-latency-bound tile stage, SH, the compositor's forward, the
+        gather-bound bilateral forward -- runs next to view v's backward (the VALU-bound compositor backward, the bilateral
+        backward) instead of behind it.  A forward reads only parameters and writes its own buffers; the backwards still run one
+        after the other on the caller's stream (same gradient accumulation order: same numbers)."""
         assert sorted(params.keys()) == sorted(ROW_NAMES), "params: means, quats, log_scales, opacity_logits, sh"
         self.params = {k: params[k] for k in ROW_NAMES}
         self.cams, self.grids, self.skies, self.targets = list(cams), list(grids), list(skies), list(targets)
@@ -68,6 +78,7 @@ class FrameGraph:
         self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         self.headroom = float(headroom)
+        self.overlap = bool(overlap)
         self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
         self.dev = self.params["means"].device
         L.require_gpu(*self.params.values(), *self.grids)
@@ -159,18 +170,39 @@ class FrameGraph:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize()
         self._check_counts(raise_on_overflow=True)
+        # graphs that share a pool are replayed in capture order on ONE stream; the forwards of the overlapped form run on their own
+        # stream and therefore get their own pool (a block one graph frees may be handed to the next graph of the same pool)
         self.pool = torch.cuda.graph_pool_handle()
+        self.pool_fwd = torch.cuda.graph_pool_handle() if self.overlap else self.pool
+        self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        self._frame_ready = torch.cuda.Event()
         outer, L.GRAPH_MARKS = L.GRAPH_MARKS, {}     # timing marks captured into THESE graphs (when _lib timers are enabled)
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool):
                 self._begin_body()
             self.begin_graph = g
-            for v in range(self.V):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool):
-                    out = self._run_view(v)
-                self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat)
+            if self.overlap:
+                # ALL forwards first, then all backwards: a block of the forwards' pool that a backward's capture frees (buffers the
+                # forward prepared for it) could otherwise be handed to the NEXT view's forward, which runs next to that backward
+                fwd = []
+                for v in range(self.V):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.pool_fwd):
+                        out = Hn.train_view(self.params, self.cams[v], self.grids, self.img_indices[v], self.skies[v], self.targets[v],
+                                            two_phase=True, **self._view_kwargs(v))
+                    fwd.append((g, out))
+                for v, (g, out) in enumerate(fwd):
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, pool=self.pool):
+                        out["backward"]()
+                    self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, gb)
+            else:
+                for v in range(self.V):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.pool):
+                        out = self._run_view(v)
+                    self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat)
         finally:
             self.marks, L.GRAPH_MARKS = L.GRAPH_MARKS, outer
         self.n_captures += 1
@@ -183,15 +215,33 @@ class FrameGraph:
         self.begin_graph.replay()
 
     def view(self, v: int) -> ViewGraph:
+        """Replay ONE view (forward, loss, backward) on the current stream; ``begin()`` first when it opens a frame."""
         vg = self.views[v]
         vg.replay()
         return vg
 
     def step(self) -> None:
         """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed."""
+        if not self.overlap:
+            self.begin_graph.replay()
+            for vg in self.views:
+                vg.replay()
+            return
+        main = torch.cuda.current_stream(self.dev)
+        # the forwards start once everything enqueued so far (the previous frame's backwards, an optimizer step) is done and the
+        # begin graph has read the previous frame's visible-id lists, which the forwards overwrite ...
         self.begin_graph.replay()
+        self._frame_ready.record(main)
+        self.side_stream.wait_event(self._frame_ready)
+        with torch.cuda.stream(self.side_stream):
+            for vg in self.views:
+                vg.graph.replay()
+                vg.fwd_done.record(self.side_stream)
+        # ... and run ahead of the backwards, which follow one another on the caller's stream
         for vg in self.views:
-            vg.replay()
+            main.wait_event(vg.fwd_done)
+            vg.graph_bwd.replay()
+            vg.done.record(main)
 
     def mark_samples(self, name: str):
         """Milliseconds of every timing mark pair ``name`` captured into the view graphs (``_lib.enable_timers`` on during the

@@ -100,8 +100,9 @@ def test_device_count_overflow_renders_nothing_and_is_flagged(mods):
             assert t.grad is None or float(t.grad.abs().max()) == 0.0, k
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("n_views", [1, 3])
-def test_frame_graph_equals_eager_frame(mods, n_views):
+def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
     """FrameGraph.step() (begin graph + one hipGraph per view) == the eager host-count frame, over several replays, and the flat
     gradient buffer holds exactly one frame's gradients each time (row-wise clear by the begin graph)."""
     FV, GV, Hn = mods
@@ -109,7 +110,7 @@ def test_frame_graph_equals_eager_frame(mods, n_views):
     yaws = (0.0, 120.0, 240.0)[:n_views]
     cams, p, grids, skies, targets = _scene(Hn, N, W, H, yaws, 3)
     outs, g_ref, sky_ref, vm_ref = _eager_frame(Hn, cams, p, grids, skies, targets)
-    frame = GV.FrameGraph(p, cams, grids, skies, targets)
+    frame = GV.FrameGraph(p, cams, grids, skies, targets, overlap=overlap)
     for rep in range(3):
         frame.step()
         assert frame.valid()
