@@ -399,6 +399,20 @@ class _FusedView(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_opacity, _v_rgb_g, v_means2d_ext, *_):
+        steps = _FusedView.backward_steps(ctx, v_rgb, v_depth, v_opacity, _v_rgb_g, v_means2d_ext)
+        next(steps)                      # image half: colour transform + compositor
+        try:
+            next(steps)                  # Gaussian half: SH + projection over the visible rows
+        except StopIteration as done:
+            return done.value
+        raise AssertionError("backward_steps yields once")
+
+    @staticmethod
+    def backward_steps(ctx, v_rgb, v_depth, v_opacity, _v_rgb_g, v_means2d_ext):
+        """The backward as a generator that yields ONCE, between its two halves: the image half (bilateral transform, compositor:
+        everything that produces the visible Gaussians' gradient records) and the Gaussian half (list-driven SH / projection
+        backward into the parameter gradients, screen-space gradient arrays, pose gradient).  The second half of view v only has to
+        precede the second half of view v + 1; ``graph_view`` replays it on a stream of its own next to view v + 1's image half."""
         (means, quats, log_scales, sh, sky, viewmat, scales, opac, radii, means2d, cam_pos, sh_rgb, rec, vis_ids, flatten,
          isect_offsets, render, alphas, last_ids, bws, *grids) = ctx.saved_tensors
         cfg = ctx.cfg
@@ -470,6 +484,8 @@ class _FusedView(torch.autograd.Function):
                                               L.ptr(order), st), "bds_rasterize_bwd")
         if v_means2d_ext is not None and n_vis:   # a loss term on info["means2d"] itself: add its rows to the records
             v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())
+        yield
+        lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
         # dense screen-space gradient + its absolute sum for the densification statistics (zeros for culled Gaussians, as gsplat)
         g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         arena = cfg.get("grad_arena") or {}
@@ -691,8 +707,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     them: per-Gaussian rows in ``grad_arena`` (``arena_rows``) or in ``param.grad``; the grids' in ``grid_grads`` / ``.grad``;
     ``sky.grad``, ``viewmat.grad`` accumulated.  Accepts the keyword arguments of ``fused_view``; ``after_forward(info)`` is called
     between the forward and the backward pass (``dist.FrameExchange.begin_view`` starts its visibility exchange there).
-    ``two_phase=True``: only the forward + loss value are enqueued; the returned dict carries ``backward``, a callable that enqueues
-    the rest (once).  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
+    ``two_phase=True``: only the forward + loss value are enqueued; the returned dict carries ``backward`` and ``backward_tail``,
+    callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
     from .losses import _PhotometricTV
     cam_pos = kwargs.pop("cam_pos", None)
     if cam_pos is None:
@@ -734,24 +750,36 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
     out = _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
 
-    def backward():
+    state = {}
+
+    def backward():          # loss backward + image half of the view's backward
         with torch.no_grad():
             one = _ONES.get(rgb.device)
             if one is None:
                 one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
             lg = _PhotometricTV.backward(lctx, one)
-            v_rgb, v_tv_grids = lg[0], lg[4:]
-            grads = _FusedView.backward(ctx, v_rgb, None, None, None, None)
+            state["v_tv_grids"] = lg[4:]
+            state["steps"] = _FusedView.backward_steps(ctx, lg[0], None, None, None, None)
+            next(state["steps"])
+
+    def backward_tail():     # Gaussian half; gradients land where autograd would put them
+        with torch.no_grad():
+            try:
+                next(state["steps"])
+                raise AssertionError("backward_steps yields once")
+            except StopIteration as done:
+                grads = done.value
             for p, g in zip(leaves, grads[1:6]):
                 _accumulate(p, g)
             _accumulate(sky, grads[6])
             _accumulate(viewmat, grads[7])
-            for g, a, b in zip(gs, v_tv_grids, grads[8:]):
+            for g, a, b in zip(gs, state["v_tv_grids"], grads[8:]):
                 _accumulate(g, a)
                 _accumulate(g, b)
 
-    if two_phase:     # the caller runs the second half itself (graph_view: forward and backward as two hipGraphs on two streams)
-        out["backward"] = backward
+    if two_phase:     # the caller enqueues the halves itself (graph_view: forward | backward | its Gaussian half as hipGraphs on three streams)
+        out["backward"], out["backward_tail"] = backward, backward_tail
         return out
     backward()
+    backward_tail()
     return out

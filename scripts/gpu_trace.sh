@@ -18,8 +18,9 @@ except Exception as e:
     print("bench line unreadable:", e); print(open("$OUT/bench.stderr").read()[-1500:])
 PY
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats "$@" > $OUT/trace_bench.json 2>$OUT/trace.stderr
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py --steps 6 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats "$@" > $OUT/trace_bench.json 2>$OUT/trace.stderr
 python $REPO/scripts/step_timeline.py $OUT/trace/bench_kernel_trace.csv 20 > $OUT/step_timeline.txt 2>&1
+python $REPO/scripts/frame_overlap_report.py $OUT/trace/bench_kernel_trace.csv > $OUT/frame_overlap.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -type f -size +8M -delete
-cat $OUT/step_timeline.txt
+cat $OUT/frame_overlap.txt
