@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--views-per-step", type=int, default=None, help="views of the rig rendered per step (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-stats", action="store_true")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the short measurement of the reference-signature operator chain")
     ap.add_argument("--cpu-sample-gaussians", type=int, default=100000)
     ap.add_argument("--cpu-sample-width", type=int, default=960)
     ap.add_argument("--cpu-sample-height", type=int, default=540)
@@ -346,11 +347,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         reps = [float(x) for x in t.tolist()]
     elapsed = sorted(reps)[len(reps) // 2] if len(reps) % 2 else sorted(reps)[len(reps) // 2 - 1]   # (lower median for even counts)
+    dom_in_situ = None
     if frame is not None:
         assert frame.valid(), "a list outgrew its calibrated capacity during the timed region"
         cnts = frame.counts()
         Ms, nvs = [c[0] for c in cnts], [c[1] for c in cnts]
-        tsum = {"rasterize_bwd": (len(dom_ms), sum(dom_ms) / max(len(dom_ms), 1))} if dom_ms else {}
+        dom_in_situ = (len(dom_ms), sum(dom_ms) / max(len(dom_ms), 1)) if dom_ms else None
+        # The same captured graphs once more on ONE stream: the kernel's own duration (in the timed region it shares the GPU with the
+        # other stream's kernels; rocprofv3 serialises the streams and reports this figure)
+        alone = []
+        for _ in range(3):
+            frame.step(serial=True)
+            torch.cuda.synchronize()
+            alone += frame.mark_samples("rasterize_bwd")
+        tsum = {"rasterize_bwd": (len(alone), sum(alone) / max(len(alone), 1))} if alone else {}
     else:
         tsum = L.timer_summary()
         Ms, nvs = list(stats["M"]), list(stats["n_vis"])
@@ -363,6 +373,28 @@ def main():
     tall = L.timer_summary()
     L.enable_timers(False)
     frame = frame_graph
+    # the drop-in path (reference-signature operators chained by autograd: projection, SH, isect_tiles, rasterize_to_pixels,
+    # bilagrid_transform -- what `gsplat.rasterization(...)` + the module `forward` cost a trainer that changes nothing else)
+    api_its = None
+    if rank == 0 and world == 1 and not args.no_api_path:
+        try:
+            Hn.FUSED = False
+            def api_view(v):
+                for t in list(params.values()) + grids + [skies[v], cams[v].viewmat]:
+                    t.grad = None
+                Hn.training_loss(Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors), targets[v], grids).backward()
+            for v in range(V):
+                api_view(v)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for v in range(V):
+                api_view(v)
+            torch.cuda.synchronize()
+            api_its = V / (time.perf_counter() - t0)
+        except Exception as e:   # measurement tooling must never take the bench line down
+            api_its = f"{type(e).__name__}: {e}"
+        finally:
+            Hn.FUSED = True
     ms_per_step = elapsed / args.steps * 1e3
     value = world * V * args.steps / elapsed
 
@@ -374,23 +406,40 @@ def main():
     calls, mean_ms = tsum.get(dom, (0, float("nan")))
     alg_bytes = 92.0 * M_mean + 28.0 * P
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if calls else float("nan")
-    kname = "rasterize_bwd_wave_kernel<4, true, true, false>"   # <CH, absgrad, coarse lists, strip skip> of the fused view
+    kname = L.rasterize_kernel_name(True, 4, True, FV.LIST_TILE)   # the library names the kernel its launch switches select
     traffic, traffic_src = _newest_profile("_pmc.json", kname, "hbm_bytes_per_launch_corrected")
-    roofline = {"bound": "hbm", "kernel": "bds::" + kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+    traffic_error = None
+    if traffic is None:   # loud, not silent: a renamed kernel or a missing counter pass must not pass as "no traffic figure"
+        traffic_error = f"no profiles/*_pmc.json holds counters of `{kname}`: re-run scripts/gpu_round.sh <tag> and scripts/summarize_profile.py"
+        print("bench.py: WARNING: " + traffic_error, file=sys.stderr)
+    roofline = {"bound": "hbm", "binding_roof": "valu issue (see `valu`): the kernel moves 0.15x its algorithmic bytes through HBM",
+                "kernel": "bds::" + kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": mean_ms,
-                "note": "achieved = algorithmic bytes (92 B/isect + 28 B/pixel, SURVEY.md 8d) / HIP-event launch time.  The composite "
-                        "kernels are bound by VALU issue, not by HBM (SURVEY.md 7, hard part 2): see `valu` for the binding roof"}
+                "frac_traffic": None if traffic is None or not calls else traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": mean_ms, "launches_timed": calls,
+                "avg_launch_ms_in_timed_region": None if dom_in_situ is None else dom_in_situ[1],
+                "note": "achieved = algorithmic bytes (92 B per (16-px tile, Gaussian) pair of the reference's lists + 28 B/pixel, SURVEY.md 8d) "
+                        "/ the kernel's HIP-event launch time.  frac is that NOMINAL figure; frac_traffic = HBM bytes the counters saw / "
+                        "time / peak -- the kernel is bound by VALU issue, not by HBM (SURVEY.md 7, hard part 2).  avg_launch_ms: timing "
+                        "marks inside the captured graphs, replayed on one stream right after the timed region (what rocprofv3, which "
+                        "serialises the streams, reports); avg_launch_ms_in_timed_region: the same marks during the timed steps, where "
+                        "the kernel shares the GPU with the next view's forward on the second stream"}
+    if traffic_error:
+        roofline["traffic_error"] = traffic_error
     # the binding roof of K7/K8: vector instructions per visited (tile, Gaussian) pair
     valu = None
     if rank == 0 and not args.no_pair_stats and args.workload == "headline" and N == wl["gaussians"]:
         try:
             ps = _pair_stats(N, W, H)
             insts, src = _newest_profile("_sq_counters.json", kname, "SQ_INSTS_VALU")
+            if insts is None:
+                print(f"bench.py: WARNING: no profiles/*_sq_counters.json holds `{kname}`", file=sys.stderr)
             busy, _ = _newest_profile("_sq_counters.json", kname, "valu_busy_frac")
             valu = {"listed_pairs": ps["isects_listed"], "visited_pairs": ps["pairs_visited"], "pixel_blends": ps["pixel_blends"],
                     "pairs_view": 0, "valu_insts_per_launch": insts, "valu_insts_per_pair": None if insts is None else insts / ps["pairs_visited"],
                     "valu_frac": busy, "counter_source": src,
+                    # per pair: ~35 vector ops per blending pixel (4 exp2, 4 rcp, fma-class rest); everything else is overhead
+                    "useful_frac": None if insts is None else min(1.0, 35.0 * ps["pixel_blends"] / 64.0 / insts),
                     "note": "visited = (tile, Gaussian) pairs that some pixel blends (early termination + alpha cut leave ~1 in 10 of the "
                             "listed pairs); valu_frac = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * kernel cycles) from the committed rocprofv3 "
                             "counter pass: the kernel issues a vector instruction in (nearly) every issue slot it has"}
@@ -431,7 +480,7 @@ def main():
                                f"{[list(l) for l in wl['levels']]} factors {list(factors)}, L1+TV loss, camera-pose gradient live; one step = one "
                                f"frame of {V} views per GPU (1 iter = 1 view)",
                    "workload_name": args.workload, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
-                   "frames_per_sec": value / V, "ms_per_view": ms_per_step / V,
+                   "frames_per_sec": value / V, "ms_per_view": ms_per_step / V, "api_path_iters_per_sec": api_its,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
                    "pipelined_fronts": bool(args.pipeline) and not args.direct,

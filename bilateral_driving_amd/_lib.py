@@ -59,6 +59,7 @@ _SIGS = {
     "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
+    "bds_rasterize_kernel_name": (_i, [_i, _i, _i, _i, C.c_char_p, _i]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
@@ -160,6 +161,12 @@ OPT_DEBUG, OPT_STRIP_ROWS = 3, 5      # 3: ablation mask (bit 16: general bilate
 OPT_STRIPS = 7                         # bilateral column-strip kernels: 1 = forward, 2 = backward (opt-in, see csrc/bilagrid.hip)
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
+
+
+def rasterize_kernel_name(backward: bool, CH: int = 4, absgrad: bool = True, list_tile_size: int = 64) -> str:
+    buf = C.create_string_buffer(128)
+    check(lib().bds_rasterize_kernel_name(int(backward), CH, int(absgrad), list_tile_size, buf, 128), "bds_rasterize_kernel_name")
+    return buf.value.decode()
 
 
 def set_option(which: int, value: int) -> None:

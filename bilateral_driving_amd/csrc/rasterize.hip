@@ -758,3 +758,14 @@ extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, in
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
+
+// Name of the compositor kernel a launch with these switches runs, as rocprofv3 prints it (bench.py looks the dominant kernel's
+// counters up under this name in profiles/: the name lives next to the template it describes, not in the benchmark)
+extern "C" int bds_rasterize_kernel_name(int backward, int CH, int absgrad, int list_tile_size, char *buf, int buf_len) {
+  BDS_REQUIRE(buf && buf_len > 0 && (CH == 1 || CH == 3 || CH == 4) && list_tile_size >= kTile && list_tile_size % kTile == 0);
+  const char *co = list_tile_size > kTile ? "true" : "false";
+  int n;
+  if (backward) n = snprintf(buf, (size_t)buf_len, "rasterize_bwd_wave_kernel<%d, %s, %s, false>", CH, absgrad ? "true" : "false", co);
+  else n = snprintf(buf, (size_t)buf_len, "rasterize_fwd_wave_kernel<%d, %s, true>", CH, co);
+  return (n > 0 && n < buf_len) ? BDS_OK : BDS_EINVAL;
+}

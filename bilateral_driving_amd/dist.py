@@ -220,8 +220,11 @@ class FrameExchange:
          view's kernels run on the compute stream);
       4. one view later: the reduced rows are added to the dense gradient buffer (``param.grad``) through the union's id list.
 
-    Only the last view's exchange is exposed.  Capacity = 1.25 x the largest union seen (the first frame sizes it with one host
-    read); a union that outgrows it is detected one frame later (the counts are copied back asynchronously) and raises.
+    Only the last view's exchange is exposed.  Capacity = ``headroom`` x the LARGEST union seen over all views so far and never
+    shrinks: during the first frame every view's union count is read back (one host wait per view, once) and the buffers grow on
+    demand; afterwards the counts travel back asynchronously and ``end_frame`` -- which has waited for the last exchange anyway --
+    checks them BEFORE the caller's optimizer step: a union that outgrew the capacity raises there (the frame's gradients are
+    incomplete, nothing has consumed them yet), one that came within 8 % of it re-sizes the buffers for the next frame.
     World size 1: ``view_kwargs`` selects the in-place arena modes of ``fused_view`` and nothing is exchanged.  ``force=True`` runs the
     compact path without any collective (single-GPU test of the kernels the exchange depends on)."""
 
@@ -240,6 +243,8 @@ class FrameExchange:
         n_row = sum(v.numel() for v in flat._views[:len(ROW_NAMES)])
         self._tail = flat.flat[n_row:] if (not self.active and flat.total > n_row) else None
         self.cap = 0
+        self._max_union = 0                 # largest union count of any view so far (the capacity follows it, never shrinks)
+        self._sized = False                 # the first frame reads every view's count back; later frames check at end_frame
         self._bufs: List[Tensor] = []
         self._free: List[int] = []
         self._pending: List[tuple] = []     # (work, buffer index, ids) of exchanges in flight, oldest first
@@ -251,7 +256,9 @@ class FrameExchange:
 
     # ---- per frame -------------------------------------------------------------------------------------------------
     def begin_frame(self) -> None:
-        self._check_overflow()
+        self._check_overflow()              # (counts of a frame whose end_frame was skipped)
+        if self.active and self._bufs and self._max_union > 0.92 * self.cap and self.cap < (self.N + 3) // 4 * 4 and not self._pending:
+            self._allocate(self._wanted_cap())   # a union came within 8 % of the capacity: re-size upward between frames
         self.flat.zero()
         if self.active:   # the reduced rows are added into the dense buffer, which IS the parameters' .grad; the small dense tail
             #               (grids, ...) is accumulated by autograd as usual and packed in end_frame
@@ -296,8 +303,13 @@ class FrameExchange:
         if work is not None:
             work.wait()
         slot = torch.cumsum(mask, 0, dtype=torch.int32) - 1
-        if self.cap == 0:   # first view ever: size the buffers from the actual union (one host read)
-            self._allocate(int(slot[-1]) + 1)
+        if not self._sized:   # first frame: every view's union is read back (one host wait per view, once) and the buffers grow on demand
+            n = int(slot[-1]) + 1
+            self._max_union = max(self._max_union, n)
+            if n > self.cap:
+                while self._pending:        # buffers in flight have the old size: drain them first
+                    self._retire()
+                self._allocate(self._wanted_cap())
         cnt = torch.empty(1, dtype=torch.int64).pin_memory() if mask.is_cuda else torch.empty(1, dtype=torch.int64)
         cnt.copy_(slot[-1:] + 1, non_blocking=True)
         ev = None
@@ -335,11 +347,14 @@ class FrameExchange:
             self._retire()
 
     def end_frame(self) -> None:
-        """After the last view: drain the exchanges and sum the small dense tail (grids, ...) over the ranks."""
+        """After the last view: drain the exchanges, check the frame's union counts (raises BEFORE the caller's optimizer step if one
+        outgrew the capacity) and sum the small dense tail (grids, ...) over the ranks."""
         if not self.active:
             return
         while self._pending:
             self._retire()
+        self._sized = True
+        self._check_overflow()
         n_row = self.N * self.row_floats
         tail = self.flat.flat[n_row:]
         if tail.numel():
@@ -354,9 +369,13 @@ class FrameExchange:
                 self.payload_bytes += tail.numel() * 4
 
     # ---- internals -------------------------------------------------------------------------------------------------
-    def _allocate(self, n_union: int) -> None:
-        cap = int(n_union * self.headroom) + 64
-        self.cap = min((cap + 3) // 4 * 4, (self.N + 3) // 4 * 4)    # multiple of 4: every sub-array starts 16-byte aligned
+    def _wanted_cap(self) -> int:
+        cap = int(self._max_union * self.headroom) + 64
+        return max(self.cap, min((cap + 3) // 4 * 4, (self.N + 3) // 4 * 4))   # multiple of 4: every sub-array starts 16-byte aligned
+
+    def _allocate(self, cap: int) -> None:
+        assert not self._pending and cap >= self.cap
+        self.cap = cap
         dev = self.arena["means"].device
         self._bufs = [torch.zeros(self.cap * self.row_floats, device=dev, dtype=torch.float32) for _ in range(self.n_buffers)]
         self._free = list(range(self.n_buffers))
@@ -392,19 +411,20 @@ class FrameExchange:
         self._free.append(b)
 
     def _check_overflow(self) -> None:
-        keep = []
-        for cnt, ev, cap in self._counts:
+        """Union counts recorded since the last check (every rank sees the same counts and decides alike)."""
+        counts, self._counts = self._counts, []
+        worst = None
+        for cnt, ev, cap in counts:
             if ev is not None:
-                ev.synchronize()    # recorded during the previous frame: long done; (never query(): every rank must decide alike)
+                ev.synchronize()    # (never query(): every rank must decide alike)
             n = int(cnt[0])
-            if n > cap:
-                raise RuntimeError(f"FrameExchange: the union of the ranks' visible sets ({n} Gaussians) outgrew the exchange "
-                                   f"capacity ({cap}); the previous frame's gradients are incomplete -- raise `headroom`")
-            if n > 0.92 * cap and cap < self.N:     # growing scene: re-size before it overflows
-                self.cap = 0
-        self._counts = keep
-        if self.cap == 0 and self._bufs and not self._pending:
-            self._bufs, self._free = [], []
+            self._max_union = max(self._max_union, n)    # the capacity follows the largest union: begin_frame re-sizes upward
+            if n > cap and (worst is None or n > worst[0]):
+                worst = (n, cap)
+        if worst is not None:
+            raise RuntimeError(f"FrameExchange: the union of the ranks' visible sets ({worst[0]} Gaussians) outgrew the exchange "
+                               f"capacity ({worst[1]}): this frame's gradients are incomplete -- discard them and repeat the frame "
+                               f"(the buffers are re-sized at the next begin_frame)")
 
 
 def reduce_densify_stats(grad_norm_accum: Tensor, vis_counts: Tensor, max_2d_size: Tensor) -> None:

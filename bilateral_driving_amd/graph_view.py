@@ -232,9 +232,10 @@ class FrameGraph:
         vg.replay()
         return vg
 
-    def step(self) -> None:
-        """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed."""
-        if not self.overlap:
+    def step(self, serial: bool = False) -> None:
+        """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed.
+        ``serial``: replay every graph on the caller's stream, one after the other (what a one-stream frame does; measurement)."""
+        if not self.overlap or serial:
             self.begin_graph.replay()
             for vg in self.views:
                 vg.replay()

@@ -277,7 +277,10 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     """means2d [C,N,2], conics [C,N,3], colors [C,N,D], opacities [C,N] -> render [C,H,W,D], alphas [C,H,W,1].
     ``tile_size``: the tile size ``isect_offsets`` / ``flatten_ids`` were built for (gsplat's argument): 16, or a multiple of 16 --
     the compositor always works on 16 x 16 tiles and filters the candidates of a larger list tile per 16 x 16 tile (include/bds.h,
-    "coarse lists"); the image and the gradients do not depend on it."""
+    "coarse lists").  As in gsplat, the result DOES depend on it slightly: through this operator the splat records carry no
+    projection radius, so a Gaussian is clipped at the bounding square's LIST-tile granularity (tile_size 32 / 64 keep a little more
+    of a splat's tail than 16; oracle-checked per tile size).  Only the fused view, whose records carry the radii, produces the
+    16-px image for any list tile size."""
     Cn, N = means2d.shape[0], means2d.shape[1]
     assert means2d.shape == (Cn, N, 2) and conics.shape == (Cn, N, 3) and opacities.shape == (Cn, N), (
         means2d.shape, conics.shape, opacities.shape)

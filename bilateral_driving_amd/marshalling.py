@@ -1,14 +1,23 @@
-"""Input marshalling of the reference's training step, restated under the reference's own names so that a
-trainer written against them runs on the MI355X operators unchanged:
+"""Input marshalling of the reference's training step, restated under the reference's own names and argument
+meaning.  The reference's versions are trainer METHODS that keep state on ``self``; these are free functions that RETURN that
+state, so two call sites differ from the reference's by their return shape (a trainer method wrapping them stores the extra value
+on ``self`` and is otherwise unchanged):
+
+  reference (method)                                          here (function)
+  ``gs = self.collect_gaussians(cam, image_ids)``             ``gs, pts_labels = collect_gaussians(models, classes, cam, image_ids)``
+      (sets self.pts_labels)
+  ``outputs, render_fn = self.render_gaussians(gs, cam)``     ``outputs, render_fn, info = render_gaussians(gs, cam, ...)``
+      (sets self.info)
+
+Where the reference's code lives:
 
   ``dataclass_camera`` / ``dataclass_gs``   /root/reference/project/models/gaussians/basics.py:112-160
   ``process_camera``                        models/trainers/base.py:317-340
   ``collect_gaussians``                     models/trainers/base.py:342-383
   ``get_gaussians``                         models/gaussians/vanilla.py:378-414 (the background class: SH colours + activations)
-  ``render_gaussians``                      models/trainers/base.py:385-432 (-> ``rasterization``; returns ``results, render_fn``)
+  ``render_gaussians``                      models/trainers/base.py:385-432 (-> ``rasterization``; returns ``results, render_fn, info``)
 
-The functions are free functions (the reference's are trainer methods); the state the methods keep on ``self`` (``pts_labels``,
-``dynamic_pts_mask``, ``info``) is returned.  ``fused_view`` / ``harness.render_view`` are the faster entry for the background
+``fused_view`` / ``harness.render_view`` are the faster entry for the background
 class alone (SH evaluated inside the view node); this module is the interface-compatible route for the multi-class scene graph,
 where every class hands over already-activated tensors."""
 from __future__ import annotations

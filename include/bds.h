@@ -332,6 +332,10 @@ int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const flo
                             const float *s_log_scales, const float *s_logits, const float *s_sh, float *v_means, float *v_quats,
                             float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
 
+/* Name (as rocprofv3 prints it, without the "bds::" prefix and the argument list) of the compositor kernel that a launch with
+ * these switches runs; measurement plumbing for bench.py's counter look-up. */
+int bds_rasterize_kernel_name(int backward, int CH, int absgrad, int list_tile_size, char *buf, int buf_len);
+
 /* ---- device-count forms: one view without a host read-back (capturable in a hipGraph) -----------------------------------------
  * gsplat's rasterization() reads the intersection count back to size its lists (one host wait per view at
  * models/trainers/base.py:393-408).  These forms take CAPACITIES from the host (what the previous visit of the camera needed, plus

@@ -319,3 +319,46 @@ def test_frame_exchange_single_process_uses_the_arena_modes():
     fx.begin_frame()
     assert float(fx.tail_grads()[0].abs().max()) == 0.0 and params[5].grad.data_ptr() == fx.tail_grads()[0].data_ptr()
     assert fx.tail_grads("nope") == []
+
+
+def test_frame_exchange_capacity_follows_the_largest_view_and_overflow_raises_before_the_step():
+    """Views of very different visibility (advisor finding, round 2): the exchange capacity is sized from the LARGEST union of the
+    first frame, not from the first view; a later union that outgrows it raises at end_frame -- before an optimizer step could consume
+    the incomplete gradients -- and the next frame runs with re-sized buffers.  Compact path without collectives (force=True)."""
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    params = _fx_params()
+    flat = FlatGradients(params, sparse_rows=True)
+    fx = FrameExchange(flat, _FX_NAMES, headroom=1.25, force=True)
+
+    def run_frame(sizes, seed, fits=True):
+        g = torch.Generator().manual_seed(seed)
+        ref = [torch.zeros_like(p) for p in params[:5]]
+        fx.begin_frame()
+        for v, n in enumerate(sizes):
+            ids = torch.randperm(_FX_N, generator=g)[:n].sort().values.to(torch.int32)
+            radii = torch.zeros(1, _FX_N, dtype=torch.int32)
+            radii[0, ids.long()] = 2
+            fx.begin_view({"radii": radii, "visible_ids": ids})
+            bufs, row_map = fx.targets(ids)
+            slots = row_map[ids.long()].long()
+            assert not fits or slots.unique().numel() == n, "two Gaussians share an exchange slot"
+            for i, k in enumerate(_FX_NAMES[:5]):
+                r = torch.randn(n, *params[i].shape[1:], generator=g)
+                bufs[k][slots] = r
+                ref[i].index_add_(0, ids.long(), r)
+            fx.end_view()
+        fx.end_frame()
+        for i in range(5):
+            assert torch.allclose(flat._views[i], ref[i], atol=1e-6), i
+
+    run_frame([20, 150, 60], 1)             # view 1 sees 7.5x what view 0 sees
+    cap0 = fx.cap
+    assert cap0 >= int(150 * 1.25) and cap0 % 4 == 0
+    run_frame([30, 140, 150], 2)            # fits: nothing changes
+    assert fx.cap == cap0
+    with pytest.raises(RuntimeError, match="outgrew the exchange capacity"):
+        run_frame([30, cap0 + 40, 50], 3, fits=False)   # (slots beyond the capacity collide) raised by end_frame, i.e. before the caller's optimizer step
+    run_frame([30, cap0 + 40, 50], 3)       # the repeated frame runs with re-sized buffers
+    assert fx.cap >= cap0 + 40 and fx.cap >= cap0
+    run_frame([10, 20, 30], 4)
+    assert fx.cap >= cap0 + 40              # never shrinks
