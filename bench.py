@@ -271,14 +271,14 @@ def main():
     torch.cuda.synchronize()
 
     stats = {}
-    use_graph = world == 1 and not args.no_graph and not dense and not args.direct and not args.pipeline
+    use_graph = not args.no_graph and not dense and not args.direct and not args.pipeline
     frame = None
     if use_graph:
         # the views are captured with the roofline kernel bracketed by timing marks (event-record nodes: re-recorded by every replay)
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap)
+                           overlap=not args.no_overlap, exchange=fx)
         L.enable_timers(False)
 
     def step(s):

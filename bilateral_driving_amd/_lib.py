@@ -77,6 +77,8 @@ _SIGS = {
     "bds_sh_view_bwd_list_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_project_view_bwd_list_dev": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list_dev": (_i, [_i64, _f, _f, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_union_slots_workspace_bytes": (_sz, [_i64]),
+    "bds_union_slots": (_i, [_i64, _f, _i64, _i, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),

@@ -302,6 +302,8 @@ class FrameExchange:
         self._union = None
         if work is not None:
             work.wait()
+        if mask.is_cuda and self._sized:
+            return self._targets_device(mask)
         slot = torch.cumsum(mask, 0, dtype=torch.int32) - 1
         if not self._sized:   # first frame: every view's union is read back (one host wait per view, once) and the buffers grow on demand
             n = int(slot[-1]) + 1
@@ -331,6 +333,121 @@ class FrameExchange:
         buf.zero_()
         self._cur = (b, ids)
         return self._views_of(buf), row_map
+
+    def _targets_device(self, mask: Tensor):
+        """``targets`` on the GPU once the buffers are sized: mask -> slot map, id list, cleared buffer rows and the count in TWO
+        launches of libbds (bds_union_slots) instead of ten framework operators on N-element tensors."""
+        from . import _lib as L
+        lib = L.lib()
+        dev = mask.device
+        if not self._bufs:          # (sized by the static form, whose buffers are per view: the rotating ones are made on first use)
+            self._allocate(max(self.cap, self._wanted_cap()))
+        if not self._free:
+            self._retire()
+        b = self._free.pop()
+        buf = self._bufs[b]
+        views = self._views_of(buf)
+        row_map = torch.empty(self.N, device=dev, dtype=torch.int32)
+        ids = torch.empty(self.cap, device=dev, dtype=torch.int32)
+        cnt = torch.zeros(1, dtype=torch.int64).pin_memory()
+        wsb = lib.bds_union_slots_workspace_bytes(self.N)
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        L.check(lib.bds_union_slots(self.N, L.ptr(mask), self.cap, self.K, L.ptr(row_map), L.ptr(ids), L.ptr(views["means"]),
+                                    L.ptr(views["quats"]), L.ptr(views["log_scales"]), L.ptr(views["opacity_logits"]), L.ptr(views["sh"]),
+                                    L.ptr(ws), wsb, None, cnt.data_ptr(), L.stream()), "bds_union_slots")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._counts.append((cnt, ev, self.cap))
+        self._cur = (b, ids)
+        return views, row_map
+
+    # ---- static form (graph_view.FrameGraph at world size > 1): per-view buffers at fixed addresses ---------------------------------
+    def static_setup(self, union_counts: Iterable[int]) -> None:
+        """One compact buffer, slot map, id list, mask and count word PER VIEW of the frame, at addresses that captured hipGraphs can
+        hold; capacity from ``union_counts`` (the views' union sizes of a calibration visit: identical on every rank)."""
+        from . import _lib as L
+        counts = [int(c) for c in union_counts]
+        self._max_union = max([self._max_union] + counts)
+        while self._pending:
+            self._retire()
+        self.cap = self._wanted_cap()
+        dev = self.arena["means"].device
+        V = len(counts)
+        self._sbuf = [torch.zeros(self.cap * self.row_floats, device=dev, dtype=torch.float32) for _ in range(V)]
+        self._srow = [torch.zeros(self.N, device=dev, dtype=torch.int32) for _ in range(V)]
+        self._sids = [torch.full((self.cap,), -1, device=dev, dtype=torch.int32) for _ in range(V)]
+        self._scnt = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(V)]
+        wsb = L.lib().bds_union_slots_workspace_bytes(self.N)
+        self._sws = [torch.empty(wsb, device=dev, dtype=torch.uint8) for _ in range(V)]
+        self._swork = [None] * V
+        self._spending: List[tuple] = []
+        self._sized = True
+        self._static = True
+
+    def static_sink(self, v: int):
+        """The ``grad_sink`` a captured view hands to its backward: ``targets`` returns view v's fixed buffers and slot map (filled by
+        ``static_targets`` right before the Gaussian half is replayed)."""
+        fx = self
+
+        class _Sink:
+            def targets(self, visible_ids):
+                return fx._views_of(fx._sbuf[v]), fx._srow[v]
+        return _Sink()
+
+    def static_begin_view(self, v: int, mask: Tensor) -> None:
+        """After view v's forward: start the MAX-all-reduce of its visibility mask (uint8 [N], reduced in place)."""
+        self._smask = getattr(self, "_smask", {})
+        self._smask[v] = mask
+        self._swork[v] = dist.all_reduce(mask, op=dist.ReduceOp.MAX, async_op=True) if self.world > 1 else None
+
+    def static_targets(self, v: int) -> None:
+        """Before view v's Gaussian half: union mask -> slot map, id list, cleared buffer rows, count (two launches)."""
+        from . import _lib as L
+        if self._swork[v] is not None:
+            self._swork[v].wait()
+            self._swork[v] = None
+        views = self._views_of(self._sbuf[v])
+        lib = L.lib()
+        L.check(lib.bds_union_slots(self.N, L.ptr(self._smask[v]), self.cap, self.K, L.ptr(self._srow[v]), L.ptr(self._sids[v]),
+                                    L.ptr(views["means"]), L.ptr(views["quats"]), L.ptr(views["log_scales"]), L.ptr(views["opacity_logits"]),
+                                    L.ptr(views["sh"]), L.ptr(self._sws[v]), self._sws[v].numel(), None, self._scnt[v].data_ptr(), L.stream()),
+                "bds_union_slots")
+
+    def static_end_view(self, v: int) -> None:
+        """After view v's Gaussian half: start the SUM-all-reduce of its compact buffer; add the PREVIOUS view's reduced rows."""
+        buf = self._sbuf[v]
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+        self.payload_bytes += buf.numel() * 4
+        self.n_exchanges += 1
+        self._spending.append((work, v))
+        while len(self._spending) > 1:
+            self._static_retire()
+
+    def _static_retire(self) -> None:
+        from . import _lib as L
+        work, v = self._spending.pop(0)
+        if work is not None:
+            work.wait()
+        src, dst, ids = self._views_of(self._sbuf[v]), self.arena, self._sids[v]
+        L.check(L.lib().bds_view_grads_add_list(ids.numel(), L.ptr(ids), self.K, L.ptr(src["means"]), L.ptr(src["quats"]),
+                                                L.ptr(src["log_scales"]), L.ptr(src["opacity_logits"]), L.ptr(src["sh"]),
+                                                L.ptr(dst["means"]), L.ptr(dst["quats"]), L.ptr(dst["log_scales"]),
+                                                L.ptr(dst["opacity_logits"]), L.ptr(dst["sh"]), L.stream()), "bds_view_grads_add_list")
+        self.flat.mark_list(ids)
+
+    def static_end_frame(self) -> None:
+        """Drain the exchanges and sum the dense tail (grids, ...), which the views accumulated in place, over the ranks."""
+        while self._spending:
+            self._static_retire()
+        n_row = self.N * self.row_floats
+        tail = self.flat.flat[n_row:]
+        if tail.numel() and self.world > 1:
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+            self.payload_bytes += tail.numel() * 4
+
+    def static_counts(self):
+        """Union sizes of the last frame's views (synchronise first); a value above ``cap`` = that view's exchange overflowed."""
+        return [int(c[0]) for c in self._scnt]
 
     def end_view(self) -> None:
         """Right after the view's backward pass."""

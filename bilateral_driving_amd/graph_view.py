@@ -51,9 +51,11 @@ class ViewGraph:
         self.fwd_done, self.bwd_done = torch.cuda.Event(), torch.cuda.Event()
 
     def replay(self) -> None:
+        """All three graphs of the view on the current stream (world size 1: with an exchange the collectives go between them,
+        ``FrameGraph.step``)."""
         self.graph.replay()
-        if self.graph_bwd is not None:
-            self.graph_bwd.replay()
+        self.graph_bwd.replay()
+        if self.graph_tail is not None:
             self.graph_tail.replay()
         self.done.record()
 
@@ -62,7 +64,8 @@ class FrameGraph:
     def __init__(self, params: Dict[str, Tensor], cams: Sequence[Hn.Camera], grids: Sequence[Tensor], skies: Sequence[Tensor],
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
-                 sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False):
+                 sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False,
+                 exchange=None):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -73,7 +76,11 @@ class FrameGraph:
         writes its own buffers; the image halves follow one another on the caller's stream, the Gaussian halves -- the only writers of
         the per-Gaussian gradient rows -- on the third when ``overlap_tail`` is set, else behind their image halves on the caller's
         stream (same accumulation order either way: same numbers).  Measured on MI355X, 2 M Gaussians / six 1080p views: one stream
-        782 it/s, forwards on a second stream 885, Gaussian halves on a third 875 -- the default is two."""
+        782 it/s, forwards on a second stream 885, Gaussian halves on a third 875 -- the default is two.
+        ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU: one process per GPU, every rank its own frame).
+        The per-view collectives -- MAX-all-reduce of the visibility mask after the forward, SUM-all-reduce of the compact gradient
+        rows after the Gaussian half -- are enqueued BETWEEN the graphs (RCCL runs them on its own stream next to the following
+        graphs); the slot map of the ranks' union is two libbds launches in front of the Gaussian half."""
         assert sorted(params.keys()) == sorted(ROW_NAMES), "params: means, quats, log_scales, opacity_logits, sh"
         self.params = {k: params[k] for k in ROW_NAMES}
         self.cams, self.grids, self.skies, self.targets = list(cams), list(grids), list(skies), list(targets)
@@ -88,8 +95,16 @@ class FrameGraph:
         L.require_gpu(*self.params.values(), *self.grids)
         self.N, self.K = self.params["means"].shape[0], self.params["sh"].shape[1]
         self.names = list(ROW_NAMES) + [f"grid{i}" for i in range(len(self.grids))]
-        self.flat = FlatGradients(list(self.params.values()) + self.grids + list(extra_params), sparse_rows=True)
-        self.arena = self.flat.arena(self.names + [f"extra{i}" for i in range(len(extra_params))])
+        self.fx = exchange if (exchange is not None and exchange.active) else None
+        if exchange is not None:
+            by_name = dict(self.params, **{f"grid{i}": g for i, g in enumerate(self.grids)})
+            assert not extra_params and sorted(exchange.names) == sorted(self.names), "the exchange covers exactly params + grids"
+            assert all(a is by_name[n] for a, n in zip(exchange.flat.params, exchange.names)), "the exchange was built over other tensors"
+            self.names = list(exchange.names)
+            self.flat, self.arena = exchange.flat, exchange.arena
+        else:
+            self.flat = FlatGradients(list(self.params.values()) + self.grids + list(extra_params), sparse_rows=True)
+            self.arena = self.flat.arena(self.names + [f"extra{i}" for i in range(len(extra_params))])
         n_row = sum(self.arena[k].numel() for k in ROW_NAMES)
         self._tail = self.flat.flat[n_row:]
         self.caps: List[Optional[ListCapacity]] = [None] * self.V
@@ -104,17 +119,25 @@ class FrameGraph:
         # caller-owned prepare workspaces: a view's visible-id list and its counts live here from one frame to the next (the next
         # frame's begin graph clears exactly those gradient rows).  Zero-initialised: "no rows yet".
         self.prep_ws = [torch.zeros(max(self._ws_bytes, 16), device=self.dev, dtype=torch.uint8) for _ in range(self.V)]
+        self._unions = [0] * self.V
         self.calibrate()
         self.capture()
 
     # ---- capacities --------------------------------------------------------------------------------------------------------------
     def calibrate(self) -> None:
-        """One forward visit of every camera through the host-count path: the list capacities are sized from what it needed."""
+        """One forward visit of every camera through the host-count path: the list capacities (and, with an exchange, the size of the
+        ranks' union per view) are sized from what it needed."""
+        import torch.distributed as dist
         with torch.no_grad():
             for v, cam in enumerate(self.cams):
                 info = Hn.render_view(self.params, cam, self.grids, self.img_indices[v], self.skies[v], factors=self.factors,
                                       sh_degree=self.sh_degree, list_tile=self.list_tile)["info"]
                 self._grow(v, int(info["n_isects"]), int(info["n_visible"]))
+                if self.fx is not None:
+                    mask = (info["radii"].reshape(-1) > 0).to(torch.uint8)
+                    if self.fx.world > 1:
+                        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+                    self._unions[v] = max(self._unions[v], int(mask.sum()))
 
     def _grow(self, v: int, M: int, n_vis: int) -> None:
         old = self.caps[v]
@@ -123,23 +146,36 @@ class FrameGraph:
         nv_cap = max(min(int(n_vis * h) + 1024, self.N), old.nvis_cap if old else 0)   # never shrinks
         self.caps[v] = ListCapacity(m_cap, max(nv_cap, 1))
 
-    # ---- capture -----------------------------------------------------------------------------------------------------------------
+    # ---- the phases of a view (eager warm-up, capture and replay walk the same protocol) -------------------------------------------
     def _view_kwargs(self, v: int) -> dict:
-        return dict(factors=self.factors, tv_weight=self.tv_weight, grid_grads=[self.arena[f"grid{i}"] for i in range(len(self.grids))],
-                    grad_arena=self.arena, arena_rows=1 if v == 0 else 2, caps=self.caps[v], prep_ws=self.prep_ws[v],
-                    list_tile=self.list_tile, sh_degree=self.sh_degree)
+        kw = dict(factors=self.factors, tv_weight=self.tv_weight, caps=self.caps[v], prep_ws=self.prep_ws[v], list_tile=self.list_tile,
+                  sh_degree=self.sh_degree, two_phase=True)
+        if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
+            kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
+        else:
+            kw.update(grid_grads=[self.arena[f"grid{i}"] for i in range(len(self.grids))], grad_arena=self.arena,
+                      arena_rows=1 if v == 0 else 2)
+        return kw
+
+    def _phase_fwd(self, v: int):
+        out = Hn.train_view(self.params, self.cams[v], self.grids, self.img_indices[v], self.skies[v], self.targets[v],
+                            **self._view_kwargs(v))
+        if self.fx is not None:
+            out["union_mask"] = (out["info"]["radii"].reshape(-1) > 0).to(torch.uint8)
+        return out
 
     def _point_grads_at_flat(self) -> None:
         for p, view in zip(self.flat.params, self.flat._views):
             p.grad = view
-        # the flat buffer's own row book-keeping is bypassed (the begin graph clears the rows): make a later flat.zero() dense
-        self.flat._dirty, self.flat._clean = None, False
-
-    def _run_view(self, v: int):
-        return Hn.train_view(self.params, self.cams[v], self.grids, self.img_indices[v], self.skies[v], self.targets[v],
-                             **self._view_kwargs(v))
+        if self.fx is None:
+            # the flat buffer's own row book-keeping is bypassed (the begin graph clears the rows): make a later flat.zero() dense
+            self.flat._dirty, self.flat._clean = None, False
 
     def _begin_body(self) -> None:
+        if self.fx is not None:      # the exchange's book of reduced rows clears the dense rows (fx.begin_frame); here only the tail
+            if self._tail.numel():
+                self._tail.zero_()
+            return
         lib, st = L.lib(), L.stream()
         a = self.arena
         for v in range(self.V):
@@ -151,12 +187,21 @@ class FrameGraph:
         if self._tail.numel():
             self._tail.zero_()
 
+    def _frame_begin(self) -> None:
+        """Host side of a frame's start with an exchange: its row-wise clear of the dense gradient rows (eager: static id lists)."""
+        if self.fx is not None:
+            self.fx.begin_frame()
+            self._point_grads_at_flat()
+
+    # ---- capture -----------------------------------------------------------------------------------------------------------------
     def capture(self) -> None:
-        """(Re-)capture the begin graph and the V view graphs against the current parameter / camera tensors and capacities."""
+        """(Re-)capture the begin graph and the view graphs against the current parameter / camera tensors and capacities."""
         self.views = [None] * self.V
         self.begin_graph = None
         self.pool = None
         torch.cuda.synchronize()
+        if self.fx is not None:
+            self.fx.static_setup(self._unions)
         self._point_grads_at_flat()
         for v in range(self.V):
             self.skies[v].grad = None
@@ -166,19 +211,31 @@ class FrameGraph:
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
+            self._frame_begin()
             self._begin_body()
             for v in range(self.V):
-                self._run_view(v)
+                out = self._phase_fwd(v)
+                if self.fx is not None:
+                    self.fx.static_begin_view(v, out["union_mask"])
+                out["backward"]()
+                if self.fx is not None:
+                    self.fx.static_targets(v)
+                out["backward_tail"]()
+                if self.fx is not None:
+                    self.fx.static_end_view(v)
                 self.skies[v].grad = None
                 self.cams[v].viewmat.grad = None
+            if self.fx is not None:
+                self.fx.static_end_frame()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize()
         self._check_counts(raise_on_overflow=True)
+        self._point_grads_at_flat()
         # graphs that share a pool are replayed in capture order on ONE stream; the forwards of the overlapped form run on their own
         # stream and therefore get their own pool (a block one graph frees may be handed to the next graph of the same pool)
         self.pool = torch.cuda.graph_pool_handle()
         self.pool_fwd = torch.cuda.graph_pool_handle() if self.overlap else self.pool
-        self.pool_tail = torch.cuda.graph_pool_handle() if self.overlap else self.pool
+        self.pool_tail = torch.cuda.graph_pool_handle() if self.overlap_tail else self.pool
         self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self.tail_stream = torch.cuda.Stream(device=self.dev) if self.overlap_tail else None
         self._frame_ready = torch.cuda.Event()
@@ -188,33 +245,31 @@ class FrameGraph:
             with torch.cuda.graph(g, pool=self.pool):
                 self._begin_body()
             self.begin_graph = g
-            if self.overlap:
-                # ALL forwards first, then all backwards: a block of the forwards' pool that a backward's capture frees (buffers the
-                # forward prepared for it) could otherwise be handed to the NEXT view's forward, which runs next to that backward
-                fwd = []
-                for v in range(self.V):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.pool_fwd):
-                        out = Hn.train_view(self.params, self.cams[v], self.grids, self.img_indices[v], self.skies[v], self.targets[v],
-                                            two_phase=True, **self._view_kwargs(v))
-                    fwd.append((g, out))
-                bwd = []
-                for v, (g, out) in enumerate(fwd):
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb, pool=self.pool):
-                        out["backward"]()
-                    bwd.append(gb)
-                for v, (g, out) in enumerate(fwd):   # (same rule one stage down: every image half before the first Gaussian half)
+            # ALL forwards first, then all image halves, then all Gaussian halves: a block of the forwards' pool that a later stage's
+            # capture frees (buffers the forward prepared for it) could otherwise be handed to the NEXT view's forward, which runs
+            # next to that stage (same rule one stage down)
+            fwd, bwd = [], []
+            for v in range(self.V):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool_fwd):
+                    out = self._phase_fwd(v)
+                fwd.append((g, out))
+            # (the Gaussian half is a graph of its own only where something goes between the halves: a third stream, or the exchange)
+            split = self.overlap_tail or self.fx is not None
+            for v, (g, out) in enumerate(fwd):
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=self.pool):
+                    out["backward"]()
+                    if not split:
+                        out["backward_tail"]()
+                bwd.append(gb)
+            for v, (g, out) in enumerate(fwd):
+                gt = None
+                if split:
                     gt = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gt, pool=self.pool_tail):
                         out["backward_tail"]()
-                    self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, bwd[v], gt)
-            else:
-                for v in range(self.V):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.pool):
-                        out = self._run_view(v)
-                    self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat)
+                self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, bwd[v], gt)
         finally:
             self.marks, L.GRAPH_MARKS = L.GRAPH_MARKS, outer
         self.n_captures += 1
@@ -223,49 +278,63 @@ class FrameGraph:
     recapture = capture
 
     # ---- replay ------------------------------------------------------------------------------------------------------------------
-    def begin(self) -> None:
-        self.begin_graph.replay()
-
-    def view(self, v: int) -> ViewGraph:
-        """Replay ONE view (forward, loss, backward) on the current stream; ``begin()`` first when it opens a frame."""
-        vg = self.views[v]
-        vg.replay()
-        return vg
-
     def step(self, serial: bool = False) -> None:
-        """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed.
-        ``serial``: replay every graph on the caller's stream, one after the other (what a one-stream frame does; measurement)."""
-        if not self.overlap or serial:
-            self.begin_graph.replay()
-            for vg in self.views:
-                vg.replay()
-            return
+        """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed (over
+        the ranks too, with an exchange).  ``serial``: every graph on the caller's stream, one after the other (measurement)."""
+        fx = self.fx
         main = torch.cuda.current_stream(self.dev)
-        # the forwards start once everything enqueued so far (the previous frame's backwards, an optimizer step) is done and the
-        # begin graph has read the previous frame's visible-id lists, which the forwards overwrite ...
+        self._frame_begin()
         self.begin_graph.replay()
-        self._frame_ready.record(main)
-        self.side_stream.wait_event(self._frame_ready)
-        with torch.cuda.stream(self.side_stream):
-            for vg in self.views:
+        side = None if (serial or not self.overlap) else self.side_stream
+        tail = None if (serial or not self.overlap_tail) else self.tail_stream
+        if side is not None:
+            # the forwards start once everything enqueued so far (the previous frame's backwards, an optimizer step) is done and the
+            # begin graph has read the previous frame's visible-id lists, which the forwards overwrite -- and then run ahead of the
+            # backwards on their own stream
+            self._frame_ready.record(main)
+            side.wait_event(self._frame_ready)
+            with torch.cuda.stream(side):
+                for v, vg in enumerate(self.views):
+                    vg.graph.replay()
+                    if fx is not None:
+                        fx.static_begin_view(v, vg.out["union_mask"])   # (RCCL orders the mask's all-reduce behind this stream)
+                    vg.fwd_done.record(side)
+        for v, vg in enumerate(self.views):
+            if side is None:
                 vg.graph.replay()
-                vg.fwd_done.record(self.side_stream)
-        # ... and run ahead of the backwards' image halves, which follow one another on the caller's stream; the Gaussian halves (the
-        # only writers of the per-Gaussian gradient rows) follow one another on a third stream, each behind its own image half
-        for vg in self.views:
-            main.wait_event(vg.fwd_done)
-            vg.graph_bwd.replay()
-            if self.tail_stream is None:
-                vg.graph_tail.replay()
+                if fx is not None:
+                    fx.static_begin_view(v, vg.out["union_mask"])
+            else:
+                main.wait_event(vg.fwd_done)
+            vg.graph_bwd.replay()       # image half: needs nothing from the other ranks
+            if tail is None:
+                if fx is not None:
+                    fx.static_targets(v)    # waits for the union mask; slot map + cleared buffer rows (two launches)
+                if vg.graph_tail is not None:
+                    vg.graph_tail.replay()
+                if fx is not None:
+                    fx.static_end_view(v)   # all-reduce of view v's rows (async), reduced rows of view v - 1 added to the dense buffer
                 vg.done.record(main)
                 continue
             vg.bwd_done.record(main)
-            self.tail_stream.wait_event(vg.bwd_done)
-            with torch.cuda.stream(self.tail_stream):
+            tail.wait_event(vg.bwd_done)
+            with torch.cuda.stream(tail):
+                if fx is not None:
+                    fx.static_targets(v)
                 vg.graph_tail.replay()
-                vg.done.record(self.tail_stream)
-        if self.tail_stream is not None:
+                if fx is not None:
+                    fx.static_end_view(v)
+                vg.done.record(tail)
+        if tail is not None:
             main.wait_event(self.views[-1].done)     # the frame's gradients are complete for whatever the caller enqueues next
+            if fx is not None:
+                with torch.cuda.stream(tail):
+                    fx.static_end_frame()
+                    self.views[-1].done.record(tail)
+                main.wait_event(self.views[-1].done)
+        elif fx is not None:
+            fx.static_end_frame()
+            self.views[-1].done.record(main)
 
     def mark_samples(self, name: str):
         """Milliseconds of every timing mark pair ``name`` captured into the view graphs (``_lib.enable_timers`` on during the
@@ -287,17 +356,26 @@ class FrameGraph:
                                      f"({c.m_cap}, {c.nvis_cap}) right after calibration")
                 ok = False
                 self._grow(v, M, n_vis)
+        if self.fx is not None:      # the ranks' unions (identical counts on every rank: every rank decides alike)
+            for v, n in enumerate(self.fx.static_counts()):
+                self._unions[v] = max(self._unions[v], n)
+                if n > self.fx.cap:
+                    if raise_on_overflow:
+                        raise L.BdsError(f"view {v}: union of the ranks' visible sets ({n}) exceeds the exchange capacity ({self.fx.cap})")
+                    ok = False
         return ok
 
     def valid(self) -> bool:
-        """Wait for the frame in flight; True if every view's lists fitted.  Otherwise the capacities are grown, the graphs captured
-        again and False is returned: the frame's gradients are incomplete (the overflowing view rendered nothing) -- repeat it."""
+        """Wait for the frame in flight; True if every view's lists (and exchange buffers) fitted.  Otherwise the capacities are grown,
+        the graphs captured again and False is returned: the frame's gradients are incomplete (the overflowing view rendered
+        nothing) -- repeat it."""
         for vg in self.views:
             vg.done.synchronize()
         if self._check_counts():
             # keep ahead of a growing scene: re-provision when a count comes within 8 % of its capacity
             grow = [v for v, c in enumerate(self.caps) if c.observed()[0] > 0.92 * c.m_cap or (c.observed()[1] > 0.92 * c.nvis_cap and c.nvis_cap < self.N)]
-            if grow:
+            near = self.fx is not None and max(self._unions) > 0.92 * self.fx.cap and self.fx.cap < (self.N + 3) // 4 * 4
+            if grow or near:
                 for v in grow:
                     self._grow(v, *self.caps[v].observed())
                 self.capture()

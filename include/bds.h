@@ -384,6 +384,18 @@ int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, con
 int bds_view_grads_clear_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means,
                                   float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
 
+/* ---- multi-GPU exchange of the visible rows (no reference counterpart; dist.FrameExchange) ---------------------------------------
+ * mask [N] uint8: the element-wise OR over the ranks of "this rank's view sees Gaussian g" (radii > 0).  In two launches:
+ * row_map [N] i32 = slot of every Gaussian in the union (cumsum(mask) - 1, clamped to [0, capacity - 1]); ids [capacity] i32 =
+ * Gaussian at slot s, -1 beyond the union; rows [0, count) of the five compact sub-arrays (b_means [capacity,3] b_quats [capacity,4]
+ * b_log_scales [capacity,3] b_logits [capacity] b_sh [capacity,K,3]) zeroed; count -> *count_dev (may be NULL) and count_pinned
+ * (page-locked int64, written by the GPU; may be NULL).  A union larger than the capacity is reported through the count (rows
+ * beyond it collide in the last slot: the caller repeats the frame with larger buffers).  ws: bds_union_slots_workspace_bytes(N). */
+size_t bds_union_slots_workspace_bytes(int64_t N);
+int bds_union_slots(int64_t N, const uint8_t *mask, int64_t capacity, int K, int32_t *row_map, int32_t *ids, float *b_means,
+                    float *b_quats, float *b_log_scales, float *b_logits, float *b_sh, void *ws, size_t ws_bytes,
+                    uint64_t *count_dev, int64_t *count_pinned, bds_stream_t stream);
+
 /* RGB+ED form of the fused image transform: the input is the compositor's 4-channel render [H*W,4] (RGB +
  * accumulated depth, gsplat render_mode "RGB+ED") and its alpha.  Forward additionally writes the expected depth
  * depth [H*W] = render[.,3] / max(alpha, 1e-10) (the normalise inside gsplat's rasterization(); split as in

@@ -58,6 +58,66 @@ def _run_frames(Hn, cams, base, grids0, sky, target, force, frames=2):
     return outs, fx
 
 
+def _run_frames_graph(Hn, cams, base, grids0, sky, target, force, frames=3, overlap=True, overlap_tail=False):
+    """The same frames as hipGraphs (graph_view.FrameGraph): per view three graphs, the exchange's collectives between them."""
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    from bilateral_driving_amd.graph_view import FrameGraph
+    p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+    grids = [g.clone().requires_grad_(True) for g in grids0]
+    flat = FlatGradients(list(p.values()) + grids, sparse_rows=True)
+    fx = FrameExchange(flat, list(p.keys()) + [f"grid{i}" for i in range(len(grids))], force=force)
+    frame = FrameGraph(p, cams, grids, [sky.clone() for _ in cams], [target for _ in cams], exchange=fx, overlap=overlap,
+                       overlap_tail=overlap_tail)
+    outs = []
+    for _ in range(frames):
+        frame.step()
+        assert frame.valid()
+        outs.append(torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids]).clone())
+    return outs, fx, frame
+
+
+@pytest.mark.parametrize("overlap,overlap_tail", [(False, False), (True, False), (True, True)])
+def test_graph_frames_with_the_compact_exchange_equal_the_dense_sum_single_process(overlap, overlap_tail):
+    """FrameGraph + FrameExchange(force=True): the compact path (union slot map by bds_union_slots, rows stored through the static
+    sink, added back through the id lists) inside the graph replay, no collective; every replayed frame == the dense sum."""
+    Hn, cams, base, grids0, sky, target = _setup("cuda")
+    ref = _dense_reference(Hn, [cams], base, grids0, sky, target)
+    outs, fx, frame = _run_frames_graph(Hn, cams, base, grids0, sky, target, force=True, overlap=overlap, overlap_tail=overlap_tail)
+    assert fx.active and 0 < fx.cap < N and frame.fx is fx
+    for o in outs:
+        assert float((o - ref).norm() / ref.norm()) < 1e-4
+    assert fx.n_exchanges == len(cams) and max(fx.static_counts()) <= fx.cap
+
+
+def test_union_slots_kernel_equals_the_framework_formulation():
+    """bds_union_slots (two launches) == cumsum / where / scatter on the same mask: slot map, id list, cleared rows, count."""
+    from bilateral_driving_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(2)
+    for n, frac, cap in ((5000, 0.3, 2000), (100_003, 0.15, 20_000), (4096 * 3, 1.0, 4096 * 3), (70_000, 0.5, 20_000)):
+        mask = (torch.rand(n, generator=g) < frac).to(torch.uint8).cuda()
+        K = 16
+        row_map = torch.empty(n, dtype=torch.int32, device="cuda")
+        ids = torch.empty(cap, dtype=torch.int32, device="cuda")
+        bufs = [torch.full(s, 7.0, device="cuda") for s in ((cap, 3), (cap, 4), (cap, 3), (cap,), (cap, K, 3))]
+        cnt = torch.zeros(1, dtype=torch.int64).pin_memory()
+        cnt_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+        wsb = lib.bds_union_slots_workspace_bytes(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        L.check(lib.bds_union_slots(n, L.ptr(mask), cap, K, L.ptr(row_map), L.ptr(ids), *[L.ptr(b) for b in bufs], L.ptr(ws), wsb,
+                                    L.ptr(cnt_dev), cnt.data_ptr(), L.stream()), "bds_union_slots")
+        torch.cuda.synchronize()
+        count = int(mask.sum())
+        assert int(cnt[0]) == count == int(cnt_dev[0])
+        slot = torch.cumsum(mask, 0, dtype=torch.int32) - 1
+        members = mask.nonzero().squeeze(1)
+        assert torch.equal(row_map[members], slot[members].clamp(max=cap - 1))
+        kept = min(count, cap)
+        assert torch.equal(ids[:kept], members[:kept].to(torch.int32)) and bool((ids[kept:] == -1).all())
+        for b in bufs:
+            assert float(b[:kept].abs().max()) == 0.0 and (kept == cap or bool((b[kept:] == 7.0).all()))
+
+
 def test_compact_exchange_path_equals_arena_accumulation_single_process():
     Hn, cams, base, grids0, sky, target = _setup("cuda")
     ref = _dense_reference(Hn, [cams], base, grids0, sky, target)
@@ -78,25 +138,29 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, graph=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     Hn, cams, base, grids0, sky, target = _setup("cuda", origin=(1.5 * rank, 0.0, 0.0))
-    outs, fx = _run_frames(Hn, cams, base, grids0, sky, target, force=False)
+    if graph:
+        outs, fx, _ = _run_frames_graph(Hn, cams, base, grids0, sky, target, force=False)
+    else:
+        outs, fx = _run_frames(Hn, cams, base, grids0, sky, target, force=False)
     assert fx.active and fx.world == world
     q.put((rank, [o.cpu().numpy() for o in outs], fx.cap, fx.payload_bytes))   # numpy: a pickled copy, no fd hand-over to wait for
     dist.destroy_process_group()
 
 
-def test_two_ranks_frame_exchange_equals_sequential_sum():
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_frame_exchange_equals_sequential_sum(graph):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])

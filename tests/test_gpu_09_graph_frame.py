@@ -121,7 +121,7 @@ def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
             assert rel_err(vg.v_sky, sky_ref[v]) < 1e-6 and rel_err(vg.v_viewmat, vm_ref[v]) < 1e-4
         for k, t in p.items():
             assert t.grad.data_ptr() == frame.arena[k].data_ptr()
-            assert rel_err(t.grad, g_ref[k]) < 3e-5, (rep, k)
+            assert rel_err(t.grad, g_ref[k]) < 2e-4, (rep, k)   # (float atomics in the compositor backward: the order of the sums varies)
         for i, g in enumerate(grids):
             assert rel_err(g.grad, g_ref[f"grid{i}"]) < 3e-5, (rep, i)
 
