@@ -70,11 +70,11 @@ if sq:
     json.dump({"note": "rocprofv3 --pmc, two passes of 8 SQ counters + GRBM_GUI_ACTIVE, mean per launch; valu_busy_frac = "
                        "4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles)",
                "kernels": sq}, open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1, sort_keys=True)
-for extra in ("valu_rate.txt", "pair_stats.json", "gpu_tests.log", "smoke.log", "step_timeline.txt"):
+for extra in ("valu_rate.txt", "pair_stats.json", "gpu_tests.log", "smoke.log", "step_timeline.txt", "frame_overlap.txt"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
         open(os.path.join(dst, f"{tag}_{extra}"), "w").write(open(p).read())
-for extra in ("bench.json", "trace_bench.json"):
+for extra in ("bench.json", "trace_bench.json", "bench_share2.json"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
         open(os.path.join(dst, f"{tag}_{extra}"), "w").write(open(p).read())
