@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="graph replay: one graph per view on one stream instead of forward / backward graphs on two streams (view v + 1's "
                          "forward next to view v's backward)")
+    ap.add_argument("--bwd-streams", type=int, default=1,
+                    help="graph replay: streams the image halves of consecutive views' backwards alternate between (> 1: the Gaussian "
+                         "halves follow one another on a stream of their own)")
     ap.add_argument("--dense-grads", action="store_true",
                     help="N = 1 only: fresh dense gradient tensors per view (zero fill of all N rows, autograd accumulation) instead of "
                          "the flat gradient buffer whose rows are cleared / written through the visible-id lists")
@@ -278,7 +281,7 @@ def main():
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap, exchange=fx)
+                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams)
         L.enable_timers(False)
 
     def step(s):

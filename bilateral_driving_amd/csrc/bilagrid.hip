@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; q++) t += sred[q][ex];
-    L.v_grid[e] += t;
+    atomicAdd(L.v_grid + e, t);   // (one add per entry and launch; atomic so that another view's backward may run next to this one)
   }
 }
 
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
   if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * scale_y;
   if (il > 0) g += 2.f * (v - x[e - sl]) * scale_l;
   if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * scale_l;
-  v_x[e] += g * v_tv[0];
+  atomicAdd(v_x + e, g * v_tv[0]);
 }
 
 
@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(kBgBlock) void tv_ms_bwd_kernel(TvLevels L, const f
   if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * L.sy[k];
   if (il > 0) g += 2.f * (v - x[e - sl]) * L.sl[k];
   if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * L.sl[k];
-  L.v_x[k][e] += g * v_tv[0];
+  atomicAdd(L.v_x[k] + e, g * v_tv[0]);   // (concurrent views add their TV terms to the same gradient slices)
 }
 
 // ---- host side ---------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ class FrameGraph:
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False,
-                 exchange=None):
+                 exchange=None, bwd_streams: int = 1):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -77,6 +77,9 @@ class FrameGraph:
         the per-Gaussian gradient rows -- on the third when ``overlap_tail`` is set, else behind their image halves on the caller's
         stream (same accumulation order either way: same numbers).  Measured on MI355X, 2 M Gaussians / six 1080p views: one stream
         782 it/s, forwards on a second stream 885, Gaussian halves on a third 875 -- the default is two.
+        ``bwd_streams`` > 1 (implies ``overlap_tail``): the image halves of consecutive views alternate between that many streams, so
+        that view v + 1's bilateral backward (gather-latency-bound) runs next to view v's compositor backward (VALU-bound); the
+        grids' gradient slices are accumulated with atomics for that.
         ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU: one process per GPU, every rank its own frame).
         The per-view collectives -- MAX-all-reduce of the visibility mask after the forward, SUM-all-reduce of the compact gradient
         rows after the Gaussian half -- are enqueued BETWEEN the graphs (RCCL runs them on its own stream next to the following
@@ -89,7 +92,8 @@ class FrameGraph:
         self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         self.headroom = float(headroom)
-        self.overlap, self.overlap_tail = bool(overlap), bool(overlap and overlap_tail)
+        self.n_bwd_streams = max(1, int(bwd_streams)) if overlap else 1
+        self.overlap, self.overlap_tail = bool(overlap), bool(overlap and (overlap_tail or self.n_bwd_streams > 1))
         self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
         self.dev = self.params["means"].device
         L.require_gpu(*self.params.values(), *self.grids)
@@ -234,6 +238,8 @@ class FrameGraph:
         # graphs that share a pool are replayed in capture order on ONE stream; the forwards of the overlapped form run on their own
         # stream and therefore get their own pool (a block one graph frees may be handed to the next graph of the same pool)
         self.pool = torch.cuda.graph_pool_handle()
+        self.pools_bwd = [self.pool] + [torch.cuda.graph_pool_handle() for _ in range(self.n_bwd_streams - 1)]
+        self.extra_bwd_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_bwd_streams - 1)]
         self.pool_fwd = torch.cuda.graph_pool_handle() if self.overlap else self.pool
         self.pool_tail = torch.cuda.graph_pool_handle() if self.overlap_tail else self.pool
         self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
@@ -258,7 +264,7 @@ class FrameGraph:
             split = self.overlap_tail or self.fx is not None
             for v, (g, out) in enumerate(fwd):
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=self.pool):
+                with torch.cuda.graph(gb, pool=self.pools_bwd[v % self.n_bwd_streams]):
                     out["backward"]()
                     if not split:
                         out["backward_tail"]()
@@ -287,6 +293,7 @@ class FrameGraph:
         self.begin_graph.replay()
         side = None if (serial or not self.overlap) else self.side_stream
         tail = None if (serial or not self.overlap_tail) else self.tail_stream
+        nb = 1 if tail is None else self.n_bwd_streams
         if side is not None:
             # the forwards start once everything enqueued so far (the previous frame's backwards, an optimizer step) is done and the
             # begin graph has read the previous frame's visible-id lists, which the forwards overwrite -- and then run ahead of the
@@ -299,42 +306,40 @@ class FrameGraph:
                     if fx is not None:
                         fx.static_begin_view(v, vg.out["union_mask"])   # (RCCL orders the mask's all-reduce behind this stream)
                     vg.fwd_done.record(side)
+            for bs in self.extra_bwd_streams[:nb - 1]:
+                bs.wait_event(self._frame_ready)
         for v, vg in enumerate(self.views):
+            # ---- forward (already on its way in the overlapped form)
             if side is None:
                 vg.graph.replay()
                 if fx is not None:
                     fx.static_begin_view(v, vg.out["union_mask"])
-            else:
-                main.wait_event(vg.fwd_done)
-            vg.graph_bwd.replay()       # image half: needs nothing from the other ranks
-            if tail is None:
+            # ---- image half of the backward: needs nothing from the other ranks
+            bs = main if v % nb == 0 else self.extra_bwd_streams[v % nb - 1]
+            if side is not None:
+                bs.wait_event(vg.fwd_done)
+            with torch.cuda.stream(bs):
+                vg.graph_bwd.replay()
+                if tail is not None:
+                    vg.bwd_done.record(bs)
+            # ---- Gaussian half: the only writer of the per-Gaussian gradient rows, one view after the other
+            ts = main if tail is None else tail
+            if tail is not None:
+                tail.wait_event(vg.bwd_done)
+            with torch.cuda.stream(ts):
                 if fx is not None:
                     fx.static_targets(v)    # waits for the union mask; slot map + cleared buffer rows (two launches)
                 if vg.graph_tail is not None:
                     vg.graph_tail.replay()
                 if fx is not None:
-                    fx.static_end_view(v)   # all-reduce of view v's rows (async), reduced rows of view v - 1 added to the dense buffer
-                vg.done.record(main)
-                continue
-            vg.bwd_done.record(main)
-            tail.wait_event(vg.bwd_done)
-            with torch.cuda.stream(tail):
-                if fx is not None:
-                    fx.static_targets(v)
-                vg.graph_tail.replay()
-                if fx is not None:
-                    fx.static_end_view(v)
-                vg.done.record(tail)
+                    fx.static_end_view(v)   # all-reduce of view v's rows (async); reduced rows of view v - 1 added to the dense buffer
+                if v == self.V - 1 and fx is not None:
+                    fx.static_end_frame()
+                vg.done.record(ts)
         if tail is not None:
             main.wait_event(self.views[-1].done)     # the frame's gradients are complete for whatever the caller enqueues next
-            if fx is not None:
-                with torch.cuda.stream(tail):
-                    fx.static_end_frame()
-                    self.views[-1].done.record(tail)
-                main.wait_event(self.views[-1].done)
-        elif fx is not None:
-            fx.static_end_frame()
-            self.views[-1].done.record(main)
+            for bs in self.extra_bwd_streams[:nb - 1]:
+                main.wait_stream(bs)
 
     def mark_samples(self, name: str):
         """Milliseconds of every timing mark pair ``name`` captured into the view graphs (``_lib.enable_timers`` on during the
