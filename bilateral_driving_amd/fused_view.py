@@ -10,6 +10,7 @@ issues ~25 launches of libbds.so kernels back to back, so the step is bound by t
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import weakref
@@ -364,7 +365,7 @@ class _FusedView(torch.autograd.Function):
         ctx.v_rec_all = v_rec_all
         rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
-        ctx.list_tile = f.list_tile
+        ctx.list_tile = f_list_tile = f.list_tile
         del f
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         with L.timed("bilagrid_fwd"):
@@ -383,6 +384,13 @@ class _FusedView(torch.autograd.Function):
                 v_sel = v_g if idx is None else [None if v is None else v[idx:idx + 1] for v in v_g]
                 ctx.bwd_pre = (v_g, _levels_struct(sel, v_sel, cfg["factors"]), sel, _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev),
                                _empty((H, W, 3), dev) if ctx.needs_input_grad[6] else None)
+        # Work of the backward that depends on the forward's outputs only is done HERE when a backward will follow: the longest-tile-
+        # first schedule of the compositor's backward and the zeroed dense screen-space gradient arrays.  In the graph-replayed frame
+        # the forward runs on a stream of its own next to the previous view's backward, which is the critical chain.
+        ctx.order = ctx.g2d = None
+        if any(ctx.needs_input_grad[1:]):
+            ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
+            ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         ctx.cfg = cfg
         ctx.M = M
         ctx.n_grids = len(grids)
@@ -472,7 +480,9 @@ class _FusedView(torch.autograd.Function):
                                     dtype=torch.float32)
         v_rec = v_rec_all[:max(n_vis, 1)]
         LT = ctx.list_tile
-        order = ops.bwd_schedule(1, W, H, LT, isect_offsets, last_ids)
+        order = getattr(ctx, "order", None)
+        if order is None:
+            order = ops.bwd_schedule(1, W, H, LT, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
             if dev_counts is not None:
                 L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
@@ -487,7 +497,9 @@ class _FusedView(torch.autograd.Function):
         yield
         lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
         # dense screen-space gradient + its absolute sum for the densification statistics (zeros for culled Gaussians, as gsplat)
-        g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
+        g2d, ctx.g2d = getattr(ctx, "g2d", None), None
+        if g2d is None:
+            g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         arena = cfg.get("grad_arena") or {}
         # arena modes (need all five per-Gaussian arena entries): 1 = store the visible rows into an arena the caller keeps zero
         # elsewhere, 2 = add them to an arena that already is the parameters' .grad (several views summed before one exchange)
@@ -510,7 +522,15 @@ class _FusedView(torch.autograd.Function):
             return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
 
         v_sh = out_like("sh", sh)
-        with L.timed("sh_bwd"):
+        # the SH and the projection backward read the same gradient records and write different arrays: with `tail_fork_stream` (a
+        # torch stream; graph_view) the SH half is forked onto it and joined behind the projection half -- two HBM / latency-bound
+        # kernels next to each other instead of one after the other
+        fork = cfg.get("tail_fork_stream")
+        cur_stream = torch.cuda.current_stream(dev)
+        if fork is not None:
+            fork.wait_stream(cur_stream)
+        with (torch.cuda.stream(fork) if fork is not None else contextlib.nullcontext()), L.timed("sh_bwd"):
+            st = L.stream()
             if dev_counts is not None:
                 L.check(lib.bds_sh_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos),
                                                      L.ptr(sh_rgb), 0, L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map), int(rows == 2), st),
@@ -519,6 +539,7 @@ class _FusedView(torch.autograd.Function):
                 L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
                                                  int(bool(getattr(ctx, "sh_by_rank", False))), L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map),
                                                  int(rows == 2), st), "bds_sh_view_bwd_list")
+        st = L.stream()
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
@@ -535,6 +556,8 @@ class _FusedView(torch.autograd.Function):
                                                       L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
                                                       L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
                                                       L.ptr(row_map), int(rows == 2), st), "bds_project_view_bwd_list")
+        if fork is not None:
+            cur_stream.wait_stream(fork)
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]
@@ -717,6 +740,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     grad_sink = kwargs.pop("grad_sink", None)
     list_tile, front, caps = kwargs.pop("list_tile", None), kwargs.pop("front", None), kwargs.pop("caps", None)
     prep_ws, two_phase = kwargs.pop("prep_ws", None), bool(kwargs.pop("two_phase", False))
+    tail_fork_stream = kwargs.pop("tail_fork_stream", None)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
     assert not kwargs, f"unknown arguments {sorted(kwargs)}"
@@ -724,7 +748,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sh_degree=int(opts["sh_degree"]), near_plane=float(opts["near_plane"]), far_plane=float(opts["far_plane"]),
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
-               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws)
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws,
+               tail_fork_stream=tail_fork_stream)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
@@ -748,17 +773,18 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
         gg = None if grid_grads is None else list(grid_grads)
         loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
+        # ... and its backward with d(loss) = 1 right away: it needs nothing but the forward's image (the TV term's gradient is added
+        # to the grids' gradient slices with atomics, so it may run next to another view's backward)
+        one = _ONES.get(rgb.device)
+        if one is None:
+            one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
+        lg = _PhotometricTV.backward(lctx, one)
     out = _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
 
-    state = {}
+    state = {"v_tv_grids": lg[4:]}
 
-    def backward():          # loss backward + image half of the view's backward
+    def backward():          # image half of the view's backward
         with torch.no_grad():
-            one = _ONES.get(rgb.device)
-            if one is None:
-                one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
-            lg = _PhotometricTV.backward(lctx, one)
-            state["v_tv_grids"] = lg[4:]
             state["steps"] = _FusedView.backward_steps(ctx, lg[0], None, None, None, None)
             next(state["steps"])
 

@@ -65,7 +65,7 @@ class FrameGraph:
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False,
-                 exchange=None, bwd_streams: int = 1):
+                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -80,6 +80,9 @@ class FrameGraph:
         ``bwd_streams`` > 1 (implies ``overlap_tail``): the image halves of consecutive views alternate between that many streams, so
         that view v + 1's bilateral backward (gather-latency-bound) runs next to view v's compositor backward (VALU-bound); the
         grids' gradient slices are accumulated with atomics for that.
+        ``fork_tail``: inside the captured backward the SH half of the Gaussian backward forks onto another stream next to the
+        projection half (a graph with parallel branches).  Measured: 772 vs 909 it/s without -- the HIP graph executor serialises badly
+        around a fork / join; off.
         ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU: one process per GPU, every rank its own frame).
         The per-view collectives -- MAX-all-reduce of the visibility mask after the forward, SUM-all-reduce of the compact gradient
         rows after the Gaussian half -- are enqueued BETWEEN the graphs (RCCL runs them on its own stream next to the following
@@ -124,6 +127,8 @@ class FrameGraph:
         # frame's begin graph clears exactly those gradient rows).  Zero-initialised: "no rows yet".
         self.prep_ws = [torch.zeros(max(self._ws_bytes, 16), device=self.dev, dtype=torch.uint8) for _ in range(self.V)]
         self._unions = [0] * self.V
+        # (inside the captured backward: the SH half of the Gaussian backward forks onto this stream, see fused_view.backward_steps)
+        self._fork_stream = torch.cuda.Stream(device=self.dev) if fork_tail else None
         self.calibrate()
         self.capture()
 
@@ -153,7 +158,7 @@ class FrameGraph:
     # ---- the phases of a view (eager warm-up, capture and replay walk the same protocol) -------------------------------------------
     def _view_kwargs(self, v: int) -> dict:
         kw = dict(factors=self.factors, tv_weight=self.tv_weight, caps=self.caps[v], prep_ws=self.prep_ws[v], list_tile=self.list_tile,
-                  sh_degree=self.sh_degree, two_phase=True)
+                  sh_degree=self.sh_degree, two_phase=True, tail_fork_stream=self._fork_stream)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
         else:
