@@ -88,6 +88,7 @@ def parse():
                          "forward next to view v's backward)")
     ap.add_argument("--fork-tail", action="store_true", help="graph replay: SH backward forked next to the projection backward inside the "
                                                              "captured graph (measured slower: 772 vs 909 it/s)")
+    ap.add_argument("--late-image", action="store_true", help="graph replay: colour transform + loss captured with the backward instead of the forward")
     ap.add_argument("--bwd-streams", type=int, default=1,
                     help="graph replay: streams the image halves of consecutive views' backwards alternate between (> 1: the Gaussian "
                          "halves follow one another on a stream of their own)")
@@ -244,6 +245,9 @@ def main():
     L.lib()  # fail loudly if libbds.so is missing
     if os.environ.get("BDS_DEBUG_OPTION"):   # kernel A/B hooks (include/bds.h: option 3), measurement sessions only
         L.set_option(3, int(os.environ["BDS_DEBUG_OPTION"]))
+    for env, which in (("BDS_PAD_BWD_KB", 1), ("BDS_PAD_FWD_KB", 2)):   # (tuning hooks: cap the compositors' resident waves)
+        if os.environ.get(env):
+            L.set_option(which, int(os.environ[env]))
     wl = dict(WORKLOADS[args.workload])
     N = args.gaussians or wl["gaussians"]
     W, H = args.width or wl["width"], args.height or wl["height"]
@@ -283,7 +287,7 @@ def main():
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail)
+                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail, late_image=args.late_image)
         L.enable_timers(False)
 
     def step(s):

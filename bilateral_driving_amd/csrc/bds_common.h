@@ -100,7 +100,8 @@ __device__ __forceinline__ float butterfly_sum16(const float *v, int lane) {
 }
 
 // test hooks (bds_set_option): force the large-input fallback paths of the tile stage; see include/bds.h
-enum Option { kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptStripRows = 5 /* tuning: rows per band of
+enum Option { kOptPadBwd = 1 /* tuning: KB of unused LDS per workgroup of the compositor backward */, kOptPadFwd = 2 /* ... forward */,
+              kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptStripRows = 5 /* tuning: rows per band of
                the bilateral strip kernels, 0 = default */, kOptPacked = 6, kOptStrips = 7 /* bilateral column strips: 1 = forward, 2 = backward */, kOptCount = 8 };
 int option_get(int which);
 

@@ -645,8 +645,11 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
+  // (tuning hook: unused dynamic LDS per workgroup caps the resident waves of this VALU-bound kernel, which leaves wave slots to the
+  // kernels of a concurrent stream: bds_set_option(2, KB))
+  const size_t pad_fwd = (size_t)option_get(kOptPadFwd) * 1024u;
 #define BDS_FWD(ch, co)                                                                                                              \
-  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
+  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), pad_fwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
                      tile_h, isect_offsets, flatten, render, alphas, last_ids, lg)
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
@@ -696,10 +699,11 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
+  const size_t pad_bwd = (size_t)option_get(kOptPadBwd) * 1024u;   // (see bds_rasterize_fwd: bds_set_option(1, KB))
   // (kStrip = false: measured on the benchmark scene, skipping untouched 16 x 4 strips costs the backward 3 % -- its per-pixel
   // body is long enough that the extra control flow outweighs the ~19 % of strips it would skip; the forward gains 7 %)
 #define BDS_BWD(ch, ab, co)                                                                                                                 \
-  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
+  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
                      tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg)
 #define BDS_BWD_CH(ab, co)            \
   do {                                \

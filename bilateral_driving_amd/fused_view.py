@@ -202,9 +202,12 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
         sh_rgb, colors = None, None        # evaluated by the record pack, for the visible Gaussians only (_composite)
     else:
         sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
-        with L.timed("sh_fwd"):
-            L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
-                                        L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
+        if caps is None or os.environ.get("BDS_SH_BEFORE_BUILD") == "1":
+            with L.timed("sh_fwd"):
+                L.check(lib.bds_sh_view_fwd(N, K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh), L.ptr(radii), L.ptr(depths),
+                                            L.ptr(sh_rgb), L.ptr(colors), st), "bds_sh_view_fwd")
+        # (device-count form: nobody waits, and the SH pass is enqueued BEHIND the list build -- _front_finish_dev: next to another
+        # stream's compositor backward the build's five small launches crawl, a streaming pass over the coefficients does not)
     key = (N, W, H, bool(cull), LT)
     cap = _LIST_CAPACITY.get(key, 0) if caps is None else caps.m_cap
     buf, ws2, ws2_bytes = None, None, 0
@@ -278,6 +281,10 @@ def _front_finish_dev(f: _Front) -> _Front:
         L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
                                         f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
                                         L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
+    if f.colors is not None and os.environ.get("BDS_SH_BEFORE_BUILD") != "1":
+        with L.timed("sh_fwd"):
+            L.check(lib.bds_sh_view_fwd(N, f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh), L.ptr(f.radii),
+                                        L.ptr(f.depths), L.ptr(f.sh_rgb), L.ptr(f.colors), st), "bds_sh_view_fwd")
     f.buf = f.ws2 = None
     f.M, f.n_vis = M, n_vis
     base = f.ws.data_ptr()
@@ -335,6 +342,18 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
 class _FusedView(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, viewmat, *grids):
+        steps = _FusedView.forward_steps(ctx, cfg, means, quats, log_scales, logits, sh, sky, viewmat, *grids)
+        next(steps)                      # Gaussian half: projection, lists, SH, compositor
+        try:
+            next(steps)                  # image half: expected depth, clamp, sky blend, bilateral transform
+        except StopIteration as done:
+            return done.value
+        raise AssertionError("forward_steps yields once")
+
+    @staticmethod
+    def forward_steps(ctx, cfg: dict, means, quats, log_scales, logits, sh, sky, viewmat, *grids):
+        """The forward as a generator that yields ONCE (the projection's radii), between the compositor and the colour transform:
+        ``graph_view`` may replay the second half -- with the loss and the backward's image half -- on the backward's stream."""
         L.require_gpu(means, quats, log_scales, logits, sh, sky, viewmat, *grids)
         lib, st = L.lib(), L.stream()
         dev = means.device
@@ -367,6 +386,15 @@ class _FusedView(torch.autograd.Function):
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f_list_tile = f.list_tile
         del f
+        # Work of the backward that depends on the compositor's outputs only is done HERE when a backward will follow: the longest-
+        # tile-first schedule of the compositor's backward and the zeroed dense screen-space gradient arrays.  In the graph-replayed
+        # frame this half runs on a stream of its own next to the previous view's backward, which is the critical chain.
+        ctx.order = ctx.g2d = None
+        if any(ctx.needs_input_grad[1:]):
+            ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
+            ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
+        yield radii
+        lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         with L.timed("bilagrid_fwd"):
             L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
@@ -384,13 +412,6 @@ class _FusedView(torch.autograd.Function):
                 v_sel = v_g if idx is None else [None if v is None else v[idx:idx + 1] for v in v_g]
                 ctx.bwd_pre = (v_g, _levels_struct(sel, v_sel, cfg["factors"]), sel, _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev),
                                _empty((H, W, 3), dev) if ctx.needs_input_grad[6] else None)
-        # Work of the backward that depends on the forward's outputs only is done HERE when a backward will follow: the longest-tile-
-        # first schedule of the compositor's backward and the zeroed dense screen-space gradient arrays.  In the graph-replayed frame
-        # the forward runs on a stream of its own next to the previous view's backward, which is the critical chain.
-        ctx.order = ctx.g2d = None
-        if any(ctx.needs_input_grad[1:]):
-            ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
-            ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         ctx.cfg = cfg
         ctx.M = M
         ctx.n_grids = len(grids)
@@ -730,8 +751,10 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     them: per-Gaussian rows in ``grad_arena`` (``arena_rows``) or in ``param.grad``; the grids' in ``grid_grads`` / ``.grad``;
     ``sky.grad``, ``viewmat.grad`` accumulated.  Accepts the keyword arguments of ``fused_view``; ``after_forward(info)`` is called
     between the forward and the backward pass (``dist.FrameExchange.begin_view`` starts its visibility exchange there).
-    ``two_phase=True``: only the forward + loss value are enqueued; the returned dict carries ``backward`` and ``backward_tail``,
-    callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
+    ``two_phase=True``: only the forward, the loss value and the loss gradient are enqueued; the returned dict carries ``backward``
+    and ``backward_tail``, callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  With
+    ``late_image=True`` the first call stops behind the compositor (``forward_steps``): the colour transform and the loss move into
+    ``backward`` and the dict's image entries appear when it has run.  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
     from .losses import _PhotometricTV
     cam_pos = kwargs.pop("cam_pos", None)
     if cam_pos is None:
@@ -740,6 +763,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     grad_sink = kwargs.pop("grad_sink", None)
     list_tile, front, caps = kwargs.pop("list_tile", None), kwargs.pop("front", None), kwargs.pop("caps", None)
     prep_ws, two_phase = kwargs.pop("prep_ws", None), bool(kwargs.pop("two_phase", False))
+    late_image = bool(kwargs.pop("late_image", False)) and two_phase
     tail_fork_stream = kwargs.pop("tail_fork_stream", None)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
@@ -756,12 +780,20 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                                     and g.grad.data_ptr() == grad_arena[f"grid{i}"].data_ptr() for i, g in enumerate(gs))
     names = ("means", "quats", "log_scales", "opacity_logits", "sh")
     leaves = [params[k] for k in names]
-    with torch.no_grad():
-        needs = (False, *[bool(t.requires_grad) for t in leaves], bool(sky.requires_grad), bool(viewmat.requires_grad),
-                 *[bool(g.requires_grad) for g in gs])
-        ctx = _DirectCtx(needs)
-        (rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ranks, isect_offsets,
-         vis_ids) = _FusedView.forward(ctx, cfg, *leaves, sky, viewmat, *gs)
+    needs = (False, *[bool(t.requires_grad) for t in leaves], bool(sky.requires_grad), bool(viewmat.requires_grad),
+             *[bool(g.requires_grad) for g in gs])
+    ctx = _DirectCtx(needs)
+    state = {}
+    out = _Out()
+
+    def image_half(fsteps):
+        """Second half of the forward (colour transform), the L1 + TV loss and its backward with d(loss) = 1 (the TV term's gradient
+        is added to the grids' gradient slices with atomics, so it may run next to another view's backward)."""
+        try:
+            next(fsteps)
+            raise AssertionError("forward_steps yields once")
+        except StopIteration as done:
+            (rgb, depth, opacity, rgb_g, means2d, radii, tiles_per_gauss, flatten_ranks, isect_offsets, vis_ids) = done.value
         cfg["_means2d_ref"] = weakref.ref(means2d)
         info = _Info({"means2d": means2d, "radii": radii, "width": int(width), "height": int(height), "tiles_per_gauss": tiles_per_gauss,
                       "flatten_ranks": flatten_ranks, "visible_ids": vis_ids, "isect_offsets": isect_offsets,
@@ -769,23 +801,27 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                       "n_visible": int(vis_ids.numel())})
         if after_forward is not None:
             after_forward(info)
-        # loss: forward (its backward, with d(loss) = 1, opens the second half)
         lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
         gg = None if grid_grads is None else list(grid_grads)
         loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
-        # ... and its backward with d(loss) = 1 right away: it needs nothing but the forward's image (the TV term's gradient is added
-        # to the grids' gradient slices with atomics, so it may run next to another view's backward)
         one = _ONES.get(rgb.device)
         if one is None:
             one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
         lg = _PhotometricTV.backward(lctx, one)
-    out = _Out(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
+        state["v_rgb"], state["v_tv_grids"] = lg[0], lg[4:]
+        out.update(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
 
-    state = {"v_tv_grids": lg[4:]}
+    with torch.no_grad():
+        fsteps = _FusedView.forward_steps(ctx, cfg, *leaves, sky, viewmat, *gs)
+        out["radii"] = next(fsteps)          # (available before the colour transform: the exchange's visibility mask)
+        if not late_image:
+            image_half(fsteps)
 
-    def backward():          # image half of the view's backward
+    def backward():          # (late_image: colour transform + loss first) image half of the view's backward
         with torch.no_grad():
-            state["steps"] = _FusedView.backward_steps(ctx, lg[0], None, None, None, None)
+            if late_image:
+                image_half(fsteps)
+            state["steps"] = _FusedView.backward_steps(ctx, state["v_rgb"], None, None, None, None)
             next(state["steps"])
 
     def backward_tail():     # Gaussian half; gradients land where autograd would put them

@@ -26,6 +26,7 @@ fact, grow the capacities (never shrink) and capture again.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -65,7 +66,7 @@ class FrameGraph:
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False,
-                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False):
+                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False, late_image: bool = False):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -83,6 +84,8 @@ class FrameGraph:
         ``fork_tail``: inside the captured backward the SH half of the Gaussian backward forks onto another stream next to the
         projection half (a graph with parallel branches).  Measured: 772 vs 909 it/s without -- the HIP graph executor serialises badly
         around a fork / join; off.
+        ``late_image``: the forward graph stops behind the compositor; the colour transform (expected depth, clamp, sky blend,
+        bilateral transform) and the loss are captured in front of the backward's image half instead (on the backward's stream).
         ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU: one process per GPU, every rank its own frame).
         The per-view collectives -- MAX-all-reduce of the visibility mask after the forward, SUM-all-reduce of the compact gradient
         rows after the Gaussian half -- are enqueued BETWEEN the graphs (RCCL runs them on its own stream next to the following
@@ -95,6 +98,7 @@ class FrameGraph:
         self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         self.headroom = float(headroom)
+        self.late_image = bool(late_image)
         self.n_bwd_streams = max(1, int(bwd_streams)) if overlap else 1
         self.overlap, self.overlap_tail = bool(overlap), bool(overlap and (overlap_tail or self.n_bwd_streams > 1))
         self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
@@ -158,7 +162,7 @@ class FrameGraph:
     # ---- the phases of a view (eager warm-up, capture and replay walk the same protocol) -------------------------------------------
     def _view_kwargs(self, v: int) -> dict:
         kw = dict(factors=self.factors, tv_weight=self.tv_weight, caps=self.caps[v], prep_ws=self.prep_ws[v], list_tile=self.list_tile,
-                  sh_degree=self.sh_degree, two_phase=True, tail_fork_stream=self._fork_stream)
+                  sh_degree=self.sh_degree, two_phase=True, tail_fork_stream=self._fork_stream, late_image=self.late_image)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
         else:
@@ -170,7 +174,7 @@ class FrameGraph:
         out = Hn.train_view(self.params, self.cams[v], self.grids, self.img_indices[v], self.skies[v], self.targets[v],
                             **self._view_kwargs(v))
         if self.fx is not None:
-            out["union_mask"] = (out["info"]["radii"].reshape(-1) > 0).to(torch.uint8)
+            out["union_mask"] = (out["radii"].reshape(-1) > 0).to(torch.uint8)
         return out
 
     def _point_grads_at_flat(self) -> None:
@@ -247,7 +251,11 @@ class FrameGraph:
         self.extra_bwd_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_bwd_streams - 1)]
         self.pool_fwd = torch.cuda.graph_pool_handle() if self.overlap else self.pool
         self.pool_tail = torch.cuda.graph_pool_handle() if self.overlap_tail else self.pool
-        self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        # HIGH priority for the forwards' stream: its kernels are mostly small and latency-bound (the tile stage's ~20 launches); at
+        # equal priority their workgroups queue behind the thousands of pending workgroups of the other stream's compositor backward
+        # (measured with in-graph timing marks, scripts/overlap_timeline.py: the 60 us list build took 370 us next to it)
+        prio = int(os.environ.get("BDS_FWD_STREAM_PRIORITY", "-1"))
+        self.side_stream = torch.cuda.Stream(device=self.dev, priority=prio) if self.overlap else None
         self.tail_stream = torch.cuda.Stream(device=self.dev) if self.overlap_tail else None
         self._frame_ready = torch.cuda.Event()
         outer, L.GRAPH_MARKS = L.GRAPH_MARKS, {}     # timing marks captured into THESE graphs (when _lib timers are enabled)
