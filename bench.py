@@ -88,7 +88,9 @@ def parse():
                          "forward next to view v's backward)")
     ap.add_argument("--fork-tail", action="store_true", help="graph replay: SH backward forked next to the projection backward inside the "
                                                              "captured graph (measured slower: 772 vs 909 it/s)")
-    ap.add_argument("--late-image", action="store_true", help="graph replay: colour transform + loss captured with the backward instead of the forward")
+    ap.add_argument("--late-image", nargs="?", const="image", default=None, choices=["image", "front"],
+                    help="graph replay: colour transform + loss (image) or everything behind the tile lists (front) captured with the "
+                         "backward instead of the forward")
     ap.add_argument("--bwd-streams", type=int, default=1,
                     help="graph replay: streams the image halves of consecutive views' backwards alternate between (> 1: the Gaussian "
                          "halves follow one another on a stream of their own)")
@@ -287,7 +289,7 @@ def main():
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail, late_image=args.late_image)
+                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail, late_image={None: False, "image": True, "front": "front"}[args.late_image])
         L.enable_timers(False)
 
     def step(s):

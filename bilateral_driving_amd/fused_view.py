@@ -382,6 +382,10 @@ class _FusedView(torch.autograd.Function):
         if f.m_dev is not None:
             v_rec_all = _empty((f.n_vis + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS), dev)
         ctx.v_rec_all = v_rec_all
+        early = bool(cfg.get("yield_after_front"))
+        if early:                          # (the generator's one stop: behind the front, or -- default -- behind the compositor)
+            yield radii
+            lib, st = L.lib(), L.stream()
         rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f_list_tile = f.list_tile
@@ -393,8 +397,9 @@ class _FusedView(torch.autograd.Function):
         if any(ctx.needs_input_grad[1:]):
             ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
             ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
-        yield radii
-        lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
+        if not early:
+            yield radii
+            lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         with L.timed("bilagrid_fwd"):
             L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
@@ -763,7 +768,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     grad_sink = kwargs.pop("grad_sink", None)
     list_tile, front, caps = kwargs.pop("list_tile", None), kwargs.pop("front", None), kwargs.pop("caps", None)
     prep_ws, two_phase = kwargs.pop("prep_ws", None), bool(kwargs.pop("two_phase", False))
-    late_image = bool(kwargs.pop("late_image", False)) and two_phase
+    late_image = kwargs.pop("late_image", False)      # False | True (stop behind the compositor) | "front" (stop behind the lists)
+    late_image = late_image if two_phase else False
     tail_fork_stream = kwargs.pop("tail_fork_stream", None)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
@@ -773,7 +779,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws,
-               tail_fork_stream=tail_fork_stream)
+               tail_fork_stream=tail_fork_stream, yield_after_front=late_image == "front")
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None

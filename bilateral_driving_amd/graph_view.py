@@ -84,7 +84,8 @@ class FrameGraph:
         ``fork_tail``: inside the captured backward the SH half of the Gaussian backward forks onto another stream next to the
         projection half (a graph with parallel branches).  Measured: 772 vs 909 it/s without -- the HIP graph executor serialises badly
         around a fork / join; off.
-        ``late_image``: the forward graph stops behind the compositor; the colour transform (expected depth, clamp, sky blend,
+        ``late_image``: True: the forward graph stops behind the compositor; "front": behind the tile lists (the compositor's forward
+        moves too); the colour transform (expected depth, clamp, sky blend,
         bilateral transform) and the loss are captured in front of the backward's image half instead (on the backward's stream).
         ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU: one process per GPU, every rank its own frame).
         The per-view collectives -- MAX-all-reduce of the visibility mask after the forward, SUM-all-reduce of the compact gradient
@@ -98,7 +99,7 @@ class FrameGraph:
         self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         self.headroom = float(headroom)
-        self.late_image = bool(late_image)
+        self.late_image = late_image if late_image == "front" else bool(late_image)
         self.n_bwd_streams = max(1, int(bwd_streams)) if overlap else 1
         self.overlap, self.overlap_tail = bool(overlap), bool(overlap and (overlap_tail or self.n_bwd_streams > 1))
         self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
