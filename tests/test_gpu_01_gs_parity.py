@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import gs_oracle as G
-from tests.util import make_scene, rel_err
+from tests.util import grad_errors, make_scene, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -316,6 +316,10 @@ def test_rasterization_end_to_end(ops, seed, N, W, H, mode):
     rc, ac = r[0].cpu().double(), a[0].cpu().double()
     err = (rc - r_ref[0]).abs() / r_ref[0].abs().clamp(min=1.0)
     assert float(err[stable].max()) < 1e-4, float(err[stable].max())
+    # ... and TRULY relative wherever the value is not tiny (the bound above is absolute for values below 1)
+    sizable = stable[..., None] & (r_ref[0].abs() > 1e-2)
+    relerr = ((rc - r_ref[0]).abs() / r_ref[0].abs().clamp(min=1e-2))[sizable]
+    assert float(relerr.max()) < 2e-4, float(relerr.max())   # measured: <= 1.2e-4 (an absolute 2e-6 on a value of 0.015)
     assert float((ac - a_ref[0]).abs()[stable].max()) < 1e-4
     assert float(a_ref.mean()) > 0.3
     # gradients: loss restricted to stable pixels
@@ -324,9 +328,12 @@ def test_rasterization_end_to_end(ops, seed, N, W, H, mode):
         if gref is None:  # e.g. colours in depth-only modes
             assert gpu_in[k].grad is None or float(gpu_in[k].grad.abs().max()) == 0.0
             continue
-        got = gpu_in[k].grad.cpu().double()
-        rel = float((got - gref).norm() / gref.norm())
+        rel, elem, elem99 = grad_errors(gpu_in[k].grad, gref)
         assert rel < 1e-3, (k, rel)
+        # element-wise, next to the norm bound (entries above 1e-3 of the largest one): 99 % of them to 5e-3, the worst to 3e-2
+        # (measured over the five cases: 99th percentile <= 2.3e-3, worst 1.4e-2, both on a position gradient -- a sum of
+        # cancelling per-pixel terms)
+        assert elem99 < 5e-3 and elem < 3e-2, (k, elem99, elem)
     # absgrad (trainers/base.py:280-297 -> gaussians/vanilla.py:163-191 drive split / duplicate with it): the VALUE against the
     # oracle's sum over pixels of |dL/dmean2d through that pixel|, on the same tensor object the caller holds
     assert hasattr(meta["means2d"], "absgrad") and meta["means2d"].absgrad.shape == meta["means2d"].shape

@@ -174,7 +174,8 @@ def test_views_of_a_frame_accumulate_into_the_arena(ops):
         assert float((got - ref).norm() / ref.norm()) < 1e-4, frame
 
 
-@pytest.mark.parametrize("N,W,H,seed,pull", [(1000, 256, 256, 0, 0.25), (3000, 320, 200, 1, 0.3), (400, 75, 50, 2, 0.2)])
+@pytest.mark.parametrize("N,W,H,seed,pull", [(1000, 256, 256, 0, 0.25), (3000, 320, 200, 1, 0.3), (400, 75, 50, 2, 0.2),
+                                             (50_000, 640, 360, 3, 0.6)])   # (the last: ~1 min of float64 oracle on the host)
 def test_fused_view_against_oracle_incl_pose_gradient_and_absgrad(ops, N, W, H, seed, pull):
     """The fused view (what bench.py times) against the float64 oracle: image 1e-4 rel, all gradients incl. the camera-pose
     gradient and the VALUE of info["means2d"].absgrad 1e-3-class; retain_grad() on info["means2d"] as trainers/base.py:429-430 does."""

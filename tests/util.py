@@ -37,6 +37,18 @@ def make_scene(N, W, H, seed=0, dtype=torch.float32, device="cpu", fov_deg=70.0,
     return {k: v.to(dtype).to(device) for k, v in out.items()}
 
 
+def grad_errors(got, ref, floor=1e-3):
+    """(norm-relative error, largest and 99th-percentile ELEMENT-wise relative error over the elements whose reference magnitude is
+    above `floor` x the largest one -- below that a gradient entry is a sum of cancelling terms and its relative error says nothing)."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    nrm = float((got - ref).norm() / ref.norm().clamp(min=1e-300))
+    big = ref.abs() > floor * ref.abs().max()
+    if not bool(big.any()):
+        return nrm, 0.0, 0.0
+    e = ((got - ref).abs() / ref.abs().clamp(min=1e-300))[big]
+    return nrm, float(e.max()), float(torch.quantile(e, 0.99)) if e.numel() < 16_000_000 else float(e.kthvalue(int(0.99 * e.numel())).values)
+
+
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp(min=1e-12))
