@@ -220,34 +220,36 @@ class AffineTransform(nn.Module):
     def __init__(self, class_name: str, n: int, embedding_dim: int = 4, pixel_affine: bool = False, base_mlp_layer_width: int = 64,
                  device="cuda"):
         super().__init__()
-        self.class_prefix = class_name + "#"
-        self.device = device
-        self.embedding_dim = embedding_dim
-        self.pixel_affine = pixel_affine
+        self.class_prefix, self.device = class_name + "#", device
+        self.embedding_dim, self.pixel_affine, self.in_test_set = embedding_dim, pixel_affine, False
+        # state-dict names fixed by the reference's checkpoints: embedding.weight [n, dim], decoder.0 / decoder.2 (Linear, ReLU, Linear)
         self.embedding = nn.Embedding(n, embedding_dim, dtype=torch.float32)
-        input_dim = (embedding_dim + 2) if self.pixel_affine else embedding_dim
-        self.decoder = nn.Sequential(nn.Linear(input_dim, base_mlp_layer_width), nn.ReLU(), nn.Linear(base_mlp_layer_width, 12))
-        self.in_test_set = False
+        code_width = embedding_dim + (2 if pixel_affine else 0)         # per-pixel variant: the pixel coordinates ride along
+        self.decoder = nn.Sequential(nn.Linear(code_width, base_mlp_layer_width), nn.ReLU(), nn.Linear(base_mlp_layer_width, 12))
         self.zero_init()
         self.to(device)
 
     def zero_init(self):
-        torch.nn.init.zeros_(self.embedding.weight)
-        for layer in self.decoder:
-            if isinstance(layer, nn.Linear):
-                torch.nn.init.zeros_(layer.weight)
-                torch.nn.init.zeros_(layer.bias)
+        """Everything zero: the decoder outputs 0 and the transform starts as the identity."""
+        with torch.no_grad():
+            for t in self.parameters():
+                t.zero_()
+
+    def _codes(self, image_infos, lead_shape=None) -> Tensor:
+        """Appearance code per element: the image's own, or -- held-out image / no index -- the mean over all images."""
+        if "img_idx" in image_infos and not self.in_test_set:
+            return self.embedding(image_infos["img_idx"])
+        mean = self.embedding.weight.mean(dim=0)
+        shape = image_infos["viewdirs"].shape[:-1] if lead_shape is None else lead_shape
+        return mean.expand(*shape, self.embedding_dim)
 
     def forward(self, image_infos) -> Tensor:
-        if "img_idx" in image_infos and not self.in_test_set:
-            embedding = self.embedding(image_infos["img_idx"])
-        else:   # mean appearance code (modules.py:247-252)
-            vd = image_infos["viewdirs"]
-            embedding = torch.ones((*vd.shape[:-1], self.embedding_dim), device=vd.device) * self.embedding.weight.mean(dim=0)
+        """[*, 3, 4] per element: decoder(code [, pixel coordinate]) reshaped, plus the identity on the 3x3 part."""
+        x = self._codes(image_infos)
         if self.pixel_affine:
-            embedding = torch.cat([embedding, image_infos["pixel_coords"]], dim=-1)
-        affine = self.decoder(embedding).reshape(*embedding.shape[:-1], 3, 4)
-        return affine + torch.eye(3, 4, device=affine.device)     # adds the identity to the 3x3 part (modules.py:259)
+            x = torch.cat((x, image_infos["pixel_coords"]), dim=-1)
+        ident = torch.eye(3, 4, device=x.device, dtype=x.dtype)
+        return self.decoder(x).unflatten(-1, (3, 4)) + ident
 
     def image_matrix(self, image_infos) -> Tensor:
         """[12] the image's colour matrix (row-major 3x4), decoder evaluated once."""
@@ -454,29 +456,29 @@ class CameraOptModule(nn.Module):
 
     def __init__(self, class_name: str, n: int, device="cuda"):
         super().__init__()
-        self.class_prefix = class_name + "#"
-        self.device = device
-        self.embeds = nn.Embedding(n, 9)
-        self.register_buffer("identity", torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]))
+        self.class_prefix, self.device = class_name + "#", device
+        self.embeds = nn.Embedding(n, 9)                                   # per image: (t, 6-D rotation offset); names fixed by checkpoints
+        self.register_buffer("identity", torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]))   # the 6-D code of "no rotation"
         self.zero_init()
         self.to(device)
 
     def zero_init(self):
-        nn.init.zeros_(self.embeds.weight)
+        with torch.no_grad():
+            self.embeds.weight.zero_()
 
     def random_init(self, std: float):
-        nn.init.normal_(self.embeds.weight, std=std)
+        with torch.no_grad():
+            self.embeds.weight.normal_(0.0, std)
 
     def forward(self, camtoworlds: Tensor, embed_ids: Tensor) -> Tensor:
+        """camtoworlds [*,4,4] x the image's rigid delta [[R_d, t_d], [0, 1]] on the right, written out by blocks instead of
+        assembling the 4x4 delta: the first three columns become A R_d, the last one A t_d + a (A = the first three columns of the
+        input, a = its last column; exact for any 4x4 input)."""
         assert camtoworlds.shape[:-2] == embed_ids.shape
-        batch_shape = camtoworlds.shape[:-2]
-        pose_deltas = self.embeds(embed_ids)
-        dx, drot = pose_deltas[..., :3], pose_deltas[..., 3:]
-        rot = rotation_6d_to_matrix(drot + self.identity.expand(*batch_shape, -1))
-        transform = torch.eye(4, device=pose_deltas.device, dtype=pose_deltas.dtype).repeat((*batch_shape, 1, 1))
-        transform[..., :3, :3] = rot
-        transform[..., :3, 3] = dx
-        return torch.matmul(camtoworlds, transform)
+        delta = self.embeds(embed_ids)
+        R_d = rotation_6d_to_matrix(delta[..., 3:] + self.identity)
+        A, a = camtoworlds[..., :, :3], camtoworlds[..., :, 3:]
+        return torch.cat((A @ R_d, A @ delta[..., :3, None] + a), dim=-1)
 
     def get_param_groups(self):
         return {self.class_prefix + "all": self.parameters()}
