@@ -87,6 +87,7 @@ _SIGS = {
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_ed_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_bilagrid_ms_ed_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_l1_tv_train": (_i, [_i64, _f, _f, _i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _fl, _f, _f, _f]),
     "bds_l1_mean_fwd": (_i, [_i64, _f, _f, _f, _f]),
     "bds_l1_mean_bwd": (_i, [_i64, _f, _f, _f, _f, _f]),
     "bds_ssim_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -1820,6 +1820,66 @@ extern "C" int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const floa
   return BDS_OK;
 }
 
+// ---- L1 + TV training loss, value AND gradient in one launch (the direct step: d(loss) is known to be `v_loss` before the value is) ----
+// loss = mean |a - b| + sum_l w_l TV(grid_l)  (models/trainers/base.py:518-565 rgb term with losses.affine, modules.py:445,466-472);
+// workgroups [0, tv_blocks) own the grids' elements (one element per thread: its forward differences for the value, its full stencil
+// for the gradient, added to v_grid with one atomic), the rest stream the image (|a - b| summed, sign(a - b) * v_loss / n written).
+// Replaces four launches (L1 forward, TV forward, L1 backward, TV backward) that read the image twice.
+__global__ __launch_bounds__(kBgBlock) void l1_tv_train_kernel(TvLevels L, int tv_blocks, int64_t n4, int64_t n,
+                                                              const float4 *__restrict__ a4, const float4 *__restrict__ b4,
+                                                              const float *__restrict__ a, const float *__restrict__ b, float inv_n,
+                                                              float v_loss, float *__restrict__ loss_out, float4 *__restrict__ v_a4,
+                                                              float *__restrict__ v_a) {
+  __shared__ float red[kBgBlock / kWave];
+  float acc = 0.f;
+  if ((int)blockIdx.x < tv_blocks) {
+    int k = 0;
+    while (k + 1 < L.n && (int)blockIdx.x >= L.blk_off[k + 1]) k++;
+    const int64_t e = (int64_t)((int)blockIdx.x - L.blk_off[k]) * kBgBlock + threadIdx.x;
+    if (e < L.total[k]) {
+      const int gx = L.gx[k], gy = L.gy[k], gl = L.gl[k];
+      const float *x = L.x[k];
+      const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
+      const int64_t sl = (int64_t)gx * gy;
+      const float v = x[e];
+      float g = 0.f;
+      if (ix > 0) { const float d = v - x[e - 1]; acc += d * d * L.sx[k]; g += 2.f * d * L.sx[k]; }
+      if (ix < gx - 1) g -= 2.f * (x[e + 1] - v) * L.sx[k];
+      if (iy > 0) { const float d = v - x[e - gx]; acc += d * d * L.sy[k]; g += 2.f * d * L.sy[k]; }
+      if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * L.sy[k];
+      if (il > 0) { const float d = v - x[e - sl]; acc += d * d * L.sl[k]; g += 2.f * d * L.sl[k]; }
+      if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * L.sl[k];
+      if (L.v_x[k]) atomicAdd(L.v_x[k] + e, g * v_loss);
+    }
+  } else {
+    const int64_t nb = (int64_t)gridDim.x - tv_blocks, bid = (int64_t)blockIdx.x - tv_blocks;
+    const float gs = v_loss * inv_n;
+    float s = 0.f;
+    for (int64_t i = bid * kBgBlock + threadIdx.x; i < n4; i += nb * kBgBlock) {
+      const float4 p = a4[i], q = b4[i];
+      const float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+      s += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+      v_a4[i] = make_float4(d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f), d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f),
+                            d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f), d3 > 0.f ? gs : (d3 < 0.f ? -gs : 0.f));   // torch: sign(0) = 0
+    }
+    if (bid == 0 && threadIdx.x < n - n4 * 4) {   // tail (n not a multiple of 4)
+      const int64_t i = n4 * 4 + threadIdx.x;
+      const float d = a[i] - b[i];
+      s += fabsf(d);
+      v_a[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
+    acc = s * inv_n;
+  }
+  acc = wave_sum_all(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBgBlock / kWave; w++) t += red[w];
+    if (t != 0.f) atomicAdd(loss_out, t);
+  }
+}
+
 static int tv_levels_fill(TvLevels &T, int nlevels, const bds_bilagrid_level_t *lv, const float *weights, bool bwd, int cap) {
   BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && lv && weights);
   T.n = nlevels;
@@ -1856,6 +1916,27 @@ extern "C" int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *l
   if (rc != BDS_OK) return rc;
   BDS_REQUIRE(v_tv);
   hipLaunchKernelGGL(tv_ms_bwd_kernel, dim3((unsigned)T.blk_off[nlevels]), dim3(kBgBlock), 0, as_stream(stream), T, v_tv);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_l1_tv_train(int64_t n, const float *a, const float *b, int nlevels, const bds_bilagrid_level_t *levels,
+                               const float *weights, float v_loss, float *loss_out, float *v_a, bds_stream_t stream) {
+  BDS_REQUIRE(n > 0 && a && b && loss_out && v_a && aligned16(a) && aligned16(b) && aligned16(v_a));
+  TvLevels T;
+  T.n = 0; T.blk_off[0] = 0;
+  int tv_blocks = 0;
+  if (nlevels > 0) {
+    int rc = tv_levels_fill(T, nlevels, levels, weights, false, 0);
+    if (rc != BDS_OK) return rc;
+    tv_blocks = T.blk_off[nlevels];
+  }
+  const int64_t n4 = n / 4;
+  int64_t l1_blocks = cdiv(n4 > 0 ? n4 : 1, kBgBlock * 4);
+  if (l1_blocks > 2048) l1_blocks = 2048;
+  hipLaunchKernelGGL(l1_tv_train_kernel, dim3((unsigned)(tv_blocks + l1_blocks)), dim3(kBgBlock), 0, as_stream(stream), T, tv_blocks, n4, n,
+                     reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b), a, b, 1.0f / (float)n, v_loss, loss_out,
+                     reinterpret_cast<float4 *>(v_a), v_a);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -760,7 +760,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     and ``backward_tail``, callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  With
     ``late_image=True`` the first call stops behind the compositor (``forward_steps``): the colour transform and the loss move into
     ``backward`` and the dict's image entries appear when it has run.  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
-    from .losses import _PhotometricTV
+    from .losses import _PhotometricTV, photometric_tv_train
     cam_pos = kwargs.pop("cam_pos", None)
     if cam_pos is None:
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
@@ -807,14 +807,19 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                       "n_visible": int(vis_ids.numel())})
         if after_forward is not None:
             after_forward(info)
-        lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
         gg = None if grid_grads is None else list(grid_grads)
-        loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
-        one = _ONES.get(rgb.device)
-        if one is None:
-            one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
-        lg = _PhotometricTV.backward(lctx, one)
-        state["v_rgb"], state["v_tv_grids"] = lg[0], lg[4:]
+        if gg is not None and all(g.requires_grad for g in gs) and all(a.is_contiguous() for a in gg):
+            # value and gradient in one launch (d(loss) = 1 is known up front); the TV gradient goes straight to the grids' slices
+            loss, state["v_rgb"] = photometric_tv_train(rgb, target, gs, tv_weights, gg)
+            state["v_tv_grids"] = (None,) * len(gs)
+        else:
+            lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
+            loss = _PhotometricTV.forward(lctx, rgb, target, tuple(float(w) for w in tv_weights), gg, *gs)
+            one = _ONES.get(rgb.device)
+            if one is None:
+                one = _ONES[rgb.device] = torch.ones((), device=rgb.device, dtype=torch.float32)
+            lg = _PhotometricTV.backward(lctx, one)
+            state["v_rgb"], state["v_tv_grids"] = lg[0], lg[4:]
         out.update(loss=loss, rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
 
     with torch.no_grad():

@@ -67,6 +67,27 @@ class _PhotometricTV(torch.autograd.Function):
         return (v_rgb, None, None, None, *v_grids)
 
 
+def photometric_tv_train(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv_weights: Sequence[float], grid_grads: Sequence[Tensor],
+                         loss_acc: Tensor = None):
+    """The direct step's loss (no autograd graph; ``fused_view.train_view``): value and gradient of
+    mean|rgb - target| + sum_l tv_weights[l] * total_variation(grids[l]) in ONE launch (``bds_l1_tv_train``): returns
+    (loss [0-d], v_rgb); the TV gradient is ADDED to ``grid_grads`` (the grids' ``.grad`` slices) with atomics.
+    ``loss_acc`` (optional): a ZEROED float32 [1] tensor to accumulate the value in (a caller that has one spares the fill)."""
+    L.require_gpu(rgb, target, *grids)
+    lib, st = L.lib(), L.stream()
+    rgb, target = rgb.contiguous(), target.contiguous()
+    assert rgb.shape == target.shape and rgb.dtype == torch.float32 and target.dtype == torch.float32
+    grids = [g.contiguous() for g in grids]
+    assert len(grid_grads) == len(grids) and all(a.numel() == g.numel() and a.is_contiguous() for a, g in zip(grid_grads, grids))
+    out = torch.zeros(1, device=rgb.device, dtype=torch.float32) if loss_acc is None else loss_acc
+    v_rgb = torch.empty_like(rgb)
+    lv = _levels_struct(grids, list(grid_grads), [1] * len(grids)) if grids else None
+    wts = (C.c_float * max(len(grids), 1))(*[float(w) for w in tv_weights])
+    L.check(lib.bds_l1_tv_train(rgb.numel(), L.ptr(rgb), L.ptr(target), len(grids), lv, wts, 1.0, L.ptr(out), L.ptr(v_rgb), st),
+            "bds_l1_tv_train")
+    return out.reshape(()), v_rgb
+
+
 def photometric_tv_loss(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv_weights: Sequence[float],
                         grid_grads: Sequence[Tensor] = None) -> Tensor:
     """mean|rgb - target| + sum_l tv_weights[l] * total_variation(grids[l])  (grids [n_img,12,L,gy,gx]).
@@ -74,7 +95,7 @@ def photometric_tv_loss(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv
     already are the grids' ``.grad``, ``dist.FrameExchange.tail_grads()``) and autograd receives no gradient for the grids."""
     assert len(grids) == len(tv_weights)
     if grid_grads is not None:
-        assert len(grid_grads) == len(grids) and all(a.shape == g.shape and a.is_contiguous() for a, g in zip(grid_grads, grids))
+        assert len(grid_grads) == len(grids) and all(a.numel() == g.numel() and a.is_contiguous() for a, g in zip(grid_grads, grids))
         grid_grads = list(grid_grads)
     return _PhotometricTV.apply(rgb, target, tuple(tv_weights), grid_grads, *grids)
 

@@ -283,6 +283,13 @@ int bds_bilagrid_tv_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, cons
 int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, const float *v_tv,
                            bds_stream_t stream);
 
+/* L1 + TV training loss of the direct step, value and gradient in ONE launch: loss_out (ADDED to: the caller zeroes it) +=
+ * mean|a - b| + sum_l weights[l] * TV(levels[l].grid); v_a [n] = sign(a - b) * v_loss / n; levels[l].v_grid (may be NULL) +=
+ * v_loss * d(weights[l] * TV)/d(grid), with atomics (concurrent views may add to the same slices).  nlevels may be 0.
+ * (models/trainers/base.py:518-565 rgb term + the `losses.affine` TV term, models/modules.py:445,466-472.) */
+int bds_l1_tv_train(int64_t n, const float *a, const float *b, int nlevels, const bds_bilagrid_level_t *levels, const float *weights,
+                    float v_loss, float *loss_out, float *v_a, bds_stream_t stream);
+
 /* ---- one-view forms for the fused training step ------------------------------------------------------
  * The per-Gaussian glue of one reference iteration folded into the two streaming kernels that sit next to it
  * (C = 1; same arithmetic as the general forms above):
