@@ -86,15 +86,25 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n_cap, c
 // that wrote two dense per-Gaussian arrays nobody reads for the culled 85 %.  sh_rgb_out [n,3] keeps the un-clamped colour of record
 // r: the backward needs to know where the clamp was active.
 template <int DEG>
-__global__ __launch_bounds__(kPackBlock) void splat_pack_sh_kernel(int64_t n, const int32_t *__restrict__ ids, int K,
+__global__ __launch_bounds__(kPackBlock) void splat_pack_sh_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
+                                                                  const int32_t *__restrict__ ids, int K,
                                                                   const float *__restrict__ means, const float *__restrict__ cam_pos,
                                                                   const float *__restrict__ coeffs, const float *__restrict__ means2d,
                                                                   const float *__restrict__ conics, const float *__restrict__ depths,
                                                                   const float *__restrict__ opacities, const int32_t *__restrict__ radii,
-                                                                  float4 *__restrict__ rec, float *__restrict__ sh_rgb_out) {
+                                                                  float4 *__restrict__ rec, float *__restrict__ sh_rgb_out,
+                                                                  float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
+                                                                  int zero_tail_f4) {
   constexpr int nb = (DEG + 1) * (DEG + 1);
+  if (zero_tail && blockIdx.x == 0)   // (as splat_pack_kernel: the gradient records / pose slots are cleared on the way)
+    for (int i = threadIdx.x; i < zero_tail_f4; i += kPackBlock) zero_tail[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t n = list_length(n_cap, n_dev);
   const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
   if (r >= n) return;
+  if (zero_rec) {
+#pragma unroll
+    for (int i = 0; i < kGradStride / 4; i++) zero_rec[r * (kGradStride / 4) + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int64_t g = ids[r];
   const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
   const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
@@ -596,19 +606,28 @@ extern "C" int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int
                          zero_tail_floats, stream);
 }
 
-extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
-                                 const float *coeffs, const float *means2d, const float *conics, const float *depths,
-                                 const float *opacities, const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream) {
+static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
+                              const float *cam_pos, const float *coeffs, const float *means2d, const float *conics, const float *depths,
+                              const float *opacities, const int32_t *radii, float *records, float *sh_rgb, float *zero_records,
+                              float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
-  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(zero_tail_floats >= 0 && zero_tail_floats % 4 == 0 && zero_tail_floats < ((int64_t)1 << 24));
+  BDS_REQUIRE((!zero_records || aligned16(zero_records)) && (!zero_tail || aligned16(zero_tail)));
+  if (n == 0) {
+    if (zero_tail && zero_tail_floats &&
+        hipMemsetAsync(zero_tail, 0, sizeof(float) * zero_tail_floats, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
+    return BDS_OK;
+  }
   BDS_REQUIRE(ids && means && cam_pos && coeffs && means2d && conics && depths && opacities && radii && records && sh_rgb);
   BDS_REQUIRE(aligned16(records) && aligned16(coeffs) && (K * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
   const dim3 grid((unsigned)cdiv(n, kPackBlock)), block(kPackBlock);
   float4 *rec = reinterpret_cast<float4 *>(records);
+  float4 *zr = reinterpret_cast<float4 *>(zero_records), *zt = reinterpret_cast<float4 *>(zero_tail);
+  const int zt4 = (int)(zero_tail_floats / 4);
   hipStream_t st = as_stream(stream);
-#define BDS_PACK_SH(d)                                                                                                              \
-  hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, 0, st, n, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
-                     opacities, radii, rec, sh_rgb)
+#define BDS_PACK_SH(d)                                                                                                                 \
+  hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, 0, st, n, n_dev, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
+                     opacities, radii, rec, sh_rgb, zr, zt, zt4)
   switch (deg) {
     case 0: BDS_PACK_SH(0); break;
     case 1: BDS_PACK_SH(1); break;
@@ -618,6 +637,22 @@ extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, 
 #undef BDS_PACK_SH
   BDS_LAUNCH_CHECK();
   return BDS_OK;
+}
+
+extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
+                                 const float *coeffs, const float *means2d, const float *conics, const float *depths,
+                                 const float *opacities, const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream) {
+  return splat_pack_sh_impl(n, nullptr, ids, K, deg, means, cam_pos, coeffs, means2d, conics, depths, opacities, radii, records, sh_rgb,
+                            nullptr, nullptr, 0, stream);
+}
+
+extern "C" int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
+                                     const float *cam_pos, const float *coeffs, const float *means2d, const float *conics,
+                                     const float *depths, const float *opacities, const int32_t *radii, float *records, float *sh_rgb,
+                                     float *zero_records, float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream) {
+  BDS_REQUIRE(n_dev);
+  return splat_pack_sh_impl(n_capacity, n_dev, ids, K, deg, means, cam_pos, coeffs, means2d, conics, depths, opacities, radii, records,
+                            sh_rgb, zero_records, zero_tail, zero_tail_floats, stream);
 }
 
 // list geometry of a launch: list tiles of list_tile_size px (a multiple of the 16-px compositing tile)

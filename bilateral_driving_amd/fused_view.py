@@ -32,6 +32,8 @@ LIST_TILE = int(os.environ.get("BDS_LIST_TILE", "64"))
 # gathering its own 192-byte coefficient row costs more than it saves: pack + forward composite 183 -> 237 us for 48 us of SH pass
 # removed (profiles/r02x).  Needs 16-byte aligned coefficient rows (K * 3 % 4 == 0).
 SH_IN_PACK = os.environ.get("BDS_SH_IN_PACK", "0") == "1"
+# device-count form (nobody waits for the counts, so a dense SH pass hides behind nothing): the record pack evaluates the colours
+SH_IN_PACK_DEV = os.environ.get("BDS_SH_IN_PACK_DEV", "1") == "1"
 
 
 def _empty(shape, dev, dtype=torch.float32):
@@ -198,7 +200,8 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
     # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
     cam_pos = cfg["cam_pos"].contiguous()
-    if caps is None and cfg.get("sh_in_pack", SH_IN_PACK) and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0:
+    in_pack = cfg.get("sh_in_pack", SH_IN_PACK if caps is None else SH_IN_PACK_DEV)
+    if in_pack and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0:
         sh_rgb, colors = None, None        # evaluated by the record pack, for the visible Gaussians only (_composite)
     else:
         sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
@@ -304,7 +307,6 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
     dev = opac.device
     n_vis, M, W, H = f.n_vis, f.M, f.W, f.H
     if f.m_dev is not None:
-        assert f.colors is not None, "device-count form: SH colours are evaluated by the dense pass (sh_in_pack off)"
         if f.rec_buf is not None:
             rec, f.rec_buf = f.rec_buf[:n_vis], None
         else:
@@ -313,9 +315,16 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
         zr = zero_grad_records
         tail = None if zr is None or zr.shape[0] <= n_vis else zr[n_vis:]
         with L.timed("rasterize_fwd"):
-            L.check(lib.bds_splat_pack_dev(n_vis, f.nvis_dev, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors),
-                                           L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(zr), L.ptr(tail),
-                                           0 if tail is None else tail.numel(), st), "bds_splat_pack_dev")
+            if f.colors is None:   # SH colours evaluated by the pack (visible Gaussians only); un-clamped values kept in list order
+                f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
+                L.check(lib.bds_splat_pack_sh_dev(n_vis, f.nvis_dev, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means),
+                                                  L.ptr(f.cam_pos), L.ptr(f.sh), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths),
+                                                  L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), L.ptr(zr), L.ptr(tail),
+                                                  0 if tail is None else tail.numel(), st), "bds_splat_pack_sh_dev")
+            else:
+                L.check(lib.bds_splat_pack_dev(n_vis, f.nvis_dev, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors),
+                                               L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(zr), L.ptr(tail),
+                                               0 if tail is None else tail.numel(), st), "bds_splat_pack_dev")
             L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
                                               L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),
                     "bds_rasterize_fwd_dev")
@@ -559,7 +568,8 @@ class _FusedView(torch.autograd.Function):
             st = L.stream()
             if dev_counts is not None:
                 L.check(lib.bds_sh_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos),
-                                                     L.ptr(sh_rgb), 0, L.ptr(v_rec), L.ptr(v_sh), L.ptr(row_map), int(rows == 2), st),
+                                                     L.ptr(sh_rgb), int(bool(getattr(ctx, "sh_by_rank", False))), L.ptr(v_rec), L.ptr(v_sh),
+                                                     L.ptr(row_map), int(rows == 2), st),
                         "bds_sh_view_bwd_list_dev")
             else:
                 L.check(lib.bds_sh_view_bwd_list(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb),
@@ -746,6 +756,9 @@ def _accumulate(p: Tensor, g: Optional[Tensor]) -> None:
         p.grad.add_(g)
 
 
+_LOSS_TWO_STEP = os.environ.get("BDS_LOSS_TWO_STEP", "0") == "1"   # ablation: the loss as forward + backward launches
+
+
 def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor], sky: Tensor,
                factors: Sequence[int], target: Tensor, tv_weights: Sequence[float], img_idx: Optional[int] = None,
                grid_grads: Optional[Sequence[Tensor]] = None, after_forward=None, **kwargs):
@@ -808,7 +821,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         if after_forward is not None:
             after_forward(info)
         gg = None if grid_grads is None else list(grid_grads)
-        if gg is not None and all(g.requires_grad for g in gs) and all(a.is_contiguous() for a in gg):
+        if gg is not None and all(g.requires_grad for g in gs) and all(a.is_contiguous() for a in gg) and not _LOSS_TWO_STEP:
             # value and gradient in one launch (d(loss) = 1 is known up front); the TV gradient goes straight to the grids' slices
             loss, state["v_rgb"] = photometric_tv_train(rgb, target, gs, tv_weights, gg)
             state["v_tv_grids"] = (None,) * len(gs)

@@ -369,6 +369,12 @@ int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t n_visible_
 int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d, const float *conics,
                        const float *colors, const float *opacities, const int32_t *radii, float *records, float *zero_records,
                        float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream);
+/* bds_splat_pack_sh with the record count on the device and the clearing options of bds_splat_pack_dev: the SH colours of the visible
+ * Gaussians are evaluated by the pack itself (no pass over all N, no dense colour arrays); sh_rgb [n_capacity, 3] in list order. */
+int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int degrees_to_use, const float *means,
+                          const float *cam_pos, const float *coeffs, const float *means2d, const float *conics, const float *depths,
+                          const float *opacities, const int32_t *radii, float *records, float *sh_rgb, float *zero_records,
+                          float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream);
 /* bds_rasterize_fwd / _bwd with the list length on the device (M_dev -> M effective) */
 int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,

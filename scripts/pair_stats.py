@@ -55,6 +55,7 @@ def pair_stats(N, W, H, view=0):
         order = torch.argsort(length, descending=True)
         ys, xs = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
         visited = strips = pairs2 = pix = quads = 0
+        vis_tile = torch.zeros(n_tiles, dtype=torch.long, device=dev)
         B = 48
         m2f, conf, opf = m2[0], con[0], op[0]
         for b0 in range(0, n_tiles, B):
@@ -79,6 +80,7 @@ def pair_stats(N, W, H, view=0):
             v4 = valid.reshape(valid.shape[0], valid.shape[1], 4, 4, 16)          # [.., strip q (rows 4q..4q+3), row in strip, col]
             anyp = valid.any(dim=2)
             visited += int(anyp.sum())
+            vis_tile[tl] = anyp.sum(dim=1)
             strips += int(v4.any(dim=4).any(dim=3).sum())
             # lane-pixel q of the wave kernel = row (lane >> 4) + 4q: pixel pairs (q0,q1), (q2,q3) as a packed kernel would group them
             vq = valid.reshape(valid.shape[0], valid.shape[1], 4, 4, 16)          # rows r = 4*q + l  -> index [q, l]
@@ -88,6 +90,12 @@ def pair_stats(N, W, H, view=0):
                    pairs_visited=visited, strips_visited=strips, halves_visited=pairs2, quadrants_visited=quads, pixel_blends=pix,
                    mean_strips_per_visited_pair=strips / max(visited, 1), mean_halves_per_visited_pair=pairs2 / max(visited, 1),
                    mean_pixels_per_visited_pair=pix / max(visited, 1))
+        vt = vis_tile.float()
+        q = torch.tensor([0.5, 0.9, 0.99, 0.999], device=dev)
+        out["visited_per_tile"] = dict(mean=float(vt.mean()), max=int(vt.max()), quantiles_50_90_99_999=[float(x) for x in torch.quantile(vt, q)],
+                                       tested_max=int(length.max()), tested_mean=float(length.float().mean()))
+        # per-SIMD load if tiles are dealt longest-first to 1024 SIMDs x k resident waves (LPT bound): sum / 1024 vs the longest tile
+        out["lpt"] = dict(visited_sum_over_1024=float(vt.sum() / 1024), longest_tile=int(vt.max()))
         return out
 
 

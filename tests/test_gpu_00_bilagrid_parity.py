@@ -231,7 +231,7 @@ def test_one_launch_training_loss_matches_the_loss_node(H, W):
     assert abs(float(got - loss)) <= 2e-6 * abs(float(loss))
     assert torch.equal(v_rgb, rgb.grad)
     for a, b, x in zip(acc, pre, grids):
-        assert torch.allclose(a - b, x.grad, rtol=1e-4, atol=1e-7 * float(x.grad.abs().max()) + 1e-7)
+        assert torch.allclose(a - b, x.grad, rtol=1e-4, atol=5e-7)    # (a - b cancels against |pre| ~ 1: fp32 rounding of the add)
     got0, v0 = photometric_tv_train(rgb.detach(), target, [], [], [])        # no grids: the L1 term alone
     assert abs(float(got0) - float((rgb.detach() - target).abs().mean())) < 1e-6 and torch.equal(v0, v_rgb)
 

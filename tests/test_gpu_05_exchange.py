@@ -12,6 +12,14 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def same_sh_kernel(monkeypatch):
+    """The device-count form evaluates the SH colours in the record pack; the host-count form defaults to the dense pass (hidden behind
+    its host wait).  Bit-equality between the two forms is asserted with both on the pack's arithmetic."""
+    from bilateral_driving_amd import fused_view as FV
+    monkeypatch.setattr(FV, "SH_IN_PACK", FV.SH_IN_PACK_DEV)
+
 W, H, N = 256, 160, 6000
 YAWS = (0.0, 100.0, 200.0)
 

@@ -9,6 +9,14 @@ from tests.util import rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def same_sh_kernel(monkeypatch):
+    """The device-count form evaluates the SH colours in the record pack; the host-count form defaults to the dense pass (hidden behind
+    its host wait).  Bit-equality between the two forms is asserted with both on the pack's arithmetic."""
+    from bilateral_driving_amd import fused_view as FV
+    monkeypatch.setattr(FV, "SH_IN_PACK", FV.SH_IN_PACK_DEV)
+
+
 @pytest.fixture(scope="module")
 def mods():
     assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
