@@ -86,9 +86,11 @@ _SIGS = {
     "bds_bilagrid_ms_uses_strips": (_i, [_i, C.POINTER(BdsLevel), _i, _i]),
     "bds_bilagrid_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, C.POINTER(C.c_void_p), _f]),
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
+    "bds_bilagrid_ms_ed_train_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _i, C.POINTER(BdsLevel),
+                                          C.POINTER(C.c_float), _fl, _f, _i, _f, _f]),
     "bds_bilagrid_ms_ed_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_bilagrid_ms_ed_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_l1_tv_train": (_i, [_i64, _f, _f, _i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _fl, _f, _f, _f]),
+    "bds_l1_tv_train": (_i, [_i64, _f, _f, _i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _fl, _f, _i, _f, _f]),
     "bds_l1_mean_fwd": (_i, [_i64, _f, _f, _f, _f]),
     "bds_l1_mean_bwd": (_i, [_i64, _f, _f, _f, _f, _f]),
     "bds_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -162,7 +164,8 @@ def lib():
 
 SPLAT_RECORD_FLOATS, GRAD_RECORD_FLOATS, POSE_GRAD_SLOTS = 12, 16, 64
 OPT_DEBUG, OPT_STRIP_ROWS = 3, 5      # 3: ablation mask (bit 16: general bilateral kernels instead of the column strips); 5: rows per band
-OPT_STRIPS = 7                         # bilateral column-strip kernels: 1 = forward, 2 = backward (opt-in, see csrc/bilagrid.hip)
+OPT_STRIPS = 7
+LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 64      # slotted loss accumulators (include/bds.h BDS_LOSS_SLOT_STRIDE)                         # bilateral column-strip kernels: 1 = forward, 2 = backward (opt-in, see csrc/bilagrid.hip)
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
 

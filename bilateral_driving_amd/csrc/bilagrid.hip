@@ -210,36 +210,117 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
   }
 }
 
+// ---- TV of several grid pyramids' levels in ONE launch each way (the levels are tiny: a launch costs more than a level) ----
+struct TvLevels {
+  int n;
+  const float *x[BDS_MAX_LEVELS];
+  float *v_x[BDS_MAX_LEVELS];
+  long long total[BDS_MAX_LEVELS];
+  int gx[BDS_MAX_LEVELS], gy[BDS_MAX_LEVELS], gl[BDS_MAX_LEVELS];
+  float sl[BDS_MAX_LEVELS], sy[BDS_MAX_LEVELS], sx[BDS_MAX_LEVELS];
+  int blk_off[BDS_MAX_LEVELS + 1];
+};
+
+// value and gradient of the TV term at the element (level by workgroup, element by thread) that workgroup `bid` of a
+// T.blk_off[T.n]-workgroup range owns: returns its share of the value, ADDS v_loss * d(TV)/d(element) to the level's gradient slice
+__device__ __forceinline__ float tv_train_element(const TvLevels &L, int bid, float v_loss) {
+  int k = 0;
+  while (k + 1 < L.n && bid >= L.blk_off[k + 1]) k++;
+  const int64_t e = (int64_t)(bid - L.blk_off[k]) * kBgBlock + threadIdx.x;
+  float acc = 0.f;
+  if (e < L.total[k]) {
+    const int gx = L.gx[k], gy = L.gy[k], gl = L.gl[k];
+    const float *x = L.x[k];
+    const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
+    const int64_t sl = (int64_t)gx * gy;
+    const float v = x[e];
+    float g = 0.f;
+    if (ix > 0) { const float d = v - x[e - 1]; acc += d * d * L.sx[k]; g += 2.f * d * L.sx[k]; }
+    if (ix < gx - 1) g -= 2.f * (x[e + 1] - v) * L.sx[k];
+    if (iy > 0) { const float d = v - x[e - gx]; acc += d * d * L.sy[k]; g += 2.f * d * L.sy[k]; }
+    if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * L.sy[k];
+    if (il > 0) { const float d = v - x[e - sl]; acc += d * d * L.sl[k]; g += 2.f * d * L.sl[k]; }
+    if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * L.sl[k];
+    if (L.v_x[k]) atomicAdd(L.v_x[k] + e, g * v_loss);
+  }
+  return acc;
+}
+
+// the training loss folded into the full-resolution forward (bds_bilagrid_ms_ed_train_fwd): L1 against `target` over the pixels this
+// launch produces, TV of the grids by tv_blocks extra workgroups behind the pix_blocks pixel workgroups
+constexpr int kLossSlotStride = BDS_LOSS_SLOT_STRIDE;   // floats between two slots: every slot in a 256-byte segment of its own
+struct TrainLoss {
+  const float *target;   // [H,W,3]
+  float *v_out;          // [H,W,3]  sign(out - target) * v_loss / (3 H W)
+  float *loss;           // [loss_slots * kLossSlotStride], zeroed by the caller: slot (workgroup % loss_slots) += its share of
+                         // mean|out - target| + TV terms.  (8100 float atomics on ONE address cost 65 us at the end of the launch.)
+  int loss_slots;        // power of two
+  float inv_n, v_loss;
+  int pix_blocks, tv_blocks;
+  TvLevels T;
+};
+
+__device__ __forceinline__ float block_sum_to_thread0(float acc, float *red /* [kBgBlock / kWave] shared */) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < kBgBlock / kWave; w++) t += red[w];
+  return t;
+}
+
 // ---- B: full-resolution compose --------------------------------------------------------------
 // (Measured and dropped, round 2: staging the y-interpolated low-res rows of a 256-pixel run in LDS so that a pixel reads 6 LDS
 // entries per level instead of 12 float4 gathers -- the staging prologue + barrier cost more than the gathers it removed:
 // forward 44 -> 48 us, backward x kernel 88 -> 111 us at 1080p.  The gathers overlap across waves; a per-workgroup prologue does not.)
-template <int NL>  // NL >= p.nlevels: bounds the static unrolling (registers) of the level loop
-__global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out) {
+template <int NL, bool kTrain>  // NL >= p.nlevels: bounds the static unrolling (registers) of the level loop
+__global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out, TrainLoss tl) {
+  __shared__ float red[kBgBlock / kWave];
+  if (kTrain && (int)blockIdx.x >= tl.pix_blocks) {   // the TV term of the loss: one grid element per thread
+    const float t = block_sum_to_thread0(tv_train_element(tl.T, (int)blockIdx.x - tl.pix_blocks, tl.v_loss), red);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(tl.loss + (size_t)(blockIdx.x & (tl.loss_slots - 1)) * kLossSlotStride, t);
+    return;
+  }
   // each XCD works on one contiguous band of the image: the rows of the low-res maps that 2f consecutive pixel rows share are then
   // fetched into ONE private L2 (measured before: 236 MB of fabric traffic for 136 MB of distinct data)
-  const int64_t pix = (int64_t)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * kBgBlock + threadIdx.x;
-  if (pix >= (int64_t)p.H * p.W) return;
-  int i, j;
-  fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, i, j);
-  float r, g, b;
-  load_input(p, i, j, r, g, b);
+  const int64_t pix = (int64_t)xcd_contiguous((int)blockIdx.x, kTrain ? tl.pix_blocks : (int)gridDim.x) * kBgBlock + threadIdx.x;
+  float l1 = 0.f;
+  if (pix < (int64_t)p.H * p.W) {
+    int i, j;
+    fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, i, j);
+    float r, g, b;
+    load_input(p, i, j, r, g, b);
 #pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l < p.nlevels) {
-      float A[12];
-      upsample_affine(p.lv[l], p.H, p.W, i, j, A);
-      if (p.lv[l].aff_out) {
-        float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out + pix * 12);
-        d[0] = make_float4(A[0], A[1], A[2], A[3]);
-        d[1] = make_float4(A[4], A[5], A[6], A[7]);
-        d[2] = make_float4(A[8], A[9], A[10], A[11]);
+    for (int l = 0; l < NL; l++) {
+      if (l < p.nlevels) {
+        float A[12];
+        upsample_affine(p.lv[l], p.H, p.W, i, j, A);
+        if (p.lv[l].aff_out) {
+          float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out + pix * 12);
+          d[0] = make_float4(A[0], A[1], A[2], A[3]);
+          d[1] = make_float4(A[4], A[5], A[6], A[7]);
+          d[2] = make_float4(A[8], A[9], A[10], A[11]);
+        }
+        apply_affine(A, r, g, b);
       }
-      apply_affine(A, r, g, b);
+    }
+    out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
+    if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
+    if (kTrain) {   // photometric L1 of the pixel just produced + its gradient (torch: sign(0) = 0)
+      const float gs = tl.v_loss * tl.inv_n;
+      const float d0 = r - tl.target[pix * 3], d1 = g - tl.target[pix * 3 + 1], d2 = b - tl.target[pix * 3 + 2];
+      l1 = fabsf(d0) + fabsf(d1) + fabsf(d2);
+      tl.v_out[pix * 3] = d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f);
+      tl.v_out[pix * 3 + 1] = d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f);
+      tl.v_out[pix * 3 + 2] = d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f);
     }
   }
-  out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
-  if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
+  if (kTrain) {
+    const float t = block_sum_to_thread0(l1, red);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(tl.loss + (size_t)(blockIdx.x & (tl.loss_slots - 1)) * kLossSlotStride, t * tl.inv_n);
+  }
 }
 
 // ---- C: full-resolution backward: direct route + per-level (P, Q) ------------------------------------
@@ -1317,17 +1398,6 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
 }
 
 
-// ---- TV of several grid pyramids' levels in ONE launch each way (the levels are tiny: a launch costs more than a level) ----
-struct TvLevels {
-  int n;
-  const float *x[BDS_MAX_LEVELS];
-  float *v_x[BDS_MAX_LEVELS];
-  long long total[BDS_MAX_LEVELS];
-  int gx[BDS_MAX_LEVELS], gy[BDS_MAX_LEVELS], gl[BDS_MAX_LEVELS];
-  float sl[BDS_MAX_LEVELS], sy[BDS_MAX_LEVELS], sx[BDS_MAX_LEVELS];
-  int blk_off[BDS_MAX_LEVELS + 1];
-};
-
 __global__ __launch_bounds__(kBgBlock) void tv_ms_fwd_kernel(TvLevels L, float *__restrict__ tv_out) {
   __shared__ float red[kBgBlock / kWave];
   int k = 0;
@@ -1523,9 +1593,12 @@ extern "C" int bds_bilagrid_ms_uses_strips(int nlevels, const bds_bilagrid_level
   return strip_geom(p, true, 0, g) ? 1 : 0;
 }
 
+static int l1_tv_train_launch(int64_t n, const float *a, const float *b, const TvLevels &T, int tv_blocks, float v_loss, float *loss_out,
+                              int loss_slots, float *v_a, hipStream_t st);
+
 static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb, int cs,
                        const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out, float *depth_out,
-                       float *const *affine_out, bds_stream_t stream) {
+                       float *const *affine_out, bds_stream_t stream, const TrainLoss *train = nullptr) {
   MsParams p;
   int rc = ms_fill(p, nlevels, levels, H, W, rgb, alpha, sky, ws, ws_bytes, affine_out);
   if (rc != BDS_OK) return rc;
@@ -1568,16 +1641,36 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       default: hipLaunchKernelGGL((ms_strip_fwd_kernel<4>), grid, block, 0, st, p, sg, rgb_out); break;
     }
   } else {
-    const dim3 grid((unsigned)cdiv((int64_t)H * W, kBgBlock)), block(kBgBlock);
+    const int pix_blocks = (int)cdiv((int64_t)H * W, kBgBlock);
+    const dim3 block(kBgBlock);
+    if (train) {   // the loss rides on the launch: L1 in the pixel workgroups' epilogue, TV in extra workgroups behind them
+      TrainLoss tl = *train;
+      tl.pix_blocks = pix_blocks;
+      const dim3 grid((unsigned)(pix_blocks + tl.tv_blocks));
+      switch (nlevels) {
+        case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1, true>), grid, block, 0, st, p, rgb_out, tl); break;
+        case 2: hipLaunchKernelGGL((ms_apply_fwd_kernel<2, true>), grid, block, 0, st, p, rgb_out, tl); break;
+        case 3: hipLaunchKernelGGL((ms_apply_fwd_kernel<3, true>), grid, block, 0, st, p, rgb_out, tl); break;
+        case 4: hipLaunchKernelGGL((ms_apply_fwd_kernel<4, true>), grid, block, 0, st, p, rgb_out, tl); break;
+        default: hipLaunchKernelGGL((ms_apply_fwd_kernel<BDS_MAX_LEVELS, true>), grid, block, 0, st, p, rgb_out, tl); break;
+      }
+      BDS_LAUNCH_CHECK();
+      return BDS_OK;
+    }
+    const dim3 grid((unsigned)pix_blocks);
+    TrainLoss none{};
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1>), grid, block, 0, st, p, rgb_out); break;
-      case 2: hipLaunchKernelGGL((ms_apply_fwd_kernel<2>), grid, block, 0, st, p, rgb_out); break;
-      case 3: hipLaunchKernelGGL((ms_apply_fwd_kernel<3>), grid, block, 0, st, p, rgb_out); break;
-      case 4: hipLaunchKernelGGL((ms_apply_fwd_kernel<4>), grid, block, 0, st, p, rgb_out); break;
-      default: hipLaunchKernelGGL((ms_apply_fwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, rgb_out); break;
+      case 1: hipLaunchKernelGGL((ms_apply_fwd_kernel<1, false>), grid, block, 0, st, p, rgb_out, none); break;
+      case 2: hipLaunchKernelGGL((ms_apply_fwd_kernel<2, false>), grid, block, 0, st, p, rgb_out, none); break;
+      case 3: hipLaunchKernelGGL((ms_apply_fwd_kernel<3, false>), grid, block, 0, st, p, rgb_out, none); break;
+      case 4: hipLaunchKernelGGL((ms_apply_fwd_kernel<4, false>), grid, block, 0, st, p, rgb_out, none); break;
+      default: hipLaunchKernelGGL((ms_apply_fwd_kernel<BDS_MAX_LEVELS, false>), grid, block, 0, st, p, rgb_out, none); break;
     }
   }
   BDS_LAUNCH_CHECK();
+  if (train)   // (column-strip form of the full-resolution stage: the loss keeps its own launch)
+    return l1_tv_train_launch((int64_t)H * W * 3, rgb_out, train->target, train->T, train->tv_blocks, train->v_loss, train->loss,
+                              train->loss_slots, train->v_out, st);
   return BDS_OK;
 }
 
@@ -1828,29 +1921,12 @@ extern "C" int bds_bilagrid_tv_bwd(int64_t n, int gx, int gy, int gl, const floa
 __global__ __launch_bounds__(kBgBlock) void l1_tv_train_kernel(TvLevels L, int tv_blocks, int64_t n4, int64_t n,
                                                               const float4 *__restrict__ a4, const float4 *__restrict__ b4,
                                                               const float *__restrict__ a, const float *__restrict__ b, float inv_n,
-                                                              float v_loss, float *__restrict__ loss_out, float4 *__restrict__ v_a4,
-                                                              float *__restrict__ v_a) {
+                                                              float v_loss, float *__restrict__ loss_out, int loss_slots,
+                                                              float4 *__restrict__ v_a4, float *__restrict__ v_a) {
   __shared__ float red[kBgBlock / kWave];
   float acc = 0.f;
   if ((int)blockIdx.x < tv_blocks) {
-    int k = 0;
-    while (k + 1 < L.n && (int)blockIdx.x >= L.blk_off[k + 1]) k++;
-    const int64_t e = (int64_t)((int)blockIdx.x - L.blk_off[k]) * kBgBlock + threadIdx.x;
-    if (e < L.total[k]) {
-      const int gx = L.gx[k], gy = L.gy[k], gl = L.gl[k];
-      const float *x = L.x[k];
-      const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
-      const int64_t sl = (int64_t)gx * gy;
-      const float v = x[e];
-      float g = 0.f;
-      if (ix > 0) { const float d = v - x[e - 1]; acc += d * d * L.sx[k]; g += 2.f * d * L.sx[k]; }
-      if (ix < gx - 1) g -= 2.f * (x[e + 1] - v) * L.sx[k];
-      if (iy > 0) { const float d = v - x[e - gx]; acc += d * d * L.sy[k]; g += 2.f * d * L.sy[k]; }
-      if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * L.sy[k];
-      if (il > 0) { const float d = v - x[e - sl]; acc += d * d * L.sl[k]; g += 2.f * d * L.sl[k]; }
-      if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * L.sl[k];
-      if (L.v_x[k]) atomicAdd(L.v_x[k] + e, g * v_loss);
-    }
+    acc = tv_train_element(L, (int)blockIdx.x, v_loss);
   } else {
     const int64_t nb = (int64_t)gridDim.x - tv_blocks, bid = (int64_t)blockIdx.x - tv_blocks;
     const float gs = v_loss * inv_n;
@@ -1876,7 +1952,7 @@ __global__ __launch_bounds__(kBgBlock) void l1_tv_train_kernel(TvLevels L, int t
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < kBgBlock / kWave; w++) t += red[w];
-    if (t != 0.f) atomicAdd(loss_out, t);
+    if (t != 0.f) atomicAdd(loss_out + (size_t)(blockIdx.x & (loss_slots - 1)) * kLossSlotStride, t);
   }
 }
 
@@ -1920,25 +1996,54 @@ extern "C" int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *l
   return BDS_OK;
 }
 
-extern "C" int bds_l1_tv_train(int64_t n, const float *a, const float *b, int nlevels, const bds_bilagrid_level_t *levels,
-                               const float *weights, float v_loss, float *loss_out, float *v_a, bds_stream_t stream) {
-  BDS_REQUIRE(n > 0 && a && b && loss_out && v_a && aligned16(a) && aligned16(b) && aligned16(v_a));
-  TvLevels T;
+static int l1_tv_train_launch(int64_t n, const float *a, const float *b, const TvLevels &T, int tv_blocks, float v_loss, float *loss_out,
+                              int loss_slots, float *v_a, hipStream_t st) {
+  const int64_t n4 = n / 4;
+  int64_t l1_blocks = cdiv(n4 > 0 ? n4 : 1, kBgBlock * 4);
+  if (l1_blocks > 2048) l1_blocks = 2048;
+  hipLaunchKernelGGL(l1_tv_train_kernel, dim3((unsigned)(tv_blocks + l1_blocks)), dim3(kBgBlock), 0, st, T, tv_blocks, n4, n,
+                     reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b), a, b, 1.0f / (float)n, v_loss, loss_out,
+                     loss_slots, reinterpret_cast<float4 *>(v_a), v_a);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+static int tv_train_levels(TvLevels &T, int &tv_blocks, int nlevels, const bds_bilagrid_level_t *levels, const float *weights) {
   T.n = 0; T.blk_off[0] = 0;
-  int tv_blocks = 0;
+  tv_blocks = 0;
   if (nlevels > 0) {
     int rc = tv_levels_fill(T, nlevels, levels, weights, false, 0);
     if (rc != BDS_OK) return rc;
     tv_blocks = T.blk_off[nlevels];
   }
-  const int64_t n4 = n / 4;
-  int64_t l1_blocks = cdiv(n4 > 0 ? n4 : 1, kBgBlock * 4);
-  if (l1_blocks > 2048) l1_blocks = 2048;
-  hipLaunchKernelGGL(l1_tv_train_kernel, dim3((unsigned)(tv_blocks + l1_blocks)), dim3(kBgBlock), 0, as_stream(stream), T, tv_blocks, n4, n,
-                     reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b), a, b, 1.0f / (float)n, v_loss, loss_out,
-                     reinterpret_cast<float4 *>(v_a), v_a);
-  BDS_LAUNCH_CHECK();
   return BDS_OK;
+}
+
+extern "C" int bds_l1_tv_train(int64_t n, const float *a, const float *b, int nlevels, const bds_bilagrid_level_t *levels,
+                               const float *weights, float v_loss, float *loss_out, int loss_slots, float *v_a, bds_stream_t stream) {
+  BDS_REQUIRE(n > 0 && a && b && loss_out && v_a && aligned16(a) && aligned16(b) && aligned16(v_a));
+  BDS_REQUIRE(loss_slots >= 1 && (loss_slots & (loss_slots - 1)) == 0);
+  TvLevels T;
+  int tv_blocks = 0;
+  int rc = tv_train_levels(T, tv_blocks, nlevels, levels, weights);
+  if (rc != BDS_OK) return rc;
+  return l1_tv_train_launch(n, a, b, T, tv_blocks, v_loss, loss_out, loss_slots, v_a, as_stream(stream));
+}
+
+extern "C" int bds_bilagrid_ms_ed_train_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                                            const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
+                                            float *depth_out, const float *target, int tv_nlevels,
+                                            const bds_bilagrid_level_t *tv_levels, const float *tv_weights, float v_loss,
+                                            float *loss_out, int loss_slots, float *v_rgb_out, bds_stream_t stream) {
+  BDS_REQUIRE(alpha && depth_out && target && loss_out && v_rgb_out && H > 0 && W > 0);
+  BDS_REQUIRE(loss_slots >= 1 && (loss_slots & (loss_slots - 1)) == 0);
+  BDS_REQUIRE(aligned16(target) && aligned16(v_rgb_out) && aligned16(rgb_out));
+  TrainLoss tl{};
+  int rc = tv_train_levels(tl.T, tl.tv_blocks, tv_nlevels, tv_levels, tv_weights);
+  if (rc != BDS_OK) return rc;
+  tl.target = target; tl.v_out = v_rgb_out; tl.loss = loss_out; tl.loss_slots = loss_slots;
+  tl.inv_n = 1.0f / (float)((int64_t)H * W * 3); tl.v_loss = v_loss;
+  return ms_fwd_impl(nlevels, levels, H, W, render, 4, alpha, sky, ws, ws_bytes, rgb_out, depth_out, nullptr, stream, &tl);
 }
 
 extern "C" int bds_bilagrid_slice_feat_fwd(int64_t P, int NC, const float *grid, int gx, int gy, int gl, const float *xy,

@@ -11,6 +11,7 @@ issues ~25 launches of libbds.so kernels back to back, so the step is bound by t
 from __future__ import annotations
 
 import contextlib
+import ctypes as C
 import math
 import os
 import weakref
@@ -410,9 +411,20 @@ class _FusedView(torch.autograd.Function):
             yield radii
             lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
+        tl = cfg.get("train_loss")     # train_view: the L1 + TV loss (value and gradients) rides on the full-resolution launch
+        ctx.train_loss = None
         with L.timed("bilagrid_fwd"):
-            L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
-                                               L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")
+            if tl is not None:
+                from .losses import loss_slots
+                loss_acc, v_rgb_loss = loss_slots(dev), _empty((H, W, 3), dev)
+                L.check(lib.bds_bilagrid_ms_ed_train_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
+                                                         L.ptr(rgb), L.ptr(depth), L.ptr(tl["target"]), len(tl["grids"]), tl["levels"],
+                                                         tl["weights"], 1.0, L.ptr(loss_acc), L.LOSS_SLOTS, L.ptr(v_rgb_loss), st),
+                        "bds_bilagrid_ms_ed_train_fwd")
+                ctx.train_loss = (loss_acc, v_rgb_loss)     # (slotted accumulator: train_view sums it off the critical chain)
+            else:
+                L.check(lib.bds_bilagrid_ms_ed_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
+                                                   L.ptr(rgb), L.ptr(depth), st), "bds_bilagrid_ms_ed_fwd")
         rgb_g = render[0, :, :, :3]   # view: the Gaussians' colour before clamp / sky / transform (clamped on access, see _Out)
         # The backward's first launch (bilateral transform) is prepared HERE when its gradient targets are already known (in-place
         # grid gradients): at that point of a step the host is only tens of microseconds ahead of the GPU, and every allocation
@@ -757,6 +769,7 @@ def _accumulate(p: Tensor, g: Optional[Tensor]) -> None:
 
 
 _LOSS_TWO_STEP = os.environ.get("BDS_LOSS_TWO_STEP", "0") == "1"   # ablation: the loss as forward + backward launches
+_LOSS_IN_TRANSFORM = os.environ.get("BDS_LOSS_IN_TRANSFORM", "1") == "1"   # the loss rides on the colour transform's launch
 
 
 def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, grids: Sequence[Tensor], sky: Tensor,
@@ -772,8 +785,10 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     ``two_phase=True``: only the forward, the loss value and the loss gradient are enqueued; the returned dict carries ``backward``
     and ``backward_tail``, callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  With
     ``late_image=True`` the first call stops behind the compositor (``forward_steps``): the colour transform and the loss move into
-    ``backward`` and the dict's image entries appear when it has run.  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
-    from .losses import _PhotometricTV, photometric_tv_train
+    ``backward`` and the dict's image entries appear when it has run; the ``loss`` entry may appear as late as ``backward_tail`` (its
+    value is summed from the loss launch's slotted accumulator there, off the critical chain).  Returns dict(loss, rgb, depth, opacity,
+    info): detached tensors."""
+    from .losses import _PhotometricTV, photometric_tv_train, slots_value
     cam_pos = kwargs.pop("cam_pos", None)
     if cam_pos is None:
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
@@ -797,6 +812,12 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
                                     and g.grad.data_ptr() == grad_arena[f"grid{i}"].data_ptr() for i, g in enumerate(gs))
+    if (grid_grads is not None and _LOSS_IN_TRANSFORM and not _LOSS_TWO_STEP and all(g.requires_grad and g.is_contiguous() for g in gs)
+            and all(a.is_contiguous() and a.numel() == g.numel() for a, g in zip(grid_grads, gs)) and target.is_contiguous()
+            and target.dtype == torch.float32 and tuple(target.shape) == (int(height), int(width), 3) and target.data_ptr() % 16 == 0):
+        from .losses import _levels_struct as _tv_levels
+        cfg["train_loss"] = dict(target=target, grids=gs, grid_grads=list(grid_grads), levels=_tv_levels(gs, list(grid_grads), [1] * len(gs)),
+                                 weights=(C.c_float * max(len(gs), 1))(*[float(w) for w in tv_weights]))
     names = ("means", "quats", "log_scales", "opacity_logits", "sh")
     leaves = [params[k] for k in names]
     needs = (False, *[bool(t.requires_grad) for t in leaves], bool(sky.requires_grad), bool(viewmat.requires_grad),
@@ -821,9 +842,13 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         if after_forward is not None:
             after_forward(info)
         gg = None if grid_grads is None else list(grid_grads)
-        if gg is not None and all(g.requires_grad for g in gs) and all(a.is_contiguous() for a in gg) and not _LOSS_TWO_STEP:
+        loss = None
+        if ctx.train_loss is not None:      # computed by the colour transform's own launch (forward_steps)
+            (state["loss_slots"], state["v_rgb"]), ctx.train_loss = ctx.train_loss, None
+            state["v_tv_grids"] = (None,) * len(gs)
+        elif gg is not None and all(g.requires_grad for g in gs) and all(a.is_contiguous() for a in gg) and not _LOSS_TWO_STEP:
             # value and gradient in one launch (d(loss) = 1 is known up front); the TV gradient goes straight to the grids' slices
-            loss, state["v_rgb"] = photometric_tv_train(rgb, target, gs, tv_weights, gg)
+            state["loss_slots"], state["v_rgb"] = photometric_tv_train(rgb, target, gs, tv_weights, gg, slots=True)
             state["v_tv_grids"] = (None,) * len(gs)
         else:
             lctx = _DirectCtx((True, False, False, False, *[bool(g.requires_grad) for g in gs]))
@@ -850,6 +875,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
 
     def backward_tail():     # Gaussian half; gradients land where autograd would put them
         with torch.no_grad():
+            if state.get("loss_slots") is not None:      # the loss VALUE: a small reduction nobody waits for
+                out["loss"] = slots_value(state.pop("loss_slots"))
             try:
                 next(state["steps"])
                 raise AssertionError("backward_steps yields once")

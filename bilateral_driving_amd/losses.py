@@ -67,25 +67,35 @@ class _PhotometricTV(torch.autograd.Function):
         return (v_rgb, None, None, None, *v_grids)
 
 
+def loss_slots(dev) -> Tensor:
+    """Zeroed accumulator of the one-launch training losses: LOSS_SLOTS slots, LOSS_SLOT_STRIDE floats apart (``slots_value``)."""
+    return torch.zeros(L.LOSS_SLOTS * L.LOSS_SLOT_STRIDE, device=dev, dtype=torch.float32)
+
+
+def slots_value(buf: Tensor) -> Tensor:
+    return buf.view(L.LOSS_SLOTS, L.LOSS_SLOT_STRIDE)[:, 0].sum()
+
+
 def photometric_tv_train(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv_weights: Sequence[float], grid_grads: Sequence[Tensor],
-                         loss_acc: Tensor = None):
+                         slots: bool = False):
     """The direct step's loss (no autograd graph; ``fused_view.train_view``): value and gradient of
     mean|rgb - target| + sum_l tv_weights[l] * total_variation(grids[l]) in ONE launch (``bds_l1_tv_train``): returns
     (loss [0-d], v_rgb); the TV gradient is ADDED to ``grid_grads`` (the grids' ``.grad`` slices) with atomics.
-    ``loss_acc`` (optional): a ZEROED float32 [1] tensor to accumulate the value in (a caller that has one spares the fill)."""
+    ``slots=True``: the first result is the slotted accumulator instead (``slots_value`` sums it: a caller with a better place for
+    that small reduction than right behind this launch)."""
     L.require_gpu(rgb, target, *grids)
     lib, st = L.lib(), L.stream()
     rgb, target = rgb.contiguous(), target.contiguous()
     assert rgb.shape == target.shape and rgb.dtype == torch.float32 and target.dtype == torch.float32
     grids = [g.contiguous() for g in grids]
     assert len(grid_grads) == len(grids) and all(a.numel() == g.numel() and a.is_contiguous() for a, g in zip(grid_grads, grids))
-    out = torch.zeros(1, device=rgb.device, dtype=torch.float32) if loss_acc is None else loss_acc
+    out = loss_slots(rgb.device)
     v_rgb = torch.empty_like(rgb)
     lv = _levels_struct(grids, list(grid_grads), [1] * len(grids)) if grids else None
     wts = (C.c_float * max(len(grids), 1))(*[float(w) for w in tv_weights])
-    L.check(lib.bds_l1_tv_train(rgb.numel(), L.ptr(rgb), L.ptr(target), len(grids), lv, wts, 1.0, L.ptr(out), L.ptr(v_rgb), st),
+    L.check(lib.bds_l1_tv_train(rgb.numel(), L.ptr(rgb), L.ptr(target), len(grids), lv, wts, 1.0, L.ptr(out), L.LOSS_SLOTS, L.ptr(v_rgb), st),
             "bds_l1_tv_train")
-    return out.reshape(()), v_rgb
+    return (out if slots else slots_value(out)), v_rgb
 
 
 def photometric_tv_loss(rgb: Tensor, target: Tensor, grids: Sequence[Tensor], tv_weights: Sequence[float],

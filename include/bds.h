@@ -283,12 +283,15 @@ int bds_bilagrid_tv_ms_fwd(int nlevels, const bds_bilagrid_level_t *levels, cons
 int bds_bilagrid_tv_ms_bwd(int nlevels, const bds_bilagrid_level_t *levels, const float *weights, const float *v_tv,
                            bds_stream_t stream);
 
-/* L1 + TV training loss of the direct step, value and gradient in ONE launch: loss_out (ADDED to: the caller zeroes it) +=
- * mean|a - b| + sum_l weights[l] * TV(levels[l].grid); v_a [n] = sign(a - b) * v_loss / n; levels[l].v_grid (may be NULL) +=
- * v_loss * d(weights[l] * TV)/d(grid), with atomics (concurrent views may add to the same slices).  nlevels may be 0.
+/* L1 + TV training loss of the direct step, value and gradient in ONE launch: the loss = mean|a - b| + sum_l weights[l] *
+ * TV(levels[l].grid) is ADDED, workgroup by workgroup, to loss_out [loss_slots * BDS_LOSS_SLOT_STRIDE] (zeroed by the caller;
+ * loss_slots a power of two; the value is the sum of the slots' first floats -- thousands of float atomics on ONE address serialise
+ * at ~8 ns each); v_a [n] = sign(a - b) * v_loss / n; levels[l].v_grid (may be NULL) += v_loss * d(weights[l] * TV)/d(grid), with
+ * atomics (concurrent views may add to the same slices).  nlevels may be 0.
  * (models/trainers/base.py:518-565 rgb term + the `losses.affine` TV term, models/modules.py:445,466-472.) */
+#define BDS_LOSS_SLOT_STRIDE 64
 int bds_l1_tv_train(int64_t n, const float *a, const float *b, int nlevels, const bds_bilagrid_level_t *levels, const float *weights,
-                    float v_loss, float *loss_out, float *v_a, bds_stream_t stream);
+                    float v_loss, float *loss_out, int loss_slots, float *v_a, bds_stream_t stream);
 
 /* ---- one-view forms for the fused training step ------------------------------------------------------
  * The per-Gaussian glue of one reference iteration folded into the two streaming kernels that sit next to it
@@ -418,6 +421,16 @@ int bds_union_slots(int64_t N, const uint8_t *mask, int64_t capacity, int K, int
 int bds_bilagrid_ms_ed_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
                            const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *rgb_out,
                            float *depth_out, bds_stream_t stream);
+/* bds_bilagrid_ms_ed_fwd with the training loss of the direct step riding on the same launch (no further pass over the image): the
+ * full-resolution kernel also compares the pixel it just produced with target [H*W,3] -- loss_out (slotted as in bds_l1_tv_train) +=
+ * mean|rgb_out - target|, v_rgb_out [H*W,3] = sign(rgb_out - target) * v_loss / (3 H W) -- and tv_nlevels extra levels' worth of
+ * workgroups add sum_l tv_weights[l] * TV(tv_levels[l].grid) to loss_out and v_loss * its gradient to tv_levels[l].v_grid (atomics;
+ * may be NULL).  Same result as bds_bilagrid_ms_ed_fwd followed by bds_l1_tv_train.  (models/trainers/base.py:518-565 rgb term +
+ * `losses.affine`, models/modules.py:445,466-472.) */
+int bds_bilagrid_ms_ed_train_fwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render, const float *alpha,
+                                 const float *sky, void *ws, size_t ws_bytes, float *rgb_out, float *depth_out, const float *target,
+                                 int tv_nlevels, const bds_bilagrid_level_t *tv_levels, const float *tv_weights, float v_loss,
+                                 float *loss_out, int loss_slots, float *v_rgb_out, bds_stream_t stream);
 int bds_bilagrid_ms_ed_bwd(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
                            const float *alpha, const float *sky, void *ws, size_t ws_bytes, const float *v_rgb_out,
                            const float *v_depth, const float *v_opacity, float *v_render, float *v_alpha, float *v_sky,

@@ -167,3 +167,30 @@ def test_frame_graph_follows_parameter_updates_and_grows_on_overflow(mods):
         assert torch.equal(rgb[v], outs[v][0])
     for k in got:
         assert rel_err(got[k], g_ref[k]) < 3e-5, k
+
+
+def test_loss_on_the_transform_launch_equals_the_separate_loss_launch(mods, monkeypatch):
+    """train_view with the L1 + TV loss folded into the colour transform's full-resolution kernel (bds_bilagrid_ms_ed_train_fwd) ==
+    train_view with the loss as its own launch (bds_l1_tv_train): image bit-equal, loss to fp32 summation order, v_rgb-driven
+    gradients to atomics noise, TV gradient in the grids' slices."""
+    FV, GV, Hn = mods
+    W, H, N = 322, 190, 5000       # (W * H not a multiple of the workgroup: the pixel tail)
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0,), 6)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(FV, "_LOSS_IN_TRANSFORM", fused)
+        for t in list(p.values()) + grids + skies + [cams[0].viewmat]:
+            t.grad = None
+        gg = [torch.zeros_like(g) for g in grids]
+        out = Hn.train_view(p, cams[0], grids, 0, skies[0], targets[0], grid_grads=gg)
+        torch.cuda.synchronize()
+        res[fused] = (out["rgb"].clone(), float(out["loss"]), {k: t.grad.clone() for k, t in p.items()}, [g.clone() for g in gg],
+                      skies[0].grad.clone())
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0])
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(a[1])
+    for k in a[2]:
+        assert rel_err(b[2][k], a[2][k]) < 2e-4, k
+    for x, y in zip(a[3], b[3]):
+        assert float(x.abs().max()) > 0 and rel_err(y, x) < 3e-5
+    assert rel_err(b[4], a[4]) < 1e-6
