@@ -400,11 +400,11 @@ class _FusedView(torch.autograd.Function):
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f_list_tile = f.list_tile
         del f
-        # Work of the backward that depends on the compositor's outputs only is done HERE when a backward will follow: the longest-
-        # tile-first schedule of the compositor's backward and the zeroed dense screen-space gradient arrays.  In the graph-replayed
-        # frame this half runs on a stream of its own next to the previous view's backward, which is the critical chain.
+        # Work of the backward that depends on the compositor's outputs only -- the longest-tile-first schedule of the compositor's
+        # backward and the zeroed dense screen-space gradient arrays -- can be done HERE (_SCHEDULE_IN_FORWARD), on whichever of the
+        # graph-replayed frame's two streams has the slack.
         ctx.order = ctx.g2d = None
-        if any(ctx.needs_input_grad[1:]):
+        if any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD:
             ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
             ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         if not early:
@@ -768,6 +768,10 @@ def _accumulate(p: Tensor, g: Optional[Tensor]) -> None:
         p.grad.add_(g)
 
 
+# Where the compositor backward's schedule (two launches) and the zeroed screen-space gradient arrays (one fill) are produced: behind
+# the compositor's forward (1) or in front of its backward (0).  Measured on the two-stream frame: 937 vs 919 it/s -- in front of the
+# compositor's backward they delay the one kernel whose end closes the phase both compositors share.
+_SCHEDULE_IN_FORWARD = os.environ.get("BDS_SCHEDULE_IN_FORWARD", "1") == "1"
 _LOSS_TWO_STEP = os.environ.get("BDS_LOSS_TWO_STEP", "0") == "1"   # ablation: the loss as forward + backward launches
 _LOSS_IN_TRANSFORM = os.environ.get("BDS_LOSS_IN_TRANSFORM", "1") == "1"   # the loss rides on the colour transform's launch
 
