@@ -789,7 +789,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     ``two_phase=True``: only the forward, the loss value and the loss gradient are enqueued; the returned dict carries ``backward``
     and ``backward_tail``, callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  With
     ``late_image=True`` the first call stops behind the compositor (``forward_steps``): the colour transform and the loss move into
-    ``backward`` and the dict's image entries appear when it has run; the ``loss`` entry may appear as late as ``backward_tail`` (its
+    ``backward`` (or into ``image``, a callable of their own, when the caller invokes it first) and the dict's image entries appear
+    when it has run; the ``loss`` entry may appear as late as ``backward_tail`` (its
     value is summed from the loss launch's slotted accumulator there, off the critical chain).  Returns dict(loss, rgb, depth, opacity,
     info): detached tensors."""
     from .losses import _PhotometricTV, photometric_tv_train, slots_value
@@ -870,9 +871,16 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
         if not late_image:
             image_half(fsteps)
 
-    def backward():          # (late_image: colour transform + loss first) image half of the view's backward
+    def image():             # late_image: the rest of the forward as a step of its own (graph_view: the lists on a third stream)
         with torch.no_grad():
-            if late_image:
+            if late_image and not state.get("image_done"):
+                state["image_done"] = True
+                image_half(fsteps)
+
+    def backward():          # (late_image: colour transform + loss first, unless ``image`` ran) image half of the view's backward
+        with torch.no_grad():
+            if late_image and not state.get("image_done"):
+                state["image_done"] = True
                 image_half(fsteps)
             state["steps"] = _FusedView.backward_steps(ctx, state["v_rgb"], None, None, None, None)
             next(state["steps"])
@@ -895,7 +903,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                 _accumulate(g, b)
 
     if two_phase:     # the caller enqueues the halves itself (graph_view: forward | backward | its Gaussian half as hipGraphs on three streams)
-        out["backward"], out["backward_tail"] = backward, backward_tail
+        out["image"], out["backward"], out["backward_tail"] = image, backward, backward_tail
         return out
     backward()
     backward_tail()

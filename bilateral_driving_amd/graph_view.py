@@ -43,8 +43,11 @@ class ViewGraph:
     (``graph`` = forward + loss value, ``graph_bwd`` = the rest) when the frame overlaps a view's forward with the previous view's
     backward."""
 
-    def __init__(self, graph, out, caps: ListCapacity, prep_ws: Tensor, sky: Tensor, viewmat: Tensor, graph_bwd=None, graph_tail=None):
+    def __init__(self, graph, out, caps: ListCapacity, prep_ws: Tensor, sky: Tensor, viewmat: Tensor, graph_bwd=None, graph_tail=None,
+                 graph_front=None):
         self.graph, self.graph_bwd, self.graph_tail, self.out, self.caps, self.prep_ws = graph, graph_bwd, graph_tail, out, caps, prep_ws
+        self.graph_front = graph_front   # (front_stream: projection + lists captured apart from the compositor / colour transform)
+        self.front_done = torch.cuda.Event()
         self.loss = out["loss"]          # static tensors: rewritten by every replay
         self.rgb, self.depth, self.opacity = out["rgb"], out["depth"], out["opacity"]
         self.v_sky, self.v_viewmat = sky.grad, viewmat.grad
@@ -54,6 +57,8 @@ class ViewGraph:
     def replay(self) -> None:
         """All three graphs of the view on the current stream (world size 1: with an exchange the collectives go between them,
         ``FrameGraph.step``)."""
+        if self.graph_front is not None:
+            self.graph_front.replay()
         self.graph.replay()
         self.graph_bwd.replay()
         if self.graph_tail is not None:
@@ -66,7 +71,7 @@ class FrameGraph:
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False,
-                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False, late_image: bool = False):
+                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False, late_image: bool = False, front_stream: bool = False, single_graph: bool = False):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -99,7 +104,13 @@ class FrameGraph:
         self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         self.headroom = float(headroom)
-        self.late_image = late_image if late_image == "front" else bool(late_image)
+        # front_stream: every view's projection + lists (no dependence on anything but the parameters) as a graph of its own on a THIRD
+        # stream, running ahead of the compositors' stream
+        # single_graph: the whole frame -- begin body, every forward on a forked branch, every backward behind its forward -- captured
+        # as ONE hipGraph with two parallel branches: one launch per frame instead of 1 + 2 per view, no inter-graph gaps on either branch
+        self.single_graph = bool(single_graph and overlap and exchange is None and not front_stream and not overlap_tail and bwd_streams <= 1)
+        self.front_stream = bool(front_stream and overlap and exchange is None)
+        self.late_image = "front" if self.front_stream else (late_image if late_image == "front" else bool(late_image))
         self.n_bwd_streams = max(1, int(bwd_streams)) if overlap else 1
         self.overlap, self.overlap_tail = bool(overlap), bool(overlap and (overlap_tail or self.n_bwd_streams > 1))
         self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
@@ -251,6 +262,9 @@ class FrameGraph:
         self.pools_bwd = [self.pool] + [torch.cuda.graph_pool_handle() for _ in range(self.n_bwd_streams - 1)]
         self.extra_bwd_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_bwd_streams - 1)]
         self.pool_fwd = torch.cuda.graph_pool_handle() if self.overlap else self.pool
+        self.pool_front = torch.cuda.graph_pool_handle() if self.front_stream else None
+        self.front_stream_h = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("BDS_FRONT_STREAM_PRIORITY", "0"))) \
+            if self.front_stream else None
         self.pool_tail = torch.cuda.graph_pool_handle() if self.overlap_tail else self.pool
         # HIGH priority for the forwards' stream: its kernels are mostly small and latency-bound (the tile stage's ~20 launches); at
         # equal priority their workgroups queue behind the thousands of pending workgroups of the other stream's compositor backward
@@ -260,7 +274,11 @@ class FrameGraph:
         self.tail_stream = torch.cuda.Stream(device=self.dev) if self.overlap_tail else None
         self._frame_ready = torch.cuda.Event()
         outer, L.GRAPH_MARKS = L.GRAPH_MARKS, {}     # timing marks captured into THESE graphs (when _lib timers are enabled)
+        self.frame_graph = None
         try:
+            if self.single_graph:
+                self._capture_single()
+                return
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool):
                 self._begin_body()
@@ -268,12 +286,25 @@ class FrameGraph:
             # ALL forwards first, then all image halves, then all Gaussian halves: a block of the forwards' pool that a later stage's
             # capture frees (buffers the forward prepared for it) could otherwise be handed to the NEXT view's forward, which runs
             # next to that stage (same rule one stage down)
-            fwd, bwd = [], []
-            for v in range(self.V):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool_fwd):
-                    out = self._phase_fwd(v)
-                fwd.append((g, out))
+            fwd, bwd, fronts = [], [], [None] * self.V
+            if self.front_stream:
+                outs = []
+                for v in range(self.V):
+                    gf = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gf, pool=self.pool_front):
+                        outs.append(self._phase_fwd(v))          # (late_image = "front": stops behind the lists)
+                    fronts[v] = gf
+                for v in range(self.V):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.pool_fwd):
+                        outs[v]["image"]()                         # compositor, colour transform, loss value + gradient
+                    fwd.append((g, outs[v]))
+            else:
+                for v in range(self.V):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.pool_fwd):
+                        out = self._phase_fwd(v)
+                    fwd.append((g, out))
             # (the Gaussian half is a graph of its own only where something goes between the halves: a third stream, or the exchange)
             split = self.overlap_tail or self.fx is not None
             for v, (g, out) in enumerate(fwd):
@@ -289,9 +320,40 @@ class FrameGraph:
                     gt = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gt, pool=self.pool_tail):
                         out["backward_tail"]()
-                self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, bwd[v], gt)
+                self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, bwd[v], gt, fronts[v])
         finally:
             self.marks, L.GRAPH_MARKS = L.GRAPH_MARKS, outer
+        self.n_captures += 1
+        torch.cuda.synchronize()
+
+    def _capture_single(self) -> None:
+        """The frame as one graph: the capture stream carries the begin body and the backwards, ``side_stream`` (forked from it inside
+        the capture) the forwards.  Same ordering rule as the separate graphs: every forward is captured before the first backward, so
+        no block a backward's capture frees can be handed to a forward that runs next to it."""
+        G = torch.cuda.CUDAGraph()
+        side = self.side_stream
+        with torch.cuda.graph(G, pool=self.pool):
+            cs = torch.cuda.current_stream(self.dev)
+            self._begin_body()
+            fork = torch.cuda.Event()
+            fork.record(cs)
+            side.wait_event(fork)
+            outs = []
+            with torch.cuda.stream(side):
+                for v in range(self.V):
+                    out = self._phase_fwd(v)
+                    e = torch.cuda.Event()
+                    e.record(side)
+                    outs.append((out, e))
+            for v, (out, e) in enumerate(outs):
+                cs.wait_event(e)
+                out["backward"]()
+                out["backward_tail"]()
+            cs.wait_stream(side)
+        self.frame_graph = G
+        self.begin_graph = None
+        for v, (out, _e) in enumerate(outs):
+            self.views[v] = ViewGraph(None, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, None, None)
         self.n_captures += 1
         torch.cuda.synchronize()
 
@@ -304,6 +366,11 @@ class FrameGraph:
         fx = self.fx
         main = torch.cuda.current_stream(self.dev)
         self._frame_begin()
+        if self.frame_graph is not None:     # single_graph: the two branches are inside (``serial`` has no meaning here)
+            self.frame_graph.replay()
+            for vg in self.views:
+                vg.done.record(main)
+            return
         self.begin_graph.replay()
         side = None if (serial or not self.overlap) else self.side_stream
         tail = None if (serial or not self.overlap_tail) else self.tail_stream
@@ -314,8 +381,17 @@ class FrameGraph:
             # backwards on their own stream
             self._frame_ready.record(main)
             side.wait_event(self._frame_ready)
+            if self.front_stream:
+                fs = self.front_stream_h
+                fs.wait_event(self._frame_ready)
+                with torch.cuda.stream(fs):
+                    for vg in self.views:
+                        vg.graph_front.replay()
+                        vg.front_done.record(fs)
             with torch.cuda.stream(side):
                 for v, vg in enumerate(self.views):
+                    if self.front_stream:
+                        side.wait_event(vg.front_done)
                     vg.graph.replay()
                     if fx is not None:
                         fx.static_begin_view(v, vg.out["union_mask"])   # (RCCL orders the mask's all-reduce behind this stream)
@@ -325,6 +401,8 @@ class FrameGraph:
         for v, vg in enumerate(self.views):
             # ---- forward (already on its way in the overlapped form)
             if side is None:
+                if vg.graph_front is not None:
+                    vg.graph_front.replay()
                 vg.graph.replay()
                 if fx is not None:
                     fx.static_begin_view(v, vg.out["union_mask"])
@@ -350,6 +428,8 @@ class FrameGraph:
                 if v == self.V - 1 and fx is not None:
                     fx.static_end_frame()
                 vg.done.record(ts)
+        if side is not None and self.front_stream:
+            main.wait_stream(self.front_stream_h)
         if tail is not None:
             main.wait_event(self.views[-1].done)     # the frame's gradients are complete for whatever the caller enqueues next
             for bs in self.extra_bwd_streams[:nb - 1]:
