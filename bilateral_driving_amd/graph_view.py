@@ -196,20 +196,21 @@ class FrameGraph:
             # the flat buffer's own row book-keeping is bypassed (the begin graph clears the rows): make a later flat.zero() dense
             self.flat._dirty, self.flat._clean = None, False
 
-    def _begin_body(self) -> None:
+    def _begin_body(self, views=None, tail: bool = True) -> None:
+        """Row-wise clear of the gradient rows the previous frame's ``views`` (default: all) wrote + (``tail``) the dense tail."""
         if self.fx is not None:      # the exchange's book of reduced rows clears the dense rows (fx.begin_frame); here only the tail
-            if self._tail.numel():
+            if self._tail.numel() and tail:
                 self._tail.zero_()
             return
         lib, st = L.lib(), L.stream()
         a = self.arena
-        for v in range(self.V):
+        for v in (range(self.V) if views is None else views):
             ws = self.prep_ws[v]
             ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
             L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K,
                                                       L.ptr(a["means"]), L.ptr(a["quats"]), L.ptr(a["log_scales"]),
                                                       L.ptr(a["opacity_logits"]), L.ptr(a["sh"]), st), "bds_view_grads_clear_list_dev")
-        if self._tail.numel():
+        if self._tail.numel() and tail:
             self._tail.zero_()
 
     def _frame_begin(self) -> None:
@@ -272,7 +273,7 @@ class FrameGraph:
         prio = int(os.environ.get("BDS_FWD_STREAM_PRIORITY", "-1"))
         self.side_stream = torch.cuda.Stream(device=self.dev, priority=prio) if self.overlap else None
         self.tail_stream = torch.cuda.Stream(device=self.dev) if self.overlap_tail else None
-        self._frame_ready = torch.cuda.Event()
+        self._frame_ready, self._frame_ready_rest = torch.cuda.Event(), torch.cuda.Event()
         outer, L.GRAPH_MARKS = L.GRAPH_MARKS, {}     # timing marks captured into THESE graphs (when _lib timers are enabled)
         self.frame_graph = None
         try:
@@ -280,8 +281,19 @@ class FrameGraph:
                 self._capture_single()
                 return
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool):
-                self._begin_body()
+            self.begin_graph_rest = None
+            if self.overlap and self.fx is None and self.V > 1:
+                # two begin graphs: the forwards' stream only has to wait until the begin stage has READ view 0's old id list (which
+                # view 0's forward overwrites); the other five clears (~100 us at 2 M Gaussians) run next to that forward
+                with torch.cuda.graph(g, pool=self.pool):
+                    self._begin_body(views=[0], tail=True)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=self.pool):
+                    self._begin_body(views=range(1, self.V), tail=False)
+                self.begin_graph_rest = g2
+            else:
+                with torch.cuda.graph(g, pool=self.pool):
+                    self._begin_body()
             self.begin_graph = g
             # ALL forwards first, then all image halves, then all Gaussian halves: a block of the forwards' pool that a later stage's
             # capture frees (buffers the forward prepared for it) could otherwise be handed to the NEXT view's forward, which runs
@@ -372,6 +384,10 @@ class FrameGraph:
                 vg.done.record(main)
             return
         self.begin_graph.replay()
+        rest = getattr(self, "begin_graph_rest", None)
+        if rest is not None and (serial or not self.overlap):
+            rest.replay()
+            rest = None
         side = None if (serial or not self.overlap) else self.side_stream
         tail = None if (serial or not self.overlap_tail) else self.tail_stream
         nb = 1 if tail is None else self.n_bwd_streams
@@ -381,23 +397,30 @@ class FrameGraph:
             # backwards on their own stream
             self._frame_ready.record(main)
             side.wait_event(self._frame_ready)
+            if rest is not None:
+                rest.replay()
+                self._frame_ready_rest.record(main)
             if self.front_stream:
                 fs = self.front_stream_h
                 fs.wait_event(self._frame_ready)
                 with torch.cuda.stream(fs):
-                    for vg in self.views:
+                    for v, vg in enumerate(self.views):
+                        if v == 1 and rest is not None:
+                            fs.wait_event(self._frame_ready_rest)
                         vg.graph_front.replay()
                         vg.front_done.record(fs)
             with torch.cuda.stream(side):
                 for v, vg in enumerate(self.views):
                     if self.front_stream:
                         side.wait_event(vg.front_done)
+                    if v == 1 and rest is not None and not self.front_stream:
+                        side.wait_event(self._frame_ready_rest)     # (the other views' old id lists have been read)
                     vg.graph.replay()
                     if fx is not None:
                         fx.static_begin_view(v, vg.out["union_mask"])   # (RCCL orders the mask's all-reduce behind this stream)
                     vg.fwd_done.record(side)
             for bs in self.extra_bwd_streams[:nb - 1]:
-                bs.wait_event(self._frame_ready)
+                bs.wait_event(self._frame_ready if rest is None else self._frame_ready_rest)
         for v, vg in enumerate(self.views):
             # ---- forward (already on its way in the overlapped form)
             if side is None:
