@@ -85,8 +85,9 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n_cap, c
 // ids[r].  Evaluating the SH colours HERE, for the visible Gaussians only and in list order, replaces a pass over all N Gaussians
 // that wrote two dense per-Gaussian arrays nobody reads for the culled 85 %.  sh_rgb_out [n,3] keeps the un-clamped colour of record
 // r: the backward needs to know where the clamp was active.
+constexpr int kPackShBlock = 128;   // (x 208 bytes of staged coefficients per thread at degree 3)
 template <int DEG>
-__global__ __launch_bounds__(kPackBlock) void splat_pack_sh_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
+__global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
                                                                   const int32_t *__restrict__ ids, int K,
                                                                   const float *__restrict__ means, const float *__restrict__ cam_pos,
                                                                   const float *__restrict__ coeffs, const float *__restrict__ means2d,
@@ -96,29 +97,49 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_sh_kernel(int64_t n_cap
                                                                   float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
                                                                   int zero_tail_f4) {
   constexpr int nb = (DEG + 1) * (DEG + 1);
+  constexpr int n4 = (nb * 3 + 3) / 4;       // 16-byte pieces of a coefficient row the colour needs
+  constexpr int ldr = n4 * 4 + 4;            // LDS row stride (floats): 16-byte aligned, an odd number of 16-byte pieces
+  // A thread gathering its own 192-byte row piece by piece touches 64 rows per load instruction; instead the workgroup's rows are
+  // staged through LDS with n4 consecutive lanes per row (each row's pieces leave memory as whole cache lines), as the list-driven
+  // SH backward writes them (csrc/sh.hip).
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int32_t s_g[kPackShBlock];
   if (zero_tail && blockIdx.x == 0)   // (as splat_pack_kernel: the gradient records / pose slots are cleared on the way)
-    for (int i = threadIdx.x; i < zero_tail_f4; i += kPackBlock) zero_tail[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < zero_tail_f4; i += kPackShBlock) zero_tail[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t n = list_length(n_cap, n_dev);
-  const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
-  if (r >= n) return;
+  const int64_t r0 = (int64_t)blockIdx.x * kPackShBlock;
+  if (r0 >= n) return;
+  const int cnt = (int)(n - r0 < (int64_t)kPackShBlock ? n - r0 : (int64_t)kPackShBlock);
+  const int tid = threadIdx.x;
+  const int64_t r = r0 + tid;
+  if (tid < cnt) s_g[tid] = ids[r];
+  __syncthreads();
+  {
+    const int total = cnt * n4;
+    const int64_t row = (int64_t)K * 3;
+#pragma unroll 4
+    for (int e = tid; e < total; e += kPackShBlock) {
+      const int rr = e / n4, c = e - rr * n4;
+      const float4 v = reinterpret_cast<const float4 *>(coeffs + (int64_t)s_g[rr] * row)[c];   // 16-byte aligned (checked by the caller)
+      *reinterpret_cast<float4 *>(lds + rr * ldr + c * 4) = v;
+    }
+  }
+  __syncthreads();
+  if (tid >= cnt) return;
   if (zero_rec) {
 #pragma unroll
     for (int i = 0; i < kGradStride / 4; i++) zero_rec[r * (kGradStride / 4) + i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int64_t g = ids[r];
+  const int64_t g = s_g[tid];
   const float x = means[g * 3] - cam_pos[0], y = means[g * 3 + 1] - cam_pos[1], z = means[g * 3 + 2] - cam_pos[2];
   const float inorm = 1.0f / sqrtf(x * x + y * y + z * z);
   float B[16];
   sh_bases(DEG, x * inorm, y * inorm, z * inorm, B);
-  const float4 *c4 = reinterpret_cast<const float4 *>(coeffs + g * (int64_t)K * 3);   // K * 3 floats, 16-byte aligned (checked by the caller)
-  float cf[nb * 3 + 3];
-  constexpr int n4 = (nb * 3 + 3) / 4;
+  float cf[n4 * 4];
 #pragma unroll
   for (int i = 0; i < n4; i++) {
-    if (i * 4 < K * 3) {
-      const float4 v = c4[i];
-      cf[i * 4] = v.x; cf[i * 4 + 1] = v.y; cf[i * 4 + 2] = v.z; cf[i * 4 + 3] = v.w;
-    }
+    const float4 v = *reinterpret_cast<const float4 *>(lds + tid * ldr + i * 4);
+    cf[i * 4] = v.x; cf[i * 4 + 1] = v.y; cf[i * 4 + 2] = v.z; cf[i * 4 + 3] = v.w;
   }
   float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
@@ -620,13 +641,14 @@ static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *i
   }
   BDS_REQUIRE(ids && means && cam_pos && coeffs && means2d && conics && depths && opacities && radii && records && sh_rgb);
   BDS_REQUIRE(aligned16(records) && aligned16(coeffs) && (K * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
-  const dim3 grid((unsigned)cdiv(n, kPackBlock)), block(kPackBlock);
+  const dim3 grid((unsigned)cdiv(n, kPackShBlock)), block(kPackShBlock);
   float4 *rec = reinterpret_cast<float4 *>(records);
   float4 *zr = reinterpret_cast<float4 *>(zero_records), *zt = reinterpret_cast<float4 *>(zero_tail);
   const int zt4 = (int)(zero_tail_floats / 4);
   hipStream_t st = as_stream(stream);
 #define BDS_PACK_SH(d)                                                                                                                 \
-  hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, 0, st, n, n_dev, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
+  hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, sizeof(float) * kPackShBlock * ((((d + 1) * (d + 1) * 3 + 3) / 4) * 4 + 4), st, \
+                     n, n_dev, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
                      opacities, radii, rec, sh_rgb, zr, zt, zt4)
   switch (deg) {
     case 0: BDS_PACK_SH(0); break;

@@ -196,3 +196,22 @@ def test_loss_on_the_transform_launch_equals_the_separate_loss_launch(mods, monk
     for x, y in zip(a[3], b[3]):
         assert float(x.abs().max()) > 0 and rel_err(y, x) < 3e-5
     assert rel_err(b[4], a[4]) < 1e-6
+
+
+def test_sh_in_the_record_pack_equals_the_dense_sh_pass(mods, monkeypatch):
+    """The record pack that evaluates the SH colours itself (LDS-staged coefficient rows, visible Gaussians only: the device-count form's
+    default) against the dense SH pass + plain pack: images and gradients to fp32 rounding of the colour sums."""
+    FV, GV, Hn = mods
+    W, H, N = 320, 192, 7000
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0,), 8)
+    res = {}
+    for in_pack in (False, True):
+        monkeypatch.setattr(FV, "SH_IN_PACK", in_pack)
+        for t in list(p.values()) + grids + skies + [cams[0].viewmat]:
+            t.grad = None
+        out = Hn.render_view(p, cams[0], grids, 0, skies[0])
+        Hn.training_loss(out, targets[0], grids).backward()
+        res[in_pack] = (out["rgb"].detach().clone(), {k: t.grad.clone() for k, t in p.items()})
+    assert float((res[True][0] - res[False][0]).abs().max()) < 2e-6
+    for k in res[False][1]:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 2e-4, k     # (float atomics in the compositor backward: order of the sums)
