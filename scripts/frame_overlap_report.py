@@ -15,8 +15,14 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # a frame starts with the row-wise gradient clear of the begin graph (6 launches back to back): take the first of each run
-    marks = [i for i, r in enumerate(rows) if "view_grads_clear_list_kernel" in r[2] and (i == 0 or "view_grads_clear_list_kernel" not in rows[i - 1][2])]
+    # a frame starts with the row-wise gradient clears of the begin stage (6 launches within the first ~200 us of a frame, since the
+    # begin stage was split in two graphs interleaved with the first forward's kernels): a clear more than 1 ms after the previous one
+    marks, last = [], None
+    for i, r in enumerate(rows):
+        if "view_grads_clear_list_kernel" in r[2]:
+            if last is None or r[0] - last > 1_000_000:
+                marks.append(i)
+            last = r[0]
     if len(marks) < 3:
         print("not enough frames in the trace", len(marks)); return
     # frames = mark-to-mark windows; the graph-replayed ones are the shortest and the most numerous: keep those within 10 % of the minimum
