@@ -32,6 +32,8 @@ struct LevelDev {
   float up_x, up_y, dn_x, dn_y;
   float lin_x, lin_y;  // 1 / (Wd - 1), 1 / (Hd - 1): step of torch.linspace(0, 1, n) over the low-res columns / rows
   uint32_t magic_wd;   // ceil(2^32 / Wd): row / column of a low-res index without an integer division (fast_divmod)
+  int dn_shift;        // log2(factor) when the factor is a power of two >= 2 that divides H and W (else 0): the bilinear down-sampler
+                       // then reads exactly the central 2 x 2 pixels of every factor x factor block with weight 1/4 each
 };
 struct MsParams {
   int nlevels, H, W;
@@ -145,10 +147,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, Lev
   const int l = sc.level[k_entry];
   const LevelDev &L = p.lv[l];
   const int vol = L.gl * L.gy * L.gx, gsz = 12 * vol;
-  if (kLds) {
-    for (int e = threadIdx.x; e < gsz * L.n_avg; e += kBgBlock) {
-      const int n = e / gsz, r = e - n * gsz, ch = r / vol, cell = r - ch * vol;
-      lds_grid[(n * vol + cell) * 12 + ch] = L.grid[e];
+  if (kLds) {   // cell-major copy of the grid; (image, channel) outermost: no integer division per element
+    for (int nc = 0; nc < 12 * L.n_avg; nc++) {
+      const int n = nc / 12, ch = nc - n * 12;
+      for (int cell = threadIdx.x; cell < vol; cell += kBgBlock) lds_grid[(n * vol + cell) * 12 + ch] = L.grid[(int64_t)nc * vol + cell];
     }
     __syncthreads();
   }
@@ -562,10 +564,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
   float *lds_cells = lds_acc + gtot;
   if (kLds) {
     for (int e = threadIdx.x; e < gtot; e += kBgBlock) lds_acc[e] = 0.f;
-    if (cells) {
-      for (int e = threadIdx.x; e < gtot; e += kBgBlock) {
-        const int n = e / gsz, r = e - n * gsz, ch = r / vol, cell = r - ch * vol;
-        lds_cells[(n * vol + cell) * 12 + ch] = L.grid[e];
+    if (cells) {   // (image, channel) outermost: no integer division per element
+      for (int nc = 0; nc < 12 * L.n_avg; nc++) {
+        const int n = nc / 12, ch = nc - n * 12;
+        for (int cell = threadIdx.x; cell < vol; cell += kBgBlock) lds_cells[(n * vol + cell) * 12 + ch] = L.grid[(int64_t)nc * vol + cell];
       }
     }
     __syncthreads();
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams
 // clamp(max=1) + sky blend in front of the transform is back-propagated.
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParams p, float *__restrict__ v_in,
-                                                                        float *__restrict__ v_alpha, float *__restrict__ v_sky) {
+                                                                        float *__restrict__ v_alpha, float *__restrict__ v_sky, int dbg) {
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
   int y, x;
@@ -690,6 +692,16 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
     if (l >= p.nlevels) break;
     const LevelDev &L = p.lv[l];
     if (L.Hd == p.H && L.Wd == p.W) { vg += L.vg[pix]; continue; }
+    if (L.dn_shift > 0 && !(dbg & 2048)) {
+      // power-of-two factor f dividing the image: low-res pixel (i, j) was sampled at f (i + 1/2) - 1/2, i.e. from the two central
+      // rows / columns of its f x f block with weights 1/2, 1/2 -- a pixel receives 1/4 of ONE low-res value or nothing (the same
+      // single term, the same product, as the general gather below: bit-identical, ~10 instructions instead of ~200)
+      const int f = 1 << L.dn_shift, h = f >> 1;
+      const int fy = y & (f - 1), fx = x & (f - 1);
+      if ((fy == h - 1 || fy == h) && (fx == h - 1 || fx == h))
+        vg += (0.5f * 0.5f) * L.vg[(int64_t)(y >> L.dn_shift) * L.Wd + (x >> L.dn_shift)];
+      continue;
+    }
     int ilo, ihi, jlo, jhi;
     adjoint_range(y, L.Hd, L.up_y, ilo, ihi);
     adjoint_range(x, L.Wd, L.up_x, jlo, jhi);
@@ -1520,6 +1532,15 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
     d.dn_x = (float)W / (float)d.Wd; d.dn_y = (float)H / (float)d.Hd;
     d.lin_x = d.Wd > 1 ? 1.0f / (float)(d.Wd - 1) : 0.f; d.lin_y = d.Hd > 1 ? 1.0f / (float)(d.Hd - 1) : 0.f;
     d.magic_wd = divmod_magic(d.Wd);
+    d.dn_shift = 0;
+    {
+      const int f = lv[l].factor;
+      if (f >= 2 && (f & (f - 1)) == 0 && d.Hd * f == H && d.Wd * f == W) {
+        int sh = 0;
+        while ((1 << sh) < f) sh++;
+        d.dn_shift = sh;
+      }
+    }
   }
   p.magic_w = divmod_magic(W);
   return BDS_OK;
@@ -1828,11 +1849,11 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   {
     const dim3 grid((unsigned)cdiv(HW, kBgBlock)), block(kBgBlock);
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<1>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
-      case 2: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<2>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
-      case 3: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<3>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
-      case 4: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<4>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
-      default: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky); break;
+      case 1: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<1>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
+      case 2: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<2>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
+      case 3: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<3>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
+      case 4: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<4>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
+      default: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
     }
     BDS_LAUNCH_CHECK();
   }
