@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
 // ms_apply_bwd_kernel + ms_adjoint_x_kernel (the halo pixels are recomputed, ~7 % extra work at factor 4).
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
-                                                                 float *__restrict__ v_in, int halo, int nbx) {
+                                                                 float *__restrict__ v_in, int halo, int nbx, int dbg) {
   __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
   const int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // one contiguous band of rows per XCD (L2 locality of the maps)
   const int y = bid / nbx, bx = bid - y * nbx;
@@ -476,13 +476,27 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
       const int anchor = min(p.W - 1, (int)(((float)cx + 0.5f) * sc));
       if (anchor < own0 || anchor >= own0 + stride) continue;   // owned by a neighbour
       int xlo, xhi;
-      adjoint_range(cx, p.W, L.dn_x, xlo, xhi);
+      // power-of-two factor f dividing the image, interior column: its taps are the 2 f pixels f cx - f/2 .. f cx + 3f/2 - 1 with the
+      // tent weights 1 - |src - cx| (exact binary fractions: the same values, in the same order, as the general form below, whose
+      // conservative window also visits 2-4 pixels of weight zero and re-derives both taps of every pixel)
+      const bool tent = L.dn_shift > 0 && cx >= 1 && cx <= L.Wd - 2 && !(dbg & 4096);
+      if (tent) {
+        const int f = 1 << L.dn_shift;
+        xlo = f * cx - (f >> 1); xhi = xlo + 2 * f - 1;
+      } else {
+        adjoint_range(cx, p.W, L.dn_x, xlo, xhi);
+      }
       float acc[12];
 #pragma unroll
       for (int k = 0; k < 12; k++) acc[k] = 0.f;
       for (int xx = xlo; xx <= xhi; xx++) {
-        const Tap tx = resample_tap_s(xx, p.W, L.Wd, L.up_x);
-        const float w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
+        float w;
+        if (tent) {
+          w = 1.f - fabsf((L.up_x * ((float)xx + 0.5f) - 0.5f) - (float)cx);
+        } else {
+          const Tap tx = resample_tap_s(xx, p.W, L.Wd, L.up_x);
+          w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
+        }
         const int k = xx - xs;   // inside the window by construction (halo >= scale + 2)
         const float p0 = sP[l][0][k], p1 = sP[l][1][k], p2 = sP[l][2][k];
 #pragma unroll
@@ -598,13 +612,25 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
       for (int k = 0; k < 12; k++) va[k] = 1.f;
     } else {  // y pass of the up-sampler adjoint over the x-reduced rows
       int ylo, yhi;
-      adjoint_range(i, p.H, L.dn_y, ylo, yhi);
+      // (power-of-two factor, interior row: exactly the 2 f rows with the tent weights, see the x pass of ms_apply_bwd_x_kernel)
+      const bool tent = L.dn_shift > 0 && i >= 1 && i <= L.Hd - 2 && !(dbg & 4096);
+      if (tent) {
+        const int f = 1 << L.dn_shift;
+        ylo = f * i - (f >> 1); yhi = ylo + 2 * f - 1;
+      } else {
+        adjoint_range(i, p.H, L.dn_y, ylo, yhi);
+      }
       // no early-out on zero weights: the few extra rows of the conservative window cost less than the
       // serialised load -> test -> load chain they would otherwise create (the loop is latency-bound)
 #pragma unroll kUnroll
       for (int y = ylo; y <= yhi; y++) {
-        const Tap ty = resample_tap_s(y, p.H, L.Hd, L.up_y);
-        const float w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
+        float w;
+        if (tent) {
+          w = 1.f - fabsf((L.up_y * ((float)y + 0.5f) - 0.5f) - (float)i);
+        } else {
+          const Tap ty = resample_tap_s(y, p.H, L.Hd, L.up_y);
+          w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
+        }
         const float4 *sv = reinterpret_cast<const float4 *>(L.R + ((int64_t)y * L.Wd + j) * 12);
         const float4 a = sv[0], b = sv[1], c = sv[2];
         va[0] += w * a.x; va[1] += w * a.y; va[2] += w * a.z; va[3] += w * a.w;
@@ -1757,11 +1783,11 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     const int nbx = (int)cdiv(W, stride);
     const dim3 grid((unsigned)((int64_t)H * nbx)), block(kBgBlock);
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
-      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx); break;
+      case 1: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<1>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx, option_get(kOptDebug)); break;
+      case 2: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<2>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx, option_get(kOptDebug)); break;
+      case 3: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<3>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx, option_get(kOptDebug)); break;
+      case 4: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<4>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx, option_get(kOptDebug)); break;
+      default: hipLaunchKernelGGL((ms_apply_bwd_x_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb_out, v_rgb, halo, nbx, option_get(kOptDebug)); break;
     }
     BDS_LAUNCH_CHECK();
   } else {

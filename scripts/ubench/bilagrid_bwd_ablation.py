@@ -39,7 +39,7 @@ def main():
         L.check(lib.bds_bilagrid_ms_ed_bwd(3, lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(ws), nb, L.ptr(v_rgb), None, None,
                                            L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_sky), st), "bwd")
 
-    for name, mask in (("full", 0), ("full, general guidance gather", 2048), ("no y pass", 1), ("no grid scatter", 2), ("no guidance route", 4), ("none of the three", 7)):
+    for name, mask in (("full", 0), ("full, general guidance gather", 2048), ("full, general x / y pass taps", 4096), ("no y pass", 1), ("no grid scatter", 2), ("no guidance route", 4), ("none of the three", 7)):
         lib.bds_set_option(L.OPT_DEBUG, mask)
         for _ in range(5):
             bwd()
