@@ -54,6 +54,11 @@ __device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t mag
   if (rr < 0) { qq--; rr += (int)d; }
   q = (int)qq; r = rr;
 }
+// 32-bit element offsets for the image-sized arrays (ms_fill requires 12 H W < 2^31): a 64-bit multiply-add per tap address
+// (v_mad_u64_u32, quarter rate) was ~30 % of the full-resolution kernels' issue time.  Rows / columns are < 2^23, so row * width is
+// one full-rate v_mul_i32_i24; the small constant factors are shift-adds.
+__device__ __forceinline__ int row_major(int row, int width, int col) { return __mul24(row, width) + col; }
+__device__ __forceinline__ int times3(int v) { return v + (v << 1); }
 static uint32_t divmod_magic(int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 // Several levels in ONE launch: workgroup ranges per level (the levels are independent, each alone
@@ -74,13 +79,14 @@ __device__ __forceinline__ int sched_find(const LevelSched &s, int bid, int &loc
 
 // input colour of the transform at pixel (y,x): clamp + sky blend fused when sky != null
 __device__ __forceinline__ void load_input(const MsParams &p, int y, int x, float &r, float &g, float &b) {
-  const int64_t o = (int64_t)y * p.W + x;
-  r = p.rgb[o * p.cs]; g = p.rgb[o * p.cs + 1]; b = p.rgb[o * p.cs + 2];
+  const int o = row_major(y, p.W, x);
+  const int oc = p.cs == 4 ? o << 2 : times3(o), o3 = times3(o);
+  r = p.rgb[oc]; g = p.rgb[oc + 1]; b = p.rgb[oc + 2];
   if (p.sky) {
     const float k = 1.f - p.alpha[o];
-    r = fminf(r, 1.f) + p.sky[o * 3] * k;
-    g = fminf(g, 1.f) + p.sky[o * 3 + 1] * k;
-    b = fminf(b, 1.f) + p.sky[o * 3 + 2] * k;
+    r = fminf(r, 1.f) + p.sky[o3] * k;
+    g = fminf(g, 1.f) + p.sky[o3 + 1] * k;
+    b = fminf(b, 1.f) + p.sky[o3 + 2] * k;
   }
 }
 
@@ -190,17 +196,19 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, Lev
 // bilinear up-sample of one level's low-res map at full-res pixel (i,j)
 __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W, int i, int j, float *A) {
   if (L.Hd == H && L.Wd == W) {
-    const float4 *s = reinterpret_cast<const float4 *>(L.lo + ((int64_t)i * W + j) * 12);
+    const float4 *s = reinterpret_cast<const float4 *>(L.lo) + times3(row_major(i, W, j));
     const float4 a = s[0], b = s[1], c = s[2];
     A[0] = a.x; A[1] = a.y; A[2] = a.z; A[3] = a.w; A[4] = b.x; A[5] = b.y; A[6] = b.z; A[7] = b.w;
     A[8] = c.x; A[9] = c.y; A[10] = c.z; A[11] = c.w;
     return;
   }
   const Tap ty = resample_tap_s(i, H, L.Hd, L.up_y), tx = resample_tap_s(j, W, L.Wd, L.up_x);
-  const float4 *s00 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + tx.i0) * 12);
-  const float4 *s01 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i0 * L.Wd + tx.i1) * 12);
-  const float4 *s10 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + tx.i0) * 12);
-  const float4 *s11 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)ty.i1 * L.Wd + tx.i1) * 12);
+  const float4 *lo4 = reinterpret_cast<const float4 *>(L.lo);
+  const int r0 = __mul24(ty.i0, L.Wd), r1 = __mul24(ty.i1, L.Wd);
+  const float4 *s00 = lo4 + times3(r0 + tx.i0);
+  const float4 *s01 = lo4 + times3(r0 + tx.i1);
+  const float4 *s10 = lo4 + times3(r1 + tx.i0);
+  const float4 *s11 = lo4 + times3(r1 + tx.i1);
   const float wx = tx.w1, wy = ty.w1;
 #pragma unroll
   for (int q = 0; q < 3; q++) {
@@ -287,9 +295,9 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
   }
   // each XCD works on one contiguous band of the image: the rows of the low-res maps that 2f consecutive pixel rows share are then
   // fetched into ONE private L2 (measured before: 236 MB of fabric traffic for 136 MB of distinct data)
-  const int64_t pix = (int64_t)xcd_contiguous((int)blockIdx.x, kTrain ? tl.pix_blocks : (int)gridDim.x) * kBgBlock + threadIdx.x;
+  const int pix = xcd_contiguous((int)blockIdx.x, kTrain ? tl.pix_blocks : (int)gridDim.x) * kBgBlock + (int)threadIdx.x;
   float l1 = 0.f;
-  if (pix < (int64_t)p.H * p.W) {
+  if (pix < p.H * p.W) {
     int i, j;
     fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, i, j);
     float r, g, b;
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
         float A[12];
         upsample_affine(p.lv[l], p.H, p.W, i, j, A);
         if (p.lv[l].aff_out) {
-          float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out + pix * 12);
+          float4 *d = reinterpret_cast<float4 *>(p.lv[l].aff_out) + times3(pix);
           d[0] = make_float4(A[0], A[1], A[2], A[3]);
           d[1] = make_float4(A[4], A[5], A[6], A[7]);
           d[2] = make_float4(A[8], A[9], A[10], A[11]);
@@ -308,15 +316,16 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
         apply_affine(A, r, g, b);
       }
     }
-    out[pix * 3] = r; out[pix * 3 + 1] = g; out[pix * 3 + 2] = b;
-    if (p.depth_out) p.depth_out[pix] = p.rgb[pix * 4 + 3] / fmaxf(p.alpha[pix], 1e-10f);
+    const int p3 = times3(pix);
+    out[p3] = r; out[p3 + 1] = g; out[p3 + 2] = b;
+    if (p.depth_out) p.depth_out[pix] = p.rgb[(pix << 2) + 3] / fmaxf(p.alpha[pix], 1e-10f);
     if (kTrain) {   // photometric L1 of the pixel just produced + its gradient (torch: sign(0) = 0)
       const float gs = tl.v_loss * tl.inv_n;
-      const float d0 = r - tl.target[pix * 3], d1 = g - tl.target[pix * 3 + 1], d2 = b - tl.target[pix * 3 + 2];
+      const float d0 = r - tl.target[p3], d1 = g - tl.target[p3 + 1], d2 = b - tl.target[p3 + 2];
       l1 = fabsf(d0) + fabsf(d1) + fabsf(d2);
-      tl.v_out[pix * 3] = d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f);
-      tl.v_out[pix * 3 + 1] = d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f);
-      tl.v_out[pix * 3 + 2] = d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f);
+      tl.v_out[p3] = d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f);
+      tl.v_out[p3 + 1] = d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f);
+      tl.v_out[p3 + 2] = d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f);
     }
   }
   if (kTrain) {
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
   const int xs = own0 - halo;
   const int x = xs + (int)threadIdx.x;
   if (x >= 0 && x < p.W) {
-    const int64_t pix = (int64_t)y * p.W + x;
+    const int pix = row_major(y, p.W, x);
     const bool owner = x >= own0 && x < own1;
     float r, g, b;
     load_input(p, y, x, r, g, b);
@@ -434,20 +443,20 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
       if (l < p.nlevels) {
         sP[l][0][threadIdx.x] = r; sP[l][1][threadIdx.x] = g; sP[l][2][threadIdx.x] = b;
         if (owner && p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {  // level without up-sampling: the low-res kernel reads P, Q
-          float *P = p.lv[l].P + pix * 3;
+          float *P = p.lv[l].P + times3(pix);
           P[0] = r; P[1] = g; P[2] = b;
         }
         upsample_affine(p.lv[l], p.H, p.W, y, x, A[l]);
         apply_affine(A[l], r, g, b);
       }
     }
-    float v0 = v_out[pix * 3], v1 = v_out[pix * 3 + 1], v2 = v_out[pix * 3 + 2];
+    float v0 = v_out[times3(pix)], v1 = v_out[times3(pix) + 1], v2 = v_out[times3(pix) + 2];
 #pragma unroll
     for (int l = NL - 1; l >= 0; l--) {
       if (l < p.nlevels) {
         sQ[l][0][threadIdx.x] = v0; sQ[l][1][threadIdx.x] = v1; sQ[l][2][threadIdx.x] = v2;
         if (owner && p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {
-          float *Q = p.lv[l].Q + pix * 3;
+          float *Q = p.lv[l].Q + times3(pix);
           Q[0] = v0; Q[1] = v1; Q[2] = v2;
         }
         const float n0 = A[l][0] * v0 + A[l][4] * v1 + A[l][8] * v2;
@@ -456,7 +465,10 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
         v0 = n0; v1 = n1; v2 = n2;
       }
     }
-    if (owner) { v_in[pix * p.cs] = v0; v_in[pix * p.cs + 1] = v1; v_in[pix * p.cs + 2] = v2; }
+    if (owner) {
+      const int oc = p.cs == 4 ? pix << 2 : times3(pix);
+      v_in[oc] = v0; v_in[oc + 1] = v1; v_in[oc + 2] = v2;
+    }
   }
   __syncthreads();
   // x pass: candidate columns of every up-sampled level, one item per thread and level.  (One flat item list over all levels --
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
           acc[r * 4 + 0] += q * p0; acc[r * 4 + 1] += q * p1; acc[r * 4 + 2] += q * p2; acc[r * 4 + 3] += q;
         }
       }
-      float4 *d = reinterpret_cast<float4 *>(L.R + ((int64_t)y * L.Wd + cx) * 12);
+      float4 *d = reinterpret_cast<float4 *>(L.R) + times3(row_major(y, L.Wd, cx));
       d[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
       d[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
       d[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
           const Tap ty = resample_tap_s(y, p.H, L.Hd, L.up_y);
           w = (ty.i0 == i ? 1.f - ty.w1 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
         }
-        const float4 *sv = reinterpret_cast<const float4 *>(L.R + ((int64_t)y * L.Wd + j) * 12);
+        const float4 *sv = reinterpret_cast<const float4 *>(L.R) + times3(row_major(y, L.Wd, j));
         const float4 a = sv[0], b = sv[1], c = sv[2];
         va[0] += w * a.x; va[1] += w * a.y; va[2] += w * a.z; va[3] += w * a.w;
         va[4] += w * b.x; va[5] += w * b.y; va[6] += w * b.z; va[7] += w * b.w;
@@ -708,8 +720,8 @@ __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParams p, float *__restrict__ v_in,
                                                                         float *__restrict__ v_alpha, float *__restrict__ v_sky, int dbg) {
-  const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
-  if (pix >= (int64_t)p.H * p.W) return;
+  const int pix = (int)blockIdx.x * kBgBlock + (int)threadIdx.x;
+  if (pix >= p.H * p.W) return;
   int y, x;
   fast_divmod((uint32_t)pix, (uint32_t)p.W, p.magic_w, y, x);
   float vg = 0.f;
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
       const int f = 1 << L.dn_shift, h = f >> 1;
       const int fy = y & (f - 1), fx = x & (f - 1);
       if ((fy == h - 1 || fy == h) && (fx == h - 1 || fx == h))
-        vg += (0.5f * 0.5f) * L.vg[(int64_t)(y >> L.dn_shift) * L.Wd + (x >> L.dn_shift)];
+        vg += (0.5f * 0.5f) * L.vg[row_major(y >> L.dn_shift, L.Wd, x >> L.dn_shift)];
       continue;
     }
     int ilo, ihi, jlo, jhi;
@@ -766,24 +778,25 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
     }
   }
   const int cs = p.cs;
-  float v[3] = {v_in[pix * cs] + vg * kGrayR, v_in[pix * cs + 1] + vg * kGrayG, v_in[pix * cs + 2] + vg * kGrayB};
+  const int oc = cs == 4 ? pix << 2 : times3(pix), p3 = times3(pix);
+  float v[3] = {v_in[oc] + vg * kGrayR, v_in[oc + 1] + vg * kGrayG, v_in[oc + 2] + vg * kGrayB};
   float va = 0.f;
   if (p.sky) {
     const float k = 1.f - p.alpha[pix];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      va -= v[c] * p.sky[pix * 3 + c];
-      if (v_sky) v_sky[pix * 3 + c] = v[c] * k;
-      v[c] = p.rgb[pix * cs + c] <= 1.f ? v[c] : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
+      va -= v[c] * p.sky[p3 + c];
+      if (v_sky) v_sky[p3 + c] = v[c] * k;
+      v[c] = p.rgb[oc + c] <= 1.f ? v[c] : 0.f;  // torch.clamp(max=1) passes gradient at x <= 1
     }
   }
-  v_in[pix * cs] = v[0]; v_in[pix * cs + 1] = v[1]; v_in[pix * cs + 2] = v[2];
+  v_in[oc] = v[0]; v_in[oc + 1] = v[1]; v_in[oc + 2] = v[2];
   if (cs == 4) {  // RGB+ED form: depth = D / clamp(alpha, min=1e-10); plus the caller's own alpha gradient
     const float a = p.alpha[pix], ac = fmaxf(a, 1e-10f);
     const float vd = p.v_depth ? p.v_depth[pix] : 0.f;
-    v_in[pix * 4 + 3] = vd / ac;
+    v_in[(pix << 2) + 3] = vd / ac;
     if (p.v_alpha_in) va += p.v_alpha_in[pix];
-    if (a >= 1e-10f) va -= p.rgb[pix * 4 + 3] * vd / (ac * ac);  // clamp(min) passes the gradient where alpha >= 1e-10
+    if (a >= 1e-10f) va -= p.rgb[(pix << 2) + 3] * vd / (ac * ac);  // clamp(min) passes the gradient where alpha >= 1e-10
     if (v_alpha) v_alpha[pix] = va;
   } else if (p.sky && v_alpha) {
     v_alpha[pix] = va;
@@ -1533,7 +1546,8 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
                    const float *alpha, const float *sky, void *ws, size_t ws_bytes, float *const *affine_out) {
   BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && lv && H > 0 && W > 0 && rgb && ws);
   BDS_REQUIRE((sky == nullptr) || (alpha != nullptr));
-  BDS_REQUIRE((int64_t)H * W < ((int64_t)1 << 31));   // pixel indices are split with 32-bit arithmetic (fast_divmod)
+  // element offsets into the image-sized arrays (up to 12 floats per pixel) are formed in 32 bits; rows / columns below 2^23 (24-bit multiplies)
+  BDS_REQUIRE((int64_t)H * W * 12 < ((int64_t)1 << 31) && H < (1 << 23) && W < (1 << 23));
   const MsLayout L = ms_layout(nlevels, lv, H, W);
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   BDS_REQUIRE(aligned16(ws));
