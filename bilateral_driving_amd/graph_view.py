@@ -220,6 +220,13 @@ class FrameGraph:
             self._point_grads_at_flat()
 
     # ---- capture -----------------------------------------------------------------------------------------------------------------
+    def _capturing(self, graph, pool):
+        """``torch.cuda.graph`` for this frame's captures.  With an exchange other threads of the process issue HIP calls of their own
+        while we capture (RCCL's proxy, the process group's watchdog): only THIS thread's unsafe calls may invalidate the capture."""
+        if self.fx is not None:
+            return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
+        return torch.cuda.graph(graph, pool=pool)
+
     def capture(self) -> None:
         """(Re-)capture the begin graph and the view graphs against the current parameter / camera tensors and capacities."""
         self.views = [None] * self.V
@@ -285,14 +292,14 @@ class FrameGraph:
             if self.overlap and self.fx is None and self.V > 1:
                 # two begin graphs: the forwards' stream only has to wait until the begin stage has READ view 0's old id list (which
                 # view 0's forward overwrites); the other five clears (~100 us at 2 M Gaussians) run next to that forward
-                with torch.cuda.graph(g, pool=self.pool):
+                with self._capturing(g, self.pool):
                     self._begin_body(views=[0], tail=True)
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=self.pool):
+                with self._capturing(g2, self.pool):
                     self._begin_body(views=range(1, self.V), tail=False)
                 self.begin_graph_rest = g2
             else:
-                with torch.cuda.graph(g, pool=self.pool):
+                with self._capturing(g, self.pool):
                     self._begin_body()
             self.begin_graph = g
             # ALL forwards first, then all image halves, then all Gaussian halves: a block of the forwards' pool that a later stage's
@@ -303,25 +310,25 @@ class FrameGraph:
                 outs = []
                 for v in range(self.V):
                     gf = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gf, pool=self.pool_front):
+                    with self._capturing(gf, self.pool_front):
                         outs.append(self._phase_fwd(v))          # (late_image = "front": stops behind the lists)
                     fronts[v] = gf
                 for v in range(self.V):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.pool_fwd):
+                    with self._capturing(g, self.pool_fwd):
                         outs[v]["image"]()                         # compositor, colour transform, loss value + gradient
                     fwd.append((g, outs[v]))
             else:
                 for v in range(self.V):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.pool_fwd):
+                    with self._capturing(g, self.pool_fwd):
                         out = self._phase_fwd(v)
                     fwd.append((g, out))
             # (the Gaussian half is a graph of its own only where something goes between the halves: a third stream, or the exchange)
             split = self.overlap_tail or self.fx is not None
             for v, (g, out) in enumerate(fwd):
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=self.pools_bwd[v % self.n_bwd_streams]):
+                with self._capturing(gb, self.pools_bwd[v % self.n_bwd_streams]):
                     out["backward"]()
                     if not split:
                         out["backward_tail"]()
@@ -330,7 +337,7 @@ class FrameGraph:
                 gt = None
                 if split:
                     gt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gt, pool=self.pool_tail):
+                    with self._capturing(gt, self.pool_tail):
                         out["backward_tail"]()
                 self.views[v] = ViewGraph(g, out, self.caps[v], self.prep_ws[v], self.skies[v], self.cams[v].viewmat, bwd[v], gt, fronts[v])
         finally:
@@ -344,7 +351,7 @@ class FrameGraph:
         no block a backward's capture frees can be handed to a forward that runs next to it."""
         G = torch.cuda.CUDAGraph()
         side = self.side_stream
-        with torch.cuda.graph(G, pool=self.pool):
+        with self._capturing(G, self.pool):
             cs = torch.cuda.current_stream(self.dev)
             self._begin_body()
             fork = torch.cuda.Event()
