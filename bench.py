@@ -90,6 +90,8 @@ def parse():
                                                              "captured graph (measured slower: 772 vs 909 it/s)")
     ap.add_argument("--single-graph", action="store_true", default=os.environ.get("BDS_SINGLE_GRAPH", "0") == "1",
                     help="graph replay: the whole frame as ONE graph with two branches (world size 1)")
+    ap.add_argument("--phase-shift", action="store_true", default=os.environ.get("BDS_PHASE_SHIFT", "0") == "1",
+                    help="graph replay: three streams, each compositor next to the other stream's gather-bound kernels")
     ap.add_argument("--front-stream", action="store_true", default=os.environ.get("BDS_FRONT_STREAM", "0") == "1",
                     help="graph replay: projection + lists of every view as graphs of their own on a third stream")
     ap.add_argument("--late-image", nargs="?", const="image", default=None, choices=["image", "front"],
@@ -293,7 +295,7 @@ def main():
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail, late_image={None: False, "image": True, "front": "front"}[args.late_image], front_stream=args.front_stream, single_graph=args.single_graph)
+                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail, late_image={None: False, "image": True, "front": "front"}[args.late_image], front_stream=args.front_stream, single_graph=args.single_graph, phase_shift=args.phase_shift)
         L.enable_timers(False)
 
     def step(s):

@@ -71,7 +71,8 @@ class FrameGraph:
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, overlap_tail: bool = False,
-                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False, late_image: bool = False, front_stream: bool = False, single_graph: bool = False):
+                 exchange=None, bwd_streams: int = 1, fork_tail: bool = False, late_image: bool = False, front_stream: bool = False, single_graph: bool = False,
+                 phase_shift: bool = False):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -109,10 +110,16 @@ class FrameGraph:
         # single_graph: the whole frame -- begin body, every forward on a forked branch, every backward behind its forward -- captured
         # as ONE hipGraph with two parallel branches: one launch per frame instead of 1 + 2 per view, no inter-graph gaps on either branch
         self.single_graph = bool(single_graph and overlap and exchange is None and not front_stream and not overlap_tail and bwd_streams <= 1)
+        # phase_shift (implies front_stream and a Gaussian half captured apart): the compositor's forward of view v + 2 is held back until
+        # the compositor's backward of view v has finished, so that each compositor runs next to the OTHER stream's gather-bound
+        # kernels (bilateral, tile stage) instead of next to the other compositor
+        self.phase_shift = bool(phase_shift and overlap and exchange is None)
+        if self.phase_shift:
+            front_stream, overlap_tail = True, True
         self.front_stream = bool(front_stream and overlap and exchange is None)
         self.late_image = "front" if self.front_stream else (late_image if late_image == "front" else bool(late_image))
         self.n_bwd_streams = max(1, int(bwd_streams)) if overlap else 1
-        self.overlap, self.overlap_tail = bool(overlap), bool(overlap and (overlap_tail or self.n_bwd_streams > 1))
+        self.overlap, self.overlap_tail = bool(overlap), bool(overlap and (overlap_tail or self.n_bwd_streams > 1 or (phase_shift and exchange is None)))
         self.list_tile = int(LIST_TILE if list_tile is None else list_tile)
         self.dev = self.params["means"].device
         L.require_gpu(*self.params.values(), *self.grids)
@@ -392,6 +399,9 @@ class FrameGraph:
             return
         self.begin_graph.replay()
         rest = getattr(self, "begin_graph_rest", None)
+        if self.phase_shift and not serial:
+            self._step_phase_shifted(main, rest)
+            return
         if rest is not None and (serial or not self.overlap):
             rest.replay()
             rest = None
@@ -464,6 +474,44 @@ class FrameGraph:
             main.wait_event(self.views[-1].done)     # the frame's gradients are complete for whatever the caller enqueues next
             for bs in self.extra_bwd_streams[:nb - 1]:
                 main.wait_stream(bs)
+
+    def _step_phase_shifted(self, main, rest) -> None:
+        """Three streams, software-pipelined on the host so that every event is recorded before it is waited for: iteration k enqueues
+        front(k) [after forward(k - 2)], image(k) = compositor + colour transform + loss [after front(k) and after the compositor
+        backward of view k - 2], and the backward of view k - 1."""
+        side, fs = self.side_stream, self.front_stream_h
+        self._frame_ready.record(main)
+        side.wait_event(self._frame_ready)
+        fs.wait_event(self._frame_ready)
+        if rest is not None:
+            rest.replay()
+            self._frame_ready_rest.record(main)
+        V = self.V
+        for k in range(V + 1):
+            if k < V:
+                vg = self.views[k]
+                with torch.cuda.stream(fs):
+                    if k == 1 and rest is not None:
+                        fs.wait_event(self._frame_ready_rest)
+                    if k >= 2:
+                        fs.wait_event(self.views[k - 2].fwd_done)
+                    vg.graph_front.replay()
+                    vg.front_done.record(fs)
+                with torch.cuda.stream(side):
+                    side.wait_event(vg.front_done)
+                    if k >= 2:
+                        side.wait_event(self.views[k - 2].bwd_done)
+                    vg.graph.replay()
+                    vg.fwd_done.record(side)
+            if k >= 1:
+                vb = self.views[k - 1]
+                main.wait_event(vb.fwd_done)
+                vb.graph_bwd.replay()
+                vb.bwd_done.record(main)
+                vb.graph_tail.replay()
+                vb.done.record(main)
+        main.wait_stream(fs)
+        main.wait_stream(side)
 
     def mark_samples(self, name: str):
         """Milliseconds of every timing mark pair ``name`` captured into the view graphs (``_lib.enable_timers`` on during the

@@ -108,7 +108,7 @@ def test_device_count_overflow_renders_nothing_and_is_flagged(mods):
             assert t.grad is None or float(t.grad.abs().max()) == 0.0, k
 
 
-@pytest.mark.parametrize("overlap", [False, True, "tail", "two", "late", "front", "fronts", "single"])
+@pytest.mark.parametrize("overlap", [False, True, "tail", "two", "late", "front", "fronts", "single", "shift"])
 @pytest.mark.parametrize("n_views", [1, 3])
 def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
     """FrameGraph.step() (begin graph + one hipGraph per view) == the eager host-count frame, over several replays, and the flat
@@ -120,7 +120,7 @@ def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
     outs, g_ref, sky_ref, vm_ref = _eager_frame(Hn, cams, p, grids, skies, targets)
     frame = GV.FrameGraph(p, cams, grids, skies, targets, overlap=bool(overlap), overlap_tail=overlap == "tail",
                           bwd_streams=2 if overlap == "two" else 1, late_image={"late": True, "front": "front"}.get(overlap, False),
-                          front_stream=overlap == "fronts", single_graph=overlap == "single")
+                          front_stream=overlap == "fronts", single_graph=overlap == "single", phase_shift=overlap == "shift")
     assert frame.single_graph == (overlap == "single")
     for rep in range(3):
         frame.step()
