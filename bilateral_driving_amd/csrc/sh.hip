@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
                                                                         const int32_t *__restrict__ ids, int K,
                                                                         float *__restrict__ v_means, float *__restrict__ v_quats,
                                                                         float *__restrict__ v_log_scales, float *__restrict__ v_logits,
-                                                                        float *__restrict__ v_sh) {
+                                                                        float *__restrict__ v_sh, float2 *__restrict__ grad2d,
+                                                                        float2 *__restrict__ absgrad2d) {
   __shared__ int32_t s_g[kShBlock];
   const int64_t n_list = list_length(n_cap, n_dev);
   const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
@@ -328,6 +329,9 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
       for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
       for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
       v_logits[g] = 0.f;
+      // (the view's persistent screen-space gradient arrays: the list-driven projection backward STORES the visible rows)
+      if (grad2d) grad2d[g] = make_float2(0.f, 0.f);
+      if (absgrad2d) absgrad2d[g] = make_float2(0.f, 0.f);
     }
   }
   __syncthreads();
@@ -558,17 +562,20 @@ extern "C" int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_de
 }
 
 static int view_grads_clear_list_impl(int64_t n_list, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means, float *v_quats,
-                                      float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
+                                      float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream, float *grad2d = nullptr,
+                                      float *absgrad2d = nullptr) {
   BDS_REQUIRE(n_list >= 0 && K >= 1 && K <= 16);
   if (n_list == 0) return BDS_OK;
   BDS_REQUIRE(ids && v_means && v_quats && v_log_scales && v_logits && v_sh);
+  BDS_REQUIRE((reinterpret_cast<uintptr_t>(grad2d) & 7u) == 0 && (reinterpret_cast<uintptr_t>(absgrad2d) & 7u) == 0);
+  float2 *g2 = reinterpret_cast<float2 *>(grad2d), *a2 = reinterpret_cast<float2 *>(absgrad2d);
   const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);
   if (((K * 3) % 4 == 0) && aligned16(v_sh))
     hipLaunchKernelGGL((view_grads_clear_list_kernel<true>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, K, v_means, v_quats,
-                       v_log_scales, v_logits, v_sh);
+                       v_log_scales, v_logits, v_sh, g2, a2);
   else
     hipLaunchKernelGGL((view_grads_clear_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, K, v_means, v_quats,
-                       v_log_scales, v_logits, v_sh);
+                       v_log_scales, v_logits, v_sh, g2, a2);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -579,9 +586,10 @@ extern "C" int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int
 }
 
 extern "C" int bds_view_grads_clear_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means,
-                                             float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream) {
+                                             float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, float *grad2d,
+                                             float *absgrad2d, bds_stream_t stream) {
   BDS_REQUIRE(n_dev);
-  return view_grads_clear_list_impl(n_capacity, n_dev, ids, K, v_means, v_quats, v_log_scales, v_logits, v_sh, stream);
+  return view_grads_clear_list_impl(n_capacity, n_dev, ids, K, v_means, v_quats, v_log_scales, v_logits, v_sh, stream, grad2d, absgrad2d);
 }
 
 extern "C" int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const float *s_means, const float *s_quats,

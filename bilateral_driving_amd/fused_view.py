@@ -389,8 +389,12 @@ class _FusedView(torch.autograd.Function):
         ctx.dev_counts = None if f.m_dev is None else (f.m_dev, f.nvis_dev)
         want_pose = bool(ctx.needs_input_grad[7])
         v_rec_all = None
+        ctx.loss_rows = 0
         if f.m_dev is not None:
-            v_rec_all = _empty((f.n_vis + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS), dev)
+            # (+ the slotted accumulator of the training loss behind them: the pack's tail clear covers it, no fill launch)
+            if cfg.get("train_loss") is not None and os.environ.get("BDS_FEWER_LAUNCHES", "1") == "1":
+                ctx.loss_rows = L.LOSS_SLOTS * L.LOSS_SLOT_STRIDE // L.GRAD_RECORD_FLOATS
+            v_rec_all = _empty((f.n_vis + (L.POSE_GRAD_SLOTS if want_pose else 0) + ctx.loss_rows, L.GRAD_RECORD_FLOATS), dev)
         ctx.v_rec_all = v_rec_all
         early = bool(cfg.get("yield_after_front"))
         if early:                          # (the generator's one stop: behind the front, or -- default -- behind the compositor)
@@ -403,10 +407,12 @@ class _FusedView(torch.autograd.Function):
         # Work of the backward that depends on the compositor's outputs only -- the longest-tile-first schedule of the compositor's
         # backward and the zeroed dense screen-space gradient arrays -- can be done HERE (_SCHEDULE_IN_FORWARD), on whichever of the
         # graph-replayed frame's two streams has the slack.
-        ctx.order = ctx.g2d = None
+        ctx.order = None
+        ctx.g2d = cfg.get("g2d_buf")       # (a caller-owned persistent buffer, kept clean row-wise by the caller: graph_view)
         if any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD:
             ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
-            ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
+            if ctx.g2d is None:
+                ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         if not early:
             yield radii
             lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
@@ -416,7 +422,11 @@ class _FusedView(torch.autograd.Function):
         with L.timed("bilagrid_fwd"):
             if tl is not None:
                 from .losses import loss_slots
-                loss_acc, v_rgb_loss = loss_slots(dev), _empty((H, W, 3), dev)
+                v_rgb_loss = _empty((H, W, 3), dev)
+                if ctx.loss_rows:       # cleared by the record pack together with the gradient records
+                    loss_acc = ctx.v_rec_all[ctx.v_rec_all.shape[0] - ctx.loss_rows:].view(-1)
+                else:
+                    loss_acc = loss_slots(dev)
                 L.check(lib.bds_bilagrid_ms_ed_train_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
                                                          L.ptr(rgb), L.ptr(depth), L.ptr(tl["target"]), len(tl["grids"]), tl["levels"],
                                                          tl["weights"], 1.0, L.ptr(loss_acc), L.LOSS_SLOTS, L.ptr(v_rgb_loss), st),
@@ -591,7 +601,8 @@ class _FusedView(torch.autograd.Function):
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
-        v_vm_slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS, 4, 4) if want_pose else None   # camera-pose gradient (base.py:328-329,399)
+        v_vm_slots = (v_rec_all[max(n_vis, 1):max(n_vis, 1) + L.POSE_GRAD_SLOTS].view(L.POSE_GRAD_SLOTS, 4, 4)
+                      if want_pose else None)   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
             if dev_counts is not None:
                 L.check(lib.bds_project_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales),
@@ -804,6 +815,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     late_image = kwargs.pop("late_image", False)      # False | True (stop behind the compositor) | "front" (stop behind the lists)
     late_image = late_image if two_phase else False
     tail_fork_stream = kwargs.pop("tail_fork_stream", None)
+    g2d_buf = kwargs.pop("g2d_buf", None)    # persistent [2,N,2] screen-space gradient arrays whose stale rows the caller clears
+    lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
     assert not kwargs, f"unknown arguments {sorted(kwargs)}"
@@ -812,7 +825,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws,
-               tail_fork_stream=tail_fork_stream, yield_after_front=late_image == "front")
+               tail_fork_stream=tail_fork_stream, yield_after_front=late_image == "front", g2d_buf=g2d_buf)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
@@ -888,7 +901,9 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     def backward_tail():     # Gaussian half; gradients land where autograd would put them
         with torch.no_grad():
             if state.get("loss_slots") is not None:      # the loss VALUE: a small reduction nobody waits for
-                out["loss"] = slots_value(state.pop("loss_slots"))
+                out["loss_slots"] = state.pop("loss_slots")
+                if not lazy_loss:
+                    out["loss"] = slots_value(out["loss_slots"])
             try:
                 next(state["steps"])
                 raise AssertionError("backward_steps yields once")

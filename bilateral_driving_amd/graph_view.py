@@ -38,6 +38,11 @@ from .fused_view import LIST_TILE, ListCapacity
 from . import harness as Hn
 
 
+# A/B switch (measurement): 0 = the loss accumulator filled and summed, and the screen-space gradient arrays filled, by launches of
+# their own in every view (three more launches per view)
+_FEWER_LAUNCHES = os.environ.get("BDS_FEWER_LAUNCHES", "1") == "1"
+
+
 class ViewGraph:
     """One captured view: forward, L1 + TV loss and backward of camera ``cam`` with image index ``img_idx`` -- ONE graph, or two
     (``graph`` = forward + loss value, ``graph_bwd`` = the rest) when the frame overlaps a view's forward with the previous view's
@@ -48,11 +53,21 @@ class ViewGraph:
         self.graph, self.graph_bwd, self.graph_tail, self.out, self.caps, self.prep_ws = graph, graph_bwd, graph_tail, out, caps, prep_ws
         self.graph_front = graph_front   # (front_stream: projection + lists captured apart from the compositor / colour transform)
         self.front_done = torch.cuda.Event()
-        self.loss = out["loss"]          # static tensors: rewritten by every replay
+        # static tensors: rewritten by every replay.  The loss VALUE is left as its slotted accumulator when the loss rode on the colour
+        # transform's launch (``loss`` sums the 64 slots on demand: one launch less per view in the replayed frame)
+        self._loss, self._loss_slots = out.get("loss"), out.get("loss_slots")
         self.rgb, self.depth, self.opacity = out["rgb"], out["depth"], out["opacity"]
         self.v_sky, self.v_viewmat = sky.grad, viewmat.grad
         self.done = torch.cuda.Event()
         self.fwd_done, self.bwd_done = torch.cuda.Event(), torch.cuda.Event()
+
+    @property
+    def loss(self) -> Tensor:
+        if self._loss_slots is None:
+            return self._loss
+        from .losses import slots_value
+        torch.cuda.current_stream(self._loss_slots.device).wait_event(self.done)
+        return slots_value(self._loss_slots)
 
     def replay(self) -> None:
         """All three graphs of the view on the current stream (world size 1: with an exchange the collectives go between them,
@@ -149,6 +164,10 @@ class FrameGraph:
         # caller-owned prepare workspaces: a view's visible-id list and its counts live here from one frame to the next (the next
         # frame's begin graph clears exactly those gradient rows).  Zero-initialised: "no rows yet".
         self.prep_ws = [torch.zeros(max(self._ws_bytes, 16), device=self.dev, dtype=torch.uint8) for _ in range(self.V)]
+        # per view: d(loss)/d(means2d) and its absolute sum, [2, N, 2], dense for the densification statistics (info["means2d"].grad /
+        # .absgrad); the projection backward stores the visible rows, the begin stage clears the rows of the previous visit
+        self.g2d = ([torch.zeros(2, self.N, 2, device=self.dev, dtype=torch.float32) for _ in range(self.V)]
+                    if not (exchange is not None and exchange.active) else None)
         self._unions = [0] * self.V
         # (inside the captured backward: the SH half of the Gaussian backward forks onto this stream, see fused_view.backward_steps)
         self._fork_stream = torch.cuda.Stream(device=self.dev) if fork_tail else None
@@ -181,12 +200,13 @@ class FrameGraph:
     # ---- the phases of a view (eager warm-up, capture and replay walk the same protocol) -------------------------------------------
     def _view_kwargs(self, v: int) -> dict:
         kw = dict(factors=self.factors, tv_weight=self.tv_weight, caps=self.caps[v], prep_ws=self.prep_ws[v], list_tile=self.list_tile,
-                  sh_degree=self.sh_degree, two_phase=True, tail_fork_stream=self._fork_stream, late_image=self.late_image)
+                  sh_degree=self.sh_degree, two_phase=True, tail_fork_stream=self._fork_stream, late_image=self.late_image,
+                  lazy_loss=_FEWER_LAUNCHES)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
         else:
             kw.update(grid_grads=[self.arena[f"grid{i}"] for i in range(len(self.grids))], grad_arena=self.arena,
-                      arena_rows=1 if v == 0 else 2)
+                      arena_rows=1 if v == 0 else 2, g2d_buf=self.g2d[v] if _FEWER_LAUNCHES else None)
         return kw
 
     def _phase_fwd(self, v: int):
@@ -214,9 +234,11 @@ class FrameGraph:
         for v in (range(self.V) if views is None else views):
             ws = self.prep_ws[v]
             ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
+            g2 = self.g2d[v]      # (the view's persistent screen-space gradient arrays: the same rows, no dense fill per view)
             L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K,
                                                       L.ptr(a["means"]), L.ptr(a["quats"]), L.ptr(a["log_scales"]),
-                                                      L.ptr(a["opacity_logits"]), L.ptr(a["sh"]), st), "bds_view_grads_clear_list_dev")
+                                                      L.ptr(a["opacity_logits"]), L.ptr(a["sh"]), L.ptr(g2[0]), L.ptr(g2[1]), st),
+                    "bds_view_grads_clear_list_dev")
         if self._tail.numel() and tail:
             self._tail.zero_()
 

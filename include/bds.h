@@ -397,8 +397,11 @@ int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, con
                                   const float *K, int W, int H, float eps2d, const float *v_records, float *v_means, float *v_quats,
                                   float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d, float *absgrad2d,
                                   const int32_t *row_map, int accumulate, bds_stream_t stream);
+/* (grad2d / absgrad2d [N,2], optional: the same rows of a view's PERSISTENT screen-space gradient arrays are cleared as well -- the
+ * list-driven projection backward stores the visible rows, so a buffer cleared by the previous visit's list needs no dense fill) */
 int bds_view_grads_clear_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means,
-                                  float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
+                                  float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, float *grad2d, float *absgrad2d,
+                                  bds_stream_t stream);
 
 /* ---- multi-GPU exchange of the visible rows (no reference counterpart; dist.FrameExchange) ---------------------------------------
  * mask [N] uint8: the element-wise OR over the ranks of "this rank's view sees Gaussian g" (radii > 0).  In two launches:

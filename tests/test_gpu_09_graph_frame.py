@@ -51,7 +51,8 @@ def _eager_frame(Hn, cams, p, grids, skies, targets):
         out = Hn.render_view(p, cam, grids, v, skies[v])
         loss = Hn.training_loss(out, targets[v], grids)
         loss.backward()
-        outs.append((out["rgb"].detach().clone(), out["depth"].detach().clone(), float(loss), out["info"]["n_isects"], out["info"]["n_visible"]))
+        outs.append((out["rgb"].detach().clone(), out["depth"].detach().clone(), float(loss), out["info"]["n_isects"], out["info"]["n_visible"],
+                     out["info"]["means2d"].absgrad.clone()))
     grads = {k: t.grad.clone() for k, t in p.items()}
     grads.update({f"grid{i}": g.grad.clone() for i, g in enumerate(grids)})
     return outs, grads, [s.grad.clone() for s in skies], [c.viewmat.grad.clone() for c in cams]
@@ -130,6 +131,9 @@ def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
             assert abs(float(vg.loss) - outs[v][2]) < 1e-6 * max(1.0, abs(outs[v][2]))
             assert frame.counts()[v] == (outs[v][3], outs[v][4])
             assert rel_err(vg.v_sky, sky_ref[v]) < 1e-6 and rel_err(vg.v_viewmat, vm_ref[v]) < 1e-4
+            # the view's persistent screen-space gradient arrays (info["means2d"].absgrad of the eager view): rows of this visit only
+            assert rel_err(frame.g2d[v][1], outs[v][5][0]) < 2e-4, (rep, v)
+            assert torch.equal(frame.g2d[v][1] != 0, outs[v][5][0] != 0)
         for k, t in p.items():
             assert t.grad.data_ptr() == frame.arena[k].data_ptr()
             assert rel_err(t.grad, g_ref[k]) < 2e-4, (rep, k)   # (float atomics in the compositor backward: the order of the sums varies)
@@ -164,9 +168,11 @@ def test_frame_graph_follows_parameter_updates_and_grows_on_overflow(mods):
     assert frame.valid()
     got = {k: t.grad.clone() for k, t in p.items()}
     rgb = [vg.rgb.clone() for vg in frame.views]
+    absg = [g[1].clone() for g in frame.g2d]
     outs, g_ref, _, _ = _eager_frame(Hn, cams, p, grids, skies, targets)
     for v in range(len(cams)):
         assert torch.equal(rgb[v], outs[v][0])
+        assert rel_err(absg[v], outs[v][5][0]) < 3e-5      # (stale rows of the visits before the update cleared by their lists)
     for k in got:
         assert rel_err(got[k], g_ref[k]) < 3e-5, k
 
