@@ -73,7 +73,8 @@ _SIGS = {
     "bds_isect_build_dev": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _i, _f]),
     "bds_splat_pack_sh_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f]),
     "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f]),
-    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_bwd_schedule_sort": (_i, [_i, _i, _i, _f, _f]),
     "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
     "bds_sh_view_bwd_list_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_project_view_bwd_list_dev": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),

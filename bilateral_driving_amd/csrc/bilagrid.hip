@@ -681,11 +681,16 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, Lev
 
 // v_grid[e] += sum_b partials[b][e].  Workgroup = 32 grid entries x 8 partial-lanes: coalesced 128-byte
 // rows, 8 independent loads in flight per thread, fixed summation order (deterministic).
-__global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams p, LevelSched sc, LevelSched red,
-                                                                       const float *__restrict__ partials_all) {
-  __shared__ float sred[8][33];
+struct PartialsJob {   // the reduction of the low-res backward's per-workgroup partial grids, riding on the launch behind it
+  LevelSched sc, red;
+  const float *partials;
+  int pix_blocks;      // workgroups [pix_blocks, pix_blocks + red.blk_off[red.n]) of the host launch run it (0 extra: nothing to do)
+};
+
+__device__ __forceinline__ void grid_partials_reduce_block(const MsParams &p, const LevelSched &sc, const LevelSched &red,
+                                                           const float *__restrict__ partials_all, int bid, float (*sred)[33]) {
   int local;
-  const int k = sched_find(red, blockIdx.x, local);  // `red` mirrors `sc` entry by entry, with its own block ranges
+  const int k = sched_find(red, bid, local);  // `red` mirrors `sc` entry by entry, with its own block ranges
   const LevelDev &L = p.lv[sc.level[k]];
   const int gtot = 12 * L.gl * L.gy * L.gx * L.n_avg, nparts = sc.nblk[k];
   const float *partials = partials_all + sc.part_off[k];
@@ -713,13 +718,20 @@ __global__ __launch_bounds__(kBgBlock) void grid_partials_reduce_kernel(MsParams
   }
 }
 
+
 // ---- E: guidance route gather + clamp / sky blend backward (in place on v_in) -----------------------
 // v_in already holds the direct-route gradient.  Every level adds  gray_weights * sum_{low-res pixels whose
 // down-sample taps include this pixel} w * v_gray  (adjoint of the bilinear down-sampler, gather form), then the
 // clamp(max=1) + sky blend in front of the transform is back-propagated.
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParams p, float *__restrict__ v_in,
-                                                                        float *__restrict__ v_alpha, float *__restrict__ v_sky, int dbg) {
+                                                                        float *__restrict__ v_alpha, float *__restrict__ v_sky, int dbg,
+                                                                        PartialsJob pj) {
+  if ((int)blockIdx.x >= pj.pix_blocks) {   // (both only need the low-res kernel's results: one launch instead of two)
+    __shared__ float sred[8][33];
+    grid_partials_reduce_block(p, pj.sc, pj.red, pj.partials, (int)blockIdx.x - pj.pix_blocks, sred);
+    return;
+  }
   const int pix = (int)blockIdx.x * kBgBlock + (int)threadIdx.x;
   if (pix >= p.H * p.W) return;
   int y, x;
@@ -1833,7 +1845,9 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   }
   const MsLayout ML = ms_layout(nlevels, levels, H, W);
   float *partials = reinterpret_cast<float *>(static_cast<char *>(ws) + ML.part_off);
-  {  // low-res backward: LDS-path levels together in one persistent launch, then one reduce launch
+  PartialsJob pj{};
+  int extra_blocks = 0;
+  {  // low-res backward: LDS-path levels together in one persistent launch; their partial grids are reduced by the next launch
     LevelSched sc{}, red{};
     size_t lds_max = 0;
     long long poff = 0;
@@ -1879,21 +1893,19 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       hipLaunchKernelGGL((ms_lowres_bwd_kernel<true>), dim3((unsigned)sc.blk_off[sc.n]), dim3(kBgBlock), lds_bytes, st, p, sc, v_rgb,
                          partials, option_get(kOptDebug), (int)(lds_bytes / sizeof(float)));
       BDS_LAUNCH_CHECK();
-      if (red.blk_off[red.n] > 0) {
-        hipLaunchKernelGGL(grid_partials_reduce_kernel, dim3((unsigned)red.blk_off[red.n]), dim3(kBgBlock), 0, st, p, sc, red,
-                           partials);
-        BDS_LAUNCH_CHECK();
-      }
+      if (red.blk_off[red.n] > 0) { pj.sc = sc; pj.red = red; pj.partials = partials; extra_blocks = red.blk_off[red.n]; }
     }
   }
   {
-    const dim3 grid((unsigned)cdiv(HW, kBgBlock)), block(kBgBlock);
+    // (the reduction of the partial grids rides on this launch as extra workgroups)
+    pj.pix_blocks = (int)cdiv(HW, kBgBlock);
+    const dim3 grid((unsigned)(pj.pix_blocks + extra_blocks)), block(kBgBlock);
     switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<1>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
-      case 2: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<2>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
-      case 3: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<3>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
-      case 4: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<4>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
-      default: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug)); break;
+      case 1: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<1>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug), pj); break;
+      case 2: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<2>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug), pj); break;
+      case 3: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<3>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug), pj); break;
+      case 4: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<4>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug), pj); break;
+      default: hipLaunchKernelGGL((ms_guidance_blend_bwd_kernel<BDS_MAX_LEVELS>), grid, block, 0, st, p, v_rgb, v_alpha, v_sky, option_get(kOptDebug), pj); break;
     }
     BDS_LAUNCH_CHECK();
   }

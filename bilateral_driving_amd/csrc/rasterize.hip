@@ -229,7 +229,8 @@ template <int CH, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg) {
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
+    int32_t *__restrict__ tile_work) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;   // (the list length may live on the device: bds_rasterize_fwd_dev)
   const int n_tiles = tile_w * tile_h;
@@ -336,6 +337,12 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 #pragma unroll
       for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + Tf * backgrounds[cam * CH + k] : out[q][k];
     }
+  }
+  if (tile_work) {
+    // the backward's schedule key: how far into its list this tile blended (what tile_work_kernel re-derives from last_ids; pixels
+    // outside the image and pixels that blended nothing hold 0)
+    const int m = wave_max_i32(max(max(cur[0], cur[1]), max(cur[2], cur[3])));
+    if (lane == 0) tile_work[item] = max(0, m - start + 1);
   }
 }
 
@@ -690,7 +697,7 @@ static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
 static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                              int32_t *last_ids, bds_stream_t stream) {
+                              int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -707,7 +714,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   const size_t pad_fwd = (size_t)option_get(kOptPadFwd) * 1024u;
 #define BDS_FWD(ch, co)                                                                                                              \
   hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), pad_fwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
-                     tile_h, isect_offsets, flatten, render, alphas, last_ids, lg)
+                     tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work)
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
@@ -733,10 +740,21 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
 extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                                     int32_t *last_ids, bds_stream_t stream) {
+                                     int32_t *last_ids, int32_t *tile_order, bds_stream_t stream) {
   BDS_REQUIRE(M_dev && M_capacity > 0);
+  // tile_order (optional, int32[2 * C*tile_w*tile_h] as for bds_rasterize_bwd_schedule): every tile's schedule key is left in the
+  // second half by the compositing wave itself; bds_rasterize_bwd_schedule_sort then orders the first half
   return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, render, alphas, last_ids, stream);
+                            isect_offsets, flatten, render, alphas, last_ids, stream,
+                            tile_order ? tile_order + (int64_t)C * tile_w * tile_h : nullptr);
+}
+
+extern "C" int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream) {
+  BDS_REQUIRE(C >= 1 && tile_w > 0 && tile_h > 0 && tile_order);
+  const int total = C * tile_w * tile_h;
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, as_stream(stream), total, tile_order + total, tile_order);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
 }
 
 static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,

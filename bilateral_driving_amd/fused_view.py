@@ -300,7 +300,7 @@ def _image_buffers(W: int, H: int, dev):
     return _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((1, H, W), dev, torch.int32)
 
 
-def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional[Tensor] = None):
+def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional[Tensor] = None, tile_order: Optional[Tensor] = None):
     """Splat records of the visible Gaussians with the given opacities [N] + the forward composite (RGB + depth).
     ``images``: (render, alphas, last_ids) allocated by the caller (before the host wait), else allocated here.
     ``zero_grad_records`` (device-count form): [n_vis capacity + pose slots, 16] gradient records the pack clears on its way."""
@@ -326,9 +326,10 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
                 L.check(lib.bds_splat_pack_dev(n_vis, f.nvis_dev, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors),
                                                L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(zr), L.ptr(tail),
                                                0 if tail is None else tail.numel(), st), "bds_splat_pack_dev")
+            # (tile_order: the backward's schedule keys are left by the compositing waves themselves)
             L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
-                                              L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),
-                    "bds_rasterize_fwd_dev")
+                                              L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids),
+                                              L.ptr(tile_order), st), "bds_rasterize_fwd_dev")
         return rec, render, alphas, last_ids
     if f.rec_buf is not None:      # provisioned before the wait (first composite over this front only)
         rec, f.rec_buf = f.rec_buf[:n_vis], None
@@ -400,7 +401,12 @@ class _FusedView(torch.autograd.Function):
         if early:                          # (the generator's one stop: behind the front, or -- default -- behind the compositor)
             yield radii
             lib, st = L.lib(), L.stream()
-        rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all)
+        # device-count form with a backward to follow: the compositor leaves the schedule keys of its own backward (one launch less)
+        sched_buf = None
+        if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
+            sched_buf = _empty((2 * f.tw * f.th,), dev, torch.int32)
+        rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all, sched_buf)
+        tiles_wh = (f.tw, f.th)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f_list_tile = f.list_tile
         del f
@@ -410,7 +416,12 @@ class _FusedView(torch.autograd.Function):
         ctx.order = None
         ctx.g2d = cfg.get("g2d_buf")       # (a caller-owned persistent buffer, kept clean row-wise by the caller: graph_view)
         if any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD:
-            ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
+            if sched_buf is not None:
+                L.check(lib.bds_rasterize_bwd_schedule_sort(1, tiles_wh[0], tiles_wh[1], L.ptr(sched_buf), L.stream()),
+                        "bds_rasterize_bwd_schedule_sort")
+                ctx.order = sched_buf
+            else:
+                ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
             if ctx.g2d is None:
                 ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
         if not early:

@@ -379,10 +379,14 @@ int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32
                           const float *opacities, const int32_t *radii, float *records, float *sh_rgb, float *zero_records,
                           float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream);
 /* bds_rasterize_fwd / _bwd with the list length on the device (M_dev -> M effective) */
+/* (tile_order, optional: int32[2 * C*tile_w*tile_h] as for bds_rasterize_bwd_schedule -- every compositing wave leaves its tile's
+ * schedule key (how far into its list the tile blended) in the second half; bds_rasterize_bwd_schedule_sort then writes the
+ * longest-first schedule into the first half: one launch instead of bds_rasterize_bwd_schedule's two) */
 int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, int32_t *last_ids,
-                          bds_stream_t stream);
+                          int32_t *tile_order, bds_stream_t stream);
+int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream);
 int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,

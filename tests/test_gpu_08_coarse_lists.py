@@ -90,3 +90,41 @@ def test_fused_view_list_tile_64_equals_16(W, H, N):
     o64 = render_classes(base, cam.viewmat, cam.K, W, H, m, list_tile=64)
     for k in o16:
         assert torch.equal(o16[k], o64[k]), k
+
+
+@pytest.mark.parametrize("list_tile", [16, 64])
+def test_schedule_keys_left_by_the_forward_compositor(list_tile):
+    """bds_rasterize_fwd_dev(tile_order=...) + bds_rasterize_bwd_schedule_sort == bds_rasterize_bwd_schedule (keys re-derived from
+    last_ids by a launch of its own): same per-tile keys, same schedule."""
+    import math
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd import gs_ops as ops
+    from bilateral_driving_amd import harness as Hn
+    dev = torch.device("cuda")
+    W, H, N = 330, 200, 6000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(0.0,), device=dev)[0]
+    p = Hn.synthetic_scene(N, seed=5, device=dev)
+    lib, st = L.lib(), L.stream()
+    with torch.no_grad():
+        radii, m2, dep, con, _ = ops.fully_fused_projection(p["means"], p["quats"], torch.exp(p["log_scales"]), cam.viewmat[None], cam.K[None],
+                                                            W, H, near_plane=0.1)
+        op = torch.sigmoid(p["opacity_logits"])[None].contiguous()
+        ltw, lth = math.ceil(W / list_tile), math.ceil(H / list_tile)
+        tw, th = math.ceil(W / 16), math.ceil(H / 16)
+        _, _, fids, offs = ops.isect_tiles(m2, radii, dep, list_tile, ltw, lth, want_isect_ids=False, conics=con, opacities=op)
+        M = fids.numel()
+        col = torch.rand(1, N, 4, device=dev)
+        rec = torch.empty(N, L.SPLAT_RECORD_FLOATS, device=dev)
+        L.check(lib.bds_splat_pack(N, 4, None, L.ptr(m2), L.ptr(con), L.ptr(col), L.ptr(op), L.ptr(radii), L.ptr(rec), st), "pack")
+        render, alphas = torch.empty(1, H, W, 4, device=dev), torch.empty(1, H, W, 1, device=dev)
+        last = torch.zeros(1, H, W, dtype=torch.int32, device=dev)
+        m_dev = torch.tensor([M], dtype=torch.int64, device=dev)
+        order = torch.full((2 * tw * th,), -7, dtype=torch.int32, device=dev)
+        L.check(lib.bds_rasterize_fwd_dev(1, N, M + 100, m_dev.data_ptr(), 4, L.ptr(rec), None, W, H, 16, list_tile, tw, th, L.ptr(offs), L.ptr(fids),
+                                          L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(order), st), "fwd")
+        L.check(lib.bds_rasterize_bwd_schedule_sort(1, tw, th, L.ptr(order), st), "sort")
+        ref = ops.bwd_schedule(1, W, H, list_tile, offs, last)
+        torch.cuda.synchronize()
+    assert int(order.min()) >= 0
+    assert torch.equal(order[tw * th:], ref[tw * th:]) and int(ref[tw * th:].max()) > 0        # keys
+    assert torch.equal(order[:tw * th], ref[:tw * th])                                        # schedule
