@@ -300,7 +300,8 @@ def _image_buffers(W: int, H: int, dev):
     return _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((1, H, W), dev, torch.int32)
 
 
-def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional[Tensor] = None, tile_order: Optional[Tensor] = None):
+def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional[Tensor] = None, tile_order: Optional[Tensor] = None,
+               zero_tail: Optional[Tensor] = None):
     """Splat records of the visible Gaussians with the given opacities [N] + the forward composite (RGB + depth).
     ``images``: (render, alphas, last_ids) allocated by the caller (before the host wait), else allocated here.
     ``zero_grad_records`` (device-count form): [n_vis capacity + pose slots, 16] gradient records the pack clears on its way."""
@@ -314,7 +315,7 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
             rec = _empty((n_vis, L.SPLAT_RECORD_FLOATS), dev)
         render, alphas, last_ids = images if images is not None else _image_buffers(W, H, dev)
         zr = zero_grad_records
-        tail = None if zr is None or zr.shape[0] <= n_vis else zr[n_vis:]
+        tail = zero_tail if zero_tail is not None else (None if zr is None or zr.shape[0] <= n_vis else zr[n_vis:])
         with L.timed("rasterize_fwd"):
             if f.colors is None:   # SH colours evaluated by the pack (visible Gaussians only); un-clamped values kept in list order
                 f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
@@ -395,7 +396,17 @@ class _FusedView(torch.autograd.Function):
             # (+ the slotted accumulator of the training loss behind them: the pack's tail clear covers it, no fill launch)
             if cfg.get("train_loss") is not None and os.environ.get("BDS_FEWER_LAUNCHES", "1") == "1":
                 ctx.loss_rows = L.LOSS_SLOTS * L.LOSS_SLOT_STRIDE // L.GRAD_RECORD_FLOATS
-            v_rec_all = _empty((f.n_vis + (L.POSE_GRAD_SLOTS if want_pose else 0) + ctx.loss_rows, L.GRAD_RECORD_FLOATS), dev)
+            tail_buf = cfg.get("tail_buf")     # caller-owned [POSE_GRAD_SLOTS + loss rows, 16] (graph_view: all views' slots in one tensor)
+            if tail_buf is not None:
+                assert tail_buf.shape[0] >= L.POSE_GRAD_SLOTS + ctx.loss_rows and tail_buf.shape[1] == L.GRAD_RECORD_FLOATS
+                assert tail_buf.is_contiguous()
+                v_rec_all, ctx.tail = _empty((f.n_vis, L.GRAD_RECORD_FLOATS), dev), tail_buf[:L.POSE_GRAD_SLOTS + ctx.loss_rows]
+                ctx.tail_pose = tail_buf[:L.POSE_GRAD_SLOTS] if want_pose else None
+            else:
+                n_pose = L.POSE_GRAD_SLOTS if want_pose else 0
+                v_rec_all = _empty((f.n_vis + n_pose + ctx.loss_rows, L.GRAD_RECORD_FLOATS), dev)
+                ctx.tail = v_rec_all[f.n_vis:] if n_pose + ctx.loss_rows else None
+                ctx.tail_pose = v_rec_all[f.n_vis:f.n_vis + n_pose] if want_pose else None
         ctx.v_rec_all = v_rec_all
         early = bool(cfg.get("yield_after_front"))
         if early:                          # (the generator's one stop: behind the front, or -- default -- behind the compositor)
@@ -405,7 +416,7 @@ class _FusedView(torch.autograd.Function):
         sched_buf = None
         if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
             sched_buf = _empty((2 * f.tw * f.th,), dev, torch.int32)
-        rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all, sched_buf)
+        rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all, sched_buf, getattr(ctx, "tail", None))
         tiles_wh = (f.tw, f.th)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
         ctx.list_tile = f_list_tile = f.list_tile
@@ -435,7 +446,7 @@ class _FusedView(torch.autograd.Function):
                 from .losses import loss_slots
                 v_rgb_loss = _empty((H, W, 3), dev)
                 if ctx.loss_rows:       # cleared by the record pack together with the gradient records
-                    loss_acc = ctx.v_rec_all[ctx.v_rec_all.shape[0] - ctx.loss_rows:].view(-1)
+                    loss_acc = ctx.tail[ctx.tail.shape[0] - ctx.loss_rows:].view(-1)
                 else:
                     loss_acc = loss_slots(dev)
                 L.check(lib.bds_bilagrid_ms_ed_train_fwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws_bytes,
@@ -612,8 +623,12 @@ class _FusedView(torch.autograd.Function):
         v_means, v_quats = out_like("means", means), out_like("quats", quats)
         v_ls, v_logits = out_like("log_scales", log_scales), out_like("opacity_logits", opac)
         Kmat = cfg["K"].contiguous()
-        v_vm_slots = (v_rec_all[max(n_vis, 1):max(n_vis, 1) + L.POSE_GRAD_SLOTS].view(L.POSE_GRAD_SLOTS, 4, 4)
-                      if want_pose else None)   # camera-pose gradient (base.py:328-329,399)
+        if dev_counts is not None:
+            tp = getattr(ctx, "tail_pose", None)
+            v_vm_slots = tp.view(L.POSE_GRAD_SLOTS, 4, 4) if (want_pose and tp is not None) else None
+        else:
+            v_vm_slots = (v_rec_all[max(n_vis, 1):max(n_vis, 1) + L.POSE_GRAD_SLOTS].view(L.POSE_GRAD_SLOTS, 4, 4)
+                          if want_pose else None)   # camera-pose gradient (base.py:328-329,399)
         with L.timed("project_bwd"):
             if dev_counts is not None:
                 L.check(lib.bds_project_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales),
@@ -632,7 +647,8 @@ class _FusedView(torch.autograd.Function):
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]
             carrier.absgrad = g2d[1:2]
-        v_viewmat = None if v_vm_slots is None else v_vm_slots.sum(0)
+        # (defer_pose_sum: the caller sums the slots of all its views in one launch -- graph_view, once per frame)
+        v_viewmat = None if (v_vm_slots is None or cfg.get("defer_pose_sum")) else v_vm_slots.sum(0)
         if grids_in_place:
             v_grids = [None] * len(grids)
         if rows == 2 or sink is not None:   # already added in place to what autograd holds as .grad (or handed to the sink)
@@ -827,6 +843,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     late_image = late_image if two_phase else False
     tail_fork_stream = kwargs.pop("tail_fork_stream", None)
     g2d_buf = kwargs.pop("g2d_buf", None)    # persistent [2,N,2] screen-space gradient arrays whose stale rows the caller clears
+    tail_buf, defer_pose_sum = kwargs.pop("tail_buf", None), bool(kwargs.pop("defer_pose_sum", False))
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
@@ -836,7 +853,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws,
-               tail_fork_stream=tail_fork_stream, yield_after_front=late_image == "front", g2d_buf=g2d_buf)
+               tail_fork_stream=tail_fork_stream, yield_after_front=late_image == "front", g2d_buf=g2d_buf, tail_buf=tail_buf,
+               defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None

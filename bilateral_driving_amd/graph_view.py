@@ -168,6 +168,12 @@ class FrameGraph:
         # .absgrad); the projection backward stores the visible rows, the begin stage clears the rows of the previous visit
         self.g2d = ([torch.zeros(2, self.N, 2, device=self.dev, dtype=torch.float32) for _ in range(self.V)]
                     if not (exchange is not None and exchange.active) else None)
+        # all views' camera-pose gradient slots (+ loss accumulators) in ONE tensor: the slots are summed once per frame, not per view
+        self._tail_rows = L.POSE_GRAD_SLOTS + L.LOSS_SLOTS * L.LOSS_SLOT_STRIDE // L.GRAD_RECORD_FLOATS
+        self._tails = torch.zeros(self.V, self._tail_rows, L.GRAD_RECORD_FLOATS, device=self.dev, dtype=torch.float32)
+        self._vm = torch.zeros(self.V, 4, 4, device=self.dev, dtype=torch.float32)
+        self._defer_pose = (_FEWER_LAUNCHES and not (exchange is not None and exchange.active)
+                            and all(c.viewmat.requires_grad for c in self.cams))
         self._unions = [0] * self.V
         # (inside the captured backward: the SH half of the Gaussian backward forks onto this stream, see fused_view.backward_steps)
         self._fork_stream = torch.cuda.Stream(device=self.dev) if fork_tail else None
@@ -207,6 +213,8 @@ class FrameGraph:
         else:
             kw.update(grid_grads=[self.arena[f"grid{i}"] for i in range(len(self.grids))], grad_arena=self.arena,
                       arena_rows=1 if v == 0 else 2, g2d_buf=self.g2d[v] if _FEWER_LAUNCHES else None)
+            if self._defer_pose:
+                kw.update(tail_buf=self._tails[v], defer_pose_sum=True)
         return kw
 
     def _phase_fwd(self, v: int):
@@ -267,7 +275,7 @@ class FrameGraph:
         self._point_grads_at_flat()
         for v in range(self.V):
             self.skies[v].grad = None
-            self.cams[v].viewmat.grad = None
+            self.cams[v].viewmat.grad = self._vm[v] if self._defer_pose else None   # (deferred: written by _sum_pose_slots)
         # One eager frame in the device-count form on a side stream: lazy one-time work (kernel attributes, allocator growth) happens
         # here and not inside a capture, and it leaves real lists + counts in the prepare workspaces
         side = torch.cuda.Stream(device=self.dev)
@@ -286,7 +294,7 @@ class FrameGraph:
                 if self.fx is not None:
                     self.fx.static_end_view(v)
                 self.skies[v].grad = None
-                self.cams[v].viewmat.grad = None
+                self.cams[v].viewmat.grad = self._vm[v] if self._defer_pose else None
             if self.fx is not None:
                 self.fx.static_end_frame()
         torch.cuda.current_stream(self.dev).wait_stream(side)
@@ -416,6 +424,7 @@ class FrameGraph:
         self._frame_begin()
         if self.frame_graph is not None:     # single_graph: the two branches are inside (``serial`` has no meaning here)
             self.frame_graph.replay()
+            self._sum_pose_slots()
             for vg in self.views:
                 vg.done.record(main)
             return
@@ -496,6 +505,13 @@ class FrameGraph:
             main.wait_event(self.views[-1].done)     # the frame's gradients are complete for whatever the caller enqueues next
             for bs in self.extra_bwd_streams[:nb - 1]:
                 main.wait_stream(bs)
+        self._sum_pose_slots()
+
+    def _sum_pose_slots(self) -> None:
+        """Camera-pose gradients of all views: ONE reduction of the views' slots per frame (``viewmat.grad`` of every camera is a row of
+        the result) instead of one per view."""
+        if self._defer_pose:
+            torch.sum(self._tails[:, :L.POSE_GRAD_SLOTS].view(self.V, L.POSE_GRAD_SLOTS, 4, 4), dim=1, out=self._vm)
 
     def _step_phase_shifted(self, main, rest) -> None:
         """Three streams, software-pipelined on the host so that every event is recorded before it is waited for: iteration k enqueues
@@ -534,6 +550,7 @@ class FrameGraph:
                 vb.done.record(main)
         main.wait_stream(fs)
         main.wait_stream(side)
+        self._sum_pose_slots()
 
     def mark_samples(self, name: str):
         """Milliseconds of every timing mark pair ``name`` captured into the view graphs (``_lib.enable_timers`` on during the
