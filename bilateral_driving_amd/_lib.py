@@ -62,6 +62,7 @@ _SIGS = {
     "bds_rasterize_kernel_name": (_i, [_i, _i, _i, _i, C.c_char_p, _i]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_project_view_prepare_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _f]),
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_splat_pack_sh": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
@@ -133,6 +134,9 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
+
+
+BDS_OK, BDS_EINVAL, BDS_EWORKSPACE, BDS_ELAUNCH, BDS_ECAPACITY = 0, -1, -2, -3, -4      # include/bds.h
 
 
 class BdsError(RuntimeError):

@@ -99,6 +99,16 @@ __device__ __forceinline__ float butterfly_sum16(const float *v, int lane) {
   return w;
 }
 
+// Slots of the tile stage's prepare workspace that the ONE-VIEW projection fills when it takes over the stage's first launch (the
+// count of visible Gaussians per 256-Gaussian workgroup, the tables the later launches add into): csrc/tiles.hip prep_reduce_slots.
+struct PrepReduceSlots {
+  uint32_t *sums256;     // [cdiv(N, 256)] visible Gaussians per projection workgroup
+  uint32_t *zero_me;     // tables to clear
+  int64_t zero_elems;
+  uint64_t *m_total;     // cleared: the counting kernels accumulate into it
+};
+int prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlots *out);   // BDS_OK, or why the short path does not apply
+
 // test hooks (bds_set_option): force the large-input fallback paths of the tile stage; see include/bds.h
 enum Option { kOptPadBwd = 1 /* tuning: KB of unused LDS per workgroup of the compositor backward */, kOptPadFwd = 2 /* ... forward */,
               kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptStripRows = 5 /* tuning: rows per band of

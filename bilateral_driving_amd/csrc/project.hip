@@ -95,13 +95,43 @@ __global__ __launch_bounds__(kProjBlock) void project_bwd_kernel(
 // scales = exp(log_scales), opacities = sigmoid(logits) (models/gaussians/vanilla.py:393-394) are produced by the
 // projection itself (they are also outputs: the compositor and the backward need them), and the backward returns
 // the gradients of the RAW parameters.  A culled Gaussian reads only its radius and writes zeros.
+// kReduce: the launch also does the tile stage's first one (visible_reduce_kernel, csrc/tiles.hip): visible Gaussians per workgroup,
+// the sort tables and tiles_per_gauss cleared -- it reads every radius anyway.
+template <bool kReduce>
 __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     int64_t N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ log_scales,
     const float *__restrict__ logits, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
     float eps2d, float near_plane, float far_plane, float radius_clip, float *__restrict__ scales,
     float *__restrict__ opacities, int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
-    float *__restrict__ conics) {
+    float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss) {
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  if (kReduce) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rs.m_total = 0;
+    for (int64_t i = g; i < rs.zero_elems; i += (int64_t)gridDim.x * kProjBlock) rs.zero_me[i] = 0u;
+    int radius = 0;
+    if (g < N) {
+      float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
+      float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+      float s[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        s[k] = expf(log_scales[g * 3 + k]);
+        scales[g * 3 + k] = s[k];
+      }
+      opacities[g] = 1.f / (1.f + expf(-logits[g]));
+      Camera cam = load_camera(viewmat, K);
+      Proj p = project_one(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
+      radius = p.radius;
+      radii[g] = p.radius;
+      means2d[g * 2] = p.mx; means2d[g * 2 + 1] = p.my;
+      depths[g] = p.depth;
+      conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
+      if (tiles_per_gauss) tiles_per_gauss[g] = 0;   // (the counting kernel writes the visible entries only)
+    }
+    const int cnt = __syncthreads_count(radius > 0);
+    if (threadIdx.x == 0) rs.sums256[blockIdx.x] = (uint32_t)cnt;
+    return;
+  }
   if (g >= N) return;
   float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
   float q[4] = {quats[g * 4], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
@@ -254,9 +284,28 @@ extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *
   if (N == 0) return BDS_OK;
   BDS_REQUIRE(means && quats && log_scales && logits && viewmat && K && scales && opacities && radii && means2d && depths &&
               conics);
-  hipLaunchKernelGGL(project_view_fwd_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
+  hipLaunchKernelGGL(project_view_fwd_kernel<false>, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
                      means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
-                     opacities, radii, means2d, depths, conics);
+                     opacities, radii, means2d, depths, conics, PrepReduceSlots{}, static_cast<int32_t *>(nullptr));
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_project_view_prepare_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                            const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                            float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                            int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss,
+                                            void *prep_ws, size_t prep_ws_bytes, bds_stream_t stream) {
+  BDS_REQUIRE(N > 0 && W > 0 && H > 0);
+  BDS_REQUIRE(means && quats && log_scales && logits && viewmat && K && scales && opacities && radii && means2d && depths &&
+              conics);
+  static_assert(kProjBlock == 256, "the tile stage reads the visible counts per 256 Gaussians");
+  PrepReduceSlots rs;
+  int rc = prep_reduce_slots(prep_ws, prep_ws_bytes, N, &rs);
+  if (rc != BDS_OK) return rc;
+  hipLaunchKernelGGL(project_view_fwd_kernel<true>, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
+                     means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
+                     opacities, radii, means2d, depths, conics, rs, tiles_per_gauss);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

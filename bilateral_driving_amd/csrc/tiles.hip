@@ -721,14 +721,15 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
                                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                     uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
                                                                     uint64_t *__restrict__ n_vis_out, uint32_t *__restrict__ asc,
-                                                                    int compact) {
+                                                                    int compact, int sums_per_tile) {
   constexpr int kSpan = kScanTile / kShortChunk + 1;   // sort chunks a tile's outputs can straddle
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   __shared__ uint32_t h[kSpan][256];
 #pragma unroll
   for (int t = 0; t < kSpan; t++) h[t][threadIdx.x] = 0;
   uint32_t part = 0;
-  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kScanBlock) part += tile_sums[b];
+  // (sums_per_tile = 8: the counts were left per 256-Gaussian workgroup by the one-view projection, bds_project_view_prepare_fwd)
+  for (int b = threadIdx.x; b < (int)blockIdx.x * sums_per_tile; b += kScanBlock) part += tile_sums[b];
   uint32_t my_offset;
   block_excl_scan(part, my_offset, lw);   // total of the partial sums = this tile's offset
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -1038,6 +1039,18 @@ static BuildWs build_layout(void *ws, int64_t M) {
 
 using namespace bds;
 
+int bds::prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlots *out) {
+  BDS_REQUIRE(ws && out && CN > 0 && CN < (int64_t)1 << 31);
+  if (!(CN <= kShortSortMax && option_get(kOptShortSort))) return BDS_ECAPACITY;
+  PrepWs L = prep_layout(ws, CN);
+  if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
+  out->sums256 = L.temp;
+  out->zero_me = L.tables;
+  out->zero_elems = (int64_t)short_sort_elems(CN);
+  out->m_total = L.total;
+  return BDS_OK;
+}
+
 extern "C" size_t bds_isect_visible_ids_offset(int C, int64_t N) {
   if (C < 1 || N < 0) return 0;
   char *const base = reinterpret_cast<char *>(static_cast<uintptr_t>(4096));   // layout arithmetic only, never dereferenced
@@ -1120,10 +1133,12 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     uint32_t *hist = L.tables, *ghist = L.tables + nb * 256;   // ghist[p] = ghist + p * ng * 256
     const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
     // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
-    hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
-                       (int64_t)short_sort_elems(CN), L.total, tiles_per_gauss);
+    // (compact & 2: the one-view projection has already left the visible counts -- per 256 Gaussians -- and cleared the tables)
+    if (!(compact & 2))
+      hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
+                         (int64_t)short_sort_elems(CN), L.total, tiles_per_gauss);
     hipLaunchKernelGGL(visible_compact_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, depths, L.temp, L.ka, L.va, hist,
-                       ghist, n_vis, L.asc, compact);
+                       ghist, n_vis, L.asc, compact & 1, (compact & 2) ? kScanTile / 256 : 1);
     BDS_LAUNCH_CHECK();
     // 2. depth order: 4 stable passes of 8 bits; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
@@ -1140,9 +1155,10 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 3. tiles per entry, in depth order (tiles_per_gauss was zeroed by visible_reduce_kernel)
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
-                       compact ? L.asc : (const uint32_t *)nullptr);
+                       (compact & 1) ? L.asc : (const uint32_t *)nullptr);
     BDS_LAUNCH_CHECK();
   } else {
+    BDS_REQUIRE(!(compact & 2));   // (the pre-reduced form exists for the short path only)
     if (hipMemsetAsync(L.total, 0, sizeof(uint64_t), st) != hipSuccess) return BDS_ELAUNCH;   // M is accumulated by the counting kernel
     // 1. compact the visible entries: flags -> exclusive scan -> (depth key, id) pairs, count stays on the device
     hipLaunchKernelGGL(isect_flag_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.kb);

@@ -167,22 +167,33 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     scales, opac = _empty((N, 3), dev), _empty((N,), dev)
     radii = _empty((1, N), dev, torch.int32)
     means2d, depths, conics = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev)
-    with L.timed("project_fwd"):
-        L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
-                                         L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
-                                         L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
-                "bds_project_view_fwd")
-    # tile ordering
-    LT = cfg.get("list_tile", LIST_TILE)
-    tw, th = math.ceil(W / LT), math.ceil(H / LT)      # list tiles
-    cull = cfg["tile_cull"]
-    opac_c = opac.view(1, N)
     tiles_per_gauss = _empty((1, N), dev, torch.int32)
     ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
     ws = cfg.get("prep_ws")   # a caller-owned prepare workspace (graph_view: the lists and their counts outlive the view)
     if ws is None:
         ws = _empty((max(ws_bytes, 16),), dev, torch.uint8)
     assert ws.dtype == torch.uint8 and ws.is_contiguous() and ws.numel() >= ws_bytes and ws.device == dev
+    # device-count form: the projection also does the tile stage's first launch (visible counts per workgroup, tables cleared)
+    pre_reduced = False
+    with L.timed("project_fwd"):
+        if cfg.get("caps") is not None and _PROJECT_PREPARES and N > 0:
+            rc = lib.bds_project_view_prepare_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
+                                                  L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
+                                                  L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
+                                                  L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, st)
+            pre_reduced = rc == L.BDS_OK
+            if rc not in (L.BDS_OK, L.BDS_ECAPACITY):     # (ECAPACITY: N beyond the short sort path -- the plain projection below)
+                L.check(rc, "bds_project_view_prepare_fwd")
+        if not pre_reduced:
+            L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
+                                             L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
+                                             L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
+                    "bds_project_view_fwd")
+    # tile ordering
+    LT = cfg.get("list_tile", LIST_TILE)
+    tw, th = math.ceil(W / LT), math.ceil(H / LT)      # list tiles
+    cull = cfg["tile_cull"]
+    opac_c = opac.view(1, N)
     isect_offsets = _empty((1, th, tw), dev, torch.int32)
     cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
     caps = cfg.get("caps")                 # ListCapacity: the device-count form (no host wait in this view)
@@ -191,7 +202,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
         with L.timed("isect_prepare"):
             L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
                                               L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
-                                              counts.data_ptr(), 1, st), "bds_isect_prepare_dev")
+                                              counts.data_ptr(), 3 if pre_reduced else 1, st), "bds_isect_prepare_dev")
     else:
         counts, ev = _host_sync_objects(dev)
         with L.timed("isect_prepare"):
@@ -810,6 +821,7 @@ def _accumulate(p: Tensor, g: Optional[Tensor]) -> None:
 # the compositor's forward (1) or in front of its backward (0).  Measured on the two-stream frame: 937 vs 919 it/s -- in front of the
 # compositor's backward they delay the one kernel whose end closes the phase both compositors share.
 _SCHEDULE_IN_FORWARD = os.environ.get("BDS_SCHEDULE_IN_FORWARD", "1") == "1"
+_PROJECT_PREPARES = os.environ.get("BDS_PROJECT_PREPARES", "1") == "1"   # (A/B: 0 = projection and visible-reduce as two launches)
 _LOSS_TWO_STEP = os.environ.get("BDS_LOSS_TWO_STEP", "0") == "1"   # ablation: the loss as forward + backward launches
 _LOSS_IN_TRANSFORM = os.environ.get("BDS_LOSS_IN_TRANSFORM", "1") == "1"   # the loss rides on the colour transform's launch
 

@@ -306,6 +306,14 @@ int bds_project_view_fwd(int64_t N, const float *means, const float *quats, cons
                          const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane,
                          float far_plane, float radius_clip, float *scales, float *opacities, int32_t *radii,
                          float *means2d, float *depths, float *conics, bds_stream_t stream);
+/* bds_project_view_fwd that also does the first launch of the tile stage (device-count form, C = 1): the number of visible Gaussians
+ * per 256-Gaussian workgroup is left in prep_ws (bds_isect_prepare_workspace_bytes(1, N)), the stage's sort tables and
+ * tiles_per_gauss [N] (may be NULL) are cleared.  Follow with bds_isect_prepare_dev(..., compact | 2, ...) on the SAME workspace.
+ * BDS_ECAPACITY when N is beyond the short sort path (use bds_project_view_fwd then). */
+int bds_project_view_prepare_fwd(int64_t N, const float *means, const float *quats, const float *log_scales, const float *logits,
+                                 const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane, float far_plane,
+                                 float radius_clip, float *scales, float *opacities, int32_t *radii, float *means2d, float *depths,
+                                 float *conics, int32_t *tiles_per_gauss, void *prep_ws, size_t prep_ws_bytes, bds_stream_t stream);
 int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, const float *cam_pos, const float *coeffs,
                     const int32_t *radii, const float *depths, float *sh_rgb, float *colors, bds_stream_t stream);
 /* Backward of the one-view forms over the VISIBLE entries only, list-driven (no reference counterpart; the reference's dense
@@ -355,7 +363,8 @@ int bds_rasterize_kernel_name(int backward, int CH, int absgrad, int list_tile_s
  * nothing instead of overrunning a buffer, and the host, which looks at `counts_pinned` (page-locked int64[3] = M, visible,
  * overflow; written by the GPU; may be NULL) whenever it likes, provisions more and repeats the view.  Launches are sized by the
  * capacities; surplus workgroups see no elements.  Packed lists only (n_visible_capacity <= 2^(32 - bits(C*tiles))), else
- * BDS_ECAPACITY.  Lists, offsets and images are bit-identical to the host-count forms. */
+ * BDS_ECAPACITY.  Lists, offsets and images are bit-identical to the host-count forms.  `compact`: bit 0 as in bds_isect_prepare,
+ * bit 1 = the workspace already holds the visible counts and cleared tables of bds_project_view_prepare_fwd (one launch less). */
 size_t bds_isect_counts_offset(int which);
 int bds_isect_prepare_dev(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
                           const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws,
