@@ -117,6 +117,8 @@ class FrameGraph:
         self.cams, self.grids, self.skies, self.targets = list(cams), list(grids), list(skies), list(targets)
         self.V = len(self.cams)
         assert len(self.skies) == self.V and len(self.targets) == self.V
+        if self.V == 1:
+            overlap = False      # nothing to run a forward next to: one graph per view (c2: 687 vs 664 it/s with two graphs on two streams)
         self.factors, self.tv_weight, self.sh_degree = tuple(int(f) for f in factors), float(tv_weight), int(sh_degree)
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         self.headroom = float(headroom)
