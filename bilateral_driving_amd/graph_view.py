@@ -18,6 +18,13 @@ Gradients land exactly where the eager frame loop (``bench.py`` / ``dist.FrameEx
 gradients (transform + TV) are added in place, ``sky.grad`` / ``viewmat.grad`` are the graph's static outputs.  Same kernels, same
 order, same numbers as ``harness.train_view`` -- tested equal.
 
+What the replayed frame keeps OUT of its launch list (a launch costs ~4.5 us of GPU time even when it does nothing, and the frame's time
+is the sum of its kernels' times whatever runs next to what -- DESIGN.md "The step"): the loss value is left as a slotted accumulator
+(``ViewGraph.loss`` sums it when asked), ``viewmat.grad`` of every camera is a row of one tensor filled by ONE reduction of all views'
+pose-gradient slots per frame (``_sum_pose_slots``; read it after ``step()`` on the stepping stream), the dense screen-space gradient
+arrays behind ``info["means2d"].grad / .absgrad`` are per-view persistent buffers (``g2d``) whose stale rows the begin stage clears by
+the previous visit's list.
+
 A graph holds device addresses: after anything that re-allocates a parameter (densification) or changes a camera call
 ``frame.recapture()``.  Overflow protocol: a view whose list counts outgrow their capacities renders NOTHING (effective counts zero,
 see bds_isect_prepare_dev) and raises the sticky overflow word in its page-locked counts; ``valid()`` / ``check()`` see it after the
