@@ -85,7 +85,7 @@ _SIGS = {
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
-    "bds_bilagrid_ms_uses_strips": (_i, [_i, C.POINTER(BdsLevel), _i, _i]),
+    "bds_bilagrid_kernel_names": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _i, _i, C.c_char_p, _i]),
     "bds_bilagrid_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, C.POINTER(C.c_void_p), _f]),
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_ed_train_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _i, C.POINTER(BdsLevel),
@@ -168,9 +168,9 @@ def lib():
 
 
 SPLAT_RECORD_FLOATS, GRAD_RECORD_FLOATS, POSE_GRAD_SLOTS = 12, 16, 64
-OPT_DEBUG, OPT_STRIP_ROWS = 3, 5      # 3: ablation mask (bit 16: general bilateral kernels instead of the column strips); 5: rows per band
-OPT_STRIPS = 7
-LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 64      # slotted loss accumulators (include/bds.h BDS_LOSS_SLOT_STRIDE)                         # bilateral column-strip kernels: 1 = forward, 2 = backward (opt-in, see csrc/bilagrid.hip)
+OPT_DEBUG = 3          # profiling only: ablation mask
+OPT_CELLS = 7          # bilateral transform: 1 [default] = cell-aligned kernels, 0 = the general kernels everywhere (include/bds.h)
+LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 64      # slotted loss accumulators (include/bds.h BDS_LOSS_SLOT_STRIDE)
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
 
@@ -179,6 +179,13 @@ def rasterize_kernel_name(backward: bool, CH: int = 4, absgrad: bool = True, lis
     buf = C.create_string_buffer(128)
     check(lib().bds_rasterize_kernel_name(int(backward), CH, int(absgrad), list_tile_size, buf, 128), "bds_rasterize_kernel_name")
     return buf.value.decode()
+
+
+def bilagrid_kernel_names(levels, H: int, W: int, backward: bool, train: bool = False) -> list:
+    """Kernel names (as rocprofv3 prints them) of the bilateral transform's launches for a BdsLevel array."""
+    buf = C.create_string_buffer(512)
+    check(lib().bds_bilagrid_kernel_names(len(levels), levels, H, W, int(backward), int(train), buf, 512), "bds_bilagrid_kernel_names")
+    return buf.value.decode().split(",")
 
 
 def set_option(which: int, value: int) -> None:

@@ -11,96 +11,12 @@
 // level's 3x4 matrix from four cached taps while the pixel stays in registers: 24-40 B/pixel of
 // HBM traffic forward.  Backward is gather-based (deterministic, no atomics on image-sized arrays);
 // grid gradients are accumulated per workgroup in LDS and flushed once.
-#include "bds_common.h"
-#include "bilagrid_math.h"
+#include <stdio.h>
+#include <string.h>
+
+#include "bilagrid_ms.h"
 
 namespace bds {
-
-constexpr int kBgBlock = 256;
-
-struct LevelDev {
-  const float *grid;   // [n_avg,12,gl,gy,gx]
-  float *v_grid;
-  float *lo;           // [Hd*Wd,12] low-res affine maps
-  float *P;            // [H*W,3] input colour of this level                  (bwd scratch)
-  float *Q;            // [H*W,3] gradient w.r.t. this level's output          (bwd scratch)
-  float *R;            // [H*Wd,12] x-reduced adjoint of the up-sampler        (bwd scratch)
-  float *vg;           // [Hd*Wd] gradient w.r.t. the low-res guidance (gray)  (bwd scratch)
-  float *aff_out;      // optional [H*W,12]
-  int gx, gy, gl, factor, n_avg, Hd, Wd;
-  // resampling scales as torch forms them, divided ONCE on the host: up = low / full (taps of the up-sampler), dn = full / low
-  float up_x, up_y, dn_x, dn_y;
-  float lin_x, lin_y;  // 1 / (Wd - 1), 1 / (Hd - 1): step of torch.linspace(0, 1, n) over the low-res columns / rows
-  uint32_t magic_wd;   // ceil(2^32 / Wd): row / column of a low-res index without an integer division (fast_divmod)
-  int dn_shift;        // log2(factor) when the factor is a power of two >= 2 that divides H and W (else 0): the bilinear down-sampler
-                       // then reads exactly the central 2 x 2 pixels of every factor x factor block with weight 1/4 each
-};
-struct MsParams {
-  int nlevels, H, W;
-  uint32_t magic_w;        // ceil(2^32 / W)
-  int cs;                  // floats per pixel of `rgb` and of the returned colour gradient: 3, or 4 in the RGB+ED form
-  const float *rgb, *alpha, *sky;
-  float *depth_out;        // RGB+ED form: [H*W] expected depth = rgb[.,3] / max(alpha, 1e-10)
-  const float *v_depth;    // RGB+ED form, backward: gradient of that depth (may be null)
-  const float *v_alpha_in; // RGB+ED form, backward: gradient arriving at alpha from the caller (may be null)
-  LevelDev lv[BDS_MAX_LEVELS];
-};
-
-// n / d and n % d for n < 2^31, d < 2^31 from magic = ceil(2^32 / d): the estimate is exact or one too large (a 64-bit division
-// by a launch constant costs ~60 vector instructions per pixel in kernels that are bound by instruction issue)
-__device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t magic, int &q, int &r) {
-  uint32_t qq = d == 1u ? n : __umulhi(n, magic);
-  int rr = (int)(n - qq * d);
-  if (rr < 0) { qq--; rr += (int)d; }
-  q = (int)qq; r = rr;
-}
-// 32-bit element offsets for the image-sized arrays (ms_fill requires 12 H W < 2^31): a 64-bit multiply-add per tap address
-// (v_mad_u64_u32, quarter rate) was ~30 % of the full-resolution kernels' issue time.  Rows / columns are < 2^23, so row * width is
-// one full-rate v_mul_i32_i24; the small constant factors are shift-adds.
-__device__ __forceinline__ int row_major(int row, int width, int col) { return __mul24(row, width) + col; }
-__device__ __forceinline__ int times3(int v) { return v + (v << 1); }
-static uint32_t divmod_magic(int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d); }
-
-// Several levels in ONE launch: workgroup ranges per level (the levels are independent, each alone
-// under-fills the chip, and a launch boundary costs ~1.5-2 us).
-struct LevelSched {
-  int n;                               // entries
-  int level[BDS_MAX_LEVELS];           // level index of entry k
-  int blk_off[BDS_MAX_LEVELS + 1];     // workgroups [blk_off[k], blk_off[k+1]) belong to entry k
-  int nblk[BDS_MAX_LEVELS];            // = blk_off[k+1] - blk_off[k]
-  long long part_off[BDS_MAX_LEVELS];  // float offset of the entry's partial-grid region
-};
-__device__ __forceinline__ int sched_find(const LevelSched &s, int bid, int &local) {
-  int k = 0;
-  while (k + 1 < s.n && bid >= s.blk_off[k + 1]) k++;
-  local = bid - s.blk_off[k];
-  return k;
-}
-
-// input colour of the transform at pixel (y,x): clamp + sky blend fused when sky != null
-__device__ __forceinline__ void load_input(const MsParams &p, int y, int x, float &r, float &g, float &b) {
-  const int o = row_major(y, p.W, x);
-  const int oc = p.cs == 4 ? o << 2 : times3(o), o3 = times3(o);
-  r = p.rgb[oc]; g = p.rgb[oc + 1]; b = p.rgb[oc + 2];
-  if (p.sky) {
-    const float k = 1.f - p.alpha[o];
-    r = fminf(r, 1.f) + p.sky[o3] * k;
-    g = fminf(g, 1.f) + p.sky[o3 + 1] * k;
-    b = fminf(b, 1.f) + p.sky[o3 + 2] * k;
-  }
-}
-
-__device__ __forceinline__ void lowres_colour(const MsParams &p, const Tap &ty, const Tap &tx, float &r, float &g, float &b) {
-  float r00, g00, b00, r01, g01, b01, r10, g10, b10, r11, g11, b11;
-  load_input(p, ty.i0, tx.i0, r00, g00, b00);
-  load_input(p, ty.i0, tx.i1, r01, g01, b01);
-  load_input(p, ty.i1, tx.i0, r10, g10, b10);
-  load_input(p, ty.i1, tx.i1, r11, g11, b11);
-  const float wx = tx.w1, wy = ty.w1;
-  r = (r00 * (1.f - wx) + r01 * wx) * (1.f - wy) + (r10 * (1.f - wx) + r11 * wx) * wy;
-  g = (g00 * (1.f - wx) + g01 * wx) * (1.f - wy) + (g10 * (1.f - wx) + g11 * wx) * wy;
-  b = (b00 * (1.f - wx) + b01 * wx) * (1.f - wy) + (b10 * (1.f - wx) + b11 * wx) * wy;
-}
 
 // ---- A: per-level low-resolution slice -------------------------------------------------------
 // trilinear sample of the 12 channels from a CELL-MAJOR copy of the grid ([cell][12] as three float4): the arithmetic (and its
@@ -170,7 +86,9 @@ __global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, Lev
     const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y), tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
     float r, g, b;
     lowres_colour(p, ty, tx, r, g, b);
-    const Cell c = slice_cell(linspace01_s(j, L.Wd, L.lin_x), linspace01_s(i, L.Hd, L.lin_y), rgb2gray(r, g, b), L.gx, L.gy, L.gl);
+    const float gray = rgb2gray(r, g, b);
+    L.lg[idx] = gray;   // (kept for the cell-aligned backward, csrc/bilagrid_cells.hip)
+    const Cell c = slice_cell(linspace01_s(j, L.Wd, L.lin_x), linspace01_s(i, L.Hd, L.lin_y), gray, L.gx, L.gy, L.gl);
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] = 0.f;
@@ -218,67 +136,6 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
     A[q * 4 + 2] = (a.z * (1.f - wx) + b.z * wx) * (1.f - wy) + (c.z * (1.f - wx) + d.z * wx) * wy;
     A[q * 4 + 3] = (a.w * (1.f - wx) + b.w * wx) * (1.f - wy) + (c.w * (1.f - wx) + d.w * wx) * wy;
   }
-}
-
-// ---- TV of several grid pyramids' levels in ONE launch each way (the levels are tiny: a launch costs more than a level) ----
-struct TvLevels {
-  int n;
-  const float *x[BDS_MAX_LEVELS];
-  float *v_x[BDS_MAX_LEVELS];
-  long long total[BDS_MAX_LEVELS];
-  int gx[BDS_MAX_LEVELS], gy[BDS_MAX_LEVELS], gl[BDS_MAX_LEVELS];
-  float sl[BDS_MAX_LEVELS], sy[BDS_MAX_LEVELS], sx[BDS_MAX_LEVELS];
-  int blk_off[BDS_MAX_LEVELS + 1];
-};
-
-// value and gradient of the TV term at the element (level by workgroup, element by thread) that workgroup `bid` of a
-// T.blk_off[T.n]-workgroup range owns: returns its share of the value, ADDS v_loss * d(TV)/d(element) to the level's gradient slice
-__device__ __forceinline__ float tv_train_element(const TvLevels &L, int bid, float v_loss) {
-  int k = 0;
-  while (k + 1 < L.n && bid >= L.blk_off[k + 1]) k++;
-  const int64_t e = (int64_t)(bid - L.blk_off[k]) * kBgBlock + threadIdx.x;
-  float acc = 0.f;
-  if (e < L.total[k]) {
-    const int gx = L.gx[k], gy = L.gy[k], gl = L.gl[k];
-    const float *x = L.x[k];
-    const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
-    const int64_t sl = (int64_t)gx * gy;
-    const float v = x[e];
-    float g = 0.f;
-    if (ix > 0) { const float d = v - x[e - 1]; acc += d * d * L.sx[k]; g += 2.f * d * L.sx[k]; }
-    if (ix < gx - 1) g -= 2.f * (x[e + 1] - v) * L.sx[k];
-    if (iy > 0) { const float d = v - x[e - gx]; acc += d * d * L.sy[k]; g += 2.f * d * L.sy[k]; }
-    if (iy < gy - 1) g -= 2.f * (x[e + gx] - v) * L.sy[k];
-    if (il > 0) { const float d = v - x[e - sl]; acc += d * d * L.sl[k]; g += 2.f * d * L.sl[k]; }
-    if (il < gl - 1) g -= 2.f * (x[e + sl] - v) * L.sl[k];
-    if (L.v_x[k]) atomicAdd(L.v_x[k] + e, g * v_loss);
-  }
-  return acc;
-}
-
-// the training loss folded into the full-resolution forward (bds_bilagrid_ms_ed_train_fwd): L1 against `target` over the pixels this
-// launch produces, TV of the grids by tv_blocks extra workgroups behind the pix_blocks pixel workgroups
-constexpr int kLossSlotStride = BDS_LOSS_SLOT_STRIDE;   // floats between two slots: every slot in a 256-byte segment of its own
-struct TrainLoss {
-  const float *target;   // [H,W,3]
-  float *v_out;          // [H,W,3]  sign(out - target) * v_loss / (3 H W)
-  float *loss;           // [loss_slots * kLossSlotStride], zeroed by the caller: slot (workgroup % loss_slots) += its share of
-                         // mean|out - target| + TV terms.  (8100 float atomics on ONE address cost 65 us at the end of the launch.)
-  int loss_slots;        // power of two
-  float inv_n, v_loss;
-  int pix_blocks, tv_blocks;
-  TvLevels T;
-};
-
-__device__ __forceinline__ float block_sum_to_thread0(float acc, float *red /* [kBgBlock / kWave] shared */) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = acc;
-  __syncthreads();
-  float t = 0.f;
-  if (threadIdx.x == 0)
-    for (int w = 0; w < kBgBlock / kWave; w++) t += red[w];
-  return t;
 }
 
 // ---- B: full-resolution compose --------------------------------------------------------------
@@ -425,7 +282,11 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
                                                                  float *__restrict__ v_in, int halo, int nbx, int dbg) {
-  __shared__ float sP[NL][3][kBgBlock], sQ[NL][3][kBgBlock];
+  // pixel k of the window sits at k + k / 32: the x pass reads with a stride of `factor` pixels between neighbouring threads, which on
+  // the plain layout put every 8th (factor 4) thread of a 32-lane group on the same bank (5.7 M conflict cycles of 9.4 M LDS cycles)
+  constexpr int kRow = kBgBlock + kBgBlock / 32;
+  __shared__ float sP[NL][3][kRow], sQ[NL][3][kRow];
+  const int tsk = (int)threadIdx.x + ((int)threadIdx.x >> 5);
   const int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // one contiguous band of rows per XCD (L2 locality of the maps)
   const int y = bid / nbx, bx = bid - y * nbx;
   const int stride = kBgBlock - 2 * halo;
@@ -441,7 +302,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       if (l < p.nlevels) {
-        sP[l][0][threadIdx.x] = r; sP[l][1][threadIdx.x] = g; sP[l][2][threadIdx.x] = b;
+        sP[l][0][tsk] = r; sP[l][1][tsk] = g; sP[l][2][tsk] = b;
         if (owner && p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {  // level without up-sampling: the low-res kernel reads P, Q
           float *P = p.lv[l].P + times3(pix);
           P[0] = r; P[1] = g; P[2] = b;
@@ -454,7 +315,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
 #pragma unroll
     for (int l = NL - 1; l >= 0; l--) {
       if (l < p.nlevels) {
-        sQ[l][0][threadIdx.x] = v0; sQ[l][1][threadIdx.x] = v1; sQ[l][2][threadIdx.x] = v2;
+        sQ[l][0][tsk] = v0; sQ[l][1][tsk] = v1; sQ[l][2][tsk] = v2;
         if (owner && p.lv[l].Wd == p.W && p.lv[l].Hd == p.H) {
           float *Q = p.lv[l].Q + times3(pix);
           Q[0] = v0; Q[1] = v1; Q[2] = v2;
@@ -509,7 +370,7 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, co
           const Tap tx = resample_tap_s(xx, p.W, L.Wd, L.up_x);
           w = (tx.i0 == cx ? 1.f - tx.w1 : 0.f) + (tx.i1 == cx ? tx.w1 : 0.f);
         }
-        const int k = xx - xs;   // inside the window by construction (halo >= scale + 2)
+        const int k0 = xx - xs, k = k0 + (k0 >> 5);   // inside the window by construction (halo >= scale + 2)
         const float p0 = sP[l][0][k], p1 = sP[l][1][k], p2 = sP[l][2][k];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -815,409 +676,6 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
   }
 }
 
-// =====================================================================================================================
-// Column-strip form of the full-resolution kernels (levels whose factor is a power of two that divides the image size)
-// =====================================================================================================================
-// The kernels above touch every full-resolution pixel three times in the backward (P / Q and the x pass, the y pass through the
-// [H, Wd, 12] scratch, the guidance epilogue) and gather 12 float4 of the low-res maps per pixel and level; they are bound by those
-// gathers and by the scratch traffic (1.0 GB moved for 0.24 GB of algorithmic bytes at 1080p).  Here ONE wave64 owns a strip of
-// 64 pixel columns (lane = column) and marches down a band of rows with the state a pixel column needs in REGISTERS:
-//   * colA[level][2][12]: the two low-res map rows the current pixel row interpolates between, already interpolated in x for this
-//     lane's column (the x taps of a column never change).  A pixel's 3x4 matrix is ONE lerp of the two with the row's
-//     wave-uniform y weight; a new map row is fetched every `factor` rows (6 float4 per lane).
-//   * colAcc[level][2][12] (backward): d(loss)/d(map) accumulated down the column for the same two map rows (the y pass of the
-//     up-sampler's adjoint, in registers).  When the march leaves a map row, its 64 column sums are reduced in x through a small
-//     wave-private LDS transpose, and the row's cells -- one lane each -- run the slice backward at once: grid gradient into the
-//     workgroup's LDS accumulator, guidance gradient into a ring of the last few rows' colour gradients (also wave-private LDS),
-//     from which a row leaves through the clamp / sky / expected-depth backward F + 1 rows after it was visited.
-// No [H*W,3] P / Q arrays, no [H,Wd,12] scratch, no low-res guidance map, no image-sized atomics, one pass over the image.
-// A strip carries F/2 halo columns and a band F/2 halo rows either side (F = largest factor): a map cell's whole support
-// (2 factor pixels per axis) then lies inside the strip that owns it.  Workgroup = 4 independent waves (adjacent strips of a band)
-// sharing a cell-major copy of the grids and ONE grid-gradient accumulator in LDS, flushed with one atomic per touched entry.
-constexpr int kStripWaves = kBgBlock / kWave;
-constexpr int kStripMaxGridFloats = 6144;   // all levels' grids together: copy + accumulator = 48 KB of the workgroup's LDS
-
-struct StripGeom {
-  int F, own, nstrips, groups, RH, nbands, RD;   // RD: rows of the colour-gradient ring (F + 2)
-  int goff[BDS_MAX_LEVELS];                      // float offset of a level's grid inside the LDS copy / accumulator
-  int gfloats;
-  int dbg;                                       // profiling only (bds_set_option(3, mask)): 32 = no grid scatter, 64 = no guidance route,
-                                                 // 128 = no x reduction, 256 = no completed-row work at all
-};
-
-// Hand-over of wave-private LDS data between the lanes of ONE wave: the wave's LDS operations complete in order, so waiting for
-// its own (lgkmcnt = 0) is enough -- and, unlike a workgroup-scope fence, leaves the row's prefetched global loads in flight
-// (a fence waits for vmcnt = 0 too: one full memory latency per pixel row).
-__device__ __forceinline__ void wave_lds_sync() {
-  __asm__ volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // vmcnt = 63, expcnt = 7, lgkmcnt = 0
-  __builtin_amdgcn_wave_barrier();
-  __asm__ volatile("" ::: "memory");
-}
-
-// x-interpolated map row `cy` of level L for the lane's column (taps tx): the first half of upsample_affine
-__device__ __forceinline__ void strip_load_col(const LevelDev &L, int cy, const Tap &tx, float *dst) {
-  const float4 *s0 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)cy * L.Wd + tx.i0) * 12);
-  const float4 *s1 = reinterpret_cast<const float4 *>(L.lo + ((int64_t)cy * L.Wd + tx.i1) * 12);
-  const float wx = tx.w1;
-#pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const float4 a = s0[q], b = s1[q];
-    dst[q * 4 + 0] = a.x * (1.f - wx) + b.x * wx;
-    dst[q * 4 + 1] = a.y * (1.f - wx) + b.y * wx;
-    dst[q * 4 + 2] = a.z * (1.f - wx) + b.z * wx;
-    dst[q * 4 + 3] = a.w * (1.f - wx) + b.w * wx;
-  }
-}
-
-template <int NL>
-__global__ __launch_bounds__(kBgBlock) void ms_strip_fwd_kernel(MsParams p, StripGeom g, float *__restrict__ out) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-  const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int band = item / g.groups, strip = (item - band * g.groups) * kStripWaves + wave;
-  if (strip >= g.nstrips) return;
-  const int x = strip * kWave + lane;
-  const bool xin = x < p.W;
-  const int xc = xin ? x : p.W - 1;
-  const int Y0 = band * g.RH, Y1 = min(p.H, Y0 + g.RH);
-  Tap tx[NL];
-  float colA[NL][2][12];
-  int cur0[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l < p.nlevels) {
-      const LevelDev &L = p.lv[l];
-      tx[l] = resample_tap_s(xc, p.W, L.Wd, L.up_x);
-      const Tap ty = resample_tap_s(Y0, p.H, L.Hd, L.up_y);
-      cur0[l] = ty.i0;
-      strip_load_col(L, ty.i0, tx[l], colA[l][0]);
-      strip_load_col(L, ty.i1, tx[l], colA[l][1]);
-    }
-  }
-  // the row's inputs are fetched one row ahead
-  float nr = 0.f, ng = 0.f, nb = 0.f, nd = 0.f;
-  auto fetch = [&](int i) {
-    if (xin && i < Y1) {
-      load_input(p, i, x, nr, ng, nb);
-      if (p.depth_out) nd = p.rgb[((int64_t)i * p.W + x) * 4 + 3];
-    }
-  };
-  fetch(Y0);
-  for (int i = Y0; i < Y1; i++) {
-    float r = nr, gg = ng, b = nb;
-    const float dcur = nd;
-    fetch(i + 1);
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (l < p.nlevels) {
-        const LevelDev &L = p.lv[l];
-        const Tap ty = resample_tap_s(i, p.H, L.Hd, L.up_y);
-        if (ty.i0 != cur0[l]) {   // (wave-uniform) the march enters the next map row
-          cur0[l] = ty.i0;
-#pragma unroll
-          for (int k = 0; k < 12; k++) colA[l][0][k] = colA[l][1][k];
-          strip_load_col(L, ty.i1, tx[l], colA[l][1]);
-        }
-        const float wy = ty.w1;
-        float A[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) A[k] = colA[l][0][k] * (1.f - wy) + colA[l][1][k] * wy;
-        apply_affine(A, r, gg, b);
-      }
-    }
-    if (xin) {
-      const int64_t pix = (int64_t)i * p.W + x;
-      out[pix * 3] = r; out[pix * 3 + 1] = gg; out[pix * 3 + 2] = b;
-      if (p.depth_out) p.depth_out[pix] = dcur / fmaxf(p.alpha[pix], 1e-10f);
-    }
-  }
-}
-
-// One completed map row `cy` of level l: x reduction of the 64 column sums, slice backward of the row's owned cells.
-template <int NL>
-__device__ __forceinline__ void strip_complete_row(const MsParams &p, const StripGeom &g, int l, int cy, const float *colsum, int lane,
-                                                   int x0, int xs, float *__restrict__ T, float *__restrict__ ring,
-                                                   const float *__restrict__ cells, float *__restrict__ acc) {
-  const LevelDev &L = p.lv[l];
-  const int f = L.factor;
-  if (g.dbg & 256) return;
-  float4 *t4 = reinterpret_cast<float4 *>(T + lane * 12);
-  t4[0] = make_float4(colsum[0], colsum[1], colsum[2], colsum[3]);
-  t4[1] = make_float4(colsum[4], colsum[5], colsum[6], colsum[7]);
-  t4[2] = make_float4(colsum[8], colsum[9], colsum[10], colsum[11]);
-  wave_lds_sync();
-  const int cx = x0 / f + lane;
-  const bool active = lane < g.own / f && cx < L.Wd;
-  float va[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) va[k] = 0.f;
-  Cell c;
-  Tap tyd, txd;
-  {
-    const int cxc = active ? cx : 0;
-    int xlo, xhi;
-    adjoint_range(cxc, p.W, L.dn_x, xlo, xhi);
-    if (active && !(g.dbg & 128)) {
-#pragma unroll 1   // (rare, wave-uniform code next to ~150 live registers of the march: keep its own footprint small)
-      for (int xx = xlo; xx <= xhi; xx++) {
-        const int k = xx - xs;
-        if (k < 0 || k >= kWave) continue;   // (the conservative window's zero-weight ends)
-        const Tap t = resample_tap_s(xx, p.W, L.Wd, L.up_x);
-        const float w = (t.i0 == cx ? 1.f - t.w1 : 0.f) + (t.i1 == cx ? t.w1 : 0.f);
-        const float4 *s = reinterpret_cast<const float4 *>(T + k * 12);
-        const float4 a = s[0], b = s[1], d = s[2];
-        va[0] += w * a.x; va[1] += w * a.y; va[2] += w * a.z; va[3] += w * a.w;
-        va[4] += w * b.x; va[5] += w * b.y; va[6] += w * b.z; va[7] += w * b.w;
-        va[8] += w * d.x; va[9] += w * d.y; va[10] += w * d.z; va[11] += w * d.w;
-      }
-    }
-    tyd = resample_tap_s(cy, L.Hd, p.H, L.dn_y);
-    txd = resample_tap_s(cxc, L.Wd, p.W, L.dn_x);
-    // down-sampled input colour of the cell (lowres_colour's arithmetic, one tap at a time: see the note on registers above)
-    float rw[2] = {0.f, 0.f}, gw[2] = {0.f, 0.f}, bw[2] = {0.f, 0.f};
-    if (active) {
-#pragma unroll 1
-      for (int t = 0; t < 4; t++) {
-        float r1, g1, b1;
-        load_input(p, (t & 2) ? tyd.i1 : tyd.i0, (t & 1) ? txd.i1 : txd.i0, r1, g1, b1);
-        const float wq = (t & 1) ? txd.w1 : 1.f - txd.w1;
-        const int row = t >> 1;
-        rw[0] = row == 0 ? rw[0] + r1 * wq : rw[0]; rw[1] = row == 1 ? rw[1] + r1 * wq : rw[1];
-        gw[0] = row == 0 ? gw[0] + g1 * wq : gw[0]; gw[1] = row == 1 ? gw[1] + g1 * wq : gw[1];
-        bw[0] = row == 0 ? bw[0] + b1 * wq : bw[0]; bw[1] = row == 1 ? bw[1] + b1 * wq : bw[1];
-      }
-    }
-    const float r = rw[0] * (1.f - tyd.w1) + rw[1] * tyd.w1, gg = gw[0] * (1.f - tyd.w1) + gw[1] * tyd.w1,
-                b = bw[0] * (1.f - tyd.w1) + bw[1] * tyd.w1;
-    c = slice_cell(linspace01_s(cxc, L.Wd, L.lin_x), linspace01_s(cy, L.Hd, L.lin_y), rgb2gray(r, gg, b), L.gx, L.gy, L.gl);
-  }
-  if (L.v_grid && !(g.dbg & 32)) slice_grid_scatter(acc + g.goff[l], c, L.gx, L.gy, L.gl, 1.f, va, active);
-  if (active && c.z_interior && !(g.dbg & 64)) {
-    // sum_ch va[ch] * d(slice)/d(iz)[ch] (slice_dz_cells, four channels at a time)
-    float v_iz = 0.f;
-    {
-      const float4 *cl = reinterpret_cast<const float4 *>(cells + g.goff[l]);
-      const int plane = L.gy * L.gx;
-      const int o00 = c.y0 * L.gx + c.x0, o01 = c.y0 * L.gx + c.x1, o10 = c.y1 * L.gx + c.x0, o11 = c.y1 * L.gx + c.x1;
-      const float w00 = (1.f - c.fy) * (1.f - c.fx), w01 = (1.f - c.fy) * c.fx, w10 = c.fy * (1.f - c.fx), w11 = c.fy * c.fx;
-      const float4 *g0 = cl + (int64_t)c.z0 * plane * 3, *g1 = cl + (int64_t)c.z1 * plane * 3;
-#pragma unroll 1
-      for (int q = 0; q < 3; q++) {
-        const float4 a00 = g0[o00 * 3 + q], a01 = g0[o01 * 3 + q], a10 = g0[o10 * 3 + q], a11 = g0[o11 * 3 + q];
-        const float4 b00 = g1[o00 * 3 + q], b01 = g1[o01 * 3 + q], b10 = g1[o10 * 3 + q], b11 = g1[o11 * 3 + q];
-        const float dx = (b00.x * w00 + b01.x * w01 + b10.x * w10 + b11.x * w11) - (a00.x * w00 + a01.x * w01 + a10.x * w10 + a11.x * w11);
-        const float dy = (b00.y * w00 + b01.y * w01 + b10.y * w10 + b11.y * w11) - (a00.y * w00 + a01.y * w01 + a10.y * w10 + a11.y * w11);
-        const float dzz = (b00.z * w00 + b01.z * w01 + b10.z * w10 + b11.z * w11) - (a00.z * w00 + a01.z * w01 + a10.z * w10 + a11.z * w11);
-        const float dw = (b00.w * w00 + b01.w * w01 + b10.w * w10 + b11.w * w11) - (a00.w * w00 + a01.w * w01 + a10.w * w10 + a11.w * w11);
-        // (va[q * 4 + k] with q a run-time index would go through scratch: select)
-        const float e0 = q == 0 ? va[0] : (q == 1 ? va[4] : va[8]), e1 = q == 0 ? va[1] : (q == 1 ? va[5] : va[9]);
-        const float e2 = q == 0 ? va[2] : (q == 1 ? va[6] : va[10]), e3 = q == 0 ? va[3] : (q == 1 ? va[7] : va[11]);
-        v_iz += e0 * dx + e1 * dy + e2 * dzz + e3 * dw;
-      }
-    }
-    const float vg = v_iz * (float)(L.gl - 1);
-    // adjoint of the bilinear down-sampler: the cell's gray gradient goes to the (up to) 2 x 2 pixels it was formed from, which
-    // still sit in the ring (blocks of different cells are disjoint: plain read-modify-write)
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-#pragma unroll
-      for (int bq = 0; bq < 2; bq++) {
-        const float w = (a ? tyd.w1 : 1.f - tyd.w1) * (bq ? txd.w1 : 1.f - txd.w1);
-        if (w == 0.f) continue;
-        const int row = a ? tyd.i1 : tyd.i0, col = bq ? txd.i1 : txd.i0;
-        float *dst = ring + ((row % g.RD) * kWave + (col - xs)) * 3;
-        const float t = vg * w;
-        dst[0] += t * kGrayR; dst[1] += t * kGrayG; dst[2] += t * kGrayB;
-      }
-    }
-  }
-  wave_lds_sync();
-}
-
-template <int NL>
-__global__ __launch_bounds__(kBgBlock, 2) void ms_strip_bwd_kernel(MsParams p, StripGeom g, const float *__restrict__ v_out,
-                                                                  float *__restrict__ v_in, float *__restrict__ v_alpha,
-                                                                  float *__restrict__ v_sky) {
-  extern __shared__ __attribute__((aligned(16))) float lds_strip[];
-  float *cells = lds_strip, *acc = lds_strip + g.gfloats;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-  const int wave_floats = kWave * 12 + g.RD * kWave * 3;
-  float *T = lds_strip + 2 * g.gfloats + wave * wave_floats;
-  float *ring = T + kWave * 12;
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l < p.nlevels) {
-      const LevelDev &L = p.lv[l];
-      const int vol = L.gl * L.gy * L.gx;
-      for (int e = threadIdx.x; e < 12 * vol; e += kBgBlock) {
-        const int ch = e / vol, cell = e - ch * vol;
-        cells[g.goff[l] + cell * 12 + ch] = L.grid[e];
-        acc[g.goff[l] + e] = 0.f;
-      }
-    }
-  }
-  __syncthreads();
-  const int item = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int band = item / g.groups, strip = (item - band * g.groups) * kStripWaves + wave;
-  if (strip < g.nstrips) {
-    const int F = g.F, x0 = strip * g.own, xs = x0 - F / 2, x = xs + lane;
-    const bool xin = x >= 0 && x < p.W;
-    const bool xown = xin && x >= x0 && x < x0 + g.own;
-    const int xc = min(max(x, 0), p.W - 1);
-    const int Y0 = band * g.RH, Y1 = min(p.H, Y0 + g.RH);
-    const int ya = max(0, Y0 - F / 2), yb = min(p.H, Y1 + F / 2);
-    const int cs = p.cs;
-    float colA[NL][2][12], colAcc[NL][2][12];
-    int cur0[NL], cur1[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (l < p.nlevels) {
-        const LevelDev &L = p.lv[l];
-        const Tap tx = resample_tap_s(xc, p.W, L.Wd, L.up_x);   // (formed again at every new map row: rare, and 3 registers per level)
-        const Tap ty = resample_tap_s(ya, p.H, L.Hd, L.up_y);
-        cur0[l] = ty.i0; cur1[l] = ty.i1;
-        strip_load_col(L, ty.i0, tx, colA[l][0]);
-        strip_load_col(L, ty.i1, tx, colA[l][1]);
-#pragma unroll
-        for (int k = 0; k < 12; k++) { colAcc[l][0][k] = 0.f; colAcc[l][1][k] = 0.f; }
-      }
-    }
-    // clamp / sky / expected-depth backward of an owned row whose colour gradient is final (ms_guidance_blend_bwd_kernel's tail)
-    auto epilogue = [&](int j) {
-      if (!xown) return;
-      const int64_t pix = (int64_t)j * p.W + x;
-      const float *src = ring + ((j % g.RD) * kWave + lane) * 3;
-      float v[3] = {src[0], src[1], src[2]};
-      float va = 0.f;
-      if (p.sky) {
-        const float k = 1.f - p.alpha[pix];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          va -= v[c] * p.sky[pix * 3 + c];
-          if (v_sky) v_sky[pix * 3 + c] = v[c] * k;
-          v[c] = p.rgb[pix * cs + c] <= 1.f ? v[c] : 0.f;
-        }
-      }
-      v_in[pix * cs] = v[0]; v_in[pix * cs + 1] = v[1]; v_in[pix * cs + 2] = v[2];
-      if (cs == 4) {
-        const float a = p.alpha[pix], ac = fmaxf(a, 1e-10f);
-        const float vd = p.v_depth ? p.v_depth[pix] : 0.f;
-        v_in[pix * 4 + 3] = vd / ac;
-        if (p.v_alpha_in) va += p.v_alpha_in[pix];
-        if (a >= 1e-10f) va -= p.rgb[pix * 4 + 3] * vd / (ac * ac);
-        if (v_alpha) v_alpha[pix] = va;
-      } else if (p.sky && v_alpha) {
-        v_alpha[pix] = va;
-      }
-    };
-    // the row's inputs are fetched one row ahead (a wave has one or two neighbours on its SIMD: nothing else hides the latency)
-    float nr = 0.f, ng = 0.f, nb = 0.f, nv0 = 0.f, nv1 = 0.f, nv2 = 0.f;
-    auto fetch = [&](int i) {
-      nr = ng = nb = nv0 = nv1 = nv2 = 0.f;
-      if (xin && i < yb) {
-        load_input(p, i, x, nr, ng, nb);
-        const int64_t pix = (int64_t)i * p.W + x;
-        nv0 = v_out[pix * 3]; nv1 = v_out[pix * 3 + 1]; nv2 = v_out[pix * 3 + 2];
-      }
-    };
-    fetch(ya);
-    for (int i = ya; i < yb; i++) {
-      float wy[NL];
-      // ---- map rows: the march leaves row cur0 when the y tap moves on
-#pragma unroll
-      for (int l = 0; l < NL; l++) {
-        if (l < p.nlevels) {
-          const LevelDev &L = p.lv[l];
-          const Tap ty = resample_tap_s(i, p.H, L.Hd, L.up_y);
-          wy[l] = ty.w1;
-          if (ty.i0 != cur0[l]) {   // wave-uniform
-            const int done = cur0[l];
-            if (done * L.factor >= Y0 && done * L.factor < Y1)
-              strip_complete_row<NL>(p, g, l, done, colAcc[l][0], lane, x0, xs, T, ring, cells, acc);
-            cur0[l] = ty.i0; cur1[l] = ty.i1;
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-              colA[l][0][k] = colA[l][1][k];
-              colAcc[l][0][k] = colAcc[l][1][k];
-              colAcc[l][1][k] = 0.f;
-            }
-            strip_load_col(L, ty.i1, resample_tap_s(xc, p.W, L.Wd, L.up_x), colA[l][1]);
-          }
-        }
-      }
-      // ---- this row's pixel: forward chain, then the way back (the 3x4 of a level is one lerp: formed again on the way back
-      // instead of being kept)
-      float r = nr, gg = ng, b = nb, v0 = nv0, v1 = nv1, v2 = nv2;
-      fetch(i + 1);
-      float P[NL][3];
-#pragma unroll
-      for (int l = 0; l < NL; l++) {
-        if (l < p.nlevels) {
-          float A[12];
-#pragma unroll
-          for (int k = 0; k < 12; k++) A[k] = colA[l][0][k] * (1.f - wy[l]) + colA[l][1][k] * wy[l];
-          P[l][0] = r; P[l][1] = gg; P[l][2] = b;
-          apply_affine(A, r, gg, b);
-        }
-      }
-#pragma unroll
-      for (int l = NL - 1; l >= 0; l--) {
-        if (l < p.nlevels) {
-          const float q[3] = {v0, v1, v2};
-          const float w1 = wy[l], w0 = 1.f - wy[l];
-          float n[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-          for (int rr = 0; rr < 3; rr++) {
-#pragma unroll
-            for (int cc = 0; cc < 4; cc++) {
-              const int k = rr * 4 + cc;
-              const float d = cc < 3 ? q[rr] * P[l][cc] : q[rr];
-              colAcc[l][0][k] += w0 * d;
-              colAcc[l][1][k] += w1 * d;
-              if (cc < 3) n[cc] += (colA[l][0][k] * w0 + colA[l][1][k] * w1) * q[rr];
-            }
-          }
-          v0 = n[0]; v1 = n[1]; v2 = n[2];
-        }
-      }
-      if (i >= Y0 && i < Y1) {   // direct-route colour gradient of an owned row waits in the ring for its guidance terms
-        float *dst = ring + ((i % g.RD) * kWave + lane) * 3;
-        dst[0] = v0; dst[1] = v1; dst[2] = v2;
-      }
-      wave_lds_sync();
-      const int j = i - (F + 1);
-      if (j >= Y0) epilogue(j);
-    }
-    // ---- the map rows still open at the end of the band
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (l < p.nlevels) {
-        const LevelDev &L = p.lv[l];
-        if (cur1[l] == cur0[l]) {   // bottom border: both taps on the last map row
-#pragma unroll
-          for (int k = 0; k < 12; k++) colAcc[l][0][k] += colAcc[l][1][k];
-        }
-        if (cur0[l] * L.factor >= Y0 && cur0[l] * L.factor < Y1)
-          strip_complete_row<NL>(p, g, l, cur0[l], colAcc[l][0], lane, x0, xs, T, ring, cells, acc);
-        if (cur1[l] != cur0[l] && cur1[l] * L.factor >= Y0 && cur1[l] * L.factor < Y1)
-          strip_complete_row<NL>(p, g, l, cur1[l], colAcc[l][1], lane, x0, xs, T, ring, cells, acc);
-      }
-    }
-    for (int j = max(Y0, yb - (F + 1)); j < Y1; j++) epilogue(j);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    if (l < p.nlevels && p.lv[l].v_grid) {
-      const int gsz = 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx;
-      for (int e = threadIdx.x; e < gsz; e += kBgBlock) {
-        const float v = acc[g.goff[l] + e];
-        if (v != 0.f) atomicAdd(p.lv[l].v_grid + e, v);
-      }
-    }
-  }
-}
-
 // ---- generic point slice (BilateralGrid.forward on arbitrary points) ------------------------------
 __global__ __launch_bounds__(kBgBlock) void slice_fwd_kernel(int64_t P, const float *__restrict__ grid, int gx, int gy, int gl,
                                                             const float *__restrict__ xy, const float *__restrict__ rgb,
@@ -1508,7 +966,7 @@ __global__ __launch_bounds__(kBgBlock) void tv_ms_bwd_kernel(TvLevels L, const f
 
 // ---- host side ---------------------------------------------------------------------------------
 struct MsLayout {
-  size_t lo_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS], vg_off[BDS_MAX_LEVELS];
+  size_t lo_off[BDS_MAX_LEVELS], lg_off[BDS_MAX_LEVELS], p_off[BDS_MAX_LEVELS], q_off[BDS_MAX_LEVELS], r_off[BDS_MAX_LEVELS], vg_off[BDS_MAX_LEVELS];
   size_t part_off;  // per-workgroup partial grid gradients (shared by the levels, which run one after the other)
   size_t bytes;
 };
@@ -1528,6 +986,8 @@ static MsLayout ms_layout(int nlevels, const bds_bilagrid_level_t *lv, int H, in
     const int Hd = H / lv[l].factor, Wd = W / lv[l].factor;
     L.lo_off[l] = off;
     off += align_up((size_t)Hd * Wd * 12 * sizeof(float), 256);
+    L.lg_off[l] = off;
+    off += align_up((size_t)Hd * Wd * sizeof(float), 256);
   }
   for (int l = 0; l < nlevels; l++) {
     const int Hd = H / lv[l].factor, Wd = W / lv[l].factor;
@@ -1572,6 +1032,7 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
     LevelDev &d = p.lv[l];
     d.grid = lv[l].grid; d.v_grid = lv[l].v_grid;
     d.lo = reinterpret_cast<float *>(base + L.lo_off[l]);
+    d.lg = reinterpret_cast<float *>(base + L.lg_off[l]);
     d.P = reinterpret_cast<float *>(base + L.p_off[l]);
     d.Q = reinterpret_cast<float *>(base + L.q_off[l]);
     d.R = reinterpret_cast<float *>(base + L.r_off[l]);
@@ -1598,47 +1059,6 @@ static int ms_fill(MsParams &p, int nlevels, const bds_bilagrid_level_t *lv, int
   return BDS_OK;
 }
 
-// Column-strip kernels: every level's factor is a power of two (2, 4, 8) that divides the image size, one grid per level, all grids
-// together small enough for the workgroup's LDS.  `rows_per_band` <= 0: default.
-static bool strip_geom(const MsParams &p, bool backward, int rows_per_band, StripGeom &g) {
-  // Opt-in (bds_set_option(7, 1 | 2): 1 = forward, 2 = backward).  Measured on MI355X at 1080p / 3 levels: the forward strips equal the
-  // general kernel; the backward strips are SLOWER than the four general kernels (340 vs 250 us on a noisy image): at two waves per
-  // SIMD (the ~150 registers of per-column state) every row's dependent loads -- inputs of the delayed epilogue, the next map row --
-  // stall the march, and the completed-row work runs at 15-30 active lanes.  Kept for the configurations / follow-up it was sized
-  // for; results equal the general kernels' (tests/test_gpu_16_bilagrid_strips.py).
-  if (!(option_get(kOptStrips) & (backward ? 2 : 1))) return false;
-  if (p.nlevels > 4 || (option_get(kOptDebug) & 16)) return false;
-  int F = 1, gf = 0;
-  for (int l = 0; l < p.nlevels; l++) {
-    const LevelDev &L = p.lv[l];
-    const int f = L.factor;
-    if (!(f == 2 || f == 4 || f == 8) || p.H % f || p.W % f || L.n_avg != 1 || L.Hd < 2 || L.Wd < 2 || L.aff_out) return false;
-    if (f > F) F = f;
-    g.goff[l] = gf;
-    gf += 12 * L.gl * L.gy * L.gx;
-  }
-  if (gf > kStripMaxGridFloats) return false;
-  g.F = F; g.gfloats = gf; g.RD = F + 2;
-  g.dbg = option_get(kOptDebug);
-  g.own = backward ? kWave - F : kWave;
-  g.nstrips = (int)cdiv(p.W, g.own);
-  g.groups = (int)cdiv(g.nstrips, kStripWaves);
-  // rows per band: enough bands to give every SIMD two waves (1024 SIMDs), not so few rows that the halo rows dominate
-  int RH = rows_per_band;
-  if (RH <= 0) {
-    const int want = (2 * 1024 + g.nstrips - 1) / g.nstrips;
-    RH = (p.H + want - 1) / want;
-    if (RH < (backward ? 16 : 8)) RH = backward ? 16 : 8;
-  }
-  RH = (RH + F - 1) / F * F;
-  g.RH = RH;
-  g.nbands = (int)cdiv(p.H, RH);
-  return true;
-}
-static size_t strip_lds_bytes(const StripGeom &g) {
-  return sizeof(float) * ((size_t)2 * g.gfloats + (size_t)kStripWaves * (kWave * 12 + g.RD * kWave * 3));
-}
-
 }  // namespace bds
 
 using namespace bds;
@@ -1648,22 +1068,6 @@ extern "C" size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagri
   for (int l = 0; l < nlevels; l++)
     if (levels[l].factor < 1) return 0;
   return ms_layout(nlevels, levels, H, W).bytes;
-}
-
-// 1 when the full-resolution stage of this configuration runs as column strips (see "column-strip form"), else 0
-extern "C" int bds_bilagrid_ms_uses_strips(int nlevels, const bds_bilagrid_level_t *levels, int H, int W) {
-  if (nlevels < 1 || nlevels > BDS_MAX_LEVELS || !levels || H <= 0 || W <= 0) return 0;
-  MsParams p;
-  p.nlevels = nlevels; p.H = H; p.W = W;
-  for (int l = 0; l < nlevels; l++) {
-    if (levels[l].factor < 1) return 0;
-    LevelDev &d = p.lv[l];
-    d.gx = levels[l].gx; d.gy = levels[l].gy; d.gl = levels[l].gl; d.factor = levels[l].factor; d.n_avg = levels[l].n_avg;
-    d.Hd = H / levels[l].factor; d.Wd = W / levels[l].factor;
-    d.aff_out = nullptr;
-  }
-  StripGeom g;
-  return strip_geom(p, true, 0, g) ? 1 : 0;
 }
 
 static int l1_tv_train_launch(int64_t n, const float *a, const float *b, const TvLevels &T, int tv_blocks, float v_loss, float *loss_out,
@@ -1678,13 +1082,19 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   BDS_REQUIRE(rgb_out);
   p.cs = cs; p.depth_out = depth_out;
   hipStream_t st = as_stream(stream);
+  const bool cells = option_get(kOptCells) != 0;
+  if (cells && cells_fused_ok(p))   // one level at full resolution: slice + application (+ loss) in one launch, no maps in memory
+    return cells_fused_fwd(p, rgb_out, train, st);
   {
-    // levels whose grid fits the staging budget share one persistent launch (a workgroup stages the grid once and walks >= 4
-    // chunks of low-res pixels); larger grids (e.g. 16x16x8) keep the gather form, one workgroup per chunk
+    // low-resolution slice of every level: cell-aligned jobs (csrc/bilagrid_cells.hip) for the levels with one grid; levels averaged
+    // over several grids (the test branch) take the general kernels -- grids up to 32 KB staged whole in LDS by persistent workgroups
+    // (one launch for all of them), larger ones gathered from global memory, one workgroup per chunk
     constexpr size_t kStageGridBytes = 32 * 1024;
     LevelSched sl{}, sg{};
     size_t lds_max = 0;
+    unsigned cell_mask = 0;
     for (int l = 0; l < nlevels; l++) {
+      if (cells && cells_level_ok(p.lv[l])) { cell_mask |= 1u << l; continue; }
       const size_t gbytes = sizeof(float) * 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
       const int64_t chunks = cdiv((int64_t)p.lv[l].Hd * p.lv[l].Wd, kBgBlock);
       LevelSched &s = gbytes <= kStageGridBytes ? sl : sg;
@@ -1695,6 +1105,8 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       s.blk_off[k + 1] = s.blk_off[k] + s.nblk[k];
       if (gbytes <= kStageGridBytes && gbytes > lds_max) lds_max = gbytes;
     }
+    rc = cells_lowres_fwd(p, cell_mask, st);
+    if (rc != BDS_OK) return rc;
     if (sl.n > 0) {
       hipLaunchKernelGGL((ms_lowres_fwd_kernel<true>), dim3((unsigned)sl.blk_off[sl.n]), dim3(kBgBlock), lds_max, st, p, sl);
       BDS_LAUNCH_CHECK();
@@ -1704,16 +1116,7 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       BDS_LAUNCH_CHECK();
     }
   }
-  StripGeom sg;
-  if (strip_geom(p, false, option_get(kOptStripRows), sg)) {
-    const dim3 grid((unsigned)(sg.nbands * sg.groups)), block(kBgBlock);
-    switch (nlevels) {
-      case 1: hipLaunchKernelGGL((ms_strip_fwd_kernel<1>), grid, block, 0, st, p, sg, rgb_out); break;
-      case 2: hipLaunchKernelGGL((ms_strip_fwd_kernel<2>), grid, block, 0, st, p, sg, rgb_out); break;
-      case 3: hipLaunchKernelGGL((ms_strip_fwd_kernel<3>), grid, block, 0, st, p, sg, rgb_out); break;
-      default: hipLaunchKernelGGL((ms_strip_fwd_kernel<4>), grid, block, 0, st, p, sg, rgb_out); break;
-    }
-  } else {
+  {
     const int pix_blocks = (int)cdiv((int64_t)H * W, kBgBlock);
     const dim3 block(kBgBlock);
     if (train) {   // the loss rides on the launch: L1 in the pixel workgroups' epilogue, TV in extra workgroups behind them
@@ -1741,9 +1144,6 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     }
   }
   BDS_LAUNCH_CHECK();
-  if (train)   // (column-strip form of the full-resolution stage: the loss keeps its own launch)
-    return l1_tv_train_launch((int64_t)H * W * 3, rgb_out, train->target, train->T, train->tv_blocks, train->v_loss, train->loss,
-                              train->loss_slots, train->v_out, st);
   return BDS_OK;
 }
 
@@ -1771,29 +1171,9 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   p.cs = cs; p.v_depth = v_depth; p.v_alpha_in = v_alpha_in;
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
-  {
-    StripGeom sg;
-    if (strip_geom(p, true, option_get(kOptStripRows), sg)) {   // one pass over the image (see "column-strip form")
-      const size_t lds = strip_lds_bytes(sg);
-      const dim3 grid((unsigned)(sg.nbands * sg.groups)), block(kBgBlock);
-#define BDS_STRIP_BWD(n)                                                                                                              \
-  do {                                                                                                                                \
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&ms_strip_bwd_kernel<n>),                              \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                 \
-      return BDS_ELAUNCH;                                                                                                             \
-    hipLaunchKernelGGL((ms_strip_bwd_kernel<n>), grid, block, lds, st, p, sg, v_rgb_out, v_rgb, v_alpha, v_sky);                      \
-  } while (0)
-      switch (nlevels) {
-        case 1: BDS_STRIP_BWD(1); break;
-        case 2: BDS_STRIP_BWD(2); break;
-        case 3: BDS_STRIP_BWD(3); break;
-        default: BDS_STRIP_BWD(4); break;
-      }
-#undef BDS_STRIP_BWD
-      BDS_LAUNCH_CHECK();
-      return BDS_OK;
-    }
-  }
+  const bool cells = option_get(kOptCells) != 0;
+  if (cells && cells_fused_ok(p))   // one level at full resolution: the whole backward in one launch, no scratch
+    return cells_fused_bwd(p, v_rgb_out, v_rgb, v_alpha, v_sky, st);
   // fused x pass when some level is up-sampled and the widest support fits the workgroup's halo
   float smax = 1.f;
   bool any_up = false;
@@ -1847,11 +1227,18 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   float *partials = reinterpret_cast<float *>(static_cast<char *>(ws) + ML.part_off);
   PartialsJob pj{};
   int extra_blocks = 0;
-  {  // low-res backward: LDS-path levels together in one persistent launch; their partial grids are reduced by the next launch
+  {  // low-res backward.  Levels with one grid: cell-aligned jobs (csrc/bilagrid_cells.hip), all of them in one launch.  The others
+     // (averaged grids): LDS-path levels together in one persistent launch; their partial grids are reduced by the next launch
     LevelSched sc{}, red{};
     size_t lds_max = 0;
     long long poff = 0;
+    unsigned cell_mask = 0;
+    for (int l = 0; l < nlevels; l++)
+      if (cells && cells_level_ok(p.lv[l])) cell_mask |= 1u << l;
+    rc = cells_lowres_bwd(p, cell_mask, st);
+    if (rc != BDS_OK) return rc;
     for (int l = 0; l < nlevels; l++) {
+      if (cell_mask & (1u << l)) continue;
       const int gtot = 12 * p.lv[l].gl * p.lv[l].gy * p.lv[l].gx * p.lv[l].n_avg;
       const size_t gbytes = sizeof(float) * gtot;
       const int64_t need = cdiv((int64_t)p.lv[l].Hd * p.lv[l].Wd, kBgBlock);
@@ -1909,6 +1296,46 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
     }
     BDS_LAUNCH_CHECK();
   }
+  return BDS_OK;
+}
+
+// Names (as rocprofv3 prints them, without "bds::" and the argument list; comma-separated) of the kernels that the forward / backward
+// of this configuration launches under the current options, in launch order; measurement plumbing for bench.py's counter look-up.
+extern "C" int bds_bilagrid_kernel_names(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, int backward, int train,
+                                         char *buf, int buf_len) {
+  BDS_REQUIRE(buf && buf_len > 0 && nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && levels && H > 0 && W > 0);
+  MsParams p{};
+  p.nlevels = nlevels; p.H = H; p.W = W;
+  bool any_cell = false, any_lds = false, any_gather = false, any_up = false;
+  for (int l = 0; l < nlevels; l++) {
+    BDS_REQUIRE(levels[l].factor >= 1);
+    LevelDev &d = p.lv[l];
+    d.gx = levels[l].gx; d.gy = levels[l].gy; d.gl = levels[l].gl; d.factor = levels[l].factor; d.n_avg = levels[l].n_avg;
+    d.Hd = H / levels[l].factor; d.Wd = W / levels[l].factor;
+    d.aff_out = nullptr;
+    const size_t gbytes = sizeof(float) * 12 * d.gl * d.gy * d.gx * d.n_avg;
+    if (option_get(kOptCells) && cells_level_ok(d)) any_cell = true;
+    else if (gbytes <= (backward ? kMaxGridLds : (size_t)32 * 1024)) any_lds = true;
+    else any_gather = true;
+    if (!(d.Hd == H && d.Wd == W)) any_up = true;
+  }
+  const int nl = nlevels <= 4 ? nlevels : BDS_MAX_LEVELS;
+  char tmp[512];
+  int n = 0;
+  if (option_get(kOptCells) && cells_fused_ok(p)) {
+    n = backward ? snprintf(tmp, sizeof(tmp), "cell_bwd_kernel<true>") : snprintf(tmp, sizeof(tmp), "cell_fwd_kernel<true, %s>", train ? "true" : "false");
+  } else if (!backward) {
+    n = snprintf(tmp, sizeof(tmp), "%s%s%sms_apply_fwd_kernel<%d, %s>", any_cell ? "cell_fwd_kernel<false, false>," : "",
+                 any_lds ? "ms_lowres_fwd_kernel<true>," : "", any_gather ? "ms_lowres_fwd_kernel<false>," : "", nl, train ? "true" : "false");
+  } else {
+    char first[96];
+    if (any_up) snprintf(first, sizeof(first), "ms_apply_bwd_x_kernel<%d>", nl);
+    else snprintf(first, sizeof(first), "ms_apply_bwd_kernel<%d>", nl);
+    n = snprintf(tmp, sizeof(tmp), "%s,%s%s%sms_guidance_blend_bwd_kernel<%d>", first, any_cell ? "cell_bwd_kernel<false>," : "",
+                 any_gather ? "ms_lowres_bwd_kernel<false, 4>," : "", any_lds ? "ms_lowres_bwd_kernel<true, 4>," : "", nl);
+  }
+  if (n <= 0 || n >= buf_len || n >= (int)sizeof(tmp)) return BDS_EINVAL;
+  memcpy(buf, tmp, (size_t)n + 1);
   return BDS_OK;
 }
 

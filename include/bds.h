@@ -45,8 +45,8 @@ const char *bds_strerror(int code);
  * 6 = tile lists: 1 [default] = packed 32-bit entries (tile << rank_bits | depth rank) whenever the visible count fits the
  *     rank bits; 0 = the (tile key, id) pair lists that larger visible counts take.
  * 3 = profiling only: ablation mask of the bilateral backward;
- * 7 = column-strip form of the bilateral transform's full-resolution stage (bds_bilagrid_ms_uses_strips): bit 0 = forward, bit 1 =
- *     backward; default 0 (measured slower than the general kernels on MI355X, kept opt-in); 5 = its rows per band (0 = default).
+ * 7 = bilateral transform: 1 [default] = the cell-aligned kernels (csrc/bilagrid_cells.hip) wherever a level qualifies (one grid
+ *     per level); 0 = the general kernels everywhere (what levels averaged over several grids always take).  Same results.
  * Other indices are unused. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);
@@ -250,10 +250,6 @@ typedef struct {
   int32_t gx, gy, gl, factor, n_avg;
 } bds_bilagrid_level_t;
 
-/* 1 when the full-resolution stage of this configuration runs as column strips -- one wave64 per strip of 64 pixel columns marching
- * down the image with the up-sampler's state in registers: opted in through bds_set_option(7, ..), every factor 2, 4 or 8 and
- * dividing H and W, one grid per level, all grids together <= 6144 floats -- else 0 (the general kernels).  Same results either way. */
-int bds_bilagrid_ms_uses_strips(int nlevels, const bds_bilagrid_level_t *levels, int H, int W);
 size_t bds_bilagrid_ms_workspace_bytes(int nlevels, const bds_bilagrid_level_t *levels, int H, int W);
 /* ws keeps the low-resolution affine maps (fwd -> bwd). affine_out (NULL or nlevels x [H,W,12]
  * pointers) receives the full-resolution per-level maps the reference module returns. */
@@ -349,6 +345,12 @@ int bds_view_grads_clear_list(int64_t n_list, const int32_t *ids, int K, float *
 int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const float *s_means, const float *s_quats,
                             const float *s_log_scales, const float *s_logits, const float *s_sh, float *v_means, float *v_quats,
                             float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
+
+/* Names (as rocprofv3 prints them, without "bds::" and the argument list; comma-separated, launch order) of the kernels the bilateral
+ * transform of this configuration launches under the current options (bds_set_option(7, ..)): forward (train != 0: with the L1 / TV
+ * loss on the launch) or backward.  Measurement plumbing for bench.py's counter look-up; no reference counterpart. */
+int bds_bilagrid_kernel_names(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, int backward, int train, char *buf,
+                              int buf_len);
 
 /* Name (as rocprofv3 prints it, without the "bds::" prefix and the argument list) of the compositor kernel that a launch with
  * these switches runs; measurement plumbing for bench.py's counter look-up. */

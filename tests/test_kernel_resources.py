@@ -12,10 +12,7 @@ from bilateral_driving_amd import build as B
 
 FILES = ["rasterize.hip", "tiles.hip", "bilagrid.hip", "sh.hip", "project.hip", "mlp_head.hip", "loss.hip", "refine.hip"]
 # scratch allowed (bytes / lane): a shape no shipped config uses
-SCRATCH_OK = {"neural_image_fwd_kernelILi32ELi8ELi0ELi0E": 16,
-              # the opt-in column-strip backward of the bilateral transform (bds_set_option(7, 2); measured slower than the default
-              # kernels and not on the benchmarked path): ~150 registers of per-column state at two waves per SIMD
-              "ms_strip_bwd_kernelILi2E": 128, "ms_strip_bwd_kernelILi3E": 256, "ms_strip_bwd_kernelILi4E": 512}
+SCRATCH_OK = {"neural_image_fwd_kernelILi32ELi8ELi0ELi0E": 16}
 # kernel name prefix (mangled, after the length digits) -> minimum waves / SIMD
 MIN_OCCUPANCY = {
     "rasterize_fwd_wave_kernelILi4ELb1ELb1E": 7,        # the benchmark's forward compositor (RGB+ED, coarse lists)
