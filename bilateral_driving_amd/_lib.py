@@ -169,7 +169,7 @@ def lib():
 
 SPLAT_RECORD_FLOATS, GRAD_RECORD_FLOATS, POSE_GRAD_SLOTS = 12, 16, 64
 OPT_DEBUG = 3          # profiling only: ablation mask
-OPT_CELLS = 7          # bilateral transform: 1 [default] = cell-aligned kernels, 0 = the general kernels everywhere (include/bds.h)
+OPT_CELLS = 7          # bilateral transform, bit mask [default 3]: 1 = cell-aligned kernels, 2 = one-pass pyramid forward, 0 = general kernels (include/bds.h)
 LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 64      # slotted loss accumulators (include/bds.h BDS_LOSS_SLOT_STRIDE)
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4

@@ -15,13 +15,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbds.so")
-SOURCES = ["api.hip", "sh.hip", "project.hip", "tiles.hip", "rasterize.hip", "bilagrid.hip", "bilagrid_cells.hip", "loss.hip", "optim.hip", "refine.hip", "envlight.hip", "colorcorrect.hip", "mlp_head.hip", "exchange.hip"]
+SOURCES = ["api.hip", "sh.hip", "project.hip", "tiles.hip", "rasterize.hip", "bilagrid.hip", "bilagrid_cells.hip", "bilagrid_tile.hip", "loss.hip", "optim.hip", "refine.hip", "envlight.hip", "colorcorrect.hip", "mlp_head.hip", "exchange.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast-honor-pragmas", "-Wall", "-Wno-unused-function"]
 # per-file additions.  bilagrid.hip: the SLP vectoriser pairs fp32 operations into v_pk_* instructions, which issue at half rate on
 # gfx950 (scripts/ubench/valu_rate.hip) and need register shuffles (v_mov) to line their operands up: net loss in kernels that
 # are bound by instruction issue (static counts: DESIGN.md section 4)
-EXTRA_FLAGS = {"bilagrid.hip": ["-fno-slp-vectorize"], "bilagrid_cells.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"bilagrid.hip": ["-fno-slp-vectorize"], "bilagrid_cells.hip": ["-fno-slp-vectorize"], "bilagrid_tile.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

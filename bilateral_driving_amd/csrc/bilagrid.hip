@@ -1082,9 +1082,11 @@ static int ms_fwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   BDS_REQUIRE(rgb_out);
   p.cs = cs; p.depth_out = depth_out;
   hipStream_t st = as_stream(stream);
-  const bool cells = option_get(kOptCells) != 0;
+  const bool cells = (option_get(kOptCells) & 1) != 0;
   if (cells && cells_fused_ok(p))   // one level at full resolution: slice + application (+ loss) in one launch, no maps in memory
     return cells_fused_fwd(p, rgb_out, train, st);
+  if ((option_get(kOptCells) & 2) && tile_fwd_ok(p))   // pyramid of dividing power-of-two factors: one pass over the image
+    return tile_fwd(p, rgb_out, train, st);
   {
     // low-resolution slice of every level: cell-aligned jobs (csrc/bilagrid_cells.hip) for the levels with one grid; levels averaged
     // over several grids (the test branch) take the general kernels -- grids up to 32 KB staged whole in LDS by persistent workgroups
@@ -1171,7 +1173,7 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   p.cs = cs; p.v_depth = v_depth; p.v_alpha_in = v_alpha_in;
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
-  const bool cells = option_get(kOptCells) != 0;
+  const bool cells = (option_get(kOptCells) & 1) != 0;
   if (cells && cells_fused_ok(p))   // one level at full resolution: the whole backward in one launch, no scratch
     return cells_fused_bwd(p, v_rgb_out, v_rgb, v_alpha, v_sky, st);
   // fused x pass when some level is up-sampled and the widest support fits the workgroup's halo
@@ -1314,7 +1316,11 @@ extern "C" int bds_bilagrid_kernel_names(int nlevels, const bds_bilagrid_level_t
     d.Hd = H / levels[l].factor; d.Wd = W / levels[l].factor;
     d.aff_out = nullptr;
     const size_t gbytes = sizeof(float) * 12 * d.gl * d.gy * d.gx * d.n_avg;
-    if (option_get(kOptCells) && cells_level_ok(d)) any_cell = true;
+    {
+      const int f = d.factor;
+      d.dn_shift = (f >= 2 && (f & (f - 1)) == 0 && d.Hd * f == H && d.Wd * f == W) ? 1 : 0;   // (non-zero is all tile_fwd_ok asks)
+    }
+    if ((option_get(kOptCells) & 1) && cells_level_ok(d)) any_cell = true;
     else if (gbytes <= (backward ? kMaxGridLds : (size_t)32 * 1024)) any_lds = true;
     else any_gather = true;
     if (!(d.Hd == H && d.Wd == W)) any_up = true;
@@ -1322,7 +1328,9 @@ extern "C" int bds_bilagrid_kernel_names(int nlevels, const bds_bilagrid_level_t
   const int nl = nlevels <= 4 ? nlevels : BDS_MAX_LEVELS;
   char tmp[512];
   int n = 0;
-  if (option_get(kOptCells) && cells_fused_ok(p)) {
+  if (!backward && !((option_get(kOptCells) & 1) && cells_fused_ok(p)) && (option_get(kOptCells) & 2) && tile_fwd_ok(p)) {
+    n = snprintf(tmp, sizeof(tmp), "ms_tile_fwd_kernel<%d, %s>", nlevels, train ? "true" : "false");
+  } else if ((option_get(kOptCells) & 1) && cells_fused_ok(p)) {
     n = backward ? snprintf(tmp, sizeof(tmp), "cell_bwd_kernel<true>") : snprintf(tmp, sizeof(tmp), "cell_fwd_kernel<true, %s>", train ? "true" : "false");
   } else if (!backward) {
     n = snprintf(tmp, sizeof(tmp), "%s%s%sms_apply_fwd_kernel<%d, %s>", any_cell ? "cell_fwd_kernel<false, false>," : "",

@@ -169,5 +169,8 @@ int cells_lowres_bwd(const MsParams &p, unsigned mask, hipStream_t st);
 // single full-resolution level: slice + apply (+ L1 / TV loss) | the whole backward
 int cells_fused_fwd(const MsParams &p, float *out, const TrainLoss *train, hipStream_t st);
 int cells_fused_bwd(const MsParams &p, const float *v_out, float *v_in, float *v_alpha, float *v_sky, hipStream_t st);
+// pyramid forward in one pass over the image (csrc/bilagrid_tile.hip): every factor a power of two >= 2 dividing the image
+bool tile_fwd_ok(const MsParams &p);
+int tile_fwd(const MsParams &p, float *out, const TrainLoss *train, hipStream_t st);
 
 }  // namespace bds

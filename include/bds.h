@@ -45,8 +45,10 @@ const char *bds_strerror(int code);
  * 6 = tile lists: 1 [default] = packed 32-bit entries (tile << rank_bits | depth rank) whenever the visible count fits the
  *     rank bits; 0 = the (tile key, id) pair lists that larger visible counts take.
  * 3 = profiling only: ablation mask of the bilateral backward;
- * 7 = bilateral transform: 1 [default] = the cell-aligned kernels (csrc/bilagrid_cells.hip) wherever a level qualifies (one grid
- *     per level); 0 = the general kernels everywhere (what levels averaged over several grids always take).  Same results.
+ * 7 = bilateral transform, bit mask [default 3]: bit 0 = the cell-aligned kernels (csrc/bilagrid_cells.hip) wherever a level
+ *     qualifies (one grid per level); bit 1 = the pyramid forward as one pass over the image (csrc/bilagrid_tile.hip) when every
+ *     factor is a power of two >= 2 dividing the image; 0 = the general kernels everywhere (what levels averaged over several
+ *     grids always take).  Same results.
  * Other indices are unused. */
 int bds_set_option(int which, int value);
 int bds_get_option(int which);

@@ -13,7 +13,7 @@ from bilateral_driving_amd.bilagrid import bilagrid_transform
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only_shapes = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None      # e.g. c2,c5
 only_kinds = sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] != "all" else None        # noise,smooth
-only_cells = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1]
+only_cells = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 3]
 dev = "cuda"
 SHAPES = {"c2": (1080, 1920, [(16, 16, 8)], [1]),
           "headline": (1080, 1920, [(2, 2, 1), (4, 4, 2), (8, 8, 4)], [4, 4, 2]),
@@ -55,4 +55,4 @@ for name, (H, W, levels, factors) in SHAPES.items():
             t = L.timer_summary()
             L.enable_timers(False)
             print(f"{name:9s} {kind:6s} cells={cells}  " + "  ".join(f"{k} {v[1] * 1e3:7.1f} us" for k, v in sorted(t.items())), flush=True)
-L.set_option(L.OPT_CELLS, 1)
+L.set_option(L.OPT_CELLS, 3)

@@ -29,6 +29,6 @@ def _reset_kernel_variants():
             _lib.set_option(_lib.OPT_SHORT_SORT, 1)
             _lib.set_option(_lib.OPT_PACKED, 1)
             _lib.set_option(_lib.OPT_DEBUG, 0)
-            _lib.set_option(_lib.OPT_CELLS, 1)
+            _lib.set_option(_lib.OPT_CELLS, 3)
     except Exception:
         pass

@@ -1,4 +1,4 @@
-"""-m gpu: the cell-aligned bilateral kernels (csrc/bilagrid_cells.hip; bds_set_option(7, 1), the default) against the general
+"""-m gpu: the cell-aligned bilateral kernels (csrc/bilagrid_cells.hip; bit 0 of bds_set_option(7, ..)) and the one-pass pyramid forward (csrc/bilagrid_tile.hip; bit 1; default 3) against the general
 kernels (option 7 = 0), the float64 oracle and the reference's golden vectors -- single-scale (one launch each way) and pyramids,
 ragged / tiny images, images smaller than the grid, smooth and noisy guidance (one / every plane bucket of the counting sort)."""
 import glob
@@ -49,7 +49,7 @@ def _run(B, L, cells, rgb, grids, factors, alpha, sky, wt):
         return out.detach().cpu(), rg.grad.cpu(), (ag.grad.cpu() if ag is not None else None), (sg.grad.cpu() if sg is not None else None), \
             [x.grad.cpu() for x in gg]
     finally:
-        L.set_option(L.OPT_CELLS, 1)
+        L.set_option(L.OPT_CELLS, 3)
 
 
 SHAPES = [
@@ -68,6 +68,13 @@ SHAPES = [
     (225, 401, [(2, 2, 1), (4, 4, 2), (8, 8, 4)], [4, 4, 2]),      # sizes the factors do not divide
     (128, 256, [(2, 2, 1), (4, 4, 2), (8, 8, 4), (16, 16, 8)], [8, 4, 4, 2]),
     (96, 160, [(8, 8, 4), (16, 16, 8)], [2, 1]),                    # a full-resolution level inside a pyramid
+    # sizes every factor divides: the forward runs as ONE pass over the image (csrc/bilagrid_tile.hip, option bit 1)
+    (272, 480, [(2, 2, 1), (4, 4, 2), (8, 8, 4)], [4, 4, 2]),
+    (16, 16, [(2, 2, 1), (4, 4, 2), (8, 8, 4)], [4, 4, 2]),         # one partial tile; cells far smaller than a tile (global-memory slice)
+    (64, 64, [(2, 2, 1), (4, 4, 2), (8, 8, 4)], [4, 4, 2]),
+    (72, 200, [(8, 8, 4)], [2]),                                    # ragged tile grid, one level
+    (540, 960, [(2, 2, 1), (4, 4, 2), (8, 8, 4)], [4, 4, 2]),
+    (320, 480, [(2, 2, 1), (4, 4, 2), (8, 8, 4), (16, 16, 8)], [8, 4, 4, 2]),
 ]
 
 
@@ -86,16 +93,17 @@ def test_cell_kernels_equal_general_kernels(B, L, H, W, levels, factors, kind, b
     grids = _grids(levels, g)
     wt = torch.randn(H, W, 3, generator=g)
     ref = _run(B, L, 0, rgb, grids, factors, alpha, sky, wt)
-    got = _run(B, L, 1, rgb, grids, factors, alpha, sky, wt)
-    assert torch.allclose(got[0], ref[0], rtol=2e-6, atol=2e-6), float((got[0] - ref[0]).abs().max())
-    # (the colour gradient: a pixel whose guidance lands within rounding of a plane boundary could flip a one-sided derivative;
-    # the two paths share the pixel arithmetic, so none may)
-    assert torch.allclose(got[1], ref[1], rtol=1e-4, atol=1e-5 * float(ref[1].abs().max())), float((got[1] - ref[1]).abs().max())
-    for a, b in ((got[2], ref[2]), (got[3], ref[3])):
-        if b is not None:
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
-    for a, b in zip(got[4], ref[4]):
-        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (float((a - b).abs().max()), float(b.abs().max()))
+    for mask in (1, 3):   # cell-aligned kernels alone; plus the one-pass pyramid forward where the shape qualifies
+        got = _run(B, L, mask, rgb, grids, factors, alpha, sky, wt)
+        assert torch.allclose(got[0], ref[0], rtol=2e-6, atol=2e-6), (mask, float((got[0] - ref[0]).abs().max()))
+        # (the colour gradient: a pixel whose guidance lands within rounding of a plane boundary could flip a one-sided derivative;
+        # the paths share the pixel arithmetic, so none may)
+        assert torch.allclose(got[1], ref[1], rtol=1e-4, atol=1e-5 * float(ref[1].abs().max())), (mask, float((got[1] - ref[1]).abs().max()))
+        for a, b in ((got[2], ref[2]), (got[3], ref[3])):
+            if b is not None:
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max())), mask
+        for a, b in zip(got[4], ref[4]):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (mask, float((a - b).abs().max()), float(b.abs().max()))
 
 
 @pytest.mark.parametrize("H,W,levels,factors", [(135, 240, [(16, 16, 8)], [1]), (67, 129, [(16, 16, 8)], [1]), (64, 64, [(5, 7, 3)], [1])])
@@ -112,7 +120,7 @@ def test_single_scale_one_launch_vs_oracle(B, L, H, W, levels, factors):
     g64 = [x.double().requires_grad_(True) for x in grids]
     ref = O.multiscale_transform(g64, O.sky_blend(r64, a64[..., None], s64), factors)
     (ref * wt.double()).sum().backward()
-    out, v_rgb, v_alpha, v_sky, v_grids = _run(B, L, 1, rgb, grids, factors, alpha, sky, wt)
+    out, v_rgb, v_alpha, v_sky, v_grids = _run(B, L, 3, rgb, grids, factors, alpha, sky, wt)
     worst = dict(out=rel_err(out, ref.detach()),
                  v_rgb=float((v_rgb.double() - r64.grad).norm() / r64.grad.norm()),
                  v_alpha=float((v_alpha.double() - a64.grad).norm() / a64.grad.norm()),
