@@ -68,14 +68,6 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=170.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="enqueue the next view's projection / tile counting ahead of the current view's backward "
-                         "(harness.render_view_begin).  Off by default: measured equal to the plain loop on MI355X (772 it/s either way "
-                         "in scripts/host_profile.py: the one host wait per view is already hidden behind the SH kernel)")
-    ap.add_argument("--direct", action="store_true",
-                    help="drive each view through harness.train_view (the same kernels called back to back without an autograd graph) "
-                         "instead of forward / loss / loss.backward() through torch autograd, the reference-shaped step (default); "
-                         "measured equal on MI355X: the host runs ahead of the GPU either way")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of --steps steps is run this many times (barrier + synchronize around each); the MEDIAN "
                          "repeat is reported (a 0.2 s window on a shared host can swing 10-20 %), min / max beside it")
@@ -86,20 +78,11 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="graph replay: one graph per view on one stream instead of forward / backward graphs on two streams (view v + 1's "
                          "forward next to view v's backward)")
-    ap.add_argument("--fork-tail", action="store_true", help="graph replay: SH backward forked next to the projection backward inside the "
-                                                             "captured graph (measured slower: 772 vs 909 it/s)")
-    ap.add_argument("--single-graph", action="store_true", default=os.environ.get("BDS_SINGLE_GRAPH", "0") == "1",
-                    help="graph replay: the whole frame as ONE graph with two branches (world size 1)")
-    ap.add_argument("--phase-shift", action="store_true", default=os.environ.get("BDS_PHASE_SHIFT", "0") == "1",
-                    help="graph replay: three streams, each compositor next to the other stream's gather-bound kernels")
-    ap.add_argument("--front-stream", action="store_true", default=os.environ.get("BDS_FRONT_STREAM", "0") == "1",
-                    help="graph replay: projection + lists of every view as graphs of their own on a third stream")
-    ap.add_argument("--late-image", nargs="?", const="image", default=None, choices=["image", "front"],
-                    help="graph replay: colour transform + loss (image) or everything behind the tile lists (front) captured with the "
-                         "backward instead of the forward")
-    ap.add_argument("--bwd-streams", type=int, default=1,
-                    help="graph replay: streams the image halves of consecutive views' backwards alternate between (> 1: the Gaussian "
-                         "halves follow one another on a stream of their own)")
+    ap.add_argument("--random-views", action="store_true",
+                    help="N = 1: also time the REPLAYABLE frame (graph_view.FrameGraph(dynamic=True)) -- every step each view slot gets "
+                         "a random camera of a pool, a new target / sky and a random image index written into its static inputs before "
+                         "the replay, as the reference's loop draws a random image per step (tools/train.py:250-283); reported as "
+                         "config.random_views_iters_per_sec next to the fixed-frame value")
     ap.add_argument("--dense-grads", action="store_true",
                     help="N = 1 only: fresh dense gradient tensors per view (zero fill of all N rows, autograd accumulation) instead of "
                          "the flat gradient buffer whose rows are cleared / written through the visible-id lists")
@@ -293,44 +276,34 @@ def main():
     torch.cuda.synchronize()
 
     stats = {}
-    use_graph = not args.no_graph and not dense and not args.direct and not args.pipeline
+    use_graph = not args.no_graph and not dense
     frame = None
     if use_graph:
         # the views are captured with the roofline kernel bracketed by timing marks (event-record nodes: re-recorded by every replay)
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap, exchange=fx, bwd_streams=args.bwd_streams, fork_tail=args.fork_tail, late_image={None: False, "image": True, "front": "front"}[args.late_image], front_stream=args.front_stream, single_graph=args.single_graph, phase_shift=args.phase_shift)
+                           overlap=not args.no_overlap, exchange=fx)
         L.enable_timers(False)
 
     def step(s):
         if frame is not None:
-            frame.step()
+            frame.step(wait=False)     # (pipelined: validity is checked once, after the timed region)
             return
         if dense:
             for p in list(params.values()) + grids:
                 p.grad = None
         else:
             fx.begin_frame()
-        pipeline = bool(args.pipeline)
-        front = Hn.render_view_begin(params, cams[0]) if pipeline else None   # (a real loop begins it right after the optimizer step)
         for v in range(V):
             skies[v].grad = None
             cams[v].viewmat.grad = None
             kw = {} if dense else fx.view_kwargs(v)
-            if not args.direct:   # the reference-shaped step: forward, loss, loss.backward() through autograd
-                out = Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, front=front, **kw)
-                if not dense:
-                    fx.begin_view(out["info"])
-                loss = Hn.training_loss(out, targets[v], grids, grid_grads=None if dense else fx.tail_grads())
-                # the next view's projection / sort / tile counts go in FRONT of this view's backward: its list counts reach the host
-                # while the GPU is busy with the backward, so its one host wait never leaves the GPU idle
-                front = Hn.render_view_begin(params, cams[v + 1]) if pipeline and v + 1 < V else None
-                loss.backward()
-            else:               # the same kernels in the same order, called back to back without an autograd graph
-                out = Hn.train_view(params, cams[v], grids, v, skies[v], targets[v], factors=factors, front=front,
-                                    grid_grads=None if dense else fx.tail_grads(), after_forward=None if dense else fx.begin_view, **kw)
-                front = None   # (train_view runs forward and backward in one call: nothing to slide in between)
+            # the reference-shaped step: forward, loss, loss.backward() through autograd
+            out = Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, **kw)
+            if not dense:
+                fx.begin_view(out["info"])
+            Hn.training_loss(out, targets[v], grids, grid_grads=None if dense else fx.tail_grads()).backward()
             if not dense:
                 fx.end_view()
             stats.setdefault("M", []).append(out["info"]["n_isects"])
@@ -424,6 +397,42 @@ def main():
         frame = frame_graph
         per_kernel_source = ("HIP events around every operator of the eager host-count loop, 2 extra frames AFTER the timed region; "
                              "algorithmic bytes: SURVEY.md 8(d) rows at this run's N, n_visible, M, pixels")
+    # the replayable frame: ONE capture, every step other cameras / targets / skies / image indices in the slots' static inputs (the
+    # reference's loop: a random image per step, tools/train.py:250-283).  Same kernels; the extra work is the input copies (a data
+    # loader would write the static tensors directly) and two launches per view that pick / return the image's grids.
+    random_its = None
+    if rank == 0 and world == 1 and args.random_views and frame is not None:
+        try:
+            from bilateral_driving_amd.graph_view import FrameGraph
+            g2 = torch.Generator().manual_seed(5)
+            pool = []
+            for k in range(4):      # 4 rigs along the drive, jittered yaws: 4 x V cameras
+                pool += Hn.ring_cameras(W, H, yaws_deg=[y + float(torch.rand(1, generator=g2)) * 20.0 - 10.0 for y in yaws], device=dev,
+                                        origin=(1.5 * k, 0.0, 0.0))
+            pool_t = [torch.rand(H, W, 3, generator=g2).to(dev) for _ in range(4)]
+            pool_s = [torch.rand(H, W, 3, generator=g2).to(dev) for _ in range(4)]
+            del frame
+            dyn = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
+                             overlap=not args.no_overlap, dynamic=True, calib_cams=pool)
+            picks = torch.randint(0, len(pool), (args.steps + 3, V), generator=g2).tolist()
+
+            def dyn_step(i):
+                for v in range(V):
+                    k = picks[i][v]
+                    dyn.set_view(v, pool[k], pool_t[k % 4], pool_s[(k + 1) % 4], k % len(cams))
+                dyn.step(wait=False)
+            for i in range(3):
+                dyn_step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                dyn_step(3 + i)
+            torch.cuda.synchronize()
+            random_its = V * args.steps / (time.perf_counter() - t0)
+            assert dyn.valid(), "a list outgrew the capacities of the calibration sweep"
+            frame = dyn     # (keeps `frame is not None` for the step_driver text below)
+        except Exception as e:   # measurement tooling must never take the bench line down
+            random_its = f"{type(e).__name__}: {e}"
     # the drop-in path (reference-signature operators chained by autograd: projection, SH, isect_tiles, rasterize_to_pixels,
     # bilagrid_transform -- what `gsplat.rasterization(...)` + the module `forward` cost a trainer that changes nothing else)
     api_its = None
@@ -570,13 +579,12 @@ def main():
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V, "api_path_iters_per_sec": api_its,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
-                   "pipelined_fronts": bool(args.pipeline) and not args.direct,
+                   "random_views_iters_per_sec": random_its,
                    "step_driver": ("hipGraph replay (graph_view.FrameGraph): per view " +
                                    ("two captured graphs (forward + L1/TV loss value | backward), the forwards on a second stream next to "
                                     "the previous view's backward" if not args.no_overlap else "ONE captured graph = forward + L1/TV loss + backward") +
                                    ", device-side list counts, no host wait") if frame is not None else
-                                  ("direct (harness.train_view: same kernels, no autograd graph)" if args.direct else
-                                   "autograd (forward, loss, loss.backward())"),
+                                  "autograd (forward, loss, loss.backward())",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
                    "exchanges_per_step": fx.n_exchanges if world > 1 else 0},

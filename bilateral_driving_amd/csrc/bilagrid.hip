@@ -1301,6 +1301,62 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
   return BDS_OK;
 }
 
+// ---- the image's grids by a DEVICE-side image index (a captured view whose image changes from replay to replay) -------------------
+namespace bds {
+struct GridSelect {
+  int n;
+  const float *full[BDS_MAX_LEVELS];   // [n_img, count]
+  float *v_full[BDS_MAX_LEVELS];
+  float *sel[BDS_MAX_LEVELS];          // [count]
+  int count[BDS_MAX_LEVELS], n_img[BDS_MAX_LEVELS];
+  int blk_off[BDS_MAX_LEVELS + 1];
+};
+// kBwd = false: sel = full[idx];  kBwd = true: v_full[idx] += sel, sel = 0 (ready for the next replay's backward)
+template <bool kBwd>
+__global__ __launch_bounds__(kBgBlock) void grid_select_kernel(GridSelect S, const int32_t *__restrict__ idx_dev) {
+  int k = 0;
+  while (k + 1 < S.n && (int)blockIdx.x >= S.blk_off[k + 1]) k++;
+  const int e = ((int)blockIdx.x - S.blk_off[k]) * kBgBlock + (int)threadIdx.x;
+  const int idx = *idx_dev;
+  if (e >= S.count[k] || idx < 0 || idx >= S.n_img[k]) return;
+  const int64_t o = (int64_t)idx * S.count[k] + e;
+  if (kBwd) {
+    const float t = S.sel[k][e];
+    if (t != 0.f) atomicAdd(S.v_full[k] + o, t);   // (atomic: another view's TV term may add to the same slice next to this launch)
+    S.sel[k][e] = 0.f;
+  } else {
+    S.sel[k][e] = S.full[k][o];
+  }
+}
+}  // namespace bds
+
+static int grid_select_launch(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *sel, bool bwd,
+                              bds_stream_t stream) {
+  BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && levels && img_idx_dev && sel);
+  GridSelect S{};
+  S.n = nlevels;
+  for (int l = 0; l < nlevels; l++) {
+    BDS_REQUIRE(sel[l] && levels[l].gx >= 1 && levels[l].gy >= 1 && levels[l].gl >= 1 && levels[l].n_avg >= 1);
+    BDS_REQUIRE(bwd ? levels[l].v_grid != nullptr : levels[l].grid != nullptr);
+    S.full[l] = levels[l].grid; S.v_full[l] = levels[l].v_grid; S.sel[l] = sel[l];
+    S.count[l] = 12 * levels[l].gl * levels[l].gy * levels[l].gx;
+    S.n_img[l] = levels[l].n_avg;
+    S.blk_off[l + 1] = S.blk_off[l] + (int)cdiv(S.count[l], kBgBlock);
+  }
+  if (bwd) hipLaunchKernelGGL((grid_select_kernel<true>), dim3((unsigned)S.blk_off[nlevels]), dim3(kBgBlock), 0, as_stream(stream), S, img_idx_dev);
+  else hipLaunchKernelGGL((grid_select_kernel<false>), dim3((unsigned)S.blk_off[nlevels]), dim3(kBgBlock), 0, as_stream(stream), S, img_idx_dev);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+extern "C" int bds_bilagrid_select(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *sel,
+                                   bds_stream_t stream) {
+  return grid_select_launch(nlevels, levels, img_idx_dev, sel, false, stream);
+}
+extern "C" int bds_bilagrid_select_bwd(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *v_sel,
+                                       bds_stream_t stream) {
+  return grid_select_launch(nlevels, levels, img_idx_dev, v_sel, true, stream);
+}
+
 // Names (as rocprofv3 prints them, without "bds::" and the argument list; comma-separated) of the kernels that the forward / backward
 // of this configuration launches under the current options, in launch order; measurement plumbing for bench.py's counter look-up.
 extern "C" int bds_bilagrid_kernel_names(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, int backward, int train,

@@ -857,6 +857,9 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     g2d_buf = kwargs.pop("g2d_buf", None)    # persistent [2,N,2] screen-space gradient arrays whose stale rows the caller clears
     tail_buf, defer_pose_sum = kwargs.pop("tail_buf", None), bool(kwargs.pop("defer_pose_sum", False))
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
+    # the TV term over OTHER tensors than the transform's grids: graph_view's replayable view slices staging copies of ONE image's
+    # grids (picked by a device-side index) while the regulariser runs over the full [n_img, ...] parameters (modules.py:445)
+    tv_grids, tv_grid_grads = kwargs.pop("tv_grids", None), kwargs.pop("tv_grid_grads", None)
     opts = dict(sh_degree=3, near_plane=0.1, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_cull=True)
     opts.update({k: kwargs.pop(k) for k in list(kwargs) if k in opts})
     assert not kwargs, f"unknown arguments {sorted(kwargs)}"
@@ -875,8 +878,10 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
             and all(a.is_contiguous() and a.numel() == g.numel() for a, g in zip(grid_grads, gs)) and target.is_contiguous()
             and target.dtype == torch.float32 and tuple(target.shape) == (int(height), int(width), 3) and target.data_ptr() % 16 == 0):
         from .losses import _levels_struct as _tv_levels
-        cfg["train_loss"] = dict(target=target, grids=gs, grid_grads=list(grid_grads), levels=_tv_levels(gs, list(grid_grads), [1] * len(gs)),
-                                 weights=(C.c_float * max(len(gs), 1))(*[float(w) for w in tv_weights]))
+        tvg = gs if tv_grids is None else [g if g.dim() == 5 else g[None] for g in tv_grids]
+        tvgg = list(grid_grads) if tv_grid_grads is None else list(tv_grid_grads)
+        cfg["train_loss"] = dict(target=target, grids=tvg, grid_grads=tvgg, levels=_tv_levels(tvg, tvgg, [1] * len(tvg)),
+                                 weights=(C.c_float * max(len(tvg), 1))(*[float(w) for w in tv_weights]))
     names = ("means", "quats", "log_scales", "opacity_logits", "sh")
     leaves = [params[k] for k in names]
     needs = (False, *[bool(t.requires_grad) for t in leaves], bool(sky.requires_grad), bool(viewmat.requires_grad),

@@ -348,6 +348,16 @@ int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const flo
                             const float *s_log_scales, const float *s_logits, const float *s_sh, float *v_means, float *v_quats,
                             float *v_log_scales, float *v_logits, float *v_sh, bds_stream_t stream);
 
+/* The grids of ONE image picked by an image index that lives in DEVICE memory: a captured (hipGraph) view whose image changes from
+ * replay to replay -- the reference draws a random image every step (tools/train.py:257) and indexes the grid parameters with it
+ * (models/modules.py:507-512, `int(image_infos["img_idx"][0][0])`, a host read-back there).  levels[l]: grid / v_grid = the FULL
+ * parameter [n_img,12,gl,gy,gx] and its gradient, n_avg = n_img.  select: sel[l] [12,gl,gy,gx] = grid_l[*img_idx_dev];
+ * select_bwd: v_grid_l[*img_idx_dev] += v_sel[l], then v_sel[l] = 0.  An index outside [0, n_img) selects / adds nothing. */
+int bds_bilagrid_select(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *sel,
+                        bds_stream_t stream);
+int bds_bilagrid_select_bwd(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *v_sel,
+                            bds_stream_t stream);
+
 /* Names (as rocprofv3 prints them, without "bds::" and the argument list; comma-separated, launch order) of the kernels the bilateral
  * transform of this configuration launches under the current options (bds_set_option(7, ..)): forward (train != 0: with the L1 / TV
  * loss on the launch) or backward.  Measurement plumbing for bench.py's counter look-up; no reference counterpart. */

@@ -24,7 +24,7 @@ L.enable_timers(True)
 frame = FrameGraph(params, cams, grids, skies, targets, overlap="--no-overlap" not in sys.argv)
 L.enable_timers(False)
 for _ in range(4):
-    frame.step()
+    frame.step(wait=False)
 torch.cuda.synchronize()
 lib = L.lib()
 ref = frame.marks["project_fwd"][0][0]

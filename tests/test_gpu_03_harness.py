@@ -183,6 +183,21 @@ def test_fused_view_against_oracle_incl_pose_gradient_and_absgrad(ops, N, W, H, 
     E.smoke_check(verbose=True, N=N, W=W, H=H, seed=seed, pull=pull)
 
 
+@pytest.mark.parametrize("views", [1, 3])
+def test_replayed_frame_against_oracle_directly(ops, views):
+    """graph_view.FrameGraph.step() -- the path bench.py times: device-side list counts, SH colours in the record pack, the loss on the
+    colour transform's launch, hipGraph replay (one view: one graph each way on one stream; three: forwards on a second stream) --
+    against gs_oracle + bilagrid_oracle DIRECTLY at configs[0]'s size: every image 1e-4, every parameter / grid / sky / pose gradient
+    1e-3-class, the persistent screen-space gradient arrays against the oracle's absgrad probe."""
+    import __graft_entry__ as E
+    E.smoke_check(verbose=True, N=1000, W=256, H=256, seed=0, pull=0.25, views=views, graph=True)
+
+
+def test_eager_multi_view_frame_against_oracle(ops):
+    import __graft_entry__ as E
+    E.smoke_check(verbose=True, N=1000, W=256, H=256, seed=4, pull=0.25, views=3, graph=False)
+
+
 def test_rasterization_api_pose_gradient_and_fused_equivalence(ops):
     """rasterization() (the gsplat-shaped API) and the fused view give the same camera-pose gradient."""
     import bilateral_driving_amd.rendering as R

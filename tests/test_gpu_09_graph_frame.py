@@ -109,7 +109,7 @@ def test_device_count_overflow_renders_nothing_and_is_flagged(mods):
             assert t.grad is None or float(t.grad.abs().max()) == 0.0, k
 
 
-@pytest.mark.parametrize("overlap", [False, True, "tail", "two", "late", "front", "fronts", "single", "shift"])
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("n_views", [1, 3])
 def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
     """FrameGraph.step() (begin graph + one hipGraph per view) == the eager host-count frame, over several replays, and the flat
@@ -119,13 +119,9 @@ def test_frame_graph_equals_eager_frame(mods, n_views, overlap):
     yaws = (0.0, 120.0, 240.0)[:n_views]
     cams, p, grids, skies, targets = _scene(Hn, N, W, H, yaws, 3)
     outs, g_ref, sky_ref, vm_ref = _eager_frame(Hn, cams, p, grids, skies, targets)
-    frame = GV.FrameGraph(p, cams, grids, skies, targets, overlap=bool(overlap), overlap_tail=overlap == "tail",
-                          bwd_streams=2 if overlap == "two" else 1, late_image={"late": True, "front": "front"}.get(overlap, False),
-                          front_stream=overlap == "fronts", single_graph=overlap == "single", phase_shift=overlap == "shift")
-    assert frame.single_graph == (overlap == "single" and n_views > 1)     # (a one-view frame is always one graph per view)
+    frame = GV.FrameGraph(p, cams, grids, skies, targets, overlap=bool(overlap))
     for rep in range(3):
-        frame.step()
-        assert frame.valid()
+        assert frame.step() is True      # (waits for the frame, returns its validity)
         for v, vg in enumerate(frame.views):
             assert torch.equal(vg.rgb, outs[v][0]) and torch.equal(vg.depth, outs[v][1]), (rep, v)
             assert abs(float(vg.loss) - outs[v][2]) < 1e-6 * max(1.0, abs(outs[v][2]))
@@ -148,13 +144,12 @@ def test_frame_graph_follows_parameter_updates_and_grows_on_overflow(mods):
     W, H, N = 256, 160, 5000
     cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0, 180.0), 4)
     frame = GV.FrameGraph(p, cams, grids, skies, targets)
-    frame.step()
-    assert frame.valid()
+    assert frame.step()
     # tight capacities (what a scene that grew since the calibration looks like), captured again
     for v, (M, nv) in enumerate(frame.counts()):
         frame.caps[v] = FV.ListCapacity(M + 16, nv + 16)
     frame.capture()
-    frame.step()
+    assert frame.step(wait=False) is None
     for vg in frame.views:
         vg.done.synchronize()
     assert frame._check_counts()
@@ -162,10 +157,8 @@ def test_frame_graph_follows_parameter_updates_and_grows_on_overflow(mods):
         p["log_scales"].add_(0.7)      # every splat 2x larger: more (tile, Gaussian) pairs than the lists hold
         p["opacity_logits"].add_(0.5)
     n_cap = frame.n_captures
-    frame.step()
-    assert not frame.valid() and frame.n_captures == n_cap + 1
-    frame.step()
-    assert frame.valid()
+    assert frame.step() is False and frame.n_captures == n_cap + 1      # overflow: captured again with larger lists, frame to be dropped
+    assert frame.step() is True
     got = {k: t.grad.clone() for k, t in p.items()}
     rgb = [vg.rgb.clone() for vg in frame.views]
     absg = [g[1].clone() for g in frame.g2d]
@@ -221,3 +214,85 @@ def test_sh_in_the_record_pack_equals_the_dense_sh_pass(mods, monkeypatch):
     assert float((res[True][0] - res[False][0]).abs().max()) < 2e-6
     for k in res[False][1]:
         assert rel_err(res[True][1][k], res[False][1][k]) < 2e-4, k     # (float atomics in the compositor backward: order of the sums)
+
+
+def test_reprovisioning_is_deferred_until_the_valid_frame_was_consumed(mods):
+    """A count within 8 % of its capacity: the frame stays valid, its static outputs (sky / pose gradients, images) stay those of the
+    replay -- the larger lists are captured at the START of the next step(), not inside valid()."""
+    FV, GV, Hn = mods
+    W, H, N = 256, 160, 5000
+    cams, p, grids, skies, targets = _scene(Hn, N, W, H, (0.0, 180.0), 5)
+    frame = GV.FrameGraph(p, cams, grids, skies, targets)
+    assert frame.step()
+    sky_ref, vm_ref = [vg.v_sky.clone() for vg in frame.views], [vg.v_viewmat.clone() for vg in frame.views]
+    rgb_ref = [vg.rgb.clone() for vg in frame.views]
+    for v, (M, nv) in enumerate(frame.counts()):
+        frame.caps[v] = FV.ListCapacity(int(M * 1.02) + 1, int(nv * 1.02) + 1)     # > 92 % full
+    frame.capture()
+    n_cap = frame.n_captures
+    assert frame.step() is True and frame._reprovision and frame.n_captures == n_cap      # nothing captured yet
+    for v, vg in enumerate(frame.views):
+        assert skies[v].grad is vg.v_sky and torch.equal(vg.v_sky, sky_ref[v]) and rel_err(vg.v_viewmat, vm_ref[v]) < 1e-5
+        assert torch.equal(vg.rgb, rgb_ref[v])
+    assert frame.step() is True and frame.n_captures == n_cap + 1 and not frame._reprovision
+    for v, vg in enumerate(frame.views):
+        assert torch.equal(vg.rgb, rgb_ref[v]) and torch.equal(vg.v_sky, sky_ref[v])
+
+
+def test_one_captured_view_replays_over_random_cameras_and_images(mods):
+    """FrameGraph(dynamic=True): ONE captured view, 20 replays with a random camera / target / sky / image index each (what the
+    reference's loop feeds a step, tools/train.py:250-283) == the eager view of the same inputs, every time: image bit-equal, loss,
+    per-Gaussian / grid / sky / pose gradients.  The image's grids are picked on the device (bds_bilagrid_select)."""
+    FV, GV, Hn = mods
+    W, H, N, n_img = 256, 160, 5000, 7
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(21)
+    yaws = [float(y) for y in (torch.rand(12, generator=gen) * 360.0)]
+    pool = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev)
+    for i, c in enumerate(pool):      # each camera its own centre and intrinsics: everything a slot holds changes between replays
+        vm = c.viewmat.clone()
+        vm[:3, 3] += (torch.rand(3, generator=gen) - 0.5).to(dev)
+        c.viewmat = vm
+        c.K = c.K.clone()
+        c.K[0, 0] *= 1.0 + 0.02 * i
+        c.K[1, 1] *= 1.0 + 0.02 * i
+        c.cam_pos = torch.linalg.inv(vm)[:3, 3].contiguous()
+    p = Hn.synthetic_scene(N, seed=9, device=dev)
+    p["means"] = p["means"] * torch.tensor([0.4, 0.4, 1.0], device=dev)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(n_img, device=dev)]
+    sky0 = torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True)
+    slot_cam = Hn.Camera(pool[0].viewmat.clone().requires_grad_(True), pool[0].K, W, H, pool[0].cam_pos)
+    frame = GV.FrameGraph(p, [slot_cam], grids, [sky0], [torch.rand(H, W, 3, generator=gen).to(dev)], img_indices=[0], dynamic=True,
+                          calib_cams=pool)
+    n_cap = frame.n_captures
+    for rep in range(20):
+        k = int(torch.randint(0, len(pool), (1,), generator=gen))
+        img = int(torch.randint(0, n_img, (1,), generator=gen))
+        target = torch.rand(H, W, 3, generator=gen).to(dev)
+        sky = torch.rand(H, W, 3, generator=gen).to(dev)
+        frame.set_view(0, pool[k], target, sky, img if rep % 2 else torch.tensor([img], device=dev))
+        assert frame.step() is True
+        vg = frame.views[0]
+        got = {n: t.grad.clone() for n, t in p.items()}
+        got_g = [g.grad.clone() for g in grids]
+        got_rgb, got_loss, got_sky, got_vm = vg.rgb.clone(), float(vg.loss), vg.v_sky.clone(), vg.v_viewmat.clone()
+        # the eager view of the same inputs (host-count path, autograd)
+        cam = Hn.Camera(pool[k].viewmat.clone().requires_grad_(True), pool[k].K, W, H, pool[k].cam_pos)
+        sky_e = sky.clone().requires_grad_(True)
+        p_e = {n: t.detach().clone().requires_grad_(True) for n, t in p.items()}
+        g_e = [g.detach().clone().requires_grad_(True) for g in grids]
+        out = Hn.render_view(p_e, cam, g_e, img, sky_e)
+        loss = Hn.training_loss(out, target, g_e)
+        loss.backward()
+        assert torch.equal(got_rgb, out["rgb"].detach()), rep
+        assert abs(got_loss - float(loss)) < 1e-6 * max(1.0, abs(float(loss)))
+        for n in p:
+            assert rel_err(got[n], p_e[n].grad) < 2e-4, (rep, n)
+        for i, g in enumerate(g_e):
+            assert rel_err(got_g[i], g.grad) < 3e-5, (rep, i)
+            others = [j for j in range(n_img) if j != img]
+            # (only the TV term reaches the other images' grids)
+            assert rel_err(got_g[i][others], g.grad[others]) < 3e-5
+        assert rel_err(got_sky, sky_e.grad) < 1e-6 and rel_err(got_vm, cam.viewmat.grad) < 1e-4
+    assert frame.n_captures == n_cap      # one capture served them all
