@@ -56,6 +56,9 @@ _SIGS = {
     "bds_isect_prepare_async": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _f, _i, _f]),
     "bds_isect_tiles": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _f, _sz, _i64, _f, _f, _f, C.POINTER(C.c_int64),
                              C.POINTER(C.c_int64), _f]),
+    "bds_splat_pack_rgbd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_expected_depth_fwd": (_i, [_i64, _f, _f, _f, _f]),
+    "bds_expected_depth_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
@@ -66,6 +69,7 @@ _SIGS = {
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_splat_pack_sh": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_project_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),
     "bds_view_grads_add_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),

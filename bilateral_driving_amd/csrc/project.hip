@@ -184,13 +184,15 @@ __device__ __forceinline__ void pose_grad_reduce(const ProjGrad &pg, float (*red
 // (kAcc = true) to the rows of the visible Gaussians only -- rows of culled Gaussians are the caller's business.  Optionally
 // scatters the screen-space gradient and its absolute sum to the dense [N,2] arrays the densification statistics read
 // (models/trainers/base.py:280-297), and reduces the camera-pose gradient (models/trainers/base.py:328-329,399).
-template <bool kAcc, bool kPose>
+// kRaw = false (the gsplat-shaped operator, rendering.rasterization): the caller passed ACTIVATED scales / opacities -- their gradients
+// are returned as they are -- and post-activation colours, whose gradient (record channels 0-2) is scattered to v_colors [N,3].
+template <bool kAcc, bool kPose, bool kRaw = true>
 __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     int64_t n_cap, const uint64_t *__restrict__ n_dev, const int32_t *__restrict__ ids, const float *__restrict__ means,
     const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     const float *__restrict__ K, int W, int H, float eps2d, const float4 *__restrict__ v_rec, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat_slots,
-    float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map) {
+    float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map, float *__restrict__ v_colors = nullptr) {
   __shared__ float red[kProjBlock / kWave][12];
   const int64_t n_list = list_length(n_cap, n_dev);
   if ((int64_t)blockIdx.x * kProjBlock >= n_list) return;   // (whole workgroup: nothing to add to the pose slots either)
@@ -219,12 +221,13 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     }
     Camera cam = load_camera(viewmat, K);
     project_one_vjp(m, q, s, cam, W, H, eps2d, r1.w, r2.x, /*v_depth*/ r0.w, r1.x, r1.y, r1.z, pg);
-    const float al = r2.w * o * (1.f - o);
+    const float al = kRaw ? r2.w * o * (1.f - o) : r2.w;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       v_means[d * 3 + i] = old_m[i] + pg.v_mean[i];
-      v_log_scales[d * 3 + i] = old_s[i] + pg.v_scale[i] * s[i];
+      v_log_scales[d * 3 + i] = old_s[i] + (kRaw ? pg.v_scale[i] * s[i] : pg.v_scale[i]);
     }
+    if (!kRaw && v_colors) { v_colors[g * 3] = r0.x; v_colors[g * 3 + 1] = r0.y; v_colors[g * 3 + 2] = r0.z; }
 #pragma unroll
     for (int i = 0; i < 4; i++) v_quats[d * 4 + i] = old_q[i] + pg.v_quat[i];
     v_logits[d] = old_l + al;
@@ -340,6 +343,30 @@ extern "C" int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, con
                                          float *absgrad2d, const int32_t *row_map, int accumulate, bds_stream_t stream) {
   return project_view_bwd_list_impl(n_list, nullptr, ids, means, quats, scales, opacities, viewmat, K, W, H, eps2d, v_records, v_means,
                                     v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d, absgrad2d, row_map, accumulate, stream);
+}
+
+// The gsplat-shaped operator's backward over the visible entries (rendering.rasterization, C = 1): gradients of the ACTIVATED scales
+// and opacities and of the post-activation colours, stored to the visible rows of dense, caller-zeroed arrays.
+extern "C" int bds_project_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats, const float *scales,
+                                    const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                    const float *v_records, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                                    float *v_colors, float *v_viewmat_slots, float *grad2d, float *absgrad2d, bds_stream_t stream) {
+  BDS_REQUIRE(n_list >= 0 && W > 0 && H > 0);
+  if (n_list == 0) return BDS_OK;
+  BDS_REQUIRE(ids && means && quats && scales && opacities && viewmat && K && v_records && aligned16(v_records) && v_means &&
+              v_quats && v_scales && v_opacities);
+  const dim3 grid((unsigned)cdiv(n_list, kProjBlock)), block(kProjBlock);
+  const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
+  if (v_viewmat_slots)
+    hipLaunchKernelGGL((project_view_bwd_list_kernel<false, true, false>), grid, block, 0, as_stream(stream), n_list, nullptr, ids, means,
+                       quats, scales, opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_scales, v_opacities, v_viewmat_slots,
+                       grad2d, absgrad2d, nullptr, v_colors);
+  else
+    hipLaunchKernelGGL((project_view_bwd_list_kernel<false, false, false>), grid, block, 0, as_stream(stream), n_list, nullptr, ids, means,
+                       quats, scales, opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_scales, v_opacities, v_viewmat_slots,
+                       grad2d, absgrad2d, nullptr, v_colors);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
 }
 
 extern "C" int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, const float *means,

@@ -620,6 +620,87 @@ static int splat_pack_impl(int64_t n, const uint64_t *n_dev, int CH, const int32
   return BDS_OK;
 }
 
+// ---- glue of the gsplat-shaped operator's one-view node (rendering._RasterizeView) ---------------------------------------------------
+namespace bds {
+// records of the visible entries from post-activation colours [N,3] + depths [N] (RGB+ED / RGB: channel 3 = depth), without a
+// dense [N,4] concatenation in front
+__global__ __launch_bounds__(kPackBlock) void splat_pack_rgbd_kernel(int64_t n, const int32_t *__restrict__ ids, const float *__restrict__ means2d,
+                                                                    const float *__restrict__ conics, const float *__restrict__ colors3,
+                                                                    const float *__restrict__ depths, const float *__restrict__ opacities,
+                                                                    const int32_t *__restrict__ radii, float4 *__restrict__ rec) {
+  const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
+  if (r >= n) return;
+  const int64_t g = ids ? (int64_t)ids[r] : r;
+  const float2 xy = *reinterpret_cast<const float2 *>(means2d + g * 2);
+  const float *cn = conics + g * 3, *cl = colors3 + g * 3;
+  rec[r * 3] = make_float4(xy.x, xy.y, (-0.5f * kLog2e) * cn[0], -kLog2e * cn[1]);
+  rec[r * 3 + 1] = make_float4((-0.5f * kLog2e) * cn[2], opacities[g], cl[0], cl[1]);
+  rec[r * 3 + 2] = make_float4(cl[2], depths[g], 0.f, __int_as_float(radii ? radii[g] : kUnboundedRadius));
+}
+// expected depth of gsplat's "ED" modes: out = (r, g, b, D / max(alpha, 1e-10))
+__global__ __launch_bounds__(256) void ed_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
+                                                     float4 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  float4 v = render[i];
+  v.w = v.w / fmaxf(alphas[i], 1e-10f);
+  out[i] = v;
+}
+// its backward, and the widening of a 3-channel ("RGB") image gradient to the compositor's 4 channels: v_render = (v_out.rgb,
+// v_out.d / max(alpha, 1e-10) | 0), v_alphas = v_alphas_in - [alpha >= 1e-10] D v_out.d / max(alpha, 1e-10)^2
+__global__ __launch_bounds__(256) void ed_bwd_kernel(int64_t P, int ch, int ed, const float4 *__restrict__ render, const float *__restrict__ alphas,
+                                                     const float *__restrict__ v_out, const float *__restrict__ v_alphas_in,
+                                                     float4 *__restrict__ v_render, float *__restrict__ v_alphas) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float va = v_alphas_in ? v_alphas_in[i] : 0.f;
+  if (v_out) {
+    v.x = v_out[i * ch]; v.y = v_out[i * ch + 1]; v.z = v_out[i * ch + 2];
+    if (ch == 4) v.w = v_out[i * 4 + 3];
+  }
+  if (ed) {
+    const float a = alphas[i], ac = fmaxf(a, 1e-10f), vd = v.w;
+    v.w = vd / ac;
+    if (a >= 1e-10f) va -= render[i].w * vd / (ac * ac);
+  }
+  v_render[i] = v;
+  v_alphas[i] = va;
+}
+}  // namespace bds
+
+extern "C" int bds_splat_pack_rgbd(int64_t n, const int32_t *ids, const float *means2d, const float *conics, const float *colors3,
+                                   const float *depths, const float *opacities, const int32_t *radii, float *records,
+                                   bds_stream_t stream) {
+  BDS_REQUIRE(n >= 0);
+  if (n == 0) return BDS_OK;
+  BDS_REQUIRE(means2d && conics && colors3 && depths && opacities && records && aligned16(records));
+  hipLaunchKernelGGL(splat_pack_rgbd_kernel, dim3((unsigned)cdiv(n, kPackBlock)), dim3(kPackBlock), 0, as_stream(stream), n, ids, means2d, conics,
+                     colors3, depths, opacities, radii, reinterpret_cast<float4 *>(records));
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+extern "C" int bds_expected_depth_fwd(int64_t P, const float *render4, const float *alphas, float *out4, bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(render4 && alphas && out4 && aligned16(render4) && aligned16(out4));
+  hipLaunchKernelGGL(ed_fwd_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, as_stream(stream), P, reinterpret_cast<const float4 *>(render4),
+                     alphas, reinterpret_cast<float4 *>(out4));
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+extern "C" int bds_expected_depth_bwd(int64_t P, int channels, int expected_depth, const float *render4, const float *alphas,
+                                      const float *v_out, const float *v_alphas_in, float *v_render4, float *v_alphas,
+                                      bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0 && (channels == 3 || channels == 4) && !(expected_depth && channels != 4));
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(render4 && alphas && v_render4 && v_alphas && aligned16(render4) && aligned16(v_render4));
+  hipLaunchKernelGGL(ed_bwd_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, as_stream(stream), P, channels, expected_depth,
+                     reinterpret_cast<const float4 *>(render4), alphas, v_out, v_alphas_in, reinterpret_cast<float4 *>(v_render4), v_alphas);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
 extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
                               const float *opacities, const int32_t *radii, float *records, bds_stream_t stream) {
   return splat_pack_impl(n, nullptr, CH, ids, means2d, conics, colors, opacities, radii, records, nullptr, nullptr, 0, stream);

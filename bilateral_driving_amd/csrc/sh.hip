@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, cons
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int deg = DEG, nb = (DEG + 1) * (DEG + 1);
   const int row = nb * 3;       // floats used per Gaussian
-  const int ldr = row + 1;      // padded LDS row
+  const int ldr = kFull ? row + 4 : row + 1;   // padded LDS row (kFull: 16-byte aligned rows; 52 floats put 16 rows on 16 bank quads)
   const int64_t g0 = (int64_t)blockIdx.x * kShBlock;
   const int cnt = (int)min((int64_t)kShBlock, n - g0);
   const int tid = threadIdx.x;
@@ -34,9 +34,7 @@ __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, cons
       int e = i * 4;
       int r = e / row, c = e - r * row;  // row % 4 == 0 -> the 4 floats stay in one row
       if (masks != nullptr && !masks[g0 + r]) continue;  // culled Gaussian: its 192-byte row is never fetched
-      float4 v = src[i];
-      float *d = lds + r * ldr + c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      *reinterpret_cast<float4 *>(lds + r * ldr + c) = src[i];
     }
   } else {
     const int tot = cnt * row;
@@ -56,11 +54,26 @@ __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, cons
     float B[16];
     sh_bases(deg, x * inorm, y * inorm, z * inorm, B);
     const float *c = lds + tid * ldr;
+    if (kFull) {   // 16-byte LDS reads of the row (same products, same order)
+      float cf[nb * 3 + 3];
 #pragma unroll
-    for (int k = 0; k < nb; k++) {
-      o0 += B[k] * c[k * 3];
-      o1 += B[k] * c[k * 3 + 1];
-      o2 += B[k] * c[k * 3 + 2];
+      for (int i = 0; i < (nb * 3) / 4; i++) {
+        const float4 v = reinterpret_cast<const float4 *>(c)[i];
+        cf[i * 4] = v.x; cf[i * 4 + 1] = v.y; cf[i * 4 + 2] = v.z; cf[i * 4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int k = 0; k < nb; k++) {
+        o0 += B[k] * cf[k * 3];
+        o1 += B[k] * cf[k * 3 + 1];
+        o2 += B[k] * cf[k * 3 + 2];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < nb; k++) {
+        o0 += B[k] * c[k * 3];
+        o1 += B[k] * c[k * 3 + 1];
+        o2 += B[k] * c[k * 3 + 2];
+      }
     }
   }
   out[g * 3] = o0; out[g * 3 + 1] = o1; out[g * 3 + 2] = o2;
@@ -450,8 +463,8 @@ extern "C" int bds_sh_fwd(int64_t n, int K, int deg, const float *dirs, const fl
   BDS_REQUIRE(dirs && coeffs && out);
   const int nb = (deg + 1) * (deg + 1);
   const int grid = (int)cdiv(n, kShBlock);
-  const size_t lds = (size_t)kShBlock * (nb * 3 + 1) * sizeof(float);
   const bool full = (nb == K) && ((nb * 3) % 4 == 0) && aligned16(coeffs);
+  const size_t lds = (size_t)kShBlock * (nb * 3 + (full ? 4 : 1)) * sizeof(float);
   hipStream_t st = as_stream(stream);
   switch (deg) {
     case 0: launch_fwd<0>(full, grid, lds, st, n, K, dirs, coeffs, masks, out); break;

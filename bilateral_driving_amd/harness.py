@@ -31,7 +31,8 @@ FACTORS_3 = (4, 4, 2)                          # modules.py:505 default guidance
 LEVELS_SINGLE = ((16, 16, 8),)
 FACTORS_SINGLE = (1,)
 TILE_CULL = True  # exact tile culling in render_view (see gs_ops.isect_tiles); images/gradients are unaffected
-FUSED = True      # render_view = one fused autograd node (fused_view.py); False = chain of individual operators
+FUSED = True      # render_view = one fused autograd node (fused_view.py); False = the reference's call sequence over the drop-in
+#                   operators (render_view_api); "ops" = the chain of individual operators (render_view_staged)
 
 
 @dataclass
@@ -93,8 +94,10 @@ def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor],
                 front=None, caps=None, prep_ws=None):
     """One view's forward (dict(rgb, depth, opacity, rgb_gaussians, info)): a single fused autograd node
     (fused_view.py) by default, or the chain of individual operators (render_view_staged) when FUSED is off."""
-    if not FUSED:
+    if FUSED == "ops":
         return render_view_staged(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
+    if not FUSED:
+        return render_view_api(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
     return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL,
                       grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink, list_tile=list_tile, front=front,
@@ -161,6 +164,34 @@ def render_view_staged(params: Dict[str, Tensor], cam: Camera, grids: Sequence[T
     info = {"means2d": means2d, "radii": radii, "depths": depths, "conics": conics, "width": W, "height": H,
             "tiles_per_gauss": tiles_per_gauss, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
             "tile_size": TILE_SIZE, "n_cameras": 1, "n_isects": int(flatten_ids.numel())}
+    return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
+
+
+def render_view_api(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
+                    factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
+                    radius_clip: float = 0.0, eps2d: float = 0.3):
+    """One view's forward through the reference's OWN call sequence, every gsplat / bilateral entry point replaced by this package's
+    drop-in and nothing else changed: the Gaussian class's activations and dense SH pass (models/gaussians/vanilla.py:378-414:
+    exp, sigmoid, normalised quaternions, ``spherical_harmonics`` over ALL Gaussians, clamp), ``rasterization(...)`` with the
+    trainer's arguments (models/trainers/base.py:393-408), split / sky blend / colour transform (base.py:409-419,
+    scene_graph.py:86-120,292-294; the transform through the module's fused ``transform``).  What bench.py reports as
+    ``api_path_iters_per_sec``."""
+    from .rendering import rasterization
+    means = params["means"]
+    W, H = cam.width, cam.height
+    opac = torch.sigmoid(params["opacity_logits"])                         # vanilla.py:393
+    scales = torch.exp(params["log_scales"])                               # vanilla.py:394
+    quats = params["quats"] / params["quats"].norm(dim=-1, keepdim=True)   # vanilla.py:395 (get_quats)
+    cam_pos = cam.cam_pos if cam.cam_pos is not None else torch.linalg.inv(cam.viewmat.detach())[:3, 3]
+    viewdirs = means.detach() - cam_pos                                    # vanilla.py:384-385
+    rgbs = spherical_harmonics(sh_degree, viewdirs, params["sh"])          # vanilla.py:388 (every Gaussian: nothing is culled yet)
+    rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)                               # vanilla.py:389
+    renders, alphas, info = rasterization(means, quats, scales, opac, rgbs, cam.viewmat[None], cam.K[None], W, H, packed=False,
+                                          absgrad=True, sparse_grad=False, rasterize_mode="classic", near_plane=near_plane,
+                                          far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, render_mode="RGB+ED")   # base.py:393-408
+    rgb_g, depth, opacity = renders[0, ..., :3], renders[0, ..., 3:4], alphas[0]      # base.py:409-416
+    grids_k = [g[img_idx:img_idx + 1] for g in grids]
+    rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)          # clamp + sky blend + slice + affine
     return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
 
 

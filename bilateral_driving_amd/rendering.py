@@ -14,14 +14,29 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from .gs_ops import (TILE_SIZE, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
+import weakref
+
+from . import _lib as L
+from .gs_ops import (TILE_SIZE, _f32c, bwd_schedule, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
 
 
 class _Meta(dict):
     """The ``meta`` dict of gsplat's rasterization().  ``isect_ids`` (the sorted 64-bit keys, which nothing on
-    the reference's path reads) is materialised on first access instead of on every step."""
+    the reference's path reads) is materialised on first access instead of on every step -- and, on the one-view fast path
+    (``_RasterizeView``), so are gsplat's per-16-px-tile lists (``tiles_per_gauss`` / ``flatten_ids`` / ``isect_offsets``): the
+    compositor there walks compact lists of 64-px tiles that never take gsplat's layout (the reference reads ``means2d`` / ``radii`` /
+    ``width`` / ``height``: models/trainers/base.py:279-297,422-430)."""
+    _LISTS = ("tiles_per_gauss", "flatten_ids", "isect_offsets")
 
     def __getitem__(self, key):
+        if key in self._LISTS and dict.__getitem__(self, key) is None:
+            cull = dict.__getitem__(self, "_cull")
+            tpg, _, fids, offs = isect_tiles(self["means2d"], self["radii"], self["depths"], self["tile_size"], self["tile_width"],
+                                             self["tile_height"], want_isect_ids=False, conics=self["conics"] if cull else None,
+                                             opacities=self["opacities"].contiguous() if cull else None)
+            dict.__setitem__(self, "tiles_per_gauss", tpg)
+            dict.__setitem__(self, "flatten_ids", fids)
+            dict.__setitem__(self, "isect_offsets", offs)
         if key == "isect_ids" and dict.__getitem__(self, key) is None:
             self["isect_ids"] = _isect_ids_from(self["isect_offsets"], self["flatten_ids"], self["depths"])
         return dict.__getitem__(self, key)
@@ -45,6 +60,144 @@ _TILE_CULLING = os.environ.get("BDS_TILE_CULL", "1") != "0"
 def set_tile_culling(on: bool) -> None:
     global _TILE_CULLING
     _TILE_CULLING = bool(on)
+
+
+# One camera, post-activation colours [N,3], "RGB" / "RGB+ED", classic mode, no backgrounds -- the reference's two call patterns
+# (models/trainers/base.py:393-408,811-826) -- run as ONE autograd node over compact lists (BDS_API_FUSED=0: the operator chain below)
+_ONE_VIEW_NODE = os.environ.get("BDS_API_FUSED", "1") != "0"
+_LIST_TILE = 64          # list tiles of the one-view node (the splat records carry the radii: the image is the 16-px one)
+_CAPACITY: Dict[tuple, list] = {}      # (N, W, H) -> [list entries, visible Gaussians] seen so far: buffers provisioned before the wait
+
+
+class _RasterizeView(torch.autograd.Function):
+    """gsplat's rasterization() for one camera as one node: general projection (activated scales), visibility compaction + depth
+    order + 64-px tile lists in compact positions (ONE host wait for the two list counts, overlapped with packing the colours),
+    48-byte splat records of the visible Gaussians only, forward composite; backward: composite -> 64-byte gradient records of the
+    visible Gaussians -> list-driven projection backward into dense, zero-initialised gradients (rows of culled Gaussians stay
+    zero, as gsplat returns them).  Against the operator chain: no dense record pack / dense gradient records over all N, no dense
+    projection backward, ~12 launches instead of ~45."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmat, Kmat, cfg):
+        from .fused_view import _host_sync_objects, _release_sync_objects
+        L.require_gpu(means, quats, scales, opacities, colors, viewmat, Kmat)
+        means, quats, scales, opacities, colors, viewmat, Kmat = map(_f32c, (means, quats, scales, opacities, colors, viewmat, Kmat))
+        lib, st = L.lib(), L.stream()
+        dev = means.device
+        W, H, N = cfg["width"], cfg["height"], means.shape[0]
+        radii = torch.empty(1, N, device=dev, dtype=torch.int32)
+        means2d, depths, conics = torch.empty(1, N, 2, device=dev), torch.empty(1, N, device=dev), torch.empty(1, N, 3, device=dev)
+        with L.timed("project_fwd"):
+            L.check(lib.bds_project_fwd(1, N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(viewmat), L.ptr(Kmat), W, H, cfg["eps2d"],
+                                        cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], L.ptr(radii), L.ptr(means2d), L.ptr(depths),
+                                        L.ptr(conics), None, st), "bds_project_fwd")
+        LT = _LIST_TILE
+        ltw, lth = math.ceil(W / LT), math.ceil(H / LT)
+        tw, th = math.ceil(W / TILE_SIZE), math.ceil(H / TILE_SIZE)
+        opac_c = opacities.view(1, N)
+        cull = cfg["cull"]
+        cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
+        tiles_per_gauss = torch.empty(1, N, device=dev, dtype=torch.int32)
+        ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
+        ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        counts, ev = _host_sync_objects(dev)
+        with L.timed("isect_prepare"):
+            L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, ltw, lth,
+                                                L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
+                    "bds_isect_prepare_async")
+        # while the two counts travel to the host: every buffer whose size is known
+        colors3 = colors.reshape(N, 3)
+        key = (N, W, H)
+        cap = _CAPACITY.setdefault(key, [0, 0])
+        flat_buf = torch.empty(cap[0], device=dev, dtype=torch.int32) if cap[0] else None
+        ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, cap[0]) if cap[0] else 0
+        ws2 = torch.empty(max(ws2_bytes, 16), device=dev, dtype=torch.uint8) if cap[0] else None
+        rec_buf = torch.empty(cap[1], L.SPLAT_RECORD_FLOATS, device=dev) if cap[1] else None
+        isect_offsets = torch.empty(1, lth, ltw, device=dev, dtype=torch.int32)
+        render = torch.empty(1, H, W, 4, device=dev)
+        alphas = torch.empty(1, H, W, 1, device=dev)
+        last_ids = torch.empty(1, H, W, device=dev, dtype=torch.int32)
+        ev.synchronize()
+        M, n_vis = int(counts.np[0]), int(counts.np[1])
+        _release_sync_objects(dev, (counts, ev))
+        if flat_buf is None or M > cap[0]:
+            flat_buf = torch.empty(M, device=dev, dtype=torch.int32)
+            ws2_bytes = lib.bds_isect_build_workspace_bytes(1, N, M)
+            ws2 = torch.empty(max(ws2_bytes, 16), device=dev, dtype=torch.uint8)
+        if rec_buf is None or n_vis > cap[1]:
+            rec_buf = torch.empty(n_vis, L.SPLAT_RECORD_FLOATS, device=dev)
+        if M + M // 16 > cap[0]:
+            cap[0] = M + M // 6 + 4096
+        if n_vis + n_vis // 16 > cap[1]:
+            cap[1] = n_vis + n_vis // 6 + 1024
+        flatten, rec = flat_buf[:M], rec_buf[:n_vis]
+        off = lib.bds_isect_visible_ids_offset(1, N)
+        vis_ids = ws[off:off + 4 * n_vis].view(torch.int32)       # ascending ids of the visible Gaussians, read in place
+        with L.timed("isect_build"):
+            L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, ltw, lth, L.ptr(ws),
+                                        ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(flatten), L.ptr(isect_offsets), None, 1, st),
+                    "bds_isect_build")
+        with L.timed("rasterize_fwd"):
+            L.check(lib.bds_splat_pack_rgbd(n_vis, L.ptr(vis_ids), L.ptr(means2d), L.ptr(conics), L.ptr(colors3), L.ptr(depths),
+                                            L.ptr(opacities), L.ptr(radii), L.ptr(rec), st), "bds_splat_pack_rgbd")
+            L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE_SIZE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
+                                          L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
+        ctx.save_for_backward(means, quats, scales, opacities, viewmat, Kmat, rec, vis_ids, ws, flatten, isect_offsets, render, alphas, last_ids)
+        ctx.cfg, ctx.M = cfg, M
+        if cfg["ed"]:      # expected depth: D / clamp(alpha, 1e-10) (gsplat "ED")
+            out = torch.empty_like(render)
+            L.check(lib.bds_expected_depth_fwd(H * W, L.ptr(render), L.ptr(alphas), L.ptr(out), st), "bds_expected_depth_fwd")
+        else:
+            out = render[..., :3] if cfg["channels"] == 3 else render
+        ctx.mark_non_differentiable(radii, depths, conics)
+        return out, alphas, means2d, radii, depths, conics
+
+    @staticmethod
+    def backward(ctx, v_out, v_alphas, v_means2d_ext, *_):
+        means, quats, scales, opacities, viewmat, Kmat, rec, vis_ids, _ws, flatten, isect_offsets, render, alphas, last_ids = ctx.saved_tensors
+        cfg, M = ctx.cfg, ctx.M
+        lib, st = L.lib(), L.stream()
+        dev = means.device
+        W, H, N = cfg["width"], cfg["height"], means.shape[0]
+        n_vis = vis_ids.numel()
+        tw, th = math.ceil(W / TILE_SIZE), math.ceil(H / TILE_SIZE)
+        v_render, v_alphas_t = torch.empty_like(render), torch.empty_like(alphas)
+        L.check(lib.bds_expected_depth_bwd(H * W, cfg["channels"], int(cfg["ed"]), L.ptr(render), L.ptr(alphas), L.ptr(_f32c(v_out)),
+                                           L.ptr(_f32c(v_alphas)), L.ptr(v_render), L.ptr(v_alphas_t), st), "bds_expected_depth_bwd")
+        v_alphas = v_alphas_t
+        want_pose = bool(ctx.needs_input_grad[5])
+        v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev)
+        v_rec = v_rec_all[:max(n_vis, 1)]
+        order = bwd_schedule(1, W, H, _LIST_TILE, isect_offsets, last_ids)
+        with L.timed("rasterize_bwd"):
+            L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE_SIZE, _LIST_TILE, tw, th, L.ptr(isect_offsets),
+                                          L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec),
+                                          int(bool(cfg["absgrad"])), L.ptr(order), st), "bds_rasterize_bwd")
+        if v_means2d_ext is not None and n_vis:   # a loss term on meta["means2d"] itself: add its rows to the records
+            v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())
+        # ONE zero fill for all dense outputs: means 3 | quats 4 | scales 3 | opacities 1 | colours 3 | grad2d 2 | absgrad2d 2
+        dense = torch.zeros(N * 18, device=dev)
+        o = 0
+        outs = []
+        for w in (3, 4, 3, 1, 3, 2, 2):
+            outs.append(dense[o:o + N * w].view(N, w) if w > 1 else dense[o:o + N])
+            o += N * w
+        v_means, v_quats, v_scales, v_opac, v_colors, g2d, ag2d = outs
+        slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS, 4, 4) if want_pose else None
+        with L.timed("project_bwd"):
+            L.check(lib.bds_project_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(viewmat),
+                                             L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales),
+                                             L.ptr(v_opac), L.ptr(v_colors), L.ptr(slots), L.ptr(g2d), L.ptr(ag2d) if cfg["absgrad"] else None, st),
+                    "bds_project_bwd_list")
+        carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
+        if carrier is not None:      # the tensor the caller holds in meta["means2d"] (trainers/base.py:280-297 read .absgrad / .grad)
+            if cfg["absgrad"]:
+                carrier.absgrad = ag2d.view(1, N, 2)
+            if carrier.retains_grad:
+                carrier.grad = g2d.view(1, N, 2)
+        g = ctx.needs_input_grad
+        return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None, v_opac if g[3] else None,
+                v_colors.view(cfg["colors_shape"]) if g[4] else None, slots.sum(0) if want_pose else None, None, None)
 
 
 def _as_int(v) -> int:
@@ -114,6 +267,20 @@ def rasterization(
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
 
+    if (_ONE_VIEW_NODE and C == 1 and N > 0 and sh_degree is None and colors.shape[-1] == 3 and backgrounds is None
+            and render_mode in ("RGB", "RGB+ED") and rasterize_mode == "classic"):
+        cfg = dict(width=width, height=height, eps2d=float(eps2d), near_plane=float(near_plane), far_plane=float(far_plane),
+                   radius_clip=float(radius_clip), ed=render_mode == "RGB+ED", channels=3 if render_mode == "RGB" else 4,
+                   absgrad=bool(absgrad), cull=_TILE_CULLING, colors_shape=tuple(colors.shape))
+        out, alphas, means2d, radii, depths, conics = _RasterizeView.apply(means, quats, scales, opacities, colors, viewmats[0], Ks[0], cfg)
+        cfg["_means2d_ref"] = weakref.ref(means2d)      # the backward attaches .absgrad (and .grad, when retained) to THIS tensor object
+        tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
+        meta = _Meta({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+                      "opacities": opacities.detach()[None, :], "tile_width": tile_width, "tile_height": tile_height,
+                      "tiles_per_gauss": None, "isect_ids": None, "flatten_ids": None, "isect_offsets": None, "width": width,
+                      "height": height, "tile_size": tile_size, "n_cameras": C, "_cull": _TILE_CULLING})
+        return out, alphas, meta
+
     radii, means2d, depths, conics, compensations = fully_fused_projection(
         means, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
         radius_clip=radius_clip, calc_compensations=(rasterize_mode == "antialiased"))
@@ -170,5 +337,6 @@ def rasterization(
         "height": height,
         "tile_size": tile_size,
         "n_cameras": C,
+        "_cull": _TILE_CULLING,
     })
     return render_colors, render_alphas, meta

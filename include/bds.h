@@ -177,6 +177,16 @@ int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii
  * API's tile_size argument).  last_ids holds positions in the coarse list. */
 #define BDS_SPLAT_RECORD_FLOATS 12
 #define BDS_GRAD_RECORD_FLOATS 16
+/* Glue of gsplat's rasterization() as ONE node for one camera (rendering._RasterizeView; models/trainers/base.py:393-408):
+ * records of the visible entries straight from post-activation colours [N,3] + depths [N] (channel 3 = depth, "RGB+ED");
+ * the expected-depth normalise out4 = (rgb, D / max(alpha, 1e-10)) and its backward, which also widens a 3-channel ("RGB") image
+ * gradient to the compositor's four channels: v_render4 = (v_out.rgb, v_out.d / max(alpha, 1e-10) | 0), v_alphas = v_alphas_in
+ * (may be NULL) - [alpha >= 1e-10] D v_out.d / max(alpha, 1e-10)^2.  v_out: [P, channels], may be NULL (zeros). */
+int bds_splat_pack_rgbd(int64_t n, const int32_t *ids, const float *means2d, const float *conics, const float *colors3,
+                        const float *depths, const float *opacities, const int32_t *radii, float *records, bds_stream_t stream);
+int bds_expected_depth_fwd(int64_t P, const float *render4, const float *alphas, float *out4, bds_stream_t stream);
+int bds_expected_depth_bwd(int64_t P, int channels, int expected_depth, const float *render4, const float *alphas, const float *v_out,
+                           const float *v_alphas_in, float *v_render4, float *v_alphas, bds_stream_t stream);
 int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
                    const float *opacities, const int32_t *radii /* [n entries] or NULL */, float *records, bds_stream_t stream);
 /* Splat records of the fused view with the SH colour evaluated on the way (vanilla.py:383-389: SH of normalise(means - cam_pos), + 0.5,
@@ -334,6 +344,14 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
 int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
                          const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs, const int32_t *row_map,
                          int accumulate, bds_stream_t stream);
+/* Backward of gsplat's rasterization() over the visible entries, C = 1 (models/trainers/base.py:393-408: the trainer passes ACTIVATED
+ * scales / opacities and post-activation colours [N,3]): what bds_project_view_bwd_list does, with the gradients of the activated
+ * scales and opacities returned as they are and the colour gradient (record channels 0-2) scattered to v_colors [N,3] (may be
+ * NULL).  Store mode: the caller zero-fills the dense arrays; rows of culled Gaussians stay zero. */
+int bds_project_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats, const float *scales,
+                         const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
+                         const float *v_records, float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *v_colors,
+                         float *v_viewmat_slots, float *grad2d, float *absgrad2d, bds_stream_t stream);
 int bds_project_view_bwd_list(int64_t n_list, const int32_t *ids, const float *means, const float *quats, const float *scales,
                               const float *opacities, const float *viewmat, const float *K, int W, int H, float eps2d,
                               const float *v_records, float *v_means, float *v_quats, float *v_log_scales, float *v_logits,

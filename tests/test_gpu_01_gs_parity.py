@@ -513,3 +513,34 @@ def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C)
             shift += 1
         assert bool(((w >> shift)[:-1] >= (w >> shift)[1:]).all())           # longest first (bucket granularity)
         first += cnt
+
+
+@pytest.mark.parametrize("mode,radius_clip", [("RGB+ED", 0.0), ("RGB", 4.0)])
+def test_one_view_node_equals_operator_chain(ops, mode, radius_clip, monkeypatch):
+    """rasterization() for one camera runs as ONE autograd node over compact lists (rendering._RasterizeView) -- the reference's two
+    call patterns (trainers/base.py:393-408: RGB+ED; :811-826: RGB, radius_clip = 4) -- and must equal the chain of individual
+    operators (BDS_API_FUSED=0): images, every input gradient incl. the camera pose, .absgrad and the retained .grad of
+    meta["means2d"], and the lazily materialised gsplat lists."""
+    import bilateral_driving_amd.rendering as R
+    sc = make_scene(3000, 320, 200, seed=5)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(R, "_ONE_VIEW_NODE", fused)
+        p = {k: sc[k].cuda().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+        vm = sc["viewmats"].cuda().requires_grad_(True)
+        r, a, meta = R.rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, sc["Ks"].cuda(), 320, 200,
+                                     packed=False, absgrad=True, render_mode=mode, radius_clip=radius_clip, near_plane=0.1)
+        meta["means2d"].retain_grad()
+        g = torch.Generator().manual_seed(3)
+        wt, wa = torch.randn(r.shape, generator=g).cuda(), torch.randn(a.shape, generator=g).cuda()
+        ((r * wt).sum() + (a * wa).sum() + 0.1 * (meta["means2d"] ** 2).sum() * 1e-4).backward()     # incl. a term ON meta["means2d"]
+        res[fused] = (r.detach(), a.detach(), {k: v.grad.clone() for k, v in p.items()}, vm.grad.clone(), meta["means2d"].absgrad.clone(),
+                      meta["means2d"].grad.clone(), meta["radii"].clone(), meta["flatten_ids"].clone(), meta["isect_offsets"].clone())
+    a_, b_ = res[False], res[True]
+    assert torch.equal(a_[6], b_[6]) and torch.equal(a_[7], b_[7]) and torch.equal(a_[8], b_[8])
+    assert float((a_[0] - b_[0]).abs().max()) < 2e-6 and float((a_[1] - b_[1]).abs().max()) < 2e-6
+    for k in a_[2]:
+        assert rel_err(b_[2][k], a_[2][k]) < 2e-4, k       # (float atomics in the compositor backward: the order of the sums varies)
+    assert rel_err(b_[3], a_[3]) < 2e-4 and rel_err(b_[4], a_[4]) < 2e-4
+    # the retained gradient of meta["means2d"]: the compositor's part + the term sent into it
+    assert rel_err(b_[5], a_[5]) < 2e-4

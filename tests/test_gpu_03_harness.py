@@ -36,7 +36,7 @@ def test_harness_view_matches_rasterization_api(ops):
         p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         grids = [g.clone().requires_grad_(True) for g in grids0]
         if mode in ("fused", "staged"):
-            Hn.FUSED = mode == "fused"
+            Hn.FUSED = True if mode == "fused" else "ops"      # "ops": the chain of individual operators
             try:
                 out = Hn.render_view(p, cam, grids, 1, sky)
             finally:
