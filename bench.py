@@ -48,6 +48,29 @@ WORKLOADS = {
 }
 
 
+def _physical_cores() -> int:
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo; psutil or half the logical count as fall-backs)."""
+    try:
+        seen, pkg = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((pkg, line.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +87,8 @@ def parse():
     ap.add_argument("--cpu-sample-gaussians", type=int, default=100000)
     ap.add_argument("--cpu-sample-width", type=int, default=960)
     ap.add_argument("--cpu-sample-height", type=int, default=540)
-    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--cpu-threads", type=int, default=_physical_cores(),
+                    help="threads of the CPU baseline: the host's PHYSICAL cores by default (SURVEY.md 8d), stated in the line")
     ap.add_argument("--cpu-timeout", type=float, default=170.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -150,7 +174,7 @@ def cpu_baseline_worker(args):
         "value": 1.0 / dt, "unit": "iters/sec", "cores": threads, "kind": "port",
         "sample": f"{sample[0]} Gaussians, one {sample[1]}x{sample[2]} view, SH3 + 3-level bilateral grid, fwd+bwd, fp32 "
                   f"pure-PyTorch CPU port (oracle/), best of 3; NOT the GPU workload size "
-                  f"(host has {os.cpu_count()} logical CPUs, {threads} torch threads used)",
+                  f"(host: {_physical_cores()} physical cores / {os.cpu_count()} logical CPUs; {threads} torch threads used)",
         "c1_value": 1.0 / t_c1, "c1_sample": "configs[0]: 1000 Gaussians, one 256x256 view, same pipeline, best of 3",
     }))
 

@@ -11,8 +11,10 @@ namespace bds {
 
 constexpr int kOptBlock = 256;
 
-template <bool kVec>
-__global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *__restrict__ p, const float *__restrict__ g,
+// kClear: the gradient is cleared as it is consumed ("consume and clear": the next step's backward accumulates into zeros without a
+// clearing pass of its own -- 4 more bytes written per element here against a row-wise clear launch per view there)
+template <bool kVec, bool kClear>
+__global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *__restrict__ p, float *__restrict__ g,
                                                              float *__restrict__ m, float *__restrict__ v, float step_size,
                                                              float one_minus_b1, float b2, float one_minus_b2,
                                                              float bc2_sqrt, float eps, float weight_decay) {
@@ -29,19 +31,24 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *
   if (kVec) {
     const int64_t n4 = n / 4;
     float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
-    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float4 *g4 = reinterpret_cast<float4 *>(g);
     for (int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4; i += stride) {
       float4 pp = p4[i], mm = m4[i], vv = v4[i];
       const float4 gg = g4[i];
       upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
       p4[i] = pp; m4[i] = mm; v4[i] = vv;
+      if (kClear) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
       const int64_t i = n4 * 4 + threadIdx.x;
       upd(p[i], g[i], m[i], v[i]);
+      if (kClear) g[i] = 0.f;
     }
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
+    for (int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n; i += stride) {
+      upd(p[i], g[i], m[i], v[i]);
+      if (kClear) g[i] = 0.f;
+    }
   }
 }
 
@@ -49,8 +56,8 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *
 
 using namespace bds;
 
-extern "C" int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
-                             double beta1, double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream) {
+static int adam_step_impl(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1, double beta2,
+                          double eps, double weight_decay, int64_t step, bool clear, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && step >= 1);
   if (n == 0) return BDS_OK;
   BDS_REQUIRE(param && grad && exp_avg && exp_avg_sq);
@@ -63,14 +70,23 @@ extern "C" int bds_adam_step(int64_t n, float *param, const float *grad, float *
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipStream_t st = as_stream(stream);
-  if (vec)
-    hipLaunchKernelGGL((adam_step_kernel<true>), dim3((unsigned)blocks), dim3(kOptBlock), 0, st, n, param, grad, exp_avg, exp_avg_sq,
-                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, (float)weight_decay);
-  else
-    hipLaunchKernelGGL((adam_step_kernel<false>), dim3((unsigned)blocks), dim3(kOptBlock), 0, st, n, param, grad, exp_avg, exp_avg_sq,
-                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, (float)weight_decay);
+#define BDS_ADAM(V, C)                                                                                                                   \
+  hipLaunchKernelGGL((adam_step_kernel<V, C>), dim3((unsigned)blocks), dim3(kOptBlock), 0, st, n, param, grad, exp_avg, exp_avg_sq, step_size, \
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, (float)weight_decay)
+  if (vec) { if (clear) BDS_ADAM(true, true); else BDS_ADAM(true, false); }
+  else     { if (clear) BDS_ADAM(false, true); else BDS_ADAM(false, false); }
+#undef BDS_ADAM
   BDS_LAUNCH_CHECK();
   return BDS_OK;
+}
+
+extern "C" int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream) {
+  return adam_step_impl(n, param, const_cast<float *>(grad), exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, false, stream);
+}
+extern "C" int bds_adam_step_consume(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1,
+                                     double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream) {
+  return adam_step_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, true, stream);
 }
 
 // ---- per-step densification statistics --------------------------------------------------------------------------------

@@ -339,14 +339,17 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
     const int64_t g = ids[r0 + tid];
     s_g[tid] = (int32_t)g;
     if (g >= 0) {   // negative ids: padding of a fixed-capacity list
-      for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
-      for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
-      v_logits[g] = 0.f;
+      if (v_means) {   // (null: only the screen-space arrays -- the parameter gradients are cleared by their consumer, bds_adam_step_consume)
+        for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
+        for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
+        v_logits[g] = 0.f;
+      }
       // (the view's persistent screen-space gradient arrays: the list-driven projection backward STORES the visible rows)
       if (grad2d) grad2d[g] = make_float2(0.f, 0.f);
       if (absgrad2d) absgrad2d[g] = make_float2(0.f, 0.f);
     }
   }
+  if (!v_sh) return;
   __syncthreads();
   const int row = K * 3;
   if (kVec) {
@@ -579,7 +582,8 @@ static int view_grads_clear_list_impl(int64_t n_list, const uint64_t *n_dev, con
                                       float *absgrad2d = nullptr) {
   BDS_REQUIRE(n_list >= 0 && K >= 1 && K <= 16);
   if (n_list == 0) return BDS_OK;
-  BDS_REQUIRE(ids && v_means && v_quats && v_log_scales && v_logits && v_sh);
+  const bool params = v_means || v_quats || v_log_scales || v_logits || v_sh;    // all five, or none (then the screen-space arrays only)
+  BDS_REQUIRE(ids && (params ? (v_means && v_quats && v_log_scales && v_logits && v_sh) : (grad2d || absgrad2d)));
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(grad2d) & 7u) == 0 && (reinterpret_cast<uintptr_t>(absgrad2d) & 7u) == 0);
   float2 *g2 = reinterpret_cast<float2 *>(grad2d), *a2 = reinterpret_cast<float2 *>(absgrad2d);
   const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);

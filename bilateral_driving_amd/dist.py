@@ -346,12 +346,14 @@ class FrameExchange:
             self._retire()
         b = self._free.pop()
         buf = self._bufs[b]
+        assert buf.numel() == self.cap * self.row_floats, "exchange buffers and capacity out of step"
         views = self._views_of(buf)
-        row_map = torch.empty(self.N, device=dev, dtype=torch.int32)
-        ids = torch.empty(self.cap, device=dev, dtype=torch.int32)
-        cnt = torch.zeros(1, dtype=torch.int64).pin_memory()
-        wsb = lib.bds_union_slots_workspace_bytes(self.N)
-        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        # slot map, id list, count word and workspace: one set per rotating buffer, made with it (a pinned allocation and a device
+        # pointer look-up per view would undo what the two-launch form saves); the count words stay alive with the exchange
+        row_map, ids, cnt_all, ws = self._scratch[b]
+        wsb = ws.numel()
+        k = self._uses[b] = (self._uses[b] + 1) % cnt_all.numel()     # (a buffer serves several views of a frame: one count word each)
+        cnt = cnt_all[k:k + 1]
         L.check(lib.bds_union_slots(self.N, L.ptr(mask), self.cap, self.K, L.ptr(row_map), L.ptr(ids), L.ptr(views["means"]),
                                     L.ptr(views["quats"]), L.ptr(views["log_scales"]), L.ptr(views["opacity_logits"]), L.ptr(views["sh"]),
                                     L.ptr(ws), wsb, None, cnt.data_ptr(), L.stream()), "bds_union_slots")
@@ -370,7 +372,10 @@ class FrameExchange:
         self._max_union = max([self._max_union] + counts)
         while self._pending:
             self._retire()
-        self.cap = self._wanted_cap()
+        cap = self._wanted_cap()
+        if cap != self.cap:       # the eager path's rotating buffers (and their per-buffer scratch) have the old size: made again on use
+            self._bufs, self._free, self._scratch, self._uses = [], [], [], []
+        self.cap = cap
         dev = self.arena["means"].device
         V = len(counts)
         self._sbuf = [torch.zeros(self.cap * self.row_floats, device=dev, dtype=torch.float32) for _ in range(V)]
@@ -496,6 +501,14 @@ class FrameExchange:
         dev = self.arena["means"].device
         self._bufs = [torch.zeros(self.cap * self.row_floats, device=dev, dtype=torch.float32) for _ in range(self.n_buffers)]
         self._free = list(range(self.n_buffers))
+        self._scratch = []
+        if dev.type == "cuda":
+            from . import _lib as L
+            wsb = L.lib().bds_union_slots_workspace_bytes(self.N)
+            self._scratch = [(torch.empty(self.N, device=dev, dtype=torch.int32), torch.empty(self.cap, device=dev, dtype=torch.int32),
+                              torch.zeros(64, dtype=torch.int64).pin_memory(), torch.empty(wsb, device=dev, dtype=torch.uint8))
+                             for _ in range(self.n_buffers)]
+        self._uses = [0] * self.n_buffers
 
     def _views_of(self, buf: Tensor) -> Dict[str, Tensor]:
         c, K = self.cap, self.K

@@ -77,7 +77,7 @@ class FrameGraph:
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, exchange=None, dynamic: bool = False,
-                 calib_cams: Optional[Sequence[Hn.Camera]] = None):
+                 calib_cams: Optional[Sequence[Hn.Camera]] = None, clear_grads: bool = True):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -86,7 +86,10 @@ class FrameGraph:
         view's backward (measured on MI355X, 2 M Gaussians / six 1080p views: one stream 782 it/s, two 885; a forward reads only
         parameters and writes its own buffers).
         ``dynamic``: replayable views (module docstring); ``calib_cams``: the cameras the capacities are sized over (default: ``cams``).
-        ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU)."""
+        ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU).
+        ``clear_grads=False``: the begin stage does not clear the parameters' gradient rows (221 us per six-view frame at 2 M
+        Gaussians) nor the dense tail -- the caller's optimizer does, as it consumes them (``optim.FusedAdam(consume_grads=True)``
+        over EVERY parameter of the frame); a frame that ``step()`` reported invalid is cleared densely before the next one."""
         assert sorted(params.keys()) == sorted(ROW_NAMES), "params: means, quats, log_scales, opacity_logits, sh"
         self.params = {k: params[k] for k in ROW_NAMES}
         self.grids = list(grids)
@@ -94,6 +97,8 @@ class FrameGraph:
         assert len(skies) == self.V and len(targets) == self.V
         self.dev = self.params["means"].device
         self.dynamic = bool(dynamic)
+        self.clear_grads = bool(clear_grads) or exchange is not None
+        self._stale = False              # clear_grads=False: the last frame was invalid, nobody consumed (and cleared) its gradients
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         if self.dynamic:       # every slot owns its inputs at fixed addresses; set_view() rewrites them
             self.cams = [Hn.Camera(c.viewmat.detach().clone().requires_grad_(c.viewmat.requires_grad), c.K.detach().clone(), c.width, c.height,
@@ -118,6 +123,7 @@ class FrameGraph:
         self.N, self.K = self.params["means"].shape[0], self.params["sh"].shape[1]
         self.names = list(ROW_NAMES) + [f"grid{i}" for i in range(len(self.grids))]
         self.fx = exchange if (exchange is not None and exchange.active) else None
+        assert not (self.dynamic and self.fx is not None), "replayable views with an exchange: not built (the reference's loop is one GPU)"
         if exchange is not None:
             by_name = dict(self.params, **{f"grid{i}": g for i, g in enumerate(self.grids)})
             assert not extra_params and sorted(exchange.names) == sorted(self.names), "the exchange covers exactly params + grids"
@@ -275,11 +281,10 @@ class FrameGraph:
             ws = self.prep_ws[v]
             ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
             g2 = self.g2d[v]      # (the view's persistent screen-space gradient arrays: the same rows, no dense fill per view)
-            L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K,
-                                                      L.ptr(a["means"]), L.ptr(a["quats"]), L.ptr(a["log_scales"]),
-                                                      L.ptr(a["opacity_logits"]), L.ptr(a["sh"]), L.ptr(g2[0]), L.ptr(g2[1]), st),
-                    "bds_view_grads_clear_list_dev")
-        if self._tail.numel() and tail:
+            pa = [L.ptr(a[k]) if self.clear_grads else None for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+            L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K, *pa,
+                                                      L.ptr(g2[0]), L.ptr(g2[1]), st), "bds_view_grads_clear_list_dev")
+        if self._tail.numel() and tail and self.clear_grads:
             self._tail.zero_()
 
     def _frame_begin(self) -> None:
@@ -334,6 +339,8 @@ class FrameGraph:
             self._reset_static_grads()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize()
+        if not self.clear_grads:      # (the warm-up frame's gradients: nobody will consume them)
+            self.flat.flat.zero_()
         self._check_counts(raise_on_overflow=True)
         self._point_grads_at_flat()
         # graphs that share a pool are replayed in capture order on ONE stream; the forwards of the overlapped form run on their own
@@ -398,6 +405,9 @@ class FrameGraph:
         (measurement)."""
         if self._reprovision:       # capacities that came close to their limit in the last (valid, consumed) frame
             self.capture()
+        if self._stale:             # clear_grads=False and nobody consumed the invalid frame's gradients
+            self.flat.flat.zero_()
+            self._stale = False
         fx = self.fx
         main = torch.cuda.current_stream(self.dev)
         self._frame_begin()
@@ -502,6 +512,7 @@ class FrameGraph:
         overflowed, wants_more = self._agree(not ok, bool(grow) or near)
         if overflowed:
             self.capture()
+            self._stale = not self.clear_grads
             return False
         if wants_more:
             for v in grow:

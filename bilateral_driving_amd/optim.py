@@ -12,7 +12,11 @@ from . import _lib as L
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 consume_grads: bool = False):
+        """``consume_grads``: every gradient is cleared by the pass that reads it (bds_adam_step_consume) -- for loops whose backward
+        accumulates into persistent ``.grad`` buffers (``graph_view.FrameGraph(clear_grads=False)``): no ``zero_grad()`` pass."""
+        self.consume_grads = bool(consume_grads)
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -44,8 +48,12 @@ class FusedAdam(torch.optim.Optimizer):
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous() and m.shape == p.shape and v.shape == p.shape):
                     raise RuntimeError("optimizer state does not match its parameter (after densification, re-create both)")
-                L.check(lib.bds_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), float(group["lr"]), float(b1), float(b2),
-                                          float(group["eps"]), float(group["weight_decay"]), int(state["step"]), st), "bds_adam_step")
+                consume = self.consume_grads and g.data_ptr() == p.grad.data_ptr()     # (clearing a contiguous COPY would clear nothing)
+                fn = lib.bds_adam_step_consume if consume else lib.bds_adam_step
+                L.check(fn(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), float(group["lr"]), float(b1), float(b2),
+                           float(group["eps"]), float(group["weight_decay"]), int(state["step"]), st), "bds_adam_step")
+                if self.consume_grads and not consume:
+                    p.grad.zero_()
         return loss
 
 

@@ -443,7 +443,9 @@ int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, con
                                   float *v_log_scales, float *v_logits, float *v_viewmat_slots, float *grad2d, float *absgrad2d,
                                   const int32_t *row_map, int accumulate, bds_stream_t stream);
 /* (grad2d / absgrad2d [N,2], optional: the same rows of a view's PERSISTENT screen-space gradient arrays are cleared as well -- the
- * list-driven projection backward stores the visible rows, so a buffer cleared by the previous visit's list needs no dense fill) */
+ * list-driven projection backward stores the visible rows, so a buffer cleared by the previous visit's list needs no dense fill.
+ * The five parameter-gradient pointers may ALL be NULL: only the screen-space arrays are cleared then -- a loop whose optimizer
+ * clears the gradients as it consumes them, bds_adam_step_consume) */
 int bds_view_grads_clear_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, float *v_means,
                                   float *v_quats, float *v_log_scales, float *v_logits, float *v_sh, float *grad2d, float *absgrad2d,
                                   bds_stream_t stream);
@@ -525,6 +527,11 @@ int bds_pixel_loss_bwd(int64_t P, const float *rgb, const float *pixels, const f
  * floats): 1 - beta and the bias corrections are formed in double and rounded to fp32 once, as torch does. */
 int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream);
+/* The same, and the gradient is cleared as it is read ("consume and clear"): a training loop whose backward ACCUMULATES into
+ * persistent gradient buffers (dist.FlatGradients / graph_view.FrameGraph) then needs no clearing pass before the next step --
+ * what optimizer.zero_grad() (tools/train.py:266) costs the reference as one more pass over every gradient. */
+int bds_adam_step_consume(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream);
 
 /* Per-step densification statistics of one set of Gaussians in one launch (models/trainers/base.py:279-297 +
  * models/gaussians/vanilla.py:163-191): grad2d [N,2] is info["means2d"].absgrad (or .grad) BEFORE the trainer's

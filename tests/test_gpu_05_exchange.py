@@ -160,9 +160,11 @@ def _worker(rank, world, port, q, graph=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_two_ranks_frame_exchange_equals_sequential_sum(graph):
-    world = 2
+@pytest.mark.parametrize("graph,world", [(False, 2), (True, 2), (True, 4), (True, 8)])
+def test_ranks_sharing_the_gpu_frame_exchange_equals_sequential_sum(graph, world):
+    """2 / 4 / 8 ranks (one process each, all on cuda:0, gloo between them) through the eager frame loop and through the graph frames
+    (the collectives between a view's graphs): every rank ends every frame with the sum over all ranks' views; the union of the
+    visible sets grows with the rank count (more of the drive is seen) and the exchange capacity follows it."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -174,9 +176,12 @@ def test_two_ranks_frame_exchange_equals_sequential_sum(graph):
         p.join(timeout=120)
         assert p.exitcode == 0
     Hn, cams0, base, grids0, sky, target = _setup("cuda")
-    cams1 = Hn.ring_cameras(W, H, yaws_deg=YAWS, device="cuda", origin=(1.5, 0.0, 0.0))
-    ref = _dense_reference(Hn, [cams0, cams1], base, grids0, sky, target).cpu()
+    rigs = [Hn.ring_cameras(W, H, yaws_deg=YAWS, device="cuda", origin=(1.5 * r, 0.0, 0.0)) for r in range(world)]
+    ref = _dense_reference(Hn, rigs, base, grids0, sky, target).cpu()
     for r in range(world):
         for o in res[r][1]:
             assert float((torch.from_numpy(o) - ref).norm() / ref.norm()) < 1e-3          # 1e-3 rel (atomics order)
-    assert res[0][2] == res[1][2] and (res[0][1][-1] == res[1][1][-1]).all()     # replicas hold identical reduced gradients
+    for r in range(1, world):     # replicas: same capacity, identical reduced gradients, same payload
+        assert res[r][2] == res[0][2] and (res[r][1][-1] == res[0][1][-1]).all() and res[r][3] == res[0][3]
+    print(f"[exchange] world {world}: capacity {res[0][2]} rows of {N} ({res[0][2] / N:.0%}), {res[0][3]} bytes all-reduced per rank and frame "
+          f"(dense: {N * 59 * 4 * len(YAWS)})")

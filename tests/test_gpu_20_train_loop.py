@@ -96,3 +96,53 @@ def test_short_training_run_converges_and_densifies():
     assert p1 > p0 + 4.0, (p0, p1)
     assert len(set(sizes + [n0])) > 1, sizes                     # densification changed the number of Gaussians
     assert all(torch.isfinite(getattr(m, a)).all() for a in names) and torch.isfinite(sky.base).all()
+
+
+def test_replayed_training_loop_with_random_views_converges():
+    """The reference's loop shape (tools/train.py:250-283: a random image per step) on ONE captured view: graph_view.FrameGraph(
+    dynamic=True) replays it with another camera / target / image index every step, FusedAdam(consume_grads=True) clears every
+    gradient as it consumes it (FrameGraph(clear_grads=False): no clearing pass), step() returns the frame's validity.  The
+    optimisation has to make progress and every gradient buffer has to be zero behind each optimizer step."""
+    import math
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.graph_view import FrameGraph
+    from bilateral_driving_amd.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    W, H, N_GT, n_img = 320, 192, 20_000, 6
+    cams = Hn.ring_cameras(W, H, device=dev)
+    gt = Hn.synthetic_scene(N_GT, seed=1, device=dev)
+    gt_grids = Hn.make_grids(n_img, seed=3, device=dev)
+    sky = torch.rand(H, W, 3, device=dev)
+    with torch.no_grad():
+        targets = [Hn.render_view(gt, c, gt_grids, v, sky)["rgb"].clone() for v, c in enumerate(cams)]
+    sel = torch.randperm(N_GT, device=dev)[: N_GT // 2]
+    p = {"means": gt["means"][sel] + 0.05 * torch.randn(len(sel), 3, device=dev), "quats": gt["quats"][sel].clone(),
+         "log_scales": gt["log_scales"][sel] + 0.2, "opacity_logits": torch.full((len(sel),), -1.0, device=dev),
+         "sh": torch.zeros(len(sel), 16, 3, device=dev)}
+    p = {k: v.contiguous().requires_grad_(True) for k, v in p.items()}
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(n_img, seed=0, device=dev)]
+    lrs = dict(means=1.6e-3, quats=1e-3, log_scales=5e-3, opacity_logits=5e-2, sh=2.5e-3)
+    groups = [{"params": [p[k]], "lr": lr, "eps": 1e-15} for k, lr in lrs.items()] + [{"params": [g], "lr": 2e-3, "eps": 1e-15} for g in grids]
+    opt = FusedAdam(groups, lr=0.0, eps=1e-15, consume_grads=True)
+    frame = FrameGraph(p, [cams[0]], grids, [sky], [targets[0]], img_indices=[0], dynamic=True, calib_cams=cams, clear_grads=False)
+
+    def psnr():
+        with torch.no_grad():
+            mse = sum(float(((Hn.render_view(p, c, grids, v, sky)["rgb"] - targets[v]) ** 2).mean()) for v, c in enumerate(cams))
+        return -10 * math.log10(mse / len(cams))
+
+    p0, n_cap, n_valid = psnr(), frame.n_captures, 0
+    for step in range(150):
+        v = int(torch.randint(0, len(cams), (1,)))
+        frame.set_view(0, cams[v], targets[v], sky, v)
+        if frame.step():
+            n_valid += 1
+            assert all(t.grad.data_ptr() == frame.arena[k].data_ptr() for k, t in p.items())
+            opt.step()
+            if step % 50 == 0:
+                assert float(frame.flat.flat.abs().max()) == 0.0      # consumed AND cleared
+    p1 = psnr()
+    print(f"[replayed loop] PSNR {p0:.2f} -> {p1:.2f} dB over {n_valid} valid steps, {frame.n_captures - n_cap} re-captures")
+    assert n_valid >= 140 and p1 > p0 + 3.0, (p0, p1, n_valid)
+    assert all(torch.isfinite(t).all() for t in p.values())
