@@ -47,7 +47,7 @@ _SYNC: Dict[torch.device, list] = {}
 def _host_sync_objects(dev):
     """(page-locked int64[3], event) used to read the two list counts back without draining the stream.  A front OWNS its pair from
     ``_front_begin`` until ``_front_finish`` has read the counts (``_release_sync_objects``): any number of fronts may be in flight
-    (``fused_view_begin`` for every camera of a rig up front, ``render_classes`` interleaved with pipelined fronts)."""
+    (``render_classes`` next to a training view)."""
     free = _SYNC.setdefault(dev, [])
     if free:
         return free.pop()
@@ -131,31 +131,15 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
-def _front_signature(cfg: dict, means, quats, log_scales, logits, sh, viewmat):
-    t = (means, quats, log_scales, logits, sh, viewmat, cfg["K"], cfg["cam_pos"])
-    return (tuple((x.data_ptr(), x._version, tuple(x.shape)) for x in t), cfg["width"], cfg["height"], cfg["sh_degree"], cfg["near_plane"],
-            cfg["far_plane"], cfg["radius_clip"], cfg["eps2d"], cfg["tile_cull"], cfg.get("list_tile", LIST_TILE))
-
-
 def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before_wait=None) -> _Front:
     """``before_wait`` (optional callable): host work of the caller that does not depend on the list counts (allocations, level
-    structs); it runs while the GPU is still producing them, so that after the one host wait of a view only launches remain.
-    ``cfg["front"]``: a state returned by ``fused_view_begin`` for exactly these inputs (its kernels are already enqueued)."""
-    state = cfg.get("front")
-    if state is not None:
-        assert state.signature == _front_signature(cfg, means, quats, log_scales, logits, sh, viewmat), (
-            "fused_view(front=...): the front was begun for other inputs, or a parameter changed since")
-        assert not state.used, "a front can be finished once"
-    else:
-        state = _front_begin(cfg, means, quats, log_scales, logits, sh, viewmat)
-    state.used = True
-    return _front_finish(state, before_wait)
+    structs); it runs while the GPU is still producing them, so that after the one host wait of a view only launches remain."""
+    return _front_finish(_front_begin(cfg, means, quats, log_scales, logits, sh, viewmat), before_wait)
 
 
 def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Front:
     """First half of a view's forward: activations + projection, visibility compaction, depth order, tile counts (whose totals travel
     to the host asynchronously) and the SH colours.  Nothing here depends on the host."""
-    signature = _front_signature(cfg, means, quats, log_scales, logits, sh, viewmat)
     L.require_gpu(means, quats, log_scales, logits, sh, viewmat)
     lib, st = L.lib(), L.stream()
     dev = means.device
@@ -234,7 +218,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     rec_buf = _empty((vcap, L.SPLAT_RECORD_FLOATS), dev) if vcap else None
     off = lib.bds_isect_visible_ids_offset(1, N)
     f = _Front()
-    f.signature, f.used, f.cfg = signature, False, cfg
+    f.cfg = cfg
     f.means, f.quats, f.log_scales, f.sh, f.viewmat, f.cam_pos = means, quats, log_scales, sh, viewmat, cam_pos
     f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
     f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
@@ -419,10 +403,6 @@ class _FusedView(torch.autograd.Function):
                 ctx.tail = v_rec_all[f.n_vis:] if n_pose + ctx.loss_rows else None
                 ctx.tail_pose = v_rec_all[f.n_vis:f.n_vis + n_pose] if want_pose else None
         ctx.v_rec_all = v_rec_all
-        early = bool(cfg.get("yield_after_front"))
-        if early:                          # (the generator's one stop: behind the front, or -- default -- behind the compositor)
-            yield radii
-            lib, st = L.lib(), L.stream()
         # device-count form with a backward to follow: the compositor leaves the schedule keys of its own backward (one launch less)
         sched_buf = None
         if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
@@ -446,9 +426,8 @@ class _FusedView(torch.autograd.Function):
                 ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
             if ctx.g2d is None:
                 ctx.g2d = torch.zeros(2, N, 2, device=dev, dtype=torch.float32)
-        if not early:
-            yield radii
-            lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
+        yield radii
+        lib, st = L.lib(), L.stream()    # (the second half may be enqueued on another stream)
         # expected depth + clamp + sky blend + bilateral transform, straight from the 4-channel render
         tl = cfg.get("train_loss")     # train_view: the L1 + TV loss (value and gradients) rides on the full-resolution launch
         ctx.train_loss = None
@@ -612,14 +591,7 @@ class _FusedView(torch.autograd.Function):
             return t.view(t.shape)  # a fresh tensor object (no other owner): autograd adopts it as .grad without cloning
 
         v_sh = out_like("sh", sh)
-        # the SH and the projection backward read the same gradient records and write different arrays: with `tail_fork_stream` (a
-        # torch stream; graph_view) the SH half is forked onto it and joined behind the projection half -- two HBM / latency-bound
-        # kernels next to each other instead of one after the other
-        fork = cfg.get("tail_fork_stream")
-        cur_stream = torch.cuda.current_stream(dev)
-        if fork is not None:
-            fork.wait_stream(cur_stream)
-        with (torch.cuda.stream(fork) if fork is not None else contextlib.nullcontext()), L.timed("sh_bwd"):
+        with L.timed("sh_bwd"):
             st = L.stream()
             if dev_counts is not None:
                 L.check(lib.bds_sh_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos),
@@ -652,8 +624,6 @@ class _FusedView(torch.autograd.Function):
                                                       L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
                                                       L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
                                                       L.ptr(row_map), int(rows == 2), st), "bds_project_view_bwd_list")
-        if fork is not None:
-            cur_stream.wait_stream(fork)
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)
             carrier.grad = g2d[0:1]
@@ -671,7 +641,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sky: Tensor, factors: Sequence[int], sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                radius_clip: float = 0.0, eps2d: float = 0.3, tile_cull: bool = True,
                grad_arena: Optional[Dict[str, Tensor]] = None, cam_pos: Optional[Tensor] = None,
-               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None, front=None,
+               img_idx: Optional[int] = None, arena_rows: int = 0, grad_sink=None, list_tile: Optional[int] = None,
                caps: Optional[ListCapacity] = None, prep_ws: Optional[Tensor] = None):
     """params: means [N,3], quats [N,4] (raw), log_scales [N,3], opacity_logits [N], sh [N,16,3];
     grids: per level [1,12,L,gy,gx] (the current image's grids), or -- with ``img_idx`` -- the full parameters
@@ -692,8 +662,6 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     ``grad_sink`` (multi-GPU, ``dist.FrameExchange``): an object whose ``targets(visible_ids)`` is called inside the backward and
     returns (compact buffers by name, row_map [N] i32); the visible rows are stored at ``row_map[g]`` of those buffers and no
     gradient is returned for the five per-Gaussian parameters (the sink adds the reduced rows to their ``.grad``).
-    ``front``: the object ``fused_view_begin`` returned for the same parameters / camera: that half of the forward is already
-    enqueued (software pipelining of the one host wait per view, see there).
     ``caps`` (``ListCapacity``): the device-count form -- no host wait at all; the lists are built into buffers of these capacities
     and every kernel takes its counts from device memory (what ``graph_view.ViewGraph`` captures in a hipGraph).  ``info["n_isects"]``
     / ``["n_visible"]`` are then the CAPACITIES (the lists' tensors have those lengths; entries beyond the counts are undefined);
@@ -704,7 +672,7 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sh_degree=int(sh_degree), near_plane=float(near_plane), far_plane=float(far_plane), radius_clip=float(radius_clip),
                eps2d=float(eps2d), tile_cull=bool(tile_cull), grad_arena=grad_arena, grad_sink=grad_sink,
                img_idx=None if img_idx is None else int(img_idx), arena_rows=int(arena_rows),
-               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws)
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     # in-place grid gradients only when the arena entries ARE the grids' .grad right now (dist.FrameExchange.begin_frame sets that up)
     if grad_arena is not None and int(arena_rows) >= 1 and grad_sink is None:
@@ -722,34 +690,6 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
 
 
 @torch.no_grad()
-def fused_view_begin(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, sh_degree: int = 3,
-                     near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
-                     tile_cull: bool = True, cam_pos: Optional[Tensor] = None, list_tile: Optional[int] = None):
-    """Enqueue the first half of a view's forward (projection, visibility compaction, depth order, tile counts, SH colours) and return
-    a handle for ``fused_view(..., front=handle)`` / ``train_view(..., front=handle)``.
-
-    A view has ONE host wait (the two list counts, as in gsplat).  Called for view v+1 BEFORE ``loss.backward()`` of view v is
-    enqueued, these kernels run ahead of that backward, the counts are on the host long before they are asked for, and the GPU never
-    idles behind the wait or behind the launches that follow it:
-
-        front = fused_view_begin(params, cams[0].viewmat, ...)
-        for v, cam in enumerate(cams):
-            out = fused_view(params, cam.viewmat, ..., front=front)
-            loss = ...
-            front = fused_view_begin(params, cams[v + 1].viewmat, ...) if v + 1 < len(cams) else None
-            loss.backward()
-
-    The parameters must not change between the two calls (checked through the tensors' version counters): begin the first view of a
-    frame after the optimizer step.  Same keyword arguments, same values as the ``fused_view`` call that consumes the handle."""
-    if cam_pos is None:
-        cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
-    cfg = dict(width=int(width), height=int(height), K=K, cam_pos=cam_pos.detach(), sh_degree=int(sh_degree), near_plane=float(near_plane),
-               far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d), tile_cull=bool(tile_cull),
-               list_tile=int(LIST_TILE if list_tile is None else list_tile))
-    return _front_begin(cfg, params["means"].detach(), params["quats"].detach(), params["log_scales"].detach(),
-                        params["opacity_logits"].detach(), params["sh"].detach(), viewmat.detach())
-
-
 @torch.no_grad()
 def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, masks: Dict[str, Tensor],
                    sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
@@ -837,23 +777,17 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     ``sky.grad``, ``viewmat.grad`` accumulated.  Accepts the keyword arguments of ``fused_view``; ``after_forward(info)`` is called
     between the forward and the backward pass (``dist.FrameExchange.begin_view`` starts its visibility exchange there).
     ``two_phase=True``: only the forward, the loss value and the loss gradient are enqueued; the returned dict carries ``backward``
-    and ``backward_tail``, callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``).  With
-    ``late_image=True`` the first call stops behind the compositor (``forward_steps``): the colour transform and the loss move into
-    ``backward`` (or into ``image``, a callable of their own, when the caller invokes it first) and the dict's image entries appear
-    when it has run; the ``loss`` entry may appear as late as ``backward_tail`` (its
-    value is summed from the loss launch's slotted accumulator there, off the critical chain).  Returns dict(loss, rgb, depth, opacity,
-    info): detached tensors."""
+    and ``backward_tail``, callables that enqueue the rest (once each, in this order: see ``_FusedView.backward_steps``); the
+    ``loss`` entry may appear as late as ``backward_tail`` (its value is summed from the loss launch's slotted accumulator there, off
+    the critical chain).  Returns dict(loss, rgb, depth, opacity, info): detached tensors."""
     from .losses import _PhotometricTV, photometric_tv_train, slots_value
     cam_pos = kwargs.pop("cam_pos", None)
     if cam_pos is None:
         cam_pos = torch.linalg.inv(viewmat.detach())[:3, 3].contiguous()
     grad_arena, arena_rows = kwargs.pop("grad_arena", None), int(kwargs.pop("arena_rows", 0))
     grad_sink = kwargs.pop("grad_sink", None)
-    list_tile, front, caps = kwargs.pop("list_tile", None), kwargs.pop("front", None), kwargs.pop("caps", None)
+    list_tile, caps = kwargs.pop("list_tile", None), kwargs.pop("caps", None)
     prep_ws, two_phase = kwargs.pop("prep_ws", None), bool(kwargs.pop("two_phase", False))
-    late_image = kwargs.pop("late_image", False)      # False | True (stop behind the compositor) | "front" (stop behind the lists)
-    late_image = late_image if two_phase else False
-    tail_fork_stream = kwargs.pop("tail_fork_stream", None)
     g2d_buf = kwargs.pop("g2d_buf", None)    # persistent [2,N,2] screen-space gradient arrays whose stale rows the caller clears
     tail_buf, defer_pose_sum = kwargs.pop("tail_buf", None), bool(kwargs.pop("defer_pose_sum", False))
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
@@ -867,8 +801,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                sh_degree=int(opts["sh_degree"]), near_plane=float(opts["near_plane"]), far_plane=float(opts["far_plane"]),
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
-               list_tile=int(LIST_TILE if list_tile is None else list_tile), front=front, caps=caps, prep_ws=prep_ws,
-               tail_fork_stream=tail_fork_stream, yield_after_front=late_image == "front", g2d_buf=g2d_buf, tail_buf=tail_buf,
+               list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws, g2d_buf=g2d_buf, tail_buf=tail_buf,
                defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
@@ -927,20 +860,10 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     with torch.no_grad():
         fsteps = _FusedView.forward_steps(ctx, cfg, *leaves, sky, viewmat, *gs)
         out["radii"] = next(fsteps)          # (available before the colour transform: the exchange's visibility mask)
-        if not late_image:
-            image_half(fsteps)
+        image_half(fsteps)
 
-    def image():             # late_image: the rest of the forward as a step of its own (graph_view: the lists on a third stream)
+    def backward():          # image half of the view's backward
         with torch.no_grad():
-            if late_image and not state.get("image_done"):
-                state["image_done"] = True
-                image_half(fsteps)
-
-    def backward():          # (late_image: colour transform + loss first, unless ``image`` ran) image half of the view's backward
-        with torch.no_grad():
-            if late_image and not state.get("image_done"):
-                state["image_done"] = True
-                image_half(fsteps)
             state["steps"] = _FusedView.backward_steps(ctx, state["v_rgb"], None, None, None, None)
             next(state["steps"])
 
@@ -963,8 +886,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                 _accumulate(g, a)
                 _accumulate(g, b)
 
-    if two_phase:     # the caller enqueues the halves itself (graph_view: forward | backward | its Gaussian half as hipGraphs on three streams)
-        out["image"], out["backward"], out["backward_tail"] = image, backward, backward_tail
+    if two_phase:     # the caller enqueues the halves itself (graph_view: forward | backward [| its Gaussian half] as hipGraphs)
+        out["backward"], out["backward_tail"] = backward, backward_tail
         return out
     backward()
     backward_tail()

@@ -91,7 +91,7 @@ def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> L
 def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor,
                 factors: Sequence[int] = FACTORS_3, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
                 radius_clip: float = 0.0, eps2d: float = 0.3, grad_arena=None, arena_rows: int = 0, grad_sink=None, list_tile=None,
-                front=None, caps=None, prep_ws=None):
+                caps=None, prep_ws=None):
     """One view's forward (dict(rgb, depth, opacity, rgb_gaussians, info)): a single fused autograd node
     (fused_view.py) by default, or the chain of individual operators (render_view_staged) when FUSED is off."""
     if FUSED == "ops":
@@ -100,18 +100,7 @@ def render_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor],
         return render_view_api(params, cam, grids, img_idx, sky, factors, sh_degree, near_plane, far_plane, radius_clip, eps2d)
     return fused_view(params, cam.viewmat, cam.K, cam.width, cam.height, grids, sky, factors, cam_pos=cam.cam_pos, sh_degree=sh_degree,
                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL,
-                      grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink, list_tile=list_tile, front=front,
-                      caps=caps, prep_ws=prep_ws)
-
-
-def render_view_begin(params: Dict[str, Tensor], cam: Camera, sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10,
-                      radius_clip: float = 0.0, eps2d: float = 0.3, list_tile=None):
-    """First half of ``render_view`` for camera ``cam`` enqueued ahead of time (``fused_view.fused_view_begin``): pass the result as
-    ``render_view(..., front=...)`` / ``train_view(..., front=...)`` with the same arguments."""
-    from .fused_view import fused_view_begin
-    return fused_view_begin(params, cam.viewmat, cam.K, cam.width, cam.height, sh_degree=sh_degree, near_plane=near_plane,
-                            far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_cull=TILE_CULL, cam_pos=cam.cam_pos,
-                            list_tile=list_tile)
+                      grad_arena=grad_arena, img_idx=img_idx, arena_rows=arena_rows, grad_sink=grad_sink, list_tile=list_tile, caps=caps, prep_ws=prep_ws)
 
 
 def train_view(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor, target: Tensor,

@@ -336,49 +336,6 @@ def test_train_view_direct_path_equals_autograd_path(ops):
             assert float((x - y).norm() / x.norm()) < 2e-5
 
 
-def test_pipelined_view_fronts_equal_the_plain_loop(ops):
-    """render_view_begin for view v+1 enqueued in front of view v's backward (the bench's loop): same images, same gradients; a front
-    is tied to its inputs (a parameter update in between is refused) and can be consumed once."""
-    from bilateral_driving_amd import harness as Hn
-    dev = "cuda"
-    W, H, N = 256, 160, 5000
-    cams = Hn.ring_cameras(W, H, yaws_deg=(0.0, 90.0, 180.0), device=dev)
-    base = Hn.synthetic_scene(N, seed=9, device=dev)
-    grids0 = Hn.make_grids(len(cams), device=dev)
-    sky, target = torch.rand(H, W, 3, device=dev), torch.rand(H, W, 3, device=dev)
-    res = {}
-    for mode in ("plain", "pipelined"):
-        p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
-        grids = [g.clone().requires_grad_(True) for g in grids0]
-        imgs = []
-        front = Hn.render_view_begin(p, cams[0]) if mode == "pipelined" else None
-        for v, cam in enumerate(cams):
-            out = Hn.render_view(p, cam, grids, v, sky, front=front)
-            loss = Hn.training_loss(out, target, grids)
-            front = Hn.render_view_begin(p, cams[v + 1]) if mode == "pipelined" and v + 1 < len(cams) else None
-            loss.backward()
-            imgs.append(out["rgb"].detach().clone())
-        res[mode] = (imgs, torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids]).clone())
-    for a, b in zip(res["plain"][0], res["pipelined"][0]):
-        assert torch.equal(a, b)
-    assert float((res["plain"][1] - res["pipelined"][1]).norm() / res["plain"][1].norm()) < 2e-5
-    # a front is bound to the state of its inputs
-    p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
-    grids = [g.clone().requires_grad_(True) for g in grids0]
-    front = Hn.render_view_begin(p, cams[0])
-    with torch.no_grad():
-        p["means"].add_(0.001)                      # e.g. an optimizer step
-    with pytest.raises(AssertionError):
-        Hn.render_view(p, cams[0], grids, 0, sky, front=front)
-    front = Hn.render_view_begin(p, cams[1])
-    with pytest.raises(AssertionError):             # begun for another camera
-        Hn.render_view(p, cams[0], grids, 0, sky, front=front)
-    front = Hn.render_view_begin(p, cams[0])
-    Hn.render_view(p, cams[0], grids, 0, sky, front=front)
-    with pytest.raises(AssertionError):             # consumed
-        Hn.render_view(p, cams[0], grids, 0, sky, front=front)
-
-
 def test_marshalled_scene_graph_route_equals_the_view_node():
     """the reference-named route -- per-class get_gaussians (SH colours at the active degree, activations) ->
     collect_gaussians (concatenation + class labels) -> render_gaussians (rasterization(), clamp, retain_grad; per-class re-render
