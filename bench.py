@@ -162,6 +162,19 @@ def cpu_baseline_worker(args):
         return best
 
     t_c1 = best_of(_cpu_iter_fn(1000, 256, 256), 3, 20.0)
+    # the port is a chain of small framework operators: on a many-core host it can be SLOWER with every physical core than with a
+    # few (measured on the 128-core GPU box: configs[0] 0.76 it/s at 128 threads, 5.2 at 16).  Both are timed at configs[0]; the
+    # faster setting runs the sample and is the `cores` of the line, the other figure is kept beside it.
+    alt, c1_alt = (16 if threads > 16 else None), None
+    if alt:
+        torch.set_num_threads(alt)
+        t_alt = best_of(_cpu_iter_fn(1000, 256, 256), 3, 20.0)
+        c1_alt = {"threads": alt, "c1_value": 1.0 / t_alt}
+        if t_alt < t_c1:
+            c1_alt = {"threads": threads, "c1_value": 1.0 / t_c1}
+            threads, t_c1 = alt, t_alt
+        else:
+            torch.set_num_threads(threads)
     small = (20000, 480, 270)
     big = (args.cpu_sample_gaussians, args.cpu_sample_width, args.cpu_sample_height)
     t_small = best_of(_cpu_iter_fn(*small), 1, 30.0)
@@ -176,6 +189,7 @@ def cpu_baseline_worker(args):
                   f"pure-PyTorch CPU port (oracle/), best of 3; NOT the GPU workload size "
                   f"(host: {_physical_cores()} physical cores / {os.cpu_count()} logical CPUs; {threads} torch threads used)",
         "c1_value": 1.0 / t_c1, "c1_sample": "configs[0]: 1000 Gaussians, one 256x256 view, same pipeline, best of 3",
+        "physical_cores": _physical_cores(), "other_thread_count": c1_alt,
     }))
 
 
