@@ -97,6 +97,10 @@ _SIGS = {
     "bds_bilagrid_ms_ed_train_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _i, C.POINTER(BdsLevel),
                                           C.POINTER(C.c_float), _fl, _f, _i, _f, _f]),
     "bds_bilagrid_ms_ed_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
+    "bds_bilagrid_ms_ed_bwd_deferrable": (_i, [_i, C.POINTER(BdsLevel), _i, _i]),
+    "bds_bilagrid_ms_ed_bwd_deferred": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
+    "bds_rasterize_bwd_ms": (_i, [_i64, _i64, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _i, C.POINTER(BdsLevel), _f, _sz,
+                                  _f, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_ed_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f, _f, _f]),
     "bds_l1_tv_train": (_i, [_i64, _f, _f, _i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _fl, _f, _i, _f, _f]),
     "bds_l1_mean_fwd": (_i, [_i64, _f, _f, _f, _f]),
@@ -182,7 +186,8 @@ OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback
 ECAPACITY = -4
 
 
-def rasterize_kernel_name(backward: bool, CH: int = 4, absgrad: bool = True, list_tile_size: int = 64) -> str:
+def rasterize_kernel_name(backward, CH: int = 4, absgrad: bool = True, list_tile_size: int = 64) -> str:
+    """``backward``: False / True, or 2 = the backward that also runs the colour transform's deferred epilogue."""
     buf = C.create_string_buffer(128)
     check(lib().bds_rasterize_kernel_name(int(backward), CH, int(absgrad), list_tile_size, buf, 128), "bds_rasterize_kernel_name")
     return buf.value.decode()

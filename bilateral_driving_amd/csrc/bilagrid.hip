@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "bilagrid_ms.h"
+#include "ed_epilogue.h"
 
 namespace bds {
 
@@ -1162,14 +1163,40 @@ extern "C" int bds_bilagrid_ms_ed_fwd(int nlevels, const bds_bilagrid_level_t *l
   return ms_fwd_impl(nlevels, levels, H, W, render, 4, alpha, sky, ws, ws_bytes, rgb_out, depth_out, nullptr, stream);
 }
 
+// The backward's last stage can move into the compositor's backward (ed_epilogue.h) when every level takes the cell-aligned low-res
+// stage (nothing rides on the epilogue's launch) and its guidance taps are the closed form: a dividing power-of-two factor, or 1.
+static bool epilogue_deferrable(const MsParams &p) {
+  if (!(option_get(kOptCells) & 1) || (option_get(kOptCells) & 4) || cells_fused_ok(p)) return false;
+  for (int l = 0; l < p.nlevels; l++) {
+    const LevelDev &L = p.lv[l];
+    if (!cells_level_ok(L)) return false;
+    if (!(L.dn_shift > 0 || (L.Hd == p.H && L.Wd == p.W))) return false;
+  }
+  return true;
+}
+namespace bds {
+int ed_epilogue_fill(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, void *ws, size_t ws_bytes, EdEpilogue *e) {
+  MsParams p;
+  float dummy = 0.f;
+  int rc = ms_fill(p, nlevels, levels, H, W, &dummy, nullptr, nullptr, ws, ws_bytes, nullptr);
+  if (rc != BDS_OK) return rc;
+  BDS_REQUIRE(e && epilogue_deferrable(p) && (int64_t)H * W * 4 < ((int64_t)1 << 31));
+  *e = EdEpilogue{};
+  e->nlevels = nlevels; e->W = W;
+  for (int l = 0; l < nlevels; l++) { e->vg[l] = p.lv[l].vg; e->Wd[l] = p.lv[l].Wd; e->shift[l] = p.lv[l].dn_shift; }
+  return BDS_OK;
+}
+}  // namespace bds
+
 static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *rgb, int cs,
                        const float *alpha, const float *sky, void *ws, size_t ws_bytes, const float *v_rgb_out,
                        const float *v_depth, const float *v_alpha_in, float *v_rgb, float *v_alpha, float *v_sky,
-                       bds_stream_t stream) {
+                       bds_stream_t stream, bool defer_epilogue = false) {
   MsParams p;
   int rc = ms_fill(p, nlevels, levels, H, W, rgb, alpha, sky, ws, ws_bytes, nullptr);
   if (rc != BDS_OK) return rc;
   BDS_REQUIRE(v_rgb_out && v_rgb);
+  if (defer_epilogue) BDS_REQUIRE(epilogue_deferrable(p));
   p.cs = cs; p.v_depth = v_depth; p.v_alpha_in = v_alpha_in;
   hipStream_t st = as_stream(stream);
   const int64_t HW = (int64_t)H * W;
@@ -1285,6 +1312,7 @@ static int ms_bwd_impl(int nlevels, const bds_bilagrid_level_t *levels, int H, i
       if (red.blk_off[red.n] > 0) { pj.sc = sc; pj.red = red; pj.partials = partials; extra_blocks = red.blk_off[red.n]; }
     }
   }
+  if (defer_epilogue) return BDS_OK;   // (the compositor's backward finishes the pixel: bds_rasterize_bwd_ms)
   {
     // (the reduction of the partial grids rides on this launch as extra workgroups)
     pj.pix_blocks = (int)cdiv(HW, kBgBlock);
@@ -1418,6 +1446,31 @@ extern "C" int bds_bilagrid_ms_ed_bwd(int nlevels, const bds_bilagrid_level_t *l
   BDS_REQUIRE(alpha && v_alpha);
   return ms_bwd_impl(nlevels, levels, H, W, render, 4, alpha, sky, ws, ws_bytes, v_rgb_out, v_depth, v_opacity, v_render, v_alpha,
                      v_sky, stream);
+}
+
+// 1 when this configuration's backward can leave its last stage to the compositor's backward (bds_rasterize_bwd_ms), else 0
+extern "C" int bds_bilagrid_ms_ed_bwd_deferrable(int nlevels, const bds_bilagrid_level_t *levels, int H, int W) {
+  if (nlevels < 1 || nlevels > BDS_MAX_LEVELS || !levels || H <= 0 || W <= 0) return 0;
+  MsParams p{};
+  p.nlevels = nlevels; p.H = H; p.W = W;
+  for (int l = 0; l < nlevels; l++) {
+    if (levels[l].factor < 1) return 0;
+    LevelDev &d = p.lv[l];
+    const int f = levels[l].factor;
+    d.gx = levels[l].gx; d.gy = levels[l].gy; d.gl = levels[l].gl; d.factor = f; d.n_avg = levels[l].n_avg;
+    d.Hd = H / f; d.Wd = W / f;
+    d.aff_out = nullptr;
+    d.dn_shift = (f >= 2 && (f & (f - 1)) == 0 && d.Hd * f == H && d.Wd * f == W) ? 1 : 0;
+  }
+  return epilogue_deferrable(p) ? 1 : 0;
+}
+
+extern "C" int bds_bilagrid_ms_ed_bwd_deferred(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                                               const float *alpha, const float *sky, void *ws, size_t ws_bytes,
+                                               const float *v_rgb_out, float *v_direct, bds_stream_t stream) {
+  BDS_REQUIRE(alpha && v_direct);
+  return ms_bwd_impl(nlevels, levels, H, W, render, 4, alpha, sky, ws, ws_bytes, v_rgb_out, nullptr, nullptr, v_direct, nullptr, nullptr,
+                     stream, true);
 }
 
 extern "C" int bds_bilagrid_slice_fwd(int64_t P, const float *grid, int gx, int gy, int gl, const float *xy,

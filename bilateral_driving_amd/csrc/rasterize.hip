@@ -24,6 +24,7 @@
 // Workgroup ids are remapped so that each XCD rasterises one contiguous band of the image (its private L2 then serves
 // the re-reads of records shared by neighbouring tiles).
 #include "bds_common.h"
+#include "ed_epilogue.h"
 #include "gs_math.h"
 
 namespace bds {
@@ -351,14 +352,16 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 // need only three per-lane moments of d(loss)/d(sigma) (S0 = sum vs, S1 = sum vs dy, S2 = sum vs dy^2) that are expanded
 // once per (lane, Gaussian); 12 per-lane sums then go through ONE 16-value transpose-reduce and 12 lanes commit them to the
 // Gaussian's gradient record.  The list is replayed back to front from the tile's deepest blended entry.
-template <int CH, bool ABS, bool kCoarse, bool kStrip>
-__global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
+// kEpi: the image gradient is not read but FORMED per pixel from the colour transform's deferred backward (ed_epilogue.h: direct route +
+// guidance route, clamp / sky blend / expected-depth backward; also writes v_sky) -- the lanes wait for their tile's first records
+// anyway, and the transform's third pass over the image (45 us, 172 MB at 1080p) goes away with its two image-sized intermediates.
+template <int CH, bool ABS, bool kCoarse, bool kStrip, bool kEpi>
+__device__ __forceinline__ void rasterize_bwd_wave_body(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  __shared__ int32_t sId[kWave];
+    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, const ListGeom &lg,
+    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId) {
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
   const int n_tiles = tile_w * tile_h;
   const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   const int lane = threadIdx.x;
   int start, end;
   list_range<kCoarse>(offsets, item, C * n_tiles, cam, tx, ty, lg, M, start, end);
-  if (end <= start) return;
+  if (!kEpi && end <= start) return;   // (kEpi: the tile's pixels still owe their sky gradient)
   const int j = tx * kTile + (lane & 15);
   const float px = (float)j + 0.5f;
   const int i0 = ty * kTile + (lane >> 4);
@@ -386,17 +389,24 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     T[q] = T_final;
     bin_final[q] = inside ? last_ids[pix] : -1;   // -1: never valid (pixel outside the image)
     max_bin = max(max_bin, bin_final[q]);
-    const float vra = inside ? v_alphas[pix] : 0.f;
-    float bgdot = 0.f;
+    float vra = 0.f, bgdot = 0.f;
+    if (kEpi) {
+      vr[q][0] = vr[q][1] = vr[q][2] = vr[q][3] = 0.f;
+      if (inside) ed_epilogue_pixel(ep, i, j, (int)pix, 1.f - T_final, vr[q], vra);
+      // one pixel's ~14 loaded values at a time: hoisting all four pixels' loads together costs 15 registers and a resident wave
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      vra = inside ? v_alphas[pix] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      vr[q][k] = (k < CH && inside) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
-      if (backgrounds && k < CH) bgdot += backgrounds[cam * CH + k] * vr[q][k];
+      for (int k = 0; k < 4; k++) {
+        vr[q][k] = (k < CH && inside) ? v_render[pix * CH + (k < CH ? k : 0)] : 0.f;
+        if (backgrounds && k < CH) bgdot += backgrounds[cam * CH + k] * vr[q][k];
+      }
     }
     Bd[q] = -T_final * (vra - bgdot);
   }
   const int tile_bin_final = wave_max_i32(max_bin);
-  if (tile_bin_final < start) return;   // no pixel of this tile blended anything (last_ids stays 0 then)
+  if (tile_bin_final < start || end <= start) return;   // no pixel of this tile blended anything (last_ids stays 0 then)
   // gradient-record slot this lane commits after the transpose-reduce (one committing lane per quad)
   const int slot = butterfly_slot(lane);
   const bool commit = ((lane & 3) == 0) && (slot < 4 ? slot < CH : (slot < 12 && (ABS || (slot != 9 && slot != 10))));
@@ -516,6 +526,30 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   }
 }
 
+template <int CH, bool ABS, bool kCoarse, bool kStrip>
+__global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  __shared__ int32_t sId[kWave];
+  const EdEpilogue none{};
+  rasterize_bwd_wave_body<CH, ABS, kCoarse, kStrip, false>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
+                                                           last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId);
+}
+// the same with the colour transform's deferred epilogue in the prologue (RGB+ED, one camera).  108 VGPRs (four waves per SIMD
+// against the plain kernel's five): held to five with __launch_bounds__(64, 5) it spills 32-76 bytes per lane and runs 8 % slower
+template <bool ABS, bool kCoarse>
+__global__ __launch_bounds__(kWave) void rasterize_bwd_epi_kernel(
+    int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, int W, int H, int tile_w, int tile_h,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas,
+    const int32_t *__restrict__ last_ids, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg, EdEpilogue ep) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  __shared__ int32_t sId[kWave];
+  rasterize_bwd_wave_body<4, ABS, kCoarse, false, true>(1, M_host, M_dev, rec, nullptr, W, H, tile_w, tile_h, offsets, flatten, alphas, last_ids,
+                                                        nullptr, nullptr, v_rec, tile_order, lg, ep, sA, sB, sC, sId);
+}
 // ---- backward schedule: longest tile first inside each XCD's range ------------------------------------
 // One wave per tile finishes when its LAST pixel does, and the chip holds only ~2 rounds of tiles
 // (8160 tiles at 1080p over 1024 SIMDs x 4 resident waves), so tiles dispatched late that happen to be long
@@ -842,20 +876,31 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
                               const float *v_render, const float *v_alphas, float *v_records, int absgrad,
-                              const int32_t *tile_order, bds_stream_t stream) {
+                              const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
   BDS_REQUIRE(list_geom(C, W, H, list_tile_size, lg));
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
   BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
-  if (M == 0) return BDS_OK;
-  BDS_REQUIRE(records && isect_offsets && flatten && alphas && last_ids && v_render && v_alphas && v_records);
+  if (M == 0 && !epi) return BDS_OK;
+  BDS_REQUIRE(records && isect_offsets && flatten && alphas && last_ids && v_records && (epi || (v_render && v_alphas)));
   BDS_REQUIRE(aligned16(records) && aligned16(v_records));
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
   const size_t pad_bwd = (size_t)option_get(kOptPadBwd) * 1024u;   // (see bds_rasterize_fwd: bds_set_option(1, KB))
+  if (epi) {   // one camera, RGB+ED, no backgrounds: the colour transform's deferred epilogue runs in the kernel's prologue
+    BDS_REQUIRE(C == 1 && CH == 4 && backgrounds == nullptr);
+#define BDS_BWD_EPI(ab, co)                                                                                                              \
+  hipLaunchKernelGGL((rasterize_bwd_epi_kernel<ab, co>), grid, dim3(kWave), pad_bwd, st, M, M_dev, rec, W, H, tile_w, tile_h, isect_offsets, \
+                     flatten, alphas, last_ids, v_records, tile_order, lg, *epi)
+    if (absgrad) { if (lg.div > 1) BDS_BWD_EPI(true, true); else BDS_BWD_EPI(true, false); }
+    else         { if (lg.div > 1) BDS_BWD_EPI(false, true); else BDS_BWD_EPI(false, false); }
+#undef BDS_BWD_EPI
+    BDS_LAUNCH_CHECK();
+    return BDS_OK;
+  }
   // (kStrip = false: measured on the benchmark scene, skipping untouched 16 x 4 strips costs the backward 3 % -- its per-pixel
   // body is long enough that the extra control flow outweighs the ~19 % of strips it would skip; the forward gains 7 %)
 #define BDS_BWD(ch, ab, co)                                                                                                                 \
@@ -899,6 +944,21 @@ extern "C" int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacit
                             isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream);
 }
 
+extern "C" int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,
+                                    int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                                    const int32_t *flatten, const float *alphas, const int32_t *last_ids, float *v_records, int absgrad,
+                                    const int32_t *tile_order, int nlevels, const bds_bilagrid_level_t *levels, void *ms_ws,
+                                    size_t ms_ws_bytes, const float *render, const float *sky, const float *v_depth,
+                                    const float *v_alpha_in, const float *v_direct, float *v_sky, bds_stream_t stream) {
+  BDS_REQUIRE(render && v_direct && aligned16(render) && aligned16(v_direct) && (sky != nullptr || v_sky == nullptr));
+  EdEpilogue e;
+  const int rc = ed_epilogue_fill(nlevels, levels, H, W, ms_ws, ms_ws_bytes, &e);
+  if (rc != BDS_OK) return rc;
+  e.v_direct = v_direct; e.render = render; e.sky = sky; e.v_depth = v_depth; e.v_alpha_in = v_alpha_in; e.v_sky = v_sky;
+  return rasterize_bwd_impl(1, n_records, M_capacity, M_dev, 4, records, nullptr, W, H, tile_size, list_tile_size, tile_w, tile_h,
+                            isect_offsets, flatten, alphas, last_ids, nullptr, nullptr, v_records, absgrad, tile_order, stream, &e);
+}
+
 extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                                           const int32_t *isect_offsets, const int32_t *last_ids, int32_t *tile_order,
                                           bds_stream_t stream) {
@@ -925,7 +985,9 @@ extern "C" int bds_rasterize_kernel_name(int backward, int CH, int absgrad, int 
   BDS_REQUIRE(buf && buf_len > 0 && (CH == 1 || CH == 3 || CH == 4) && list_tile_size >= kTile && list_tile_size % kTile == 0);
   const char *co = list_tile_size > kTile ? "true" : "false";
   int n;
-  if (backward) n = snprintf(buf, (size_t)buf_len, "rasterize_bwd_wave_kernel<%d, %s, %s, false>", CH, absgrad ? "true" : "false", co);
+  if (backward == 2)   // with the colour transform's deferred epilogue (bds_rasterize_bwd_ms)
+    n = snprintf(buf, (size_t)buf_len, "rasterize_bwd_epi_kernel<%s, %s>", absgrad ? "true" : "false", co);
+  else if (backward) n = snprintf(buf, (size_t)buf_len, "rasterize_bwd_wave_kernel<%d, %s, %s, false>", CH, absgrad ? "true" : "false", co);
   else n = snprintf(buf, (size_t)buf_len, "rasterize_fwd_wave_kernel<%d, %s, true>", CH, co);
   return (n > 0 && n < buf_len) ? BDS_OK : BDS_EINVAL;
 }

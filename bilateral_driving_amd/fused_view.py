@@ -62,6 +62,14 @@ def _release_sync_objects(dev, pair) -> None:
     _SYNC.setdefault(dev, []).append(pair)
 
 
+# The colour transform's backward leaves its last stage to the compositor's backward (bds_rasterize_bwd_ms) where views run one after
+# the other: -1 launch, -38 us of transform for +10 us of compositor at 1080p (one-stream frame 847 -> 867 it/s).  A frame that runs
+# the next view's forward next to this backward (graph_view.FrameGraph(overlap=True)) asks for the three-launch form instead
+# (cfg["defer_epilogue"] = False): there the transform's memory-bound last stage hides behind the other stream's compositor for free,
+# while folded into the compositor's backward it lengthens the frame's VALU-bound critical kernel (1006 -> 968 it/s).
+_DEFER_EPILOGUE = os.environ.get("BDS_DEFER_EPILOGUE", "1") != "0"
+
+
 class ListCapacity:
     """Capacities of one camera's intersection lists for the DEVICE-COUNT form of the view (include/bds.h "device-count forms"):
     no host read-back between the tile counting and the list build, every launch sized by these bounds, the actual counts read from
@@ -532,10 +540,19 @@ class _FusedView(torch.autograd.Function):
         v_rgb = torch.zeros(H, W, 3, device=dev) if v_rgb is None else v_rgb.contiguous()
         v_depth = None if v_depth is None else v_depth.contiguous()
         v_opacity = None if v_opacity is None else v_opacity.contiguous()
+        # The transform's backward leaves its last stage -- guidance route, clamp / sky blend / expected-depth backward: a per-pixel
+        # function -- to the compositor's backward wherever the configuration allows it (include/bds.h bds_rasterize_bwd_ms): v_render
+        # then holds the direct-route gradient only, v_alphas is not touched, and one launch over the image is gone.
+        defer = (_DEFER_EPILOGUE and cfg.get("defer_epilogue", True) and M > 0 and n_vis > 0
+                 and bool(lib.bds_bilagrid_ms_ed_bwd_deferrable(len(grids), lv, H, W)))
         with L.timed("bilagrid_bwd"):
-            L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
-                                               L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
-                                               L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
+            if defer:
+                L.check(lib.bds_bilagrid_ms_ed_bwd_deferred(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws),
+                                                            bws.numel(), L.ptr(v_rgb), L.ptr(v_render), st), "bds_bilagrid_ms_ed_bwd_deferred")
+            else:
+                L.check(lib.bds_bilagrid_ms_ed_bwd(len(grids), lv, H, W, L.ptr(render), L.ptr(alphas), L.ptr(sky), L.ptr(bws), bws.numel(),
+                                                   L.ptr(v_rgb), L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_alphas),
+                                                   L.ptr(v_sky), st), "bds_bilagrid_ms_ed_bwd")
         # compositing: gradient records of the visible Gaussians, in the order of vis_ids (64 bytes each)
         # (+ the camera-pose gradient slots of the projection backward behind them: one zero fill for both)
         want_pose = bool(ctx.needs_input_grad[7])
@@ -553,7 +570,12 @@ class _FusedView(torch.autograd.Function):
         if order is None:
             order = ops.bwd_schedule(1, W, H, LT, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
-            if dev_counts is not None:
+            if defer:
+                L.check(lib.bds_rasterize_bwd_ms(n_vis, M, None if dev_counts is None else dev_counts[0], L.ptr(rec), W, H, TILE, LT, tw, th,
+                                                 L.ptr(isect_offsets), L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_rec), 1,
+                                                 L.ptr(order), len(grids), lv, L.ptr(bws), bws.numel(), L.ptr(render), L.ptr(sky),
+                                                 L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_sky), st), "bds_rasterize_bwd_ms")
+            elif dev_counts is not None:
                 L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
                                                   L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
                                                   L.ptr(v_rec), 1, L.ptr(order), st), "bds_rasterize_bwd_dev")
@@ -791,6 +813,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     g2d_buf = kwargs.pop("g2d_buf", None)    # persistent [2,N,2] screen-space gradient arrays whose stale rows the caller clears
     tail_buf, defer_pose_sum = kwargs.pop("tail_buf", None), bool(kwargs.pop("defer_pose_sum", False))
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
+    defer_epilogue = bool(kwargs.pop("defer_epilogue", True))   # (see _DEFER_EPILOGUE)
     # the TV term over OTHER tensors than the transform's grids: graph_view's replayable view slices staging copies of ONE image's
     # grids (picked by a device-side index) while the regulariser runs over the full [n_img, ...] parameters (modules.py:445)
     tv_grids, tv_grid_grads = kwargs.pop("tv_grids", None), kwargs.pop("tv_grid_grads", None)
@@ -802,6 +825,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws, g2d_buf=g2d_buf, tail_buf=tail_buf,
+               defer_epilogue=defer_epilogue,
                defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and arena_rows >= 1 and grad_sink is None:

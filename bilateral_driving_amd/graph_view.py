@@ -227,7 +227,10 @@ class FrameGraph:
     # ---- the phases of a view (eager warm-up, capture and replay walk the same protocol) -------------------------------------------
     def _view_kwargs(self, v: int) -> dict:
         kw = dict(factors=self.factors, tv_weight=self.tv_weight, caps=self.caps[v], prep_ws=self.prep_ws[v], list_tile=self.list_tile,
-                  sh_degree=self.sh_degree, two_phase=True, lazy_loss=True)
+                  sh_degree=self.sh_degree, two_phase=True, lazy_loss=True,
+                  # two streams: the transform's memory-bound last stage hides behind the other stream's compositor; folded into the
+                  # compositor's backward it would lengthen the VALU-bound critical kernel (fused_view._DEFER_EPILOGUE)
+                  defer_epilogue=not self.overlap)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
         else:

@@ -47,7 +47,8 @@ const char *bds_strerror(int code);
  * 3 = profiling only: ablation mask of the bilateral backward;
  * 7 = bilateral transform, bit mask [default 3]: bit 0 = the cell-aligned kernels (csrc/bilagrid_cells.hip) wherever a level
  *     qualifies (one grid per level); bit 1 = the pyramid forward as one pass over the image (csrc/bilagrid_tile.hip) when every
- *     factor is a power of two >= 2 dividing the image; 0 = the general kernels everywhere (what levels averaged over several
+ *     factor is a power of two >= 2 dividing the image; bit 2 = do NOT defer the backward's last stage to the compositor
+ *     (bds_bilagrid_ms_ed_bwd_deferrable returns 0); 0 = the general kernels everywhere (what levels averaged over several
  *     grids always take).  Same results.
  * Other indices are unused. */
 int bds_set_option(int which, int value);
@@ -376,6 +377,28 @@ int bds_bilagrid_select(int nlevels, const bds_bilagrid_level_t *levels, const i
 int bds_bilagrid_select_bwd(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *v_sel,
                             bds_stream_t stream);
 
+/* The colour transform's backward WITHOUT its last stage, and the compositor's backward that finishes it (one camera, RGB+ED; the
+ * fused view, models/trainers/base.py:393-419 + scene_graph.py:86-120,292-294 as one backward).  The last stage of
+ * bds_bilagrid_ms_ed_bwd -- guidance route added to the direct route, clamp(max=1) / sky blend / expected-depth backward -- is a
+ * per-pixel function of arrays that exist by then; bds_rasterize_bwd_ms evaluates it for its tile's pixels while it waits for the
+ * tile's first records, so v_render [H,W,4] and v_alpha [H,W] are never written and read back and one pass over the image (45 us,
+ * 172 MB at 1080p) disappears.  _deferrable: 1 when every level has one grid (gl <= 8) and a factor that is 1 or a power of two
+ * dividing H and W (and bit 2 of bds_set_option(7, ..) is clear), else 0 -- use bds_bilagrid_ms_ed_bwd then.  _deferred: v_direct
+ * [H,W,4] receives the direct-route gradient (channels 0-2); the grids' gradients are complete on return.  bds_rasterize_bwd_ms:
+ * bds_rasterize_bwd / _dev (M_dev NULL: M_capacity is the host-side count) for C = 1, CH = 4, no backgrounds, with the image
+ * gradient formed from (levels, ms_ws: the transform's workspace), render [H,W,4] (the compositor's forward output), sky,
+ * v_depth / v_alpha_in (may be NULL) and v_direct; writes v_sky [H,W,3] (may be NULL). */
+int bds_bilagrid_ms_ed_bwd_deferrable(int nlevels, const bds_bilagrid_level_t *levels, int H, int W);
+int bds_bilagrid_ms_ed_bwd_deferred(int nlevels, const bds_bilagrid_level_t *levels, int H, int W, const float *render,
+                                    const float *alpha, const float *sky, void *ws, size_t ws_bytes, const float *v_rgb_out,
+                                    float *v_direct, bds_stream_t stream);
+int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,
+                         int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
+                         const int32_t *flatten, const float *alphas, const int32_t *last_ids, float *v_records, int absgrad,
+                         const int32_t *tile_order, int nlevels, const bds_bilagrid_level_t *levels, void *ms_ws, size_t ms_ws_bytes,
+                         const float *render, const float *sky, const float *v_depth, const float *v_alpha_in, const float *v_direct,
+                         float *v_sky, bds_stream_t stream);
+
 /* Names (as rocprofv3 prints them, without "bds::" and the argument list; comma-separated, launch order) of the kernels the bilateral
  * transform of this configuration launches under the current options (bds_set_option(7, ..)): forward (train != 0: with the L1 / TV
  * loss on the launch) or backward.  Measurement plumbing for bench.py's counter look-up; no reference counterpart. */
@@ -383,7 +406,8 @@ int bds_bilagrid_kernel_names(int nlevels, const bds_bilagrid_level_t *levels, i
                               int buf_len);
 
 /* Name (as rocprofv3 prints it, without the "bds::" prefix and the argument list) of the compositor kernel that a launch with
- * these switches runs; measurement plumbing for bench.py's counter look-up. */
+ * these switches runs (backward: 0 = forward, 1 = backward, 2 = backward with the colour transform's deferred epilogue,
+ * bds_rasterize_bwd_ms); measurement plumbing for bench.py's counter look-up. */
 int bds_rasterize_kernel_name(int backward, int CH, int absgrad, int list_tile_size, char *buf, int buf_len);
 
 /* ---- device-count forms: one view without a host read-back (capturable in a hipGraph) -----------------------------------------

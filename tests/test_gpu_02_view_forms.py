@@ -260,3 +260,47 @@ def test_fused_view_with_nothing_on_screen(env):
         assert any(float(g.grad.abs().max()) > 0 for g in grids)
         for t_ in list(p.values()) + grids:
             t_.grad = None
+
+
+@pytest.mark.parametrize("W,H,levels,factors", [(320, 192, None, None), (256, 160, [(8, 8, 4), (16, 16, 8)], [2, 1])])
+def test_epilogue_deferred_to_the_compositor_equals_the_three_launch_backward(env, W, H, levels, factors):
+    """The colour transform's backward with its last stage (guidance route, clamp / sky blend / expected-depth backward) formed per
+    pixel inside the compositor's backward (bds_bilagrid_ms_ed_bwd_deferred + bds_rasterize_bwd_ms: the one-stream default of the
+    fused view) == the three-launch form (bit 2 of bds_set_option(7, ..)): every gradient, with a loss that also reaches the depth
+    and the opacity image (v_depth / v_alpha_in) and a learnable sky.  A pyramid with a full-resolution level included."""
+    ops, L = env
+    from bilateral_driving_amd import harness as Hn
+    N = 5000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(30.0,), device="cuda")[0]
+    cam.viewmat.requires_grad_(True)
+    base = Hn.synthetic_scene(N, seed=12, device="cuda")
+    base["means"] = base["means"] * torch.tensor([0.4, 0.4, 1.0], device="cuda")
+    lv = Hn.LEVELS_3 if levels is None else levels
+    fs = Hn.FACTORS_3 if factors is None else factors
+    grids0 = Hn.make_grids(2, levels=lv, device="cuda")
+    g = torch.Generator().manual_seed(4)
+    sky0 = torch.rand(H, W, 3, generator=g).cuda()
+    wr, wd, wo = torch.randn(H, W, 3, generator=g).cuda(), torch.randn(H, W, 1, generator=g).cuda(), torch.randn(H, W, 1, generator=g).cuda()
+    res = {}
+    for mode in (3 | 4, 3):     # three launches; deferred
+        L.set_option(L.OPT_CELLS, mode)
+        try:
+            assert bool(L.lib().bds_get_option(L.OPT_CELLS) & 4) == (mode == 7)
+            p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            grids = [x.clone().requires_grad_(True) for x in grids0]
+            sky = sky0.clone().requires_grad_(True)
+            cam.viewmat.grad = None
+            out = Hn.render_view(p, cam, grids, 1, sky, factors=fs)
+            ((out["rgb"] * wr).sum() + 0.05 * (out["depth"] * wd).sum() + (out["opacity"] * wo).sum()).backward()
+            res[mode] = ({k: v.grad.clone() for k, v in p.items()}, [x.grad.clone() for x in grids], sky.grad.clone(), cam.viewmat.grad.clone(),
+                         out["info"]["means2d"].absgrad.clone(), out["rgb"].detach().clone())
+        finally:
+            L.set_option(L.OPT_CELLS, 3)
+    a, b = res[7], res[3]
+    assert torch.equal(a[5], b[5])
+    for k in a[0]:
+        assert float((a[0][k] - b[0][k]).norm() / a[0][k].norm()) < 2e-4, k      # (float atomics in the compositor backward)
+    for x, y in zip(a[1], b[1]):
+        assert float((x - y).norm() / x.norm()) < 3e-5
+    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7)                        # sky gradient: the same per-pixel arithmetic
+    assert float((a[3] - b[3]).norm() / a[3].norm()) < 2e-4 and float((a[4] - b[4]).norm() / a[4].norm()) < 2e-4
