@@ -29,8 +29,22 @@ def _c(a):
     return torch.from_numpy(np.asarray(a)).float().cuda()
 
 
-TOL = dict(rtol=3e-4, atol=3e-5)
+TOL = dict(rtol=3e-4, atol=3e-5)     # the goldens are float32 runs of the reference: its own rounding is of this order at |rgb| ~ 1
 GTOL = dict(rtol=2e-3, atol=2e-3)
+
+
+def _worst(tag, pairs):
+    """Print the measured worst case next to the bound it is held to (north_star: 1e-4 rel on the image, 1e-3 rel on gradients):
+    relative to max(1, |ref|) for values, to the largest reference entry for gradients."""
+    msg = []
+    for name, got, ref, grad in pairs:
+        got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        if grad:
+            e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+        else:
+            e = (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max()
+        msg.append(f"{name} {e:.1e}")
+    print(f"[golden {tag}] worst: " + ", ".join(msg))
 
 
 @pytest.mark.parametrize("path", _files("bilagrid_ms_*_f32.npz"), ids=os.path.basename)
@@ -57,6 +71,8 @@ def test_fused_multiscale_vs_reference_golden(B, path):
         ref = z[f"v_grids{i}"]
         got = allg[i].grad.cpu().numpy()
         assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), (i, np.abs(got - ref).max(), np.abs(ref).max())
+    _worst(os.path.basename(path), [("out", out.detach().cpu().numpy(), z["out"], False), ("v_rgb", rgb.grad.cpu().numpy(), z["v_rgb"], True)]
+           + [(f"v_grid{i}", allg[i].grad.cpu().numpy(), z[f"v_grids{i}"], True) for i in range(nl)])
     # test branch
     near = [int(n) for n in z["near"]]
     with torch.no_grad():
@@ -81,6 +97,8 @@ def test_fused_single_scale_vs_reference_golden(B, path):
     np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["v_rgb"], rtol=2e-3, atol=2e-4 * scale)
     ref = z["v_grids0"]
     assert np.abs(g.grad.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    _worst(os.path.basename(path), [("out", out.detach().cpu().numpy(), z["out"], False), ("v_rgb", rgb.grad.cpu().numpy(), z["v_rgb"], True),
+                                    ("v_grid", g.grad.cpu().numpy(), ref, True)])
 
 
 @pytest.mark.parametrize("path", _files("bilagrid_points_f32.npz"), ids=os.path.basename)

@@ -10,16 +10,22 @@ import pytest
 
 from bilateral_driving_amd import build as B
 
-FILES = ["rasterize.hip", "tiles.hip", "bilagrid.hip", "sh.hip", "project.hip", "mlp_head.hip", "loss.hip", "refine.hip"]
+FILES = ["rasterize.hip", "tiles.hip", "bilagrid.hip", "bilagrid_cells.hip", "bilagrid_tile.hip", "sh.hip", "project.hip", "mlp_head.hip", "loss.hip", "refine.hip"]
 # scratch allowed (bytes / lane): a shape no shipped config uses
 SCRATCH_OK = {"neural_image_fwd_kernelILi32ELi8ELi0ELi0E": 16}
 # kernel name prefix (mangled, after the length digits) -> minimum waves / SIMD
 MIN_OCCUPANCY = {
     "rasterize_fwd_wave_kernelILi4ELb1ELb1E": 7,        # the benchmark's forward compositor (RGB+ED, coarse lists)
     "rasterize_bwd_wave_kernelILi4ELb1ELb1ELb0E": 5,    # ... and its backward (absgrad)
+    "rasterize_bwd_epi_kernelILb1ELb1E": 4,             # ... with the colour transform's deferred epilogue (one-stream frames)
     "ms_apply_fwd_kernelILi3E": 6,
     "ms_apply_bwd_x_kernelILi3E": 5,
     "ms_lowres_bwd_kernelILb1ELi4E": 3,
+    "ms_tile_fwd_kernelILi3ELb1E": 4,                   # pyramid forward, one pass (headline / c3)
+    "ms_tile_fwd_kernelILi4ELb1E": 4,                   # ... c5
+    "cell_fwd_kernelILb1ELb1E": 5,                      # single-scale transform in one launch (c2)
+    "cell_bwd_kernelILb1E": 4,
+    "cell_bwd_kernelILb0E": 4,                          # low-resolution stage of a pyramid's backward
     "mlp_head_fwd_kernelILi24E": 2,
     "neural_image_fwd_kernelILi24ELi8ELi0ELi0E": 2,
     "neural_image_bwd_kernelILi24ELi8ELi0ELi0E": 1,     # 256 VGPRs + the weight / slot gradient accumulators in AGPRs: one wave per SIMD by design
