@@ -102,6 +102,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="graph replay: one graph per view on one stream instead of forward / backward graphs on two streams (view v + 1's "
                          "forward next to view v's backward)")
+    ap.add_argument("--exchange", choices=("auto", "view", "frame"), default="auto",
+                    help="N > 1: sum the gradients over the ranks per view (compact union rows, overlapped with the next view), once per "
+                         "frame (one dense all-reduce), or whichever dist.plan_exchange prices cheaper from the measured unions, the "
+                         "measured compute time of a frame and the measured all-reduce bandwidth of the fabric (default)")
     ap.add_argument("--random-views", action="store_true",
                     help="N = 1: also time the REPLAYABLE frame (graph_view.FrameGraph(dynamic=True)) -- every step each view slot gets "
                          "a random camera of a pool, a new target / sky and a random image index written into its static inputs before "
@@ -304,24 +308,52 @@ def main():
     # zero_grad clears exactly the rows the previous frame wrote (a view sees ~15 % of the scene); at N > 1 the rows travel in compact
     # per-view exchange buffers (dist.FrameExchange)
     flat = FlatGradients(list(params.values()) + grids, sparse_rows=True)
-    fx = FrameExchange(flat, list(params.keys()) + [f"grid{i}" for i in range(len(grids))])
+    fx_names = list(params.keys()) + [f"grid{i}" for i in range(len(grids))]
+    fx = FrameExchange(flat, fx_names, per_view=args.exchange != "frame")
 
     # (16-px tile, Gaussian) pairs per view = the intersections of the reference's algorithm (SURVEY.md 8d counts bytes per such pair);
     # the fused view builds its lists for larger tiles (fused_view.LIST_TILE) and never materialises them, so they are counted once here
     from bilateral_driving_amd import fused_view as FV
     with torch.no_grad():
-        M16 = [Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, list_tile=16)["info"]["n_isects"] for v in range(V)]
+        infos16 = [Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, list_tile=16)["info"] for v in range(V)]
+        M16 = [i["n_isects"] for i in infos16]
+        vis_masks = [(i["radii"].reshape(-1) > 0) for i in infos16] if world > 1 else None
+        del infos16
     torch.cuda.synchronize()
 
     stats = {}
+    plan = None
     use_graph = not args.no_graph and not dense
     frame = None
     if use_graph:
         # the views are captured with the roofline kernel bracketed by timing marks (event-record nodes: re-recorded by every replay)
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
-        frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                           overlap=not args.no_overlap, exchange=fx)
+        def build_frame(exchange):
+            return FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
+                              overlap=not args.no_overlap, exchange=exchange)
+        frame = build_frame(fx)
+        if world > 1 and args.exchange == "auto":
+            # price the two exchanges from what this job measures: the ranks' unions per view, one rank's frame, the fabric
+            from bilateral_driving_amd.dist import measure_busbw, plan_exchange, union_row_counts
+            unions = union_row_counts(vis_masks)
+            local = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
+                               overlap=not args.no_overlap) if fx.active else frame
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                local.step(wait=False, local=True)
+            torch.cuda.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            plan = plan_exchange(unions, N, fx.row_floats, flat.total - N * fx.row_floats, world, float(tt[0]), measure_busbw(dev))
+            if plan["per_view"] != fx.per_view:
+                del frame, local
+                torch.cuda.empty_cache()
+                fx = FrameExchange(flat, fx_names, per_view=plan["per_view"])
+                frame = build_frame(fx)
+            else:
+                del local
         L.enable_timers(False)
 
     def step(s):
@@ -625,7 +657,8 @@ def main():
                                   "autograd (forward, loss, loss.backward())",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
-                   "exchanges_per_step": fx.n_exchanges if world > 1 else 0},
+                   "exchanges_per_step": fx.n_exchanges if world > 1 else 0,
+                   "exchange": None if world == 1 else dict(mode="view" if fx.per_view else "frame", chosen_by=args.exchange, plan=plan)},
         "roofline": roofline,
         "roofline_composite": roofline_composite,
         "valu": valu,

@@ -228,7 +228,8 @@ class FrameExchange:
     World size 1: ``view_kwargs`` selects the in-place arena modes of ``fused_view`` and nothing is exchanged.  ``force=True`` runs the
     compact path without any collective (single-GPU test of the kernels the exchange depends on)."""
 
-    def __init__(self, flat: FlatGradients, names: Iterable[str], headroom: float = 1.25, n_buffers: int = 3, force: bool = False):
+    def __init__(self, flat: FlatGradients, names: Iterable[str], headroom: float = 1.25, n_buffers: int = 3, force: bool = False,
+                 per_view: bool = True):
         self.flat = flat
         self.names = list(names)
         assert flat.sparse_rows, "FrameExchange keeps the dense buffer clean row-wise: FlatGradients(sparse_rows=True)"
@@ -238,7 +239,12 @@ class FrameExchange:
         self.K = self.arena["sh"].shape[1]
         self.row_floats = 3 + 4 + 3 + 1 + self.K * 3
         self.world = dist.get_world_size() if _active() else 1
-        self.active = bool(force) or self.world > 1
+        # per_view=False: the frame's gradients accumulate in place exactly as at world size 1 and ``end_frame`` sums the dense buffer over
+        # the ranks ONCE (fewer bytes than the per-view exchanges when the ranks' unions approach the whole scene, none of them hidden:
+        # ``plan_exchange`` prices the two)
+        self.per_view = bool(per_view)
+        self.frame_reduce = self.world > 1 and not self.per_view and not force
+        self.active = bool(force) or (self.world > 1 and self.per_view)
         self.headroom, self.n_buffers = float(headroom), int(n_buffers)
         n_row = sum(v.numel() for v in flat._views[:len(ROW_NAMES)])
         self._tail = flat.flat[n_row:] if (not self.active and flat.total > n_row) else None
@@ -470,7 +476,10 @@ class FrameExchange:
 
     def end_frame(self) -> None:
         """After the last view: drain the exchanges, check the frame's union counts (raises BEFORE the caller's optimizer step if one
-        outgrew the capacity) and sum the small dense tail (grids, ...) over the ranks."""
+        outgrew the capacity) and sum the small dense tail (grids, ...) over the ranks.  ``per_view=False``: the one dense all-reduce."""
+        if self.frame_reduce:
+            self.reduce_frame()
+            return
         if not self.active:
             return
         while self._pending:
@@ -489,6 +498,14 @@ class FrameExchange:
             if self.world > 1:
                 dist.all_reduce(tail, op=dist.ReduceOp.SUM)
                 self.payload_bytes += tail.numel() * 4
+
+    def reduce_frame(self) -> None:
+        """``per_view=False``: sum the whole flat gradient buffer over the ranks (on the current stream; RCCL orders it behind the frame's
+        kernels).  Rows other ranks wrote are non-zero afterwards: the next ``begin_frame`` clears the buffer densely."""
+        assert self.frame_reduce
+        dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
+        self.flat._dirty, self.flat._clean = None, False
+        self.payload_bytes, self.n_exchanges = self.flat.nbytes, 1
 
     # ---- internals -------------------------------------------------------------------------------------------------
     def _wanted_cap(self) -> int:
@@ -598,3 +615,65 @@ def refinement_after_synced(model, step: int, optimizer, stats=None, verbose: bo
 def view_for_rank(step: int, rank: int, world: int, n_views: int) -> int:
     """Round-robin view assignment: at step s, rank r renders view (s*world + r) mod n_views."""
     return (step * world + rank) % n_views
+
+
+def measure_busbw(device, nbytes: int = 256 << 20, iters: int = 3) -> float:
+    """Bus bandwidth (bytes / s, the rccl-tests convention: 2 (n-1)/n x message / time) of a SUM all-reduce of ``nbytes`` over the
+    process group as it is -- RCCL over xGMI on a multi-GPU node, gloo when the ranks share a device.  Collective; 0.0 at world size 1."""
+    if not _active():
+        return 0.0
+    import time
+    n = dist.get_world_size()
+    buf = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
+    dist.all_reduce(buf)                      # (connection set-up)
+    if buf.is_cuda:
+        torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    if buf.is_cuda:
+        torch.cuda.synchronize(device)
+    dt = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    return 2.0 * (n - 1) / n * nbytes / float(dt[0])
+
+
+def union_row_counts(masks: Iterable[Tensor]) -> List[int]:
+    """Per view: how many Gaussians at least one rank sees (``masks``: this rank's uint8 / bool visibility mask of every view of its
+    frame, [N] each).  Collective; identical on every rank."""
+    out = []
+    for m in masks:
+        u = m.reshape(-1).to(torch.uint8).clone()
+        if _active():
+            dist.all_reduce(u, op=dist.ReduceOp.MAX)
+        out.append(int(u.sum()))
+    return out
+
+
+def plan_exchange(union_counts: Iterable[int], n_rows: int, row_floats: int, tail_floats: int, world: int, frame_seconds: float,
+                  busbw: float, headroom: float = 1.25) -> dict:
+    """Price the two ways a frame's gradients can be summed over ``world`` ranks, from measured inputs only: the per-view unions of
+    the ranks' visible sets (``union_row_counts``), one rank's compute time per frame and the fabric's all-reduce bus bandwidth
+    (``measure_busbw``).
+
+      per view  -- V all-reduces of ``headroom x max union`` compact rows each; all but the last run behind the following view's
+                   compute, so the exposed time is what the wire needs beyond (V-1)/V of the frame + the last view's exchange;
+      per frame -- one all-reduce of the dense buffer, fully exposed.
+
+    Returns both prices and ``per_view`` = the cheaper one (``FrameExchange(per_view=...)``).  Deterministic in its inputs, which are
+    identical on every rank when ``frame_seconds`` / ``busbw`` were max-reduced over the ranks."""
+    counts = [int(c) for c in union_counts]
+    V = max(len(counts), 1)
+    ring = 2.0 * (world - 1) / max(world, 1)
+    cap = min(int(max(counts, default=0) * headroom) + 64, n_rows)
+    view_bytes = cap * row_floats * 4
+    dense_bytes = (n_rows * row_floats + tail_floats) * 4
+    bw = max(float(busbw), 1.0)
+    wire_view = ring * view_bytes / bw                     # seconds per view's exchange
+    hidden = frame_seconds * (V - 1) / V
+    exposed_view = max(0.0, (V - 1) * wire_view - hidden) + wire_view + ring * tail_floats * 4 / bw
+    exposed_frame = ring * dense_bytes / bw
+    return {"per_view": bool(exposed_view <= exposed_frame), "exposed_per_view_ms": exposed_view * 1e3, "exposed_per_frame_ms": exposed_frame * 1e3,
+            "per_view_bytes": V * view_bytes + tail_floats * 4, "per_frame_bytes": dense_bytes, "busbw_GBps": bw / 1e9,
+            "frame_compute_ms": frame_seconds * 1e3, "union_fraction": max(counts, default=0) / max(n_rows, 1)}

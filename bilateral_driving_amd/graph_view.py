@@ -32,6 +32,9 @@ With an ``exchange`` (``dist.FrameExchange``; one process per GPU, every rank it
 all-reduce of the visibility mask after the forward, SUM all-reduce of the compact gradient rows after the Gaussian half -- are
 enqueued BETWEEN the graphs.  ``valid()`` / ``recapture()`` are then COLLECTIVE calls: the ranks agree (one MAX all-reduce of their
 flags) before any of them captures again, because a capture's warm-up frame issues collectives of its own.
+``FrameExchange(per_view=False)``: nothing between the graphs -- the frame replays exactly as on one GPU (both streams, in-place
+accumulation) and ``step()`` ends with ONE dense all-reduce of the flat gradient buffer on the caller's stream; the next frame
+clears that buffer densely (other ranks' rows are in it).  ``dist.plan_exchange`` prices the two modes.
 
 A graph holds device addresses: after anything that re-allocates a parameter (densification) call ``recapture()``.  Overflow
 protocol: a view whose list counts outgrow their capacities renders NOTHING (effective counts zero, bds_isect_prepare_dev) and raises
@@ -123,6 +126,9 @@ class FrameGraph:
         self.N, self.K = self.params["means"].shape[0], self.params["sh"].shape[1]
         self.names = list(ROW_NAMES) + [f"grid{i}" for i in range(len(self.grids))]
         self.fx = exchange if (exchange is not None and exchange.active) else None
+        self.world = exchange.world if exchange is not None else 1
+        # FrameExchange(per_view=False) at world size > 1: the frame runs exactly as on one GPU and step() ends with ONE dense all-reduce
+        self._frame_fx = exchange if (exchange is not None and exchange.frame_reduce) else None
         assert not (self.dynamic and self.fx is not None), "replayable views with an exchange: not built (the reference's loop is one GPU)"
         if exchange is not None:
             by_name = dict(self.params, **{f"grid{i}": g for i, g in enumerate(self.grids)})
@@ -300,7 +306,7 @@ class FrameGraph:
     def _capturing(self, graph, pool):
         """``torch.cuda.graph`` for this frame's captures.  With an exchange other threads of the process issue HIP calls of their own
         while we capture (RCCL's proxy, the process group's watchdog): only THIS thread's unsafe calls may invalidate the capture."""
-        if self.fx is not None:
+        if self.world > 1:
             return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
         return torch.cuda.graph(graph, pool=pool)
 
@@ -400,12 +406,12 @@ class FrameGraph:
     recapture = capture
 
     # ---- replay ------------------------------------------------------------------------------------------------------------------
-    def step(self, serial: bool = False, wait: bool = True) -> Optional[bool]:
+    def step(self, serial: bool = False, wait: bool = True, local: bool = False) -> Optional[bool]:
         """One frame: clear the previous frame's gradient rows, then every view (forward + loss + backward), gradients summed (over
         the ranks too, with an exchange).  ``wait`` (default): waits for the frame and returns ``valid()`` -- False: a list overflowed,
         the gradients are incomplete and must not reach the optimizer; with ``wait=False`` nothing is waited for and None is returned
         (call ``valid()`` before trusting the gradients).  ``serial``: every graph on the caller's stream, one after the other
-        (measurement)."""
+        (measurement).  ``local``: leave out the per-frame all-reduce of ``FrameExchange(per_view=False)`` (timing one rank's compute)."""
         if self._reprovision:       # capacities that came close to their limit in the last (valid, consumed) frame
             self.capture()
         if self._stale:             # clear_grads=False and nobody consumed the invalid frame's gradients
@@ -413,6 +419,8 @@ class FrameGraph:
             self._stale = False
         fx = self.fx
         main = torch.cuda.current_stream(self.dev)
+        if self._frame_fx is not None:   # the last frame's all-reduce left the other ranks' rows behind: the row-wise clear does not know them
+            self.flat.flat.zero_()
         self._frame_begin()
         self.begin_graph.replay()
         rest = self.begin_graph_rest
@@ -453,6 +461,8 @@ class FrameGraph:
                     fx.static_end_frame()
             vg.done.record(main)
         self._sum_pose_slots()
+        if self._frame_fx is not None and not local:
+            self._frame_fx.reduce_frame()     # (on this stream: whoever consumes the gradients on it is ordered behind the collective)
         return self.valid() if wait else None
 
     def _sum_pose_slots(self) -> None:
@@ -493,7 +503,7 @@ class FrameGraph:
     def _agree(self, overflowed: bool, wants_more: bool):
         """The ranks' decision: (any rank overflowed, any rank wants larger lists).  A list count is rank-local -- one rank capturing
         again while its peers step on would pair its warm-up frame's collectives with their frame's."""
-        if self.fx is None or self.fx.world == 1:
+        if self.world == 1:
             return overflowed, wants_more
         import torch.distributed as dist
         flags = torch.tensor([int(overflowed), int(wants_more)], device=self.dev, dtype=torch.int32)

@@ -298,6 +298,79 @@ def test_frame_exchange_equals_sequential_sum_over_views_and_ranks():
     assert res[0][4] == res[1][4] and res[0][4] % 4 == 0               # same capacity on every rank, 16-byte aligned sub-arrays
 
 
+def _fx_frame_worker(rank, world, port, q):
+    """FrameExchange(per_view=False): every view accumulates in place as at world size 1 (arena modes); ONE dense all-reduce per frame."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    params = _fx_params()
+    flat = FlatGradients(params, sparse_rows=True)
+    fx = FrameExchange(flat, _FX_NAMES, per_view=False)
+    assert not fx.active and fx.frame_reduce and fx.world == world
+    outs = []
+    for frame in range(_FX_FRAMES):
+        fx.begin_frame()
+        tail = fx.tail_grads()
+        for v in range(_FX_VIEWS):
+            kw = fx.view_kwargs(v)
+            assert kw["arena_rows"] == (1 if v == 0 else 2)
+            ids, rows, grid_grad = _fx_view(rank, frame, v)
+            fx.begin_view({"radii": None, "visible_ids": ids})
+            for k, r in rows.items():     # ... the fused view's backward, arena mode: rows of the visible Gaussians added in place
+                kw["grad_arena"][k].index_add_(0, ids.long(), r)
+            tail[0].add_(grid_grad)
+            fx.end_view()
+        fx.end_frame()
+        outs.append(flat.flat.clone())
+        assert fx.payload_bytes == flat.nbytes and fx.n_exchanges == 1
+    q.put((rank, [o.numpy() for o in outs]))
+    dist.destroy_process_group()
+
+
+def test_frame_exchange_per_frame_mode_equals_sequential_sum():
+    """The other exchange: one dense all-reduce at the end of the frame; rows the OTHER ranks wrote are cleared before the next frame."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fx_frame_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [tuple(p.shape) for p in _fx_params()]
+    for frame in range(_FX_FRAMES):
+        ref = [torch.zeros(s) for s in shapes]
+        for rank in range(world):
+            for v in range(_FX_VIEWS):
+                ids, rows, grid_grad = _fx_view(rank, frame, v)
+                for i, k in enumerate(_FX_NAMES[:5]):
+                    ref[i].index_add_(0, ids.long(), rows[k])
+                ref[5] += grid_grad
+        ref = torch.cat([r.reshape(-1) for r in ref]).numpy()
+        for r in range(world):
+            assert abs(res[r][1][frame] - ref).max() < 1e-5, (frame, r)
+
+
+def test_plan_exchange_prices_the_two_exchanges():
+    """dist.plan_exchange on the sizes measured for the benchmark scene (profiles/r05i_bench_share*.json: unions of 18 / 27 / 47 % of 2 M
+    Gaussians at 2 / 4 / 8 ranks, 5.9 ms of compute per frame): per view while the exchanges hide behind the next view, per frame once
+    the wire time of six union buffers exceeds the frame; a slow fabric flips the choice earlier, a fast one later."""
+    from bilateral_driving_amd.dist import plan_exchange
+    N = 2_000_000
+    plans = {w: plan_exchange([int(f * N)] * 6, N, 59, 50_000, w, 5.9e-3, 300e9) for w, f in ((2, 0.18), (4, 0.27), (8, 0.47))}
+    assert plans[2]["per_view"] and plans[4]["per_view"] and not plans[8]["per_view"]
+    assert plans[8]["per_frame_bytes"] == (N * 59 + 50_000) * 4 and plans[8]["per_view_bytes"] > 3 * plans[8]["per_frame_bytes"]
+    assert abs(plans[8]["exposed_per_frame_ms"] - 1.75 * (N * 59 + 50_000) * 4 / 300e9 * 1e3) < 1e-6
+    assert not plan_exchange([int(0.27 * N)] * 6, N, 59, 50_000, 4, 5.9e-3, 100e9)["per_view"]      # a third of the bandwidth: nothing hides
+    assert plan_exchange([int(0.47 * N)] * 6, N, 59, 50_000, 8, 5.9e-3, 900e9)["per_view"]
+    one = plan_exchange([N // 10], N, 59, 0, 1, 1e-3, 0.0)                                            # world size 1: nothing on the wire
+    assert one["exposed_per_view_ms"] == 0.0 and one["exposed_per_frame_ms"] == 0.0
+
+
 def test_frame_exchange_single_process_uses_the_arena_modes():
     from bilateral_driving_amd.dist import FlatGradients, FrameExchange
     params = _fx_params()

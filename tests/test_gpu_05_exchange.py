@@ -66,14 +66,14 @@ def _run_frames(Hn, cams, base, grids0, sky, target, force, frames=2):
     return outs, fx
 
 
-def _run_frames_graph(Hn, cams, base, grids0, sky, target, force, frames=3, overlap=True):
+def _run_frames_graph(Hn, cams, base, grids0, sky, target, force, frames=3, overlap=True, per_view=True):
     """The same frames as hipGraphs (graph_view.FrameGraph): per view three graphs, the exchange's collectives between them."""
     from bilateral_driving_amd.dist import FlatGradients, FrameExchange
     from bilateral_driving_amd.graph_view import FrameGraph
     p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
     grids = [g.clone().requires_grad_(True) for g in grids0]
     flat = FlatGradients(list(p.values()) + grids, sparse_rows=True)
-    fx = FrameExchange(flat, list(p.keys()) + [f"grid{i}" for i in range(len(grids))], force=force)
+    fx = FrameExchange(flat, list(p.keys()) + [f"grid{i}" for i in range(len(grids))], force=force, per_view=per_view)
     frame = FrameGraph(p, cams, grids, [sky.clone() for _ in cams], [target for _ in cams], exchange=fx, overlap=overlap)
     outs = []
     for _ in range(frames):
@@ -144,7 +144,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, graph=False):
+def _worker(rank, world, port, q, graph=False, per_view=True):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -152,23 +152,24 @@ def _worker(rank, world, port, q, graph=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     Hn, cams, base, grids0, sky, target = _setup("cuda", origin=(1.5 * rank, 0.0, 0.0))
     if graph:
-        outs, fx, _ = _run_frames_graph(Hn, cams, base, grids0, sky, target, force=False)
+        outs, fx, _ = _run_frames_graph(Hn, cams, base, grids0, sky, target, force=False, per_view=per_view)
     else:
         outs, fx = _run_frames(Hn, cams, base, grids0, sky, target, force=False)
-    assert fx.active and fx.world == world
+    assert fx.active == per_view and fx.frame_reduce == (not per_view) and fx.world == world
     q.put((rank, [o.cpu().numpy() for o in outs], fx.cap, fx.payload_bytes))   # numpy: a pickled copy, no fd hand-over to wait for
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph,world", [(False, 2), (True, 2), (True, 4), (True, 8)])
-def test_ranks_sharing_the_gpu_frame_exchange_equals_sequential_sum(graph, world):
+@pytest.mark.parametrize("graph,world,per_view", [(False, 2, True), (True, 2, True), (True, 4, True), (True, 8, True), (True, 2, False), (True, 4, False)])
+def test_ranks_sharing_the_gpu_frame_exchange_equals_sequential_sum(graph, world, per_view):
     """2 / 4 / 8 ranks (one process each, all on cuda:0, gloo between them) through the eager frame loop and through the graph frames
     (the collectives between a view's graphs): every rank ends every frame with the sum over all ranks' views; the union of the
-    visible sets grows with the rank count (more of the drive is seen) and the exchange capacity follows it."""
+    visible sets grows with the rank count (more of the drive is seen) and the exchange capacity follows it.  ``per_view=False``: the
+    frame replays as on one GPU and ends with one dense all-reduce (``FrameExchange(per_view=False)``)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph, per_view)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
@@ -183,5 +184,7 @@ def test_ranks_sharing_the_gpu_frame_exchange_equals_sequential_sum(graph, world
             assert float((torch.from_numpy(o) - ref).norm() / ref.norm()) < 1e-3          # 1e-3 rel (atomics order)
     for r in range(1, world):     # replicas: same capacity, identical reduced gradients, same payload
         assert res[r][2] == res[0][2] and (res[r][1][-1] == res[0][1][-1]).all() and res[r][3] == res[0][3]
+    if not per_view:
+        assert res[0][2] == 0 and res[0][3] == (N * 59 + sum(g.numel() for g in grids0)) * 4      # no compact buffers; the dense buffer once
     print(f"[exchange] world {world}: capacity {res[0][2]} rows of {N} ({res[0][2] / N:.0%}), {res[0][3]} bytes all-reduced per rank and frame "
           f"(dense: {N * 59 * 4 * len(YAWS)})")
