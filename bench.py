@@ -283,7 +283,7 @@ def main():
     L.lib()  # fail loudly if libbds.so is missing
     if os.environ.get("BDS_DEBUG_OPTION"):   # kernel A/B hooks (include/bds.h: option 3), measurement sessions only
         L.set_option(3, int(os.environ["BDS_DEBUG_OPTION"]))
-    for env, which in (("BDS_PAD_BWD_KB", 1), ("BDS_PAD_FWD_KB", 2), ("BDS_CELLS", 7)):   # (tuning hooks: cap the compositors' resident waves)
+    for env, which in (("BDS_PAD_BWD_KB", 1), ("BDS_PAD_FWD_KB", 2), ("BDS_CELLS", 7), ("BDS_SCHED_BINS", 8)):   # (tuning hooks: cap the compositors' resident waves)
         if os.environ.get(env):
             L.set_option(which, int(os.environ[env]))
     wl = dict(WORKLOADS[args.workload])
@@ -309,7 +309,8 @@ def main():
     # per-view exchange buffers (dist.FrameExchange)
     flat = FlatGradients(list(params.values()) + grids, sparse_rows=True)
     fx_names = list(params.keys()) + [f"grid{i}" for i in range(len(grids))]
-    fx = FrameExchange(flat, fx_names, per_view=args.exchange != "frame")
+    # (auto: the per-frame form is built first -- its step(local=True) is one rank's compute time without a second build)
+    fx = FrameExchange(flat, fx_names, per_view=args.exchange == "view")
 
     # (16-px tile, Gaussian) pairs per view = the intersections of the reference's algorithm (SURVEY.md 8d counts bytes per such pair);
     # the fused view builds its lists for larger tiles (fused_view.LIST_TILE) and never materialises them, so they are counted once here
@@ -337,23 +338,19 @@ def main():
             # price the two exchanges from what this job measures: the ranks' unions per view, one rank's frame, the fabric
             from bilateral_driving_amd.dist import measure_busbw, plan_exchange, union_row_counts
             unions = union_row_counts(vis_masks)
-            local = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
-                               overlap=not args.no_overlap) if fx.active else frame
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3):
-                local.step(wait=False, local=True)
+                frame.step(wait=False, local=True)
             torch.cuda.synchronize()
             tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             plan = plan_exchange(unions, N, fx.row_floats, flat.total - N * fx.row_floats, world, float(tt[0]), measure_busbw(dev))
-            if plan["per_view"] != fx.per_view:
-                del frame, local
+            if plan["per_view"]:
+                del frame
                 torch.cuda.empty_cache()
-                fx = FrameExchange(flat, fx_names, per_view=plan["per_view"])
+                fx = FrameExchange(flat, fx_names, per_view=True)
                 frame = build_frame(fx)
-            else:
-                del local
         L.enable_timers(False)
 
     def step(s):

@@ -76,8 +76,9 @@ _SIGS = {
     "bds_isect_counts_offset": (_sz, [_i]),
     "bds_isect_prepare_dev": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _i64, _i64, _f, _i, _f]),
     "bds_isect_build_dev": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _i, _f]),
-    "bds_splat_pack_sh_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f]),
-    "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f]),
+    "bds_splat_pack_sh_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
+    "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
+    "bds_rasterize_schedule_ints": (_i64, [_i, _i, _i]),
     "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd_schedule_sort": (_i, [_i, _i, _i, _f, _f]),
     "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
@@ -180,6 +181,7 @@ def lib():
 
 SPLAT_RECORD_FLOATS, GRAD_RECORD_FLOATS, POSE_GRAD_SLOTS = 12, 16, 64
 OPT_DEBUG = 3          # profiling only: ablation mask
+OPT_SCHED_BINS = 8     # device-count compositor: 1 [default] = the forward's waves bin the backward's schedule, 0 = a sort launch (include/bds.h)
 OPT_CELLS = 7          # bilateral transform, bit mask [default 3]: 1 = cell-aligned kernels, 2 = one-pass pyramid forward, 0 = general kernels (include/bds.h)
 LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 64      # slotted loss accumulators (include/bds.h BDS_LOSS_SLOT_STRIDE)
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)

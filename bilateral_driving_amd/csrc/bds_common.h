@@ -112,7 +112,8 @@ int prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlots *ou
 // test hooks (bds_set_option): force the large-input fallback paths of the tile stage; see include/bds.h
 enum Option { kOptPadBwd = 1 /* tuning: KB of unused LDS per workgroup of the compositor backward */, kOptPadFwd = 2 /* ... forward */,
               kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptPacked = 6,
-              kOptCells = 7 /* bilateral transform, bit 0: cell-aligned kernels where a level qualifies, bit 1: one-pass pyramid forward; 0 = general kernels */, kOptCount = 8 };
+              kOptCells = 7 /* bilateral transform, bit 0: cell-aligned kernels where a level qualifies, bit 1: one-pass pyramid forward; 0 = general kernels */,
+              kOptSchedBins = 8 /* device-count form: the forward compositor bins the backward's schedule itself (no sort launch) */, kOptCount = 9 };
 int option_get(int which);
 
 }  // namespace bds

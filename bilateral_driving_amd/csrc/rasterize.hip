@@ -44,9 +44,39 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 // Work item of a workgroup: the XCD-contiguous position, optionally redirected through a schedule
 // (bds_rasterize_bwd_schedule: each XCD's range re-ordered longest tile first, see below).
+// Schedule buffer (int32, bds_rasterize_schedule_ints): word 0 tags the form.
+//   sorted (tag 1): [1 | order[total] | work[total]] -- bds_rasterize_bwd_schedule(_sort): every XCD's range of tiles ordered by a
+//                   counting sort over 1024 linear bins of the tiles' visited lengths;
+//   binned (tag 0): [0 | count[8][32] | list[8][32][total / 8 + 1]] -- device-count form: every compositing wave of the FORWARD drops
+//                   its tile into the bin of its visited length (32 bins a factor 2^(1/4) apart, longest first) of its XCD's range
+//                   with one atomic; the backward's workgroup resolves (range, slot) -> bin by a prefix walk over the 32 counts.  No sort launch
+//                   between the passes; the header is cleared by the record pack in front of the forward (bds_splat_pack*_dev).
+constexpr int kSchedXcd = 8, kSchedLogBins = 32, kSchedHeader = 1 + kSchedXcd * kSchedLogBins;
+__host__ __device__ __forceinline__ int sched_stride(int total) { return total / kSchedXcd + 1; }
+__device__ __forceinline__ int sched_bin(int w) {   // 0 = longest ... kSchedLogBins - 1 = nothing to do
+  if (w <= 0) return kSchedLogBins - 1;
+  const int lz = 31 - __clz(w);
+  const int h = 4 * lz + (lz >= 2 ? ((w >> (lz - 2)) & 3) : 0);   // floor(4 log2 w) (to the next two mantissa bits)
+  return min(max(57 - h, 0), kSchedLogBins - 2);                   // bin 0: >= 20 480 entries; bin 30: < 128
+}
+
 __device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int bid, int total) {
   const int p = xcd_contiguous(bid, total);
-  return order ? order[p] : p;
+  if (!order) return p;
+  if (order[0] != 0) return order[1 + p];
+  // (all counts are read unconditionally -- wave-uniform addresses: a few wide scalar loads and a scalar prefix walk, no vector
+  // registers and no chain of dependent loads in front of a kernel that sits on its register budget)
+  const int x = bid % kSchedXcd, slot = bid / kSchedXcd;
+  const int32_t *__restrict__ cnt = order + 1 + x * kSchedLogBins;
+  int acc = 0, sel = -1, before = 0;
+#pragma unroll
+  for (int b = 0; b < kSchedLogBins; b++) {
+    const int c = cnt[b];
+    if (sel < 0 && slot < acc + c) { sel = b; before = acc; }
+    acc += c;
+  }
+  if (sel >= 0) return order[kSchedHeader + (x * kSchedLogBins + sel) * sched_stride(total) + (slot - before)];
+  return p;   // (a header nobody filled: plain order)
 }
 
 // ---- splat records --------------------------------------------------------------------------------------
@@ -58,11 +88,14 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n_cap, c
                                                                const float *__restrict__ colors, const float *__restrict__ opacities,
                                                                const int32_t *__restrict__ radii, float4 *__restrict__ rec,
                                                                float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
-                                                               int zero_tail_f4) {
+                                                               int zero_tail_f4, int32_t *__restrict__ schedule) {
   // (fused view: the gradient record of every packed row -- what the composite backward accumulates into -- and the camera-pose
-  // gradient slots behind them are cleared here instead of by a fill launch of their own)
+  // gradient slots behind them are cleared here instead of by a fill launch of their own; likewise the header of the binned
+  // backward schedule the forward compositor is about to fill)
   if (zero_tail && blockIdx.x == 0)
     for (int i = threadIdx.x; i < zero_tail_f4; i += kPackBlock) zero_tail[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (schedule && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kSchedHeader; i += kPackBlock) schedule[i] = 0;
   const int64_t n = list_length(n_cap, n_dev);
   const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
   if (r >= n) return;
@@ -96,7 +129,7 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
                                                                   const float *__restrict__ opacities, const int32_t *__restrict__ radii,
                                                                   float4 *__restrict__ rec, float *__restrict__ sh_rgb_out,
                                                                   float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
-                                                                  int zero_tail_f4) {
+                                                                  int zero_tail_f4, int32_t *__restrict__ schedule) {
   constexpr int nb = (DEG + 1) * (DEG + 1);
   constexpr int n4 = (nb * 3 + 3) / 4;       // 16-byte pieces of a coefficient row the colour needs
   constexpr int ldr = n4 * 4 + 4;            // LDS row stride (floats): 16-byte aligned, an odd number of 16-byte pieces
@@ -107,6 +140,8 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
   __shared__ int32_t s_g[kPackShBlock];
   if (zero_tail && blockIdx.x == 0)   // (as splat_pack_kernel: the gradient records / pose slots are cleared on the way)
     for (int i = threadIdx.x; i < zero_tail_f4; i += kPackShBlock) zero_tail[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (schedule && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kSchedHeader; i += kPackShBlock) schedule[i] = 0;
   const int64_t n = list_length(n_cap, n_dev);
   const int64_t r0 = (int64_t)blockIdx.x * kPackShBlock;
   if (r0 >= n) return;
@@ -178,6 +213,7 @@ __device__ __forceinline__ float splat_exponent(float eadx2, float ebdx, float e
 struct ListGeom {
   int div, w, h;   // compositing tiles per list tile (per axis); list tiles per row / column
   int total;       // C * w * h lists
+  int sched;       // forward's tile_work argument: 0 = a work array, 1 = the binned schedule buffer (see pick_item)
 };
 
 __device__ __forceinline__ bool tile_candidate_hit(const float4 &A, const float4 &B, const float4 &Cr, int tx, int ty, int tile_w,
@@ -343,7 +379,16 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     // the backward's schedule key: how far into its list this tile blended (what tile_work_kernel re-derives from last_ids; pixels
     // outside the image and pixels that blended nothing hold 0)
     const int m = wave_max_i32(max(max(cur[0], cur[1]), max(cur[2], cur[3])));
-    if (lane == 0) tile_work[item] = max(0, m - start + 1);
+    const int w = max(0, m - start + 1);
+    if (lane == 0) {
+      if (lg.sched) {   // binned: the tile joins its length's bin of this XCD's range (the range xcd_contiguous gave this workgroup)
+        const int x = (int)blockIdx.x % kSchedXcd, slot = x * kSchedLogBins + sched_bin(w), stride = sched_stride(C * n_tiles);
+        const int pos = atomicAdd(tile_work + 1 + slot, 1);
+        if (pos < stride) tile_work[kSchedHeader + slot * stride + pos] = item;
+      } else {
+        tile_work[item] = w;
+      }
+    }
   }
 }
 
@@ -583,7 +628,7 @@ __global__ __launch_bounds__(kWorkBlock) void tile_work_kernel(int C, int W, int
 
 constexpr int kSchedThreads = 1024, kSchedBins = 1024;
 __global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, const int32_t *__restrict__ work,
-                                                                   int32_t *__restrict__ order) {
+                                                                   int32_t *__restrict__ order, int32_t *__restrict__ tag) {
   __shared__ int hist[kSchedBins];
   __shared__ int s_max;
   constexpr int kXcd = 8;
@@ -591,6 +636,7 @@ __global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, co
   const int cnt = per + (x < rem ? 1 : 0), first = x * per + (x < rem ? x : rem);
   const int tid = threadIdx.x;
   if (tid == 0) s_max = 0;
+  if (tid == 0 && x == 0) *tag = 1;   // (the sorted form of the schedule buffer: pick_item)
   for (int b = tid; b < kSchedBins; b += kSchedThreads) hist[b] = 0;
   __syncthreads();
   int lmax = 0;
@@ -627,7 +673,7 @@ using namespace bds;
 
 static int splat_pack_impl(int64_t n, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d, const float *conics,
                            const float *colors, const float *opacities, const int32_t *radii, float *records, float *zero_records,
-                           float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream) {
+                           float *zero_tail, int64_t zero_tail_floats, int32_t *schedule, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && (CH == 1 || CH == 3 || CH == 4));
   BDS_REQUIRE(zero_tail_floats >= 0 && zero_tail_floats % 4 == 0 && zero_tail_floats < ((int64_t)1 << 24));
   BDS_REQUIRE(!zero_records || aligned16(zero_records));
@@ -635,6 +681,7 @@ static int splat_pack_impl(int64_t n, const uint64_t *n_dev, int CH, const int32
   if (n == 0) {
     if (zero_tail && zero_tail_floats &&
         hipMemsetAsync(zero_tail, 0, sizeof(float) * zero_tail_floats, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
+    if (schedule && hipMemsetAsync(schedule, 0, sizeof(int32_t) * kSchedHeader, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
     return BDS_OK;
   }
   BDS_REQUIRE(means2d && conics && colors && opacities && records && aligned16(records));
@@ -645,7 +692,7 @@ static int splat_pack_impl(int64_t n, const uint64_t *n_dev, int CH, const int32
   const int zt4 = (int)(zero_tail_floats / 4);
   hipStream_t st = as_stream(stream);
 #define BDS_PACK(ch) \
-  hipLaunchKernelGGL((splat_pack_kernel<ch>), grid, block, 0, st, n, n_dev, ids, means2d, conics, colors, opacities, radii, rec, zr, zt, zt4)
+  hipLaunchKernelGGL((splat_pack_kernel<ch>), grid, block, 0, st, n, n_dev, ids, means2d, conics, colors, opacities, radii, rec, zr, zt, zt4, schedule)
   if (CH == 1) BDS_PACK(1);
   else if (CH == 3) BDS_PACK(3);
   else BDS_PACK(4);
@@ -737,28 +784,29 @@ extern "C" int bds_expected_depth_bwd(int64_t P, int channels, int expected_dept
 
 extern "C" int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
                               const float *opacities, const int32_t *radii, float *records, bds_stream_t stream) {
-  return splat_pack_impl(n, nullptr, CH, ids, means2d, conics, colors, opacities, radii, records, nullptr, nullptr, 0, stream);
+  return splat_pack_impl(n, nullptr, CH, ids, means2d, conics, colors, opacities, radii, records, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d,
                                   const float *conics, const float *colors, const float *opacities, const int32_t *radii,
                                   float *records, float *zero_records, float *zero_tail, int64_t zero_tail_floats,
-                                  bds_stream_t stream) {
+                                  int32_t *schedule, bds_stream_t stream) {
   BDS_REQUIRE(n_dev);
   return splat_pack_impl(n_capacity, n_dev, CH, ids, means2d, conics, colors, opacities, radii, records, zero_records, zero_tail,
-                         zero_tail_floats, stream);
+                         zero_tail_floats, schedule, stream);
 }
 
 static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
                               const float *cam_pos, const float *coeffs, const float *means2d, const float *conics, const float *depths,
                               const float *opacities, const int32_t *radii, float *records, float *sh_rgb, float *zero_records,
-                              float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream) {
+                              float *zero_tail, int64_t zero_tail_floats, int32_t *schedule, bds_stream_t stream) {
   BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
   BDS_REQUIRE(zero_tail_floats >= 0 && zero_tail_floats % 4 == 0 && zero_tail_floats < ((int64_t)1 << 24));
   BDS_REQUIRE((!zero_records || aligned16(zero_records)) && (!zero_tail || aligned16(zero_tail)));
   if (n == 0) {
     if (zero_tail && zero_tail_floats &&
         hipMemsetAsync(zero_tail, 0, sizeof(float) * zero_tail_floats, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
+    if (schedule && hipMemsetAsync(schedule, 0, sizeof(int32_t) * kSchedHeader, as_stream(stream)) != hipSuccess) return BDS_ELAUNCH;
     return BDS_OK;
   }
   BDS_REQUIRE(ids && means && cam_pos && coeffs && means2d && conics && depths && opacities && radii && records && sh_rgb);
@@ -771,7 +819,7 @@ static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *i
 #define BDS_PACK_SH(d)                                                                                                                 \
   hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, sizeof(float) * kPackShBlock * ((((d + 1) * (d + 1) * 3 + 3) / 4) * 4 + 4), st, \
                      n, n_dev, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
-                     opacities, radii, rec, sh_rgb, zr, zt, zt4)
+                     opacities, radii, rec, sh_rgb, zr, zt, zt4, schedule)
   switch (deg) {
     case 0: BDS_PACK_SH(0); break;
     case 1: BDS_PACK_SH(1); break;
@@ -787,16 +835,17 @@ extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, 
                                  const float *coeffs, const float *means2d, const float *conics, const float *depths,
                                  const float *opacities, const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream) {
   return splat_pack_sh_impl(n, nullptr, ids, K, deg, means, cam_pos, coeffs, means2d, conics, depths, opacities, radii, records, sh_rgb,
-                            nullptr, nullptr, 0, stream);
+                            nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
                                      const float *cam_pos, const float *coeffs, const float *means2d, const float *conics,
                                      const float *depths, const float *opacities, const int32_t *radii, float *records, float *sh_rgb,
-                                     float *zero_records, float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream) {
+                                     float *zero_records, float *zero_tail, int64_t zero_tail_floats, int32_t *schedule,
+                                     bds_stream_t stream) {
   BDS_REQUIRE(n_dev);
   return splat_pack_sh_impl(n_capacity, n_dev, ids, K, deg, means, cam_pos, coeffs, means2d, conics, depths, opacities, radii, records,
-                            sh_rgb, zero_records, zero_tail, zero_tail_floats, stream);
+                            sh_rgb, zero_records, zero_tail, zero_tail_floats, schedule, stream);
 }
 
 // list geometry of a launch: list tiles of list_tile_size px (a multiple of the 16-px compositing tile)
@@ -806,17 +855,19 @@ static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
   lg.w = (W + list_tile_size - 1) / list_tile_size;
   lg.h = (H + list_tile_size - 1) / list_tile_size;
   lg.total = C * lg.w * lg.h;
+  lg.sched = 0;
   return true;
 }
 
 static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                              int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr) {
+                              int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr, bool binned = false) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
   BDS_REQUIRE(list_geom(C, W, H, list_tile_size, lg));
+  lg.sched = binned ? 1 : 0;
   BDS_REQUIRE(tile_w == (W + kTile - 1) / kTile && tile_h == (H + kTile - 1) / kTile);
   BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
   BDS_REQUIRE(isect_offsets && render && alphas && last_ids);
@@ -857,17 +908,27 @@ extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacit
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
                                      int32_t *last_ids, int32_t *tile_order, bds_stream_t stream) {
   BDS_REQUIRE(M_dev && M_capacity > 0);
-  // tile_order (optional, int32[2 * C*tile_w*tile_h] as for bds_rasterize_bwd_schedule): every tile's schedule key is left in the
-  // second half by the compositing wave itself; bds_rasterize_bwd_schedule_sort then orders the first half
+  // tile_order (optional, bds_rasterize_schedule_ints words): the compositing waves leave the backward's schedule themselves --
+  // binned form (option 8, default; header cleared by the record pack in front), or their tiles' keys for bds_rasterize_bwd_schedule_sort
+  const bool binned = option_get(kOptSchedBins) != 0;
   return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
                             isect_offsets, flatten, render, alphas, last_ids, stream,
-                            tile_order ? tile_order + (int64_t)C * tile_w * tile_h : nullptr);
+                            !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned);
+}
+
+extern "C" int64_t bds_rasterize_schedule_ints(int C, int tile_w, int tile_h) {
+  if (C < 1 || tile_w < 1 || tile_h < 1) return 0;
+  const int64_t total = (int64_t)C * tile_w * tile_h;
+  const int64_t sorted = 1 + 2 * total, binned = kSchedHeader + (int64_t)kSchedXcd * kSchedLogBins * sched_stride((int)total);
+  return sorted > binned ? sorted : binned;
 }
 
 extern "C" int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream) {
   BDS_REQUIRE(C >= 1 && tile_w > 0 && tile_h > 0 && tile_order);
+  if (option_get(kOptSchedBins) != 0) return BDS_OK;   // (binned form: bds_rasterize_fwd_dev left the finished schedule)
   const int total = C * tile_w * tile_h;
-  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, as_stream(stream), total, tile_order + total, tile_order);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, as_stream(stream), total, tile_order + 1 + total, tile_order + 1,
+                     tile_order);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -970,11 +1031,11 @@ extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, in
   BDS_REQUIRE(isect_offsets && last_ids && tile_order);
   const int total = C * tile_w * tile_h;
   hipStream_t st = as_stream(stream);
-  int32_t *work = tile_order + total;   // second half of the caller's buffer
+  int32_t *work = tile_order + 1 + total;   // [tag | order | work] (pick_item)
   constexpr int per_block = kWorkBlock / kWave;
   hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(kWorkBlock), 0, st, C, W,
                      H, tile_w, tile_h, isect_offsets, last_ids, work, lg);
-  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, st, total, work, tile_order);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(kSchedThreads), 0, st, total, work, tile_order + 1, tile_order);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -325,12 +325,12 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
                 L.check(lib.bds_splat_pack_sh_dev(n_vis, f.nvis_dev, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means),
                                                   L.ptr(f.cam_pos), L.ptr(f.sh), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths),
                                                   L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), L.ptr(zr), L.ptr(tail),
-                                                  0 if tail is None else tail.numel(), st), "bds_splat_pack_sh_dev")
+                                                  0 if tail is None else tail.numel(), L.ptr(tile_order), st), "bds_splat_pack_sh_dev")
             else:
                 L.check(lib.bds_splat_pack_dev(n_vis, f.nvis_dev, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors),
                                                L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(zr), L.ptr(tail),
-                                               0 if tail is None else tail.numel(), st), "bds_splat_pack_dev")
-            # (tile_order: the backward's schedule keys are left by the compositing waves themselves)
+                                               0 if tail is None else tail.numel(), L.ptr(tile_order), st), "bds_splat_pack_dev")
+            # (tile_order: the backward's schedule is left by the compositing waves themselves; its header was cleared by the pack)
             L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
                                               L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids),
                                               L.ptr(tile_order), st), "bds_rasterize_fwd_dev")
@@ -414,7 +414,7 @@ class _FusedView(torch.autograd.Function):
         # device-count form with a backward to follow: the compositor leaves the schedule keys of its own backward (one launch less)
         sched_buf = None
         if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
-            sched_buf = _empty((2 * f.tw * f.th,), dev, torch.int32)
+            sched_buf = _empty((int(lib.bds_rasterize_schedule_ints(1, f.tw, f.th)),), dev, torch.int32)
         rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all, sched_buf, getattr(ctx, "tail", None))
         tiles_wh = (f.tw, f.th)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)

@@ -306,7 +306,8 @@ class FrameGraph:
     def _capturing(self, graph, pool):
         """``torch.cuda.graph`` for this frame's captures.  With an exchange other threads of the process issue HIP calls of their own
         while we capture (RCCL's proxy, the process group's watchdog): only THIS thread's unsafe calls may invalidate the capture."""
-        if self.world > 1:
+        import torch.distributed as dist
+        if self.world > 1 or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
         return torch.cuda.graph(graph, pool=pool)
 

@@ -207,7 +207,7 @@ def bwd_schedule(C_: int, width: int, height: int, list_tile_size: int, isect_of
     if not _BWD_SCHEDULE:
         return None
     tw, th = math.ceil(width / TILE_SIZE), math.ceil(height / TILE_SIZE)
-    order = torch.empty(2 * C_ * tw * th, device=last_ids.device, dtype=torch.int32)
+    order = torch.empty(int(L.lib().bds_rasterize_schedule_ints(C_, tw, th)), device=last_ids.device, dtype=torch.int32)
     L.check(L.lib().bds_rasterize_bwd_schedule(C_, width, height, TILE_SIZE, list_tile_size, tw, th, L.ptr(isect_offsets),
                                                L.ptr(last_ids), L.ptr(order), L.stream()), "bds_rasterize_bwd_schedule")
     return order

@@ -213,8 +213,10 @@ int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *
 /* Launch schedule for bds_rasterize_bwd (no reference counterpart; results do not depend on it).  One wave owns a
  * tile and the chip holds only about two rounds of tiles, so the launch ends with a tail of long tiles that started
  * late.  After the forward pass each tile's visited length is known exactly (max last_id - list start); this call
- * orders every XCD's contiguous range of tiles longest-first.  tile_order: int32[2 * C*tile_w*tile_h] — the first
- * half receives the schedule, the second half is scratch. */
+ * orders every XCD's contiguous range of tiles longest-first.  tile_order: int32[bds_rasterize_schedule_ints(C, tile_w, tile_h)]:
+ * word 0 tags the form (1 = sorted: the order follows, then scratch; 0 = binned, written by bds_rasterize_fwd_dev), which the
+ * backward kernels read -- hand the buffer over as it is. */
+int64_t bds_rasterize_schedule_ints(int C, int tile_w, int tile_h);
 int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
                                const int32_t *last_ids, int32_t *tile_order, bds_stream_t stream);
 
@@ -433,20 +435,24 @@ int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t n_visible_
                         int compact, bds_stream_t stream);
 /* bds_splat_pack with the record count on the device (n_dev -> visible effective).  Optionally clears, on the way, the gradient
  * record of every packed row (zero_records [n_capacity, BDS_GRAD_RECORD_FLOATS]: what bds_rasterize_bwd accumulates into) and a
- * tail of zero_tail_floats (multiple of 4) floats (the camera-pose gradient slots): no fill launches of their own. */
+ * tail of zero_tail_floats (multiple of 4) floats (the camera-pose gradient slots): no fill launches of their own.  schedule
+ * (optional): the schedule buffer the following bds_rasterize_fwd_dev fills in its binned form -- its header is cleared here too. */
 int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int CH, const int32_t *ids, const float *means2d, const float *conics,
                        const float *colors, const float *opacities, const int32_t *radii, float *records, float *zero_records,
-                       float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream);
+                       float *zero_tail, int64_t zero_tail_floats, int32_t *schedule, bds_stream_t stream);
 /* bds_splat_pack_sh with the record count on the device and the clearing options of bds_splat_pack_dev: the SH colours of the visible
  * Gaussians are evaluated by the pack itself (no pass over all N, no dense colour arrays); sh_rgb [n_capacity, 3] in list order. */
 int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int degrees_to_use, const float *means,
                           const float *cam_pos, const float *coeffs, const float *means2d, const float *conics, const float *depths,
                           const float *opacities, const int32_t *radii, float *records, float *sh_rgb, float *zero_records,
-                          float *zero_tail, int64_t zero_tail_floats, bds_stream_t stream);
+                          float *zero_tail, int64_t zero_tail_floats, int32_t *schedule, bds_stream_t stream);
 /* bds_rasterize_fwd / _bwd with the list length on the device (M_dev -> M effective) */
-/* (tile_order, optional: int32[2 * C*tile_w*tile_h] as for bds_rasterize_bwd_schedule -- every compositing wave leaves its tile's
- * schedule key (how far into its list the tile blended) in the second half; bds_rasterize_bwd_schedule_sort then writes the
- * longest-first schedule into the first half: one launch instead of bds_rasterize_bwd_schedule's two) */
+/* (tile_order, optional: the schedule buffer of bds_rasterize_bwd_schedule.  Every compositing wave knows how far into its list its
+ * tile blended when it ends, and leaves the backward's schedule itself: BINNED form (bds_set_option(8, 1), default) -- one atomic
+ * drops the tile into the bin of its length (32 bins a factor 2^(1/4) apart, longest first) of its XCD's range of tiles, the
+ * backward's workgroups find their tile by a prefix walk over the 32 counts, NO launch between the passes; the header must be clear when the
+ * forward starts (the record pack's `schedule` argument).  bds_set_option(8, 0): the waves leave their keys and
+ * bds_rasterize_bwd_schedule_sort -- one launch, a no-op in the binned form -- writes the sorted schedule.) */
 int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, int32_t *last_ids,

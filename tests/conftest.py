@@ -30,5 +30,6 @@ def _reset_kernel_variants():
             _lib.set_option(_lib.OPT_PACKED, 1)
             _lib.set_option(_lib.OPT_DEBUG, 0)
             _lib.set_option(_lib.OPT_CELLS, 3)
+            _lib.set_option(_lib.OPT_SCHED_BINS, 1)
     except Exception:
         pass

@@ -494,8 +494,9 @@ def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C)
                                       L.ptr(last), L.stream()), "fwd")
     order = ops.bwd_schedule(Cn, W, H, 16, offs, last)
     total = Cn * tw * th
-    o = order[:total].cpu().long()
-    work = order[total:].cpu().long()
+    assert int(order[0]) == 1                         # [tag = sorted | order | work] (csrc/rasterize.hip: pick_item)
+    o = order[1:1 + total].cpu().long()
+    work = order[1 + total:1 + 2 * total].cpu().long()
     assert torch.equal(o.sort().values, torch.arange(total))
     Hp, Wp = th * 16, tw * 16
     lid = torch.zeros(Cn, Hp, Wp, dtype=torch.long); lid[:, :H, :W] = last.cpu().long()

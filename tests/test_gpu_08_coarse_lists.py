@@ -119,12 +119,55 @@ def test_schedule_keys_left_by_the_forward_compositor(list_tile):
         render, alphas = torch.empty(1, H, W, 4, device=dev), torch.empty(1, H, W, 1, device=dev)
         last = torch.zeros(1, H, W, dtype=torch.int32, device=dev)
         m_dev = torch.tensor([M], dtype=torch.int64, device=dev)
-        order = torch.full((2 * tw * th,), -7, dtype=torch.int32, device=dev)
-        L.check(lib.bds_rasterize_fwd_dev(1, N, M + 100, m_dev.data_ptr(), 4, L.ptr(rec), None, W, H, 16, list_tile, tw, th, L.ptr(offs), L.ptr(fids),
-                                          L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(order), st), "fwd")
-        L.check(lib.bds_rasterize_bwd_schedule_sort(1, tw, th, L.ptr(order), st), "sort")
+        n_ints = int(lib.bds_rasterize_schedule_ints(1, tw, th))
+        total, NB = tw * th, 32          # (bins per XCD range: csrc/rasterize.hip kSchedLogBins)
+
+        def forward(order):
+            L.check(lib.bds_rasterize_fwd_dev(1, N, M + 100, m_dev.data_ptr(), 4, L.ptr(rec), None, W, H, 16, list_tile, tw, th, L.ptr(offs),
+                                              L.ptr(fids), L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(order), st), "fwd")
+            L.check(lib.bds_rasterize_bwd_schedule_sort(1, tw, th, L.ptr(order), st), "sort")
+
+        # sorted form (option 8 = 0): the waves leave their keys, one launch sorts them
+        L.set_option(L.OPT_SCHED_BINS, 0)
+        try:
+            order = torch.full((n_ints,), -7, dtype=torch.int32, device=dev)
+            forward(order)
+        finally:
+            L.set_option(L.OPT_SCHED_BINS, 1)
         ref = ops.bwd_schedule(1, W, H, list_tile, offs, last)
+        # binned form (default): the waves drop their tile into the bin of its length; no launch (the sort call is a no-op).  The header
+        # is cleared by the record pack in the product; here by hand
+        binned = torch.full((n_ints,), -7, dtype=torch.int32, device=dev)
+        binned[:1 + 8 * NB] = 0
+        forward(binned)
         torch.cuda.synchronize()
-    assert int(order.min()) >= 0
-    assert torch.equal(order[tw * th:], ref[tw * th:]) and int(ref[tw * th:].max()) > 0        # keys
-    assert torch.equal(order[:tw * th], ref[:tw * th])                                        # schedule
+    assert int(order[0]) == 1 and int(ref[0]) == 1 and int(order[1:1 + 2 * total].min()) >= 0
+    assert torch.equal(order[1 + total:1 + 2 * total], ref[1 + total:1 + 2 * total]) and int(ref[1 + total:1 + 2 * total].max()) > 0        # keys
+    assert torch.equal(order[1:1 + total], ref[1:1 + total])                                  # schedule
+    work = ref[1 + total:1 + 2 * total].cpu().long()
+    b = binned.cpu().long()
+    assert int(b[0]) == 0
+    counts = b[1:1 + 8 * NB].reshape(8, NB)
+    stride = total // 8 + 1
+    lists = b[1 + 8 * NB:1 + 8 * NB + 8 * NB * stride].reshape(8, NB, stride)
+    per, rem = divmod(total, 8)
+    first = 0
+    for x in range(8):
+        cnt = per + (1 if x < rem else 0)
+        assert int(counts[x].sum()) == cnt
+        seen, floor_prev = [], None
+        for k in range(NB):
+            items = lists[x, k, :int(counts[x, k])]
+            seen.append(items)
+            if items.numel():
+                w = work[items]
+                if k < NB - 1:
+                    assert int(w.min()) > 0
+                    if floor_prev is not None:
+                        assert int(w.max()) <= floor_prev                 # bins are ordered longest first
+                    floor_prev = int(w.min())
+                else:
+                    assert int(w.max()) == 0                              # the last bin: nothing to do
+        seen = torch.cat(seen).sort().values
+        assert torch.equal(seen, torch.arange(first, first + cnt))        # every tile of the XCD's range exactly once
+        first += cnt
