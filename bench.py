@@ -338,6 +338,8 @@ def main():
             # price the two exchanges from what this job measures: the ranks' unions per view, one rank's frame, the fabric
             from bilateral_driving_amd.dist import measure_busbw, plan_exchange, union_row_counts
             unions = union_row_counts(vis_masks)
+            for _ in range(2):      # (the first replay of a captured graph uploads it)
+                frame.step(wait=False, local=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3):
