@@ -446,6 +446,15 @@ def main():
                 for name in marked.marks:
                     acc.setdefault(name, []).extend(marked.mark_samples(name))
             tall = {k: (len(v), sum(v) / max(len(v), 1)) for k, v in acc.items() if v}
+            if os.environ.get("BDS_BENCH_OVERLAP_TABLE") == "1":   # diagnostic: the same marks while the two streams share the GPU
+                acc2 = {}
+                for _ in range(4):
+                    marked.step()
+                    torch.cuda.synchronize()
+                    for name in marked.marks:
+                        acc2.setdefault(name, []).extend(marked.mark_samples(name))
+                print("bench.py: operator ms, one stream vs the overlapped frame: " + json.dumps(
+                    {k: [round(tall[k][1], 4), round(sum(v) / max(len(v), 1), 4)] for k, v in sorted(acc2.items()) if v and k in tall}), file=sys.stderr)
             per_kernel_source = ("timing marks (event-record nodes) around every operator inside a second capture of the timed frame graphs, "
                                  "replayed on ONE stream after the timed region: rasterize_fwd includes the record pack with the SH colours, "
                                  "bilagrid_fwd the L1 + TV loss; algorithmic bytes: SURVEY.md 8(d) rows at this run's N, n_visible, M, pixels")
