@@ -350,29 +350,41 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
 // ---- wide-digit form of the two kernels above, for the packed tile pass: digits of up to 10 bits (kBins = 512 / 1024) --------
 // With coarse list tiles the whole tile key is 9-10 bits (1080p, 64-px list tiles: 510 lists): ONE stable pass orders the
 // pairs instead of two (a pass over the list costs a histogram, a scan of [bins][workgroups] and a scatter launch).
+// No scan launches either: as in the short sort below, the histogram is stored workgroup-major, every 64 workgroups also add
+// theirs to a group row (zeroed by the emission kernel in front), and a scatter workgroup derives its bases from <= ng group rows +
+// <= 63 workgroup rows (L2-resident) -- two launches per pass instead of four, which matters most where it runs: next to another
+// stream's compositor every launch of this latency-bound stage waits for wave slots (profiles/NOTES.md, round 4).
+constexpr int kWideGroupShift = 6;
 template <int kBins>
 __global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint32_t *__restrict__ keys, int64_t n_host,
                                                                     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask,
-                                                                    int nblocks, uint32_t *__restrict__ hist) {
+                                                                    uint32_t *__restrict__ hist /*[nblocks][kBins]*/,
+                                                                    uint32_t *__restrict__ ghist /*[ng][kBins], zeroed*/) {
   __shared__ uint32_t h[kBins];
   const int64_t n = list_length(n_host, n_dev);
+  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+  if (base >= n) return;   // (rows of surplus workgroups are never read)
   for (int d = threadIdx.x; d < kBins; d += kSortBlock) h[d] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
 #pragma unroll 4
   for (int r = 0; r < kSortRounds; r++) {
     const int64_t i = base + r * kSortBlock + threadIdx.x;
     if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d <= (int)mask; d += kSortBlock) hist[(int64_t)d * nblocks + blockIdx.x] = h[d];
+  for (int d = threadIdx.x; d < kBins; d += kSortBlock) {
+    const uint32_t c = h[d];
+    hist[(int64_t)blockIdx.x * kBins + d] = c;
+    if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kWideGroupShift) * kBins + d], c);
+  }
 }
 
 template <int kBins>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
     const uint32_t *__restrict__ keys_in, int64_t n_host, const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits,
-    int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
-    uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out, int n_offsets) {
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
+    const uint32_t *__restrict__ unpack, uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out,
+    int n_offsets) {
   constexpr int kPer = kBins / kSortBlock;   // digits per thread (consecutive: thread t owns [t * kPer, (t + 1) * kPer))
   const int64_t n = list_length(n_host, n_dev);
   const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
@@ -410,13 +422,53 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
       for (int w = 0; w < kSortWaves; w++) tot[u] += wrun[w][d];
       sum += tot[u];
     }
+    // this thread's digits in the whole input (gt) and in front of this workgroup (below): group rows, then the <= 63 workgroup rows
+    // of its own group (independent partial sums: several loads in flight)
+    uint32_t gt[kPer], below[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; u++) { gt[u] = 0; below[u] = 0; }
+    {
+      const int nb = (int)((n + kSortChunk - 1) / kSortChunk), ng = (nb + (1 << kWideGroupShift) - 1) >> kWideGroupShift;
+      const int gb = (int)blockIdx.x >> kWideGroupShift;
+      for (int g = 0; g < ng; g++) {
+        const uint32_t *q = ghist + (int64_t)g * kBins + tid * kPer;
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+          const uint32_t c = q[u];
+          gt[u] += c;
+          if (g < gb) below[u] += c;
+        }
+      }
+      const uint32_t *hp = hist + ((int64_t)gb << kWideGroupShift) * kBins + tid * kPer;
+      const int nrows = (int)blockIdx.x - (gb << kWideGroupShift);
+      uint32_t p0[kPer], p1[kPer], p2[kPer], p3[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; u++) { p0[u] = 0; p1[u] = 0; p2[u] = 0; p3[u] = 0; }
+      int r = 0;
+      for (; r + 4 <= nrows; r += 4) {
+        const uint32_t *q = hp + (int64_t)r * kBins;
+#pragma unroll
+        for (int u = 0; u < kPer; u++) { p0[u] += q[u]; p1[u] += q[kBins + u]; p2[u] += q[2 * kBins + u]; p3[u] += q[3 * kBins + u]; }
+      }
+      for (; r < nrows; r++) {
+#pragma unroll
+        for (int u = 0; u < kPer; u++) p0[u] += hp[(int64_t)r * kBins + u];
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; u++) below[u] += (p0[u] + p1[u]) + (p2[u] + p3[u]);
+    }
+    uint32_t gsum = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; u++) gsum += gt[u];
     uint32_t all;
+    uint32_t dbase = block_excl_scan(gsum, all, lw);   // entries of smaller digits in the whole input
     uint32_t base = block_excl_scan(sum, all, lw);
 #pragma unroll
     for (int u = 0; u < kPer; u++) {
       const int d = tid * kPer + u;
       dstart[d] = base;
-      gbase[d] = d <= (int)mask ? hist_scanned[(int64_t)d * nblocks + blockIdx.x] : 0u;
+      gbase[d] = dbase + below[u];
+      dbase += gt[u];
       // when this pass covers the whole tile key, the first workgroup's bases ARE the per-tile offsets (entries with a smaller key)
       if (offsets_out && blockIdx.x == 0 && d < n_offsets) offsets_out[d] = (int32_t)gbase[d];
       uint32_t b2 = base;
@@ -466,7 +518,14 @@ constexpr int kWideBits = 10;   // widest digit of the packed tile pass
 static size_t radix_temp_elems(int64_t n, int max_bins = 256) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, kSortChunk);
   const size_t h = align_up((size_t)max_bins * nblocks, 4);
-  return h + scan_temp_elems((int64_t)max_bins * nblocks);
+  const size_t group_rows = max_bins > 256 ? (size_t)max_bins * (size_t)cdiv(nblocks, 1 << kWideGroupShift) : 0;   // wide passes
+  const size_t behind = scan_temp_elems((int64_t)max_bins * nblocks);
+  return h + (behind > group_rows ? behind : group_rows);
+}
+
+// uint32 words behind the histogram that the wide pass expects ZERO when it starts (its group rows)
+static size_t radix_wide_group_elems(int64_t n, int bits) {
+  return (size_t)(1 << bits) * (size_t)cdiv(cdiv(n > 0 ? n : 1, kSortChunk), 1 << kWideGroupShift);
 }
 
 static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift,
@@ -498,24 +557,25 @@ static int radix_pass_keys(const uint32_t *kin, uint32_t *kout, int64_t n, int s
   uint32_t *hist = temp;
   uint32_t *stemp = temp + align_up((size_t)(bits > 8 ? (1 << kWideBits) : 256) * nblocks, 4);
   if (bits > 8) {
-    if (bits == 9) hipLaunchKernelGGL((radix_hist_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
-    else hipLaunchKernelGGL((radix_hist_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
-  } else {
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
+    uint32_t *ghist = stemp;   // zeroed by the caller's preceding launch (radix_wide_group_elems words)
+    if (bits == 9) {
+      hipLaunchKernelGGL((radix_hist_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, hist, ghist);
+      hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits,
+                         hist, ghist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
+    } else {
+      hipLaunchKernelGGL((radix_hist_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, hist, ghist);
+      hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits,
+                         hist, ghist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
+    }
+    BDS_LAUNCH_CHECK();
+    return BDS_OK;
   }
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, nblocks, hist);
   BDS_LAUNCH_CHECK();
   int rc = exclusive_scan_u32(hist, hist, hn, stemp, nullptr, st);
   if (rc != BDS_OK) return rc;
-  if (bits == 9) {
-    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<512>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
-  } else if (bits > 9) {
-    hipLaunchKernelGGL((radix_scatter_keys_wide_kernel<1024>), dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits,
-                       nblocks, hist, kout, unpack, rank_mask, vout, offsets_out, n_offsets);
-  } else {
-    hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits, nblocks,
-                       hist, kout, unpack, rank_mask, vout);
-  }
+  hipLaunchKernelGGL(radix_scatter_keys_kernel, dim3(nblocks), dim3(kSortBlock), 0, st, kin, n, n_dev, shift, mask, bits, nblocks,
+                     hist, kout, unpack, rank_mask, vout);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -903,8 +963,10 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
     const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ btot,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec) {
+    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec, uint32_t *__restrict__ zero_words, int n_zero) {
   __shared__ RowStage S;
+  // (the group rows of the tile pass that follows: cleared here, by every workgroup of the launch a word each, before anything returns)
+  for (int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * kIsectBlock) zero_words[i] = 0u;
   const int64_t n_vis = (int64_t)*n_vis_dev;
   const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
   if (j0 >= n_vis) return;
@@ -1324,8 +1386,13 @@ static int isect_build_impl(int C, int64_t N, int64_t M, int64_t n_visible, cons
   if (packed) {
     key_shift = rank_bits;
     uint32_t *k_emit = (npass % 2 == 1) ? B.ka : B.kb;   // the last pass lands in B.kb
+    // a wide pass (radix_pass_keys, bits > 8) finds its group rows behind the histogram; the emission clears them on its way
+    const bool wide = bits_per > 8;
+    uint32_t *wide_zero = wide ? B.temp + align_up((size_t)(1 << kWideBits) * (size_t)cdiv(M, kSortChunk), 4) : nullptr;
+    const int wide_zero_n = wide ? (int)radix_wide_group_elems(M, bits_per) : 0;
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, nvis_dev, N, P.va,
-                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec);
+                       P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec,
+                       wide_zero, wide_zero_n);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     const uint32_t rank_mask = (1u << rank_bits) - 1u;
@@ -1347,7 +1414,8 @@ static int isect_build_impl(int C, int64_t N, int64_t M, int64_t n_visible, cons
     if (npass % 2 == 1) { k_emit = B.ka; v_emit = B.va; }   // A -> (kb, fl)
     else { k_emit = B.kb; v_emit = fl; }                      // (kb, fl) -> A -> (kb, fl)
     hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, P.total + 1, N,
-                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec);
+                       P.va, P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, v_emit, 0, P.rec,
+                       (uint32_t *)nullptr, 0);
     BDS_LAUNCH_CHECK();
     kin = k_emit;
     uint32_t *vin = v_emit;
