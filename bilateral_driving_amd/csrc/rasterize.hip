@@ -509,14 +509,14 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
       const float opac = B.y, ec = B.x;
       const float eadx = A.z * dx, ebdx = A.w * dx;
       const float eadx2 = eadx * dx;
-      float e[4], vis[4], ov[4];
+      float e[4], ov[4], dyq[4];
       bool valid[4];
       bool any = false;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        e[q] = splat_exponent(eadx2, ebdx, ec, A.y - pyc[q]);
-        vis[q] = __builtin_amdgcn_exp2f(e[q]);
-        ov[q] = opac * vis[q];
+        dyq[q] = A.y - pyc[q];
+        e[q] = splat_exponent(eadx2, ebdx, ec, dyq[q]);
+        ov[q] = opac * __builtin_amdgcn_exp2f(e[q]);
         valid[q] = (gidx <= bin_final[q]) & !((e[q] > 0.f) | (ov[q] < kAlphaMin));
         any |= valid[q];
       }
@@ -525,14 +525,14 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
       if (CH > 2) { col[2] = Cc.x; col[3] = Cc.y; }
       const float two_eadx = eadx + eadx, two_ec = ec + ec;
       // per-lane sums over the four pixels (branch-free: a pixel that did not blend this Gaussian contributes alpha = 0)
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, ax = 0.f, ay = 0.f, go = 0.f;
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, ax = 0.f, ay = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         // q = one 16 x 4 strip of the tile: a strip none of whose pixels blends this Gaussian adds exact zeros (and T *= 1)
         if (kStrip && !__any(valid[q])) continue;
-        const float dy = A.y - pyc[q];
+        const float dy = dyq[q];
         const float am = valid[q] ? clamp_alpha(ov[q]) : 0.f;
-        const float vm = (valid[q] & (ov[q] <= kAlphaMax)) ? vis[q] : 0.f;   // the 0.999 clamp passes no gradient
+        const float ovm = (valid[q] & (ov[q] <= kAlphaMax)) ? ov[q] : 0.f;   // opacity x falloff; the 0.999 clamp passes no gradient
         const float ra = __builtin_amdgcn_rcpf(1.f - am);                   // exactly 1 for am = 0
         T[q] *= ra;
         const float fac = am * T[q];
@@ -543,7 +543,7 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
         if (CH > 3) { cdot = __builtin_fmaf(col[3], vr[q][3], cdot); g3 = __builtin_fmaf(fac, vr[q][3], g3); }
         const float v_alpha = __builtin_fmaf(-ra, Bd[q], T[q] * cdot);
         Bd[q] = __builtin_fmaf(fac, cdot, Bd[q]);
-        const float vs = -(opac * vm) * v_alpha;   // d(loss)/d(sigma), sigma = -ln2 * e
+        const float vs = -ovm * v_alpha;   // d(loss)/d(sigma), sigma = -ln2 * e
         S0 += vs;
         S1 = __builtin_fmaf(vs, dy, S1);
         S2 = __builtin_fmaf(vs * dy, dy, S2);
@@ -551,8 +551,9 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
           ax = __builtin_fmaf(fabsf(vs), fabsf(__builtin_fmaf(A.w, dy, two_eadx)), ax);
           ay = __builtin_fmaf(fabsf(vs), fabsf(__builtin_fmaf(two_ec, dy, ebdx)), ay);
         }
-        go = __builtin_fmaf(vm, v_alpha, go);
       }
+      // d(loss)/d(opacity) = sum vm v_alpha = -S0 / opacity (vs = -(opacity vm) v_alpha term by term): no accumulator of its own
+      const float go = -S0 * __builtin_amdgcn_rcpf(opac);
       // expand the moments: d sigma / d (a, b, c) = (dx^2 / 2, dx dy, dy^2 / 2); d sigma / d mean = -ln2 * d e / d (dx, dy)
       float acc[16];
       acc[0] = g0; acc[1] = g1; acc[2] = g2; acc[3] = g3;
