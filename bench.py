@@ -106,8 +106,8 @@ def parse():
                     help="N > 1: sum the gradients over the ranks per view (compact union rows, overlapped with the next view), once per "
                          "frame (one dense all-reduce), or whichever dist.plan_exchange prices cheaper from the measured unions, the "
                          "measured compute time of a frame and the measured all-reduce bandwidth of the fabric (default)")
-    ap.add_argument("--random-views", action="store_true",
-                    help="N = 1: also time the REPLAYABLE frame (graph_view.FrameGraph(dynamic=True)) -- every step each view slot gets "
+    ap.add_argument("--no-random-views", dest="random_views", action="store_false",
+                    help="skip the measurement of the REPLAYABLE frame.  Default at N = 1: also time the replayable frame (graph_view.FrameGraph(dynamic=True)) -- every step each view slot gets "
                          "a random camera of a pool, a new target / sky and a random image index written into its static inputs before "
                          "the replay, as the reference's loop draws a random image per step (tools/train.py:250-283); reported as "
                          "config.random_views_iters_per_sec next to the fixed-frame value")
@@ -489,7 +489,6 @@ def main():
                                         origin=(1.5 * k, 0.0, 0.0))
             pool_t = [torch.rand(H, W, 3, generator=g2).to(dev) for _ in range(4)]
             pool_s = [torch.rand(H, W, 3, generator=g2).to(dev) for _ in range(4)]
-            del frame
             dyn = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
                              overlap=not args.no_overlap, dynamic=True, calib_cams=pool)
             picks = torch.randint(0, len(pool), (args.steps + 3, V), generator=g2).tolist()
