@@ -6,10 +6,12 @@
 // The two-stage form (low-resolution slice of every level -> maps in memory -> full-resolution compose) reads the input image once
 // per stage and level (80 + 96 B/pixel moved for 44 algorithmic).  Here a workgroup owns a kTileW x kTileH tile of the image:
 //   A. it evaluates, for every level, the low-resolution maps of the (TH/f + 2) x (TW/f + 2) low-res pixels its own pixels
-//      interpolate between -- guidance from the four central input pixels of each f x f block, trilinear sample from an LDS copy of
-//      the <= 3 x 3 x gl grid nodes the tile can touch -- into LDS (48 B per low-res pixel; 26.7 KB for the shipped pyramid);
-//   B. every pixel composes its levels' 3x4 matrices from 4 LDS taps each (the arithmetic of upsample_affine), applies them, and the
-//      expected-depth normalise / clamp / sky blend / L1 + TV loss ride along as in the two-stage form.
+//      interpolate between -- guidance from the four central input pixels of each f x f block (formed ONCE for all levels of the same
+//      factor), trilinear sample from an LDS copy of the <= 3 x 3 x gl grid nodes the tile can touch -- into LDS (48 B per low-res
+//      pixel; 26.7 KB for the shipped pyramid);
+//   B. a thread composes FOUR consecutive rows of one column: the x pass of the up-sampler once per low-res row those pixels touch
+//      (their row taps are wave-uniform), the y pass and the 3x4 apply per pixel, level after level; the expected-depth normalise /
+//      clamp / sky blend / L1 + TV loss ride along as in the two-stage form.
 // The ring of low-res pixels around a tile is evaluated by its neighbours too (+45 % low-res work, which is 0.375 of a pixel's), in
 // exchange no map is ever read back from memory by the forward; the tile's OWN low-res pixels are still written out (maps + guidance)
 // for the backward.  Taken when every level's factor is a power of two >= 2 that divides the image and the level has one grid with
@@ -26,8 +28,10 @@ struct TileGeom {
   int tiles_x, tiles_y;
   int lo_off[BDS_MAX_LEVELS];      // float offset of the level's low-res block in the dynamic LDS
   int nrows[BDS_MAX_LEVELS], ncols[BDS_MAX_LEVELS];   // block extent (before clamping at the image border)
-  int item_off[BDS_MAX_LEVELS + 1];
   int nodes_off[BDS_MAX_LEVELS];   // float offset of the level's sub-grid copy [gl][3][3][12]
+  // levels of equal factor have the same low-res pixels: their down-sampled input colour / guidance is formed once per group
+  int ngroups, g_nlev[BDS_MAX_LEVELS], g_lev[BDS_MAX_LEVELS][BDS_MAX_LEVELS];
+  float g_inv_ncols[BDS_MAX_LEVELS];   // 1 / ncols of the group's block
 };
 
 // trilinear sample from the tile's sub-grid copy sub[z][ly][lx][12] (origin node (yn0, xn0)); slice_sample's arithmetic and order
@@ -49,6 +53,19 @@ __device__ __forceinline__ void slice_sub(const float *__restrict__ sub, int xn0
     out12[q * 4 + 1] = ay * (1.f - c.fz) + by * c.fz;
     out12[q * 4 + 2] = az * (1.f - c.fz) + bz * c.fz;
     out12[q * 4 + 3] = aw * (1.f - c.fz) + bw * c.fz;
+  }
+}
+
+// x pass of the up-sampler for one low-res row of the tile's block: out[c] = lo[row][i0][c] (1 - wx) + lo[row][i1][c] wx
+__device__ __forceinline__ void xlerp_row(const float4 *__restrict__ lo4, int row_base, int c0, int c1, float wx, float *out12) {
+  const float4 *s0 = lo4 + times3(row_base + c0), *s1 = lo4 + times3(row_base + c1);
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float4 a = s0[q], b = s1[q];
+    out12[q * 4 + 0] = a.x * (1.f - wx) + b.x * wx;
+    out12[q * 4 + 1] = a.y * (1.f - wx) + b.y * wx;
+    out12[q * 4 + 2] = a.z * (1.f - wx) + b.z * wx;
+    out12[q * 4 + 3] = a.w * (1.f - wx) + b.w * wx;
   }
 }
 
@@ -90,76 +107,112 @@ __global__ __launch_bounds__(kBgBlock) void ms_tile_fwd_kernel(MsParams p, TileG
     }
   }
   __syncthreads();
-  // ---- A: low-res maps of the tile's block of every level ------------------------------------------------------------------------
-  for (int it = threadIdx.x; it < G.item_off[p.nlevels]; it += kBgBlock) {
-    int l = 0;
-    while (l + 1 < p.nlevels && it >= G.item_off[l + 1]) l++;
-    const LevelDev &L = p.lv[l];
-    const int f = L.factor, k = it - G.item_off[l];
-    const int lr = k / G.ncols[l], lc = k - lr * G.ncols[l];
-    const int i = Y0 / f - 1 + lr, j = X0 / f - 1 + lc;
-    if (i < 0 || j < 0 || i >= L.Hd || j >= L.Wd) continue;
-    const Tap ty = resample_tap_s(i, L.Hd, p.H, L.dn_y), tx = resample_tap_s(j, L.Wd, p.W, L.dn_x);
-    float r, g, b;
-    lowres_colour(p, ty, tx, r, g, b);
-    const float gray = rgb2gray(r, g, b);
-    const Cell c = slice_cell(linspace01_s(j, L.Wd, L.lin_x), linspace01_s(i, L.Hd, L.lin_y), gray, L.gx, L.gy, L.gl);
-    float A[12];
-    if (sub_org[l][2] > 0) slice_sub(lds + G.nodes_off[l], sub_org[l][0], sub_org[l][1], c, A);
-    else slice_sample(L.grid, L.gx, L.gy, L.gl, c, A, nullptr);
-    float4 *dst = reinterpret_cast<float4 *>(lds + G.lo_off[l]) + times3(k);
-    const float4 a0 = make_float4(A[0], A[1], A[2], A[3]), a1 = make_float4(A[4], A[5], A[6], A[7]), a2 = make_float4(A[8], A[9], A[10], A[11]);
-    dst[0] = a0; dst[1] = a1; dst[2] = a2;
-    if (lr >= 1 && lr <= kTileH / f && lc >= 1 && lc <= kTileW / f) {   // the tile's own low-res pixels: kept for the backward
-      const int idx = row_major(i, L.Wd, j);
-      float4 *gdst = reinterpret_cast<float4 *>(L.lo) + times3(idx);
-      gdst[0] = a0; gdst[1] = a1; gdst[2] = a2;
-      L.lg[idx] = gray;
+  // ---- A: low-res maps of the tile's block of every level; group by group (one factor each: the loop and every level parameter
+  //         inside it are wave-uniform), the down-sampled colour and the guidance of a low-res pixel formed once per group ------------
+  for (int gi = 0; gi < G.ngroups; gi++) {
+    const int l0 = G.g_lev[gi][0];
+    const LevelDev &L0 = p.lv[l0];
+    const int f = L0.factor, nc = G.ncols[l0], nitems = G.nrows[l0] * nc;
+    const float inv_nc = G.g_inv_ncols[gi];
+    for (int k = threadIdx.x; k < nitems; k += kBgBlock) {
+      const int lr = (int)(((float)k + 0.5f) * inv_nc), lc = k - lr * nc;
+      const int i = Y0 / f - 1 + lr, j = X0 / f - 1 + lc;
+      if (i < 0 || j < 0 || i >= L0.Hd || j >= L0.Wd) continue;
+      const Tap ty = resample_tap_s(i, L0.Hd, p.H, L0.dn_y), tx = resample_tap_s(j, L0.Wd, p.W, L0.dn_x);
+      float r, g, b;
+      lowres_colour(p, ty, tx, r, g, b);
+      const float gray = rgb2gray(r, g, b);
+      const float x01 = linspace01_s(j, L0.Wd, L0.lin_x), y01 = linspace01_s(i, L0.Hd, L0.lin_y);
+      const bool own = lr >= 1 && lr <= kTileH / f && lc >= 1 && lc <= kTileW / f;   // the tile's own low-res pixels: kept for the backward
+      const int idx = row_major(i, L0.Wd, j);
+      for (int u = 0; u < G.g_nlev[gi]; u++) {
+        const int l = G.g_lev[gi][u];
+        const LevelDev &L = p.lv[l];
+        const Cell c = slice_cell(x01, y01, gray, L.gx, L.gy, L.gl);
+        float A[12];
+        if (sub_org[l][2] > 0) slice_sub(lds + G.nodes_off[l], sub_org[l][0], sub_org[l][1], c, A);
+        else slice_sample(L.grid, L.gx, L.gy, L.gl, c, A, nullptr);
+        float4 *dst = reinterpret_cast<float4 *>(lds + G.lo_off[l]) + times3(k);
+        const float4 a0 = make_float4(A[0], A[1], A[2], A[3]), a1 = make_float4(A[4], A[5], A[6], A[7]), a2 = make_float4(A[8], A[9], A[10], A[11]);
+        dst[0] = a0; dst[1] = a1; dst[2] = a2;
+        if (own) {
+          float4 *gdst = reinterpret_cast<float4 *>(L.lo) + times3(idx);
+          gdst[0] = a0; gdst[1] = a1; gdst[2] = a2;
+          L.lg[idx] = gray;
+        }
+      }
     }
   }
   __syncthreads();
-  // ---- B: compose + apply at the tile's pixels ---------------------------------------------------------------------------------------
+  // ---- B: compose + apply.  A thread owns FOUR consecutive rows of one column (a wave: 64 columns x 4 rows): the rows of a wave and
+  //         hence their low-res row taps are wave-uniform, so the x pass of the up-sampler is done once per low-res ROW the four pixels
+  //         touch (3 at factor 4, 4 at factor 2, 2 at factor 8) instead of twice per pixel, and every pixel adds its y pass -------------
+  const int lx = (int)threadIdx.x & (kTileW - 1);
+  const int rg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int j = X0 + lx, ib = Y0 + 4 * rg;
   float l1 = 0.f;
-  const int lx = (int)threadIdx.x & (kTileW - 1), ly0 = (int)threadIdx.x / kTileW;
-#pragma unroll 1
-  for (int ly = ly0; ly < kTileH; ly += kBgBlock / kTileW) {
-    const int i = Y0 + ly, j = X0 + lx;
-    if (i >= p.H || j >= p.W) continue;
-    float r, g, b;
-    load_input(p, i, j, r, g, b);
+  if (j < p.W && ib < p.H) {
+    float r[4], g[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      r[q] = g[q] = b[q] = 0.f;
+      if (ib + q < p.H) load_input(p, ib + q, j, r[q], g[q], b[q]);
+    }
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       if (l >= p.nlevels) break;
       const LevelDev &L = p.lv[l];
-      const int f = L.factor;
-      const Tap ty = resample_tap_s(i, p.H, L.Hd, L.up_y), tx = resample_tap_s(j, p.W, L.Wd, L.up_x);
+      const int f = L.factor, nc = G.ncols[l];
+      const Tap tx = resample_tap_s(j, p.W, L.Wd, L.up_x);
       const float4 *lo4 = reinterpret_cast<const float4 *>(lds + G.lo_off[l]);
       const int rb = Y0 / f - 1, cb = X0 / f - 1;
-      const int r0 = (ty.i0 - rb) * G.ncols[l], r1 = (ty.i1 - rb) * G.ncols[l];
-      const float4 *s00 = lo4 + times3(r0 + tx.i0 - cb), *s01 = lo4 + times3(r0 + tx.i1 - cb);
-      const float4 *s10 = lo4 + times3(r1 + tx.i0 - cb), *s11 = lo4 + times3(r1 + tx.i1 - cb);
-      const float wx = tx.w1, wy = ty.w1;
-      float A[12];
+      const int c0 = tx.i0 - cb, c1 = tx.i1 - cb;
+      float R0[12], R1[12];
+      int t0 = -1, t1 = -1;   // low-res rows (block-local) held in R0 / R1
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const float4 a = s00[q], bq = s01[q], c = s10[q], d = s11[q];
-        A[q * 4 + 0] = (a.x * (1.f - wx) + bq.x * wx) * (1.f - wy) + (c.x * (1.f - wx) + d.x * wx) * wy;
-        A[q * 4 + 1] = (a.y * (1.f - wx) + bq.y * wx) * (1.f - wy) + (c.y * (1.f - wx) + d.y * wx) * wy;
-        A[q * 4 + 2] = (a.z * (1.f - wx) + bq.z * wx) * (1.f - wy) + (c.z * (1.f - wx) + d.z * wx) * wy;
-        A[q * 4 + 3] = (a.w * (1.f - wx) + bq.w * wx) * (1.f - wy) + (c.w * (1.f - wx) + d.w * wx) * wy;
+      for (int q = 0; q < 4; q++) {
+        if (ib + q >= p.H) break;
+        const Tap ty = resample_tap_s(ib + q, p.H, L.Hd, L.up_y);   // (wave-uniform)
+        const int a = ty.i0 - rb, bb = ty.i1 - rb;
+        if (a != t0) {
+          if (a == t1) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) R0[c] = R1[c];
+          } else {
+            xlerp_row(lo4, a * nc, c0, c1, tx.w1, R0);
+          }
+          t0 = a;
+        }
+        if (bb != t1) {
+          if (bb == t0) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) R1[c] = R0[c];
+          } else {
+            xlerp_row(lo4, bb * nc, c0, c1, tx.w1, R1);
+          }
+          t1 = bb;
+        }
+        const float wy = ty.w1;
+        float A[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) A[c] = R0[c] * (1.f - wy) + R1[c] * wy;
+        apply_affine(A, r[q], g[q], b[q]);
       }
-      apply_affine(A, r, g, b);
     }
-    const int pix = row_major(i, p.W, j), p3 = times3(pix);
-    out[p3] = r; out[p3 + 1] = g; out[p3 + 2] = b;
-    if (p.depth_out) p.depth_out[pix] = p.rgb[(pix << 2) + 3] / fmaxf(p.alpha[pix], 1e-10f);
-    if (kTrain) {   // photometric L1 of the pixel just produced + its gradient (torch: sign(0) = 0)
-      const float gs = tl.v_loss * tl.inv_n;
-      const float d0 = r - tl.target[p3], d1 = g - tl.target[p3 + 1], d2 = b - tl.target[p3 + 2];
-      l1 += fabsf(d0) + fabsf(d1) + fabsf(d2);
-      tl.v_out[p3] = d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f);
-      tl.v_out[p3 + 1] = d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f);
-      tl.v_out[p3 + 2] = d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f);
+    const float gs = kTrain ? tl.v_loss * tl.inv_n : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (ib + q >= p.H) break;
+      const int pix = row_major(ib + q, p.W, j), p3 = times3(pix);
+      out[p3] = r[q]; out[p3 + 1] = g[q]; out[p3 + 2] = b[q];
+      if (p.depth_out) p.depth_out[pix] = p.rgb[(pix << 2) + 3] / fmaxf(p.alpha[pix], 1e-10f);
+      if (kTrain) {   // photometric L1 of the pixel just produced + its gradient (torch: sign(0) = 0)
+        const float d0 = r[q] - tl.target[p3], d1 = g[q] - tl.target[p3 + 1], d2 = b[q] - tl.target[p3 + 2];
+        l1 += fabsf(d0) + fabsf(d1) + fabsf(d2);
+        tl.v_out[p3] = d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f);
+        tl.v_out[p3 + 1] = d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f);
+        tl.v_out[p3 + 2] = d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f);
+      }
     }
   }
   if (kTrain) {
@@ -187,7 +240,10 @@ int tile_fwd(const MsParams &p, float *out, const TrainLoss *train, hipStream_t 
     G.nrows[l] = kTileH / f + 2; G.ncols[l] = kTileW / f + 2;
     G.lo_off[l] = off;
     off += G.nrows[l] * G.ncols[l] * 12;
-    G.item_off[l + 1] = G.item_off[l] + G.nrows[l] * G.ncols[l];
+    int gi = 0;
+    while (gi < G.ngroups && p.lv[G.g_lev[gi][0]].factor != f) gi++;
+    if (gi == G.ngroups) { G.ngroups++; G.g_nlev[gi] = 0; G.g_inv_ncols[gi] = 1.f / (float)G.ncols[l]; }
+    G.g_lev[gi][G.g_nlev[gi]++] = l;
   }
   for (int l = 0; l < p.nlevels; l++) {
     G.nodes_off[l] = off;
