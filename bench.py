@@ -369,6 +369,8 @@ def main():
                     for _ in range(2):
                         assert frame.step() is True
                     torch.cuda.synchronize()
+                    if os.environ.get("BDS_BENCH_FAIL_PER_VIEW") == "1":   # (plumbing check of the fallback below)
+                        raise RuntimeError("forced by BDS_BENCH_FAIL_PER_VIEW")
                     del frame_frame
                 except Exception as e:   # (see above: keep the form that already ran)
                     print(f"bench.py: WARNING: per-view exchange failed ({type(e).__name__}: {e}); staying with the per-frame all-reduce",

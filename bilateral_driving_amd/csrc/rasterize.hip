@@ -75,7 +75,10 @@ __device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int 
     if (sel < 0 && slot < acc + c) { sel = b; before = acc; }
     acc += c;
   }
-  if (sel >= 0) return order[kSchedHeader + (x * kSchedLogBins + sel) * sched_stride(total) + (slot - before)];
+  if (sel >= 0) {
+    const int item = order[kSchedHeader + (x * kSchedLogBins + sel) * sched_stride(total) + (slot - before)];
+    if ((unsigned)item < (unsigned)total) return item;   // (anything else: a header the pack did not clear -- plain order)
+  }
   return p;   // (a header nobody filled: plain order)
 }
 
