@@ -411,7 +411,8 @@ class _FusedView(torch.autograd.Function):
                 ctx.tail = v_rec_all[f.n_vis:] if n_pose + ctx.loss_rows else None
                 ctx.tail_pose = v_rec_all[f.n_vis:f.n_vis + n_pose] if want_pose else None
         ctx.v_rec_all = v_rec_all
-        # device-count form with a backward to follow: the compositor leaves the schedule keys of its own backward (one launch less)
+        # device-count form with a backward to follow: the compositor's waves leave the schedule of their own backward (binned form:
+        # no launch at all; bds_set_option(8, 0): their keys, which the sort call below orders)
         sched_buf = None
         if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
             sched_buf = _empty((int(lib.bds_rasterize_schedule_ints(1, f.tw, f.th)),), dev, torch.int32)
@@ -428,7 +429,7 @@ class _FusedView(torch.autograd.Function):
         if any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD:
             if sched_buf is not None:
                 L.check(lib.bds_rasterize_bwd_schedule_sort(1, tiles_wh[0], tiles_wh[1], L.ptr(sched_buf), L.stream()),
-                        "bds_rasterize_bwd_schedule_sort")
+                        "bds_rasterize_bwd_schedule_sort")      # (a no-op in the binned form)
                 ctx.order = sched_buf
             else:
                 ctx.order = ops.bwd_schedule(1, W, H, f_list_tile, isect_offsets, last_ids)
