@@ -355,44 +355,58 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
 // <= 63 workgroup rows (L2-resident) -- two launches per pass instead of four, which matters most where it runs: next to another
 // stream's compositor every launch of this latency-bound stage waits for wave slots (profiles/NOTES.md, round 4).
 constexpr int kWideGroupShift = 6;
+// (every kernel of the device-count tile stage is a thin wrapper around a *_block body that takes its workgroup index as an argument:
+//  the persistent launch tile_stage_persistent_kernel below runs the same bodies phase by phase over grid-strided workgroup indices)
+template <int kBins>
+struct HistWideSh { uint32_t h[kBins]; };
+template <int kBins>
+__device__ __forceinline__ void radix_hist_wide_block(HistWideSh<kBins> &sh, int vb, const uint32_t *keys, int64_t n, int shift, uint32_t mask,
+                                                      uint32_t *hist /*[nblocks][kBins]*/, uint32_t *ghist /*[ng][kBins], zeroed*/) {
+  const int64_t base = (int64_t)vb * kSortChunk;
+  if (base >= n) return;   // (rows of surplus workgroups are never read)
+  for (int d = threadIdx.x; d < kBins; d += kSortBlock) sh.h[d] = 0;
+  __syncthreads();
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; r++) {
+    const int64_t i = base + r * kSortBlock + threadIdx.x;
+    if (i < n) atomicAdd(&sh.h[(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kBins; d += kSortBlock) {
+    const uint32_t c = sh.h[d];
+    hist[(int64_t)vb * kBins + d] = c;
+    if (c) atomicAdd(&ghist[(int64_t)(vb >> kWideGroupShift) * kBins + d], c);
+  }
+}
 template <int kBins>
 __global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint32_t *__restrict__ keys, int64_t n_host,
                                                                     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask,
                                                                     uint32_t *__restrict__ hist /*[nblocks][kBins]*/,
                                                                     uint32_t *__restrict__ ghist /*[ng][kBins], zeroed*/) {
-  __shared__ uint32_t h[kBins];
-  const int64_t n = list_length(n_host, n_dev);
-  const int64_t base = (int64_t)blockIdx.x * kSortChunk;
-  if (base >= n) return;   // (rows of surplus workgroups are never read)
-  for (int d = threadIdx.x; d < kBins; d += kSortBlock) h[d] = 0;
-  __syncthreads();
-#pragma unroll 4
-  for (int r = 0; r < kSortRounds; r++) {
-    const int64_t i = base + r * kSortBlock + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
-  }
-  __syncthreads();
-  for (int d = threadIdx.x; d < kBins; d += kSortBlock) {
-    const uint32_t c = h[d];
-    hist[(int64_t)blockIdx.x * kBins + d] = c;
-    if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kWideGroupShift) * kBins + d], c);
-  }
+  __shared__ HistWideSh<kBins> sh;
+  radix_hist_wide_block<kBins>(sh, (int)blockIdx.x, keys, list_length(n_host, n_dev), shift, mask, hist, ghist);
 }
 
 template <int kBins>
-__global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
-    const uint32_t *__restrict__ keys_in, int64_t n_host, const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits,
-    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
-    const uint32_t *__restrict__ unpack, uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out,
+struct ScatterWideSh {
+  uint32_t wrun[kSortWaves][kBins];
+  uint32_t dstart[kBins], gbase[kBins];
+  uint32_t lw[kSortBlock / kWave + 1];
+  uint32_t lk[kSortChunk];
+};
+template <int kBins>
+__device__ __forceinline__ void radix_scatter_keys_wide_block(
+    ScatterWideSh<kBins> &sh, int vb, const uint32_t *keys_in, int64_t n, int shift, uint32_t mask, int bits, const uint32_t *hist,
+    const uint32_t *ghist, uint32_t *keys_out, const uint32_t *unpack, uint32_t rank_mask, uint32_t *vals_out, int32_t *offsets_out,
     int n_offsets) {
   constexpr int kPer = kBins / kSortBlock;   // digits per thread (consecutive: thread t owns [t * kPer, (t + 1) * kPer))
-  const int64_t n = list_length(n_host, n_dev);
-  const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
-  if (bbase >= n && !(offsets_out && blockIdx.x == 0)) return;   // (an empty list still owes its per-tile offsets: all zero)
-  __shared__ uint32_t wrun[kSortWaves][kBins];
-  __shared__ uint32_t dstart[kBins], gbase[kBins];
-  __shared__ uint32_t lw[kSortBlock / kWave + 1];
-  __shared__ uint32_t lk[kSortChunk];
+  const int64_t bbase = (int64_t)vb * kSortChunk;
+  if (bbase >= n && !(offsets_out && vb == 0)) return;   // (an empty list still owes its per-tile offsets: all zero)
+  auto &wrun = sh.wrun;
+  auto &dstart = sh.dstart;
+  auto &gbase = sh.gbase;
+  auto &lk = sh.lk;
+  uint32_t *lw = sh.lw;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   for (int d = tid; d < kBins; d += kSortBlock) {
 #pragma unroll
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
     for (int u = 0; u < kPer; u++) { gt[u] = 0; below[u] = 0; }
     {
       const int nb = (int)((n + kSortChunk - 1) / kSortChunk), ng = (nb + (1 << kWideGroupShift) - 1) >> kWideGroupShift;
-      const int gb = (int)blockIdx.x >> kWideGroupShift;
+      const int gb = vb >> kWideGroupShift;
       for (int g = 0; g < ng; g++) {
         const uint32_t *q = ghist + (int64_t)g * kBins + tid * kPer;
 #pragma unroll
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
         }
       }
       const uint32_t *hp = hist + ((int64_t)gb << kWideGroupShift) * kBins + tid * kPer;
-      const int nrows = (int)blockIdx.x - (gb << kWideGroupShift);
+      const int nrows = vb - (gb << kWideGroupShift);
       uint32_t p0[kPer], p1[kPer], p2[kPer], p3[kPer];
 #pragma unroll
       for (int u = 0; u < kPer; u++) { p0[u] = 0; p1[u] = 0; p2[u] = 0; p3[u] = 0; }
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
       gbase[d] = dbase + below[u];
       dbase += gt[u];
       // when this pass covers the whole tile key, the first workgroup's bases ARE the per-tile offsets (entries with a smaller key)
-      if (offsets_out && blockIdx.x == 0 && d < n_offsets) offsets_out[d] = (int32_t)gbase[d];
+      if (offsets_out && vb == 0 && d < n_offsets) offsets_out[d] = (int32_t)gbase[d];
       uint32_t b2 = base;
 #pragma unroll
       for (int w = 0; w < kSortWaves; w++) {
@@ -511,6 +525,16 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
     keys_out[g] = kk;
     if (unpack) vals_out[g] = unpack[kk & rank_mask];
   }
+}
+template <int kBins>
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
+    const uint32_t *__restrict__ keys_in, int64_t n_host, const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits,
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
+    const uint32_t *__restrict__ unpack, uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out,
+    int n_offsets) {
+  __shared__ ScatterWideSh<kBins> sh;
+  radix_scatter_keys_wide_block<kBins>(sh, (int)blockIdx.x, keys_in, list_length(n_host, n_dev), shift, mask, bits, hist, ghist, keys_out,
+                                       unpack, rank_mask, vals_out, offsets_out, n_offsets);
 }
 
 constexpr int kWideBits = 10;   // widest digit of the packed tile pass
@@ -597,42 +621,54 @@ constexpr int kChunkShift = 10;
 static_assert(kShortChunk == (1 << kChunkShift), "chunk shift");
 constexpr int64_t kShortSortMax = (int64_t)kShortChunk * 8192;   // <= 128 group rows
 
-__global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *__restrict__ keys,
-                                                               const uint64_t *__restrict__ n_dev, int shift,
-                                                               uint32_t *__restrict__ hist /*[nblocks][256]*/,
-                                                               uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
-  __shared__ uint32_t h[256];
-  const int64_t n = (int64_t)*n_dev;
-  const int64_t base = (int64_t)blockIdx.x * kShortChunk;
+struct ShortHistSh { uint32_t h[256]; };
+__device__ __forceinline__ void short_hist_block(ShortHistSh &sh, int vb, const uint32_t *keys, int64_t n, int shift,
+                                                 uint32_t *hist /*[nblocks][256]*/, uint32_t *ghist /*[ng][256], zeroed*/) {
+  const int64_t base = (int64_t)vb * kShortChunk;
   if (base >= n) return;  // the launch is sized for the host-side bound
-  h[threadIdx.x] = 0;
+  sh.h[threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll 4
   for (int r = 0; r < kShortRounds; r++) {
     const int64_t i = base + r * kSortBlock + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    if (i < n) atomicAdd(&sh.h[(keys[i] >> shift) & 255u], 1u);
   }
   __syncthreads();
-  const uint32_t c = h[threadIdx.x];
-  hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
-  if (c) atomicAdd(&ghist[(int64_t)(blockIdx.x >> kGroupShift) * 256 + threadIdx.x], c);
+  const uint32_t c = sh.h[threadIdx.x];
+  hist[(int64_t)vb * 256 + threadIdx.x] = c;
+  if (c) atomicAdd(&ghist[(int64_t)(vb >> kGroupShift) * 256 + threadIdx.x], c);
+}
+// n_cap >= 0: the launch covers n_cap entries only (device-count form: the caller's capacity); a count beyond it is an overflow the
+// host will hear about -- the entries are then left alone altogether (a partial sort would hand garbage positions downstream)
+__device__ __forceinline__ int64_t bounded_count(const uint64_t *n_dev, int64_t n_cap) {
+  const int64_t n = (int64_t)*n_dev;
+  return (n_cap >= 0 && n > n_cap) ? 0 : n;
+}
+__global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *__restrict__ keys,
+                                                               const uint64_t *__restrict__ n_dev, int64_t n_cap, int shift,
+                                                               uint32_t *__restrict__ hist /*[nblocks][256]*/,
+                                                               uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
+  __shared__ ShortHistSh sh;
+  short_hist_block(sh, (int)blockIdx.x, keys, bounded_count(n_dev, n_cap), shift, hist, ghist);
 }
 
 // wave-private ranking as in radix_scatter_lds_kernel; bases from the group / workgroup rows
-__global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int shift,
-    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
-  const int64_t n = (int64_t)*n_dev;
-  if ((int64_t)blockIdx.x * kShortChunk >= n) return;
-  __shared__ uint32_t wrun[kSortWaves][256];
-  __shared__ uint32_t lw[kSortBlock / kWave + 1];
+struct ShortScatterSh {
+  uint32_t wrun[kSortWaves][256];
+  uint32_t lw[kSortBlock / kWave + 1];
+};
+__device__ __forceinline__ void short_scatter_block(ShortScatterSh &sh, int vb, const uint32_t *keys_in, const uint32_t *vals_in, int64_t n,
+                                                    int shift, const uint32_t *hist, const uint32_t *ghist, uint32_t *keys_out,
+                                                    uint32_t *vals_out) {
+  if ((int64_t)vb * kShortChunk >= n) return;
+  auto &wrun = sh.wrun;
+  uint32_t *lw = sh.lw;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 #pragma unroll
   for (int w = 0; w < kSortWaves; w++) wrun[w][tid] = 0;
   // digit `tid`: elements of this digit in front of this workgroup, and in the whole input
   const int nb = (int)((n + kShortChunk - 1) >> kChunkShift), ng = (nb + (1 << kGroupShift) - 1) >> kGroupShift;
-  const int gb = (int)blockIdx.x >> kGroupShift;
+  const int gb = vb >> kGroupShift;
   uint32_t below = 0, total = 0;
   {
     int g = 0;
@@ -652,7 +688,7 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     // up to 63 rows of the workgroup-major histogram: EIGHT independent partial sums, so that eight loads are in flight at a time
     // (a single running sum serialises the L2 latency of every row: that chain was most of this kernel's 14 us)
     const uint32_t *hp = hist + ((int64_t)gb << kGroupShift) * 256 + tid;
-    const int nrows = (int)blockIdx.x - (gb << kGroupShift);
+    const int nrows = vb - (gb << kGroupShift);
     uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
     int r = 0;
     for (; r + 8 <= nrows; r += 8) {
@@ -666,7 +702,7 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
   uint32_t all;
   const uint32_t digit_base = block_excl_scan(total, all, lw);   // (contains the barrier that publishes wrun = 0)
   constexpr int kPerWave = kShortChunk / kSortWaves;
-  const int64_t wbase = (int64_t)blockIdx.x * kShortChunk + (int64_t)wv * kPerWave;
+  const int64_t wbase = (int64_t)vb * kShortChunk + (int64_t)wv * kPerWave;
   uint32_t k[kShortRounds], v[kShortRounds];
 #pragma unroll
   for (int r = 0; r < kShortRounds; r++) {
@@ -712,6 +748,13 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
       vals_out[pos + rank] = v[r];
     }
   }
+}
+__global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int64_t n_cap,
+    int shift, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out) {
+  __shared__ ShortScatterSh sh;
+  short_scatter_block(sh, (int)blockIdx.x, keys_in, vals_in, bounded_count(n_dev, n_cap), shift, hist, ghist, keys_out, vals_out);
 }
 
 // uint32 elements: one workgroup-major histogram + four zero-initialised group tables
@@ -775,24 +818,25 @@ __global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, 
 
 // visible_compact: (depth bits, cam*N+g) of the visible entries in index order; the histogram of the first
 // sort digit is accumulated on the way (a tile's outputs fall into at most kSpan sort chunks).
-__global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN, const int32_t *__restrict__ radii,
-                                                                    const float *__restrict__ depths,
-                                                                    const uint32_t *__restrict__ tile_sums,
-                                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                                    uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
-                                                                    uint64_t *__restrict__ n_vis_out, uint32_t *__restrict__ asc,
-                                                                    int compact, int sums_per_tile) {
-  constexpr int kSpan = kScanTile / kShortChunk + 1;   // sort chunks a tile's outputs can straddle
-  __shared__ uint32_t lw[kScanBlock / kWave + 1];
-  __shared__ uint32_t h[kSpan][256];
+constexpr int kCompactSpan = kScanTile / kShortChunk + 1;   // sort chunks a tile's outputs can straddle
+struct VisCompactSh {
+  uint32_t lw[kScanBlock / kWave + 1];
+  uint32_t h[kCompactSpan][256];
+};
+__device__ __forceinline__ void visible_compact_block(VisCompactSh &sh, int vb, int nvb, int64_t CN, const int32_t *radii, const float *depths,
+                                                      const uint32_t *tile_sums, uint32_t *keys, uint32_t *vals, uint32_t *hist,
+                                                      uint32_t *ghist, uint64_t *n_vis_out, uint32_t *asc, int compact, int sums_per_tile) {
+  constexpr int kSpan = kCompactSpan;
+  uint32_t *lw = sh.lw;
+  auto &h = sh.h;
 #pragma unroll
   for (int t = 0; t < kSpan; t++) h[t][threadIdx.x] = 0;
   uint32_t part = 0;
   // (sums_per_tile = 8: the counts were left per 256-Gaussian workgroup by the one-view projection, bds_project_view_prepare_fwd)
-  for (int b = threadIdx.x; b < (int)blockIdx.x * sums_per_tile; b += kScanBlock) part += tile_sums[b];
+  for (int b = threadIdx.x; b < vb * sums_per_tile; b += kScanBlock) part += tile_sums[b];
   uint32_t my_offset;
   block_excl_scan(part, my_offset, lw);   // total of the partial sums = this tile's offset
-  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  const int64_t base = (int64_t)vb * kScanTile + (int64_t)threadIdx.x * kScanItems;
   bool vis[kScanItems];
   uint32_t s = 0;
 #pragma unroll
@@ -823,7 +867,18 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
       atomicAdd(&ghist[(int64_t)((chunk0 + t) >> kGroupShift) * 256 + threadIdx.x], c);
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_vis_out = (uint64_t)my_offset + tot;
+  if (vb == nvb - 1 && threadIdx.x == 0) *n_vis_out = (uint64_t)my_offset + tot;
+}
+__global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN, const int32_t *__restrict__ radii,
+                                                                    const float *__restrict__ depths,
+                                                                    const uint32_t *__restrict__ tile_sums,
+                                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                                    uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
+                                                                    uint64_t *__restrict__ n_vis_out, uint32_t *__restrict__ asc,
+                                                                    int compact, int sums_per_tile) {
+  __shared__ VisCompactSh sh;
+  visible_compact_block(sh, (int)blockIdx.x, (int)gridDim.x, CN, radii, depths, tile_sums, keys, vals, hist, ghist, n_vis_out, asc, compact,
+                        sums_per_tile);
 }
 
 // ---- row-parallel counting / emission ---------------------------------------------------------------------
@@ -925,18 +980,19 @@ __device__ __forceinline__ void row_span_of(const RowStage &S, int g, int ty, bo
   if (cull) row_tile_span(S.mx[g], S.my[g], S.a[g], S.b[g], S.c[g], S.qmax[g], ty, tile_size, S.x0[g], S.x1[g], lo, hi);
 }
 
-__global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
-    int64_t CN, const uint64_t *__restrict__ n_vis_dev, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
-    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
-    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, uint32_t *__restrict__ cnt_sorted, int64_t N,
-    float4 *__restrict__ rec, uint32_t *__restrict__ btot, uint64_t *__restrict__ m_total, const uint32_t *__restrict__ asc) {
-  __shared__ RowStage S;
-  __shared__ uint32_t cnt[kIsectBlock];
-  const int64_t n_vis = (int64_t)*n_vis_dev;
-  const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock, j = j0 + threadIdx.x;
-  if (j0 >= n_vis) {  // zeros beyond the visible count (a later scan may run over the host-side bound)
-    if (j < CN) cnt_sorted[j] = 0u;
-    if (threadIdx.x == 0) btot[blockIdx.x] = 0u;
+struct CountRowsSh {
+  RowStage S;
+  uint32_t cnt[kIsectBlock];
+};
+__device__ __forceinline__ void isect_count_rows_block(CountRowsSh &sh, int vb, int64_t n_vis, const uint32_t *sorted_idx, const float *means2d,
+                                                       const int32_t *radii, const float *conics, const float *opacities, int tile_size,
+                                                       int tile_w, int tile_h, int32_t *tiles_per_gauss, int64_t N, float4 *rec,
+                                                       uint32_t *btot, const uint32_t *asc) {
+  RowStage &S = sh.S;
+  uint32_t *cnt = sh.cnt;
+  const int64_t j0 = (int64_t)vb * kIsectBlock, j = j0 + threadIdx.x;
+  if (j0 >= n_vis) {   // (groups beyond the visible count: the launch is sized for a host-side bound)
+    if (threadIdx.x == 0) btot[vb] = 0u;
     return;
   }
   cnt[threadIdx.x] = 0u;
@@ -949,26 +1005,30 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     if (hi > lo) atomicAdd(&cnt[g], (uint32_t)(hi - lo));
   }
   __syncthreads();
-  if (j < CN) cnt_sorted[j] = cnt[threadIdx.x];
   if (tiles_per_gauss && j < n_vis) tiles_per_gauss[asc ? asc[sorted_idx[j]] : sorted_idx[j]] = (int32_t)cnt[threadIdx.x];
   uint32_t total;
   block_excl_scan(cnt[threadIdx.x], total, S.lw);
   // (the grand total M is formed from btot[] by finish_counts_kernel: one atomic per workgroup on ONE address serialises in L2,
   //  ~7 ns each, at the tail of a kernel that runs a single round of workgroups)
-  if (threadIdx.x == 0) btot[blockIdx.x] = total;
-  (void)m_total;
+  if (threadIdx.x == 0) btot[vb] = total;
+}
+__global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
+    const uint64_t *__restrict__ n_vis_dev, int64_t n_cap, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
+    int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int64_t N, float4 *__restrict__ rec, uint32_t *__restrict__ btot,
+    const uint32_t *__restrict__ asc) {
+  __shared__ CountRowsSh sh;
+  isect_count_rows_block(sh, (int)blockIdx.x, bounded_count(n_vis_dev, n_cap), sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h,
+                         tiles_per_gauss, N, rec, btot, asc);
 }
 
-__global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
-    const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ btot,
-    const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
-    const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
-    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec, uint32_t *__restrict__ zero_words, int n_zero) {
-  __shared__ RowStage S;
-  // (the group rows of the tile pass that follows: cleared here, by every workgroup of the launch a word each, before anything returns)
-  for (int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * kIsectBlock) zero_words[i] = 0u;
-  const int64_t n_vis = (int64_t)*n_vis_dev;
-  const int64_t j0 = (int64_t)blockIdx.x * kIsectBlock;
+struct EmitRowsSh { RowStage S; };
+__device__ __forceinline__ void isect_emit_rows_block(EmitRowsSh &sh, int vb, int64_t n_vis, int64_t N, const uint32_t *sorted_idx,
+                                                      const uint32_t *btot, const float *means2d, const int32_t *radii, const float *conics,
+                                                      const float *opacities, int tile_size, int tile_w, int tile_h, uint32_t *keys,
+                                                      uint32_t *vals, int pack_shift, const float4 *rec) {
+  RowStage &S = sh.S;
+  const int64_t j0 = (int64_t)vb * kIsectBlock;
   if (j0 >= n_vis) return;
   const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, nullptr, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec);
   const bool cull = conics != nullptr;
@@ -977,7 +1037,7 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
   uint32_t carry;
   {
     uint32_t part = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kIsectBlock) part += btot[b];
+    for (int b = threadIdx.x; b < vb; b += kIsectBlock) part += btot[b];
     block_excl_scan(part, carry, S.lw);
   }
   for (uint32_t base = 0; base < R; base += kIsectBlock) {   // uniform trip count: the scan below has barriers
@@ -1006,6 +1066,17 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
       }
     }
   }
+}
+__global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
+    const uint64_t *__restrict__ n_vis_dev, int64_t N, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ btot,
+    const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec, uint32_t *__restrict__ zero_words, int n_zero) {
+  __shared__ EmitRowsSh sh;
+  // (the group rows of the tile pass that follows: cleared here, by every workgroup of the launch a word each, before anything returns)
+  for (int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * kIsectBlock) zero_words[i] = 0u;
+  isect_emit_rows_block(sh, (int)blockIdx.x, (int64_t)*n_vis_dev, N, sorted_idx, btot, means2d, radii, conics, opacities, tile_size, tile_w,
+                        tile_h, keys, vals, pack_shift, rec);
 }
 
 
@@ -1110,6 +1181,7 @@ int bds::prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlot
   out->zero_me = L.tables;
   out->zero_elems = (int64_t)short_sort_elems(CN);
   out->m_total = L.total;
+  out->bar = reinterpret_cast<uint32_t *>(L.total) + 10;   // (kBarCountWord, kBarGenWord: the persistent launch's device-wide barrier)
   return BDS_OK;
 }
 
@@ -1169,11 +1241,191 @@ __global__ __launch_bounds__(256) void finish_counts_kernel(const uint32_t *__re
   if (counts_host) __threadfence_system();
 }
 
+// ------------------------------------------------------------------------------------------
+// The device-count tile stage as ONE persistent launch (bds_isect_lists_dev)
+// ------------------------------------------------------------------------------------------
+// In the replayed frame the stage's 13 short launches run next to another stream's compositor, whose thousands of pending one-wave
+// workgroups take every wave slot that frees up: each launch of this latency-bound stage starts from zero resident waves and queues
+// again (195 us alone, ~520 us in the frame; profiles/NOTES.md).  Here a fixed set of workgroups -- few enough to be resident
+// together whatever else runs -- keeps its waves from the compaction to the last scatter and walks the SAME block bodies phase by
+// phase over grid-strided workgroup indices; the phases are separated by a device-wide barrier (arrive counter + generation word in
+// the prepare workspace, cleared by the projection's prepare launch).  Each XCD has its own L2: a barrier releases the workgroup's
+// writes (__threadfence = L2 write-back on gfx950) before it arrives and invalidates after it leaves.  A barrier that is not
+// released within ~1 s gives up: the view is marked overflowed (it renders nothing; counts_host[2] = 2) instead of hanging the GPU.
+constexpr int kBarCountWord = 10;   // arrive counter; the generation word follows (uint32 words of PrepWs::total, behind the five uint64 counts)
+constexpr uint32_t kBarSpinLimit = 1u << 20;
+
+__device__ __forceinline__ bool grid_barrier(uint32_t *bar, uint32_t nwg, uint32_t *lds_ok) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ok = 1u;
+    __threadfence();   // release: this workgroup's phase output leaves its XCD's L2
+    const uint32_t gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == nwg - 1u) {   // last to arrive: re-arm the counter, then open the gate
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kBarSpinLimit) { ok = 0u; break; }
+      }
+    }
+    __threadfence();   // acquire: the other workgroups' output is read from memory, not from stale L2 lines
+    *lds_ok = ok;
+  }
+  __syncthreads();
+  return *lds_ok != 0u;
+}
+
+struct TileStageArgs {
+  // compaction + depth order (PrepWs)
+  int64_t N;
+  const int32_t *radii;
+  const float *depths, *means2d, *conics, *opacities;
+  uint32_t *tile_sums, *ka, *va, *kb, *vb, *asc, *hist, *ghist;
+  int64_t ng;
+  uint64_t *counts;
+  volatile int64_t *counts_host;
+  int64_t cap_m, cap_vis;
+  int tile_size, tile_w, tile_h;
+  int32_t *tiles_per_gauss;
+  float4 *rec;
+  uint32_t *btot;
+  // list build (BuildWs)
+  uint32_t *k_emit, *k_out, *whist, *wghist;
+  int wide_zero_n, rank_bits, bits, n_tiles;
+  uint32_t *vals_out;
+  int32_t *offsets;
+  // launch shape
+  int nvb_compact, nvb_sort, nvb_rows, nvb_wide;
+};
+
+template <int kBins>
+__global__ __launch_bounds__(256) void tile_stage_persistent_kernel(TileStageArgs a) {
+  union Sh {
+    VisCompactSh vc;
+    ShortHistSh sh;
+    ShortScatterSh ss;
+    CountRowsSh cr;
+    EmitRowsSh er;
+    HistWideSh<kBins> hw;
+    ScatterWideSh<kBins> sw;
+    unsigned long long part[256];
+  };
+  __shared__ Sh S;
+  __shared__ uint32_t bar_ok;
+  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+  uint32_t *bar = reinterpret_cast<uint32_t *>(a.counts) + kBarCountWord;
+  uint64_t *n_vis_slot = a.counts + 1;
+#define BDS_TILE_BARRIER()                                   \
+  do {                                                       \
+    if (!grid_barrier(bar, (uint32_t)G, &bar_ok)) {          \
+      if (threadIdx.x == 0) {                                \
+        a.counts[kCountMEff] = 0ull;                         \
+        a.counts[kCountVisEff] = 0ull;                       \
+        a.counts[kCountOverflow] = 1ull;                     \
+        if (a.counts_host) a.counts_host[2] = 2;             \
+      }                                                      \
+      return;                                                \
+    }                                                        \
+  } while (0)
+  // 1. visible entries -> (depth key, position) in index order + the first digit's histogram
+  for (int vb = wg; vb < a.nvb_compact; vb += G) {
+    visible_compact_block(S.vc, vb, a.nvb_compact, a.N, a.radii, a.depths, a.tile_sums, a.ka, a.va, a.hist, a.ghist, n_vis_slot, a.asc, 1,
+                          kScanTile / 256);
+    __syncthreads();
+  }
+  BDS_TILE_BARRIER();
+  const int64_t n_vis_raw = (int64_t)*n_vis_slot;
+  const int64_t n_vis = n_vis_raw > a.cap_vis ? 0 : n_vis_raw;   // (an overflow: nothing is sorted or counted, see bounded_count)
+  // 2. depth order: four stable 8-bit passes; ends in (ka, va)
+  {
+    uint32_t *kin = a.ka, *vin = a.va, *kout = a.kb, *vout = a.vb;
+    for (int p = 0; p < 4; p++) {
+      uint32_t *gh = a.ghist + (int64_t)p * a.ng * 256;
+      if (p > 0) {
+        for (int vb = wg; vb < a.nvb_sort; vb += G) {
+          short_hist_block(S.sh, vb, kin, n_vis, 8 * p, a.hist, gh);
+          __syncthreads();
+        }
+        BDS_TILE_BARRIER();
+      }
+      for (int vb = wg; vb < a.nvb_sort; vb += G) {
+        short_scatter_block(S.ss, vb, kin, vin, n_vis, 8 * p, a.hist, gh, kout, vout);
+        __syncthreads();
+      }
+      BDS_TILE_BARRIER();
+      uint32_t *t;
+      t = kin; kin = kout; kout = t;
+      t = vin; vin = vout; vout = t;
+    }
+  }
+  // 3. tiles per entry, in depth order
+  for (int vb = wg; vb < a.nvb_rows; vb += G) {
+    isect_count_rows_block(S.cr, vb, n_vis, a.va, a.means2d, a.radii, a.conics, a.opacities, a.tile_size, a.tile_w, a.tile_h,
+                           a.tiles_per_gauss, a.N, a.rec, a.btot, a.asc);
+    __syncthreads();
+  }
+  BDS_TILE_BARRIER();
+  // 4. M: every workgroup sums the per-group totals itself (a few thousand L2-resident words); the first one publishes the counts
+  int64_t M_eff, nvis_eff;
+  {
+    unsigned long long s = 0;
+    for (int b = threadIdx.x; b < a.nvb_rows; b += 256) s += a.btot[b];
+    S.part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) S.part[threadIdx.x] += S.part[threadIdx.x + o];
+      __syncthreads();
+    }
+    const unsigned long long M = S.part[0];
+    __syncthreads();
+    const bool over = (int64_t)M > a.cap_m || n_vis_raw > a.cap_vis;
+    M_eff = over ? 0 : (int64_t)M;
+    nvis_eff = over ? 0 : n_vis;
+    if (wg == 0 && threadIdx.x == 0) {
+      a.counts[0] = M;
+      a.counts[kCountMEff] = (uint64_t)M_eff;
+      a.counts[kCountVisEff] = (uint64_t)nvis_eff;
+      a.counts[kCountOverflow] = over ? 1ull : 0ull;
+      if (a.counts_host) {
+        if (over) a.counts_host[2] = 1;   // sticky: the host clears it when it has provisioned more
+        a.counts_host[0] = (int64_t)M;
+        a.counts_host[1] = n_vis_raw;
+        __threadfence_system();
+      }
+    }
+  }
+  // 5. packed entries (tile << rank_bits | depth rank) in depth order; the tile pass's group rows cleared on the way
+  for (int64_t i = (int64_t)wg * 256 + threadIdx.x; i < a.wide_zero_n; i += (int64_t)G * 256) a.wghist[i] = 0u;
+  for (int vb = wg; vb < a.nvb_rows; vb += G) {
+    isect_emit_rows_block(S.er, vb, nvis_eff, a.N, a.va, a.btot, a.means2d, a.radii, a.conics, a.opacities, a.tile_size, a.tile_w, a.tile_h,
+                          a.k_emit, (uint32_t *)nullptr, a.rank_bits, a.rec);
+    __syncthreads();
+  }
+  BDS_TILE_BARRIER();
+  // 6. ONE stable pass over the whole tile key: lists of compact positions + per-tile offsets
+  const uint32_t mask = (1u << a.bits) - 1u;
+  for (int vb = wg; vb < a.nvb_wide; vb += G) {
+    radix_hist_wide_block<kBins>(S.hw, vb, a.k_emit, M_eff, a.rank_bits, mask, a.whist, a.wghist);
+    __syncthreads();
+  }
+  BDS_TILE_BARRIER();
+  for (int vb = wg; vb < a.nvb_wide; vb += G) {
+    radix_scatter_keys_wide_block<kBins>(S.sw, vb, a.k_emit, M_eff, a.rank_bits, mask, a.bits, a.whist, a.wghist, a.k_out, a.va,
+                                         (1u << a.rank_bits) - 1u, a.vals_out, a.offsets, a.n_tiles);
+    __syncthreads();
+  }
+#undef BDS_TILE_BARRIER
+}
+
 // enqueues the whole prepare stage; the counts (M, visible entries) end up in L.total on the device
 static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,
                            const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                            int32_t *tiles_per_gauss, void *ws, size_t ws_bytes, int compact, bds_stream_t stream,
-                           uint64_t **counts_dev, const uint32_t **btot_out, int *nblocks_out) {
+                           uint64_t **counts_dev, const uint32_t **btot_out, int *nblocks_out, int64_t nvis_bound = -1) {
   BDS_REQUIRE(C >= 1 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0);
   const int64_t CN = (int64_t)C * N;
   BDS_REQUIRE(CN < (int64_t)1 << 31);
@@ -1186,12 +1438,19 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
   PrepWs L = prep_layout(ws, CN);
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const unsigned grid = (unsigned)cdiv(CN, kIsectBlock);
+  // nvis_bound (device-count form: the caller's capacity for the visible entries): everything behind the compaction is launched for
+  // that many entries instead of for all C*N -- at 15 % visibility four of five workgroups of those launches had nothing to do, and
+  // next to another stream's compositor every workgroup, idle or not, waits for wave slots (a count beyond the bound is an overflow:
+  // the view renders nothing, whatever these launches leave behind)
+  if (nvis_bound < 0 || nvis_bound > CN || !option_get(kOptCapLaunch)) nvis_bound = CN;
+  const int64_t n_cap = nvis_bound < CN ? nvis_bound : (int64_t)-1;
+  const unsigned grid = (unsigned)cdiv(nvis_bound > 0 ? nvis_bound : 1, kIsectBlock);
   uint64_t *n_vis = L.total + 1;
   int rc;
   if (CN <= kShortSortMax && option_get(kOptShortSort)) {
     // 12 launches instead of 27: the whole stage is launch-latency bound at this size
     const int64_t nb = cdiv(CN, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
+    const unsigned nb_launch = (unsigned)cdiv(nvis_bound > 0 ? nvis_bound : 1, kShortChunk);
     uint32_t *hist = L.tables, *ghist = L.tables + nb * 256;   // ghist[p] = ghist + p * ng * 256
     const unsigned tiles = (unsigned)cdiv(CN, kScanTile);
     // 1. visible entries -> (depth key, id) pairs in index order + histogram of the first digit
@@ -1206,8 +1465,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
     for (int p = 0; p < 4; p++) {
       uint32_t *gh = ghist + (int64_t)p * ng * 256;
-      if (p > 0) hipLaunchKernelGGL(short_hist_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, n_vis, 8 * p, hist, gh);
-      hipLaunchKernelGGL(short_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, st, kin, vin, n_vis, 8 * p, hist, gh, kout,
+      if (p > 0) hipLaunchKernelGGL(short_hist_kernel, dim3(nb_launch), dim3(kSortBlock), 0, st, kin, n_vis, n_cap, 8 * p, hist, gh);
+      hipLaunchKernelGGL(short_scatter_kernel, dim3(nb_launch), dim3(kSortBlock), 0, st, kin, vin, n_vis, n_cap, 8 * p, hist, gh, kout,
                          vout);
       uint32_t *t;
       t = kin; kin = kout; kout = t;
@@ -1215,8 +1474,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     }
     BDS_LAUNCH_CHECK();
     // 3. tiles per entry, in depth order (tiles_per_gauss was zeroed by visible_reduce_kernel)
-    hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
+    hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, n_vis, n_cap, L.va, means2d, radii, conics,
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, N, L.rec, L.btot,
                        (compact & 1) ? L.asc : (const uint32_t *)nullptr);
     BDS_LAUNCH_CHECK();
   } else {
@@ -1240,8 +1499,8 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     }
     // 3. tiles per entry, in depth order
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
-    hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, n_vis, L.va, means2d, radii, conics,
-                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, L.kb, N, L.rec, L.btot, L.total,
+    hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, n_vis, (int64_t)-1, L.va, means2d, radii, conics,
+                       opacities, tile_size, tile_w, tile_h, tiles_per_gauss, N, L.rec, L.btot,
                        compact ? L.asc : (const uint32_t *)nullptr);
     BDS_LAUNCH_CHECK();
   }
@@ -1318,7 +1577,7 @@ extern "C" int bds_isect_prepare_dev(int C, int64_t N, const float *means2d, con
   const uint32_t *btot = nullptr;
   int nblocks = 0;
   int rc = prepare_enqueue(C, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, tiles_per_gauss, ws, ws_bytes,
-                           compact, stream, &counts_dev, &btot, &nblocks);
+                           compact, stream, &counts_dev, &btot, &nblocks, n_visible_capacity);
   if (rc != BDS_OK) return rc;
   void *mapped = nullptr;
   if (counts_pinned && hipHostGetDevicePointer(&mapped, counts_pinned, 0) != hipSuccess) { (void)hipGetLastError(); return BDS_EINVAL; }
@@ -1390,7 +1649,9 @@ static int isect_build_impl(int C, int64_t N, int64_t M, int64_t n_visible, cons
     const bool wide = bits_per > 8;
     uint32_t *wide_zero = wide ? B.temp + align_up((size_t)(1 << kWideBits) * (size_t)cdiv(M, kSortChunk), 4) : nullptr;
     const int wide_zero_n = wide ? (int)radix_wide_group_elems(M, bits_per) : 0;
-    hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(CN, kIsectBlock)), dim3(kIsectBlock), 0, st, nvis_dev, N, P.va,
+    // (n_visible: the exact count, or the capacity of the device-count form -- no workgroups for entries that cannot exist)
+    const int64_t emit_bound = (n_visible > 0 && n_visible < CN && option_get(kOptCapLaunch)) ? n_visible : CN;
+    hipLaunchKernelGGL(isect_emit_rows_kernel, dim3((unsigned)cdiv(emit_bound, kIsectBlock)), dim3(kIsectBlock), 0, st, nvis_dev, N, P.va,
                        P.btot, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, k_emit, (uint32_t *)nullptr, rank_bits, P.rec,
                        wide_zero, wide_zero_n);
     BDS_LAUNCH_CHECK();
@@ -1459,6 +1720,60 @@ extern "C" int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t
   BDS_REQUIRE(M_capacity > 0 && n_visible_capacity > 0);
   return isect_build_impl(C, N, M_capacity, n_visible_capacity, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws,
                           ws_bytes, ws2, ws2_bytes, nullptr, flatten_ids, isect_offsets, nullptr, compact, stream, true);
+}
+
+// prepare_dev (compact = 3: compact positions, visible counts left by bds_project_view_prepare_fwd) + build_dev as ONE persistent
+// launch (tile_stage_persistent_kernel).  BDS_ECAPACITY when the configuration is outside what that kernel covers (the short sort
+// path, packed lists whose whole tile key is one 9-10 bit digit) or bds_set_option(5, 0): call the two entry points then.
+extern "C" int bds_isect_lists_dev(int64_t N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                                   const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws,
+                                   size_t ws_bytes, int64_t M_capacity, int64_t n_visible_capacity, int64_t *counts_pinned, void *ws2,
+                                   size_t ws2_bytes, int32_t *flatten_ids, int32_t *isect_offsets, bds_stream_t stream) {
+  BDS_REQUIRE(N > 0 && N < (int64_t)1 << 31 && tile_size > 0 && tile_w > 0 && tile_h > 0);
+  BDS_REQUIRE(M_capacity > 0 && M_capacity < (int64_t)1 << 31 && n_visible_capacity > 0);
+  BDS_REQUIRE(means2d && radii && depths && ws && ws2 && flatten_ids && isect_offsets);
+  BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
+  const int G = option_get(kOptTilePersist);
+  if (G <= 0) return BDS_ECAPACITY;
+  if (!(N <= kShortSortMax && option_get(kOptShortSort) && option_get(kOptPacked))) return BDS_ECAPACITY;
+  const int n_tiles = tile_w * tile_h;
+  int nbits = 1;
+  while (((int64_t)1 << nbits) < n_tiles) nbits++;
+  const int rank_bits = 32 - nbits;
+  if (nbits <= 8 || nbits > kWideBits || n_visible_capacity > ((int64_t)1 << rank_bits)) return BDS_ECAPACITY;
+  PrepWs P = prep_layout(ws, N);
+  if (ws_bytes < P.bytes) return BDS_EWORKSPACE;
+  BuildWs B = build_layout(ws2, M_capacity);
+  if (ws2_bytes < B.bytes) return BDS_EWORKSPACE;
+  void *mapped = nullptr;
+  if (counts_pinned && hipHostGetDevicePointer(&mapped, counts_pinned, 0) != hipSuccess) { (void)hipGetLastError(); return BDS_EINVAL; }
+  const int64_t nb = cdiv(N, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
+  const int64_t vis_bound = n_visible_capacity < N ? n_visible_capacity : N;
+  TileStageArgs a;
+  a.N = N;
+  a.radii = radii; a.depths = depths; a.means2d = means2d; a.conics = conics; a.opacities = opacities;
+  a.tile_sums = P.temp; a.ka = P.ka; a.va = P.va; a.kb = P.kb; a.vb = P.vb; a.asc = P.asc;
+  a.hist = P.tables; a.ghist = P.tables + nb * 256; a.ng = ng;
+  a.counts = P.total; a.counts_host = static_cast<volatile int64_t *>(mapped);
+  a.cap_m = M_capacity; a.cap_vis = n_visible_capacity;
+  a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h;
+  a.tiles_per_gauss = tiles_per_gauss; a.rec = P.rec; a.btot = P.btot;
+  a.k_emit = B.ka; a.k_out = B.kb;     // (one pass: emitted into ka, sorted into kb -- as isect_build_impl lays it out)
+  a.whist = B.temp;
+  a.wghist = B.temp + align_up((size_t)(1 << kWideBits) * (size_t)cdiv(M_capacity, kSortChunk), 4);
+  a.wide_zero_n = (int)radix_wide_group_elems(M_capacity, nbits);
+  a.rank_bits = rank_bits; a.bits = nbits; a.n_tiles = n_tiles;
+  a.vals_out = reinterpret_cast<uint32_t *>(flatten_ids);
+  a.offsets = isect_offsets;
+  a.nvb_compact = (int)cdiv(N, kScanTile);
+  a.nvb_sort = (int)cdiv(vis_bound, kShortChunk);
+  a.nvb_rows = (int)cdiv(vis_bound, kIsectBlock);
+  a.nvb_wide = (int)cdiv(M_capacity, kSortChunk);
+  hipStream_t st = as_stream(stream);
+  if (nbits == 9) hipLaunchKernelGGL((tile_stage_persistent_kernel<512>), dim3((unsigned)G), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((tile_stage_persistent_kernel<1024>), dim3((unsigned)G), dim3(256), 0, st, a);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
 }
 
 extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,

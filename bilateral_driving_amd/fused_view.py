@@ -82,8 +82,17 @@ class ListCapacity:
         self.counts.np = self.counts.numpy()
 
     def observed(self):
-        """(M, visible) of the last completed visit (the caller has synchronised with it)."""
+        """(M, visible) of the last completed visit (the caller has synchronised with it).  When the VISIBLE count outgrew its
+        capacity the tile counting did not run (its launches are sized by that capacity) and M reads 0; ``wanted`` extrapolates."""
         return int(self.counts.np[0]), int(self.counts.np[1])
+
+    def wanted(self):
+        """(M, visible) to provision for after the last visit: ``observed()``; after a visible-count overflow (M unknown) the
+        current list capacity scaled by the growth of the visible set."""
+        M, n_vis = self.observed()
+        if n_vis > self.nvis_cap:
+            M = max(M, int(self.m_cap * (n_vis / max(self.nvis_cap, 1))) + 1)
+        return M, n_vis
 
     def overflowed(self) -> bool:
         return bool(self.counts.np[2])
@@ -139,6 +148,23 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
+_TILE_PERSIST = None
+
+
+def _tile_persist_groups() -> int:
+    """Workgroups of the persistent tile-stage launch (include/bds.h option 5; 0 = the 13-launch form).  ``BDS_TILE_PERSIST``
+    sets the option once (A/B sessions); otherwise whatever ``bds_set_option(5, ..)`` says."""
+    global _TILE_PERSIST
+    if _TILE_PERSIST is None:
+        _TILE_PERSIST = True
+        env = os.environ.get("BDS_TILE_PERSIST")
+        if env is not None:
+            L.set_option(L.OPT_TILE_PERSIST, int(env))
+        if os.environ.get("BDS_CAP_LAUNCH") is not None:
+            L.set_option(L.OPT_CAP_LAUNCH, int(os.environ["BDS_CAP_LAUNCH"]))
+    return int(L.lib().bds_get_option(L.OPT_TILE_PERSIST))
+
+
 def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before_wait=None) -> _Front:
     """``before_wait`` (optional callable): host work of the caller that does not depend on the list counts (allocations, level
     structs); it runs while the GPU is still producing them, so that after the one host wait of a view only launches remain."""
@@ -189,12 +215,16 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     isect_offsets = _empty((1, th, tw), dev, torch.int32)
     cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
     caps = cfg.get("caps")                 # ListCapacity: the device-count form (no host wait in this view)
+    persist = False
     if caps is not None:
         counts, ev = caps.counts, None
-        with L.timed("isect_prepare"):
-            L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
-                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
-                                              counts.data_ptr(), 3 if pre_reduced else 1, st), "bds_isect_prepare_dev")
+        # the whole tile stage as ONE persistent launch (bds_isect_lists_dev, enqueued by _front_finish_dev) where it applies
+        persist = pre_reduced and _tile_persist_groups() > 0
+        if not persist:
+            with L.timed("isect_prepare"):
+                L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
+                                                  L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
+                                                  counts.data_ptr(), 3 if pre_reduced else 1, st), "bds_isect_prepare_dev")
     else:
         counts, ev = _host_sync_objects(dev)
         with L.timed("isect_prepare"):
@@ -232,6 +262,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
     f.tiles_per_gauss, f.isect_offsets, f.ws, f.ws_bytes, f.cull = tiles_per_gauss, isect_offsets, ws, ws_bytes, cull
     f.counts, f.ev, f.key, f.cap, f.vcap, f.caps = counts, ev, key, cap, vcap, caps
+    f.persist = persist
     f.buf, f.ws2, f.ws2_bytes, f.rec_buf, f.ids_offset = buf, ws2, ws2_bytes, rec_buf, off
     f.list_tile, f.list_tw, f.list_th = LT, tw, th
     f.W, f.H, f.N = W, H, N
@@ -285,9 +316,21 @@ def _front_finish_dev(f: _Front) -> _Front:
     f.flatten = f.buf
     f.vis_ids = f.ws[f.ids_offset:f.ids_offset + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
-                                        f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
-                                        L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
+        rc = L.BDS_ECAPACITY
+        if f.persist:
+            rc = lib.bds_isect_lists_dev(N, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile, f.list_tw, f.list_th,
+                                         L.ptr(f.tiles_per_gauss), L.ptr(f.ws), f.ws_bytes, M, n_vis, f.caps.counts.data_ptr(), L.ptr(f.ws2),
+                                         f.ws2_bytes, L.ptr(f.flatten), L.ptr(f.isect_offsets), st)
+            if rc not in (L.BDS_OK, L.BDS_ECAPACITY):
+                L.check(rc, "bds_isect_lists_dev")
+            if rc == L.BDS_ECAPACITY:      # a shape the persistent launch does not cover: the prepare stage it skipped, then the build
+                L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile, f.list_tw,
+                                                  f.list_th, L.ptr(f.tiles_per_gauss), L.ptr(f.ws), f.ws_bytes, M, n_vis,
+                                                  f.caps.counts.data_ptr(), 3, st), "bds_isect_prepare_dev")
+        if rc == L.BDS_ECAPACITY:
+            L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
+                                            f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
+                                            L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
     if f.colors is not None and os.environ.get("BDS_SH_BEFORE_BUILD") != "1":
         with L.timed("sh_fwd"):
             L.check(lib.bds_sh_view_fwd(N, f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh), L.ptr(f.radii),

@@ -485,7 +485,7 @@ class FrameGraph:
     def _check_counts(self, raise_on_overflow: bool = False) -> bool:
         ok = True
         for v, c in enumerate(self.caps):
-            M, n_vis = c.observed()
+            M, n_vis = c.wanted()
             if c.overflowed() or M > c.m_cap or n_vis > c.nvis_cap:
                 if raise_on_overflow:
                     raise L.BdsError(f"view {v}: list counts (M = {M}, visible = {n_vis}) exceed the calibrated capacities "
