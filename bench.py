@@ -77,6 +77,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one frame (all views of the rig) per rank")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline")
+    ap.add_argument("--scene", choices=("ring", "lidar"), default="ring",
+                    help="ring: SURVEY.md 8(d)'s synthetic scene (BASELINE.json's metric is quoted on it).  lidar: a lidar-INITIALISED street "
+                         "scene as the reference seeds its Background class (harness.lidar_scene: 0.8 N points on road / facades / clutter + "
+                         "0.1 N near + 0.1 N far randoms, isotropic scales = mean 3-NN distance; default N = 1 M) -- the other end of the "
+                         "splat-size distribution, same rig, same line")
+    ap.add_argument("--lidar-opacity", choices=("trained", "init"), default="trained")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -234,11 +240,51 @@ def _newest_profile(suffix, kernel_substr, field, workload="headline"):
     return None, None
 
 
-def _pair_stats(N, W, H):
+# kernels of ONE replayed view of the headline frame (name substring, launches per view): what `frame_valu_issue_frac` sums
+_FRAME_KERNELS = (("project_view_fwd_kernel<true>", 1), ("visible_compact_kernel", 1), ("short_hist_kernel", 3), ("short_scatter_kernel", 4),
+                  ("isect_count_rows_kernel", 1), ("finish_counts_kernel", 1), ("isect_emit_rows_kernel", 1), ("radix_hist_wide_kernel", 1),
+                  ("radix_scatter_keys_wide_kernel", 1), ("tile_stage_persistent_kernel", 1), ("splat_pack_sh_kernel", 1),
+                  ("rasterize_fwd_wave_kernel<4, true, true>", 1), ("ms_tile_fwd_kernel<3, true>", 1), ("ms_apply_bwd_x_kernel", 1),
+                  ("ms_tile_bwd_kernel", 1), ("cell_bwd_kernel<false>", 1), ("ms_guidance_blend_bwd_kernel", 1), ("rasterize_bwd_wave_kernel<4, true, true, false>", 1),
+                  ("sh_view_bwd_list_kernel<3, true, true>", 1), ("project_view_bwd_list_kernel<true, true, true>", 1),
+                  ("view_grads_clear_list_kernel", 1))
+
+
+def _frame_valu_issue(ms_per_view, workload="headline", clock_ghz=2.4):
+    """Vector-issue time of one view's kernels / the measured time per view.  A wave64 vector instruction occupies its SIMD's issue
+    port for 4 cycles: the committed SQ counter pass (profiles/*_sq_counters.json, SQ_ACTIVE_INST_VALU per launch) summed over the
+    frame's kernels x 4 / (1024 SIMDs x clock) is the time the view would take if every SIMD issued a vector instruction every
+    cycle it could -- the floor of this instruction mix; the fraction says how much of the frame's time the issue ports are busy."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+        base = os.path.basename(f)
+        if any(o in base for o in ("_c2_", "_c3_", "_c5_")) != (workload != "headline") or (workload != "headline" and f"_{workload}_" not in base):
+            continue
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        busy, used = 0.0, []
+        for pat, mult in _FRAME_KERNELS:
+            hit = [v for k, v in ks.items() if pat in k and "SQ_ACTIVE_INST_VALU" in v]
+            if hit:
+                busy += mult * 4.0 * hit[0]["SQ_ACTIVE_INST_VALU"]
+                used.append(pat)
+        if not used:
+            continue
+        issue_ms = busy / 1024.0 / (clock_ghz * 1e9) * 1e3
+        return {"value": issue_ms / ms_per_view, "issue_ms_per_view": issue_ms, "ms_per_view": ms_per_view, "counter_source": base,
+                "kernels_found": len(used), "clock_ghz_assumed": clock_ghz,
+                "note": "sum over the view's kernels of 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x clock) from the committed counter pass, "
+                        "divided by the measured time per view: the share of the frame in which the vector issue ports are busy"}
+    return None
+
+
+def _pair_stats(N, W, H, params=None):
     spec = importlib.util.spec_from_file_location("pair_stats", os.path.join(ROOT, "scripts", "pair_stats.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.pair_stats(N, W, H, view=0)
+    return mod.pair_stats(N, W, H, view=0, params=params)
 
 
 def main():
@@ -287,14 +333,14 @@ def main():
         if os.environ.get(env):
             L.set_option(which, int(os.environ[env]))
     wl = dict(WORKLOADS[args.workload])
-    N = args.gaussians or wl["gaussians"]
+    N = args.gaussians or (1_000_000 if args.scene == "lidar" else wl["gaussians"])
     W, H = args.width or wl["width"], args.height or wl["height"]
     yaws = {"six": Hn.SIX_CAM_YAWS, "five": Hn.FIVE_CAM_YAWS, "one": (0.0,)}[wl["rig"]]
     cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev, origin=(1.5 * rank, 0.0, 0.0))   # this rank's timestep of the drive
     V = min(args.views_per_step or len(cams), len(cams))
     for cam in cams:   # the camera pose is learnable in the reference (trainers/base.py:328-329,399): its gradient stays live
         cam.viewmat.requires_grad_(os.environ.get("BDS_BENCH_NO_POSE") != "1")   # (diagnostic switch)
-    params = Hn.synthetic_scene(N, seed=0, device=dev)
+    params = Hn.synthetic_scene(N, seed=0, device=dev) if args.scene == "ring" else Hn.lidar_scene(N, seed=0, device=dev, opacity=args.lidar_opacity)
     for v in params.values():
         v.requires_grad_(True)
     grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), levels=wl["levels"], device=dev)]
@@ -324,6 +370,7 @@ def main():
 
     stats = {}
     plan = None
+    selfcheck = None
     use_graph = not args.no_graph and not dense
     frame = None
     if use_graph:
@@ -450,6 +497,15 @@ def main():
             torch.cuda.synchronize()
             alone += frame.mark_samples("rasterize_bwd")
         tsum = {"rasterize_bwd": (len(alone), sum(alone) / max(len(alone), 1))} if alone else {}
+        # the TIMED path checked at this size, every run: one more replayed frame against one eager frame on the same parameters
+        if world == 1 and os.environ.get("BDS_BENCH_NO_SELFCHECK") != "1":
+            from bilateral_driving_amd.selfcheck import frame_against_eager
+            try:
+                selfcheck = frame_against_eager(frame, params, cams[:V], grids, skies[:V], targets[:V], factors)
+            except Exception as e:
+                selfcheck = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+            if not selfcheck["ok"]:
+                print(f"bench.py: ERROR: the replayed frame does not match the eager frame: {selfcheck}", file=sys.stderr)
     else:
         tsum = L.timer_summary()
         Ms, nvs = list(stats["M"]), list(stats["n_vis"])
@@ -569,9 +625,10 @@ def main():
     alg_bytes = 92.0 * M_mean + 28.0 * P
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if calls else float("nan")
     kname = L.rasterize_kernel_name(True, 4, True, FV.LIST_TILE)   # the library names the kernel its launch switches select
-    traffic, traffic_src = _newest_profile("_pmc.json", kname, "hbm_bytes_per_launch_corrected", args.workload)
+    counters_apply = args.scene == "ring"     # (the committed counter passes are of the ring scene)
+    traffic, traffic_src = _newest_profile("_pmc.json", kname, "hbm_bytes_per_launch_corrected", args.workload) if counters_apply else (None, None)
     traffic_error = None
-    if traffic is None:   # loud, not silent: a renamed kernel or a missing counter pass must not pass as "no traffic figure"
+    if traffic is None and counters_apply:   # loud, not silent: a renamed kernel or a missing counter pass must not pass as "no traffic figure"
         traffic_error = f"no profiles/*_pmc.json holds counters of `{kname}`: re-run scripts/gpu_round.sh <tag> and scripts/summarize_profile.py"
         print("bench.py: WARNING: " + traffic_error, file=sys.stderr)
     roofline = {"bound": "hbm", "binding_roof": "valu issue (see `valu`): the kernel moves 0.15x its algorithmic bytes through HBM",
@@ -590,14 +647,17 @@ def main():
         roofline["traffic_error"] = traffic_error
     # the binding roof of K7/K8: vector instructions per visited (tile, Gaussian) pair
     valu = None
-    if rank == 0 and not args.no_pair_stats and args.workload == "headline" and N == wl["gaussians"]:
+    ring_headline = args.scene == "ring" and N == wl["gaussians"]     # (the committed counter passes are of this scene)
+    if rank == 0 and not args.no_pair_stats and args.workload == "headline" and (ring_headline or args.scene == "lidar"):
         try:
-            ps = _pair_stats(N, W, H)
-            insts, src = _newest_profile("_sq_counters.json", kname, "SQ_INSTS_VALU")
-            if insts is None:
+            ps = _pair_stats(N, W, H, params if args.scene == "lidar" else None)
+            insts, src = _newest_profile("_sq_counters.json", kname, "SQ_INSTS_VALU") if ring_headline else (None, None)
+            if insts is None and ring_headline:
                 print(f"bench.py: WARNING: no profiles/*_sq_counters.json holds `{kname}`", file=sys.stderr)
-            busy, _ = _newest_profile("_sq_counters.json", kname, "valu_busy_frac")
+            busy, _ = _newest_profile("_sq_counters.json", kname, "valu_busy_frac") if ring_headline else (None, None)
             valu = {"listed_pairs": ps["isects_listed"], "visited_pairs": ps["pairs_visited"], "pixel_blends": ps["pixel_blends"],
+                    "visited_over_listed": ps["pairs_visited"] / max(ps["isects_listed"], 1),
+                    "pixels_per_visited_pair": ps["mean_pixels_per_visited_pair"], "strips_per_visited_pair": ps["mean_strips_per_visited_pair"],
                     "pairs_view": 0, "valu_insts_per_launch": insts, "valu_insts_per_pair": None if insts is None else insts / ps["pairs_visited"],
                     "valu_frac": busy, "counter_source": src,
                     # per pair: ~35 vector ops per blending pixel (4 exp2, 4 rcp, fma-class rest); everything else is overhead
@@ -626,12 +686,22 @@ def main():
     if per_kernel_source.startswith("timing marks"):   # (what the marks of the device-count form bracket)
         alg["rasterize_fwd"] += 216.0 * nv_mean           # SH colours evaluated by the record pack (K1 on the visible rows)
         alg["bilagrid_fwd"] += 36.0 * P                   # L1 + TV loss on the launch: target in, loss gradient out
+    # entries whose SURVEY 8(d) byte count describes the REFERENCE's formulation rather than what this kernel moves: their GB/s figure
+    # is a speed-up over that formulation, not an achieved bandwidth
+    nominal = {"isect_build": "bytes of the reference's 16-px (tile, Gaussian) pairs; the fused view lists 64-px pairs (config.list_pairs_mean)",
+               "rasterize_fwd": "bytes of the reference's 16-px pairs; ~1 in 10 is ever reached by a pixel (valu.visited_over_listed) and the records stay in L2",
+               "rasterize_bwd": "bytes of the reference's 16-px pairs (92 B each); the counters see 0.15x of them (roofline_composite.traffic)",
+               "project_fwd": "counts all N rows; the outputs of the ~85 % culled Gaussians are never read again",
+               "isect_prepare": "36 B x all N + 64 B x visible: the stage is launch-latency bound, not bandwidth bound",
+               "sh_fwd": "32 B x all N of radii / depth / colour rows + the visible coefficient rows"}
     per_kernel = {}
     for k, (c, ms) in sorted(tall.items()):
         e = {"ms": round(ms, 4)}
         if k in alg and ms > 0:
             e["algorithmic_bytes"] = alg[k]
             e["algorithmic_GBps"] = round(alg[k] / (ms * 1e-3) / 1e9, 1)
+            if k in nominal:
+                e["nominal"], e["nominal_reason"] = True, nominal[k]
         per_kernel[k] = e
     # ---- the roofline block follows the workload's ACTUAL dominant operator: the longest entry of the per-operator table (the marked
     # capture of the timed frame).  The compositor's block stays as `roofline_composite`.
@@ -647,7 +717,7 @@ def main():
         knames = op_kernels[dom_op]() if dom_op in op_kernels else []
         tr, srcs = 0.0, []
         for kn in knames:   # counter traffic of every kernel the operator launches (None as soon as one is missing)
-            t_k, src_k = _newest_profile("_pmc.json", kn, "hbm_bytes_per_launch_corrected", args.workload)
+            t_k, src_k = _newest_profile("_pmc.json", kn, "hbm_bytes_per_launch_corrected", args.workload) if counters_apply else (None, None)
             if t_k is None:
                 tr = None
                 print(f"bench.py: WARNING: no profiles/*_pmc.json of workload {args.workload} holds counters of `{kn}`", file=sys.stderr)
@@ -674,10 +744,11 @@ def main():
         "ms_per_step_max": max(reps) / args.steps * 1e3, "timing": "median of `repeats` timed regions of `steps` steps each",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {wl['text']}; {N} Gaussians, {len(cams)}-cam ring {W}x{H}, RGB+ED, grids "
+        "config": {"workload": f"{args.workload}{'' if args.scene == 'ring' else ' on the LIDAR-initialised street scene (harness.lidar_scene, opacity ' + args.lidar_opacity + '), NOT the scene the metric is quoted on'}: "
+                               f"{wl['text']}; {N} Gaussians, {len(cams)}-cam ring {W}x{H}, RGB+ED, grids "
                                f"{[list(l) for l in wl['levels']]} factors {list(factors)}, L1+TV loss, camera-pose gradient live; one step = one "
                                f"frame of {V} views per GPU (1 iter = 1 view)",
-                   "workload_name": args.workload, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
+                   "workload_name": args.workload, "scene": args.scene, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V, "api_path_iters_per_sec": api_its,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
@@ -691,11 +762,13 @@ def main():
                    "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
                    "exchanges_per_step": fx.n_exchanges if world > 1 else 0,
                    "exchange": None if world == 1 else dict(mode="view" if fx.per_view else "frame", chosen_by=args.exchange, plan=plan)},
+        "frame_valu_issue_frac": _frame_valu_issue(ms_per_step / V, args.workload) if (counters_apply and args.workload == "headline" and N == wl["gaussians"]) else None,
         "roofline": roofline,
         "roofline_composite": roofline_composite,
         "valu": valu,
         "per_kernel": per_kernel,
         "per_kernel_source": per_kernel_source,
+        "selfcheck": selfcheck,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)
@@ -703,6 +776,8 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+    if selfcheck is not None and not selfcheck["ok"]:
+        sys.exit(3)      # a fast frame whose results differ from the eager frame's is not a result
 
 
 if __name__ == "__main__":

@@ -79,6 +79,82 @@ def synthetic_scene(N: int, seed: int = 0, device="cpu") -> Dict[str, Tensor]:
     return {k: v.to(device).contiguous() for k, v in out.items()}
 
 
+def lidar_scene(N: int = 1_000_000, seed: int = 0, device="cpu", opacity: str = "trained") -> Dict[str, Tensor]:
+    """A lidar-INITIALISED street scene, the other end of the splat-size distribution from ``synthetic_scene``: the reference seeds
+    its Background class with 800 k points sampled from the drive's accumulated lidar sweeps plus 100 k "near" randoms (uniform in
+    the scene sphere) and 100 k "far" ones (inverse distance uniform: the sky's stand-ins), and sets every scale to the MEAN DISTANCE
+    OF THE 3 NEAREST NEIGHBOURS in that combined set, isotropic, with random rotations
+    (/root/reference/project/configs/omnire_ms_bilateral_extended.yaml:75-80, models/trainers/scene_graph.py:156-190,
+    models/gaussians/vanilla.py:82-92; kNN: models/gaussians/basics.py:208-224) -- centimetre-sized splats on surfaces, most of them
+    smaller than half a 16-px tile, instead of the ring scene's range-proportional ones.  0.8 N lidar points on a 120 m street
+    corridor in the rig's frame (x forward, y left, z up; sensor 1.7 m above the road): 45 % road surface (denser near the
+    trajectory), 35 % facades of building blocks either side, 20 % clutter (parked cars, poles, tree crowns), 0.1 N + 0.1 N randoms.
+    ``opacity``: "trained" = logits N(0, 1.5) on the lidar points, N(-2.5, 1) on the randoms, SH rest N(0, 0.05); "init" = the
+    reference's step-0 state (opacity 0.1 everywhere, rest coefficients 0: vanilla.py:96-104)."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(1234 + seed)
+    n_lidar, n_near = int(0.8 * N), int(0.1 * N)
+    n_far = N - n_lidar - n_near
+    n_road, n_fac = int(0.45 * n_lidar), int(0.35 * n_lidar)
+    n_clut = n_lidar - n_road - n_fac
+    z0 = -1.7
+    # road: x along the drive, lateral spread of a spinning lidar's returns around the trajectory
+    road = np.stack([rng.uniform(-20.0, 100.0, n_road), np.clip(rng.normal(0.0, 8.0, n_road), -25.0, 25.0),
+                     z0 + rng.normal(0.0, 0.02, n_road)], -1)
+    # facades: building blocks of 8-30 m length at 11-16 m either side, returns denser at low heights
+    n_blocks = 40
+    bx0 = rng.uniform(-20.0, 95.0, n_blocks)
+    blen, bside = rng.uniform(8.0, 30.0, n_blocks), rng.choice([-1.0, 1.0], n_blocks)
+    bdist, bh = rng.uniform(11.0, 16.0, n_blocks), rng.uniform(6.0, 18.0, n_blocks)
+    b = rng.integers(0, n_blocks, n_fac)
+    fac = np.stack([bx0[b] + rng.uniform(0.0, 1.0, n_fac) * blen[b], bside[b] * bdist[b] + rng.normal(0.0, 0.03, n_fac),
+                    z0 + bh[b] * rng.uniform(0.0, 1.0, n_fac) ** 1.5], -1)
+    # clutter: 500 objects -- cars (boxes 4.5 x 1.9 x 1.5), poles (0.2 x 0.2 x 6), tree crowns (spheres r = 2 at 5 m)
+    n_obj = 500
+    kind = rng.choice(3, n_obj, p=[0.5, 0.25, 0.25])
+    ox, oy = rng.uniform(-20.0, 100.0, n_obj), rng.choice([-1.0, 1.0], n_obj) * rng.uniform(3.5, 10.0, n_obj)
+    o = rng.integers(0, n_obj, n_clut)
+    u = rng.uniform(-1.0, 1.0, (n_clut, 3))
+    face = rng.integers(0, 3, n_clut)
+    u[np.arange(n_clut), face] = np.sign(u[np.arange(n_clut), face])          # on a face of the unit cube
+    half = np.array([[2.25, 0.95, 0.75], [0.1, 0.1, 3.0], [2.0, 2.0, 2.0]])[kind[o]]
+    centre_z = np.array([z0 + 0.75, z0 + 3.0, z0 + 5.0])[kind[o]]
+    sph = u / np.linalg.norm(u, axis=1, keepdims=True)
+    local = np.where((kind[o] == 2)[:, None], sph * 2.0, u * half)
+    clut = np.stack([ox[o], oy[o], centre_z], -1) + local
+    # randoms (scene_graph.py:165-176): uniform in the scene sphere; inverse distance uniform in (0, 1 / radius), capped at 2 km
+    centre, radius = np.array([40.0, 0.0, 0.0]), 70.0
+    def unit(n):
+        v = rng.normal(size=(n, 3))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    near = centre + unit(n_near) * radius * rng.uniform(0.0, 1.0, (n_near, 1)) ** (1.0 / 3.0)
+    far = centre + unit(n_far) * (radius / rng.uniform(radius / 2000.0, 1.0, (n_far, 1)))
+    near[:, 2] = np.abs(near[:, 2] - z0) + z0          # (the reference keeps what some camera sees: nothing under the road)
+    far[:, 2] = np.abs(far[:, 2] - z0) + z0
+    pts = np.concatenate([road, fac, clut, near, far], 0).astype(np.float32)
+    is_random = np.concatenate([np.zeros(n_lidar, bool), np.ones(n_near + n_far, bool)])
+    perm = rng.permutation(pts.shape[0])               # (the reference's point order carries no spatial meaning either)
+    pts, is_random = pts[perm], is_random[perm]
+    d, _ = cKDTree(pts).query(pts, k=4, workers=-1)
+    avg = np.maximum(d[:, 1:].mean(-1), 1e-4).astype(np.float32)           # vanilla.py:85-88
+    g = torch.Generator().manual_seed(seed)
+    means = torch.from_numpy(pts)
+    log_scales = torch.log(torch.from_numpy(avg))[:, None].repeat(1, 3)
+    quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=-1)
+    sh = torch.zeros(N, 16, 3)
+    sh[:, 0] = (torch.rand(N, 3, generator=g) - 0.5) / 0.28209479177387814   # RGB2SH of random colours (basics.py:76-89)
+    if opacity == "init":
+        opac_logit = torch.full((N,), math.log(0.1 / 0.9))
+    else:
+        # the metre-sized randoms do not survive training as opaque blobs (opacity reset + cull_alpha_thresh, vanilla.py:205-302):
+        # they stay as a faint background layer
+        opac_logit = torch.where(torch.from_numpy(is_random), torch.randn(N, generator=g) - 2.5, torch.randn(N, generator=g) * 1.5)
+        sh[:, 1:] = torch.randn(N, 15, 3, generator=g) * 0.05
+    out = dict(means=means, log_scales=log_scales, quats=quats, opacity_logits=opac_logit, sh=sh)
+    return {k: v.to(device).contiguous() for k, v in out.items()}
+
+
 def make_grids(n_images: int, levels=LEVELS_3, seed: int = 0, device="cpu") -> List[Tensor]:
     g = torch.Generator().manual_seed(1000 + seed)
     out = []

@@ -20,10 +20,12 @@ from bilateral_driving_amd import gs_ops as ops  # noqa: E402
 from bilateral_driving_amd import harness as Hn  # noqa: E402
 
 
-def pair_stats(N, W, H, view=0):
+def pair_stats(N, W, H, view=0, params=None):
+    """``params``: the scene's raw parameters (default: the ring scene ``Hn.synthetic_scene(N, seed=0)``)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     cam = Hn.ring_cameras(W, H, device=dev)[view]
-    p = Hn.synthetic_scene(N, seed=0, device=dev)
+    p = Hn.synthetic_scene(N, seed=0, device=dev) if params is None else {k: v.detach() for k, v in params.items()}
+    N = p["means"].shape[0]
     with torch.no_grad():
         radii, m2, dep, con, _ = ops.fully_fused_projection(p["means"], p["quats"], torch.exp(p["log_scales"]), cam.viewmat[None], cam.K[None],
                                                             W, H, near_plane=0.1)

@@ -31,6 +31,9 @@ def _c(a):
 
 TOL = dict(rtol=3e-4, atol=3e-5)     # the goldens are float32 runs of the reference: its own rounding is of this order at |rgb| ~ 1
 GTOL = dict(rtol=2e-3, atol=2e-3)
+VRGB = (2e-3, 2e-4)                  # v_rgb: rtol, atol relative to the largest reference entry
+if os.environ.get("BDS_GOLDEN_STRICT") == "1":      # north_star's bounds as they are written (measurement sessions: does the margin hold?)
+    TOL, GTOL, VRGB = dict(rtol=1e-4, atol=1e-5), dict(rtol=1e-3, atol=1e-3), (1e-3, 1e-4)
 
 
 def _worst(tag, pairs):
@@ -44,7 +47,11 @@ def _worst(tag, pairs):
         else:
             e = (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max()
         msg.append(f"{name} {e:.1e}")
-    print(f"[golden {tag}] worst: " + ", ".join(msg))
+    line = f"[golden {tag}] worst: " + ", ".join(msg)
+    print(line)
+    if os.environ.get("BDS_GOLDEN_WORST_LOG"):      # (pytest -q swallows the print: a GPU visit keeps the lines in a file)
+        with open(os.environ["BDS_GOLDEN_WORST_LOG"], "a") as f:
+            f.write(line + "\n")
 
 
 @pytest.mark.parametrize("path", _files("bilagrid_ms_*_f32.npz"), ids=os.path.basename)
@@ -66,7 +73,7 @@ def test_fused_multiscale_vs_reference_golden(B, path):
     np.testing.assert_allclose(float(tv), float(z["tv"]), rtol=1e-4)
     ((out * _c(z["wt"])).sum() + float(z["tv_coef"]) * tv).backward()
     scale = max(1.0, float(np.abs(z["v_rgb"]).max()))
-    np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["v_rgb"], rtol=2e-3, atol=2e-4 * scale)
+    np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["v_rgb"], rtol=VRGB[0], atol=VRGB[1] * scale)
     for i in range(nl):
         ref = z[f"v_grids{i}"]
         got = allg[i].grad.cpu().numpy()
@@ -94,7 +101,7 @@ def test_fused_single_scale_vs_reference_golden(B, path):
     np.testing.assert_allclose(float(tv), float(z["tv"]), rtol=1e-4)
     ((out * _c(z["wt"])).sum() + float(z["tv_coef"]) * tv).backward()
     scale = max(1.0, float(np.abs(z["v_rgb"]).max()))
-    np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["v_rgb"], rtol=2e-3, atol=2e-4 * scale)
+    np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["v_rgb"], rtol=VRGB[0], atol=VRGB[1] * scale)
     ref = z["v_grids0"]
     assert np.abs(g.grad.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
     _worst(os.path.basename(path), [("out", out.detach().cpu().numpy(), z["out"], False), ("v_rgb", rgb.grad.cpu().numpy(), z["v_rgb"], True),

@@ -233,6 +233,37 @@ def test_other_baseline_configs_fullsize_properties(name):
     assert float((got - ref).norm() / ref.norm()) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["c3_2M_6cam_1600x900_3level", "c5_5M_5cam_1920x1280_4level"])
+def test_replayed_frame_at_full_size_equals_eager_frame(name):
+    """What bench.py TIMES -- graph_view.FrameGraph.step(): device-side list counts, SH colours in the record pack, loss on the
+    transform's launch, two streams, in-place gradient rows -- against the eager host-count frame on the same parameters, at
+    BASELINE.json's configs[2] and [4] (bilateral_driving_amd/selfcheck.py: images bit-equal, per-view loss within 1e-5, the frame's
+    flat gradient within 1e-4 norm-relative: atomics order only); two replays, the second after the first's row-wise clear."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.graph_view import FrameGraph
+    from bilateral_driving_amd.selfcheck import frame_against_eager
+    N, yaws, W, H, levels, factors = _CONFIGS[name]
+    yaws = Hn.SIX_CAM_YAWS if yaws is None else (Hn.FIVE_CAM_YAWS if yaws == "five" else yaws)
+    levels, factors = levels or Hn.LEVELS_3, factors or Hn.FACTORS_3
+    dev = "cuda"
+    cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev)
+    for c in cams:
+        c.viewmat.requires_grad_(True)
+    p = {k: t.requires_grad_(True) for k, t in Hn.synthetic_scene(N, seed=0, device=dev).items()}
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), levels=levels, device=dev)]
+    gen = torch.Generator().manual_seed(13)
+    skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
+    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    frame = FrameGraph(p, cams, grids, skies, targets, factors=factors)
+    for rep in range(2):
+        res = frame_against_eager(frame, p, cams, grids, skies, targets, factors)
+        print(f"[fullsize frame {name} rep {rep}] {res}")
+        assert res["ok"], res
+        assert res["sky_grad_rel_err"] < 1e-5 and res["pose_grad_rel_err"] < 1e-3, res
+    counts = frame.counts()
+    assert all(M > 100_000 and 0 < nv < N for M, nv in counts), counts
+
+
 def test_fullsize_coarse_lists_equal_16px_lists(full):
     """Benchmark size: the fused view through 64-px list tiles (its default) gives bit for bit the image of gsplat's 16-px lists and
     the same gradients; the 64-px lists are a fraction of the 16-px ones."""
