@@ -76,7 +76,6 @@ _SIGS = {
     "bds_isect_counts_offset": (_sz, [_i]),
     "bds_isect_prepare_dev": (_i, [_i, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _i64, _i64, _f, _i, _f]),
     "bds_isect_build_dev": (_i, [_i, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f, _sz, _f, _f, _i, _f]),
-    "bds_isect_lists_dev": (_i, [_i64, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f, _sz, _i64, _i64, _f, _f, _sz, _f, _f, _f]),
     "bds_splat_pack_sh_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
     "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
     "bds_rasterize_schedule_ints": (_i64, [_i, _i, _i]),
@@ -188,7 +187,6 @@ LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 64      # slotted loss accumulators (include/
 OPT_SHORT_SORT, OPT_PACKED = 4, 6   # test hooks: force the large-input fallback paths of the tile stage (include/bds.h)
 ECAPACITY = -4
 OPT_CAP_LAUNCH = 0     # device-count tile stage: 1 [default] = launches sized by the visible-entry capacity, 0 = by all N
-OPT_TILE_PERSIST = 5   # device-count tile stage as ONE persistent launch of this many workgroups (bds_isect_lists_dev); 0 = off
 
 
 def rasterize_kernel_name(backward, CH: int = 4, absgrad: bool = True, list_tile_size: int = 64) -> str:

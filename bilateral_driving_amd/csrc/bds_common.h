@@ -106,15 +106,12 @@ struct PrepReduceSlots {
   uint32_t *zero_me;     // tables to clear
   int64_t zero_elems;
   uint64_t *m_total;     // cleared: the counting kernels accumulate into it
-  uint32_t *bar;         // [2] cleared: arrive counter + generation of bds_isect_lists_dev's device-wide barrier
 };
 int prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlots *out);   // BDS_OK, or why the short path does not apply
 
 // test hooks (bds_set_option): force the large-input fallback paths of the tile stage; see include/bds.h
 enum Option { kOptCapLaunch = 0 /* device-count tile stage: launches sized by the visible-entry capacity instead of C*N */, kOptPadBwd = 1 /* tuning: KB of unused LDS per workgroup of the compositor backward */, kOptPadFwd = 2 /* ... forward */,
-              kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4,
-              kOptTilePersist = 5 /* device-count tile stage as ONE persistent launch of this many workgroups (0 = the 13-launch form) */,
-              kOptPacked = 6,
+              kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptPacked = 6,
               kOptCells = 7 /* bilateral transform, bit 0: cell-aligned kernels where a level qualifies, bit 1: one-pass pyramid forward; 0 = general kernels */,
               kOptSchedBins = 8 /* device-count form: the forward compositor bins the backward's schedule itself (no sort launch) */, kOptCount = 9 };
 int option_get(int which);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss) {
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   if (kReduce) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *rs.m_total = 0; rs.bar[0] = 0u; rs.bar[1] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rs.m_total = 0;
     for (int64_t i = g; i < rs.zero_elems; i += (int64_t)gridDim.x * kProjBlock) rs.zero_me[i] = 0u;
     int radius = 0;
     if (g < N) {

@@ -355,8 +355,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
 // <= 63 workgroup rows (L2-resident) -- two launches per pass instead of four, which matters most where it runs: next to another
 // stream's compositor every launch of this latency-bound stage waits for wave slots (profiles/NOTES.md, round 4).
 constexpr int kWideGroupShift = 6;
-// (every kernel of the device-count tile stage is a thin wrapper around a *_block body that takes its workgroup index as an argument:
-//  the persistent launch tile_stage_persistent_kernel below runs the same bodies phase by phase over grid-strided workgroup indices)
+// (the kernels of the device-count tile stage are thin wrappers around *_block bodies that take their workgroup index and element
+//  count as arguments: the launch shape is not baked into the bodies.  Round 5 ran the same bodies phase by phase inside ONE
+//  persistent launch with device-wide barriers; it lost -- every barrier is an L2 write-back + invalidate per workgroup on this
+//  multi-XCD part -- and was removed again: profiles/NOTES.md)
 template <int kBins>
 struct HistWideSh { uint32_t h[kBins]; };
 template <int kBins>
@@ -1181,7 +1183,6 @@ int bds::prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlot
   out->zero_me = L.tables;
   out->zero_elems = (int64_t)short_sort_elems(CN);
   out->m_total = L.total;
-  out->bar = reinterpret_cast<uint32_t *>(L.total) + 10;   // (kBarCountWord, kBarGenWord: the persistent launch's device-wide barrier)
   return BDS_OK;
 }
 
@@ -1239,186 +1240,6 @@ __global__ __launch_bounds__(256) void finish_counts_kernel(const uint32_t *__re
     if (counts_host) { counts_host[0] = (int64_t)part[0]; counts_host[1] = (int64_t)nv; }
   }
   if (counts_host) __threadfence_system();
-}
-
-// ------------------------------------------------------------------------------------------
-// The device-count tile stage as ONE persistent launch (bds_isect_lists_dev)
-// ------------------------------------------------------------------------------------------
-// In the replayed frame the stage's 13 short launches run next to another stream's compositor, whose thousands of pending one-wave
-// workgroups take every wave slot that frees up: each launch of this latency-bound stage starts from zero resident waves and queues
-// again (195 us alone, ~520 us in the frame; profiles/NOTES.md).  Here a fixed set of workgroups -- few enough to be resident
-// together whatever else runs -- keeps its waves from the compaction to the last scatter and walks the SAME block bodies phase by
-// phase over grid-strided workgroup indices; the phases are separated by a device-wide barrier (arrive counter + generation word in
-// the prepare workspace, cleared by the projection's prepare launch).  Each XCD has its own L2: a barrier releases the workgroup's
-// writes (__threadfence = L2 write-back on gfx950) before it arrives and invalidates after it leaves.  A barrier that is not
-// released within ~1 s gives up: the view is marked overflowed (it renders nothing; counts_host[2] = 2) instead of hanging the GPU.
-constexpr int kBarCountWord = 10;   // arrive counter; the generation word follows (uint32 words of PrepWs::total, behind the five uint64 counts)
-constexpr uint32_t kBarSpinLimit = 1u << 20;
-
-__device__ __forceinline__ bool grid_barrier(uint32_t *bar, uint32_t nwg, uint32_t *lds_ok) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t ok = 1u;
-    __threadfence();   // release: this workgroup's phase output leaves its XCD's L2
-    const uint32_t gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == nwg - 1u) {   // last to arrive: re-arm the counter, then open the gate
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      uint32_t spins = 0;
-      while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > kBarSpinLimit) { ok = 0u; break; }
-      }
-    }
-    __threadfence();   // acquire: the other workgroups' output is read from memory, not from stale L2 lines
-    *lds_ok = ok;
-  }
-  __syncthreads();
-  return *lds_ok != 0u;
-}
-
-struct TileStageArgs {
-  // compaction + depth order (PrepWs)
-  int64_t N;
-  const int32_t *radii;
-  const float *depths, *means2d, *conics, *opacities;
-  uint32_t *tile_sums, *ka, *va, *kb, *vb, *asc, *hist, *ghist;
-  int64_t ng;
-  uint64_t *counts;
-  volatile int64_t *counts_host;
-  int64_t cap_m, cap_vis;
-  int tile_size, tile_w, tile_h;
-  int32_t *tiles_per_gauss;
-  float4 *rec;
-  uint32_t *btot;
-  // list build (BuildWs)
-  uint32_t *k_emit, *k_out, *whist, *wghist;
-  int wide_zero_n, rank_bits, bits, n_tiles;
-  uint32_t *vals_out;
-  int32_t *offsets;
-  // launch shape
-  int nvb_compact, nvb_sort, nvb_rows, nvb_wide;
-};
-
-template <int kBins>
-__global__ __launch_bounds__(256) void tile_stage_persistent_kernel(TileStageArgs a) {
-  union Sh {
-    VisCompactSh vc;
-    ShortHistSh sh;
-    ShortScatterSh ss;
-    CountRowsSh cr;
-    EmitRowsSh er;
-    HistWideSh<kBins> hw;
-    ScatterWideSh<kBins> sw;
-    unsigned long long part[256];
-  };
-  __shared__ Sh S;
-  __shared__ uint32_t bar_ok;
-  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
-  uint32_t *bar = reinterpret_cast<uint32_t *>(a.counts) + kBarCountWord;
-  uint64_t *n_vis_slot = a.counts + 1;
-#define BDS_TILE_BARRIER()                                   \
-  do {                                                       \
-    if (!grid_barrier(bar, (uint32_t)G, &bar_ok)) {          \
-      if (threadIdx.x == 0) {                                \
-        a.counts[kCountMEff] = 0ull;                         \
-        a.counts[kCountVisEff] = 0ull;                       \
-        a.counts[kCountOverflow] = 1ull;                     \
-        if (a.counts_host) a.counts_host[2] = 2;             \
-      }                                                      \
-      return;                                                \
-    }                                                        \
-  } while (0)
-  // 1. visible entries -> (depth key, position) in index order + the first digit's histogram
-  for (int vb = wg; vb < a.nvb_compact; vb += G) {
-    visible_compact_block(S.vc, vb, a.nvb_compact, a.N, a.radii, a.depths, a.tile_sums, a.ka, a.va, a.hist, a.ghist, n_vis_slot, a.asc, 1,
-                          kScanTile / 256);
-    __syncthreads();
-  }
-  BDS_TILE_BARRIER();
-  const int64_t n_vis_raw = (int64_t)*n_vis_slot;
-  const int64_t n_vis = n_vis_raw > a.cap_vis ? 0 : n_vis_raw;   // (an overflow: nothing is sorted or counted, see bounded_count)
-  // 2. depth order: four stable 8-bit passes; ends in (ka, va)
-  {
-    uint32_t *kin = a.ka, *vin = a.va, *kout = a.kb, *vout = a.vb;
-    for (int p = 0; p < 4; p++) {
-      uint32_t *gh = a.ghist + (int64_t)p * a.ng * 256;
-      if (p > 0) {
-        for (int vb = wg; vb < a.nvb_sort; vb += G) {
-          short_hist_block(S.sh, vb, kin, n_vis, 8 * p, a.hist, gh);
-          __syncthreads();
-        }
-        BDS_TILE_BARRIER();
-      }
-      for (int vb = wg; vb < a.nvb_sort; vb += G) {
-        short_scatter_block(S.ss, vb, kin, vin, n_vis, 8 * p, a.hist, gh, kout, vout);
-        __syncthreads();
-      }
-      BDS_TILE_BARRIER();
-      uint32_t *t;
-      t = kin; kin = kout; kout = t;
-      t = vin; vin = vout; vout = t;
-    }
-  }
-  // 3. tiles per entry, in depth order
-  for (int vb = wg; vb < a.nvb_rows; vb += G) {
-    isect_count_rows_block(S.cr, vb, n_vis, a.va, a.means2d, a.radii, a.conics, a.opacities, a.tile_size, a.tile_w, a.tile_h,
-                           a.tiles_per_gauss, a.N, a.rec, a.btot, a.asc);
-    __syncthreads();
-  }
-  BDS_TILE_BARRIER();
-  // 4. M: every workgroup sums the per-group totals itself (a few thousand L2-resident words); the first one publishes the counts
-  int64_t M_eff, nvis_eff;
-  {
-    unsigned long long s = 0;
-    for (int b = threadIdx.x; b < a.nvb_rows; b += 256) s += a.btot[b];
-    S.part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) S.part[threadIdx.x] += S.part[threadIdx.x + o];
-      __syncthreads();
-    }
-    const unsigned long long M = S.part[0];
-    __syncthreads();
-    const bool over = (int64_t)M > a.cap_m || n_vis_raw > a.cap_vis;
-    M_eff = over ? 0 : (int64_t)M;
-    nvis_eff = over ? 0 : n_vis;
-    if (wg == 0 && threadIdx.x == 0) {
-      a.counts[0] = M;
-      a.counts[kCountMEff] = (uint64_t)M_eff;
-      a.counts[kCountVisEff] = (uint64_t)nvis_eff;
-      a.counts[kCountOverflow] = over ? 1ull : 0ull;
-      if (a.counts_host) {
-        if (over) a.counts_host[2] = 1;   // sticky: the host clears it when it has provisioned more
-        a.counts_host[0] = (int64_t)M;
-        a.counts_host[1] = n_vis_raw;
-        __threadfence_system();
-      }
-    }
-  }
-  // 5. packed entries (tile << rank_bits | depth rank) in depth order; the tile pass's group rows cleared on the way
-  for (int64_t i = (int64_t)wg * 256 + threadIdx.x; i < a.wide_zero_n; i += (int64_t)G * 256) a.wghist[i] = 0u;
-  for (int vb = wg; vb < a.nvb_rows; vb += G) {
-    isect_emit_rows_block(S.er, vb, nvis_eff, a.N, a.va, a.btot, a.means2d, a.radii, a.conics, a.opacities, a.tile_size, a.tile_w, a.tile_h,
-                          a.k_emit, (uint32_t *)nullptr, a.rank_bits, a.rec);
-    __syncthreads();
-  }
-  BDS_TILE_BARRIER();
-  // 6. ONE stable pass over the whole tile key: lists of compact positions + per-tile offsets
-  const uint32_t mask = (1u << a.bits) - 1u;
-  for (int vb = wg; vb < a.nvb_wide; vb += G) {
-    radix_hist_wide_block<kBins>(S.hw, vb, a.k_emit, M_eff, a.rank_bits, mask, a.whist, a.wghist);
-    __syncthreads();
-  }
-  BDS_TILE_BARRIER();
-  for (int vb = wg; vb < a.nvb_wide; vb += G) {
-    radix_scatter_keys_wide_block<kBins>(S.sw, vb, a.k_emit, M_eff, a.rank_bits, mask, a.bits, a.whist, a.wghist, a.k_out, a.va,
-                                         (1u << a.rank_bits) - 1u, a.vals_out, a.offsets, a.n_tiles);
-    __syncthreads();
-  }
-#undef BDS_TILE_BARRIER
 }
 
 // enqueues the whole prepare stage; the counts (M, visible entries) end up in L.total on the device
@@ -1720,60 +1541,6 @@ extern "C" int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t
   BDS_REQUIRE(M_capacity > 0 && n_visible_capacity > 0);
   return isect_build_impl(C, N, M_capacity, n_visible_capacity, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, ws,
                           ws_bytes, ws2, ws2_bytes, nullptr, flatten_ids, isect_offsets, nullptr, compact, stream, true);
-}
-
-// prepare_dev (compact = 3: compact positions, visible counts left by bds_project_view_prepare_fwd) + build_dev as ONE persistent
-// launch (tile_stage_persistent_kernel).  BDS_ECAPACITY when the configuration is outside what that kernel covers (the short sort
-// path, packed lists whose whole tile key is one 9-10 bit digit) or bds_set_option(5, 0): call the two entry points then.
-extern "C" int bds_isect_lists_dev(int64_t N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
-                                   const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws,
-                                   size_t ws_bytes, int64_t M_capacity, int64_t n_visible_capacity, int64_t *counts_pinned, void *ws2,
-                                   size_t ws2_bytes, int32_t *flatten_ids, int32_t *isect_offsets, bds_stream_t stream) {
-  BDS_REQUIRE(N > 0 && N < (int64_t)1 << 31 && tile_size > 0 && tile_w > 0 && tile_h > 0);
-  BDS_REQUIRE(M_capacity > 0 && M_capacity < (int64_t)1 << 31 && n_visible_capacity > 0);
-  BDS_REQUIRE(means2d && radii && depths && ws && ws2 && flatten_ids && isect_offsets);
-  BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
-  const int G = option_get(kOptTilePersist);
-  if (G <= 0) return BDS_ECAPACITY;
-  if (!(N <= kShortSortMax && option_get(kOptShortSort) && option_get(kOptPacked))) return BDS_ECAPACITY;
-  const int n_tiles = tile_w * tile_h;
-  int nbits = 1;
-  while (((int64_t)1 << nbits) < n_tiles) nbits++;
-  const int rank_bits = 32 - nbits;
-  if (nbits <= 8 || nbits > kWideBits || n_visible_capacity > ((int64_t)1 << rank_bits)) return BDS_ECAPACITY;
-  PrepWs P = prep_layout(ws, N);
-  if (ws_bytes < P.bytes) return BDS_EWORKSPACE;
-  BuildWs B = build_layout(ws2, M_capacity);
-  if (ws2_bytes < B.bytes) return BDS_EWORKSPACE;
-  void *mapped = nullptr;
-  if (counts_pinned && hipHostGetDevicePointer(&mapped, counts_pinned, 0) != hipSuccess) { (void)hipGetLastError(); return BDS_EINVAL; }
-  const int64_t nb = cdiv(N, kShortChunk), ng = cdiv(nb, 1 << kGroupShift);
-  const int64_t vis_bound = n_visible_capacity < N ? n_visible_capacity : N;
-  TileStageArgs a;
-  a.N = N;
-  a.radii = radii; a.depths = depths; a.means2d = means2d; a.conics = conics; a.opacities = opacities;
-  a.tile_sums = P.temp; a.ka = P.ka; a.va = P.va; a.kb = P.kb; a.vb = P.vb; a.asc = P.asc;
-  a.hist = P.tables; a.ghist = P.tables + nb * 256; a.ng = ng;
-  a.counts = P.total; a.counts_host = static_cast<volatile int64_t *>(mapped);
-  a.cap_m = M_capacity; a.cap_vis = n_visible_capacity;
-  a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h;
-  a.tiles_per_gauss = tiles_per_gauss; a.rec = P.rec; a.btot = P.btot;
-  a.k_emit = B.ka; a.k_out = B.kb;     // (one pass: emitted into ka, sorted into kb -- as isect_build_impl lays it out)
-  a.whist = B.temp;
-  a.wghist = B.temp + align_up((size_t)(1 << kWideBits) * (size_t)cdiv(M_capacity, kSortChunk), 4);
-  a.wide_zero_n = (int)radix_wide_group_elems(M_capacity, nbits);
-  a.rank_bits = rank_bits; a.bits = nbits; a.n_tiles = n_tiles;
-  a.vals_out = reinterpret_cast<uint32_t *>(flatten_ids);
-  a.offsets = isect_offsets;
-  a.nvb_compact = (int)cdiv(N, kScanTile);
-  a.nvb_sort = (int)cdiv(vis_bound, kShortChunk);
-  a.nvb_rows = (int)cdiv(vis_bound, kIsectBlock);
-  a.nvb_wide = (int)cdiv(M_capacity, kSortChunk);
-  hipStream_t st = as_stream(stream);
-  if (nbits == 9) hipLaunchKernelGGL((tile_stage_persistent_kernel<512>), dim3((unsigned)G), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((tile_stage_persistent_kernel<1024>), dim3((unsigned)G), dim3(256), 0, st, a);
-  BDS_LAUNCH_CHECK();
-  return BDS_OK;
 }
 
 extern "C" int bds_isect_tiles(int C, int64_t N, const float *means2d, const int32_t *radii, const float *depths,

@@ -148,21 +148,16 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
-_TILE_PERSIST = None
+_TILE_OPTIONS_READ = False
 
 
-def _tile_persist_groups() -> int:
-    """Workgroups of the persistent tile-stage launch (include/bds.h option 5; 0 = the 13-launch form).  ``BDS_TILE_PERSIST``
-    sets the option once (A/B sessions); otherwise whatever ``bds_set_option(5, ..)`` says."""
-    global _TILE_PERSIST
-    if _TILE_PERSIST is None:
-        _TILE_PERSIST = True
-        env = os.environ.get("BDS_TILE_PERSIST")
-        if env is not None:
-            L.set_option(L.OPT_TILE_PERSIST, int(env))
+def _tile_stage_options() -> None:
+    """A/B sessions: ``BDS_CAP_LAUNCH=0`` sizes the device-count tile stage's launches by N again (include/bds.h option 0)."""
+    global _TILE_OPTIONS_READ
+    if not _TILE_OPTIONS_READ:
+        _TILE_OPTIONS_READ = True
         if os.environ.get("BDS_CAP_LAUNCH") is not None:
             L.set_option(L.OPT_CAP_LAUNCH, int(os.environ["BDS_CAP_LAUNCH"]))
-    return int(L.lib().bds_get_option(L.OPT_TILE_PERSIST))
 
 
 def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before_wait=None) -> _Front:
@@ -215,16 +210,13 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     isect_offsets = _empty((1, th, tw), dev, torch.int32)
     cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
     caps = cfg.get("caps")                 # ListCapacity: the device-count form (no host wait in this view)
-    persist = False
     if caps is not None:
         counts, ev = caps.counts, None
-        # the whole tile stage as ONE persistent launch (bds_isect_lists_dev, enqueued by _front_finish_dev) where it applies
-        persist = pre_reduced and _tile_persist_groups() > 0
-        if not persist:
-            with L.timed("isect_prepare"):
-                L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
-                                                  L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
-                                                  counts.data_ptr(), 3 if pre_reduced else 1, st), "bds_isect_prepare_dev")
+        _tile_stage_options()
+        with L.timed("isect_prepare"):
+            L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
+                                              L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
+                                              counts.data_ptr(), 3 if pre_reduced else 1, st), "bds_isect_prepare_dev")
     else:
         counts, ev = _host_sync_objects(dev)
         with L.timed("isect_prepare"):
@@ -262,7 +254,6 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
     f.tiles_per_gauss, f.isect_offsets, f.ws, f.ws_bytes, f.cull = tiles_per_gauss, isect_offsets, ws, ws_bytes, cull
     f.counts, f.ev, f.key, f.cap, f.vcap, f.caps = counts, ev, key, cap, vcap, caps
-    f.persist = persist
     f.buf, f.ws2, f.ws2_bytes, f.rec_buf, f.ids_offset = buf, ws2, ws2_bytes, rec_buf, off
     f.list_tile, f.list_tw, f.list_th = LT, tw, th
     f.W, f.H, f.N = W, H, N
@@ -316,21 +307,9 @@ def _front_finish_dev(f: _Front) -> _Front:
     f.flatten = f.buf
     f.vis_ids = f.ws[f.ids_offset:f.ids_offset + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
-        rc = L.BDS_ECAPACITY
-        if f.persist:
-            rc = lib.bds_isect_lists_dev(N, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile, f.list_tw, f.list_th,
-                                         L.ptr(f.tiles_per_gauss), L.ptr(f.ws), f.ws_bytes, M, n_vis, f.caps.counts.data_ptr(), L.ptr(f.ws2),
-                                         f.ws2_bytes, L.ptr(f.flatten), L.ptr(f.isect_offsets), st)
-            if rc not in (L.BDS_OK, L.BDS_ECAPACITY):
-                L.check(rc, "bds_isect_lists_dev")
-            if rc == L.BDS_ECAPACITY:      # a shape the persistent launch does not cover: the prepare stage it skipped, then the build
-                L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile, f.list_tw,
-                                                  f.list_th, L.ptr(f.tiles_per_gauss), L.ptr(f.ws), f.ws_bytes, M, n_vis,
-                                                  f.caps.counts.data_ptr(), 3, st), "bds_isect_prepare_dev")
-        if rc == L.BDS_ECAPACITY:
-            L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
-                                            f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
-                                            L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
+        L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
+                                        f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
+                                        L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
     if f.colors is not None and os.environ.get("BDS_SH_BEFORE_BUILD") != "1":
         with L.timed("sh_fwd"):
             L.check(lib.bds_sh_view_fwd(N, f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh), L.ptr(f.radii),

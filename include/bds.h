@@ -41,7 +41,6 @@ const char *bds_strerror(int code);
 /* Test hooks that force the large-input fallback paths of the tile stage on small inputs (there is ONE kernel per
  * operation; these select which size regime a call is treated as).  which:
  * 0 = device-count tile stage: 1 [default] = launches behind the compaction sized by the visible-entry CAPACITY, 0 = by C*N;
- * 5 = device-count tile stage as one persistent launch of this many workgroups (bds_isect_lists_dev); 0 [default] = off;
  * 4 = depth ordering of the visible entries: 1 [default] = the two-launch radix passes used up to 8.4 M (camera, Gaussian)
  *     entries; 0 = the generic histogram / scan / scatter passes that larger inputs take;
  * 6 = tile lists: 1 [default] = packed 32-bit entries (tile << rank_bits | depth rank) whenever the visible count fits the
@@ -435,18 +434,6 @@ int bds_isect_build_dev(int C, int64_t N, int64_t M_capacity, int64_t n_visible_
                         const float *depths, const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
                         const void *ws, size_t ws_bytes, void *ws2, size_t ws2_bytes, int32_t *flatten_ids, int32_t *isect_offsets,
                         int compact, bds_stream_t stream);
-/* bds_isect_prepare_dev(compact = 3) + bds_isect_build_dev(compact = 1) for C = 1 as ONE persistent launch: bds_set_option(5, G)
- * workgroups (G > 0; default 0 = off) stay resident from the compaction to the last scatter and walk the stage's phases separated by
- * a device-wide barrier, instead of 13 short launches that each queue for wave slots again next to another stream's long kernel
- * (the isect / sort stages inside gsplat's rasterization(), models/trainers/base.py:393-408; no reference counterpart for the
- * launch structure).  Needs the workspace of bds_project_view_prepare_fwd (visible counts, cleared tables and barrier words).
- * Same lists, offsets and counts, bit for bit.  BDS_ECAPACITY: the configuration is outside what the launch covers (option off,
- * N beyond the short sort path, a tile key that is not ONE 9-10 bit digit, unpacked lists) -- call the two entry points instead.
- * A barrier that does not open within ~1 s marks the view overflowed (counts_pinned[2] = 2) instead of hanging. */
-int bds_isect_lists_dev(int64_t N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
-                        const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, void *ws, size_t ws_bytes,
-                        int64_t M_capacity, int64_t n_visible_capacity, int64_t *counts_pinned, void *ws2, size_t ws2_bytes,
-                        int32_t *flatten_ids, int32_t *isect_offsets, bds_stream_t stream);
 /* bds_splat_pack with the record count on the device (n_dev -> visible effective).  Optionally clears, on the way, the gradient
  * record of every packed row (zero_records [n_capacity, BDS_GRAD_RECORD_FLOATS]: what bds_rasterize_bwd accumulates into) and a
  * tail of zero_tail_floats (multiple of 4) floats (the camera-pose gradient slots): no fill launches of their own.  schedule

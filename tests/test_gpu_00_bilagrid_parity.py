@@ -29,11 +29,12 @@ def _c(a):
     return torch.from_numpy(np.asarray(a)).float().cuda()
 
 
-TOL = dict(rtol=3e-4, atol=3e-5)     # the goldens are float32 runs of the reference: its own rounding is of this order at |rgb| ~ 1
-GTOL = dict(rtol=2e-3, atol=2e-3)
-VRGB = (2e-3, 2e-4)                  # v_rgb: rtol, atol relative to the largest reference entry
-if os.environ.get("BDS_GOLDEN_STRICT") == "1":      # north_star's bounds as they are written (measurement sessions: does the margin hold?)
-    TOL, GTOL, VRGB = dict(rtol=1e-4, atol=1e-5), dict(rtol=1e-3, atol=1e-3), (1e-3, 1e-4)
+# north_star's bounds as written: 1e-4 rel on values, 1e-3 rel on gradients.  Measured worst case over all goldens on MI355X
+# (profiles/r06_golden_worst.txt, relative to max(1, |ref|) / to the largest reference entry): 2.7e-6 on values, 1.5e-6 on gradients
+# -- the goldens are float32 runs of the reference, the difference is summation order.
+TOL = dict(rtol=1e-4, atol=1e-5)
+GTOL = dict(rtol=1e-3, atol=1e-3)
+VRGB = (1e-3, 1e-4)                  # v_rgb: rtol, atol relative to the largest reference entry
 
 
 def _worst(tag, pairs):
