@@ -11,7 +11,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbds.so")
+LIB_PATH = os.environ.get("BDS_LIB") or os.path.join(_HERE, "libbds.so")    # (BDS_LIB: an A/B variant built by build.py --variant)
 ABI_VERSION = 1
 
 _lock = threading.Lock()

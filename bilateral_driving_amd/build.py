@@ -39,34 +39,41 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB, subdir: str = "build") -> str:
+    """``defines`` / ``out`` / ``subdir``: an A/B variant of the library next to the product (e.g. ``defines=("BDS_PRIO=0",)``,
+    ``out=".../libbds_prio0.so"``; ``BDS_LIB=<path>`` makes ``_lib`` load it) -- measurement sessions only."""
+    if out == LIB and not force and not _stale():
         return LIB
     hipcc = _hipcc()
     objs = []
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, subdir)
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *[f"-D{d}" for d in defines], *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-        if verbose and out:
-            print(out.decode())
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"]
+            raise RuntimeError(f"hipcc failed on {src}:\n{log.decode()}")
+        if verbose and log:
+            print(log.decode())
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out + ".tmp"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:     # python -m bilateral_driving_amd.build --variant prio0 BDS_PRIO=0
+        i = sys.argv.index("--variant")
+        name, defs = sys.argv[i + 1], sys.argv[i + 2:]
+        print(build(force=True, verbose=False, defines=defs, out=os.path.join(HERE, f"libbds_{name}.so"), subdir=f"build_{name}"))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))
