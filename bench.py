@@ -329,7 +329,7 @@ def main():
     L.lib()  # fail loudly if libbds.so is missing
     if os.environ.get("BDS_DEBUG_OPTION"):   # kernel A/B hooks (include/bds.h: option 3), measurement sessions only
         L.set_option(3, int(os.environ["BDS_DEBUG_OPTION"]))
-    for env, which in (("BDS_PAD_BWD_KB", 1), ("BDS_PAD_FWD_KB", 2), ("BDS_CELLS", 7), ("BDS_SCHED_BINS", 8), ("BDS_SLOTS_BWD", 9), ("BDS_SLOTS_FWD", 10)):   # (tuning hooks: cap the compositors' resident waves)
+    for env, which in (("BDS_PAD_BWD_KB", 1), ("BDS_PAD_FWD_KB", 2), ("BDS_CELLS", 7), ("BDS_SCHED_BINS", 8)):   # (tuning hooks: cap the compositors' resident waves)
         if os.environ.get(env):
             L.set_option(which, int(os.environ[env]))
     wl = dict(WORKLOADS[args.workload])

@@ -15,7 +15,7 @@ extern "C" const char *bds_strerror(int code) {
 }
 
 namespace bds {
-static int g_options[kOptCount] = {/*cap_launch*/ 1, 0, 0, /*debug*/ 0, /*short_sort*/ 1, 0, /*packed*/ 1, /*cells*/ 3, /*sched_bins*/ 1, /*slots_bwd*/ 0, /*slots_fwd*/ 0};
+static int g_options[kOptCount] = {/*cap_launch*/ 1, 0, 0, /*debug*/ 0, /*short_sort*/ 1, 0, /*packed*/ 1, /*cells*/ 3, /*sched_bins*/ 1};
 int option_get(int which) { return (which >= 0 && which < kOptCount) ? g_options[which] : 0; }
 }  // namespace bds
 

@@ -15,21 +15,6 @@
     if (hipGetLastError() != hipSuccess) return BDS_ELAUNCH; \
   } while (0)
 
-// Issue priority of every kernel other than the two compositors.  A SIMD arbitrates vector issue between its resident waves by
-// priority, then AGE (MI355X_MICROARCH.md): next to another stream's compositor -- five long-lived waves per SIMD that issue a
-// vector instruction in ~90 % of the cycles -- a newly arrived wave of a short kernel is the youngest and gets the leftover slots
-// only: the tile stage ran 3-5x longer in the two-stream frame than alone, although it needs few issue slots itself (it waits
-// for memory most of the time).  s_setprio outranks age: the short kernels take the slots they need when they need them, the
-// compositors give up what those kernels use (little).  -DBDS_PRIO=0 builds the library without it (A/B).
-#ifndef BDS_PRIO
-#define BDS_PRIO 2
-#endif
-#if BDS_PRIO > 0
-#define BDS_RAISE_PRIO() __builtin_amdgcn_s_setprio(BDS_PRIO)
-#else
-#define BDS_RAISE_PRIO() ((void)0)
-#endif
-
 namespace bds {
 
 constexpr int kWave = 64;  // CDNA wavefront
@@ -128,9 +113,7 @@ int prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlots *ou
 enum Option { kOptCapLaunch = 0 /* device-count tile stage: launches sized by the visible-entry capacity instead of C*N */, kOptPadBwd = 1 /* tuning: KB of unused LDS per workgroup of the compositor backward */, kOptPadFwd = 2 /* ... forward */,
               kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptPacked = 6,
               kOptCells = 7 /* bilateral transform, bit 0: cell-aligned kernels where a level qualifies, bit 1: one-pass pyramid forward; 0 = general kernels */,
-              kOptSchedBins = 8 /* device-count form: the forward compositor bins the backward's schedule itself (no sort launch) */,
-              kOptSlotsBwd = 9, kOptSlotsFwd = 10 /* compositor backward / forward as a slot-capped launch of this many waves per SIMD (0 = one workgroup per tile) */,
-              kOptCount = 11 };
+              kOptSchedBins = 8 /* device-count form: the forward compositor bins the backward's schedule itself (no sort launch) */, kOptCount = 9 };
 int option_get(int which);
 
 }  // namespace bds

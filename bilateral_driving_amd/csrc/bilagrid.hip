@@ -64,7 +64,6 @@ __device__ __forceinline__ void slice_dz_cells(const float4 *__restrict__ cells,
 // global-memory form gathered 96 scalars per pixel from L1/L2 and was bound by the latency of those chains.
 template <bool kLds>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_fwd_kernel(MsParams p, LevelSched sc) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds_grid[];
   int local;
   const int k_entry = sched_find(sc, blockIdx.x, local);
@@ -146,7 +145,6 @@ __device__ __forceinline__ void upsample_affine(const LevelDev &L, int H, int W,
 // forward 44 -> 48 us, backward x kernel 88 -> 111 us at 1080p.  The gathers overlap across waves; a per-workgroup prologue does not.)
 template <int NL, bool kTrain>  // NL >= p.nlevels: bounds the static unrolling (registers) of the level loop
 __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, float *__restrict__ out, TrainLoss tl) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kBgBlock / kWave];
   if (kTrain && (int)blockIdx.x >= tl.pix_blocks) {   // the TV term of the loss: one grid element per thread
     const float t = block_sum_to_thread0(tv_train_element(tl.T, (int)blockIdx.x - tl.pix_blocks, tl.v_loss), red);
@@ -203,7 +201,6 @@ __global__ __launch_bounds__(kBgBlock) void ms_apply_fwd_kernel(MsParams p, floa
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_kernel(MsParams p, const float *__restrict__ v_out,
                                                                float *__restrict__ v_in) {
-  BDS_RAISE_PRIO();
   const int64_t pix = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (pix >= (int64_t)p.H * p.W) return;
   int i, j;
@@ -246,7 +243,6 @@ __device__ __forceinline__ void adjoint_range(int c, int full, float s /* = (flo
 
 // ---- D1: x pass of the up-sampler adjoint: R[y, cx, :] = sum_x wx(x -> cx) * Q[y,x] (x) [P[y,x]; 1] -------
 __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, LevelSched sc) {
-  BDS_RAISE_PRIO();
   int local;
   const int l = sc.level[sched_find(sc, blockIdx.x, local)];
   const LevelDev &L = p.lv[l];
@@ -287,7 +283,6 @@ __global__ __launch_bounds__(kBgBlock) void ms_adjoint_x_kernel(MsParams p, Leve
 template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_apply_bwd_x_kernel(MsParams p, const float *__restrict__ v_out,
                                                                  float *__restrict__ v_in, int halo, int nbx, int dbg) {
-  BDS_RAISE_PRIO();
   // pixel k of the window sits at k + k / 32: the x pass reads with a stride of `factor` pixels between neighbouring threads, which on
   // the plain layout put every 8th (factor 4) thread of a 32-lane group on the same bank (5.7 M conflict cycles of 9.4 M LDS cycles)
   constexpr int kRow = kBgBlock + kBgBlock / 32;
@@ -445,7 +440,6 @@ __device__ __forceinline__ void slice_grid_scatter(float *acc, const Cell &c, in
 template <bool kLds, int kUnroll = 4>
 __global__ __launch_bounds__(kBgBlock) void ms_lowres_bwd_kernel(MsParams p, LevelSched sc, float *__restrict__ v_in,
                                                                 float *__restrict__ partials, int dbg, int lds_floats) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds_acc[];
   int local;
   const int k_entry = sched_find(sc, blockIdx.x, local);
@@ -595,7 +589,6 @@ template <int NL>
 __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParams p, float *__restrict__ v_in,
                                                                         float *__restrict__ v_alpha, float *__restrict__ v_sky, int dbg,
                                                                         PartialsJob pj) {
-  BDS_RAISE_PRIO();
   if ((int)blockIdx.x >= pj.pix_blocks) {   // (both only need the low-res kernel's results: one launch instead of two)
     __shared__ float sred[8][33];
     grid_partials_reduce_block(p, pj.sc, pj.red, pj.partials, (int)blockIdx.x - pj.pix_blocks, sred);
@@ -688,7 +681,6 @@ __global__ __launch_bounds__(kBgBlock) void ms_guidance_blend_bwd_kernel(MsParam
 __global__ __launch_bounds__(kBgBlock) void slice_fwd_kernel(int64_t P, const float *__restrict__ grid, int gx, int gy, int gl,
                                                             const float *__restrict__ xy, const float *__restrict__ rgb,
                                                             float *__restrict__ affine) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (i >= P) return;
   const Cell c = slice_cell(xy[i * 2], xy[i * 2 + 1], rgb2gray(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]), gx, gy, gl);
@@ -702,7 +694,6 @@ __global__ __launch_bounds__(kBgBlock) void slice_bwd_kernel(int64_t P, const fl
                                                             const float *__restrict__ xy, const float *__restrict__ rgb,
                                                             const float *__restrict__ v_affine, float *__restrict__ v_grid,
                                                             float *__restrict__ v_rgb) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   const bool active = i < P;
   const int64_t ii = active ? i : 0;
@@ -729,7 +720,6 @@ __global__ __launch_bounds__(kBgBlock) void slice_bwd_kernel(int64_t P, const fl
 __global__ __launch_bounds__(kBgBlock) void slice_feat_fwd_kernel(int64_t P, int NC, const float *__restrict__ grid, int gx, int gy,
                                                                  int gl, const float *__restrict__ xy, const float *__restrict__ rgb,
                                                                  float *__restrict__ out) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (i >= P) return;
   const Cell c = slice_cell(xy[i * 2], xy[i * 2 + 1], rgb2gray(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]), gx, gy, gl);
@@ -746,7 +736,6 @@ __global__ __launch_bounds__(kBgBlock) void slice_feat_bwd_kernel(int64_t P, int
                                                                  int gl, const float *__restrict__ xy, const float *__restrict__ rgb,
                                                                  const float *__restrict__ v_out, float *__restrict__ v_grid,
                                                                  float *__restrict__ v_rgb) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   const bool active = i < P;
   const int64_t ii = active ? i : 0;
@@ -800,7 +789,6 @@ __device__ __forceinline__ Cell band_cell(int x, int W, float lin_x, float y01, 
 __global__ __launch_bounds__(kBgBlock) void slice_feat_image_fwd_kernel(int H, int W, int NC, const float *__restrict__ grid, int gx,
                                                                        int gy, int gl, float lin_x, float lin_y, int rows_per_wg,
                                                                        const float *__restrict__ rgb, float *__restrict__ out) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float band[];
   const int volb = gl * 2 * gx;
   int cur = -1;
@@ -836,7 +824,6 @@ __global__ __launch_bounds__(kBgBlock) void slice_feat_image_bwd_kernel(int H, i
                                                                        int gy, int gl, float lin_x, float lin_y, int rows_per_wg,
                                                                        const float *__restrict__ rgb, const float *__restrict__ v_out,
                                                                        float *__restrict__ v_grid, float *__restrict__ v_rgb) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float band[];
   const int volb = gl * 2 * gx, nband = NC * volb;
   float *vals = band, *acc = band + nband;
@@ -895,7 +882,6 @@ __global__ __launch_bounds__(kBgBlock) void slice_feat_image_bwd_kernel(int H, i
 __global__ __launch_bounds__(kBgBlock) void tv_fwd_kernel(int64_t total, int gx, int gy, int gl, const float *__restrict__ x,
                                                          float scale_l, float scale_y, float scale_x,
                                                          float *__restrict__ tv_out) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kBgBlock / kWave];
   float acc = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * kBgBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBgBlock) {
@@ -918,7 +904,6 @@ __global__ __launch_bounds__(kBgBlock) void tv_fwd_kernel(int64_t total, int gx,
 __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx, int gy, int gl, const float *__restrict__ x,
                                                          float scale_l, float scale_y, float scale_x,
                                                          const float *__restrict__ v_tv, float *__restrict__ v_x) {
-  BDS_RAISE_PRIO();
   const int64_t e = (int64_t)blockIdx.x * kBgBlock + threadIdx.x;
   if (e >= total) return;
   const int ix = (int)(e % gx), iy = (int)((e / gx) % gy), il = (int)((e / ((int64_t)gx * gy)) % gl);
@@ -936,7 +921,6 @@ __global__ __launch_bounds__(kBgBlock) void tv_bwd_kernel(int64_t total, int gx,
 
 
 __global__ __launch_bounds__(kBgBlock) void tv_ms_fwd_kernel(TvLevels L, float *__restrict__ tv_out) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kBgBlock / kWave];
   int k = 0;
   while (k + 1 < L.n && (int)blockIdx.x >= L.blk_off[k + 1]) k++;
@@ -962,7 +946,6 @@ __global__ __launch_bounds__(kBgBlock) void tv_ms_fwd_kernel(TvLevels L, float *
 }
 
 __global__ __launch_bounds__(kBgBlock) void tv_ms_bwd_kernel(TvLevels L, const float *__restrict__ v_tv) {
-  BDS_RAISE_PRIO();
   int k = 0;
   while (k + 1 < L.n && (int)blockIdx.x >= L.blk_off[k + 1]) k++;
   const int64_t e = (int64_t)((int)blockIdx.x - L.blk_off[k]) * kBgBlock + threadIdx.x;
@@ -1359,7 +1342,6 @@ struct GridSelect {
 // kBwd = false: sel = full[idx];  kBwd = true: v_full[idx] += sel, sel = 0 (ready for the next replay's backward)
 template <bool kBwd>
 __global__ __launch_bounds__(kBgBlock) void grid_select_kernel(GridSelect S, const int32_t *__restrict__ idx_dev) {
-  BDS_RAISE_PRIO();
   int k = 0;
   while (k + 1 < S.n && (int)blockIdx.x >= S.blk_off[k + 1]) k++;
   const int e = ((int)blockIdx.x - S.blk_off[k]) * kBgBlock + (int)threadIdx.x;
@@ -1558,7 +1540,6 @@ __global__ __launch_bounds__(kBgBlock) void l1_tv_train_kernel(TvLevels L, int t
                                                               const float *__restrict__ a, const float *__restrict__ b, float inv_n,
                                                               float v_loss, float *__restrict__ loss_out, int loss_slots,
                                                               float4 *__restrict__ v_a4, float *__restrict__ v_a) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kBgBlock / kWave];
   float acc = 0.f;
   if ((int)blockIdx.x < tv_blocks) {

@@ -171,7 +171,6 @@ __device__ __forceinline__ void walk_next(PixWalk &w) {
 // kFused = true : out = A(pixel) * in + b at full resolution (one level, factor 1); kTrain adds the L1 / TV loss epilogue.
 template <bool kFused, bool kTrain>
 __global__ __launch_bounds__(kBgBlock) void cell_fwd_kernel(MsParams p, CellSched sc, float *__restrict__ out, TrainLoss tl) {
-  BDS_RAISE_PRIO();
   __shared__ __attribute__((aligned(16))) float nodes[kCellMaxGl * kNodeStride];
   __shared__ float red[kCellWaves];
   __shared__ int bounds[4];
@@ -266,7 +265,6 @@ template <bool kFused>
 __global__ __launch_bounds__(kBgBlock) void cell_bwd_kernel(MsParams p, CellSched sc, const float *__restrict__ v_out,
                                                            float *__restrict__ v_in, float *__restrict__ v_alpha,
                                                            float *__restrict__ v_sky) {
-  BDS_RAISE_PRIO();
   __shared__ __attribute__((aligned(16))) float nodes[kCellMaxGl * kNodeStride];
   __shared__ __attribute__((aligned(16))) float stg_all[kCellWaves][kStgRows * kStgStride];   // per wave: [field][slot]
   __shared__ int bounds[4];

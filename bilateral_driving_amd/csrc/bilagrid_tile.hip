@@ -71,7 +71,6 @@ __device__ __forceinline__ void xlerp_row(const float4 *__restrict__ lo4, int ro
 
 template <int NL, bool kTrain>
 __global__ __launch_bounds__(kBgBlock) void ms_tile_fwd_kernel(MsParams p, TileGeom G, float *__restrict__ out, TrainLoss tl) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[kBgBlock / kWave];
   __shared__ int sub_org[BDS_MAX_LEVELS][4];   // per level: xn0, yn0, nodes in x, nodes in y (0 = sample the grid in global memory)

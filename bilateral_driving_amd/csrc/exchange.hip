@@ -41,7 +41,6 @@ __device__ __forceinline__ uint32_t union_block_scan(uint32_t v, uint32_t &total
 
 __global__ __launch_bounds__(kUnionBlock) void union_count_kernel(int64_t N, const uint8_t *__restrict__ mask,
                                                                  uint32_t *__restrict__ tile_sums) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t lw[kUnionBlock / kWave + 1];
   const int64_t base = (int64_t)blockIdx.x * kUnionTile + (int64_t)threadIdx.x * kUnionItems;
   uint32_t s = 0;
@@ -66,7 +65,6 @@ __global__ __launch_bounds__(kUnionBlock) void union_slots_kernel(
     int32_t *__restrict__ row_map, int32_t *__restrict__ ids, float *__restrict__ b_means, float *__restrict__ b_quats,
     float *__restrict__ b_log_scales, float *__restrict__ b_logits, float *__restrict__ b_sh, uint64_t *__restrict__ count_dev,
     volatile int64_t *__restrict__ count_host) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t lw[kUnionBlock / kWave + 1];
   __shared__ uint32_t s_off, s_cnt;
   // this tile's first slot = union members in the tiles in front of it (a few hundred L2-resident sums)

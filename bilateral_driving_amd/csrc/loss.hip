@@ -12,7 +12,6 @@ __global__ __launch_bounds__(kLossBlock) void l1_mean_fwd_kernel(int64_t n4, int
                                                                 const float4 *__restrict__ b4, const float *__restrict__ a,
                                                                 const float *__restrict__ b, float scale,
                                                                 float *__restrict__ out) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kLossBlock / kWave];
   float s = 0.f;
   const int64_t stride = (int64_t)gridDim.x * kLossBlock;
@@ -46,7 +45,6 @@ __global__ __launch_bounds__(kLossBlock) void l1_mean_fwd_kernel(int64_t n4, int
 __global__ __launch_bounds__(kLossBlock) void l1_mean_bwd_kernel(int64_t n, const float *__restrict__ a,
                                                                 const float *__restrict__ b, float scale,
                                                                 const float *__restrict__ v_out, float *__restrict__ v_a) {
-  BDS_RAISE_PRIO();
   const float g = *v_out * scale;
   for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLossBlock) {
     const float d = a[i] - b[i];
@@ -68,7 +66,6 @@ __global__ __launch_bounds__(kSsimTile * kSsimTile) void ssim_fwd_kernel(int H, 
                                                                         const float *__restrict__ y, SsimWindow win, float C1,
                                                                         float C2, float scale, float *__restrict__ out,
                                                                         float *__restrict__ dmaps) {
-  BDS_RAISE_PRIO();
   __shared__ float sx[kSsimIn][kSsimIn + 1], sy[kSsimIn][kSsimIn + 1];
   __shared__ float hb[5][kSsimIn][kSsimTile + 1];
   __shared__ float red[kSsimTile * kSsimTile / kWave];
@@ -130,7 +127,6 @@ __global__ __launch_bounds__(kSsimTile * kSsimTile) void ssim_bwd_kernel(int H, 
                                                                         const float *__restrict__ y, SsimWindow win, float scale,
                                                                         const float *__restrict__ v_out,
                                                                         const float *__restrict__ dmaps, float *__restrict__ v_y) {
-  BDS_RAISE_PRIO();
   __shared__ float sd[3][kSsimIn][kSsimIn + 1];
   __shared__ float hb[3][kSsimIn][kSsimTile + 1];
   const int Ho = H - (kSsimWin - 1), Wo = W - (kSsimWin - 1);
@@ -186,7 +182,6 @@ struct PixelLossArgs {
 __device__ __forceinline__ float bce_log(float v) { return fmaxf(logf(v), -100.f); }   // torch clamps the logs at -100
 
 __global__ __launch_bounds__(kLossBlock) void pixel_loss_fwd_kernel(int64_t P, PixelLossArgs a, float *__restrict__ sums) {
-  BDS_RAISE_PRIO();
   __shared__ float red[4][kLossBlock / kWave];
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < P; i += (int64_t)gridDim.x * kLossBlock) {
@@ -223,7 +218,6 @@ __global__ __launch_bounds__(kLossBlock) void pixel_loss_fwd_kernel(int64_t P, P
 // terms[0..2] = weighted rgb / mask / depth losses (depth: 0/0 = NaN when no lidar return is valid, as torch's empty mean)
 __global__ void pixel_loss_finalize_kernel(int64_t P, const float *__restrict__ sums, float w_rgb, float w_mask, float w_depth,
                                            int has_mask, int has_depth, float *__restrict__ terms) {
-  BDS_RAISE_PRIO();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   terms[0] = w_rgb * (sums[0] / (3.f * (float)P));
   terms[1] = has_mask ? w_mask * (sums[1] / (float)P) : 0.f;
@@ -234,7 +228,6 @@ __global__ __launch_bounds__(kLossBlock) void pixel_loss_bwd_kernel(int64_t P, P
                                                                    const float *__restrict__ v_terms, float w_rgb, float w_mask,
                                                                    float w_depth, float *__restrict__ v_rgb,
                                                                    float *__restrict__ v_opacity, float *__restrict__ v_depth) {
-  BDS_RAISE_PRIO();
   const float g_rgb = v_terms[0] * w_rgb / (3.f * (float)P), g_mask = v_terms[1] * w_mask / (float)P;
   const float g_depth = a.depth ? v_terms[2] * w_depth / sums[3] : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < P; i += (int64_t)gridDim.x * kLossBlock) {
@@ -290,7 +283,6 @@ __device__ __forceinline__ float edge_weight(const RegLossArgs &a, int64_t p, in
 }
 
 __global__ __launch_bounds__(kLossBlock) void reg_loss_fwd_kernel(RegLossArgs a, float *__restrict__ sums) {
-  BDS_RAISE_PRIO();
   __shared__ float red[5][kLossBlock / kWave];
   float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   const int64_t P = (int64_t)a.H * a.W;
@@ -330,7 +322,6 @@ __global__ __launch_bounds__(kLossBlock) void reg_loss_fwd_kernel(RegLossArgs a,
 // terms[0..2] = entropy, smoothness, dynamic-region L1 (0 when the mask is empty: the reference then adds no term)
 __global__ void reg_loss_finalize_kernel(int H, int W, const float *__restrict__ sums, int has_entropy, int has_smooth, int has_dyn,
                                          float *__restrict__ terms) {
-  BDS_RAISE_PRIO();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float P = (float)H * (float)W;
   terms[0] = has_entropy ? sums[0] / P : 0.f;
@@ -345,7 +336,6 @@ __global__ void reg_loss_finalize_kernel(int H, int W, const float *__restrict__
 __global__ __launch_bounds__(kLossBlock) void reg_loss_bwd_kernel(RegLossArgs a, const float *__restrict__ sums,
                                                                  const float *__restrict__ v_terms, float *__restrict__ v_opacity,
                                                                  float *__restrict__ v_depth, float *__restrict__ v_rgb) {
-  BDS_RAISE_PRIO();
   const int64_t P = (int64_t)a.H * a.W;
   const float g_ent = v_terms[0] / (float)P;
   const float gx = v_terms[1] / ((float)a.H * (float)(a.W - 1)), gy = v_terms[1] / ((float)(a.H - 1) * (float)a.W);

@@ -16,7 +16,6 @@ __global__ __launch_bounds__(kProjBlock) void project_fwd_kernel(
     const float *__restrict__ viewmats, const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane,
     float far_plane, float radius_clip, int32_t *__restrict__ radii, float *__restrict__ means2d,
     float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps) {
-  BDS_RAISE_PRIO();
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   if (g >= N) return;
   float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
@@ -46,7 +45,6 @@ __global__ __launch_bounds__(kProjBlock) void project_bwd_kernel(
     const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
     const float *__restrict__ v_conics, float *__restrict__ v_means, float *__restrict__ v_quats,
     float *__restrict__ v_scales, float *__restrict__ v_viewmats) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kProjBlock / kWave][12];
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   const bool live = g < N;
@@ -106,7 +104,6 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     float eps2d, float near_plane, float far_plane, float radius_clip, float *__restrict__ scales,
     float *__restrict__ opacities, int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
     float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss) {
-  BDS_RAISE_PRIO();
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   if (kReduce) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *rs.m_total = 0;
@@ -196,7 +193,6 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     const float *__restrict__ K, int W, int H, float eps2d, const float4 *__restrict__ v_rec, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat_slots,
     float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map, float *__restrict__ v_colors = nullptr) {
-  BDS_RAISE_PRIO();
   __shared__ float red[kProjBlock / kWave][12];
   const int64_t n_list = list_length(n_cap, n_dev);
   if ((int64_t)blockIdx.x * kProjBlock >= n_list) return;   // (whole workgroup: nothing to add to the pose slots either)

@@ -92,7 +92,6 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_kernel(int64_t n_cap, c
                                                                const int32_t *__restrict__ radii, float4 *__restrict__ rec,
                                                                float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
                                                                int zero_tail_f4, int32_t *__restrict__ schedule) {
-  BDS_RAISE_PRIO();
   // (fused view: the gradient record of every packed row -- what the composite backward accumulates into -- and the camera-pose
   // gradient slots behind them are cleared here instead of by a fill launch of their own; likewise the header of the binned
   // backward schedule the forward compositor is about to fill)
@@ -134,7 +133,6 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
                                                                   float4 *__restrict__ rec, float *__restrict__ sh_rgb_out,
                                                                   float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
                                                                   int zero_tail_f4, int32_t *__restrict__ schedule) {
-  BDS_RAISE_PRIO();
   constexpr int nb = (DEG + 1) * (DEG + 1);
   constexpr int n4 = (nb * 3 + 3) / 4;       // 16-byte pieces of a coefficient row the colour needs
   constexpr int ldr = n4 * 4 + 4;            // LDS row stride (floats): 16-byte aligned, an odd number of 16-byte pieces
@@ -267,17 +265,16 @@ __device__ __forceinline__ void list_range(const int32_t *__restrict__ offsets, 
 __device__ __forceinline__ float clamp_alpha(float ov) { return __builtin_amdgcn_fmed3f(ov, kAlphaMax, -1.f); }
 
 // ---- forward ----------------------------------------------------------------------------------------------
-// (bid: the workgroup's index in the launch of one workgroup per tile -- blockIdx.x there; a slot-capped launch, bds_set_option(10, ..),
-// walks bid = blockIdx.x, blockIdx.x + gridDim.x, ...: gridDim.x is a multiple of 8, so bid % 8 stays the workgroup's XCD)
 template <int CH, bool kCoarse, bool kStrip>
-__device__ __forceinline__ void rasterize_fwd_wave_body(
-    int bid, int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+__global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, const ListGeom &lg,
-    int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC) {
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
+    int32_t *__restrict__ tile_work) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;   // (the list length may live on the device: bds_rasterize_fwd_dev)
   const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(bid, C * n_tiles);
+  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -388,39 +385,13 @@ __device__ __forceinline__ void rasterize_fwd_wave_body(
     const int w = max(0, m - start + 1);
     if (lane == 0) {
       if (lg.sched) {   // binned: the tile joins its length's bin of this XCD's range (the range xcd_contiguous gave this workgroup)
-        const int x = bid % kSchedXcd, slot = x * kSchedLogBins + sched_bin(w), stride = sched_stride(C * n_tiles);
+        const int x = (int)blockIdx.x % kSchedXcd, slot = x * kSchedLogBins + sched_bin(w), stride = sched_stride(C * n_tiles);
         const int pos = atomicAdd(tile_work + 1 + slot, 1);
         if (pos < stride) tile_work[kSchedHeader + slot * stride + pos] = item;
       } else {
         tile_work[item] = w;
       }
     }
-  }
-}
-
-template <int CH, bool kCoarse, bool kStrip>
-__global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
-    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
-    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
-    int32_t *__restrict__ tile_work) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  rasterize_fwd_wave_body<CH, kCoarse, kStrip>((int)blockIdx.x, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
-                                               alphas, last_ids, lg, tile_work, sA, sB, sC);
-}
-// the slot-capped launch's form: every workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (6 registers more than one tile per workgroup)
-template <int CH, bool kCoarse, bool kStrip>
-__global__ __launch_bounds__(kWave) void rasterize_fwd_walk_kernel(
-    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
-    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
-    int32_t *__restrict__ tile_work) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  const int total = C * tile_w * tile_h;
-  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
-    rasterize_fwd_wave_body<CH, kCoarse, kStrip>(bid, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render, alphas,
-                                                 last_ids, lg, tile_work, sA, sB, sC);
-    __syncthreads();
   }
 }
 
@@ -438,10 +409,10 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, const ListGeom &lg,
-    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid) {
+    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId) {
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
   const int n_tiles = tile_w * tile_h;
-  const int item = pick_item(tile_order, bid, C * n_tiles);
+  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -614,26 +585,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   __shared__ int32_t sId[kWave];
   const EdEpilogue none{};
   rasterize_bwd_wave_body<CH, ABS, kCoarse, kStrip, false>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
-                                                           last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId,
-                                                           (int)blockIdx.x);
-}
-// the slot-capped launch's form (bds_set_option(9, waves per SIMD)): every workgroup walks the schedule with the grid as its stride --
-// longest tiles first, a resident wave takes the next-longest tile of its XCD's range when it is done.  98 registers instead of 92.
-template <int CH, bool ABS, bool kCoarse, bool kStrip>
-__global__ __launch_bounds__(kWave) void rasterize_bwd_walk_kernel(
-    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
-    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  __shared__ int32_t sId[kWave];
-  const EdEpilogue none{};
-  const int total = C * tile_w * tile_h;
-  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
-    rasterize_bwd_wave_body<CH, ABS, kCoarse, kStrip, false>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
-                                                             last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid);
-    __syncthreads();
-  }
+                                                           last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId);
 }
 // the same with the colour transform's deferred epilogue in the prologue (RGB+ED, one camera).  108 VGPRs (four waves per SIMD
 // against the plain kernel's five): held to five with __launch_bounds__(64, 5) it spills 32-76 bytes per lane and runs 8 % slower
@@ -645,7 +597,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_epi_kernel(
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   rasterize_bwd_wave_body<4, ABS, kCoarse, false, true>(1, M_host, M_dev, rec, nullptr, W, H, tile_w, tile_h, offsets, flatten, alphas, last_ids,
-                                                        nullptr, nullptr, v_rec, tile_order, lg, ep, sA, sB, sC, sId, (int)blockIdx.x);
+                                                        nullptr, nullptr, v_rec, tile_order, lg, ep, sA, sB, sC, sId);
 }
 // ---- backward schedule: longest tile first inside each XCD's range ------------------------------------
 // One wave per tile finishes when its LAST pixel does, and the chip holds only ~2 rounds of tiles
@@ -658,7 +610,6 @@ __global__ __launch_bounds__(kWorkBlock) void tile_work_kernel(int C, int W, int
                                                                const int32_t *__restrict__ offsets,
                                                                const int32_t *__restrict__ last_ids,
                                                                int32_t *__restrict__ work, ListGeom lg) {
-  BDS_RAISE_PRIO();
   const int n_tiles = tile_w * tile_h, total = C * n_tiles;
   const int item = blockIdx.x * (kWorkBlock / kWave) + (threadIdx.x >> 6);
   if (item >= total) return;
@@ -682,7 +633,6 @@ __global__ __launch_bounds__(kWorkBlock) void tile_work_kernel(int C, int W, int
 constexpr int kSchedThreads = 1024, kSchedBins = 1024;
 __global__ __launch_bounds__(kSchedThreads) void tile_order_kernel(int total, const int32_t *__restrict__ work,
                                                                    int32_t *__restrict__ order, int32_t *__restrict__ tag) {
-  BDS_RAISE_PRIO();
   __shared__ int hist[kSchedBins];
   __shared__ int s_max;
   constexpr int kXcd = 8;
@@ -763,7 +713,6 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_rgbd_kernel(int64_t n, 
                                                                     const float *__restrict__ conics, const float *__restrict__ colors3,
                                                                     const float *__restrict__ depths, const float *__restrict__ opacities,
                                                                     const int32_t *__restrict__ radii, float4 *__restrict__ rec) {
-  BDS_RAISE_PRIO();
   const int64_t r = (int64_t)blockIdx.x * kPackBlock + threadIdx.x;
   if (r >= n) return;
   const int64_t g = ids ? (int64_t)ids[r] : r;
@@ -776,7 +725,6 @@ __global__ __launch_bounds__(kPackBlock) void splat_pack_rgbd_kernel(int64_t n, 
 // expected depth of gsplat's "ED" modes: out = (r, g, b, D / max(alpha, 1e-10))
 __global__ __launch_bounds__(256) void ed_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
                                                      float4 *__restrict__ out) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   float4 v = render[i];
@@ -788,7 +736,6 @@ __global__ __launch_bounds__(256) void ed_fwd_kernel(int64_t P, const float4 *__
 __global__ __launch_bounds__(256) void ed_bwd_kernel(int64_t P, int ch, int ed, const float4 *__restrict__ render, const float *__restrict__ alphas,
                                                      const float *__restrict__ v_out, const float *__restrict__ v_alphas_in,
                                                      float4 *__restrict__ v_render, float *__restrict__ v_alphas) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -905,16 +852,6 @@ extern "C" int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, 
                             sh_rgb, zero_records, zero_tail, zero_tail_floats, schedule, stream);
 }
 
-// Slot-capped launch of a compositor (bds_set_option(9 / 10, waves per SIMD); 0 = one workgroup per tile): at most that many one-wave
-// workgroups per SIMD of the chip are launched and each walks several tiles.  A launch of one workgroup per tile keeps thousands of
-// workgroups PENDING for ~0.4 ms: every wave slot (and the registers with it) that frees up goes to the next of them, and the short
-// kernels of a concurrent stream queue behind that flood; a capped launch has nothing pending -- what it does not occupy stays free.
-static unsigned capped_grid(int total, int waves_per_simd) {
-  if (waves_per_simd <= 0) return (unsigned)total;
-  const int cap = waves_per_simd * 1024;   // 256 CUs x 4 SIMDs (a multiple of 8: the stride keeps a workgroup's tiles on its XCD's range)
-  return (unsigned)(total < cap ? total : cap);
-}
-
 // list geometry of a launch: list tiles of list_tile_size px (a multiple of the 16-px compositing tile)
 static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
   if (list_tile_size < kTile || list_tile_size % kTile) return false;
@@ -939,8 +876,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   BDS_REQUIRE(CH == 1 || CH == 3 || CH == 4);
   BDS_REQUIRE(isect_offsets && render && alphas && last_ids);
   BDS_REQUIRE(M == 0 || (records && flatten && aligned16(records)));
-  // (the walking instantiation exists for the fused view's shape: 4 channels, coarse lists)
-  const dim3 grid((CH == 4 && lg.div > 1) ? capped_grid(C * tile_w * tile_h, option_get(kOptSlotsFwd)) : (unsigned)(C * tile_w * tile_h));
+  const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
   // (tuning hook: unused dynamic LDS per workgroup caps the resident waves of this VALU-bound kernel, which leaves wave slots to the
@@ -952,9 +888,6 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
-    else if (grid.x < (unsigned)(C * tile_w * tile_h))
-      hipLaunchKernelGGL((rasterize_fwd_walk_kernel<4, true, true>), grid, dim3(kWave), pad_fwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w,
-                         tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work);
     else BDS_FWD(4, true);
   } else {
     if (CH == 1) BDS_FWD(1, false);
@@ -1018,7 +951,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   if (M == 0 && !epi) return BDS_OK;
   BDS_REQUIRE(records && isect_offsets && flatten && alphas && last_ids && v_records && (epi || (v_render && v_alphas)));
   BDS_REQUIRE(aligned16(records) && aligned16(v_records));
-  const dim3 grid((!epi && CH == 4 && lg.div > 1 && absgrad) ? capped_grid(C * tile_w * tile_h, option_get(kOptSlotsBwd)) : (unsigned)(C * tile_w * tile_h));
+  const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
   const size_t pad_bwd = (size_t)option_get(kOptPadBwd) * 1024u;   // (see bds_rasterize_fwd: bds_set_option(1, KB))
@@ -1044,10 +977,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     else if (CH == 3) BDS_BWD(3, ab, co); \
     else BDS_BWD(4, ab, co);          \
   } while (0)
-  if (grid.x < (unsigned)(C * tile_w * tile_h)) {      // slot-capped launch (4 channels, absgrad, coarse lists): the walking instantiation
-    hipLaunchKernelGGL((rasterize_bwd_walk_kernel<4, true, true, false>), grid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H,
-                       tile_w, tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg);
-  } else if (absgrad) {
+  if (absgrad) {
     if (lg.div > 1) BDS_BWD_CH(true, true);
     else BDS_BWD_CH(true, false);
   } else {

@@ -19,7 +19,6 @@ template <int DEG, bool kFull>
 __global__ __launch_bounds__(kShBlock) void sh_fwd_kernel(int64_t n, int K, const float *__restrict__ dirs,
                                                          const float *__restrict__ coeffs,
                                                          const uint8_t *__restrict__ masks, float *__restrict__ out) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int deg = DEG, nb = (DEG + 1) * (DEG + 1);
   const int row = nb * 3;       // floats used per Gaussian
@@ -87,7 +86,6 @@ template <int DEG, bool kVec>
 __global__ __launch_bounds__(kShBlock) void sh_fwd_masked_kernel(int64_t n, int K, const float *__restrict__ dirs,
                                                                 const float *__restrict__ coeffs,
                                                                 const uint8_t *__restrict__ masks, float *__restrict__ out) {
-  BDS_RAISE_PRIO();
   constexpr int nb = (DEG + 1) * (DEG + 1);
   const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
   if (g >= n) return;
@@ -128,7 +126,6 @@ __global__ __launch_bounds__(kShBlock) void sh_bwd_kernel(int64_t n, int K, cons
                                                          const uint8_t *__restrict__ masks,
                                                          const float *__restrict__ v_out, float *__restrict__ v_coeffs,
                                                          float *__restrict__ v_dirs) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int deg = DEG, nb = (DEG + 1) * (DEG + 1);
   const int row = K * 3;   // the whole output row is written (bases >= nb get zero)
@@ -201,7 +198,6 @@ __global__ __launch_bounds__(kShBlock) void sh_view_fwd_kernel(int64_t n, int K,
                                                               const int32_t *__restrict__ radii,
                                                               const float *__restrict__ depths, float *__restrict__ sh_rgb,
                                                               float4 *__restrict__ colors) {
-  BDS_RAISE_PRIO();
   constexpr int nb = (DEG + 1) * (DEG + 1);
   const int64_t g = (int64_t)blockIdx.x * kShBlock + threadIdx.x;
   if (g >= n) return;
@@ -253,7 +249,6 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_ca
                                                                    const float *__restrict__ sh_rgb,
                                                                    const float4 *__restrict__ v_rec, float *__restrict__ v_coeffs,
                                                                    const int32_t *__restrict__ row_map, int sh_rgb_by_rank) {
-  BDS_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int32_t s_g[kShBlock];   // destination row of each staged entry
   constexpr int nb = (DEG + 1) * (DEG + 1);
@@ -334,7 +329,6 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
                                                                         float *__restrict__ v_log_scales, float *__restrict__ v_logits,
                                                                         float *__restrict__ v_sh, float2 *__restrict__ grad2d,
                                                                         float2 *__restrict__ absgrad2d) {
-  BDS_RAISE_PRIO();
   __shared__ int32_t s_g[kShBlock];
   const int64_t n_list = list_length(n_cap, n_dev);
   const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
@@ -380,7 +374,6 @@ __global__ __launch_bounds__(kShBlock) void view_grads_add_list_kernel(
     const float *__restrict__ s_log_scales, const float *__restrict__ s_logits, const float *__restrict__ s_sh,
     float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits,
     float *__restrict__ v_sh) {
-  BDS_RAISE_PRIO();
   __shared__ int32_t s_g[kShBlock];
   const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
   const int cnt = (int)min((int64_t)kShBlock, n_list - r0);

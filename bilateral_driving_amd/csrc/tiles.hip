@@ -52,7 +52,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t &total,
 
 __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(const uint32_t *__restrict__ in, int64_t n,
                                                                 uint32_t *__restrict__ block_sums) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   uint32_t s = 0;
@@ -67,7 +66,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(const uint32_t 
 // single-block in-place exclusive scan of a short array (n <= kScanTile)
 __global__ __launch_bounds__(kScanBlock) void scan_small_kernel(uint32_t *__restrict__ data, int64_t n,
                                                                uint64_t *__restrict__ total_out) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   const int64_t base = (int64_t)threadIdx.x * kScanItems;
   uint32_t v[kScanItems];
@@ -93,7 +91,6 @@ template <bool kSelfOffset>
 __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const uint32_t *__restrict__ in, int64_t n,
                                                                const uint32_t *__restrict__ block_offsets,
                                                                uint32_t *__restrict__ out, uint64_t *__restrict__ total_out) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   uint32_t my_offset;
   if (kSelfOffset) {
@@ -175,7 +172,6 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t *
                                                                const uint64_t *__restrict__ n_dev, int shift,
                                                                uint32_t mask, int nblocks,
                                                                uint32_t *__restrict__ hist /*[256][nblocks]*/) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t h[256];
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   h[threadIdx.x] = 0;
@@ -200,7 +196,6 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_lds_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n_host,
     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits, int nblocks,
     const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
-  BDS_RAISE_PRIO();
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
   if (bbase >= n) return;
@@ -280,7 +275,6 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_kernel(
     const uint32_t *__restrict__ keys_in, int64_t n_host, const uint64_t *__restrict__ n_dev, int shift, uint32_t mask, int bits,
     int nblocks, const uint32_t *__restrict__ hist_scanned, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ unpack,
     uint32_t rank_mask, uint32_t *__restrict__ vals_out) {
-  BDS_RAISE_PRIO();
   const int64_t n = list_length(n_host, n_dev);
   const int64_t bbase = (int64_t)blockIdx.x * kSortChunk;
   if (bbase >= n) return;
@@ -391,7 +385,6 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_wide_kernel(const uint3
                                                                     const uint64_t *__restrict__ n_dev, int shift, uint32_t mask,
                                                                     uint32_t *__restrict__ hist /*[nblocks][kBins]*/,
                                                                     uint32_t *__restrict__ ghist /*[ng][kBins], zeroed*/) {
-  BDS_RAISE_PRIO();
   __shared__ HistWideSh<kBins> sh;
   radix_hist_wide_block<kBins>(sh, (int)blockIdx.x, keys, list_length(n_host, n_dev), shift, mask, hist, ghist);
 }
@@ -541,7 +534,6 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_keys_wide_kernel(
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
     const uint32_t *__restrict__ unpack, uint32_t rank_mask, uint32_t *__restrict__ vals_out, int32_t *__restrict__ offsets_out,
     int n_offsets) {
-  BDS_RAISE_PRIO();
   __shared__ ScatterWideSh<kBins> sh;
   radix_scatter_keys_wide_block<kBins>(sh, (int)blockIdx.x, keys_in, list_length(n_host, n_dev), shift, mask, bits, hist, ghist, keys_out,
                                        unpack, rank_mask, vals_out, offsets_out, n_offsets);
@@ -658,7 +650,6 @@ __global__ __launch_bounds__(kSortBlock) void short_hist_kernel(const uint32_t *
                                                                const uint64_t *__restrict__ n_dev, int64_t n_cap, int shift,
                                                                uint32_t *__restrict__ hist /*[nblocks][256]*/,
                                                                uint32_t *__restrict__ ghist /*[ng][256], zeroed*/) {
-  BDS_RAISE_PRIO();
   __shared__ ShortHistSh sh;
   short_hist_block(sh, (int)blockIdx.x, keys, bounded_count(n_dev, n_cap), shift, hist, ghist);
 }
@@ -764,7 +755,6 @@ __global__ __launch_bounds__(kSortBlock) void short_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint64_t *__restrict__ n_dev, int64_t n_cap,
     int shift, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out) {
-  BDS_RAISE_PRIO();
   __shared__ ShortScatterSh sh;
   short_scatter_block(sh, (int)blockIdx.x, keys_in, vals_in, bounded_count(n_dev, n_cap), shift, hist, ghist, keys_out, vals_out);
 }
@@ -785,7 +775,6 @@ constexpr int kIsectBlock = 256;
 // un-compacted list) and the depth sort shrinks with them.  The visible count stays on the device.
 __global__ __launch_bounds__(kIsectBlock) void isect_flag_kernel(int64_t CN, const int32_t *__restrict__ radii,
                                                                 uint32_t *__restrict__ flags) {
-  BDS_RAISE_PRIO();
   const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (o < CN) flags[o] = radii[o] > 0 ? 1u : 0u;
 }
@@ -797,7 +786,6 @@ __global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, 
                                                                    const float *__restrict__ depths,
                                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                    uint32_t *__restrict__ asc, int compact) {
-  BDS_RAISE_PRIO();
   const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (o >= CN || radii[o] <= 0) return;
   const uint32_t j = pos[o];
@@ -812,7 +800,6 @@ __global__ __launch_bounds__(kScanBlock) void visible_reduce_kernel(int64_t CN, 
                                                                    uint32_t *__restrict__ tile_sums,
                                                                    uint32_t *__restrict__ zero_me, int64_t zero_elems,
                                                                    uint64_t *__restrict__ m_total, int32_t *__restrict__ zero_cn) {
-  BDS_RAISE_PRIO();
   __shared__ uint32_t lw[kScanBlock / kWave + 1];
   if (blockIdx.x == 0 && threadIdx.x == 0) *m_total = 0;   // M is accumulated by the counting kernels
   for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < zero_elems; i += (int64_t)gridDim.x * kScanBlock)
@@ -891,7 +878,6 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
                                                                     uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
                                                                     uint64_t *__restrict__ n_vis_out, uint32_t *__restrict__ asc,
                                                                     int compact, int sums_per_tile) {
-  BDS_RAISE_PRIO();
   __shared__ VisCompactSh sh;
   visible_compact_block(sh, (int)blockIdx.x, (int)gridDim.x, CN, radii, depths, tile_sums, keys, vals, hist, ghist, n_vis_out, asc, compact,
                         sums_per_tile);
@@ -1033,7 +1019,6 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
     int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int64_t N, float4 *__restrict__ rec, uint32_t *__restrict__ btot,
     const uint32_t *__restrict__ asc) {
-  BDS_RAISE_PRIO();
   __shared__ CountRowsSh sh;
   isect_count_rows_block(sh, (int)blockIdx.x, bounded_count(n_vis_dev, n_cap), sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h,
                          tiles_per_gauss, N, rec, btot, asc);
@@ -1089,7 +1074,6 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, int tile_size, int tile_w, int tile_h, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ vals, int pack_shift, const float4 *__restrict__ rec, uint32_t *__restrict__ zero_words, int n_zero) {
-  BDS_RAISE_PRIO();
   __shared__ EmitRowsSh sh;
   // (the group rows of the tile pass that follows: cleared here, by every workgroup of the launch a word each, before anything returns)
   for (int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * kIsectBlock) zero_words[i] = 0u;
@@ -1103,7 +1087,6 @@ __global__ __launch_bounds__(kIsectBlock) void isect_emit_rows_kernel(
 __global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M_host, const uint64_t *__restrict__ M_dev,
                                                                    const uint32_t *__restrict__ keys, int key_shift,
                                                                    int n_tiles_total, int32_t *__restrict__ offsets) {
-  BDS_RAISE_PRIO();
   const int64_t M = list_length(M_host, M_dev);
   const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (i > M) return;
@@ -1117,7 +1100,6 @@ __global__ __launch_bounds__(kIsectBlock) void isect_ids_kernel(int64_t M, const
                                                                const int32_t *__restrict__ flatten_ids,
                                                                const float *__restrict__ depths,
                                                                int64_t *__restrict__ isect_ids) {
-  BDS_RAISE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (i >= M) return;
   const uint32_t d = __float_as_uint(depths[flatten_ids[i]]);
@@ -1231,7 +1213,6 @@ extern "C" size_t bds_isect_build_workspace_bytes(int C, int64_t N, int64_t M) {
 constexpr int kCountMEff = 2, kCountVisEff = 3, kCountOverflow = 4;
 __global__ __launch_bounds__(256) void finish_counts_kernel(const uint32_t *__restrict__ btot, int nblocks, uint64_t *__restrict__ counts_dev,
                                                            volatile int64_t *__restrict__ counts_host, int64_t cap_m, int64_t cap_vis) {
-  BDS_RAISE_PRIO();
   __shared__ unsigned long long part[256];
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // (independent partial sums: four loads in flight per thread)
   int b = threadIdx.x;
