@@ -90,8 +90,8 @@ _SIGS = {
     "bds_bilagrid_slice_fwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_bwd": (_i, [_i64, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_workspace_bytes": (_sz, [_i, C.POINTER(BdsLevel), _i, _i]),
-    "bds_bilagrid_select": (_i, [_i, C.POINTER(BdsLevel), _f, C.POINTER(C.c_void_p), _f]),
-    "bds_bilagrid_select_bwd": (_i, [_i, C.POINTER(BdsLevel), _f, C.POINTER(C.c_void_p), _f]),
+    "bds_bilagrid_select": (_i, [_i, C.POINTER(BdsLevel), _f, C.POINTER(C.c_void_p), _f, _f]),
+    "bds_bilagrid_select_bwd": (_i, [_i, C.POINTER(BdsLevel), _f, C.POINTER(C.c_void_p), _f, _f]),
     "bds_bilagrid_kernel_names": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _i, _i, C.c_char_p, _i]),
     "bds_bilagrid_ms_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, C.POINTER(C.c_void_p), _f]),
     "bds_bilagrid_ms_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f]),

@@ -1338,6 +1338,7 @@ struct GridSelect {
   float *sel[BDS_MAX_LEVELS];          // [count]
   int count[BDS_MAX_LEVELS], n_img[BDS_MAX_LEVELS];
   int blk_off[BDS_MAX_LEVELS + 1];
+  volatile int32_t *err;
 };
 // kBwd = false: sel = full[idx];  kBwd = true: v_full[idx] += sel, sel = 0 (ready for the next replay's backward)
 template <bool kBwd>
@@ -1346,23 +1347,33 @@ __global__ __launch_bounds__(kBgBlock) void grid_select_kernel(GridSelect S, con
   while (k + 1 < S.n && (int)blockIdx.x >= S.blk_off[k + 1]) k++;
   const int e = ((int)blockIdx.x - S.blk_off[k]) * kBgBlock + (int)threadIdx.x;
   const int idx = *idx_dev;
-  if (e >= S.count[k] || idx < 0 || idx >= S.n_img[k]) return;
-  const int64_t o = (int64_t)idx * S.count[k] + e;
+  // an index outside [0, n_img) selects / adds nothing -- and says so: the host cannot see a device-side index, so the sticky error
+  // word (page-locked, may be NULL) is what graph_view.FrameGraph.valid() looks at.  The backward clears the staging gradients
+  // either way: a stale gradient must not leak into the next replay.
+  const bool ok = idx >= 0 && idx < S.n_img[k];
+  if (!ok && S.err && blockIdx.x == 0 && threadIdx.x == 0) *S.err = 1;
+  if (e >= S.count[k]) return;
+  const int64_t o = (int64_t)(ok ? idx : 0) * S.count[k] + e;
   if (kBwd) {
     const float t = S.sel[k][e];
-    if (t != 0.f) atomicAdd(S.v_full[k] + o, t);   // (atomic: another view's TV term may add to the same slice next to this launch)
+    if (ok && t != 0.f) atomicAdd(S.v_full[k] + o, t);   // (atomic: another view's TV term may add to the same slice next to this launch)
     S.sel[k][e] = 0.f;
-  } else {
+  } else if (ok) {
     S.sel[k][e] = S.full[k][o];
   }
 }
 }  // namespace bds
 
 static int grid_select_launch(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *sel, bool bwd,
-                              bds_stream_t stream) {
+                              int32_t *error_pinned, bds_stream_t stream) {
   BDS_REQUIRE(nlevels >= 1 && nlevels <= BDS_MAX_LEVELS && levels && img_idx_dev && sel);
   GridSelect S{};
   S.n = nlevels;
+  if (error_pinned) {
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, error_pinned, 0) != hipSuccess) { (void)hipGetLastError(); return BDS_EINVAL; }
+    S.err = static_cast<volatile int32_t *>(mapped);
+  }
   for (int l = 0; l < nlevels; l++) {
     BDS_REQUIRE(sel[l] && levels[l].gx >= 1 && levels[l].gy >= 1 && levels[l].gl >= 1 && levels[l].n_avg >= 1);
     BDS_REQUIRE(bwd ? levels[l].v_grid != nullptr : levels[l].grid != nullptr);
@@ -1377,12 +1388,12 @@ static int grid_select_launch(int nlevels, const bds_bilagrid_level_t *levels, c
   return BDS_OK;
 }
 extern "C" int bds_bilagrid_select(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *sel,
-                                   bds_stream_t stream) {
-  return grid_select_launch(nlevels, levels, img_idx_dev, sel, false, stream);
+                                   int32_t *error_pinned, bds_stream_t stream) {
+  return grid_select_launch(nlevels, levels, img_idx_dev, sel, false, error_pinned, stream);
 }
 extern "C" int bds_bilagrid_select_bwd(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *v_sel,
-                                       bds_stream_t stream) {
-  return grid_select_launch(nlevels, levels, img_idx_dev, v_sel, true, stream);
+                                       int32_t *error_pinned, bds_stream_t stream) {
+  return grid_select_launch(nlevels, levels, img_idx_dev, v_sel, true, error_pinned, stream);
 }
 
 // Names (as rocprofv3 prints them, without "bds::" and the argument list; comma-separated) of the kernels that the forward / backward

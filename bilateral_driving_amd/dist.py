@@ -639,6 +639,19 @@ def measure_busbw(device, nbytes: int = 256 << 20, iters: int = 3) -> float:
     return 2.0 * (n - 1) / n * nbytes / float(dt[0])
 
 
+def dynamic_union_bound(n_vis_max: int, n_rows: int, device=None) -> int:
+    """Exchange capacity of a REPLAYABLE view slot (graph_view.FrameGraph(dynamic=True, exchange=..)): every rank draws its own random
+    camera per step, so the union of a slot's visible sets over the ranks is bounded by the SUM of the ranks' largest visible sets
+    (each rank's maximum over its calibration sweep), capped at the scene.  A collective (SUM all-reduce of one integer) when a
+    process group is up: every rank gets the same number.  ``device``: where the one-element tensor lives (None: CPU / gloo)."""
+    total = int(n_vis_max)
+    if _active():
+        t = torch.tensor([total], dtype=torch.int64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = int(t[0])
+    return min(total, int(n_rows))
+
+
 def union_row_counts(masks: Iterable[Tensor]) -> List[int]:
     """Per view: how many Gaussians at least one rank sees (``masks``: this rank's uint8 / bool visibility mask of every view of its
     frame, [N] each).  Collective; identical on every rank."""

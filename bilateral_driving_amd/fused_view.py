@@ -483,7 +483,7 @@ class _FusedView(torch.autograd.Function):
         # grid gradients): at that point of a step the host is only tens of microseconds ahead of the GPU, and every allocation
         # or struct fill in front of that launch is GPU idle time.
         ctx.bwd_pre = None
-        if cfg.get("grids_in_place") and cfg.get("grad_sink") is None and any(ctx.needs_input_grad[8:]):
+        if cfg.get("grids_in_place") and any(ctx.needs_input_grad[8:]):
             arena_g = [cfg["grad_arena"][f"grid{i}"] for i in range(len(grids))]
             if all(a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)):
                 v_g = [a if ctx.needs_input_grad[8 + i] else None for i, a in enumerate(arena_g)]
@@ -537,7 +537,7 @@ class _FusedView(torch.autograd.Function):
         # image's slice written (no slice-backward / scatter in the autograd graph)
         # ... or, with grad_arena["grid<i>"] and arena_rows >= 1, ADDED in place to the caller's accumulators (their .grad)
         arena_g = [(cfg.get("grad_arena") or {}).get(f"grid{i}") for i in range(len(grids))]
-        grids_in_place = pre is not None or (bool(cfg.get("grids_in_place")) and cfg.get("grad_sink") is None and any(need_g)
+        grids_in_place = pre is not None or (bool(cfg.get("grids_in_place")) and any(need_g)
                                             and all(a is not None and a.shape == g.shape and a.is_contiguous() for a, g in zip(arena_g, grids)))
         if pre is not None:
             v_grids = pre[0]
@@ -851,7 +851,8 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                defer_epilogue=defer_epilogue,
                defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
-    if grad_arena is not None and arena_rows >= 1 and grad_sink is None:
+    if grad_arena is not None and (arena_rows >= 1 or grad_sink is not None):
+        # (with a sink the arena names the GRID gradients only: the per-Gaussian rows go to the sink's compact buffers)
         cfg["grids_in_place"] = all(g.grad is not None and grad_arena.get(f"grid{i}") is not None
                                     and g.grad.data_ptr() == grad_arena[f"grid{i}"].data_ptr() for i, g in enumerate(gs))
     if (grid_grads is not None and _LOSS_IN_TRANSFORM and not _LOSS_TWO_STEP and all(g.requires_grad and g.is_contiguous() for g in gs)

@@ -113,6 +113,7 @@ class FrameGraph:
             self.sel_grids = [[torch.zeros(1, *g.shape[1:], device=self.dev, dtype=torch.float32).requires_grad_(True) for g in self.grids]
                               for _ in range(self.V)]
             self.sel_grads = [[torch.zeros(1, *g.shape[1:], device=self.dev, dtype=torch.float32) for g in self.grids] for _ in range(self.V)]
+            self.sel_err = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(self.V)]   # sticky: image index out of range
         else:
             self.cams, self.skies, self.targets = list(cams), list(skies), list(targets)
         self.calib_cams = list(calib_cams) if calib_cams is not None else list(cams)
@@ -129,7 +130,6 @@ class FrameGraph:
         self.world = exchange.world if exchange is not None else 1
         # FrameExchange(per_view=False) at world size > 1: the frame runs exactly as on one GPU and step() ends with ONE dense all-reduce
         self._frame_fx = exchange if (exchange is not None and exchange.frame_reduce) else None
-        assert not (self.dynamic and self.fx is not None), "replayable views with an exchange: not built (the reference's loop is one GPU)"
         if exchange is not None:
             by_name = dict(self.params, **{f"grid{i}": g for i, g in enumerate(self.grids)})
             assert not extra_params and sorted(exchange.names) == sorted(self.names), "the exchange covers exactly params + grids"
@@ -178,9 +178,10 @@ class FrameGraph:
             slot.cam_pos.copy_(cam.cam_pos if cam.cam_pos is not None else _camera_centre(slot.viewmat), non_blocking=True)
             self.targets[v].copy_(target, non_blocking=True)
             self.skies[v].copy_(sky, non_blocking=True)
-            if isinstance(img_idx, Tensor):
+            if isinstance(img_idx, Tensor):      # (a device-side index: an out-of-range value is reported by valid())
                 self.img_idx_dev[v].copy_(img_idx.reshape(1), non_blocking=True)
             else:
+                assert 0 <= int(img_idx) < self.grids[0].shape[0], f"image index {img_idx} outside the {self.grids[0].shape[0]} grids"
                 self.img_idx_dev[v].fill_(int(img_idx))
                 self.img_indices[v] = int(img_idx)
 
@@ -194,7 +195,8 @@ class FrameGraph:
         bufs = self.sel_grads[v] if bwd else self.sel_grids[v]
         ptrs = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
         fn = L.lib().bds_bilagrid_select_bwd if bwd else L.lib().bds_bilagrid_select
-        L.check(fn(len(bufs), self._select_levels(bwd), L.ptr(self.img_idx_dev[v]), ptrs, L.stream()), "bds_bilagrid_select")
+        L.check(fn(len(bufs), self._select_levels(bwd), L.ptr(self.img_idx_dev[v]), ptrs, self.sel_err[v].data_ptr(), L.stream()),
+                "bds_bilagrid_select")
 
     # ---- capacities --------------------------------------------------------------------------------------------------------------
     def calibrate(self) -> None:
@@ -211,7 +213,10 @@ class FrameGraph:
                 for v in range(self.V):
                     self._grow(v, M, n_vis)
                 if self.fx is not None:
-                    self._unions = [self.N] * self.V      # (any camera may come: size the exchange for the dense case)
+                    # any camera of any rank's sweep may meet any camera of another's: the union of a slot over the ranks is at most
+                    # the SUM of the ranks' largest visible sets (and at most the scene) -- the same number on every rank
+                    from .dist import dynamic_union_bound
+                    self._unions = [dynamic_union_bound(n_vis, self.N, self.dev if self.fx.world > 1 else None)] * self.V
                 return
             for v, cam in enumerate(self.cams):
                 info = Hn.render_view(self.params, cam, self.grids, self.img_indices[v], self.skies[v], factors=self.factors,
@@ -239,6 +244,9 @@ class FrameGraph:
                   defer_epilogue=not self.overlap)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
+            if self.dynamic:        # the transform's grid gradient -> the slot's staging slices, the TV term -> the parameters' slices
+                kw.update(grid_grads=self.sel_grads[v], grad_arena={f"grid{i}": g for i, g in enumerate(self.sel_grads[v])},
+                          tv_grids=self.grids, tv_grid_grads=[self.arena[f"grid{i}"] for i in range(len(self.grids))])
         else:
             grid_grads = [self.arena[f"grid{i}"] for i in range(len(self.grids))]
             arena = self.arena
@@ -266,7 +274,7 @@ class FrameGraph:
 
     def _phase_bwd(self, v: int, out, tail: bool) -> None:
         out["backward"]()
-        if self.dynamic and self.fx is None:
+        if self.dynamic:
             self._grid_select(v, bwd=True)
         if tail:
             out["backward_tail"]()
@@ -290,10 +298,11 @@ class FrameGraph:
             ws = self.prep_ws[v]
             ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
             g2 = self.g2d[v]      # (the view's persistent screen-space gradient arrays: the same rows, no dense fill per view)
-            pa = [L.ptr(a[k]) if self.clear_grads else None for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+            row_clear = self.clear_grads and self._frame_fx is None   # (per-frame exchange: step() clears the flat buffer densely)
+            pa = [L.ptr(a[k]) if row_clear else None for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
             L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K, *pa,
                                                       L.ptr(g2[0]), L.ptr(g2[1]), st), "bds_view_grads_clear_list_dev")
-        if self._tail.numel() and tail and self.clear_grads:
+        if self._tail.numel() and tail and self.clear_grads and self._frame_fx is None:
             self._tail.zero_()
 
     def _frame_begin(self) -> None:
@@ -404,7 +413,10 @@ class FrameGraph:
         self.n_captures += 1
         torch.cuda.synchronize()
 
-    recapture = capture
+    def recapture(self) -> None:
+        """After anything that re-allocates a parameter (densification): size the lists again (the scene changed), then capture."""
+        self.calibrate()
+        self.capture()
 
     # ---- replay ------------------------------------------------------------------------------------------------------------------
     def step(self, serial: bool = False, wait: bool = True, local: bool = False) -> Optional[bool]:
@@ -484,14 +496,17 @@ class FrameGraph:
 
     def _check_counts(self, raise_on_overflow: bool = False) -> bool:
         ok = True
+        seen = [c.wanted() for c in self.caps]
         for v, c in enumerate(self.caps):
-            M, n_vis = c.wanted()
+            M, n_vis = seen[v]
             if c.overflowed() or M > c.m_cap or n_vis > c.nvis_cap:
                 if raise_on_overflow:
                     raise L.BdsError(f"view {v}: list counts (M = {M}, visible = {n_vis}) exceed the calibrated capacities "
                                      f"({c.m_cap}, {c.nvis_cap}) right after calibration")
                 ok = False
                 self._grow(v, M, n_vis)
+        if self.dynamic and not ok:
+            self._grow_all_slots(max(m for m, _ in seen), max(n for _, n in seen))
         if self.fx is not None:      # the ranks' unions (identical counts on every rank)
             for v, n in enumerate(self.fx.static_counts()):
                 self._unions[v] = max(self._unions[v], n)
@@ -500,6 +515,13 @@ class FrameGraph:
                         raise L.BdsError(f"view {v}: union of the ranks' visible sets ({n}) exceeds the exchange capacity ({self.fx.cap})")
                     ok = False
         return ok
+
+    def _grow_all_slots(self, M: int, n_vis: int) -> None:
+        """dynamic: any slot may render any camera, so what one slot needed every slot is sized for (one recapture, not V of them)."""
+        for v in range(self.V):
+            self._grow(v, M, n_vis)
+        m_cap, nv_cap = max(c.m_cap for c in self.caps), max(c.nvis_cap for c in self.caps)
+        self.caps = [ListCapacity(m_cap, nv_cap) for _ in range(self.V)]
 
     def _agree(self, overflowed: bool, wants_more: bool):
         """The ranks' decision: (any rank overflowed, any rank wants larger lists).  A list count is rank-local -- one rank capturing
@@ -518,6 +540,12 @@ class FrameGraph:
         view rendered nothing) -- do not step the optimizer on them.  With an exchange a COLLECTIVE call (every rank, every frame)."""
         for vg in self.views:
             vg.done.synchronize()
+        if self.dynamic and any(int(e[0]) for e in self.sel_err):
+            bad = [v for v, e in enumerate(self.sel_err) if int(e[0])]
+            for e in self.sel_err:
+                e.zero_()
+            raise L.BdsError(f"view slot(s) {bad}: image index outside the {self.grids[0].shape[0]} bilateral grids (set_view's device-side "
+                             f"index): the slot kept its previous grids and added no grid gradient -- the frame is not usable")
         ok = self._check_counts()
         # keep ahead of a growing scene: re-provision when a count comes within 8 % of its capacity -- at the start of the NEXT step
         # (the caller consumes this frame's gradients first; a capture's warm-up frame would overwrite the static outputs)
@@ -529,8 +557,11 @@ class FrameGraph:
             self._stale = not self.clear_grads
             return False
         if wants_more:
+            seen = [c.observed() for c in self.caps]
             for v in grow:
-                self._grow(v, *self.caps[v].observed())
+                self._grow(v, *seen[v])
+            if self.dynamic and grow:
+                self._grow_all_slots(max(m for m, _ in seen), max(n for _, n in seen))
             self._reprovision = True
         return True
 

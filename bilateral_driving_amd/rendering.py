@@ -28,6 +28,19 @@ class _Meta(dict):
     ``width`` / ``height``: models/trainers/base.py:279-297,422-430)."""
     _LISTS = ("tiles_per_gauss", "flatten_ids", "isect_offsets")
 
+    # (every reading accessor goes through __getitem__: meta.get(..), .items(), .values(), dict(meta) and ** unpacking see the lists too)
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):      # (overridden on purpose: CPython's dict(meta) / ** take a raw-copy fast path for dict subclasses that keep dict's iterator)
+        return iter(list(dict.keys(self)))
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
     def __getitem__(self, key):
         if key in self._LISTS and dict.__getitem__(self, key) is None:
             cull = dict.__getitem__(self, "_cull")
@@ -150,6 +163,9 @@ class _RasterizeView(torch.autograd.Function):
         else:
             out = render[..., :3] if cfg["channels"] == 3 else render
         ctx.mark_non_differentiable(radii, depths, conics)
+        # undefined output gradients stay None: the reference never puts a loss on meta["means2d"], and a materialised [1,N,2] zero
+        # tensor would cost a fill, an index_select and an add over the records in every backward
+        ctx.set_materialize_grads(False)
         return out, alphas, means2d, radii, depths, conics
 
     @staticmethod
@@ -162,8 +178,9 @@ class _RasterizeView(torch.autograd.Function):
         n_vis = vis_ids.numel()
         tw, th = math.ceil(W / TILE_SIZE), math.ceil(H / TILE_SIZE)
         v_render, v_alphas_t = torch.empty_like(render), torch.empty_like(alphas)
-        L.check(lib.bds_expected_depth_bwd(H * W, cfg["channels"], int(cfg["ed"]), L.ptr(render), L.ptr(alphas), L.ptr(_f32c(v_out)),
-                                           L.ptr(_f32c(v_alphas)), L.ptr(v_render), L.ptr(v_alphas_t), st), "bds_expected_depth_bwd")
+        L.check(lib.bds_expected_depth_bwd(H * W, cfg["channels"], int(cfg["ed"]), L.ptr(render), L.ptr(alphas),
+                                           None if v_out is None else L.ptr(_f32c(v_out)), None if v_alphas is None else L.ptr(_f32c(v_alphas)),
+                                           L.ptr(v_render), L.ptr(v_alphas_t), st), "bds_expected_depth_bwd")
         v_alphas = v_alphas_t
         want_pose = bool(ctx.needs_input_grad[5])
         v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev)

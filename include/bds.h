@@ -374,11 +374,13 @@ int bds_view_grads_add_list(int64_t n_list, const int32_t *ids, int K, const flo
  * replay to replay -- the reference draws a random image every step (tools/train.py:257) and indexes the grid parameters with it
  * (models/modules.py:507-512, `int(image_infos["img_idx"][0][0])`, a host read-back there).  levels[l]: grid / v_grid = the FULL
  * parameter [n_img,12,gl,gy,gx] and its gradient, n_avg = n_img.  select: sel[l] [12,gl,gy,gx] = grid_l[*img_idx_dev];
- * select_bwd: v_grid_l[*img_idx_dev] += v_sel[l], then v_sel[l] = 0.  An index outside [0, n_img) selects / adds nothing. */
+ * select_bwd: v_grid_l[*img_idx_dev] += v_sel[l], then v_sel[l] = 0.  An index outside [0, n_img) selects / adds nothing (the
+ * staging grids keep their contents; select_bwd still clears v_sel) and sets *error_pinned = 1 (page-locked int32, sticky, may be
+ * NULL): the host cannot see a device-side index otherwise. */
 int bds_bilagrid_select(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *sel,
-                        bds_stream_t stream);
+                        int32_t *error_pinned, bds_stream_t stream);
 int bds_bilagrid_select_bwd(int nlevels, const bds_bilagrid_level_t *levels, const int32_t *img_idx_dev, float *const *v_sel,
-                            bds_stream_t stream);
+                            int32_t *error_pinned, bds_stream_t stream);
 
 /* The colour transform's backward WITHOUT its last stage, and the compositor's backward that finishes it (one camera, RGB+ED; the
  * fused view, models/trainers/base.py:393-419 + scene_graph.py:86-120,292-294 as one backward).  The last stage of

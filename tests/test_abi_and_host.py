@@ -225,3 +225,27 @@ def test_dropin_lib_bilagrid_exports_the_product_functions():
             "try:\n    LB.slice4d()\nexcept NotImplementedError:\n    print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_meta_dict_materialises_its_lazy_lists_through_every_accessor(monkeypatch):
+    """rendering._Meta (the one-view fast path of rasterization()): gsplat's per-tile lists are built on first access -- through [],
+    .get(), .items(), .values(), dict(meta) and ** alike (round-4 advisor finding: only [] did)."""
+    import torch
+    from bilateral_driving_amd import rendering as R
+    calls = []
+
+    def fake_isect_tiles(means2d, radii, depths, tile_size, tw, th, want_isect_ids=False, conics=None, opacities=None):
+        calls.append(1)
+        return torch.tensor([1]), None, torch.tensor([7, 8]), torch.tensor([0])
+    monkeypatch.setattr(R, "isect_tiles", fake_isect_tiles)
+
+    def fresh():
+        return R._Meta({"means2d": 0, "radii": 0, "depths": torch.zeros(1, 9), "conics": 0, "opacities": torch.zeros(1, 9), "tile_size": 16,
+                        "tile_width": 1, "tile_height": 1, "tiles_per_gauss": None, "isect_ids": None, "flatten_ids": None,
+                        "isect_offsets": None, "_cull": False})
+    for read in (lambda m: m["flatten_ids"], lambda m: m.get("flatten_ids"), lambda m: dict(m.items())["flatten_ids"],
+                 lambda m: dict(m)["flatten_ids"], lambda m: (lambda **kw: kw["flatten_ids"])(**m),
+                 lambda m: list(m.values())[list(m.keys()).index("flatten_ids")]):
+        got = read(fresh())
+        assert got is not None and got.tolist() == [7, 8]
+    assert fresh().get("no_such_key", 5) == 5 and len(calls) >= 6

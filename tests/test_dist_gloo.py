@@ -515,3 +515,33 @@ def test_frame_exchange_when_the_union_approaches_the_whole_scene(world):
         assert unions[-1] >= 0.9 * _FX_N, unions                       # the regime this test is about
         assert caps[0] == caps[1] == res[0][2][0] and unions[-1] <= caps[-1] <= cap_max, (caps, unions)
         assert payloads[1] >= _FX_VIEWS * caps[1] * row_floats * 4      # (+ the dense tail)
+
+
+def _bound_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd.dist import dynamic_union_bound
+    q.put((rank, dynamic_union_bound(100 * (rank + 1), 10_000), dynamic_union_bound(4000 + rank, 10_000)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_capacity_protocol_of_replayable_view_slots_with_an_exchange(world):
+    """graph_view.FrameGraph(dynamic=True, exchange=..): every rank draws its own camera per step, so a slot's union over the ranks is
+    bounded by the SUM of the ranks' largest visible sets, capped at the scene -- one collective, the same number on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bound_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = sum(100 * (r + 1) for r in range(world))
+    assert all(r[1] == want for r in res)
+    assert all(r[2] == min(10_000, sum(4000 + r for r in range(world))) for r in res)       # (world 3: capped at the scene)
+    from bilateral_driving_amd.dist import dynamic_union_bound          # no process group: the rank's own maximum
+    assert dynamic_union_bound(123, 1000) == 123 and dynamic_union_bound(5000, 1000) == 1000

@@ -188,3 +188,81 @@ def test_ranks_sharing_the_gpu_frame_exchange_equals_sequential_sum(graph, world
         assert res[0][2] == 0 and res[0][3] == (N * 59 + sum(g.numel() for g in grids0)) * 4      # no compact buffers; the dense buffer once
     print(f"[exchange] world {world}: capacity {res[0][2]} rows of {N} ({res[0][2] / N:.0%}), {res[0][3]} bytes all-reduced per rank and frame "
           f"(dense: {N * 59 * 4 * len(YAWS)})")
+
+
+def _worker_dynamic(rank, world, port, q, per_view, steps=10):
+    """Replayable view slots WITH an exchange: every step every rank writes a random (camera, target, sky, image index) of ITS pool into
+    each slot, ONE capture serves all steps, and after every step every rank holds the sum over all ranks' views of that step."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.dist import FlatGradients, FrameExchange
+    from bilateral_driving_amd.graph_view import FrameGraph
+    dev = "cuda"
+    V, n_img = 2, 5
+    g = torch.Generator().manual_seed(100 + rank)
+    pool = []
+    for k in range(3):      # this rank's timestep of the drive, three jittered rigs: 9 cameras
+        pool += Hn.ring_cameras(W, H, yaws_deg=[y + float(torch.rand(1, generator=g)) * 30.0 - 15.0 for y in YAWS], device=dev,
+                                origin=(1.5 * rank + 0.4 * k, 0.0, 0.0))
+    base = Hn.synthetic_scene(N, seed=4, device=dev)
+    grids0 = Hn.make_grids(n_img, device=dev)
+    targets = [torch.rand(H, W, 3, generator=g).to(dev) for _ in range(3)]
+    skies = [torch.rand(H, W, 3, generator=g).to(dev) for _ in range(3)]
+    p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
+    grids = [x.clone().requires_grad_(True) for x in grids0]
+    flat = FlatGradients(list(p.values()) + grids, sparse_rows=True)
+    fx = FrameExchange(flat, list(p.keys()) + [f"grid{i}" for i in range(len(grids))], per_view=per_view)
+    frame = FrameGraph(p, pool[:V], grids, [skies[0].clone() for _ in range(V)], [targets[0].clone() for _ in range(V)], exchange=fx,
+                       dynamic=True, calib_cams=pool, img_indices=[0] * V)
+    assert (frame.fx is fx) == per_view and fx.world == world
+    worst = 0.0
+    for step in range(steps):
+        picks = [(int(torch.randint(0, len(pool), (1,), generator=g)), int(torch.randint(0, 3, (1,), generator=g)),
+                  int(torch.randint(0, n_img, (1,), generator=g))) for _ in range(V)]
+        for v, (c, t, i) in enumerate(picks):
+            frame.set_view(v, pool[c], targets[t], skies[(t + 1) % 3], i if step % 2 else torch.tensor([i], device=dev, dtype=torch.int32))
+        assert frame.step() is True
+        got = torch.cat([t.grad.reshape(-1) for t in list(p.values()) + grids]).cpu()
+        # this rank's share of the reference: its views of this step on fresh leaves, dense; summed over the ranks through gloo
+        ref = None
+        for c, t, i in picks:
+            q_ = {k: x.clone().requires_grad_(True) for k, x in base.items()}
+            g_ = [x.clone().requires_grad_(True) for x in grids0]
+            Hn.training_loss(Hn.render_view(q_, pool[c], g_, i, skies[(t + 1) % 3]), targets[t], g_).backward()
+            r = torch.cat([x.grad.reshape(-1) for x in list(q_.values()) + g_])
+            ref = r if ref is None else ref + r
+        ref = ref.cpu()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        worst = max(worst, float((got - ref).norm() / ref.norm()))
+    q.put((rank, worst, frame.n_captures, fx.cap, fx.payload_bytes))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,per_view", [(2, True), (4, True), (2, False)])
+def test_replayable_view_slots_with_an_exchange(world, per_view):
+    """FrameGraph(dynamic=True, exchange=fx) (/root/reference/project/tools/train.py:250-283: a random image per step, here on every
+    rank): 10 steps of other cameras / targets / skies / image indices per rank, every rank's gradients == the sum over all ranks'
+    views of the step (1e-3: atomics order), ONE capture; the per-view exchange is sized by the sum of the ranks' largest visible
+    sets (dist.dynamic_union_bound)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dynamic, args=(r, world, port, q, per_view)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, worst, n_captures, cap, payload in res:
+        assert worst < 1e-3, (rank, worst)
+        assert n_captures == 1, (rank, n_captures)
+    assert len({(r[3], r[4]) for r in res}) == 1          # replicas: same capacity, same payload
+    if per_view:
+        assert 0 < res[0][3] <= (N + 3) // 4 * 4
+    print(f"[dynamic exchange] world {world} per_view {per_view}: worst rel err {max(r[1] for r in res):.1e}, capacity {res[0][3]} rows of {N}, "
+          f"{res[0][4]} bytes all-reduced per rank and frame")
