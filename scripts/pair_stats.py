@@ -107,8 +107,12 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--view", type=int, default=0)
+    ap.add_argument("--scene", choices=("ring", "lidar"), default="ring")
     a = ap.parse_args()
-    print(json.dumps(pair_stats(a.gaussians, a.width, a.height, a.view)))
+    params = None
+    if a.scene == "lidar":
+        params = Hn.lidar_scene(a.gaussians if a.gaussians != 2_000_000 else 1_000_000, seed=0, device=torch.device("cuda", torch.cuda.current_device()))
+    print(json.dumps(pair_stats(a.gaussians, a.width, a.height, a.view, params=params)))
 
 
 if __name__ == "__main__":

@@ -233,7 +233,10 @@ def test_other_baseline_configs_fullsize_properties(name):
     assert float((got - ref).norm() / ref.norm()) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["c3_2M_6cam_1600x900_3level", "c5_5M_5cam_1920x1280_4level"])
+_CONFIGS["lidar_1M_6cam_1080p_3level"] = (1_000_000, None, 1920, 1080, None, None)      # harness.lidar_scene: the small-splat end
+
+
+@pytest.mark.parametrize("name", ["c3_2M_6cam_1600x900_3level", "c5_5M_5cam_1920x1280_4level", "lidar_1M_6cam_1080p_3level"])
 def test_replayed_frame_at_full_size_equals_eager_frame(name):
     """What bench.py TIMES -- graph_view.FrameGraph.step(): device-side list counts, SH colours in the record pack, loss on the
     transform's launch, two streams, in-place gradient rows -- against the eager host-count frame on the same parameters, at
@@ -249,7 +252,8 @@ def test_replayed_frame_at_full_size_equals_eager_frame(name):
     cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev)
     for c in cams:
         c.viewmat.requires_grad_(True)
-    p = {k: t.requires_grad_(True) for k, t in Hn.synthetic_scene(N, seed=0, device=dev).items()}
+    scene = Hn.lidar_scene(N, seed=0, device=dev) if name.startswith("lidar") else Hn.synthetic_scene(N, seed=0, device=dev)
+    p = {k: t.requires_grad_(True) for k, t in scene.items()}
     grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), levels=levels, device=dev)]
     gen = torch.Generator().manual_seed(13)
     skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
