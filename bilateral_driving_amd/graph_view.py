@@ -36,11 +36,9 @@ flags) before any of them captures again, because a capture's warm-up frame issu
 accumulation) and ``step()`` ends with ONE dense all-reduce of the flat gradient buffer on the caller's stream; the next frame
 clears that buffer densely (other ranks' rows are in it).  ``dist.plan_exchange`` prices the two modes.
 
-A graph holds device addresses: after anything that re-allocates a parameter (densification) call ``recapture()``.  Overflow
-protocol: a view whose list counts outgrow their capacities renders NOTHING (effective counts zero, bds_isect_prepare_dev) and raises
-the sticky overflow word in its page-locked counts; ``valid()`` sees it after the fact, grows the capacities (never shrinks) and
-captures again.  Capacities that come within 8 % of their limit are grown at the START of the next ``step()`` -- after the caller
-has consumed the valid frame's gradients, which a capture's warm-up would overwrite.
+A graph holds device addresses: after anything that re-allocates a parameter (densification) call ``recapture()``.  Slots,
+capacities and the overflow protocol (a view whose lists outgrow their capacities renders NOTHING; ``valid()`` sees it after the
+fact, grows the capacities and captures again): ``graph_slots.FrameCapacities``.
 """
 from __future__ import annotations
 
