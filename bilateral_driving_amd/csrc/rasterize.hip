@@ -219,8 +219,10 @@ struct ListGeom {
   int sched;       // forward's tile_work argument: 0 = a work array, 1 = the binned schedule buffer (see pick_item)
 };
 
+// (row0, nrows: the band of the tile's pixel rows the caller composites -- the whole tile, or one 16 x 4 strip of a LONG tile: the
+//  bounding-square part stays at tile granularity, as gsplat clips, the alpha part is taken over the band)
 __device__ __forceinline__ bool tile_candidate_hit(const float4 &A, const float4 &B, const float4 &Cr, int tx, int ty, int tile_w,
-                                                   int tile_h) {
+                                                   int tile_h, int row0 = 0, int nrows = kTile) {
 #pragma clang fp contract(off)
   int x0, y0, x1, y1;
   tile_rect(A.x, A.y, __float_as_int(Cr.w), kTile, tile_w, tile_h, x0, y0, x1, y1);
@@ -235,7 +237,7 @@ __device__ __forceinline__ bool tile_candidate_hit(const float4 &A, const float4
   const float ia = __builtin_amdgcn_rcpf(a), tid = tau * __builtin_amdgcn_rcpf(det);
   const float hy = __builtin_amdgcn_sqrtf(a * tid), hx = __builtin_amdgcn_sqrtf(c * tid);
   constexpr float kSlack = 0.03f;
-  float e0 = ((float)(ty * kTile) + 0.5f) - A.y, e1 = e0 + (float)(kTile - 1);
+  float e0 = ((float)(ty * kTile + row0) + 0.5f) - A.y, e1 = e0 + (float)(nrows - 1);
   if (e0 > hy + kSlack || e1 < -hy - kSlack) return false;
   e0 = fminf(fmaxf(e0, -hy), hy);
   e1 = fminf(fmaxf(e1, -hy), hy);
@@ -265,31 +267,43 @@ __device__ __forceinline__ void list_range(const int32_t *__restrict__ offsets, 
 __device__ __forceinline__ float clamp_alpha(float ov) { return __builtin_amdgcn_fmed3f(ov, kAlphaMax, -1.f); }
 
 // ---- forward ----------------------------------------------------------------------------------------------
-template <int CH, bool kCoarse, bool kStrip>
-__global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
-    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
-    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
-    int32_t *__restrict__ tile_work) {
-  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+// every pixel of a lane finished (T < 0)
+template <int NQ>
+__device__ __forceinline__ bool lane_done(const float *T) {
+  float m = T[0];
+#pragma unroll
+  for (int q = 1; q < NQ; q++) m = fmaxf(m, T[q]);
+  return m < 0.f;
+}
+
+// One wave, one tile (NQ = 4: lane l owns column l % 16, rows l / 16 + 4 q) or one 16 x 4 STRIP q0 of a tile (NQ = 1: one pixel per
+// lane; bds_rasterize_*_dev(split_len): a tile whose list is that long is composited by four waves).  bid: the workgroup's index in a
+// launch of one workgroup per tile.
+template <int CH, bool kCoarse, bool kStrip, int NQ>
+__device__ __forceinline__ void rasterize_fwd_wave_body(
+    int bid, int q0, int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec,
+    const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ flatten, float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+    const ListGeom &lg, int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC) {
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;   // (the list length may live on the device: bds_rasterize_fwd_dev)
   const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(blockIdx.x, C * n_tiles);
+  const int item = xcd_contiguous(bid, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
   const int j = tx * kTile + (lane & 15);
-  const int i0 = ty * kTile + (lane >> 4);
+  const int i0 = ty * kTile + (lane >> 4) + 4 * q0;
   const float px = (float)j + 0.5f;
   int start, end;
   list_range<kCoarse>(offsets, item, C * n_tiles, cam, tx, ty, lg, M, start, end);
   // T[q] > 0: running transmittance; T[q] < 0: the pixel is finished and |T[q]| is its final transmittance
   // (pixels outside the image start finished).  One register instead of a flag + a value per pixel.
-  float T[4], pyc[4];
-  int cur[4] = {0, 0, 0, 0};
-  float out[4][4];
+  float T[NQ], pyc[NQ];
+  int cur[NQ];
+  float out[NQ][4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < NQ; q++) {
+    cur[q] = 0;
     T[q] = ((i0 + 4 * q) < H && j < W) ? 1.f : -1.f;
     pyc[q] = (float)(i0 + 4 * q) + 0.5f;
 #pragma unroll
@@ -305,13 +319,13 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     if (CH > 2 || kCoarse) pC = rec[r * 3 + 2];
   }
   for (int b = 0; b < nbatch; b++) {
-    if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
+    if (__all(lane_done<NQ>(T))) break;
     const int bstart = start + b * kWave;
     int bs = min(kWave, end - bstart);
     __syncthreads();
     if (kCoarse) {
       // keep the candidates that reach this tile, in list order; their list position rides in the record's spare slot
-      const bool hit = (bstart + lane < end) && tile_candidate_hit(pA, pB, pC, tx, ty, tile_w, tile_h);
+      const bool hit = (bstart + lane < end) && tile_candidate_hit(pA, pB, pC, tx, ty, tile_w, tile_h, NQ == 4 ? 0 : 4 * q0, 4 * NQ);
       const uint64_t m = __ballot(hit);
       bs = __popcll(m);
       if (hit) {
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       if (CH > 2 || kCoarse) Cc = sC[t];
       const int pos_t = kCoarse ? __float_as_int(Cc.z) : bstart + t;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < NQ; q++) {
         // branch-free per pixel (as the backward): a pixel that does not blend this Gaussian adds vis = 0 and keeps T, cur.
         // (Exec-masked branches cost ~16 scalar instructions per pixel row here: the kernel was issuing 0.7 scalar per vector op.)
         const float e = splat_exponent(eadx2, ebdx, B.x, A.y - pyc[q]);
@@ -360,13 +374,13 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     };
     // the all-pixels-finished test runs every second entry: an entry blended against a finished tile changes nothing
     for (int t = 0; t < bs; t += 2) {
-      if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) < 0.f)) break;
+      if (__all(lane_done<NQ>(T))) break;
       blend_entry(t);
       if (t + 1 < bs) blend_entry(t + 1);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < NQ; q++) {
     const int i = i0 + 4 * q;
     if (i < H && j < W) {
       const int64_t pix = ((int64_t)cam * H + i) * W + j;
@@ -378,20 +392,72 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
       for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + Tf * backgrounds[cam * CH + k] : out[q][k];
     }
   }
-  if (tile_work) {
+  if (tile_work && q0 == 0) {   // (a long tile: its first strip's length stands for the tile -- the key only orders the backward's launch)
     // the backward's schedule key: how far into its list this tile blended (what tile_work_kernel re-derives from last_ids; pixels
     // outside the image and pixels that blended nothing hold 0)
-    const int m = wave_max_i32(max(max(cur[0], cur[1]), max(cur[2], cur[3])));
+    int mc = cur[0];
+#pragma unroll
+    for (int q = 1; q < NQ; q++) mc = max(mc, cur[q]);
+    const int m = wave_max_i32(mc);
     const int w = max(0, m - start + 1);
     if (lane == 0) {
       if (lg.sched) {   // binned: the tile joins its length's bin of this XCD's range (the range xcd_contiguous gave this workgroup)
-        const int x = (int)blockIdx.x % kSchedXcd, slot = x * kSchedLogBins + sched_bin(w), stride = sched_stride(C * n_tiles);
+        const int x = bid % kSchedXcd, slot = x * kSchedLogBins + sched_bin(w), stride = sched_stride(C * n_tiles);
         const int pos = atomicAdd(tile_work + 1 + slot, 1);
         if (pos < stride) tile_work[kSchedHeader + slot * stride + pos] = item;
       } else {
         tile_work[item] = w;
       }
     }
+  }
+}
+
+template <int CH, bool kCoarse, bool kStrip>
+__global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
+    int32_t *__restrict__ tile_work) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  rasterize_fwd_wave_body<CH, kCoarse, kStrip, 4>((int)blockIdx.x, 0, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten,
+                                                  render, alphas, last_ids, lg, tile_work, sA, sB, sC);
+}
+
+// ---- long tiles: four waves per tile ---------------------------------------------------------------------------------------------
+// One wave per tile runs as long as the tile's list: where thousands of small splats fall into a few tiles (the vanishing point of a
+// street seen from a lidar-initialised scene: 8 300 listed / 4 700 blended entries in one tile against 160 on average) the launch waits
+// for those waves -- 2.3 ms forward, 3.2 ms backward for a view whose other tiles are done in 0.3 / 0.6.  The split launch has FOUR
+// workgroups per tile: a tile whose (list-tile) list holds >= split_len entries is composited strip by strip, one 16 x 4 strip per
+// wave -- one pixel per lane, and the candidate filter taken over the strip's rows, so a small splat is blended by the strips it
+// touches only -- every other tile by its first workgroup as before (the other three leave at once).  Same pixels, same order per
+// pixel: the image is bit-identical.  Workgroup b: XCD x = b % 8 (kept: the XCD's band of tiles), strip (b / 8) % 4, tile slot b / 32.
+__device__ __forceinline__ bool split_slot(int total, int &bid, int &strip) {
+  const int b = (int)blockIdx.x, x = b & 7, k = b >> 3;
+  strip = k & 3;
+  bid = (k >> 2) * 8 + x;
+  return bid < total;
+}
+static unsigned split_grid(int total) { return (unsigned)(4 * 8 * ((total + 7) / 8)); }
+
+template <int CH, bool kStrip>
+__global__ __launch_bounds__(kWave) void rasterize_fwd_split_kernel(
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
+    int32_t *__restrict__ tile_work, int split_len) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  const int n_tiles = tile_w * tile_h, total = C * n_tiles;
+  int bid, strip;
+  if (!split_slot(total, bid, strip)) return;
+  const int item = xcd_contiguous(bid, total), cam = item / n_tiles, tile = item - cam * n_tiles;
+  int start, end;
+  list_range<true>(offsets, item, total, cam, tile % tile_w, tile / tile_w, lg, M_dev ? (int64_t)*M_dev : M_host, start, end);
+  if (end - start >= split_len) {
+    rasterize_fwd_wave_body<CH, true, kStrip, 1>(bid, strip, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
+                                                 alphas, last_ids, lg, tile_work, sA, sB, sC);
+  } else if (strip == 0) {
+    rasterize_fwd_wave_body<CH, true, kStrip, 4>(bid, 0, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
+                                                 alphas, last_ids, lg, tile_work, sA, sB, sC);
   }
 }
 
@@ -403,16 +469,17 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 // kEpi: the image gradient is not read but FORMED per pixel from the colour transform's deferred backward (ed_epilogue.h: direct route +
 // guidance route, clamp / sky blend / expected-depth backward; also writes v_sky) -- the lanes wait for their tile's first records
 // anyway, and the transform's third pass over the image (45 us, 172 MB at 1080p) goes away with its two image-sized intermediates.
-template <int CH, bool ABS, bool kCoarse, bool kStrip, bool kEpi>
+template <int CH, bool ABS, bool kCoarse, bool kStrip, bool kEpi, int NQ = 4>
 __device__ __forceinline__ void rasterize_bwd_wave_body(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, const ListGeom &lg,
-    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId) {
+    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid, int q0 = 0) {
+  // (NQ = 4: the whole tile, four pixels per lane; NQ = 1: strip q0 of a LONG tile, one pixel per lane -- see rasterize_fwd_split_kernel)
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
   const int n_tiles = tile_w * tile_h;
-  const int item = pick_item(tile_order, blockIdx.x, C * n_tiles);
+  const int item = pick_item(tile_order, bid, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -421,14 +488,14 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
   if (!kEpi && end <= start) return;   // (kEpi: the tile's pixels still owe their sky gradient)
   const int j = tx * kTile + (lane & 15);
   const float px = (float)j + 0.5f;
-  const int i0 = ty * kTile + (lane >> 4);
+  const int i0 = ty * kTile + (lane >> 4) + 4 * q0;
   // Bd[q] = sum_k buffer_k * v_render_k - T_final * (v_alpha - bg . v_render): the only combination of the accumulated
   // colour `buffer` that the gradient needs, kept as ONE scalar per pixel
-  float T[4], Bd[4], vr[4][4], pyc[4];
-  int bin_final[4];
+  float T[NQ], Bd[NQ], vr[NQ][4], pyc[NQ];
+  int bin_final[NQ];
   int max_bin = -1;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < NQ; q++) {
     const int i = i0 + 4 * q;
     const bool inside = i < H && j < W;
     pyc[q] = (float)i + 0.5f;
@@ -481,7 +548,8 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
       // survivors of this chunk (same test as the forward), compacted in replay order; entries behind the tile's deepest blended
       // one are dropped here instead of being skipped through t0
       const int idx = batch_end - lane;
-      const bool hit = idx >= start && idx <= tile_bin_final && tile_candidate_hit(pA, pB, pC, tx, ty, tile_w, tile_h);
+      const bool hit = idx >= start && idx <= tile_bin_final &&
+                       tile_candidate_hit(pA, pB, pC, tx, ty, tile_w, tile_h, NQ == 4 ? 0 : 4 * q0, 4 * NQ);
       const uint64_t m = __ballot(hit);
       bs = __popcll(m);
       t0 = 0;
@@ -512,11 +580,11 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
       const float opac = B.y, ec = B.x;
       const float eadx = A.z * dx, ebdx = A.w * dx;
       const float eadx2 = eadx * dx;
-      float e[4], ov[4], dyq[4];
-      bool valid[4];
+      float e[NQ], ov[NQ], dyq[NQ];
+      bool valid[NQ];
       bool any = false;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < NQ; q++) {
         dyq[q] = A.y - pyc[q];
         e[q] = splat_exponent(eadx2, ebdx, ec, dyq[q]);
         ov[q] = opac * __builtin_amdgcn_exp2f(e[q]);
@@ -530,7 +598,7 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
       // per-lane sums over the four pixels (branch-free: a pixel that did not blend this Gaussian contributes alpha = 0)
       float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, ax = 0.f, ay = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < NQ; q++) {
         // q = one 16 x 4 strip of the tile: a strip none of whose pixels blends this Gaussian adds exact zeros (and T *= 1)
         if (kStrip && !__any(valid[q])) continue;
         const float dy = dyq[q];
@@ -585,7 +653,32 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
   __shared__ int32_t sId[kWave];
   const EdEpilogue none{};
   rasterize_bwd_wave_body<CH, ABS, kCoarse, kStrip, false>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
-                                                           last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId);
+                                                           last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId,
+                                                           (int)blockIdx.x);
+}
+// four workgroups per tile: a tile whose list holds >= split_len entries goes strip by strip (rasterize_fwd_split_kernel)
+template <int CH, bool ABS>
+__global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
+    int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
+    int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg, int split_len) {
+  __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
+  __shared__ int32_t sId[kWave];
+  const EdEpilogue none{};
+  const int n_tiles = tile_w * tile_h, total = C * n_tiles;
+  int bid, strip;
+  if (!split_slot(total, bid, strip)) return;
+  const int item = pick_item(tile_order, bid, total), cam = item / n_tiles, tile = item - cam * n_tiles;
+  int start, end;
+  list_range<true>(offsets, item, total, cam, tile % tile_w, tile / tile_w, lg, M_dev ? (int64_t)*M_dev : M_host, start, end);
+  if (end - start >= split_len) {
+    rasterize_bwd_wave_body<CH, ABS, true, false, false, 1>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
+                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid, strip);
+  } else if (strip == 0) {
+    rasterize_bwd_wave_body<CH, ABS, true, false, false, 4>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
+                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid, 0);
+  }
 }
 // the same with the colour transform's deferred epilogue in the prologue (RGB+ED, one camera).  108 VGPRs (four waves per SIMD
 // against the plain kernel's five): held to five with __launch_bounds__(64, 5) it spills 32-76 bytes per lane and runs 8 % slower
@@ -597,7 +690,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_epi_kernel(
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   rasterize_bwd_wave_body<4, ABS, kCoarse, false, true>(1, M_host, M_dev, rec, nullptr, W, H, tile_w, tile_h, offsets, flatten, alphas, last_ids,
-                                                        nullptr, nullptr, v_rec, tile_order, lg, ep, sA, sB, sC, sId);
+                                                        nullptr, nullptr, v_rec, tile_order, lg, ep, sA, sB, sC, sId, (int)blockIdx.x);
 }
 // ---- backward schedule: longest tile first inside each XCD's range ------------------------------------
 // One wave per tile finishes when its LAST pixel does, and the chip holds only ~2 rounds of tiles
@@ -866,7 +959,8 @@ static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
 static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                              int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr, bool binned = false) {
+                              int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr, bool binned = false,
+                              int split_len = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -888,6 +982,9 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
+    else if (split_len > 0)     // long tiles strip by strip: four workgroups per tile (the fused view's shape: 4 channels, coarse lists)
+      hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3(split_grid(C * tile_w * tile_h)), dim3(kWave), pad_fwd, st, C, M, M_dev, rec,
+                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, split_len);
     else BDS_FWD(4, true);
   } else {
     if (CH == 1) BDS_FWD(1, false);
@@ -910,14 +1007,14 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
 extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                                     int32_t *last_ids, int32_t *tile_order, bds_stream_t stream) {
-  BDS_REQUIRE(M_dev && M_capacity > 0);
+                                     int32_t *last_ids, int32_t *tile_order, int split_len, bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0);
   // tile_order (optional, bds_rasterize_schedule_ints words): the compositing waves leave the backward's schedule themselves --
   // binned form (option 8, default; header cleared by the record pack in front), or their tiles' keys for bds_rasterize_bwd_schedule_sort
   const bool binned = option_get(kOptSchedBins) != 0;
   return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
                             isect_offsets, flatten, render, alphas, last_ids, stream,
-                            !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned);
+                            !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned, split_len);
 }
 
 extern "C" int64_t bds_rasterize_schedule_ints(int C, int tile_w, int tile_h) {
@@ -941,7 +1038,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
                               const float *v_render, const float *v_alphas, float *v_records, int absgrad,
-                              const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr) {
+                              const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr, int split_len = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -977,7 +1074,15 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     else if (CH == 3) BDS_BWD(3, ab, co); \
     else BDS_BWD(4, ab, co);          \
   } while (0)
-  if (absgrad) {
+  if (split_len > 0 && CH == 4 && lg.div > 1) {      // long tiles strip by strip (see rasterize_fwd_split_kernel)
+    const dim3 sgrid(split_grid(C * tile_w * tile_h));
+    if (absgrad)
+      hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, true>), sgrid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
+                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, split_len);
+    else
+      hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, false>), sgrid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
+                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, split_len);
+  } else if (absgrad) {
     if (lg.div > 1) BDS_BWD_CH(true, true);
     else BDS_BWD_CH(true, false);
   } else {
@@ -1003,10 +1108,11 @@ extern "C" int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacit
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, const float *alphas,
                                      const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records,
-                                     int absgrad, const int32_t *tile_order, bds_stream_t stream) {
-  BDS_REQUIRE(M_dev && M_capacity > 0);
+                                     int absgrad, const int32_t *tile_order, int split_len, bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0);
   return rasterize_bwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream);
+                            isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream, nullptr,
+                            split_len);
 }
 
 extern "C" int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,

@@ -148,6 +148,18 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
+def _split_len(cfg: dict, list_tile: int) -> int:
+    """``split_len`` of the device-count compositors (include/bds.h): tiles whose list holds at least this many entries are composited
+    by four waves, strip by strip.  0 = off; ``cfg["split_len"]`` (graph_view sets it per view slot from the calibration visit's
+    longest list) or ``BDS_SPLIT_LEN`` (A/B sessions)."""
+    if list_tile <= TILE:
+        return 0
+    v = cfg.get("split_len")
+    if v is None:
+        v = int(os.environ.get("BDS_SPLIT_LEN", "0"))
+    return max(int(v), 0)
+
+
 _TILE_OPTIONS_READ = False
 
 
@@ -355,7 +367,7 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
             # (tile_order: the backward's schedule is left by the compositing waves themselves; its header was cleared by the pack)
             L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
                                               L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids),
-                                              L.ptr(tile_order), st), "bds_rasterize_fwd_dev")
+                                              L.ptr(tile_order), _split_len(f.cfg, f.list_tile), st), "bds_rasterize_fwd_dev")
         return rec, render, alphas, last_ids
     if f.rec_buf is not None:      # provisioned before the wait (first composite over this front only)
         rec, f.rec_buf = f.rec_buf[:n_vis], None
@@ -601,7 +613,7 @@ class _FusedView(torch.autograd.Function):
             elif dev_counts is not None:
                 L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
                                                   L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
-                                                  L.ptr(v_rec), 1, L.ptr(order), st), "bds_rasterize_bwd_dev")
+                                                  L.ptr(v_rec), 1, L.ptr(order), _split_len(cfg, LT), st), "bds_rasterize_bwd_dev")
             else:
                 L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
                                               L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
@@ -837,6 +849,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     tail_buf, defer_pose_sum = kwargs.pop("tail_buf", None), bool(kwargs.pop("defer_pose_sum", False))
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
     defer_epilogue = bool(kwargs.pop("defer_epilogue", True))   # (see _DEFER_EPILOGUE)
+    split_len = kwargs.pop("split_len", None)                   # device-count compositors: long tiles strip by strip (see _split_len)
     # the TV term over OTHER tensors than the transform's grids: graph_view's replayable view slices staging copies of ONE image's
     # grids (picked by a device-side index) while the regulariser runs over the full [n_img, ...] parameters (modules.py:445)
     tv_grids, tv_grid_grads = kwargs.pop("tv_grids", None), kwargs.pop("tv_grid_grads", None)
@@ -848,7 +861,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws, g2d_buf=g2d_buf, tail_buf=tail_buf,
-               defer_epilogue=defer_epilogue,
+               defer_epilogue=defer_epilogue, split_len=split_len,
                defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and (arena_rows >= 1 or grad_sink is not None):
