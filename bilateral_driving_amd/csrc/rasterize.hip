@@ -79,7 +79,9 @@ __device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int 
     const int item = order[kSchedHeader + (x * kSchedLogBins + sel) * sched_stride(total) + (slot - before)];
     if ((unsigned)item < (unsigned)total) return item;   // (anything else: a header the pack did not clear -- plain order)
   }
-  return p;   // (a header nobody filled: plain order)
+  // a header nobody filled: plain order.  A FILLED one without this slot (the split launch keeps its long tiles out of the bins,
+  // so a range has fewer entries than workgroups): nothing to do
+  return acc == 0 ? p : -1;
 }
 
 // ---- splat records --------------------------------------------------------------------------------------
@@ -284,10 +286,10 @@ __device__ __forceinline__ void rasterize_fwd_wave_body(
     int bid, int q0, int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec,
     const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten, float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
-    const ListGeom &lg, int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC) {
+    const ListGeom &lg, int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC, int item_in = -1) {
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;   // (the list length may live on the device: bds_rasterize_fwd_dev)
   const int n_tiles = tile_w * tile_h;
-  const int item = xcd_contiguous(bid, C * n_tiles);
+  const int item = item_in >= 0 ? item_in : xcd_contiguous(bid, C * n_tiles);
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -392,7 +394,7 @@ __device__ __forceinline__ void rasterize_fwd_wave_body(
       for (int k = 0; k < CH; k++) r[k] = backgrounds ? out[q][k] + Tf * backgrounds[cam * CH + k] : out[q][k];
     }
   }
-  if (tile_work && q0 == 0) {   // (a long tile: its first strip's length stands for the tile -- the key only orders the backward's launch)
+  if (tile_work && NQ == 4) {   // (the strips of a long tile stay out of the schedule: the backward finds them in the long-tile list)
     // the backward's schedule key: how far into its list this tile blended (what tile_work_kernel re-derives from last_ids; pixels
     // outside the image and pixels that blended nothing hold 0)
     int mc = cur[0];
@@ -426,36 +428,76 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
 // ---- long tiles: four waves per tile ---------------------------------------------------------------------------------------------
 // One wave per tile runs as long as the tile's list: where thousands of small splats fall into a few tiles (the vanishing point of a
 // street seen from a lidar-initialised scene: 8 300 listed / 4 700 blended entries in one tile against 160 on average) the launch waits
-// for those waves -- 2.3 ms forward, 3.2 ms backward for a view whose other tiles are done in 0.3 / 0.6.  The split launch has FOUR
-// workgroups per tile: a tile whose (list-tile) list holds >= split_len entries is composited strip by strip, one 16 x 4 strip per
-// wave -- one pixel per lane, and the candidate filter taken over the strip's rows, so a small splat is blended by the strips it
-// touches only -- every other tile by its first workgroup as before (the other three leave at once).  Same pixels, same order per
-// pixel: the image is bit-identical.  Workgroup b: XCD x = b % 8 (kept: the XCD's band of tiles), strip (b / 8) % 4, tile slot b / 32.
-__device__ __forceinline__ bool split_slot(int total, int &bid, int &strip) {
-  const int b = (int)blockIdx.x, x = b & 7, k = b >> 3;
-  strip = k & 3;
-  bid = (k >> 2) * 8 + x;
-  return bid < total;
+// for those waves -- 2.3 ms forward, 3.1 ms backward for a view whose other tiles are done in 0.3 / 0.6.  A tile whose (list-tile)
+// list holds >= split_len entries is therefore composited strip by strip, one 16 x 4 strip per wave -- one pixel per lane, the
+// candidate filter taken over the strip's rows, so a small splat is blended by the strips it touches only.  Same pixels, same order
+// per pixel: the image is bit-identical.  The launch: [4 x cap strip workgroups of the long tiles, FIRST | one workgroup per tile,
+// which leaves at once for a long tile]; the long tiles are listed by a one-workgroup kernel in front (an earlier form with four
+// workgroups for EVERY tile, three of which left at once, cost 1.3 ms per launch in empty workgroups alone: profiles/NOTES.md).
+// Split area behind the schedule words (bds_rasterize_schedule_ints): [count | 7 unused | flag[total] | list[total]].
+constexpr int kSplitHead = 8, kLongBlock = 1024;
+static int64_t split_area_offset(int64_t total) {
+  const int64_t sorted = 1 + 2 * total, binned = kSchedHeader + (int64_t)kSchedXcd * kSchedLogBins * sched_stride((int)total);
+  return sorted > binned ? sorted : binned;
 }
-static unsigned split_grid(int total) { return (unsigned)(4 * 8 * ((total + 7) / 8)); }
+__global__ __launch_bounds__(kLongBlock) void long_tiles_kernel(const int32_t *__restrict__ offsets, ListGeom lg, int64_t M_host,
+                                                                 const uint64_t *__restrict__ M_dev, int tile_w, int tile_h, int split_len,
+                                                                 int cap, int32_t *__restrict__ area) {
+  __shared__ int wsum[kLongBlock / kWave];
+  const int n_tiles = tile_w * tile_h, per = (n_tiles + kLongBlock - 1) / kLongBlock;
+  const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
+  const int t0 = (int)threadIdx.x * per;
+  int n = 0;
+  for (int t = t0; t < min(t0 + per, n_tiles); t++) {
+    int start, end;
+    list_range<true>(offsets, t, n_tiles, 0, t % tile_w, t / tile_w, lg, M, start, end);
+    n += (end - start >= split_len) ? 1 : 0;
+  }
+  // exclusive scan of n over the workgroup (positions in tile order: deterministic)
+  int inc = n;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == kWave - 1) wsum[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < kLongBlock / kWave; w++) {
+    if (w < wv) base += wsum[w];
+    tot += wsum[w];
+  }
+  int pos = base + inc - n;
+  for (int t = t0; t < min(t0 + per, n_tiles); t++) {
+    int start, end;
+    list_range<true>(offsets, t, n_tiles, 0, t % tile_w, t / tile_w, lg, M, start, end);
+    int flag = -1;
+    if (end - start >= split_len) {
+      if (pos < cap) { flag = pos; area[kSplitHead + n_tiles + pos] = t; }   // (beyond the capacity: one wave, as every other tile)
+      pos++;
+    }
+    area[kSplitHead + t] = flag;
+  }
+  if (threadIdx.x == 0) area[0] = min(tot, cap);
+}
 
 template <int CH, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_split_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
-    int32_t *__restrict__ tile_work, int split_len) {
+    int32_t *__restrict__ tile_work, const int32_t *__restrict__ area, int cap) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
-  const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-  int bid, strip;
-  if (!split_slot(total, bid, strip)) return;
-  const int item = xcd_contiguous(bid, total), cam = item / n_tiles, tile = item - cam * n_tiles;
-  int start, end;
-  list_range<true>(offsets, item, total, cam, tile % tile_w, tile / tile_w, lg, M_dev ? (int64_t)*M_dev : M_host, start, end);
-  if (end - start >= split_len) {
-    rasterize_fwd_wave_body<CH, true, kStrip, 1>(bid, strip, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
-                                                 alphas, last_ids, lg, tile_work, sA, sB, sC);
-  } else if (strip == 0) {
+  const int total = C * tile_w * tile_h, b = (int)blockIdx.x;
+  if (b < 4 * cap) {
+    const int jl = b >> 2;
+    if (jl >= area[0]) return;
+    rasterize_fwd_wave_body<CH, true, kStrip, 1>(0, b & 3, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
+                                                 alphas, last_ids, lg, tile_work, sA, sB, sC, area[kSplitHead + total + jl]);
+  } else {
+    const int bid = b - 4 * cap;
+    if (area[kSplitHead + xcd_contiguous(bid, total)] >= 0) return;      // a long tile: its strips do it
     rasterize_fwd_wave_body<CH, true, kStrip, 4>(bid, 0, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
                                                  alphas, last_ids, lg, tile_work, sA, sB, sC);
   }
@@ -475,11 +517,12 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, const ListGeom &lg,
-    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid, int q0 = 0) {
+    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid, int q0 = 0, int item_in = -1) {
   // (NQ = 4: the whole tile, four pixels per lane; NQ = 1: strip q0 of a LONG tile, one pixel per lane -- see rasterize_fwd_split_kernel)
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
   const int n_tiles = tile_w * tile_h;
-  const int item = pick_item(tile_order, bid, C * n_tiles);
+  const int item = item_in >= 0 ? item_in : pick_item(tile_order, bid, C * n_tiles);
+  if (item < 0) return;   // (a schedule slot without a tile: the split launch keeps its long tiles out of the bins)
   const int cam = item / n_tiles, tile = item - cam * n_tiles;
   const int ty = tile / tile_w, tx = tile - ty * tile_w;
   const int lane = threadIdx.x;
@@ -656,28 +699,30 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId,
                                                            (int)blockIdx.x);
 }
-// four workgroups per tile: a tile whose list holds >= split_len entries goes strip by strip (rasterize_fwd_split_kernel)
+// the split launch's backward: [strip workgroups of the listed long tiles | one workgroup per schedule slot] (rasterize_fwd_split_kernel)
 template <int CH, bool ABS>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg, int split_len) {
+    const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg,
+    const int32_t *__restrict__ area, int cap) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   const EdEpilogue none{};
-  const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-  int bid, strip;
-  if (!split_slot(total, bid, strip)) return;
-  const int item = pick_item(tile_order, bid, total), cam = item / n_tiles, tile = item - cam * n_tiles;
-  int start, end;
-  list_range<true>(offsets, item, total, cam, tile % tile_w, tile / tile_w, lg, M_dev ? (int64_t)*M_dev : M_host, start, end);
-  if (end - start >= split_len) {
+  const int total = C * tile_w * tile_h, b = (int)blockIdx.x;
+  if (b < 4 * cap) {
+    const int jl = b >> 2;
+    if (jl >= area[0]) return;
     rasterize_bwd_wave_body<CH, ABS, true, false, false, 1>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
-                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid, strip);
-  } else if (strip == 0) {
+                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, 0, b & 3,
+                                                            area[kSplitHead + total + jl]);
+  } else {
+    const int bid = b - 4 * cap;
+    const int item = pick_item(tile_order, bid, total);
+    if (item < 0 || area[kSplitHead + item] >= 0) return;
     rasterize_bwd_wave_body<CH, ABS, true, false, false, 4>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
-                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid, 0);
+                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid, 0, item);
   }
 }
 // the same with the colour transform's deferred epilogue in the prologue (RGB+ED, one camera).  108 VGPRs (four waves per SIMD
@@ -960,7 +1005,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
                               int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr, bool binned = false,
-                              int split_len = 0) {
+                              int split_len = 0, int split_cap = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -982,10 +1027,14 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
-    else if (split_len > 0)     // long tiles strip by strip: four workgroups per tile (the fused view's shape: 4 channels, coarse lists)
-      hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3(split_grid(C * tile_w * tile_h)), dim3(kWave), pad_fwd, st, C, M, M_dev, rec,
-                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, split_len);
-    else BDS_FWD(4, true);
+    else if (split_len > 0) {   // long tiles strip by strip (the fused view's shape: one camera, 4 channels, coarse lists, binned schedule)
+      BDS_REQUIRE(C == 1 && tile_work && binned && split_cap > 0);
+      const int total = tile_w * tile_h, cap = split_cap < total ? split_cap : total;
+      int32_t *area = tile_work + split_area_offset(total);
+      hipLaunchKernelGGL(long_tiles_kernel, dim3(1), dim3(kLongBlock), 0, st, isect_offsets, lg, M, M_dev, tile_w, tile_h, split_len, cap, area);
+      hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3((unsigned)(4 * cap + total)), dim3(kWave), pad_fwd, st, C, M, M_dev, rec,
+                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, area, cap);
+    } else BDS_FWD(4, true);
   } else {
     if (CH == 1) BDS_FWD(1, false);
     else if (CH == 3) BDS_FWD(3, false);
@@ -1007,21 +1056,21 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
 extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                                     int32_t *last_ids, int32_t *tile_order, int split_len, bds_stream_t stream) {
-  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0);
+                                     int32_t *last_ids, int32_t *tile_order, int split_len, int split_cap, bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0);
   // tile_order (optional, bds_rasterize_schedule_ints words): the compositing waves leave the backward's schedule themselves --
   // binned form (option 8, default; header cleared by the record pack in front), or their tiles' keys for bds_rasterize_bwd_schedule_sort
   const bool binned = option_get(kOptSchedBins) != 0;
   return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
                             isect_offsets, flatten, render, alphas, last_ids, stream,
-                            !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned, split_len);
+                            !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned, split_len,
+                            split_cap);
 }
 
 extern "C" int64_t bds_rasterize_schedule_ints(int C, int tile_w, int tile_h) {
   if (C < 1 || tile_w < 1 || tile_h < 1) return 0;
   const int64_t total = (int64_t)C * tile_w * tile_h;
-  const int64_t sorted = 1 + 2 * total, binned = kSchedHeader + (int64_t)kSchedXcd * kSchedLogBins * sched_stride((int)total);
-  return sorted > binned ? sorted : binned;
+  return split_area_offset(total) + kSplitHead + 2 * total;   // (+ the split launch's long-tile flags and list)
 }
 
 extern "C" int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream) {
@@ -1038,7 +1087,8 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
                               const float *v_render, const float *v_alphas, float *v_records, int absgrad,
-                              const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr, int split_len = 0) {
+                              const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr, int split_len = 0,
+                              int split_cap = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -1074,14 +1124,17 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     else if (CH == 3) BDS_BWD(3, ab, co); \
     else BDS_BWD(4, ab, co);          \
   } while (0)
-  if (split_len > 0 && CH == 4 && lg.div > 1) {      // long tiles strip by strip (see rasterize_fwd_split_kernel)
-    const dim3 sgrid(split_grid(C * tile_w * tile_h));
+  if (split_len > 0 && CH == 4 && lg.div > 1) {      // long tiles strip by strip: the forward left their list behind the schedule
+    BDS_REQUIRE(C == 1 && tile_order && option_get(kOptSchedBins) != 0 && split_cap > 0);
+    const int total = tile_w * tile_h, cap = split_cap < total ? split_cap : total;
+    const int32_t *area = tile_order + split_area_offset(total);
+    const dim3 sgrid((unsigned)(4 * cap + total));
     if (absgrad)
       hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, true>), sgrid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
-                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, split_len);
+                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap);
     else
       hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, false>), sgrid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
-                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, split_len);
+                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap);
   } else if (absgrad) {
     if (lg.div > 1) BDS_BWD_CH(true, true);
     else BDS_BWD_CH(true, false);
@@ -1108,11 +1161,11 @@ extern "C" int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacit
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, const float *alphas,
                                      const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records,
-                                     int absgrad, const int32_t *tile_order, int split_len, bds_stream_t stream) {
-  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0);
+                                     int absgrad, const int32_t *tile_order, int split_len, int split_cap, bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0);
   return rasterize_bwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
                             isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream, nullptr,
-                            split_len);
+                            split_len, split_cap);
 }
 
 extern "C" int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,

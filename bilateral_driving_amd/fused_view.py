@@ -148,16 +148,19 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
-def _split_len(cfg: dict, list_tile: int) -> int:
-    """``split_len`` of the device-count compositors (include/bds.h): tiles whose list holds at least this many entries are composited
-    by four waves, strip by strip.  0 = off; ``cfg["split_len"]`` (graph_view sets it per view slot from the calibration visit's
-    longest list) or ``BDS_SPLIT_LEN`` (A/B sessions)."""
-    if list_tile <= TILE:
-        return 0
-    v = cfg.get("split_len")
-    if v is None:
-        v = int(os.environ.get("BDS_SPLIT_LEN", "0"))
-    return max(int(v), 0)
+def _split(cfg: dict, list_tile: int, n_tiles: int, have_schedule: bool):
+    """(split_len, split_cap) of the device-count compositors (include/bds.h): tiles whose list holds at least split_len entries --
+    at most split_cap of them -- are composited by four waves, strip by strip.  (0, 0) = off.  ``cfg["split_len"]`` /
+    ``cfg["split_cap"]`` (graph_view sets them per view slot from the calibration visit's lists) or ``BDS_SPLIT_LEN`` /
+    ``BDS_SPLIT_CAP`` (A/B sessions, tests; default capacity: every tile).  Needs the backward's schedule buffer (the long-tile list
+    lives behind it): a forward without one is not split."""
+    if list_tile <= TILE or not have_schedule:
+        return 0, 0
+    n = int(cfg.get("split_len") or os.environ.get("BDS_SPLIT_LEN", "0"))
+    if n <= 0:
+        return 0, 0
+    cap = int(cfg.get("split_cap") or os.environ.get("BDS_SPLIT_CAP", "0")) or n_tiles
+    return n, max(1, min(cap, n_tiles))
 
 
 _TILE_OPTIONS_READ = False
@@ -367,7 +370,8 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
             # (tile_order: the backward's schedule is left by the compositing waves themselves; its header was cleared by the pack)
             L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
                                               L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids),
-                                              L.ptr(tile_order), _split_len(f.cfg, f.list_tile), st), "bds_rasterize_fwd_dev")
+                                              L.ptr(tile_order), *_split(f.cfg, f.list_tile, f.tw * f.th, tile_order is not None), st),
+                    "bds_rasterize_fwd_dev")
         return rec, render, alphas, last_ids
     if f.rec_buf is not None:      # provisioned before the wait (first composite over this front only)
         rec, f.rec_buf = f.rec_buf[:n_vis], None
@@ -450,6 +454,7 @@ class _FusedView(torch.autograd.Function):
         sched_buf = None
         if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
             sched_buf = _empty((int(lib.bds_rasterize_schedule_ints(1, f.tw, f.th)),), dev, torch.int32)
+        ctx.split_ok = sched_buf is not None     # (the long-tile list of a split launch lives behind the schedule words)
         rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all, sched_buf, getattr(ctx, "tail", None))
         tiles_wh = (f.tw, f.th)
         sh_rgb, ctx.sh_by_rank = f.sh_rgb, bool(f.sh_by_rank)      # (set by the composite when the pack evaluated the colours)
@@ -613,7 +618,8 @@ class _FusedView(torch.autograd.Function):
             elif dev_counts is not None:
                 L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
                                                   L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
-                                                  L.ptr(v_rec), 1, L.ptr(order), _split_len(cfg, LT), st), "bds_rasterize_bwd_dev")
+                                                  L.ptr(v_rec), 1, L.ptr(order), *_split(cfg, LT, tw * th, getattr(ctx, "split_ok", False)), st),
+                        "bds_rasterize_bwd_dev")
             else:
                 L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
                                               L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
@@ -849,7 +855,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     tail_buf, defer_pose_sum = kwargs.pop("tail_buf", None), bool(kwargs.pop("defer_pose_sum", False))
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
     defer_epilogue = bool(kwargs.pop("defer_epilogue", True))   # (see _DEFER_EPILOGUE)
-    split_len = kwargs.pop("split_len", None)                   # device-count compositors: long tiles strip by strip (see _split_len)
+    split_len, split_cap = kwargs.pop("split_len", None), kwargs.pop("split_cap", None)   # device-count compositors: long tiles strip by strip (_split)
     # the TV term over OTHER tensors than the transform's grids: graph_view's replayable view slices staging copies of ONE image's
     # grids (picked by a device-side index) while the regulariser runs over the full [n_img, ...] parameters (modules.py:445)
     tv_grids, tv_grid_grads = kwargs.pop("tv_grids", None), kwargs.pop("tv_grid_grads", None)
@@ -861,7 +867,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws, g2d_buf=g2d_buf, tail_buf=tail_buf,
-               defer_epilogue=defer_epilogue, split_len=split_len,
+               defer_epilogue=defer_epilogue, split_len=split_len, split_cap=split_cap,
                defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and (arena_rows >= 1 or grad_sink is not None):

@@ -49,21 +49,24 @@ def camera_centre(viewmat: Tensor) -> Tensor:
 SPLIT_LIST_LEN = int(__import__("os").environ.get("BDS_SPLIT_LIST_LEN", "6144"))   # entries of a list-tile list from which its tiles go strip by strip
 
 
-def split_len_for(info) -> int:
-    """``split_len`` for a camera from the lists of a host-count visit (0 = off): one wave per tile runs as long as the tile's list,
-    so a view in which a few list tiles hold several times the entries of a typical busy one (the vanishing point of a street full
-    of small splats) waits for those waves; their tiles are then composited by four waves (include/bds.h bds_rasterize_fwd_dev).
-    Off unless some list reaches ``SPLIT_LIST_LEN`` entries AND four times the mean list: a view of evenly long lists gains
-    nothing from three more workgroups per tile."""
+def split_len_for(info):
+    """(split_len, split_cap) for a camera from the lists of a host-count visit ((0, 0) = off): one wave per tile runs as long as the
+    tile's list, so a view in which a few list tiles hold several times the entries of a typical busy one (the vanishing point of a
+    street full of small splats) waits for those waves; their tiles are then composited by four waves (include/bds.h
+    bds_rasterize_fwd_dev).  Off unless some list reaches ``SPLIT_LIST_LEN`` entries AND four times the mean list: a view of evenly
+    long lists gains nothing from more workgroups.  Capacity: twice the 16-px tiles of the lists that long now, + 64."""
     if SPLIT_LIST_LEN <= 0:
-        return 0
+        return 0, 0
     offs = info["isect_offsets"].reshape(-1).long()
     if offs.numel() < 2:
-        return 0
+        return 0, 0
     M = int(info["n_isects"])
     lens = torch.diff(offs, append=offs.new_tensor([M]))
     longest, mean = int(lens.max()), float(lens.float().mean())
-    return SPLIT_LIST_LEN if (longest >= SPLIT_LIST_LEN and longest >= 4.0 * mean) else 0
+    if not (longest >= SPLIT_LIST_LEN and longest >= 4.0 * mean):
+        return 0, 0
+    div = max(int(info.get("tile_size", 64)) // 16, 1)
+    return SPLIT_LIST_LEN, 2 * int((lens >= SPLIT_LIST_LEN).sum()) * div * div + 64
 
 
 class FrameCapacities:
@@ -107,15 +110,16 @@ class FrameCapacities:
         import torch.distributed as dist
         with torch.no_grad():
             if self.dynamic:
-                M = n_vis = split = 0
+                M = n_vis = 0
+                split = (0, 0)
                 for cam in self.calib_cams:
                     info = Hn.render_view(self.params, cam, self.grids, 0, self.skies[0], factors=self.factors, sh_degree=self.sh_degree,
                                           list_tile=self.list_tile)["info"]
                     M, n_vis = max(M, int(info["n_isects"])), max(n_vis, int(info["n_visible"]))
-                    split = max(split, split_len_for(info))
+                    split = max(split, split_len_for(info), key=lambda t: t[1])
                 for v in range(self.V):
                     self._grow(v, M, n_vis)
-                    self.split_len[v] = split
+                    self.split_len[v], self.split_cap[v] = split
                 if self.fx is not None:
                     # any camera of any rank's sweep may meet any camera of another's: the union of a slot over the ranks is at most
                     # the SUM of the ranks' largest visible sets (and at most the scene) -- the same number on every rank
@@ -126,7 +130,7 @@ class FrameCapacities:
                 info = Hn.render_view(self.params, cam, self.grids, self.img_indices[v], self.skies[v], factors=self.factors,
                                       sh_degree=self.sh_degree, list_tile=self.list_tile)["info"]
                 self._grow(v, int(info["n_isects"]), int(info["n_visible"]))
-                self.split_len[v] = split_len_for(info)
+                self.split_len[v], self.split_cap[v] = split_len_for(info)
                 if self.fx is not None:
                     mask = (info["radii"].reshape(-1) > 0).to(torch.uint8)
                     if self.fx.world > 1:

@@ -141,14 +141,14 @@ class FrameGraph(FrameCapacities):
         self._vm = torch.zeros(self.V, 4, 4, device=self.dev, dtype=torch.float32)
         self._defer_pose = self.fx is None and all(c.viewmat.requires_grad for c in self.cams)
         self._unions = [0] * self.V
-        self.split_len = [0] * self.V     # per slot: tiles with lists this long are composited by four waves (graph_slots.calibrate)
+        self.split_len, self.split_cap = [0] * self.V, [0] * self.V   # per slot: long tiles composited by four waves (graph_slots.calibrate)
         self.calibrate()
         self.capture()
 
     # ---- the phases of a view (eager warm-up, capture and replay walk the same protocol) -------------------------------------------
     def _view_kwargs(self, v: int) -> dict:
         kw = dict(factors=self.factors, tv_weight=self.tv_weight, caps=self.caps[v], prep_ws=self.prep_ws[v], list_tile=self.list_tile,
-                  sh_degree=self.sh_degree, two_phase=True, lazy_loss=True, split_len=self.split_len[v],
+                  sh_degree=self.sh_degree, two_phase=True, lazy_loss=True, split_len=self.split_len[v], split_cap=self.split_cap[v],
                   # two streams: the transform's memory-bound last stage hides behind the other stream's compositor; folded into the
                   # compositor's backward it would lengthen the VALU-bound critical kernel (fused_view._DEFER_EPILOGUE)
                   defer_epilogue=not self.overlap)

@@ -456,22 +456,24 @@ int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32
  * backward's workgroups find their tile by a prefix walk over the 32 counts, NO launch between the passes; the header must be clear when the
  * forward starts (the record pack's `schedule` argument).  bds_set_option(8, 0): the waves leave their keys and
  * bds_rasterize_bwd_schedule_sort -- one launch, a no-op in the binned form -- writes the sorted schedule.)
- * split_len (> 0: four channels and lists of tiles larger than 16 px, i.e. the fused view; 0 = off): a tile whose list-tile list
- * holds >= split_len entries is composited by FOUR waves, one 16 x 4 strip each (one pixel per lane; the candidates filtered per
- * strip), instead of one -- the launch then has four workgroups per tile, three of which leave at once for every other tile.  For
- * views in which a few tiles collect thousands of small splats (the vanishing point of a street: the launch waits for those waves).
- * Same pixels in the same order: images bit-identical, gradients to the order of their atomics.  Pass the SAME value to the
- * backward.  No reference counterpart (gsplat runs 256 threads per tile everywhere). */
+ * split_len (> 0: one camera, four channels, lists of tiles larger than 16 px, the binned schedule, i.e. the fused view; 0 = off): a
+ * tile whose list-tile list holds >= split_len entries is composited by FOUR waves, one 16 x 4 strip each (one pixel per lane; the
+ * candidates filtered per strip), instead of one: a one-workgroup kernel lists those tiles behind the schedule words (at most
+ * split_cap of them; a long tile beyond that is taken by one wave like any other) and the launch is [4 x split_cap strip workgroups,
+ * first | one workgroup per tile].  For views in which a few tiles collect thousands of small splats (the vanishing point of a
+ * street: the launch waits for those waves).  Same pixels in the same order: images bit-identical, gradients to the order of their
+ * atomics.  Pass the SAME values and the same tile_order buffer to the backward.  No reference counterpart (gsplat runs 256 threads
+ * per tile everywhere). */
 int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, int32_t *last_ids,
-                          int32_t *tile_order, int split_len, bds_stream_t stream);
+                          int32_t *tile_order, int split_len, int split_cap, bds_stream_t stream);
 int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream);
 int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
                           const float *v_render, const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order,
-                          int split_len, bds_stream_t stream);
+                          int split_len, int split_cap, bds_stream_t stream);
 /* the list-driven backward kernels and the row-wise clear with the list length on the device (n_dev -> visible effective) */
 int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int degrees_to_use,
                              const float *means, const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank,

@@ -30,6 +30,12 @@ L.enable_timers(False)
 for _ in range(3):
     frame.step(serial=True)
 torch.cuda.synchronize()
-print("counts (M, visible) per view:", frame.counts())
+print("counts (M, visible) per view:", frame.counts(), "split_len per view:", frame.split_len)
+with torch.no_grad():
+    for v, cam in enumerate(cams):
+        info = Hn.render_view(params, cam, grids, v, skies[v])["info"]
+        offs = info["isect_offsets"].reshape(-1).long()
+        lens = torch.diff(offs, append=offs.new_tensor([int(info["n_isects"])])).float()
+        print(f"view {v}: list-tile lists: mean {float(lens.mean()):.0f} max {int(lens.max())} q99 {float(lens.quantile(0.99)):.0f} lists >= 6144: {int((lens >= 6144).sum())}")
 for name in sorted(frame.marks):
     print(f"{name:16s}", " ".join(f"{ms * 1e3:7.0f}" for ms in frame.mark_samples(name)), "us per view")

@@ -1,5 +1,5 @@
 """-m gpu: long tiles composited strip by strip (include/bds.h bds_rasterize_fwd_dev / _bwd_dev ``split_len``): a tile whose list
-holds at least split_len entries is taken by FOUR waves, one 16 x 4 strip each, the candidates filtered per strip -- against the
+holds at least split_len entries (the first split_cap of them) is taken by FOUR waves, one 16 x 4 strip each, the candidates filtered per strip -- against the
 one-wave-per-tile form that tests/test_gpu_01 / test_gpu_03 tie to the oracle.  Same pixels in the same order: images and last-id maps
 bit-identical, gradients equal to the order of their atomics."""
 import pytest
@@ -62,15 +62,16 @@ def test_strip_split_equals_one_wave_per_tile(monkeypatch, N, W, H, lidar):
     monkeypatch.setenv("BDS_SPLIT_LEN", "0")
     base = _run(Hn, FV, cam, p, grids, sky, target, M, nv)
     assert torch.equal(base[0], ref["rgb"])
-    for split in (1, mixed, int(lens.max()) + 1):
+    for split, cap in ((1, 0), (mixed, 0), (mixed, 7), (int(lens.max()) + 1, 0)):   # (cap 0: every tile; 7: most long tiles overflow the list)
         monkeypatch.setenv("BDS_SPLIT_LEN", str(split))
+        monkeypatch.setenv("BDS_SPLIT_CAP", str(cap))
         got = _run(Hn, FV, cam, p, grids, sky, target, M, nv)
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]) and torch.equal(got[2], base[2]), split
         for k in base[3]:
-            assert rel_err(got[3][k], base[3][k]) < 2e-5, (split, k, rel_err(got[3][k], base[3][k]))
+            assert rel_err(got[3][k], base[3][k]) < 1e-4, (split, k, rel_err(got[3][k], base[3][k]))    # (four times the atomics per pair)
         for a, b in zip(got[4], base[4]):
             assert rel_err(a, b) < 2e-5, split
-        assert rel_err(got[5], base[5]) < 1e-6 and rel_err(got[6], base[6]) < 1e-4 and rel_err(got[7], base[7]) < 2e-5, split
+        assert rel_err(got[5], base[5]) < 1e-6 and rel_err(got[6], base[6]) < 2e-4 and rel_err(got[7], base[7]) < 1e-4, split
 
 
 def test_frame_graph_picks_the_split_for_a_view_with_a_few_very_long_lists(monkeypatch):
@@ -92,7 +93,7 @@ def test_frame_graph_picks_the_split_for_a_view_with_a_few_very_long_lists(monke
     skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
     targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
     frame = FrameGraph(p, cams, grids, skies, targets)
-    assert frame.split_len[0] == 1500, frame.split_len        # the camera looking down the street
+    assert frame.split_len[0] == 1500 and frame.split_cap[0] > 64, (frame.split_len, frame.split_cap)        # the camera looking down the street
     res = frame_against_eager(frame, p, cams, grids, skies, targets, Hn.FACTORS_3)
     assert res["ok"], res
     q = {k: t.requires_grad_(True) for k, t in Hn.synthetic_scene(50_000, seed=0, device=dev).items()}
