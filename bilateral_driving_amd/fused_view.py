@@ -583,7 +583,9 @@ class _FusedView(torch.autograd.Function):
         # The transform's backward leaves its last stage -- guidance route, clamp / sky blend / expected-depth backward: a per-pixel
         # function -- to the compositor's backward wherever the configuration allows it (include/bds.h bds_rasterize_bwd_ms): v_render
         # then holds the direct-route gradient only, v_alphas is not touched, and one launch over the image is gone.
-        defer = (_DEFER_EPILOGUE and cfg.get("defer_epilogue", True) and M > 0 and n_vis > 0
+        # (a split launch -- long tiles strip by strip -- keeps those tiles out of the schedule: only bds_rasterize_bwd_dev finds them)
+        split = _split(cfg, ctx.list_tile, tw * th, getattr(ctx, "split_ok", False)) if getattr(ctx, "dev_counts", None) is not None else (0, 0)
+        defer = (_DEFER_EPILOGUE and cfg.get("defer_epilogue", True) and M > 0 and n_vis > 0 and split[0] == 0
                  and bool(lib.bds_bilagrid_ms_ed_bwd_deferrable(len(grids), lv, H, W)))
         with L.timed("bilagrid_bwd"):
             if defer:
@@ -618,8 +620,7 @@ class _FusedView(torch.autograd.Function):
             elif dev_counts is not None:
                 L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
                                                   L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
-                                                  L.ptr(v_rec), 1, L.ptr(order), *_split(cfg, LT, tw * th, getattr(ctx, "split_ok", False)), st),
-                        "bds_rasterize_bwd_dev")
+                                                  L.ptr(v_rec), 1, L.ptr(order), *split, st), "bds_rasterize_bwd_dev")
             else:
                 L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
                                               L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
