@@ -593,26 +593,45 @@ def main():
             random_its = f"{type(e).__name__}: {e}"
     # the drop-in path (reference-signature operators chained by autograd: projection, SH, isect_tiles, rasterize_to_pixels,
     # bilagrid_transform -- what `gsplat.rasterization(...)` + the module `forward` cost a trainer that changes nothing else)
-    api_its = None
+    # api_path_iters_per_sec: that sequence starting at the Gaussian class's own get_gaussians with marshalling.install (deferred
+    # activations -> the raw one-view node); api_path_eager_iters_per_sec: with the class's eager activations + dense SH pass (the
+    # figure of rounds 3-4)
+    api_its = api_eager_its = None
     if rank == 0 and world == 1 and not args.no_api_path:
+        def api_loop(view):
+            for v in range(V):
+                view(v)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for v in range(V):
+                view(v)
+            torch.cuda.synchronize()
+            return V / (time.perf_counter() - t0)
         try:
             Hn.FUSED = False
             def api_view(v):
                 for t in list(params.values()) + grids + [skies[v], cams[v].viewmat]:
                     t.grad = None
                 Hn.training_loss(Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors), targets[v], grids).backward()
-            for v in range(V):
-                api_view(v)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for v in range(V):
-                api_view(v)
-            torch.cuda.synchronize()
-            api_its = V / (time.perf_counter() - t0)
+            api_eager_its = api_loop(api_view)
         except Exception as e:   # measurement tooling must never take the bench line down
-            api_its = f"{type(e).__name__}: {e}"
+            api_eager_its = f"{type(e).__name__}: {e}"
         finally:
             Hn.FUSED = True
+        try:
+            from bilateral_driving_amd import marshalling as Marsh
+            model = Hn.VanillaModel(params)
+            Marsh.install(Hn.VanillaModel)
+            def model_view(v):
+                for t in model.parameters() + grids + [skies[v], cams[v].viewmat]:
+                    t.grad = None
+                Hn.training_loss(Hn.render_view_model(model, cams[v], grids, v, skies[v], factors=factors), targets[v], grids).backward()
+            api_its = api_loop(model_view)
+            del model
+        except Exception as e:
+            api_its = f"{type(e).__name__}: {e}"
+        finally:
+            Marsh.uninstall(Hn.VanillaModel)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * V * args.steps / elapsed
 
@@ -749,7 +768,7 @@ def main():
                                f"{[list(l) for l in wl['levels']]} factors {list(factors)}, L1+TV loss, camera-pose gradient live; one step = one "
                                f"frame of {V} views per GPU (1 iter = 1 view)",
                    "workload_name": args.workload, "scene": args.scene, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
-                   "frames_per_sec": value / V, "ms_per_view": ms_per_step / V, "api_path_iters_per_sec": api_its,
+                   "frames_per_sec": value / V, "ms_per_view": ms_per_step / V, "api_path_iters_per_sec": api_its, "api_path_eager_iters_per_sec": api_eager_its,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
                    "random_views_iters_per_sec": random_its,

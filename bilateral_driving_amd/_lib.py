@@ -69,6 +69,9 @@ _SIGS = {
     "bds_sh_view_fwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd_list": (_i, [_i64, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_splat_pack_sh": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_splat_pack_sh_split": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_sh_view_bwd_list_split": (_i, [_i64, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
+    "bds_nonfinite_flags": (_i, [_i, _f, _f, _f, _f, _f]),
     "bds_project_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),

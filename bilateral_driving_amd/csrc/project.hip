@@ -239,6 +239,47 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
   if (kPose) pose_grad_reduce(pg, red, v_viewmat_slots);
 }
 
+// ---- NaN / Inf check of a Gaussian class's tensors (models/gaussians/vanilla.py:407-412 raises per tensor: 2 reductions + 2 host
+// waits each; here one streaming launch over up to 8 tensors that ORs bit t into a flag word when tensor t holds a non-finite value)
+struct FiniteArgs {
+  const uint32_t *p[8];
+  int64_t n[8];
+  int count;
+};
+constexpr int kFiniteBlock = 256;
+__device__ __forceinline__ bool nonfinite_bits(uint32_t x) { return (x & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ uint32_t nonfinite4(uint4 v) {
+  return (uint32_t)nonfinite_bits(v.x) | (uint32_t)nonfinite_bits(v.y) | (uint32_t)nonfinite_bits(v.z) | (uint32_t)nonfinite_bits(v.w);
+}
+__global__ __launch_bounds__(kFiniteBlock) void nonfinite_flags_kernel(FiniteArgs A, uint32_t *__restrict__ flags) {
+  // a workgroup reads CONTIGUOUS 16 KB pieces (four 16-byte loads per thread in flight), grid-strided piece by piece
+  constexpr int64_t kPiece = 4 * kFiniteBlock;
+  const int64_t gtid = (int64_t)blockIdx.x * kFiniteBlock + threadIdx.x;
+  uint32_t bad = 0;
+  for (int t = 0; t < A.count; t++) {
+    const uint32_t *q = A.p[t];
+    const int64_t n = A.n[t];
+    const int64_t head = min(n, (int64_t)((16 - (reinterpret_cast<uintptr_t>(q) & 15u)) & 15u) / 4);   // floats in front of a 16-byte boundary
+    const int64_t n4 = (n - head) / 4;
+    const uint4 *q4 = reinterpret_cast<const uint4 *>(q + head);
+    uint32_t b = 0;
+    for (int64_t base = (int64_t)blockIdx.x * kPiece; base < n4; base += (int64_t)gridDim.x * kPiece) {
+      const int64_t i = base + threadIdx.x;
+      if (base + kPiece <= n4) {
+        const uint4 v0 = q4[i], v1 = q4[i + kFiniteBlock], v2 = q4[i + 2 * kFiniteBlock], v3 = q4[i + 3 * kFiniteBlock];
+        b |= (nonfinite4(v0) | nonfinite4(v1)) | (nonfinite4(v2) | nonfinite4(v3));
+      } else {
+        for (int64_t k = i; k < n4; k += kFiniteBlock) b |= nonfinite4(q4[k]);
+      }
+    }
+    if (gtid < head) b |= (uint32_t)nonfinite_bits(q[gtid]);
+    const int64_t tail0 = head + n4 * 4;
+    if (gtid < n - tail0) b |= (uint32_t)nonfinite_bits(q[tail0 + gtid]);
+    if (b) bad |= 1u << t;
+  }
+  if (bad) atomicOr(flags, bad);
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -378,4 +419,30 @@ extern "C" int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t 
   return project_view_bwd_list_impl(n_capacity, n_dev, ids, means, quats, scales, opacities, viewmat, K, W, H, eps2d, v_records,
                                     v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d, absgrad2d, row_map, accumulate,
                                     stream);
+}
+
+// Bit t of *flags_dev is set when tensors[t] (counts[t] floats) holds a NaN or an Inf (vanilla.py:407-412); the word is cleared first.
+// flags_pinned (optional, page-locked): receives a copy behind the launch -- the host reads it after its next wait on the stream.
+extern "C" int bds_nonfinite_flags(int n_tensors, const float *const *tensors, const int64_t *counts, uint32_t *flags_dev,
+                                   uint32_t *flags_pinned, bds_stream_t stream) {
+  BDS_REQUIRE(n_tensors >= 0 && n_tensors <= 8 && flags_dev && (n_tensors == 0 || (tensors && counts)));
+  FiniteArgs A;
+  A.count = n_tensors;
+  int64_t total = 0;
+  for (int t = 0; t < n_tensors; t++) {
+    BDS_REQUIRE(counts[t] >= 0 && (counts[t] == 0 || tensors[t]) && (reinterpret_cast<uintptr_t>(tensors[t]) & 3u) == 0);
+    A.p[t] = reinterpret_cast<const uint32_t *>(tensors[t]);
+    A.n[t] = counts[t];
+    total += counts[t];
+  }
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(flags_dev, 0, sizeof(uint32_t), st) != hipSuccess) return BDS_ELAUNCH;
+  if (total > 0) {
+    const int64_t want = cdiv(cdiv(total, 16), kFiniteBlock);     // four 16-byte pieces per thread and step
+    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(nonfinite_flags_kernel, dim3(grid), dim3(kFiniteBlock), 0, st, A, flags_dev);
+    BDS_LAUNCH_CHECK();
+  }
+  if (flags_pinned && hipMemcpyAsync(flags_pinned, flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return BDS_ELAUNCH;
+  return BDS_OK;
 }

@@ -129,7 +129,8 @@ template <int DEG>
 __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_cap, const uint64_t *__restrict__ n_dev,
                                                                   const int32_t *__restrict__ ids, int K,
                                                                   const float *__restrict__ means, const float *__restrict__ cam_pos,
-                                                                  const float *__restrict__ coeffs, const float *__restrict__ means2d,
+                                                                  const float *__restrict__ coeffs, const float *__restrict__ coeffs_rest,
+                                                                  const float *__restrict__ means2d,
                                                                   const float *__restrict__ conics, const float *__restrict__ depths,
                                                                   const float *__restrict__ opacities, const int32_t *__restrict__ radii,
                                                                   float4 *__restrict__ rec, float *__restrict__ sh_rgb_out,
@@ -155,7 +156,17 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
   const int64_t r = r0 + tid;
   if (tid < cnt) s_g[tid] = ids[r];
   __syncthreads();
-  {
+  if (coeffs_rest != nullptr) {
+    // split storage (the reference's parameters: band 0 [N,3] in `coeffs`, bands 1.. [N,K-1,3] in `coeffs_rest`,
+    // models/gaussians/vanilla.py:96-104,382): rows of 4-byte alignment, staged float by float
+    const int need = nb * 3, total = cnt * need;
+    const int64_t row_rest = (int64_t)(K - 1) * 3;
+    for (int e = tid; e < total; e += kPackShBlock) {
+      const int rr = e / need, c = e - rr * need;
+      const int64_t g = s_g[rr];
+      lds[rr * ldr + c] = c < 3 ? coeffs[g * 3 + c] : coeffs_rest[g * row_rest + (c - 3)];
+    }
+  } else {
     const int total = cnt * n4;
     const int64_t row = (int64_t)K * 3;
 #pragma unroll 4
@@ -941,7 +952,8 @@ extern "C" int bds_splat_pack_dev(int64_t n_capacity, const uint64_t *n_dev, int
 static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
                               const float *cam_pos, const float *coeffs, const float *means2d, const float *conics, const float *depths,
                               const float *opacities, const int32_t *radii, float *records, float *sh_rgb, float *zero_records,
-                              float *zero_tail, int64_t zero_tail_floats, int32_t *schedule, bds_stream_t stream) {
+                              float *zero_tail, int64_t zero_tail_floats, int32_t *schedule, bds_stream_t stream,
+                              const float *coeffs_rest = nullptr) {
   BDS_REQUIRE(n >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
   BDS_REQUIRE(zero_tail_floats >= 0 && zero_tail_floats % 4 == 0 && zero_tail_floats < ((int64_t)1 << 24));
   BDS_REQUIRE((!zero_records || aligned16(zero_records)) && (!zero_tail || aligned16(zero_tail)));
@@ -952,7 +964,8 @@ static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *i
     return BDS_OK;
   }
   BDS_REQUIRE(ids && means && cam_pos && coeffs && means2d && conics && depths && opacities && radii && records && sh_rgb);
-  BDS_REQUIRE(aligned16(records) && aligned16(coeffs) && (K * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
+  BDS_REQUIRE(aligned16(records) && (reinterpret_cast<uintptr_t>(means2d) & 7u) == 0);
+  BDS_REQUIRE(coeffs_rest ? K >= 2 : (aligned16(coeffs) && (K * 3) % 4 == 0));
   const dim3 grid((unsigned)cdiv(n, kPackShBlock)), block(kPackShBlock);
   float4 *rec = reinterpret_cast<float4 *>(records);
   float4 *zr = reinterpret_cast<float4 *>(zero_records), *zt = reinterpret_cast<float4 *>(zero_tail);
@@ -960,7 +973,7 @@ static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *i
   hipStream_t st = as_stream(stream);
 #define BDS_PACK_SH(d)                                                                                                                 \
   hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, sizeof(float) * kPackShBlock * ((((d + 1) * (d + 1) * 3 + 3) / 4) * 4 + 4), st, \
-                     n, n_dev, ids, K, means, cam_pos, coeffs, means2d, conics, depths, \
+                     n, n_dev, ids, K, means, cam_pos, coeffs, coeffs_rest, means2d, conics, depths, \
                      opacities, radii, rec, sh_rgb, zr, zt, zt4, schedule)
   switch (deg) {
     case 0: BDS_PACK_SH(0); break;
@@ -978,6 +991,16 @@ extern "C" int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int deg, 
                                  const float *opacities, const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream) {
   return splat_pack_sh_impl(n, nullptr, ids, K, deg, means, cam_pos, coeffs, means2d, conics, depths, opacities, radii, records, sh_rgb,
                             nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int bds_splat_pack_sh_split(int64_t n, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
+                                       const float *coeffs_dc, const float *coeffs_rest, const float *means2d, const float *conics,
+                                       const float *depths, const float *opacities, const int32_t *radii, float *records, float *sh_rgb,
+                                       bds_stream_t stream) {
+  BDS_REQUIRE(n == 0 || (coeffs_dc && (coeffs_rest || K == 1)));
+  if (K == 1) coeffs_rest = coeffs_dc;   // band 0 only (never read: degree 0 takes three floats of coeffs_dc per row)
+  return splat_pack_sh_impl(n, nullptr, ids, K, deg, means, cam_pos, coeffs_dc, means2d, conics, depths, opacities, radii, records, sh_rgb,
+                            nullptr, nullptr, 0, nullptr, stream, coeffs_rest);
 }
 
 extern "C" int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_ca
                                                                    const float *__restrict__ cam_pos,
                                                                    const float *__restrict__ sh_rgb,
                                                                    const float4 *__restrict__ v_rec, float *__restrict__ v_coeffs,
-                                                                   const int32_t *__restrict__ row_map, int sh_rgb_by_rank) {
+                                                                   const int32_t *__restrict__ row_map, int sh_rgb_by_rank,
+                                                                   float *__restrict__ v_rest) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int32_t s_g[kShBlock];   // destination row of each staged entry
   constexpr int nb = (DEG + 1) * (DEG + 1);
@@ -314,7 +315,9 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_ca
   } else {
     for (int e = tid; e < cnt * row; e += kShBlock) {
       const int r = e / row, cc = e - r * row;
-      float *dst = v_coeffs + (int64_t)s_g[r] * row + cc;
+      // split storage (v_rest != null): band 0 -> v_coeffs [N,3], bands 1.. -> v_rest [N,K-1,3]
+      float *dst = v_rest == nullptr ? v_coeffs + (int64_t)s_g[r] * row + cc
+                   : (cc < 3 ? v_coeffs + (int64_t)s_g[r] * 3 + cc : v_rest + (int64_t)s_g[r] * (row - 3) + (cc - 3));
       *dst = kAcc ? *dst + lds[r * ldr + cc] : lds[r * ldr + cc];
     }
   }
@@ -532,10 +535,10 @@ template <int DEG>
 static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipStream_t st, int64_t n_list, const uint64_t *n_dev,
                                  const int32_t *ids, int K,
                                  const float *means, const float *cam_pos, const float *sh_rgb, const float4 *v_rec, float *v_coeffs,
-                                 const int32_t *row_map, int by_rank) {
+                                 const int32_t *row_map, int by_rank, float *v_rest) {
 #define BDS_LIST(V, A)                                                                                                           \
   hipLaunchKernelGGL((sh_view_bwd_list_kernel<DEG, V, A>), dim3(grid), dim3(kShBlock), lds, st, n_list, n_dev, ids, K, means, cam_pos, \
-                     sh_rgb, v_rec, v_coeffs, row_map, by_rank)
+                     sh_rgb, v_rec, v_coeffs, row_map, by_rank, v_rest)
   if (vec) { if (acc) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else     { if (acc) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST
@@ -543,20 +546,20 @@ static void launch_view_bwd_list(bool vec, bool acc, int grid, size_t lds, hipSt
 
 static int sh_view_bwd_list_impl(int64_t n_list, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,
                                  const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs,
-                                 const int32_t *row_map, int accumulate, bds_stream_t stream) {
+                                 const int32_t *row_map, int accumulate, bds_stream_t stream, float *v_rest = nullptr) {
   BDS_REQUIRE(n_list >= 0 && deg >= 0 && deg <= 3 && K >= (deg + 1) * (deg + 1) && K <= 16);
   if (n_list == 0) return BDS_OK;
   BDS_REQUIRE(ids && means && cam_pos && sh_rgb && v_records && v_coeffs && aligned16(v_records));
   const int grid = (int)cdiv(n_list, kShBlock);
   const size_t lds = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
-  const bool vec = ((K * 3) % 4 == 0) && aligned16(v_coeffs);
+  const bool vec = ((K * 3) % 4 == 0) && aligned16(v_coeffs) && v_rest == nullptr;
   hipStream_t st = as_stream(stream);
   const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
   switch (deg) {
-    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
-    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
-    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
-    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank); break;
+    case 0: launch_view_bwd_list<0>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank, v_rest); break;
+    case 1: launch_view_bwd_list<1>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank, v_rest); break;
+    case 2: launch_view_bwd_list<2>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank, v_rest); break;
+    default: launch_view_bwd_list<3>(vec, accumulate != 0, grid, lds, st, n_list, n_dev, ids, K, means, cam_pos, sh_rgb, v4, v_coeffs, row_map, sh_rgb_by_rank, v_rest); break;
   }
   BDS_LAUNCH_CHECK();
   return BDS_OK;
@@ -567,6 +570,14 @@ extern "C" int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, i
                                     const int32_t *row_map, int accumulate, bds_stream_t stream) {
   return sh_view_bwd_list_impl(n_list, nullptr, ids, K, deg, means, cam_pos, sh_rgb, sh_rgb_by_rank, v_records, v_coeffs, row_map,
                                accumulate, stream);
+}
+
+extern "C" int bds_sh_view_bwd_list_split(int64_t n_list, const int32_t *ids, int K, int deg, const float *means, const float *cam_pos,
+                                          const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs_dc,
+                                          float *v_coeffs_rest, int accumulate, bds_stream_t stream) {
+  BDS_REQUIRE(n_list == 0 || (v_coeffs_dc && (v_coeffs_rest || K == 1)));
+  return sh_view_bwd_list_impl(n_list, nullptr, ids, K, deg, means, cam_pos, sh_rgb, sh_rgb_by_rank, v_records, v_coeffs_dc, nullptr,
+                               accumulate, stream, K == 1 ? nullptr : v_coeffs_rest);
 }
 
 extern "C" int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int deg, const float *means,

@@ -184,11 +184,15 @@ def _view_front(cfg: dict, means, quats, log_scales, logits, sh, viewmat, before
 def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _Front:
     """First half of a view's forward: activations + projection, visibility compaction, depth order, tile counts (whose totals travel
     to the host asynchronously) and the SH colours.  Nothing here depends on the host."""
+    sh_rest = None
+    if isinstance(sh, (tuple, list)):     # split storage, as the reference's classes hold it: (band 0 [N,3], bands 1.. [N,K-1,3])
+        sh, sh_rest = sh[0].contiguous(), sh[1].contiguous()
+        assert sh.dim() == 2 and sh.shape[1] == 3 and sh_rest.dim() == 3 and sh_rest.shape[2] == 3 and cfg.get("caps") is None
     L.require_gpu(means, quats, log_scales, logits, sh, viewmat)
     lib, st = L.lib(), L.stream()
     dev = means.device
     W, H = cfg["width"], cfg["height"]
-    N, K = means.shape[0], sh.shape[1]
+    N, K = means.shape[0], (sh.shape[1] if sh_rest is None else 1 + sh_rest.shape[1])
     means, quats, log_scales, logits, sh = (t.contiguous() for t in (means, quats, log_scales, logits, sh))
     viewmat, Kmat = viewmat.contiguous(), cfg["K"].contiguous()
     # activations (vanilla.py:393-394) + projection (C = 1)
@@ -242,7 +246,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
     cam_pos = cfg["cam_pos"].contiguous()
     in_pack = cfg.get("sh_in_pack", SH_IN_PACK if caps is None else SH_IN_PACK_DEV)
-    if in_pack and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0:
+    if sh_rest is not None or (in_pack and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0):
         sh_rgb, colors = None, None        # evaluated by the record pack, for the visible Gaussians only (_composite)
     else:
         sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
@@ -265,6 +269,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     f = _Front()
     f.cfg = cfg
     f.means, f.quats, f.log_scales, f.sh, f.viewmat, f.cam_pos = means, quats, log_scales, sh, viewmat, cam_pos
+    f.sh_rest, f.K = sh_rest, K
     f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
     f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
     f.tiles_per_gauss, f.isect_offsets, f.ws, f.ws_bytes, f.cull = tiles_per_gauss, isect_offsets, ws, ws_bytes, cull
@@ -381,9 +386,14 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
     with L.timed("rasterize_fwd"):
         if f.colors is None:       # SH colours evaluated on the way; their un-clamped values stay in list order for the backward
             f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
-            L.check(lib.bds_splat_pack_sh(n_vis, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh),
-                                          L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths), L.ptr(opac), L.ptr(f.radii), L.ptr(rec),
-                                          L.ptr(f.sh_rgb), st), "bds_splat_pack_sh")
+            if f.sh_rest is not None:
+                L.check(lib.bds_splat_pack_sh_split(n_vis, L.ptr(f.vis_ids), f.K, f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh),
+                                                    L.ptr(f.sh_rest), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths), L.ptr(opac),
+                                                    L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), st), "bds_splat_pack_sh_split")
+            else:
+                L.check(lib.bds_splat_pack_sh(n_vis, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos),
+                                              L.ptr(f.sh), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths), L.ptr(opac), L.ptr(f.radii),
+                                              L.ptr(rec), L.ptr(f.sh_rgb), st), "bds_splat_pack_sh")
         else:
             L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac),
                                        L.ptr(f.radii), L.ptr(rec), st), "bds_splat_pack")
@@ -753,7 +763,6 @@ def fused_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     return _Out(rgb=rgb, depth=depth, opacity=opacity, _rgb_g_raw=rgb_g, _sky=sky, info=info)
 
 
-@torch.no_grad()
 @torch.no_grad()
 def render_classes(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int, height: int, masks: Dict[str, Tensor],
                    sh_degree: int = 3, near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,

@@ -260,6 +260,64 @@ def render_view_api(params: Dict[str, Tensor], cam: Camera, grids: Sequence[Tens
     return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
 
 
+class VanillaModel:
+    """A Gaussian class with the attributes of the reference's ``VanillaGaussians`` (models/gaussians/vanilla.py:96-104,151-181:
+    ``_means``, ``_scales`` (log), ``_quats`` (raw), ``_opacities`` [N,1] (logits), ``_features_dc`` [N,3], ``_features_rest``
+    [N,K-1,3], ``sh_degree``, ``step``, ``ctrl_cfg.sh_degree_interval``) built from this harness's parameter dict -- what the a13
+    mirrors and ``marshalling.install`` are exercised on where the reference's class (pytorch3d, omegaconf) can not be imported.
+    ``get_gaussians`` is the eager mirror; ``marshalling.install(VanillaModel)`` swaps in the deferred one."""
+
+    class _Ctrl:
+        sh_degree_interval = 1000
+
+    def __init__(self, params: Dict[str, Tensor], sh_degree: int = 3, step: int = 10 ** 6):
+        leaf = lambda t: t.detach().clone().contiguous().requires_grad_(True)
+        self._means, self._quats, self._scales = leaf(params["means"]), leaf(params["quats"]), leaf(params["log_scales"])
+        self._opacities = leaf(params["opacity_logits"].reshape(-1, 1))
+        self._features_dc, self._features_rest = leaf(params["sh"][:, 0, :]), leaf(params["sh"][:, 1:, :])
+        self.sh_degree, self.step, self.ctrl_cfg = int(sh_degree), int(step), VanillaModel._Ctrl()
+
+    def parameters(self):
+        return [self._means, self._quats, self._scales, self._opacities, self._features_dc, self._features_rest]
+
+    def get_gaussians(self, cam):
+        from .marshalling import get_gaussians
+        return get_gaussians(self, cam)
+
+
+def reference_camera(cam: Camera):
+    """The reference's ``dataclass_camera`` of a harness camera (cached on it: the trainer gets ``camtoworlds`` from its dataset,
+    models/trainers/base.py:317-340; ``get_gaussians`` reads the camera centre only, vanilla.py:384)."""
+    dc = getattr(cam, "_reference_camera", None)
+    if dc is None:
+        from .marshalling import dataclass_camera
+        cam_pos = cam.cam_pos if cam.cam_pos is not None else torch.linalg.inv(cam.viewmat.detach())[:3, 3]
+        c2w = torch.eye(4, device=cam.viewmat.device)
+        c2w[:3, 3] = cam_pos.detach()
+        dc = cam._reference_camera = dataclass_camera(camtoworlds=c2w, camtoworlds_gt=c2w, Ks=cam.K, H=cam.height, W=cam.width)
+    return dc
+
+
+def render_view_model(model, cam: Camera, grids: Sequence[Tensor], img_idx: int, sky: Tensor, factors: Sequence[int] = FACTORS_3,
+                      near_plane: float = 0.1, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3):
+    """One view's forward through the reference's call sequence for a scene of ONE Gaussian class, starting at the class's own
+    ``get_gaussians`` (models/trainers/base.py:342-383 ``collect_gaussians``: every entry through ``torch.cat``; :385-419
+    ``render_gaussians``: ``rasterization`` with the trainer's arguments, ``gs.opacities.squeeze()``; then split / sky blend / colour
+    transform as ``render_view_api``).  With ``marshalling.install`` on the model's class the same lines reach the raw one-view node."""
+    from .rendering import rasterization
+    W, H = cam.width, cam.height
+    gs = model.get_gaussians(reference_camera(cam))
+    gs = {k: torch.cat([v], dim=0) for k, v in gs.items()}                                   # base.py:365-366
+    renders, alphas, info = rasterization(means=gs["_means"], quats=gs["_quats"], scales=gs["_scales"], opacities=gs["_opacities"].squeeze(),
+                                          colors=gs["_rgbs"], viewmats=cam.viewmat[None], Ks=cam.K[None], width=W, height=H, packed=False,
+                                          absgrad=True, sparse_grad=False, rasterize_mode="classic", near_plane=near_plane,
+                                          far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, render_mode="RGB+ED")   # base.py:393-408
+    rgb_g, depth, opacity = renders[0, ..., :3], renders[0, ..., 3:4], alphas[0]
+    grids_k = [g[img_idx:img_idx + 1] for g in grids]
+    rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)
+    return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
+
+
 FUSED_LOSS = True   # one autograd node (losses.photometric_tv_loss) instead of ~30 framework kernels
 
 

@@ -125,6 +125,44 @@ def get_gaussians(model, cam: dataclass_camera) -> Dict[str, Tensor]:
     return gs
 
 
+def get_gaussians_lazy(self, cam: dataclass_camera) -> Dict[str, Tensor]:
+    """Drop-in for ``VanillaGaussians.get_gaussians`` (vanilla.py:378-414) that DEFERS the activations: the same dict, its five entries
+    placeholders (``lazy_gaussians.LazyField``) over the raw parameters.  ``rasterization`` runs a complete set of them through one
+    node -- sigmoid / exp / quaternion normalisation inside the projection kernel, SH colours for the visible Gaussians only, read
+    from ``_features_dc`` / ``_features_rest`` where they lie, the NaN / Inf check as one launch whose flag arrives with the list
+    counts; every other use of a placeholder materialises it with the reference's own expression (``lazy_gaussians``).  A class
+    without SH bands (``sh_degree == 0``: sigmoid colours) takes the eager mirror ``get_gaussians``."""
+    from .lazy_gaussians import LazyField, RawGaussians
+    if self.sh_degree <= 0:
+        return get_gaussians(self, cam)
+    if getattr(self, "filter_mask", None) is None or self.filter_mask.shape[0] != self._means.shape[0]:
+        self.filter_mask = torch.ones(self._means.shape[0], dtype=torch.bool, device=self._means.device)   # vanilla.py:379-380 (all ones: kept)
+    n = min(self.step // self.ctrl_cfg.sh_degree_interval, self.sh_degree)           # vanilla.py:387
+    src = RawGaussians(self._means, self._quats, self._scales, self._opacities, self._features_dc, self._features_rest, n,
+                       cam.camtoworlds.data[..., :3, 3], step=getattr(self, "step", -1))
+    N = self._means.shape[0]
+    return dict(_means=LazyField(src, "_means", (N, 3)), _opacities=LazyField(src, "_opacities", self._opacities.shape),
+                _rgbs=LazyField(src, "_rgbs", (N, 3)), _scales=LazyField(src, "_scales", (N, 3)), _quats=LazyField(src, "_quats", (N, 4)))
+
+
+def install(gaussian_class) -> None:
+    """``install(VanillaGaussians)``: the class's ``get_gaussians`` becomes ``get_gaussians_lazy`` (the reference's file is not
+    touched; the same mechanism as assigning ``densify.refinement_after``).  The original stays reachable as
+    ``gaussian_class._bds_reference_get_gaussians``; ``uninstall`` puts it back."""
+    if getattr(gaussian_class, "_bds_reference_get_gaussians", None) is None:
+        gaussian_class._bds_reference_get_gaussians = gaussian_class.__dict__.get("get_gaussians")
+    gaussian_class.get_gaussians = get_gaussians_lazy
+
+
+def uninstall(gaussian_class) -> None:
+    ref = getattr(gaussian_class, "_bds_reference_get_gaussians", None)
+    if ref is not None:
+        gaussian_class.get_gaussians = ref
+    elif "get_gaussians" in gaussian_class.__dict__:
+        del gaussian_class.get_gaussians
+    gaussian_class._bds_reference_get_gaussians = None
+
+
 def collect_gaussians(models: Mapping[str, object], gaussian_classes: Mapping[str, int], cam: dataclass_camera,
                       image_ids: Optional[Tensor] = None) -> Tuple[dataclass_gs, Tensor]:
     """base.py:342-383: every class's ``get_gaussians(cam)`` dict (a class may return None: no instance in this frame) concatenated

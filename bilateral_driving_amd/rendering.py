@@ -7,6 +7,7 @@ Pipeline (every stage a hand-written gfx950 kernel behind libbds.so):
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from typing import Dict, Optional, Tuple
@@ -17,6 +18,7 @@ from torch import Tensor
 import weakref
 
 from . import _lib as L
+from .lazy_gaussians import lazy_source, materialised
 from .gs_ops import (TILE_SIZE, _f32c, bwd_schedule, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
 
 
@@ -78,6 +80,7 @@ def set_tile_culling(on: bool) -> None:
 # One camera, post-activation colours [N,3], "RGB" / "RGB+ED", classic mode, no backgrounds -- the reference's two call patterns
 # (models/trainers/base.py:393-408,811-826) -- run as ONE autograd node over compact lists (BDS_API_FUSED=0: the operator chain below)
 _ONE_VIEW_NODE = os.environ.get("BDS_API_FUSED", "1") != "0"
+_CHECK_FINITE = os.environ.get("BDS_API_CHECK_FINITE", "1") != "0"    # the raw one-view node's NaN / Inf check (vanilla.py:407-412)
 _LIST_TILE = 64          # list tiles of the one-view node (the splat records carry the radii: the image is the 16-px one)
 _CAPACITY: Dict[tuple, list] = {}      # (N, W, H) -> [list entries, visible Gaussians] seen so far: buffers provisioned before the wait
 
@@ -217,6 +220,118 @@ class _RasterizeView(torch.autograd.Function):
                 v_colors.view(cfg["colors_shape"]) if g[4] else None, slots.sum(0) if want_pose else None, None, None)
 
 
+class _RasterizeRawView(torch.autograd.Function):
+    """rasterization() for one camera over a class's RAW parameters (``lazy_gaussians``: the reference's unmodified call sequence
+    with ``marshalling.install``): what ``_RasterizeView`` does, with sigmoid / exp / quaternion normalisation inside the projection
+    kernel (bds_project_view_fwd), the SH colours (+0.5, clamp) evaluated by the record pack for the VISIBLE Gaussians only, straight
+    from the class's two SH parameters (bds_splat_pack_sh_split: no concatenation, no dense SH pass over all N), and the backward
+    list-driven into the raw parameters' gradients (bds_sh_view_bwd_list_split, bds_project_view_bwd_list).  The reference's NaN /
+    Inf check (vanilla.py:407-412) is one streaming launch whose flag word arrives with the list counts."""
+
+    @staticmethod
+    def forward(ctx, means, quats, log_scales, logits, dc, rest, viewmat, Kmat, cfg):
+        from .fused_view import _composite, _image_buffers, _view_front
+        L.require_gpu(means, quats, log_scales, logits, dc, rest, viewmat, Kmat)
+        means, quats, log_scales, logits, dc, rest, viewmat, Kmat = map(_f32c, (means, quats, log_scales, logits, dc, rest, viewmat, Kmat))
+        lib, st = L.lib(), L.stream()
+        dev = means.device
+        W, H, N = cfg["width"], cfg["height"], means.shape[0]
+        fcfg = dict(width=W, height=H, K=Kmat, cam_pos=cfg["cam_pos"], sh_degree=cfg["sh_degree"], near_plane=cfg["near_plane"],
+                    far_plane=cfg["far_plane"], radius_clip=cfg["radius_clip"], eps2d=cfg["eps2d"], tile_cull=cfg["cull"],
+                    list_tile=_LIST_TILE)
+        flags = None
+        if cfg["check_finite"]:
+            # in FRONT of the projection: the flag's copy to the host is then older than the event the one wait of this view waits for.
+            # On the raw values (an activation is non-finite iff its argument is NaN, or +Inf for a scale; -Inf log-scales / +-Inf
+            # logits are reported too although exp / sigmoid map them to finite values, a finite log-scale above 88.7 is not)
+            flags = _finite_words(dev)
+            ts = (means, quats, log_scales, logits, dc, rest)
+            ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            cnts = (ctypes.c_int64 * len(ts))(*[t.numel() for t in ts])
+            L.check(lib.bds_nonfinite_flags(len(ts), ptrs, cnts, flags[0].data_ptr(), flags[1].data_ptr(), st), "bds_nonfinite_flags")
+        f = _view_front(fcfg, means, quats, log_scales, logits.reshape(N), (dc, rest), viewmat, lambda: _image_buffers(W, H, dev))
+        if flags is not None and int(flags[1][0]):
+            bad = [n for i, n in enumerate(("means", "quats", "scales", "opacities", "features_dc", "features_rest")) if int(flags[1][0]) >> i & 1]
+            raise ValueError(f"NaN / Inf detected in gaussian {', '.join(bad)} at step {cfg['step']}")
+        rec, render, alphas, last_ids = _composite(f, f.opac, f.pre)
+        ctx.save_for_backward(f.means, f.quats, f.scales, f.opac, viewmat, Kmat, rec, f.vis_ids, f.ws, f.flatten, f.isect_offsets, render, alphas,
+                              last_ids, f.sh_rgb, f.cam_pos)
+        ctx.cfg, ctx.M, ctx.shapes = cfg, f.M, (tuple(log_scales.shape), tuple(cfg["logits_shape"]), tuple(dc.shape), tuple(rest.shape))
+        if cfg["ed"]:
+            out = torch.empty_like(render)
+            L.check(lib.bds_expected_depth_fwd(H * W, L.ptr(render), L.ptr(alphas), L.ptr(out), st), "bds_expected_depth_fwd")
+        else:
+            out = render[..., :3] if cfg["channels"] == 3 else render
+        ctx.mark_non_differentiable(f.radii, f.depths, f.conics, f.opac)
+        ctx.set_materialize_grads(False)
+        return out, alphas, f.means2d, f.radii, f.depths, f.conics, f.opac
+
+    @staticmethod
+    def backward(ctx, v_out, v_alphas, v_means2d_ext, *_):
+        (means, quats, scales, opac, viewmat, Kmat, rec, vis_ids, _ws, flatten, isect_offsets, render, alphas, last_ids, sh_rgb,
+         cam_pos) = ctx.saved_tensors
+        cfg, M = ctx.cfg, ctx.M
+        lib, st = L.lib(), L.stream()
+        dev = means.device
+        W, H, N = cfg["width"], cfg["height"], means.shape[0]
+        n_vis = vis_ids.numel()
+        tw, th = math.ceil(W / TILE_SIZE), math.ceil(H / TILE_SIZE)
+        v_render, v_alphas_t = torch.empty_like(render), torch.empty_like(alphas)
+        L.check(lib.bds_expected_depth_bwd(H * W, cfg["channels"], int(cfg["ed"]), L.ptr(render), L.ptr(alphas),
+                                           None if v_out is None else L.ptr(_f32c(v_out)), None if v_alphas is None else L.ptr(_f32c(v_alphas)),
+                                           L.ptr(v_render), L.ptr(v_alphas_t), st), "bds_expected_depth_bwd")
+        want_pose = bool(ctx.needs_input_grad[6])
+        v_rec_all = torch.zeros(max(n_vis, 1) + (L.POSE_GRAD_SLOTS if want_pose else 0), L.GRAD_RECORD_FLOATS, device=dev)
+        v_rec = v_rec_all[:max(n_vis, 1)]
+        order = bwd_schedule(1, W, H, _LIST_TILE, isect_offsets, last_ids)
+        with L.timed("rasterize_bwd"):
+            L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE_SIZE, _LIST_TILE, tw, th, L.ptr(isect_offsets),
+                                          L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas_t), L.ptr(v_rec),
+                                          int(bool(cfg["absgrad"])), L.ptr(order), st), "bds_rasterize_bwd")
+        if v_means2d_ext is not None and n_vis:
+            v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())
+        ls_shape, lg_shape, dc_shape, rest_shape = ctx.shapes
+        K = 1 + rest_shape[1]
+        # ONE zero fill for all dense outputs: means 3 | quats 4 | log_scales 3 | logits 1 | dc 3 | rest 3 (K - 1) | grad2d 2 | absgrad2d 2
+        widths = (3, 4, 3, 1, 3, 3 * (K - 1), 2, 2)
+        dense = torch.zeros(N * sum(widths), device=dev)
+        outs, o = [], 0
+        for w in widths:
+            outs.append(dense[o:o + N * w].view(N, w))
+            o += N * w
+        v_means, v_quats, v_ls, v_logits, v_dc, v_rest, g2d, ag2d = outs
+        with L.timed("sh_bwd"):
+            L.check(lib.bds_sh_view_bwd_list_split(n_vis, L.ptr(vis_ids), K, cfg["sh_degree"], L.ptr(means), L.ptr(cam_pos), L.ptr(sh_rgb), 1,
+                                                   L.ptr(v_rec), L.ptr(v_dc), L.ptr(v_rest), 0, st), "bds_sh_view_bwd_list_split")
+        slots = v_rec_all[max(n_vis, 1):].view(L.POSE_GRAD_SLOTS, 4, 4) if want_pose else None
+        with L.timed("project_bwd"):
+            L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac), L.ptr(viewmat),
+                                                  L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls),
+                                                  L.ptr(v_logits), L.ptr(slots), L.ptr(g2d), L.ptr(ag2d) if cfg["absgrad"] else None, None, 0,
+                                                  st), "bds_project_view_bwd_list")
+        carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
+        if carrier is not None:
+            if cfg["absgrad"]:
+                carrier.absgrad = ag2d.view(1, N, 2)
+            if carrier.retains_grad:
+                carrier.grad = g2d.view(1, N, 2)
+        g = ctx.needs_input_grad
+        return (v_means if g[0] else None, v_quats if g[1] else None, v_ls.view(ls_shape) if g[2] else None,
+                v_logits.view(lg_shape) if g[3] else None, v_dc.view(dc_shape) if g[4] else None, v_rest.view(rest_shape) if g[5] else None,
+                slots.sum(0) if want_pose else None, None, None)
+
+
+_FINITE_WORDS: Dict[torch.device, tuple] = {}
+
+
+def _finite_words(dev):
+    """(device word, page-locked word) of bds_nonfinite_flags, one pair per device (a view waits for its counts before the next one)."""
+    w = _FINITE_WORDS.get(dev)
+    if w is None:
+        w = _FINITE_WORDS[dev] = (torch.zeros(1, device=dev, dtype=torch.int32), torch.zeros(1, dtype=torch.int32).pin_memory())
+    return w
+
+
 def _as_int(v) -> int:
     # the reference passes 0-d (GPU) int64 tensors for width/height
     # (/root/reference/project/datasets/base/pixel_source.py:653-654, tools/train.py:262-264)
@@ -266,6 +381,11 @@ def rasterization(
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
     assert tile_size >= TILE_SIZE and tile_size % TILE_SIZE == 0, (
         f"tile_size={tile_size}: a multiple of {TILE_SIZE} is required (lists of larger tiles are filtered per 16-px compositing tile)")
+    src = lazy_source(means, quats, scales, opacities, colors)     # marshalling.install: a class's raw parameters behind placeholders
+    raw_ok = (src is not None and _ONE_VIEW_NODE and viewmats.shape[0] == 1 and sh_degree is None and backgrounds is None
+              and render_mode in ("RGB", "RGB+ED") and rasterize_mode == "classic" and means.shape[0] > 0 and src.features_rest.shape[1] >= 1)
+    if not raw_ok:
+        means, quats, scales, opacities, colors = materialised((means, quats, scales, opacities, colors))
     N = means.shape[0]
     C = viewmats.shape[0]
     assert means.shape == (N, 3), means.shape
@@ -283,6 +403,21 @@ def rasterization(
         assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+
+    if raw_ok:
+        cfg = dict(width=width, height=height, eps2d=float(eps2d), near_plane=float(near_plane), far_plane=float(far_plane),
+                   radius_clip=float(radius_clip), ed=render_mode == "RGB+ED", channels=3 if render_mode == "RGB" else 4,
+                   absgrad=bool(absgrad), cull=_TILE_CULLING, sh_degree=src.sh_degree, cam_pos=_f32c(src.cam_pos.detach().reshape(3)),
+                   logits_shape=tuple(src.logits.shape), step=src.step, check_finite=_CHECK_FINITE)
+        out, alphas, means2d, radii, depths, conics, opac = _RasterizeRawView.apply(
+            src.means, src.quats, src.log_scales, src.logits, src.features_dc, src.features_rest, viewmats[0], Ks[0], cfg)
+        cfg["_means2d_ref"] = weakref.ref(means2d)
+        tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
+        meta = _Meta({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+                      "opacities": opac.detach()[None, :], "tile_width": tile_width, "tile_height": tile_height,
+                      "tiles_per_gauss": None, "isect_ids": None, "flatten_ids": None, "isect_offsets": None, "width": width,
+                      "height": height, "tile_size": tile_size, "n_cameras": C, "_cull": _TILE_CULLING})
+        return out, alphas, meta
 
     if (_ONE_VIEW_NODE and C == 1 and N > 0 and sh_degree is None and colors.shape[-1] == 3 and backgrounds is None
             and render_mode in ("RGB", "RGB+ED") and rasterize_mode == "classic"):

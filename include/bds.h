@@ -198,6 +198,14 @@ int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, 
 int bds_splat_pack_sh(int64_t n, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
                       const float *coeffs, const float *means2d, const float *conics, const float *depths, const float *opacities,
                       const int32_t *radii, float *records, float *sh_rgb, bds_stream_t stream);
+/* The same with the coefficients where the reference's Gaussian classes hold them (models/gaussians/vanilla.py:96-104: `_features_dc`
+ * [N,3] and `_features_rest` [N,K-1,3], two parameters with their own learning rates; :382 concatenates them on every call --
+ * 192 bytes per Gaussian written and read back before anything is culled): band 0 from coeffs_dc, bands 1.. from coeffs_rest
+ * (ignored for K = 1), rows of 4-byte alignment, visible rows only. */
+int bds_splat_pack_sh_split(int64_t n, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
+                            const float *coeffs_dc, const float *coeffs_rest, const float *means2d, const float *conics,
+                            const float *depths, const float *opacities, const int32_t *radii, float *records, float *sh_rgb,
+                            bds_stream_t stream);
 int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
                       int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
                       const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
@@ -348,6 +356,16 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
 int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
                          const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs, const int32_t *row_map,
                          int accumulate, bds_stream_t stream);
+/* ... into the split storage of bds_splat_pack_sh_split: v_coeffs_dc [N,3], v_coeffs_rest [N,K-1,3] (visible rows stored or added to). */
+int bds_sh_view_bwd_list_split(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
+                               const float *sh_rgb, int sh_rgb_by_rank, const float *v_records, float *v_coeffs_dc,
+                               float *v_coeffs_rest, int accumulate, bds_stream_t stream);
+/* NaN / Inf check of the tensors a Gaussian class hands to the rasterizer (models/gaussians/vanilla.py:407-412 raises ValueError per
+ * tensor; two reductions and two host waits each there): ONE streaming launch over up to 8 tensors; bit t of *flags_dev (cleared
+ * first) is set when tensors[t] (counts[t] floats) holds a non-finite value; flags_pinned (optional, page-locked) receives a copy
+ * behind the launch, for the host to read after its next wait on the stream. */
+int bds_nonfinite_flags(int n_tensors, const float *const *tensors, const int64_t *counts, uint32_t *flags_dev,
+                        uint32_t *flags_pinned, bds_stream_t stream);
 /* Backward of gsplat's rasterization() over the visible entries, C = 1 (models/trainers/base.py:393-408: the trainer passes ACTIVATED
  * scales / opacities and post-activation colours [N,3]): what bds_project_view_bwd_list does, with the gradients of the activated
  * scales and opacities returned as they are and the colour gradient (record channels 0-2) scattered to v_colors [N,3] (may be

@@ -1,0 +1,67 @@
+"""Host logic of the deferred activations (``lazy_gaussians`` / ``marshalling.install``): placeholders keep their metadata, stay lazy
+through exactly the operations the reference's trainer applies between ``get_gaussians`` and ``rasterization``
+(/root/reference/project/models/trainers/base.py:342-408: ``torch.cat`` per key, ``gs.opacities.squeeze()``) and turn into the
+reference's own tensors (vanilla.py:383-395) under anything else.  CPU: no kernel runs (the SH colours are not materialised here)."""
+import torch
+
+from bilateral_driving_amd import harness as Hn
+from bilateral_driving_amd import marshalling as M
+from bilateral_driving_amd.lazy_gaussians import LazyField, RawGaussians, lazy_source, materialised
+
+
+def _src(N=12):
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).requires_grad_(True)
+    return RawGaussians(r(N, 3), r(N, 4), r(N, 3), r(N, 1), r(N, 3), r(N, 15, 3), 3, torch.zeros(3), step=7)
+
+
+def test_placeholders_carry_metadata_and_stay_lazy_through_the_trainers_own_steps():
+    src = _src()
+    N = src.means.shape[0]
+    f = {k: LazyField(src, k, s) for k, s in (("_means", (N, 3)), ("_opacities", (N, 1)), ("_scales", (N, 3)), ("_quats", (N, 4)), ("_rgbs", (N, 3)))}
+    assert f["_opacities"].shape == (N, 1) and f["_quats"].dim() == 2 and f["_rgbs"].dtype == torch.float32 and len(f["_means"]) == N
+    cat = {k: torch.cat([v], dim=0) for k, v in f.items()}                      # base.py:365-366, one class
+    assert all(cat[k] is f[k] for k in f)
+    op = cat["_opacities"].squeeze()                                            # base.py:397
+    assert isinstance(op, LazyField) and op.shape == (N,)
+    assert lazy_source(cat["_means"], cat["_quats"], cat["_scales"], op, cat["_rgbs"]) is src
+    assert lazy_source(src.means, cat["_quats"], cat["_scales"], op, cat["_rgbs"]) is src
+    other = _src()
+    assert lazy_source(cat["_means"], LazyField(other, "_quats", (N, 4)), cat["_scales"], op, cat["_rgbs"]) is None
+    assert lazy_source(cat["_means"], cat["_quats"], cat["_scales"], torch.zeros(N), cat["_rgbs"]) is None
+
+
+def test_any_other_use_materialises_the_references_expression():
+    src = _src()
+    N = src.means.shape[0]
+    op = LazyField(src, "_opacities", (N, 1))
+    m = op.squeeze() * torch.ones(N)                                            # an opacity mask (scene_graph.py:296-313)
+    assert type(m) is torch.Tensor and m.requires_grad and torch.equal(m, torch.sigmoid(src.logits).squeeze())
+    q = LazyField(src, "_quats", (N, 4))
+    assert torch.equal(q.detach(), (src.quats / src.quats.norm(dim=-1, keepdim=True)).detach())
+    both = torch.cat([q, torch.ones(2, 4)], dim=0)                              # a second class's tensor next to it
+    assert type(both) is torch.Tensor and both.shape == (N + 2, 4)
+    s = materialised({"a": [LazyField(src, "_scales", (N, 3))]})["a"][0]
+    assert torch.equal(s, torch.exp(src.log_scales)) and s is src.materialise("_scales")      # (cached: one graph node per field)
+    assert materialised(LazyField(src, "_means", (N, 3))) is src.means
+    s.sum().backward()
+    assert src.log_scales.grad is not None
+
+
+def test_install_swaps_the_class_method_and_uninstall_restores_it():
+    p = Hn.synthetic_scene(50, seed=1)
+    model = Hn.VanillaModel(p)
+    eager = Hn.VanillaModel.__dict__["get_gaussians"]
+    M.install(Hn.VanillaModel)
+    try:
+        assert Hn.VanillaModel.get_gaussians is M.get_gaussians_lazy
+        cam = M.dataclass_camera(camtoworlds=torch.eye(4), camtoworlds_gt=torch.eye(4), Ks=torch.eye(3), H=8, W=8)
+        gs = model.get_gaussians(cam)
+        assert sorted(gs) == ["_means", "_opacities", "_quats", "_rgbs", "_scales"] and all(isinstance(v, LazyField) for v in gs.values())
+        assert gs["_opacities"].shape == (50, 1) and gs["_rgbs"].shape == (50, 3)
+        assert gs["_quats"]._src.sh_degree == 3 and model.filter_mask.all()
+        model.step = 1500                                                        # vanilla.py:387: degree = step // interval, capped
+        assert model.get_gaussians(cam)["_quats"]._src.sh_degree == 1
+    finally:
+        M.uninstall(Hn.VanillaModel)
+    assert Hn.VanillaModel.__dict__["get_gaussians"] is eager
