@@ -32,6 +32,29 @@ __device__ __forceinline__ int64_t list_length(int64_t n_cap, const uint64_t *__
   return n < n_cap ? n : n_cap;
 }
 
+// Row form of a view's projection outputs.  The five per-Gaussian arrays the projection leaves (means2d [N,2], depths [N], radii [N],
+// conics [N,3], activated opacities [N]) are gathered by the tile stage and the record pack for the VISIBLE Gaussians only -- one
+// partly used cache line per array and Gaussian.  A caller may hand them over as the COLUMNS of one [N,8] block of 32-byte rows
+// {m2d.x, m2d.y, depth, radius (int bits) | conic a, b, c, opacity}: no signature changes, the layout is recognised by the addresses
+// (depths == means2d + 2 can not hold for separate arrays of more than one row: they would overlap).  Strides in floats.
+struct ProjLayout {
+  int s2, sd, sc, so;   // means2d, depths, conics, opacities
+  int row_radius;       // gather the radius from the row (word 3) instead of the dense radii array
+};
+static inline ProjLayout proj_layout(const float *means2d, const float *depths, const float *conics, const float *opacities) {
+  ProjLayout p;
+  const bool rows = means2d != nullptr && depths == means2d + 2;
+  p.s2 = rows ? 8 : 2;
+  p.sd = rows ? 8 : 1;
+  p.row_radius = rows ? 1 : 0;
+  p.sc = (rows && conics == means2d + 4) ? 8 : 3;
+  p.so = (rows && opacities == means2d + 7) ? 8 : 1;      // (a caller may composite other opacities over the same rows: render_classes)
+  return p;
+}
+__device__ __forceinline__ int proj_radius(const ProjLayout &pl, const float *__restrict__ means2d, const int32_t *__restrict__ radii, int64_t o) {
+  return pl.row_radius ? __float_as_int(means2d[o * 8 + 3]) : radii[o];
+}
+
 // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8 (observed; used for L2 locality only).
 // Map a linear block id to a work item so that each XCD owns one contiguous range of items.
 __device__ __forceinline__ int xcd_contiguous(int bid, int total) {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     const float *__restrict__ logits, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
     float eps2d, float near_plane, float far_plane, float radius_clip, float *__restrict__ scales,
     float *__restrict__ opacities, int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
-    float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss) {
+    float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss, int rows) {
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   if (kReduce) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *rs.m_total = 0;
@@ -118,14 +118,21 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
         s[k] = expf(log_scales[g * 3 + k]);
         scales[g * 3 + k] = s[k];
       }
-      opacities[g] = 1.f / (1.f + expf(-logits[g]));
+      const float op = 1.f / (1.f + expf(-logits[g]));
+      opacities[g] = op;
       Camera cam = load_camera(viewmat, K);
       Proj p = project_one(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
       radius = p.radius;
       radii[g] = p.radius;
-      means2d[g * 2] = p.mx; means2d[g * 2 + 1] = p.my;
-      depths[g] = p.depth;
-      conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
+      if (rows) {      // (bds_common.h ProjLayout: one 32-byte row per Gaussian; radii / opacities stay dense arrays as well)
+        float4 *row = reinterpret_cast<float4 *>(means2d + g * 8);
+        row[0] = make_float4(p.mx, p.my, p.depth, __int_as_float(p.radius));
+        row[1] = make_float4(p.ca, p.cb, p.cc, op);
+      } else {
+        means2d[g * 2] = p.mx; means2d[g * 2 + 1] = p.my;
+        depths[g] = p.depth;
+        conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
+      }
       if (tiles_per_gauss) tiles_per_gauss[g] = 0;   // (the counting kernel writes the visible entries only)
     }
     const int cnt = __syncthreads_count(radius > 0);
@@ -141,13 +148,20 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     s[k] = expf(log_scales[g * 3 + k]);
     scales[g * 3 + k] = s[k];
   }
-  opacities[g] = 1.f / (1.f + expf(-logits[g]));
+  const float op = 1.f / (1.f + expf(-logits[g]));
+  opacities[g] = op;
   Camera cam = load_camera(viewmat, K);
   Proj p = project_one(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
   radii[g] = p.radius;
-  means2d[g * 2] = p.mx; means2d[g * 2 + 1] = p.my;
-  depths[g] = p.depth;
-  conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
+  if (rows) {
+    float4 *row = reinterpret_cast<float4 *>(means2d + g * 8);
+    row[0] = make_float4(p.mx, p.my, p.depth, __int_as_float(p.radius));
+    row[1] = make_float4(p.ca, p.cb, p.cc, op);
+  } else {
+    means2d[g * 2] = p.mx; means2d[g * 2 + 1] = p.my;
+    depths[g] = p.depth;
+    conics[g * 3] = p.ca; conics[g * 3 + 1] = p.cb; conics[g * 3 + 2] = p.cc;
+  }
 }
 
 // Block reduction of the camera-pose gradient (9 rotation + 3 translation partials per Gaussian): one 16-value
@@ -320,6 +334,14 @@ extern "C" int bds_project_bwd(int C, int64_t N, const float *means, const float
   return BDS_OK;
 }
 
+// the [N,8] row form of the projection outputs (bds_common.h ProjLayout): depths and conics are then columns of means2d's block
+static int view_rows(const float *means2d, const float *depths, const float *conics, int *rows) {
+  const bool a = depths == means2d + 2, b = conics == means2d + 4;
+  if (a != b || (a && !aligned16(means2d))) return BDS_EINVAL;
+  *rows = a ? 1 : 0;
+  return BDS_OK;
+}
+
 extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
                                     const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
                                     float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
@@ -328,9 +350,11 @@ extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *
   if (N == 0) return BDS_OK;
   BDS_REQUIRE(means && quats && log_scales && logits && viewmat && K && scales && opacities && radii && means2d && depths &&
               conics);
+  int rows = 0;
+  if (view_rows(means2d, depths, conics, &rows) != BDS_OK) return BDS_EINVAL;
   hipLaunchKernelGGL(project_view_fwd_kernel<false>, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
                      means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
-                     opacities, radii, means2d, depths, conics, PrepReduceSlots{}, static_cast<int32_t *>(nullptr));
+                     opacities, radii, means2d, depths, conics, PrepReduceSlots{}, static_cast<int32_t *>(nullptr), rows);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
@@ -347,9 +371,11 @@ extern "C" int bds_project_view_prepare_fwd(int64_t N, const float *means, const
   PrepReduceSlots rs;
   int rc = prep_reduce_slots(prep_ws, prep_ws_bytes, N, &rs);
   if (rc != BDS_OK) return rc;
+  int rows = 0;
+  if (view_rows(means2d, depths, conics, &rows) != BDS_OK) return BDS_EINVAL;
   hipLaunchKernelGGL(project_view_fwd_kernel<true>, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
                      means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
-                     opacities, radii, means2d, depths, conics, rs, tiles_per_gauss);
+                     opacities, radii, means2d, depths, conics, rs, tiles_per_gauss, rows);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
                                                                   const float *__restrict__ opacities, const int32_t *__restrict__ radii,
                                                                   float4 *__restrict__ rec, float *__restrict__ sh_rgb_out,
                                                                   float4 *__restrict__ zero_rec, float4 *__restrict__ zero_tail,
-                                                                  int zero_tail_f4, int32_t *__restrict__ schedule) {
+                                                                  int zero_tail_f4, int32_t *__restrict__ schedule, const ProjLayout pl) {
   constexpr int nb = (DEG + 1) * (DEG + 1);
   constexpr int n4 = (nb * 3 + 3) / 4;       // 16-byte pieces of a coefficient row the colour needs
   constexpr int ldr = n4 * 4 + 4;            // LDS row stride (floats): 16-byte aligned, an odd number of 16-byte pieces
@@ -201,11 +201,12 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
     o2 += B[k] * cf[k * 3 + 2];
   }
   sh_rgb_out[r * 3] = o0; sh_rgb_out[r * 3 + 1] = o1; sh_rgb_out[r * 3 + 2] = o2;
-  const float2 xy = *reinterpret_cast<const float2 *>(means2d + g * 2);
-  const float *cn = conics + g * 3;
+  // (the projection's outputs: five arrays, or the columns of one [N,8] row block -- bds_common.h ProjLayout)
+  const float2 xy = *reinterpret_cast<const float2 *>(means2d + g * pl.s2);
+  const float *cn = conics + g * pl.sc;
   rec[r * 3] = make_float4(xy.x, xy.y, (-0.5f * kLog2e) * cn[0], -kLog2e * cn[1]);
-  rec[r * 3 + 1] = make_float4((-0.5f * kLog2e) * cn[2], opacities[g], fminf(fmaxf(o0 + 0.5f, 0.f), 1.f), fminf(fmaxf(o1 + 0.5f, 0.f), 1.f));
-  rec[r * 3 + 2] = make_float4(fminf(fmaxf(o2 + 0.5f, 0.f), 1.f), depths[g], 0.f, __int_as_float(radii[g]));
+  rec[r * 3 + 1] = make_float4((-0.5f * kLog2e) * cn[2], opacities[g * pl.so], fminf(fmaxf(o0 + 0.5f, 0.f), 1.f), fminf(fmaxf(o1 + 0.5f, 0.f), 1.f));
+  rec[r * 3 + 2] = make_float4(fminf(fmaxf(o2 + 0.5f, 0.f), 1.f), depths[g * pl.sd], 0.f, __int_as_float(proj_radius(pl, means2d, radii, g)));
 }
 
 // exponent (base 2) of a Gaussian at a pixel of the lane's column: ea dx^2 + (ec dy + eb dx) dy, <= 0 for a valid conic.
@@ -971,10 +972,11 @@ static int splat_pack_sh_impl(int64_t n, const uint64_t *n_dev, const int32_t *i
   float4 *zr = reinterpret_cast<float4 *>(zero_records), *zt = reinterpret_cast<float4 *>(zero_tail);
   const int zt4 = (int)(zero_tail_floats / 4);
   hipStream_t st = as_stream(stream);
+  const ProjLayout pl = proj_layout(means2d, depths, conics, opacities);
 #define BDS_PACK_SH(d)                                                                                                                 \
   hipLaunchKernelGGL((splat_pack_sh_kernel<d>), grid, block, sizeof(float) * kPackShBlock * ((((d + 1) * (d + 1) * 3 + 3) / 4) * 4 + 4), st, \
                      n, n_dev, ids, K, means, cam_pos, coeffs, coeffs_rest, means2d, conics, depths, \
-                     opacities, radii, rec, sh_rgb, zr, zt, zt4, schedule)
+                     opacities, radii, rec, sh_rgb, zr, zt, zt4, schedule, pl)
   switch (deg) {
     case 0: BDS_PACK_SH(0); break;
     case 1: BDS_PACK_SH(1); break;

@@ -785,11 +785,11 @@ __global__ __launch_bounds__(kIsectBlock) void isect_compact_kernel(int64_t CN, 
                                                                    const uint32_t *__restrict__ pos,
                                                                    const float *__restrict__ depths,
                                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                                   uint32_t *__restrict__ asc, int compact) {
+                                                                   uint32_t *__restrict__ asc, int compact, int sd) {
   const int64_t o = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (o >= CN || radii[o] <= 0) return;
   const uint32_t j = pos[o];
-  keys[j] = __float_as_uint(depths[o]);
+  keys[j] = __float_as_uint(depths[o * sd]);
   vals[j] = compact ? j : (uint32_t)o;   // compact mode: the sort carries the entry's position in the ascending visible list
   asc[j] = (uint32_t)o;
 }
@@ -827,7 +827,8 @@ struct VisCompactSh {
 };
 __device__ __forceinline__ void visible_compact_block(VisCompactSh &sh, int vb, int nvb, int64_t CN, const int32_t *radii, const float *depths,
                                                       const uint32_t *tile_sums, uint32_t *keys, uint32_t *vals, uint32_t *hist,
-                                                      uint32_t *ghist, uint64_t *n_vis_out, uint32_t *asc, int compact, int sums_per_tile) {
+                                                      uint32_t *ghist, uint64_t *n_vis_out, uint32_t *asc, int compact, int sums_per_tile,
+                                                      int sd) {
   constexpr int kSpan = kCompactSpan;
   uint32_t *lw = sh.lw;
   auto &h = sh.h;
@@ -852,7 +853,7 @@ __device__ __forceinline__ void visible_compact_block(VisCompactSh &sh, int vb, 
 #pragma unroll
   for (int i = 0; i < kScanItems; i++) {
     if (vis[i]) {
-      const uint32_t key = __float_as_uint(depths[base + i]);
+      const uint32_t key = __float_as_uint(depths[(base + i) * sd]);
       keys[j] = key;
       vals[j] = compact ? j : (uint32_t)(base + i);
       asc[j] = (uint32_t)(base + i);
@@ -877,10 +878,10 @@ __global__ __launch_bounds__(kScanBlock) void visible_compact_kernel(int64_t CN,
                                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                     uint32_t *__restrict__ hist, uint32_t *__restrict__ ghist,
                                                                     uint64_t *__restrict__ n_vis_out, uint32_t *__restrict__ asc,
-                                                                    int compact, int sums_per_tile) {
+                                                                    int compact, int sums_per_tile, int sd) {
   __shared__ VisCompactSh sh;
   visible_compact_block(sh, (int)blockIdx.x, (int)gridDim.x, CN, radii, depths, tile_sums, keys, vals, hist, ghist, n_vis_out, asc, compact,
-                        sums_per_tile);
+                        sums_per_tile, sd);
 }
 
 // ---- row-parallel counting / emission ---------------------------------------------------------------------
@@ -911,7 +912,7 @@ __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t 
                                                const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                const float *__restrict__ conics, const float *__restrict__ opacities,
                                                int tile_size, int tile_w, int tile_h, float4 *__restrict__ rec_out,
-                                               const float4 *__restrict__ rec_in) {
+                                               const float4 *__restrict__ rec_in, const ProjLayout pl) {
   const int t = threadIdx.x;
   const int64_t j = j0 + t;
   uint32_t nrows = 0;
@@ -927,12 +928,12 @@ __device__ __forceinline__ uint32_t stage_rows(RowStage &S, int64_t j0, int64_t 
       const uint32_t o = asc ? asc[val] : val;
       // every gather of this member is issued before the first one is consumed (the entries of the list ARE visible: testing the
       // radius first would only put one more memory latency in front of the others)
-      const int r = radii[o];
-      float mx = means2d[(int64_t)o * 2], my = means2d[(int64_t)o * 2 + 1];
+      const int r = proj_radius(pl, means2d, radii, (int64_t)o);
+      float mx = means2d[(int64_t)o * pl.s2], my = means2d[(int64_t)o * pl.s2 + 1];
       float a = 0.f, b = 0.f, c = 0.f, q_max = 0.f, op = 0.f;
       if (conics != nullptr) {
-        a = conics[(int64_t)o * 3]; b = conics[(int64_t)o * 3 + 1]; c = conics[(int64_t)o * 3 + 2];
-        op = opacities[o];
+        a = conics[(int64_t)o * pl.sc]; b = conics[(int64_t)o * pl.sc + 1]; c = conics[(int64_t)o * pl.sc + 2];
+        op = opacities[(int64_t)o * pl.so];
       }
       int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
       if (r > 0) {
@@ -989,7 +990,7 @@ struct CountRowsSh {
 __device__ __forceinline__ void isect_count_rows_block(CountRowsSh &sh, int vb, int64_t n_vis, const uint32_t *sorted_idx, const float *means2d,
                                                        const int32_t *radii, const float *conics, const float *opacities, int tile_size,
                                                        int tile_w, int tile_h, int32_t *tiles_per_gauss, int64_t N, float4 *rec,
-                                                       uint32_t *btot, const uint32_t *asc) {
+                                                       uint32_t *btot, const uint32_t *asc, const ProjLayout pl) {
   RowStage &S = sh.S;
   uint32_t *cnt = sh.cnt;
   const int64_t j0 = (int64_t)vb * kIsectBlock, j = j0 + threadIdx.x;
@@ -998,7 +999,7 @@ __device__ __forceinline__ void isect_count_rows_block(CountRowsSh &sh, int vb, 
     return;
   }
   cnt[threadIdx.x] = 0u;
-  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, asc, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, rec, nullptr);
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, asc, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, rec, nullptr, pl);
   const bool cull = conics != nullptr;
   for (uint32_t r = threadIdx.x; r < R; r += kIsectBlock) {
     const int g = row_owner(S, r);
@@ -1018,10 +1019,10 @@ __global__ __launch_bounds__(kIsectBlock) void isect_count_rows_kernel(
     const uint64_t *__restrict__ n_vis_dev, int64_t n_cap, const uint32_t *__restrict__ sorted_idx, const float *__restrict__ means2d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ opacities, int tile_size,
     int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int64_t N, float4 *__restrict__ rec, uint32_t *__restrict__ btot,
-    const uint32_t *__restrict__ asc) {
+    const uint32_t *__restrict__ asc, const ProjLayout pl) {
   __shared__ CountRowsSh sh;
   isect_count_rows_block(sh, (int)blockIdx.x, bounded_count(n_vis_dev, n_cap), sorted_idx, means2d, radii, conics, opacities, tile_size, tile_w, tile_h,
-                         tiles_per_gauss, N, rec, btot, asc);
+                         tiles_per_gauss, N, rec, btot, asc, pl);
 }
 
 struct EmitRowsSh { RowStage S; };
@@ -1032,7 +1033,8 @@ __device__ __forceinline__ void isect_emit_rows_block(EmitRowsSh &sh, int vb, in
   RowStage &S = sh.S;
   const int64_t j0 = (int64_t)vb * kIsectBlock;
   if (j0 >= n_vis) return;
-  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, nullptr, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec);
+  const uint32_t R = stage_rows(S, j0, n_vis, N, sorted_idx, nullptr, means2d, radii, conics, opacities, tile_size, tile_w, tile_h, nullptr, rec,
+                                ProjLayout{2, 1, 3, 1, 0});   // (records only: nothing is gathered here)
   const bool cull = conics != nullptr;
   // output offset of the workgroup's first row = intersections of all groups in front of it (no scan launch: <= a few
   // thousand L2-resident totals are summed here)
@@ -1099,10 +1101,10 @@ __global__ __launch_bounds__(kIsectBlock) void isect_offsets_kernel(int64_t M_ho
 __global__ __launch_bounds__(kIsectBlock) void isect_ids_kernel(int64_t M, const uint32_t *__restrict__ keys, int key_shift,
                                                                const int32_t *__restrict__ flatten_ids,
                                                                const float *__restrict__ depths,
-                                                               int64_t *__restrict__ isect_ids) {
+                                                               int64_t *__restrict__ isect_ids, int sd) {
   const int64_t i = (int64_t)blockIdx.x * kIsectBlock + threadIdx.x;
   if (i >= M) return;
-  const uint32_t d = __float_as_uint(depths[flatten_ids[i]]);
+  const uint32_t d = __float_as_uint(depths[(int64_t)flatten_ids[i] * sd]);
   isect_ids[i] = (int64_t)(((uint64_t)(keys[i] >> key_shift) << 32) | (uint64_t)d);
 }
 
@@ -1256,6 +1258,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
   if (CN == 0) return BDS_OK;
   BDS_REQUIRE(means2d && radii && depths && ws);
   BDS_REQUIRE((conics == nullptr) == (opacities == nullptr));
+  const ProjLayout pl = proj_layout(means2d, depths, conics, opacities);   // (the [N,8] row form is recognised by the addresses)
   PrepWs L = prep_layout(ws, CN);
   if (ws_bytes < L.bytes) return BDS_EWORKSPACE;
   hipStream_t st = as_stream(stream);
@@ -1280,7 +1283,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
       hipLaunchKernelGGL(visible_reduce_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, L.temp, L.tables,
                          (int64_t)short_sort_elems(CN), L.total, tiles_per_gauss);
     hipLaunchKernelGGL(visible_compact_kernel, dim3(tiles), dim3(kScanBlock), 0, st, CN, radii, depths, L.temp, L.ka, L.va, hist,
-                       ghist, n_vis, L.asc, compact & 1, (compact & 2) ? kScanTile / 256 : 1);
+                       ghist, n_vis, L.asc, compact & 1, (compact & 2) ? kScanTile / 256 : 1, pl.sd);
     BDS_LAUNCH_CHECK();
     // 2. depth order: 4 stable passes of 8 bits; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
@@ -1297,7 +1300,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     // 3. tiles per entry, in depth order (tiles_per_gauss was zeroed by visible_reduce_kernel)
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, n_vis, n_cap, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, N, L.rec, L.btot,
-                       (compact & 1) ? L.asc : (const uint32_t *)nullptr);
+                       (compact & 1) ? L.asc : (const uint32_t *)nullptr, pl);
     BDS_LAUNCH_CHECK();
   } else {
     BDS_REQUIRE(!(compact & 2));   // (the pre-reduced form exists for the short path only)
@@ -1307,7 +1310,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     BDS_LAUNCH_CHECK();
     rc = exclusive_scan_u32(L.kb, L.cum, CN, L.temp, n_vis, st);
     if (rc != BDS_OK) return rc;
-    hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va, L.asc, compact);
+    hipLaunchKernelGGL(isect_compact_kernel, dim3(grid), dim3(kIsectBlock), 0, st, CN, radii, L.cum, depths, L.ka, L.va, L.asc, compact, pl.sd);
     BDS_LAUNCH_CHECK();
     // 2. depth order: 4 stable passes of 8 bits over the visible entries; ends in (ka, va)
     uint32_t *kin = L.ka, *vin = L.va, *kout = L.kb, *vout = L.vb;
@@ -1322,7 +1325,7 @@ static int prepare_enqueue(int C, int64_t N, const float *means2d, const int32_t
     if (tiles_per_gauss && hipMemsetAsync(tiles_per_gauss, 0, sizeof(int32_t) * CN, st) != hipSuccess) return BDS_ELAUNCH;
     hipLaunchKernelGGL(isect_count_rows_kernel, dim3(grid), dim3(kIsectBlock), 0, st, n_vis, (int64_t)-1, L.va, means2d, radii, conics,
                        opacities, tile_size, tile_w, tile_h, tiles_per_gauss, N, L.rec, L.btot,
-                       compact ? L.asc : (const uint32_t *)nullptr);
+                       compact ? L.asc : (const uint32_t *)nullptr, pl);
     BDS_LAUNCH_CHECK();
   }
   // 4. (no scan: every counting kernel leaves the per-256-member totals and adds them to M; the emission derives its offsets)
@@ -1439,6 +1442,7 @@ static int isect_build_impl(int C, int64_t N, int64_t M, int64_t n_visible, cons
     return BDS_OK;
   }
   BDS_REQUIRE(means2d && radii && depths && ws && ws2 && flatten_ids);
+  const ProjLayout pl = proj_layout(means2d, depths, conics, opacities);
   PrepWs P = prep_layout(const_cast<void *>(ws), CN);
   if (ws_bytes < P.bytes) return BDS_EWORKSPACE;
   const uint64_t *const M_dev = dev ? P.total + kCountMEff : nullptr;
@@ -1519,7 +1523,7 @@ static int isect_build_impl(int C, int64_t N, int64_t M, int64_t n_visible, cons
   }
   if (isect_ids) {
     hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)cdiv(M, kIsectBlock)), dim3(kIsectBlock), 0, st, M, kin, key_shift,
-                       flatten_ids, depths, isect_ids);
+                       flatten_ids, depths, isect_ids, pl.sd);
     BDS_LAUNCH_CHECK();
   }
   return BDS_OK;

@@ -37,6 +37,14 @@ SH_IN_PACK = os.environ.get("BDS_SH_IN_PACK", "0") == "1"
 SH_IN_PACK_DEV = os.environ.get("BDS_SH_IN_PACK_DEV", "1") == "1"
 
 
+_PROJ_ROWS = os.environ.get("BDS_PROJ_ROWS", "1") == "1"   # (A/B: 0 = the projection's outputs as five separate arrays)
+
+
+def _dp(t):
+    """Device address of a tensor that may be a COLUMN of the projection's row block (fused_view._front_begin); None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
 def _empty(shape, dev, dtype=torch.float32):
     return torch.empty(shape, device=dev, dtype=dtype)
 
@@ -198,7 +206,16 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     # activations (vanilla.py:393-394) + projection (C = 1)
     scales, opac = _empty((N, 3), dev), _empty((N,), dev)
     radii = _empty((1, N), dev, torch.int32)
-    means2d, depths, conics = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev)
+    caps = cfg.get("caps")                 # ListCapacity: the device-count form (no host wait in this view)
+    in_pack = cfg.get("sh_in_pack", SH_IN_PACK if caps is None else SH_IN_PACK_DEV)
+    pack_colours = sh_rest is not None or (in_pack and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0)
+    if pack_colours and _PROJ_ROWS and N > 0:
+        # the projection's outputs as the columns of ONE [N,8] block of 32-byte rows (csrc/bds_common.h ProjLayout): the tile stage
+        # and the record pack gather one line per visible Gaussian instead of one per array; radii / opacities stay dense as well
+        rows = _empty((N, 8), dev)
+        means2d, depths, conics, opac_row = rows[None, :, 0:2], rows[None, :, 2], rows[None, :, 4:7], rows[:, 7]
+    else:
+        means2d, depths, conics, opac_row = _empty((1, N, 2), dev), _empty((1, N), dev), _empty((1, N, 3), dev), opac
     tiles_per_gauss = _empty((1, N), dev, torch.int32)
     ws_bytes = lib.bds_isect_prepare_workspace_bytes(1, N)
     ws = cfg.get("prep_ws")   # a caller-owned prepare workspace (graph_view: the lists and their counts outlive the view)
@@ -211,7 +228,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
         if cfg.get("caps") is not None and _PROJECT_PREPARES and N > 0:
             rc = lib.bds_project_view_prepare_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
                                                   L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
-                                                  L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
+                                                  L.ptr(scales), L.ptr(opac), L.ptr(radii), _dp(means2d), _dp(depths), _dp(conics),
                                                   L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, st)
             pre_reduced = rc == L.BDS_OK
             if rc not in (L.BDS_OK, L.BDS_ECAPACITY):     # (ECAPACITY: N beyond the short sort path -- the plain projection below)
@@ -219,34 +236,31 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
         if not pre_reduced:
             L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
                                              L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
-                                             L.ptr(scales), L.ptr(opac), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), st),
+                                             L.ptr(scales), L.ptr(opac), L.ptr(radii), _dp(means2d), _dp(depths), _dp(conics), st),
                     "bds_project_view_fwd")
     # tile ordering
     LT = cfg.get("list_tile", LIST_TILE)
     tw, th = math.ceil(W / LT), math.ceil(H / LT)      # list tiles
     cull = cfg["tile_cull"]
-    opac_c = opac.view(1, N)
     isect_offsets = _empty((1, th, tw), dev, torch.int32)
-    cptr, optr = (L.ptr(conics), L.ptr(opac_c)) if cull else (None, None)
-    caps = cfg.get("caps")                 # ListCapacity: the device-count form (no host wait in this view)
+    cptr, optr = (_dp(conics), _dp(opac_row)) if cull else (None, None)
     if caps is not None:
         counts, ev = caps.counts, None
         _tile_stage_options()
         with L.timed("isect_prepare"):
-            L.check(lib.bds_isect_prepare_dev(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
+            L.check(lib.bds_isect_prepare_dev(1, N, _dp(means2d), L.ptr(radii), _dp(depths), cptr, optr, LT, tw, th,
                                               L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, caps.m_cap, caps.nvis_cap,
                                               counts.data_ptr(), 3 if pre_reduced else 1, st), "bds_isect_prepare_dev")
     else:
         counts, ev = _host_sync_objects(dev)
         with L.timed("isect_prepare"):
-            L.check(lib.bds_isect_prepare_async(1, N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), cptr, optr, LT, tw, th,
+            L.check(lib.bds_isect_prepare_async(1, N, _dp(means2d), L.ptr(radii), _dp(depths), cptr, optr, LT, tw, th,
                                                 L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, counts.data_ptr(), ev.cuda_event, 1, st),
                     "bds_isect_prepare_async")
     # While the host waits for the two counts, the GPU evaluates the SH colours (vanilla.py:384-389), which do not
     # depend on the lists; the list buffers are provisioned beforehand from the largest count seen so far.
     cam_pos = cfg["cam_pos"].contiguous()
-    in_pack = cfg.get("sh_in_pack", SH_IN_PACK if caps is None else SH_IN_PACK_DEV)
-    if sh_rest is not None or (in_pack and (K * 3) % 4 == 0 and sh.data_ptr() % 16 == 0):
+    if pack_colours:
         sh_rgb, colors = None, None        # evaluated by the record pack, for the visible Gaussians only (_composite)
     else:
         sh_rgb, colors = _empty((N, 3), dev), _empty((1, N, 4), dev)
@@ -271,6 +285,7 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     f.means, f.quats, f.log_scales, f.sh, f.viewmat, f.cam_pos = means, quats, log_scales, sh, viewmat, cam_pos
     f.sh_rest, f.K = sh_rest, K
     f.scales, f.opac, f.radii, f.means2d, f.depths, f.conics = scales, opac, radii, means2d, depths, conics
+    f.opac_row = opac_row      # (the activated opacities where the tile stage / the pack read them: the rows' column, or `opac` itself)
     f.sh_rgb, f.colors, f.sh_by_rank, f.sh_degree = sh_rgb, colors, False, cfg["sh_degree"]
     f.tiles_per_gauss, f.isect_offsets, f.ws, f.ws_bytes, f.cull = tiles_per_gauss, isect_offsets, ws, ws_bytes, cull
     f.counts, f.ev, f.key, f.cap, f.vcap, f.caps = counts, ev, key, cap, vcap, caps
@@ -285,7 +300,7 @@ def _front_finish(f: _Front, before_wait=None) -> _Front:
     """Second half: the one host wait of a view (list counts), then the per-tile lists."""
     lib, st = L.lib(), L.stream()
     dev, N = f.means.device, f.N
-    cptr, optr = (L.ptr(f.conics), L.ptr(f.opac.view(1, N))) if f.cull else (None, None)
+    cptr, optr = (_dp(f.conics), _dp(f.opac_row)) if f.cull else (None, None)
     f.pre = before_wait() if before_wait is not None else None
     if f.caps is not None:
         return _front_finish_dev(f)
@@ -306,7 +321,7 @@ def _front_finish(f: _Front, before_wait=None) -> _Front:
     # order).  Read in place from the prepare workspace (which this view keeps alive): no copy node between the kernels.
     f.vis_ids = f.ws[f.ids_offset:f.ids_offset + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile, f.list_tw,
+        L.check(lib.bds_isect_build(1, N, M, n_vis, _dp(f.means2d), L.ptr(f.radii), _dp(f.depths), cptr, optr, f.list_tile, f.list_tw,
                                     f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(ws2), ws2_bytes, None, L.ptr(f.flatten),
                                     L.ptr(f.isect_offsets), None, 1, st), "bds_isect_build")
     if M + M // 16 > f.cap:
@@ -322,12 +337,12 @@ def _front_finish_dev(f: _Front) -> _Front:
     reads the two EFFECTIVE counts from the first words of the prepare workspace (f.m_dev / f.nvis_dev: device addresses)."""
     lib, st = L.lib(), L.stream()
     N = f.N
-    cptr, optr = (L.ptr(f.conics), L.ptr(f.opac.view(1, N))) if f.cull else (None, None)
+    cptr, optr = (_dp(f.conics), _dp(f.opac_row)) if f.cull else (None, None)
     M, n_vis = f.caps.m_cap, f.caps.nvis_cap
     f.flatten = f.buf
     f.vis_ids = f.ws[f.ids_offset:f.ids_offset + 4 * n_vis].view(torch.int32)
     with L.timed("isect_build"):
-        L.check(lib.bds_isect_build_dev(1, N, M, n_vis, L.ptr(f.means2d), L.ptr(f.radii), L.ptr(f.depths), cptr, optr, f.list_tile,
+        L.check(lib.bds_isect_build_dev(1, N, M, n_vis, _dp(f.means2d), L.ptr(f.radii), _dp(f.depths), cptr, optr, f.list_tile,
                                         f.list_tw, f.list_th, L.ptr(f.ws), f.ws_bytes, L.ptr(f.ws2), f.ws2_bytes, L.ptr(f.flatten),
                                         L.ptr(f.isect_offsets), 1, st), "bds_isect_build_dev")
     if f.colors is not None and os.environ.get("BDS_SH_BEFORE_BUILD") != "1":
@@ -353,6 +368,8 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
     lib, st = L.lib(), L.stream()
     dev = opac.device
     n_vis, M, W, H = f.n_vis, f.M, f.W, f.H
+    if opac is f.opac:          # (the view's own opacities: read from the rows; a masked copy -- render_classes -- is a dense array)
+        opac = f.opac_row
     if f.m_dev is not None:
         if f.rec_buf is not None:
             rec, f.rec_buf = f.rec_buf[:n_vis], None
@@ -365,8 +382,8 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
             if f.colors is None:   # SH colours evaluated by the pack (visible Gaussians only); un-clamped values kept in list order
                 f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
                 L.check(lib.bds_splat_pack_sh_dev(n_vis, f.nvis_dev, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means),
-                                                  L.ptr(f.cam_pos), L.ptr(f.sh), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths),
-                                                  L.ptr(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), L.ptr(zr), L.ptr(tail),
+                                                  L.ptr(f.cam_pos), L.ptr(f.sh), _dp(f.means2d), _dp(f.conics), _dp(f.depths),
+                                                  _dp(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), L.ptr(zr), L.ptr(tail),
                                                   0 if tail is None else tail.numel(), L.ptr(tile_order), st), "bds_splat_pack_sh_dev")
             else:
                 L.check(lib.bds_splat_pack_dev(n_vis, f.nvis_dev, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors),
@@ -388,11 +405,11 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
             f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
             if f.sh_rest is not None:
                 L.check(lib.bds_splat_pack_sh_split(n_vis, L.ptr(f.vis_ids), f.K, f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos), L.ptr(f.sh),
-                                                    L.ptr(f.sh_rest), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths), L.ptr(opac),
+                                                    L.ptr(f.sh_rest), _dp(f.means2d), _dp(f.conics), _dp(f.depths), _dp(opac),
                                                     L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), st), "bds_splat_pack_sh_split")
             else:
                 L.check(lib.bds_splat_pack_sh(n_vis, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means), L.ptr(f.cam_pos),
-                                              L.ptr(f.sh), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.depths), L.ptr(opac), L.ptr(f.radii),
+                                              L.ptr(f.sh), _dp(f.means2d), _dp(f.conics), _dp(f.depths), _dp(opac), L.ptr(f.radii),
                                               L.ptr(rec), L.ptr(f.sh_rgb), st), "bds_splat_pack_sh")
         else:
             L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac),
