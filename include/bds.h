@@ -322,6 +322,12 @@ int bds_l1_tv_train(int64_t n, const float *a, const float *b, int nlevels, cons
  *   sh_view: view direction = means - cam_pos (vanilla.py:384, detached), visibility = radii > 0, output packed for
  *     the RGB+ED compositor as colors [N,4] = (clamp(sh + 0.5, 0, 1), depth) (vanilla.py:389); sh_rgb [N,3] keeps the
  *     un-clamped value for the backward. */
+/* ROW FORM of the projection's outputs (optional, recognised by the addresses -- no argument says so): means2d, depths and conics may
+ * be the COLUMNS of one 16-byte aligned [N,8] block of 32-byte rows {m2d.x, m2d.y, depth, radius (int bits) | conic a, b, c, opacity}:
+ * pass means2d = block, depths = block + 2, conics = block + 4 (both or neither; separate arrays of more than one row can not have
+ * these addresses).  bds_project_view_fwd / _prepare_fwd then write whole rows (radii [N] and opacities [N] are written as dense
+ * arrays as well), and bds_isect_prepare* / bds_isect_build* / bds_splat_pack_sh* given the same three pointers (and opacities =
+ * block + 7, or any dense [N] array of other opacities) gather ONE line per visible Gaussian instead of one per array. */
 int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales, const float *logits,
                          const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane,
                          float far_plane, float radius_clip, float *scales, float *opacities, int32_t *radii,

@@ -77,3 +77,33 @@ def test_launch_forms_give_identical_lists(mods, options, W, H, N):
                 assert torch.equal(out["rgb"], ref["rgb"]) and torch.equal(out["depth"], ref["depth"]), (cap_launch, groups, rep)
             seen.append((cap_launch, groups))
         assert len(seen) == 2
+
+
+@pytest.mark.parametrize("device_counts", [False, True])
+def test_row_form_of_the_projection_outputs_changes_nothing(mods, monkeypatch, device_counts):
+    """include/bds.h "ROW FORM": means2d / depths / conics / opacities as the columns of one [N,8] block (recognised by the addresses)
+    against five separate arrays -- lists, counts, images and gradients bit for bit (the same values from other addresses)."""
+    L, FV, GV, Hn = mods
+    res = {}
+    for rows in (False, True):
+        monkeypatch.setattr(FV, "_PROJ_ROWS", rows)
+        cam, p, grids, sky, target = _scene(Hn, 90000, 1280, 832, 5)
+        caps = None
+        if device_counts:
+            with torch.no_grad():
+                ref = Hn.render_view(p, cam, grids, 0, sky)
+            caps = FV.ListCapacity(int(ref["info"]["n_isects"] * 1.3) + 100, int(ref["info"]["n_visible"] * 1.3) + 100)
+        out = Hn.render_view(p, cam, grids, 0, sky, caps=caps)
+        assert out["info"]["means2d"].is_contiguous() != rows          # (the row form really is what ran)
+        Hn.training_loss(out, target, grids).backward()
+        torch.cuda.synchronize()
+        M, nv = (caps.observed() if device_counts else (out["info"]["n_isects"], out["info"]["n_visible"]))
+        res[rows] = (_lists(out, M, nv), out["rgb"].detach().clone(), out["depth"].detach().clone(), out["info"]["means2d"].detach().clone(),
+                     [p[k].grad.clone() for k in sorted(p)], cam.viewmat.grad.clone())
+    a, b = res[False], res[True]
+    for x, y, name in zip(a[0], b[0], ("flatten_ranks", "visible_ids", "isect_offsets", "tiles_per_gauss")):
+        assert torch.equal(x, y), name
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for x, y, k in zip(a[4], b[4], sorted(res[True][4] and ["log_scales", "means", "opacity_logits", "quats", "sh"])):
+        assert (x - y).abs().max() <= 1e-6 * max(1.0, float(y.abs().max())), k       # (atomics in the compositor's backward: order only)
+    assert (a[5] - b[5]).abs().max() <= 1e-5 * max(1.0, float(b[5].abs().max()))
