@@ -133,8 +133,8 @@ struct PrepReduceSlots {
 int prep_reduce_slots(void *ws, size_t ws_bytes, int64_t CN, PrepReduceSlots *out);   // BDS_OK, or why the short path does not apply
 
 // test hooks (bds_set_option): force the large-input fallback paths of the tile stage; see include/bds.h
-enum Option { kOptCapLaunch = 0 /* device-count tile stage: launches sized by the visible-entry capacity instead of C*N */, kOptPadBwd = 1 /* tuning: KB of unused LDS per workgroup of the compositor backward */, kOptPadFwd = 2 /* ... forward */,
-              kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptPacked = 6,
+enum Option { kOptCapLaunch = 0 /* device-count tile stage: launches sized by the visible-entry capacity instead of C*N */, 
+              /* (1, 2: retired -- LDS padding of the compositors, measured in rounds 3 and 5, profiles/NOTES.md) */ kOptDebug = 3 /* profiling only: ablation mask */, kOptShortSort = 4, kOptPacked = 6,
               kOptCells = 7 /* bilateral transform, bit 0: cell-aligned kernels where a level qualifies, bit 1: one-pass pyramid forward; 0 = general kernels */,
               kOptSchedBins = 8 /* device-count form: the forward compositor bins the backward's schedule itself (no sort launch) */, kOptCount = 9 };
 int option_get(int which);

@@ -1043,11 +1043,8 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-  // (tuning hook: unused dynamic LDS per workgroup caps the resident waves of this VALU-bound kernel, which leaves wave slots to the
-  // kernels of a concurrent stream: bds_set_option(2, KB))
-  const size_t pad_fwd = (size_t)option_get(kOptPadFwd) * 1024u;
 #define BDS_FWD(ch, co)                                                                                                              \
-  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), pad_fwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
+  hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
                      tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work)
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
@@ -1057,7 +1054,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
       const int total = tile_w * tile_h, cap = split_cap < total ? split_cap : total;
       int32_t *area = tile_work + split_area_offset(total);
       hipLaunchKernelGGL(long_tiles_kernel, dim3(1), dim3(kLongBlock), 0, st, isect_offsets, lg, M, M_dev, tile_w, tile_h, split_len, cap, area);
-      hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3((unsigned)(4 * cap + total)), dim3(kWave), pad_fwd, st, C, M, M_dev, rec,
+      hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3((unsigned)(4 * cap + total)), dim3(kWave), 0, st, C, M, M_dev, rec,
                          backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, area, cap);
     } else BDS_FWD(4, true);
   } else {
@@ -1126,11 +1123,10 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   const dim3 grid((unsigned)(C * tile_w * tile_h));
   hipStream_t st = as_stream(stream);
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-  const size_t pad_bwd = (size_t)option_get(kOptPadBwd) * 1024u;   // (see bds_rasterize_fwd: bds_set_option(1, KB))
   if (epi) {   // one camera, RGB+ED, no backgrounds: the colour transform's deferred epilogue runs in the kernel's prologue
     BDS_REQUIRE(C == 1 && CH == 4 && backgrounds == nullptr);
 #define BDS_BWD_EPI(ab, co)                                                                                                              \
-  hipLaunchKernelGGL((rasterize_bwd_epi_kernel<ab, co>), grid, dim3(kWave), pad_bwd, st, M, M_dev, rec, W, H, tile_w, tile_h, isect_offsets, \
+  hipLaunchKernelGGL((rasterize_bwd_epi_kernel<ab, co>), grid, dim3(kWave), 0, st, M, M_dev, rec, W, H, tile_w, tile_h, isect_offsets, \
                      flatten, alphas, last_ids, v_records, tile_order, lg, *epi)
     if (absgrad) { if (lg.div > 1) BDS_BWD_EPI(true, true); else BDS_BWD_EPI(true, false); }
     else         { if (lg.div > 1) BDS_BWD_EPI(false, true); else BDS_BWD_EPI(false, false); }
@@ -1141,7 +1137,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   // (kStrip = false: measured on the benchmark scene, skipping untouched 16 x 4 strips costs the backward 3 % -- its per-pixel
   // body is long enough that the extra control flow outweighs the ~19 % of strips it would skip; the forward gains 7 %)
 #define BDS_BWD(ch, ab, co)                                                                                                                 \
-  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
+  hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
                      tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg)
 #define BDS_BWD_CH(ab, co)            \
   do {                                \
@@ -1155,10 +1151,10 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     const int32_t *area = tile_order + split_area_offset(total);
     const dim3 sgrid((unsigned)(4 * cap + total));
     if (absgrad)
-      hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, true>), sgrid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
+      hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, true>), sgrid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
                          isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap);
     else
-      hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, false>), sgrid, dim3(kWave), pad_bwd, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
+      hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, false>), sgrid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
                          isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap);
   } else if (absgrad) {
     if (lg.div > 1) BDS_BWD_CH(true, true);
