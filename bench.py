@@ -378,6 +378,8 @@ def main():
         from bilateral_driving_amd.graph_view import FrameGraph
         L.enable_timers(os.environ.get("BDS_BENCH_NO_TIMERS") != "1", only=("rasterize_bwd",))
         def build_frame(exchange):
+            if world > 1 and os.environ.get("BDS_BENCH_FAIL_GRAPH") == "1":     # (plumbing check of the last-resort fallback below)
+                raise RuntimeError("forced by BDS_BENCH_FAIL_GRAPH")
             return FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)),
                               overlap=not args.no_overlap, exchange=exchange)
         try:
@@ -385,13 +387,24 @@ def main():
         except Exception as e:
             # (the per-view exchange puts collectives between captured graphs; should the runtime refuse that on this fabric, the frame
             # that replays exactly as on one GPU + one dense all-reduce still measures the path)
-            if not (world > 1 and fx.per_view):
+            if world == 1:
                 raise
-            print(f"bench.py: WARNING: per-view exchange failed to build ({type(e).__name__}: {e}); falling back to --exchange frame", file=sys.stderr)
-            torch.cuda.synchronize()
-            fx = FrameExchange(flat, fx_names, per_view=False)
-            frame = build_frame(fx)
-        if world > 1 and args.exchange == "auto":
+            if fx.per_view:
+                print(f"bench.py: WARNING: per-view exchange failed to build ({type(e).__name__}: {e}); falling back to --exchange frame", file=sys.stderr)
+                torch.cuda.synchronize()
+                fx = FrameExchange(flat, fx_names, per_view=False)
+                try:
+                    frame = build_frame(fx)
+                except Exception as e2:
+                    e, frame = e2, None
+            if frame is None:
+                # last resort on a fabric no round could test (no multi-GPU box was ever available): the eager frame loop with the
+                # exchange between the views -- slower (one host wait per view), but the N-GPU line exists
+                print(f"bench.py: WARNING: the graph-replayed frame failed to build on {world} ranks ({type(e).__name__}: {e}); "
+                      "timing the eager frame loop", file=sys.stderr)
+                torch.cuda.synchronize()
+                fx = FrameExchange(flat, fx_names, per_view=True)
+        if world > 1 and args.exchange == "auto" and frame is not None:
             # price the two exchanges from what this job measures: the ranks' unions per view, one rank's frame, the fabric
             from bilateral_driving_amd.dist import measure_busbw, plan_exchange, union_row_counts
             unions = union_row_counts(vis_masks)
