@@ -138,6 +138,7 @@ _SIGS = {
     "bds_color_correct_step": (_i, [_i64, _f, _f, _f, _fl, _f, _f, _f, _f]),
     "bds_adam_step": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_adam_step_consume": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
+    "bds_adam_step_rows": (_i, [_i64, _i, _i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _i, _f]),
     "bds_bilagrid_slice_feat_fwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_feat_bwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_grid_tv_fwd": (_i, [_i64, _i, _i, _i, _i, _f, _fl, _f, _f]),

@@ -55,6 +55,15 @@ __device__ __forceinline__ int proj_radius(const ProjLayout &pl, const float *__
   return pl.row_radius ? __float_as_int(means2d[o * 8 + 3]) : radii[o];
 }
 
+// Row form of the per-Gaussian parameter GRADIENTS: v_means [N,3], v_quats [N,4], v_log_scales [N,3], v_logits [N] may be the columns
+// of one [N,16] block of 64-byte rows {v_mean 3, v_logit | v_quat 4 | v_log_scale 3, -, | - - - -} (the list-driven backward then
+// updates ONE line per visible Gaussian instead of four partly used ones); recognised by the addresses, as ProjLayout.
+struct GradLayout { int sm, sq, ss, sl; };
+static inline GradLayout grad_layout(const float *v_means, const float *v_quats, const float *v_log_scales, const float *v_logits) {
+  const bool rows = v_means != nullptr && v_quats == v_means + 4 && v_log_scales == v_means + 8 && v_logits == v_means + 3;
+  return rows ? GradLayout{16, 16, 16, 16} : GradLayout{3, 4, 3, 1};
+}
+
 // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8 (observed; used for L2 locality only).
 // Map a linear block id to a work item so that each XCD owns one contiguous range of items.
 __device__ __forceinline__ int xcd_contiguous(int bid, int total) {

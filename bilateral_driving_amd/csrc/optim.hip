@@ -52,9 +52,53 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(int64_t n, float *
   }
 }
 
+// The same update for a parameter [N, width] whose GRADIENT is a column range of a wider row block (element (r, c) at
+// grad[r * grad_stride + c]: dist.FlatGradients(row_block=True) keeps the four small per-Gaussian gradients as one [N,16] block)
+template <bool kClear>
+__global__ __launch_bounds__(kOptBlock) void adam_step_rows_kernel(int64_t n, int width, int64_t grad_stride, float *__restrict__ p,
+                                                                  float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                                                  float step_size, float one_minus_b1, float b2, float one_minus_b2,
+                                                                  float bc2_sqrt, float eps, float weight_decay) {
+#pragma clang fp contract(off)
+  for (int64_t i = (int64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kOptBlock) {
+    const int64_t r = i / width;
+    float *gp = g + r * grad_stride + (i - r * width);
+    float gg = *gp, pp = p[i], mm = m[i], vv = v[i];
+    if (weight_decay != 0.f) gg = gg + weight_decay * pp;
+    mm = one_minus_b1 < 0.5f ? mm + one_minus_b1 * (gg - mm) : gg - (gg - mm) * (1.f - one_minus_b1);
+    vv = vv * b2 + (one_minus_b2 * gg) * gg;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pp + (-step_size) * (mm / denom);
+    m[i] = mm; v[i] = vv;
+    if (kClear) *gp = 0.f;
+  }
+}
+
 }  // namespace bds
 
 using namespace bds;
+
+extern "C" int bds_adam_step_rows(int64_t n_rows, int width, int64_t grad_stride, float *param, float *grad, float *exp_avg,
+                                  float *exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                                  int consume, bds_stream_t stream) {
+  BDS_REQUIRE(n_rows >= 0 && width >= 1 && grad_stride >= width && step >= 1);
+  if (n_rows == 0) return BDS_OK;
+  BDS_REQUIRE(param && grad && exp_avg && exp_avg_sq);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const int64_t n = n_rows * width;
+  int64_t blocks = cdiv(n, kOptBlock * 2);
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = as_stream(stream);
+#define BDS_ADAM_ROWS(C)                                                                                                              \
+  hipLaunchKernelGGL((adam_step_rows_kernel<C>), dim3((unsigned)blocks), dim3(kOptBlock), 0, st, n, width, grad_stride, param, grad,   \
+                     exp_avg, exp_avg_sq, step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps,   \
+                     (float)weight_decay)
+  if (consume) BDS_ADAM_ROWS(true); else BDS_ADAM_ROWS(false);
+#undef BDS_ADAM_ROWS
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
 
 static int adam_step_impl(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1, double beta2,
                           double eps, double weight_decay, int64_t step, bool clear, bds_stream_t stream) {

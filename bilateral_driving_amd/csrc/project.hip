@@ -206,7 +206,8 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     const float *__restrict__ K, int W, int H, float eps2d, const float4 *__restrict__ v_rec, float *__restrict__ v_means,
     float *__restrict__ v_quats, float *__restrict__ v_log_scales, float *__restrict__ v_logits, float *__restrict__ v_viewmat_slots,
-    float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map, float *__restrict__ v_colors = nullptr) {
+    float *__restrict__ grad2d, float *__restrict__ absgrad2d, const int32_t *__restrict__ row_map, float *__restrict__ v_colors = nullptr,
+    const GradLayout gl = GradLayout{3, 4, 3, 1}) {
   __shared__ float red[kProjBlock / kWave][12];
   const int64_t n_list = list_length(n_cap, n_dev);
   if ((int64_t)blockIdx.x * kProjBlock >= n_list) return;   // (whole workgroup: nothing to add to the pose slots either)
@@ -228,23 +229,23 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
     float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_q[4] = {0.f, 0.f, 0.f, 0.f}, old_l = 0.f;
     if (kAcc) {
 #pragma unroll
-      for (int i = 0; i < 3; i++) { old_m[i] = v_means[d * 3 + i]; old_s[i] = v_log_scales[d * 3 + i]; }
+      for (int i = 0; i < 3; i++) { old_m[i] = v_means[d * gl.sm + i]; old_s[i] = v_log_scales[d * gl.ss + i]; }
 #pragma unroll
-      for (int i = 0; i < 4; i++) old_q[i] = v_quats[d * 4 + i];
-      old_l = v_logits[d];
+      for (int i = 0; i < 4; i++) old_q[i] = v_quats[d * gl.sq + i];
+      old_l = v_logits[d * gl.sl];
     }
     Camera cam = load_camera(viewmat, K);
     project_one_vjp(m, q, s, cam, W, H, eps2d, r1.w, r2.x, /*v_depth*/ r0.w, r1.x, r1.y, r1.z, pg);
     const float al = kRaw ? r2.w * o * (1.f - o) : r2.w;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      v_means[d * 3 + i] = old_m[i] + pg.v_mean[i];
-      v_log_scales[d * 3 + i] = old_s[i] + (kRaw ? pg.v_scale[i] * s[i] : pg.v_scale[i]);
+      v_means[d * gl.sm + i] = old_m[i] + pg.v_mean[i];
+      v_log_scales[d * gl.ss + i] = old_s[i] + (kRaw ? pg.v_scale[i] * s[i] : pg.v_scale[i]);
     }
     if (!kRaw && v_colors) { v_colors[g * 3] = r0.x; v_colors[g * 3 + 1] = r0.y; v_colors[g * 3 + 2] = r0.z; }
 #pragma unroll
-    for (int i = 0; i < 4; i++) v_quats[d * 4 + i] = old_q[i] + pg.v_quat[i];
-    v_logits[d] = old_l + al;
+    for (int i = 0; i < 4; i++) v_quats[d * gl.sq + i] = old_q[i] + pg.v_quat[i];
+    v_logits[d * gl.sl] = old_l + al;
     if (grad2d) { grad2d[g * 2] = r1.w; grad2d[g * 2 + 1] = r2.x; }
     if (absgrad2d) { absgrad2d[g * 2] = r2.y; absgrad2d[g * 2 + 1] = r2.z; }
   }
@@ -392,10 +393,11 @@ static int project_view_bwd_list_impl(int64_t n_list, const uint64_t *n_dev, con
               v_quats && v_log_scales && v_logits);
   const dim3 grid((unsigned)cdiv(n_list, kProjBlock)), block(kProjBlock);
   const float4 *v4 = reinterpret_cast<const float4 *>(v_records);
+  const GradLayout gl = grad_layout(v_means, v_quats, v_log_scales, v_logits);   // (the [N,16] row form is recognised by the addresses)
 #define BDS_LIST(A, P)                                                                                                                \
   hipLaunchKernelGGL((project_view_bwd_list_kernel<A, P>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, means, quats, scales, \
                      opacities, viewmat, K, W, H, eps2d, v4, v_means, v_quats, v_log_scales, v_logits, v_viewmat_slots, grad2d,        \
-                     absgrad2d, row_map)
+                     absgrad2d, row_map, static_cast<float *>(nullptr), gl)
   if (accumulate) { if (v_viewmat_slots) BDS_LIST(true, true); else BDS_LIST(true, false); }
   else            { if (v_viewmat_slots) BDS_LIST(false, true); else BDS_LIST(false, false); }
 #undef BDS_LIST

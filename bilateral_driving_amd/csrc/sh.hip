@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
                                                                         float *__restrict__ v_means, float *__restrict__ v_quats,
                                                                         float *__restrict__ v_log_scales, float *__restrict__ v_logits,
                                                                         float *__restrict__ v_sh, float2 *__restrict__ grad2d,
-                                                                        float2 *__restrict__ absgrad2d) {
+                                                                        float2 *__restrict__ absgrad2d, const GradLayout gl) {
   __shared__ int32_t s_g[kShBlock];
   const int64_t n_list = list_length(n_cap, n_dev);
   const int64_t r0 = (int64_t)blockIdx.x * kShBlock;
@@ -343,9 +343,14 @@ __global__ __launch_bounds__(kShBlock) void view_grads_clear_list_kernel(int64_t
     s_g[tid] = (int32_t)g;
     if (g >= 0) {   // negative ids: padding of a fixed-capacity list
       if (v_means) {   // (null: only the screen-space arrays -- the parameter gradients are cleared by their consumer, bds_adam_step_consume)
-        for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
-        for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
-        v_logits[g] = 0.f;
+        if (gl.sm == 16) {      // row form (bds_common.h GradLayout): the whole 64-byte row
+          float4 *row = reinterpret_cast<float4 *>(v_means + g * 16);
+          row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          for (int i = 0; i < 3; i++) { v_means[g * 3 + i] = 0.f; v_log_scales[g * 3 + i] = 0.f; }
+          for (int i = 0; i < 4; i++) v_quats[g * 4 + i] = 0.f;
+          v_logits[g] = 0.f;
+        }
       }
       // (the view's persistent screen-space gradient arrays: the list-driven projection backward STORES the visible rows)
       if (grad2d) grad2d[g] = make_float2(0.f, 0.f);
@@ -598,12 +603,14 @@ static int view_grads_clear_list_impl(int64_t n_list, const uint64_t *n_dev, con
   BDS_REQUIRE((reinterpret_cast<uintptr_t>(grad2d) & 7u) == 0 && (reinterpret_cast<uintptr_t>(absgrad2d) & 7u) == 0);
   float2 *g2 = reinterpret_cast<float2 *>(grad2d), *a2 = reinterpret_cast<float2 *>(absgrad2d);
   const dim3 grid((unsigned)cdiv(n_list, kShBlock)), block(kShBlock);
+  const GradLayout gl = grad_layout(v_means, v_quats, v_log_scales, v_logits);
+  BDS_REQUIRE(gl.sm != 16 || aligned16(v_means));
   if (((K * 3) % 4 == 0) && aligned16(v_sh))
     hipLaunchKernelGGL((view_grads_clear_list_kernel<true>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, K, v_means, v_quats,
-                       v_log_scales, v_logits, v_sh, g2, a2);
+                       v_log_scales, v_logits, v_sh, g2, a2, gl);
   else
     hipLaunchKernelGGL((view_grads_clear_list_kernel<false>), grid, block, 0, as_stream(stream), n_list, n_dev, ids, K, v_means, v_quats,
-                       v_log_scales, v_logits, v_sh, g2, a2);
+                       v_log_scales, v_logits, v_sh, g2, a2, gl);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

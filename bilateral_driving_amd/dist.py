@@ -24,8 +24,13 @@ class FlatGradients:
     gradients into the flat buffer (one read + one write of the payload), runs ONE sum-all-reduce, and
     re-points every ``param.grad`` at its slice of the reduced buffer."""
 
-    def __init__(self, params: Iterable[Tensor], sparse_rows: bool = False):
-        """``sparse_rows``: the flat buffer is kept all-zero between steps by clearing only the rows that were written
+    def __init__(self, params: Iterable[Tensor], sparse_rows: bool = False, row_block: bool = False):
+        """``row_block``: the gradients of the first four parameters -- means [N,3], quats [N,4], log_scales [N,3], opacity logits [N]
+        (``ROW_NAMES`` order) -- are the COLUMNS of one [N,16] block at the head of the flat buffer (64-byte rows {mean 3, logit |
+        quat 4 | log_scale 3, - | - - - -}): a list-driven backward then updates ONE line per visible Gaussian instead of four
+        partly used ones (csrc/bds_common.h GradLayout: recognised by the addresses).  Their ``.grad`` are strided views; the five
+        unused columns stay zero.  Single-process use (``graph_view.FrameGraph`` without an exchange).
+        ``sparse_rows``: the flat buffer is kept all-zero between steps by clearing only the rows that were written
         (``mark_list`` / ``begin_rows_union`` tell which), so that a producer may touch just the rows it needs
         (``fused_view(grad_arena=..., arena_rows=1 | 2)``: a view sees ~15 % of the Gaussians).  Whenever the book is incomplete
         the whole buffer is cleared."""
@@ -38,7 +43,12 @@ class FlatGradients:
         dev = self.params[0].device
         for p in self.params:
             assert p.dtype == torch.float32 and p.device == dev and p.requires_grad
-        self.total = sum(p.numel() for p in self.params)
+        self.row_block = bool(row_block)
+        if self.row_block:
+            N = self.params[0].shape[0]
+            assert len(self.params) >= 4 and [tuple(p.shape) for p in self.params[:4]] == [(N, 3), (N, 4), (N, 3), (N,)], \
+                "row_block: means [N,3], quats [N,4], log_scales [N,3], opacity logits [N] first"
+        self.total = sum(p.numel() for p in self.params) + (5 * self.params[0].shape[0] if self.row_block else 0)
         self._flat: Optional[Tensor] = None
         self._views: List[Tensor] = []
         self._work = None
@@ -50,8 +60,13 @@ class FlatGradients:
     def flat(self) -> Tensor:
         if self._flat is None:
             self._flat = torch.zeros(self.total, device=self.params[0].device, dtype=torch.float32)
-            off = 0
-            for p in self.params:
+            off, rest = 0, self.params
+            if self.row_block:
+                N = self.params[0].shape[0]
+                block = self._flat[:N * 16].view(N, 16)
+                self._views += [block[:, 0:3], block[:, 4:8], block[:, 8:11], block[:, 3]]
+                off, rest = N * 16, self.params[4:]
+            for p in rest:
                 self._views.append(self._flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
         return self._flat

@@ -675,7 +675,9 @@ class _FusedView(torch.autograd.Function):
             t = arena.get(name)
             if t is None:
                 return torch.zeros_like(ref)
-            assert t.dtype == ref.dtype and t.is_contiguous() and t.device == ref.device and t.shape[1:] == ref.shape[1:], name
+            # (contiguous, or a column of the gradients' [N,16] row block: dist.FlatGradients(row_block=True))
+            assert t.dtype == ref.dtype and t.device == ref.device and t.shape[1:] == ref.shape[1:], name
+            assert t.is_contiguous() or (t.stride(0) == 16 and (t.dim() == 1 or t.stride(-1) == 1)), name
             assert sink is not None or t.shape == ref.shape, name
             if not rows:
                 t.zero_()
@@ -707,13 +709,13 @@ class _FusedView(torch.autograd.Function):
             if dev_counts is not None:
                 L.check(lib.bds_project_view_bwd_list_dev(n_vis, dev_counts[1], L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales),
                                                           L.ptr(opac), L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec),
-                                                          L.ptr(v_means), L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots),
+                                                          _dp(v_means), _dp(v_quats), _dp(v_ls), _dp(v_logits), L.ptr(v_vm_slots),
                                                           L.ptr(g2d[0]), L.ptr(g2d[1]), L.ptr(row_map), int(rows == 2), st),
                         "bds_project_view_bwd_list_dev")
             else:
                 L.check(lib.bds_project_view_bwd_list(n_vis, L.ptr(vis_ids), L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opac),
-                                                      L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), L.ptr(v_means),
-                                                      L.ptr(v_quats), L.ptr(v_ls), L.ptr(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
+                                                      L.ptr(viewmat.contiguous()), L.ptr(Kmat), W, H, cfg["eps2d"], L.ptr(v_rec), _dp(v_means),
+                                                      _dp(v_quats), _dp(v_ls), _dp(v_logits), L.ptr(v_vm_slots), L.ptr(g2d[0]), L.ptr(g2d[1]),
                                                       L.ptr(row_map), int(rows == 2), st), "bds_project_view_bwd_list")
         carrier = cfg["_means2d_ref"]() if cfg.get("_means2d_ref") is not None else None
         if carrier is not None:  # the tensor the caller holds in info["means2d"] (trainers/base.py:282-284 read .absgrad / .grad)

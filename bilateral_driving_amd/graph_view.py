@@ -51,7 +51,7 @@ from . import _lib as L
 from .dist import ROW_NAMES, FlatGradients
 from .fused_view import LIST_TILE
 from . import harness as Hn
-from .graph_slots import FrameCapacities, ViewGraph, camera_centre as _camera_centre
+from .graph_slots import GRAD_ROWS, FrameCapacities, ViewGraph, camera_centre as _camera_centre
 
 
 class FrameGraph(FrameCapacities):
@@ -116,9 +116,9 @@ class FrameGraph(FrameCapacities):
             self.names = list(exchange.names)
             self.flat, self.arena = exchange.flat, exchange.arena
         else:
-            self.flat = FlatGradients(list(self.params.values()) + self.grids + list(extra_params), sparse_rows=True)
+            self.flat = FlatGradients(list(self.params.values()) + self.grids + list(extra_params), sparse_rows=True, row_block=GRAD_ROWS)
             self.arena = self.flat.arena(self.names + [f"extra{i}" for i in range(len(extra_params))])
-        n_row = sum(self.arena[k].numel() for k in ROW_NAMES)
+        n_row = sum(self.arena[k].numel() for k in ROW_NAMES) + (5 * self.N if getattr(self.flat, "row_block", False) else 0)
         self._tail = self.flat.flat[n_row:]
         self.caps: list = [None] * self.V              # fused_view.ListCapacity per view slot
         self.views: List[Optional[ViewGraph]] = [None] * self.V
@@ -209,7 +209,7 @@ class FrameGraph(FrameCapacities):
             ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
             g2 = self.g2d[v]      # (the view's persistent screen-space gradient arrays: the same rows, no dense fill per view)
             row_clear = self.clear_grads and self._frame_fx is None   # (per-frame exchange: step() clears the flat buffer densely)
-            pa = [L.ptr(a[k]) if row_clear else None for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+            pa = [a[k].data_ptr() if row_clear else None for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
             L.check(lib.bds_view_grads_clear_list_dev(self.caps[v].nvis_cap, ws.data_ptr() + self._nvis_off, L.ptr(ids), self.K, *pa,
                                                       L.ptr(g2[0]), L.ptr(g2[1]), st), "bds_view_grads_clear_list_dev")
         if self._tail.numel() and tail and self.clear_grads and self._frame_fx is None:

@@ -44,10 +44,19 @@ class FusedAdam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                g = p.grad.contiguous()
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous() and m.shape == p.shape and v.shape == p.shape):
                     raise RuntimeError("optimizer state does not match its parameter (after densification, re-create both)")
+                gr = p.grad
+                if (not gr.is_contiguous() and gr.dim() in (1, 2) and gr.shape == p.shape and (gr.dim() == 1 or gr.stride(1) == 1)
+                        and gr.stride(0) >= (1 if gr.dim() == 1 else gr.shape[1])):
+                    # a column range of a row block (dist.FlatGradients(row_block=True)): read -- and cleared -- where it lies
+                    width = 1 if gr.dim() == 1 else int(gr.shape[1])
+                    L.check(lib.bds_adam_step_rows(p.shape[0], width, int(gr.stride(0)), L.ptr(p), gr.data_ptr(), L.ptr(m), L.ptr(v),
+                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                   int(state["step"]), int(self.consume_grads), st), "bds_adam_step_rows")
+                    continue
+                g = p.grad.contiguous()
                 consume = self.consume_grads and g.data_ptr() == p.grad.data_ptr()     # (clearing a contiguous COPY would clear nothing)
                 fn = lib.bds_adam_step_consume if consume else lib.bds_adam_step
                 L.check(fn(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), float(group["lr"]), float(b1), float(b2),

@@ -357,6 +357,11 @@ int bds_sh_view_fwd(int64_t N, int K, int degrees_to_use, const float *means, co
  * row_map (may be NULL) [N] i32: the parameter-gradient row of Gaussian g is row_map[g] instead of g -- the rows then land in a
  * compact exchange buffer (multi-GPU: the slot of g in the union of the ranks' visible sets) instead of the dense arrays. */
 #define BDS_POSE_GRAD_SLOTS 64
+/* ROW FORM of the four small parameter gradients (optional, recognised by the addresses like the projection's row form): v_means,
+ * v_quats, v_log_scales, v_logits may be the columns of one 16-byte aligned [N,16] block of 64-byte rows {v_mean 3, v_logit | v_quat 4 |
+ * v_log_scale 3, - | - - - -}: pass v_means = block, v_logits = block + 3, v_quats = block + 4, v_log_scales = block + 8.
+ * bds_project_view_bwd_list* then update, and bds_view_grads_clear_list* clear, ONE line per visible Gaussian instead of four partly
+ * used ones; bds_adam_step_rows reads such columns. */
 /* sh_rgb: the un-clamped colours the forward left -- [N,3] indexed by Gaussian (bds_sh_view_fwd), or, with sh_rgb_by_rank != 0,
  * [n_list,3] in list order (bds_splat_pack_sh). */
 int bds_sh_view_bwd_list(int64_t n_list, const int32_t *ids, int K, int degrees_to_use, const float *means, const float *cam_pos,
@@ -597,6 +602,12 @@ int bds_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, fl
  * what optimizer.zero_grad() (tools/train.py:266) costs the reference as one more pass over every gradient. */
 int bds_adam_step_consume(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1,
                           double beta2, double eps, double weight_decay, int64_t step, bds_stream_t stream);
+/* The same update for a parameter [n_rows, width] whose gradient is a column range of a wider row block: element (r, c) at
+ * grad[r * grad_stride + c] (the [N,16] row form of the four small per-Gaussian gradients, see bds_project_view_bwd_list);
+ * consume != 0 clears the gradient as it is read. */
+int bds_adam_step_rows(int64_t n_rows, int width, int64_t grad_stride, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                       double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int consume,
+                       bds_stream_t stream);
 
 /* Per-step densification statistics of one set of Gaussians in one launch (models/trainers/base.py:279-297 +
  * models/gaussians/vanilla.py:163-191): grad2d [N,2] is info["means2d"].absgrad (or .grad) BEFORE the trainer's

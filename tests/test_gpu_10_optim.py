@@ -41,6 +41,42 @@ def test_fused_adam_matches_torch_adam(wd):
             assert err < 2e-6, (i, what, err)
 
 
+@pytest.mark.parametrize("consume", [False, True])
+def test_fused_adam_reads_gradients_that_are_columns_of_a_row_block(consume):
+    """dist.FlatGradients(row_block=True): the gradients of means / quats / log_scales / opacity logits are column ranges of one [N,16]
+    block -- bds_adam_step_rows updates from (and, consuming, clears) them where they lie: the same numbers, bit for bit, as the
+    contiguous pass."""
+    from bilateral_driving_amd.dist import FlatGradients
+    from bilateral_driving_amd.optim import FusedAdam
+    N = 5003
+    g = torch.Generator().manual_seed(1)
+    shapes = [(N, 3), (N, 4), (N, 3), (N,), (N, 16, 3)]
+
+    def make():
+        return [torch.randn(s, generator=torch.Generator().manual_seed(7 + i)).cuda().requires_grad_(True) for i, s in enumerate(shapes)]
+
+    pa, pb = make(), make()
+    flat = FlatGradients(pb, sparse_rows=True, row_block=True)
+    views = flat.arena(["means", "quats", "log_scales", "opacity_logits", "sh"])
+    assert not views["quats"].is_contiguous() and views["sh"].is_contiguous() and flat.flat.numel() == N * (16 + 48)
+    oa = FusedAdam([{"params": [p], "lr": 1e-3 * (i + 1)} for i, p in enumerate(pa)], lr=0.0, eps=1e-15, consume_grads=consume)
+    ob = FusedAdam([{"params": [p], "lr": 1e-3 * (i + 1)} for i, p in enumerate(pb)], lr=0.0, eps=1e-15, consume_grads=consume)
+    names = ["means", "quats", "log_scales", "opacity_logits", "sh"]
+    for it in range(5):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            gr = (torch.randn(x.shape, generator=g) * 0.1).cuda()
+            x.grad = gr.clone()
+            views[names[i]].copy_(gr)
+            y.grad = views[names[i]]
+        oa.step(); ob.step()
+        if consume:
+            assert float(flat.flat.abs().max()) == 0.0 and all(float(x.grad.abs().max()) == 0.0 for x in pa)
+        assert float(flat.flat[:N * 16].view(N, 16)[:, 11:].abs().max()) == 0.0          # the unused columns stay zero
+    for x, y in zip(pa, pb):
+        assert torch.equal(x.detach(), y.detach())
+        assert torch.equal(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"]) and torch.equal(oa.state[x]["exp_avg"], ob.state[y]["exp_avg"])
+
+
 def test_fused_adam_state_layout_allows_the_reference_surgery():
     """models/gaussians/basics.py:162-206 style: replace a parameter and its state tensors by concatenated ones."""
     from bilateral_driving_amd.optim import FusedAdam
