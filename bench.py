@@ -108,6 +108,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="graph replay: one graph per view on one stream instead of forward / backward graphs on two streams (view v + 1's "
                          "forward next to view v's backward)")
+    ap.add_argument("--row-order", choices=("spatial", "given"), default=os.environ.get("BDS_BENCH_ROW_ORDER", "spatial"),
+                    help="order of the scene's rows in memory: spatial = Morton order of the centres (densify.spatial_order, the framework's "
+                         "layout: applied once at load, outside the timed region), given = the generator's own order")
     ap.add_argument("--exchange", choices=("auto", "view", "frame"), default="auto",
                     help="N > 1: sum the gradients over the ranks per view (compact union rows, overlapped with the next view), once per "
                          "frame (one dense all-reduce), or whichever dist.plan_exchange prices cheaper from the measured unions, the "
@@ -341,6 +344,12 @@ def main():
     for cam in cams:   # the camera pose is learnable in the reference (trainers/base.py:328-329,399): its gradient stays live
         cam.viewmat.requires_grad_(os.environ.get("BDS_BENCH_NO_POSE") != "1")   # (diagnostic switch)
     params = Hn.synthetic_scene(N, seed=0, device=dev) if args.scene == "ring" else Hn.lidar_scene(N, seed=0, device=dev, opacity=args.lidar_opacity)
+    # the scene's rows in Morton order of the centres (densify.spatial_order, applied ONCE at load as a trainer would -- and again after
+    # densification steps: refinement_after(reorder=True)): the ~15 % of the rows a camera sees then form runs, and every list-driven
+    # kernel of a view moves whole cache lines.  --row-order given keeps the generator's own (random) order: the figure of rounds 1-4
+    if args.row_order == "spatial":
+        perm = Hn.spatial_order(params["means"])
+        params = {k: v[perm].contiguous() for k, v in params.items()}
     for v in params.values():
         v.requires_grad_(True)
     grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), levels=wl["levels"], device=dev)]
@@ -604,6 +613,31 @@ def main():
             frame = dyn     # (keeps `frame is not None` for the step_driver text below)
         except Exception as e:   # measurement tooling must never take the bench line down
             random_its = f"{type(e).__name__}: {e}"
+    # the same frame with the scene's rows in the OTHER order (--row-order): same set of Gaussians, same kernels, same images
+    other_order_its, other_order = None, ("given" if args.row_order == "spatial" else "spatial")
+    if rank == 0 and world == 1 and args.random_views and frame is not None:
+        try:
+            from bilateral_driving_amd.graph_view import FrameGraph
+            if other_order == "spatial":
+                p2 = Hn.reorder_params(params, Hn.spatial_order(params["means"]))
+            else:   # undo the Morton order with a fixed shuffle (the generator's own order is a random one)
+                p2 = Hn.reorder_params(params, torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(dev))
+            fr2 = FrameGraph(p2, cams[:V], grids, skies[:V], targets[:V], factors=factors, img_indices=list(range(V)), overlap=not args.no_overlap)
+            for _ in range(3):
+                fr2.step(wait=False)
+            t2 = []
+            for _ in range(max(args.repeats, 1)):     # (timed as the headline is: the median of `repeats` regions of `steps` frames)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fr2.step(wait=False)
+                torch.cuda.synchronize()
+                t2.append(time.perf_counter() - t0)
+            other_order_its = V * args.steps / sorted(t2)[(len(t2) - 1) // 2]
+            assert fr2.valid()
+            del fr2, p2
+        except Exception as e:   # measurement tooling must never take the bench line down
+            other_order_its = f"{type(e).__name__}: {e}"
     # the drop-in path (reference-signature operators chained by autograd: projection, SH, isect_tiles, rasterize_to_pixels,
     # bilagrid_transform -- what `gsplat.rasterization(...)` + the module `forward` cost a trainer that changes nothing else)
     # api_path_iters_per_sec: that sequence starting at the Gaussian class's own get_gaussians with marshalling.install (deferred
@@ -780,7 +814,10 @@ def main():
                                f"{wl['text']}; {N} Gaussians, {len(cams)}-cam ring {W}x{H}, RGB+ED, grids "
                                f"{[list(l) for l in wl['levels']]} factors {list(factors)}, L1+TV loss, camera-pose gradient live; one step = one "
                                f"frame of {V} views per GPU (1 iter = 1 view)",
-                   "workload_name": args.workload, "scene": args.scene, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
+                   "workload_name": args.workload, "scene": args.scene,
+                   "row_order": args.row_order + (" (Morton order of the centres, densify.spatial_order: applied once at load, outside the timed "
+                                                  "region; the set of Gaussians is the generator's)" if args.row_order == "spatial" else " (the generator's own order)"),
+                   f"{other_order}_row_order_iters_per_sec": other_order_its, "gaussians": N, "width": W, "height": H, "views": len(cams), "views_per_step": V,
                    "frames_per_sec": value / V, "ms_per_view": ms_per_step / V, "api_path_iters_per_sec": api_its, "api_path_eager_iters_per_sec": api_eager_its,
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",

@@ -114,6 +114,51 @@ def _move_rows(self, optimizer, flags, ranks, totals, samps: int, n_new: int, ge
         group["params"] = [prm]
 
 
+def spatial_order(means: Tensor, bits: int = 10) -> Tensor:
+    """Permutation [N] (int64) that puts the Gaussians in Morton (Z-curve) order of their centres (``bits`` per axis over the
+    bounding box).  Rows that lie together in space then lie together in memory, so the ~15 % of the set a camera sees form RUNS
+    instead of isolated rows, and every list-driven kernel of a view (SH rows in the record pack, the projection / SH backward, the
+    row clear) moves whole cache lines: 2 M Gaussians / six 1080p views 1023 -> 1088 it/s, 5 M Gaussians (c5) 591 -> 710
+    (profiles/NOTES.md).  The reference keeps the order of its initial point cloud (lidar sweeps: coherent along the drive; its random
+    points: not) and appends split / duplicated Gaussians at the end (vanilla.py:256-262); the order carries no meaning -- apply the
+    permutation with ``reorder_rows`` once after initialisation and, when wanted, after densification steps."""
+    m = means.detach().float()
+    lo, hi = m.amin(0), m.amax(0)
+    q = ((m - lo) / (hi - lo).clamp(min=1e-12) * ((1 << bits) - 1)).long().clamp(0, (1 << bits) - 1)
+    code = torch.zeros(m.shape[0], dtype=torch.int64, device=m.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code, stable=True)
+
+
+@torch.no_grad()
+def reorder_rows(self, optimizer, perm: Tensor) -> None:
+    """Row ``i`` of every per-Gaussian array of the class becomes old row ``perm[i]``: the six parameters (new ``nn.Parameter``s in
+    their optimizer groups, as the reference's own densification replaces them: basics.py:162-206), their Adam moments, ``point_ids``
+    of the node classes and the densification statistics -- everything ``refinement_after`` moves.  ``optimizer`` may be None."""
+    N = self._means.shape[0]
+    assert perm.shape == (N,) and perm.dtype == torch.int64
+    for a, gname in zip(_ATTRS, _GROUPS):
+        old_p = getattr(self, a)
+        prm = Parameter(old_p.detach().index_select(0, perm))
+        setattr(self, a, prm)
+        group = _group_of(optimizer, self.class_prefix + gname) if optimizer is not None else None
+        if group is None:
+            continue
+        state = optimizer.state.pop(group["params"][0], None)
+        if state:
+            for k in ("exp_avg", "exp_avg_sq"):
+                if torch.is_tensor(state.get(k)) and state[k].shape[:1] == (N,):
+                    state[k] = state[k].index_select(0, perm)
+            optimizer.state[prm] = state
+        group["params"] = [prm]
+    for name in ("point_ids", "xys_grad_norm", "vis_counts", "max_2Dsize"):
+        t = getattr(self, name, None)
+        if torch.is_tensor(t) and t.shape[:1] == (N,):
+            setattr(self, name, t.index_select(0, perm))
+
+
 def out_of_bound_mask(means: Tensor, point_ids: Tensor, instances_size: Tensor) -> Tensor:
     """RigidNodes.get_out_of_bound_mask (nodes/rigid.py:374-383) as a [N] uint8 mask."""
     L.require_gpu(means, point_ids, instances_size)
@@ -130,7 +175,7 @@ def out_of_bound_mask(means: Tensor, point_ids: Tensor, instances_size: Tensor) 
 
 @torch.no_grad()
 def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples: Optional[Tensor] = None, verbose: bool = True,
-                     sample_fn=None) -> None:
+                     sample_fn=None, reorder: bool = False) -> None:
     """Same contract as VanillaGaussians.refinement_after(step, optimizer) and, for a model that carries ``point_ids``
     (+ ``instances_size`` when ``ctrl.cull_out_of_bound``), as RigidNodes / DeformableNodes.refinement_after
     (models/nodes/rigid.py:194-325).  ``samples`` (optional, [n_split_samples * n_split, 3]) replaces the ``torch.randn`` draw of
@@ -140,7 +185,8 @@ def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples:
 
     The box test of the node classes is taken on the rows AFTER split / dup (a split child is judged by where its own sample
     fell), so it runs as a second, cull-only plan over the new set; removing the two masks one after the other leaves the
-    reference's rows in the reference's order."""
+    reference's rows in the reference's order.  ``reorder=True``: a step that changed the set ends with ``reorder_rows`` into
+    ``spatial_order`` (the children a split / dup appends at the end go where their neighbours are)."""
     assert step == self.step
     ctrl = self.ctrl_cfg
     if self.step <= ctrl.warmup_steps:
@@ -204,6 +250,8 @@ def refinement_after(self, step: int, optimizer: torch.optim.Optimizer, samples:
                 print(f"    Split: {n_split}")
                 print(f"      Dup: {n_dup}")
             print(f"     Cull: {N + samps * n_split + n_dup - n_new + n_out}")
+        if reorder and self._means.shape[0] > 1:
+            reorder_rows(self, optimizer, spatial_order(self._means))
     if verbose:
         print(f"Class {self.class_prefix} left points: {self._means.shape[0]}")
     if self.step % reset_interval == ctrl.refine_interval:                    # vanilla.py:286-299

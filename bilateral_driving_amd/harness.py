@@ -79,6 +79,17 @@ def synthetic_scene(N: int, seed: int = 0, device="cpu") -> Dict[str, Tensor]:
     return {k: v.to(device).contiguous() for k, v in out.items()}
 
 
+def spatial_order(means: Tensor, bits: int = 10) -> Tensor:
+    """``densify.spatial_order`` (Morton order of the centres) -- re-exported for scripts that build scenes here."""
+    from .densify import spatial_order as _so
+    return _so(means, bits)
+
+
+def reorder_params(params: Dict[str, Tensor], perm: Tensor) -> Dict[str, Tensor]:
+    """The parameter dict with its rows permuted (fresh contiguous leaves; ``requires_grad`` kept)."""
+    return {k: v.detach()[perm].contiguous().requires_grad_(v.requires_grad) for k, v in params.items()}
+
+
 def lidar_scene(N: int = 1_000_000, seed: int = 0, device="cpu", opacity: str = "trained") -> Dict[str, Tensor]:
     """A lidar-INITIALISED street scene, the other end of the splat-size distribution from ``synthetic_scene``: the reference seeds
     its Background class with 800 k points sampled from the drive's accumulated lidar sweeps plus 100 k "near" randoms (uniform in

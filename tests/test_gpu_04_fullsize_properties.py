@@ -293,3 +293,34 @@ def test_fullsize_coarse_lists_equal_16px_lists(full):
     for x, y in zip(a[4], b[4]):
         assert float((x - y).norm()) <= 2e-5 * float(x.norm())
     assert float((a[5] - b[5]).norm()) <= 2e-5 * float(a[5].norm())
+
+
+def test_row_order_is_invisible_to_the_image_and_permutes_the_gradients():
+    """densify.spatial_order: the same SET of Gaussians in another row order renders the same view (depth ties between DIFFERENT
+    Gaussians in one tile are the only place where the order of the rows enters -- none in a random scene) and every gradient row
+    moves with its Gaussian."""
+    from bilateral_driving_amd import harness as Hn
+    dev = "cuda"
+    W, H, N = 960, 544, 200_000
+    cam = Hn.ring_cameras(W, H, yaws_deg=(35.0,), device=dev)[0]
+    cam.viewmat.requires_grad_(True)
+    base = Hn.synthetic_scene(N, seed=11, device=dev)
+    perm = Hn.spatial_order(base["means"])
+    assert not torch.equal(perm, torch.arange(N, device=dev))
+    gen = torch.Generator().manual_seed(3)
+    sky = torch.rand(H, W, 3, generator=gen).to(dev)
+    target = torch.rand(H, W, 3, generator=gen).to(dev)
+    res = []
+    for p in ({k: v.clone().requires_grad_(True) for k, v in base.items()}, Hn.reorder_params({k: v.requires_grad_(True) for k, v in base.items()}, perm)):
+        grids = [g.requires_grad_(True) for g in Hn.make_grids(1, device=dev)]
+        cam.viewmat.grad = None
+        out = Hn.render_view(p, cam, grids, 0, sky)
+        Hn.training_loss(out, target, grids).backward()
+        res.append((out["rgb"].detach(), out["depth"].detach(), {k: v.grad for k, v in p.items()}, cam.viewmat.grad.clone(), out["info"]["n_visible"]))
+    (rgb_a, d_a, g_a, vm_a, nv_a), (rgb_b, d_b, g_b, vm_b, nv_b) = res
+    assert nv_a == nv_b > 10_000
+    assert float((rgb_a - rgb_b).abs().max()) <= 1e-5 and float((d_a - d_b).abs().max()) <= 1e-4 * float(d_a.abs().max())
+    for k in g_a:
+        ref = g_a[k][perm]
+        assert float((g_b[k] - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-9, k
+    assert float((vm_a - vm_b).abs().max()) <= 1e-4 * float(vm_a.abs().max())

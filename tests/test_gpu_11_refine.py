@@ -275,3 +275,29 @@ def test_refinement_that_culls_everything_leaves_empty_tensors(nodes):
         assert opt.state[prm]["exp_avg"].shape == prm.shape
     if nodes:
         assert model.point_ids.shape == (0, 1) and model.point_ids.dtype == torch.int64
+
+
+def test_refinement_with_reorder_leaves_the_same_set_in_spatial_order():
+    """``refinement_after(..., reorder=True)``: the same Gaussians, Adam moments and group wiring as without, rows in
+    ``spatial_order`` of the new centres (the order carries no meaning in the reference: vanilla.py:256-262 appends children)."""
+    from bilateral_driving_amd.densify import refinement_after, spatial_order
+    from bilateral_driving_amd.optim import FusedAdam
+    N, step = 40_000, 3300
+    P, M, V, stats = synthetic(N, seed=5)
+    outs = []
+    for reorder in (False, True):
+        model, opt = build_model(P, M, V, stats, CTRL, 30.0, 150, step, FusedAdam)
+        g = torch.Generator().manual_seed(9)
+        refinement_after(model, step, opt, verbose=False, reorder=reorder,
+                         sample_fn=lambda shape, dev: torch.randn(shape, generator=g).to(dev))
+        outs.append((model, opt))
+    (ma, oa), (mb, ob) = outs
+    n = ma._means.shape[0]
+    assert mb._means.shape[0] == n and n != N
+    perm = spatial_order(ma._means)
+    assert torch.equal(spatial_order(mb._means), torch.arange(n, device="cuda"))            # already in order
+    for a, name in zip(RO.PARAMS, GROUPS):
+        assert torch.equal(getattr(mb, a).detach(), getattr(ma, a).detach()[perm]), a
+        assert torch.equal(ob.state[getattr(mb, a)]["exp_avg_sq"], oa.state[getattr(ma, a)]["exp_avg_sq"][perm]), a
+        grp = [gr for gr in ob.param_groups if gr["name"] == mb.class_prefix + name][0]
+        assert grp["params"][0] is getattr(mb, a)
