@@ -230,6 +230,43 @@ BDS_HD Proj project_one(const float *mean, const float *quat, const float *scale
   return o;
 }
 
+// Can project_one return a visible Gaussian for ANY centre inside the box [lo, hi] when no Gaussian of the box has a scale above
+// smax?  false = provably not (the caller may skip the whole block); true = maybe.  Conservative, from the tests of project_one:
+//   near / far: z is affine in the centre, so its extremes over the box are at the 8 corners;
+//   radius <= 3 sqrt(v1) + 1, v1 <= lambda_max(J covc J^T) + eps2d + 0.1 (the 0.01 floor under the root adds at most 0.1),
+//     lambda_max <= ||J||_F^2 smax^2 <= F smax^2 / z^2 with F = fx^2 + fy^2 + (0.65 W)^2 + (0.65 H)^2 (|tx| <= 0.65 W z / fx by the
+//     clamp) -- decreasing in z, so the value at the smallest depth any live centre of the box can have bounds them all;
+//   image rectangle: mx + radius <= 0  <=  fx x + (cx + rho) z <= 0 for z > 0: linear in the camera-space centre, extremes at the
+//     corners again (4 px of slack against the rounding of mx and of this test); likewise the other three sides.
+BDS_HD bool box_may_be_visible(const float *lo, const float *hi, float smax, const Camera &cam, int W, int H, float eps2d,
+                               float near_plane, float far_plane) {
+  const float *R = cam.R.m;
+  float zmin = 3.0e38f, zmax = -3.0e38f;
+  float qx[8], qy[8], qz[8];
+  for (int k = 0; k < 8; k++) {
+    const float px = (k & 1) ? hi[0] : lo[0], py = (k & 2) ? hi[1] : lo[1], pz = (k & 4) ? hi[2] : lo[2];
+    qx[k] = R[0] * px + R[1] * py + R[2] * pz + cam.t[0];
+    qy[k] = R[3] * px + R[4] * py + R[5] * pz + cam.t[1];
+    qz[k] = R[6] * px + R[7] * py + R[8] * pz + cam.t[2];
+    zmin = fminf(zmin, qz[k]); zmax = fmaxf(zmax, qz[k]);
+  }
+  const float slack = 1e-4f * (fabsf(zmin) + fabsf(zmax)) + 1e-6f;     // rounding of the kernel's own z against this one's
+  if (!(zmax + slack > near_plane) || !(zmin - slack < far_plane)) return false;
+  const float zlo = fmaxf(zmin - slack, near_plane);
+  if (!(zlo > 0.f) || !(smax < 3.0e38f) || !(smax == smax)) return true;
+  const float F = cam.fx * cam.fx + cam.fy * cam.fy + 0.4225f * ((float)W * (float)W + (float)H * (float)H);
+  const float rho = 3.f * sqrtf(F * smax * smax / (zlo * zlo) + eps2d + 0.1f) + 5.f;    // (+1 for the ceil, +4 px of slack)
+  float left = -3.0e38f, right = 3.0e38f, top = -3.0e38f, bottom = 3.0e38f;
+  for (int k = 0; k < 8; k++) {
+    left = fmaxf(left, cam.fx * qx[k] + (cam.cx + rho) * qz[k]);
+    right = fminf(right, cam.fx * qx[k] + (cam.cx - (float)W - rho) * qz[k]);
+    top = fmaxf(top, cam.fy * qy[k] + (cam.cy + rho) * qz[k]);
+    bottom = fminf(bottom, cam.fy * qy[k] + (cam.cy - (float)H - rho) * qz[k]);
+  }
+  if (left <= 0.f || right >= 0.f || top <= 0.f || bottom >= 0.f) return false;
+  return true;
+}
+
 struct ProjGrad {
   float v_mean[3], v_quat[4], v_scale[3];
   float v_R[9], v_t[3];  // gradient w.r.t. the camera rotation / translation

@@ -103,11 +103,37 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     const float *__restrict__ logits, const float *__restrict__ viewmat, const float *__restrict__ K, int W, int H,
     float eps2d, float near_plane, float far_plane, float radius_clip, float *__restrict__ scales,
     float *__restrict__ opacities, int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
-    float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss, int rows) {
+    float *__restrict__ conics, PrepReduceSlots rs, int32_t *__restrict__ tiles_per_gauss, int rows,
+    const float *__restrict__ block_bounds) {
   const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
   if (kReduce) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *rs.m_total = 0;
     for (int64_t i = g; i < rs.zero_elems; i += (int64_t)gridDim.x * kProjBlock) rs.zero_me[i] = 0u;
+  }
+  // Block bound (bds_gaussian_block_bounds: this workgroup's 256 rows lie in a box, none is larger than smax): when no centre in the
+  // box can come out visible, the rows are not even read -- a culled Gaussian's outputs are zeros.  (Rows kept in spatial order,
+  // densify.spatial_order, make the boxes small: a camera then rejects most of the ~85 % it does not see block-wise.)
+  if (block_bounds != nullptr) {
+    const float *bb = block_bounds + (int64_t)blockIdx.x * 8;
+    const float lo[3] = {bb[0], bb[1], bb[2]}, hi[3] = {bb[4], bb[5], bb[6]};
+    if (!box_may_be_visible(lo, hi, bb[3], load_camera(viewmat, K), W, H, eps2d, near_plane, far_plane)) {
+      if (g < N) {
+        radii[g] = 0;
+        if (rows) {
+          float4 *row = reinterpret_cast<float4 *>(means2d + g * 8);
+          row[0] = row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          means2d[g * 2] = 0.f; means2d[g * 2 + 1] = 0.f;
+          depths[g] = 0.f;
+          conics[g * 3] = 0.f; conics[g * 3 + 1] = 0.f; conics[g * 3 + 2] = 0.f;
+        }
+        if (kReduce && tiles_per_gauss) tiles_per_gauss[g] = 0;
+      }
+      if (kReduce && threadIdx.x == 0) rs.sums256[blockIdx.x] = 0u;
+      return;
+    }
+  }
+  if (kReduce) {
     int radius = 0;
     if (g < N) {
       float m[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
@@ -343,10 +369,11 @@ static int view_rows(const float *means2d, const float *depths, const float *con
   return BDS_OK;
 }
 
-extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
-                                    const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
-                                    float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
-                                    int32_t *radii, float *means2d, float *depths, float *conics, bds_stream_t stream) {
+static int project_view_fwd_impl(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                 const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                 float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                 int32_t *radii, float *means2d, float *depths, float *conics, const float *block_bounds,
+                                 bds_stream_t stream) {
   BDS_REQUIRE(N >= 0 && W > 0 && H > 0);
   if (N == 0) return BDS_OK;
   BDS_REQUIRE(means && quats && log_scales && logits && viewmat && K && scales && opacities && radii && means2d && depths &&
@@ -355,16 +382,24 @@ extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *
   if (view_rows(means2d, depths, conics, &rows) != BDS_OK) return BDS_EINVAL;
   hipLaunchKernelGGL(project_view_fwd_kernel<false>, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
                      means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
-                     opacities, radii, means2d, depths, conics, PrepReduceSlots{}, static_cast<int32_t *>(nullptr), rows);
+                     opacities, radii, means2d, depths, conics, PrepReduceSlots{}, static_cast<int32_t *>(nullptr), rows, block_bounds);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }
 
-extern "C" int bds_project_view_prepare_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
-                                            const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
-                                            float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
-                                            int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss,
-                                            void *prep_ws, size_t prep_ws_bytes, bds_stream_t stream) {
+extern "C" int bds_project_view_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                    const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                    float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                    int32_t *radii, float *means2d, float *depths, float *conics, bds_stream_t stream) {
+  return project_view_fwd_impl(N, means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
+                               opacities, radii, means2d, depths, conics, nullptr, stream);
+}
+
+static int project_view_prepare_fwd_impl(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                         const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                         float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                         int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss,
+                                         void *prep_ws, size_t prep_ws_bytes, const float *block_bounds, bds_stream_t stream) {
   BDS_REQUIRE(N > 0 && W > 0 && H > 0);
   BDS_REQUIRE(means && quats && log_scales && logits && viewmat && K && scales && opacities && radii && means2d && depths &&
               conics);
@@ -376,7 +411,89 @@ extern "C" int bds_project_view_prepare_fwd(int64_t N, const float *means, const
   if (view_rows(means2d, depths, conics, &rows) != BDS_OK) return BDS_EINVAL;
   hipLaunchKernelGGL(project_view_fwd_kernel<true>, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N,
                      means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
-                     opacities, radii, means2d, depths, conics, rs, tiles_per_gauss, rows);
+                     opacities, radii, means2d, depths, conics, rs, tiles_per_gauss, rows, block_bounds);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_project_view_prepare_fwd(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                            const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                            float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                            int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss,
+                                            void *prep_ws, size_t prep_ws_bytes, bds_stream_t stream) {
+  return project_view_prepare_fwd_impl(N, means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip,
+                                       scales, opacities, radii, means2d, depths, conics, tiles_per_gauss, prep_ws, prep_ws_bytes, nullptr,
+                                       stream);
+}
+
+// ... with a bound per 256-row block (bds_gaussian_block_bounds over the SAME means / log_scales): blocks no centre of which can come
+// out visible are not read; their rows get the outputs of a culled Gaussian (radius 0, zeros).  scales / opacities of such rows are
+// NOT written (nothing reads them for a culled Gaussian).
+extern "C" int bds_project_view_fwd_blocks(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                           const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                           float near_plane, float far_plane, float radius_clip, float *scales, float *opacities,
+                                           int32_t *radii, float *means2d, float *depths, float *conics, const float *block_bounds,
+                                           bds_stream_t stream) {
+  BDS_REQUIRE(block_bounds);
+  return project_view_fwd_impl(N, means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip, scales,
+                               opacities, radii, means2d, depths, conics, block_bounds, stream);
+}
+extern "C" int bds_project_view_prepare_fwd_blocks(int64_t N, const float *means, const float *quats, const float *log_scales,
+                                                   const float *logits, const float *viewmat, const float *K, int W, int H, float eps2d,
+                                                   float near_plane, float far_plane, float radius_clip, float *scales,
+                                                   float *opacities, int32_t *radii, float *means2d, float *depths, float *conics,
+                                                   int32_t *tiles_per_gauss, void *prep_ws, size_t prep_ws_bytes,
+                                                   const float *block_bounds, bds_stream_t stream) {
+  BDS_REQUIRE(block_bounds);
+  return project_view_prepare_fwd_impl(N, means, quats, log_scales, logits, viewmat, K, W, H, eps2d, near_plane, far_plane, radius_clip,
+                                       scales, opacities, radii, means2d, depths, conics, tiles_per_gauss, prep_ws, prep_ws_bytes,
+                                       block_bounds, stream);
+}
+
+namespace bds {
+// bounds[b] = {lo.x, lo.y, lo.z, smax | hi.x, hi.y, hi.z, -} of rows [256 b, 256 (b + 1)): box of the centres, largest activated scale
+__global__ __launch_bounds__(kProjBlock) void block_bounds_kernel(int64_t N, const float *__restrict__ means,
+                                                                 const float *__restrict__ log_scales, float *__restrict__ bounds) {
+  __shared__ float red[kProjBlock / kWave][8];
+  const int64_t g = (int64_t)blockIdx.x * kProjBlock + threadIdx.x;
+  float v[7] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};   // lo xyz | hi xyz | max log-scale
+  if (g < N) {
+    for (int k = 0; k < 3; k++) { const float m = means[g * 3 + k]; v[k] = m; v[3 + k] = m; }
+    v[6] = fmaxf(fmaxf(log_scales[g * 3], log_scales[g * 3 + 1]), log_scales[g * 3 + 2]);
+    // (a NaN centre or scale: the comparisons below would drop it -- make the box unbounded instead, the projection then decides)
+    if (!(v[0] == v[0]) || !(v[1] == v[1]) || !(v[2] == v[2]) || !(v[6] == v[6])) {
+      for (int k = 0; k < 3; k++) { v[k] = -3.0e38f; v[3 + k] = 3.0e38f; }
+      v[6] = 80.f;
+    }
+  }
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    for (int k = 0; k < 3; k++) v[k] = fminf(v[k], __shfl_xor(v[k], o));
+    for (int k = 3; k < 7; k++) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
+  }
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0)
+    for (int k = 0; k < 7; k++) red[wv][k] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kProjBlock / kWave; w++) {
+      for (int k = 0; k < 3; k++) v[k] = fminf(v[k], red[w][k]);
+      for (int k = 3; k < 7; k++) v[k] = fmaxf(v[k], red[w][k]);
+    }
+    float *b = bounds + (int64_t)blockIdx.x * 8;
+    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = expf(v[6]);
+    b[4] = v[3]; b[5] = v[4]; b[6] = v[5]; b[7] = 0.f;
+  }
+}
+}  // namespace bds
+
+// block_bounds [cdiv(N, 256), 8] for bds_project_view_*_fwd_blocks; recompute whenever means / log_scales changed (once per frame)
+extern "C" int bds_gaussian_block_bounds(int64_t N, const float *means, const float *log_scales, float *block_bounds,
+                                         bds_stream_t stream) {
+  BDS_REQUIRE(N >= 0);
+  if (N == 0) return BDS_OK;
+  BDS_REQUIRE(means && log_scales && block_bounds);
+  hipLaunchKernelGGL(block_bounds_kernel, dim3((unsigned)cdiv(N, kProjBlock)), dim3(kProjBlock), 0, as_stream(stream), N, means,
+                     log_scales, block_bounds);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -224,19 +224,23 @@ def _front_begin(cfg: dict, means, quats, log_scales, logits, sh, viewmat) -> _F
     assert ws.dtype == torch.uint8 and ws.is_contiguous() and ws.numel() >= ws_bytes and ws.device == dev
     # device-count form: the projection also does the tile stage's first launch (visible counts per workgroup, tables cleared)
     pre_reduced = False
+    bounds = cfg.get("block_bounds")      # [cdiv(N, 256), 8] of bds_gaussian_block_bounds over THESE means / log_scales (graph_view: once per frame)
     with L.timed("project_fwd"):
         if cfg.get("caps") is not None and _PROJECT_PREPARES and N > 0:
-            rc = lib.bds_project_view_prepare_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
-                                                  L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
-                                                  L.ptr(scales), L.ptr(opac), L.ptr(radii), _dp(means2d), _dp(depths), _dp(conics),
-                                                  L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes, st)
+            args = (N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
+                    L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
+                    L.ptr(scales), L.ptr(opac), L.ptr(radii), _dp(means2d), _dp(depths), _dp(conics),
+                    L.ptr(tiles_per_gauss), L.ptr(ws), ws_bytes)
+            rc = (lib.bds_project_view_prepare_fwd(*args, st) if bounds is None
+                  else lib.bds_project_view_prepare_fwd_blocks(*args, L.ptr(bounds), st))
             pre_reduced = rc == L.BDS_OK
             if rc not in (L.BDS_OK, L.BDS_ECAPACITY):     # (ECAPACITY: N beyond the short sort path -- the plain projection below)
                 L.check(rc, "bds_project_view_prepare_fwd")
         if not pre_reduced:
-            L.check(lib.bds_project_view_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
-                                             L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
-                                             L.ptr(scales), L.ptr(opac), L.ptr(radii), _dp(means2d), _dp(depths), _dp(conics), st),
+            args = (N, L.ptr(means), L.ptr(quats), L.ptr(log_scales), L.ptr(logits), L.ptr(viewmat),
+                    L.ptr(Kmat), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"],
+                    L.ptr(scales), L.ptr(opac), L.ptr(radii), _dp(means2d), _dp(depths), _dp(conics))
+            L.check(lib.bds_project_view_fwd(*args, st) if bounds is None or N == 0 else lib.bds_project_view_fwd_blocks(*args, L.ptr(bounds), st),
                     "bds_project_view_fwd")
     # tile ordering
     LT = cfg.get("list_tile", LIST_TILE)
@@ -885,6 +889,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     lazy_loss = bool(kwargs.pop("lazy_loss", False))    # leave the loss value as out["loss_slots"] (losses.slots_value sums it on demand)
     defer_epilogue = bool(kwargs.pop("defer_epilogue", True))   # (see _DEFER_EPILOGUE)
     split_len, split_cap = kwargs.pop("split_len", None), kwargs.pop("split_cap", None)   # device-count compositors: long tiles strip by strip (_split)
+    block_bounds = kwargs.pop("block_bounds", None)    # bds_gaussian_block_bounds of the current parameters (the projection skips whole blocks)
     # the TV term over OTHER tensors than the transform's grids: graph_view's replayable view slices staging copies of ONE image's
     # grids (picked by a device-side index) while the regulariser runs over the full [n_img, ...] parameters (modules.py:445)
     tv_grids, tv_grid_grads = kwargs.pop("tv_grids", None), kwargs.pop("tv_grid_grads", None)
@@ -896,7 +901,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                radius_clip=float(opts["radius_clip"]), eps2d=float(opts["eps2d"]), tile_cull=bool(opts["tile_cull"]),
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws, g2d_buf=g2d_buf, tail_buf=tail_buf,
-               defer_epilogue=defer_epilogue, split_len=split_len, split_cap=split_cap,
+               defer_epilogue=defer_epilogue, split_len=split_len, split_cap=split_cap, block_bounds=block_bounds,
                defer_pose_sum=defer_pose_sum)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and (arena_rows >= 1 or grad_sink is not None):

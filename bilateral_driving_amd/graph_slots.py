@@ -46,6 +46,7 @@ def camera_centre(viewmat: Tensor) -> Tensor:
     return -(vm[:3, :3].transpose(0, 1) @ vm[:3, 3]).contiguous()
 
 
+BLOCK_BOUNDS = __import__("os").environ.get("BDS_BLOCK_BOUNDS", "1") == "1"   # the projection skips 256-row blocks no centre of which can be visible (include/bds.h bds_gaussian_block_bounds)
 GRAD_ROWS = __import__("os").environ.get("BDS_GRAD_ROWS", "1") == "1"   # the four small per-Gaussian gradients as one [N,16] row block (dist.FlatGradients(row_block=True); 0 = one array each)
 SPLIT_LIST_LEN = int(__import__("os").environ.get("BDS_SPLIT_LIST_LEN", "6144"))   # entries of a list-tile list from which its tiles go strip by strip
 

@@ -51,7 +51,7 @@ from . import _lib as L
 from .dist import ROW_NAMES, FlatGradients
 from .fused_view import LIST_TILE
 from . import harness as Hn
-from .graph_slots import GRAD_ROWS, FrameCapacities, ViewGraph, camera_centre as _camera_centre
+from .graph_slots import BLOCK_BOUNDS, GRAD_ROWS, FrameCapacities, ViewGraph, camera_centre as _camera_centre
 
 
 class FrameGraph(FrameCapacities):
@@ -63,10 +63,8 @@ class FrameGraph(FrameCapacities):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
-        ``overlap`` (V > 1): every view is captured as two graphs and ``step()`` replays the forwards -- projection, the
-        launch-latency-bound tile stage, SH, the compositor's forward, the bilateral forward -- on a second stream next to the previous
-        view's backward (measured on MI355X, 2 M Gaussians / six 1080p views: one stream 782 it/s, two 885; a forward reads only
-        parameters and writes its own buffers).
+        ``overlap`` (V > 1): every view is captured as two graphs and ``step()`` replays the forwards on a second stream next to the
+        previous view's backward (round 3: one stream 782 it/s, two 885; a forward reads only parameters and writes its own buffers).
         ``dynamic``: replayable views (module docstring); ``calib_cams``: the cameras the capacities are sized over (default: ``cams``).
         ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU).
         ``clear_grads=False``: the begin stage does not clear the parameters' gradient rows (221 us per six-view frame at 2 M
@@ -120,8 +118,7 @@ class FrameGraph(FrameCapacities):
             self.arena = self.flat.arena(self.names + [f"extra{i}" for i in range(len(extra_params))])
         n_row = sum(self.arena[k].numel() for k in ROW_NAMES) + (5 * self.N if getattr(self.flat, "row_block", False) else 0)
         self._tail = self.flat.flat[n_row:]
-        self.caps: list = [None] * self.V              # fused_view.ListCapacity per view slot
-        self.views: List[Optional[ViewGraph]] = [None] * self.V
+        self.caps, self.views = [None] * self.V, [None] * self.V      # fused_view.ListCapacity / ViewGraph per view slot
         self.begin_graph = self.begin_graph_rest = None
         self.n_captures = 0
         self._reprovision = False        # grow + capture again at the start of the next step()
@@ -142,6 +139,8 @@ class FrameGraph(FrameCapacities):
         self._defer_pose = self.fx is None and all(c.viewmat.requires_grad for c in self.cams)
         self._unions = [0] * self.V
         self.split_len, self.split_cap = [0] * self.V, [0] * self.V   # per slot: long tiles composited by four waves (graph_slots.calibrate)
+        # a bound per 256-row block, refreshed by the begin stage: a view's projection skips the blocks it can not see (densify.spatial_order)
+        self._bounds = torch.zeros((self.N + 255) // 256, 8, device=self.dev) if BLOCK_BOUNDS and self.N > 0 else None
         self.calibrate()
         self.capture()
 
@@ -151,7 +150,7 @@ class FrameGraph(FrameCapacities):
                   sh_degree=self.sh_degree, two_phase=True, lazy_loss=True, split_len=self.split_len[v], split_cap=self.split_cap[v],
                   # two streams: the transform's memory-bound last stage hides behind the other stream's compositor; folded into the
                   # compositor's backward it would lengthen the VALU-bound critical kernel (fused_view._DEFER_EPILOGUE)
-                  defer_epilogue=not self.overlap)
+                  defer_epilogue=not self.overlap, block_bounds=self._bounds)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
             if self.dynamic:        # the transform's grid gradient -> the slot's staging slices, the TV term -> the parameters' slices
@@ -198,12 +197,14 @@ class FrameGraph(FrameCapacities):
 
     def _begin_body(self, views=None, tail: bool = True) -> None:
         """Row-wise clear of the gradient rows the previous frame's ``views`` (default: all) wrote + (``tail``) the dense tail."""
+        lib, st, a = L.lib(), L.stream(), self.arena
+        if self._bounds is not None and (views is None or 0 in views):      # (the parameters moved since the last frame)
+            L.check(lib.bds_gaussian_block_bounds(self.N, L.ptr(self.params["means"]), L.ptr(self.params["log_scales"]), L.ptr(self._bounds), st),
+                    "bds_gaussian_block_bounds")
         if self.fx is not None:      # the exchange's book of reduced rows clears the dense rows (fx.begin_frame); here only the tail
             if self._tail.numel() and tail:
                 self._tail.zero_()
             return
-        lib, st = L.lib(), L.stream()
-        a = self.arena
         for v in (range(self.V) if views is None else views):
             ws = self.prep_ws[v]
             ids = ws[self._ids_off:self._ids_off + 4 * self.caps[v].nvis_cap].view(torch.int32)
@@ -388,8 +389,7 @@ class FrameGraph(FrameCapacities):
         return self.valid() if wait else None
 
     def _sum_pose_slots(self) -> None:
-        """Camera-pose gradients of all views: ONE reduction of the views' slots per frame (``viewmat.grad`` of every camera is a row of
-        the result) instead of one per view."""
+        """Camera-pose gradients of all views: ONE reduction of the views' slots per frame (``viewmat.grad`` = a row of the result)."""
         if self._defer_pose:
             torch.sum(self._tails[:, :L.POSE_GRAD_SLOTS].view(self.V, L.POSE_GRAD_SLOTS, 4, 4), dim=1, out=self._vm)
 

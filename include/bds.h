@@ -332,6 +332,23 @@ int bds_project_view_fwd(int64_t N, const float *means, const float *quats, cons
                          const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane,
                          float far_plane, float radius_clip, float *scales, float *opacities, int32_t *radii,
                          float *means2d, float *depths, float *conics, bds_stream_t stream);
+/* Block bounds: rows kept in spatial order (Morton order of the centres: the host side's densify.spatial_order) make every 256-row
+ * block a small box, and a camera then rejects most of the ~85 % of the Gaussians it does not see a BLOCK at a time.
+ * bds_gaussian_block_bounds: block_bounds [cdiv(N, 256), 8] = {lo.xyz, largest activated scale | hi.xyz, -} of the centres of rows
+ * [256 b, 256 (b + 1)); recompute whenever means / log_scales changed (once per frame).  The _blocks forms of the two projections
+ * below skip a block when no centre inside its box can come out visible (conservative: csrc/gs_math.h box_may_be_visible follows
+ * the tests of the projection itself) -- its rows get a culled Gaussian's outputs (radius 0, zeros) without being read; scales /
+ * opacities of such rows are not written.  Results are identical to the plain forms. */
+int bds_gaussian_block_bounds(int64_t N, const float *means, const float *log_scales, float *block_bounds, bds_stream_t stream);
+int bds_project_view_fwd_blocks(int64_t N, const float *means, const float *quats, const float *log_scales, const float *logits,
+                                const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane, float far_plane,
+                                float radius_clip, float *scales, float *opacities, int32_t *radii, float *means2d, float *depths,
+                                float *conics, const float *block_bounds, bds_stream_t stream);
+int bds_project_view_prepare_fwd_blocks(int64_t N, const float *means, const float *quats, const float *log_scales, const float *logits,
+                                        const float *viewmat, const float *K, int W, int H, float eps2d, float near_plane,
+                                        float far_plane, float radius_clip, float *scales, float *opacities, int32_t *radii,
+                                        float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss, void *prep_ws,
+                                        size_t prep_ws_bytes, const float *block_bounds, bds_stream_t stream);
 /* bds_project_view_fwd that also does the first launch of the tile stage (device-count form, C = 1): the number of visible Gaussians
  * per 256-Gaussian workgroup is left in prep_ws (bds_isect_prepare_workspace_bytes(1, N)), the stage's sort tables and
  * tiles_per_gauss [N] (may be NULL) are cleared.  Follow with bds_isect_prepare_dev(..., compact | 2, ...) on the SAME workspace.

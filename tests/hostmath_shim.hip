@@ -39,6 +39,12 @@ extern "C" void hm_project_fwd(int n, const float *means, const float *quats, co
   }
 }
 
+// the block bound of the one-view projection (bds_project_view_*_fwd_blocks): 1 = some centre of the box may come out visible
+extern "C" int hm_box_may_be_visible(const float *lo, const float *hi, float smax, const float *viewmat, const float *K, int W, int H,
+                                     float eps2d, float near_plane, float far_plane) {
+  return box_may_be_visible(lo, hi, smax, load_camera(viewmat, K), W, H, eps2d, near_plane, far_plane) ? 1 : 0;
+}
+
 extern "C" void hm_project_bwd(int n, const float *means, const float *quats, const float *scales, const float *viewmat,
                                const float *K, int W, int H, float eps2d, const int *radii, const float *v_means2d,
                                const float *v_depths, const float *v_conics, float *v_means, float *v_quats,

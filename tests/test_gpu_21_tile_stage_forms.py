@@ -107,3 +107,57 @@ def test_row_form_of_the_projection_outputs_changes_nothing(mods, monkeypatch, d
     for x, y, k in zip(a[4], b[4], sorted(res[True][4] and ["log_scales", "means", "opacity_logits", "quats", "sh"])):
         assert (x - y).abs().max() <= 1e-6 * max(1.0, float(y.abs().max())), k       # (atomics in the compositor's backward: order only)
     assert (a[5] - b[5]).abs().max() <= 1e-5 * max(1.0, float(b[5].abs().max()))
+
+
+@pytest.mark.parametrize("ordered", [True, False], ids=["spatial_order", "given_order"])
+@pytest.mark.parametrize("device_counts", [False, True])
+def test_block_bounds_skip_blocks_without_changing_anything(mods, ordered, device_counts):
+    """bds_gaussian_block_bounds + bds_project_view_{,prepare_}fwd_blocks: a projection that skips the 256-row blocks it can not see
+    leaves the same radii, lists, images and gradients as the one that reads every row -- with the rows in spatial order (where
+    most blocks go) and in the generator's order (where hardly any does), for cameras all round the rig."""
+    L, FV, GV, Hn = mods
+    dev = "cuda"
+    W, H, N = 960, 544, 150_000
+    p = Hn.synthetic_scene(N, seed=2, device=dev)
+    if ordered:
+        p = Hn.reorder_params(p, Hn.spatial_order(p["means"]))
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    bounds = torch.zeros((N + 255) // 256, 8, device=dev)
+    L.check(L.lib().bds_gaussian_block_bounds(N, L.ptr(p["means"]), L.ptr(p["log_scales"]), L.ptr(bounds), L.stream()), "bds_gaussian_block_bounds")
+    lo, hi = bounds[:, 0:3], bounds[:, 4:7]
+    blk = torch.arange(N, device=dev) // 256
+    assert bool((p["means"].detach() >= lo[blk]).all()) and bool((p["means"].detach() <= hi[blk]).all())
+    assert torch.allclose(bounds[:, 3], torch.zeros_like(bounds[:, 3]).scatter_reduce(0, blk, p["log_scales"].detach().exp().amax(1), "amax", include_self=False))
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(1, device=dev)]
+    gen = torch.Generator().manual_seed(4)
+    sky, target = torch.rand(H, W, 3, generator=gen).to(dev), torch.rand(H, W, 3, generator=gen).to(dev)
+    skipped = 0
+    for cam in Hn.ring_cameras(W, H, yaws_deg=(0.0, 100.0, -150.0), device=dev):
+        outs = []
+        for b in (None, bounds):
+            for t in list(p.values()) + grids:
+                t.grad = None
+            caps = None
+            if device_counts:
+                with torch.no_grad():
+                    ref = Hn.render_view(p, cam, grids, 0, sky)
+                caps = FV.ListCapacity(int(ref["info"]["n_isects"] * 1.3) + 100, int(ref["info"]["n_visible"] * 1.3) + 100)
+            out = Hn.train_view(p, cam, grids, 0, sky, target, caps=caps, block_bounds=b)
+            torch.cuda.synchronize()
+            M, nv = (caps.observed() if device_counts else (out["info"]["n_isects"], out["info"]["n_visible"]))
+            outs.append((out["radii"].clone(), _lists(out, M, nv), out["rgb"].clone(), out["info"]["means2d"].detach().clone(),
+                         {k: v.grad.clone() for k, v in p.items()}))
+        (ra, la, ia, ma, ga), (rb, lb, ib, mb, gb) = outs
+        assert torch.equal(ra, rb) and int((ra > 0).sum()) > 1000
+        for x, y, name in zip(la, lb, ("flatten_ranks", "visible_ids", "isect_offsets", "tiles_per_gauss")):
+            assert torch.equal(x, y), name
+        assert torch.equal(ia, ib)
+        vis = (ra.reshape(-1) > 0)
+        assert torch.equal(ma.reshape(-1, 2)[vis], mb.reshape(-1, 2)[vis]) and float(mb.reshape(-1, 2)[~vis].abs().max()) == 0.0
+        for k in ga:
+            assert (ga[k] - gb[k]).abs().max() <= 1e-6 * max(1.0, float(ga[k].abs().max())), k
+        # how many blocks the bound rejects for this camera: every row of a rejected block is culled
+        per_block = torch.zeros(bounds.shape[0], device=dev).scatter_add_(0, blk, vis.float())
+        skipped += int((per_block == 0).sum())
+    if ordered:
+        assert skipped > 1.5 * bounds.shape[0]      # (of 3 x the blocks: most of what the cameras do not see goes block-wise)

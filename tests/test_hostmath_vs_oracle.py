@@ -201,3 +201,47 @@ def test_axis_cell_is_slice_cell_with_the_last_node_folded_into_the_last_cell(hm
     np.testing.assert_array_equal(wa, wb)
     if g > 1 and n > 1:
         assert i0[-1] == g - 2 and f[-1] == 1.0 and x0[-1] == g - 1 and fx[-1] == 0.0     # the folded case really occurs: the last index
+
+
+def test_block_bound_never_rejects_a_box_that_holds_a_visible_gaussian(hm):
+    """csrc/gs_math.h box_may_be_visible (the bound behind bds_project_view_*_fwd_blocks) against project_one itself: whenever a box is
+    rejected, NO Gaussian with its centre inside the box and scales up to the box's maximum comes out of the projection with a
+    radius -- for boxes in front of, beside, behind and around the camera, near-plane straddlers and large splats included.  And the
+    bound does reject: most boxes well outside the frustum go."""
+    import ctypes
+    rng = np.random.default_rng(0)
+    W, H = 640, 360
+    f = 0.5 * W / np.tan(np.radians(35.0))
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
+    hm.hm_box_may_be_visible.restype = ctypes.c_int
+    n_rejected = n_boxes = n_visible_in_kept = 0
+    for trial in range(400):
+        yaw, pitch = rng.uniform(-np.pi, np.pi), rng.uniform(-0.3, 0.3)
+        cy_, sy_, cp_, sp_ = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+        R = (np.array([[1, 0, 0], [0, cp_, -sp_], [0, sp_, cp_]]) @ np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])).astype(np.float32)
+        t = rng.uniform(-3, 3, 3).astype(np.float32)
+        vm = np.eye(4, dtype=np.float32); vm[:3, :3] = R; vm[:3, 3] = t
+        centre = rng.uniform(-40, 40, 3).astype(np.float32)
+        if trial % 5 == 0:
+            centre = (R.T @ (np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-0.5, 1.0)], np.float32) - t)).astype(np.float32)  # around the camera
+        half = np.exp(rng.uniform(np.log(0.05), np.log(8.0), 3)).astype(np.float32)
+        lo, hi = centre - half, centre + half
+        smax = float(np.exp(rng.uniform(np.log(0.005), np.log(3.0))))
+        n = 600
+        means = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+        means[:8] = np.array([[lo[0] if k & 1 == 0 else hi[0], lo[1] if k & 2 == 0 else hi[1], lo[2] if k & 4 == 0 else hi[2]] for k in range(8)], np.float32)
+        scales = (smax * np.exp(rng.uniform(np.log(0.01), 0.0, (n, 3)))).astype(np.float32)
+        scales[::7] = smax
+        quats = rng.standard_normal((n, 4)).astype(np.float32)
+        radii = np.zeros(n, np.int32); m2 = np.zeros((n, 2), np.float32); d = np.zeros(n, np.float32); c = np.zeros((n, 3), np.float32); cp = np.zeros(n, np.float32)
+        hm.hm_project_fwd(n, fptr(means), fptr(quats), fptr(scales), fptr(vm), fptr(K), W, H, ctypes.c_float(0.3), ctypes.c_float(0.1),
+                          ctypes.c_float(1e10), ctypes.c_float(0.0), fptr(radii), fptr(m2), fptr(d), fptr(c), fptr(cp))
+        keep = hm.hm_box_may_be_visible(fptr(lo.astype(np.float32)), fptr(hi.astype(np.float32)), ctypes.c_float(np.float32(smax)), fptr(vm), fptr(K), W, H,
+                                        ctypes.c_float(0.3), ctypes.c_float(0.1), ctypes.c_float(1e10))
+        n_boxes += 1
+        if not keep:
+            n_rejected += 1
+            assert int((radii > 0).sum()) == 0, (trial, int((radii > 0).sum()), lo, hi, smax)
+        else:
+            n_visible_in_kept += int((radii > 0).any())
+    assert n_rejected > 0.45 * n_boxes and n_visible_in_kept > 0.1 * n_boxes, (n_rejected, n_visible_in_kept, n_boxes)
