@@ -97,6 +97,11 @@ def parse():
                     help="threads of the CPU baseline: the host's PHYSICAL cores by default (SURVEY.md 8d), stated in the line")
     ap.add_argument("--cpu-timeout", type=float, default=170.0)
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--exchange-probe-only", action="store_true", help="(child process of the default run) see exchange_probe_worker")
+    ap.add_argument("--no-exchange-probe", action="store_true",
+                    help="N = 1: skip the child process that runs the frame with the multi-GPU exchange's collectives really issued over "
+                         "RCCL at world size 1 (config.exchange_world1: ms per frame without an exchange, per view, per frame)")
+    ap.add_argument("--probe-timeout", type=float, default=240.0)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of --steps steps is run this many times (barrier + synchronize around each); the MEDIAN "
@@ -290,19 +295,135 @@ def _pair_stats(N, W, H, params=None):
     return mod.pair_stats(N, W, H, view=0, params=params)
 
 
+def build_scene(args, dev, rank):
+    """SURVEY.md 8(d)'s synthetic scene of the workload on ``dev`` (rank r's rig sits 1.5 m x r further along the road)."""
+    from bilateral_driving_amd import harness as Hn
+    wl = dict(WORKLOADS[args.workload])
+    N = args.gaussians or (1_000_000 if args.scene == "lidar" else wl["gaussians"])
+    W, H = args.width or wl["width"], args.height or wl["height"]
+    yaws = {"six": Hn.SIX_CAM_YAWS, "five": Hn.FIVE_CAM_YAWS, "one": (0.0,)}[wl["rig"]]
+    cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev, origin=(1.5 * rank, 0.0, 0.0))   # this rank's timestep of the drive
+    for cam in cams:   # the camera pose is learnable in the reference (trainers/base.py:328-329,399): its gradient stays live
+        cam.viewmat.requires_grad_(os.environ.get("BDS_BENCH_NO_POSE") != "1")   # (diagnostic switch)
+    params = Hn.synthetic_scene(N, seed=0, device=dev) if args.scene == "ring" else Hn.lidar_scene(N, seed=0, device=dev, opacity=args.lidar_opacity)
+    # the scene's rows in Morton order of the centres (densify.spatial_order, applied ONCE at load as a trainer would -- and again after
+    # densification steps: refinement_after(reorder=True)): the ~15 % of the rows a camera sees then form runs, and every list-driven
+    # kernel of a view moves whole cache lines.  --row-order given keeps the generator's own (random) order: the figure of rounds 1-4
+    if args.row_order == "spatial":
+        perm = Hn.spatial_order(params["means"])
+        params = {k: v[perm].contiguous() for k, v in params.items()}
+    for v in params.values():
+        v.requires_grad_(True)
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), levels=wl["levels"], device=dev)]
+    gen = torch.Generator().manual_seed(7)
+    # the sky colour comes from a trainable sky model in the reference: its gradient path stays live (SURVEY.md 8d, K12)
+    skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
+    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    return wl, N, W, H, yaws, cams, params, grids, skies, targets
+
+
+def _free_port():
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def exchange_probe_worker(args):
+    """Child process of the default N = 1 run: ONE rank, backend "nccl" (= RCCL), ``dist.force_collectives``: the workload's frame
+    without an exchange, with the per-view exchange (mask MAX + compact-row SUM all-reduce between every view's graphs) and with the
+    per-frame dense all-reduce -- every collective really issued.  A one-rank all-reduce moves nothing over xGMI: what this measures is
+    the exchange's OVERHEAD on a rank (enqueue, union-slot kernels, compact stores + row adds, RCCL's kernel launch), not a fabric."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    from bilateral_driving_amd import dist as D
+    from bilateral_driving_amd.graph_view import FrameGraph
+    D.force_collectives(True)
+    wl, N, W, H, yaws, cams, params, grids, skies, targets = build_scene(args, dev, 0)
+    V = min(args.views_per_step or len(cams), len(cams))
+    names = list(params.keys()) + [f"grid{i}" for i in range(len(grids))]
+    out = {"backend": dist.get_backend(), "world": 1, "steps": args.steps}
+
+    def timed(frame):
+        for _ in range(3):
+            assert frame.step() is True
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                frame.step(wait=False)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / args.steps * 1e3)
+        assert frame.valid()
+        return sorted(ts)[1]
+
+    def flat_grad():
+        return torch.cat([t.grad.reshape(-1) for t in list(params.values()) + grids]).clone()
+
+    frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=wl["factors"], img_indices=list(range(V)))
+    out["plain_ms_per_frame"] = timed(frame)
+    ref = flat_grad()
+    del frame
+    for mode, per_view in (("per_view", True), ("per_frame", False)):
+        flat = D.FlatGradients(list(params.values()) + grids, sparse_rows=True)
+        fx = D.FrameExchange(flat, names, per_view=per_view)
+        frame = FrameGraph(params, cams[:V], grids, skies[:V], targets[:V], factors=wl["factors"], img_indices=list(range(V)), exchange=fx)
+        ms = timed(frame)
+        n1 = D.ISSUED["all_reduce"]
+        assert frame.step() is True
+        got = flat_grad()
+        out[mode] = {"ms_per_frame": ms, "overhead_ms_per_frame": ms - out["plain_ms_per_frame"], "all_reduces_per_frame": D.ISSUED["all_reduce"] - n1,
+                     "payload_bytes_per_frame": fx.payload_bytes, "grad_rel_vs_plain": float((got - ref).norm() / ref.norm()),
+                     "exchange_rows_capacity": fx.cap}
+        del frame, fx, flat
+    out["all_reduces_issued"] = D.ISSUED["all_reduce"]
+    out["note"] = ("RCCL executed at world size 1: a one-rank all-reduce is a device copy, so this is the exchange's per-rank overhead "
+                   "(enqueue + union-slot kernels + compact stores / row adds + RCCL's launches); no xGMI number exists")
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps(out))
+
+
+def exchange_probe(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-probe-only", "--workload", args.workload, "--scene", args.scene,
+           "--steps", str(min(args.steps, 20)), "--row-order", args.row_order, "--lidar-opacity", args.lidar_opacity]
+    for flag, val in (("--gaussians", args.gaussians), ("--width", args.width), ("--height", args.height), ("--views-per-step", args.views_per_step)):
+        if val is not None:
+            cmd += [flag, str(val)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "BDS_FORCE_COLLECTIVES"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.probe_timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            return {"error": f"exit code {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+        return json.loads(lines[-1])
+    except Exception as e:  # timeout or failure: report it, never hang the benchmark
+        return {"error": f"{type(e).__name__} (limit {args.probe_timeout}s)"}
+
+
 def main():
+
     args = parse()
     if args.cpu_baseline_only:
         cpu_baseline_worker(args)
         return
+    if args.exchange_probe_only:
+        exchange_probe_worker(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run on 127.0.0.1)
-        import socket
         import subprocess
-        sock = socket.socket()
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-        sock.close()
+        port = _free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
@@ -317,8 +438,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # BDS_FORCE_COLLECTIVES=1 at N = 1: a process group of ONE rank over RCCL whose collectives are really issued (dist.force_collectives)
+    coll = world > 1 or os.environ.get("BDS_FORCE_COLLECTIVES", "0") == "1"
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if share:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
@@ -335,30 +460,10 @@ def main():
     for env, which in (("BDS_PAD_BWD_KB", 1), ("BDS_PAD_FWD_KB", 2), ("BDS_CELLS", 7), ("BDS_SCHED_BINS", 8)):   # (tuning hooks: cap the compositors' resident waves)
         if os.environ.get(env):
             L.set_option(which, int(os.environ[env]))
-    wl = dict(WORKLOADS[args.workload])
-    N = args.gaussians or (1_000_000 if args.scene == "lidar" else wl["gaussians"])
-    W, H = args.width or wl["width"], args.height or wl["height"]
-    yaws = {"six": Hn.SIX_CAM_YAWS, "five": Hn.FIVE_CAM_YAWS, "one": (0.0,)}[wl["rig"]]
-    cams = Hn.ring_cameras(W, H, yaws_deg=yaws, device=dev, origin=(1.5 * rank, 0.0, 0.0))   # this rank's timestep of the drive
+    wl, N, W, H, yaws, cams, params, grids, skies, targets = build_scene(args, dev, rank)
     V = min(args.views_per_step or len(cams), len(cams))
-    for cam in cams:   # the camera pose is learnable in the reference (trainers/base.py:328-329,399): its gradient stays live
-        cam.viewmat.requires_grad_(os.environ.get("BDS_BENCH_NO_POSE") != "1")   # (diagnostic switch)
-    params = Hn.synthetic_scene(N, seed=0, device=dev) if args.scene == "ring" else Hn.lidar_scene(N, seed=0, device=dev, opacity=args.lidar_opacity)
-    # the scene's rows in Morton order of the centres (densify.spatial_order, applied ONCE at load as a trainer would -- and again after
-    # densification steps: refinement_after(reorder=True)): the ~15 % of the rows a camera sees then form runs, and every list-driven
-    # kernel of a view moves whole cache lines.  --row-order given keeps the generator's own (random) order: the figure of rounds 1-4
-    if args.row_order == "spatial":
-        perm = Hn.spatial_order(params["means"])
-        params = {k: v[perm].contiguous() for k, v in params.items()}
-    for v in params.values():
-        v.requires_grad_(True)
-    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), levels=wl["levels"], device=dev)]
     factors = wl["factors"]
-    gen = torch.Generator().manual_seed(7)
-    # the sky colour comes from a trainable sky model in the reference: its gradient path stays live
-    skies = [torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True) for _ in cams]
-    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
-    dense = bool(args.dense_grads) and world == 1
+    dense = bool(args.dense_grads) and not coll
     # param.grad = slices of ONE flat buffer: the backward kernels write the rows of the Gaussians a view sees straight into it,
     # zero_grad clears exactly the rows the previous frame wrote (a view sees ~15 % of the scene); at N > 1 the rows travel in compact
     # per-view exchange buffers (dist.FrameExchange)
@@ -373,7 +478,7 @@ def main():
     with torch.no_grad():
         infos16 = [Hn.render_view(params, cams[v], grids, v, skies[v], factors=factors, list_tile=16)["info"] for v in range(V)]
         M16 = [i["n_isects"] for i in infos16]
-        vis_masks = [(i["radii"].reshape(-1) > 0) for i in infos16] if world > 1 else None
+        vis_masks = [(i["radii"].reshape(-1) > 0) for i in infos16] if coll else None
         del infos16
     torch.cuda.synchronize()
 
@@ -396,7 +501,7 @@ def main():
         except Exception as e:
             # (the per-view exchange puts collectives between captured graphs; should the runtime refuse that on this fabric, the frame
             # that replays exactly as on one GPU + one dense all-reduce still measures the path)
-            if world == 1:
+            if not coll:
                 raise
             if fx.per_view:
                 print(f"bench.py: WARNING: per-view exchange failed to build ({type(e).__name__}: {e}); falling back to --exchange frame", file=sys.stderr)
@@ -413,7 +518,7 @@ def main():
                       "timing the eager frame loop", file=sys.stderr)
                 torch.cuda.synchronize()
                 fx = FrameExchange(flat, fx_names, per_view=True)
-        if world > 1 and args.exchange == "auto" and frame is not None:
+        if coll and args.exchange == "auto" and frame is not None:
             # price the two exchanges from what this job measures: the ranks' unions per view, one rank's frame, the fabric
             from bilateral_driving_amd.dist import measure_busbw, plan_exchange, union_row_counts
             unions = union_row_counts(vis_masks)
@@ -487,20 +592,20 @@ def main():
     for r in range(max(args.repeats, 1)):
         stats.clear()
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(args.steps):
             step(args.warmup + r * args.steps + s)
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         reps.append(time.perf_counter() - t0)
         if frame is not None:   # the marks of the repeat's last frame (one pair per view), recorded inside the timed region
             dom_ms += frame.mark_samples("rasterize_bwd")
-    if world > 1:
+    if coll:
         t = torch.tensor(reps, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         reps = [float(x) for x in t.tolist()]
@@ -520,7 +625,7 @@ def main():
             alone += frame.mark_samples("rasterize_bwd")
         tsum = {"rasterize_bwd": (len(alone), sum(alone) / max(len(alone), 1))} if alone else {}
         # the TIMED path checked at this size, every run: one more replayed frame against one eager frame on the same parameters
-        if world == 1 and os.environ.get("BDS_BENCH_NO_SELFCHECK") != "1":
+        if not coll and os.environ.get("BDS_BENCH_NO_SELFCHECK") != "1":
             from bilateral_driving_amd.selfcheck import frame_against_eager
             try:
                 selfcheck = frame_against_eager(frame, params, cams[:V], grids, skies[:V], targets[:V], factors)
@@ -828,9 +933,10 @@ def main():
                                    ", device-side list counts, no host wait") if frame is not None else
                                   "autograd (forward, loss, loss.backward())",
                    "gradient_buffer": "dense tensors (autograd accumulation)" if dense else "flat, visible rows only",
-                   "allreduce_bytes_per_step": fx.payload_bytes if world > 1 else 0, "allreduce_dense_bytes": flat.nbytes if world > 1 else 0,
-                   "exchanges_per_step": fx.n_exchanges if world > 1 else 0,
-                   "exchange": None if world == 1 else dict(mode="view" if fx.per_view else "frame", chosen_by=args.exchange, plan=plan)},
+                   "allreduce_bytes_per_step": fx.payload_bytes if coll else 0, "allreduce_dense_bytes": flat.nbytes if coll else 0,
+                   "exchanges_per_step": fx.n_exchanges if coll else 0,
+                   "collectives_forced_at_world1": bool(coll and world == 1),
+                   "exchange": None if not coll else dict(mode="view" if fx.per_view else "frame", chosen_by=args.exchange, plan=plan)},
         "frame_valu_issue_frac": _frame_valu_issue(ms_per_step / V, args.workload) if (counters_apply and args.workload == "headline" and N == wl["gaussians"]) else None,
         "roofline": roofline,
         "roofline_composite": roofline_composite,
@@ -839,11 +945,14 @@ def main():
         "per_kernel_source": per_kernel_source,
         "selfcheck": selfcheck,
     }
+    if rank == 0 and not coll and not args.no_exchange_probe:
+        torch.cuda.empty_cache()
+        result["config"]["exchange_world1"] = exchange_probe(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
     if selfcheck is not None and not selfcheck["ok"]:
         sys.exit(3)      # a fast frame whose results differ from the eager frame's is not a result

@@ -15,6 +15,30 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+# Collectives at world size 1.  A one-rank all-reduce is the identity, so every guard below used to skip it -- and the RCCL call
+# sequence (uint8 MAX masks, async work handles next to the two-stream graph replay, captures next to RCCL's proxy thread) had never
+# executed on a one-GPU box.  ``force_collectives(True)`` (or BDS_FORCE_COLLECTIVES=1) makes an initialised process group of ONE rank
+# behave like a group of several: every collective of the exchange is really issued.  Gradients must then equal the no-exchange frame.
+_FORCE: Optional[bool] = None
+ISSUED = {"all_reduce": 0, "broadcast": 0, "bytes": 0}      # collectives this process has issued through this module
+
+
+def force_collectives(on: Optional[bool]) -> None:
+    """True / False: override; None: follow the environment (BDS_FORCE_COLLECTIVES=1)."""
+    global _FORCE
+    _FORCE = on
+
+
+def collectives_forced() -> bool:
+    import os
+    return bool(_FORCE) if _FORCE is not None else os.environ.get("BDS_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _all_reduce(t: Tensor, op, async_op: bool = False):
+    ISSUED["all_reduce"] += 1
+    ISSUED["bytes"] += t.numel() * t.element_size()
+    return dist.all_reduce(t, op=op, async_op=async_op)
+
 
 class FlatGradients:
     """One contiguous fp32 communication buffer for the gradients of a fixed parameter list.
@@ -148,10 +172,10 @@ class FlatGradients:
         The element-wise OR over the ranks is started asynchronously; the next ``all_reduce()`` then exchanges only the
         rows touched on at least one rank (a view sees ~15 % of the Gaussians, so with few ranks most of the 59 floats per
         Gaussian that a dense all-reduce would move are zeros on every rank).  The result is identical to the dense sum."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not _active():
             return
         self._union = touched.reshape(-1).to(torch.uint8).clone()
-        self._union_work = dist.all_reduce(self._union, op=dist.ReduceOp.MAX, async_op=True)
+        self._union_work = _all_reduce(self._union, dist.ReduceOp.MAX, async_op=True)
         self._clean = False
 
     def _all_reduce_rows(self, flat: Tensor) -> bool:
@@ -171,7 +195,7 @@ class FlatGradients:
         k = idx.numel()
         parts = [v.reshape(n_rows, -1).index_select(0, idx).reshape(-1) for v in row_views] + [v.reshape(-1) for v in other_views]
         comm = torch.cat(parts)
-        dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+        _all_reduce(comm, dist.ReduceOp.SUM)
         off = 0
         for v in row_views:
             w = v.reshape(n_rows, -1)
@@ -185,7 +209,7 @@ class FlatGradients:
 
     def all_reduce(self, average: bool = False, async_op: bool = False):
         """Sum (or average) the gradients over all ranks.  No-op for world size 1."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not _active():
             return None
         flat = self.pack()
         for p, v in zip(self.params, self._views):
@@ -200,7 +224,7 @@ class FlatGradients:
             self._dirty = None
             self._clean = False
         self.last_payload_bytes = flat.numel() * 4
-        self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        self._work = _all_reduce(flat, dist.ReduceOp.SUM, async_op=async_op)
         if not async_op and average:
             flat.div_(dist.get_world_size())
         return self._work
@@ -254,12 +278,13 @@ class FrameExchange:
         self.K = self.arena["sh"].shape[1]
         self.row_floats = 3 + 4 + 3 + 1 + self.K * 3
         self.world = dist.get_world_size() if _active() else 1
+        self.coll = _active()               # collectives are issued (world > 1, or one rank with ``force_collectives``)
         # per_view=False: the frame's gradients accumulate in place exactly as at world size 1 and ``end_frame`` sums the dense buffer over
         # the ranks ONCE (fewer bytes than the per-view exchanges when the ranks' unions approach the whole scene, none of them hidden:
         # ``plan_exchange`` prices the two)
         self.per_view = bool(per_view)
-        self.frame_reduce = self.world > 1 and not self.per_view and not force
-        self.active = bool(force) or (self.world > 1 and self.per_view)
+        self.frame_reduce = self.coll and not self.per_view and not force
+        self.active = bool(force) or (self.coll and self.per_view)
         self.headroom, self.n_buffers = float(headroom), int(n_buffers)
         n_row = sum(v.numel() for v in flat._views[:len(ROW_NAMES)])
         self._tail = flat.flat[n_row:] if (not self.active and flat.total > n_row) else None
@@ -314,7 +339,7 @@ class FrameExchange:
             self.flat.mark_list(info["visible_ids"])
             return
         mask = (info["radii"].reshape(-1) > 0).to(torch.uint8)
-        work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, async_op=True) if self.world > 1 else None
+        work = _all_reduce(mask, dist.ReduceOp.MAX, async_op=True) if self.coll else None
         self._union = (mask, work)
 
     def targets(self, visible_ids: Tensor):
@@ -424,7 +449,7 @@ class FrameExchange:
         """After view v's forward: start the MAX-all-reduce of its visibility mask (uint8 [N], reduced in place)."""
         self._smask = getattr(self, "_smask", {})
         self._smask[v] = mask
-        self._swork[v] = dist.all_reduce(mask, op=dist.ReduceOp.MAX, async_op=True) if self.world > 1 else None
+        self._swork[v] = _all_reduce(mask, dist.ReduceOp.MAX, async_op=True) if self.coll else None
 
     def static_targets(self, v: int) -> None:
         """Before view v's Gaussian half: union mask -> slot map, id list, cleared buffer rows, count (two launches)."""
@@ -442,7 +467,7 @@ class FrameExchange:
     def static_end_view(self, v: int) -> None:
         """After view v's Gaussian half: start the SUM-all-reduce of its compact buffer; add the PREVIOUS view's reduced rows."""
         buf = self._sbuf[v]
-        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+        work = _all_reduce(buf, dist.ReduceOp.SUM, async_op=True) if self.coll else None
         self.payload_bytes += buf.numel() * 4
         self.n_exchanges += 1
         self._spending.append((work, v))
@@ -467,8 +492,8 @@ class FrameExchange:
             self._static_retire()
         n_row = self.N * self.row_floats
         tail = self.flat.flat[n_row:]
-        if tail.numel() and self.world > 1:
-            dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+        if tail.numel() and self.coll:
+            _all_reduce(tail, dist.ReduceOp.SUM)
             self.payload_bytes += tail.numel() * 4
 
     def static_counts(self):
@@ -482,7 +507,7 @@ class FrameExchange:
         b, ids = self._cur
         self._cur = None
         buf = self._bufs[b]
-        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+        work = _all_reduce(buf, dist.ReduceOp.SUM, async_op=True) if self.coll else None
         self.payload_bytes += buf.numel() * 4
         self.n_exchanges += 1
         self._pending.append((work, b, ids))
@@ -510,15 +535,15 @@ class FrameExchange:
                 elif p.grad.data_ptr() != v.data_ptr():
                     v.copy_(p.grad)
                 p.grad = v
-            if self.world > 1:
-                dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+            if self.coll:
+                _all_reduce(tail, dist.ReduceOp.SUM)
                 self.payload_bytes += tail.numel() * 4
 
     def reduce_frame(self) -> None:
         """``per_view=False``: sum the whole flat gradient buffer over the ranks (on the current stream; RCCL orders it behind the frame's
         kernels).  Rows other ranks wrote are non-zero afterwards: the next ``begin_frame`` clears the buffer densely."""
         assert self.frame_reduce
-        dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
+        _all_reduce(self.flat.flat, dist.ReduceOp.SUM)
         self.flat._dirty, self.flat._clean = None, False
         self.payload_bytes, self.n_exchanges = self.flat.nbytes, 1
 
@@ -569,7 +594,10 @@ class FrameExchange:
             il = ids[ok].long()
             for k in ROW_NAMES:
                 dst[k].index_add_(0, il, src[k][ok])
-        self.flat.mark_list(ids)
+        # a COPY of the list: ``ids`` is buffer b's scratch, and b goes back to the free list now -- a later view of this same frame may
+        # take it and overwrite the list before the next begin_frame clears the rows it names (found by the third eager frame of
+        # tests/rccl_world1_worker.py: V = n_buffers = 3, view 2 re-used view 0's buffer and view 0's rows were never cleared)
+        self.flat.mark_list(ids.clone())
         self._free.append(b)
 
     def _check_overflow(self) -> None:
@@ -592,11 +620,11 @@ class FrameExchange:
 def reduce_densify_stats(grad_norm_accum: Tensor, vis_counts: Tensor, max_2d_size: Tensor) -> None:
     """Per-view densification statistics (models/gaussians/vanilla.py:163-191) become global:
     sums for the accumulated gradient norm / visibility counts, max for the screen-space size."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return
-    dist.all_reduce(grad_norm_accum, op=dist.ReduceOp.SUM)
-    dist.all_reduce(vis_counts, op=dist.ReduceOp.SUM)
-    dist.all_reduce(max_2d_size, op=dist.ReduceOp.MAX)
+    _all_reduce(grad_norm_accum, dist.ReduceOp.SUM)
+    _all_reduce(vis_counts, dist.ReduceOp.SUM)
+    _all_reduce(max_2d_size, dist.ReduceOp.MAX)
 
 
 def broadcast_randn(shape, device) -> Tensor:
@@ -604,12 +632,14 @@ def broadcast_randn(shape, device) -> Tensor:
     the same on every replica, or the replicas' Gaussians diverge at the first densification ("extra state")."""
     t = torch.randn(tuple(shape), device=device) if (not _active() or dist.get_rank() == 0) else torch.empty(tuple(shape), device=device)
     if _active():
+        ISSUED["broadcast"] += 1
         dist.broadcast(t, src=0)
     return t
 
 
 def _active() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group is up and its collectives are to be issued: several ranks, or ONE rank with ``force_collectives``."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or collectives_forced())
 
 
 def refinement_after_synced(model, step: int, optimizer, stats=None, verbose: bool = False) -> None:
@@ -640,17 +670,17 @@ def measure_busbw(device, nbytes: int = 256 << 20, iters: int = 3) -> float:
     import time
     n = dist.get_world_size()
     buf = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
-    dist.all_reduce(buf)                      # (connection set-up)
+    _all_reduce(buf, dist.ReduceOp.SUM)                      # (connection set-up)
     if buf.is_cuda:
         torch.cuda.synchronize(device)
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
-        dist.all_reduce(buf)
+        _all_reduce(buf, dist.ReduceOp.SUM)
     if buf.is_cuda:
         torch.cuda.synchronize(device)
     dt = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=device)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    _all_reduce(dt, dist.ReduceOp.MAX)
     return 2.0 * (n - 1) / n * nbytes / float(dt[0])
 
 
@@ -662,7 +692,7 @@ def dynamic_union_bound(n_vis_max: int, n_rows: int, device=None) -> int:
     total = int(n_vis_max)
     if _active():
         t = torch.tensor([total], dtype=torch.int64, device=device if device is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t, dist.ReduceOp.SUM)
         total = int(t[0])
     return min(total, int(n_rows))
 
@@ -674,7 +704,7 @@ def union_row_counts(masks: Iterable[Tensor]) -> List[int]:
     for m in masks:
         u = m.reshape(-1).to(torch.uint8).clone()
         if _active():
-            dist.all_reduce(u, op=dist.ReduceOp.MAX)
+            _all_reduce(u, dist.ReduceOp.MAX)
         out.append(int(u.sum()))
     return out
 

@@ -126,7 +126,7 @@ class FrameCapacities:
                     # any camera of any rank's sweep may meet any camera of another's: the union of a slot over the ranks is at most
                     # the SUM of the ranks' largest visible sets (and at most the scene) -- the same number on every rank
                     from .dist import dynamic_union_bound
-                    self._unions = [dynamic_union_bound(n_vis, self.N, self.dev if self.fx.world > 1 else None)] * self.V
+                    self._unions = [dynamic_union_bound(n_vis, self.N, self.dev if self.fx.coll else None)] * self.V
                 return
             for v, cam in enumerate(self.cams):
                 info = Hn.render_view(self.params, cam, self.grids, self.img_indices[v], self.skies[v], factors=self.factors,
@@ -135,8 +135,9 @@ class FrameCapacities:
                 self.split_len[v], self.split_cap[v] = split_len_for(info)
                 if self.fx is not None:
                     mask = (info["radii"].reshape(-1) > 0).to(torch.uint8)
-                    if self.fx.world > 1:
-                        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+                    if self.fx.coll:
+                        from .dist import _all_reduce
+                        _all_reduce(mask, dist.ReduceOp.MAX)
                     self._unions[v] = max(self._unions[v], int(mask.sum()))
 
     def _grow(self, v: int, M: int, n_vis: int) -> None:
@@ -183,11 +184,12 @@ class FrameCapacities:
     def _agree(self, overflowed: bool, wants_more: bool):
         """The ranks' decision: (any rank overflowed, any rank wants larger lists).  A list count is rank-local -- one rank capturing
         again while its peers step on would pair its warm-up frame's collectives with their frame's."""
-        if self.world == 1:
+        if not self.coll:
             return overflowed, wants_more
         import torch.distributed as dist
+        from .dist import _all_reduce
         flags = torch.tensor([int(overflowed), int(wants_more)], device=self.dev, dtype=torch.int32)
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        _all_reduce(flags, dist.ReduceOp.MAX)
         o, w = flags.tolist()
         return bool(o), bool(w)
 

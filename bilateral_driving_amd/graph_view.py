@@ -105,6 +105,7 @@ class FrameGraph(FrameCapacities):
         self.names = list(ROW_NAMES) + [f"grid{i}" for i in range(len(self.grids))]
         self.fx = exchange if (exchange is not None and exchange.active) else None
         self.world = exchange.world if exchange is not None else 1
+        self.coll = bool(exchange is not None and exchange.coll)     # collectives are issued (several ranks, or one with dist.force_collectives)
         # FrameExchange(per_view=False) at world size > 1: the frame runs exactly as on one GPU and step() ends with ONE dense all-reduce
         self._frame_fx = exchange if (exchange is not None and exchange.frame_reduce) else None
         if exchange is not None:
@@ -226,8 +227,8 @@ class FrameGraph(FrameCapacities):
     def _capturing(self, graph, pool):
         """``torch.cuda.graph`` for this frame's captures.  With an exchange other threads of the process issue HIP calls of their own
         while we capture (RCCL's proxy, the process group's watchdog): only THIS thread's unsafe calls may invalidate the capture."""
-        import torch.distributed as dist
-        if self.world > 1 or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        from .dist import _active
+        if self.coll or _active():
             return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
         return torch.cuda.graph(graph, pool=pool)
 

@@ -545,3 +545,76 @@ def test_capacity_protocol_of_replayable_view_slots_with_an_exchange(world):
     assert all(r[2] == min(10_000, sum(4000 + r for r in range(world))) for r in res)       # (world 3: capped at the scene)
     from bilateral_driving_amd.dist import dynamic_union_bound          # no process group: the rank's own maximum
     assert dynamic_union_bound(123, 1000) == 123 and dynamic_union_bound(5000, 1000) == 1000
+
+
+def _forced_world1_worker(port, q):
+    """ONE rank, gloo, ``force_collectives``: the per-view and the per-frame exchange issue every collective and give the plain sum."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from bilateral_driving_amd import dist as D
+    assert not D._active()
+    D.force_collectives(True)
+    assert D._active() and D.collectives_forced()
+    res = {}
+    for per_view in (True, False):
+        params = _fx_params()
+        flat = D.FlatGradients(params, sparse_rows=True)
+        fx = D.FrameExchange(flat, _FX_NAMES, headroom=1.6, per_view=per_view)
+        assert fx.coll and fx.world == 1 and fx.active == per_view and fx.frame_reduce == (not per_view)
+        n0 = D.ISSUED["all_reduce"]
+        outs = []
+        for frame in range(_FX_FRAMES):
+            fx.begin_frame()
+            for v in range(_FX_VIEWS):
+                ids, rows, grid_grad = _fx_view(0, frame, v)
+                radii = torch.zeros(1, _FX_N, dtype=torch.int32)
+                radii[0, ids.long()] = 3
+                fx.begin_view({"radii": radii, "visible_ids": ids})
+                if per_view:
+                    bufs, row_map = fx.targets(ids)
+                    slots = row_map[ids.long()].long()
+                    for k, r in rows.items():
+                        bufs[k][slots] = r
+                else:       # the frame accumulates in place, as at world size 1
+                    for k, r in rows.items():
+                        fx.arena[k].index_add_(0, ids.long(), r)
+                    for p_, v_ in zip(flat.params[:5], flat._views[:5]):
+                        p_.grad = v_
+                params[5].grad = grid_grad.clone() if params[5].grad is None else params[5].grad + grid_grad
+                fx.end_view()
+            if not per_view:
+                flat.pack()
+            fx.end_frame()
+            outs.append(flat.flat.clone().numpy())
+        res[per_view] = (outs, D.ISSUED["all_reduce"] - n0)
+    D.force_collectives(None)
+    assert not D._active()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_1_issue_every_collective_and_change_nothing():
+    """dist.force_collectives (BDS_FORCE_COLLECTIVES=1): what lets ONE GPU execute the RCCL call sequence of the multi-GPU exchange
+    (tests/test_gpu_24_rccl_world1.py); here the same switch over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    shapes = [tuple(t.shape) for t in _fx_params()]
+    for per_view in (True, False):
+        outs, issued = res[per_view]
+        # per view: mask MAX + rows SUM per view + the tail per frame; per frame: ONE dense all-reduce
+        assert issued == (_FX_FRAMES * (2 * _FX_VIEWS + 1) if per_view else _FX_FRAMES), (per_view, issued)
+        for frame in range(_FX_FRAMES):
+            ref = [torch.zeros(s) for s in shapes]
+            for v in range(_FX_VIEWS):
+                ids, rows, grid_grad = _fx_view(0, frame, v)
+                for i, k in enumerate(_FX_NAMES[:5]):
+                    ref[i].index_add_(0, ids.long(), rows[k])
+                ref[5] += grid_grad
+            ref = torch.cat([r.reshape(-1) for r in ref]).numpy()
+            assert abs(outs[frame] - ref).max() < 1e-5, (per_view, frame)

@@ -47,7 +47,7 @@ def _dense_reference(Hn, cam_sets, base, grids0, sky, target):
     return ref
 
 
-def _run_frames(Hn, cams, base, grids0, sky, target, force, frames=2):
+def _run_frames(Hn, cams, base, grids0, sky, target, force, frames=4):
     from bilateral_driving_amd.dist import FlatGradients, FrameExchange
     p = {k: t.clone().requires_grad_(True) for k, t in base.items()}
     grids = [g.clone().requires_grad_(True) for g in grids0]
