@@ -102,6 +102,8 @@ def parse():
                     help="N = 1: skip the child process that runs the frame with the multi-GPU exchange's collectives really issued over "
                          "RCCL at world size 1 (config.exchange_world1: ms per frame without an exchange, per view, per frame)")
     ap.add_argument("--probe-timeout", type=float, default=240.0)
+    ap.add_argument("--no-train-cadence", action="store_true",
+                    help="N = 1: skip config.train_cadence (one view per step; + optimizer step and densification statistics: the reference's loop)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of --steps steps is run this many times (barrier + synchronize around each); the MEDIAN "
@@ -322,6 +324,97 @@ def build_scene(args, dev, rank):
     return wl, N, W, H, yaws, cams, params, grids, skies, targets
 
 
+def train_cadence(args, params, cams, grids, skies, targets, factors, V, dev):
+    """The reference's TRAINING cadence at this workload's size (what `value` -- fwd + bwd of a frame of views, gradients accumulated,
+    view v + 1's forward next to view v's backward -- leaves out):
+
+      one_view_step         a frame of ONE view per step, nothing to overlap with (tools/train.py:252-283: one image per iteration);
+      train_step            that + the optimizer step over EVERY parameter + the densification statistics of the view
+                            (models/trainers/base.py:502-516 step, :222-226 one dense Adam over all groups, :279-297 statistics),
+                            with the dense one-pass FusedAdam and with optim.DeferredRowAdam (the SH rows step through the view's
+                            visible-id list, missed zero-gradient steps replayed in the next forward that sees the row: same numbers);
+      train_frame           the frame of all views + ONE optimizer step + the statistics of every view.
+
+    Every variant starts from a copy of the same parameters; the reference's learning rates (configs/omnire_ms_bilateral_extended.yaml
+    :39-52); a random camera of the rig per step where the frame has one view."""
+    from bilateral_driving_amd import _lib as L
+    from bilateral_driving_amd.graph_view import FrameGraph
+    from bilateral_driving_amd.optim import DeferredRowAdam, FusedAdam
+    steps = max(6, min(args.steps, 30))
+    N = params["means"].shape[0]
+    W, H = cams[0].width, cams[0].height
+    lrs = dict(means=1.6e-4, quats=1e-3, log_scales=5e-3, opacity_logits=5e-2)
+    gen = torch.Generator().manual_seed(11)
+    picks = torch.randint(0, len(cams), (steps + 3,), generator=gen).tolist()
+    out = {"steps": steps}
+
+    def variant(n_views, optim):
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        g = [x.detach().clone().requires_grad_(True) for x in grids]
+        sk = [s.detach().clone().requires_grad_(True) for s in skies[:n_views]]
+        opt = None
+        if optim is not None:
+            groups = [{"params": [p[k]], "lr": lr, "eps": 1e-15} for k, lr in lrs.items()] + [{"params": [x], "lr": 2e-3, "eps": 1e-15} for x in g]
+            if optim == "deferred":
+                groups.append({"params": [p["sh"]], "lr": 2.5e-3, "lr_b": 1.25e-4, "col_split": 3, "deferred_rows": True, "eps": 1e-15})
+                opt = DeferredRowAdam(groups, lr=0.0, eps=1e-15, consume_grads=True)
+            else:
+                groups.append({"params": [p["sh"]], "lr": 2.5e-3, "eps": 1e-15})
+                opt = FusedAdam(groups, lr=0.0, eps=1e-15, consume_grads=True)
+        dyn = n_views == 1
+        fr = FrameGraph(p, cams[:n_views], g, sk, targets[:n_views], factors=factors, img_indices=list(range(n_views)), dynamic=dyn,
+                        calib_cams=cams if dyn else None, clear_grads=opt is None,
+                        row_catchup=opt.catchup if optim == "deferred" else None)
+        stats = [torch.zeros(N, device=dev) for _ in range(3)]
+        lib, t_opt = L.lib(), []
+
+        def one(i):
+            if dyn:
+                k = picks[i]
+                fr.set_view(0, cams[k], targets[k], skies[k].detach(), k)
+            fr.step(wait=False)
+            if opt is None:
+                return
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if optim == "deferred":
+                opt.step(lists=fr.row_lists())
+            else:
+                opt.step()
+            for v in range(n_views):    # trainers/base.py:279-297 + gaussians/vanilla.py:163-191 for the view's absgrad
+                L.check(lib.bds_densify_stats(N, L.ptr(fr.g2d[v][1]), L.ptr(fr.views[v].out["radii"]), W, H, 1, max(W, H), 0, L.ptr(stats[0]),
+                                              L.ptr(stats[1]), L.ptr(stats[2]), L.stream()), "bds_densify_stats")
+            e1.record()
+            t_opt.append((e0, e1))
+        for i in range(3):
+            one(i)
+        torch.cuda.synchronize()
+        assert fr.valid()
+        t_opt.clear()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(3 + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = fr.valid()
+        res = {"iters_per_sec": n_views * steps / dt, "ms_per_step": dt / steps * 1e3, "valid": bool(ok)}
+        if t_opt:
+            res["optimizer_and_stats_ms_per_step"] = sum(a.elapsed_time(b) for a, b in t_opt) / len(t_opt)
+        if optim == "deferred":
+            res["sh_rows_behind"] = int((opt.state[p["sh"]]["last_step"] < opt._t).sum())
+        del fr, opt, p, g
+        torch.cuda.empty_cache()
+        return res
+
+    for name, (nv, optim) in (("one_view_step", (1, None)), ("train_step_dense_adam", (1, "dense")), ("train_step_deferred_adam", (1, "deferred")),
+                              ("train_frame_dense_adam", (V, "dense")), ("train_frame_deferred_adam", (V, "deferred"))):
+        try:
+            out[name] = variant(nv, optim)
+        except Exception as e:   # measurement tooling must never take the bench line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def _free_port():
     import socket
     sock = socket.socket()
@@ -535,23 +628,46 @@ def main():
             if os.environ.get("BDS_BENCH_ASSUME_BUSBW_GBPS"):   # (plumbing checks on a box without the fabric: price with this instead)
                 busbw = float(os.environ["BDS_BENCH_ASSUME_BUSBW_GBPS"]) * 1e9
             plan = plan_exchange(unions, N, fx.row_floats, flat.total - N * fx.row_floats, world, float(tt[0]), busbw)
-            if plan["per_view"]:
-                frame_fx, frame_frame = fx, frame
-                try:
-                    fx = FrameExchange(flat, fx_names, per_view=True)
-                    frame = build_frame(fx)
-                    for _ in range(2):
-                        assert frame.step() is True
-                    torch.cuda.synchronize()
-                    if os.environ.get("BDS_BENCH_FAIL_PER_VIEW") == "1":   # (plumbing check of the fallback below)
-                        raise RuntimeError("forced by BDS_BENCH_FAIL_PER_VIEW")
-                    del frame_frame
-                except Exception as e:   # (see above: keep the form that already ran)
-                    print(f"bench.py: WARNING: per-view exchange failed ({type(e).__name__}: {e}); staying with the per-frame all-reduce",
-                          file=sys.stderr)
-                    plan = dict(plan, per_view_failed=f"{type(e).__name__}: {e}")
+
+            def timed_with_collectives(fr):     # ms per frame, max over the ranks: the exchange's enqueue / kernel overhead is in it
+                for _ in range(2):
+                    assert fr.step() is True
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    fr.step(wait=False)
+                torch.cuda.synchronize()
+                t = torch.tensor([(time.perf_counter() - t0) / 4], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                assert fr.valid()
+                return float(t[0]) * 1e3
+            # the model prices the wire only; the per-view form also costs ~0.3 ms of enqueue + slot kernels per view on every rank
+            # (config.exchange_world1) -- so both forms are built and TIMED with their collectives, and the faster one is kept
+            frame_fx, frame_frame = fx, frame
+            plan["per_frame_measured_ms"] = timed_with_collectives(frame_frame)
+            try:
+                fx = FrameExchange(flat, fx_names, per_view=True)
+                frame = build_frame(fx)
+                plan["per_view_measured_ms"] = timed_with_collectives(frame)
+                if os.environ.get("BDS_BENCH_FAIL_PER_VIEW") == "1":   # (plumbing check of the fallback below)
+                    raise RuntimeError("forced by BDS_BENCH_FAIL_PER_VIEW")
+                plan["model_says_per_view"] = plan["per_view"]
+                plan["per_view"] = bool(plan["per_view_measured_ms"] < plan["per_frame_measured_ms"])
+                if not plan["per_view"]:
+                    del frame
                     fx, frame = frame_fx, frame_frame
                     flat._dirty, flat._clean = None, False
+                    for _ in range(2):      # (the gradient buffer's views belong to this frame again)
+                        assert frame.step() is True
+                else:
+                    del frame_frame
+            except Exception as e:   # (keep the form that already ran)
+                print(f"bench.py: WARNING: per-view exchange failed ({type(e).__name__}: {e}); staying with the per-frame all-reduce",
+                      file=sys.stderr)
+                plan = dict(plan, per_view=False, per_view_failed=f"{type(e).__name__}: {e}")
+                fx, frame = frame_fx, frame_frame
+                flat._dirty, flat._clean = None, False
         L.enable_timers(False)
 
     def step(s):
@@ -784,6 +900,15 @@ def main():
             api_its = f"{type(e).__name__}: {e}"
         finally:
             Marsh.uninstall(Hn.VanillaModel)
+    cadence = None
+    if rank == 0 and world == 1 and not args.no_train_cadence and frame is not None:
+        del frame
+        frame = True     # (only `frame is not None` is read below)
+        torch.cuda.empty_cache()
+        try:
+            cadence = train_cadence(args, params, cams, grids, skies, targets, factors, V, dev)
+        except Exception as e:   # measurement tooling must never take the bench line down
+            cadence = {"error": f"{type(e).__name__}: {e}"}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * V * args.steps / elapsed
 
@@ -927,6 +1052,10 @@ def main():
                    "n_visible_mean": nv_mean, "isects_mean": M_mean, "list_tile": FV.LIST_TILE,
                    "list_pairs_mean": list_pairs_mean, "parallelism": f"view-dp{world}",
                    "random_views_iters_per_sec": random_its,
+                   "train_cadence": cadence,
+                   "one_view_step_iters_per_sec": None if not cadence or "error" in cadence.get("one_view_step", {"error": 1}) else cadence["one_view_step"]["iters_per_sec"],
+                   "train_step_iters_per_sec": None if not cadence or "error" in cadence.get("train_step_deferred_adam", {"error": 1}) else cadence["train_step_deferred_adam"]["iters_per_sec"],
+                   "train_step_dense_adam_iters_per_sec": None if not cadence or "error" in cadence.get("train_step_dense_adam", {"error": 1}) else cadence["train_step_dense_adam"]["iters_per_sec"],
                    "step_driver": ("hipGraph replay (graph_view.FrameGraph): per view " +
                                    ("two captured graphs (forward + L1/TV loss value | backward), the forwards on a second stream next to "
                                     "the previous view's backward" if not args.no_overlap else "ONE captured graph = forward + L1/TV loss + backward") +

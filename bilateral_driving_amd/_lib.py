@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BDS_LIB") or os.path.join(_HERE, "libbds.so")    # (BDS_LIB: an A/B variant built by build.py --variant)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -142,6 +142,8 @@ _SIGS = {
     "bds_adam_step": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_adam_step_consume": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_adam_step_rows": (_i, [_i64, _i, _i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _i, _f]),
+    "bds_adam_rows_advance": (_i, [_i64, _f, _f, _i64, _i, _i, _f, _f, _i, _f, _f, _f, _f, _i64, _i, _f, _i, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, _f]),
     "bds_bilagrid_slice_feat_fwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f]),
     "bds_bilagrid_slice_feat_bwd": (_i, [_i64, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "bds_grid_tv_fwd": (_i, [_i64, _i, _i, _i, _i, _f, _fl, _f, _f]),

@@ -133,6 +133,139 @@ extern "C" int bds_adam_step_consume(int64_t n, float *param, float *grad, float
   return adam_step_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, true, stream);
 }
 
+// ---- deferred ("row-lazy") Adam: the SAME numbers as the dense pass, bytes proportional to the rows a step touches ---------------
+// The reference steps ONE dense torch.optim.Adam after every single-view iteration (tools/train.py:252-283 -> trainers/base.py:502-516,
+// optimizer at :222-226; gsplat's gradients are dense tensors whose rows are exact zeros for the ~85 % of the Gaussians the view does
+// not see).  A row with zero gradient still moves (m <- b1 m, v <- b2 v, p <- p - lr_t m^/(sqrt(v^)+eps)), so skipping it changes the
+// training; but its recurrence needs nothing except the per-step scalars.  For a parameter that only the VISIBLE rows of a view read
+// (the SH coefficients: evaluated by the record pack over the view's visible-id list) the missed steps can therefore be replayed, in
+// the same fp32 order, right before the row is next read:
+//   * last_step[row]  = the optimizer step this row's (p, m, v) are current for;
+//   * table[s % T]    = (lr_s / (1 - b1^s) for the columns < split, the same for the columns >= split, sqrt(1 - b2^s), -) written by
+//                       the step launch of step s (block 0), read by every later replay of step s;
+//   * advance(list, t): rows of the list with last < t replay the zero-gradient steps last+1 .. t-1 (or .. t without a gradient) from
+//     the table and, with a gradient, take step t from it; last = t.  Called (a) inside the view's forward, after the visible list is
+//     known and before the record pack reads the coefficients (target = the device-side clock, so that a captured hipGraph stays
+//     valid), (b) by the optimizer's step over the frame's lists, (c) densely (ids = NULL) before anything else reads the tensor
+//     (densification, checkpoints, evaluation) and at least every T - 1 steps.
+// The arithmetic is `adam_upd` below for both forms: bit-equal to bds_adam_step by construction (tests/test_gpu_10_optim.py).
+// A block owns floor(256 / row_floats) whole rows: the row's step word is read by all of its threads, a barrier, then written by one.
+namespace bds {
+
+__device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &vv, float step_size, float bc2_sqrt, float one_minus_b1,
+                                         float b2, float one_minus_b2, float eps, float weight_decay) {
+#pragma clang fp contract(off)
+  if (weight_decay != 0.f) gg = gg + weight_decay * pp;
+  mm = one_minus_b1 < 0.5f ? mm + one_minus_b1 * (gg - mm) : gg - (gg - mm) * (1.f - one_minus_b1);
+  vv = vv * b2 + (one_minus_b2 * gg) * gg;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  pp = pp + (-step_size) * (mm / denom);
+}
+
+// kVec = 4: row_floats % 4 == 0 and 16-byte aligned arrays: a thread owns four consecutive columns of a row (one float4 of p / m / v /
+// g each way; the replay loop reads its table entry once for the four)
+template <int kVec>
+__global__ __launch_bounds__(kOptBlock) void adam_rows_advance_kernel(
+    int64_t n_cap, const uint64_t *__restrict__ n_dev, const int32_t *__restrict__ ids, int64_t N, int row_floats, int split_col,
+    float *__restrict__ p, float *__restrict__ g, int consume, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ last,
+    int32_t *__restrict__ clock, int32_t t_host, int with_step, float4 *__restrict__ table, int T, float ss_a, float ss_b, float bc2s,
+    float one_minus_b1, float b2, float one_minus_b2, float eps, float weight_decay) {
+  const int tpr = row_floats / kVec;                   // threads per row
+  const int rpb = kOptBlock / tpr;                     // whole rows per block
+  const int lr = threadIdx.x / tpr, c = (threadIdx.x - lr * tpr) * kVec;
+  const int32_t t = with_step ? t_host : (clock != nullptr ? *clock : t_host);
+  int64_t n = n_cap;
+  if (n_dev != nullptr) { const int64_t nd = (int64_t)*n_dev; n = nd < n_cap ? nd : n_cap; }
+  if (ids == nullptr && n > N) n = N;
+  const int64_t groups = (n + rpb - 1) / rpb;
+  for (int64_t gi = blockIdx.x; gi < groups; gi += gridDim.x) {
+    const int64_t r = gi * rpb + lr;
+    int64_t row = -1;
+    if (lr < rpb && r < n) row = ids != nullptr ? (int64_t)ids[r] : r;
+    if (row >= N) row = -1;
+    const int32_t k0 = row >= 0 ? last[row] : t;
+    __syncthreads();                                     // every thread of the row has read its step word
+    if (row >= 0 && k0 < t) {
+      const int64_t e = row * row_floats + c;
+      float pp[kVec], mm[kVec], vv[kVec];
+      if (kVec == 4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(p + e), b4 = *reinterpret_cast<const float4 *>(m + e),
+                     c4 = *reinterpret_cast<const float4 *>(v + e);
+        pp[0] = a4.x; pp[1 % kVec] = a4.y; pp[2 % kVec] = a4.z; pp[3 % kVec] = a4.w;
+        mm[0] = b4.x; mm[1 % kVec] = b4.y; mm[2 % kVec] = b4.z; mm[3 % kVec] = b4.w;
+        vv[0] = c4.x; vv[1 % kVec] = c4.y; vv[2 % kVec] = c4.z; vv[3 % kVec] = c4.w;
+      } else {
+        pp[0] = p[e]; mm[0] = m[e]; vv[0] = v[e];
+      }
+      const int32_t stop = with_step ? t - 1 : t;
+      for (int32_t s = k0 + 1; s <= stop; ++s) {
+        const float4 h = table[s % T];
+#pragma unroll
+        for (int j = 0; j < kVec; ++j)
+          adam_upd(pp[j], 0.f, mm[j], vv[j], c + j < split_col ? h.x : h.y, h.z, one_minus_b1, b2, one_minus_b2, eps, weight_decay);
+      }
+      if (with_step) {
+        float gg[kVec];
+        if (kVec == 4) {
+          const float4 g4 = *reinterpret_cast<const float4 *>(g + e);
+          gg[0] = g4.x; gg[1 % kVec] = g4.y; gg[2 % kVec] = g4.z; gg[3 % kVec] = g4.w;
+          if (consume) *reinterpret_cast<float4 *>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          gg[0] = g[e];
+          if (consume) g[e] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kVec; ++j)
+          adam_upd(pp[j], gg[j], mm[j], vv[j], c + j < split_col ? ss_a : ss_b, bc2s, one_minus_b1, b2, one_minus_b2, eps, weight_decay);
+      }
+      if (kVec == 4) {
+        *reinterpret_cast<float4 *>(p + e) = make_float4(pp[0], pp[1 % kVec], pp[2 % kVec], pp[3 % kVec]);
+        *reinterpret_cast<float4 *>(m + e) = make_float4(mm[0], mm[1 % kVec], mm[2 % kVec], mm[3 % kVec]);
+        *reinterpret_cast<float4 *>(v + e) = make_float4(vv[0], vv[1 % kVec], vv[2 % kVec], vv[3 % kVec]);
+      } else {
+        p[e] = pp[0]; m[e] = mm[0]; v[e] = vv[0];
+      }
+      if (c == 0) last[row] = t;
+    }
+    __syncthreads();                                     // (the next group's rows are other rows, but keep the phases apart)
+  }
+  if (with_step && blockIdx.x == 0 && threadIdx.x == 0) {
+    table[t % T] = make_float4(ss_a, ss_b, bc2s, 0.f);   // (no replay of this launch reads slot t % T: every gap is < T)
+    if (clock != nullptr) *clock = t;
+  }
+}
+
+}  // namespace bds
+
+extern "C" int bds_adam_rows_advance(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int64_t N, int row_floats, int split_col,
+                                     float *param, float *grad, int consume, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                                     int32_t *clock_dev, int64_t step, int with_step, float *table, int table_steps, double lr_a,
+                                     double lr_b, double beta1, double beta2, double eps, double weight_decay, bds_stream_t stream) {
+  BDS_REQUIRE(n_capacity >= 0 && N >= 0 && row_floats >= 1 && row_floats <= kOptBlock && split_col >= 0 && table_steps >= 2);
+  BDS_REQUIRE(step >= 0 && step < (int64_t)1 << 31 && (with_step == 0 || (step >= 1 && grad != nullptr)));
+  BDS_REQUIRE(param && exp_avg && exp_avg_sq && last_step && table && aligned16(table));
+  BDS_REQUIRE(ids != nullptr || n_capacity <= N || n_dev != nullptr);
+  float ss_a = 0.f, ss_b = 0.f, bc2s = 1.f;
+  if (with_step) {      // scalars in double, rounded once: as bds_adam_step
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    ss_a = (float)(lr_a / bc1); ss_b = (float)(lr_b / bc1); bc2s = (float)sqrt(bc2);
+  }
+  const bool vec = row_floats % 4 == 0 && aligned16(param) && aligned16(exp_avg) && aligned16(exp_avg_sq) && (grad == nullptr || aligned16(grad));
+  const int rpb = kOptBlock / (vec ? row_floats / 4 : row_floats);
+  int64_t blocks = cdiv(n_capacity, (int64_t)rpb);
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+#define BDS_ADAM_ADVANCE(V)                                                                                                              \
+  hipLaunchKernelGGL((bds::adam_rows_advance_kernel<V>), dim3((unsigned)blocks), dim3(kOptBlock), 0, as_stream(stream), n_capacity, n_dev, \
+                     ids, N, row_floats, split_col, param, grad, consume, exp_avg, exp_avg_sq, last_step, clock_dev, (int32_t)step,          \
+                     with_step, reinterpret_cast<float4 *>(table), table_steps, ss_a, ss_b, bc2s, (float)(1.0 - beta1), (float)beta2,       \
+                     (float)(1.0 - beta2), (float)eps, (float)weight_decay)
+  if (vec) BDS_ADAM_ADVANCE(4); else BDS_ADAM_ADVANCE(1);
+#undef BDS_ADAM_ADVANCE
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
 // ---- per-step densification statistics --------------------------------------------------------------------------------
 // BasicTrainer.postprocess_per_train_step (models/trainers/base.py:279-297) + VanillaGaussians.after_train
 // (models/gaussians/vanilla.py:163-191) for one set of Gaussians, in one launch and without the boolean-mask indexing of the

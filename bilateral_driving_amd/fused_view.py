@@ -385,6 +385,10 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
         with L.timed("rasterize_fwd"):
             if f.colors is None:   # SH colours evaluated by the pack (visible Gaussians only); un-clamped values kept in list order
                 f.sh_rgb, f.sh_by_rank = _empty((max(n_vis, 1), 3), dev), True
+                if f.cfg.get("row_catchup") is not None:
+                    # a row-lazy optimizer (optim.DeferredRowAdam) brings the coefficient rows of THIS view's visible Gaussians up to
+                    # its current step before the pack reads them: (capacity, device count, device id list)
+                    f.cfg["row_catchup"](n_vis, f.nvis_dev, L.ptr(f.vis_ids))
                 L.check(lib.bds_splat_pack_sh_dev(n_vis, f.nvis_dev, L.ptr(f.vis_ids), f.sh.shape[1], f.sh_degree, L.ptr(f.means),
                                                   L.ptr(f.cam_pos), L.ptr(f.sh), _dp(f.means2d), _dp(f.conics), _dp(f.depths),
                                                   _dp(opac), L.ptr(f.radii), L.ptr(rec), L.ptr(f.sh_rgb), L.ptr(zr), L.ptr(tail),
@@ -890,6 +894,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
     defer_epilogue = bool(kwargs.pop("defer_epilogue", True))   # (see _DEFER_EPILOGUE)
     split_len, split_cap = kwargs.pop("split_len", None), kwargs.pop("split_cap", None)   # device-count compositors: long tiles strip by strip (_split)
     block_bounds = kwargs.pop("block_bounds", None)    # bds_gaussian_block_bounds of the current parameters (the projection skips whole blocks)
+    row_catchup = kwargs.pop("row_catchup", None)      # optim.DeferredRowAdam.catchup (device-count form with the SH colours in the pack)
     # the TV term over OTHER tensors than the transform's grids: graph_view's replayable view slices staging copies of ONE image's
     # grids (picked by a device-side index) while the regulariser runs over the full [n_img, ...] parameters (modules.py:445)
     tv_grids, tv_grid_grads = kwargs.pop("tv_grids", None), kwargs.pop("tv_grid_grads", None)
@@ -902,7 +907,7 @@ def train_view(params: Dict[str, Tensor], viewmat: Tensor, K: Tensor, width: int
                grad_arena=grad_arena, grad_sink=grad_sink, img_idx=None if img_idx is None else int(img_idx), arena_rows=arena_rows,
                list_tile=int(LIST_TILE if list_tile is None else list_tile), caps=caps, prep_ws=prep_ws, g2d_buf=g2d_buf, tail_buf=tail_buf,
                defer_epilogue=defer_epilogue, split_len=split_len, split_cap=split_cap, block_bounds=block_bounds,
-               defer_pose_sum=defer_pose_sum)
+               defer_pose_sum=defer_pose_sum, row_catchup=row_catchup)
     gs = [g if g.dim() == 5 else g[None] for g in grids]
     if grad_arena is not None and (arena_rows >= 1 or grad_sink is not None):
         # (with a sink the arena names the GRID gradients only: the per-Gaussian rows go to the sink's compact buffers)

@@ -152,6 +152,12 @@ class FrameCapacities:
         """[(M, visible)] per view as last written by the GPU (synchronise first for the current frame's values)."""
         return [c.observed() for c in self.caps]
 
+    def row_lists(self):
+        """[(capacity, device address of the count, device address of the int32 id list)] of the views' visible Gaussians as the last
+        ``step()`` left them in the prepare workspaces -- what a row-lazy optimizer steps over (``optim.DeferredRowAdam.step``)."""
+        return [(self.caps[v].nvis_cap, self.prep_ws[v].data_ptr() + self._nvis_off, self.prep_ws[v].data_ptr() + self._ids_off)
+                for v in range(self.V)]
+
     def _check_counts(self, raise_on_overflow: bool = False) -> bool:
         ok = True
         seen = [c.wanted() for c in self.caps]

@@ -59,7 +59,7 @@ class FrameGraph(FrameCapacities):
                  targets: Sequence[Tensor], factors: Sequence[int] = Hn.FACTORS_3, tv_weight: float = 0.01,
                  img_indices: Optional[Sequence[int]] = None, headroom: float = 1.5, list_tile: Optional[int] = None,
                  sh_degree: int = 3, extra_params: Sequence[Tensor] = (), overlap: bool = True, exchange=None, dynamic: bool = False,
-                 calib_cams: Optional[Sequence[Hn.Camera]] = None, clear_grads: bool = True):
+                 calib_cams: Optional[Sequence[Hn.Camera]] = None, clear_grads: bool = True, row_catchup=None):
         """params: the five per-Gaussian leaves (``dist.ROW_NAMES``); grids: per level [n_img,12,L,gy,gx] leaves; cams / skies /
         targets: one per view of the frame; ``img_indices[v]``: the grid image of view v (default v).  ``headroom``: list capacity =
         headroom x the counts of the calibration visit.
@@ -69,7 +69,9 @@ class FrameGraph(FrameCapacities):
         ``exchange``: a ``dist.FrameExchange`` over ``params`` + ``grids`` (multi-GPU).
         ``clear_grads=False``: the begin stage does not clear the parameters' gradient rows (221 us per six-view frame at 2 M
         Gaussians) nor the dense tail -- the caller's optimizer does, as it consumes them (``optim.FusedAdam(consume_grads=True)``
-        over EVERY parameter of the frame); a frame that ``step()`` reported invalid is cleared densely before the next one."""
+        over EVERY parameter of the frame); a frame that ``step()`` reported invalid is cleared densely before the next one.
+        ``row_catchup``: ``optim.DeferredRowAdam.catchup`` -- every view's forward brings the SH rows of its visible Gaussians up to
+        the optimizer's step before its record pack reads them; step the optimizer with ``opt.step(lists=frame.row_lists())``."""
         assert sorted(params.keys()) == sorted(ROW_NAMES), "params: means, quats, log_scales, opacity_logits, sh"
         self.params = {k: params[k] for k in ROW_NAMES}
         self.grids = list(grids)
@@ -78,6 +80,7 @@ class FrameGraph(FrameCapacities):
         self.dev = self.params["means"].device
         self.dynamic = bool(dynamic)
         self.clear_grads = bool(clear_grads) or exchange is not None
+        self.row_catchup = row_catchup
         self._stale = False              # clear_grads=False: the last frame was invalid, nobody consumed (and cleared) its gradients
         self.img_indices = list(range(self.V)) if img_indices is None else [int(i) for i in img_indices]
         if self.dynamic:       # every slot owns its inputs at fixed addresses; set_view() rewrites them
@@ -151,7 +154,7 @@ class FrameGraph(FrameCapacities):
                   sh_degree=self.sh_degree, two_phase=True, lazy_loss=True, split_len=self.split_len[v], split_cap=self.split_cap[v],
                   # two streams: the transform's memory-bound last stage hides behind the other stream's compositor; folded into the
                   # compositor's backward it would lengthen the VALU-bound critical kernel (fused_view._DEFER_EPILOGUE)
-                  defer_epilogue=not self.overlap, block_bounds=self._bounds)
+                  defer_epilogue=not self.overlap, block_bounds=self._bounds, row_catchup=self.row_catchup)
         if self.fx is not None:     # rows into view v's compact exchange buffer; the dense tail (grids) accumulates in place in .grad
             kw.update(grad_sink=self.fx.static_sink(v), grid_grads=None)
             if self.dynamic:        # the transform's grid gradient -> the slot's staging slices, the TV term -> the parameters' slices

@@ -30,6 +30,8 @@ class FusedAdam(torch.optim.Optimizer):
         lib, st = L.lib(), L.stream()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            if group.get("deferred_rows"):       # (DeferredRowAdam steps these through the views' visible-id lists)
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -63,6 +65,148 @@ class FusedAdam(torch.optim.Optimizer):
                            float(group["eps"]), float(group["weight_decay"]), int(state["step"]), st), "bds_adam_step")
                 if self.consume_grads and not consume:
                     p.grad.zero_()
+        return loss
+
+
+class DeferredRowAdam(FusedAdam):
+    """``FusedAdam`` whose groups marked ``deferred_rows=True`` are stepped ROW-LAZILY with the dense pass's numbers, bit for bit.
+
+    The reference steps one dense ``torch.optim.Adam`` after every single-view iteration
+    (/root/reference/project/tools/train.py:252-283 -> models/trainers/base.py:502-516, optimizer at :222-226): 28 bytes per
+    parameter float per step, 81 % of them SH coefficients of Gaussians the view never saw (their gradient rows are exact zeros, but a
+    zero-gradient row still moves: m <- b1 m, v <- b2 v, p <- p - lr_t m^/(sqrt(v^)+eps)).  A deferred parameter keeps, per row, the
+    step it is current for; the steps it missed are replayed -- same fp32 operations, same order, per-step lr and bias corrections from
+    a small device table -- when the row is next read (``catchup``: enqueued by the view's forward between the visible-id list and the
+    record pack, ``graph_view.FrameGraph(row_catchup=opt.catchup)``) and stepped from its gradient row by ``step(lists=...)`` over the
+    frame's visible-id lists (``FrameGraph.row_lists()``).  Adam's bytes per step are then proportional to the visible rows.
+
+    Only parameters that nothing but a view's list-driven kernels read may be deferred: the SH coefficients ([N,K,3], or the reference's
+    ``_features_dc`` [N,3] / ``_features_rest`` [N,K-1,3]).  Means / quats / scales decide visibility and the opacity is activated by
+    the projection pass over ALL rows: they stay dense.  ``flush()`` brings every row up to date -- call it before anything else reads
+    a deferred tensor (densification: ``before_refinement()``; checkpoints: ``state_dict()`` does; evaluation through another path);
+    it also runs by itself every ``table_steps - 2`` steps (the table is a ring).
+
+    Group keys: ``deferred_rows`` (bool); ``col_split`` / ``lr_b``: columns >= col_split of a row (the flattened trailing dimensions)
+    use ``lr_b`` instead of ``lr`` (one [N,16,3] tensor holding dc + rest: col_split = 3, lr_b = the rest's rate)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 consume_grads: bool = False, table_steps: int = 1024, dense_above: float = 0.6):
+        """``dense_above``: a step whose lists' capacities add up to at least this fraction of the rows runs as ONE pass over all rows."""
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, consume_grads=consume_grads)
+        self.dense_above = float(dense_above)
+        assert table_steps >= 8
+        self.table_steps = int(table_steps)
+        self._t = 0                      # steps taken by the deferred parameters
+        self._last_flush = 0
+        self._clock = None               # int32 [1] on the device: the step the deferred parameters are at (read by captured catch-ups)
+        for group in self.param_groups:
+            if group.get("deferred_rows"):
+                for p in group["params"]:
+                    self._ensure(p, group)
+
+    # ---- state ---------------------------------------------------------------------------------------------------------------------
+    def _deferred(self):
+        for group in self.param_groups:
+            if group.get("deferred_rows"):
+                for p in group["params"]:
+                    yield group, p
+
+    def _ensure(self, p, group):
+        L.require_gpu(p)
+        if p.dtype != torch.float32 or not p.is_contiguous() or p.dim() < 1:
+            raise RuntimeError("DeferredRowAdam expects contiguous float32 parameters [N, ...]")
+        N = p.shape[0]
+        rf = p.numel() // max(N, 1)
+        if not 1 <= rf <= 256:
+            raise RuntimeError(f"deferred rows of {rf} floats (1 .. 256 supported)")
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.tensor(float(self._t))
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if "last_step" not in st or st["last_step"].shape[0] != N:
+            # (after densification surgery: every row is current -- ``before_refinement`` flushed -- and so are the new ones)
+            st["last_step"] = torch.full((N,), self._t, device=p.device, dtype=torch.int32)
+        if "table" not in st:
+            st["table"] = torch.zeros(self.table_steps, 4, device=p.device, dtype=torch.float32)
+            st["hyper"] = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+        if self._clock is None:
+            self._clock = torch.full((1,), self._t, device=p.device, dtype=torch.int32)
+        if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].shape == p.shape):
+            raise RuntimeError("optimizer state does not match its parameter (after densification, re-create both)")
+        return st, N, rf
+
+    def _advance(self, group, p, n_cap, n_dev, ids, with_step: bool, clock: bool):
+        st, N, rf = self._ensure(p, group)
+        (b1, b2), eps, wd = st["hyper"]
+        split = int(group.get("col_split", rf))
+        g = None
+        if with_step:
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.shape != p.shape:
+                raise RuntimeError("a deferred parameter needs a contiguous dense .grad buffer (dist.FlatGradients)")
+        L.check(L.lib().bds_adam_rows_advance(int(n_cap), n_dev, ids, N, rf, split, L.ptr(p), None if g is None else g.data_ptr(),
+                                              int(self.consume_grads), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]),
+                                              L.ptr(self._clock) if (clock or with_step) else None, self._t, int(with_step), L.ptr(st["table"]),
+                                              self.table_steps, float(group["lr"]), float(group.get("lr_b", group["lr"])), float(b1), float(b2),
+                                              eps, wd, L.stream()), "bds_adam_rows_advance")
+
+    # ---- the three uses ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def catchup(self, n_cap: int, n_dev, ids) -> None:
+        """Bring the rows of a view's visible-id list (``ids``: device pointer to int32 [n_cap]; ``n_dev``: device pointer to the
+        count, or None) to the optimizer's current step -- read from the device-side clock, so a captured launch stays valid."""
+        ids = ids.data_ptr() if torch.is_tensor(ids) else ids
+        for group, p in self._deferred():
+            self._advance(group, p, n_cap, n_dev, ids, with_step=False, clock=True)
+
+    @torch.no_grad()
+    def flush(self) -> None:
+        """Every row of every deferred parameter up to the current step (dense pass; replays only what is missing)."""
+        for group, p in self._deferred():
+            self._advance(group, p, p.shape[0], None, None, with_step=False, clock=False)
+        self._last_flush = self._t
+
+    def before_refinement(self) -> None:
+        """Densification reads and re-allocates the parameters and their moments: make them current first."""
+        self.flush()
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
+
+    @torch.no_grad()
+    def step(self, closure=None, lists=None):
+        """``lists``: [(n_capacity, n_dev_ptr | None, ids)] -- the visible-id lists of the views whose gradients are in ``.grad``
+        (``FrameGraph.row_lists()``); a row listed twice steps once.  None: every row takes the step (the dense pass, same numbers)."""
+        loss = super().step(closure)          # the dense groups
+        deferred = list(self._deferred())
+        if not deferred:
+            return loss
+        for group, p in deferred:             # hyper-parameters other than lr are baked into the replay: a change flushes first
+            st, _, _ = self._ensure(p, group)
+            now = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+            if st["hyper"] != now:
+                self.flush()
+                st["hyper"] = now
+        self._t += 1
+        dense_step = False
+        for group, p in deferred:
+            self.state[p]["step"] += 1
+            if lists is None or sum(int(l[0]) for l in lists) >= self.dense_above * p.shape[0]:
+                # every row takes the step (rows that are behind replay first: the same numbers) -- also when the lists' capacities
+                # add up to most of the tensor (a frame of several views): one pass over whole rows beats one pass per list
+                self._advance(group, p, p.shape[0], None, None, with_step=True, clock=True)
+                dense_step = True
+            else:
+                for n_cap, n_dev, ids in lists:
+                    self._advance(group, p, n_cap, n_dev, ids.data_ptr() if torch.is_tensor(ids) else ids, with_step=True, clock=True)
+                if not lists:                 # (no view this step: the step's table entry and the clock still have to be written)
+                    self._advance(group, p, 0, None, None, with_step=True, clock=True)
+        if dense_step:
+            self._last_flush = self._t
+        elif self._t - self._last_flush >= self.table_steps - 2:
+            self.flush()
         return loss
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDS_ABI_VERSION 1
+#define BDS_ABI_VERSION 2   /* 2: round 5 changed exported signatures (split_len / split_cap, error_pinned) + the round-6 entries */
 
 #define BDS_OK 0
 #define BDS_EINVAL (-1)      /* null / misaligned pointer, bad shape or unsupported parameter */
@@ -625,6 +625,26 @@ int bds_adam_step_consume(int64_t n, float *param, float *grad, float *exp_avg, 
 int bds_adam_step_rows(int64_t n_rows, int width, int64_t grad_stride, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
                        double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int consume,
                        bds_stream_t stream);
+
+/* Deferred ("row-lazy") Adam for a parameter [N, row_floats] (row_floats <= 256) that only the rows of a view's visible-id list read
+ * -- the SH coefficients -- with the numbers of the dense pass, bit for bit: the reference steps one dense Adam after every
+ * single-view iteration (tools/train.py:252-283, models/trainers/base.py:222-226,502-516) and a row whose gradient is zero still
+ * moves, so the steps a row missed are REPLAYED (same fp32 operations, same order, per-step scalars from `table`) when the row is
+ * next needed.  last_step [N] i32: the step each row is current for; table [table_steps][4] floats (16-byte aligned): per-step
+ * (lr_s/(1-b1^s) for columns < split_col, the same for columns >= split_col with lr_b, sqrt(1-b2^s), -), slot s % table_steps
+ * written by the with_step launch of step s.  One call = "bring the rows of the list (ids [n_capacity] i32, entries < 0 skipped;
+ * NULL: rows 0 .. n_capacity-1; n_dev: optional device-side count) to step t":
+ *   with_step = 0: t = *clock_dev if clock_dev else `step`; rows with last < t replay the zero-gradient steps last+1 .. t.  Enqueued
+ *                  inside a view's forward (after the visible list, before the record pack) with clock_dev, so that a captured
+ *                  graph follows the optimizer; or densely before anything else reads the tensor / every table_steps-1 steps.
+ *   with_step = 1: t = `step` (1-based, after the increment); rows with last < t replay last+1 .. t-1 and take step t from grad
+ *                  [N, row_floats] (cleared as read when consume); rows already at t are skipped (a row listed by two views of a
+ *                  frame steps once); table[t % table_steps] is written and *clock_dev = t.
+ * The caller guarantees t - last < table_steps for every row it lists.  No reference counterpart (torch.optim.Adam is dense). */
+int bds_adam_rows_advance(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int64_t N, int row_floats, int split_col,
+                          float *param, float *grad, int consume, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                          int32_t *clock_dev, int64_t step, int with_step, float *table, int table_steps, double lr_a, double lr_b,
+                          double beta1, double beta2, double eps, double weight_decay, bds_stream_t stream);
 
 /* Per-step densification statistics of one set of Gaussians in one launch (models/trainers/base.py:279-297 +
  * models/gaussians/vanilla.py:163-191): grad2d [N,2] is info["means2d"].absgrad (or .grad) BEFORE the trainer's

@@ -31,7 +31,8 @@ def test_header_symbols_are_exported(libpath):
     for n in names:
         assert hasattr(h, n), f"{n} declared in include/bds.h but not exported by libbds.so"
     h.bds_abi_version.restype = ctypes.c_int
-    assert h.bds_abi_version() == 1
+    from bilateral_driving_amd import _lib as _L
+    assert h.bds_abi_version() == _L.ABI_VERSION == 2
     h.bds_strerror.restype = ctypes.c_char_p
     assert b"workspace" in h.bds_strerror(-2)
 

@@ -111,3 +111,76 @@ def test_densify_stats_match_the_reference_method(golden_dir):
             ref = torch.from_numpy(z[f"{name}{call}"]).cuda()
             got = getattr(st, name)
             assert torch.allclose(got, ref, rtol=2e-7, atol=0), (call, name, float((got - ref).abs().max()))
+
+
+@pytest.mark.parametrize("wd,table_steps", [(0.0, 1024), (0.0, 16), (0.01, 16)])
+def test_deferred_row_adam_is_bit_equal_to_the_dense_pass(wd, table_steps):
+    """optim.DeferredRowAdam: the SH rows step only when a view's list names them, the missed zero-gradient steps are replayed when the
+    row is next read (catchup) -- parameters and both moments equal the dense FusedAdam (= torch.optim.Adam, first test) BIT FOR BIT
+    after K steps of random visibility, a per-step lr schedule, rows listed by two views of a step, device-side counts, a ring table
+    that wraps (table_steps = 16: the automatic flush) and weight decay (a zero gradient is then not a zero update).  The reference's
+    cadence: one dense Adam step per single-view iteration (/root/reference/project/models/trainers/base.py:222-226,502-516)."""
+    from bilateral_driving_amd.optim import DeferredRowAdam, FusedAdam
+    N, K, steps = 5003, 16, 60
+    gen = torch.Generator().manual_seed(3)
+    sh0 = torch.randn(N, K, 3, generator=gen).cuda()
+    mu0 = torch.randn(N, 3, generator=gen).cuda()
+    # dense reference: dc and rest as two tensors with their own rates (the reference's _features_dc / _features_rest)
+    dc = sh0[:, :1].clone().contiguous().requires_grad_(True)
+    rest = sh0[:, 1:].clone().contiguous().requires_grad_(True)
+    mu_a = mu0.clone().requires_grad_(True)
+    oa = FusedAdam([{"params": [dc], "lr": 2.5e-3, "weight_decay": wd}, {"params": [rest], "lr": 2.5e-3 / 20, "weight_decay": wd},
+                    {"params": [mu_a], "lr": 1.6e-4}], lr=0.0, eps=1e-15)
+    sh = sh0.clone().requires_grad_(True)
+    mu_b = mu0.clone().requires_grad_(True)
+    ob = DeferredRowAdam([{"params": [sh], "lr": 2.5e-3, "lr_b": 2.5e-3 / 20, "col_split": 3, "deferred_rows": True, "weight_decay": wd},
+                          {"params": [mu_b], "lr": 1.6e-4}], lr=0.0, eps=1e-15, table_steps=table_steps)
+    sh.grad = torch.zeros_like(sh)
+    cap = 1500
+
+    def make_list():
+        n = int(torch.randint(200, 1200, (1,), generator=gen))
+        ids = torch.randperm(N, generator=gen)[:n].sort().values.to(torch.int32)
+        pad = torch.full((cap,), -1, dtype=torch.int32)
+        pad[:n] = ids
+        return pad.cuda(), torch.tensor([n], dtype=torch.int64).cuda(), ids.long().cuda()
+
+    for it in range(steps):
+        lists = [make_list() for _ in range(1 if it % 3 else 2)]
+        if it == 20:
+            lists = []                                    # a step without any view
+        # the view's forward: the listed rows are brought up to date before they are read
+        for ids, cnt, rows in lists:
+            ob.catchup(cap, cnt.data_ptr(), ids)
+            assert torch.equal(sh.detach()[rows, :1], dc.detach()[rows]) and torch.equal(sh.detach()[rows, 1:], rest.detach()[rows])
+        # the backward: gradient rows of the listed Gaussians only (dense zeros elsewhere, as gsplat's dense gradients)
+        g = torch.zeros(N, K, 3, device="cuda")
+        for ids, cnt, rows in lists:
+            g[rows] += torch.randn(rows.numel(), K, 3, generator=gen).cuda() * 0.01
+        if it % 7 == 5 and lists:
+            g[lists[0][2][:50]] = 0.0                     # visible rows whose gradient is exactly zero
+        dc.grad, rest.grad = g[:, :1].contiguous(), g[:, 1:].contiguous()
+        sh.grad.copy_(g)
+        gm = torch.randn(N, 3, generator=gen).cuda()
+        mu_a.grad, mu_b.grad = gm.clone(), gm.clone()
+        for grp_a in oa.param_groups:                     # the reference's schedulers rewrite group["lr"] every step
+            grp_a["lr"] *= 0.99
+        ob.param_groups[0]["lr"] *= 0.99; ob.param_groups[0]["lr_b"] *= 0.99; ob.param_groups[1]["lr"] *= 0.99
+        oa.step()
+        ob.step(lists=[(cap, cnt.data_ptr(), ids) for ids, cnt, rows in lists])
+    assert torch.equal(mu_a.detach(), mu_b.detach())
+    stale = int((ob.state[sh]["last_step"] < steps).sum())
+    assert table_steps == 16 or stale > 0                 # (rows no list has named since: still behind)
+    ob.flush()
+    assert int((ob.state[sh]["last_step"] != steps).sum()) == 0 and float(ob.state[sh]["step"]) == steps
+    for got, a, b in ((sh.detach(), dc.detach(), rest.detach()),
+                      (ob.state[sh]["exp_avg"], oa.state[dc]["exp_avg"], oa.state[rest]["exp_avg"]),
+                      (ob.state[sh]["exp_avg_sq"], oa.state[dc]["exp_avg_sq"], oa.state[rest]["exp_avg_sq"])):
+        assert torch.equal(got[:, :1], a) and torch.equal(got[:, 1:], b)
+    # every row at once (lists=None) is the dense pass through the same kernel
+    g = torch.randn(N, K, 3, generator=gen).cuda()
+    dc.grad, rest.grad = g[:, :1].contiguous(), g[:, 1:].contiguous()
+    sh.grad.copy_(g)
+    mu_a.grad, mu_b.grad = None, None
+    oa.step(); ob.step()
+    assert torch.equal(sh.detach()[:, :1], dc.detach()) and torch.equal(sh.detach()[:, 1:], rest.detach())

@@ -146,3 +146,66 @@ def test_replayed_training_loop_with_random_views_converges():
     print(f"[replayed loop] PSNR {p0:.2f} -> {p1:.2f} dB over {n_valid} valid steps, {frame.n_captures - n_cap} re-captures")
     assert n_valid >= 140 and p1 > p0 + 3.0, (p0, p1, n_valid)
     assert all(torch.isfinite(t).all() for t in p.values())
+
+
+def test_replayed_loop_with_the_deferred_row_optimizer_follows_the_dense_one():
+    """The reference's cadence -- ONE view, then one optimizer step over every parameter (tools/train.py:252-283 ->
+    models/trainers/base.py:502-516) -- with optim.DeferredRowAdam: the SH rows step through the view's visible-id list, the missed
+    zero-gradient steps are replayed inside the next forward that sees the row (FrameGraph(row_catchup=...)).  Bit-equality of the
+    update itself is tests/test_gpu_10's; here the whole loop: the same 60 steps with the dense FusedAdam and with the deferred one end
+    in the same parameters up to what two dense runs differ by (the float atomics of the composite backward), rows NO view has named
+    are behind until flush(), and every gradient is cleared behind each step."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.graph_view import FrameGraph
+    from bilateral_driving_amd.optim import DeferredRowAdam, FusedAdam
+    dev = torch.device("cuda", 0)
+    W, H, N, n_img, steps = 320, 192, 12_000, 6, 60
+    cams = Hn.ring_cameras(W, H, device=dev)
+    base = Hn.synthetic_scene(N, seed=2, device=dev)
+    grids0 = Hn.make_grids(n_img, seed=0, device=dev)
+    gen = torch.Generator().manual_seed(4)
+    sky = torch.rand(H, W, 3, generator=gen).to(dev)
+    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    picks = torch.randint(0, len(cams), (steps,), generator=gen).tolist()
+    lrs = dict(means=1.6e-4, quats=1e-3, log_scales=5e-3, opacity_logits=5e-2)
+
+    def run(deferred):
+        p = {k: v.clone().contiguous().requires_grad_(True) for k, v in base.items()}
+        grids = [g.clone().requires_grad_(True) for g in grids0]
+        groups = [{"params": [p[k]], "lr": lr, "eps": 1e-15} for k, lr in lrs.items()] + [{"params": [g], "lr": 2e-3, "eps": 1e-15} for g in grids]
+        if deferred:
+            groups.append({"params": [p["sh"]], "lr": 2.5e-3, "lr_b": 1.25e-4, "col_split": 3, "deferred_rows": True, "eps": 1e-15})
+            opt = DeferredRowAdam(groups, lr=0.0, eps=1e-15, consume_grads=True)
+        else:    # the same rates through the dense pass: dc and rest columns as two passes is not expressible -> one rate for both runs
+            groups.append({"params": [p["sh"]], "lr": 2.5e-3, "eps": 1e-15})
+            opt = FusedAdam(groups, lr=0.0, eps=1e-15, consume_grads=True)
+        if deferred:
+            opt.param_groups[-1]["lr_b"] = 2.5e-3
+        frame = FrameGraph(p, [cams[0]], grids, [sky], [targets[0]], img_indices=[0], dynamic=True, calib_cams=cams, clear_grads=False,
+                           row_catchup=opt.catchup if deferred else None)
+        behind = None
+        for it, v in enumerate(picks):
+            frame.set_view(0, cams[v], targets[v], sky, v)
+            assert frame.step() is True
+            if deferred:
+                opt.step(lists=frame.row_lists())
+            else:
+                opt.step()
+            if it % 20 == 0:
+                assert float(frame.flat.flat.abs().max()) == 0.0          # consumed AND cleared (the SH rows through the list)
+        if deferred:
+            behind = int((opt.state[p["sh"]]["last_step"] < steps).sum())
+            opt.flush()
+            assert int((opt.state[p["sh"]]["last_step"] != steps).sum()) == 0
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in p.items()}, behind, frame.n_captures
+
+    a, _, _ = run(False)
+    a2, _, _ = run(False)
+    b, behind, caps = run(True)
+    assert behind > 0 and caps == 1
+    for k in a:
+        noise = float((a[k] - a2[k]).norm() / a[k].norm())
+        diff = float((a[k] - b[k]).norm() / a[k].norm())
+        print(f"[deferred loop] {k}: dense vs dense {noise:.2e}, dense vs deferred {diff:.2e}")
+        assert diff <= max(10.0 * noise, 1e-5), (k, diff, noise)
