@@ -85,9 +85,10 @@ _SIGS = {
     "bds_splat_pack_sh_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
     "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
     "bds_rasterize_schedule_ints": (_i64, [_i, _i, _i]),
-    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _f]),
+    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i64, _f]),
+    "bds_rasterize_split_pool_ints": (_i64, [_i, _i, _i, _i, _i64, _i64]),
     "bds_rasterize_bwd_schedule_sort": (_i, [_i, _i, _i, _f, _f]),
-    "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _f]),
+    "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i64, _f]),
     "bds_sh_view_bwd_list_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_project_view_bwd_list_dev": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list_dev": (_i, [_i64, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f]),

@@ -298,7 +298,9 @@ __device__ __forceinline__ void rasterize_fwd_wave_body(
     int bid, int q0, int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec,
     const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten, float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
-    const ListGeom &lg, int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC, int item_in = -1) {
+    const ListGeom &lg, int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC, int item_in = -1, int ov_start = -1,
+    int ov_end = -1) {
+  // (ov_start / ov_end: the tile's list is [ov_start, ov_end) of `flatten` instead of its list tile's -- a long tile's REFINED list)
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;   // (the list length may live on the device: bds_rasterize_fwd_dev)
   const int n_tiles = tile_w * tile_h;
   const int item = item_in >= 0 ? item_in : xcd_contiguous(bid, C * n_tiles);
@@ -310,6 +312,7 @@ __device__ __forceinline__ void rasterize_fwd_wave_body(
   const float px = (float)j + 0.5f;
   int start, end;
   list_range<kCoarse>(offsets, item, C * n_tiles, cam, tx, ty, lg, M, start, end);
+  if (ov_start >= 0) { start = ov_start; end = ov_end; }
   // T[q] > 0: running transmittance; T[q] < 0: the pixel is finished and |T[q]| is its final transmittance
   // (pixels outside the image start finished).  One register instead of a flag + a value per pixel.
   float T[NQ], pyc[NQ];
@@ -491,7 +494,124 @@ __global__ __launch_bounds__(kLongBlock) void long_tiles_kernel(const int32_t *_
     }
     area[kSplitHead + t] = flag;
   }
-  if (threadIdx.x == 0) area[0] = min(tot, cap);
+  if (threadIdx.x == 0) { area[0] = min(tot, cap); area[1] = 0; area[2] = tot; }   // (area[1]: the refined lists' pool cursor; [2]: all long tiles)
+}
+
+// ---- refined lists of the long tiles ----------------------------------------------------------------------------------------------
+// A strip wave of a long tile used to walk the whole list of its 64-px list tile chunk by chunk (the front camera of a lidar-
+// initialised street: 36 355 entries = 568 dependent gathers per strip, 64 strips per list tile, forward and again backward) to keep the
+// ~1 in 4 entries that reach its 16-px tile.  Now, per view: (A) long_tiles_masks_kernel -- the sub-tiles of a long list tile share ITS
+// list: each of their workgroups takes one segment of it and leaves, per entry, the bit mask of the list tile's sub-tiles the entry
+// reaches (one record gather per entry instead of one per entry AND sub-tile); (B) long_tiles_refine_kernel -- one workgroup per long
+// tile reads its bit of those masks (coalesced, no gather), and writes the tile's own candidates -- same order -- into a pool behind
+// the long-tile list; the tile's four strips (forward AND backward) walk that.  Area behind the long-tile list:
+// [ref_off[cap] | ref_cnt[cap] | pool[pool_cap] | masks: uint16[M capacity]]; ref_cnt = -1: not refined (the pool ran out, the list
+// exceeds kRefMaxChunks x 64 entries, more long tiles than the capacity lists, or list tiles of more than 4 x 4 tiles): the strips walk
+// the list tile's list as before.  A refined tile's last_ids are positions in the pool -- forward and backward agree on that, nothing
+// else reads them.
+constexpr int kRefBlock = 1024, kRefMaxChunks = 2048, kMaskBlock = 256;
+__global__ __launch_bounds__(kMaskBlock) void long_tiles_masks_kernel(const float4 *__restrict__ rec, const int32_t *__restrict__ offsets,
+                                                                      const int32_t *__restrict__ flatten, ListGeom lg, int64_t M_host,
+                                                                      const uint64_t *__restrict__ M_dev, int tile_w, int tile_h, int cap,
+                                                                      const int32_t *__restrict__ area, uint16_t *__restrict__ masks) {
+  const int total = tile_w * tile_h, jl = (int)blockIdx.x;
+  if (jl >= area[0] || area[2] > cap) return;       // (a long tile the capacity does not list would leave its segment undone)
+  const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
+  const int tile = area[kSplitHead + total + jl], ty = tile / tile_w, tx = tile - ty * tile_w;
+  int start, end;
+  list_range<true>(offsets, tile, total, 0, tx, ty, lg, M, start, end);
+  // this workgroup's segment of the list: sub-tile ordinal o of the nsx x nsy sub-tiles of the list tile that exist
+  const int lx = tx / lg.div, ly = ty / lg.div, bx = lx * lg.div, by = ly * lg.div;
+  const int nsx = min(lg.div, tile_w - bx), nsy = min(lg.div, tile_h - by), nsub = nsx * nsy;
+  const int o = (ty - by) * nsx + (tx - bx);
+  const int len = end - start, seg = (len + nsub - 1) / nsub;
+  const int s0 = start + o * seg, s1 = min(s0 + seg, end);
+  for (int i = s0 + (int)threadIdx.x; i < s1; i += kMaskBlock) {
+    const int64_t r = flatten[i];
+    const float4 A = rec[r * 3], B = rec[r * 3 + 1], Cr = rec[r * 3 + 2];
+    uint32_t m = 0;
+    for (int dy = 0; dy < nsy; dy++)
+      for (int dx = 0; dx < nsx; dx++)
+        if (tile_candidate_hit(A, B, Cr, bx + dx, by + dy, tile_w, tile_h)) m |= 1u << (dy * lg.div + dx);
+    masks[i] = (uint16_t)m;
+  }
+}
+
+__global__ __launch_bounds__(kRefBlock) void long_tiles_refine_kernel(const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
+                                                                      ListGeom lg, int64_t M_host, const uint64_t *__restrict__ M_dev,
+                                                                      int tile_w, int tile_h, int cap, int32_t *__restrict__ area,
+                                                                      int pool_cap, const uint16_t *__restrict__ masks) {
+  __shared__ uint64_t bm[kRefMaxChunks];
+  __shared__ int pre[kRefMaxChunks];
+  __shared__ int wsum[kRefBlock / kWave];
+  __shared__ int s_base;
+  const int total = tile_w * tile_h, jl = (int)blockIdx.x;
+  if (jl >= area[0]) return;
+  int32_t *ref_off = area + kSplitHead + 2 * total, *ref_cnt = ref_off + cap, *pool = ref_cnt + cap;
+  const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
+  const int tile = area[kSplitHead + total + jl], ty = tile / tile_w, tx = tile - ty * tile_w;
+  int start, end;
+  list_range<true>(offsets, tile, total, 0, tx, ty, lg, M, start, end);
+  const int nchunks = (end - start + kWave - 1) / kWave;
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  constexpr int kWaves = kRefBlock / kWave;
+  if (nchunks > kRefMaxChunks || pool_cap <= 0 || area[2] > cap) {
+    if (tid == 0) ref_cnt[jl] = -1;
+    return;
+  }
+  const int bit = (ty % lg.div) * lg.div + (tx % lg.div);
+  for (int c = wv; c < nchunks; c += kWaves) {
+    const int i = start + c * kWave + lane;
+    const bool hit = i < end && ((masks[i] >> bit) & 1u);
+    const uint64_t m = __ballot(hit);
+    if (lane == 0) bm[c] = m;
+  }
+  __syncthreads();
+  // exclusive scan of the chunks' counts: a thread owns kRefMaxChunks / kRefBlock consecutive chunks
+  constexpr int kPer = kRefMaxChunks / kRefBlock;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int c = tid * kPer + k;
+    n += c < nchunks ? __popcll(bm[c]) : 0;
+  }
+  int inc = n;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == kWave - 1) wsum[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < kRefBlock / kWave; w++) {
+    if (w < wv) base += wsum[w];
+    tot += wsum[w];
+  }
+  int run = base + inc - n;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int c = tid * kPer + k;
+    if (c < nchunks) { pre[c] = run; run += __popcll(bm[c]); }
+  }
+  if (tid == 0) {
+    const int b = atomicAdd(area + 1, tot);
+    s_base = (b + tot <= pool_cap) ? b : -1;
+  }
+  __syncthreads();
+  const int pb = s_base;
+  if (pb < 0) {
+    if (tid == 0) ref_cnt[jl] = -1;
+    return;
+  }
+  for (int c = wv; c < nchunks; c += kRefBlock / kWave) {
+    const uint64_t m = bm[c];
+    if ((m >> lane) & 1ull) {
+      const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      pool[pb + pre[c] + pos] = flatten[start + c * kWave + lane];
+    }
+  }
+  if (tid == 0) { ref_off[jl] = pb; ref_cnt[jl] = tot; }
 }
 
 template <int CH, bool kStrip>
@@ -499,14 +619,21 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_split_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
-    int32_t *__restrict__ tile_work, const int32_t *__restrict__ area, int cap) {
+    int32_t *__restrict__ tile_work, const int32_t *__restrict__ area, int cap, int pool_cap) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   const int total = C * tile_w * tile_h, b = (int)blockIdx.x;
   if (b < 4 * cap) {
     const int jl = b >> 2;
     if (jl >= area[0]) return;
-    rasterize_fwd_wave_body<CH, true, kStrip, 1>(0, b & 3, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
-                                                 alphas, last_ids, lg, tile_work, sA, sB, sC, area[kSplitHead + total + jl]);
+    const int32_t *fl = flatten;
+    int ovs = -1, ove = -1;
+    if (pool_cap > 0) {      // the tile's refined list (long_tiles_refine_kernel)
+      const int32_t *ref_off = area + kSplitHead + 2 * total, *ref_cnt = ref_off + cap;
+      const int cnt = ref_cnt[jl];
+      if (cnt >= 0) { fl = ref_cnt + cap; ovs = ref_off[jl]; ove = ovs + cnt; }
+    }
+    rasterize_fwd_wave_body<CH, true, kStrip, 1>(0, b & 3, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, fl, render,
+                                                 alphas, last_ids, lg, tile_work, sA, sB, sC, area[kSplitHead + total + jl], ovs, ove);
   } else {
     const int bid = b - 4 * cap;
     if (area[kSplitHead + xcd_contiguous(bid, total)] >= 0) return;      // a long tile: its strips do it
@@ -529,7 +656,8 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, const ListGeom &lg,
-    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid, int q0 = 0, int item_in = -1) {
+    const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid, int q0 = 0, int item_in = -1, int ov_start = -1,
+    int ov_end = -1) {
   // (NQ = 4: the whole tile, four pixels per lane; NQ = 1: strip q0 of a LONG tile, one pixel per lane -- see rasterize_fwd_split_kernel)
   const int64_t M = M_dev ? (int64_t)*M_dev : M_host;
   const int n_tiles = tile_w * tile_h;
@@ -540,6 +668,7 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
   const int lane = threadIdx.x;
   int start, end;
   list_range<kCoarse>(offsets, item, C * n_tiles, cam, tx, ty, lg, M, start, end);
+  if (ov_start >= 0) { start = ov_start; end = ov_end; }     // (a long tile's refined list: see long_tiles_refine_kernel)
   if (!kEpi && end <= start) return;   // (kEpi: the tile's pixels still owe their sky gradient)
   const int j = tx * kTile + (lane & 15);
   const float px = (float)j + 0.5f;
@@ -718,7 +847,7 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg,
-    const int32_t *__restrict__ area, int cap) {
+    const int32_t *__restrict__ area, int cap, int pool_cap) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   const EdEpilogue none{};
@@ -726,9 +855,16 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
   if (b < 4 * cap) {
     const int jl = b >> 2;
     if (jl >= area[0]) return;
-    rasterize_bwd_wave_body<CH, ABS, true, false, false, 1>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
+    const int32_t *fl = flatten;
+    int ovs = -1, ove = -1;
+    if (pool_cap > 0) {      // the forward refined this tile's list: its last_ids are positions in the pool
+      const int32_t *ref_off = area + kSplitHead + 2 * total, *ref_cnt = ref_off + cap;
+      const int cnt = ref_cnt[jl];
+      if (cnt >= 0) { fl = ref_cnt + cap; ovs = ref_off[jl]; ove = ovs + cnt; }
+    }
+    rasterize_bwd_wave_body<CH, ABS, true, false, false, 1>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, fl, alphas,
                                                             last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, 0, b & 3,
-                                                            area[kSplitHead + total + jl]);
+                                                            area[kSplitHead + total + jl], ovs, ove);
   } else {
     const int bid = b - 4 * cap;
     const int item = pick_item(tile_order, bid, total);
@@ -1030,7 +1166,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                               const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
                               int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr, bool binned = false,
-                              int split_len = 0, int split_cap = 0) {
+                              int split_len = 0, int split_cap = 0, int64_t split_pool = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -1053,9 +1189,19 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
       BDS_REQUIRE(C == 1 && tile_work && binned && split_cap > 0);
       const int total = tile_w * tile_h, cap = split_cap < total ? split_cap : total;
       int32_t *area = tile_work + split_area_offset(total);
+      BDS_REQUIRE(split_pool >= 0 && split_pool < ((int64_t)1 << 31));
       hipLaunchKernelGGL(long_tiles_kernel, dim3(1), dim3(kLongBlock), 0, st, isect_offsets, lg, M, M_dev, tile_w, tile_h, split_len, cap, area);
+      if (split_pool > 0 && lg.div > 4) split_pool = 0;     // (16-bit sub-tile masks: list tiles of at most 4 x 4 tiles are refined)
+      if (split_pool > 0) {
+        uint16_t *masks = reinterpret_cast<uint16_t *>(area + kSplitHead + 2 * total + 2 * cap + split_pool);
+        hipLaunchKernelGGL(long_tiles_masks_kernel, dim3((unsigned)cap), dim3(kMaskBlock), 0, st, rec, isect_offsets, flatten, lg, M, M_dev, tile_w,
+                           tile_h, cap, area, masks);
+        hipLaunchKernelGGL(long_tiles_refine_kernel, dim3((unsigned)cap), dim3(kRefBlock), 0, st, isect_offsets, flatten, lg, M, M_dev, tile_w,
+                           tile_h, cap, area, (int)split_pool, masks);
+      }
       hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3((unsigned)(4 * cap + total)), dim3(kWave), 0, st, C, M, M_dev, rec,
-                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, area, cap);
+                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, area, cap,
+                         (int)split_pool);
     } else BDS_FWD(4, true);
   } else {
     if (CH == 1) BDS_FWD(1, false);
@@ -1078,15 +1224,23 @@ extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, co
 extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                                     int32_t *last_ids, int32_t *tile_order, int split_len, int split_cap, bds_stream_t stream) {
-  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0);
+                                     int32_t *last_ids, int32_t *tile_order, int split_len, int split_cap, int64_t split_pool,
+                                     bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0 && split_pool >= 0);
   // tile_order (optional, bds_rasterize_schedule_ints words): the compositing waves leave the backward's schedule themselves --
   // binned form (option 8, default; header cleared by the record pack in front), or their tiles' keys for bds_rasterize_bwd_schedule_sort
   const bool binned = option_get(kOptSchedBins) != 0;
   return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
                             isect_offsets, flatten, render, alphas, last_ids, stream,
                             !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned, split_len,
-                            split_cap);
+                            split_cap, split_pool);
+}
+
+extern "C" int64_t bds_rasterize_split_pool_ints(int C, int tile_w, int tile_h, int split_cap, int64_t split_pool, int64_t M_capacity) {
+  if (C < 1 || tile_w < 1 || tile_h < 1 || split_cap < 0 || split_pool < 0 || M_capacity < 0) return 0;
+  const int64_t total = (int64_t)C * tile_w * tile_h, cap = split_cap < total ? split_cap : total;
+  // [ref_off | ref_cnt | pool | uint16 masks[M_capacity]] behind bds_rasterize_schedule_ints words
+  return split_pool > 0 ? 2 * cap + split_pool + (M_capacity + 1) / 2 : 0;
 }
 
 extern "C" int64_t bds_rasterize_schedule_ints(int C, int tile_w, int tile_h) {
@@ -1110,7 +1264,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                               const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
                               const float *v_render, const float *v_alphas, float *v_records, int absgrad,
                               const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr, int split_len = 0,
-                              int split_cap = 0) {
+                              int split_cap = 0, int64_t split_pool = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
   BDS_REQUIRE(tile_size == kTile);
   ListGeom lg;
@@ -1149,13 +1303,14 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     BDS_REQUIRE(C == 1 && tile_order && option_get(kOptSchedBins) != 0 && split_cap > 0);
     const int total = tile_w * tile_h, cap = split_cap < total ? split_cap : total;
     const int32_t *area = tile_order + split_area_offset(total);
+    if (lg.div > 4) split_pool = 0;      // (as the forward: no refined lists for list tiles of more than 4 x 4 tiles)
     const dim3 sgrid((unsigned)(4 * cap + total));
     if (absgrad)
       hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, true>), sgrid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
-                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap);
+                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap, (int)split_pool);
     else
       hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, false>), sgrid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
-                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap);
+                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap, (int)split_pool);
   } else if (absgrad) {
     if (lg.div > 1) BDS_BWD_CH(true, true);
     else BDS_BWD_CH(true, false);
@@ -1182,11 +1337,12 @@ extern "C" int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacit
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, const float *alphas,
                                      const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records,
-                                     int absgrad, const int32_t *tile_order, int split_len, int split_cap, bds_stream_t stream) {
-  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0);
+                                     int absgrad, const int32_t *tile_order, int split_len, int split_cap, int64_t split_pool,
+                                     bds_stream_t stream) {
+  BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0 && split_pool >= 0 && split_pool < ((int64_t)1 << 31));
   return rasterize_bwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
                             isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream, nullptr,
-                            split_len, split_cap);
+                            split_len, split_cap, split_pool);
 }
 
 extern "C" int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,

@@ -156,19 +156,23 @@ class _Front:
 _VIS_CAPACITY: Dict[tuple, int] = {}   # visible-Gaussian count seen per configuration: the splat records are provisioned before the wait
 
 
+SPLIT_POOL_PER_TILE = int(os.environ.get("BDS_SPLIT_POOL_PER_TILE", "4096"))   # refined-list pool: int32 words per long tile of the capacity (0 = no refinement)
+
+
 def _split(cfg: dict, list_tile: int, n_tiles: int, have_schedule: bool):
-    """(split_len, split_cap) of the device-count compositors (include/bds.h): tiles whose list holds at least split_len entries --
-    at most split_cap of them -- are composited by four waves, strip by strip.  (0, 0) = off.  ``cfg["split_len"]`` /
-    ``cfg["split_cap"]`` (graph_view sets them per view slot from the calibration visit's lists) or ``BDS_SPLIT_LEN`` /
-    ``BDS_SPLIT_CAP`` (A/B sessions, tests; default capacity: every tile).  Needs the backward's schedule buffer (the long-tile list
-    lives behind it): a forward without one is not split."""
+    """(split_len, split_cap, split_pool) of the device-count compositors (include/bds.h): tiles whose list holds at least split_len
+    entries -- at most split_cap of them -- are composited by four waves, strip by strip, over their own REFINED candidate lists (a
+    pool of split_pool words behind the schedule).  (0, 0, 0) = off.  ``cfg["split_len"]`` / ``cfg["split_cap"]`` (graph_view sets them
+    per view slot from the calibration visit's lists) or ``BDS_SPLIT_LEN`` / ``BDS_SPLIT_CAP`` (A/B sessions, tests; default capacity:
+    every tile).  Needs the backward's schedule buffer (the long-tile list lives behind it): a forward without one is not split."""
     if list_tile <= TILE or not have_schedule:
-        return 0, 0
+        return 0, 0, 0
     n = int(cfg.get("split_len") or os.environ.get("BDS_SPLIT_LEN", "0"))
     if n <= 0:
-        return 0, 0
+        return 0, 0, 0
     cap = int(cfg.get("split_cap") or os.environ.get("BDS_SPLIT_CAP", "0")) or n_tiles
-    return n, max(1, min(cap, n_tiles))
+    cap = max(1, min(cap, n_tiles))
+    return n, cap, min(cap * SPLIT_POOL_PER_TILE, (1 << 31) - 1)
 
 
 _TILE_OPTIONS_READ = False
@@ -488,7 +492,9 @@ class _FusedView(torch.autograd.Function):
         # no launch at all; bds_set_option(8, 0): their keys, which the sort call below orders)
         sched_buf = None
         if f.m_dev is not None and any(ctx.needs_input_grad[1:]) and _SCHEDULE_IN_FORWARD and ops._BWD_SCHEDULE:
-            sched_buf = _empty((int(lib.bds_rasterize_schedule_ints(1, f.tw, f.th)),), dev, torch.int32)
+            sp = _split(cfg, f.list_tile, f.tw * f.th, True)
+            sched_buf = _empty((int(lib.bds_rasterize_schedule_ints(1, f.tw, f.th)) + int(lib.bds_rasterize_split_pool_ints(1, f.tw, f.th, sp[1], sp[2], f.M)),),
+                               dev, torch.int32)
         ctx.split_ok = sched_buf is not None     # (the long-tile list of a split launch lives behind the schedule words)
         rec, render, alphas, last_ids = _composite(f, opac, images, v_rec_all, sched_buf, getattr(ctx, "tail", None))
         tiles_wh = (f.tw, f.th)
@@ -619,7 +625,7 @@ class _FusedView(torch.autograd.Function):
         # function -- to the compositor's backward wherever the configuration allows it (include/bds.h bds_rasterize_bwd_ms): v_render
         # then holds the direct-route gradient only, v_alphas is not touched, and one launch over the image is gone.
         # (a split launch -- long tiles strip by strip -- keeps those tiles out of the schedule: only bds_rasterize_bwd_dev finds them)
-        split = _split(cfg, ctx.list_tile, tw * th, getattr(ctx, "split_ok", False)) if getattr(ctx, "dev_counts", None) is not None else (0, 0)
+        split = _split(cfg, ctx.list_tile, tw * th, getattr(ctx, "split_ok", False)) if getattr(ctx, "dev_counts", None) is not None else (0, 0, 0)
         defer = (_DEFER_EPILOGUE and cfg.get("defer_epilogue", True) and M > 0 and n_vis > 0 and split[0] == 0
                  and bool(lib.bds_bilagrid_ms_ed_bwd_deferrable(len(grids), lv, H, W)))
         with L.timed("bilagrid_bwd"):

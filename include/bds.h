@@ -509,17 +509,25 @@ int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32
  * first | one workgroup per tile].  For views in which a few tiles collect thousands of small splats (the vanishing point of a
  * street: the launch waits for those waves).  Same pixels in the same order: images bit-identical, gradients to the order of their
  * atomics.  Pass the SAME values and the same tile_order buffer to the backward.  No reference counterpart (gsplat runs 256 threads
- * per tile everywhere). */
+ * per tile everywhere).
+ * split_pool (> 0, with split_len; 0 = off): int32 words of a pool behind the schedule words -- the tile_order buffer then holds
+ * bds_rasterize_schedule_ints(..) + bds_rasterize_split_pool_ints(.., split_cap, split_pool, M_capacity) words.  The long tiles of a
+ * list tile share one walk of its list (per entry the mask of the sub-tiles it reaches), then one workgroup per long tile leaves the
+ * tile's own candidates in the pool, in list order; the tile's strips (forward and
+ * backward) walk that instead of the whole list-tile list (the front camera of a lidar-initialised street: 36 k entries per strip
+ * wave -> the ~8 k that reach the tile).  A tile the pool has no room for keeps the list-tile list: never an error.  last_ids of a
+ * refined tile are positions in the pool. */
 int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, int32_t *last_ids,
-                          int32_t *tile_order, int split_len, int split_cap, bds_stream_t stream);
+                          int32_t *tile_order, int split_len, int split_cap, int64_t split_pool, bds_stream_t stream);
+int64_t bds_rasterize_split_pool_ints(int C, int tile_w, int tile_h, int split_cap, int64_t split_pool, int64_t M_capacity);
 int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream);
 int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
                           const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
                           const float *v_render, const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order,
-                          int split_len, int split_cap, bds_stream_t stream);
+                          int split_len, int split_cap, int64_t split_pool, bds_stream_t stream);
 /* the list-driven backward kernels and the row-wise clear with the list length on the device (n_dev -> visible effective) */
 int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int degrees_to_use,
                              const float *means, const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank,

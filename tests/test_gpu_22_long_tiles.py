@@ -62,9 +62,13 @@ def test_strip_split_equals_one_wave_per_tile(monkeypatch, N, W, H, lidar):
     monkeypatch.setenv("BDS_SPLIT_LEN", "0")
     base = _run(Hn, FV, cam, p, grids, sky, target, M, nv)
     assert torch.equal(base[0], ref["rgb"])
-    for split, cap in ((1, 0), (mixed, 0), (mixed, 7), (int(lens.max()) + 1, 0)):   # (cap 0: every tile; 7: most long tiles overflow the list)
+    # (cap 0: every tile; 7: most long tiles overflow the list.  pool: int32 words per long tile of the capacity for the tiles' REFINED
+    #  lists -- 4096: every long tile's strips walk its own candidates; 0: off, the strips walk the list-tile list; 24: the pool runs out
+    #  after a few tiles, the rest fall back -- all of them the same pixels)
+    for split, cap, pool in ((1, 0, 4096), (mixed, 0, 4096), (mixed, 0, 0), (mixed, 0, 24), (mixed, 7, 4096), (int(lens.max()) + 1, 0, 4096)):
         monkeypatch.setenv("BDS_SPLIT_LEN", str(split))
         monkeypatch.setenv("BDS_SPLIT_CAP", str(cap))
+        monkeypatch.setattr(FV, "SPLIT_POOL_PER_TILE", pool)
         got = _run(Hn, FV, cam, p, grids, sky, target, M, nv)
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]) and torch.equal(got[2], base[2]), split
         for k in base[3]:
