@@ -60,8 +60,8 @@ _SIGS = {
     "bds_expected_depth_fwd": (_i, [_i64, _f, _f, _f, _f]),
     "bds_expected_depth_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
-    "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
+    "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
     "bds_rasterize_kernel_name": (_i, [_i, _i, _i, _i, C.c_char_p, _i]),
     "bds_rasterize_bwd_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "bds_project_view_fwd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _f, _f, _f, _f, _f]),
@@ -75,6 +75,7 @@ _SIGS = {
     "bds_splat_pack_sh_split": (_i, [_i64, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_sh_view_bwd_list_split": (_i, [_i64, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_nonfinite_flags": (_i, [_i, _f, _f, _f, _f, _f]),
+    "bds_nonfinite_flags_kinds": (_i, [_i, _f, _f, _f, _f, _f, _f]),
     "bds_project_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_project_view_bwd_list": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f]),
@@ -85,10 +86,10 @@ _SIGS = {
     "bds_splat_pack_sh_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
     "bds_splat_pack_dev": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _f, _f]),
     "bds_rasterize_schedule_ints": (_i64, [_i, _i, _i]),
-    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i64, _f]),
+    "bds_rasterize_fwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i64, _f]),
     "bds_rasterize_split_pool_ints": (_i64, [_i, _i, _i, _i, _i64, _i64]),
     "bds_rasterize_bwd_schedule_sort": (_i, [_i, _i, _i, _f, _f]),
-    "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i64, _f]),
+    "bds_rasterize_bwd_dev": (_i, [_i, _i64, _i64, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _i, _i, _i64, _f]),
     "bds_sh_view_bwd_list_dev": (_i, [_i64, _f, _f, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _f]),
     "bds_project_view_bwd_list_dev": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_view_grads_clear_list_dev": (_i, [_i64, _f, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
@@ -107,7 +108,7 @@ _SIGS = {
     "bds_bilagrid_ms_ed_fwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
     "bds_bilagrid_ms_ed_bwd_deferrable": (_i, [_i, C.POINTER(BdsLevel), _i, _i]),
     "bds_bilagrid_ms_ed_bwd_deferred": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f]),
-    "bds_rasterize_bwd_ms": (_i, [_i64, _i64, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _i, C.POINTER(BdsLevel), _f, _sz,
+    "bds_rasterize_bwd_ms": (_i, [_i64, _i64, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _f, _i, C.POINTER(BdsLevel), _f, _sz,
                                   _f, _f, _f, _f, _f, _f, _f]),
     "bds_bilagrid_ms_ed_bwd": (_i, [_i, C.POINTER(BdsLevel), _i, _i, _f, _f, _f, _f, _sz, _f, _f, _f, _f, _f, _f, _f]),
     "bds_l1_tv_train": (_i, [_i64, _f, _f, _i, C.POINTER(BdsLevel), C.POINTER(C.c_float), _fl, _f, _i, _f, _f]),

@@ -241,6 +241,10 @@ BDS_HD Proj project_one(const float *mean, const float *quat, const float *scale
 BDS_HD bool box_may_be_visible(const float *lo, const float *hi, float smax, const Camera &cam, int W, int H, float eps2d,
                                float near_plane, float far_plane) {
   const float *R = cam.R.m;
+  // an unbounded (or NaN) box -- a row of the block holds a non-finite centre: bds_gaussian_block_bounds opens the box for it -- would
+  // run the tests below in Inf / NaN arithmetic and might cull the block's healthy rows: such a block is projected row by row
+  for (int k = 0; k < 3; k++)
+    if (!(fabsf(lo[k]) < 1.0e37f) || !(fabsf(hi[k]) < 1.0e37f)) return true;
   float zmin = 3.0e38f, zmax = -3.0e38f;
   float qx[8], qy[8], qz[8];
   for (int k = 0; k < 8; k++) {

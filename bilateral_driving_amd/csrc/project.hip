@@ -119,6 +119,8 @@ __global__ __launch_bounds__(kProjBlock) void project_view_fwd_kernel(
     if (!box_may_be_visible(lo, hi, bb[3], load_camera(viewmat, K), W, H, eps2d, near_plane, far_plane)) {
       if (g < N) {
         radii[g] = 0;
+        // (dense [N] outputs a later dense consumer may read -- render_classes' opacity x mask: never uninitialised memory)
+        scales[g * 3] = 0.f; scales[g * 3 + 1] = 0.f; scales[g * 3 + 2] = 0.f; opacities[g] = 0.f;
         if (rows) {
           float4 *row = reinterpret_cast<float4 *>(means2d + g * 8);
           row[0] = row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -285,37 +287,59 @@ __global__ __launch_bounds__(kProjBlock) void project_view_bwd_list_kernel(
 struct FiniteArgs {
   const uint32_t *p[8];
   int64_t n[8];
+  int kind[8];   // BDS_FINITE_*: what makes the ACTIVATED value of an element non-finite (bds_nonfinite_flags_kinds)
   int count;
 };
 constexpr int kFiniteBlock = 256;
-__device__ __forceinline__ bool nonfinite_bits(uint32_t x) { return (x & 0x7f800000u) == 0x7f800000u; }
+// kind 0 (plain): NaN or +-Inf.  kind 1 (argument of exp -- log-scales): NaN, +Inf, or a finite value whose exp overflows
+// (x >= 88.72284, the first float with exp(x) = Inf); -Inf is fine (exp = 0).  kind 2 (quaternions, rows of four, q / |q|): NaN or
+// +-Inf components (Inf / Inf), or an all-zero row (0 / 0).  kind 3 (argument of sigmoid -- logits): NaN only.
+template <int kKind>
+__device__ __forceinline__ bool nonfinite_bits(uint32_t x) {
+  if (kKind == 1) return ((x & 0x7f800000u) == 0x7f800000u && x != 0xff800000u) || (x < 0x80000000u && x >= 0x42b17218u);
+  if (kKind == 3) return (x & 0x7fffffffu) > 0x7f800000u;
+  return (x & 0x7f800000u) == 0x7f800000u;
+}
+template <int kKind>
 __device__ __forceinline__ uint32_t nonfinite4(uint4 v) {
-  return (uint32_t)nonfinite_bits(v.x) | (uint32_t)nonfinite_bits(v.y) | (uint32_t)nonfinite_bits(v.z) | (uint32_t)nonfinite_bits(v.w);
+  uint32_t b = (uint32_t)nonfinite_bits<kKind>(v.x) | (uint32_t)nonfinite_bits<kKind>(v.y) | (uint32_t)nonfinite_bits<kKind>(v.z) |
+               (uint32_t)nonfinite_bits<kKind>(v.w);
+  if (kKind == 2) b |= (uint32_t)(((v.x | v.y | v.z | v.w) & 0x7fffffffu) == 0u);   // (an aligned 16-byte piece of a [N,4] array is a row)
+  return b;
+}
+template <int kKind>
+__device__ __forceinline__ uint32_t nonfinite_tensor(const uint32_t *q, int64_t n, int64_t gtid) {
+  constexpr int64_t kPiece = 4 * kFiniteBlock;
+  const int64_t head = min(n, (int64_t)((16 - (reinterpret_cast<uintptr_t>(q) & 15u)) & 15u) / 4);   // floats in front of a 16-byte boundary
+  const int64_t n4 = (n - head) / 4;
+  const uint4 *q4 = reinterpret_cast<const uint4 *>(q + head);
+  uint32_t b = 0;
+  for (int64_t base = (int64_t)blockIdx.x * kPiece; base < n4; base += (int64_t)gridDim.x * kPiece) {
+    const int64_t i = base + threadIdx.x;
+    if (base + kPiece <= n4) {
+      const uint4 v0 = q4[i], v1 = q4[i + kFiniteBlock], v2 = q4[i + 2 * kFiniteBlock], v3 = q4[i + 3 * kFiniteBlock];
+      b |= (nonfinite4<kKind>(v0) | nonfinite4<kKind>(v1)) | (nonfinite4<kKind>(v2) | nonfinite4<kKind>(v3));
+    } else {
+      for (int64_t k = i; k < n4; k += kFiniteBlock) b |= nonfinite4<kKind>(q4[k]);
+    }
+  }
+  if (gtid < head) b |= (uint32_t)nonfinite_bits<kKind>(q[gtid]);
+  const int64_t tail0 = head + n4 * 4;
+  if (gtid < n - tail0) b |= (uint32_t)nonfinite_bits<kKind>(q[tail0 + gtid]);
+  return b;
 }
 __global__ __launch_bounds__(kFiniteBlock) void nonfinite_flags_kernel(FiniteArgs A, uint32_t *__restrict__ flags) {
   // a workgroup reads CONTIGUOUS 16 KB pieces (four 16-byte loads per thread in flight), grid-strided piece by piece
-  constexpr int64_t kPiece = 4 * kFiniteBlock;
   const int64_t gtid = (int64_t)blockIdx.x * kFiniteBlock + threadIdx.x;
   uint32_t bad = 0;
   for (int t = 0; t < A.count; t++) {
-    const uint32_t *q = A.p[t];
-    const int64_t n = A.n[t];
-    const int64_t head = min(n, (int64_t)((16 - (reinterpret_cast<uintptr_t>(q) & 15u)) & 15u) / 4);   // floats in front of a 16-byte boundary
-    const int64_t n4 = (n - head) / 4;
-    const uint4 *q4 = reinterpret_cast<const uint4 *>(q + head);
-    uint32_t b = 0;
-    for (int64_t base = (int64_t)blockIdx.x * kPiece; base < n4; base += (int64_t)gridDim.x * kPiece) {
-      const int64_t i = base + threadIdx.x;
-      if (base + kPiece <= n4) {
-        const uint4 v0 = q4[i], v1 = q4[i + kFiniteBlock], v2 = q4[i + 2 * kFiniteBlock], v3 = q4[i + 3 * kFiniteBlock];
-        b |= (nonfinite4(v0) | nonfinite4(v1)) | (nonfinite4(v2) | nonfinite4(v3));
-      } else {
-        for (int64_t k = i; k < n4; k += kFiniteBlock) b |= nonfinite4(q4[k]);
-      }
+    uint32_t b;
+    switch (A.kind[t]) {
+      case 1: b = nonfinite_tensor<1>(A.p[t], A.n[t], gtid); break;
+      case 2: b = nonfinite_tensor<2>(A.p[t], A.n[t], gtid); break;
+      case 3: b = nonfinite_tensor<3>(A.p[t], A.n[t], gtid); break;
+      default: b = nonfinite_tensor<0>(A.p[t], A.n[t], gtid); break;
     }
-    if (gtid < head) b |= (uint32_t)nonfinite_bits(q[gtid]);
-    const int64_t tail0 = head + n4 * 4;
-    if (gtid < n - tail0) b |= (uint32_t)nonfinite_bits(q[tail0 + gtid]);
     if (b) bad |= 1u << t;
   }
   if (bad) atomicOr(flags, bad);
@@ -568,13 +592,24 @@ extern "C" int bds_project_view_bwd_list_dev(int64_t n_capacity, const uint64_t 
 
 // Bit t of *flags_dev is set when tensors[t] (counts[t] floats) holds a NaN or an Inf (vanilla.py:407-412); the word is cleared first.
 // flags_pinned (optional, page-locked): receives a copy behind the launch -- the host reads it after its next wait on the stream.
+extern "C" int bds_nonfinite_flags_kinds(int n_tensors, const float *const *tensors, const int64_t *counts, const int *kinds,
+                                         uint32_t *flags_dev, uint32_t *flags_pinned, bds_stream_t stream);
 extern "C" int bds_nonfinite_flags(int n_tensors, const float *const *tensors, const int64_t *counts, uint32_t *flags_dev,
                                    uint32_t *flags_pinned, bds_stream_t stream) {
+  return bds_nonfinite_flags_kinds(n_tensors, tensors, counts, nullptr, flags_dev, flags_pinned, stream);
+}
+// kinds (optional, [n_tensors]): 0 plain | 1 argument of exp | 2 quaternion rows [n/4, 4] (16-byte aligned) | 3 argument of sigmoid:
+// the bit then says "the ACTIVATED tensor would hold a NaN / Inf" (vanilla.py:393-395 activations, :407-412 check)
+extern "C" int bds_nonfinite_flags_kinds(int n_tensors, const float *const *tensors, const int64_t *counts, const int *kinds,
+                                         uint32_t *flags_dev, uint32_t *flags_pinned, bds_stream_t stream) {
   BDS_REQUIRE(n_tensors >= 0 && n_tensors <= 8 && flags_dev && (n_tensors == 0 || (tensors && counts)));
   FiniteArgs A;
   A.count = n_tensors;
   int64_t total = 0;
   for (int t = 0; t < n_tensors; t++) {
+    A.kind[t] = kinds ? kinds[t] : 0;
+    BDS_REQUIRE(A.kind[t] >= 0 && A.kind[t] <= 3);
+    BDS_REQUIRE(A.kind[t] != 2 || (counts[t] % 4 == 0 && (reinterpret_cast<uintptr_t>(tensors[t]) & 15u) == 0));
     BDS_REQUIRE(counts[t] >= 0 && (counts[t] == 0 || tensors[t]) && (reinterpret_cast<uintptr_t>(tensors[t]) & 3u) == 0);
     A.p[t] = reinterpret_cast<const uint32_t *>(tensors[t]);
     A.n[t] = counts[t];

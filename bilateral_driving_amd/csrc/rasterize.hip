@@ -60,7 +60,10 @@ __device__ __forceinline__ int sched_bin(int w) {   // 0 = longest ... kSchedLog
   return min(max(57 - h, 0), kSchedLogBins - 2);                   // bin 0: >= 20 480 entries; bin 30: < 128
 }
 
-__device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int bid, int total) {
+// may_be_missing: the SPLIT launch keeps its long tiles out of the bins, so a range has fewer entries than workgroups and a slot without
+// an entry means "nothing to do" (-1); everywhere else every tile sits in some bin, and a slot without a valid entry can only mean a
+// header nobody cleared / filled: plain order, every tile still processed
+__device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int bid, int total, bool may_be_missing = false) {
   const int p = xcd_contiguous(bid, total);
   if (!order) return p;
   if (order[0] != 0) return order[1 + p];
@@ -79,9 +82,7 @@ __device__ __forceinline__ int pick_item(const int32_t *__restrict__ order, int 
     const int item = order[kSchedHeader + (x * kSchedLogBins + sel) * sched_stride(total) + (slot - before)];
     if ((unsigned)item < (unsigned)total) return item;   // (anything else: a header the pack did not clear -- plain order)
   }
-  // a header nobody filled: plain order.  A FILLED one without this slot (the split launch keeps its long tiles out of the bins,
-  // so a range has fewer entries than workgroups): nothing to do
-  return acc == 0 ? p : -1;
+  return (acc == 0 || !may_be_missing) ? p : -1;
 }
 
 // ---- splat records --------------------------------------------------------------------------------------
@@ -297,7 +298,7 @@ template <int CH, bool kCoarse, bool kStrip, int NQ>
 __device__ __forceinline__ void rasterize_fwd_wave_body(
     int bid, int q0, int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec,
     const float *__restrict__ backgrounds, int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets,
-    const int32_t *__restrict__ flatten, float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+    const int32_t *__restrict__ flatten, float *__restrict__ render, float *__restrict__ alphas, float *__restrict__ t_final, int32_t *__restrict__ last_ids,
     const ListGeom &lg, int32_t *__restrict__ tile_work, float4 *sA, float4 *sB, float4 *sC, int item_in = -1, int ov_start = -1,
     int ov_end = -1) {
   // (ov_start / ov_end: the tile's list is [ov_start, ov_end) of `flatten` instead of its list tile's -- a long tile's REFINED list)
@@ -403,6 +404,7 @@ __device__ __forceinline__ void rasterize_fwd_wave_body(
       const int64_t pix = ((int64_t)cam * H + i) * W + j;
       const float Tf = fabsf(T[q]);
       alphas[pix] = 1.f - Tf;
+      if (t_final) t_final[pix] = Tf;     // (1 - Tf rounds the last bits of a small Tf away: the backward starts from the value itself)
       last_ids[pix] = cur[q];
       float *r = render + pix * CH;
 #pragma unroll
@@ -433,11 +435,11 @@ template <int CH, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_wave_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
+    float *__restrict__ render, float *__restrict__ alphas, float *__restrict__ t_final, int32_t *__restrict__ last_ids, ListGeom lg,
     int32_t *__restrict__ tile_work) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   rasterize_fwd_wave_body<CH, kCoarse, kStrip, 4>((int)blockIdx.x, 0, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten,
-                                                  render, alphas, last_ids, lg, tile_work, sA, sB, sC);
+                                                  render, alphas, t_final, last_ids, lg, tile_work, sA, sB, sC);
 }
 
 // ---- long tiles: four waves per tile ---------------------------------------------------------------------------------------------
@@ -618,7 +620,7 @@ template <int CH, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_fwd_split_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids, ListGeom lg,
+    float *__restrict__ render, float *__restrict__ alphas, float *__restrict__ t_final, int32_t *__restrict__ last_ids, ListGeom lg,
     int32_t *__restrict__ tile_work, const int32_t *__restrict__ area, int cap, int pool_cap) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   const int total = C * tile_w * tile_h, b = (int)blockIdx.x;
@@ -633,12 +635,12 @@ __global__ __launch_bounds__(kWave) void rasterize_fwd_split_kernel(
       if (cnt >= 0) { fl = ref_cnt + cap; ovs = ref_off[jl]; ove = ovs + cnt; }
     }
     rasterize_fwd_wave_body<CH, true, kStrip, 1>(0, b & 3, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, fl, render,
-                                                 alphas, last_ids, lg, tile_work, sA, sB, sC, area[kSplitHead + total + jl], ovs, ove);
+                                                 alphas, t_final, last_ids, lg, tile_work, sA, sB, sC, area[kSplitHead + total + jl], ovs, ove);
   } else {
     const int bid = b - 4 * cap;
     if (area[kSplitHead + xcd_contiguous(bid, total)] >= 0) return;      // a long tile: its strips do it
     rasterize_fwd_wave_body<CH, true, kStrip, 4>(bid, 0, C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, render,
-                                                 alphas, last_ids, lg, tile_work, sA, sB, sC);
+                                                 alphas, t_final, last_ids, lg, tile_work, sA, sB, sC);
   }
 }
 
@@ -654,7 +656,7 @@ template <int CH, bool ABS, bool kCoarse, bool kStrip, bool kEpi, int NQ = 4>
 __device__ __forceinline__ void rasterize_bwd_wave_body(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ alphas, const float *__restrict__ t_final, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, const ListGeom &lg,
     const EdEpilogue &ep, float4 *sA, float4 *sB, float4 *sC, int32_t *sId, int bid, int q0 = 0, int item_in = -1, int ov_start = -1,
     int ov_end = -1) {
@@ -684,7 +686,7 @@ __device__ __forceinline__ void rasterize_bwd_wave_body(
     const bool inside = i < H && j < W;
     pyc[q] = (float)i + 0.5f;
     const int64_t pix = ((int64_t)cam * H + (inside ? i : 0)) * W + (inside ? j : 0);
-    const float T_final = inside ? 1.f - alphas[pix] : 1.f;
+    const float T_final = inside ? (t_final ? t_final[pix] : 1.f - alphas[pix]) : 1.f;
     T[q] = T_final;
     bin_final[q] = inside ? last_ids[pix] : -1;   // -1: never valid (pixel outside the image)
     max_bin = max(max_bin, bin_final[q]);
@@ -831,12 +833,12 @@ template <int CH, bool ABS, bool kCoarse, bool kStrip>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_wave_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ alphas, const float *__restrict__ t_final, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
   const EdEpilogue none{};
-  rasterize_bwd_wave_body<CH, ABS, kCoarse, kStrip, false>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
+  rasterize_bwd_wave_body<CH, ABS, kCoarse, kStrip, false>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas, t_final,
                                                            last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId,
                                                            (int)blockIdx.x);
 }
@@ -845,7 +847,7 @@ template <int CH, bool ABS>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
     int C, int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, const float *__restrict__ backgrounds,
     int W, int H, int tile_w, int tile_h, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ alphas, const float *__restrict__ t_final, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg,
     const int32_t *__restrict__ area, int cap, int pool_cap) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
@@ -862,14 +864,14 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
       const int cnt = ref_cnt[jl];
       if (cnt >= 0) { fl = ref_cnt + cap; ovs = ref_off[jl]; ove = ovs + cnt; }
     }
-    rasterize_bwd_wave_body<CH, ABS, true, false, false, 1>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, fl, alphas,
+    rasterize_bwd_wave_body<CH, ABS, true, false, false, 1>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, fl, alphas, t_final,
                                                             last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, 0, b & 3,
                                                             area[kSplitHead + total + jl], ovs, ove);
   } else {
     const int bid = b - 4 * cap;
-    const int item = pick_item(tile_order, bid, total);
+    const int item = pick_item(tile_order, bid, total, true);
     if (item < 0 || area[kSplitHead + item] >= 0) return;
-    rasterize_bwd_wave_body<CH, ABS, true, false, false, 4>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas,
+    rasterize_bwd_wave_body<CH, ABS, true, false, false, 4>(C, M_host, M_dev, rec, backgrounds, W, H, tile_w, tile_h, offsets, flatten, alphas, t_final,
                                                             last_ids, v_render, v_alphas, v_rec, tile_order, lg, none, sA, sB, sC, sId, bid, 0, item);
   }
 }
@@ -878,11 +880,11 @@ __global__ __launch_bounds__(kWave) void rasterize_bwd_split_kernel(
 template <bool ABS, bool kCoarse>
 __global__ __launch_bounds__(kWave) void rasterize_bwd_epi_kernel(
     int64_t M_host, const uint64_t *__restrict__ M_dev, const float4 *__restrict__ rec, int W, int H, int tile_w, int tile_h,
-    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten, const float *__restrict__ alphas, const float *__restrict__ t_final,
     const int32_t *__restrict__ last_ids, float *__restrict__ v_rec, const int32_t *__restrict__ tile_order, ListGeom lg, EdEpilogue ep) {
   __shared__ float4 sA[kWave], sB[kWave], sC[kWave];
   __shared__ int32_t sId[kWave];
-  rasterize_bwd_wave_body<4, ABS, kCoarse, false, true>(1, M_host, M_dev, rec, nullptr, W, H, tile_w, tile_h, offsets, flatten, alphas, last_ids,
+  rasterize_bwd_wave_body<4, ABS, kCoarse, false, true>(1, M_host, M_dev, rec, nullptr, W, H, tile_w, tile_h, offsets, flatten, alphas, t_final, last_ids,
                                                         nullptr, nullptr, v_rec, tile_order, lg, ep, sA, sB, sC, sId, (int)blockIdx.x);
 }
 // ---- backward schedule: longest tile first inside each XCD's range ------------------------------------
@@ -1164,7 +1166,7 @@ static bool list_geom(int C, int W, int H, int list_tile_size, ListGeom &lg) {
 
 static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                              const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
+                              const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, float *t_final,
                               int32_t *last_ids, bds_stream_t stream, int32_t *tile_work = nullptr, bool binned = false,
                               int split_len = 0, int split_cap = 0, int64_t split_pool = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
@@ -1181,7 +1183,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   const float4 *rec = reinterpret_cast<const float4 *>(records);
 #define BDS_FWD(ch, co)                                                                                                              \
   hipLaunchKernelGGL((rasterize_fwd_wave_kernel<ch, co, true>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
-                     tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work)
+                     tile_h, isect_offsets, flatten, render, alphas, t_final, last_ids, lg, tile_work)
   if (lg.div > 1) {
     if (CH == 1) BDS_FWD(1, true);
     else if (CH == 3) BDS_FWD(3, true);
@@ -1200,7 +1202,7 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
                            tile_h, cap, area, (int)split_pool, masks);
       }
       hipLaunchKernelGGL((rasterize_fwd_split_kernel<4, true>), dim3((unsigned)(4 * cap + total)), dim3(kWave), 0, st, C, M, M_dev, rec,
-                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, last_ids, lg, tile_work, area, cap,
+                         backgrounds, W, H, tile_w, tile_h, isect_offsets, flatten, render, alphas, t_final, last_ids, lg, tile_work, area, cap,
                          (int)split_pool);
     } else BDS_FWD(4, true);
   } else {
@@ -1215,23 +1217,23 @@ static int rasterize_fwd_impl(int C, int64_t n_records, int64_t M, const uint64_
 
 extern "C" int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
                                  int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                                 const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
+                                 const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, float *t_final,
                                  int32_t *last_ids, bds_stream_t stream) {
   return rasterize_fwd_impl(C, n_records, M, nullptr, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, render, alphas, last_ids, stream);
+                            isect_offsets, flatten, render, alphas, t_final, last_ids, stream);
 }
 
 extern "C" int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas,
-                                     int32_t *last_ids, int32_t *tile_order, int split_len, int split_cap, int64_t split_pool,
+                                     float *t_final, int32_t *last_ids, int32_t *tile_order, int split_len, int split_cap, int64_t split_pool,
                                      bds_stream_t stream) {
   BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0 && split_pool >= 0);
   // tile_order (optional, bds_rasterize_schedule_ints words): the compositing waves leave the backward's schedule themselves --
   // binned form (option 8, default; header cleared by the record pack in front), or their tiles' keys for bds_rasterize_bwd_schedule_sort
   const bool binned = option_get(kOptSchedBins) != 0;
   return rasterize_fwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, render, alphas, last_ids, stream,
+                            isect_offsets, flatten, render, alphas, t_final, last_ids, stream,
                             !tile_order ? nullptr : (binned ? tile_order : tile_order + 1 + (int64_t)C * tile_w * tile_h), binned, split_len,
                             split_cap, split_pool);
 }
@@ -1261,8 +1263,8 @@ extern "C" int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, in
 
 static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_t *M_dev, int CH, const float *records,
                               const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                              const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
-                              const float *v_render, const float *v_alphas, float *v_records, int absgrad,
+                              const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const float *t_final,
+                              const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records, int absgrad,
                               const int32_t *tile_order, bds_stream_t stream, const EdEpilogue *epi = nullptr, int split_len = 0,
                               int split_cap = 0, int64_t split_pool = 0) {
   BDS_REQUIRE(C >= 1 && n_records >= 0 && M >= 0 && W > 0 && H > 0);
@@ -1281,7 +1283,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     BDS_REQUIRE(C == 1 && CH == 4 && backgrounds == nullptr);
 #define BDS_BWD_EPI(ab, co)                                                                                                              \
   hipLaunchKernelGGL((rasterize_bwd_epi_kernel<ab, co>), grid, dim3(kWave), 0, st, M, M_dev, rec, W, H, tile_w, tile_h, isect_offsets, \
-                     flatten, alphas, last_ids, v_records, tile_order, lg, *epi)
+                     flatten, alphas, t_final, last_ids, v_records, tile_order, lg, *epi)
     if (absgrad) { if (lg.div > 1) BDS_BWD_EPI(true, true); else BDS_BWD_EPI(true, false); }
     else         { if (lg.div > 1) BDS_BWD_EPI(false, true); else BDS_BWD_EPI(false, false); }
 #undef BDS_BWD_EPI
@@ -1292,7 +1294,7 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
   // body is long enough that the extra control flow outweighs the ~19 % of strips it would skip; the forward gains 7 %)
 #define BDS_BWD(ch, ab, co)                                                                                                                 \
   hipLaunchKernelGGL((rasterize_bwd_wave_kernel<ch, ab, co, false>), grid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, \
-                     tile_h, isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg)
+                     tile_h, isect_offsets, flatten, alphas, t_final, last_ids, v_render, v_alphas, v_records, tile_order, lg)
 #define BDS_BWD_CH(ab, co)            \
   do {                                \
     if (CH == 1) BDS_BWD(1, ab, co);  \
@@ -1307,10 +1309,10 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
     const dim3 sgrid((unsigned)(4 * cap + total));
     if (absgrad)
       hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, true>), sgrid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
-                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap, (int)split_pool);
+                         isect_offsets, flatten, alphas, t_final, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap, (int)split_pool);
     else
       hipLaunchKernelGGL((rasterize_bwd_split_kernel<4, false>), sgrid, dim3(kWave), 0, st, C, M, M_dev, rec, backgrounds, W, H, tile_w, tile_h,
-                         isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap, (int)split_pool);
+                         isect_offsets, flatten, alphas, t_final, last_ids, v_render, v_alphas, v_records, tile_order, lg, area, cap, (int)split_pool);
   } else if (absgrad) {
     if (lg.div > 1) BDS_BWD_CH(true, true);
     else BDS_BWD_CH(true, false);
@@ -1326,29 +1328,29 @@ static int rasterize_bwd_impl(int C, int64_t n_records, int64_t M, const uint64_
 
 extern "C" int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds,
                                  int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                                 const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
-                                 const float *v_render, const float *v_alphas, float *v_records, int absgrad,
+                                 const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const float *t_final,
+                                 const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records, int absgrad,
                                  const int32_t *tile_order, bds_stream_t stream) {
   return rasterize_bwd_impl(C, n_records, M, nullptr, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream);
+                            isect_offsets, flatten, alphas, t_final, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream);
 }
 
 extern "C" int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                                      const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w,
                                      int tile_h, const int32_t *isect_offsets, const int32_t *flatten, const float *alphas,
-                                     const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records,
+                                     const float *t_final, const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records,
                                      int absgrad, const int32_t *tile_order, int split_len, int split_cap, int64_t split_pool,
                                      bds_stream_t stream) {
   BDS_REQUIRE(M_dev && M_capacity > 0 && split_len >= 0 && split_cap >= 0 && split_pool >= 0 && split_pool < ((int64_t)1 << 31));
   return rasterize_bwd_impl(C, n_records, M_capacity, M_dev, CH, records, backgrounds, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, alphas, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream, nullptr,
+                            isect_offsets, flatten, alphas, t_final, last_ids, v_render, v_alphas, v_records, absgrad, tile_order, stream, nullptr,
                             split_len, split_cap, split_pool);
 }
 
 extern "C" int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,
                                     int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                                    const int32_t *flatten, const float *alphas, const int32_t *last_ids, float *v_records, int absgrad,
-                                    const int32_t *tile_order, int nlevels, const bds_bilagrid_level_t *levels, void *ms_ws,
+                                    const int32_t *flatten, const float *alphas, const float *t_final, const int32_t *last_ids,
+                                    float *v_records, int absgrad, const int32_t *tile_order, int nlevels, const bds_bilagrid_level_t *levels, void *ms_ws,
                                     size_t ms_ws_bytes, const float *render, const float *sky, const float *v_depth,
                                     const float *v_alpha_in, const float *v_direct, float *v_sky, bds_stream_t stream) {
   BDS_REQUIRE(render && v_direct && aligned16(render) && aligned16(v_direct) && (sky != nullptr || v_sky == nullptr));
@@ -1357,7 +1359,7 @@ extern "C" int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const
   if (rc != BDS_OK) return rc;
   e.v_direct = v_direct; e.render = render; e.sky = sky; e.v_depth = v_depth; e.v_alpha_in = v_alpha_in; e.v_sky = v_sky;
   return rasterize_bwd_impl(1, n_records, M_capacity, M_dev, 4, records, nullptr, W, H, tile_size, list_tile_size, tile_w, tile_h,
-                            isect_offsets, flatten, alphas, last_ids, nullptr, nullptr, v_records, absgrad, tile_order, stream, &e);
+                            isect_offsets, flatten, alphas, t_final, last_ids, nullptr, nullptr, v_records, absgrad, tile_order, stream, &e);
 }
 
 extern "C" int bds_rasterize_bwd_schedule(int C, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,

@@ -69,6 +69,8 @@ class FlatGradients:
             assert p.dtype == torch.float32 and p.device == dev and p.requires_grad
         self.row_block = bool(row_block)
         if self.row_block:
+            # single-process layout: pack() / all_reduce() move whole tensors, the exchange's compact buffers are five arrays
+            assert not _active(), "FlatGradients(row_block=True) is the single-process layout (no process group of several ranks)"
             N = self.params[0].shape[0]
             assert len(self.params) >= 4 and [tuple(p.shape) for p in self.params[:4]] == [(N, 3), (N, 4), (N, 3), (N,)], \
                 "row_block: means [N,3], quats [N,4], log_scales [N,3], opacity logits [N] first"
@@ -133,9 +135,12 @@ class FlatGradients:
         keys = ("means", "quats", "log_scales", "opacity_logits", "sh")
         if self._dirty is not None and flat.is_cuda and all(k in row for k in keys) and row["sh"].dim() == 3:
             K = row["sh"].shape[1]
+            # (row_block: the four small gradients are strided columns of one [N,16] block -- the kernel recognises the layout by the
+            #  addresses, csrc/bds_common.h GradLayout -- so their base addresses go in as they are)
+            addr = (lambda t: t.data_ptr()) if self.row_block else L.ptr
             for ids in self._dirty:
-                L.check(L.lib().bds_view_grads_clear_list(ids.numel(), L.ptr(ids.contiguous()), K, L.ptr(row["means"]), L.ptr(row["quats"]),
-                                                          L.ptr(row["log_scales"]), L.ptr(row["opacity_logits"]), L.ptr(row["sh"]),
+                L.check(L.lib().bds_view_grads_clear_list(ids.numel(), L.ptr(ids.contiguous()), K, addr(row["means"]), addr(row["quats"]),
+                                                          addr(row["log_scales"]), addr(row["opacity_logits"]), L.ptr(row["sh"]),
                                                           L.stream()), "bds_view_grads_clear_list")
             # the other slices are dense: pack() / autograd overwrite (or zero) them before they are read
         elif self._dirty is not None and not flat.is_cuda:   # CPU tensors (the gloo tests of the exchange logic): same effect

@@ -365,7 +365,17 @@ def _front_finish_dev(f: _Front) -> _Front:
 
 
 def _image_buffers(W: int, H: int, dev):
-    return _empty((1, H, W, 4), dev), _empty((1, H, W, 1), dev), _empty((1, H, W), dev, torch.int32)
+    """(render, alphas, last_ids) of one camera.  ``alphas`` is the first plane of a [2, H, W, 1] buffer: the second receives every
+    pixel's final transmittance itself (``_tfinal_ptr``; include/bds.h bds_rasterize_fwd ``t_final``) -- the backward starts from that
+    value instead of 1 - alpha, which has lost the low bits of a small transmittance."""
+    a2 = _empty((2, H, W, 1), dev)
+    return _empty((1, H, W, 4), dev), a2[0:1], _empty((1, H, W), dev, torch.int32)
+
+
+def _tfinal_ptr(alphas: Tensor) -> int:
+    """Device address of the T_final plane behind an ``alphas`` tensor made by ``_image_buffers``."""
+    assert alphas.is_contiguous() and alphas.untyped_storage().nbytes() >= alphas.storage_offset() * 4 + 2 * alphas.numel() * 4
+    return alphas.data_ptr() + alphas.numel() * 4
 
 
 def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional[Tensor] = None, tile_order: Optional[Tensor] = None,
@@ -403,8 +413,8 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
                                                0 if tail is None else tail.numel(), L.ptr(tile_order), st), "bds_splat_pack_dev")
             # (tile_order: the backward's schedule is left by the compositing waves themselves; its header was cleared by the pack)
             L.check(lib.bds_rasterize_fwd_dev(1, n_vis, M, f.m_dev, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th,
-                                              L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), L.ptr(last_ids),
-                                              L.ptr(tile_order), *_split(f.cfg, f.list_tile, f.tw * f.th, tile_order is not None), st),
+                                              L.ptr(f.isect_offsets), L.ptr(f.flatten), L.ptr(render), L.ptr(alphas), _tfinal_ptr(alphas),
+                                              L.ptr(last_ids), L.ptr(tile_order), *_split(f.cfg, f.list_tile, f.tw * f.th, tile_order is not None), st),
                     "bds_rasterize_fwd_dev")
         return rec, render, alphas, last_ids
     if f.rec_buf is not None:      # provisioned before the wait (first composite over this front only)
@@ -427,7 +437,7 @@ def _composite(f: _Front, opac: Tensor, images=None, zero_grad_records: Optional
             L.check(lib.bds_splat_pack(n_vis, 4, L.ptr(f.vis_ids), L.ptr(f.means2d), L.ptr(f.conics), L.ptr(f.colors), L.ptr(opac),
                                        L.ptr(f.radii), L.ptr(rec), st), "bds_splat_pack")
         L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, f.list_tile, f.tw, f.th, L.ptr(f.isect_offsets), L.ptr(f.flatten),
-                                      L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
+                                      L.ptr(render), L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
     return rec, render, alphas, last_ids
 
 
@@ -655,16 +665,16 @@ class _FusedView(torch.autograd.Function):
         with L.timed("rasterize_bwd"):
             if defer:
                 L.check(lib.bds_rasterize_bwd_ms(n_vis, M, None if dev_counts is None else dev_counts[0], L.ptr(rec), W, H, TILE, LT, tw, th,
-                                                 L.ptr(isect_offsets), L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_rec), 1,
+                                                 L.ptr(isect_offsets), L.ptr(flatten), L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), L.ptr(v_rec), 1,
                                                  L.ptr(order), len(grids), lv, L.ptr(bws), bws.numel(), L.ptr(render), L.ptr(sky),
                                                  L.ptr(v_depth), L.ptr(v_opacity), L.ptr(v_render), L.ptr(v_sky), st), "bds_rasterize_bwd_ms")
             elif dev_counts is not None:
                 L.check(lib.bds_rasterize_bwd_dev(1, n_vis, M, dev_counts[0], 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets),
-                                                  L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas),
-                                                  L.ptr(v_rec), 1, L.ptr(order), *split, st), "bds_rasterize_bwd_dev")
+                                                  L.ptr(flatten), L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), L.ptr(v_render),
+                                                  L.ptr(v_alphas), L.ptr(v_rec), 1, L.ptr(order), *split, st), "bds_rasterize_bwd_dev")
             else:
                 L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
-                                              L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
+                                              L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec), 1,
                                               L.ptr(order), st), "bds_rasterize_bwd")
         if v_means2d_ext is not None and n_vis:   # a loss term on info["means2d"] itself: add its rows to the records
             v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())

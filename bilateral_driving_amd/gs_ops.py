@@ -229,21 +229,23 @@ class _RasterizeToPixels(torch.autograd.Function):
         # splat records in array order (record index = cam*N + g = what flatten_ids holds)
         rec = torch.empty(Cn * N, L.SPLAT_RECORD_FLOATS, device=dev, dtype=torch.float32)
         render = torch.empty(Cn, height, width, CH, device=dev, dtype=torch.float32)
-        alphas = torch.empty(Cn, height, width, 1, device=dev, dtype=torch.float32)
+        # (second plane: every pixel's final transmittance itself -- the backward starts from it, not from 1 - alpha; include/bds.h)
+        a2 = torch.empty(2, Cn, height, width, 1, device=dev, dtype=torch.float32)
+        alphas, t_final = a2[0], a2[1]
         last_ids = torch.empty(Cn, height, width, device=dev, dtype=torch.int32)
         with L.timed("rasterize_fwd"):
             L.check(lib.bds_splat_pack(Cn * N, CH, None, L.ptr(means2d_c), L.ptr(conics), L.ptr(colors), L.ptr(opacities), None, L.ptr(rec), st),
                     "bds_splat_pack")
             L.check(lib.bds_rasterize_fwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, TILE_SIZE, tile_size, tw, th,
-                                          L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st),
+                                          L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(render), L.ptr(alphas), L.ptr(t_final), L.ptr(last_ids), st),
                     "bds_rasterize_fwd")
-        ctx.save_for_backward(means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids)
+        ctx.save_for_backward(means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids, t_final)
         ctx.cfg = (width, height, tile_size, absgrad, CH)
         return render, alphas
 
     @staticmethod
     def backward(ctx, v_render, v_alphas):
-        means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        means2d, rec, backgrounds, isect_offsets, flatten_ids, alphas, last_ids, t_final = ctx.saved_tensors
         width, height, tile_size, absgrad, CH = ctx.cfg
         Cn, N = means2d.shape[0], means2d.shape[1]
         tw, th = math.ceil(width / TILE_SIZE), math.ceil(height / TILE_SIZE)
@@ -254,7 +256,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         order = bwd_schedule(Cn, width, height, tile_size, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
             L.check(L.lib().bds_rasterize_bwd(Cn, Cn * N, M, CH, L.ptr(rec), L.ptr(backgrounds), width, height, TILE_SIZE, tile_size, tw, th,
-                                              L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render),
+                                              L.ptr(isect_offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(t_final), L.ptr(last_ids), L.ptr(v_render),
                                               L.ptr(v_alphas), L.ptr(v_rec), int(bool(absgrad)), L.ptr(order), L.stream()),
                     "bds_rasterize_bwd")
         v = v_rec.view(Cn, N, L.GRAD_RECORD_FLOATS)

@@ -54,6 +54,13 @@ class RawGaussians:
                 t = torch.clamp(spherical_harmonics(self.sh_degree, viewdirs, colors) + 0.5, 0.0, 1.0)   # vanilla.py:388-389
             else:
                 raise KeyError(field)
+            # the reference raises on a NaN / Inf in ANY of the activated tensors (vanilla.py:407-412).  The one-view node checks the
+            # raw parameters itself (bds_nonfinite_flags_kinds); every OTHER route to an activated tensor -- several classes
+            # concatenated, opacity masks, backgrounds, the fall-back of rasterization() -- comes through here, once per field
+            v = t.detach()
+            if bool((~torch.isfinite(v)).any()):
+                what = "NaN" if bool(torch.isnan(v).any()) else "Inf"
+                raise ValueError(f"{what} detected in gaussian {field} at step {self.step}")
             self._cache[field] = t
         return t
 

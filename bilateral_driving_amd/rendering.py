@@ -19,6 +19,11 @@ import weakref
 
 from . import _lib as L
 from .lazy_gaussians import lazy_source, materialised
+
+
+def _tfinal_ptr(alphas):       # (the T_final plane behind an ``alphas`` tensor: fused_view._tfinal_ptr)
+    from .fused_view import _tfinal_ptr as f
+    return f(alphas)
 from .gs_ops import (TILE_SIZE, _f32c, bwd_schedule, fully_fused_projection, isect_tiles, rasterize_to_pixels, spherical_harmonics)
 
 
@@ -131,7 +136,7 @@ class _RasterizeView(torch.autograd.Function):
         rec_buf = torch.empty(cap[1], L.SPLAT_RECORD_FLOATS, device=dev) if cap[1] else None
         isect_offsets = torch.empty(1, lth, ltw, device=dev, dtype=torch.int32)
         render = torch.empty(1, H, W, 4, device=dev)
-        alphas = torch.empty(1, H, W, 1, device=dev)
+        alphas = torch.empty(2, H, W, 1, device=dev)[0:1]     # (second plane: every pixel's final transmittance, fused_view._tfinal_ptr)
         last_ids = torch.empty(1, H, W, device=dev, dtype=torch.int32)
         ev.synchronize()
         M, n_vis = int(counts.np[0]), int(counts.np[1])
@@ -157,7 +162,7 @@ class _RasterizeView(torch.autograd.Function):
             L.check(lib.bds_splat_pack_rgbd(n_vis, L.ptr(vis_ids), L.ptr(means2d), L.ptr(conics), L.ptr(colors3), L.ptr(depths),
                                             L.ptr(opacities), L.ptr(radii), L.ptr(rec), st), "bds_splat_pack_rgbd")
             L.check(lib.bds_rasterize_fwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE_SIZE, LT, tw, th, L.ptr(isect_offsets), L.ptr(flatten),
-                                          L.ptr(render), L.ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
+                                          L.ptr(render), L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), st), "bds_rasterize_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, viewmat, Kmat, rec, vis_ids, ws, flatten, isect_offsets, render, alphas, last_ids)
         ctx.cfg, ctx.M = cfg, M
         if cfg["ed"]:      # expected depth: D / clamp(alpha, 1e-10) (gsplat "ED")
@@ -191,7 +196,7 @@ class _RasterizeView(torch.autograd.Function):
         order = bwd_schedule(1, W, H, _LIST_TILE, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
             L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE_SIZE, _LIST_TILE, tw, th, L.ptr(isect_offsets),
-                                          L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec),
+                                          L.ptr(flatten), L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_rec),
                                           int(bool(cfg["absgrad"])), L.ptr(order), st), "bds_rasterize_bwd")
         if v_means2d_ext is not None and n_vis:   # a loss term on meta["means2d"] itself: add its rows to the records
             v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())
@@ -242,13 +247,15 @@ class _RasterizeRawView(torch.autograd.Function):
         flags = None
         if cfg["check_finite"]:
             # in FRONT of the projection: the flag's copy to the host is then older than the event the one wait of this view waits for.
-            # On the raw values (an activation is non-finite iff its argument is NaN, or +Inf for a scale; -Inf log-scales / +-Inf
-            # logits are reported too although exp / sigmoid map them to finite values, a finite log-scale above 88.7 is not)
+            # On the raw values, by what makes each tensor's ACTIVATION non-finite (the reference checks the activated tensors,
+            # vanilla.py:393-395,407-412): a log-scale whose exp overflows (NaN, +Inf, >= 88.72284; -Inf gives 0), a quaternion with a
+            # NaN / Inf component or all zeros (0 / 0), a NaN logit (sigmoid maps +-Inf to 0 / 1); means and SH coefficients as they are
             flags = _finite_words(dev)
             ts = (means, quats, log_scales, logits, dc, rest)
             ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
             cnts = (ctypes.c_int64 * len(ts))(*[t.numel() for t in ts])
-            L.check(lib.bds_nonfinite_flags(len(ts), ptrs, cnts, flags[0].data_ptr(), flags[1].data_ptr(), st), "bds_nonfinite_flags")
+            kinds = (ctypes.c_int * len(ts))(0, 2 if quats.data_ptr() % 16 == 0 else 0, 1, 3, 0, 0)
+            L.check(lib.bds_nonfinite_flags_kinds(len(ts), ptrs, cnts, kinds, flags[0].data_ptr(), flags[1].data_ptr(), st), "bds_nonfinite_flags")
         f = _view_front(fcfg, means, quats, log_scales, logits.reshape(N), (dc, rest), viewmat, lambda: _image_buffers(W, H, dev))
         if flags is not None and int(flags[1][0]):
             bad = [n for i, n in enumerate(("means", "quats", "scales", "opacities", "features_dc", "features_rest")) if int(flags[1][0]) >> i & 1]
@@ -286,7 +293,7 @@ class _RasterizeRawView(torch.autograd.Function):
         order = bwd_schedule(1, W, H, _LIST_TILE, isect_offsets, last_ids)
         with L.timed("rasterize_bwd"):
             L.check(lib.bds_rasterize_bwd(1, n_vis, M, 4, L.ptr(rec), None, W, H, TILE_SIZE, _LIST_TILE, tw, th, L.ptr(isect_offsets),
-                                          L.ptr(flatten), L.ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas_t), L.ptr(v_rec),
+                                          L.ptr(flatten), L.ptr(alphas), _tfinal_ptr(alphas), L.ptr(last_ids), L.ptr(v_render), L.ptr(v_alphas_t), L.ptr(v_rec),
                                           int(bool(cfg["absgrad"])), L.ptr(order), st), "bds_rasterize_bwd")
         if v_means2d_ext is not None and n_vis:
             v_rec[:n_vis, 7:9] += v_means2d_ext.reshape(N, 2).index_select(0, vis_ids.long())

@@ -208,7 +208,11 @@ int bds_splat_pack_sh_split(int64_t n, const int32_t *ids, int K, int degrees_to
                             bds_stream_t stream);
 int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
                       int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                      const int32_t *flatten, float *render, float *alphas, int32_t *last_ids, bds_stream_t stream);
+                      const int32_t *flatten, float *render, float *alphas, float *t_final, int32_t *last_ids, bds_stream_t stream);
+/* (t_final [C,H,W], optional -- NULL: not written: every pixel's final transmittance ITSELF.  alphas = 1 - T rounds the low bits of a
+ * small T away (T = 1e-4: 6e-4 relative), and the backward divides its way up from T: handed the same buffer, the backward starts
+ * from the exact value -- element-wise gradient errors of dense scenes drop from ~1e-2 to the fp32 formulation's ~1e-3,
+ * profiles/r09_gs_gradient_errors.json.  gsplat's backward starts from 1 - render_alphas.) */
 /* Backward into GRADIENT RECORDS v_records [n_records, 16] (64-byte stride, zero-filled by the caller, accumulated with
  * atomics), in the units of the un-scaled inputs:
  *     0-3 d/d colour | 4-6 d/d conic (a, b, c) | 7-8 d/d mean2d | 9-10 sum over pixels of |d/d mean2d| (absgrad != 0) |
@@ -217,7 +221,7 @@ int bds_rasterize_fwd(int C, int64_t n_records, int64_t M, int CH, const float *
  * bds_rasterize_bwd_schedule. */
 int bds_rasterize_bwd(int C, int64_t n_records, int64_t M, int CH, const float *records, const float *backgrounds, int W, int H,
                       int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                      const int32_t *flatten, const float *alphas, const int32_t *last_ids, const float *v_render,
+                      const int32_t *flatten, const float *alphas, const float *t_final, const int32_t *last_ids, const float *v_render,
                       const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order, bds_stream_t stream);
 /* Launch schedule for bds_rasterize_bwd (no reference counterpart; results do not depend on it).  One wave owns a
  * tile and the chip holds only about two rounds of tiles, so the launch ends with a tail of long tiles that started
@@ -394,6 +398,12 @@ int bds_sh_view_bwd_list_split(int64_t n_list, const int32_t *ids, int K, int de
  * behind the launch, for the host to read after its next wait on the stream. */
 int bds_nonfinite_flags(int n_tensors, const float *const *tensors, const int64_t *counts, uint32_t *flags_dev,
                         uint32_t *flags_pinned, bds_stream_t stream);
+/* The same with a KIND per tensor (kinds [n_tensors], NULL = all 0): the bit says "the tensor's ACTIVATED value would hold a NaN / Inf"
+ * for raw parameters whose activation runs inside a kernel (vanilla.py:393-395, checked at :407-412 on the activated tensors):
+ * 0 plain (NaN, +-Inf) | 1 argument of exp (NaN, +Inf, x >= 88.72284: exp overflows; -Inf is fine) | 2 quaternion rows [n/4, 4],
+ * 16-byte aligned (NaN / Inf components, or an all-zero row: 0/0) | 3 argument of sigmoid (NaN only). */
+int bds_nonfinite_flags_kinds(int n_tensors, const float *const *tensors, const int64_t *counts, const int *kinds, uint32_t *flags_dev,
+                              uint32_t *flags_pinned, bds_stream_t stream);
 /* Backward of gsplat's rasterization() over the visible entries, C = 1 (models/trainers/base.py:393-408: the trainer passes ACTIVATED
  * scales / opacities and post-activation colours [N,3]): what bds_project_view_bwd_list does, with the gradients of the activated
  * scales and opacities returned as they are and the colour gradient (record channels 0-2) scattered to v_colors [N,3] (may be
@@ -445,8 +455,8 @@ int bds_bilagrid_ms_ed_bwd_deferred(int nlevels, const bds_bilagrid_level_t *lev
                                     float *v_direct, bds_stream_t stream);
 int bds_rasterize_bwd_ms(int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, const float *records, int W, int H,
                          int tile_size, int list_tile_size, int tile_w, int tile_h, const int32_t *isect_offsets,
-                         const int32_t *flatten, const float *alphas, const int32_t *last_ids, float *v_records, int absgrad,
-                         const int32_t *tile_order, int nlevels, const bds_bilagrid_level_t *levels, void *ms_ws, size_t ms_ws_bytes,
+                         const int32_t *flatten, const float *alphas, const float *t_final, const int32_t *last_ids, float *v_records,
+                         int absgrad, const int32_t *tile_order, int nlevels, const bds_bilagrid_level_t *levels, void *ms_ws, size_t ms_ws_bytes,
                          const float *render, const float *sky, const float *v_depth, const float *v_alpha_in, const float *v_direct,
                          float *v_sky, bds_stream_t stream);
 
@@ -519,15 +529,15 @@ int bds_splat_pack_sh_dev(int64_t n_capacity, const uint64_t *n_dev, const int32
  * refined tile are positions in the pool. */
 int bds_rasterize_fwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                          const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, int32_t *last_ids,
-                          int32_t *tile_order, int split_len, int split_cap, int64_t split_pool, bds_stream_t stream);
+                          const int32_t *isect_offsets, const int32_t *flatten, float *render, float *alphas, float *t_final,
+                          int32_t *last_ids, int32_t *tile_order, int split_len, int split_cap, int64_t split_pool, bds_stream_t stream);
 int64_t bds_rasterize_split_pool_ints(int C, int tile_w, int tile_h, int split_cap, int64_t split_pool, int64_t M_capacity);
 int bds_rasterize_bwd_schedule_sort(int C, int tile_w, int tile_h, int32_t *tile_order, bds_stream_t stream);
 int bds_rasterize_bwd_dev(int C, int64_t n_records, int64_t M_capacity, const uint64_t *M_dev, int CH, const float *records,
                           const float *backgrounds, int W, int H, int tile_size, int list_tile_size, int tile_w, int tile_h,
-                          const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const int32_t *last_ids,
-                          const float *v_render, const float *v_alphas, float *v_records, int absgrad, const int32_t *tile_order,
-                          int split_len, int split_cap, int64_t split_pool, bds_stream_t stream);
+                          const int32_t *isect_offsets, const int32_t *flatten, const float *alphas, const float *t_final,
+                          const int32_t *last_ids, const float *v_render, const float *v_alphas, float *v_records, int absgrad,
+                          const int32_t *tile_order, int split_len, int split_cap, int64_t split_pool, bds_stream_t stream);
 /* the list-driven backward kernels and the row-wise clear with the list length on the device (n_dev -> visible effective) */
 int bds_sh_view_bwd_list_dev(int64_t n_capacity, const uint64_t *n_dev, const int32_t *ids, int K, int degrees_to_use,
                              const float *means, const float *cam_pos, const float *sh_rgb, int sh_rgb_by_rank,

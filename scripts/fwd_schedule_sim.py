@@ -61,7 +61,7 @@ with torch.no_grad():
         render, alphas = torch.empty(1, H, W, 4, device=dev), torch.empty(1, H, W, 1, device=dev)
         last = torch.zeros(1, H, W, dtype=torch.int32, device=dev)
         L.check(L.lib().bds_rasterize_fwd(1, N, M, 4, L.ptr(rec), None, W, H, 16, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(render), L.ptr(alphas),
-                                          L.ptr(last), st), "fwd")
+                                          None, L.ptr(last), st), "fwd")
         order = ops.bwd_schedule(1, W, H, 16, offs, last)
         torch.cuda.synchronize()
         work = order[1 + total:1 + 2 * total].cpu().tolist()

@@ -39,7 +39,7 @@ def pair_stats(N, W, H, view=0, params=None):
         rec = torch.empty(N, L.SPLAT_RECORD_FLOATS, device=dev)
         L.check(L.lib().bds_splat_pack(N, 3, None, L.ptr(m2), L.ptr(con), L.ptr(col), L.ptr(op), None, L.ptr(rec), L.stream()), "pack")
         L.check(L.lib().bds_rasterize_fwd(1, N, M, 3, L.ptr(rec), None, W, H, 16, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(render),
-                                          L.ptr(alphas), L.ptr(last), L.stream()), "fwd")
+                                          L.ptr(alphas), None, L.ptr(last), L.stream()), "fwd")
         n_tiles = tw * th
         start = offs.reshape(-1).long()
         end = torch.cat([start[1:], torch.tensor([M], device=dev)])

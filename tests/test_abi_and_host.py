@@ -57,15 +57,15 @@ def test_argument_validation_without_gpu(libpath):
     h = _lib.lib()
     assert h.bds_sh_fwd(10, 16, 7, None, None, None, None, None) == -1        # degree > 3
     assert h.bds_sh_fwd(0, 16, 3, None, None, None, None, None) == 0          # empty input is fine
-    assert h.bds_rasterize_fwd(1, 10, 0, 5, None, None, 64, 64, 16, 16, 4, 4, None, None, None, None, None, None) == -1    # CH = 5
-    assert h.bds_rasterize_fwd(1, 10, 0, 3, None, None, 64, 64, 8, 8, 8, 8, None, None, None, None, None, None) == -1     # tile size 8
-    assert h.bds_rasterize_fwd(1, 10, 0, 3, None, None, 64, 64, 16, 24, 4, 4, None, None, None, None, None, None) == -1   # list tile not a multiple of 16
-    assert h.bds_splat_pack(0, 4, None, None, None, None, None, None, None, None) == 0 and h.bds_splat_pack(5, 2, None, None, None, None, None, None, None, None) == -1
+    assert h.bds_rasterize_fwd(1, 10, 0, 5, None, None, 64, 64, 16, 16, 4, 4, None, None, None, None, None, None, None) == -1    # CH = 5
+    assert h.bds_rasterize_fwd(1, 10, 0, 3, None, None, 64, 64, 8, 8, 8, 8, None, None, None, None, None, None, None) == -1     # tile size 8
+    assert h.bds_rasterize_fwd(1, 10, 0, 3, None, None, 64, 64, 16, 24, 4, 4, None, None, None, None, None, None, None) == -1   # list tile not a multiple of 16
+    assert h.bds_splat_pack(0, 4, None, None, None, None, None, None, None, None) == 0 and h.bds_splat_pack(5, 2, None, None, None, None, None, None, None, None, None) == -1
     assert h.bds_sh_view_bwd_list(0, None, 16, 3, None, None, None, 0, None, None, None, 0, None) == 0
     assert h.bds_sh_view_bwd_list(4, None, 16, 3, None, None, None, 0, None, None, None, 0, None) == -1               # null list
     assert h.bds_splat_pack_sh(0, None, 16, 3, None, None, None, None, None, None, None, None, None, None, None) == 0
-    assert h.bds_splat_pack_sh(4, None, 16, 3, None, None, None, None, None, None, None, None, None, None, None) == -1   # null list
-    assert h.bds_splat_pack_sh(4, None, 15, 3, None, None, None, None, None, None, None, None, None, None, None) == -1   # K < 16 bases
+    assert h.bds_splat_pack_sh(4, None, 16, 3, None, None, None, None, None, None, None, None, None, None, None, None) == -1   # null list
+    assert h.bds_splat_pack_sh(4, None, 15, 3, None, None, None, None, None, None, None, None, None, None, None, None) == -1   # K < 16 bases
     assert h.bds_isect_prepare_workspace_bytes(1, 1000) > 5 * 4000
     assert h.bds_isect_build_workspace_bytes(1, 1000, 50000) > 3 * 4 * 50000
     lv = (_lib.BdsLevel * 1)()

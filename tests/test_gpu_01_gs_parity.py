@@ -60,7 +60,8 @@ def test_projection_fwd_bwd(ops, seed, N, W, H):
     radii, m2, d, c, comp = ops.fully_fused_projection(gpu_in["means"], gpu_in["quats"], gpu_in["scales"], vm_g, sc["Ks"].cuda(), W, H)
     assert comp is None
     same = radii[0].cpu() == radii_r
-    assert same.float().mean() > 0.99
+    print(f"[projection] seed {seed}: radii decisions equal to the fp64 oracle's for {float(same.float().mean()):.5f} of the Gaussians")
+    assert same.float().mean() > 0.997
     vis = (radii_r > 0) & same
     assert int(vis.sum()) > N // 10
     assert rel_err(m2[0].cpu()[vis], m2_r[vis]) < 1e-5
@@ -274,6 +275,20 @@ def test_isect_empty(ops):
 
 
 _ORACLE_CACHE = {}
+_GRAD_LOG = []     # per (case, parameter): the HIP path's gradient errors next to the fp32 oracle's, both against the fp64 oracle
+
+
+def teardown_module(module):
+    """Leave the measured gradient errors where scripts/gpu_round.sh collects them (gpurun_out/ -> profiles/)."""
+    import json
+    import os
+    if _GRAD_LOG:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            json.dump(_GRAD_LOG, open(os.path.join(d, "gs_gradient_errors.json"), "w"), indent=1)
+        except OSError:
+            pass
 
 
 def _oracle_render(key, sc, W, H, mode, bg, seed):
@@ -291,9 +306,17 @@ def _oracle_render(key, sc, W, H, mode, bg, seed):
     wt = torch.randn(r_ref.shape, generator=g) * stable[None, ..., None]
     wa = torch.randn(a_ref.shape, generator=g) * stable[None, ..., None]
     ((r_ref * wt.double()).sum() + (a_ref * wa.double()).sum()).backward()
+    # the SAME oracle in float32 on the same loss: what plain fp32 arithmetic of the reference's formulation loses against fp64 -- the
+    # yardstick the HIP path's element-wise gradient error is held against below (norm-relative alone hides single elements)
+    in32 = {k: sc[k].detach().clone().float().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    r32, a32, m32 = G.rasterization(in32["means"], in32["quats"], in32["scales"], in32["opacities"], in32["colors"], sc["viewmats"].float(),
+                                    sc["Ks"].float(), W, H, render_mode=mode, backgrounds=None if bg is None else bg.float())
+    ((r32 * wt).sum() + (a32 * wa).sum()).backward()
     out = dict(r=r_ref.detach(), a=a_ref.detach(), radii=m_ref["radii"], stable=stable, wt=wt, wa=wa,
                absgrad=G.absgrad_from_probe(probes[0], sc["means"].shape[0]), means2d=m_ref["means2d"].detach(),
-               grads={k: (None if v.grad is None else v.grad.clone()) for k, v in ref_in.items()})
+               grads={k: (None if v.grad is None else v.grad.clone()) for k, v in ref_in.items()},
+               grads32={k: (None if v.grad is None else v.grad.clone()) for k, v in in32.items()},
+               radii32_equal=bool(torch.equal(m32["radii"], m_ref["radii"])))
     _ORACLE_CACHE[key] = out
     return out
 
@@ -329,11 +352,19 @@ def test_rasterization_end_to_end(ops, seed, N, W, H, mode):
             assert gpu_in[k].grad is None or float(gpu_in[k].grad.abs().max()) == 0.0
             continue
         rel, elem, elem99 = grad_errors(gpu_in[k].grad, gref)
+        rel32, elem32, elem99_32 = grad_errors(ref["grads32"][k], gref) if ref["radii32_equal"] else (float("nan"),) * 3
+        _GRAD_LOG.append(dict(case=f"seed{seed}_N{N}_{W}x{H}_{mode}", param=k, hip_norm_rel=rel, hip_elem_worst=elem, hip_elem_p99=elem99,
+                              oracle_fp32_norm_rel=rel32, oracle_fp32_elem_worst=elem32, oracle_fp32_elem_p99=elem99_32))
         assert rel < 1e-3, (k, rel)
-        # element-wise, next to the norm bound (entries above 1e-3 of the largest one): 99 % of them to 5e-3, the worst to 6e-2
-        # (measured over the five cases: 99th percentile <= 2.4e-3, worst 4.0e-2 on ONE scale gradient of the 4000-Gaussian case
-        # -- a sum of cancelling per-pixel terms, fp32 here against fp64 in the oracle)
-        assert elem99 < 5e-3 and elem < 6e-2, (k, elem99, elem)
+        # element-wise, next to the norm bound (entries above 1e-3 of the largest one), held against the SAME oracle run in float32 (what
+        # plain fp32 arithmetic of the reference's formulation loses against fp64): the HIP path's worst element and 99th percentile
+        # stay within 2x the fp32 oracle's (+ a floor for cases where that is ~1e-5) and under north_star's 1e-3 / 3e-4 outright.
+        # Measured (profiles/r09_gs_gradient_errors.json): worst 9.3e-4 (fp32 oracle: 1.2e-3), 99th percentile <= 1.4e-4 (1.1e-4).
+        # Before the backward started from the exact final transmittance (bds.h ``t_final``; it used 1 - alpha as gsplat does) the
+        # dense cases sat at 4.0e-2 / 3.8e-3 -- 40x the fp32 oracle: not "fp32 cancellation", the rounding of alpha = 1 - T.
+        assert elem < 2e-3 and elem99 < 3e-4, (k, elem, elem99)
+        if ref["radii32_equal"]:
+            assert elem <= 2.0 * elem32 + 1e-4 and elem99 <= 2.0 * elem99_32 + 2e-5, (k, elem, elem32, elem99, elem99_32)
     # absgrad (trainers/base.py:280-297 -> gaussians/vanilla.py:163-191 drive split / duplicate with it): the VALUE against the
     # oracle's sum over pixels of |dL/dmean2d through that pixel|, on the same tensor object the caller holds
     assert hasattr(meta["means2d"], "absgrad") and meta["means2d"].absgrad.shape == meta["means2d"].shape
@@ -491,7 +522,7 @@ def test_backward_schedule_is_a_permutation_and_invisible(ops, seed, N, W, H, C)
     L.check(L.lib().bds_splat_pack(Cn * N, 3, None, L.ptr(m2.detach()), L.ptr(con.detach()), L.ptr(col.detach()), L.ptr(op.detach()), None, L.ptr(rec),
                                    L.stream()), "pack")
     L.check(L.lib().bds_rasterize_fwd(Cn, Cn * N, M, 3, L.ptr(rec), None, W, H, 16, 16, tw, th, L.ptr(offs), L.ptr(fids), L.ptr(rr), L.ptr(aa),
-                                      L.ptr(last), L.stream()), "fwd")
+                                      None, L.ptr(last), L.stream()), "fwd")
     order = ops.bwd_schedule(Cn, W, H, 16, offs, last)
     total = Cn * tw * th
     assert int(order[0]) == 1                         # [tag = sorted | order | work] (csrc/rasterize.hip: pick_item)

@@ -124,7 +124,7 @@ def test_schedule_keys_left_by_the_forward_compositor(list_tile):
 
         def forward(order):
             L.check(lib.bds_rasterize_fwd_dev(1, N, M + 100, m_dev.data_ptr(), 4, L.ptr(rec), None, W, H, 16, list_tile, tw, th, L.ptr(offs),
-                                              L.ptr(fids), L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(order), 0, 0, 0, st), "fwd")
+                                              L.ptr(fids), L.ptr(render), L.ptr(alphas), None, L.ptr(last), L.ptr(order), 0, 0, 0, st), "fwd")
             L.check(lib.bds_rasterize_bwd_schedule_sort(1, tw, th, L.ptr(order), st), "sort")
 
         # sorted form (option 8 = 0): the waves leave their keys, one launch sorts them

@@ -147,3 +147,66 @@ def test_nonfinite_flags_sees_every_element(mods):
     big = torch.finfo(torch.float32).max
     ts[0][5] = big                                                               # the largest finite value is finite
     assert run() == 0
+
+
+def test_nonfinite_kinds_follow_the_activations(mods):
+    """bds_nonfinite_flags_kinds: the raw one-view node checks the raw parameters, so the bit has to say what the reference's check of
+    the ACTIVATED tensors would (vanilla.py:393-395,407-412): exp of a log-scale >= 88.72284 is Inf (and of -Inf is 0: fine), a
+    zero quaternion normalises to NaN, sigmoid maps +-Inf logits to 0 / 1 (fine) -- each against torch's own activation."""
+    import ctypes
+    from bilateral_driving_amd import _lib as L
+    lib = L.lib()
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+    g = torch.Generator().manual_seed(0)
+    ls = (torch.rand(30011, generator=g) * 8 - 6).cuda()
+    q = torch.randn(5001, 4, generator=g).cuda()
+    lo = (torch.randn(7003, generator=g) * 3).cuda()
+    ts, kinds = [ls, q, lo], (1, 2, 3)
+    acts = [torch.exp, lambda t: t / t.norm(dim=-1, keepdim=True), torch.sigmoid]
+
+    def run():
+        ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        cnts = (ctypes.c_int64 * 3)(*[t.numel() for t in ts])
+        L.check(lib.bds_nonfinite_flags_kinds(3, ptrs, cnts, (ctypes.c_int * 3)(*kinds), flag.data_ptr(), None, L.stream()), "kinds")
+        got = int(flag.item())
+        want = sum((1 << i) for i, (t, f) in enumerate(zip(ts, acts)) if not bool(torch.isfinite(f(t)).all()))
+        assert got == want, (got, want)
+        return got
+
+    assert run() == 0
+    cases = [(0, 17, 88.72284, 1), (0, 17, 88.7228, 0), (0, 30010, float("inf"), 1), (0, 3, -float("inf"), 0), (0, 9, float("nan"), 1),
+             (0, 11, 200.0, 1), (2, 5, float("inf"), 0), (2, 5, -float("inf"), 0), (2, 7002, float("nan"), 4)]
+    for t_i, idx, val, want in cases:
+        keep = float(ts[t_i].view(-1)[idx])
+        ts[t_i].view(-1)[idx] = val
+        assert run() == want, (t_i, idx, val)
+        ts[t_i].view(-1)[idx] = keep
+    for row, vals, want in ((123, (0.0, 0.0, 0.0, 0.0), 2), (123, (0.0, -0.0, 0.0, 0.0), 2), (123, (0.0, 0.0, 1e-30, 0.0), 0),
+                            (5000, (float("inf"), 1.0, 0.0, 0.0), 2), (0, (float("nan"), 1.0, 0.0, 0.0), 2)):
+        keep = q[row].clone()
+        q[row] = torch.tensor(vals, device="cuda")
+        assert run() == want, (row, vals)
+        q[row] = keep
+    assert run() == 0
+
+
+def test_raw_node_raises_on_what_the_activations_make_nonfinite(mods):
+    Hn, M = mods
+    cam, p, grids, sky, target = _setup(Hn, N=8000, W=256, H=192)
+    model = Hn.VanillaModel(p)
+    M.install(Hn.VanillaModel)
+    try:
+        with torch.no_grad():
+            model._scales[17, 2] = 90.0                          # finite, but exp(90) is not
+            with pytest.raises(ValueError, match="scales"):
+                Hn.render_view_model(model, cam, grids, 0, sky)
+            model._scales[17, 2] = -float("inf")                 # exp(-Inf) = 0: the reference does not raise
+            model._opacities.view(-1)[5] = float("inf")          # sigmoid(Inf) = 1: neither
+            Hn.render_view_model(model, cam, grids, 0, sky)
+            model._scales[17, 2] = 0.0
+            model._opacities.view(-1)[5] = 0.0
+            model._quats[99] = 0.0                               # 0 / 0
+            with pytest.raises(ValueError, match="quats"):
+                Hn.render_view_model(model, cam, grids, 0, sky)
+    finally:
+        M.uninstall(Hn.VanillaModel)

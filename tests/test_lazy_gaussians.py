@@ -65,3 +65,30 @@ def test_install_swaps_the_class_method_and_uninstall_restores_it():
     finally:
         M.uninstall(Hn.VanillaModel)
     assert Hn.VanillaModel.__dict__["get_gaussians"] is eager
+
+
+def test_materialising_a_placeholder_raises_on_nonfinite_values_as_the_reference_does():
+    """vanilla.py:407-412 raises when an ACTIVATED tensor holds a NaN / Inf; the one-view node checks the raw parameters itself, every
+    other route (several classes concatenated, opacity masks, the fall-back of rasterization()) materialises a placeholder -- which
+    runs the same check, on the activated value: a log-scale of 90 (finite, exp = Inf) and a zero quaternion (0 / 0) raise,
+    exp(-Inf) = 0 and sigmoid(Inf) = 1 do not."""
+    import pytest
+    src = _src()
+    N = src.means.shape[0]
+    with torch.no_grad():
+        src.log_scales[3, 1] = 90.0
+    with pytest.raises(ValueError, match="Inf detected in gaussian _scales at step 7"):
+        torch.cat([LazyField(src, "_scales", (N, 3)), torch.ones(2, 3)], dim=0)
+    src = _src()
+    with torch.no_grad():
+        src.quats[5] = 0.0
+        src.log_scales[0, 0] = -float("inf")
+        src.logits[2] = float("inf")
+    with pytest.raises(ValueError, match="NaN detected in gaussian _quats"):
+        LazyField(src, "_quats", (N, 4)) * 1.0
+    assert bool(torch.isfinite(LazyField(src, "_scales", (N, 3)) * 1.0).all())
+    assert bool(torch.isfinite(LazyField(src, "_opacities", (N, 1)).squeeze() * torch.ones(N)).all())
+    with torch.no_grad():
+        src.means[1, 2] = float("nan")
+    with pytest.raises(ValueError, match="NaN detected in gaussian _means"):
+        LazyField(src, "_means", (N, 3)) + 0.0
