@@ -304,7 +304,12 @@ template <int kKind>
 __device__ __forceinline__ uint32_t nonfinite4(uint4 v) {
   uint32_t b = (uint32_t)nonfinite_bits<kKind>(v.x) | (uint32_t)nonfinite_bits<kKind>(v.y) | (uint32_t)nonfinite_bits<kKind>(v.z) |
                (uint32_t)nonfinite_bits<kKind>(v.w);
-  if (kKind == 2) b |= (uint32_t)(((v.x | v.y | v.z | v.w) & 0x7fffffffu) == 0u);   // (an aligned 16-byte piece of a [N,4] array is a row)
+  if (kKind == 2) {   // (an aligned 16-byte piece of a [N,4] array is a row.)  |q|^2 == 0 in fp32 -- all zeros, or components so small that
+    //                     their squares underflow, as torch's norm does: q / 0 is NaN / Inf
+    const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z), w = __uint_as_float(v.w);
+    const float n2 = x * x + y * y + z * z + w * w;
+    b |= (uint32_t)(!(n2 > 0.f));
+  }
   return b;
 }
 template <int kKind>

@@ -69,8 +69,6 @@ class FlatGradients:
             assert p.dtype == torch.float32 and p.device == dev and p.requires_grad
         self.row_block = bool(row_block)
         if self.row_block:
-            # single-process layout: pack() / all_reduce() move whole tensors, the exchange's compact buffers are five arrays
-            assert not _active(), "FlatGradients(row_block=True) is the single-process layout (no process group of several ranks)"
             N = self.params[0].shape[0]
             assert len(self.params) >= 4 and [tuple(p.shape) for p in self.params[:4]] == [(N, 3), (N, 4), (N, 3), (N,)], \
                 "row_block: means [N,3], quats [N,4], log_scales [N,3], opacity logits [N] first"
@@ -216,6 +214,8 @@ class FlatGradients:
         """Sum (or average) the gradients over all ranks.  No-op for world size 1."""
         if not _active():
             return None
+        # (row_block is the single-process layout: the exchange's compact buffers and pack() know the five arrays only)
+        assert not self.row_block, "FlatGradients(row_block=True) can not be exchanged over ranks"
         flat = self.pack()
         for p, v in zip(self.params, self._views):
             p.grad = v
@@ -277,6 +277,7 @@ class FrameExchange:
         self.flat = flat
         self.names = list(names)
         assert flat.sparse_rows, "FrameExchange keeps the dense buffer clean row-wise: FlatGradients(sparse_rows=True)"
+        assert not flat.row_block, "FrameExchange: FlatGradients(row_block=True) is the single-process layout"
         self.arena = flat.arena(self.names)
         assert sorted(self.names[:len(ROW_NAMES)]) == sorted(ROW_NAMES), "the five per-Gaussian parameters must lead the parameter list"
         self.N = self.arena["means"].shape[0]

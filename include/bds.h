@@ -401,7 +401,7 @@ int bds_nonfinite_flags(int n_tensors, const float *const *tensors, const int64_
 /* The same with a KIND per tensor (kinds [n_tensors], NULL = all 0): the bit says "the tensor's ACTIVATED value would hold a NaN / Inf"
  * for raw parameters whose activation runs inside a kernel (vanilla.py:393-395, checked at :407-412 on the activated tensors):
  * 0 plain (NaN, +-Inf) | 1 argument of exp (NaN, +Inf, x >= 88.72284: exp overflows; -Inf is fine) | 2 quaternion rows [n/4, 4],
- * 16-byte aligned (NaN / Inf components, or an all-zero row: 0/0) | 3 argument of sigmoid (NaN only). */
+ * 16-byte aligned (NaN / Inf components, or a row whose squared norm is 0 in fp32: 0/0, x/0) | 3 argument of sigmoid (NaN only). */
 int bds_nonfinite_flags_kinds(int n_tensors, const float *const *tensors, const int64_t *counts, const int *kinds, uint32_t *flags_dev,
                               uint32_t *flags_pinned, bds_stream_t stream);
 /* Backward of gsplat's rasterization() over the visible entries, C = 1 (models/trainers/base.py:393-408: the trainer passes ACTIVATED

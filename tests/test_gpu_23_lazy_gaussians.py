@@ -181,7 +181,7 @@ def test_nonfinite_kinds_follow_the_activations(mods):
         ts[t_i].view(-1)[idx] = val
         assert run() == want, (t_i, idx, val)
         ts[t_i].view(-1)[idx] = keep
-    for row, vals, want in ((123, (0.0, 0.0, 0.0, 0.0), 2), (123, (0.0, -0.0, 0.0, 0.0), 2), (123, (0.0, 0.0, 1e-30, 0.0), 0),
+    for row, vals, want in ((123, (0.0, 0.0, 0.0, 0.0), 2), (123, (0.0, -0.0, 0.0, 0.0), 2), (123, (0.0, 0.0, 1e-30, 0.0), 2), (123, (0.0, 0.0, 1e-10, 0.0), 0),
                             (5000, (float("inf"), 1.0, 0.0, 0.0), 2), (0, (float("nan"), 1.0, 0.0, 0.0), 2)):
         keep = q[row].clone()
         q[row] = torch.tensor(vals, device="cuda")
