@@ -162,6 +162,40 @@ __device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &
   pp = pp + (-step_size) * (mm / denom);
 }
 
+// ---- several tensors, one launch ------------------------------------------------------------------------------------------------
+// The reference's optimizer holds ~10 small groups next to the two SH tensors (xyz, rotation, scaling, opacity, the bilateral grids of
+// every level, sky, poses: models/trainers/base.py:201-226); one launch per tensor is ~8 us of launch gap each for microseconds of
+// work.  bds_adam_step_multi takes up to kAdamMulti tensors with their own hyper-parameters, steps and gradient layouts (contiguous,
+// or a column range of a row block as bds_adam_step_rows) and gives every tensor a contiguous range of the workgroups.
+constexpr int kAdamMulti = 12;
+struct AdamMultiArgs {
+  float *p[kAdamMulti], *g[kAdamMulti], *m[kAdamMulti], *v[kAdamMulti];
+  int64_t n[kAdamMulti], grad_stride[kAdamMulti];
+  int width[kAdamMulti], block0[kAdamMulti + 1];
+  float step_size[kAdamMulti], bc2_sqrt[kAdamMulti], eps[kAdamMulti], wd[kAdamMulti], one_minus_b1[kAdamMulti], b2[kAdamMulti],
+      one_minus_b2[kAdamMulti];
+  int count, consume;
+};
+__global__ __launch_bounds__(kOptBlock) void adam_step_multi_kernel(AdamMultiArgs A) {
+  int t = 0;
+#pragma unroll 1
+  while (t + 1 < A.count && (int)blockIdx.x >= A.block0[t + 1]) t++;
+  const int nb = A.block0[t + 1] - A.block0[t], lb = (int)blockIdx.x - A.block0[t];
+  const int64_t n = A.n[t], gs = A.grad_stride[t];
+  const int width = A.width[t];
+  float *__restrict__ p = A.p[t], *__restrict__ g = A.g[t], *__restrict__ m = A.m[t], *__restrict__ v = A.v[t];
+  const float ss = A.step_size[t], bc2s = A.bc2_sqrt[t], eps = A.eps[t], wd = A.wd[t], omb1 = A.one_minus_b1[t], b2 = A.b2[t],
+              omb2 = A.one_minus_b2[t];
+  for (int64_t i = (int64_t)lb * kOptBlock + threadIdx.x; i < n; i += (int64_t)nb * kOptBlock) {
+    float *gp = g + i;
+    if (width > 0) { const int64_t r = i / width; gp = g + r * gs + (i - r * width); }
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_upd(pp, *gp, mm, vv, ss, bc2s, omb1, b2, omb2, eps, wd);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (A.consume) *gp = 0.f;
+  }
+}
+
 // kVec = 4: row_floats % 4 == 0 and 16-byte aligned arrays: a thread owns four consecutive columns of a row (one float4 of p / m / v /
 // g each way; the replay loop reads its table entry once for the four)
 template <int kVec>
@@ -262,6 +296,41 @@ extern "C" int bds_adam_rows_advance(int64_t n_capacity, const uint64_t *n_dev, 
                      (float)(1.0 - beta2), (float)eps, (float)weight_decay)
   if (vec) BDS_ADAM_ADVANCE(4); else BDS_ADAM_ADVANCE(1);
 #undef BDS_ADAM_ADVANCE
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_adam_step_multi(int n_tensors, float *const *params, float *const *grads, float *const *exp_avgs,
+                                   float *const *exp_avg_sqs, const int64_t *counts, const int *widths, const int64_t *grad_strides,
+                                   const double *lrs, const double *beta1s, const double *beta2s, const double *eps,
+                                   const double *weight_decays, const int64_t *steps, int consume, bds_stream_t stream) {
+  BDS_REQUIRE(n_tensors >= 0 && n_tensors <= bds::kAdamMulti);
+  if (n_tensors == 0) return BDS_OK;
+  BDS_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && counts && widths && grad_strides && lrs && beta1s && beta2s && eps &&
+              weight_decays && steps);
+  bds::AdamMultiArgs A;
+  A.count = 0; A.consume = consume;
+  int blocks = 0;
+  for (int t = 0; t < n_tensors; t++) {
+    BDS_REQUIRE(counts[t] >= 0 && steps[t] >= 1 && widths[t] >= 0 && (widths[t] == 0 || grad_strides[t] >= widths[t]));
+    if (counts[t] == 0) continue;
+    BDS_REQUIRE(params[t] && grads[t] && exp_avgs[t] && exp_avg_sqs[t]);
+    const int k = A.count++;
+    A.p[k] = params[t]; A.g[k] = grads[t]; A.m[k] = exp_avgs[t]; A.v[k] = exp_avg_sqs[t];
+    A.n[k] = counts[t]; A.width[k] = widths[t]; A.grad_stride[k] = grad_strides[t];
+    const double bc1 = 1.0 - pow(beta1s[t], (double)steps[t]), bc2 = 1.0 - pow(beta2s[t], (double)steps[t]);   // (as bds_adam_step)
+    A.step_size[k] = (float)(lrs[t] / bc1); A.bc2_sqrt[k] = (float)sqrt(bc2);
+    A.eps[k] = (float)eps[t]; A.wd[k] = (float)weight_decays[t];
+    A.one_minus_b1[k] = (float)(1.0 - beta1s[t]); A.b2[k] = (float)beta2s[t]; A.one_minus_b2[k] = (float)(1.0 - beta2s[t]);
+    int64_t nb = cdiv(counts[t], kOptBlock * 2);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    A.block0[k] = blocks;
+    blocks += (int)nb;
+  }
+  if (A.count == 0) return BDS_OK;
+  A.block0[A.count] = blocks;
+  hipLaunchKernelGGL(bds::adam_step_multi_kernel, dim3((unsigned)blocks), dim3(kOptBlock), 0, as_stream(stream), A);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

@@ -12,14 +12,32 @@ from . import _lib as L
 
 
 class FusedAdam(torch.optim.Optimizer):
+    MULTI_MAX_TENSORS, MULTI_MAX_ELEMS = 12, 1 << 24     # bds_adam_step_multi: tensors per launch; larger tensors take their own pass
+
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  consume_grads: bool = False):
         """``consume_grads``: every gradient is cleared by the pass that reads it (bds_adam_step_consume) -- for loops whose backward
         accumulates into persistent ``.grad`` buffers (``graph_view.FrameGraph(clear_grads=False)``): no ``zero_grad()`` pass."""
         self.consume_grads = bool(consume_grads)
+        # the small groups (xyz, rotation, scaling, opacity, the grids of every level, ...) step in ONE launch (include/bds.h
+        # bds_adam_step_multi: same arithmetic per element); BDS_ADAM_MULTI=0: one launch per tensor
+        self.multi_tensor = __import__("os").environ.get("BDS_ADAM_MULTI", "1") == "1"
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def _step_multi(self, batch) -> None:
+        import ctypes as C
+        n = len(batch)
+        if n == 0:
+            return
+        vp = lambda vals: (C.c_void_p * n)(*vals)
+        dbl = lambda i: (C.c_double * n)(*[b[i] for b in batch])
+        L.check(L.lib().bds_adam_step_multi(
+            n, vp([b[0].data_ptr() for b in batch]), vp([b[1] for b in batch]), vp([b[2].data_ptr() for b in batch]),
+            vp([b[3].data_ptr() for b in batch]), (C.c_int64 * n)(*[b[4] for b in batch]), (C.c_int * n)(*[b[5] for b in batch]),
+            (C.c_int64 * n)(*[b[6] for b in batch]), dbl(7), dbl(8), dbl(9), dbl(10), dbl(11), (C.c_int64 * n)(*[b[12] for b in batch]),
+            int(self.consume_grads), L.stream()), "bds_adam_step_multi")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -28,6 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib, st = L.lib(), L.stream()
+        batch = []      # (p, grad address, m, v, n, width, grad stride, lr, b1, b2, eps, wd, step): tensors stepped by ONE launch
         for group in self.param_groups:
             b1, b2 = group["betas"]
             if group.get("deferred_rows"):       # (DeferredRowAdam steps these through the views' visible-id lists)
@@ -50,21 +69,30 @@ class FusedAdam(torch.optim.Optimizer):
                 if not (m.is_contiguous() and v.is_contiguous() and m.shape == p.shape and v.shape == p.shape):
                     raise RuntimeError("optimizer state does not match its parameter (after densification, re-create both)")
                 gr = p.grad
+                hyper = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(state["step"]))
                 if (not gr.is_contiguous() and gr.dim() in (1, 2) and gr.shape == p.shape and (gr.dim() == 1 or gr.stride(1) == 1)
                         and gr.stride(0) >= (1 if gr.dim() == 1 else gr.shape[1])):
                     # a column range of a row block (dist.FlatGradients(row_block=True)): read -- and cleared -- where it lies
                     width = 1 if gr.dim() == 1 else int(gr.shape[1])
+                    if self.multi_tensor:
+                        batch.append((p, gr.data_ptr(), m, v, p.numel(), width, int(gr.stride(0)), *hyper))
+                        continue
                     L.check(lib.bds_adam_step_rows(p.shape[0], width, int(gr.stride(0)), L.ptr(p), gr.data_ptr(), L.ptr(m), L.ptr(v),
-                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                   int(state["step"]), int(self.consume_grads), st), "bds_adam_step_rows")
+                                                   *hyper[:5], hyper[5], int(self.consume_grads), st), "bds_adam_step_rows")
                     continue
                 g = p.grad.contiguous()
                 consume = self.consume_grads and g.data_ptr() == p.grad.data_ptr()     # (clearing a contiguous COPY would clear nothing)
+                if self.multi_tensor and p.numel() <= self.MULTI_MAX_ELEMS and (consume or not self.consume_grads):
+                    batch.append((p, g.data_ptr(), m, v, p.numel(), 0, 0, *hyper))      # (large tensors keep the 16-byte-vector pass)
+                    if g is not p.grad:
+                        batch[-1] = batch[-1] + (g,)     # (keep the contiguous copy alive until the launch)
+                    continue
                 fn = lib.bds_adam_step_consume if consume else lib.bds_adam_step
-                L.check(fn(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), float(group["lr"]), float(b1), float(b2),
-                           float(group["eps"]), float(group["weight_decay"]), int(state["step"]), st), "bds_adam_step")
+                L.check(fn(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), *hyper, st), "bds_adam_step")
                 if self.consume_grads and not consume:
                     p.grad.zero_()
+        for k in range(0, len(batch), self.MULTI_MAX_TENSORS):
+            self._step_multi(batch[k:k + self.MULTI_MAX_TENSORS])
         return loss
 
 

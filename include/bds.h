@@ -644,6 +644,14 @@ int bds_adam_step_rows(int64_t n_rows, int width, int64_t grad_stride, float *pa
                        double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int consume,
                        bds_stream_t stream);
 
+/* bds_adam_step / _consume / _rows for up to 12 tensors in ONE launch (the trainer's ~10 small groups, models/trainers/base.py:201-226:
+ * one launch per tensor is mostly launch gap).  Arrays of n_tensors entries; widths[t] = 0: a contiguous gradient, else element
+ * (r, c) of tensor t's gradient at grads[t][r * grad_strides[t] + c] with c < widths[t]; steps[t]: the tensor's own 1-based step.
+ * The same arithmetic per element: bit-equal to the single-tensor passes. */
+int bds_adam_step_multi(int n_tensors, float *const *params, float *const *grads, float *const *exp_avgs, float *const *exp_avg_sqs,
+                        const int64_t *counts, const int *widths, const int64_t *grad_strides, const double *lrs, const double *beta1s,
+                        const double *beta2s, const double *eps, const double *weight_decays, const int64_t *steps, int consume,
+                        bds_stream_t stream);
 /* Deferred ("row-lazy") Adam for a parameter [N, row_floats] (row_floats <= 256) that only the rows of a view's visible-id list read
  * -- the SH coefficients -- with the numbers of the dense pass, bit for bit: the reference steps one dense Adam after every
  * single-view iteration (tools/train.py:252-283, models/trainers/base.py:222-226,502-516) and a row whose gradient is zero still
