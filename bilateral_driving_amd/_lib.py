@@ -59,6 +59,8 @@ _SIGS = {
     "bds_splat_pack_rgbd": (_i, [_i64, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_expected_depth_fwd": (_i, [_i64, _f, _f, _f, _f]),
     "bds_expected_depth_bwd": (_i, [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "bds_expected_depth_split_fwd": (_i, [_i64, _i, _f, _f, _f, _f, _f]),
+    "bds_expected_depth_split_bwd": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_splat_pack": (_i, [_i64, _i, _f, _f, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_fwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "bds_rasterize_bwd": (_i, [_i, _i64, _i64, _i, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),

@@ -1040,6 +1040,34 @@ __global__ __launch_bounds__(256) void ed_bwd_kernel(int64_t P, int ch, int ed, 
   v_render[i] = v;
   v_alphas[i] = va;
 }
+// the same with the image handed out as TWO arrays, rgb [P,3] and depth [P,1] -- what the reference's trainer splits the render into
+// right away (models/trainers/base.py:409-419 torch.split(renders, [3, 1])): as node outputs of their own they need no slice backward
+__global__ __launch_bounds__(256) void ed_split_fwd_kernel(int64_t P, int ed, const float4 *__restrict__ render, const float *__restrict__ alphas,
+                                                           float *__restrict__ rgb, float *__restrict__ depth) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float4 v = render[i];
+  rgb[i * 3] = v.x; rgb[i * 3 + 1] = v.y; rgb[i * 3 + 2] = v.z;
+  depth[i] = ed ? v.w / fmaxf(alphas[i], 1e-10f) : v.w;
+}
+__global__ __launch_bounds__(256) void ed_split_bwd_kernel(int64_t P, int ed, const float4 *__restrict__ render, const float *__restrict__ alphas,
+                                                           const float *__restrict__ v_rgb, const float *__restrict__ v_depth,
+                                                           const float *__restrict__ v_alphas_in, float4 *__restrict__ v_render,
+                                                           float *__restrict__ v_alphas) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float va = v_alphas_in ? v_alphas_in[i] : 0.f;
+  if (v_rgb) { v.x = v_rgb[i * 3]; v.y = v_rgb[i * 3 + 1]; v.z = v_rgb[i * 3 + 2]; }
+  if (v_depth) v.w = v_depth[i];
+  if (ed) {   // (the arithmetic of ed_bwd_kernel)
+    const float a = alphas[i], ac = fmaxf(a, 1e-10f), vd = v.w;
+    v.w = vd / ac;
+    if (a >= 1e-10f) va -= render[i].w * vd / (ac * ac);
+  }
+  v_render[i] = v;
+  v_alphas[i] = va;
+}
 }  // namespace bds
 
 extern "C" int bds_splat_pack_rgbd(int64_t n, const int32_t *ids, const float *means2d, const float *conics, const float *colors3,
@@ -1070,6 +1098,29 @@ extern "C" int bds_expected_depth_bwd(int64_t P, int channels, int expected_dept
   BDS_REQUIRE(render4 && alphas && v_render4 && v_alphas && aligned16(render4) && aligned16(v_render4));
   hipLaunchKernelGGL(ed_bwd_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, as_stream(stream), P, channels, expected_depth,
                      reinterpret_cast<const float4 *>(render4), alphas, v_out, v_alphas_in, reinterpret_cast<float4 *>(v_render4), v_alphas);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+
+extern "C" int bds_expected_depth_split_fwd(int64_t P, int expected_depth, const float *render4, const float *alphas, float *rgb3,
+                                           float *depth1, bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(render4 && alphas && rgb3 && depth1 && aligned16(render4));
+  hipLaunchKernelGGL(ed_split_fwd_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, as_stream(stream), P, expected_depth,
+                     reinterpret_cast<const float4 *>(render4), alphas, rgb3, depth1);
+  BDS_LAUNCH_CHECK();
+  return BDS_OK;
+}
+extern "C" int bds_expected_depth_split_bwd(int64_t P, int expected_depth, const float *render4, const float *alphas, const float *v_rgb3,
+                                           const float *v_depth1, const float *v_alphas_in, float *v_render4, float *v_alphas,
+                                           bds_stream_t stream) {
+  BDS_REQUIRE(P >= 0);
+  if (P == 0) return BDS_OK;
+  BDS_REQUIRE(render4 && alphas && v_render4 && v_alphas && aligned16(render4) && aligned16(v_render4));
+  hipLaunchKernelGGL(ed_split_bwd_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, as_stream(stream), P, expected_depth,
+                     reinterpret_cast<const float4 *>(render4), alphas, v_rgb3, v_depth1, v_alphas_in, reinterpret_cast<float4 *>(v_render4),
+                     v_alphas);
   BDS_LAUNCH_CHECK();
   return BDS_OK;
 }

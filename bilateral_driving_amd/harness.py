@@ -323,9 +323,13 @@ def render_view_model(model, cam: Camera, grids: Sequence[Tensor], img_idx: int,
                                           colors=gs["_rgbs"], viewmats=cam.viewmat[None], Ks=cam.K[None], width=W, height=H, packed=False,
                                           absgrad=True, sparse_grad=False, rasterize_mode="classic", near_plane=near_plane,
                                           far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, render_mode="RGB+ED")   # base.py:393-408
-    rgb_g, depth, opacity = renders[0, ..., :3], renders[0, ..., 3:4], alphas[0]
+    renders = renders[0]                                                                      # base.py:409
+    alphas = alphas[0].squeeze(-1)                                                            # base.py:410
+    assert renders.shape[-1] == 4, "Must render rgb, depth and alpha"                         # base.py:413
+    rgb_g, depth = torch.split(renders, [3, 1], dim=-1)                                       # base.py:414
+    opacity = alphas[..., None]                                                               # base.py:417
     grids_k = [g[img_idx:img_idx + 1] for g in grids]
-    rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)
+    rgb = bilagrid_transform(rgb_g, grids_k, factors, alpha=opacity, sky=sky)                 # (clamp(max=1), sky blend, transform)
     return dict(rgb=rgb, depth=depth, opacity=opacity, rgb_gaussians=rgb_g, info=info)
 
 

@@ -189,6 +189,14 @@ int bds_splat_pack_rgbd(int64_t n, const int32_t *ids, const float *means2d, con
 int bds_expected_depth_fwd(int64_t P, const float *render4, const float *alphas, float *out4, bds_stream_t stream);
 int bds_expected_depth_bwd(int64_t P, int channels, int expected_depth, const float *render4, const float *alphas, const float *v_out,
                            const float *v_alphas_in, float *v_render4, float *v_alphas, bds_stream_t stream);
+/* The same with the image as TWO arrays, rgb3 [P,3] and depth1 [P,1] (expected_depth = 0: the composited depth as it is): the
+ * reference's trainer splits the render at once (models/trainers/base.py:409-419: torch.split(renders, [3, 1], dim=-1)); handed out as
+ * two outputs of the rasterization node (rendering.SplitRender) that split costs no copy forward and no slice backward.
+ * v_rgb3 / v_depth1 / v_alphas_in may be NULL (zero). */
+int bds_expected_depth_split_fwd(int64_t P, int expected_depth, const float *render4, const float *alphas, float *rgb3, float *depth1,
+                                 bds_stream_t stream);
+int bds_expected_depth_split_bwd(int64_t P, int expected_depth, const float *render4, const float *alphas, const float *v_rgb3,
+                                 const float *v_depth1, const float *v_alphas_in, float *v_render4, float *v_alphas, bds_stream_t stream);
 int bds_splat_pack(int64_t n, int CH, const int32_t *ids, const float *means2d, const float *conics, const float *colors,
                    const float *opacities, const int32_t *radii /* [n entries] or NULL */, float *records, bds_stream_t stream);
 /* Splat records of the fused view with the SH colour evaluated on the way (vanilla.py:383-389: SH of normalise(means - cam_pos), + 0.5,

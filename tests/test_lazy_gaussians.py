@@ -92,3 +92,35 @@ def test_materialising_a_placeholder_raises_on_nonfinite_values_as_the_reference
         src.means[1, 2] = float("nan")
     with pytest.raises(ValueError, match="NaN detected in gaussian _means"):
         LazyField(src, "_means", (N, 3)) + 0.0
+
+
+def test_split_render_answers_the_trainers_split_with_the_nodes_own_outputs():
+    """rendering.SplitRender: ``render_colors`` of the raw one-view node as a placeholder over its two image outputs.  The reference's
+    trainer does ``renders[0]`` then ``torch.split(renders, [3, 1], dim=-1)`` (models/trainers/base.py:409-419): those return the
+    node's outputs themselves (no copy, no slice backward); anything else sees ``cat((rgb, depth), -1)`` with the same gradients."""
+    from bilateral_driving_amd.rendering import SplitRender
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.rand(1, 5, 7, 3, generator=g).requires_grad_(True)
+    depth = torch.rand(1, 5, 7, 1, generator=g).requires_grad_(True)
+    rgb_o, depth_o = rgb * 1.0, depth * 1.0          # (node outputs: non-leaf tensors)
+    S = SplitRender(rgb_o, depth_o)
+    assert S.shape == (1, 5, 7, 4) and S.dim() == 4 and S.dtype == torch.float32 and S.shape[-1] == 4
+    r0 = S[0]
+    assert isinstance(r0, SplitRender) and r0.shape == (5, 7, 4)
+    a, b = torch.split(r0, [3, 1], dim=-1)
+    assert a.shape == (5, 7, 3) and b.shape == (5, 7, 1) and not isinstance(a, SplitRender)
+    assert a.data_ptr() == rgb_o.data_ptr() and a.is_contiguous()          # the node's output itself
+    a2, b2 = r0.split([3, 1], dim=-1)
+    assert torch.equal(a2, a) and torch.equal(b2, b)
+    assert S[..., :3] is rgb_o and S[..., 3:4] is depth_o and r0[..., 0:3].shape == (5, 7, 3)
+    (torch.clamp(a, max=0.5).sum() + 2.0 * b.sum()).backward()
+    assert torch.equal(depth.grad, torch.full_like(depth, 2.0)) and float(rgb.grad.sum()) == float((rgb <= 0.5).sum())
+    # anything else: an ordinary tensor with the values of the concatenation
+    full = torch.cat((rgb_o, depth_o), dim=-1)
+    for got, want in ((S * 2.0, full * 2.0), (S[0, 2], full[0, 2]), (S[..., 1:3], full[..., 1:3]), (S.mean(dim=(1, 2)), full.mean(dim=(1, 2))),
+                      (torch.split(S, 2, dim=-1)[1], torch.split(full, 2, dim=-1)[1]), (S.reshape(-1, 4), full.reshape(-1, 4))):
+        assert type(got) is torch.Tensor and torch.equal(got, want)
+    rgb.grad = None; depth.grad = None
+    S2 = SplitRender(rgb * 1.0, depth * 1.0)
+    (S2 * torch.arange(4.0)).sum().backward()
+    assert torch.equal(rgb.grad, torch.arange(3.0).expand_as(rgb)) and torch.equal(depth.grad, torch.full_like(depth, 3.0))
