@@ -22,22 +22,22 @@ fi
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python $REPO/bench.py $BA --steps 6 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views > $OUT/trace_bench.json 2>$OUT/trace.stderr
+    python $REPO/bench.py $BA --steps 6 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views --no-train-cadence --no-exchange-probe > $OUT/trace_bench.json 2>$OUT/trace.stderr
 python $REPO/scripts/step_timeline.py $OUT/trace/bench_kernel_trace.csv 20 > $OUT/step_timeline.txt 2>&1
 python $REPO/scripts/frame_overlap_report.py $OUT/trace/bench_kernel_trace.csv > $OUT/frame_overlap.txt 2>&1
 # the exchange's plumbing on this one-GPU box: two ranks share cuda:0 and talk through gloo (the numbers mean nothing)
-(BDS_BENCH_SHARE_GPU=1 timeout 300 python $REPO/bench.py $BA --gpus 2 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views 2>$OUT/share2.stderr | tail -1) > $OUT/bench_share2.json
+(BDS_BENCH_SHARE_GPU=1 timeout 300 python $REPO/bench.py $BA --gpus 2 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views --no-train-cadence --no-exchange-probe 2>$OUT/share2.stderr | tail -1) > $OUT/bench_share2.json
 if [ "$DO_PMC" = "pmc" ]; then
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
-      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views > /dev/null 2>$OUT/pmc_fetch.stderr
+      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views --no-train-cadence --no-exchange-probe > /dev/null 2>$OUT/pmc_fetch.stderr
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
-      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views > /dev/null 2>$OUT/pmc_write.stderr
+      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views --no-train-cadence --no-exchange-probe > /dev/null 2>$OUT/pmc_write.stderr
   timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
       --output-format csv -d $OUT/pmc_sq -o bench -- \
-      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views > /dev/null 2>$OUT/pmc_sq.stderr
+      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views --no-train-cadence --no-exchange-probe > /dev/null 2>$OUT/pmc_sq.stderr
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
       --output-format csv -d $OUT/pmc_sq2 -o bench -- \
-      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views > /dev/null 2>$OUT/pmc_sq2.stderr
+      python $REPO/bench.py $BA --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-pair-stats --no-api-path --no-random-views --no-train-cadence --no-exchange-probe > /dev/null 2>$OUT/pmc_sq2.stderr
 fi
 # optional 4th argument "neural": the neural bilateral variants (one-kernel transform) -- timing, kernel stats and, with pmc, the MFMA
 # busy cycles of the head / fused-image kernels (SQ_VALU_MFMA_BUSY_CYCLES counts cycles: 64 per v_mfma_f32_32x32x2_f32)
