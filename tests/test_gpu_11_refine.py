@@ -301,3 +301,71 @@ def test_refinement_with_reorder_leaves_the_same_set_in_spatial_order():
         assert torch.equal(ob.state[getattr(mb, a)]["exp_avg_sq"], oa.state[getattr(ma, a)]["exp_avg_sq"][perm]), a
         grp = [gr for gr in ob.param_groups if gr["name"] == mb.class_prefix + name][0]
         assert grp["params"][0] is getattr(mb, a)
+
+
+def test_deferred_row_adam_goes_through_a_refinement_bit_equal_to_the_dense_one():
+    """optim.DeferredRowAdam keeps the SH rows of unseen Gaussians behind; ``before_refinement()`` brings them up to date, the
+    refinement's optimizer-state surgery (basics.py:162-206 as densify._move_rows does it) moves parameters and moments, the rows'
+    step words are made again at the new size -- and the run continues.  Same random visibility, same gradients, same refinement:
+    the SH parameters and both moments equal the dense FusedAdam's bit for bit before and after the refinement."""
+    from bilateral_driving_amd.densify import refinement_after
+    from bilateral_driving_amd.optim import DeferredRowAdam, FusedAdam
+    N, step = 20_011, 3300
+    P, M, V, stats = synthetic(N, seed=5)
+    sch = RO.schedule(step, CTRL, 30.0, 150)
+    n_split = int(RO.plan(sch, CTRL, P["_scales"], P["_opacities"], stats["xys_grad_norm"], stats["vis_counts"], stats["max_2Dsize"])[0].sum())
+    samples = torch.from_numpy(np.random.default_rng(1).standard_normal((2 * n_split, 3)).astype(np.float32))
+    deferred = ("_features_dc", "_features_rest")
+
+    def make(lazy):
+        model, opt0 = build_model(P, M, V, stats, CTRL, 30.0, 150, step, FusedAdam)
+        groups = []
+        for a, n in zip(RO.PARAMS, GROUPS):
+            g = {"params": [getattr(model, a)], "lr": 2e-3, "eps": 1e-15, "weight_decay": 0, "name": model.class_prefix + n}
+            if lazy and a in deferred:
+                g["deferred_rows"] = True
+            groups.append(g)
+        opt = (DeferredRowAdam if lazy else FusedAdam)(groups, lr=0.0, eps=1e-15)
+        for a in RO.PARAMS:      # the moments of build_model (a run in progress)
+            prm = getattr(model, a)
+            st = opt.state[prm]
+            st["exp_avg"], st["exp_avg_sq"] = opt0.state[prm]["exp_avg"].clone(), opt0.state[prm]["exp_avg_sq"].clone()
+            if "step" not in st:
+                st["step"] = torch.tensor(0.0)
+        return model, opt
+
+    def steps(model, opt, lazy, k0, k1):
+        for it in range(k0, k1):
+            gen = torch.Generator().manual_seed(1000 + it)
+            n = model._means.shape[0]
+            ids = torch.randperm(n, generator=gen)[: max(n // 7, 1)].sort().values
+            for a in RO.PARAMS:
+                prm = getattr(model, a)
+                g = torch.zeros(prm.shape)
+                g[ids] = torch.randn((ids.numel(),) + tuple(prm.shape[1:]), generator=gen) * 0.01     # dense zeros elsewhere
+                prm.grad = g.cuda()
+            if lazy:
+                lst = ids.to(torch.int32).cuda()
+                opt.catchup(lst.numel(), None, lst)               # the forward: the listed rows are made current before they are read
+                opt.step(lists=[(lst.numel(), None, lst)])
+            else:
+                opt.step()
+
+    (ma, oa), (mb, ob) = make(False), make(True)
+    steps(ma, oa, False, 0, 12); steps(mb, ob, True, 0, 12)
+    assert int((ob.state[mb._features_rest]["last_step"] < 12).sum()) > 0          # rows no list has named are behind
+    ob.before_refinement()
+    for a in deferred:
+        assert torch.equal(getattr(ma, a).detach(), getattr(mb, a).detach()), a
+    for m_, o_ in ((ma, oa), (mb, ob)):
+        for k, v in stats.items():
+            setattr(m_, k, torch.from_numpy(v).cuda())
+        refinement_after(m_, step, o_, samples=samples, verbose=False)
+    assert ma._means.shape[0] == mb._means.shape[0] != N
+    steps(ma, oa, False, 12, 24); steps(mb, ob, True, 12, 24)
+    ob.flush()
+    for a in RO.PARAMS:
+        pa, pb = getattr(ma, a), getattr(mb, a)
+        assert torch.equal(pa.detach(), pb.detach()), a
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]) and torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), a
+    assert int(ob.state[mb._features_rest]["last_step"].min()) == 24 and ob.state[mb._features_rest]["last_step"].shape[0] == mb._means.shape[0]
