@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--no-exchange-probe", action="store_true",
                     help="N = 1: skip the child process that runs the frame with the multi-GPU exchange's collectives really issued over "
                          "RCCL at world size 1 (config.exchange_world1: ms per frame without an exchange, per view, per frame)")
-    ap.add_argument("--probe-timeout", type=float, default=240.0)
+    ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--no-train-cadence", action="store_true",
                     help="N = 1: skip config.train_cadence (one view per step; + optimizer step and densification statistics: the reference's loop)")
     ap.add_argument("--verbose", action="store_true")
