@@ -61,7 +61,9 @@ def test_projection_fwd_bwd(ops, seed, N, W, H):
     assert comp is None
     same = radii[0].cpu() == radii_r
     print(f"[projection] seed {seed}: radii decisions equal to the fp64 oracle's for {float(same.float().mean()):.5f} of the Gaussians")
-    assert same.float().mean() > 0.997
+    # measured on MI355X: all three cases 1.00000 (every radius / cull decision equals the fp64 oracle's); one Gaussian in a thousand
+    # on a ceil() boundary is what fp32 against fp64 may legitimately flip
+    assert same.float().mean() >= 0.999
     vis = (radii_r > 0) & same
     assert int(vis.sum()) > N // 10
     assert rel_err(m2[0].cpu()[vis], m2_r[vis]) < 1e-5
