@@ -209,3 +209,68 @@ def test_replayed_loop_with_the_deferred_row_optimizer_follows_the_dense_one():
         diff = float((a[k] - b[k]).norm() / a[k].norm())
         print(f"[deferred loop] {k}: dense vs dense {noise:.2e}, dense vs deferred {diff:.2e}")
         assert diff <= max(10.0 * noise, 1e-5), (k, diff, noise)
+
+
+def test_deferred_row_adam_inside_the_replayed_loop_is_the_dense_adam_on_the_same_gradients():
+    """The integration, bit for bit: a replayed one-view loop with ``optim.DeferredRowAdam`` (catch-up inside the captured forward,
+    step over ``frame.row_lists()``); every step's SH gradient buffer is recorded and fed to a dense ``FusedAdam`` next to it.
+    (1) the gradient rows outside the view's list are exact zeros -- what makes the deferral legal; (2) when a view's forward has
+    run, every row it lists is current (its step word = the optimizer's step) and holds the dense run's value -- the pack read what
+    the reference's dense optimizer would have left there; (3) after a flush the parameter and both moments equal the dense run's."""
+    from bilateral_driving_amd import harness as Hn
+    from bilateral_driving_amd.graph_view import FrameGraph
+    from bilateral_driving_amd.optim import DeferredRowAdam, FusedAdam
+    dev = torch.device("cuda", 0)
+    W, H, N, steps = 320, 192, 9_000, 40
+    cams = Hn.ring_cameras(W, H, device=dev)
+    base = Hn.synthetic_scene(N, seed=6, device=dev)
+    gen = torch.Generator().manual_seed(8)
+    sky = torch.rand(H, W, 3, generator=gen).to(dev)
+    targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
+    picks = torch.randint(0, len(cams), (steps,), generator=gen).tolist()
+    p = {k: v.clone().contiguous().requires_grad_(True) for k, v in base.items()}
+    grids = [g.requires_grad_(True) for g in Hn.make_grids(len(cams), seed=0, device=dev)]
+    lrs = dict(means=1.6e-4, quats=1e-3, log_scales=5e-3, opacity_logits=5e-2)
+    groups = [{"params": [p[k]], "lr": lr, "eps": 1e-15} for k, lr in lrs.items()] + [{"params": [g], "lr": 2e-3, "eps": 1e-15} for g in grids]
+    groups.append({"params": [p["sh"]], "lr": 2.5e-3, "lr_b": 1.25e-4, "col_split": 3, "deferred_rows": True, "eps": 1e-15})
+    opt = DeferredRowAdam(groups, lr=0.0, eps=1e-15, consume_grads=True)
+    # the dense twin of the SH parameter: dc and rest columns as two tensors with their own rates
+    dc = base["sh"][:, :1].clone().contiguous().requires_grad_(True)
+    rest = base["sh"][:, 1:].clone().contiguous().requires_grad_(True)
+    twin = FusedAdam([{"params": [dc], "lr": 2.5e-3, "eps": 1e-15}, {"params": [rest], "lr": 1.25e-4, "eps": 1e-15}], lr=0.0, eps=1e-15)
+    frame = FrameGraph(p, [cams[0]], grids, [sky], [targets[0]], img_indices=[0], dynamic=True, calib_cams=cams, clear_grads=False,
+                       row_catchup=opt.catchup)
+    last = opt.state[p["sh"]]["last_step"]
+    seen = torch.zeros(N, dtype=torch.bool, device=dev)
+    for t, v in enumerate(picks):
+        frame.set_view(0, cams[v], targets[v], sky, v)
+        assert frame.step() is True
+        (cap, n_dev, ids_ptr), = frame.row_lists()
+        n_vis = frame.counts()[0][1]
+        ws = frame.prep_ws[0]
+        ids = ws[frame._ids_off:frame._ids_off + 4 * cap].view(torch.int32)[:n_vis].long()
+        assert 0 < n_vis < N and ids_ptr == ws.data_ptr() + frame._ids_off
+        seen[ids] = True
+        # (2) the rows the pack has just read: current, and bit-equal to the dense run's
+        assert bool((last[ids] == t).all())
+        sh_now = p["sh"].detach()
+        assert torch.equal(sh_now[ids, :1], dc.detach()[ids]) and torch.equal(sh_now[ids, 1:], rest.detach()[ids])
+        # (1) the gradient outside the list is exactly zero
+        g = p["sh"].grad.clone()
+        outside = torch.ones(N, dtype=torch.bool, device=dev)
+        outside[ids] = False
+        assert float(g[outside].abs().max()) == 0.0 and float(g[ids].abs().max()) > 0.0
+        dc.grad, rest.grad = g[:, :1].contiguous(), g[:, 1:].contiguous()
+        twin.step()
+        opt.step(lists=frame.row_lists())
+        assert float(p["sh"].grad.abs().max()) == 0.0                      # consumed and cleared through the list
+    behind = int((last < steps).sum())
+    assert behind > 0 and int((~seen).sum()) > 0                            # rows no view listed: never touched so far ...
+    assert torch.equal(p["sh"].detach()[~seen], base["sh"][~seen])
+    opt.flush()                                                             # ... until the flush replays their zero-gradient steps
+    sh_end = p["sh"].detach()
+    assert torch.equal(sh_end[:, :1], dc.detach()) and torch.equal(sh_end[:, 1:], rest.detach())
+    st = opt.state[p["sh"]]
+    assert torch.equal(st["exp_avg"][:, :1], twin.state[dc]["exp_avg"]) and torch.equal(st["exp_avg"][:, 1:], twin.state[rest]["exp_avg"])
+    assert torch.equal(st["exp_avg_sq"][:, :1], twin.state[dc]["exp_avg_sq"]) and torch.equal(st["exp_avg_sq"][:, 1:], twin.state[rest]["exp_avg_sq"])
+    assert frame.n_captures == 1
