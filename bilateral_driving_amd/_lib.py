@@ -146,6 +146,7 @@ _SIGS = {
     "bds_adam_step": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_adam_step_consume": (_i, [_i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _f]),
     "bds_adam_step_rows": (_i, [_i64, _i, _i64, _f, _f, _f, _f, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _i, _f]),
+    "bds_adam_step_rowblock": (_i, [_i64, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_adam_step_multi": (_i, [_i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "bds_adam_rows_advance": (_i, [_i64, _f, _f, _i64, _i, _i, _f, _f, _i, _f, _f, _f, _f, _i64, _i, _f, _i, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_double, C.c_double, _f]),

@@ -26,6 +26,16 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def _step_rowblock(self, base: int, n_rows: int, members) -> None:
+        import ctypes as C
+        n = len(members)
+        vp = lambda vals: (C.c_void_p * n)(*vals)
+        dbl = lambda i: (C.c_double * n)(*[b[i] for b in members])
+        L.check(L.lib().bds_adam_step_rowblock(
+            n_rows, base, n, vp([b[0].data_ptr() for b in members]), vp([b[2].data_ptr() for b in members]), vp([b[3].data_ptr() for b in members]),
+            (C.c_int * n)(*[(b[1] - base) // 4 for b in members]), (C.c_int * n)(*[b[5] for b in members]), dbl(7), dbl(8), dbl(9), dbl(10), dbl(11),
+            (C.c_int64 * n)(*[b[12] for b in members]), int(self.consume_grads), L.stream()), "bds_adam_step_rowblock")
+
     def _step_multi(self, batch) -> None:
         import ctypes as C
         n = len(batch)
@@ -91,6 +101,16 @@ class FusedAdam(torch.optim.Optimizer):
                 L.check(fn(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), *hyper, st), "bds_adam_step")
                 if self.consume_grads and not consume:
                     p.grad.zero_()
+        # tensors whose gradients are column ranges of ONE [N,16] row block (dist.FlatGradients(row_block=True)) step together through
+        # the block, which is then read -- and cleared -- once (bds_adam_step_rowblock) instead of once per tensor
+        blocks = {}
+        for b in batch:
+            if b[5] > 0 and b[5] <= 4 and b[6] == 16 and b[0].dim() >= 1:
+                blocks.setdefault((b[1] & ~63, b[0].shape[0]), []).append(b)
+        for (base, n_rows), members in blocks.items():
+            if 2 <= len(members) <= 4 and base % 16 == 0:
+                self._step_rowblock(base, n_rows, members)
+                batch = [b for b in batch if not any(b is m for m in members)]
         for k in range(0, len(batch), self.MULTI_MAX_TENSORS):
             self._step_multi(batch[k:k + self.MULTI_MAX_TENSORS])
         return loss

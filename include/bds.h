@@ -652,6 +652,13 @@ int bds_adam_step_rows(int64_t n_rows, int width, int64_t grad_stride, float *pa
                        double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int consume,
                        bds_stream_t stream);
 
+/* The same update for up to four parameter tensors [N, widths[t]] whose gradients are the column ranges [col0[t], col0[t] + widths[t])
+ * of ONE [N,16] row block (64-byte rows; the four small per-Gaussian gradients, see bds_project_view_bwd_list), in one launch that
+ * reads -- and, consuming, clears -- every row once: stepping the four tensors one after the other reads every 64-byte row four times. */
+int bds_adam_step_rowblock(int64_t N, float *grad_block, int n_parts, float *const *params, float *const *exp_avgs,
+                           float *const *exp_avg_sqs, const int *col0, const int *widths, const double *lrs, const double *beta1s,
+                           const double *beta2s, const double *eps, const double *weight_decays, const int64_t *steps, int consume,
+                           bds_stream_t stream);
 /* bds_adam_step / _consume / _rows for up to 12 tensors in ONE launch (the trainer's ~10 small groups, models/trainers/base.py:201-226:
  * one launch per tensor is mostly launch gap).  Arrays of n_tensors entries; widths[t] = 0: a contiguous gradient, else element
  * (r, c) of tensor t's gradient at grads[t][r * grad_strides[t] + c] with c < widths[t]; steps[t]: the tensor's own 1-based step.
