@@ -1,3 +1,5 @@
+"""The eager per-view exchange loop over RCCL at world size 1 against the dense sum, frame by frame (found the stale id-list bug of
+round 6: third frame wrong before the fix in dist.FrameExchange._retire)."""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")

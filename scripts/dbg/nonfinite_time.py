@@ -1,3 +1,4 @@
+"""bds_nonfinite_flags_kinds over the 472 MB of a 2 M-Gaussian parameter set: plain vs activation-aware kinds (us)."""
 import os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bilateral_driving_amd import _lib as L

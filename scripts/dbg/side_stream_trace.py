@@ -1,3 +1,5 @@
+"""One-view training steps with optim.DeferredRowAdam, one stream (`one`) or -- with profiles/r09j_split_forward_side_stream.patch applied --
+the SH step on the optimizer's own stream behind a split forward (`side`): ms per step + host enqueue time (profiles/NOTES.md, round 6)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bilateral_driving_amd import harness as Hn
@@ -16,9 +18,9 @@ targets = [torch.rand(H, W, 3, generator=gen).to(dev) for _ in cams]
 lrs = dict(means=1.6e-4, quats=1e-3, log_scales=5e-3, opacity_logits=5e-2)
 groups = [{"params": [p[k]], "lr": lr, "eps": 1e-15} for k, lr in lrs.items()] + [{"params": [x], "lr": 2e-3, "eps": 1e-15} for x in grids]
 groups.append({"params": [p["sh"]], "lr": 2.5e-3, "lr_b": 1.25e-4, "col_split": 3, "deferred_rows": True, "eps": 1e-15})
-opt = DeferredRowAdam(groups, lr=0.0, eps=1e-15, consume_grads=True, side_stream=side)
+opt = DeferredRowAdam(groups, lr=0.0, eps=1e-15, consume_grads=True, **({"side_stream": True} if side else {}))
 fr = FrameGraph(p, cams[:1], grids, skies[:1], targets[:1], img_indices=[0], dynamic=True, calib_cams=cams, clear_grads=False,
-                row_catchup=opt.catchup, split_forward=side, row_sync=opt.row_sync if side else None)
+                row_catchup=opt.catchup, **({"split_forward": True, "row_sync": opt.row_sync} if side else {}))
 def one(i):
     k = i % len(cams)
     fr.set_view(0, cams[k], targets[k], skies[k].detach(), k)

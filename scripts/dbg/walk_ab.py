@@ -1,3 +1,5 @@
+"""A/B of the WALKING form of the bilateral pyramid backward (profiles/r09i_bilagrid_bwd_walk_ab.txt).  The form lost and was removed:
+this script needs profiles/r09i_bilagrid_bwd_walk_form.patch applied (option 9 = rows a workgroup walks)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bilateral_driving_amd import _lib as L
