@@ -223,6 +223,24 @@ class DeferredRowAdam(FusedAdam):
         self.flush()
         return super().state_dict()
 
+    def load_state_dict(self, state_dict) -> None:
+        """A checkpoint written by ``state_dict()`` holds every row at the step of the save (it flushes): the rows' step words are made
+        again (torch's loader casts every state tensor to the parameter's dtype), the clock and the step count follow ``state["step"]``."""
+        super().load_state_dict(state_dict)
+        for group, p in self._deferred():
+            st = self.state[p]
+            self._t = int(st["step"])
+            st["last_step"] = torch.full((p.shape[0],), self._t, device=p.device, dtype=torch.int32)
+            st["table"] = st["table"].to(device=p.device, dtype=torch.float32).contiguous() if torch.is_tensor(st.get("table")) else \
+                torch.zeros(self.table_steps, 4, device=p.device, dtype=torch.float32)
+            if st["table"].shape != (self.table_steps, 4):
+                st["table"] = torch.zeros(self.table_steps, 4, device=p.device, dtype=torch.float32)     # (every row is current: no entry is needed)
+            st["hyper"] = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+            if self._clock is None:
+                self._clock = torch.full((1,), self._t, device=p.device, dtype=torch.int32)
+            self._clock.fill_(self._t)
+        self._last_flush = self._t
+
     @torch.no_grad()
     def step(self, closure=None, lists=None):
         """``lists``: [(n_capacity, n_dev_ptr | None, ids)] -- the visible-id lists of the views whose gradients are in ``.grad``

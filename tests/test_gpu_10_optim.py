@@ -184,3 +184,42 @@ def test_deferred_row_adam_is_bit_equal_to_the_dense_pass(wd, table_steps):
     mu_a.grad, mu_b.grad = None, None
     oa.step(); ob.step()
     assert torch.equal(sh.detach()[:, :1], dc.detach()) and torch.equal(sh.detach()[:, 1:], rest.detach())
+
+
+def test_deferred_row_adam_checkpoint_round_trip_continues_bit_equal():
+    """state_dict() flushes (every row at the step of the save); a fresh optimizer that loads it continues exactly where the first one
+    would have: parameters and moments bit-equal to the uninterrupted run after more lazy steps (the reference resumes model-only,
+    trainers/base.py:683-705 -- an optimizer checkpoint is this package's addition and must not change the numbers)."""
+    from bilateral_driving_amd.optim import DeferredRowAdam
+    N, K = 3001, 16
+    gen = torch.Generator().manual_seed(11)
+    sh0 = torch.randn(N, K, 3, generator=gen).cuda()
+
+    def make(x):
+        p = x.clone().requires_grad_(True)
+        p.grad = torch.zeros_like(p)
+        return p, DeferredRowAdam([{"params": [p], "lr": 2.5e-3, "lr_b": 1.25e-4, "col_split": 3, "deferred_rows": True}], lr=0.0, eps=1e-15)
+
+    def steps(p, opt, k0, k1):
+        for it in range(k0, k1):
+            g = torch.Generator().manual_seed(500 + it)
+            ids = torch.randperm(N, generator=g)[:400].sort().values
+            lst = ids.to(torch.int32).cuda()
+            opt.catchup(lst.numel(), None, lst)
+            p.grad.zero_()
+            p.grad[ids.cuda()] = (torch.randn(400, K, 3, generator=g) * 0.01).cuda()
+            opt.step(lists=[(lst.numel(), None, lst)])
+
+    pa, oa = make(sh0)
+    steps(pa, oa, 0, 30)                      # the uninterrupted run
+    pb, ob = make(sh0)
+    steps(pb, ob, 0, 17)
+    sd = ob.state_dict()
+    assert int((ob.state[pb]["last_step"] != 17).sum()) == 0
+    pc, oc = make(pb.detach())                # "resume": parameters from the model checkpoint, optimizer from its own
+    oc.load_state_dict(sd)
+    assert oc._t == 17 and oc.state[pc]["last_step"].dtype == torch.int32 and int(oc._clock[0]) == 17
+    steps(pc, oc, 17, 30)
+    oa.flush(); oc.flush()
+    assert torch.equal(pa.detach(), pc.detach())
+    assert torch.equal(oa.state[pa]["exp_avg"], oc.state[pc]["exp_avg"]) and torch.equal(oa.state[pa]["exp_avg_sq"], oc.state[pc]["exp_avg_sq"])
