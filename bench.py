@@ -1076,7 +1076,12 @@ def main():
     }
     if rank == 0 and not coll and not args.no_exchange_probe:
         torch.cuda.empty_cache()
-        result["config"]["exchange_world1"] = exchange_probe(args)
+        probe = exchange_probe(args)
+        result["config"]["exchange_world1"] = probe
+        # (per frame of this workload, on ONE rank, every collective issued over RCCL at world size 1: what the exchange costs before a
+        #  byte crosses xGMI)
+        result["config"]["exchange_overhead_ms"] = None if "error" in probe else {
+            "per_view": probe["per_view"]["overhead_ms_per_frame"], "per_frame": probe["per_frame"]["overhead_ms_per_frame"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
