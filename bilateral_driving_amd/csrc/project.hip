@@ -322,7 +322,13 @@ __device__ __forceinline__ uint32_t nonfinite_tensor(const uint32_t *q, int64_t 
   for (int64_t base = (int64_t)blockIdx.x * kPiece; base < n4; base += (int64_t)gridDim.x * kPiece) {
     const int64_t i = base + threadIdx.x;
     if (base + kPiece <= n4) {
-      const uint4 v0 = q4[i], v1 = q4[i + kFiniteBlock], v2 = q4[i + 2 * kFiniteBlock], v3 = q4[i + 3 * kFiniteBlock];
+      // (read once: non-temporal loads -- 84 -> 76 us over the 472 MB of a 2 M-Gaussian parameter set)
+      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+      const v4u *qn = reinterpret_cast<const v4u *>(q4);
+      const v4u a0 = __builtin_nontemporal_load(qn + i), a1 = __builtin_nontemporal_load(qn + i + kFiniteBlock),
+                a2 = __builtin_nontemporal_load(qn + i + 2 * kFiniteBlock), a3 = __builtin_nontemporal_load(qn + i + 3 * kFiniteBlock);
+      const uint4 v0 = make_uint4(a0.x, a0.y, a0.z, a0.w), v1 = make_uint4(a1.x, a1.y, a1.z, a1.w), v2 = make_uint4(a2.x, a2.y, a2.z, a2.w),
+                  v3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
       b |= (nonfinite4<kKind>(v0) | nonfinite4<kKind>(v1)) | (nonfinite4<kKind>(v2) | nonfinite4<kKind>(v3));
     } else {
       for (int64_t k = i; k < n4; k += kFiniteBlock) b |= nonfinite4<kKind>(q4[k]);
