@@ -36,7 +36,9 @@ flags) before any of them captures again, because a capture's warm-up frame issu
 accumulation) and ``step()`` ends with ONE dense all-reduce of the flat gradient buffer on the caller's stream; the next frame
 clears that buffer densely (other ranks' rows are in it).  ``dist.plan_exchange`` prices the two modes.
 
-A graph holds device addresses: after anything that re-allocates a parameter (densification) call ``recapture()``.  Slots,
+A graph holds device addresses: after anything that moves a parameter's VALUES far enough to change the lists' sizes call
+``recapture()``; after anything that RE-ALLOCATES the parameters (densification: other tensors, another N) call ``rebind(params)``
+-- the same frame (cameras, targets, options) over the new tensors, with a gradient buffer and lists of the new size.  Slots,
 capacities and the overflow protocol (a view whose lists outgrow their capacities renders NOTHING; ``valid()`` sees it after the
 fact, grows the capacities and captures again): ``graph_slots.FrameCapacities``.
 """
@@ -73,6 +75,10 @@ class FrameGraph(FrameCapacities):
         ``row_catchup``: ``optim.DeferredRowAdam.catchup`` -- every view's forward brings the SH rows of its visible Gaussians up to
         the optimizer's step before its record pack reads them; step the optimizer with ``opt.step(lists=frame.row_lists())``."""
         assert sorted(params.keys()) == sorted(ROW_NAMES), "params: means, quats, log_scales, opacity_logits, sh"
+        # (what rebind() needs to make this frame again over other parameter tensors)
+        self._ctor = dict(cams=cams, grids=grids, skies=skies, targets=targets, factors=factors, tv_weight=tv_weight, img_indices=img_indices,
+                          headroom=headroom, list_tile=list_tile, sh_degree=sh_degree, extra_params=extra_params, overlap=overlap,
+                          exchange=exchange, dynamic=dynamic, calib_cams=calib_cams, clear_grads=clear_grads, row_catchup=row_catchup)
         self.params = {k: params[k] for k in ROW_NAMES}
         self.grids = list(grids)
         self.V = len(cams)
@@ -329,8 +335,20 @@ class FrameGraph(FrameCapacities):
         torch.cuda.synchronize()
 
     def recapture(self) -> None:
-        """After anything that re-allocates a parameter (densification): size the lists again (the scene changed), then capture."""
+        """The scene changed under the same tensors: size the lists again, then capture."""
         self.calibrate(); self.capture()
+
+    def rebind(self, params: Dict[str, Tensor], **changes) -> None:
+        """After densification (``densify.refinement_after``: the parameters are OTHER tensors of another length): this frame again --
+        same cameras / targets / skies / options, ``changes`` overriding constructor arguments (e.g. ``row_catchup`` of a new
+        optimizer) -- over ``params``: new flat gradient buffer, new per-view buffers, lists calibrated for the new set, new graphs.
+        Single-process frames (an exchange holds a flat buffer of its own: build a new ``FrameExchange`` and pass ``exchange=``)."""
+        kw = dict(self._ctor, **changes)
+        assert kw.get("exchange") is None or "exchange" in changes, "rebind: pass the new exchange (its flat buffer is sized for the old parameters)"
+        if self.dynamic:      # the slots' CURRENT inputs, not the ones of the first construction
+            kw.update(cams=self.cams, skies=self.skies, targets=self.targets, img_indices=self.img_indices)
+        torch.cuda.synchronize()
+        self.__init__(params, **kw)
 
     # ---- replay ------------------------------------------------------------------------------------------------------------------
     def step(self, serial: bool = False, wait: bool = True, local: bool = False) -> Optional[bool]:

@@ -298,3 +298,28 @@ def test_one_captured_view_replays_over_random_cameras_and_images(mods):
             assert rel_err(got_g[i][others], g.grad[others]) < 3e-5
         assert rel_err(got_sky, sky_e.grad) < 1e-6 and rel_err(got_vm, cam.viewmat.grad) < 1e-4
     assert frame.n_captures == n_cap      # one capture served them all
+
+
+def test_rebind_makes_the_same_frame_over_other_parameter_tensors(mods):
+    """Densification re-allocates every per-Gaussian tensor with another length; ``FrameGraph.rebind(params)`` is the frame again over
+    the new tensors (gradient buffer, per-view buffers, lists, graphs of the new size): images and gradients equal a frame built from
+    scratch over them, for a fixed frame and for replayable slots."""
+    FV, GV, Hn = mods
+    FrameGraph = GV.FrameGraph
+    for dynamic in (False, True):
+        cams, p, grids, skies, targets = _scene(Hn, 9000, 256, 160, (0.0, 120.0), 21)
+        frame = FrameGraph(p, cams, grids, skies, targets, dynamic=dynamic, calib_cams=cams if dynamic else None)
+        assert frame.step() is True
+        keep = torch.arange(0, 9000, 3, device="cuda")                        # "densification": another set of another length
+        q = {k: torch.cat([v.detach()[keep], v.detach()[:700] * 1.01]).contiguous().requires_grad_(True) for k, v in p.items()}
+        frame.rebind(q)
+        assert frame.N == q["means"].shape[0] != 9000 and frame.flat.flat.numel() >= frame.N * 59
+        assert frame.step() is True
+        fresh = FrameGraph({k: v.detach().clone().requires_grad_(True) for k, v in q.items()}, cams, [g.detach().clone().requires_grad_(True) for g in grids],
+                           [s.detach().clone().requires_grad_(True) for s in skies], targets, dynamic=dynamic, calib_cams=cams if dynamic else None)
+        assert fresh.step() is True
+        for a, b in zip(frame.views, fresh.views):
+            assert torch.equal(a.rgb, b.rgb)
+        for k in q:
+            ga, gb = q[k].grad, fresh.params[k].grad
+            assert float((ga - gb).norm() / gb.norm()) < 1e-5, k
