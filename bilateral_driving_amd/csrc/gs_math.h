@@ -302,16 +302,17 @@ BDS_HD void project_one_vjp(const float *mean, const float *quat, const float *s
   float s10 = t10 * j00 + t12 * j02;
   float s11 = t11 * j11 + t12 * j12 + eps2d;
   float idet = 1.f / (s00 * s11 - s01 * s10);
-  // Sigma2^{-1} (full 2x2)
-  float i00 = s11 * idet, i01 = -s01 * idet, i10 = -s10 * idet, i11 = s00 * idet;
-  // v_inv = [[v_ca, v_cb/2],[v_cb/2, v_cc]] ;  v_S = -inv^T v_inv inv^T
-  float h = 0.5f * v_cb;
-  // A = inv^T * v_inv
-  float a00 = i00 * v_ca + i10 * h, a01 = i00 * h + i10 * v_cc;
-  float a10 = i01 * v_ca + i11 * h, a11 = i01 * h + i11 * v_cc;
-  // v_S = -A * inv^T
-  float vs00 = -(a00 * i00 + a01 * i01), vs01 = -(a00 * i10 + a01 * i11);
-  float vs10 = -(a10 * i00 + a11 * i01), vs11 = -(a10 * i10 + a11 * i11);
+  // conic (a, b, c) = (s11, -s01, s00) / det, det = s00 s11 - s01^2.  Through the ADJUGATE:
+  //   v_S = adj(V) / det - tau conic,   tau = v_a a + v_b b + v_c c,   V = [[v_a, v_b / 2], [v_b / 2, v_c]]
+  // and not as the closed form -conic V conic.  For a thin splat (conic eigenvalues 3 and 3e-4) seen along its length V is ~k u u^T
+  // with u the long axis, so every entry of conic V conic is a difference of terms ~1e3 that leaves ~1: rounding of 1e-4 in ALL
+  // directions of v_S, while the gradient of the quaternion rides on its mixed (long x short) component of ~1e-2 -- errors of 1-10 %
+  // per such row (tests/test_gpu_25, seeds 16 / 20 / 35; gsplat 1.3.0's inverse_vjp is the closed form and shares them).  Here the
+  // cancelling scalar tau multiplies the conic itself -- an error in it has no mixed component -- and adj(V) is exact.
+  const float ca = s11 * idet, cb = -0.5f * (s01 + s10) * idet, cc = s00 * idet;
+  const float tau = v_ca * ca + v_cb * cb + v_cc * cc;
+  const float vs00 = v_cc * idet - tau * ca, vs11 = v_ca * idet - tau * cc;
+  const float vs01 = -0.5f * v_cb * idet - tau * cb, vs10 = vs01;   // (each off-diagonal entry: half of d / d s01)
   // v_covc = J^T v_S J  (3x3)
   float J[6] = {j00, 0.f, j02, 0.f, j11, j12};
   float VS[4] = {vs00, vs01, vs10, vs11};

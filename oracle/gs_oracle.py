@@ -228,13 +228,17 @@ def isect_offset_encode(isect_ids, tile_w, tile_h):
 # compositing
 # --------------------------------------------------------------------------------------
 def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-                        backgrounds=None, return_unstable=False, margin=1e-4, absgrad_probe=None):
+                        backgrounds=None, return_unstable=False, margin=1e-4, absgrad_probe=None, cond_margin=0.0, perturb=None):
     """means2d [N,2], conics [N,3], colors [N,D], opacities [N]; per-pixel front-to-back blend.
 
     Returns render [H,W,D], alphas [H,W,1], last_ids [H,W] (index into the sorted intersection
     list of the last blended Gaussian; 0 if none).  With ``return_unstable`` also a bool map of
     pixels in which some discrete decision (alpha cut, T stop) sits within ``margin`` (relative)
-    of its threshold, i.e. where an fp32 reimplementation may legitimately differ.
+    of its threshold, i.e. where an fp32 reimplementation may legitimately differ.  The margin widens per (Gaussian, pixel) by the
+    uncertainty of sigma itself: ``cond_margin`` x (|a| dx^2 / 2 + |c| dy^2 / 2 + |b dx dy|) -- the rounding of a quadratic form whose
+    terms cancel (a thin splat far from its centre: terms ~1e5 for a sigma of 5) -- and, with ``perturb`` = a list of (d_means2d [N,2],
+    d_conics [N,3]) SIGNED errors of the inputs (an fp32 projection's against this one's), by twice their first-order effect on sigma
+    (signed: the conic of a thin splat is mostly off by a common factor, which moves sigma by that factor only).  Both default to none.
 
     ``absgrad_probe`` (a list): every tile appends (ids, dx, dy) with the per-(Gaussian, pixel) offsets kept as
     graph tensors whose gradient is retained; after ``backward()`` ``absgrad_from_probe`` sums their absolute values --
@@ -292,10 +296,23 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, tile_
                     with torch.no_grad():
                         cs = torch.cumsum(stop.to(torch.int32), 0)
                         considered = (cs == 0) | (stop & (cs == 1))  # pairs evaluated before/at termination
-                        near_a = (torch.abs(alpha - ALPHA_MIN) < margin * ALPHA_MIN) & (sigma >= 0)
-                        near_c = torch.abs(raw - ALPHA_MAX) < margin
-                        near_t = ok & (torch.abs(nextT - T_STOP) < margin * T_STOP)
-                        near_s = torch.abs(sigma) < 1e-7
+                        ds = torch.zeros_like(sigma)     # absolute uncertainty of sigma = relative uncertainty of alpha
+                        if cond_margin > 0:
+                            ds = cond_margin * (0.5 * (cn[:, 0:1].abs() * dx * dx + cn[:, 2:3].abs() * dy * dy) + (cn[:, 1:2] * dx * dy).abs())
+                        w_t = a / (1 - a)                   # d ln T / d sigma of an entry
+                        dT = torch.cumsum(w_t * ds, 0)      # relative uncertainty of T behind each entry
+                        ds_p, dT_p = torch.zeros_like(ds), torch.zeros_like(ds)
+                        for dm, dc in (perturb or ()):     # signed input errors: twice their first-order effect on sigma and on ln T
+                            dm, dc = dm.to(dt)[ids], dc.to(dt)[ids]
+                            d1 = (0.5 * (dc[:, 0:1] * dx * dx + dc[:, 2:3] * dy * dy) + dc[:, 1:2] * dx * dy
+                                  + (cn[:, 0:1] * dx + cn[:, 1:2] * dy) * dm[:, 0:1] + (cn[:, 1:2] * dx + cn[:, 2:3] * dy) * dm[:, 1:2])
+                            ds_p = torch.maximum(ds_p, 2.0 * d1.abs())
+                            dT_p = torch.maximum(dT_p, 2.0 * torch.cumsum(w_t * d1, 0).abs())
+                        ds, dT = ds + ds_p, dT + dT_p
+                        near_a = (torch.abs(alpha - ALPHA_MIN) < (margin + ds) * ALPHA_MIN) & (sigma >= -ds)
+                        near_c = torch.abs(raw - ALPHA_MAX) < margin + ds * raw
+                        near_t = ok & (torch.abs(nextT - T_STOP) < (margin + dT) * T_STOP)
+                        near_s = torch.abs(sigma) < 1e-7 + ds
                         u = ((near_a | near_t | near_s | near_c) & considered).any(0)
                         unstable[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] = u.reshape(len(ys), len(xs))
             else:

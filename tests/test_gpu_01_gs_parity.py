@@ -77,9 +77,16 @@ def test_projection_fwd_bwd(ops, seed, N, W, H):
     ((m2_r * w2.double() * m[:, None]).sum() + (d_r * wd.double() * m).sum() + (c_r * wc.double() * m[:, None]).sum()).backward()
     mg = same.cuda().float()
     ((m2[0] * w2.cuda() * mg[:, None]).sum() + (d[0] * wd.cuda() * mg).sum() + (c[0] * wc.cuda() * mg[:, None]).sum()).backward()
+    # the yardstick: the same oracle in float32 on the same loss (a random gradient on the conics of wide, thin splats is dominated by a
+    # few ill-conditioned rows: plain fp32 autograd itself is at 1.2e-4 / 1.3e-4 on quats / scales of the 5000-Gaussian case)
+    in32 = {k: sc[k].detach().clone().float().requires_grad_(True) for k in ("means", "quats", "scales")}
+    _, m2_32, d_32, c_32, _ = G.project(in32["means"], in32["quats"], in32["scales"], sc["viewmats"][0].float(), sc["Ks"][0].float(), W, H)
+    ((m2_32 * w2 * m.float()[:, None]).sum() + (d_32 * wd * m.float()).sum() + (c_32 * wc * m.float()[:, None]).sum()).backward()
     for k in ("means", "quats", "scales"):
         got, ref = gpu_in[k].grad.cpu().double(), ref_in[k].grad
-        assert float((got - ref).norm() / ref.norm()) < 1e-4, k
+        e, e32 = float((got - ref).norm() / ref.norm()), float((in32[k].grad.double() - ref).norm() / ref.norm())
+        print(f"[projection] seed {seed} {k}: gradient norm-rel error {e:.2e} (fp32 oracle {e32:.2e})")
+        assert e < max(1e-4, 2.0 * e32), (k, e, e32)
     got, ref = vm_g.grad.cpu().double()[0, :3], vm.grad[0, :3]
     assert float((got - ref).norm() / ref.norm()) < 1e-4
 
