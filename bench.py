@@ -235,7 +235,7 @@ def _newest_profile(suffix, kernel_substr, field, workload="headline"):
     BASELINE workloads carry `_c2_` / `_c3_` / `_c5_` in their names; bench.py cannot collect counters itself: gfx950 counter
     passes are separate rocprofv3 runs of this same command, scripts/gpu_round.sh)."""
     import glob
-    others = ("_c2_", "_c3_", "_c5_")
+    others = ("_c2_", "_c3_", "_c5_", "_lidar_")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), reverse=True):
         base = os.path.basename(f)
         if (workload == "headline" and any(o in base for o in others)) or (workload != "headline" and f"_{workload}_" not in base):
