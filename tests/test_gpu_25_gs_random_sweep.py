@@ -237,3 +237,129 @@ def _compare(seed, case):
         ag = meta["means2d"].absgrad[0].cpu().double()
         case["absgrad_norm_rel"] = float((ag - ag_ref).norm() / ag_ref.norm())
         assert case["absgrad_norm_rel"] < 1e-3, case
+
+
+# ---- the same on the call forms the eval / viewer paths use: several cameras in one call, colours as SH coefficients ------------------
+def _cams(sc, seed):
+    """1-3 cameras: the scene's own and perturbed copies of it."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    C = int(torch.randint(1, 4, (1,), generator=g))
+    vms = [sc["viewmats"][0].double()]
+    for _ in range(C - 1):
+        a = (torch.rand(3, generator=g, dtype=torch.float64) - 0.5) * 0.3
+        cx, sx, cy, sy, cz, sz = torch.cos(a[0]), torch.sin(a[0]), torch.cos(a[1]), torch.sin(a[1]), torch.cos(a[2]), torch.sin(a[2])
+        Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
+        Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
+        Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
+        d = torch.eye(4, dtype=torch.float64)
+        d[:3, :3] = Rz @ Ry @ Rx
+        d[:3, 3] = (torch.rand(3, generator=g, dtype=torch.float64) - 0.5) * 0.6
+        vms.append(d @ vms[0])
+    return torch.stack(vms).float(), sc["Ks"].repeat(C, 1, 1), int(torch.randint(0, 4, (1,), generator=g)), g
+
+
+@pytest.mark.parametrize("seed", list(range(max(N_CASES // 2, 1))))
+def test_random_scene_several_cameras_sh_colours(seed):
+    """`rasterization(..., sh_degree=d)` with colours [N, K, 3] and C = 1-3 cameras (trainers/base.py:811-826, scene_graph.py:296-313 call
+    forms; gsplat evaluates the SH colours per camera from means - camera centre and clamps at 0 from below only)."""
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import bilateral_driving_amd.rendering as R
+    from bilateral_driving_amd import _lib
+    _lib.lib()
+    sc, W, H, _, kw, _ = random_scene(600 + seed)
+    A = kw.pop("anisotropy")
+    vms, Ks, deg, g = _cams(sc, seed)
+    C, N = vms.shape[0], sc["means"].shape[0]
+    coeffs = torch.randn(N, 16, 3, generator=g) * 0.2
+    coeffs[:, 0] = (sc["colors"] - 0.5) / 0.28209479177387814
+    mode = ("RGB", "RGB+ED")[seed % 2]
+    case = dict(seed=600 + seed, form="several cameras + SH colours", N=N, W=W, H=H, mode=mode, cameras=C, sh_degree=deg, anisotropy=A, **kw)
+    names = ("means", "quats", "scales", "opacities", "coeffs")
+    src = dict(means=sc["means"], quats=sc["quats"], scales=sc["scales"], opacities=sc["opacities"], coeffs=coeffs)
+    gpu_in = {k: src[k].cuda().requires_grad_(True) for k in names}
+    r, a, meta = R.rasterization(gpu_in["means"], gpu_in["quats"], gpu_in["scales"], gpu_in["opacities"], gpu_in["coeffs"], vms.cuda(), Ks.cuda(),
+                                 W, H, packed=False, absgrad=False, render_mode=mode, sh_degree=deg, **kw)
+    assert r.shape == (C, H, W, 3 if mode == "RGB" else 4) and a.shape == (C, H, W, 1)
+
+    def oracle(dt, decisions):
+        inp = {k: src[k].detach().clone().to(dt).requires_grad_(True) for k in names}
+        outs = []
+        for c in range(C):
+            radii, m2, dep, con, _ = G.project(inp["means"], inp["quats"], inp["scales"], vms[c].to(dt), Ks[c].to(dt), W, H, 0.3, kw["near_plane"], 1e10,
+                                               kw["radius_clip"])
+            if decisions is None:
+                outs.append((radii, m2.detach(), con.detach()))
+                continue
+            cam_pos = torch.linalg.inv(vms[c].double())[:3, 3].to(dt)
+            # (inside gsplat's rasterization the directions are NOT detached -- the centres also get the colours' gradient through them;
+            #  the reference's own SH call, vanilla.py:385, detaches: that form is tests/test_gpu_27's)
+            col = torch.clamp_min(G.spherical_harmonics(deg, inp["means"] - cam_pos, inp["coeffs"]) + 0.5, 0.0)
+            if mode == "RGB+ED":
+                col = torch.cat([col, dep[:, None]], -1)
+            radii_use, m2k, dk, pert = decisions[c]
+            tw, th = (W + 15) // 16, (H + 15) // 16
+            _, iids, fids = G.isect_tiles(m2k, radii_use, dk, 16, tw, th)
+            offs = G.isect_offset_encode(iids, tw, th)
+            res = G.rasterize_to_pixels(m2, con, col, inp["opacities"], W, H, 16, offs, fids, None, pert is not None,
+                                        cond_margin=2.0 ** -20 if pert is not None else 0.0, perturb=pert)
+            rr, aa = res[0], res[1]
+            if mode == "RGB+ED":
+                rr = torch.cat([rr[..., :-1], rr[..., -1:] / aa.clamp(min=1e-10)], -1)
+            outs.append((rr, aa, res[3] if pert is not None else None, fids.numel()))
+        return inp, outs
+
+    try:
+        _, p64 = oracle(torch.float64, None)
+        _, p32 = oracle(torch.float32, None)
+        decisions = []
+        for c in range(C):
+            radii_gpu = meta["radii"][c].cpu().to(torch.int32)
+            if bool(((radii_gpu > 0) != (p64[c][0] > 0)).any()):
+                case["skipped"] = "a visible / culled decision differs between fp32 and fp64"
+                pytest.skip(case["skipped"])
+            assert int((radii_gpu - p64[c][0]).abs().max()) <= 1
+            m2g, cg, dg = meta["means2d"][c].detach().cpu(), meta["conics"][c].detach().cpu(), meta["depths"][c].detach().cpu()
+            pert = [(m2g.double() - p64[c][1], cg.double() - p64[c][2]), (p32[c][1].double() - p64[c][1], p32[c][2].double() - p64[c][2])]
+            decisions.append((radii_gpu, m2g, dg, pert))
+        ref_in, o64 = oracle(torch.float64, decisions)
+        in32, o32 = oracle(torch.float32, [(d[0], d[1], d[2], None) for d in decisions])
+        gen = torch.Generator().manual_seed(seed)
+        loss64, loss32, lossg, img, img32, pairs = 0.0, 0.0, 0.0, 0.0, 0.0, 0
+        for c in range(C):
+            rr, aa, unstable, n = o64[c]
+            stable = ~unstable
+            if mode == "RGB+ED":
+                stable = stable & (aa[..., 0].detach() > 1e-4)
+            pairs += n
+            e = _image_errors(r[c].detach().cpu(), a[c].detach().cpu(), rr.detach(), aa.detach(), stable)
+            e32 = _image_errors(o32[c][0].detach(), o32[c][1].detach(), rr.detach(), aa.detach(), stable)
+            img, img32 = max(img, e[0], e[1]), max(img32, e32[0], e32[1])
+            wt = torch.randn(rr.shape, generator=gen, dtype=torch.float64) * stable[..., None]
+            wa = torch.randn(aa.shape, generator=gen, dtype=torch.float64) * stable[..., None]
+            loss64 = loss64 + (rr * wt).sum() + (aa * wa).sum()
+            loss32 = loss32 + (o32[c][0] * wt.float()).sum() + (o32[c][1] * wa.float()).sum()
+            lossg = lossg + (r[c] * wt.float().cuda()).sum() + (a[c] * wa.float().cuda()).sum()
+        case.update(isects=pairs, image_err=img, oracle_fp32_image_err=img32)
+        assert img < max(1e-4, 3.0 * img32), case
+        lossg.backward()
+        if pairs == 0:
+            return
+        loss64.backward()
+        loss32.backward()
+        case["grads"] = {}
+        for k in names:
+            gref = ref_in[k].grad
+            if gref is None or float(gref.abs().max()) == 0.0 or (k == "quats" and A == 1.0):
+                continue
+            rel, elem, elem99 = grad_errors(gpu_in[k].grad, gref)
+            rel32, elem32, elem99_32 = grad_errors(in32[k].grad, gref)
+            case["grads"][k] = dict(norm_rel=rel, elem_worst=elem, elem_p99=elem99, oracle_fp32_norm_rel=rel32, oracle_fp32_elem_worst=elem32,
+                                    oracle_fp32_elem_p99=elem99_32)
+            assert rel < max(1e-3, 3.0 * rel32), (k, case)
+            # (worst element: 1 of 60 cases at 1.24e-2 with the fp32 oracle at 2.4e-3 -- a 27-Gaussian scene; see the note in _compare)
+            assert elem < max(2e-2, 5.0 * elem32) and elem99 < max(3e-4 if gref.numel() >= 1000 else 2e-3, 5.0 * elem99_32), (k, case)
+    except AssertionError as ex:
+        case["failed"] = str(ex).splitlines()[0][:200]
+        raise
+    finally:
+        _LOG.append(case)
