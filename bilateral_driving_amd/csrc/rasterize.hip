@@ -160,12 +160,29 @@ __global__ __launch_bounds__(kPackShBlock) void splat_pack_sh_kernel(int64_t n_c
   if (coeffs_rest != nullptr) {
     // split storage (the reference's parameters: band 0 [N,3] in `coeffs`, bands 1.. [N,K-1,3] in `coeffs_rest`,
     // models/gaussians/vanilla.py:96-104,382): rows of 4-byte alignment, staged float by float
-    const int need = nb * 3, total = cnt * need;
+    // (the first form: float by float, 48 scalar loads per thread at degree 3 -- 70 us for the 310 k visible rows of the headline
+    //  view where the one-array form takes 33).  Now n4 lanes per row as below: piece 0 = band 0 + the first float of `coeffs_rest`,
+    //  piece c >= 1 = floats 4c-3 .. 4c of the row's `coeffs_rest`, ONE 16-byte load at 4-byte alignment each (gfx950 runs with
+    //  unaligned vector access enabled; a piece that would run past the row's end -- K = (DEG+1)^2 exactly -- goes float by float)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const int64_t row_rest = (int64_t)(K - 1) * 3;
+    const int total = cnt * n4;
+#pragma unroll 4
     for (int e = tid; e < total; e += kPackShBlock) {
-      const int rr = e / need, c = e - rr * need;
+      const int rr = e / n4, c = e - rr * n4;
       const int64_t g = s_g[rr];
-      lds[rr * ldr + c] = c < 3 ? coeffs[g * 3 + c] : coeffs_rest[g * row_rest + (c - 3)];
+      const float *rest = coeffs_rest + g * row_rest;
+      float4 v;
+      if (c == 0) {
+        v = make_float4(coeffs[g * 3], coeffs[g * 3 + 1], coeffs[g * 3 + 2], row_rest > 0 ? rest[0] : 0.f);
+      } else if (4 * c + 1 <= row_rest) {
+        const f4u u = *reinterpret_cast<const f4u *>(rest + 4 * c - 3);
+        v = make_float4(u.x, u.y, u.z, u.w);
+      } else {
+        const int b = 4 * c - 3;
+        v = make_float4(b < row_rest ? rest[b] : 0.f, b + 1 < row_rest ? rest[b + 1] : 0.f, b + 2 < row_rest ? rest[b + 2] : 0.f, 0.f);
+      }
+      *reinterpret_cast<float4 *>(lds + rr * ldr + c * 4) = v;
     }
   } else {
     const int total = cnt * n4;

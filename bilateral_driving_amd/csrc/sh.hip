@@ -312,6 +312,30 @@ __global__ __launch_bounds__(kShBlock) void sh_view_bwd_list_kernel(int64_t n_ca
 #pragma unroll
       for (int u = 0; u < 4; u++) if (dst[u]) *dst[u] = o[u];
     }
+  } else if (v_rest != nullptr && row % 4 == 0) {
+    // split storage (the reference's two parameters): band 0 -> v_coeffs [N,3], bands 1.. -> v_rest [N,K-1,3], rows of 4-byte
+    // alignment.  q4 lanes per row: piece 0 = the three floats of band 0 + the first of the rest, piece c >= 1 = floats 4c-3 .. 4c of
+    // the row's rest as ONE 16-byte access at 4-byte alignment (unaligned vector access is on for gfx950 compute); the last float of
+    // a row's last piece is the rest's last (row - 3 = 4 q4 - 3 floats: 4 (q4-1) + 1)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int q4 = row / 4, total = cnt * q4;
+    for (int e = tid; e < total; e += kShBlock) {
+      const int r = e / q4, c = e - r * q4;
+      const float *sp = lds + r * ldr + c * 4;
+      const int64_t g = s_g[r];
+      float *rest = v_rest + g * (row - 3);
+      if (c == 0) {
+        float *dc = v_coeffs + g * 3;
+        if (kAcc) { dc[0] += sp[0]; dc[1] += sp[1]; dc[2] += sp[2]; rest[0] += sp[3]; }
+        else { dc[0] = sp[0]; dc[1] = sp[1]; dc[2] = sp[2]; rest[0] = sp[3]; }
+      } else {
+        f4u *dst = reinterpret_cast<f4u *>(rest + 4 * c - 3);
+        f4u o;
+        o.x = sp[0]; o.y = sp[1]; o.z = sp[2]; o.w = sp[3];
+        if (kAcc) { const f4u p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        *dst = o;
+      }
+    }
   } else {
     for (int e = tid; e < cnt * row; e += kShBlock) {
       const int r = e / row, cc = e - r * row;
