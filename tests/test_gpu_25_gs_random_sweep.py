@@ -10,7 +10,7 @@ legitimately take differently handed over from the HIP path after being checked 
 the depth ORDER (the sort key is the fp32 depth, compared to 1e-5).  Everything
 floating-point -- screen means, conics, depths, image, alphas, every gradient, the absgrad buffer -- is the oracle's own float64.
 
-BDS_SWEEP_CASES (default 10) cases; the measured errors of every case go to gpurun_out/gs_parity_sweep.json (-> profiles/)."""
+BDS_SWEEP_CASES (default 8) cases; the measured errors of every case go to gpurun_out/gs_parity_sweep.json (-> profiles/)."""
 import json
 import math
 import os
@@ -22,7 +22,7 @@ from oracle import gs_oracle as G
 from tests.util import grad_errors
 
 pytestmark = pytest.mark.gpu
-N_CASES = int(os.environ.get("BDS_SWEEP_CASES", "10"))
+N_CASES = int(os.environ.get("BDS_SWEEP_CASES", "8"))
 MODES = ("RGB", "RGB+ED", "ED", "RGB+D", "D")
 _LOG = []
 
